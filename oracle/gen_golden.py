@@ -1,0 +1,192 @@
+"""Generate tests/golden/*.npz from the REAL reference (build container only).
+
+The reference (pure Python) is imported from /root/reference through a namespace shim
+(its __init__ needs xarray + package metadata, both absent here).
+Only inputs and reference OUTPUTS are stored -- never reference source.  Run:
+
+    python oracle/gen_golden.py            # rewrites tests/golden/*.npz
+
+The GPU box has no /root/reference: tests only read the committed .npz files.
+"""
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+
+REF = "/root/reference/spectral_connectivity"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+
+def import_reference():
+    pkg = types.ModuleType("spectral_connectivity")
+    pkg.__path__ = [REF]
+    sys.modules["spectral_connectivity"] = pkg
+    from spectral_connectivity import connectivity, minimum_phase_decomposition, simulate, transforms
+    return transforms, connectivity, minimum_phase_decomposition, simulate
+
+
+MEASURES = [
+    "power", "coherency", "coherence_magnitude", "coherence_phase", "imaginary_coherence",
+    "phase_locking_value", "phase_lag_index", "weighted_phase_lag_index",
+    "debiased_squared_phase_lag_index", "debiased_squared_weighted_phase_lag_index",
+    "pairwise_phase_consistency",
+]
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB, keys={len(arrays)}")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    warnings.simplefilter("ignore")
+    T, Cn, mpd, sim = import_reference()
+    Multitaper, Connectivity = T.Multitaper, Cn.Connectivity
+
+    # F1: BASELINE cfg1 -- 2 ch x 1 trial x 1024, sine + noise, NW=3, single window
+    fs = 1000.0
+    t = np.arange(1024) / fs
+    rng = np.random.default_rng(0)
+    x = np.stack([np.sin(2 * np.pi * 50 * t) + 0.5 * rng.standard_normal(1024),
+                  np.sin(2 * np.pi * 50 * t + np.pi / 4) + 0.5 * rng.standard_normal(1024)],
+                 axis=-1)[:, None, :]
+    m = Multitaper(x, sampling_frequency=fs, time_halfbandwidth_product=3)
+    c = Connectivity.from_multitaper(m)
+    save("f1_cfg1", x=x, fs=fs, NW=3.0, tapers=m.tapers, fft=m.fft(),
+         frequencies=m.frequencies, time=m.time, conn_frequencies=c.frequencies,
+         power=c.power(), coherency=c.coherency(), coherence_magnitude=c.coherence_magnitude())
+
+    # F2: detrend variants
+    x = np.random.default_rng(1).standard_normal((256, 6, 5))
+    x += np.linspace(0, 3, 256)[:, None, None] * np.arange(1, 6)[None, None, :]
+    arrs = dict(x=x, fs=500.0, NW=3.0)
+    for det in ("constant", "linear", None):
+        m = Multitaper(x, sampling_frequency=500.0, time_halfbandwidth_product=3, detrend_type=det)
+        arrs[f"fft_{det}"] = m.fft()
+    save("f2_detrend", **arrs)
+
+    # F3: sliding windows, every measure, every expectation type (kept small: 3 ch, L=64)
+    x = np.random.default_rng(3).standard_normal((256, 3, 3))
+    tt = np.arange(256) / fs
+    for ch in range(3):
+        x[:, :, ch] += 0.8 * np.sin(2 * np.pi * 120 * tt + 2 * np.pi * ch / 3)[:, None]
+    m = Multitaper(x, sampling_frequency=fs, time_halfbandwidth_product=2,
+                   n_time_samples_per_window=64, n_time_samples_per_step=32)
+    arrs = dict(x=x, fs=fs, NW=2.0, L=64, step=32, fft=m.fft(), time=m.time,
+                tapers=m.tapers, frequencies=m.frequencies)
+    for et in Cn.EXPECTATION:
+        c = Connectivity.from_multitaper(m, expectation_type=et)
+        for name in MEASURES:
+            arrs[f"{et}__{name}"] = getattr(c, name)()
+    save("f3_windows_all_measures", **arrs)
+
+    # F4: non power-of-two lengths (Nyquist handling, zero padding, truncation)
+    x = np.random.default_rng(4).standard_normal((600, 3, 4))
+    arrs = dict(x=x, fs=250.0, NW=2.0)
+    for tag, kw in {
+        "L250": dict(n_time_samples_per_window=250),
+        "L250_N300": dict(n_time_samples_per_window=250, n_fft_samples=300),
+        "L255": dict(n_time_samples_per_window=255),
+        "L256_N255": dict(n_time_samples_per_window=256, n_fft_samples=255),
+        "dur_step": dict(time_window_duration=0.8, time_window_step=0.29),
+    }.items():
+        m = Multitaper(x, sampling_frequency=250.0, time_halfbandwidth_product=2, **kw)
+        c = Connectivity.from_multitaper(m)
+        arrs[f"{tag}__fft"] = m.fft()
+        arrs[f"{tag}__time"] = m.time
+        arrs[f"{tag}__frequencies"] = m.frequencies
+        arrs[f"{tag}__conn_frequencies"] = c.frequencies
+        arrs[f"{tag}__coherence_magnitude"] = c.coherence_magnitude()
+        arrs[f"{tag}__power"] = c.power()
+    save("f4_lengths", **arrs)
+
+    # F5: MVAR systems -> CSM, Wilson factor, pairwise spectral Granger
+    # Baccala & Sameshima 3-channel-like VAR(2) and Ding 2-channel VAR(2)
+    def simulate(coefs, cov, n_time, n_trials, seed):
+        rs = np.random.default_rng(seed)
+        return sim.simulate_MVAR(coefs, noise_covariance=cov, n_time_samples=n_time,
+                                 n_trials=n_trials, n_burnin_samples=200, random_state=rs)
+
+    coefs2 = np.array([[[0.9, 0.0], [0.16, 0.8]], [[-0.5, 0.0], [-0.2, -0.5]]])
+    cov2 = np.array([[1.0, 0.4], [0.4, 0.7]])
+    x2 = simulate(coefs2, cov2, 1000, 30, 5)
+    coefs3 = np.zeros((2, 3, 3))
+    coefs3[0] = [[0.5, 0.3, 0.4], [-0.5, 0.3, 1.0], [0.0, -0.3, -0.2]]
+    coefs3[1] = [[-0.2, 0.0, 0.0], [0.3, -0.3, 0.0], [0.0, 0.0, 0.3]]
+    x3 = simulate(coefs3 * 0.6, np.eye(3), 500, 20, 6)
+    arrs = {}
+    for tag, xs, kw in (("ding2", x2, dict(time_halfbandwidth_product=1)),
+                        ("bacc3", x3, dict(time_halfbandwidth_product=2,
+                                           n_time_samples_per_window=250))):
+        m = Multitaper(xs, sampling_frequency=200.0, **kw)
+        c = Connectivity.from_multitaper(m)
+        csm = c._expectation_cross_spectral_matrix()
+        arrs[f"{tag}__x"] = xs
+        arrs[f"{tag}__csm"] = csm
+        arrs[f"{tag}__power"] = c.power()
+        arrs[f"{tag}__granger"] = c.pairwise_spectral_granger_prediction()
+        sub = csm[..., :2, :2]
+        arrs[f"{tag}__wilson01"] = mpd.minimum_phase_decomposition(sub)
+    save("f5_granger", **arrs)
+
+    # F6: canonical coherence, 12 channels in 3 groups (2/4/6), 8 trials
+    x = np.random.default_rng(6).standard_normal((512, 8, 12))
+    labels = np.array([0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2])
+    src = np.random.default_rng(66).standard_normal((512, 8))
+    x[:, :, :2] += 0.7 * src[..., None]
+    x[:, :, 6:9] += 0.7 * src[..., None]
+    m = Multitaper(x, sampling_frequency=fs, time_halfbandwidth_product=3,
+                   n_time_samples_per_window=256)
+    c = Connectivity.from_multitaper(m)
+    cc, lab = c.canonical_coherence(labels)
+    save("f6_canonical", x=x, fs=fs, NW=3.0, L=256, group_labels=labels,
+         canonical_coherence=cc, labels=lab)
+
+    # F7: edge cases
+    arrs = {}
+    x = np.random.default_rng(7).standard_normal((200, 5, 4))
+    x[:, :, 2] = 0.0                                       # zero-power channel
+    m = Multitaper(x, sampling_frequency=100.0, time_halfbandwidth_product=2)
+    c = Connectivity.from_multitaper(m)
+    arrs["zero__x"] = x
+    arrs["zero__coherence_magnitude"] = c.coherence_magnitude()
+    arrs["zero__imaginary_coherence"] = c.imaginary_coherence()
+    arrs["zero__weighted_phase_lag_index"] = c.weighted_phase_lag_index()
+    arrs["zero__phase_lag_index"] = c.phase_lag_index()
+    # NW=1.75 -> 2 tapers requested; low-bias cut
+    x = np.random.default_rng(8).standard_normal((128, 3, 2))
+    m = Multitaper(x, sampling_frequency=100.0, time_halfbandwidth_product=1.75)
+    arrs["nw175__x"] = x
+    arrs["nw175__tapers"] = m.tapers
+    arrs["nw175__fft"] = m.fft()
+    m = Multitaper(x, sampling_frequency=100.0, time_halfbandwidth_product=1.0)
+    arrs["nw1__tapers"] = m.tapers
+    # user supplied tapers (Hann, 2 columns)
+    user = np.stack([np.hanning(128), np.hanning(128) ** 2], axis=1)
+    m = Multitaper(x, sampling_frequency=100.0, tapers=user)
+    arrs["user__tapers"] = user
+    arrs["user__fft"] = m.fft()
+    # synthetic coefficients fed straight to Connectivity (complex64 dtype path)
+    rs = np.random.default_rng(9)
+    coef = rs.standard_normal((2, 5, 3, 16, 4)) + 1j * rs.standard_normal((2, 5, 3, 16, 4))
+    c = Connectivity(coef, dtype=np.complex64)
+    arrs["raw__coef"] = coef
+    arrs["raw__coherence_magnitude"] = c.coherence_magnitude()
+    arrs["raw__csm"] = c._expectation_cross_spectral_matrix()
+    save("f7_edges", **arrs)
+
+    # DPSS tapers at the BASELINE shapes (float64, already scaled by sqrt(fs))
+    arrs = {}
+    for L, NW in ((1024, 3.0), (256, 4.0), (4096, 3.0), (250, 2.0), (64, 2.5)):
+        tap, eig = T.dpss_windows(L, NW, int(np.floor(2 * NW - 1)), is_low_bias=False)
+        arrs[f"L{L}_NW{NW}__tapers"] = np.asarray(tap)
+        arrs[f"L{L}_NW{NW}__eig"] = np.asarray(eig)
+    save("f8_dpss", **arrs)
+
+
+if __name__ == "__main__":
+    main()
