@@ -1,0 +1,234 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the hot path (BASELINE.json metric).
+
+Metric: channel-pair x frequency-bins per second for CSM + coherence (+ wPLI) on the
+configuration the metric is quoted on (BASELINE.json configs[2]): 128 channels x 1000 trials
+x 1024 samples, NW=4 (7 tapers), sliding 256-sample windows with 128-sample step (W=7,
+F=129), coherence_magnitude + weighted_phase_lag_index, expectation over trials x tapers.
+
+One "step" = one full pass of the hot path over the synthetic batch, inputs resident in HBM:
+  stage A  window/detrend/taper (HIP) + batched R2C FFT (rocFFT)
+  stage B  cross-spectral accumulation (MFMA) + |Im s| plane (VALU)
+  (N>1)    reduce-scatter of the accumulator records over RCCL
+  stage C  coherence + wPLI epilogue on the owned bins, (N>1) all-gather of the measures
+N GPUs: the 1000 trials are sharded over the ranks (strong scaling), one process per GPU.
+
+Prints ONE JSON line on rank 0 (see the driver contract), with `roofline` for the dominant
+kernel (durations from HIP events on the launch stream) and `cpu_baseline` (the NumPy
+oracle's faithful per-observation path, single core, on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from spectral_connectivity_amd import _lib, engine, parallel  # noqa: E402
+from spectral_connectivity_amd.transforms import _make_tapers  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32 dense peak
+
+CONFIGS = {
+    # name: T, R, C, NW, L, step
+    "cfg3": dict(T=1024, R=1000, C=128, NW=4.0, L=256, step=128, tone=60.0,
+                 label="128ch x 1000 trials x 1024 samples, NW=4 (7 tapers), 256-pt windows step 128 "
+                       "(W=7, F=129), coherence_magnitude + weighted_phase_lag_index"),
+    "cfg2": dict(T=1024, R=100, C=32, NW=3.0, L=1024, step=1024, tone=40.0,
+                 label="32ch x 100 trials x 1024 samples, NW=3 (5 tapers), single window, "
+                       "coherence_magnitude + weighted_phase_lag_index"),
+}
+FS = 1000.0
+
+
+def synth(cfg, r_lo, r_hi, device, seed):
+    """SURVEY 8(d) synthetic input: white noise + shared sinusoid, per-channel phase 2*pi*c/C."""
+    T, C = cfg["T"], cfg["C"]
+    g = torch.Generator(device=device)
+    g.manual_seed(seed * 1000003 + r_lo)
+    x = torch.randn((T, r_hi - r_lo, C), generator=g, device=device, dtype=torch.float32)
+    t = torch.arange(T, device=device, dtype=torch.float32) / FS
+    ph = 2 * np.pi * torch.arange(C, device=device, dtype=torch.float32) / C
+    x += 0.5 * torch.sin(2 * np.pi * cfg["tone"] * t[:, None, None] + ph[None, None, :])
+    return x
+
+
+class StageTimer:
+    def __init__(self):
+        self.events = []
+
+    def mark(self, name):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        self.events.append((name, ev))
+
+    def durations(self):
+        out = {}
+        for (n0, e0), (n1, e1) in zip(self.events[:-1], self.events[1:]):
+            out[n1] = out.get(n1, 0.0) + e0.elapsed_time(e1)
+        return out
+
+
+def one_step(x, h, cfg, geom, planes, world, timer=None):
+    lib = _lib.load()
+    mark = timer.mark if timer else (lambda name: None)
+    L, step, N, W = geom
+    mark("start")
+    sp = engine.multitaper_spectra(x, h, L, step, N, W, "constant", mark=mark)
+    accum, n_obs = engine.accumulate(sp, "trials_tapers", planes, mark=mark)
+    del sp
+    n_bins = accum.shape[0]
+    shard, lo, hi = parallel.reduce_scatter_bins(accum)
+    n_total = n_obs * world          # equal shards (R divisible by world is enforced below)
+    mark("reduce_scatter")
+    coh = engine.measure(shard, cfg["C"], planes, n_total, _lib.M_COHERENCE_MAGNITUDE)
+    wpli = engine.measure(shard, cfg["C"], planes, n_total, _lib.M_WPLI)
+    mark("measure_epilogue")
+    if world > 1:
+        coh = parallel.all_gather_bins(coh, n_bins)
+        wpli = parallel.all_gather_bins(wpli, n_bins)
+        mark("all_gather")
+    return coh, wpli
+
+
+def cpu_baseline(cfg, geom, budget_trials=1):
+    """Time the oracle's faithful (reference op-for-op) path on `budget_trials` trials."""
+    from oracle import spectral_oracle as so
+    L, step, N, W = geom
+    x = synth(cfg, 0, budget_trials, "cpu", seed=3).numpy().astype(np.float64)
+    t0 = time.perf_counter()
+    coef, _ = so.multitaper_fft(x, fs=FS, NW=cfg["NW"], n_time_samples_per_window=L,
+                                n_time_samples_per_step=step)
+    so.coherence_magnitude(coef)
+    so.weighted_phase_lag_index(coef)
+    dt = time.perf_counter() - t0
+    return dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
+    ap.add_argument("--trials", type=int, default=None, help="override total trial count (debug)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    _lib.require_gpu()
+
+    cfg = dict(CONFIGS[args.config])
+    if args.trials:
+        cfg["R"] = args.trials
+    assert cfg["R"] % world == 0, "trials must divide evenly over ranks"
+    r_lo, r_hi = parallel.shard_bounds(cfg["R"], world, rank)
+    T, C, L, step = cfg["T"], cfg["C"], cfg["L"], cfg["step"]
+    N = L
+    W = int(np.floor(T / step - L / step + 1))
+    F = N // 2 + 1
+    geom = (L, step, N, W)
+    K_req = int(np.floor(2 * cfg["NW"] - 1))
+    tapers = _make_tapers(L, FS, cfg["NW"], K_req)                    # (L, K) float64, host, once
+    K = tapers.shape[1]
+    h = torch.from_numpy(np.ascontiguousarray(tapers.T / FS, dtype=np.float32)).to(device)
+    x = synth(cfg, r_lo, r_hi, device, seed=3)
+    planes = _lib.PLANE_CSM | _lib.PLANE_ABS_IM
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step(x, h, cfg, geom, planes, world)
+    sync()
+    timers = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tm = StageTimer()
+        one_step(x, h, cfg, geom, planes, world, tm)
+        timers.append(tm)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    units = W * F * C * C                                   # channel-pair x frequency bins
+    value = units / (elapsed / args.steps)
+
+    # per-stage kernel durations (HIP events on the launch stream), averaged over steps
+    stage_ms = {}
+    for tm in timers:
+        for k, v in tm.durations().items():
+            stage_ms[k] = stage_ms.get(k, 0.0) + v / len(timers)
+    R_loc = r_hi - r_lo
+    n_obs_loc = R_loc * K
+    # algorithmic work per launch on this rank (DESIGN.md "Roofline")
+    stage_model = {
+        "taper_windows": ("hbm", 4.0 * T * R_loc * C + 4.0 * N * W * R_loc * K * C),
+        "rocfft_r2c": ("hbm", 4.0 * N * W * R_loc * K * C + 8.0 * F * W * R_loc * K * C),
+        "csm_mfma": ("mfma", 8.0 * n_obs_loc * (C * (C + 1) / 2) * W * F),
+        "nonlinear_valu": ("hbm", 8.0 * F * W * R_loc * K * C + 4.0 * W * F * C * (C + 1) / 2),
+        "measure_epilogue": ("hbm", (3 * 4.0 * C * (C + 1) / 2 + 2 * 4.0 * C * C) * W * F / world),
+    }
+    dominant = max((k for k in stage_model if k in stage_ms), key=lambda k: stage_ms[k])
+    bound, work = stage_model[dominant]
+    dur_s = stage_ms[dominant] * 1e-3
+    if bound == "mfma":
+        achieved, peak, unit = work / dur_s / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
+    else:
+        achieved, peak, unit = work / dur_s / 1e9, HBM_PEAK_GBS, "GB/s"
+    roofline = {"kernel": dominant, "bound": bound, "achieved": round(achieved, 3), "peak": peak,
+                "unit": unit, "frac": round(achieved / peak, 4), "traffic": None,
+                "kernel_ms": round(stage_ms[dominant], 4),
+                "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()}}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        n_sample = 1
+        dt = cpu_baseline(cfg, geom, n_sample)
+        cpu = {"value": round(units / (dt * cfg["R"] / n_sample), 3), "unit": "channel-pair*freq-bins/s",
+               "cores": 1, "kind": "port",
+               "measured_seconds_on_sample": round(dt, 3),
+               "sample": (f"oracle faithful path (per-observation outer product + mean, float64 NumPy, "
+                          f"single thread) on {n_sample} of {cfg['R']} trials of the same workload; cost is "
+                          f"exactly linear in trials, value = units / (t_sample * {cfg['R']}/{n_sample}); "
+                          f"os.cpu_count()={os.cpu_count()}")}
+
+    if rank == 0:
+        print(json.dumps({
+            "metric": "channel-pair*freq-bins/s for CSM+coherence(+wPLI)",
+            "value": value, "unit": "channel-pair*freq-bins/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": cfg["label"], "name": args.config, "trials_total": cfg["R"],
+                       "trials_per_gpu": R_loc, "n_tapers": K, "n_windows": W, "n_freq_bins": F,
+                       "units_per_step": units, "parallelism": f"trials sharded over {world} GPU(s)"},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

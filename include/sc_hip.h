@@ -1,0 +1,164 @@
+/* sc_hip.h -- C ABI of libsc_hip.so: the MI355X (gfx950) engine behind the
+ * Multitaper / Connectivity API of Eden-Kramer-Lab/spectral_connectivity.
+ *
+ * This is the drop-in boundary for ONE path of the reference: time series ->
+ * DPSS-tapered sliding-window FFT -> cross-spectral matrix -> expectation ->
+ * coherence / PLI / wPLI / PLV / PPC (-> pairwise spectral Granger, canonical coherence).
+ * It replaces the reference's array-backend plug point, the import-time switch
+ * `xp = cupy | numpy` plus `fft/ifft/...` (transforms.py:405-439, connectivity.py:31-65,
+ * minimum_phase_decomposition.py:14-26), for the call sites listed per function below.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes.  Every `dev_*`/`d_*` pointer is DEVICE memory
+ *    owned by the caller (the Python host allocates it with torch); the library never
+ *    allocates or frees caller buffers and keeps no pointer past the call.  The only
+ *    library-owned objects are opaque `sc_fft_plan` handles (rocFFT plan + work buffer).
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream).  All calls are
+ *    asynchronous on that stream; nothing synchronises the device.
+ *  - Return value: 0 on success, negative SC_E* otherwise; sc_last_error() returns a
+ *    thread-local message for the last failure.
+ *  - One plan / one stream is used by one host thread at a time; different streams may be
+ *    driven from different threads.
+ *
+ * Device layouts (row-major, last index fastest)
+ *  - time series      x[T][R][C]                      float   (reference layout, transforms.py:574)
+ *  - tapers           h[K][L]                         float   (= reference tapers^T / fs, see sc_taper_windows_f32)
+ *  - tapered windows  y[N][W][R][K][C]                float   (time-major: lanes <-> channels)
+ *  - spectra          X[F][W][R][K][C]                float2  (one-sided, F = N/2+1) -- or any
+ *                     layout described by sc_spectra_desc strides (e.g. the reference's
+ *                     own (W,R,K,N,C) order for uploaded coefficients)
+ *  - accumulators     A[bin][plane][tile][16][16]     float   bin = group*F + f ; upper-triangular
+ *                     16x16 channel tiles (bi <= bj), tile index = bi*NB - bi*(bi-1)/2 + (bj-bi);
+ *                     UN-normalised sums over observations (so trial shards can be summed)
+ *  - measures         M[bin][C][C]                    float (or float2 for complex measures)
+ */
+#ifndef SC_HIP_H
+#define SC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SC_ABI_VERSION 1
+
+/* error codes */
+#define SC_OK 0
+#define SC_EINVAL (-1)   /* bad argument / shape                 */
+#define SC_EHIP (-2)     /* HIP runtime error (launch, memcpy)   */
+#define SC_EFFT (-3)     /* rocFFT error                         */
+#define SC_ENOMEM (-4)   /* work-buffer allocation failed        */
+#define SC_EUNSUPPORTED (-5)
+
+/* detrend_type of sc_taper_windows_f32 (transforms.py:1798-1915) */
+#define SC_DETREND_NONE 0
+#define SC_DETREND_CONSTANT 1
+#define SC_DETREND_LINEAR 2
+
+/* accumulator planes (bit mask).  Plane order inside a bin record is the order below,
+ * skipping planes that are not requested.  CSM always occupies two planes (re, im). */
+#define SC_PLANE_CSM 0x01u      /* sum X_i conj(X_j)            : 2 planes (re, im)  connectivity.py:447-461 */
+#define SC_PLANE_ABS_IM 0x02u   /* sum |Im s|                   : 1 plane            connectivity.py:1008-1014 */
+#define SC_PLANE_IM_SQ 0x04u    /* sum (Im s)^2                 : 1 plane            connectivity.py:1096-1102 */
+#define SC_PLANE_SIGN_IM 0x08u  /* sum sign(Im s)               : 1 plane            connectivity.py:970-980 */
+#define SC_PLANE_UNIT 0x10u     /* sum s/|s|                    : 2 planes (re, im)  connectivity.py:899-903 */
+
+/* measures of sc_measure_f32 (all on non-negative frequency bins the caller accumulated) */
+#define SC_M_POWER 0                 /* connectivity.py:612-630   out float [bin][C]        */
+#define SC_M_CSM 1                   /* connectivity.py:463-492   out float2 [bin][C][C]    */
+#define SC_M_COHERENCY 2             /* connectivity.py:632-657   out float2                */
+#define SC_M_COHERENCE_MAGNITUDE 3   /* connectivity.py:675-702   out float                 */
+#define SC_M_COHERENCE_PHASE 4       /* connectivity.py:659-673                             */
+#define SC_M_IMAGINARY_COHERENCE 5   /* connectivity.py:704-743                             */
+#define SC_M_PLV 6                   /* connectivity.py:905-931   needs SC_PLANE_UNIT       */
+#define SC_M_PLI 7                   /* connectivity.py:933-980   needs SC_PLANE_SIGN_IM    */
+#define SC_M_WPLI 8                  /* connectivity.py:982-1028  needs CSM + ABS_IM        */
+#define SC_M_DEBIASED_PLI2 9         /* connectivity.py:1030-1058 needs SIGN_IM             */
+#define SC_M_DEBIASED_WPLI2 10       /* connectivity.py:1060-1127 needs CSM+ABS_IM+IM_SQ    */
+#define SC_M_PPC 11                  /* connectivity.py:1129-1159 needs UNIT                */
+#define SC_M_PLV_COMPLEX 12          /* connectivity.py:897-903   out float2                */
+
+typedef struct sc_fft_plan sc_fft_plan; /* opaque */
+
+/* How the (window, trial, taper) axes of the spectra map to memory and which of them the
+ * expectation averages (connectivity.py:67-75 EXPECTATION).  Strides are in complex
+ * elements; the channel stride is 1. */
+typedef struct sc_spectra_desc {
+    int64_t n_freq;      /* F: number of frequency bins to process                    */
+    int64_t n_windows;   /* W */
+    int64_t n_trials;    /* R */
+    int64_t n_tapers;    /* K */
+    int64_t n_signals;   /* C */
+    int64_t stride_freq; /* elements between consecutive bins                          */
+    int64_t stride_window;
+    int64_t stride_trial;
+    int64_t stride_taper;
+    int32_t reduce_window; /* 1 if the expectation averages over windows ("time")     */
+    int32_t reduce_trial;
+    int32_t reduce_taper;
+    int32_t reserved;
+} sc_spectra_desc;
+
+/* ---- library ------------------------------------------------------------------------ */
+int sc_abi_version(void);
+const char* sc_last_error(void);
+int sc_device_count(int* count);
+
+/* ---- stage A: window extraction + detrend + taper multiply (custom HIP) ---------------
+ * Replaces _sliding_window (transforms.py:1311-1374), detrend (:1798-1915) and the taper
+ * broadcast-multiply of _multitaper_fft (:1402-1404), fused, no window copy.
+ *   y[n][w][r][k][c] = (x[w*step+n][r][c] - trend) * h[k][n]   for n <  min(L, N)
+ *                    = 0                                        for min(L,N) <= n < N
+ * The caller folds the reference's sqrt(fs) taper scaling and the 1/fs of
+ * transforms.py:1405 into h (h = tapers^T / fs). */
+int sc_taper_windows_f32(const float* d_x, int64_t T, int64_t R, int64_t C,
+                         int64_t L, int64_t step, int64_t W, int64_t N,
+                         const float* d_tapers, int64_t K, int detrend_type,
+                         float* d_y, void* stream);
+
+/* ---- stage A: batched real-to-complex FFT (rocFFT) -----------------------------------
+ * Replaces fft(projected, n=N, axis=-2) of transforms.py:1405 (scipy.fft / cupyx.scipy.fft).
+ * Input  y[N][batch] float  (stride batch along time, distance 1 between transforms),
+ * output X[F][batch] float2 (F = N/2+1), i.e. both sides keep "batch fastest". */
+int sc_fft_plan_create(sc_fft_plan** plan, int64_t N, int64_t batch);
+int sc_fft_plan_work_bytes(const sc_fft_plan* plan, size_t* bytes);
+int sc_fft_execute(sc_fft_plan* plan, const float* d_y, void* d_X /*float2*/, void* stream);
+int sc_fft_plan_destroy(sc_fft_plan* plan);
+
+/* ---- stage B: accumulators -----------------------------------------------------------
+ * Number of floats of one bin record for `planes`, and total bins (groups * F). */
+int sc_accum_layout(const sc_spectra_desc* desc, uint32_t planes,
+                    int64_t* n_bins, int64_t* floats_per_bin, int64_t* n_groups,
+                    int64_t* n_observations);
+
+/* Sum over the averaged axes of the per-observation cross-spectral outer product, on the
+ * matrix cores (v_mfma_f32_16x16x4_f32), upper-triangular 16x16 tiles only.
+ * Replaces _complex_inner_product + mean of connectivity.py:447-492, :1799-1822 without
+ * materialising the per-observation (W,R,K,N,C,C) temporary.  Writes the two CSM planes
+ * of every bin record in d_accum (other planes untouched).  `obs_begin/obs_end` restrict
+ * the observation range (for sharding trials over GPUs pass the local shard and the full
+ * range: the sums are un-normalised). */
+int sc_csm_accumulate_f32(const void* d_X /*float2*/, const sc_spectra_desc* desc,
+                          uint32_t planes, float* d_accum, void* stream);
+
+/* Per-observation non-linear planes (|Im s|, (Im s)^2, sign Im s, s/|s|), VALU kernel.
+ * Replaces the fcn hook of _expectation_cross_spectral_matrix (connectivity.py:463-492)
+ * as used by PLV/PLI/wPLI/debiased variants/PPC (:897-1159).  Writes the requested
+ * non-CSM planes of every bin record. */
+int sc_nonlinear_accumulate_f32(const void* d_X /*float2*/, const sc_spectra_desc* desc,
+                                uint32_t planes, uint32_t which, float* d_accum, void* stream);
+
+/* ---- stage C: measures epilogue ------------------------------------------------------
+ * Elementwise measure algebra on accumulated sums (connectivity.py:612-1159): divides by
+ * n_observations AFTER any cross-GPU reduction, applies the reference's eps clamps, NaN /
+ * zero diagonals and clips, mirrors the triangle into the full C x C matrix.
+ * d_out: float [n_bins][C][C] (float2 for complex measures, float [n_bins][C] for power). */
+int sc_measure_f32(const float* d_accum, int64_t n_bins, int64_t n_signals, uint32_t planes,
+                   int64_t n_observations, int measure, void* d_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SC_HIP_H */

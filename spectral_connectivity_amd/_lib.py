@@ -1,0 +1,119 @@
+"""ctypes binding of the C ABI in include/sc_hip.h (libsc_hip.so).
+
+The HIP library is the ONLY compute path of this package: if it cannot be loaded the import
+of any compute entry point raises -- there is no NumPy/CPU fallback.
+
+torch is imported BEFORE the library on purpose: the PyTorch-ROCm wheel ships its own HIP
+runtime / rocFFT (same SONAMEs as /opt/rocm); loading it first makes libsc_hip.so bind to
+that single runtime, so device pointers of torch tensors are valid inside our kernels.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, byref, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_uint32, c_void_p
+
+import torch  # noqa: F401  (must precede CDLL, see module docstring)
+
+from . import _build
+
+c_int64_p = POINTER(c_int64)
+
+# ---- constants mirrored from include/sc_hip.h -------------------------------------------
+SC_ABI_VERSION = 1
+DETREND = {None: 0, "constant": 1, "c": 1, "linear": 2, "l": 2}
+PLANE_CSM, PLANE_ABS_IM, PLANE_IM_SQ, PLANE_SIGN_IM, PLANE_UNIT = 0x01, 0x02, 0x04, 0x08, 0x10
+(M_POWER, M_CSM, M_COHERENCY, M_COHERENCE_MAGNITUDE, M_COHERENCE_PHASE, M_IMAGINARY_COHERENCE,
+ M_PLV, M_PLI, M_WPLI, M_DEBIASED_PLI2, M_DEBIASED_WPLI2, M_PPC, M_PLV_COMPLEX) = range(13)
+COMPLEX_MEASURES = {M_CSM, M_COHERENCY, M_PLV_COMPLEX}
+MEASURE_PLANES = {
+    M_POWER: PLANE_CSM, M_CSM: PLANE_CSM, M_COHERENCY: PLANE_CSM, M_COHERENCE_MAGNITUDE: PLANE_CSM,
+    M_COHERENCE_PHASE: PLANE_CSM, M_IMAGINARY_COHERENCE: PLANE_CSM,
+    M_PLV: PLANE_UNIT, M_PLV_COMPLEX: PLANE_UNIT, M_PPC: PLANE_UNIT,
+    M_PLI: PLANE_SIGN_IM, M_DEBIASED_PLI2: PLANE_SIGN_IM,
+    M_WPLI: PLANE_CSM | PLANE_ABS_IM, M_DEBIASED_WPLI2: PLANE_CSM | PLANE_ABS_IM | PLANE_IM_SQ,
+}
+
+
+class SpectraDesc(Structure):
+    _fields_ = [("n_freq", c_int64), ("n_windows", c_int64), ("n_trials", c_int64),
+                ("n_tapers", c_int64), ("n_signals", c_int64), ("stride_freq", c_int64),
+                ("stride_window", c_int64), ("stride_trial", c_int64), ("stride_taper", c_int64),
+                ("reduce_window", c_int32), ("reduce_trial", c_int32), ("reduce_taper", c_int32),
+                ("reserved", c_int32)]
+
+
+# every symbol include/sc_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "sc_abi_version": (c_int, []),
+    "sc_last_error": (c_char_p, []),
+    "sc_device_count": (c_int, [POINTER(c_int)]),
+    "sc_taper_windows_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64,
+                                     c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "sc_fft_plan_create": (c_int, [POINTER(c_void_p), c_int64, c_int64]),
+    "sc_fft_plan_work_bytes": (c_int, [c_void_p, POINTER(c_size_t)]),
+    "sc_fft_execute": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sc_fft_plan_destroy": (c_int, [c_void_p]),
+    "sc_accum_layout": (c_int, [POINTER(SpectraDesc), c_uint32, c_int64_p, c_int64_p, c_int64_p, c_int64_p]),
+    "sc_csm_accumulate_f32": (c_int, [c_void_p, POINTER(SpectraDesc), c_uint32, c_void_p, c_void_p]),
+    "sc_nonlinear_accumulate_f32": (c_int, [c_void_p, POINTER(SpectraDesc), c_uint32, c_uint32, c_void_p, c_void_p]),
+    "sc_measure_f32": (c_int, [c_void_p, c_int64, c_int64, c_uint32, c_int64, c_int, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+class HipEngineError(RuntimeError):
+    """A libsc_hip.so entry point returned a negative status."""
+
+
+def library_path():
+    return os.environ.get("SC_HIP_LIB", _build.LIB)
+
+
+def load():
+    """Load (building in-tree if the sources are newer) and type libsc_hip.so.  Raises if impossible."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if path == _build.LIB and _build.is_stale():
+        try:
+            _build.build(verbose=False)
+        except Exception as exc:  # no hipcc, compile error: fail loudly, no CPU fallback
+            if not os.path.exists(path):
+                raise RuntimeError(
+                    "spectral_connectivity_amd needs its HIP extension libsc_hip.so and could not "
+                    f"build it ({exc}). Run `python -m spectral_connectivity_amd._build` on a machine "
+                    "with ROCm's hipcc; there is no CPU fallback.") from exc
+    try:
+        lib = ctypes.CDLL(path)
+    except OSError as exc:
+        raise RuntimeError(f"cannot load HIP extension {path}: {exc}. There is no CPU fallback.") from exc
+    for name, (restype, argtypes) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export it
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.sc_abi_version() != SC_ABI_VERSION:
+        raise RuntimeError(f"{path}: ABI version {lib.sc_abi_version()} != {SC_ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(status, what=""):
+    if status != 0:
+        msg = load().sc_last_error()
+        raise HipEngineError(f"{what} failed with status {status}: {msg.decode() if msg else ''}")
+
+
+def device_count():
+    n = c_int(0)
+    check(load().sc_device_count(byref(n)), "sc_device_count")
+    return n.value
+
+
+def require_gpu():
+    """The product path runs on an MI355X only: fail loudly when none is visible."""
+    if not torch.cuda.is_available():
+        raise RuntimeError(
+            "spectral_connectivity_amd: no ROCm GPU is visible (torch.cuda.is_available() is False). "
+            "This engine has no CPU fallback; run on an MI355X host.")
+    load()

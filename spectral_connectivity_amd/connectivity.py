@@ -1,0 +1,226 @@
+"""Connectivity measures: host-side mirror of the reference's ``Connectivity`` API.
+
+Same constructor, properties, method names, output shapes (NumPy float64 / complex128,
+non-negative frequencies only) and error behaviour as
+``spectral_connectivity.connectivity.Connectivity`` (reference connectivity.py:163-1650) for
+the hot-path measures.  All arithmetic runs on an MI355X through ``libsc_hip.so``:
+
+    expectation of the cross-spectral matrix   -> MFMA kernel        (sc_csm.hip)
+    |Im s|, (Im s)^2, sign Im s, s/|s| planes   -> VALU kernel        (sc_nonlinear.hip)
+    measure algebra, eps clamps, NaN diagonals  -> epilogue kernel    (sc_measure.hip)
+
+There is no NumPy fallback: without the HIP extension / a GPU every measure raises.
+"""
+import warnings
+from logging import getLogger
+
+import numpy as np
+
+from . import _lib
+from .engine import EXPECTATION_AXES
+
+logger = getLogger(__name__)
+
+# kept for API parity with reference connectivity.py:67-75 (keys are what matters)
+EXPECTATION = dict.fromkeys(EXPECTATION_AXES)
+
+
+class Connectivity:
+    """Frequency-domain connectivity measures computed on an MI355X.
+
+    Parameters mirror reference connectivity.py:277-285.  ``fourier_coefficients`` is either
+    a 5-D complex array (n_time_windows, n_trials, n_tapers, n_fft_samples, n_signals) --
+    uploaded once -- or, through :meth:`from_multitaper`, the HBM-resident spectra of a
+    :class:`~spectral_connectivity_amd.transforms.Multitaper` (no host round trip).
+
+    ``blocks`` is accepted for compatibility and ignored: the engine never materialises the
+    per-observation cross-spectra the reference blocks over.  ``dtype`` is accepted; the
+    device pipeline computes in complex64/float32 with fp64 epilogue algebra.
+    """
+
+    def __init__(self, fourier_coefficients, expectation_type="trials_tapers", frequencies=None,
+                 time=None, blocks=None, dtype=np.complex128):
+        from .engine import DeviceSpectra
+        self._spectra = None
+        self._host_coefficients = None
+        self._multitaper = None
+        if isinstance(fourier_coefficients, DeviceSpectra):
+            self._spectra = fourier_coefficients
+        else:
+            fourier_coefficients = np.asarray(fourier_coefficients)
+            if fourier_coefficients.ndim != 5:
+                raise ValueError(
+                    f"fourier_coefficients must be 5-dimensional, got {fourier_coefficients.ndim}D array.\n"
+                    "Expected shape: (n_time_windows, n_trials, n_tapers, n_fft_samples, n_signals)\n"
+                    f"Got shape: {fourier_coefficients.shape}\n\n"
+                    "If you have time series data, use the Multitaper class to transform it:\n"
+                    "  from spectral_connectivity_amd import Multitaper\n"
+                    "  m = Multitaper(time_series, sampling_frequency=your_fs, ...)\n"
+                    "  fourier_coefficients = m.fft()")
+            self._host_coefficients = fourier_coefficients
+        if expectation_type not in EXPECTATION_AXES:
+            words = set(expectation_type.split("_"))
+            suggestion = None
+            if words.issubset({"time", "trials", "tapers"}):
+                for key in EXPECTATION_AXES:
+                    if set(key.split("_")) == words:
+                        suggestion = key
+                        break
+            msg = (f"Invalid expectation_type '{expectation_type}' is not supported.\n"
+                   "This parameter controls which dimensions to average over when computing "
+                   "the cross-spectral matrix.\n")
+            if suggestion:
+                msg += f"\nDid you mean '{suggestion}'? (The words must be in a specific order)\n"
+            msg += "\nValid options are:\n" + "".join(f"  - '{k}'\n" for k in sorted(EXPECTATION_AXES))
+            msg += "\nMost common: 'trials_tapers' (average over both trials and tapers)"
+            raise ValueError(msg)
+        if self._host_coefficients is not None and not np.all(np.isfinite(self._host_coefficients)):
+            warnings.warn(
+                "fourier_coefficients contains NaN or Inf values. This may indicate:\n"
+                "  - NaN/Inf in your input time series data\n"
+                "  - Issues with windowing parameters (e.g., window too short)\n"
+                "  - Numerical instability in preprocessing", UserWarning, stacklevel=2)
+        self.expectation_type = expectation_type
+        self._frequencies = frequencies
+        self._blocks = blocks
+        self._dtype = dtype
+        self.time = None if time is None else np.asarray(time)
+        self._accum_cache = {}
+
+    @classmethod
+    def from_multitaper(cls, multitaper_instance, expectation_type="trials_tapers", blocks=None,
+                        dtype=np.complex128):
+        """Reference connectivity.py:366-400, but the coefficients never leave the device."""
+        obj = cls(multitaper_instance.device_spectra(), expectation_type=expectation_type,
+                  time=multitaper_instance.time, frequencies=multitaper_instance.frequencies,
+                  blocks=blocks, dtype=dtype)
+        obj._multitaper = multitaper_instance
+        return obj
+
+    # ---- bookkeeping ---------------------------------------------------------------------
+    @property
+    def fourier_coefficients(self):
+        if self._host_coefficients is None:
+            self._host_coefficients = self._multitaper.fft()
+        return self._host_coefficients
+
+    @property
+    def _shape5(self):
+        if self._host_coefficients is not None:
+            return self._host_coefficients.shape
+        s = self._spectra
+        return (s.W, s.R, s.K, s.n_fft, s.C)
+
+    @property
+    def frequencies(self):
+        """Non-negative frequencies (reference connectivity.py:402-424)."""
+        if self._frequencies is None:
+            return None
+        f = np.asarray(self._frequencies)
+        out = np.array(f[: len(f) // 2 + 1], dtype=float)
+        if len(out) and out[-1] < 0:
+            out[-1] = abs(out[-1])
+        return out
+
+    @property
+    def all_frequencies(self):
+        return None if self._frequencies is None else np.asarray(self._frequencies)
+
+    @property
+    def n_observations(self):
+        """Reference connectivity.py:594-610."""
+        return int(np.prod([self._shape5[a] for a in EXPECTATION_AXES[self.expectation_type]]))
+
+    # ---- device plumbing -----------------------------------------------------------------
+    def _device(self):
+        if self._spectra is None:
+            from . import engine
+            _lib.require_gpu()
+            self._spectra = engine.upload_coefficients(self._host_coefficients)
+        return self._spectra
+
+    @property
+    def _n_freq(self):
+        return self._shape5[3] // 2 + 1
+
+    def _accumulators(self, planes):
+        """Accumulator record containing at least ``planes`` (cached)."""
+        from . import engine
+        for have, rec in self._accum_cache.items():
+            if have & planes == planes:
+                return have, rec
+        sp = self._device()
+        accum, n_obs = engine.accumulate(sp, self.expectation_type, planes, n_freq=self._n_freq)
+        accum = self._reduce_over_ranks(accum)
+        self._accum_cache[planes] = (accum, n_obs)
+        return planes, (accum, n_obs)
+
+    def _reduce_over_ranks(self, accum):
+        """Hook for trial-sharded multi-GPU runs (see parallel.ShardedConnectivity)."""
+        return accum
+
+    def _kept_shape(self):
+        W, R, K = self._shape5[:3]
+        axes = EXPECTATION_AXES[self.expectation_type]
+        return tuple(n for i, n in enumerate((W, R, K)) if i not in axes)
+
+    def _measure(self, which):
+        from . import engine
+        have, (accum, n_obs) = self._accumulators(_lib.MEASURE_PLANES[which])
+        C = self._shape5[4]
+        out = engine.measure(accum, C, have, self._n_observations_total(n_obs), which)
+        host = out.cpu().numpy()
+        host = host.astype(np.complex128 if np.iscomplexobj(host) else np.float64)
+        tail = (C,) if which == _lib.M_POWER else (C, C)
+        return host.reshape(self._kept_shape() + (self._n_freq,) + tail)
+
+    def _n_observations_total(self, local_n_obs):
+        return local_n_obs
+
+    # ---- measures (reference connectivity.py:612-1159) -----------------------------------
+    def power(self):
+        """Power spectral density, non-negative frequencies: (..., n_freq, n_signals)."""
+        return self._measure(_lib.M_POWER)
+
+    def _expectation_cross_spectral_matrix(self):
+        """E[X_i conj X_j] on the non-negative bins (reference connectivity.py:463-526)."""
+        return self._measure(_lib.M_CSM)
+
+    def coherency(self):
+        return self._measure(_lib.M_COHERENCY)
+
+    def coherence_phase(self):
+        return self._measure(_lib.M_COHERENCE_PHASE)
+
+    def coherence_magnitude(self):
+        return self._measure(_lib.M_COHERENCE_MAGNITUDE)
+
+    def imaginary_coherence(self):
+        return self._measure(_lib.M_IMAGINARY_COHERENCE)
+
+    def _phase_locking_value(self):
+        return self._measure(_lib.M_PLV_COMPLEX)
+
+    def phase_locking_value(self):
+        return self._measure(_lib.M_PLV)
+
+    def phase_lag_index(self):
+        return self._measure(_lib.M_PLI)
+
+    def weighted_phase_lag_index(self):
+        return self._measure(_lib.M_WPLI)
+
+    def debiased_squared_phase_lag_index(self):
+        return self._measure(_lib.M_DEBIASED_PLI2)
+
+    def debiased_squared_weighted_phase_lag_index(self):
+        return self._measure(_lib.M_DEBIASED_WPLI2)
+
+    def pairwise_phase_consistency(self):
+        return self._measure(_lib.M_PPC)
+
+    def conditional_spectral_granger_prediction(self):
+        raise NotImplementedError   # reference connectivity.py:1215-1224 raises too
+
+    def blockwise_spectral_granger_prediction(self):
+        raise NotImplementedError   # reference connectivity.py:1226-1235 raises too

@@ -1,0 +1,92 @@
+// sc_common.h -- shared host/device helpers of libsc_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/sc_hip.h"
+
+void sc_set_error(const char* fmt, ...);
+
+#define SC_CHECK_HIP(expr)                                                        \
+    do {                                                                          \
+        hipError_t e_ = (expr);                                                   \
+        if (e_ != hipSuccess) {                                                   \
+            sc_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),   \
+                         __FILE__, __LINE__);                                     \
+            return SC_EHIP;                                                       \
+        }                                                                         \
+    } while (0)
+
+#define SC_REQUIRE(cond, msg)                                                     \
+    do {                                                                          \
+        if (!(cond)) {                                                            \
+            sc_set_error("invalid argument: %s (%s)", msg, #cond);                \
+            return SC_EINVAL;                                                     \
+        }                                                                         \
+    } while (0)
+
+#define SC_TILE 16            // channel tile edge of the accumulator layout
+#define SC_TILE_ELEMS 256
+#define SC_MAX_SIGNALS 256    // v1 kernels stage all channels of an observation row in LDS
+
+// number of planes / offset (in planes) of a plane inside a bin record
+__host__ __device__ inline int sc_plane_count(uint32_t planes) {
+    int n = 0;
+    if (planes & SC_PLANE_CSM) n += 2;
+    if (planes & SC_PLANE_ABS_IM) n += 1;
+    if (planes & SC_PLANE_IM_SQ) n += 1;
+    if (planes & SC_PLANE_SIGN_IM) n += 1;
+    if (planes & SC_PLANE_UNIT) n += 2;
+    return n;
+}
+__host__ __device__ inline int sc_plane_offset(uint32_t planes, uint32_t which) {
+    int n = 0;
+    if (which == SC_PLANE_CSM) return n;
+    if (planes & SC_PLANE_CSM) n += 2;
+    if (which == SC_PLANE_ABS_IM) return n;
+    if (planes & SC_PLANE_ABS_IM) n += 1;
+    if (which == SC_PLANE_IM_SQ) return n;
+    if (planes & SC_PLANE_IM_SQ) n += 1;
+    if (which == SC_PLANE_SIGN_IM) return n;
+    if (planes & SC_PLANE_SIGN_IM) n += 1;
+    return n;  // SC_PLANE_UNIT
+}
+__host__ __device__ inline int sc_n_blocks(int64_t C) { return (int)((C + SC_TILE - 1) / SC_TILE); }
+__host__ __device__ inline int sc_n_tiles(int nb) { return nb * (nb + 1) / 2; }
+// packed index of upper tile (bi <= bj)
+__host__ __device__ inline int sc_tile_index(int bi, int bj, int nb) {
+    return bi * nb - bi * (bi - 1) / 2 + (bj - bi);
+}
+
+// Decoding of group / observation indices into element offsets (see sc_spectra_desc).
+struct ScAxes {
+    int64_t sW, sR, sK, sF;
+    int W, R, K, C, F;
+    int kW, kR, kK;   // kept sizes (1 if reduced)
+    int rW, rR, rK;   // reduced sizes (1 if kept)
+    int n_groups, n_obs;
+};
+
+inline int sc_make_axes(const sc_spectra_desc* d, ScAxes* a) {
+    if (!d) return SC_EINVAL;
+    a->sW = d->stride_window; a->sR = d->stride_trial; a->sK = d->stride_taper; a->sF = d->stride_freq;
+    a->W = (int)d->n_windows; a->R = (int)d->n_trials; a->K = (int)d->n_tapers;
+    a->C = (int)d->n_signals; a->F = (int)d->n_freq;
+    a->kW = d->reduce_window ? 1 : a->W; a->rW = d->reduce_window ? a->W : 1;
+    a->kR = d->reduce_trial ? 1 : a->R;  a->rR = d->reduce_trial ? a->R : 1;
+    a->kK = d->reduce_taper ? 1 : a->K;  a->rK = d->reduce_taper ? a->K : 1;
+    a->n_groups = a->kW * a->kR * a->kK;
+    a->n_obs = a->rW * a->rR * a->rK;
+    return SC_OK;
+}
+
+__device__ inline int64_t sc_group_offset(const ScAxes& a, int g) {
+    int gk = g % a.kK; g /= a.kK;
+    int gr = g % a.kR; g /= a.kR;
+    return (int64_t)g * a.sW + (int64_t)gr * a.sR + (int64_t)gk * a.sK;
+}
+__device__ inline int64_t sc_obs_offset(const ScAxes& a, int o) {
+    int ok = o % a.rK; o /= a.rK;
+    int orr = o % a.rR; o /= a.rR;
+    return (int64_t)o * a.sW + (int64_t)orr * a.sR + (int64_t)ok * a.sK;
+}

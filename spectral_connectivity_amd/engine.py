@@ -1,0 +1,163 @@
+"""Device pipeline glue: torch owns HBM buffers and streams, libsc_hip.so does the work.
+
+Nothing here computes on the CPU: every function launches HIP kernels / rocFFT through the
+C ABI (include/sc_hip.h) on the current torch stream and returns device tensors.
+"""
+import ctypes
+from ctypes import byref, c_int64, c_void_p
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import SpectraDesc
+
+# connectivity.py:67-75 of the reference: which of (window, trial, taper) are averaged
+EXPECTATION_AXES = {
+    "time": (0,),
+    "trials": (1,),
+    "tapers": (2,),
+    "time_trials": (0, 1),
+    "time_tapers": (0, 2),
+    "trials_tapers": (1, 2),
+    "time_trials_tapers": (0, 1, 2),
+}
+
+_plan_cache = {}
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return c_void_p(t.data_ptr())
+
+
+def fft_plan(n_fft, batch):
+    """rocFFT real-forward plan, 'batch fastest' on both sides (cached per (N, batch, device))."""
+    key = (int(n_fft), int(batch), torch.cuda.current_device())
+    plan = _plan_cache.get(key)
+    if plan is None:
+        lib = _lib.load()
+        handle = c_void_p()
+        _lib.check(lib.sc_fft_plan_create(byref(handle), n_fft, batch), "sc_fft_plan_create")
+        plan = handle
+        _plan_cache[key] = plan
+    return plan
+
+
+def clear_plan_cache():
+    lib = _lib.load()
+    for plan in _plan_cache.values():
+        lib.sc_fft_plan_destroy(plan)
+    _plan_cache.clear()
+
+
+class DeviceSpectra:
+    """One-sided (or caller-described) Fourier coefficients resident in HBM.
+
+    ``X`` is a complex64 tensor; ``dims`` = (F, W, R, K, C) logical sizes and ``strides`` =
+    element strides of (freq, window, trial, taper) -- channel stride is 1.
+    """
+
+    def __init__(self, X, dims, strides, n_fft, real_input):
+        self.X = X
+        self.F, self.W, self.R, self.K, self.C = (int(d) for d in dims)
+        self.strides = tuple(int(s) for s in strides)
+        self.n_fft = int(n_fft)
+        self.real_input = bool(real_input)   # negative bins are conj mirrors of positive ones
+
+    def desc(self, expectation_type, n_freq=None):
+        axes = EXPECTATION_AXES[expectation_type]
+        sF, sW, sR, sK = self.strides
+        return SpectraDesc(n_freq=self.F if n_freq is None else n_freq, n_windows=self.W,
+                           n_trials=self.R, n_tapers=self.K, n_signals=self.C, stride_freq=sF,
+                           stride_window=sW, stride_trial=sR, stride_taper=sK,
+                           reduce_window=int(0 in axes), reduce_trial=int(1 in axes),
+                           reduce_taper=int(2 in axes), reserved=0)
+
+
+def multitaper_spectra(x, tapers_over_fs, n_window, n_step, n_fft, n_windows, detrend_type, mark=None):
+    """Stage A on device: (T,R,C) float32 tensor -> DeviceSpectra [F][W][R][K][C].
+
+    ``tapers_over_fs``: (K, L) float32 device tensor = reference tapers^T / fs
+    (folds the sqrt(fs) of transforms.py:1440 and the /fs of transforms.py:1405).
+    """
+    lib = _lib.load()
+    T, R, C = x.shape
+    K, L = tapers_over_fs.shape
+    assert L == n_window
+    batch = n_windows * R * K * C
+    y = torch.empty((n_fft, batch), dtype=torch.float32, device=x.device)
+    _lib.check(lib.sc_taper_windows_f32(_ptr(x), T, R, C, L, n_step, n_windows, n_fft,
+                                        _ptr(tapers_over_fs), K, _lib.DETREND[detrend_type],
+                                        _ptr(y), _stream()), "sc_taper_windows_f32")
+    if mark:
+        mark("taper_windows")
+    F = n_fft // 2 + 1
+    X = torch.empty((F, n_windows, R, K, C), dtype=torch.complex64, device=x.device)
+    _lib.check(lib.sc_fft_execute(fft_plan(n_fft, batch), _ptr(y), _ptr(X), _stream()), "sc_fft_execute")
+    if mark:
+        mark("rocfft_r2c")
+    del y
+    sK = C
+    sR = K * C
+    sW = R * K * C
+    sF = n_windows * R * K * C
+    return DeviceSpectra(X, (F, n_windows, R, K, C), (sF, sW, sR, sK), n_fft, real_input=True)
+
+
+def upload_coefficients(coef, device="cuda"):
+    """Reference-layout (W,R,K,N,C) complex coefficients -> DeviceSpectra (all N bins, as given)."""
+    coef = np.asarray(coef)
+    W, R, K, N, C = coef.shape
+    X = torch.from_numpy(np.ascontiguousarray(coef, dtype=np.complex64)).to(device)
+    return DeviceSpectra(X, (N, W, R, K, C), (C, R * K * N * C, K * N * C, N * C), N, real_input=False)
+
+
+def accum_layout(spectra, expectation_type, planes, n_freq=None):
+    lib = _lib.load()
+    d = spectra.desc(expectation_type, n_freq)
+    n_bins, fpb, n_groups, n_obs = c_int64(), c_int64(), c_int64(), c_int64()
+    _lib.check(lib.sc_accum_layout(byref(d), planes, byref(n_bins), byref(fpb), byref(n_groups),
+                                   byref(n_obs)), "sc_accum_layout")
+    return n_bins.value, fpb.value, n_groups.value, n_obs.value
+
+
+def accumulate(spectra, expectation_type, planes, n_freq=None, mark=None):
+    """Stage B: un-normalised accumulator record tensor [n_bins, floats_per_bin] (float32)."""
+    lib = _lib.load()
+    d = spectra.desc(expectation_type, n_freq)
+    n_bins, fpb, _, n_obs = accum_layout(spectra, expectation_type, planes, n_freq)
+    accum = torch.empty((n_bins, fpb), dtype=torch.float32, device=spectra.X.device)
+    if planes & _lib.PLANE_CSM:
+        _lib.check(lib.sc_csm_accumulate_f32(_ptr(spectra.X), byref(d), planes, _ptr(accum), _stream()),
+                   "sc_csm_accumulate_f32")
+        if mark:
+            mark("csm_mfma")
+    nl = planes & ~_lib.PLANE_CSM
+    if nl:
+        _lib.check(lib.sc_nonlinear_accumulate_f32(_ptr(spectra.X), byref(d), planes, nl, _ptr(accum),
+                                                   _stream()), "sc_nonlinear_accumulate_f32")
+        if mark:
+            mark("nonlinear_valu")
+    return accum, n_obs
+
+
+def measure(accum, n_signals, planes, n_obs, which, out=None):
+    """Stage C: one measure from an accumulator tensor (after any cross-GPU sum)."""
+    lib = _lib.load()
+    n_bins = accum.shape[0]
+    C = n_signals
+    if which == _lib.M_POWER:
+        shape, dtype = (n_bins, C), torch.float32
+    elif which in _lib.COMPLEX_MEASURES:
+        shape, dtype = (n_bins, C, C), torch.complex64
+    else:
+        shape, dtype = (n_bins, C, C), torch.float32
+    if out is None:
+        out = torch.empty(shape, dtype=dtype, device=accum.device)
+    _lib.check(lib.sc_measure_f32(_ptr(accum), n_bins, C, planes, n_obs, which, _ptr(out), _stream()),
+               "sc_measure_f32")
+    return out

@@ -1,0 +1,71 @@
+"""Trial sharding over the GPUs of one node (one process per GPU, torch.distributed / RCCL).
+
+The expectation over trials x tapers is a plain sum of per-observation terms for every
+accumulator plane (reference connectivity.py:67-75, :489), so trials shard embarrassingly:
+each rank runs stages A and B on its own trials, then ONE exchange sums the un-normalised
+accumulator records.  The exchange is a reduce-scatter over frequency/window bins (each
+rank ends up owning 1/N of the bins, summed over all ranks), the measures epilogue runs on
+the owned bins only, and an all-gather assembles the final measures -- 2(N-1)/N of the data
+per link instead of the 2x of an all-reduce followed by a redundant epilogue.  Division by
+n_observations happens after the sum (never average ratios).
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_items, world_size, rank):
+    """Contiguous balanced partition [lo, hi) of n_items (first n_items % world get one more)."""
+    base, extra = divmod(n_items, world_size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def padded_bins(n_bins, world_size):
+    return (n_bins + world_size - 1) // world_size * world_size
+
+
+def reduce_scatter_bins(accum, group=None):
+    """Sum accumulator records over ranks; return (this rank's bin shard, bin_lo, bin_hi).
+
+    ``accum``: [n_bins, floats_per_bin] float32.  Bins are padded to a multiple of the
+    world size so every rank owns the same count; ``bin_hi`` is clipped to n_bins.
+    """
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return accum, 0, accum.shape[0]
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n_bins, fpb = accum.shape
+    per = padded_bins(n_bins, world) // world
+    if per * world != n_bins:
+        pad = torch.zeros((per * world - n_bins, fpb), dtype=accum.dtype, device=accum.device)
+        accum = torch.cat([accum, pad], dim=0)
+    lo = rank * per
+    hi = min(lo + per, n_bins)
+    if dist.get_backend(group) == "gloo":      # CPU tests: gloo has no reduce_scatter
+        dist.all_reduce(accum, group=group)
+        shard = accum[lo:lo + per].clone()
+    else:
+        shard = torch.empty((per, fpb), dtype=accum.dtype, device=accum.device)
+        dist.reduce_scatter_tensor(shard, accum, group=group)
+    return shard, lo, max(hi, lo)
+
+
+def all_gather_bins(shard_out, n_bins, group=None):
+    """Assemble per-rank measure shards [per, ...] into the full [n_bins, ...] tensor."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return shard_out[:n_bins]
+    world = dist.get_world_size(group)
+    full = torch.empty((shard_out.shape[0] * world,) + tuple(shard_out.shape[1:]),
+                       dtype=shard_out.dtype, device=shard_out.device)
+    dist.all_gather_into_tensor(full, shard_out.contiguous(), group=group)
+    return full[:n_bins]
+
+
+def total_observations(local_n_obs, group=None):
+    """n_observations of the whole job = sum of the shards' counts (trials differ per rank)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return int(local_n_obs)
+    t = torch.tensor([int(local_n_obs)], dtype=torch.int64)
+    if dist.get_backend(group) != "gloo":
+        t = t.cuda()
+    dist.all_reduce(t, group=group)
+    return int(t.item())

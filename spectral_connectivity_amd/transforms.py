@@ -1,0 +1,334 @@
+"""Multitaper transform: host-side mirror of the reference's ``Multitaper`` API.
+
+Same constructor, properties and error/warning behaviour as
+``spectral_connectivity.transforms.Multitaper`` (reference transforms.py:442-1171), but the
+work -- window extraction, detrending, taper multiply (hand-written HIP) and the batched
+real FFT (rocFFT) -- runs on an MI355X through ``libsc_hip.so`` and the coefficients stay
+resident in HBM for ``Connectivity.from_multitaper``.  Host code here is parameter logic
+and the (tiny, once-per-object, float64) DPSS taper generation only.
+"""
+import warnings
+from logging import getLogger
+
+import numpy as np
+from scipy.fft import fft as _host_fft
+from scipy.fft import fftfreq, ifft as _host_ifft, next_fast_len
+from scipy.linalg import eigh_tridiagonal
+
+logger = getLogger(__name__)
+
+MIN_EIGENVALUE_THRESHOLD = 0.9   # reference transforms.py:22
+TAPER_MULTIPLIER = 2.0           # reference transforms.py:30
+
+
+def estimate_frequency_resolution(sampling_frequency, time_window_duration, time_halfbandwidth_product):
+    """Frequency resolution 2*NW/T in Hz (reference transforms.py:63-141)."""
+    return TAPER_MULTIPLIER * time_halfbandwidth_product / time_window_duration
+
+
+def estimate_n_tapers(time_halfbandwidth_product):
+    """floor(2*NW) - 1 (reference transforms.py:144-196)."""
+    return int(np.floor(TAPER_MULTIPLIER * time_halfbandwidth_product)) - 1
+
+
+def prepare_time_series(time_series, axis=None):
+    """Reshape 1-D / 2-D input to (n_time, n_trials, n_signals) (reference transforms.py:1174-1297)."""
+    arr = np.asarray(time_series)
+    if arr.ndim == 1:
+        return arr[:, np.newaxis, np.newaxis]
+    if arr.ndim == 2:
+        if axis is None:
+            raise ValueError(
+                "For 2D input, you must specify the 'axis' parameter.\n"
+                f"Input shape: {arr.shape}\n"
+                "  - axis='signals' if shape is (n_time_samples, n_signals)\n"
+                "  - axis='trials' if shape is (n_time_samples, n_trials)")
+        if axis == "signals":
+            return arr[:, np.newaxis, :]
+        if axis == "trials":
+            return arr[:, :, np.newaxis]
+        raise ValueError(f"axis must be either 'signals' or 'trials', got: {axis!r}")
+    if arr.ndim == 3:
+        return arr
+    raise ValueError(f"Expected 1D, 2D, or 3D array, got {arr.ndim}D array with shape {arr.shape}")
+
+
+# ------------------------------------------------------------------------------ DPSS (host)
+def dpss_windows(n_time_samples_per_window, time_halfbandwidth_product, n_tapers, is_low_bias=True):
+    """Discrete prolate spheroidal sequences and their concentration eigenvalues.
+
+    Same definition and conventions as reference transforms.py:1539-1613: eigenvectors of
+    the Slepian tridiagonal matrix (:1654-1714) for the ``n_tapers`` largest eigenvalues,
+    unit l2 norm; symmetric tapers have positive mean, antisymmetric ones start with a
+    positive lobe (:1717-1745); concentration by the autocorrelation method (:1768-1795);
+    ``is_low_bias`` keeps eigenvalue > 0.9, or the best one if none (:1758-1765).
+    The eigenvectors come from LAPACK (stemr) instead of the reference's Python inverse
+    iteration.  Returns (tapers (K', L), eigenvalues (K',)).
+    """
+    L = int(n_time_samples_per_window)
+    K = int(n_tapers)
+    half_bw = float(time_halfbandwidth_product) / L
+    t = np.arange(L, dtype=np.float64)
+    diag = ((L - 1 - 2 * t) / 2.0) ** 2 * np.cos(2 * np.pi * half_bw)
+    off = t[1:] * (L - t[1:]) / 2.0
+    if L == 1:
+        vecs = np.ones((1, 1))
+    else:
+        lo = max(L - K, 0)
+        _, vecs = eigh_tridiagonal(diag, off, select="i", select_range=(lo, L - 1))
+    tapers = np.ascontiguousarray(vecs[:, ::-1].T)            # largest eigenvalue first
+    tapers /= np.linalg.norm(tapers, axis=1, keepdims=True)
+    # sign conventions
+    neg = tapers[::2].sum(axis=1) < 0
+    tapers[::2][neg] *= -1
+    if tapers.shape[0] > 1:
+        peak = np.argmax(np.abs(tapers[1::2, : L // 2]), axis=1)
+        for i, p in enumerate(peak):
+            if tapers[2 * i + 1, :p].sum() < 0:
+                tapers[2 * i + 1] *= -1
+    # concentration eigenvalues
+    nfft = next_fast_len(2 * L - 1)
+    spec = _host_fft(tapers, nfft, axis=-1)
+    acorr = np.real(_host_ifft(spec * spec.conj(), axis=-1))[:, :L]
+    kernel = 4 * half_bw * np.sinc(2 * half_bw * t)
+    kernel[0] = 2 * half_bw
+    eig = acorr @ kernel
+    if is_low_bias:
+        keep = eig > MIN_EIGENVALUE_THRESHOLD
+        if not keep.any():
+            logger.warning("Could not properly use low_bias, keeping lowest-bias taper")
+            keep = np.zeros_like(keep)
+            keep[np.argmax(eig)] = True
+        tapers, eig = tapers[keep], eig[keep]
+    return tapers, eig
+
+
+def _make_tapers(n_time_samples_per_window, sampling_frequency, time_halfbandwidth_product, n_tapers,
+                 is_low_bias=True):
+    """(L, K') tapers scaled by sqrt(fs) (reference transforms.py:1408-1440)."""
+    tapers, _ = dpss_windows(n_time_samples_per_window, time_halfbandwidth_product, n_tapers,
+                             is_low_bias=is_low_bias)
+    return tapers.T * np.sqrt(sampling_frequency)
+
+
+def _n_windows(n_time, window, step):
+    """reference transforms.py:1363-1365 (floating-point floor)."""
+    return int(np.floor((n_time / step) - (window / step) + 1))
+
+
+_SHAPE_HELP_1D = (
+    "For a single time series, use:\n"
+    "  >>> from spectral_connectivity_amd.transforms import prepare_time_series\n"
+    "  >>> time_series_3d = prepare_time_series(time_series)\n"
+    "Or manually:\n"
+    "  >>> time_series_3d = time_series[:, np.newaxis, np.newaxis]")
+_SHAPE_HELP_2D = (
+    "For 2D data, you must clarify the meaning of the second dimension.\n"
+    "Use prepare_time_series() helper (axis='signals' or axis='trials'),\n"
+    "or add the missing axis manually with np.newaxis.")
+
+
+class Multitaper:
+    """Multitaper spectral transform on an MI355X (drop-in for the reference class).
+
+    Parameters are those of reference transforms.py:574-589.  ``time_series`` has shape
+    (n_time_samples, n_trials, n_signals).
+    """
+
+    def __init__(self, time_series, sampling_frequency=1000, time_halfbandwidth_product=3,
+                 detrend_type="constant", time_window_duration=None, time_window_step=None,
+                 n_tapers=None, tapers=None, start_time=0, n_fft_samples=None,
+                 n_time_samples_per_window=None, n_time_samples_per_step=None, is_low_bias=True):
+        self.time_series = np.asarray(time_series)
+        nd = self.time_series.ndim
+        if nd != 3:
+            msg = (f"Expected 3D array with shape (n_time_samples, n_trials, n_signals), "
+                   f"but got {nd}D array with shape {self.time_series.shape}.\n\n")
+            if nd == 1:
+                msg += _SHAPE_HELP_1D
+            elif nd == 2:
+                msg += _SHAPE_HELP_2D
+            else:
+                msg += (f"Arrays with {nd} dimensions are not supported.\n"
+                        "Expected shape: (n_time_samples, n_trials, n_signals)")
+            raise ValueError(msg)
+        if sampling_frequency <= 0:
+            raise ValueError(f"sampling_frequency must be positive, got {sampling_frequency}.\n"
+                             "The sampling frequency is the rate at which your data was collected.")
+        if time_halfbandwidth_product < 1:
+            raise ValueError(
+                f"time_halfbandwidth_product must be at least 1, got {time_halfbandwidth_product}.\n"
+                "It controls the spectral concentration and the number of tapers; typical values are 1-5.")
+        if time_halfbandwidth_product > 10:
+            warnings.warn(
+                f"time_halfbandwidth_product = {time_halfbandwidth_product} is unusually large.\n"
+                "Values above 10 apply very heavy spectral smoothing and are rarely used.",
+                UserWarning, stacklevel=2)
+        if time_window_duration is not None and time_window_duration <= 0:
+            raise ValueError(f"time_window_duration must be positive, got {time_window_duration}.\n"
+                             "Use None (default) to analyze the entire time series without windowing.")
+        if time_window_step is not None and time_window_step <= 0:
+            raise ValueError(f"time_window_step must be positive, got {time_window_step}.\n"
+                             "Use None (default) to match time_window_duration (no overlap).")
+        if (time_window_step is not None and time_window_duration is not None
+                and time_window_step > time_window_duration):
+            warnings.warn(
+                f"time_window_step ({time_window_step}s) is larger than time_window_duration "
+                f"({time_window_duration}s).\nThis creates gaps between analysis windows - some data "
+                "will not be analyzed.", UserWarning, stacklevel=2)
+        n_time, _, n_signals = self.time_series.shape
+        if n_time < n_signals:
+            warnings.warn(
+                f"Your time series has only {n_time} time points but {n_signals} signals. "
+                "This seems unusual and your data may be transposed.\n"
+                "Expected shape: (n_time_samples, n_trials, n_signals)", UserWarning, stacklevel=2)
+        if not np.all(np.isfinite(self.time_series)):
+            warnings.warn(
+                "Input time_series contains NaN or infinite values.\n"
+                "This will produce invalid spectral estimates.", UserWarning, stacklevel=2)
+
+        self.sampling_frequency = sampling_frequency
+        self.time_halfbandwidth_product = time_halfbandwidth_product
+        self.detrend_type = detrend_type
+        self._time_window_duration = time_window_duration
+        self._time_window_step = time_window_step
+        self.is_low_bias = is_low_bias
+        self.start_time = np.asarray(start_time)
+        self._n_fft_samples = n_fft_samples
+        self._tapers = tapers
+        self._n_tapers = n_tapers
+        self._n_time_samples_per_window = n_time_samples_per_window
+        self._n_samples_per_time_step = n_time_samples_per_step
+        self._device_spectra = None
+
+    def __repr__(self):
+        return ("Multitaper("
+                f"sampling_frequency={self.sampling_frequency!r}, "
+                f"time_halfbandwidth_product={self.time_halfbandwidth_product!r},\n"
+                f"           time_window_duration={self.time_window_duration!r}, "
+                f"time_window_step={self.time_window_step!r},\n"
+                f"           detrend_type={self.detrend_type!r}, "
+                f"start_time={self.start_time}, n_tapers={self.n_tapers})")
+
+    # ---- derived parameters (reference transforms.py:925-1145) ---------------------------
+    @property
+    def tapers(self):
+        """(n_time_samples_per_window, n_tapers) tapers, scaled by sqrt(fs)."""
+        if self._tapers is None:
+            self._tapers = _make_tapers(self.n_time_samples_per_window, self.sampling_frequency,
+                                        self.time_halfbandwidth_product, self.n_tapers,
+                                        is_low_bias=self.is_low_bias)
+        return self._tapers
+
+    @property
+    def time_window_duration(self):
+        if self._time_window_duration is None:
+            self._time_window_duration = self.n_time_samples_per_window / self.sampling_frequency
+        return self._time_window_duration
+
+    @property
+    def time_window_step(self):
+        if self._time_window_step is None:
+            self._time_window_step = self.n_time_samples_per_step / self.sampling_frequency
+        return self._time_window_step
+
+    @property
+    def n_tapers(self):
+        if self._n_tapers is None:
+            return int(np.floor(TAPER_MULTIPLIER * self.time_halfbandwidth_product - 1))
+        return self._n_tapers
+
+    @property
+    def n_time_samples_per_window(self):
+        if self._n_time_samples_per_window is None and self._time_window_duration is None:
+            self._n_time_samples_per_window = self.time_series.shape[0]
+        elif self._time_window_duration is not None:
+            self._n_time_samples_per_window = int(
+                np.around(self.time_window_duration * self.sampling_frequency))
+        return self._n_time_samples_per_window
+
+    @property
+    def n_fft_samples(self):
+        if self._n_fft_samples is None:
+            self._n_fft_samples = next_fast_len(self.n_time_samples_per_window)
+        return self._n_fft_samples
+
+    @property
+    def frequencies(self):
+        """Two-sided FFT bin frequencies (reference transforms.py:1038-1048)."""
+        return fftfreq(self.n_fft_samples, 1.0 / self.sampling_frequency)
+
+    @property
+    def n_time_samples_per_step(self):
+        if self._n_samples_per_time_step is None and self._time_window_step is None:
+            self._n_samples_per_time_step = self.n_time_samples_per_window
+        elif self._time_window_step is not None:
+            # truncation, not rounding: reference transforms.py:1068-1070
+            self._n_samples_per_time_step = int(self.time_window_step * self.sampling_frequency)
+        return self._n_samples_per_time_step
+
+    @property
+    def n_time_windows(self):
+        return _n_windows(self.time_series.shape[0], self.n_time_samples_per_window,
+                          self.n_time_samples_per_step)
+
+    @property
+    def time(self):
+        """Start time of every window (reference transforms.py:1075-1091)."""
+        starts = np.arange(self.n_time_windows) * self.n_time_samples_per_step
+        return self.start_time + starts / self.sampling_frequency
+
+    @property
+    def n_signals(self):
+        return self.time_series.shape[-1]
+
+    @property
+    def n_trials(self):
+        return self.time_series.shape[1]
+
+    @property
+    def frequency_resolution(self):
+        return TAPER_MULTIPLIER * self.time_halfbandwidth_product / self.time_window_duration
+
+    @property
+    def nyquist_frequency(self):
+        return self.sampling_frequency / 2
+
+    # ---- device path ---------------------------------------------------------------------
+    def device_spectra(self, device=None):
+        """Run stage A on the GPU; returns (and caches) the HBM-resident one-sided spectra."""
+        if self._device_spectra is None:
+            import torch
+            from . import _lib, engine
+            _lib.require_gpu()
+            if self.detrend_type not in _lib.DETREND:
+                raise ValueError(f"Invalid trend type '{self.detrend_type}' is not supported.\n"
+                                 "Valid options are 'linear'/'l', 'constant'/'c' or None.")
+            dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+            x = torch.from_numpy(np.ascontiguousarray(self.time_series, dtype=np.float32)).to(dev)
+            tapers = np.asarray(self.tapers, dtype=np.float64)             # (L, K), * sqrt(fs)
+            h = np.ascontiguousarray(tapers.T / self.sampling_frequency, dtype=np.float32)
+            h = torch.from_numpy(h).to(dev)
+            logger.info(self)
+            self._device_spectra = engine.multitaper_spectra(
+                x, h, self.n_time_samples_per_window, self.n_time_samples_per_step,
+                self.n_fft_samples, self.n_time_windows, self.detrend_type)
+        return self._device_spectra
+
+    def fft(self):
+        """Fourier coefficients (n_time_windows, n_trials, n_tapers, n_fft_samples, n_signals).
+
+        Drop-in for reference transforms.py:1147-1171: complex128, two-sided.  Computed on
+        the device as a one-sided real transform; the negative-frequency half is the
+        conjugate mirror (real input) and is filled on the host only for this export.
+        """
+        sp = self.device_spectra()
+        one = sp.X.cpu().numpy().astype(np.complex128)          # (F, W, R, K, C)
+        one = np.moveaxis(one, 0, 3)                            # (W, R, K, F, C)
+        N = self.n_fft_samples
+        out = np.empty(one.shape[:3] + (N, one.shape[-1]), dtype=np.complex128)
+        F = one.shape[3]
+        out[..., :F, :] = one
+        if N > F:
+            out[..., F:, :] = np.conj(one[..., N - F:0:-1, :])
+        return out

@@ -1,0 +1,165 @@
+"""Parity of the HIP path (through the C ABI) against golden vectors from the real reference
+and against the CPU oracle on seeded inputs.  Tolerance: the device pipeline computes in
+fp32 / complex64 (fp64 only for trend sums and the measures epilogue); north-star bar is
+1e-5 relative.  `close32` checks |a-b| <= rtol*|b| + atol_scale*max|b| -- i.e. 1e-5 relative
+elementwise, with entries that are cancellation-small compared to the array's scale allowed
+an absolute error of 1e-5 of that scale (they are sums of O(scale) terms in fp32)."""
+import numpy as np
+import pytest
+
+from oracle import spectral_oracle as so
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+ATOL_SCALE = 1e-5
+
+
+def close32(a, b, rtol=RTOL, atol_scale=ATOL_SCALE, what=""):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, f"{what}: shape {a.shape} != {b.shape}"
+    nan_a, nan_b = np.isnan(a), np.isnan(b)
+    assert np.array_equal(nan_a, nan_b), f"{what}: NaN pattern differs ({nan_a.sum()} vs {nan_b.sum()})"
+    ok = ~nan_b
+    if not ok.any():
+        return
+    scale = np.abs(b[ok]).max()
+    err = np.abs(a[ok] - b[ok])
+    bound = rtol * np.abs(b[ok]) + atol_scale * scale
+    worst = (err / np.maximum(bound, 1e-300)).max()
+    assert worst <= 1.0, (f"{what}: max err {err.max():.3e} (scale {scale:.3e}), "
+                          f"worst err/bound {worst:.2f}")
+
+
+@pytest.fixture(scope="module")
+def sc():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a ROCm device"
+    import spectral_connectivity_amd as pkg
+    from spectral_connectivity_amd import _lib
+    _lib.load()
+    return pkg
+
+
+MEASURE_NAMES = list(so.MEASURES)
+
+
+def test_f1_cfg1(sc, golden):
+    g = golden("f1_cfg1")
+    m = sc.Multitaper(g["x"], sampling_frequency=float(g["fs"]), time_halfbandwidth_product=float(g["NW"]))
+    close32(m.fft(), g["fft"], what="fft")
+    c = sc.Connectivity.from_multitaper(m)
+    close32(c.power(), g["power"], what="power")
+    close32(c.coherency(), g["coherency"], what="coherency")
+    close32(c.coherence_magnitude(), g["coherence_magnitude"], what="coherence")
+    np.testing.assert_allclose(c.frequencies, g["conn_frequencies"])
+
+
+@pytest.mark.parametrize("det", ["constant", "linear", None])
+def test_f2_detrend(sc, golden, det):
+    g = golden("f2_detrend")
+    m = sc.Multitaper(g["x"], sampling_frequency=float(g["fs"]), time_halfbandwidth_product=float(g["NW"]),
+                      detrend_type=det)
+    close32(m.fft(), g[f"fft_{det}"], what=f"fft detrend={det}")
+
+
+@pytest.mark.parametrize("et", list(so.EXPECTATION_AXES))
+def test_f3_every_measure_every_expectation(sc, golden, et):
+    g = golden("f3_windows_all_measures")
+    m = sc.Multitaper(g["x"], sampling_frequency=float(g["fs"]), time_halfbandwidth_product=float(g["NW"]),
+                      n_time_samples_per_window=int(g["L"]), n_time_samples_per_step=int(g["step"]))
+    c = sc.Connectivity.from_multitaper(m, expectation_type=et)
+    for name in MEASURE_NAMES:
+        ref = g[f"{et}__{name}"]
+        got = getattr(c, name)()
+        if name in ("phase_lag_index", "debiased_squared_phase_lag_index"):
+            # sign(Im s) is discontinuous: an fp32 coefficient within rounding of Im s = 0 flips
+            # one observation.  Require exactness up to a handful of flips.
+            n = c.n_observations
+            bad = np.abs(got - ref) > 1e-6 + 1e-5 * np.abs(ref)
+            assert bad.mean() < 2e-3, f"{et}/{name}: {bad.sum()} of {bad.size} entries differ"
+            assert np.nanmax(np.abs(got - ref)) <= 4.0 / n + 1e-6 if name == "phase_lag_index" else True
+            continue
+        if name == "coherence_phase":
+            d = np.angle(np.exp(1j * (got - ref)))
+            ok = ~np.isnan(ref)
+            mag = g[f"{et}__coherence_magnitude"]
+            # phase is ill-conditioned where coherence ~ 0: weight the error by |coherency|
+            assert np.nanmax(np.abs(d[ok]) * np.sqrt(mag[ok])) < 2e-5, f"{et}/phase"
+            continue
+        close32(got, ref, what=f"{et}/{name}")
+
+
+@pytest.mark.parametrize("tag,kw", [
+    ("L250", dict(n_time_samples_per_window=250)),
+    ("L250_N300", dict(n_time_samples_per_window=250, n_fft_samples=300)),
+    ("L255", dict(n_time_samples_per_window=255)),
+    ("L256_N255", dict(n_time_samples_per_window=256, n_fft_samples=255)),
+    ("dur_step", dict(time_window_duration=0.8, time_window_step=0.29)),
+])
+def test_f4_lengths(sc, golden, tag, kw):
+    g = golden("f4_lengths")
+    m = sc.Multitaper(g["x"], sampling_frequency=float(g["fs"]), time_halfbandwidth_product=float(g["NW"]), **kw)
+    close32(m.fft(), g[f"{tag}__fft"], what=f"{tag} fft")
+    c = sc.Connectivity.from_multitaper(m)
+    close32(c.coherence_magnitude(), g[f"{tag}__coherence_magnitude"], what=f"{tag} coherence")
+    close32(c.power(), g[f"{tag}__power"], what=f"{tag} power")
+    np.testing.assert_allclose(c.frequencies, g[f"{tag}__conn_frequencies"])
+
+
+def test_f7_edges(sc, golden):
+    g = golden("f7_edges")
+    m = sc.Multitaper(g["zero__x"], sampling_frequency=100.0, time_halfbandwidth_product=2)
+    c = sc.Connectivity.from_multitaper(m)
+    for name in ("coherence_magnitude", "imaginary_coherence", "weighted_phase_lag_index"):
+        close32(getattr(c, name)(), g[f"zero__{name}"], what=f"zero-power {name}")
+    m = sc.Multitaper(g["nw175__x"], sampling_frequency=100.0, tapers=g["user__tapers"])
+    close32(m.fft(), g["user__fft"], what="user tapers fft")
+    # raw 5-D coefficients uploaded straight into Connectivity (reference tests build these)
+    c = sc.Connectivity(g["raw__coef"], dtype=np.complex64)
+    close32(c._expectation_cross_spectral_matrix(), g["raw__csm"][:, :9], what="raw csm")
+    close32(c.coherence_magnitude(), g["raw__coherence_magnitude"], what="raw coherence")
+
+
+def test_known_answers_from_reference_unit_tests(sc):
+    # reference tests/test_connectivity.py:25-56, :82-99, :137-161, :200-264
+    coef = np.zeros((1, 1, 1, 1, 2), dtype=complex)
+    coef[..., 0] = 2 * np.exp(1j * np.pi / 2)
+    coef[..., 1] = 3 * np.exp(-1j * np.pi / 2)
+    c = sc.Connectivity(coef)
+    close32(c._expectation_cross_spectral_matrix()[0, 0], np.array([[4, -6], [-6, 9]], complex), what="csm KAT")
+    close32(c.power()[0, 0], np.array([4.0, 9.0]), what="power KAT")
+    coh = c.coherency()[0, 0]
+    assert np.isnan(coh[0, 0]) and np.isnan(coh[1, 1])
+    assert abs(abs(coh[0, 1]) - 1) < 1e-6 and abs(abs(np.angle(coh[0, 1])) - np.pi) < 1e-6
+    coef[..., 1] = 3.0
+    c = sc.Connectivity(coef)
+    np.testing.assert_allclose(c.phase_lag_index()[0, 0], [[0, 1], [-1, 0]], atol=1e-7)
+    np.testing.assert_allclose(c.weighted_phase_lag_index()[0, 0], [[0, 1], [-1, 0]], atol=1e-6)
+    np.testing.assert_allclose(c.phase_locking_value()[0, 0, 0, 1], 1.0, atol=1e-6)
+
+
+@pytest.mark.parametrize("C,R,et", [(32, 20, "trials_tapers"), (128, 6, "trials_tapers"),
+                                    (40, 5, "trials"), (19, 7, "time_trials_tapers"), (160, 3, "trials_tapers")])
+def test_seeded_vs_oracle_multi_tile(sc, C, R, et):
+    """Channel counts that exercise 1..10 channel blocks, odd sizes and the tile mirroring."""
+    rng = np.random.default_rng(100 + C)
+    T = 384
+    x = rng.standard_normal((T, R, C))
+    t = np.arange(T) / 500.0
+    x += 0.6 * np.sin(2 * np.pi * 45 * t)[:, None, None] * rng.standard_normal(C)[None, None, :]
+    x += 0.6 * np.cos(2 * np.pi * 45 * t)[:, None, None] * rng.standard_normal(C)[None, None, :]
+    kw = dict(n_time_samples_per_window=128, n_time_samples_per_step=64)
+    m = sc.Multitaper(x, sampling_frequency=500.0, time_halfbandwidth_product=2, **kw)
+    c = sc.Connectivity.from_multitaper(m, expectation_type=et)
+    coef, _ = so.multitaper_fft(x, fs=500.0, NW=2, **kw)
+    csm = so.expectation_csm_gemm(coef, et)
+    close32(c.coherence_magnitude(), so.coherence_magnitude(coef, et, csm=csm), what="coherence")
+    close32(c.imaginary_coherence(), so.imaginary_coherence(coef, et, csm=csm), what="imag coh")
+    close32(c.power(), so.power(coef, et), what="power")
+    if C <= 40:
+        close32(c.weighted_phase_lag_index(), so.weighted_phase_lag_index(coef, et), what="wpli")
+        close32(c.phase_locking_value(), so.phase_locking_value(coef, et), what="plv")
+        close32(c.debiased_squared_weighted_phase_lag_index(),
+                so.debiased_squared_weighted_phase_lag_index(coef, et), rtol=1e-4, atol_scale=1e-4,
+                what="dwpli2")
