@@ -116,12 +116,15 @@ static int launch_csm(const CsmArgs& a, bool vec, hipStream_t stream) {
     const int bins8 = (a.n_bins + 7) / 8;
     const unsigned grid = (unsigned)(bins8 * 8 * args.n_tile_groups);
     const size_t shmem = (size_t)2 * OC * a.st.RS * sizeof(float);
-    if (vec)
-        hipLaunchKernelGGL((csm_mfma_kernel<MAX_SLOTS, OC, CPMAX, true>), dim3(grid), dim3(256), shmem,
-                           stream, args);
-    else
-        hipLaunchKernelGGL((csm_mfma_kernel<MAX_SLOTS, OC, CPMAX, false>), dim3(grid), dim3(256), shmem,
-                           stream, args);
+    if (vec) {
+        auto k = csm_mfma_kernel<MAX_SLOTS, OC, CPMAX, true>;
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(256), shmem, stream, args);
+    } else {
+        auto k = csm_mfma_kernel<MAX_SLOTS, OC, CPMAX, false>;
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(256), shmem, stream, args);
+    }
     SC_CHECK_HIP(hipGetLastError());
     return SC_OK;
 }
