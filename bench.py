@@ -185,6 +185,7 @@ def main():
     n_obs_loc = R_loc * K
     # algorithmic work per launch on this rank (DESIGN.md "Roofline")
     stage_model = {
+        "mtfft_fused": ("hbm", 4.0 * T * R_loc * C + 8.0 * F * W * R_loc * K * C),
         "taper_windows": ("hbm", 4.0 * T * R_loc * C + 4.0 * N * W * R_loc * K * C),
         "rocfft_r2c": ("hbm", 4.0 * N * W * R_loc * K * C + 8.0 * F * W * R_loc * K * C),
         "csm_mfma": ("mfma", 8.0 * n_obs_loc * (C * (C + 1) / 2) * W * F),

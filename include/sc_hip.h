@@ -127,6 +127,22 @@ int sc_fft_plan_work_bytes(const sc_fft_plan* plan, size_t* bytes);
 int sc_fft_execute(sc_fft_plan* plan, const float* d_y, void* d_X /*float2*/, void* stream);
 int sc_fft_plan_destroy(sc_fft_plan* plan);
 
+/* ---- stage A, fused fast path (custom HIP, power-of-two N) ---------------------------
+ * Window extraction + detrend + taper multiply + real FFT + transposed store in ONE kernel:
+ * replaces _sliding_window, detrend, _multitaper_fft and the swapaxes of Multitaper.fft
+ * (transforms.py:1147-1171, :1311-1405) with a single read of x and a single write of
+ *   X[f][w][r][k][c],  f = 0..N/2   (one-sided; the negative bins of a real input are
+ *                                    conjugate mirrors and are never materialised).
+ * Supported when sc_multitaper_fft_supported(L, N) != 0 (power-of-two 64 <= N <= 4096,
+ * L <= N); otherwise use sc_taper_windows_f32 + sc_fft_execute (rocFFT, any length).
+ * d_twiddles: float2[N] device table filled once by sc_fft_twiddles_f32(N, ...). */
+int sc_multitaper_fft_supported(int64_t L, int64_t N);
+int sc_fft_twiddles_f32(int64_t N, void* d_twiddles /*float2[N]*/, void* stream);
+int sc_multitaper_fft_f32(const float* d_x, int64_t T, int64_t R, int64_t C,
+                          int64_t L, int64_t step, int64_t W, int64_t N,
+                          const float* d_tapers, int64_t K, int detrend_type,
+                          const void* d_twiddles, void* d_X /*float2*/, void* stream);
+
 /* ---- stage B: accumulators -----------------------------------------------------------
  * Number of floats of one bin record for `planes`, and total bins (groups * F). */
 int sc_accum_layout(const sc_spectra_desc* desc, uint32_t planes,
@@ -137,9 +153,8 @@ int sc_accum_layout(const sc_spectra_desc* desc, uint32_t planes,
  * matrix cores (v_mfma_f32_16x16x4_f32), upper-triangular 16x16 tiles only.
  * Replaces _complex_inner_product + mean of connectivity.py:447-492, :1799-1822 without
  * materialising the per-observation (W,R,K,N,C,C) temporary.  Writes the two CSM planes
- * of every bin record in d_accum (other planes untouched).  `obs_begin/obs_end` restrict
- * the observation range (for sharding trials over GPUs pass the local shard and the full
- * range: the sums are un-normalised). */
+ * of every bin record in d_accum (other planes untouched).  Sums are UN-normalised: a rank
+ * that holds a shard of the trials accumulates its shard and the records are added. */
 int sc_csm_accumulate_f32(const void* d_X /*float2*/, const sc_spectra_desc* desc,
                           uint32_t planes, float* d_accum, void* stream);
 

@@ -75,15 +75,16 @@ __global__ void __launch_bounds__(256) csm_mfma_kernel(CsmArgs p) {
         for (int kk = 0; kk < OC / 4; ++kk) {
             const float* rowp = cur + (kk * 4 + frag_row) * st.RS + 2 * frag_col;
 #pragma unroll
+            // invalid slots (last tile group only) recompute tile (0,0) and are never stored:
+            // keeping the body branch-free lets the compiler run the ds_reads of slot s+1
+            // under the MFMAs of slot s.
             for (int s = 0; s < MAX_SLOTS; ++s) {
-                if (valid[s]) {
-                    const float2 a = *reinterpret_cast<const float2*>(rowp + 32 * bi[s]);
-                    const float2 b = *reinterpret_cast<const float2*>(rowp + 32 * bj[s]);
-                    re[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, re[s], 0, 0, 0);
-                    im[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.x, im[s], 0, 0, 0);
-                    re[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, re[s], 0, 0, 0);
-                    im[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(-a.x, b.y, im[s], 0, 0, 0);
-                }
+                const float2 a = *reinterpret_cast<const float2*>(rowp + 32 * bi[s]);
+                const float2 b = *reinterpret_cast<const float2*>(rowp + 32 * bj[s]);
+                re[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, re[s], 0, 0, 0);
+                im[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.x, im[s], 0, 0, 0);
+                re[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, re[s], 0, 0, 0);
+                im[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(-a.x, b.y, im[s], 0, 0, 0);
             }
         }
         if (more) sc_stage_store<OC, CPMAX, VEC>(st, nxt, tid, regs);
@@ -157,6 +158,14 @@ extern "C" int sc_csm_accumulate_f32(const void* d_X, const sc_spectra_desc* des
     a.st.RS = sc_row_stride(a.st.CP);
     a.st.n_obs = ax.n_obs;
     const bool vec = sc_stage_vec_ok(d_X, ax);
-    if (a.st.CP <= 128) return launch_csm<9, 32, 128>(a, vec, (hipStream_t)stream);
-    return launch_csm<9, 16, 256>(a, vec, (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    // slots per wave: smallest instantiation that covers all tiles in one tile group
+    const int need = (a.n_tiles + 3) / 4;
+    if (a.st.CP <= 128) {
+        if (need <= 1) return launch_csm<1, 32, 128>(a, vec, st);
+        if (need <= 3) return launch_csm<3, 32, 128>(a, vec, st);
+        if (need <= 5) return launch_csm<5, 32, 128>(a, vec, st);
+        return launch_csm<9, 32, 128>(a, vec, st);
+    }
+    return launch_csm<9, 16, 256>(a, vec, st);
 }

@@ -1,0 +1,262 @@
+// sc_mtfft.hip -- fused multitaper transform for power-of-two FFT lengths:
+//   sliding-window extraction + detrend + DPSS taper multiply + real FFT + transposed store,
+// one kernel, the time series is read once and the one-sided spectra are written once,
+// straight into the layout stage B consumes (X[f][w][r][k][c], channels fastest).
+//
+// Why not rocFFT here: its batched real transform is fast only for unit-stride batches
+// ([batch][n] -> [batch][f]); the layouts the path needs (lanes <-> channels on both sides)
+// cost it 8-10x (measured on MI355X, profiles/r01_rocfft_layouts.txt) and add a 6.4 GB
+// tapered-window round trip through HBM.  rocFFT stays the transform for every other length.
+//
+// Workgroup = one (window w, trial r, tile of CT channels).  The L x CT window tile is loaded
+// once into LDS with coalesced rows (channels are the fastest axis of x), detrended in place
+// (fp64 trend sums), and then for every taper k the CT real sequences are packed two-by-two
+// (channels c, c+1) into CT/2 complex sequences ("two-for-one" real FFT), transformed by an
+// in-LDS Stockham autosort FFT (radix-4 passes + one radix-2 pass when log2 N is odd, fp32,
+// twiddles from an LDS table rounded from fp64), separated by conjugate symmetry
+//   A[f] = (Z[f] + conj Z[N-f]) / 2,   B[f] = (Z[f] - conj Z[N-f]) / (2i)
+// (DC and Nyquist come out exactly real, like the reference's real input), and stored as
+// float4 (A, B) so a wave writes contiguous CT*8-byte segments per frequency.
+#include "sc_common.h"
+
+struct MtArgs {
+    const float* x;
+    const float* tapers;   // [K][L], already divided by fs
+    const float2* tw;      // [N] exp(-2 pi i m / N)
+    float2* X;             // [F][W][R][K][C]
+    int T, R, C, L, step, W, K, detrend;
+};
+
+__device__ inline float2 cmul(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+template <int LOG2N, int CT>
+__global__ void __launch_bounds__(256) mtfft_kernel(MtArgs p) {
+    constexpr int N = 1 << LOG2N;
+    constexpr int NF = CT / 2;           // complex FFTs in flight (channel pairs)
+    constexpr int TPF = 256 / NF;        // threads per FFT
+    constexpr int BPT = (N / 4) / TPF;   // radix-4 butterflies per thread per pass
+    constexpr int ZS = N + 1;            // z row stride (float2): odd -> conflict-free columns
+    static_assert(BPT >= 1, "tile too wide for this N");
+    extern __shared__ __align__(16) unsigned char smem[];
+    float* xt = reinterpret_cast<float*>(smem);                       // [L][CT]  (N rows reserved)
+    float2* z = reinterpret_cast<float2*>(smem + (size_t)N * CT * 4); // [NF][ZS]
+    float2* tw = z + NF * ZS;                                         // [N]
+    double* red = reinterpret_cast<double*>(tw + N);                  // [2][256] then trend [2][CT]
+
+    const int tid = threadIdx.x;
+    const int c0 = blockIdx.x * CT, r = blockIdx.y, w = blockIdx.z;
+    const int L = p.L, C = p.C;
+    const int64_t RC = (int64_t)p.R * C;
+
+    for (int i = tid; i < N; i += 256) tw[i] = p.tw[i];
+    // 1. window tile, rows are contiguous in x (channel fastest)
+    const float* xw = p.x + ((int64_t)w * p.step * p.R + r) * C + c0;
+    for (int idx = tid; idx < L * CT; idx += 256) {
+        const int l = idx / CT, cc = idx - l * CT;
+        xt[idx] = (c0 + cc < C) ? xw[(int64_t)l * RC + cc] : 0.f;
+    }
+    __syncthreads();
+    // 2. detrend in place: per-column sums in fp64 over 256/CT row slices
+    if (p.detrend != SC_DETREND_NONE) {
+        constexpr int SL = 256 / CT;
+        const int cc = tid % CT, sl = tid / CT;
+        double s = 0.0, st = 0.0;
+        for (int l = sl; l < L; l += SL) {
+            const double v = (double)xt[l * CT + cc];
+            s += v;
+            st += v * (double)(l + 1);
+        }
+        red[tid] = s;
+        red[256 + tid] = st;
+        __syncthreads();
+        if (tid < CT) {
+            double sum = 0.0, sumt = 0.0;
+            for (int q = 0; q < SL; ++q) { sum += red[q * CT + tid]; sumt += red[256 + q * CT + tid]; }
+            sumt /= (double)L;
+            const double n = (double)L;
+            double a = 0.0, b;
+            if (p.detrend == SC_DETREND_CONSTANT) {
+                b = sum / n;
+            } else {  // least-squares line on abscissa (l+1)/L (reference transforms.py:1903-1909)
+                const double St = (n + 1.0) * 0.5, Stt = (n + 1.0) * (2.0 * n + 1.0) / (6.0 * n);
+                const double den = n * Stt - St * St;
+                a = (den != 0.0) ? (n * sumt - St * sum) / den : 0.0;
+                b = (sum - a * St) / n;
+            }
+            red[512 + tid] = a;
+            red[512 + CT + tid] = b;
+        }
+        __syncthreads();
+        const double invL = 1.0 / (double)L;
+        for (int idx = tid; idx < L * CT; idx += 256) {
+            const int l = idx / CT, cc2 = idx - l * CT;
+            const double t = (double)(l + 1) * invL;
+            xt[idx] = (float)((double)xt[idx] - (red[512 + cc2] * t + red[512 + CT + cc2]));
+        }
+        __syncthreads();
+    }
+
+    const int fft = tid / TPF, jt = tid - fft * TPF;
+    float2* zf = z + fft * ZS;
+    const int F = N / 2 + 1;
+    for (int k = 0; k < p.K; ++k) {
+        // 3a. z[pair][n] = (x[n][2p] h[n], x[n][2p+1] h[n]), zero padded to N
+        const float* hk = p.tapers + (int64_t)k * L;
+        for (int idx = tid; idx < N * NF; idx += 256) {
+            const int n = idx / NF, pr = idx - n * NF;
+            float2 v = make_float2(0.f, 0.f);
+            if (n < L) {
+                const float h = hk[n];
+                const float2 xv = *reinterpret_cast<const float2*>(xt + n * CT + 2 * pr);
+                v = make_float2(xv.x * h, xv.y * h);
+            }
+            z[pr * ZS + n] = v;
+        }
+        __syncthreads();
+        // 3b. Stockham autosort passes, in place through registers
+        int P = 1;
+#pragma unroll
+        for (int pass = 0; pass < LOG2N / 2; ++pass) {
+            float2 o[BPT][4];
+#pragma unroll
+            for (int b = 0; b < BPT; ++b) {
+                const int i = jt + b * TPF;
+                const int kk = i & (P - 1);
+                const int tstep = kk * (N / 4 / P);          // twiddle index step kk * N/(4P)
+                const float2 a0 = zf[i];
+                const float2 a1 = cmul(zf[i + N / 4], tw[tstep]);
+                const float2 a2 = cmul(zf[i + N / 2], tw[2 * tstep]);
+                const float2 a3 = cmul(zf[i + 3 * N / 4], tw[3 * tstep]);
+                const float2 b0 = make_float2(a0.x + a2.x, a0.y + a2.y);
+                const float2 b1 = make_float2(a0.x - a2.x, a0.y - a2.y);
+                const float2 b2 = make_float2(a1.x + a3.x, a1.y + a3.y);
+                const float2 b3 = make_float2(a1.y - a3.y, a3.x - a1.x);   // -i (a1 - a3)
+                o[b][0] = make_float2(b0.x + b2.x, b0.y + b2.y);
+                o[b][1] = make_float2(b1.x + b3.x, b1.y + b3.y);
+                o[b][2] = make_float2(b0.x - b2.x, b0.y - b2.y);
+                o[b][3] = make_float2(b1.x - b3.x, b1.y - b3.y);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int b = 0; b < BPT; ++b) {
+                const int i = jt + b * TPF;
+                const int kk = i & (P - 1);
+                const int j = ((i - kk) << 2) + kk;
+                zf[j] = o[b][0];
+                zf[j + P] = o[b][1];
+                zf[j + 2 * P] = o[b][2];
+                zf[j + 3 * P] = o[b][3];
+            }
+            __syncthreads();
+            P <<= 2;
+        }
+        if constexpr (LOG2N & 1) {
+            float2 o[2 * BPT][2];
+#pragma unroll
+            for (int b = 0; b < 2 * BPT; ++b) {
+                const int i = jt + b * TPF;
+                const int kk = i & (P - 1);
+                const float2 u0 = zf[i];
+                const float2 u1 = cmul(zf[i + N / 2], tw[kk * (N / 2 / P)]);
+                o[b][0] = make_float2(u0.x + u1.x, u0.y + u1.y);
+                o[b][1] = make_float2(u0.x - u1.x, u0.y - u1.y);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int b = 0; b < 2 * BPT; ++b) {
+                const int i = jt + b * TPF;
+                const int kk = i & (P - 1);
+                const int j = ((i - kk) << 1) + kk;
+                zf[j] = o[b][0];
+                zf[j + P] = o[b][1];
+            }
+            __syncthreads();
+        }
+        // 3c. split the packed pair, store X[f][w][r][k][c..c+1]
+        float2* Xk = p.X + (((int64_t)w * p.R + r) * p.K + k) * C + c0;
+        const int64_t sF = (int64_t)p.W * p.R * p.K * C;
+        const bool vec_ok = (C % 2) == 0;
+        for (int idx = tid; idx < F * NF; idx += 256) {
+            const int f = idx / NF, pr = idx - f * NF;
+            const int c = c0 + 2 * pr;
+            if (c >= C) continue;
+            const float2 z1 = z[pr * ZS + f];
+            const float2 z2 = z[pr * ZS + ((N - f) & (N - 1))];
+            const float2 A = make_float2(0.5f * (z1.x + z2.x), 0.5f * (z1.y - z2.y));
+            const float2 B = make_float2(0.5f * (z1.y + z2.y), 0.5f * (z2.x - z1.x));
+            float2* dst = Xk + (int64_t)f * sF + 2 * pr;
+            if (vec_ok) {
+                *reinterpret_cast<float4*>(dst) = make_float4(A.x, A.y, B.x, B.y);
+            } else {
+                dst[0] = A;
+                if (c + 1 < C) dst[1] = B;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void twiddle_kernel(float2* tw, int N) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= N) return;
+    double s, c;
+    sincospi(-2.0 * (double)m / (double)N, &s, &c);
+    tw[m] = make_float2((float)c, (float)s);
+}
+
+extern "C" int sc_fft_twiddles_f32(int64_t N, void* d_tw, void* stream) {
+    SC_REQUIRE(d_tw != nullptr && N >= 1, "bad twiddle request");
+    hipLaunchKernelGGL(twiddle_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (float2*)d_tw, (int)N);
+    SC_CHECK_HIP(hipGetLastError());
+    return SC_OK;
+}
+
+template <int LOG2N, int CT>
+static int launch_mt(const MtArgs& a, hipStream_t stream) {
+    constexpr int N = 1 << LOG2N;
+    constexpr size_t shmem = (size_t)N * CT * 4 + (size_t)(CT / 2) * (N + 1) * 8 + (size_t)N * 8 +
+                             (size_t)(512 + 2 * CT) * 8;
+    static_assert(shmem <= 160 * 1024, "LDS budget exceeded");
+    auto k = mtfft_kernel<LOG2N, CT>;
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    dim3 grid((unsigned)((a.C + CT - 1) / CT), (unsigned)a.R, (unsigned)a.W);
+    hipLaunchKernelGGL(k, grid, dim3(256), shmem, stream, a);
+    SC_CHECK_HIP(hipGetLastError());
+    return SC_OK;
+}
+
+extern "C" int sc_multitaper_fft_supported(int64_t L, int64_t N) {
+    if (N < 64 || N > 4096 || (N & (N - 1)) != 0) return 0;
+    return (L >= 1 && L <= N) ? 1 : 0;
+}
+
+extern "C" int sc_multitaper_fft_f32(const float* d_x, int64_t T, int64_t R, int64_t C, int64_t L,
+                                     int64_t step, int64_t W, int64_t N, const float* d_tapers, int64_t K,
+                                     int detrend_type, const void* d_twiddles, void* d_X, void* stream) {
+    SC_REQUIRE(d_x && d_tapers && d_twiddles && d_X, "NULL device pointer");
+    SC_REQUIRE(T >= 1 && R >= 1 && C >= 1 && L >= 1 && step >= 1 && W >= 1 && K >= 1, "dimensions must be positive");
+    SC_REQUIRE((W - 1) * step + L <= T, "windows exceed the time series");
+    SC_REQUIRE(detrend_type >= 0 && detrend_type <= 2, "unknown detrend_type");
+    SC_REQUIRE(R <= 65535 && W <= 65535, "too many trials/windows for one launch");
+    if (!sc_multitaper_fft_supported(L, N)) {
+        sc_set_error("fused multitaper FFT needs a power-of-two 64 <= N <= 4096 and L <= N (got L=%lld N=%lld); "
+                     "use sc_taper_windows_f32 + sc_fft_execute", (long long)L, (long long)N);
+        return SC_EUNSUPPORTED;
+    }
+    MtArgs a{d_x, d_tapers, (const float2*)d_twiddles, (float2*)d_X, (int)T, (int)R, (int)C, (int)L,
+             (int)step, (int)W, (int)K, detrend_type};
+    hipStream_t s = (hipStream_t)stream;
+    switch (N) {
+    case 64: return launch_mt<6, 64>(a, s);
+    case 128: return launch_mt<7, 64>(a, s);
+    case 256: return launch_mt<8, 32>(a, s);
+    case 512: return launch_mt<9, 16>(a, s);
+    case 1024: return launch_mt<10, 16>(a, s);
+    case 2048: return launch_mt<11, 8>(a, s);
+    case 4096: return launch_mt<12, 2>(a, s);
+    }
+    return SC_EUNSUPPORTED;
+}

@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(256) nonlinear_kernel(NlArgs p) {
             const float* rp = cur + row * st.RS;
 #pragma unroll
             for (int s = 0; s < MAXB; ++s) {
-                if (valid[s]) {
+                {   // invalid slots (last block set) recompute block (0,0) and are never stored
                     float2 xi[4], xj[4];
                     const float4* pi = reinterpret_cast<const float4*>(rp + (BI[s] * 32 + li * 4) * 2);
                     const float4* pj = reinterpret_cast<const float4*>(rp + (BJ[s] * 32 + lj * 4) * 2);

@@ -24,6 +24,7 @@ EXPECTATION_AXES = {
 }
 
 _plan_cache = {}
+_twiddle_cache = {}
 
 
 def _stream():
@@ -78,7 +79,20 @@ class DeviceSpectra:
                            reduce_taper=int(2 in axes), reserved=0)
 
 
-def multitaper_spectra(x, tapers_over_fs, n_window, n_step, n_fft, n_windows, detrend_type, mark=None):
+def twiddles(n_fft, device):
+    """exp(-2 pi i m / N) table for the fused FFT kernel (device, cached per (N, device))."""
+    key = (int(n_fft), str(device))
+    tw = _twiddle_cache.get(key)
+    if tw is None:
+        lib = _lib.load()
+        tw = torch.empty((n_fft,), dtype=torch.complex64, device=device)
+        _lib.check(lib.sc_fft_twiddles_f32(n_fft, _ptr(tw), _stream()), "sc_fft_twiddles_f32")
+        _twiddle_cache[key] = tw
+    return tw
+
+
+def multitaper_spectra(x, tapers_over_fs, n_window, n_step, n_fft, n_windows, detrend_type, mark=None,
+                       use_fused=None):
     """Stage A on device: (T,R,C) float32 tensor -> DeviceSpectra [F][W][R][K][C].
 
     ``tapers_over_fs``: (K, L) float32 device tensor = reference tapers^T / fs
@@ -88,6 +102,20 @@ def multitaper_spectra(x, tapers_over_fs, n_window, n_step, n_fft, n_windows, de
     T, R, C = x.shape
     K, L = tapers_over_fs.shape
     assert L == n_window
+    F = n_fft // 2 + 1
+    strides = (n_windows * R * K * C, R * K * C, K * C, C)
+    if use_fused is None:
+        use_fused = bool(lib.sc_multitaper_fft_supported(L, n_fft))
+    if use_fused:
+        # one kernel: window + detrend + taper + FFT + transposed store (sc_mtfft.hip)
+        X = torch.empty((F, n_windows, R, K, C), dtype=torch.complex64, device=x.device)
+        _lib.check(lib.sc_multitaper_fft_f32(_ptr(x), T, R, C, L, n_step, n_windows, n_fft,
+                                             _ptr(tapers_over_fs), K, _lib.DETREND[detrend_type],
+                                             _ptr(twiddles(n_fft, x.device)), _ptr(X), _stream()),
+                   "sc_multitaper_fft_f32")
+        if mark:
+            mark("mtfft_fused")
+        return DeviceSpectra(X, (F, n_windows, R, K, C), strides, n_fft, real_input=True)
     batch = n_windows * R * K * C
     y = torch.empty((n_fft, batch), dtype=torch.float32, device=x.device)
     _lib.check(lib.sc_taper_windows_f32(_ptr(x), T, R, C, L, n_step, n_windows, n_fft,
@@ -95,17 +123,12 @@ def multitaper_spectra(x, tapers_over_fs, n_window, n_step, n_fft, n_windows, de
                                         _ptr(y), _stream()), "sc_taper_windows_f32")
     if mark:
         mark("taper_windows")
-    F = n_fft // 2 + 1
     X = torch.empty((F, n_windows, R, K, C), dtype=torch.complex64, device=x.device)
     _lib.check(lib.sc_fft_execute(fft_plan(n_fft, batch), _ptr(y), _ptr(X), _stream()), "sc_fft_execute")
     if mark:
         mark("rocfft_r2c")
     del y
-    sK = C
-    sR = K * C
-    sW = R * K * C
-    sF = n_windows * R * K * C
-    return DeviceSpectra(X, (F, n_windows, R, K, C), (sF, sW, sR, sK), n_fft, real_input=True)
+    return DeviceSpectra(X, (F, n_windows, R, K, C), strides, n_fft, real_input=True)
 
 
 def upload_coefficients(coef, device="cuda"):

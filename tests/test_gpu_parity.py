@@ -163,3 +163,26 @@ def test_seeded_vs_oracle_multi_tile(sc, C, R, et):
         close32(c.debiased_squared_weighted_phase_lag_index(),
                 so.debiased_squared_weighted_phase_lag_index(coef, et), rtol=1e-4, atol_scale=1e-4,
                 what="dwpli2")
+
+
+@pytest.mark.parametrize("N,L,C,det", [(64, 64, 5, "constant"), (128, 100, 70, "linear"), (256, 256, 33, None),
+                                       (512, 300, 16, "constant"), (1024, 1024, 18, "linear"),
+                                       (2048, 2048, 6, "constant"), (4096, 4000, 3, "constant")])
+def test_fused_fft_matches_oracle_and_rocfft(sc, N, L, C, det):
+    """Fused HIP transform (power-of-two N, zero padding, odd channel counts, every detrend)
+    against the float64 oracle, and the rocFFT fallback path against the same oracle."""
+    import torch
+    from spectral_connectivity_amd import engine
+    rng = np.random.default_rng(N + C)
+    R, step = 3, max(L // 2, 1)
+    T = L + 2 * step
+    x = rng.standard_normal((T, R, C)) + 5.0 + np.linspace(0, 2, T)[:, None, None]
+    kw = dict(n_time_samples_per_window=L, n_time_samples_per_step=step, n_fft_samples=N)
+    coef, info = so.multitaper_fft(x, fs=200.0, NW=2.5, detrend_type=det, **kw)
+    m = sc.Multitaper(x, sampling_frequency=200.0, time_halfbandwidth_product=2.5, detrend_type=det, **kw)
+    close32(m.fft(), coef, what=f"fused N={N}")
+    xd = torch.from_numpy(x.astype(np.float32)).cuda()
+    h = torch.from_numpy(np.ascontiguousarray(m.tapers.T / 200.0, dtype=np.float32)).cuda()
+    sp = engine.multitaper_spectra(xd, h, L, step, N, m.n_time_windows, det, use_fused=False)
+    got = np.moveaxis(sp.X.cpu().numpy(), 0, 3)
+    close32(got, coef[..., : N // 2 + 1, :], what=f"rocfft N={N}")
