@@ -188,6 +188,7 @@ def main():
         "mtfft_fused": ("hbm", 4.0 * T * R_loc * C + 8.0 * F * W * R_loc * K * C),
         "taper_windows": ("hbm", 4.0 * T * R_loc * C + 4.0 * N * W * R_loc * K * C),
         "rocfft_r2c": ("hbm", 4.0 * N * W * R_loc * K * C + 8.0 * F * W * R_loc * K * C),
+        "fused_csm_absim": ("mfma", 8.0 * n_obs_loc * (C * (C + 1) / 2) * W * F),
         "csm_mfma": ("mfma", 8.0 * n_obs_loc * (C * (C + 1) / 2) * W * F),
         "nonlinear_valu": ("hbm", 8.0 * F * W * R_loc * K * C + 4.0 * W * F * C * (C + 1) / 2),
         "measure_epilogue": ("hbm", (3 * 4.0 * C * (C + 1) / 2 + 2 * 4.0 * C * C) * W * F / world),

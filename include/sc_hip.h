@@ -165,6 +165,14 @@ int sc_csm_accumulate_f32(const void* d_X /*float2*/, const sc_spectra_desc* des
 int sc_nonlinear_accumulate_f32(const void* d_X /*float2*/, const sc_spectra_desc* desc,
                                 uint32_t planes, uint32_t which, float* d_accum, void* stream);
 
+/* Fused stage B for the headline pair coherence + wPLI: ONE pass over the spectra computes
+ * the CSM planes on the matrix cores and the ABS_IM plane on the VALU concurrently (8-wave
+ * workgroups, one MFMA wave + one VALU wave per SIMD, shared LDS staging).  Same results as
+ * sc_csm_accumulate_f32 + sc_nonlinear_accumulate_f32(SC_PLANE_ABS_IM); n_signals <= 128. */
+int sc_fused_supported(int64_t n_signals);
+int sc_fused_csm_absim_f32(const void* d_X /*float2*/, const sc_spectra_desc* desc,
+                           uint32_t planes, float* d_accum, void* stream);
+
 /* ---- stage C: measures epilogue ------------------------------------------------------
  * Elementwise measure algebra on accumulated sums (connectivity.py:612-1159): divides by
  * n_observations AFTER any cross-GPU reduction, applies the reference's eps clamps, NaN /

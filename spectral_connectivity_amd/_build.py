@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsc_hip.so")
-SOURCES = ["sc_api.hip", "sc_taper.hip", "sc_mtfft.hip", "sc_csm.hip", "sc_nonlinear.hip", "sc_measure.hip",
+SOURCES = ["sc_api.hip", "sc_taper.hip", "sc_mtfft.hip", "sc_csm.hip", "sc_nonlinear.hip", "sc_fused.hip", "sc_measure.hip",
            "sc_wilson.hip", "sc_canonical.hip"]
 HEADERS = ["sc_common.h", "sc_stage.h", os.path.join("..", "..", "include", "sc_hip.h")]
 
@@ -41,7 +41,7 @@ def build(force=False, verbose=True):
     if not force and not is_stale():
         return LIB
     cmd = [_hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
-           "-Wno-unused-result", *sources(), "-lrocfft", "-o", LIB + ".tmp"]
+           "-Wno-unused-result", "-fno-slp-vectorize", *sources(), "-lrocfft", "-o", LIB + ".tmp"]
     if verbose:
         print("[spectral_connectivity_amd] " + " ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)

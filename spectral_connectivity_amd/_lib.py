@@ -59,6 +59,8 @@ SYMBOLS = {
     "sc_accum_layout": (c_int, [POINTER(SpectraDesc), c_uint32, c_int64_p, c_int64_p, c_int64_p, c_int64_p]),
     "sc_csm_accumulate_f32": (c_int, [c_void_p, POINTER(SpectraDesc), c_uint32, c_void_p, c_void_p]),
     "sc_nonlinear_accumulate_f32": (c_int, [c_void_p, POINTER(SpectraDesc), c_uint32, c_uint32, c_void_p, c_void_p]),
+    "sc_fused_supported": (c_int, [c_int64]),
+    "sc_fused_csm_absim_f32": (c_int, [c_void_p, POINTER(SpectraDesc), c_uint32, c_void_p, c_void_p]),
     "sc_measure_f32": (c_int, [c_void_p, c_int64, c_int64, c_uint32, c_int64, c_int, c_void_p, c_void_p]),
 }
 

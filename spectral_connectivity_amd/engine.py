@@ -148,12 +148,28 @@ def accum_layout(spectra, expectation_type, planes, n_freq=None):
     return n_bins.value, fpb.value, n_groups.value, n_obs.value
 
 
-def accumulate(spectra, expectation_type, planes, n_freq=None, mark=None):
+def accumulate(spectra, expectation_type, planes, n_freq=None, mark=None, use_fused=None):
     """Stage B: un-normalised accumulator record tensor [n_bins, floats_per_bin] (float32)."""
     lib = _lib.load()
     d = spectra.desc(expectation_type, n_freq)
     n_bins, fpb, _, n_obs = accum_layout(spectra, expectation_type, planes, n_freq)
     accum = torch.empty((n_bins, fpb), dtype=torch.float32, device=spectra.X.device)
+    both = _lib.PLANE_CSM | _lib.PLANE_ABS_IM
+    if use_fused is None:
+        use_fused = bool(lib.sc_fused_supported(spectra.C))
+    if use_fused and (planes & both) == both:
+        # one pass: CSM on the matrix cores + |Im s| on the VALU (sc_fused.hip)
+        _lib.check(lib.sc_fused_csm_absim_f32(_ptr(spectra.X), byref(d), planes, _ptr(accum), _stream()),
+                   "sc_fused_csm_absim_f32")
+        if mark:
+            mark("fused_csm_absim")
+        nl = planes & ~both
+        if nl:
+            _lib.check(lib.sc_nonlinear_accumulate_f32(_ptr(spectra.X), byref(d), planes, nl, _ptr(accum),
+                                                       _stream()), "sc_nonlinear_accumulate_f32")
+            if mark:
+                mark("nonlinear_valu")
+        return accum, n_obs
     if planes & _lib.PLANE_CSM:
         _lib.check(lib.sc_csm_accumulate_f32(_ptr(spectra.X), byref(d), planes, _ptr(accum), _stream()),
                    "sc_csm_accumulate_f32")

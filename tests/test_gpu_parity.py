@@ -159,7 +159,10 @@ def test_seeded_vs_oracle_multi_tile(sc, C, R, et):
     close32(c.power(), so.power(coef, et), what="power")
     if C <= 40:
         close32(c.weighted_phase_lag_index(), so.weighted_phase_lag_index(coef, et), what="wpli")
-        close32(c.phase_locking_value(), so.phase_locking_value(coef, et), what="plv")
+        # PLV normalises every observation to unit modulus, so the fp32 phase error of the
+        # SMALLEST coefficients enters at full weight: 3e-5 is the honest fp32 bar here
+        close32(c.phase_locking_value(), so.phase_locking_value(coef, et), rtol=3e-5, atol_scale=3e-5,
+                what="plv")
         close32(c.debiased_squared_weighted_phase_lag_index(),
                 so.debiased_squared_weighted_phase_lag_index(coef, et), rtol=1e-4, atol_scale=1e-4,
                 what="dwpli2")
@@ -186,3 +189,27 @@ def test_fused_fft_matches_oracle_and_rocfft(sc, N, L, C, det):
     sp = engine.multitaper_spectra(xd, h, L, step, N, m.n_time_windows, det, use_fused=False)
     got = np.moveaxis(sp.X.cpu().numpy(), 0, 3)
     close32(got, coef[..., : N // 2 + 1, :], what=f"rocfft N={N}")
+
+
+@pytest.mark.parametrize("C,R", [(128, 9), (96, 5), (64, 6), (24, 11), (7, 4)])
+def test_fused_stage_b_equals_separate_kernels(sc, C, R):
+    """Fused MFMA+VALU kernel against the separate CSM and |Im| kernels on the same spectra
+    (identical fp32 arithmetic per plane up to summation order of the VALU row split)."""
+    import torch
+    from spectral_connectivity_amd import _lib, engine
+    rng = np.random.default_rng(C)
+    x = rng.standard_normal((300, R, C))
+    m = sc.Multitaper(x, sampling_frequency=300.0, time_halfbandwidth_product=3,
+                      n_time_samples_per_window=128, n_time_samples_per_step=64)
+    sp = m.device_spectra()
+    planes = _lib.PLANE_CSM | _lib.PLANE_ABS_IM
+    a_f, n = engine.accumulate(sp, "trials_tapers", planes, use_fused=True)
+    a_s, _ = engine.accumulate(sp, "trials_tapers", planes, use_fused=False)
+    for which in (_lib.M_CSM, _lib.M_WPLI, _lib.M_COHERENCE_MAGNITUDE):
+        got = engine.measure(a_f, C, planes, n, which).cpu().numpy()
+        ref = engine.measure(a_s, C, planes, n, which).cpu().numpy()
+        close32(got, ref, rtol=2e-6, atol_scale=2e-6, what=f"fused vs separate, measure {which}")
+    coef, _ = so.multitaper_fft(x, fs=300.0, NW=3, n_time_samples_per_window=128, n_time_samples_per_step=64)
+    if C <= 64:
+        close32(sc.Connectivity.from_multitaper(m).weighted_phase_lag_index(),
+                so.weighted_phase_lag_index(coef), what="wpli vs oracle")
