@@ -181,6 +181,47 @@ int sc_fused_csm_absim_f32(const void* d_X /*float2*/, const sc_spectra_desc* de
 int sc_measure_f32(const float* d_accum, int64_t n_bins, int64_t n_signals, uint32_t planes,
                    int64_t n_observations, int measure, void* d_out, void* stream);
 
+/* ---- pairwise spectral Granger prediction (batched 2x2 Wilson factorisation, fp64) -----
+ * Replaces Connectivity.pairwise_spectral_granger_prediction / subset_... and the Python
+ * loop over pairs of _estimate_spectral_granger_prediction (connectivity.py:1161-1213,
+ * :2282-2340) together with minimum_phase_decomposition (minimum_phase_decomposition.py:
+ * 227-322), _estimate_transfer_function / _estimate_noise_covariance /
+ * _remove_instantaneous_causality / _estimate_predictive_power (connectivity.py:1679-1779,
+ * :1825-1848).  All (group, pair) problems advance together; FFTs along frequency are rocFFT
+ * batched Z2Z plans created inside the call.
+ *   d_accum     accumulator records with SC_PLANE_CSM, n_groups * n_freq_accum bins;
+ *               n_freq_accum = N/2+1 (real input: negative bins are mirrored) or N.
+ *   d_pairs     int32 [n_pairs][2] channel indices (i, j)
+ *   d_out       double [n_groups][N/2+1][C][C]; out[.., i, j] = influence j -> i, NaN
+ *               elsewhere (diagonal, pairs not requested, non-positive values)
+ *   d_n_iter    int32 [n_groups*n_pairs] Wilson iterations used per problem
+ *   d_status    int32 [n_groups*n_pairs]: 1 converged, 0 hit max_iter, -1 lag-0 covariance
+ *               not positive definite (pair left NaN)
+ *   h_summary   optional HOST int32[2]: {iterations run, problems not converged}
+ * Unlike every other entry point this one SYNCHRONISES the stream once per Wilson iteration
+ * (to stop when every problem has converged, like the reference loop). */
+int sc_granger_workspace_bytes(int64_t n_groups, int64_t n_pairs, int64_t N, size_t* bytes);
+int sc_granger_pairwise_f64(const float* d_accum, int64_t n_groups, int64_t n_freq_accum,
+                            int64_t N, int64_t n_signals, uint32_t planes, int64_t n_observations,
+                            const int32_t* d_pairs, int64_t n_pairs, double tolerance, int max_iterations,
+                            void* d_work, size_t work_bytes, double* d_out, int32_t* d_n_iter,
+                            int32_t* d_status, int32_t* h_summary, void* stream);
+
+/* ---- canonical coherence between channel groups (fp64, from the accumulated CSM) -------
+ * Replaces Connectivity.canonical_coherence, _normalize_fourier_coefficients and
+ * _estimate_canonical_coherence (connectivity.py:745-820, :1979-2032): per (bin, group pair)
+ * the squared largest singular value of L_g^-1 S_gh L_h^-H with S_gg = L_g L_g^H.
+ *   d_members   int32 [n_groups][stride] channel indices of every group, stride = 16 if
+ *               max_group_size <= 16 else 32 (max supported: sc_canonical_max_group())
+ *   d_sizes     int32 [n_groups]
+ *   d_out       double [n_bins][n_groups][n_groups], symmetric, NaN diagonal
+ *   d_fail      int32 [1]: number of group blocks that were not positive definite */
+int sc_canonical_max_group(void);
+int sc_canonical_coherence_f64(const float* d_accum, int64_t n_bins, int64_t n_signals, uint32_t planes,
+                               int64_t n_observations, const int32_t* d_members, const int32_t* d_sizes,
+                               int n_groups, int max_group_size, double* d_out, int32_t* d_fail,
+                               void* stream);
+
 #ifdef __cplusplus
 }
 #endif

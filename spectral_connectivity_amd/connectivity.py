@@ -219,6 +219,68 @@ class Connectivity:
     def pairwise_phase_consistency(self):
         return self._measure(_lib.M_PPC)
 
+    # ---- pairwise spectral Granger (reference connectivity.py:1161-1213) -----------------
+    def _granger(self, pairs):
+        from . import engine
+        sp = self._device()
+        N, C = self._shape5[3], self._shape5[4]
+        # real-input spectra hold bins 0..N/2 (negative bins are mirrored on device);
+        # uploaded coefficients are accumulated on all N bins
+        n_freq = sp.F if sp.real_input else N
+        planes = _lib.PLANE_CSM
+        key = ("granger", n_freq)
+        if key not in self._accum_cache:
+            accum, n_obs = engine.accumulate(sp, self.expectation_type, planes, n_freq=n_freq)
+            self._accum_cache[key] = (self._reduce_over_ranks(accum), n_obs)
+        accum, n_obs = self._accum_cache[key]
+        n_groups = accum.shape[0] // n_freq
+        out, n_iter, status, (iters, not_conv) = engine.granger_pairwise(
+            accum, n_groups, n_freq, N, C, planes, self._n_observations_total(n_obs), pairs)
+        if not_conv:
+            logger.warning(f"Maximum iterations reached. {status.numel() - not_conv} of {status.numel()} converged")
+        self._last_wilson = dict(iterations=iters, not_converged=not_conv,
+                                 n_iter=n_iter.cpu().numpy(), status=status.cpu().numpy())
+        return out.cpu().numpy().reshape(self._kept_shape() + (N // 2 + 1, C, C))
+
+    def pairwise_spectral_granger_prediction(self):
+        """Power at node i explained by node j, out[..., i, j] = j -> i (diagonal NaN)."""
+        C = self._shape5[4]
+        pairs = np.array([(i, j) for i in range(C) for j in range(i + 1, C)], dtype=np.int32)
+        if pairs.size == 0:
+            return np.full(self._kept_shape() + (self._n_freq, C, C), np.nan)
+        return self._granger(pairs)
+
+    def subset_pairwise_spectral_granger_prediction(self, pairs):
+        return self._granger(np.asarray(pairs, dtype=np.int32))
+
+    # ---- canonical coherence (reference connectivity.py:745-820) --------------------------
+    def canonical_coherence(self, group_labels):
+        """Maximal coherence between linear combinations of each pair of channel groups.
+
+        Returns (array (n_time_windows, n_frequencies, n_groups, n_groups), sorted labels).
+        Like the reference this always averages over trials and tapers.
+        """
+        from . import engine
+        group_labels = np.asarray(group_labels)
+        labels = np.unique(group_labels)
+        groups = [np.flatnonzero(np.isin(group_labels, lab)) for lab in labels]
+        sp = self._device()
+        planes = _lib.PLANE_CSM
+        key = ("canonical", self._n_freq)
+        if key not in self._accum_cache:
+            accum, n_obs = engine.accumulate(sp, "trials_tapers", planes, n_freq=self._n_freq)
+            self._accum_cache[key] = (self._reduce_over_ranks(accum), n_obs)
+        accum, n_obs = self._accum_cache[key]
+        n_total = self._n_observations_total(n_obs)
+        if max(len(g) for g in groups) > n_total:
+            raise ValueError("canonical_coherence needs n_trials * n_tapers >= the largest group size "
+                             "(the cross-spectral blocks are rank deficient otherwise)")
+        out, n_fail = engine.canonical_coherence(accum, self._shape5[4], planes, n_total, groups)
+        if n_fail:
+            logger.warning(f"{n_fail} group cross-spectral blocks were not positive definite (NaN output)")
+        W = self._shape5[0]
+        return out.cpu().numpy().reshape(W, self._n_freq, len(labels), len(labels)), labels
+
     def conditional_spectral_granger_prediction(self):
         raise NotImplementedError   # reference connectivity.py:1215-1224 raises too
 

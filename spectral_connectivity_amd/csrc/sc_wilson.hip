@@ -1,0 +1,400 @@
+// sc_wilson.hip -- batched 2x2 Wilson spectral factorisation + pairwise spectral Granger.
+//
+// The reference loops over channel pairs in Python and runs Wilson's algorithm on one
+// (W, N, 2, 2) problem at a time (connectivity.py:2282-2340, minimum_phase_decomposition.py:
+// 227-322; ~0.16 s per pair measured).  Here every (group, pair) problem is a row of one batch:
+//   k_build    two-sided 2x2 cross-spectral matrices from the accumulator records (fp64)
+//   k_init     G0 = chol(Re ifft_n(S)[lag 0])^H                 (minimum_phase...py:48-77)
+//   loop <= max_iter, all problems at once:
+//     k_predict  A = G^-1 (G^-1 S)^H + I, closed-form 2x2       (:184-224)
+//     rocFFT     a = ifft_n(A)              batched Z2Z, unit stride, 4 series per problem
+//     k_causal   a[0] *= 1/2, strict lower of a[0] = 0, a[n >= (N+1)/2] = 0   (:96-142)
+//     rocFFT     A+ = fft_n(a)
+//     k_update   G <- G A+ unless the problem already converged; err = max |G - G_old| (:145-181, :301-315)
+//   k_h0 / k_granger   H0 = Re ifft_n(G)[0]; H = G (H0 + lam I)^-1; Sigma = H0 H0^T;
+//                      GP = log P - log(P - rot |H|^2)          (connectivity.py:1679-1779, :1825-1848)
+// Everything is fp64: the reference's convergence test (max |dG| < 1e-8 absolute) is not
+// reachable in fp32.  Each (group, pair) problem stops at its own convergence; the reference
+// freezes a window once converged, which yields the same iterate.
+// Layouts: S [P][4][N] doubles (s00, s11, Re s01, Im s01); G, A [P][4][N] complex128
+// (entry e = 2*row + col), n fastest so the FFTs are unit-stride and pointwise kernels coalesce.
+#include <rocfft/rocfft.h>
+#include "sc_common.h"
+
+typedef double2 cd;
+__device__ inline cd cmul(cd a, cd b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ inline cd cconj(cd a) { return make_double2(a.x, -a.y); }
+__device__ inline cd cadd(cd a, cd b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ inline cd csub(cd a, cd b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ inline cd cdivi(cd a, cd b) {
+    const double d = b.x * b.x + b.y * b.y;
+    return make_double2((a.x * b.x + a.y * b.y) / d, (a.y * b.x - a.x * b.y) / d);
+}
+
+struct WilsonDims {
+    int64_t P;       // problems = n_groups * n_pairs
+    int64_t N;       // two-sided FFT length
+    int64_t n_pairs;
+    int64_t F;       // accumulated bins per group
+    int C, NB, n_tiles;
+    int p_csm;
+    int two_sided;   // accumulators hold all N bins (uploaded coefficients) instead of N/2+1
+    int64_t floats_per_bin;
+    double n_obs;
+};
+
+__device__ inline float acc_read(const float* rec, int plane, int n_tiles, int NB, int i, int j, bool* mirrored) {
+    int ti = i >> 4, tj = j >> 4, ii = i & 15, jj = j & 15;
+    const bool m = ti > tj;
+    if (m) { int t = ti; ti = tj; tj = t; t = ii; ii = jj; jj = t; }
+    *mirrored = m;
+    return rec[((int64_t)plane * n_tiles + sc_tile_index(ti, tj, NB)) * SC_TILE_ELEMS + ii * 16 + jj];
+}
+
+__global__ void k_build(const float* accum, const int32_t* pairs, WilsonDims d, double* S) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t p = blockIdx.y;
+    if (n >= d.N) return;
+    const int64_t g = p / d.n_pairs, pr = p % d.n_pairs;
+    const int i = pairs[2 * pr], j = pairs[2 * pr + 1];
+    int64_t bin = n;
+    bool conj = false;
+    if (!d.two_sided && n > d.N / 2) { bin = d.N - n; conj = true; }   // real input: S(-f) = conj S(f)
+    const float* rec = accum + (g * d.F + bin) * d.floats_per_bin;
+    bool m, mm;
+    const double s00 = (double)acc_read(rec, d.p_csm, d.n_tiles, d.NB, i, i, &mm) / d.n_obs;
+    const double s11 = (double)acc_read(rec, d.p_csm, d.n_tiles, d.NB, j, j, &mm) / d.n_obs;
+    const double re = (double)acc_read(rec, d.p_csm, d.n_tiles, d.NB, i, j, &m) / d.n_obs;
+    double im = (double)acc_read(rec, d.p_csm + 1, d.n_tiles, d.NB, i, j, &m) / d.n_obs;
+    if (m) im = -im;
+    if (conj) im = -im;
+    double* Sp = S + p * 4 * d.N;
+    Sp[n] = s00; Sp[d.N + n] = s11; Sp[2 * d.N + n] = re; Sp[3 * d.N + n] = im;
+}
+
+// one block per problem: lag-0 covariance = mean_n Re S[n]; G0 = chol(R0)^H broadcast over n
+__global__ void __launch_bounds__(256) k_init(const double* S, cd* G, int32_t* status, int64_t N) {
+    __shared__ double red[3][256];
+    const int64_t p = blockIdx.x;
+    const double* Sp = S + p * 4 * N;
+    double a = 0, b = 0, c = 0;
+    for (int64_t n = threadIdx.x; n < N; n += 256) { a += Sp[n]; b += Sp[N + n]; c += Sp[2 * N + n]; }
+    red[0][threadIdx.x] = a; red[1][threadIdx.x] = b; red[2][threadIdx.x] = c;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s)
+            for (int q = 0; q < 3; ++q) red[q][threadIdx.x] += red[q][threadIdx.x + s];
+        __syncthreads();
+    }
+    const double r00 = red[0][0] / (double)N, r11 = red[1][0] / (double)N, r01 = red[2][0] / (double)N;
+    // lower Cholesky L of [[r00, r01],[r01, r11]]; G0 = L^T (upper triangular, real)
+    const double l00 = sqrt(r00), l10 = r01 / l00, t = r11 - l10 * l10, l11 = sqrt(t);
+    const bool bad = !(r00 > 0.0) || !(t > 0.0);
+    if (threadIdx.x == 0) status[p] = bad ? -1 : 0;      // -1: not positive definite (LinAlgError)
+    cd* Gp = G + p * 4 * N;
+    for (int64_t n = threadIdx.x; n < N; n += 256) {
+        Gp[n] = make_double2(l00, 0); Gp[N + n] = make_double2(l10, 0);
+        Gp[2 * N + n] = make_double2(0, 0); Gp[3 * N + n] = make_double2(l11, 0);
+    }
+}
+
+__global__ void k_predict(const double* S, const cd* G, const int32_t* status, cd* A, int64_t N) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t p = blockIdx.y;
+    if (n >= N || status[p] != 0) return;
+    const double* Sp = S + p * 4 * N;
+    const cd* Gp = G + p * 4 * N;
+    const cd g00 = Gp[n], g01 = Gp[N + n], g10 = Gp[2 * N + n], g11 = Gp[3 * N + n];
+    const cd s00 = make_double2(Sp[n], 0), s11 = make_double2(Sp[N + n], 0);
+    const cd s01 = make_double2(Sp[2 * N + n], Sp[3 * N + n]), s10 = cconj(s01);
+    const cd det = csub(cmul(g00, g11), cmul(g01, g10));
+    // Ginv = 1/det [[g11, -g01], [-g10, g00]]
+    const cd i00 = cdivi(g11, det), i01 = cdivi(make_double2(-g01.x, -g01.y), det);
+    const cd i10 = cdivi(make_double2(-g10.x, -g10.y), det), i11 = cdivi(g00, det);
+    // X = Ginv S
+    const cd x00 = cadd(cmul(i00, s00), cmul(i01, s10)), x01 = cadd(cmul(i00, s01), cmul(i01, s11));
+    const cd x10 = cadd(cmul(i10, s00), cmul(i11, s10)), x11 = cadd(cmul(i10, s01), cmul(i11, s11));
+    // Y = Ginv X^H ; A = Y + I
+    const cd h00 = cconj(x00), h01 = cconj(x10), h10 = cconj(x01), h11 = cconj(x11);
+    cd* Ap = A + p * 4 * N;
+    cd a00 = cadd(cmul(i00, h00), cmul(i01, h10)); a00.x += 1.0;
+    cd a11 = cadd(cmul(i10, h01), cmul(i11, h11)); a11.x += 1.0;
+    Ap[n] = a00;
+    Ap[N + n] = cadd(cmul(i00, h01), cmul(i01, h11));
+    Ap[2 * N + n] = cadd(cmul(i10, h00), cmul(i11, h10));
+    Ap[3 * N + n] = a11;
+}
+
+// after the (unnormalised) inverse FFT: 1/N, halve lag 0, zero strict lower triangle at lag 0,
+// zero the non-causal half
+__global__ void k_causal(cd* A, int64_t N) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t p = blockIdx.y;
+    if (n >= N) return;
+    cd* Ap = A + p * 4 * N;
+    const double invN = 1.0 / (double)N;
+    const bool keep = n < (N + 1) / 2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        cd v = Ap[e * N + n];
+        double sc = keep ? invN : 0.0;
+        if (n == 0) { sc *= 0.5; if (e == 2) sc = 0.0; }
+        Ap[e * N + n] = make_double2(v.x * sc, v.y * sc);
+    }
+}
+
+__device__ inline void atomic_max_nonneg(double* addr, double v) {
+    // order of non-negative doubles == order of their bit patterns
+    atomicMax(reinterpret_cast<unsigned long long*>(addr), (unsigned long long)__double_as_longlong(v));
+}
+
+__global__ void __launch_bounds__(256) k_update(cd* G, const cd* Aplus, const int32_t* status, double* err, int64_t N) {
+    __shared__ double red[256];
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t p = blockIdx.y;
+    double e = 0.0;
+    if (n < N && status[p] == 0) {
+        cd* Gp = G + p * 4 * N;
+        const cd* Ap = Aplus + p * 4 * N;
+        const cd g00 = Gp[n], g01 = Gp[N + n], g10 = Gp[2 * N + n], g11 = Gp[3 * N + n];
+        const cd a00 = Ap[n], a01 = Ap[N + n], a10 = Ap[2 * N + n], a11 = Ap[3 * N + n];
+        const cd n00 = cadd(cmul(g00, a00), cmul(g01, a10)), n01 = cadd(cmul(g00, a01), cmul(g01, a11));
+        const cd n10 = cadd(cmul(g10, a00), cmul(g11, a10)), n11 = cadd(cmul(g10, a01), cmul(g11, a11));
+        cd d;
+        d = csub(n00, g00); e = fmax(e, hypot(d.x, d.y));
+        d = csub(n01, g01); e = fmax(e, hypot(d.x, d.y));
+        d = csub(n10, g10); e = fmax(e, hypot(d.x, d.y));
+        d = csub(n11, g11); e = fmax(e, hypot(d.x, d.y));
+        Gp[n] = n00; Gp[N + n] = n01; Gp[2 * N + n] = n10; Gp[3 * N + n] = n11;
+    }
+    red[threadIdx.x] = e;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && red[0] > 0.0) atomic_max_nonneg(err + p, red[0]);
+}
+
+// status: 0 running -> 1 converged (err < tol); counts iterations; clears err; *n_running = #still 0
+__global__ void k_flags(int32_t* status, int32_t* n_iter, double* err, double tol, int64_t P, int32_t* n_running) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    if (status[p] == 0) {
+        n_iter[p] += 1;
+        if (err[p] < tol) status[p] = 1;
+        else atomicAdd(n_running, 1);
+    }
+    err[p] = 0.0;
+}
+
+// H0 = Re ifft_n(G)[lag 0] = mean_n Re G[n]  -> h0[p][4]
+__global__ void __launch_bounds__(256) k_h0(const cd* G, double* h0, int64_t N) {
+    __shared__ double red[4][256];
+    const int64_t p = blockIdx.x;
+    const cd* Gp = G + p * 4 * N;
+    double s[4] = {0, 0, 0, 0};
+    for (int64_t n = threadIdx.x; n < N; n += 256)
+        for (int e = 0; e < 4; ++e) s[e] += Gp[e * N + n].x;
+    for (int e = 0; e < 4; ++e) red[e][threadIdx.x] = s[e];
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st)
+            for (int e = 0; e < 4; ++e) red[e][threadIdx.x] += red[e][threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x < 4) h0[p * 4 + threadIdx.x] = red[threadIdx.x][0] / (double)N;
+}
+
+// per pair: lam = 1e-12 * mean over (groups, entries) of H0^2 (connectivity.py:1739-1742 takes the
+// mean over the whole (W,1,2,2) array); Hinv = (H0 + lam I)^-1; rot from Sigma = H0 H0^T
+__global__ void k_pair_consts(const double* h0, double* hinv, double* rot, int64_t n_groups, int64_t n_pairs) {
+    const int64_t pr = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pr >= n_pairs) return;
+    double m = 0.0;
+    for (int64_t g = 0; g < n_groups; ++g)
+        for (int e = 0; e < 4; ++e) { const double v = h0[(g * n_pairs + pr) * 4 + e]; m += v * v; }
+    const double lam = 1e-12 * m / (double)(4 * n_groups);
+    for (int64_t g = 0; g < n_groups; ++g) {
+        const int64_t p = g * n_pairs + pr;
+        const double a = h0[p * 4], b = h0[p * 4 + 1], c = h0[p * 4 + 2], d = h0[p * 4 + 3];
+        const double ra = a + lam, rd = d + lam, det = ra * rd - b * c;
+        hinv[p * 4] = rd / det; hinv[p * 4 + 1] = -b / det; hinv[p * 4 + 2] = -c / det; hinv[p * 4 + 3] = ra / det;
+        // Sigma = H0 H0^T
+        const double s00 = a * a + b * b, s01 = a * c + b * d, s11 = c * c + d * d;
+        // rot[x][y] = var[y] - Sigma[x][y]^2 / var[x]   (connectivity.py:1847-1848)
+        rot[p * 4] = s00 - s00 * s00 / s00; rot[p * 4 + 1] = s11 - s01 * s01 / s00;
+        rot[p * 4 + 2] = s00 - s01 * s01 / s11; rot[p * 4 + 3] = s11 - s11 * s11 / s11;
+    }
+}
+
+__global__ void k_fill_nan(double* out, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) out[i] = nan("");
+}
+
+__global__ void k_granger(const cd* G, const double* S, const double* hinv, const double* rot,
+                          const int32_t* status, const int32_t* pairs, WilsonDims d, int64_t Fout, double* out) {
+    const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t p = blockIdx.y;
+    if (f >= Fout) return;
+    const int64_t g = p / d.n_pairs, pr = p % d.n_pairs;
+    const int i = pairs[2 * pr], j = pairs[2 * pr + 1];
+    const int idx[2] = {i, j};
+    const int64_t N = d.N;
+    double* o = out + ((g * Fout + f) * d.C) * d.C;
+    if (status[p] < 0) return;                       // Cholesky failed: pair stays NaN
+    const cd* Gp = G + p * 4 * N;
+    const double* Sp = S + p * 4 * N;
+    const cd gg[4] = {Gp[f], Gp[N + f], Gp[2 * N + f], Gp[3 * N + f]};
+    const double* hi = hinv + p * 4;
+    // H = G Hinv (Hinv real)
+    cd H[4];
+    H[0] = make_double2(gg[0].x * hi[0] + gg[1].x * hi[2], gg[0].y * hi[0] + gg[1].y * hi[2]);
+    H[1] = make_double2(gg[0].x * hi[1] + gg[1].x * hi[3], gg[0].y * hi[1] + gg[1].y * hi[3]);
+    H[2] = make_double2(gg[2].x * hi[0] + gg[3].x * hi[2], gg[2].y * hi[0] + gg[3].y * hi[2]);
+    H[3] = make_double2(gg[2].x * hi[1] + gg[3].x * hi[3], gg[2].y * hi[1] + gg[3].y * hi[3]);
+    const double tp[2] = {Sp[f], Sp[N + f]};         // total power of the two channels
+    for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b) {
+            if (a == b) continue;                    // diagonal is NaN (connectivity.py:2337-2339)
+            const cd h = H[a * 2 + b];
+            double intrinsic = tp[a] - rot[p * 4 + a * 2 + b] * (h.x * h.x + h.y * h.y);
+            if (intrinsic == 0.0) intrinsic = 2.220446049250313e-16;
+            double gp = log(tp[a]) - log(intrinsic);
+            if (!(gp > 0.0)) gp = nan("");
+            o[(int64_t)idx[a] * d.C + idx[b]] = gp;
+        }
+}
+
+// ------------------------------------------------------------------------------- host side
+struct WilsonPlan {
+    rocfft_plan fwd, inv;
+    rocfft_execution_info info_f, info_i;
+    void* work;
+    size_t work_bytes;
+};
+
+static int make_z2z(rocfft_plan* plan, rocfft_transform_type type, size_t N, size_t batch) {
+    size_t lengths[1] = {N};
+    rocfft_status s = rocfft_plan_create(plan, rocfft_placement_inplace, type, rocfft_precision_double, 1,
+                                         lengths, batch, nullptr);
+    if (s != rocfft_status_success) {
+        sc_set_error("rocfft_plan_create(Z2Z N=%zu batch=%zu) failed: %d", N, batch, (int)s);
+        return SC_EFFT;
+    }
+    return SC_OK;
+}
+
+extern "C" int sc_granger_workspace_bytes(int64_t n_groups, int64_t n_pairs, int64_t N, size_t* bytes) {
+    SC_REQUIRE(bytes && n_groups >= 1 && n_pairs >= 1 && N >= 2, "bad workspace query");
+    const size_t P = (size_t)n_groups * n_pairs;
+    // S (4 doubles) + G (4 complex) + A (4 complex) per (problem, bin) + per-problem scalars
+    *bytes = P * (size_t)N * (4 * 8 + 4 * 16 + 4 * 16) + P * (8 + 4 + 4 + 4 * 8 * 3) + 256;
+    return SC_OK;
+}
+
+#define SC_CHECK_FFT2(expr)                                                                      \
+    do {                                                                                         \
+        rocfft_status s_ = (expr);                                                               \
+        if (s_ != rocfft_status_success) {                                                       \
+            sc_set_error("%s failed: rocfft_status %d (%s:%d)", #expr, (int)s_, __FILE__, __LINE__); \
+            rc = SC_EFFT; goto done;                                                             \
+        }                                                                                        \
+    } while (0)
+
+extern "C" int sc_granger_pairwise_f64(const float* d_accum, int64_t n_groups, int64_t n_freq_accum,
+                                       int64_t N, int64_t C, uint32_t planes, int64_t n_obs,
+                                       const int32_t* d_pairs, int64_t n_pairs, double tol, int max_iter,
+                                       void* d_work, size_t work_bytes, double* d_out, int32_t* d_n_iter,
+                                       int32_t* d_status, int32_t* h_summary, void* stream) {
+    SC_REQUIRE(d_accum && d_pairs && d_work && d_out && d_n_iter && d_status, "NULL argument");
+    SC_REQUIRE(planes & SC_PLANE_CSM, "accumulator record must contain SC_PLANE_CSM");
+    SC_REQUIRE(n_freq_accum == N || n_freq_accum == N / 2 + 1, "accumulators must hold N or N/2+1 bins");
+    SC_REQUIRE(n_groups * n_pairs <= 65535, "too many (group, pair) problems for one launch");
+    size_t need = 0;
+    sc_granger_workspace_bytes(n_groups, n_pairs, N, &need);
+    SC_REQUIRE(work_bytes >= need, "workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    WilsonDims d;
+    d.P = n_groups * n_pairs; d.N = N; d.n_pairs = n_pairs; d.F = n_freq_accum; d.C = (int)C;
+    d.NB = sc_n_blocks(C); d.n_tiles = sc_n_tiles(d.NB);
+    d.p_csm = sc_plane_offset(planes, SC_PLANE_CSM);
+    d.two_sided = (n_freq_accum == N && N > 1) ? 1 : 0;
+    d.floats_per_bin = (int64_t)sc_plane_count(planes) * d.n_tiles * SC_TILE_ELEMS;
+    d.n_obs = (double)n_obs;
+    const int64_t P = d.P, Fout = N / 2 + 1;
+    char* w = (char*)d_work;
+    double* S = (double*)w; w += (size_t)P * N * 4 * 8;
+    cd* G = (cd*)w; w += (size_t)P * N * 4 * 16;
+    cd* A = (cd*)w; w += (size_t)P * N * 4 * 16;
+    double* err = (double*)w; w += (size_t)P * 8;
+    double* h0 = (double*)w; w += (size_t)P * 32;
+    double* hinv = (double*)w; w += (size_t)P * 32;
+    double* rot = (double*)w; w += (size_t)P * 32;
+    int32_t* n_running = (int32_t*)w;
+
+    int rc = SC_OK;
+    rocfft_plan fwd = nullptr, inv = nullptr;
+    rocfft_execution_info info = nullptr;
+    void* fft_work = nullptr;
+    size_t ws_f = 0, ws_i = 0;
+    static int rocfft_ready = 0;
+    if (!rocfft_ready) { rocfft_setup(); rocfft_ready = 1; }
+    const dim3 gridN((unsigned)((N + 255) / 256), (unsigned)P), gridF((unsigned)((Fout + 255) / 256), (unsigned)P);
+    int iters = 0, running = (int)P;
+
+    if ((rc = make_z2z(&fwd, rocfft_transform_type_complex_forward, N, 4 * P)) != SC_OK) goto done;
+    if ((rc = make_z2z(&inv, rocfft_transform_type_complex_inverse, N, 4 * P)) != SC_OK) goto done;
+    SC_CHECK_FFT2(rocfft_plan_get_work_buffer_size(fwd, &ws_f));
+    SC_CHECK_FFT2(rocfft_plan_get_work_buffer_size(inv, &ws_i));
+    SC_CHECK_FFT2(rocfft_execution_info_create(&info));
+    if (ws_f < ws_i) ws_f = ws_i;
+    if (ws_f) {
+        if (hipMalloc(&fft_work, ws_f) != hipSuccess) { sc_set_error("rocFFT work buffer alloc failed"); rc = SC_ENOMEM; goto done; }
+        SC_CHECK_FFT2(rocfft_execution_info_set_work_buffer(info, fft_work, ws_f));
+    }
+    SC_CHECK_FFT2(rocfft_execution_info_set_stream(info, st));
+
+    hipMemsetAsync(err, 0, (size_t)P * 8, st);
+    hipMemsetAsync(d_n_iter, 0, (size_t)P * 4, st);
+    hipLaunchKernelGGL(k_fill_nan, dim3((unsigned)((n_groups * Fout * C * C + 255) / 256)), dim3(256), 0, st, d_out,
+                       n_groups * Fout * C * C);
+    hipLaunchKernelGGL(k_build, gridN, dim3(256), 0, st, d_accum, d_pairs, d, S);
+    hipLaunchKernelGGL(k_init, dim3((unsigned)P), dim3(256), 0, st, S, G, d_status, N);
+    for (iters = 0; iters < max_iter; ++iters) {
+        void* bufs[1] = {A};
+        hipLaunchKernelGGL(k_predict, gridN, dim3(256), 0, st, S, G, d_status, A, N);
+        SC_CHECK_FFT2(rocfft_execute(inv, bufs, nullptr, info));
+        hipLaunchKernelGGL(k_causal, gridN, dim3(256), 0, st, A, N);
+        SC_CHECK_FFT2(rocfft_execute(fwd, bufs, nullptr, info));
+        hipLaunchKernelGGL(k_update, gridN, dim3(256), 0, st, G, A, d_status, err, N);
+        hipMemsetAsync(n_running, 0, 4, st);
+        hipLaunchKernelGGL(k_flags, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, d_status, d_n_iter, err, tol, P,
+                           n_running);
+        if (hipMemcpyAsync(&running, n_running, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) {
+            sc_set_error("Wilson iteration %d: %s", iters, hipGetErrorString(hipGetLastError()));
+            rc = SC_EHIP; goto done;
+        }
+        if (running == 0) { ++iters; break; }
+    }
+    hipLaunchKernelGGL(k_h0, dim3((unsigned)P), dim3(256), 0, st, G, h0, N);
+    hipLaunchKernelGGL(k_pair_consts, dim3((unsigned)((n_pairs + 63) / 64)), dim3(64), 0, st, h0, hinv, rot, n_groups,
+                       n_pairs);
+    hipLaunchKernelGGL(k_granger, gridF, dim3(256), 0, st, G, S, hinv, rot, d_status, d_pairs, d, Fout, d_out);
+    if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) {
+        sc_set_error("Granger epilogue failed: %s", hipGetErrorString(hipGetLastError()));
+        rc = SC_EHIP; goto done;
+    }
+    if (h_summary) { h_summary[0] = iters; h_summary[1] = running; }
+done:
+    if (info) rocfft_execution_info_destroy(info);
+    if (fwd) rocfft_plan_destroy(fwd);
+    if (inv) rocfft_plan_destroy(inv);
+    if (fft_work) (void)hipFree(fft_work);
+    return rc;
+}
+
+// Minimum-phase factor only (minimum_phase_decomposition.py:227-322) for callers that hand in
+// their own two-sided 2x2 spectra: S [P][4][N] doubles as above; G out [P][4][N] complex128.

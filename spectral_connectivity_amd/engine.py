@@ -200,3 +200,46 @@ def measure(accum, n_signals, planes, n_obs, which, out=None):
     _lib.check(lib.sc_measure_f32(_ptr(accum), n_bins, C, planes, n_obs, which, _ptr(out), _stream()),
                "sc_measure_f32")
     return out
+
+
+def granger_pairwise(accum, n_groups, n_freq_accum, n_fft, n_signals, planes, n_obs, pairs,
+                     tolerance=1e-8, max_iterations=60):
+    """Batched 2x2 Wilson + spectral Granger (sc_wilson.hip).  Returns (out, n_iter, status, summary)."""
+    lib = _lib.load()
+    dev = accum.device
+    pairs_t = torch.as_tensor(np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)).to(dev)
+    n_pairs = pairs_t.shape[0]
+    nbytes = ctypes.c_size_t()
+    _lib.check(lib.sc_granger_workspace_bytes(n_groups, n_pairs, n_fft, byref(nbytes)), "sc_granger_workspace_bytes")
+    work = torch.empty((nbytes.value,), dtype=torch.uint8, device=dev)
+    F = n_fft // 2 + 1
+    out = torch.empty((n_groups, F, n_signals, n_signals), dtype=torch.float64, device=dev)
+    n_iter = torch.empty((n_groups * n_pairs,), dtype=torch.int32, device=dev)
+    status = torch.empty((n_groups * n_pairs,), dtype=torch.int32, device=dev)
+    summary = (ctypes.c_int32 * 2)(0, 0)
+    _lib.check(lib.sc_granger_pairwise_f64(_ptr(accum), n_groups, n_freq_accum, n_fft, n_signals, planes, n_obs,
+                                           _ptr(pairs_t), n_pairs, tolerance, max_iterations, _ptr(work),
+                                           nbytes.value, _ptr(out), _ptr(n_iter), _ptr(status), summary, _stream()),
+               "sc_granger_pairwise_f64")
+    return out, n_iter, status, (summary[0], summary[1])
+
+
+def canonical_coherence(accum, n_signals, planes, n_obs, groups):
+    """groups: list of int arrays (channel indices per group).  Returns ([n_bins, G, G] float64, n_fail)."""
+    lib = _lib.load()
+    dev = accum.device
+    G = len(groups)
+    cmax = max(len(g) for g in groups)
+    stride = 16 if cmax <= 16 else 32
+    members = np.full((G, stride), -1, dtype=np.int32)
+    for i, g in enumerate(groups):
+        members[i, : min(len(g), stride)] = np.asarray(g, dtype=np.int32)[:stride]
+    sizes = np.array([len(g) for g in groups], dtype=np.int32)
+    members_t, sizes_t = torch.from_numpy(members).to(dev), torch.from_numpy(sizes).to(dev)
+    n_bins = accum.shape[0]
+    out = torch.empty((n_bins, G, G), dtype=torch.float64, device=dev)
+    fail = torch.zeros((1,), dtype=torch.int32, device=dev)
+    _lib.check(lib.sc_canonical_coherence_f64(_ptr(accum), n_bins, n_signals, planes, n_obs, _ptr(members_t),
+                                              _ptr(sizes_t), G, int(cmax), _ptr(out), _ptr(fail), _stream()),
+               "sc_canonical_coherence_f64")
+    return out, int(fail.item())

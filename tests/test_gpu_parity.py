@@ -213,3 +213,47 @@ def test_fused_stage_b_equals_separate_kernels(sc, C, R):
     if C <= 64:
         close32(sc.Connectivity.from_multitaper(m).weighted_phase_lag_index(),
                 so.weighted_phase_lag_index(coef), what="wpli vs oracle")
+
+
+@pytest.mark.parametrize("tag,kw", [
+    ("ding2", dict(time_halfbandwidth_product=1)),
+    ("bacc3", dict(time_halfbandwidth_product=2, n_time_samples_per_window=250)),
+])
+def test_f5_granger_vs_reference(sc, golden, tag, kw):
+    """Pairwise spectral Granger through the batched 2x2 Wilson kernel vs the real reference."""
+    g = golden("f5_granger")
+    m = sc.Multitaper(g[f"{tag}__x"], sampling_frequency=200.0, **kw)
+    c = sc.Connectivity.from_multitaper(m)
+    got = c.pairwise_spectral_granger_prediction()
+    ref = g[f"{tag}__granger"]
+    # values are log-ratios built from an fp32 CSM; NaN pattern (non-positive values) can flip
+    # for entries that are ~0: compare where both are finite and require few flips
+    both = ~np.isnan(got) & ~np.isnan(ref)
+    assert (np.isnan(got) != np.isnan(ref)).mean() < 0.02
+    scale = np.nanmax(ref)
+    assert np.max(np.abs(got[both] - ref[both])) <= 2e-5 * scale + 1e-5 * 0
+    assert c._last_wilson["not_converged"] == 0
+    # subset == full on the requested pairs (reference tests/test_connectivity.py:591-613)
+    sub = c.subset_pairwise_spectral_granger_prediction([(0, 1)])
+    np.testing.assert_allclose(sub[..., 0, 1], got[..., 0, 1], rtol=1e-12, equal_nan=True)
+    np.testing.assert_allclose(sub[..., 1, 0], got[..., 1, 0], rtol=1e-12, equal_nan=True)
+
+
+def test_granger_from_uploaded_two_sided_coefficients(sc, golden):
+    g = golden("f5_granger")
+    coef, _ = so.multitaper_fft(g["ding2__x"], fs=200.0, NW=1)
+    c = sc.Connectivity(coef)
+    got = c.pairwise_spectral_granger_prediction()
+    ref = g["ding2__granger"]
+    both = ~np.isnan(got) & ~np.isnan(ref)
+    assert np.max(np.abs(got[both] - ref[both])) <= 2e-5 * np.nanmax(ref)
+
+
+def test_f6_canonical_coherence(sc, golden):
+    g = golden("f6_canonical")
+    m = sc.Multitaper(g["x"], sampling_frequency=float(g["fs"]), time_halfbandwidth_product=float(g["NW"]),
+                      n_time_samples_per_window=int(g["L"]))
+    c = sc.Connectivity.from_multitaper(m)
+    cc, labels = c.canonical_coherence(g["group_labels"])
+    assert np.array_equal(labels, g["labels"])
+    close32(cc, g["canonical_coherence"], rtol=2e-5, atol_scale=2e-5, what="canonical coherence")
