@@ -147,7 +147,7 @@ class Connectivity:
         """Accumulator record containing at least ``planes`` (cached)."""
         from . import engine
         for have, rec in self._accum_cache.items():
-            if have & planes == planes:
+            if isinstance(have, int) and have & planes == planes:
                 return have, rec
         sp = self._device()
         accum, n_obs = engine.accumulate(sp, self.expectation_type, planes, n_freq=self._n_freq)
