@@ -191,7 +191,7 @@ def test_fused_fft_matches_oracle_and_rocfft(sc, N, L, C, det):
     close32(got, coef[..., : N // 2 + 1, :], what=f"rocfft N={N}")
 
 
-@pytest.mark.parametrize("C,R", [(128, 9), (96, 5), (64, 6), (24, 11), (7, 4)])
+@pytest.mark.parametrize("C,R", [(128, 9), (96, 5), (64, 6), (24, 11), (6, 4), (128, 40)])
 def test_fused_stage_b_equals_separate_kernels(sc, C, R):
     """Fused MFMA+VALU kernel against the separate CSM and |Im| kernels on the same spectra
     (identical fp32 arithmetic per plane up to summation order of the VALU row split)."""
