@@ -198,6 +198,206 @@ __global__ void __launch_bounds__(256) mtfft_kernel(MtArgs p) {
     }
 }
 
+// ----------------------------------------------------------------------------------------
+// Radix-16 variant for N = 256 (16x16), 1024 (16x16x4), 4096 (16x16x16): every thread owns 16
+// points per pass, so a 256-point transform is TWO register-resident radix-16 butterflies with
+// one LDS exchange between them (the radix-4 kernel above needs four passes, eight barriers and
+// a separate pack pass).  Pass 1 reads the detrended window tile directly (x * taper, packed two
+// channels per complex sequence), so the tapered sequences are never materialised.  The exchange
+// buffer is skewed, phys(idx) = idx + idx/16, which makes the stride-16 writes of pass 1 and the
+// stride-N/16 reads of pass 2 both conflict-free; window rows are padded by 2 floats for the same
+// reason.  3 + (1 if N > 256) workgroup barriers per taper instead of 10.
+__device__ __forceinline__ void dft4r(float2& a0, float2& a1, float2& a2, float2& a3) {
+    const float2 b0 = make_float2(a0.x + a2.x, a0.y + a2.y), b1 = make_float2(a0.x - a2.x, a0.y - a2.y);
+    const float2 b2 = make_float2(a1.x + a3.x, a1.y + a3.y), b3 = make_float2(a1.y - a3.y, a3.x - a1.x);
+    a0 = make_float2(b0.x + b2.x, b0.y + b2.y);
+    a1 = make_float2(b1.x + b3.x, b1.y + b3.y);
+    a2 = make_float2(b0.x - b2.x, b0.y - b2.y);
+    a3 = make_float2(b1.x - b3.x, b1.y - b3.y);
+}
+__device__ __forceinline__ float2 cmulc(float2 a, float c, float s) {   // a * (c + i s)
+    return make_float2(a.x * c - a.y * s, a.x * s + a.y * c);
+}
+// in: x[n], n = 4*n1 + n2 ; out: o[k], k = k1 + 4*k2   (forward DFT, exp(-2 pi i nk/16))
+__device__ __forceinline__ void dft16(float2 (&x)[16], float2 (&o)[16]) {
+    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, H = 0.70710678118654752f;
+#pragma unroll
+    for (int n2 = 0; n2 < 4; ++n2) dft4r(x[n2], x[4 + n2], x[8 + n2], x[12 + n2]);   // x[4*k1 + n2]
+    // twiddles W16^(n2*k1)
+    x[4 + 1] = cmulc(x[4 + 1], C1, -S1);  x[8 + 1] = cmulc(x[8 + 1], H, -H);    x[12 + 1] = cmulc(x[12 + 1], S1, -C1);
+    x[4 + 2] = cmulc(x[4 + 2], H, -H);    x[8 + 2] = make_float2(x[8 + 2].y, -x[8 + 2].x);
+    x[12 + 2] = cmulc(x[12 + 2], -H, -H);
+    x[4 + 3] = cmulc(x[4 + 3], S1, -C1);  x[8 + 3] = cmulc(x[8 + 3], -H, -H);   x[12 + 3] = cmulc(x[12 + 3], -C1, S1);
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) {
+        float2 a0 = x[4 * k1], a1 = x[4 * k1 + 1], a2 = x[4 * k1 + 2], a3 = x[4 * k1 + 3];
+        dft4r(a0, a1, a2, a3);
+        o[k1] = a0; o[k1 + 4] = a1; o[k1 + 8] = a2; o[k1 + 12] = a3;
+    }
+}
+
+template <int LOG2N>
+__global__ void __launch_bounds__(256) mtfft16_kernel(MtArgs p) {
+    constexpr int N = 1 << LOG2N;
+    constexpr int TPF = N / 16;          // threads per FFT: 16 points each
+    constexpr int NF = 256 / TPF;        // complex FFTs (channel pairs) per workgroup
+    constexpr int CT = 2 * NF;           // channels per workgroup
+    constexpr int XS = CT + 2;           // padded window-row stride (floats)
+    constexpr int ZS = N + N / 16 + 1;   // skewed exchange buffer per FFT (float2), odd stride
+    extern __shared__ __align__(16) unsigned char smem[];
+    float* xt = reinterpret_cast<float*>(smem);                                   // [N][XS]
+    float2* z = reinterpret_cast<float2*>(smem + (size_t)N * XS * 4);             // [NF][ZS]
+    float2* tw = z + NF * ZS;                                                     // [N]
+    float* hk = reinterpret_cast<float*>(tw + N);                                 // [N] current taper
+    double* red = reinterpret_cast<double*>(hk + N);                              // [2][256] + trend [2][CT]
+
+    const int tid = threadIdx.x;
+    const int c0 = blockIdx.x * CT, r = blockIdx.y, w = blockIdx.z;
+    const int L = p.L, C = p.C;
+    const int64_t RC = (int64_t)p.R * C;
+    for (int i = tid; i < N; i += 256) tw[i] = p.tw[i];
+    const float* xw = p.x + ((int64_t)w * p.step * p.R + r) * C + c0;
+    for (int idx = tid; idx < L * CT; idx += 256) {
+        const int l = idx / CT, cc = idx - l * CT;
+        xt[l * XS + cc] = (c0 + cc < C) ? xw[(int64_t)l * RC + cc] : 0.f;
+    }
+    __syncthreads();
+    if (p.detrend != SC_DETREND_NONE) {
+        constexpr int SL = 256 / CT;
+        const int cc = tid % CT, sl = tid / CT;
+        double s = 0.0, st = 0.0;
+        for (int l = sl; l < L; l += SL) {
+            const double v = (double)xt[l * XS + cc];
+            s += v;
+            st += v * (double)(l + 1);
+        }
+        red[tid] = s;
+        red[256 + tid] = st;
+        __syncthreads();
+        if (tid < CT) {
+            double sum = 0.0, sumt = 0.0;
+            for (int q = 0; q < SL; ++q) { sum += red[q * CT + tid]; sumt += red[256 + q * CT + tid]; }
+            sumt /= (double)L;
+            const double n = (double)L;
+            double a = 0.0, b;
+            if (p.detrend == SC_DETREND_CONSTANT) {
+                b = sum / n;
+            } else {
+                const double St = (n + 1.0) * 0.5, Stt = (n + 1.0) * (2.0 * n + 1.0) / (6.0 * n);
+                const double den = n * Stt - St * St;
+                a = (den != 0.0) ? (n * sumt - St * sum) / den : 0.0;
+                b = (sum - a * St) / n;
+            }
+            red[512 + tid] = a;
+            red[512 + CT + tid] = b;
+        }
+        __syncthreads();
+        const double invL = 1.0 / (double)L;
+        for (int idx = tid; idx < L * CT; idx += 256) {
+            const int l = idx / CT, cc2 = idx - l * CT;
+            const double t = (double)(l + 1) * invL;
+            xt[l * XS + cc2] = (float)((double)xt[l * XS + cc2] - (red[512 + cc2] * t + red[512 + CT + cc2]));
+        }
+    }
+
+    const int pf = tid / TPF, i = tid - pf * TPF;     // FFT (channel pair) and butterfly index
+    float2* zf = z + pf * ZS;
+    const int F = N / 2 + 1;
+    const int64_t sF = (int64_t)p.W * p.R * p.K * C;
+    const bool vec_ok = (C % 2) == 0;
+#define PHYS(idx) ((idx) + ((idx) >> 4))
+    for (int k = 0; k < p.K; ++k) {
+        const float* hg = p.tapers + (int64_t)k * L;
+        for (int n = tid; n < L; n += 256) hk[n] = hg[n];
+        __syncthreads();     // taper k (and, first time, the detrended tile) visible; post of k-1 done
+        float2 a[16], o[16];
+        // pass 1: radix 16, P = 1, inputs straight from the window tile
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int n = i + t * TPF;
+            float2 v = make_float2(0.f, 0.f);
+            if (n < L) {
+                const float h = hk[n];
+                const float2 xv = *reinterpret_cast<const float2*>(xt + n * XS + 2 * pf);
+                v = make_float2(xv.x * h, xv.y * h);
+            }
+            a[t] = v;
+        }
+        dft16(a, o);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) zf[PHYS(16 * i + u)] = o[u];
+        __syncthreads();
+        // pass 2: radix 16, P = 16
+        {
+            const int kk = i & 15;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const float2 v = zf[PHYS(i + t * TPF)];
+                a[t] = (t == 0) ? v : cmul(v, tw[t * kk * (N / 256)]);
+            }
+            dft16(a, o);
+            __syncthreads();
+            const int j = ((i - kk) << 4) + kk;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) zf[PHYS(j + 16 * u)] = o[u];
+            __syncthreads();
+        }
+        if constexpr (LOG2N == 10) {        // pass 3: radix 4, P = 256, four butterflies per thread
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int ib = i + b * TPF;            // 0..255, k = ib
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float2 v = zf[PHYS(ib + t * 256)];
+                    a[4 * b + t] = (t == 0) ? v : cmul(v, tw[t * ib]);
+                }
+                dft4r(a[4 * b], a[4 * b + 1], a[4 * b + 2], a[4 * b + 3]);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int ib = i + b * TPF;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) zf[PHYS(ib + 256 * u)] = a[4 * b + u];
+            }
+            __syncthreads();
+        }
+        if constexpr (LOG2N == 12) {        // pass 3: radix 16, P = 256, k = i
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const float2 v = zf[PHYS(i + t * TPF)];
+                a[t] = (t == 0) ? v : cmul(v, tw[t * i]);
+            }
+            dft16(a, o);
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 16; ++u) zf[PHYS(i + 256 * u)] = o[u];
+            __syncthreads();
+        }
+        // split the packed pair, store X[f][w][r][k][c..c+1]
+        float2* Xk = p.X + (((int64_t)w * p.R + r) * p.K + k) * C + c0;
+        for (int idx = tid; idx < F * NF; idx += 256) {
+            const int f = idx / NF, pr = idx - f * NF;
+            const int c = c0 + 2 * pr;
+            if (c >= C) continue;
+            const int f2 = (N - f) & (N - 1);
+            const float2 z1 = z[pr * ZS + PHYS(f)];
+            const float2 z2 = z[pr * ZS + PHYS(f2)];
+            const float2 A = make_float2(0.5f * (z1.x + z2.x), 0.5f * (z1.y - z2.y));
+            const float2 B = make_float2(0.5f * (z1.y + z2.y), 0.5f * (z2.x - z1.x));
+            float2* dst = Xk + (int64_t)f * sF + 2 * pr;
+            if (vec_ok) {
+                *reinterpret_cast<float4*>(dst) = make_float4(A.x, A.y, B.x, B.y);
+            } else {
+                dst[0] = A;
+                if (c + 1 < C) dst[1] = B;
+            }
+        }
+        // the barrier at the top of the next taper orders these reads before pass 1 rewrites z
+    }
+#undef PHYS
+}
+
 __global__ void twiddle_kernel(float2* tw, int N) {
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= N) return;
@@ -221,6 +421,21 @@ static int launch_mt(const MtArgs& a, hipStream_t stream) {
                              (size_t)(512 + 2 * CT) * 8;
     static_assert(shmem <= 160 * 1024, "LDS budget exceeded");
     auto k = mtfft_kernel<LOG2N, CT>;
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    dim3 grid((unsigned)((a.C + CT - 1) / CT), (unsigned)a.R, (unsigned)a.W);
+    hipLaunchKernelGGL(k, grid, dim3(256), shmem, stream, a);
+    SC_CHECK_HIP(hipGetLastError());
+    return SC_OK;
+}
+
+template <int LOG2N>
+static int launch_mt16(const MtArgs& a, hipStream_t stream) {
+    constexpr int N = 1 << LOG2N;
+    constexpr int TPF = N / 16, NF = 256 / TPF, CT = 2 * NF;
+    constexpr size_t shmem = (size_t)N * (CT + 2) * 4 + (size_t)NF * (N + N / 16 + 1) * 8 + (size_t)N * 8 +
+                             (size_t)N * 4 + (size_t)(512 + 2 * CT) * 8;
+    static_assert(shmem <= 160 * 1024, "LDS budget exceeded");
+    auto k = mtfft16_kernel<LOG2N>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     dim3 grid((unsigned)((a.C + CT - 1) / CT), (unsigned)a.R, (unsigned)a.W);
     hipLaunchKernelGGL(k, grid, dim3(256), shmem, stream, a);
@@ -252,11 +467,11 @@ extern "C" int sc_multitaper_fft_f32(const float* d_x, int64_t T, int64_t R, int
     switch (N) {
     case 64: return launch_mt<6, 64>(a, s);
     case 128: return launch_mt<7, 64>(a, s);
-    case 256: return launch_mt<8, 32>(a, s);
+    case 256: return launch_mt16<8>(a, s);
     case 512: return launch_mt<9, 16>(a, s);
-    case 1024: return launch_mt<10, 16>(a, s);
+    case 1024: return launch_mt16<10>(a, s);
     case 2048: return launch_mt<11, 8>(a, s);
-    case 4096: return launch_mt<12, 2>(a, s);
+    case 4096: return launch_mt16<12>(a, s);
     }
     return SC_EUNSUPPORTED;
 }
