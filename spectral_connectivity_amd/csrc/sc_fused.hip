@@ -218,21 +218,36 @@ __device__ __forceinline__ void fused_valu_role(const FusedArgs& p, const ScStag
         fu_store(st, rows, planes, tid, regs);
         __syncthreads();
         if (ch + 1 < n_chunks) fu_load(st, (ch + 1) * FU_OC, tid, regs);
-        // zero rows past n_obs contribute |0| = 0: no bound needed for this plane
-        for (int row = rsub; row < FU_OC; row += wps) {
-            const float* rp = rows + row * st.RS;
+        // zero rows past n_obs contribute |0| = 0: no bound needed for this plane.
+        // Operands of the NEXT (row, block) are fetched before the current block is consumed, so
+        // the ~100-cycle LDS latency hides under the 48 VALU ops instead of stalling the wave.
+        {
+            float4 ci0, ci1, cj0, cj1;
+            {
+                const float* rp = rows + rsub * st.RS;
+                const float4* pi = reinterpret_cast<const float4*>(rp + (BI[0] * 32 + li * 4) * 2);
+                const float4* pj = reinterpret_cast<const float4*>(rp + (BJ[0] * 32 + lj * 4) * 2);
+                ci0 = pi[0]; ci1 = pi[1]; cj0 = pj[0]; cj1 = pj[1];
+            }
+            for (int row = rsub; row < FU_OC; row += wps) {
+                const float* rp = rows + row * st.RS;
+                const float* rn = rows + ((row + wps < FU_OC) ? row + wps : row) * st.RS;
 #pragma unroll
-            for (int s = 0; s < FU_MAXB; ++s) {
-                const float4* pi = reinterpret_cast<const float4*>(rp + (BI[s] * 32 + li * 4) * 2);
-                const float4* pj = reinterpret_cast<const float4*>(rp + (BJ[s] * 32 + lj * 4) * 2);
-                const float4 i0 = pi[0], i1 = pi[1], j0 = pj[0], j1 = pj[1];
-                const float xi_re[4] = {i0.x, i0.z, i1.x, i1.z}, xi_im[4] = {i0.y, i0.w, i1.y, i1.w};
-                const float xj_re[4] = {j0.x, j0.z, j1.x, j1.z}, xj_im[4] = {j0.y, j0.w, j1.y, j1.w};
+                for (int s = 0; s < FU_MAXB; ++s) {
+                    const float* rq = (s + 1 < FU_MAXB) ? rp : rn;
+                    const int sn = (s + 1 < FU_MAXB) ? s + 1 : 0;
+                    const float4* pi = reinterpret_cast<const float4*>(rq + (BI[sn] * 32 + li * 4) * 2);
+                    const float4* pj = reinterpret_cast<const float4*>(rq + (BJ[sn] * 32 + lj * 4) * 2);
+                    const float4 ni0 = pi[0], ni1 = pi[1], nj0 = pj[0], nj1 = pj[1];
+                    const float xi_re[4] = {ci0.x, ci0.z, ci1.x, ci1.z}, xi_im[4] = {ci0.y, ci0.w, ci1.y, ci1.w};
+                    const float xj_re[4] = {cj0.x, cj0.z, cj1.x, cj1.z}, xj_im[4] = {cj0.y, cj0.w, cj1.y, cj1.w};
 #pragma unroll
-                for (int a = 0; a < 4; ++a)
+                    for (int a = 0; a < 4; ++a)
 #pragma unroll
-                    for (int b = 0; b < 4; ++b)
-                        acc[s][a * 4 + b] += fabsf(xi_im[a] * xj_re[b] - xi_re[a] * xj_im[b]);
+                        for (int b = 0; b < 4; ++b)
+                            acc[s][a * 4 + b] += fabsf(xi_im[a] * xj_re[b] - xi_re[a] * xj_im[b]);
+                    ci0 = ni0; ci1 = ni1; cj0 = nj0; cj1 = nj1;
+                }
             }
         }
         __syncthreads();

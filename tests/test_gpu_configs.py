@@ -1,0 +1,182 @@
+"""BASELINE.json configurations on the GPU: parity against the oracle at sizes the oracle finishes
+in seconds, and size-independent properties (shard additivity, symmetry, bounds, known coupling
+structure) at the full sizes."""
+import time
+
+import numpy as np
+import pytest
+
+from oracle import spectral_oracle as so
+
+pytestmark = pytest.mark.gpu
+FS = 1000.0
+
+
+def synth(T, R, C, tone, seed):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((T, R, C)).astype(np.float32)
+    t = np.arange(T) / FS
+    x += (0.5 * np.sin(2 * np.pi * tone * t[:, None, None] + 2 * np.pi * np.arange(C)[None, None, :] / C)).astype(np.float32)
+    return x
+
+
+def close(a, b, rtol, atol_scale, what):
+    ok = ~np.isnan(b)
+    assert np.array_equal(np.isnan(a), np.isnan(b)), what
+    scale = np.abs(b[ok]).max()
+    err = np.abs(a[ok] - b[ok])
+    worst = (err / (rtol * np.abs(b[ok]) + atol_scale * scale)).max()
+    assert worst <= 1.0, f"{what}: max err {err.max():.3e}, scale {scale:.3e}, err/bound {worst:.2f}"
+
+
+@pytest.fixture(scope="module")
+def sc():
+    import spectral_connectivity_amd as pkg
+    return pkg
+
+
+def test_cfg2_full_size_csm_coherency(sc):
+    """configs[1]: 32 ch x 100 trials x 1024 samples, 5 tapers, single window."""
+    x = synth(1024, 100, 32, 40.0, 2)
+    m = sc.Multitaper(x, sampling_frequency=FS, time_halfbandwidth_product=3)
+    c = sc.Connectivity.from_multitaper(m)
+    coef, _ = so.multitaper_fft(x.astype(np.float64), fs=FS, NW=3)
+    csm = so.expectation_csm_gemm(coef)
+    close(c._expectation_cross_spectral_matrix(), csm[:, :513], 1e-5, 1e-5, "csm")
+    close(c.coherency(), so.coherency(coef, csm=csm), 1e-5, 1e-5, "coherency")
+    close(c.coherence_magnitude(), so.coherence_magnitude(coef, csm=csm), 1e-5, 1e-5, "coherence")
+
+
+def _wpli_chunked(coef):
+    """wPLI of the oracle without the (W,R,K,N,C,C) temporary: loop over (window, trial)."""
+    W, R, K, N, C = coef.shape
+    F = N // 2 + 1
+    s_im = np.zeros((W, F, C, C))
+    s_abs = np.zeros((W, F, C, C))
+    for w in range(W):
+        for r in range(R):
+            X = coef[w, r, :, :F, :]
+            im = (X[..., :, None] * X[..., None, :].conj()).imag
+            s_im[w] += im.sum(axis=0)
+            s_abs[w] += np.abs(im).sum(axis=0)
+    n = R * K
+    idx = np.arange(C)
+    s_im[..., idx, idx] = 0
+    s_abs[..., idx, idx] = 0
+    wgt = s_abs / n
+    wgt[wgt < so.EPS] = 1
+    return (s_im / n) / wgt
+
+
+def test_cfg3_reduced_trials_coherence_wpli(sc):
+    """configs[2] geometry (128 ch, NW=4, 256-pt windows, step 128) with 6 trials vs the oracle."""
+    x = synth(1024, 6, 128, 60.0, 3)
+    kw = dict(n_time_samples_per_window=256, n_time_samples_per_step=128)
+    m = sc.Multitaper(x, sampling_frequency=FS, time_halfbandwidth_product=4, **kw)
+    c = sc.Connectivity.from_multitaper(m)
+    coef, _ = so.multitaper_fft(x.astype(np.float64), fs=FS, NW=4, **kw)
+    csm = so.expectation_csm_gemm(coef)
+    close(c.coherence_magnitude(), so.coherence_magnitude(coef, csm=csm), 1e-5, 1e-5, "coherence")
+    close(c.weighted_phase_lag_index(), _wpli_chunked(coef), 1e-5, 1e-5, "wpli")
+
+
+def test_cfg3_full_size_properties(sc):
+    """configs[2] at full size (1000 trials): properties that need no reference run."""
+    import torch
+    from spectral_connectivity_amd import _lib, engine
+    x = synth(1024, 1000, 128, 60.0, 3)
+    kw = dict(n_time_samples_per_window=256, n_time_samples_per_step=128)
+    m = sc.Multitaper(x, sampling_frequency=FS, time_halfbandwidth_product=4, **kw)
+    c = sc.Connectivity.from_multitaper(m)
+    coh, wpli = c.coherence_magnitude(), c.weighted_phase_lag_index()
+    assert coh.shape == wpli.shape == (7, 129, 128, 128)
+    off = ~np.eye(128, dtype=bool)
+    assert np.isnan(coh[..., ~off]).all() and np.all((coh[..., off] >= 0) & (coh[..., off] <= 1))
+    assert np.all(np.abs(wpli) <= 1 + 1e-6) and np.all(wpli[..., ~off] == 0)
+    np.testing.assert_allclose(coh, np.swapaxes(coh, -1, -2), rtol=0, atol=0, equal_nan=True)     # Hermitian mirror
+    np.testing.assert_allclose(wpli, -np.swapaxes(wpli, -1, -2), rtol=0, atol=0)                   # antisymmetric
+    f60 = int(round(60.0 / (FS / 256)))
+    assert np.nanmean(coh[:, f60]) > 5 * np.nanmean(coh[:, 100])        # shared 60 Hz tone, white elsewhere
+    # shard additivity (the multi-GPU sum rule): accumulators of trials [0,400) + [400,1000) == all trials
+    planes = _lib.PLANE_CSM | _lib.PLANE_ABS_IM
+    h = torch.from_numpy(np.ascontiguousarray(m.tapers.T / FS, dtype=np.float32)).cuda()
+    def acc(lo, hi):
+        xs = torch.from_numpy(x[:, lo:hi]).cuda()
+        sp = engine.multitaper_spectra(xs, h, 256, 128, 256, 7, "constant")
+        return engine.accumulate(sp, "trials_tapers", planes)[0]
+    whole, parts = acc(0, 1000), acc(0, 400) + acc(400, 1000)
+    rel = (whole - parts).abs().max() / whole.abs().max()
+    assert rel < 2e-6, rel
+
+
+def test_cfg4_granger_reduced_vs_oracle_and_full_size(sc):
+    """configs[3]: 64 ch x 200 trials x 4096 samples, all 2016 pairs through the batched Wilson kernel."""
+    rng = np.random.default_rng(4)
+    C, T = 64, 4096
+    # sparse stable VAR(2): channel c is driven by c-1 (lag 1) and c-5 (lag 2)
+    def simulate(R):
+        e = rng.standard_normal((T + 200, R, C))
+        y = np.zeros_like(e)
+        for t in range(2, T + 200):
+            y[t] = 0.5 * y[t - 1] - 0.3 * y[t - 2] + e[t]
+            y[t, :, 1:] += 0.35 * y[t - 1, :, :-1]
+            y[t, :, 5:] += 0.25 * y[t - 2, :, :-5]
+        return y[200:]
+    x = simulate(12)
+    m = sc.Multitaper(x, sampling_frequency=FS, time_halfbandwidth_product=3)
+    c = sc.Connectivity.from_multitaper(m)
+    pairs = [(0, 1), (3, 8), (10, 40), (62, 63)]
+    got = c.subset_pairwise_spectral_granger_prediction(pairs)
+    coef, _ = so.multitaper_fft(x, fs=FS, NW=3)
+    ref = so.pairwise_spectral_granger_prediction(coef, pairs=pairs)
+    both = ~np.isnan(got) & ~np.isnan(ref)
+    assert (np.isnan(got) != np.isnan(ref)).mean() < 0.01
+    assert np.abs(got[both] - ref[both]).max() <= 3e-5 * np.nanmax(ref)
+    # full size: 200 trials, every pair
+    x = simulate(200).astype(np.float32)
+    m = sc.Multitaper(x, sampling_frequency=FS, time_halfbandwidth_product=3)
+    c = sc.Connectivity.from_multitaper(m)
+    t0 = time.perf_counter()
+    gp = c.pairwise_spectral_granger_prediction()
+    dt = time.perf_counter() - t0
+    print(f"cfg4 full: 2016 pairs in {dt:.2f} s, Wilson iterations {c._last_wilson['iterations']}, "
+          f"not converged {c._last_wilson['not_converged']}")
+    assert gp.shape == (1, 2049, 64, 64) and c._last_wilson["not_converged"] == 0
+    band = slice(20, 900)
+    drive = np.nanmean(np.nan_to_num(gp[0, band, np.arange(1, 64), np.arange(0, 63)]))      # c-1 -> c
+    back = np.nanmean(np.nan_to_num(gp[0, band, np.arange(0, 63), np.arange(1, 64)]))       # c -> c-1
+    far = np.nanmean(np.nan_to_num(gp[0, band, 0, 30:60]))
+    assert drive > 10 * back and drive > 10 * far, (drive, back, far)
+
+
+def test_cfg5_canonical_coherence_reduced_vs_oracle_and_full_size(sc):
+    """configs[4]: 256 ch, 16 groups of 16; oracle SVD form at 24 trials, properties at 500."""
+    rng = np.random.default_rng(5)
+    C, T = 256, 1024
+    labels = np.repeat(np.arange(16), 16)
+    t = np.arange(T) / FS
+    def make(R):
+        x = rng.standard_normal((T, R, C)).astype(np.float32)
+        src = rng.standard_normal((T, R, 16)).astype(np.float32)
+        x += 0.6 * np.repeat(src, 16, axis=2)                  # each group shares a latent source
+        x[:, :, :32] += (0.8 * np.sin(2 * np.pi * 30 * t)[:, None, None] * rng.standard_normal((1, R, 1))).astype(np.float32)
+        return x
+    x = make(24)
+    m = sc.Multitaper(x, sampling_frequency=FS, time_halfbandwidth_product=3)
+    c = sc.Connectivity.from_multitaper(m)
+    cc, lab = c.canonical_coherence(labels)
+    coef, _ = so.multitaper_fft(x.astype(np.float64), fs=FS, NW=3)
+    ref, _ = so.canonical_coherence(coef[..., :129, :][:, :, :, :, :] if False else coef, labels)
+    close(cc, ref, 5e-5, 5e-5, "canonical coherence (256 ch, 24 trials)")
+    x = make(500)
+    m = sc.Multitaper(x, sampling_frequency=FS, time_halfbandwidth_product=3)
+    c = sc.Connectivity.from_multitaper(m)
+    t0 = time.perf_counter()
+    cc, lab = c.canonical_coherence(labels)
+    print(f"cfg5 full: canonical coherence in {time.perf_counter() - t0:.2f} s")
+    assert cc.shape == (1, 513, 16, 16)
+    off = ~np.eye(16, dtype=bool)
+    assert np.all((cc[..., off] >= 0) & (cc[..., off] <= 1 + 1e-9)) and np.isnan(cc[..., ~off]).all()
+    np.testing.assert_array_equal(cc, np.swapaxes(cc, -1, -2))
+    f30 = int(round(30.0 / (FS / 1024)))
+    assert cc[0, f30, 0, 1] > 0.5 and cc[0, f30, 0, 1] > 3 * np.nanmedian(cc[0, f30][2:, 2:][~np.eye(14, dtype=bool)])
