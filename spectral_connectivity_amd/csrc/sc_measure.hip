@@ -27,7 +27,10 @@ struct MeasureArgs {
 __device__ inline float tile_read(const float* bin_rec, int plane, int n_tiles, int NB, int i, int j,
                                   bool* mirrored) {
     int ti = i >> 4, tj = j >> 4, ii = i & 15, jj = j & 15;
-    bool m = ti > tj;
+    // lower triangle (tile-wise AND inside diagonal tiles) is read from its mirror: the matrix
+    // cores fill diagonal tiles completely, but (i,j) and (j,i) there differ by rounding; using
+    // one of them keeps every measure exactly (anti)symmetric like the reference.
+    bool m = (ti > tj) || (ti == tj && ii > jj);
     if (m) { int t = ti; ti = tj; tj = t; t = ii; ii = jj; jj = t; }
     *mirrored = m;
     return bin_rec[((int64_t)plane * n_tiles + sc_tile_index(ti, tj, NB)) * SC_TILE_ELEMS + ii * 16 + jj];

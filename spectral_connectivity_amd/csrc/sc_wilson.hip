@@ -45,7 +45,7 @@ struct WilsonDims {
 
 __device__ inline float acc_read(const float* rec, int plane, int n_tiles, int NB, int i, int j, bool* mirrored) {
     int ti = i >> 4, tj = j >> 4, ii = i & 15, jj = j & 15;
-    const bool m = ti > tj;
+    const bool m = (ti > tj) || (ti == tj && ii > jj);
     if (m) { int t = ti; ti = tj; tj = t; t = ii; ii = jj; jj = t; }
     *mirrored = m;
     return rec[((int64_t)plane * n_tiles + sc_tile_index(ti, tj, NB)) * SC_TILE_ELEMS + ii * 16 + jj];
