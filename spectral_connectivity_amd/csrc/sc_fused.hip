@@ -15,16 +15,19 @@
 // Workgroup = 12 waves = one output bin (C <= 128, even).  Every SIMD hosts 1 MFMA wave and
 // 2 VALU waves (a single wave issues one VALU op per ~5 cycles; two interleave to the pipe
 // rate).  All waves stage a chunk of 32 observation rows HBM -> registers -> LDS twice:
-//   rows   [obs][channel] float2            for the VALU waves (ds_read_b128, 4x4 pair tiles)
-//   planes [6][channel][obs] bf16           for the MFMA waves (ds_read_b128 = 8 obs of one
-//                                           channel = one 16x16x32 operand fragment)
+//   rows   [obs][Re(ch) | Im(ch)] float     for the VALU waves (ds_read_b128, 4x4 pair tiles)
+//   planes [9][channel][obs] bf16           for the MFMA waves (ds_read_b128 = 8 obs of one
+//                                           channel = one 16x16x32 operand fragment; planes 6-8
+//                                           hold -Re so Im needs no negation in registers)
 // so the 6.5 GB of spectra of the headline configuration are read from HBM once for both
 // products (the unfused path reads them twice).
+#include <stdlib.h>
 #include "sc_stage.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define FU_OC 32            // observation rows per chunk (= K of the bf16 MFMA)
 #define FU_THREADS 768
@@ -38,6 +41,7 @@ struct FusedArgs {
     int64_t floats_per_bin;
     int n_bins, F, NB, n_tiles, NB32, n_blocks32, n_sets;
     int csm_plane, abs_plane;
+    int debug_skip;      // profiling aid (SC_FUSED_DEBUG): 1 = MFMA waves idle, 2 = VALU waves idle
 };
 
 __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
@@ -81,10 +85,15 @@ __device__ __forceinline__ void fu_store(const ScStage& st, float* rows, unsigne
                                          const FuRegs& r) {
     const int q = tid & 63, oq = (tid >> 6) - 4;
     if (2 * q >= st.CP) return;
+    // rows are PLANAR per observation: [Re of CP channels | Im of CP channels], so four consecutive
+    // channels' Re (or Im) are one aligned float4 = two 64-bit register pairs for v_pk_* operands
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-        *reinterpret_cast<float4*>(rows + (oq * 4 + k) * st.RS + 4 * q) = r.v[k];
-    // planes: 0 re_h 1 re_m 2 re_l 3 im_h 4 im_m 5 im_l ; element (plane, ch, obs)
+    for (int k = 0; k < 4; ++k) {
+        float* rowp = rows + (oq * 4 + k) * st.RS + 2 * q;
+        *reinterpret_cast<float2*>(rowp) = make_float2(r.v[k].x, r.v[k].z);
+        *reinterpret_cast<float2*>(rowp + st.CP) = make_float2(r.v[k].y, r.v[k].w);
+    }
+    // planes: 0 re_h 1 re_m 2 re_l 3 im_h 4 im_m 5 im_l 6..8 -(re_h, re_m, re_l); element (plane, ch, obs)
     const int plane_elems = st.CP * FU_PSTRIDE;
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc) {
@@ -100,6 +109,9 @@ __device__ __forceinline__ void fu_store(const ScStage& st, float* rows, unsigne
         *reinterpret_cast<uint2*>(base) = h;
         *reinterpret_cast<uint2*>(base + plane_elems) = m;
         *reinterpret_cast<uint2*>(base + 2 * plane_elems) = l;
+        *reinterpret_cast<uint2*>(base + 6 * plane_elems) = make_uint2(h.x ^ 0x80008000u, h.y ^ 0x80008000u);
+        *reinterpret_cast<uint2*>(base + 7 * plane_elems) = make_uint2(m.x ^ 0x80008000u, m.y ^ 0x80008000u);
+        *reinterpret_cast<uint2*>(base + 8 * plane_elems) = make_uint2(l.x ^ 0x80008000u, l.y ^ 0x80008000u);
         split4(im, h, m, l);
         *reinterpret_cast<uint2*>(base + 3 * plane_elems) = h;
         *reinterpret_cast<uint2*>(base + 4 * plane_elems) = m;
@@ -107,73 +119,85 @@ __device__ __forceinline__ void fu_store(const ScStage& st, float* rows, unsigne
     }
 }
 
-__device__ __forceinline__ bf16x8 neg8(bf16x8 v) {
-    u32x4 u = __builtin_bit_cast(u32x4, v);
-    u ^= 0x80008000u;
-    return __builtin_bit_cast(bf16x8, u);
-}
 
 #define FU_MFMA(a, b, c) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#define FU_NPLANES 9
 
 // The two roles are separate functions so their accumulators never coexist in registers.
 // Both execute the same barrier sequence: per chunk 2 barriers, then 2*log2(waves per set).
-template <int MAX_SLOTS>
+//
+// MFMA role.  Wave w owns tile rows w and NB-1-w of the upper triangle (NB+1 tiles for even NB):
+// the nine A fragments of a row (Re, Im, -Re x h,m,l) are loaded once per row and chunk, the six B
+// fragments per tile, and the first two B fragments of the NEXT tile are prefetched under the 24
+// MFMAs of the current one.
+template <int NB32>
 __device__ __forceinline__ void fused_mfma_role(const FusedArgs& p, const ScStage& st, float* rows,
                                                 unsigned short* planes, int tid, int wave, int bin) {
+    constexpr int MAXS = 2 * NB32 + 1;
     const int lane = tid & 63;
-    int bi[MAX_SLOTS], bj[MAX_SLOTS];
-    f32x4 re[MAX_SLOTS], im[MAX_SLOTS];
+    const int NB = p.NB;
+    const int rA_ = wave, rB_ = NB - 1 - wave;
+    const int nA_ = (rA_ <= rB_) ? NB - rA_ : 0;      // tiles in row rA (0: this wave has no tiles)
+    const int nB_ = (rB_ > rA_) ? NB - rB_ : 0;
+    const int total = nA_ + nB_;
+    f32x4 re[MAXS], im[MAXS];
 #pragma unroll
-    for (int s = 0; s < MAX_SLOTS; ++s) {
-        const int t = s * 4 + wave;
-        int r = 0, rem = (t < p.n_tiles) ? t : 0, len = p.NB;
-        while (rem >= len) { rem -= len; ++r; --len; }
-        bi[s] = r; bj[s] = r + rem;
-        re[s] = (f32x4){0.f, 0.f, 0.f, 0.f}; im[s] = re[s];
-    }
+    for (int s = 0; s < MAXS; ++s) { re[s] = (f32x4){0.f, 0.f, 0.f, 0.f}; im[s] = re[s]; }
     const int n_chunks = (st.n_obs + FU_OC - 1) / FU_OC;
     const int plane_elems = st.CP * FU_PSTRIDE;
-    // fragment address of lane (channel c = lane & 15, obs group g = lane >> 4) inside a block
     const unsigned short* frag0 = planes + (lane & 15) * FU_PSTRIDE + (lane >> 4) * 8;
     float* out = p.accum + (int64_t)bin * p.floats_per_bin + (int64_t)p.csm_plane * p.n_tiles * SC_TILE_ELEMS;
+#define FU_LD(ptr, k) (*reinterpret_cast<const bf16x8*>((ptr) + (k) * plane_elems))
     for (int ch = 0; ch < n_chunks; ++ch) {
         __syncthreads();          // chunk ch staged by the VALU waves
+        if ((p.debug_skip & 1) == 0 && total > 0) {
+            // opaque per-chunk copies: otherwise ~2 loop-invariant address VGPRs per tile stay live
+            // across the chunk loop and spill at the 168-register budget
+            int rA = rA_, rB = rB_, nA = nA_;
+            asm volatile("" : "+s"(rA), "+s"(rB), "+s"(nA));
+            bf16x8 arh, arm, arl, aih, aim, ail, nrh, nrm, nrl;      // A fragments of the current row
+            bf16x8 brh, bih;                                        // first B fragments (prefetched)
+            {
+                const unsigned short* fb = frag0 + rA * 16 * FU_PSTRIDE;   // first tile (rA, rA)
+                brh = FU_LD(fb, 0); bih = FU_LD(fb, 3);
+            }
 #pragma unroll
-        for (int s = 0; s < MAX_SLOTS; ++s) {
-            // recompute the two fragment addresses per chunk (opaque SGPR copies): keeping 18
-            // loop-invariant address VGPRs alive would spill at the 168-register budget
-            int bis = bi[s], bjs = bj[s];
-            asm volatile("" : "+s"(bis), "+s"(bjs));
-            const unsigned short* fa = frag0 + bis * 16 * FU_PSTRIDE;
-            const unsigned short* fb = frag0 + bjs * 16 * FU_PSTRIDE;
-            // six leading terms of (h+m+l)(h+m+l): hh hm mh mm with the h and m planes, then hl lh
-            // with the l planes loaded over the m registers (keeps <= 8 fragments live).
-            // Re += ar*br + ai*bi ; Im += ai*br - ar*bi : two independent accumulate chains, interleaved.
-#define FU_LD(ptr, k) (*reinterpret_cast<const bf16x8*>((ptr) + (k) * plane_elems))
-            const bf16x8 arh = FU_LD(fa, 0), aih = FU_LD(fa, 3), brh = FU_LD(fb, 0), bih = FU_LD(fb, 3);
-            const bf16x8 nrh = neg8(arh);
-            {
-                const bf16x8 arm = FU_LD(fa, 1), aim = FU_LD(fa, 4), brm = FU_LD(fb, 1), bimm = FU_LD(fb, 4);
-                const bf16x8 nrm = neg8(arm);
-                FU_MFMA(arh, brh, re[s]);  FU_MFMA(aih, brh, im[s]);
-                FU_MFMA(aih, bih, re[s]);  FU_MFMA(nrh, bih, im[s]);
-                FU_MFMA(arh, brm, re[s]);  FU_MFMA(aih, brm, im[s]);
-                FU_MFMA(aih, bimm, re[s]); FU_MFMA(nrh, bimm, im[s]);
-                FU_MFMA(arm, brh, re[s]);  FU_MFMA(aim, brh, im[s]);
-                FU_MFMA(aim, bih, re[s]);  FU_MFMA(nrm, bih, im[s]);
-                FU_MFMA(arm, brm, re[s]);  FU_MFMA(aim, brm, im[s]);
-                FU_MFMA(aim, bimm, re[s]); FU_MFMA(nrm, bimm, im[s]);
+            for (int s = 0; s < MAXS; ++s) {
+                if (s < total) {
+                    const bool in_a = s < nA;
+                    const int row = in_a ? rA : rB;
+                    const int col = row + (in_a ? s : s - nA);
+                    if (s == 0 || s == nA) {
+                        const unsigned short* fa = frag0 + row * 16 * FU_PSTRIDE;
+                        arh = FU_LD(fa, 0); arm = FU_LD(fa, 1); arl = FU_LD(fa, 2);
+                        aih = FU_LD(fa, 3); aim = FU_LD(fa, 4); ail = FU_LD(fa, 5);
+                        nrh = FU_LD(fa, 6); nrm = FU_LD(fa, 7); nrl = FU_LD(fa, 8);
+                    }
+                    const unsigned short* fb = frag0 + col * 16 * FU_PSTRIDE;
+                    const bf16x8 brm = FU_LD(fb, 1), bimm = FU_LD(fb, 4), brl = FU_LD(fb, 2), bil = FU_LD(fb, 5);
+                    const bf16x8 cbrh = brh, cbih = bih;
+                    if (s + 1 < total) {      // prefetch the next tile's first fragments
+                        const bool na = (s + 1) < nA;
+                        const int ncol = (na ? rA : rB) + (na ? s + 1 : s + 1 - nA);
+                        const unsigned short* fn = frag0 + ncol * 16 * FU_PSTRIDE;
+                        brh = FU_LD(fn, 0); bih = FU_LD(fn, 3);
+                    }
+                    // six leading terms of (h+m+l)(h+m+l): hh hm mh mm hl lh
+                    // Re += ar*br + ai*bi ; Im += ai*br + (-ar)*bi   (two chains, interleaved)
+                    FU_MFMA(arh, cbrh, re[s]);  FU_MFMA(aih, cbrh, im[s]);
+                    FU_MFMA(aih, cbih, re[s]);  FU_MFMA(nrh, cbih, im[s]);
+                    FU_MFMA(arh, brm, re[s]);   FU_MFMA(aih, brm, im[s]);
+                    FU_MFMA(aih, bimm, re[s]);  FU_MFMA(nrh, bimm, im[s]);
+                    FU_MFMA(arm, cbrh, re[s]);  FU_MFMA(aim, cbrh, im[s]);
+                    FU_MFMA(aim, cbih, re[s]);  FU_MFMA(nrm, cbih, im[s]);
+                    FU_MFMA(arm, brm, re[s]);   FU_MFMA(aim, brm, im[s]);
+                    FU_MFMA(aim, bimm, re[s]);  FU_MFMA(nrm, bimm, im[s]);
+                    FU_MFMA(arh, brl, re[s]);   FU_MFMA(aih, brl, im[s]);
+                    FU_MFMA(aih, bil, re[s]);   FU_MFMA(nrh, bil, im[s]);
+                    FU_MFMA(arl, cbrh, re[s]);  FU_MFMA(ail, cbrh, im[s]);
+                    FU_MFMA(ail, cbih, re[s]);  FU_MFMA(nrl, cbih, im[s]);
+                }
             }
-            {
-                const bf16x8 arl = FU_LD(fa, 2), ail = FU_LD(fa, 5), brl = FU_LD(fb, 2), bil = FU_LD(fb, 5);
-                const bf16x8 nrl = neg8(arl);
-                FU_MFMA(arh, brl, re[s]);  FU_MFMA(aih, brl, im[s]);
-                FU_MFMA(aih, bil, re[s]);  FU_MFMA(nrh, bil, im[s]);
-                FU_MFMA(arl, brh, re[s]);  FU_MFMA(ail, brh, im[s]);
-                FU_MFMA(ail, bih, re[s]);  FU_MFMA(nrl, bih, im[s]);
-            }
-#undef FU_LD
-            __builtin_amdgcn_sched_barrier(0);   // keep the next slot's fragment loads from piling up registers
         }
         // Two-level summation: every FU_FLUSH chunks (512 observations) the f32 accumulators are
         // folded into the output record (owned by this wave, L2-resident) and cleared, so no f32
@@ -182,10 +206,12 @@ __device__ __forceinline__ void fused_mfma_role(const FusedArgs& p, const ScStag
         if (((ch + 1) % FU_FLUSH) == 0 || ch + 1 == n_chunks) {
             const bool first = ch < FU_FLUSH;
 #pragma unroll
-            for (int s = 0; s < MAX_SLOTS; ++s) {
-                const int t = s * 4 + wave;
-                if (t < p.n_tiles) {
-                    float* o_re = out + (int64_t)t * SC_TILE_ELEMS;
+            for (int s = 0; s < MAXS; ++s) {
+                if (s < total) {
+                    const bool in_a = s < nA_;
+                    const int row = in_a ? rA_ : rB_;
+                    const int col = row + (in_a ? s : s - nA_);
+                    float* o_re = out + (int64_t)sc_tile_index(row, col, NB) * SC_TILE_ELEMS;
                     float* o_im = o_re + (int64_t)p.n_tiles * SC_TILE_ELEMS;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -199,26 +225,61 @@ __device__ __forceinline__ void fused_mfma_role(const FusedArgs& p, const ScStag
         }
         __syncthreads();
     }
+#undef FU_LD
     const int wps = 8 / p.n_sets;
     for (int half = wps >> 1; half >= 1; half >>= 1) { __syncthreads(); __syncthreads(); }
 }
 
-__device__ __forceinline__ void fused_valu_role(const FusedArgs& p, const ScStage& st, float* rows,
-                                                unsigned short* planes, int tid, int vw, int bin) {
+// ---- VALU role ---------------------------------------------------------------------------------
+// Upper-triangular 32x32 blocks, row-major: t -> (BI, BJ).  Tables are compile-time (template on
+// the number of 32-channel blocks and the set) so that operand fragments shared by several blocks
+// of a set (same BI or same BJ) are loaded from LDS once per observation row.
+__host__ __device__ constexpr int fu_nblocks(int nb32) { return nb32 * (nb32 + 1) / 2; }
+__host__ __device__ constexpr int fu_nsets(int nb32) { return (fu_nblocks(nb32) + FU_MAXB - 1) / FU_MAXB; }
+__host__ __device__ constexpr int fu_per_set(int nb32) { return (fu_nblocks(nb32) + fu_nsets(nb32) - 1) / fu_nsets(nb32); }
+__host__ __device__ constexpr int fu_bi(int nb32, int t) {
+    int r = 0, len = nb32;
+    while (t >= len) { t -= len; ++r; --len; }
+    return r;
+}
+__host__ __device__ constexpr int fu_bj(int nb32, int t) {
+    int r = 0, len = nb32;
+    while (t >= len) { t -= len; ++r; --len; }
+    return r + t;
+}
+
+template <int NB32, int SET>
+struct FuTab {
+    static constexpr int PER = fu_per_set(NB32);
+    static constexpr int T0 = SET * PER;
+    static constexpr int NBLK = (fu_nblocks(NB32) - T0) < PER ? (fu_nblocks(NB32) - T0) : PER;   // blocks of this set
+    struct Arr { int bi[FU_MAXB]; int bj[FU_MAXB]; bool use_i[4]; bool use_j[4]; };
+    static constexpr Arr make() {
+        Arr a{};
+        for (int s = 0; s < FU_MAXB; ++s) { a.bi[s] = 0; a.bj[s] = 0; }
+        for (int b = 0; b < 4; ++b) { a.use_i[b] = false; a.use_j[b] = false; }
+        for (int s = 0; s < NBLK; ++s) {
+            a.bi[s] = fu_bi(NB32, T0 + s);
+            a.bj[s] = fu_bj(NB32, T0 + s);
+            a.use_i[a.bi[s]] = true;
+            a.use_j[a.bj[s]] = true;
+        }
+        return a;
+    }
+    static constexpr Arr tab = make();
+};
+
+template <int NB32, int SET>
+__device__ __forceinline__ void fused_valu_body(const FusedArgs& p, const ScStage& st, float* rows,
+                                                unsigned short* planes, int tid, int rsub, int wps, int bin) {
+    using Tab = FuTab<NB32, SET>;
+    constexpr int NBLK = Tab::NBLK;
     const int lane = tid & 63;
-    const int wps = 8 / p.n_sets;                         // VALU waves per block set (8 or 4)
-    const int set = vw / wps, rsub = vw % wps;
-    int BI[FU_MAXB], BJ[FU_MAXB];
-    float acc[FU_MAXB][16];
+    float acc[NBLK > 0 ? NBLK : 1][16];
 #pragma unroll
-    for (int s = 0; s < FU_MAXB; ++s) {
-        const int t = set * FU_MAXB + s;
-        int r = 0, rem = (t < p.n_blocks32) ? t : 0, len = p.NB32;
-        while (rem >= len) { rem -= len; ++r; --len; }
-        BI[s] = r; BJ[s] = r + rem;
+    for (int s = 0; s < NBLK; ++s)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[s][e] = 0.f;
-    }
     const int n_chunks = (st.n_obs + FU_OC - 1) / FU_OC;
     const int li = lane >> 3, lj = lane & 7;
     FuRegs regs;
@@ -227,36 +288,35 @@ __device__ __forceinline__ void fused_valu_role(const FusedArgs& p, const ScStag
         fu_store(st, rows, planes, tid, regs);
         __syncthreads();
         if (ch + 1 < n_chunks) fu_load(st, (ch + 1) * FU_OC, tid, regs);
-        // zero rows past n_obs contribute |0| = 0: no bound needed for this plane.
-        // Operands of the NEXT (row, block) are fetched before the current block is consumed, so
-        // the ~100-cycle LDS latency hides under the 48 VALU ops instead of stalling the wave.
-        {
-            float4 ci0, ci1, cj0, cj1;
-            {
-                const float* rp = rows + rsub * st.RS;
-                const float4* pi = reinterpret_cast<const float4*>(rp + (BI[0] * 32 + li * 4) * 2);
-                const float4* pj = reinterpret_cast<const float4*>(rp + (BJ[0] * 32 + lj * 4) * 2);
-                ci0 = pi[0]; ci1 = pi[1]; cj0 = pj[0]; cj1 = pj[1];
-            }
-            for (int row = rsub; row < FU_OC; row += wps) {
-                const float* rp = rows + row * st.RS;
-                const float* rn = rows + ((row + wps < FU_OC) ? row + wps : row) * st.RS;
+        // zero rows past n_obs contribute |0| = 0: no bound needed for this plane
+        for (int row = ((p.debug_skip & 2) ? FU_OC : rsub); row < FU_OC; row += wps) {
+            const float* rp = rows + row * st.RS;
+            float4 XIre[NB32], XIim[NB32], XJre[NB32], XJim[NB32];
 #pragma unroll
-                for (int s = 0; s < FU_MAXB; ++s) {
-                    const float* rq = (s + 1 < FU_MAXB) ? rp : rn;
-                    const int sn = (s + 1 < FU_MAXB) ? s + 1 : 0;
-                    const float4* pi = reinterpret_cast<const float4*>(rq + (BI[sn] * 32 + li * 4) * 2);
-                    const float4* pj = reinterpret_cast<const float4*>(rq + (BJ[sn] * 32 + lj * 4) * 2);
-                    const float4 ni0 = pi[0], ni1 = pi[1], nj0 = pj[0], nj1 = pj[1];
-                    const float xi_re[4] = {ci0.x, ci0.z, ci1.x, ci1.z}, xi_im[4] = {ci0.y, ci0.w, ci1.y, ci1.w};
-                    const float xj_re[4] = {cj0.x, cj0.z, cj1.x, cj1.z}, xj_im[4] = {cj0.y, cj0.w, cj1.y, cj1.w};
-#pragma unroll
-                    for (int a = 0; a < 4; ++a)
-#pragma unroll
-                        for (int b = 0; b < 4; ++b)
-                            acc[s][a * 4 + b] += fabsf(xi_im[a] * xj_re[b] - xi_re[a] * xj_im[b]);
-                    ci0 = ni0; ci1 = ni1; cj0 = nj0; cj1 = nj1;
+            for (int b = 0; b < NB32; ++b) {
+                if (Tab::tab.use_i[b]) {
+                    XIre[b] = *reinterpret_cast<const float4*>(rp + b * 32 + li * 4);
+                    XIim[b] = *reinterpret_cast<const float4*>(rp + st.CP + b * 32 + li * 4);
                 }
+                if (Tab::tab.use_j[b]) {
+                    XJre[b] = *reinterpret_cast<const float4*>(rp + b * 32 + lj * 4);
+                    XJim[b] = *reinterpret_cast<const float4*>(rp + st.CP + b * 32 + lj * 4);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < NBLK; ++s) {
+                const int bi = Tab::tab.bi[s], bj = Tab::tab.bj[s];
+                const float4 ire = XIre[bi], iim = XIim[bi], jre = XJre[bj], jim = XJim[bj];
+                // 3 VALU instructions per pair (v_mul, v_fma, v_add with |.| source modifier).  Packed
+                // v_pk_mul/v_pk_fma_f32 (2 issues per 2 pairs) measured SLOWER here (6.9 vs 6.1 ms): the
+                // loop is VALU-pipe bound, not issue bound, and packed f32 ops take twice the pipe time.
+                const float are[4] = {ire.x, ire.y, ire.z, ire.w}, aim[4] = {iim.x, iim.y, iim.z, iim.w};
+                const float bre[4] = {jre.x, jre.y, jre.z, jre.w}, bim[4] = {jim.x, jim.y, jim.z, jim.w};
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        acc[s][a * 4 + b] += fabsf(aim[a] * bre[b] - are[a] * bim[b]);
             }
         }
         __syncthreads();
@@ -265,17 +325,17 @@ __device__ __forceinline__ void fused_valu_role(const FusedArgs& p, const ScStag
     float* red = rows;
     for (int half = wps >> 1; half >= 1; half >>= 1) {
         if (rsub >= half && rsub < 2 * half) {
-            float* dst = red + (size_t)(set * (wps >> 1) + (rsub - half)) * (FU_MAXB * 16 * 64);
+            float* dst = red + (size_t)(SET * (wps >> 1) + (rsub - half)) * (FU_MAXB * 16 * 64);
 #pragma unroll
-            for (int s = 0; s < FU_MAXB; ++s)
+            for (int s = 0; s < NBLK; ++s)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) dst[(s * 16 + e) * 64 + lane] = acc[s][e];
         }
         __syncthreads();
         if (rsub < half) {
-            const float* src = red + (size_t)(set * (wps >> 1) + rsub) * (FU_MAXB * 16 * 64);
+            const float* src = red + (size_t)(SET * (wps >> 1) + rsub) * (FU_MAXB * 16 * 64);
 #pragma unroll
-            for (int s = 0; s < FU_MAXB; ++s)
+            for (int s = 0; s < NBLK; ++s)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[s][e] += src[(s * 16 + e) * 64 + lane];
         }
@@ -284,22 +344,34 @@ __device__ __forceinline__ void fused_valu_role(const FusedArgs& p, const ScStag
     if (rsub == 0) {
         float* out = p.accum + (int64_t)bin * p.floats_per_bin + (int64_t)p.abs_plane * p.n_tiles * SC_TILE_ELEMS;
 #pragma unroll
-        for (int s = 0; s < FU_MAXB; ++s) {
-            if (set * FU_MAXB + s < p.n_blocks32) {
+        for (int s = 0; s < NBLK; ++s) {
+            const int BIs = Tab::tab.bi[s], BJs = Tab::tab.bj[s];
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int i = BI[s] * 32 + li * 4 + (e >> 2), j = BJ[s] * 32 + lj * 4 + (e & 3);
-                    const int ti = i >> 4, tj = j >> 4;
-                    if (ti <= tj && tj < p.NB)
-                        out[(int64_t)sc_tile_index(ti, tj, p.NB) * SC_TILE_ELEMS + (i & 15) * 16 + (j & 15)] =
-                            acc[s][e];
-                }
+            for (int e = 0; e < 16; ++e) {
+                const int i = BIs * 32 + li * 4 + (e >> 2), j = BJs * 32 + lj * 4 + (e & 3);
+                const int ti = i >> 4, tj = j >> 4;
+                if (ti <= tj && tj < p.NB)
+                    out[(int64_t)sc_tile_index(ti, tj, p.NB) * SC_TILE_ELEMS + (i & 15) * 16 + (j & 15)] = acc[s][e];
             }
         }
     }
 }
 
-template <int MAX_SLOTS>
+template <int NB32>
+__device__ __forceinline__ void fused_valu_role(const FusedArgs& p, const ScStage& st, float* rows,
+                                                unsigned short* planes, int tid, int vw, int bin) {
+    constexpr int NSETS = fu_nsets(NB32);
+    constexpr int wps = 8 / NSETS;                        // VALU waves per block set (8 or 4)
+    const int set = vw / wps, rsub = vw % wps;
+    if constexpr (NSETS == 1) {
+        fused_valu_body<NB32, 0>(p, st, rows, planes, tid, rsub, wps, bin);
+    } else {
+        if (set == 0) fused_valu_body<NB32, 0>(p, st, rows, planes, tid, rsub, wps, bin);
+        else fused_valu_body<NB32, 1>(p, st, rows, planes, tid, rsub, wps, bin);
+    }
+}
+
+template <int NB32>
 __global__ void __launch_bounds__(FU_THREADS) fused_csm_absim_kernel(FusedArgs p) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -310,16 +382,16 @@ __global__ void __launch_bounds__(FU_THREADS) fused_csm_absim_kernel(FusedArgs p
     st.base = p.st.base + (int64_t)f * st.ax.sF + sc_group_offset(st.ax, g);
     float* rows = reinterpret_cast<float*>(smem);
     unsigned short* planes = reinterpret_cast<unsigned short*>(smem + (size_t)FU_OC * st.RS * sizeof(float));
-    if (wave < 4) fused_mfma_role<MAX_SLOTS>(p, st, rows, planes, tid, wave, bin);
-    else fused_valu_role(p, st, rows, planes, tid, wave - 4, bin);
+    if (wave < 4) fused_mfma_role<NB32>(p, st, rows, planes, tid, wave, bin);
+    else fused_valu_role<NB32>(p, st, rows, planes, tid, wave - 4, bin);
 }
 
-template <int MAX_SLOTS>
+template <int NB32>
 static int launch_fused(const FusedArgs& a, hipStream_t stream) {
-    size_t shmem = (size_t)FU_OC * a.st.RS * sizeof(float) + (size_t)6 * a.st.CP * FU_PSTRIDE * 2;
+    size_t shmem = (size_t)FU_OC * a.st.RS * sizeof(float) + (size_t)FU_NPLANES * a.st.CP * FU_PSTRIDE * 2;
     const size_t red = (size_t)4 * FU_MAXB * 16 * 64 * sizeof(float);
     if (shmem < red) shmem = red;
-    auto k = fused_csm_absim_kernel<MAX_SLOTS>;
+    auto k = fused_csm_absim_kernel<NB32>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     hipLaunchKernelGGL(k, dim3((unsigned)a.n_bins), dim3(FU_THREADS), shmem, stream, a);
     SC_CHECK_HIP(hipGetLastError());
@@ -354,7 +426,7 @@ extern "C" int sc_fused_csm_absim_f32(const void* d_X, const sc_spectra_desc* de
     a.n_tiles = sc_n_tiles(a.NB);
     a.NB32 = (ax.C + 31) / 32;
     a.n_blocks32 = a.NB32 * (a.NB32 + 1) / 2;
-    a.n_sets = (a.n_blocks32 + FU_MAXB - 1) / FU_MAXB;        // 1 or 2
+    a.n_sets = fu_nsets(a.NB32);
     a.n_bins = ax.n_groups * ax.F;
     a.F = ax.F;
     a.floats_per_bin = (int64_t)sc_plane_count(planes) * a.n_tiles * SC_TILE_ELEMS;
@@ -368,10 +440,15 @@ extern "C" int sc_fused_csm_absim_f32(const void* d_X, const sc_spectra_desc* de
     a.st.CP = a.NB32 * 32;                    // VALU blocks need 32-channel padding
     a.st.RS = sc_row_stride(a.st.CP);
     a.st.n_obs = ax.n_obs;
+    {
+        const char* dbg = getenv("SC_FUSED_DEBUG");
+        a.debug_skip = dbg ? atoi(dbg) : 0;
+    }
     hipStream_t s = (hipStream_t)stream;
-    const int need = (a.n_tiles + 3) / 4;
-    if (need <= 1) return launch_fused<1>(a, s);
-    if (need <= 3) return launch_fused<3>(a, s);
-    if (need <= 5) return launch_fused<5>(a, s);
-    return launch_fused<9>(a, s);
+    switch (a.NB32) {
+    case 1: return launch_fused<1>(a, s);
+    case 2: return launch_fused<2>(a, s);
+    case 3: return launch_fused<3>(a, s);
+    default: return launch_fused<4>(a, s);
+    }
 }
