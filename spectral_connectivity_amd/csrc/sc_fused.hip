@@ -12,15 +12,20 @@
 // are <= 2^-25 relative, below f32 rounding), leaving the f32 VALU free for the per-observation
 // non-linearity  acc += |Im(x_i conj x_j)|  at 3 instructions per channel pair.
 //
-// Workgroup = 12 waves = one output bin (C <= 128, even).  Every SIMD hosts 1 MFMA wave and
-// 2 VALU waves (a single wave issues one VALU op per ~5 cycles; two interleave to the pipe
-// rate).  All waves stage a chunk of 32 observation rows HBM -> registers -> LDS twice:
-//   rows   [obs][Re(ch) | Im(ch)] float     for the VALU waves (ds_read_b128, 4x4 pair tiles)
-//   planes [9][channel][obs] bf16           for the MFMA waves (ds_read_b128 = 8 obs of one
-//                                           channel = one 16x16x32 operand fragment; planes 6-8
-//                                           hold -Re so Im needs no negation in registers)
-// so the 6.5 GB of spectra of the headline configuration are read from HBM once for both
-// products (the unfused path reads them twice).
+// Workgroup = 12 waves = one output bin (C <= 128, even).  Every SIMD hosts 1 "CSM" wave and
+// 2 "abs" waves.  A chunk of 32 observation rows is staged HBM -> registers -> LDS as bf16 pieces
+// (h, m, l of Re and Im, exact 3-way split of every f32 coefficient) in two layouts:
+//   planes [6][channel][obs] bf16          K = observations: operand fragments of the rank-n_obs
+//                                          update S += X^H X (v_mfma_f32_16x16x32_bf16, six leading
+//                                          cross terms hh hm mh mm hl lh per product, f32 accumulate)
+//   recs   [obs][Re|Im][channel] {h,m,l,0} K = the six cross terms of ONE observation: a single
+//                                          v_mfma_f32_32x32x16_bf16 with C = 0 returns the per-
+//                                          observation Im(x_i conj x_j) of a 32x32 channel block at
+//                                          f32 accuracy, and the VALU only does acc += |d| (16
+//                                          instructions per 1024 pairs instead of 3 per pair).
+// The non-linearity (|.| before the expectation) is what keeps this from being a GEMM; moving its
+// products onto the idle bf16 matrix pipe cut the VALU work 2.5x (round-1 v3 -> v4: 7.9 -> see
+// DESIGN.md).  The spectra are read from HBM once for both products.
 #include <stdlib.h>
 #include "sc_stage.h"
 
@@ -33,7 +38,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define FU_THREADS 768
 #define FU_MAXB 5
 #define FU_FLUSH 16         // chunks between folds of the MFMA accumulators into the output record
-#define FU_PSTRIDE 40       // bf16 elements per (plane, channel): 32 obs + 8 pad -> 80 B, conflict-free b128
+#define FU_PSTRIDE 48       // bf16 per (plane, channel): 32 obs + 16 pad -> 96 B: conflict-free for the b128
+                            // fragment reads AND for the b64 staging writes (lanes = obs quad x channel pair)
 
 struct FusedArgs {
     ScStage st;
@@ -68,8 +74,11 @@ __device__ __forceinline__ void split4(const float x[4], uint2& h, uint2& m, uin
 // accumulators and fragments.
 struct FuRegs { float4 v[4]; };
 
+// lane -> (observation quad oq = lane & 7, channel pair q = 8 * staging wave + lane / 8): a 16-lane
+// write group then covers 8 consecutive 8-byte obs quads of two channels 2 apart, i.e. all 32 LDS
+// banks exactly once for the plane stores; global loads stay full 128-byte lines (8 pairs x 16 B).
 __device__ __forceinline__ void fu_load(const ScStage& st, int o0, int tid, FuRegs& r) {
-    const int q = tid & 63, oq = (tid >> 6) - 4;
+    const int lane = tid & 63, oq = lane & 7, q = ((tid >> 6) - 4) * 8 + (lane >> 3);
     const int c = 2 * q;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -81,20 +90,24 @@ __device__ __forceinline__ void fu_load(const ScStage& st, int o0, int tid, FuRe
     }
 }
 
-__device__ __forceinline__ void fu_store(const ScStage& st, float* rows, unsigned short* planes, int tid,
+__device__ __forceinline__ unsigned perm_b32(unsigned a, unsigned b, unsigned sel) {
+    return __builtin_amdgcn_perm(a, b, sel);     // bytes 0-3 of sel pick from b, 4-7 from a
+}
+
+// record of observation k (0..3 of the quad) of one component: {h | m << 16, l}
+__device__ __forceinline__ uint2 make_rec(const uint2& h, const uint2& m, const uint2& l, int k) {
+    const unsigned hh = (k < 2) ? h.x : h.y, mm = (k < 2) ? m.x : m.y, ll = (k < 2) ? l.x : l.y;
+    return (k & 1) ? make_uint2(perm_b32(mm, hh, 0x07060302u), ll >> 16)
+                   : make_uint2(perm_b32(mm, hh, 0x05040100u), ll & 0xffffu);
+}
+
+__device__ __forceinline__ void fu_store(const ScStage& st, uint2* recs, unsigned short* planes, int tid,
                                          const FuRegs& r) {
-    const int q = tid & 63, oq = (tid >> 6) - 4;
+    const int lane = tid & 63, oq = lane & 7, q = ((tid >> 6) - 4) * 8 + (lane >> 3);
     if (2 * q >= st.CP) return;
-    // rows are PLANAR per observation: [Re of CP channels | Im of CP channels], so four consecutive
-    // channels' Re (or Im) are one aligned float4 = two 64-bit register pairs for v_pk_* operands
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        float* rowp = rows + (oq * 4 + k) * st.RS + 2 * q;
-        *reinterpret_cast<float2*>(rowp) = make_float2(r.v[k].x, r.v[k].z);
-        *reinterpret_cast<float2*>(rowp + st.CP) = make_float2(r.v[k].y, r.v[k].w);
-    }
-    // planes: 0 re_h 1 re_m 2 re_l 3 im_h 4 im_m 5 im_l 6..8 -(re_h, re_m, re_l); element (plane, ch, obs)
+    // planes: 0 re_h 1 re_m 2 re_l 3 im_h 4 im_m 5 im_l ; element (plane, ch, obs)
     const int plane_elems = st.CP * FU_PSTRIDE;
+    uint2 h[2][2], m[2][2], l[2][2];          // [channel][Re|Im]
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc) {
         float re[4], im[4];
@@ -103,35 +116,49 @@ __device__ __forceinline__ void fu_store(const ScStage& st, float* rows, unsigne
             re[k] = cc ? r.v[k].z : r.v[k].x;
             im[k] = cc ? r.v[k].w : r.v[k].y;
         }
-        uint2 h, m, l;
         unsigned short* base = planes + (2 * q + cc) * FU_PSTRIDE + oq * 4;
-        split4(re, h, m, l);
-        *reinterpret_cast<uint2*>(base) = h;
-        *reinterpret_cast<uint2*>(base + plane_elems) = m;
-        *reinterpret_cast<uint2*>(base + 2 * plane_elems) = l;
-        *reinterpret_cast<uint2*>(base + 6 * plane_elems) = make_uint2(h.x ^ 0x80008000u, h.y ^ 0x80008000u);
-        *reinterpret_cast<uint2*>(base + 7 * plane_elems) = make_uint2(m.x ^ 0x80008000u, m.y ^ 0x80008000u);
-        *reinterpret_cast<uint2*>(base + 8 * plane_elems) = make_uint2(l.x ^ 0x80008000u, l.y ^ 0x80008000u);
-        split4(im, h, m, l);
-        *reinterpret_cast<uint2*>(base + 3 * plane_elems) = h;
-        *reinterpret_cast<uint2*>(base + 4 * plane_elems) = m;
-        *reinterpret_cast<uint2*>(base + 5 * plane_elems) = l;
+        split4(re, h[cc][0], m[cc][0], l[cc][0]);
+        *reinterpret_cast<uint2*>(base) = h[cc][0];
+        *reinterpret_cast<uint2*>(base + plane_elems) = m[cc][0];
+        *reinterpret_cast<uint2*>(base + 2 * plane_elems) = l[cc][0];
+        split4(im, h[cc][1], m[cc][1], l[cc][1]);
+        *reinterpret_cast<uint2*>(base + 3 * plane_elems) = h[cc][1];
+        *reinterpret_cast<uint2*>(base + 4 * plane_elems) = m[cc][1];
+        *reinterpret_cast<uint2*>(base + 5 * plane_elems) = l[cc][1];
     }
+    // recs[obs][part][channel]: channels 2q, 2q+1 are adjacent -> one 16-byte store per (obs, part)
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            const uint2 a = make_rec(h[0][part], m[0][part], l[0][part], k);
+            const uint2 b = make_rec(h[1][part], m[1][part], l[1][part], k);
+            // 16-byte slots of a row are XOR-swizzled by the obs quad so the 8 lanes of a write group
+            // (same q, oq = 0..7) hit 8 different slots; readers apply the same XOR (fu_rec_index)
+            *reinterpret_cast<uint4*>(recs + ((oq * 4 + k) * 2 + part) * st.CP + 2 * (q ^ oq)) =
+                make_uint4(a.x, a.y, b.x, b.y);
+        }
 }
 
 
+__device__ __forceinline__ bf16x8 neg8(bf16x8 v) {
+    u32x4 u = __builtin_bit_cast(u32x4, v);
+    u ^= 0x80008000u;
+    return __builtin_bit_cast(bf16x8, u);
+}
+
 #define FU_MFMA(a, b, c) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
-#define FU_NPLANES 9
+#define FU_NPLANES 6
 
 // The two roles are separate functions so their accumulators never coexist in registers.
 // Both execute the same barrier sequence: per chunk 2 barriers, then 2*log2(waves per set).
 //
 // MFMA role.  Wave w owns tile rows w and NB-1-w of the upper triangle (NB+1 tiles for even NB):
-// the nine A fragments of a row (Re, Im, -Re x h,m,l) are loaded once per row and chunk, the six B
+// the six A fragments of a row (Re, Im x h,m,l; -Re by a sign flip in registers) are loaded once per row and chunk, the six B
 // fragments per tile, and the first two B fragments of the NEXT tile are prefetched under the 24
 // MFMAs of the current one.
 template <int NB32>
-__device__ __forceinline__ void fused_mfma_role(const FusedArgs& p, const ScStage& st, float* rows,
+__device__ __forceinline__ void fused_mfma_role(const FusedArgs& p, const ScStage& st, uint2* recs,
                                                 unsigned short* planes, int tid, int wave, int bin) {
     constexpr int MAXS = 2 * NB32 + 1;
     const int lane = tid & 63;
@@ -171,10 +198,10 @@ __device__ __forceinline__ void fused_mfma_role(const FusedArgs& p, const ScStag
                         const unsigned short* fa = frag0 + row * 16 * FU_PSTRIDE;
                         arh = FU_LD(fa, 0); arm = FU_LD(fa, 1); arl = FU_LD(fa, 2);
                         aih = FU_LD(fa, 3); aim = FU_LD(fa, 4); ail = FU_LD(fa, 5);
-                        nrh = FU_LD(fa, 6); nrm = FU_LD(fa, 7); nrl = FU_LD(fa, 8);
+                        nrh = neg8(arh); nrm = neg8(arm); nrl = neg8(arl);
                     }
                     const unsigned short* fb = frag0 + col * 16 * FU_PSTRIDE;
-                    const bf16x8 brm = FU_LD(fb, 1), bimm = FU_LD(fb, 4), brl = FU_LD(fb, 2), bil = FU_LD(fb, 5);
+                    const bf16x8 cbrm = FU_LD(fb, 1), cbim = FU_LD(fb, 4), cbrl = FU_LD(fb, 2), cbil = FU_LD(fb, 5);
                     const bf16x8 cbrh = brh, cbih = bih;
                     if (s + 1 < total) {      // prefetch the next tile's first fragments
                         const bool na = (s + 1) < nA;
@@ -186,14 +213,14 @@ __device__ __forceinline__ void fused_mfma_role(const FusedArgs& p, const ScStag
                     // Re += ar*br + ai*bi ; Im += ai*br + (-ar)*bi   (two chains, interleaved)
                     FU_MFMA(arh, cbrh, re[s]);  FU_MFMA(aih, cbrh, im[s]);
                     FU_MFMA(aih, cbih, re[s]);  FU_MFMA(nrh, cbih, im[s]);
-                    FU_MFMA(arh, brm, re[s]);   FU_MFMA(aih, brm, im[s]);
-                    FU_MFMA(aih, bimm, re[s]);  FU_MFMA(nrh, bimm, im[s]);
+                    FU_MFMA(arh, cbrm, re[s]);   FU_MFMA(aih, cbrm, im[s]);
+                    FU_MFMA(aih, cbim, re[s]);  FU_MFMA(nrh, cbim, im[s]);
                     FU_MFMA(arm, cbrh, re[s]);  FU_MFMA(aim, cbrh, im[s]);
                     FU_MFMA(aim, cbih, re[s]);  FU_MFMA(nrm, cbih, im[s]);
-                    FU_MFMA(arm, brm, re[s]);   FU_MFMA(aim, brm, im[s]);
-                    FU_MFMA(aim, bimm, re[s]);  FU_MFMA(nrm, bimm, im[s]);
-                    FU_MFMA(arh, brl, re[s]);   FU_MFMA(aih, brl, im[s]);
-                    FU_MFMA(aih, bil, re[s]);   FU_MFMA(nrh, bil, im[s]);
+                    FU_MFMA(arm, cbrm, re[s]);   FU_MFMA(aim, cbrm, im[s]);
+                    FU_MFMA(aim, cbim, re[s]);  FU_MFMA(nrm, cbim, im[s]);
+                    FU_MFMA(arh, cbrl, re[s]);   FU_MFMA(aih, cbrl, im[s]);
+                    FU_MFMA(aih, cbil, re[s]);   FU_MFMA(nrh, cbil, im[s]);
                     FU_MFMA(arl, cbrh, re[s]);  FU_MFMA(ail, cbrh, im[s]);
                     FU_MFMA(ail, cbih, re[s]);  FU_MFMA(nrl, cbih, im[s]);
                 }
@@ -269,60 +296,88 @@ struct FuTab {
     static constexpr Arr tab = make();
 };
 
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// "abs" role: per observation row and 32x32 channel block ONE v_mfma_f32_32x32x16_bf16 with C = 0
+// yields d = Im(x_i conj x_j) for the 1024 pairs of the block (K = 16 slots: lanes 0-31 carry the
+// six cross terms of Im(x_i) Re(x_j), lanes 32-63 those of Re(x_i) (-Im(x_j))), then acc += |d|.
+//   A operand (row channel i):  P(v) = [h h | m h | l m | 0 0]      v = Im x_i (lanes 0-31) / Re x_i
+//   B operand (col channel j):  Q(v) = [h m | h l | h m | 0 0]      v = Re x_j (lanes 0-31) / -Im x_j
+// slot products: h.h  h.m  m.h  h.l  l.h  m.m  (the six leading terms of (h+m+l)(h+m+l)).
+struct FuFragA { unsigned d0, d1, d2; };
+struct FuFragB { unsigned d0, d1; };
+__device__ __forceinline__ FuFragA fu_frag_a(uint2 r) {
+    FuFragA f;
+    f.d0 = perm_b32(r.x, r.x, 0x01000100u);        // (h, h)
+    f.d1 = __builtin_amdgcn_alignbit(r.x, r.x, 16);  // (m, h)
+    f.d2 = perm_b32(r.x, r.y, 0x07060100u);        // (l, m)
+    return f;
+}
+__device__ __forceinline__ FuFragB fu_frag_b(uint2 r, unsigned negmask) {
+    FuFragB f;
+    f.d0 = r.x ^ negmask;                                   // (h, m)
+    f.d1 = perm_b32(r.y, r.x, 0x05040100u) ^ negmask;       // (h, l)
+    return f;
+}
+
 template <int NB32, int SET>
-__device__ __forceinline__ void fused_valu_body(const FusedArgs& p, const ScStage& st, float* rows,
+__device__ __forceinline__ void fused_valu_body(const FusedArgs& p, const ScStage& st, uint2* recs,
                                                 unsigned short* planes, int tid, int rsub, int wps, int bin) {
     using Tab = FuTab<NB32, SET>;
     constexpr int NBLK = Tab::NBLK;
     const int lane = tid & 63;
-    float acc[NBLK > 0 ? NBLK : 1][16];
+    f32x16 acc[NBLK > 0 ? NBLK : 1];
 #pragma unroll
     for (int s = 0; s < NBLK; ++s)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[s][e] = 0.f;
     const int n_chunks = (st.n_obs + FU_OC - 1) / FU_OC;
-    const int li = lane >> 3, lj = lane & 7;
+    const int i32 = lane & 31, hf = lane >> 5;
+    const unsigned negmask = hf ? 0x80008000u : 0u;
+    // per-lane record offsets inside an observation row: A reads Im (lanes 0-31) / Re (32-63),
+    // B reads Re (lanes 0-31) / Im (32-63)
+    const int offA = (hf ? 0 : st.CP), offB = (hf ? st.CP : 0);
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     FuRegs regs;
     fu_load(st, 0, tid, regs);
     for (int ch = 0; ch < n_chunks; ++ch) {
-        fu_store(st, rows, planes, tid, regs);
+        fu_store(st, recs, planes, tid, regs);
         __syncthreads();
-        if (ch + 1 < n_chunks) fu_load(st, (ch + 1) * FU_OC, tid, regs);
+        if (ch + 1 < n_chunks && !(p.debug_skip & 8)) fu_load(st, (ch + 1) * FU_OC, tid, regs);
         // zero rows past n_obs contribute |0| = 0: no bound needed for this plane
         for (int row = ((p.debug_skip & 2) ? FU_OC : rsub); row < FU_OC; row += wps) {
-            const float* rp = rows + row * st.RS;
-            float4 XIre[NB32], XIim[NB32], XJre[NB32], XJim[NB32];
+            const uint2* rp = recs + row * 2 * st.CP;
+            // channel c lives at slot ((c >> 1) ^ (row >> 2)) * 2 + (c & 1): XOR of the pair index
+            // with the obs quad (< 8) only permutes pairs inside a 16-channel group
+            const int sw = (((i32 >> 1) ^ (row >> 2)) << 1) | (i32 & 1);
+            FuFragA FA[NB32];
+            FuFragB FB[NB32];
 #pragma unroll
             for (int b = 0; b < NB32; ++b) {
-                if (Tab::tab.use_i[b]) {
-                    XIre[b] = *reinterpret_cast<const float4*>(rp + b * 32 + li * 4);
-                    XIim[b] = *reinterpret_cast<const float4*>(rp + st.CP + b * 32 + li * 4);
-                }
-                if (Tab::tab.use_j[b]) {
-                    XJre[b] = *reinterpret_cast<const float4*>(rp + b * 32 + lj * 4);
-                    XJim[b] = *reinterpret_cast<const float4*>(rp + st.CP + b * 32 + lj * 4);
-                }
+                if (Tab::tab.use_i[b]) FA[b] = fu_frag_a(rp[offA + b * 32 + sw]);
+                if (Tab::tab.use_j[b]) FB[b] = fu_frag_b(rp[offB + b * 32 + sw], negmask);
             }
+            f32x16 dprev;
 #pragma unroll
             for (int s = 0; s < NBLK; ++s) {
                 const int bi = Tab::tab.bi[s], bj = Tab::tab.bj[s];
-                const float4 ire = XIre[bi], iim = XIim[bi], jre = XJre[bj], jim = XJim[bj];
-                // 3 VALU instructions per pair (v_mul, v_fma, v_add with |.| source modifier).  Packed
-                // v_pk_mul/v_pk_fma_f32 (2 issues per 2 pairs) measured SLOWER here (6.9 vs 6.1 ms): the
-                // loop is VALU-pipe bound, not issue bound, and packed f32 ops take twice the pipe time.
-                const float are[4] = {ire.x, ire.y, ire.z, ire.w}, aim[4] = {iim.x, iim.y, iim.z, iim.w};
-                const float bre[4] = {jre.x, jre.y, jre.z, jre.w}, bim[4] = {jim.x, jim.y, jim.z, jim.w};
+                const u32x4 ua = {FA[bi].d0, FA[bi].d1, FA[bi].d2, 0u};
+                const u32x4 ub = {FB[bj].d0, FB[bj].d1, FB[bj].d0, 0u};
+                const f32x16 d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                    __builtin_bit_cast(bf16x8, ua), __builtin_bit_cast(bf16x8, ub), zero, 0, 0, 0);
+                if (s > 0) {
 #pragma unroll
-                for (int a = 0; a < 4; ++a)
-#pragma unroll
-                    for (int b = 0; b < 4; ++b)
-                        acc[s][a * 4 + b] += fabsf(aim[a] * bre[b] - are[a] * bim[b]);
+                    for (int e = 0; e < 16; ++e) acc[s - 1][e] += fabsf(dprev[e]);
+                }
+                dprev = d;
             }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[NBLK - 1][e] += fabsf(dprev[e]);
         }
         __syncthreads();
     }
-    // tree-sum the row-split partials of a set through LDS (rows + planes region, 20 KB per writer)
-    float* red = rows;
+    // tree-sum the row-split partials of a set through LDS (planes region, 20 KB per writer)
+    float* red = reinterpret_cast<float*>(planes);
     for (int half = wps >> 1; half >= 1; half >>= 1) {
         if (rsub >= half && rsub < 2 * half) {
             float* dst = red + (size_t)(SET * (wps >> 1) + (rsub - half)) * (FU_MAXB * 16 * 64);
@@ -342,13 +397,14 @@ __device__ __forceinline__ void fused_valu_body(const FusedArgs& p, const ScStag
         __syncthreads();
     }
     if (rsub == 0) {
+        // D layout of v_mfma_f32_32x32x16_bf16: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
         float* out = p.accum + (int64_t)bin * p.floats_per_bin + (int64_t)p.abs_plane * p.n_tiles * SC_TILE_ELEMS;
 #pragma unroll
         for (int s = 0; s < NBLK; ++s) {
             const int BIs = Tab::tab.bi[s], BJs = Tab::tab.bj[s];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int i = BIs * 32 + li * 4 + (e >> 2), j = BJs * 32 + lj * 4 + (e & 3);
+                const int i = BIs * 32 + (e & 3) + 8 * (e >> 2) + 4 * hf, j = BJs * 32 + i32;
                 const int ti = i >> 4, tj = j >> 4;
                 if (ti <= tj && tj < p.NB)
                     out[(int64_t)sc_tile_index(ti, tj, p.NB) * SC_TILE_ELEMS + (i & 15) * 16 + (j & 15)] = acc[s][e];
@@ -358,16 +414,16 @@ __device__ __forceinline__ void fused_valu_body(const FusedArgs& p, const ScStag
 }
 
 template <int NB32>
-__device__ __forceinline__ void fused_valu_role(const FusedArgs& p, const ScStage& st, float* rows,
+__device__ __forceinline__ void fused_valu_role(const FusedArgs& p, const ScStage& st, uint2* recs,
                                                 unsigned short* planes, int tid, int vw, int bin) {
     constexpr int NSETS = fu_nsets(NB32);
     constexpr int wps = 8 / NSETS;                        // VALU waves per block set (8 or 4)
     const int set = vw / wps, rsub = vw % wps;
     if constexpr (NSETS == 1) {
-        fused_valu_body<NB32, 0>(p, st, rows, planes, tid, rsub, wps, bin);
+        fused_valu_body<NB32, 0>(p, st, recs, planes, tid, rsub, wps, bin);
     } else {
-        if (set == 0) fused_valu_body<NB32, 0>(p, st, rows, planes, tid, rsub, wps, bin);
-        else fused_valu_body<NB32, 1>(p, st, rows, planes, tid, rsub, wps, bin);
+        if (set == 0) fused_valu_body<NB32, 0>(p, st, recs, planes, tid, rsub, wps, bin);
+        else fused_valu_body<NB32, 1>(p, st, recs, planes, tid, rsub, wps, bin);
     }
 }
 
@@ -380,17 +436,22 @@ __global__ void __launch_bounds__(FU_THREADS) fused_csm_absim_kernel(FusedArgs p
     const int g = bin / p.F, f = bin - g * p.F;
     ScStage st = p.st;
     st.base = p.st.base + (int64_t)f * st.ax.sF + sc_group_offset(st.ax, g);
-    float* rows = reinterpret_cast<float*>(smem);
-    unsigned short* planes = reinterpret_cast<unsigned short*>(smem + (size_t)FU_OC * st.RS * sizeof(float));
-    if (wave < 4) fused_mfma_role<NB32>(p, st, rows, planes, tid, wave, bin);
-    else fused_valu_role<NB32>(p, st, rows, planes, tid, wave - 4, bin);
+    // LDS: planes first (also the scratch of the final tree reduction), then the records
+    unsigned short* planes = reinterpret_cast<unsigned short*>(smem);
+    size_t plane_bytes = (size_t)FU_NPLANES * st.CP * FU_PSTRIDE * 2;
+    const size_t red_bytes = (size_t)4 * FU_MAXB * 16 * 64 * sizeof(float);
+    if (plane_bytes < red_bytes) plane_bytes = red_bytes;
+    uint2* recs = reinterpret_cast<uint2*>(smem + plane_bytes);
+    if (wave < 4) fused_mfma_role<NB32>(p, st, recs, planes, tid, wave, bin);
+    else fused_valu_role<NB32>(p, st, recs, planes, tid, wave - 4, bin);
 }
 
 template <int NB32>
 static int launch_fused(const FusedArgs& a, hipStream_t stream) {
-    size_t shmem = (size_t)FU_OC * a.st.RS * sizeof(float) + (size_t)FU_NPLANES * a.st.CP * FU_PSTRIDE * 2;
+    size_t plane_bytes = (size_t)FU_NPLANES * a.st.CP * FU_PSTRIDE * 2;
     const size_t red = (size_t)4 * FU_MAXB * 16 * 64 * sizeof(float);
-    if (shmem < red) shmem = red;
+    if (plane_bytes < red) plane_bytes = red;
+    const size_t shmem = plane_bytes + (size_t)FU_OC * 2 * a.st.CP * sizeof(uint2);
     auto k = fused_csm_absim_kernel<NB32>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     hipLaunchKernelGGL(k, dim3((unsigned)a.n_bins), dim3(FU_THREADS), shmem, stream, a);
