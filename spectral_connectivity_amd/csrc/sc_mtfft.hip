@@ -245,9 +245,14 @@ __global__ void __launch_bounds__(256) mtfft16_kernel(MtArgs p) {
     constexpr int XS = CT + 2;           // padded window-row stride (floats)
     constexpr int ZS = N + N / 16 + 1;   // skewed exchange buffer per FFT (float2), odd stride
     extern __shared__ __align__(16) unsigned char smem[];
+    // The window tile lives in LDS only until every thread has pulled its 16 x 2 samples into
+    // registers (they are the same for all tapers); the exchange buffer z then reuses that space,
+    // so a workgroup needs ~44 KB instead of ~78 KB and three of them fit a CU.
+    constexpr size_t XT_BYTES = (size_t)N * XS * 4, Z_BYTES = (size_t)NF * ZS * 8;
+    constexpr size_t UNION_BYTES = XT_BYTES > Z_BYTES ? XT_BYTES : Z_BYTES;
     float* xt = reinterpret_cast<float*>(smem);                                   // [N][XS]
-    float2* z = reinterpret_cast<float2*>(smem + (size_t)N * XS * 4);             // [NF][ZS]
-    float2* tw = z + NF * ZS;                                                     // [N]
+    float2* z = reinterpret_cast<float2*>(smem);                                  // [NF][ZS] (aliases xt)
+    float2* tw = reinterpret_cast<float2*>(smem + UNION_BYTES);                   // [N]
     float* hk = reinterpret_cast<float*>(tw + N);                                 // [N] current taper
     double* red = reinterpret_cast<double*>(hk + N);                              // [2][256] + trend [2][CT]
 
@@ -305,23 +310,25 @@ __global__ void __launch_bounds__(256) mtfft16_kernel(MtArgs p) {
     const int F = N / 2 + 1;
     const int64_t sF = (int64_t)p.W * p.R * p.K * C;
     const bool vec_ok = (C % 2) == 0;
+    __syncthreads();                                  // detrended tile complete
+    float2 xs[16];                                    // this thread's pass-1 inputs, all tapers
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int n = i + t * TPF;
+        xs[t] = (n < L) ? *reinterpret_cast<const float2*>(xt + n * XS + 2 * pf) : make_float2(0.f, 0.f);
+    }
 #define PHYS(idx) ((idx) + ((idx) >> 4))
     for (int k = 0; k < p.K; ++k) {
         const float* hg = p.tapers + (int64_t)k * L;
         for (int n = tid; n < L; n += 256) hk[n] = hg[n];
-        __syncthreads();     // taper k (and, first time, the detrended tile) visible; post of k-1 done
+        __syncthreads();     // taper k visible; post of k-1 (and, first time, the tile reads) done
         float2 a[16], o[16];
         // pass 1: radix 16, P = 1, inputs straight from the window tile
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             const int n = i + t * TPF;
-            float2 v = make_float2(0.f, 0.f);
-            if (n < L) {
-                const float h = hk[n];
-                const float2 xv = *reinterpret_cast<const float2*>(xt + n * XS + 2 * pf);
-                v = make_float2(xv.x * h, xv.y * h);
-            }
-            a[t] = v;
+            const float h = (n < L) ? hk[n] : 0.f;
+            a[t] = make_float2(xs[t].x * h, xs[t].y * h);
         }
         dft16(a, o);
 #pragma unroll
@@ -432,8 +439,8 @@ template <int LOG2N>
 static int launch_mt16(const MtArgs& a, hipStream_t stream) {
     constexpr int N = 1 << LOG2N;
     constexpr int TPF = N / 16, NF = 256 / TPF, CT = 2 * NF;
-    constexpr size_t shmem = (size_t)N * (CT + 2) * 4 + (size_t)NF * (N + N / 16 + 1) * 8 + (size_t)N * 8 +
-                             (size_t)N * 4 + (size_t)(512 + 2 * CT) * 8;
+    constexpr size_t xt_b = (size_t)N * (CT + 2) * 4, z_b = (size_t)NF * (N + N / 16 + 1) * 8;
+    constexpr size_t shmem = (xt_b > z_b ? xt_b : z_b) + (size_t)N * 8 + (size_t)N * 4 + (size_t)(512 + 2 * CT) * 8;
     static_assert(shmem <= 160 * 1024, "LDS budget exceeded");
     auto k = mtfft16_kernel<LOG2N>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
