@@ -36,6 +36,8 @@ from spectral_connectivity_amd.transforms import _make_tapers  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32 dense peak
+# HBM bytes per launch of the dominant kernel, measured with rocprofv3 --pmc (profiles/r01_hbm_traffic.txt)
+MEASURED_TRAFFIC_BYTES = {("cfg3", "fused_csm_absim"): 8.47e9, ("cfg3", "mtfft_fused"): 7.39e9}
 
 CONFIGS = {
     # name: T, R, C, NW, L, step
@@ -99,16 +101,17 @@ def one_step(x, h, cfg, geom, planes, world, timer=None):
     return coh, wpli
 
 
-def cpu_baseline(cfg, geom, budget_trials=1):
+def cpu_baseline(cfg, geom, budget_trials=4):
     """Time the oracle's faithful (reference op-for-op) path on `budget_trials` trials."""
     from oracle import spectral_oracle as so
     L, step, N, W = geom
     x = synth(cfg, 0, budget_trials, "cpu", seed=3).numpy().astype(np.float64)
     t0 = time.perf_counter()
-    coef, _ = so.multitaper_fft(x, fs=FS, NW=cfg["NW"], n_time_samples_per_window=L,
-                                n_time_samples_per_step=step)
-    so.coherence_magnitude(coef)
-    so.weighted_phase_lag_index(coef)
+    for r in range(budget_trials):          # one trial at a time: bounds the (W,1,K,N,C,C) temporary to 3.3 GB
+        coef, _ = so.multitaper_fft(x[:, r:r + 1], fs=FS, NW=cfg["NW"], n_time_samples_per_window=L,
+                                    n_time_samples_per_step=step)
+        so.coherence_magnitude(coef)
+        so.weighted_phase_lag_index(coef)
     dt = time.perf_counter() - t0
     return dt
 
@@ -200,14 +203,30 @@ def main():
         achieved, peak, unit = work / dur_s / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
     else:
         achieved, peak, unit = work / dur_s / 1e9, HBM_PEAK_GBS, "GB/s"
+    def stage_roof(name):
+        b, wk = stage_model[name]
+        d = stage_ms[name] * 1e-3
+        if b == "mfma":
+            return {"bound": b, "achieved": round(wk / d / 1e12, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(wk / d / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)}
+        return {"bound": b, "achieved": round(wk / d / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(wk / d / 1e9 / HBM_PEAK_GBS, 4)}
+
     roofline = {"kernel": dominant, "bound": bound, "achieved": round(achieved, 3), "peak": peak,
-                "unit": unit, "frac": round(achieved / peak, 4), "traffic": None,
+                "unit": unit, "frac": round(achieved / peak, 4),
+                # HBM bytes per launch from rocprofv3 PMC (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE),
+                # collected offline: profiles/r01_hbm_traffic.txt; null when the dominant kernel differs
+                "traffic": MEASURED_TRAFFIC_BYTES.get((args.config, dominant)) if world == 1 else None,
                 "kernel_ms": round(stage_ms[dominant], 4),
-                "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()}}
+                "note": ("f32-equivalent flops of the Hermitian rank-n_obs update (8*n_obs*C(C+1)/2 per bin, "
+                         "triangle only) over the f32 MFMA peak; the kernel runs them as six bf16 cross terms "
+                         "and also produces the per-observation |Im s| plane in the same launch"),
+                "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+                "stages": {k: stage_roof(k) for k in stage_ms if k in stage_model}}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        n_sample = 1
+        n_sample = 4
         dt = cpu_baseline(cfg, geom, n_sample)
         cpu = {"value": round(units / (dt * cfg["R"] / n_sample), 3), "unit": "channel-pair*freq-bins/s",
                "cores": 1, "kind": "port",

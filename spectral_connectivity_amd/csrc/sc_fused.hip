@@ -47,7 +47,8 @@ struct FusedArgs {
     int64_t floats_per_bin;
     int n_bins, F, NB, n_tiles, NB32, n_blocks32, n_sets;
     int csm_plane, abs_plane;
-    int debug_skip;      // profiling aid (SC_FUSED_DEBUG): 1 = MFMA waves idle, 2 = VALU waves idle
+    int debug_skip;      // profiling aid (env SC_FUSED_DEBUG, bit mask; results are WRONG when set):
+                         // 1 = CSM waves skip their MFMAs, 2 = abs waves skip theirs, 8 = no HBM loads
 };
 
 __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
