@@ -10,7 +10,7 @@ One "step" = one full pass of the hot path over the synthetic batch, inputs resi
   stage A  window/detrend/taper (HIP) + batched R2C FFT (rocFFT)
   stage B  cross-spectral accumulation (MFMA) + |Im s| plane (VALU)
   (N>1)    reduce-scatter of the accumulator records over RCCL
-  stage C  coherence + wPLI epilogue on the owned bins, (N>1) all-gather of the measures
+  stage C  coherence + wPLI epilogue on the owned bins, (N>1) gather of the measures on rank 0
 N GPUs: the 1000 trials are sharded over the ranks (strong scaling), one process per GPU.
 
 Prints ONE JSON line on rank 0 (see the driver contract), with `roofline` for the dominant
@@ -94,10 +94,10 @@ def one_step(x, h, cfg, geom, planes, world, timer=None):
     coh = engine.measure(shard, cfg["C"], planes, n_total, _lib.M_COHERENCE_MAGNITUDE)
     wpli = engine.measure(shard, cfg["C"], planes, n_total, _lib.M_WPLI)
     mark("measure_epilogue")
-    if world > 1:
-        coh = parallel.all_gather_bins(coh, n_bins)
-        wpli = parallel.all_gather_bins(wpli, n_bins)
-        mark("all_gather")
+    if world > 1:       # final measures assembled on rank 0 (the process a Connectivity user talks to)
+        coh = parallel.gather_bins(coh, n_bins, dst=0)
+        wpli = parallel.gather_bins(wpli, n_bins, dst=0)
+        mark("gather")
     return coh, wpli
 
 

@@ -366,12 +366,17 @@ __device__ __forceinline__ void fused_valu_body(const FusedArgs& p, const ScStag
                 const u32x4 ub = {FB[bj].d0, FB[bj].d1, FB[bj].d0, 0u};
                 const f32x16 d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                     __builtin_bit_cast(bf16x8, ua), __builtin_bit_cast(bf16x8, ub), zero, 0, 0, 0);
+                // keep the software pipeline: the |d| accumulation of block s-1 must be issued AFTER the
+                // MFMA of block s (otherwise hipcc sinks each MFMA next to its consumer and the wave sits
+                // out the 64-cycle MFMA latency 40 times per chunk)
+                __builtin_amdgcn_sched_barrier(0);
                 if (s > 0) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[s - 1][e] += fabsf(dprev[e]);
                 }
                 dprev = d;
             }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[NBLK - 1][e] += fabsf(dprev[e]);
         }

@@ -5,7 +5,8 @@ accumulator plane (reference connectivity.py:67-75, :489), so trials shard embar
 each rank runs stages A and B on its own trials, then ONE exchange sums the un-normalised
 accumulator records.  The exchange is a reduce-scatter over frequency/window bins (each
 rank ends up owning 1/N of the bins, summed over all ranks), the measures epilogue runs on
-the owned bins only, and an all-gather assembles the final measures -- 2(N-1)/N of the data
+the owned bins only, and a gather assembles the final measures on the rank that owns the
+user-facing result (or an all-gather when every rank needs them) -- (N-1)/N of the records
 per link instead of the 2x of an all-reduce followed by a redundant epilogue.  Division by
 n_observations happens after the sum (never average ratios).
 """
@@ -58,6 +59,24 @@ def all_gather_bins(shard_out, n_bins, group=None):
                        dtype=shard_out.dtype, device=shard_out.device)
     dist.all_gather_into_tensor(full, shard_out.contiguous(), group=group)
     return full[:n_bins]
+
+
+def gather_bins(shard_out, n_bins, dst=0, group=None):
+    """Assemble the per-rank measure shards on ONE rank (the process that owns the user-facing result).
+
+    Over xGMI every rank sends its 1/N directly to `dst` on its own link (N-1 concurrent transfers of
+    1/N of the data) instead of the N-1 ring steps of an all-gather.  Returns the [n_bins, ...] tensor
+    on `dst`, None elsewhere.
+    """
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return shard_out[:n_bins]
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    shard_out = shard_out.contiguous()
+    parts = [torch.empty_like(shard_out) for _ in range(world)] if rank == dst else None
+    dist.gather(shard_out, parts, dst=dst, group=group)
+    if rank != dst:
+        return None
+    return torch.cat(parts, dim=0)[:n_bins]
 
 
 def total_observations(local_n_obs, group=None):

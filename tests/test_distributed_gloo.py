@@ -68,6 +68,11 @@ def worker(rank, world, port, x, ref_rec, ref_power, errors):
         power[: b_hi - b_lo] = torch.from_numpy(unpack_diag_power(shard[: b_hi - b_lo].numpy(), C) / n_total)
         full = parallel.all_gather_bins(power, n_bins)
         np.testing.assert_allclose(full.numpy(), ref_power, rtol=2e-5)
+        on0 = parallel.gather_bins(power, n_bins, dst=0)
+        if rank == 0:
+            np.testing.assert_allclose(on0.numpy(), ref_power, rtol=2e-5)
+        else:
+            assert on0 is None
         dist.destroy_process_group()
     except Exception as exc:  # surface the failure in the parent
         errors.put(f"rank {rank}: {exc!r}")
