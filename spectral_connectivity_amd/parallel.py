@@ -41,9 +41,14 @@ def reduce_scatter_bins(accum, group=None):
         accum = torch.cat([accum, pad], dim=0)
     lo = rank * per
     hi = min(lo + per, n_bins)
-    if dist.get_backend(group) == "gloo":      # CPU tests: gloo has no reduce_scatter
-        dist.all_reduce(accum, group=group)
-        shard = accum[lo:lo + per].clone()
+    if dist.get_backend(group) == "gloo":      # CPU tests / debug runs: gloo has no reduce_scatter
+        if accum.is_cuda:                      # gloo moves CUDA tensors through the host
+            host = accum.cpu()
+            dist.all_reduce(host, group=group)
+            shard = host[lo:lo + per].to(accum.device)
+        else:
+            dist.all_reduce(accum, group=group)
+            shard = accum[lo:lo + per].clone()
     else:
         shard = torch.empty((per, fpb), dtype=accum.dtype, device=accum.device)
         dist.reduce_scatter_tensor(shard, accum, group=group)
@@ -71,12 +76,15 @@ def gather_bins(shard_out, n_bins, dst=0, group=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return shard_out[:n_bins]
     world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = shard_out.device
     shard_out = shard_out.contiguous()
+    if dist.get_backend(group) == "gloo" and shard_out.is_cuda:
+        shard_out = shard_out.cpu()
     parts = [torch.empty_like(shard_out) for _ in range(world)] if rank == dst else None
     dist.gather(shard_out, parts, dst=dst, group=group)
     if rank != dst:
         return None
-    return torch.cat(parts, dim=0)[:n_bins]
+    return torch.cat(parts, dim=0)[:n_bins].to(dev)
 
 
 def total_observations(local_n_obs, group=None):
