@@ -7,9 +7,11 @@ by hand-written HIP kernels for gfx950 + rocFFT behind the C ABI of ``include/sc
 from .connectivity import Connectivity
 from .transforms import (
     Multitaper,
+    MultitaperParameters,
     estimate_frequency_resolution,
     estimate_n_tapers,
     prepare_time_series,
+    suggest_parameters,
 )
 from .utils import get_compute_backend
 
@@ -18,7 +20,9 @@ __version__ = "0.1.0"
 __all__ = [
     "Connectivity",
     "Multitaper",
+    "MultitaperParameters",
     "prepare_time_series",
+    "suggest_parameters",
     "estimate_frequency_resolution",
     "estimate_n_tapers",
     "get_compute_backend",

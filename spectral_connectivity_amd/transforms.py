@@ -9,6 +9,7 @@ and the (tiny, once-per-object, float64) DPSS taper generation only.
 """
 import warnings
 from logging import getLogger
+from typing import TypedDict
 
 import numpy as np
 from scipy.fft import fft as _host_fft
@@ -29,6 +30,68 @@ def estimate_frequency_resolution(sampling_frequency, time_window_duration, time
 def estimate_n_tapers(time_halfbandwidth_product):
     """floor(2*NW) - 1 (reference transforms.py:144-196)."""
     return int(np.floor(TAPER_MULTIPLIER * time_halfbandwidth_product)) - 1
+
+
+class MultitaperParameters(TypedDict):
+    """Parameter suggestion returned by :func:`suggest_parameters` (reference transforms.py:33-60)."""
+
+    sampling_frequency: float
+    time_halfbandwidth_product: float
+    time_window_duration: float
+    n_tapers: int
+    frequency_resolution: float
+    n_time_windows: int
+    nyquist_frequency: float
+
+
+def suggest_parameters(sampling_frequency, signal_duration, desired_freq_resolution=None,
+                       desired_n_tapers=None):
+    """Suggest multitaper parameters for a recording (same rules as reference transforms.py:199-402).
+
+    No target: NW = 3 and a window of a fifth of the signal (at least 0.5 s, at most the signal).
+    ``desired_freq_resolution``: window T = 2 NW / df with NW = 3; impossible if T exceeds the signal;
+    if fewer than 3 windows would fit, the window is capped at a third of the signal and NW is lowered
+    to df T / 2 (never below 1).  ``desired_n_tapers``: NW = (n + 1) / 2 with the default window.
+    Both given: the resolution wins (with a ``UserWarning``).
+    """
+    if desired_freq_resolution is not None and desired_n_tapers is not None:
+        warnings.warn(
+            "Both 'desired_freq_resolution' and 'desired_n_tapers' were specified. "
+            "This is typically not recommended as they have competing effects on the analysis. "
+            "Using 'desired_freq_resolution' and ignoring 'desired_n_tapers'.", UserWarning, stacklevel=2)
+        desired_n_tapers = None
+
+    def default_window():
+        return min(max(signal_duration / 5.0, 0.5), signal_duration)
+
+    if desired_freq_resolution is not None:
+        nw = 3.0
+        window = TAPER_MULTIPLIER * nw / desired_freq_resolution
+        if window > signal_duration:
+            raise ValueError(
+                f"Cannot achieve desired frequency resolution of {desired_freq_resolution} Hz "
+                f"with signal duration of {signal_duration}s.\n"
+                f"Required window duration: {window:.2f}s; available: {signal_duration:.2f}s.\n"
+                f"Use a longer signal or a coarser resolution (at least "
+                f"{TAPER_MULTIPLIER * nw / signal_duration:.2f} Hz).")
+        if window > signal_duration / 3:
+            window = signal_duration / 3
+            nw = max(desired_freq_resolution * window / 2.0, 1.0)
+    elif desired_n_tapers is not None:
+        nw = (desired_n_tapers + 1) / 2.0
+        window = default_window()
+    else:
+        nw = 3.0
+        window = default_window()
+    return {
+        "sampling_frequency": sampling_frequency,
+        "time_halfbandwidth_product": nw,
+        "time_window_duration": window,
+        "n_tapers": estimate_n_tapers(nw),
+        "frequency_resolution": estimate_frequency_resolution(sampling_frequency, window, nw),
+        "n_time_windows": int(np.floor(signal_duration / window)),
+        "nyquist_frequency": sampling_frequency / 2.0,
+    }
 
 
 def prepare_time_series(time_series, axis=None):
@@ -209,6 +272,46 @@ class Multitaper:
                 f"time_window_step={self.time_window_step!r},\n"
                 f"           detrend_type={self.detrend_type!r}, "
                 f"start_time={self.start_time}, n_tapers={self.n_tapers})")
+
+    def summarize_parameters(self):
+        """Human-readable summary of the analysis configuration (reference transforms.py:810-923)."""
+        n_time = self.time_series.shape[0]
+        if self.time_window_step == self.time_window_duration:
+            overlap = "(non-overlapping)"
+        else:
+            pct = 100 * (self.time_window_duration - self.time_window_step) / self.time_window_duration
+            overlap = f"({pct:.0f}% overlap)"
+        n_windows = int(np.floor((n_time - self.n_time_samples_per_window) / self.n_time_samples_per_step) + 1)
+        lines = [
+            "Multitaper Spectral Analysis Configuration",
+            "===========================================",
+            "",
+            "Data Shape",
+            "----------",
+            f"Time samples:    {n_time} ({n_time / self.sampling_frequency:.2f} seconds)",
+            f"Signals:         {self.n_signals}",
+            f"Trials:          {self.n_trials}",
+            "",
+            "Spectral Parameters",
+            "-------------------",
+            f"Sampling frequency:            {self.sampling_frequency} Hz",
+            f"Time-halfbandwidth product:    {self.time_halfbandwidth_product}",
+            f"Number of tapers:              {self.n_tapers}",
+            "",
+            "Time Windowing",
+            "--------------",
+            f"Window duration:  {self.time_window_duration:.3f} s ({self.n_time_samples_per_window} samples)",
+            f"Window step:      {self.time_window_step:.3f} s {overlap}",
+            f"Number of windows: {n_windows}",
+            "",
+            "Frequency Analysis",
+            "------------------",
+            f"Frequency resolution: {self.frequency_resolution:.1f} Hz",
+            f"Nyquist frequency:    {self.nyquist_frequency:.1f} Hz",
+            f"Frequency range:      0.0 - {self.nyquist_frequency:.1f} Hz",
+            f"FFT samples:          {self.n_fft_samples}",
+        ]
+        return "\n".join(lines)
 
     # ---- derived parameters (reference transforms.py:925-1145) ---------------------------
     @property
