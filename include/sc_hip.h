@@ -207,6 +207,15 @@ int sc_granger_pairwise_f64(const float* d_accum, int64_t n_groups, int64_t n_fr
                             void* d_work, size_t work_bytes, double* d_out, int32_t* d_n_iter,
                             int32_t* d_status, int32_t* h_summary, void* stream);
 
+/* Minimum-phase (Wilson) factor of caller-supplied two-sided 2x2 Hermitian spectra: replaces
+ * minimum_phase_decomposition() (minimum_phase_decomposition.py:227-322) for c <= 2 (a 1x1
+ * spectrum is embedded as diag(s, 1)).  d_S: double [P][4][N] = (s00, s11, Re s01, Im s01) per bin;
+ * d_G: complex128 [P][4][N] = (g00, g01, g10, g11), S = G G^H.  Workspace as for n_groups = 1,
+ * n_pairs = P of sc_granger_workspace_bytes.  Synchronises the stream (see above). */
+int sc_wilson_factor_f64(const double* d_S, int64_t n_problems, int64_t N, double tolerance,
+                         int max_iterations, void* d_work, size_t work_bytes, void* d_G /*complex128*/,
+                         int32_t* d_n_iter, int32_t* d_status, int32_t* h_summary, void* stream);
+
 /* ---- canonical coherence between channel groups (fp64, from the accumulated CSM) -------
  * Replaces Connectivity.canonical_coherence, _normalize_fourier_coefficients and
  * _estimate_canonical_coherence (connectivity.py:745-820, :1979-2032): per (bin, group pair)

@@ -65,6 +65,8 @@ SYMBOLS = {
     "sc_granger_pairwise_f64": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_uint32, c_int64,
                                         c_void_p, c_int64, c_double, c_int, c_void_p, c_size_t, c_void_p,
                                         c_void_p, c_void_p, POINTER(c_int32), c_void_p]),
+    "sc_wilson_factor_f64": (c_int, [c_void_p, c_int64, c_int64, c_double, c_int, c_void_p, c_size_t, c_void_p,
+                                     c_void_p, c_void_p, POINTER(c_int32), c_void_p]),
     "sc_canonical_max_group": (c_int, []),
     "sc_canonical_coherence_f64": (c_int, [c_void_p, c_int64, c_int64, c_uint32, c_int64, c_void_p, c_void_p,
                                            c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -303,6 +303,78 @@ extern "C" int sc_granger_workspace_bytes(int64_t n_groups, int64_t n_pairs, int
         }                                                                                        \
     } while (0)
 
+struct WilsonWork {
+    double* S; cd* G; cd* A; double* err; double* h0; double* hinv; double* rot; int32_t* n_running;
+};
+
+static WilsonWork wilson_carve(void* d_work, int64_t P, int64_t N) {
+    WilsonWork k;
+    char* w = (char*)d_work;
+    k.S = (double*)w; w += (size_t)P * N * 4 * 8;
+    k.G = (cd*)w; w += (size_t)P * N * 4 * 16;
+    k.A = (cd*)w; w += (size_t)P * N * 4 * 16;
+    k.err = (double*)w; w += (size_t)P * 8;
+    k.h0 = (double*)w; w += (size_t)P * 32;
+    k.hinv = (double*)w; w += (size_t)P * 32;
+    k.rot = (double*)w; w += (size_t)P * 32;
+    k.n_running = (int32_t*)w;
+    return k;
+}
+
+// k_init + the Wilson iteration on work.S -> work.G.  Synchronises the stream once per iteration.
+static int wilson_iterate(const WilsonWork& k, int64_t P, int64_t N, double tol, int max_iter,
+                          int32_t* d_n_iter, int32_t* d_status, int* iters_out, int* running_out, hipStream_t st) {
+    int rc = SC_OK;
+    rocfft_plan fwd = nullptr, inv = nullptr;
+    rocfft_execution_info info = nullptr;
+    void* fft_work = nullptr;
+    size_t ws_f = 0, ws_i = 0;
+    static int rocfft_ready = 0;
+    if (!rocfft_ready) { rocfft_setup(); rocfft_ready = 1; }
+    const dim3 gridN((unsigned)((N + 255) / 256), (unsigned)P);
+    int iters = 0, running = (int)P;
+
+    if ((rc = make_z2z(&fwd, rocfft_transform_type_complex_forward, N, 4 * P)) != SC_OK) goto done;
+    if ((rc = make_z2z(&inv, rocfft_transform_type_complex_inverse, N, 4 * P)) != SC_OK) goto done;
+    SC_CHECK_FFT2(rocfft_plan_get_work_buffer_size(fwd, &ws_f));
+    SC_CHECK_FFT2(rocfft_plan_get_work_buffer_size(inv, &ws_i));
+    SC_CHECK_FFT2(rocfft_execution_info_create(&info));
+    if (ws_f < ws_i) ws_f = ws_i;
+    if (ws_f) {
+        if (hipMalloc(&fft_work, ws_f) != hipSuccess) { sc_set_error("rocFFT work buffer alloc failed"); rc = SC_ENOMEM; goto done; }
+        SC_CHECK_FFT2(rocfft_execution_info_set_work_buffer(info, fft_work, ws_f));
+    }
+    SC_CHECK_FFT2(rocfft_execution_info_set_stream(info, st));
+    hipMemsetAsync(k.err, 0, (size_t)P * 8, st);
+    hipMemsetAsync(d_n_iter, 0, (size_t)P * 4, st);
+    hipLaunchKernelGGL(k_init, dim3((unsigned)P), dim3(256), 0, st, k.S, k.G, d_status, N);
+    for (iters = 0; iters < max_iter; ++iters) {
+        void* bufs[1] = {k.A};
+        hipLaunchKernelGGL(k_predict, gridN, dim3(256), 0, st, k.S, k.G, d_status, k.A, N);
+        SC_CHECK_FFT2(rocfft_execute(inv, bufs, nullptr, info));
+        hipLaunchKernelGGL(k_causal, gridN, dim3(256), 0, st, k.A, N);
+        SC_CHECK_FFT2(rocfft_execute(fwd, bufs, nullptr, info));
+        hipLaunchKernelGGL(k_update, gridN, dim3(256), 0, st, k.G, k.A, d_status, k.err, N);
+        hipMemsetAsync(k.n_running, 0, 4, st);
+        hipLaunchKernelGGL(k_flags, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, d_status, d_n_iter, k.err, tol, P,
+                           k.n_running);
+        if (hipMemcpyAsync(&running, k.n_running, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) {
+            sc_set_error("Wilson iteration %d: %s", iters, hipGetErrorString(hipGetLastError()));
+            rc = SC_EHIP; goto done;
+        }
+        if (running == 0) { ++iters; break; }
+    }
+    *iters_out = iters;
+    *running_out = running;
+done:
+    if (info) rocfft_execution_info_destroy(info);
+    if (fwd) rocfft_plan_destroy(fwd);
+    if (inv) rocfft_plan_destroy(inv);
+    if (fft_work) (void)hipFree(fft_work);
+    return rc;
+}
+
 extern "C" int sc_granger_pairwise_f64(const float* d_accum, int64_t n_groups, int64_t n_freq_accum,
                                        int64_t N, int64_t C, uint32_t planes, int64_t n_obs,
                                        const int32_t* d_pairs, int64_t n_pairs, double tol, int max_iter,
@@ -324,77 +396,45 @@ extern "C" int sc_granger_pairwise_f64(const float* d_accum, int64_t n_groups, i
     d.floats_per_bin = (int64_t)sc_plane_count(planes) * d.n_tiles * SC_TILE_ELEMS;
     d.n_obs = (double)n_obs;
     const int64_t P = d.P, Fout = N / 2 + 1;
-    char* w = (char*)d_work;
-    double* S = (double*)w; w += (size_t)P * N * 4 * 8;
-    cd* G = (cd*)w; w += (size_t)P * N * 4 * 16;
-    cd* A = (cd*)w; w += (size_t)P * N * 4 * 16;
-    double* err = (double*)w; w += (size_t)P * 8;
-    double* h0 = (double*)w; w += (size_t)P * 32;
-    double* hinv = (double*)w; w += (size_t)P * 32;
-    double* rot = (double*)w; w += (size_t)P * 32;
-    int32_t* n_running = (int32_t*)w;
-
-    int rc = SC_OK;
-    rocfft_plan fwd = nullptr, inv = nullptr;
-    rocfft_execution_info info = nullptr;
-    void* fft_work = nullptr;
-    size_t ws_f = 0, ws_i = 0;
-    static int rocfft_ready = 0;
-    if (!rocfft_ready) { rocfft_setup(); rocfft_ready = 1; }
+    const WilsonWork k = wilson_carve(d_work, P, N);
     const dim3 gridN((unsigned)((N + 255) / 256), (unsigned)P), gridF((unsigned)((Fout + 255) / 256), (unsigned)P);
-    int iters = 0, running = (int)P;
-
-    if ((rc = make_z2z(&fwd, rocfft_transform_type_complex_forward, N, 4 * P)) != SC_OK) goto done;
-    if ((rc = make_z2z(&inv, rocfft_transform_type_complex_inverse, N, 4 * P)) != SC_OK) goto done;
-    SC_CHECK_FFT2(rocfft_plan_get_work_buffer_size(fwd, &ws_f));
-    SC_CHECK_FFT2(rocfft_plan_get_work_buffer_size(inv, &ws_i));
-    SC_CHECK_FFT2(rocfft_execution_info_create(&info));
-    if (ws_f < ws_i) ws_f = ws_i;
-    if (ws_f) {
-        if (hipMalloc(&fft_work, ws_f) != hipSuccess) { sc_set_error("rocFFT work buffer alloc failed"); rc = SC_ENOMEM; goto done; }
-        SC_CHECK_FFT2(rocfft_execution_info_set_work_buffer(info, fft_work, ws_f));
-    }
-    SC_CHECK_FFT2(rocfft_execution_info_set_stream(info, st));
-
-    hipMemsetAsync(err, 0, (size_t)P * 8, st);
-    hipMemsetAsync(d_n_iter, 0, (size_t)P * 4, st);
     hipLaunchKernelGGL(k_fill_nan, dim3((unsigned)((n_groups * Fout * C * C + 255) / 256)), dim3(256), 0, st, d_out,
                        n_groups * Fout * C * C);
-    hipLaunchKernelGGL(k_build, gridN, dim3(256), 0, st, d_accum, d_pairs, d, S);
-    hipLaunchKernelGGL(k_init, dim3((unsigned)P), dim3(256), 0, st, S, G, d_status, N);
-    for (iters = 0; iters < max_iter; ++iters) {
-        void* bufs[1] = {A};
-        hipLaunchKernelGGL(k_predict, gridN, dim3(256), 0, st, S, G, d_status, A, N);
-        SC_CHECK_FFT2(rocfft_execute(inv, bufs, nullptr, info));
-        hipLaunchKernelGGL(k_causal, gridN, dim3(256), 0, st, A, N);
-        SC_CHECK_FFT2(rocfft_execute(fwd, bufs, nullptr, info));
-        hipLaunchKernelGGL(k_update, gridN, dim3(256), 0, st, G, A, d_status, err, N);
-        hipMemsetAsync(n_running, 0, 4, st);
-        hipLaunchKernelGGL(k_flags, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, d_status, d_n_iter, err, tol, P,
-                           n_running);
-        if (hipMemcpyAsync(&running, n_running, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
-            hipStreamSynchronize(st) != hipSuccess) {
-            sc_set_error("Wilson iteration %d: %s", iters, hipGetErrorString(hipGetLastError()));
-            rc = SC_EHIP; goto done;
-        }
-        if (running == 0) { ++iters; break; }
-    }
-    hipLaunchKernelGGL(k_h0, dim3((unsigned)P), dim3(256), 0, st, G, h0, N);
-    hipLaunchKernelGGL(k_pair_consts, dim3((unsigned)((n_pairs + 63) / 64)), dim3(64), 0, st, h0, hinv, rot, n_groups,
-                       n_pairs);
-    hipLaunchKernelGGL(k_granger, gridF, dim3(256), 0, st, G, S, hinv, rot, d_status, d_pairs, d, Fout, d_out);
+    hipLaunchKernelGGL(k_build, gridN, dim3(256), 0, st, d_accum, d_pairs, d, k.S);
+    int iters = 0, running = 0;
+    const int rc = wilson_iterate(k, P, N, tol, max_iter, d_n_iter, d_status, &iters, &running, st);
+    if (rc != SC_OK) return rc;
+    hipLaunchKernelGGL(k_h0, dim3((unsigned)P), dim3(256), 0, st, k.G, k.h0, N);
+    hipLaunchKernelGGL(k_pair_consts, dim3((unsigned)((n_pairs + 63) / 64)), dim3(64), 0, st, k.h0, k.hinv, k.rot,
+                       n_groups, n_pairs);
+    hipLaunchKernelGGL(k_granger, gridF, dim3(256), 0, st, k.G, k.S, k.hinv, k.rot, d_status, d_pairs, d, Fout, d_out);
     if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) {
         sc_set_error("Granger epilogue failed: %s", hipGetErrorString(hipGetLastError()));
-        rc = SC_EHIP; goto done;
+        return SC_EHIP;
     }
     if (h_summary) { h_summary[0] = iters; h_summary[1] = running; }
-done:
-    if (info) rocfft_execution_info_destroy(info);
-    if (fwd) rocfft_plan_destroy(fwd);
-    if (inv) rocfft_plan_destroy(inv);
-    if (fft_work) (void)hipFree(fft_work);
-    return rc;
+    return SC_OK;
 }
 
-// Minimum-phase factor only (minimum_phase_decomposition.py:227-322) for callers that hand in
-// their own two-sided 2x2 spectra: S [P][4][N] doubles as above; G out [P][4][N] complex128.
+// Minimum-phase factor only (minimum_phase_decomposition.py:227-322) for callers that hand in their
+// own two-sided 2x2 Hermitian spectra: d_S [P][4][N] doubles (s00, s11, Re s01, Im s01);
+// d_G out [P][4][N] complex128 (entries g00, g01, g10, g11), with S = G G^H.
+extern "C" int sc_wilson_factor_f64(const double* d_S, int64_t n_problems, int64_t N, double tol, int max_iter,
+                                    void* d_work, size_t work_bytes, void* d_G, int32_t* d_n_iter,
+                                    int32_t* d_status, int32_t* h_summary, void* stream) {
+    SC_REQUIRE(d_S && d_work && d_G && d_n_iter && d_status, "NULL argument");
+    SC_REQUIRE(n_problems >= 1 && n_problems <= 65535 && N >= 2, "bad problem size");
+    size_t need = 0;
+    sc_granger_workspace_bytes(1, n_problems, N, &need);
+    SC_REQUIRE(work_bytes >= need, "workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const WilsonWork k = wilson_carve(d_work, n_problems, N);
+    SC_CHECK_HIP(hipMemcpyAsync(k.S, d_S, (size_t)n_problems * N * 4 * 8, hipMemcpyDeviceToDevice, st));
+    int iters = 0, running = 0;
+    const int rc = wilson_iterate(k, n_problems, N, tol, max_iter, d_n_iter, d_status, &iters, &running, st);
+    if (rc != SC_OK) return rc;
+    SC_CHECK_HIP(hipMemcpyAsync(d_G, k.G, (size_t)n_problems * N * 4 * 16, hipMemcpyDeviceToDevice, st));
+    SC_CHECK_HIP(hipStreamSynchronize(st));
+    if (h_summary) { h_summary[0] = iters; h_summary[1] = running; }
+    return SC_OK;
+}
