@@ -236,11 +236,11 @@ __device__ __forceinline__ void dft16(float2 (&x)[16], float2 (&o)[16]) {
     }
 }
 
-template <int LOG2N>
-__global__ void __launch_bounds__(256) mtfft16_kernel(MtArgs p) {
+template <int LOG2N, int THREADS>
+__global__ void __launch_bounds__(THREADS) mtfft16_kernel(MtArgs p) {
     constexpr int N = 1 << LOG2N;
     constexpr int TPF = N / 16;          // threads per FFT: 16 points each
-    constexpr int NF = 256 / TPF;        // complex FFTs (channel pairs) per workgroup
+    constexpr int NF = THREADS / TPF;    // complex FFTs (channel pairs) per workgroup
     constexpr int CT = 2 * NF;           // channels per workgroup
     constexpr int XS = CT + 2;           // padded window-row stride (floats)
     constexpr int ZS = N + N / 16 + 1;   // skewed exchange buffer per FFT (float2), odd stride
@@ -254,21 +254,21 @@ __global__ void __launch_bounds__(256) mtfft16_kernel(MtArgs p) {
     float2* z = reinterpret_cast<float2*>(smem);                                  // [NF][ZS] (aliases xt)
     float2* tw = reinterpret_cast<float2*>(smem + UNION_BYTES);                   // [N]
     float* hk = reinterpret_cast<float*>(tw + N);                                 // [N] current taper
-    double* red = reinterpret_cast<double*>(hk + N);                              // [2][256] + trend [2][CT]
+    double* red = reinterpret_cast<double*>(hk + N);                              // [2][THREADS] + trend [2][CT]
 
     const int tid = threadIdx.x;
     const int c0 = blockIdx.x * CT, r = blockIdx.y, w = blockIdx.z;
     const int L = p.L, C = p.C;
     const int64_t RC = (int64_t)p.R * C;
-    for (int i = tid; i < N; i += 256) tw[i] = p.tw[i];
+    for (int i = tid; i < N; i += THREADS) tw[i] = p.tw[i];
     const float* xw = p.x + ((int64_t)w * p.step * p.R + r) * C + c0;
-    for (int idx = tid; idx < L * CT; idx += 256) {
+    for (int idx = tid; idx < L * CT; idx += THREADS) {
         const int l = idx / CT, cc = idx - l * CT;
         xt[l * XS + cc] = (c0 + cc < C) ? xw[(int64_t)l * RC + cc] : 0.f;
     }
     __syncthreads();
     if (p.detrend != SC_DETREND_NONE) {
-        constexpr int SL = 256 / CT;
+        constexpr int SL = THREADS / CT;
         const int cc = tid % CT, sl = tid / CT;
         double s = 0.0, st = 0.0;
         for (int l = sl; l < L; l += SL) {
@@ -277,11 +277,11 @@ __global__ void __launch_bounds__(256) mtfft16_kernel(MtArgs p) {
             st += v * (double)(l + 1);
         }
         red[tid] = s;
-        red[256 + tid] = st;
+        red[THREADS + tid] = st;
         __syncthreads();
         if (tid < CT) {
             double sum = 0.0, sumt = 0.0;
-            for (int q = 0; q < SL; ++q) { sum += red[q * CT + tid]; sumt += red[256 + q * CT + tid]; }
+            for (int q = 0; q < SL; ++q) { sum += red[q * CT + tid]; sumt += red[THREADS + q * CT + tid]; }
             sumt /= (double)L;
             const double n = (double)L;
             double a = 0.0, b;
@@ -293,15 +293,15 @@ __global__ void __launch_bounds__(256) mtfft16_kernel(MtArgs p) {
                 a = (den != 0.0) ? (n * sumt - St * sum) / den : 0.0;
                 b = (sum - a * St) / n;
             }
-            red[512 + tid] = a;
-            red[512 + CT + tid] = b;
+            red[2 * THREADS + tid] = a;
+            red[2 * THREADS + CT + tid] = b;
         }
         __syncthreads();
         const double invL = 1.0 / (double)L;
-        for (int idx = tid; idx < L * CT; idx += 256) {
+        for (int idx = tid; idx < L * CT; idx += THREADS) {
             const int l = idx / CT, cc2 = idx - l * CT;
             const double t = (double)(l + 1) * invL;
-            xt[l * XS + cc2] = (float)((double)xt[l * XS + cc2] - (red[512 + cc2] * t + red[512 + CT + cc2]));
+            xt[l * XS + cc2] = (float)((double)xt[l * XS + cc2] - (red[2 * THREADS + cc2] * t + red[2 * THREADS + CT + cc2]));
         }
     }
 
@@ -320,7 +320,7 @@ __global__ void __launch_bounds__(256) mtfft16_kernel(MtArgs p) {
 #define PHYS(idx) ((idx) + ((idx) >> 4))
     for (int k = 0; k < p.K; ++k) {
         const float* hg = p.tapers + (int64_t)k * L;
-        for (int n = tid; n < L; n += 256) hk[n] = hg[n];
+        for (int n = tid; n < L; n += THREADS) hk[n] = hg[n];
         __syncthreads();     // taper k visible; post of k-1 (and, first time, the tile reads) done
         float2 a[16], o[16];
         // pass 1: radix 16, P = 1, inputs straight from the window tile
@@ -383,7 +383,7 @@ __global__ void __launch_bounds__(256) mtfft16_kernel(MtArgs p) {
         }
         // split the packed pair, store X[f][w][r][k][c..c+1]
         float2* Xk = p.X + (((int64_t)w * p.R + r) * p.K + k) * C + c0;
-        for (int idx = tid; idx < F * NF; idx += 256) {
+        for (int idx = tid; idx < F * NF; idx += THREADS) {
             const int f = idx / NF, pr = idx - f * NF;
             const int c = c0 + 2 * pr;
             if (c >= C) continue;
@@ -435,17 +435,18 @@ static int launch_mt(const MtArgs& a, hipStream_t stream) {
     return SC_OK;
 }
 
-template <int LOG2N>
+template <int LOG2N, int THREADS>
 static int launch_mt16(const MtArgs& a, hipStream_t stream) {
     constexpr int N = 1 << LOG2N;
-    constexpr int TPF = N / 16, NF = 256 / TPF, CT = 2 * NF;
+    constexpr int TPF = N / 16, NF = THREADS / TPF, CT = 2 * NF;
     constexpr size_t xt_b = (size_t)N * (CT + 2) * 4, z_b = (size_t)NF * (N + N / 16 + 1) * 8;
-    constexpr size_t shmem = (xt_b > z_b ? xt_b : z_b) + (size_t)N * 8 + (size_t)N * 4 + (size_t)(512 + 2 * CT) * 8;
+    constexpr size_t shmem = (xt_b > z_b ? xt_b : z_b) + (size_t)N * 8 + (size_t)N * 4 +
+                             (size_t)(2 * THREADS + 2 * CT) * 8;
     static_assert(shmem <= 160 * 1024, "LDS budget exceeded");
-    auto k = mtfft16_kernel<LOG2N>;
+    auto k = mtfft16_kernel<LOG2N, THREADS>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     dim3 grid((unsigned)((a.C + CT - 1) / CT), (unsigned)a.R, (unsigned)a.W);
-    hipLaunchKernelGGL(k, grid, dim3(256), shmem, stream, a);
+    hipLaunchKernelGGL(k, grid, dim3(THREADS), shmem, stream, a);
     SC_CHECK_HIP(hipGetLastError());
     return SC_OK;
 }
@@ -474,11 +475,11 @@ extern "C" int sc_multitaper_fft_f32(const float* d_x, int64_t T, int64_t R, int
     switch (N) {
     case 64: return launch_mt<6, 64>(a, s);
     case 128: return launch_mt<7, 64>(a, s);
-    case 256: return launch_mt16<8>(a, s);
+    case 256: return (a.C > 32) ? launch_mt16<8, 512>(a, s) : launch_mt16<8, 256>(a, s);   // 64- or 32-channel tiles
     case 512: return launch_mt<9, 16>(a, s);
-    case 1024: return launch_mt16<10>(a, s);
+    case 1024: return launch_mt16<10, 256>(a, s);
     case 2048: return launch_mt<11, 8>(a, s);
-    case 4096: return launch_mt16<12>(a, s);
+    case 4096: return launch_mt16<12, 256>(a, s);
     }
     return SC_EUNSUPPORTED;
 }
