@@ -25,6 +25,7 @@ struct MtArgs {
     const float2* tw;      // [N] exp(-2 pi i m / N)
     float2* X;             // [F][W][R][K][C]
     int T, R, C, L, step, W, K, detrend;
+    int kh;                // tapers resident in LDS (K, or 1 = reload per taper)
 };
 
 __device__ inline float2 cmul(float2 a, float2 b) {
@@ -236,11 +237,11 @@ __device__ __forceinline__ void dft16(float2 (&x)[16], float2 (&o)[16]) {
     }
 }
 
-template <int LOG2N, int THREADS>
-__global__ void __launch_bounds__(THREADS) mtfft16_kernel(MtArgs p) {
+template <int LOG2N>
+__global__ void __launch_bounds__(256) mtfft16_kernel(MtArgs p) {
     constexpr int N = 1 << LOG2N;
     constexpr int TPF = N / 16;          // threads per FFT: 16 points each
-    constexpr int NF = THREADS / TPF;    // complex FFTs (channel pairs) per workgroup
+    constexpr int NF = 256 / TPF;        // complex FFTs (channel pairs) per workgroup
     constexpr int CT = 2 * NF;           // channels per workgroup
     constexpr int XS = CT + 2;           // padded window-row stride (floats)
     constexpr int ZS = N + N / 16 + 1;   // skewed exchange buffer per FFT (float2), odd stride
@@ -252,23 +253,27 @@ __global__ void __launch_bounds__(THREADS) mtfft16_kernel(MtArgs p) {
     constexpr size_t UNION_BYTES = XT_BYTES > Z_BYTES ? XT_BYTES : Z_BYTES;
     float* xt = reinterpret_cast<float*>(smem);                                   // [N][XS]
     float2* z = reinterpret_cast<float2*>(smem);                                  // [NF][ZS] (aliases xt)
-    float2* tw = reinterpret_cast<float2*>(smem + UNION_BYTES);                   // [N]
-    float* hk = reinterpret_cast<float*>(tw + N);                                 // [N] current taper
-    double* red = reinterpret_cast<double*>(hk + N);                              // [2][THREADS] + trend [2][CT]
+    // The detrend scratch is dead once the tile is detrended; twiddles and tapers then take its place.
+    double* red = reinterpret_cast<double*>(smem + UNION_BYTES);                  // [2][256] + trend [2][CT]
+    float2* tw = reinterpret_cast<float2*>(smem + UNION_BYTES);                   // [N]   (aliases red)
+    float* hk = reinterpret_cast<float*>(tw + N);                                 // [kh][L] tapers
+    // An FFT's 16 x TPF points are exchanged between lanes of ONE wavefront when TPF <= 64, and
+    // LDS executes a wave's instructions in order: those exchanges need no workgroup barrier.
+    constexpr bool WAVE_LOCAL = TPF <= 64;
 
     const int tid = threadIdx.x;
     const int c0 = blockIdx.x * CT, r = blockIdx.y, w = blockIdx.z;
     const int L = p.L, C = p.C;
     const int64_t RC = (int64_t)p.R * C;
-    for (int i = tid; i < N; i += THREADS) tw[i] = p.tw[i];
+    const bool resident = p.kh == p.K;
     const float* xw = p.x + ((int64_t)w * p.step * p.R + r) * C + c0;
-    for (int idx = tid; idx < L * CT; idx += THREADS) {
+    for (int idx = tid; idx < L * CT; idx += 256) {
         const int l = idx / CT, cc = idx - l * CT;
         xt[l * XS + cc] = (c0 + cc < C) ? xw[(int64_t)l * RC + cc] : 0.f;
     }
     __syncthreads();
     if (p.detrend != SC_DETREND_NONE) {
-        constexpr int SL = THREADS / CT;
+        constexpr int SL = 256 / CT;
         const int cc = tid % CT, sl = tid / CT;
         double s = 0.0, st = 0.0;
         for (int l = sl; l < L; l += SL) {
@@ -277,11 +282,11 @@ __global__ void __launch_bounds__(THREADS) mtfft16_kernel(MtArgs p) {
             st += v * (double)(l + 1);
         }
         red[tid] = s;
-        red[THREADS + tid] = st;
+        red[256 + tid] = st;
         __syncthreads();
         if (tid < CT) {
             double sum = 0.0, sumt = 0.0;
-            for (int q = 0; q < SL; ++q) { sum += red[q * CT + tid]; sumt += red[THREADS + q * CT + tid]; }
+            for (int q = 0; q < SL; ++q) { sum += red[q * CT + tid]; sumt += red[256 + q * CT + tid]; }
             sumt /= (double)L;
             const double n = (double)L;
             double a = 0.0, b;
@@ -293,15 +298,15 @@ __global__ void __launch_bounds__(THREADS) mtfft16_kernel(MtArgs p) {
                 a = (den != 0.0) ? (n * sumt - St * sum) / den : 0.0;
                 b = (sum - a * St) / n;
             }
-            red[2 * THREADS + tid] = a;
-            red[2 * THREADS + CT + tid] = b;
+            red[512 + tid] = a;
+            red[512 + CT + tid] = b;
         }
         __syncthreads();
         const double invL = 1.0 / (double)L;
-        for (int idx = tid; idx < L * CT; idx += THREADS) {
+        for (int idx = tid; idx < L * CT; idx += 256) {
             const int l = idx / CT, cc2 = idx - l * CT;
             const double t = (double)(l + 1) * invL;
-            xt[l * XS + cc2] = (float)((double)xt[l * XS + cc2] - (red[2 * THREADS + cc2] * t + red[2 * THREADS + CT + cc2]));
+            xt[l * XS + cc2] = (float)((double)xt[l * XS + cc2] - (red[512 + cc2] * t + red[512 + CT + cc2]));
         }
     }
 
@@ -310,7 +315,10 @@ __global__ void __launch_bounds__(THREADS) mtfft16_kernel(MtArgs p) {
     const int F = N / 2 + 1;
     const int64_t sF = (int64_t)p.W * p.R * p.K * C;
     const bool vec_ok = (C % 2) == 0;
-    __syncthreads();                                  // detrended tile complete
+    __syncthreads();                                  // detrended tile complete, scratch free
+    for (int i2 = tid; i2 < N; i2 += 256) tw[i2] = p.tw[i2];
+    if (resident)
+        for (int i2 = tid; i2 < p.K * p.L; i2 += 256) hk[i2] = p.tapers[i2];
     float2 xs[16];                                    // this thread's pass-1 inputs, all tapers
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
@@ -318,22 +326,37 @@ __global__ void __launch_bounds__(THREADS) mtfft16_kernel(MtArgs p) {
         xs[t] = (n < L) ? *reinterpret_cast<const float2*>(xt + n * XS + 2 * pf) : make_float2(0.f, 0.f);
     }
 #define PHYS(idx) ((idx) + ((idx) >> 4))
+#define XBAR()                                                      \
+    do {                                                            \
+        if constexpr (WAVE_LOCAL) {                                 \
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  \
+            __builtin_amdgcn_wave_barrier();                        \
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  \
+        } else {                                                    \
+            __syncthreads();                                        \
+        }                                                           \
+    } while (0)
     for (int k = 0; k < p.K; ++k) {
-        const float* hg = p.tapers + (int64_t)k * L;
-        for (int n = tid; n < L; n += THREADS) hk[n] = hg[n];
+        const float* hkk = hk;
+        if (resident) {
+            hkk = hk + k * L;
+        } else {
+            const float* hg = p.tapers + (int64_t)k * L;
+            for (int n = tid; n < L; n += 256) hk[n] = hg[n];
+        }
         __syncthreads();     // taper k visible; post of k-1 (and, first time, the tile reads) done
         float2 a[16], o[16];
         // pass 1: radix 16, P = 1, inputs straight from the window tile
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             const int n = i + t * TPF;
-            const float h = (n < L) ? hk[n] : 0.f;
+            const float h = (n < L) ? hkk[n] : 0.f;
             a[t] = make_float2(xs[t].x * h, xs[t].y * h);
         }
         dft16(a, o);
 #pragma unroll
         for (int u = 0; u < 16; ++u) zf[PHYS(16 * i + u)] = o[u];
-        __syncthreads();
+        XBAR();
         // pass 2: radix 16, P = 16
         {
             const int kk = i & 15;
@@ -343,11 +366,11 @@ __global__ void __launch_bounds__(THREADS) mtfft16_kernel(MtArgs p) {
                 a[t] = (t == 0) ? v : cmul(v, tw[t * kk * (N / 256)]);
             }
             dft16(a, o);
-            __syncthreads();
+            if constexpr (LOG2N != 8) XBAR();      // N = 256 writes back exactly the slots it read
             const int j = ((i - kk) << 4) + kk;
 #pragma unroll
             for (int u = 0; u < 16; ++u) zf[PHYS(j + 16 * u)] = o[u];
-            __syncthreads();
+            if constexpr (LOG2N == 8) __syncthreads(); else XBAR();
         }
         if constexpr (LOG2N == 10) {        // pass 3: radix 4, P = 256, four butterflies per thread
 #pragma unroll
@@ -360,7 +383,7 @@ __global__ void __launch_bounds__(THREADS) mtfft16_kernel(MtArgs p) {
                 }
                 dft4r(a[4 * b], a[4 * b + 1], a[4 * b + 2], a[4 * b + 3]);
             }
-            __syncthreads();
+            // in place: every thread writes back exactly the slots it read
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 const int ib = i + b * TPF;
@@ -383,7 +406,7 @@ __global__ void __launch_bounds__(THREADS) mtfft16_kernel(MtArgs p) {
         }
         // split the packed pair, store X[f][w][r][k][c..c+1]
         float2* Xk = p.X + (((int64_t)w * p.R + r) * p.K + k) * C + c0;
-        for (int idx = tid; idx < F * NF; idx += THREADS) {
+        for (int idx = tid; idx < F * NF; idx += 256) {
             const int f = idx / NF, pr = idx - f * NF;
             const int c = c0 + 2 * pr;
             if (c >= C) continue;
@@ -402,6 +425,7 @@ __global__ void __launch_bounds__(THREADS) mtfft16_kernel(MtArgs p) {
         }
         // the barrier at the top of the next taper orders these reads before pass 1 rewrites z
     }
+#undef XBAR
 #undef PHYS
 }
 
@@ -435,18 +459,24 @@ static int launch_mt(const MtArgs& a, hipStream_t stream) {
     return SC_OK;
 }
 
-template <int LOG2N, int THREADS>
-static int launch_mt16(const MtArgs& a, hipStream_t stream) {
+template <int LOG2N>
+static int launch_mt16(const MtArgs& a_in, hipStream_t stream) {
     constexpr int N = 1 << LOG2N;
-    constexpr int TPF = N / 16, NF = THREADS / TPF, CT = 2 * NF;
+    constexpr int TPF = N / 16, NF = 256 / TPF, CT = 2 * NF;
     constexpr size_t xt_b = (size_t)N * (CT + 2) * 4, z_b = (size_t)NF * (N + N / 16 + 1) * 8;
-    constexpr size_t shmem = (xt_b > z_b ? xt_b : z_b) + (size_t)N * 8 + (size_t)N * 4 +
-                             (size_t)(2 * THREADS + 2 * CT) * 8;
-    static_assert(shmem <= 160 * 1024, "LDS budget exceeded");
-    auto k = mtfft16_kernel<LOG2N, THREADS>;
+    constexpr size_t uni = (xt_b > z_b ? xt_b : z_b), red_b = (size_t)(512 + 2 * CT) * 8;
+    static_assert(uni + (size_t)N * 12 <= 160 * 1024 && uni + red_b <= 160 * 1024, "LDS budget exceeded");
+    auto lds = [&](size_t kh, size_t L) { size_t t = (size_t)N * 8 + kh * L * 4; return uni + (t > red_b ? t : red_b); };
+    // Keep all K tapers in LDS when that does not cost a resident workgroup per CU.
+    constexpr size_t cu_lds = 160 * 1024;
+    MtArgs a = a_in;
+    const size_t one = lds(1, a.L), all = lds(a.K, a.L);
+    a.kh = (all <= cu_lds && cu_lds / all == cu_lds / one) ? a.K : 1;
+    const size_t shmem = a.kh == a.K ? all : one;
+    auto k = mtfft16_kernel<LOG2N>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     dim3 grid((unsigned)((a.C + CT - 1) / CT), (unsigned)a.R, (unsigned)a.W);
-    hipLaunchKernelGGL(k, grid, dim3(THREADS), shmem, stream, a);
+    hipLaunchKernelGGL(k, grid, dim3(256), shmem, stream, a);
     SC_CHECK_HIP(hipGetLastError());
     return SC_OK;
 }
@@ -475,11 +505,11 @@ extern "C" int sc_multitaper_fft_f32(const float* d_x, int64_t T, int64_t R, int
     switch (N) {
     case 64: return launch_mt<6, 64>(a, s);
     case 128: return launch_mt<7, 64>(a, s);
-    case 256: return (a.C > 32) ? launch_mt16<8, 512>(a, s) : launch_mt16<8, 256>(a, s);   // 64- or 32-channel tiles
+    case 256: return launch_mt16<8>(a, s);
     case 512: return launch_mt<9, 16>(a, s);
-    case 1024: return launch_mt16<10, 256>(a, s);
+    case 1024: return launch_mt16<10>(a, s);
     case 2048: return launch_mt<11, 8>(a, s);
-    case 4096: return launch_mt16<12, 256>(a, s);
+    case 4096: return launch_mt16<12>(a, s);
     }
     return SC_EUNSUPPORTED;
 }
