@@ -17,6 +17,7 @@
 //   A[f] = (Z[f] + conj Z[N-f]) / 2,   B[f] = (Z[f] - conj Z[N-f]) / (2i)
 // (DC and Nyquist come out exactly real, like the reference's real input), and stored as
 // float4 (A, B) so a wave writes contiguous CT*8-byte segments per frequency.
+#include <cstdlib>
 #include "sc_common.h"
 
 struct MtArgs {
@@ -26,6 +27,8 @@ struct MtArgs {
     float2* X;             // [F][W][R][K][C]
     int T, R, C, L, step, W, K, detrend;
     int kh;                // tapers resident in LDS (K, or 1 = reload per taper)
+    int dbg;               // profiling aid (env SC_MTFFT_DEBUG bit mask, results WRONG when set):
+                           // 1 = no HBM stores, 2 = skip both radix-16 passes, 4 = skip the split/store loop
 };
 
 __device__ inline float2 cmul(float2 a, float2 b) {
@@ -238,7 +241,7 @@ __device__ __forceinline__ void dft16(float2 (&x)[16], float2 (&o)[16]) {
 }
 
 template <int LOG2N>
-__global__ void __launch_bounds__(256) mtfft16_kernel(MtArgs p) {
+__global__ void __launch_bounds__(256, LOG2N == 8 ? 4 : 1) mtfft16_kernel(MtArgs p) {
     constexpr int N = 1 << LOG2N;
     constexpr int TPF = N / 16;          // threads per FFT: 16 points each
     constexpr int NF = 256 / TPF;        // complex FFTs (channel pairs) per workgroup
@@ -267,9 +270,41 @@ __global__ void __launch_bounds__(256) mtfft16_kernel(MtArgs p) {
     const int64_t RC = (int64_t)p.R * C;
     const bool resident = p.kh == p.K;
     const float* xw = p.x + ((int64_t)w * p.step * p.R + r) * C + c0;
-    for (int idx = tid; idx < L * CT; idx += 256) {
-        const int l = idx / CT, cc = idx - l * CT;
-        xt[l * XS + cc] = (c0 + cc < C) ? xw[(int64_t)l * RC + cc] : 0.f;
+    if constexpr (CT % 4 == 0) {
+        // 16-byte loads, all of a thread's rows in flight at once (the tile is N x CT floats = 16 KB x 2)
+        constexpr int V = CT / 4, ROUNDS = N * V / 256;
+        const bool vec = (C % 4) == 0;
+        float4 v[ROUNDS];
+#pragma unroll
+        for (int it = 0; it < ROUNDS; ++it) {
+            const int idx = tid + it * 256, l = idx / V, cc = 4 * (idx - l * V);
+            const float* src = xw + (int64_t)l * RC + cc;
+            v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (l < L) {
+                if (vec && c0 + cc + 3 < C) {
+                    v[it] = *reinterpret_cast<const float4*>(src);
+                } else {
+                    if (c0 + cc < C) v[it].x = src[0];
+                    if (c0 + cc + 1 < C) v[it].y = src[1];
+                    if (c0 + cc + 2 < C) v[it].z = src[2];
+                    if (c0 + cc + 3 < C) v[it].w = src[3];
+                }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < ROUNDS; ++it) {
+            const int idx = tid + it * 256, l = idx / V, cc = 4 * (idx - l * V);
+            if (l < L) {
+                float2* d = reinterpret_cast<float2*>(xt + l * XS + cc);
+                d[0] = make_float2(v[it].x, v[it].y);
+                d[1] = make_float2(v[it].z, v[it].w);
+            }
+        }
+    } else {
+        for (int idx = tid; idx < L * CT; idx += 256) {
+            const int l = idx / CT, cc = idx - l * CT;
+            xt[l * XS + cc] = (c0 + cc < C) ? xw[(int64_t)l * RC + cc] : 0.f;
+        }
     }
     __syncthreads();
     if (p.detrend != SC_DETREND_NONE) {
@@ -346,6 +381,7 @@ __global__ void __launch_bounds__(256) mtfft16_kernel(MtArgs p) {
         }
         __syncthreads();     // taper k visible; post of k-1 (and, first time, the tile reads) done
         float2 a[16], o[16];
+        if (!(p.dbg & 2)) {
         // pass 1: radix 16, P = 1, inputs straight from the window tile
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
@@ -404,24 +440,44 @@ __global__ void __launch_bounds__(256) mtfft16_kernel(MtArgs p) {
             for (int u = 0; u < 16; ++u) zf[PHYS(i + 256 * u)] = o[u];
             __syncthreads();
         }
+        } else { __syncthreads(); }
         // split the packed pair, store X[f][w][r][k][c..c+1]
+        if (p.dbg & 4) continue;
         float2* Xk = p.X + (((int64_t)w * p.R + r) * p.K + k) * C + c0;
-        for (int idx = tid; idx < F * NF; idx += 256) {
-            const int f = idx / NF, pr = idx - f * NF;
-            const int c = c0 + 2 * pr;
-            if (c >= C) continue;
-            const int f2 = (N - f) & (N - 1);
-            const float2 z1 = z[pr * ZS + PHYS(f)];
-            const float2 z2 = z[pr * ZS + PHYS(f2)];
-            const float2 A = make_float2(0.5f * (z1.x + z2.x), 0.5f * (z1.y - z2.y));
-            const float2 B = make_float2(0.5f * (z1.y + z2.y), 0.5f * (z2.x - z1.x));
-            float2* dst = Xk + (int64_t)f * sF + 2 * pr;
-            if (vec_ok) {
-                *reinterpret_cast<float4*>(dst) = make_float4(A.x, A.y, B.x, B.y);
-            } else {
-                dst[0] = A;
-                if (c + 1 < C) dst[1] = B;
+        // F * NF = 8 * 256 + NF outputs: eight full rounds (LDS reads batched four at a time ahead of the stores) and
+        // the Nyquist row on the first NF threads.
+        const int pr = tid & (NF - 1), fb = tid / NF, c = c0 + 2 * pr;
+        if (c < C) {
+            const float2* zp = z + pr * ZS;
+            const bool last = tid < NF;
+            float2 zn = make_float2(0.f, 0.f);
+            if (last) zn = zp[PHYS(N / 2)];
+            float2* dst0 = Xk + 2 * pr;
+            auto put = [&](int f, float2 u1, float2 u2) {
+                const float2 A = make_float2(0.5f * (u1.x + u2.x), 0.5f * (u1.y - u2.y));
+                const float2 B = make_float2(0.5f * (u1.y + u2.y), 0.5f * (u2.x - u1.x));
+                float2* dst = dst0 + (int64_t)f * sF;
+                if ((p.dbg & 1) && A.x != 12345.f) return;
+                if (vec_ok) {
+                    *reinterpret_cast<float4*>(dst) = make_float4(A.x, A.y, B.x, B.y);
+                } else {
+                    dst[0] = A;
+                    if (c + 1 < C) dst[1] = B;
+                }
+            };
+#pragma unroll
+            for (int h = 0; h < 8; h += 4) {
+                float2 z1[4], z2[4];
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int f = fb + (h + it) * (256 / NF);
+                    z1[it] = zp[PHYS(f)];
+                    z2[it] = zp[PHYS((N - f) & (N - 1))];
+                }
+#pragma unroll
+                for (int it = 0; it < 4; ++it) put(fb + (h + it) * (256 / NF), z1[it], z2[it]);
             }
+            if (last) put(N / 2, zn, zn);
         }
         // the barrier at the top of the next taper orders these reads before pass 1 rewrites z
     }
@@ -472,6 +528,7 @@ static int launch_mt16(const MtArgs& a_in, hipStream_t stream) {
     MtArgs a = a_in;
     const size_t one = lds(1, a.L), all = lds(a.K, a.L);
     a.kh = (all <= cu_lds && cu_lds / all == cu_lds / one) ? a.K : 1;
+    { const char* d = getenv("SC_MTFFT_DEBUG"); a.dbg = d ? atoi(d) : 0; }
     const size_t shmem = a.kh == a.K ? all : one;
     auto k = mtfft16_kernel<LOG2N>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
