@@ -95,11 +95,12 @@ __device__ __forceinline__ void split4(const float x[4], uint2& h, uint2& m, uin
     l.x = cvt_pk_bf16(s0, s1); l.y = cvt_pk_bf16(s2, s3);
 }
 
-// Staging.  Abs wave v owns the observation rows 4v .. 4v+3 of every chunk: it pulls them from HBM
-// straight into an f32 LDS buffer (global_load_lds_dwordx4: lane l of the wave lands at base + 16 l,
+// Staging (done by the CSM waves, see fused_mfma_role).  A staging wave owns eight observation rows of
+// every chunk (two quads vw): it pulls them from HBM straight into an f32 LDS buffer (global_load_lds_dwordx4: lane l of the wave lands at base + 16 l,
 // i.e. one 1 KB row = 64 channel pairs per instruction, no VGPRs held while the loads are in flight),
 // later reads its own rows back, splits them and writes the bf16 planes.  Because nobody else touches
 // those raw rows, re-filling them needs no barrier.
+#define FU_NPLANES 6
 #define FU_RAW_ROW 256      // floats per raw row: 64 slots x (Re, Im) x 2 channels
 // Lane id re-materialised on the spot (never CSE'd or hoisted): everything derived from it has a short
 // live range, so the register allocator does not carry -- and spill -- per-lane constants of one phase
@@ -162,6 +163,35 @@ __device__ __forceinline__ void fu_split(const float* raw, unsigned short* plane
     }
 }
 
+// Prologue of a staging wave (quad vw): clear its raw rows (slots of absent channels stay zero for
+// good), fetch and stage chunk 0, put chunk 1 in flight.
+template <int NB32>
+__device__ __forceinline__ void fu_stage_first(const ScStage& st, float* raw, unsigned short* planes, int vw,
+                                               int n_chunks, bool loads) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        *reinterpret_cast<float4*>(raw + (4 * vw + k) * FU_RAW_ROW + 4 * fu_lane()) = make_float4(0.f, 0.f, 0.f, 0.f);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    fu_fetch(st, raw, 0, vw);       // (debug "no HBM loads" keeps re-using this chunk: realistic operand values)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    fu_split<NB32>(raw, planes, vw);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (n_chunks > 1 && loads) fu_fetch(st, raw, FU_OC, vw);
+}
+
+// Stage chunk ch + 1 into the other plane buffer, then put the loads of chunk ch + 2 in flight.
+template <int NB32>
+__device__ __forceinline__ void fu_stage_next(const ScStage& st, float* raw, unsigned short* planes, int vw, int ch,
+                                              int n_chunks, bool loads) {
+    constexpr int plane_elems = NB32 * 32 * FU_PSTRIDE;
+    if (ch + 1 < n_chunks) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // raw rows of chunk ch + 1 landed
+        fu_split<NB32>(raw, planes + ((ch + 1) & 1) * FU_NPLANES * plane_elems, vw);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // raw rows read before the refill
+        if (ch + 2 < n_chunks && loads) fu_fetch(st, raw, (ch + 2) * FU_OC, vw);
+    }
+}
+
 __device__ __forceinline__ unsigned perm_b32(unsigned a, unsigned b, unsigned sel) {
     return __builtin_amdgcn_perm(a, b, sel);     // bytes 0-3 of sel pick from b, 4-7 from a
 }
@@ -179,9 +209,13 @@ __device__ __forceinline__ bf16x8 fu_ld8(const unsigned short* ptr) {
     return __builtin_bit_cast(bf16x8, u);
 }
 
-#define FU_MFMA(a, b, c) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
-#define FU_NPLANES 6
+// Workgroup barrier that publishes LDS writes only.  __syncthreads() would also drain vmcnt, i.e. make
+// every wave sit out the HBM->LDS row loads that were just put in flight for a later chunk.
+#define FU_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
+#define FU_MFMA(a, b, c) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+
+static_assert(2 * 4 + 1 <= FU_FLUSH, "one fold slot per tile of a wave");
 // The two roles are separate functions so their accumulators never coexist in registers.
 // Both execute the same barrier sequence: one before the first chunk, one per chunk, then
 // 2*log2(waves per set).
@@ -192,7 +226,7 @@ __device__ __forceinline__ bf16x8 fu_ld8(const unsigned short* ptr) {
 // MFMAs of the current one.
 template <int NB32>
 __device__ __forceinline__ void fused_mfma_role(const FusedArgs& p, const ScStage& st,
-                                                unsigned short* planes, int tid, int wave, int bin) {
+                                                unsigned short* planes, float* raw, int tid, int wave, int bin) {
     constexpr int MAXS = 2 * NB32 + 1;
     const int lane = tid & 63;
     const int NB = p.NB;
@@ -208,7 +242,11 @@ __device__ __forceinline__ void fused_mfma_role(const FusedArgs& p, const ScStag
     const unsigned short* frag00 = planes + (lane & 15) * FU_PSTRIDE + (lane >> 4) * 8;
     float* out = p.accum + (int64_t)bin * p.floats_per_bin + (int64_t)p.csm_plane * p.n_tiles * SC_TILE_ELEMS;
 #define FU_LD(ptr, k) fu_ld8((ptr) + (k) * plane_elems)
-    __syncthreads();              // chunk 0 staged by the abs waves
+    // Staging is shared: the four CSM waves (VALU idle under their MFMA stream) stage observation
+    // quads 0-3 AFTER their products, abs waves 0-3 stage quads 4-7 BEFORE theirs.
+    const bool loads = !(p.debug_skip & 8);
+    fu_stage_first<NB32>(st, raw, planes, wave, n_chunks, loads);
+    FU_BARRIER();                 // chunk 0 staged
     FU_T0();
     for (int ch = 0; ch < n_chunks; ++ch) {
         const unsigned short* frag0 = frag00 + (ch & 1) * FU_NPLANES * plane_elems;
@@ -263,15 +301,22 @@ __device__ __forceinline__ void fused_mfma_role(const FusedArgs& p, const ScStag
             }
         }
         FU_TICK(1);
-        // Two-level summation: every FU_FLUSH chunks (512 observations) the f32 accumulators are
-        // folded into the output record (owned by this wave, L2-resident) and cleared, so no f32
+        // stage chunk ch + 1 into the other buffer, then put the loads of chunk ch + 2 in flight
+        fu_stage_next<NB32>(st, raw, planes, wave, ch, n_chunks, loads);
+        FU_TICK(0);
+        // Two-level summation: every FU_FLUSH chunks (512 observations) the f32 accumulators of a tile
+        // are folded into the output record (owned by this wave, L2-resident) and cleared, so no f32
         // chain is longer than 16 chunk-sums + n_obs/512 partials: at n_obs = 7000 the power error
-        // drops from 8e-6 (one 219-long chain) to < 1e-6 relative.
-        if (((ch + 1) % FU_FLUSH) == 0 || ch + 1 == n_chunks) {
-            const bool first = ch < FU_FLUSH;
+        // drops from 8e-6 (one 219-long chain) to < 1e-6 relative.  The tiles take turns (tile s folds
+        // when ch + 1 + s is a multiple of FU_FLUSH) so that no chunk carries all the folds.
+        {
+            const bool last = ch + 1 == n_chunks;
 #pragma unroll
             for (int s = 0; s < MAXS; ++s) {
-                if (s < total) {
+                const int f_s = FU_FLUSH - 1 - s;              // chunk of this tile's first scheduled fold
+                const bool due = ((ch + 1 + s) % FU_FLUSH) == 0;
+                if (s < total && (due || last)) {
+                    const bool first = ch <= f_s;
                     const bool in_a = s < nA_;
                     const int row = in_a ? rA_ : rB_;
                     const int col = row + (in_a ? s : s - nA_);
@@ -290,12 +335,12 @@ __device__ __forceinline__ void fused_mfma_role(const FusedArgs& p, const ScStag
                             unsafeAtomicAdd(o_im + idx, im[s][r]);
                         }
                     }
+                    re[s] = (f32x4){0.f, 0.f, 0.f, 0.f}; im[s] = re[s];
                 }
-                re[s] = (f32x4){0.f, 0.f, 0.f, 0.f}; im[s] = re[s];
             }
         }
         FU_TICK(2);
-        __syncthreads();          // chunk ch consumed by both roles, chunk ch + 1 staged
+        FU_BARRIER();             // chunk ch consumed by both roles, chunk ch + 1 staged
         FU_TICK(3);
     }
 #undef FU_LD
@@ -393,33 +438,12 @@ __device__ __forceinline__ void fused_valu_body(const FusedArgs& p, const ScStag
     constexpr int plane_elems = NB32 * 32 * FU_PSTRIDE;
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const bool loads = !(p.debug_skip & 8);
-    // prologue: clear this wave's raw rows (slots of absent channels stay zero for good), fetch and
-    // stage chunk 0, put chunk 1 in flight
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        *reinterpret_cast<float4*>(raw + (4 * vw + k) * FU_RAW_ROW + 4 * fu_lane()) = make_float4(0.f, 0.f, 0.f, 0.f);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    fu_fetch(st, raw, 0, vw);       // (debug "no HBM loads" keeps re-using this chunk: realistic operand values)
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    fu_split<NB32>(raw, planes, vw);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (n_chunks > 1 && loads) fu_fetch(st, raw, FU_OC, vw);
-    __syncthreads();              // chunk 0 staged
+    if (vw < 4) fu_stage_first<NB32>(st, raw, planes, 4 + vw, n_chunks, loads);
+    FU_BARRIER();                 // chunk 0 staged
     FU_T0();
     for (int ch = 0; ch < n_chunks; ++ch) {
-        // Stage chunk ch + 1 into the other buffer (the CSM waves are already on chunk ch), then put the
-        // loads of chunk ch + 2 in flight.  The two abs waves of a SIMD belong to different sets: set 0
-        // stages BEFORE its products and set 1 AFTER, so one wave's VALU-only split runs under the
-        // other's MFMAs instead of both idling the matrix pipe at the same time.
-        auto stage_next = [&]() {
-            if (ch + 1 < n_chunks) {
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // raw rows of chunk ch + 1 landed
-                fu_split<NB32>(raw, planes + ((ch + 1) & 1) * FU_NPLANES * plane_elems, vw);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // raw rows read before the refill
-                if (ch + 2 < n_chunks && loads) fu_fetch(st, raw, (ch + 2) * FU_OC, vw);
-            }
-        };
-        if constexpr (SET == 0) { stage_next(); FU_TICK(0); }
+        if (vw < 4) fu_stage_next<NB32>(st, raw, planes, 4 + vw, ch, n_chunks, loads);
+        FU_TICK(0);
         const unsigned short* pb = planes + (ch & 1) * FU_NPLANES * plane_elems;
         // per-lane plane triples: A reads Im (lanes 0-31) / Re (32-63), B reads Re (lanes 0-31) / Im (32-63)
         const int cl = fu_lane(), ci32 = cl & 31, chf = cl >> 5;
@@ -480,8 +504,7 @@ __device__ __forceinline__ void fused_valu_body(const FusedArgs& p, const ScStag
             }
         }
         FU_TICK(1);
-        if constexpr (SET != 0) { stage_next(); FU_TICK(0); }
-        __syncthreads();          // chunk ch consumed by both roles, chunk ch + 1 staged
+        FU_BARRIER();             // chunk ch consumed by both roles, chunk ch + 1 staged
         FU_TICK(3);
     }
     // tree-sum the row-split partials of a set through LDS (planes region, 20 KB per writer)
@@ -549,7 +572,7 @@ __global__ void __launch_bounds__(FU_THREADS) fused_csm_absim_kernel(FusedArgs p
     // scratch of the final tree reduction)
     float* raw = reinterpret_cast<float*>(smem);
     unsigned short* planes = reinterpret_cast<unsigned short*>(smem + FU_OC * FU_RAW_ROW * sizeof(float));
-    if (wave < 4) fused_mfma_role<NB32>(p, st, planes, tid, wave, bin);
+    if (wave < 4) fused_mfma_role<NB32>(p, st, planes, raw, tid, wave, bin);
     else fused_valu_role<NB32>(p, st, planes, raw, tid, wave - 4, bin);
 }
 
