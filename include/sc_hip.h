@@ -172,6 +172,12 @@ int sc_nonlinear_accumulate_f32(const void* d_X /*float2*/, const sc_spectra_des
 int sc_fused_supported(int64_t n_signals);
 int sc_fused_csm_absim_f32(const void* d_X /*float2*/, const sc_spectra_desc* desc,
                            uint32_t planes, float* d_accum, void* stream);
+/* Same, with a device workspace (sc_fused_workspace_bytes; may be 0) that lets several workgroups share
+ * one (window, frequency) bin when the bin count does not fill the GPU's compute units evenly: each
+ * sums part of the observations into its own record, folded together in a fixed order afterwards. */
+int64_t sc_fused_workspace_bytes(const sc_spectra_desc* desc, uint32_t planes);
+int sc_fused_csm_absim_ws_f32(const void* d_X /*float2*/, const sc_spectra_desc* desc, uint32_t planes,
+                              float* d_accum, void* d_workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- stage C: measures epilogue ------------------------------------------------------
  * Elementwise measure algebra on accumulated sums (connectivity.py:612-1159): divides by

@@ -72,6 +72,8 @@ struct FusedArgs {
     int64_t floats_per_bin;
     int n_bins, F, NB, n_tiles, NB32, n_blocks32, n_sets;
     int csm_plane, abs_plane;
+    int n_split;         // workgroups per bin: part k sums the chunks [k NC / n_split, (k+1) NC / n_split)
+    float* ws;           // partial records of parts 1 .. n_split-1: [n_split-1][n_bins][floats_per_bin]
     int debug_skip;      // profiling aid (env SC_FUSED_DEBUG, bit mask; results are WRONG when set):
                          // 1 = CSM waves skip their MFMAs, 2 = abs waves skip theirs, 8 = no HBM loads after chunk 0
 };
@@ -167,28 +169,28 @@ __device__ __forceinline__ void fu_split(const float* raw, unsigned short* plane
 // good), fetch and stage chunk 0, put chunk 1 in flight.
 template <int NB32>
 __device__ __forceinline__ void fu_stage_first(const ScStage& st, float* raw, unsigned short* planes, int vw,
-                                               int n_chunks, bool loads) {
+                                               int o_lo, int n_chunks, bool loads) {
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         *reinterpret_cast<float4*>(raw + (4 * vw + k) * FU_RAW_ROW + 4 * fu_lane()) = make_float4(0.f, 0.f, 0.f, 0.f);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    fu_fetch(st, raw, 0, vw);       // (debug "no HBM loads" keeps re-using this chunk: realistic operand values)
+    fu_fetch(st, raw, o_lo, vw);       // (debug "no HBM loads" keeps re-using this chunk: realistic operand values)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     fu_split<NB32>(raw, planes, vw);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (n_chunks > 1 && loads) fu_fetch(st, raw, FU_OC, vw);
+    if (n_chunks > 1 && loads) fu_fetch(st, raw, o_lo + FU_OC, vw);
 }
 
 // Stage chunk ch + 1 into the other plane buffer, then put the loads of chunk ch + 2 in flight.
 template <int NB32>
-__device__ __forceinline__ void fu_stage_next(const ScStage& st, float* raw, unsigned short* planes, int vw, int ch,
-                                              int n_chunks, bool loads) {
+__device__ __forceinline__ void fu_stage_next(const ScStage& st, float* raw, unsigned short* planes, int vw,
+                                              int o_lo, int ch, int n_chunks, bool loads) {
     constexpr int plane_elems = NB32 * 32 * FU_PSTRIDE;
     if (ch + 1 < n_chunks) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // raw rows of chunk ch + 1 landed
         fu_split<NB32>(raw, planes + ((ch + 1) & 1) * FU_NPLANES * plane_elems, vw);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // raw rows read before the refill
-        if (ch + 2 < n_chunks && loads) fu_fetch(st, raw, (ch + 2) * FU_OC, vw);
+        if (ch + 2 < n_chunks && loads) fu_fetch(st, raw, o_lo + (ch + 2) * FU_OC, vw);
     }
 }
 
@@ -226,7 +228,8 @@ static_assert(2 * 4 + 1 <= FU_FLUSH, "one fold slot per tile of a wave");
 // MFMAs of the current one.
 template <int NB32>
 __device__ __forceinline__ void fused_mfma_role(const FusedArgs& p, const ScStage& st,
-                                                unsigned short* planes, float* raw, int tid, int wave, int bin) {
+                                                unsigned short* planes, float* raw, int tid, int wave,
+                                                float* rec, int o_lo) {
     constexpr int MAXS = 2 * NB32 + 1;
     const int lane = tid & 63;
     const int NB = p.NB;
@@ -237,15 +240,15 @@ __device__ __forceinline__ void fused_mfma_role(const FusedArgs& p, const ScStag
     f32x4 re[MAXS], im[MAXS];
 #pragma unroll
     for (int s = 0; s < MAXS; ++s) { re[s] = (f32x4){0.f, 0.f, 0.f, 0.f}; im[s] = re[s]; }
-    const int n_chunks = (st.n_obs + FU_OC - 1) / FU_OC;
+    const int n_chunks = (st.n_obs - o_lo + FU_OC - 1) / FU_OC;     // st.n_obs: end of this part
     constexpr int plane_elems = NB32 * 32 * FU_PSTRIDE;
     const unsigned short* frag00 = planes + (lane & 15) * FU_PSTRIDE + (lane >> 4) * 8;
-    float* out = p.accum + (int64_t)bin * p.floats_per_bin + (int64_t)p.csm_plane * p.n_tiles * SC_TILE_ELEMS;
+    float* out = rec + (int64_t)p.csm_plane * p.n_tiles * SC_TILE_ELEMS;
 #define FU_LD(ptr, k) fu_ld8((ptr) + (k) * plane_elems)
     // Staging is shared: the four CSM waves (VALU idle under their MFMA stream) stage observation
     // quads 0-3 AFTER their products, abs waves 0-3 stage quads 4-7 BEFORE theirs.
     const bool loads = !(p.debug_skip & 8);
-    fu_stage_first<NB32>(st, raw, planes, wave, n_chunks, loads);
+    fu_stage_first<NB32>(st, raw, planes, wave, o_lo, n_chunks, loads);
     FU_BARRIER();                 // chunk 0 staged
     FU_T0();
     for (int ch = 0; ch < n_chunks; ++ch) {
@@ -302,7 +305,7 @@ __device__ __forceinline__ void fused_mfma_role(const FusedArgs& p, const ScStag
         }
         FU_TICK(1);
         // stage chunk ch + 1 into the other buffer, then put the loads of chunk ch + 2 in flight
-        fu_stage_next<NB32>(st, raw, planes, wave, ch, n_chunks, loads);
+        fu_stage_next<NB32>(st, raw, planes, wave, o_lo, ch, n_chunks, loads);
         FU_TICK(0);
         // Two-level summation: every FU_FLUSH chunks (512 observations) the f32 accumulators of a tile
         // are folded into the output record (owned by this wave, L2-resident) and cleared, so no f32
@@ -425,7 +428,8 @@ __device__ __forceinline__ FuFragB fu_frag_b(unsigned h, unsigned m, unsigned l,
 
 template <int NB32, int SET>
 __device__ __forceinline__ void fused_valu_body(const FusedArgs& p, const ScStage& st, unsigned short* planes,
-                                                float* raw, int tid, int vw, int rsub, int wps, int bin) {
+                                                float* raw, int tid, int vw, int rsub, int wps, float* rec,
+                                                int o_lo) {
     using Tab = FuTab<NB32, SET>;
     constexpr int NBLK = Tab::NBLK;
     const int lane = tid & 63;
@@ -434,15 +438,15 @@ __device__ __forceinline__ void fused_valu_body(const FusedArgs& p, const ScStag
     for (int s = 0; s < NBLK; ++s)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[s][e] = 0.f;
-    const int n_chunks = (st.n_obs + FU_OC - 1) / FU_OC;
+    const int n_chunks = (st.n_obs - o_lo + FU_OC - 1) / FU_OC;
     constexpr int plane_elems = NB32 * 32 * FU_PSTRIDE;
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const bool loads = !(p.debug_skip & 8);
-    if (vw < 4) fu_stage_first<NB32>(st, raw, planes, 4 + vw, n_chunks, loads);
+    if (vw < 4) fu_stage_first<NB32>(st, raw, planes, 4 + vw, o_lo, n_chunks, loads);
     FU_BARRIER();                 // chunk 0 staged
     FU_T0();
     for (int ch = 0; ch < n_chunks; ++ch) {
-        if (vw < 4) fu_stage_next<NB32>(st, raw, planes, 4 + vw, ch, n_chunks, loads);
+        if (vw < 4) fu_stage_next<NB32>(st, raw, planes, 4 + vw, o_lo, ch, n_chunks, loads);
         FU_TICK(0);
         const unsigned short* pb = planes + (ch & 1) * FU_NPLANES * plane_elems;
         // per-lane plane triples: A reads Im (lanes 0-31) / Re (32-63), B reads Re (lanes 0-31) / Im (32-63)
@@ -530,7 +534,7 @@ __device__ __forceinline__ void fused_valu_body(const FusedArgs& p, const ScStag
     if (rsub == 0) {
         const int i32 = lane & 31, hf = lane >> 5;
         // D layout of v_mfma_f32_32x32x16_bf16: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
-        float* out = p.accum + (int64_t)bin * p.floats_per_bin + (int64_t)p.abs_plane * p.n_tiles * SC_TILE_ELEMS;
+        float* out = rec + (int64_t)p.abs_plane * p.n_tiles * SC_TILE_ELEMS;
 #pragma unroll
         for (int s = 0; s < NBLK; ++s) {
             const int BIs = Tab::tab.bi[s], BJs = Tab::tab.bj[s];
@@ -547,15 +551,16 @@ __device__ __forceinline__ void fused_valu_body(const FusedArgs& p, const ScStag
 
 template <int NB32>
 __device__ __forceinline__ void fused_valu_role(const FusedArgs& p, const ScStage& st,
-                                                unsigned short* planes, float* raw, int tid, int vw, int bin) {
+                                                unsigned short* planes, float* raw, int tid, int vw, float* rec,
+                                                int o_lo) {
     constexpr int NSETS = fu_nsets(NB32);
     constexpr int wps = 8 / NSETS;                        // VALU waves per block set (8 or 4)
     const int set = vw / wps, rsub = vw % wps;
     if constexpr (NSETS == 1) {
-        fused_valu_body<NB32, 0>(p, st, planes, raw, tid, vw, rsub, wps, bin);
+        fused_valu_body<NB32, 0>(p, st, planes, raw, tid, vw, rsub, wps, rec, o_lo);
     } else {
-        if (set == 0) fused_valu_body<NB32, 0>(p, st, planes, raw, tid, vw, rsub, wps, bin);
-        else fused_valu_body<NB32, 1>(p, st, planes, raw, tid, vw, rsub, wps, bin);
+        if (set == 0) fused_valu_body<NB32, 0>(p, st, planes, raw, tid, vw, rsub, wps, rec, o_lo);
+        else fused_valu_body<NB32, 1>(p, st, planes, raw, tid, vw, rsub, wps, rec, o_lo);
     }
 }
 
@@ -564,16 +569,43 @@ __global__ void __launch_bounds__(FU_THREADS) fused_csm_absim_kernel(FusedArgs p
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int bin = blockIdx.x;   // one workgroup per bin: consecutive bins on consecutive XCDs
+    // n_split workgroups per bin (consecutive workgroups land on consecutive XCDs); part k sums its
+    // share of the observation chunks into its own record: part 0 into the caller's, the others into
+    // the workspace, folded in afterwards by fused_combine_kernel in a fixed order.
+    const int bin = blockIdx.x / p.n_split, part = blockIdx.x - bin * p.n_split;
     const int g = bin / p.F, f = bin - g * p.F;
     ScStage st = p.st;
     st.base = p.st.base + (int64_t)f * st.ax.sF + sc_group_offset(st.ax, g);
+    const int nc = (p.st.n_obs + FU_OC - 1) / FU_OC;
+    const int o_lo = (int)((int64_t)part * nc / p.n_split) * FU_OC;
+    const int o_hi = (int)((int64_t)(part + 1) * nc / p.n_split) * FU_OC;
+    st.n_obs = o_hi < p.st.n_obs ? o_hi : p.st.n_obs;
+    float* rec = (part == 0 ? p.accum : p.ws + (int64_t)(part - 1) * p.n_bins * p.floats_per_bin) +
+                 (int64_t)bin * p.floats_per_bin;
     // LDS: the f32 landing rows of the direct HBM->LDS loads, then the two plane buffers (also the
     // scratch of the final tree reduction)
     float* raw = reinterpret_cast<float*>(smem);
     unsigned short* planes = reinterpret_cast<unsigned short*>(smem + FU_OC * FU_RAW_ROW * sizeof(float));
-    if (wave < 4) fused_mfma_role<NB32>(p, st, planes, raw, tid, wave, bin);
-    else fused_valu_role<NB32>(p, st, planes, raw, tid, wave - 4, bin);
+    if (wave < 4) fused_mfma_role<NB32>(p, st, planes, raw, tid, wave, rec, o_lo);
+    else fused_valu_role<NB32>(p, st, planes, raw, tid, wave - 4, rec, o_lo);
+}
+
+// accum[bin][plane] += ws[0][bin][plane] + ws[1][bin][plane] + ... for the CSM (re, im) and |Im| planes
+__global__ void __launch_bounds__(256) fused_combine_kernel(FusedArgs p) {
+    const int64_t plane = (int64_t)p.n_tiles * SC_TILE_ELEMS;      // floats per plane (multiple of 256)
+    const int64_t per_bin = 3 * plane / 4;                          // float4 items per bin
+    const int64_t total = per_bin * p.n_bins;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t bin = i / per_bin, e = (i - bin * per_bin) * 4;
+        const int64_t off = bin * p.floats_per_bin +
+                            (e < 2 * plane ? (int64_t)p.csm_plane * plane + e : (int64_t)p.abs_plane * plane + (e - 2 * plane));
+        float4 a = *reinterpret_cast<const float4*>(p.accum + off);
+        for (int k = 0; k + 1 < p.n_split; ++k) {
+            const float4 b = *reinterpret_cast<const float4*>(p.ws + (int64_t)k * p.n_bins * p.floats_per_bin + off);
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        *reinterpret_cast<float4*>(p.accum + off) = a;
+    }
 }
 
 template <int NB32>
@@ -584,8 +616,12 @@ static int launch_fused(const FusedArgs& a, hipStream_t stream) {
     shmem += (size_t)FU_OC * FU_RAW_ROW * sizeof(float);
     auto k = fused_csm_absim_kernel<NB32>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    hipLaunchKernelGGL(k, dim3((unsigned)a.n_bins), dim3(FU_THREADS), shmem, stream, a);
+    hipLaunchKernelGGL(k, dim3((unsigned)(a.n_bins * a.n_split)), dim3(FU_THREADS), shmem, stream, a);
     SC_CHECK_HIP(hipGetLastError());
+    if (a.n_split > 1) {
+        hipLaunchKernelGGL(fused_combine_kernel, dim3(2048), dim3(256), 0, stream, a);
+        SC_CHECK_HIP(hipGetLastError());
+    }
     return SC_OK;
 }
 
@@ -600,29 +636,69 @@ extern "C" int sc_fused_supported(int64_t n_signals) {
     return (n_signals >= 2 && n_signals <= 128 && (n_signals % 2) == 0) ? 1 : 0;
 }
 
-extern "C" int sc_fused_csm_absim_f32(const void* d_X, const sc_spectra_desc* desc, uint32_t planes,
-                                      float* d_accum, void* stream) {
-    SC_REQUIRE(d_X && desc && d_accum, "NULL argument");
+// Workgroups per bin.  One workgroup fills a CU (LDS), so n_bins workgroups run in ceil(n_bins / n_cu)
+// rounds and the last round may be nearly empty (903 bins on 256 CUs: 4 rounds for 3.53 rounds of
+// work).  Splitting every bin's observations over S workgroups shortens the rounds; pick the S <= 8
+// with the fewest (rounds / S), keeping >= 16 chunks per part.
+static int fused_pick_split(int n_bins, int n_obs) {
+    const char* e = getenv("SC_FUSED_SPLIT");
+    const int nc = (n_obs + FU_OC - 1) / FU_OC;
+    int dev = 0, n_cu = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+        n_cu = prop.multiProcessorCount;
+    int best = 1;
+    double best_cost = 1e30;
+    for (int S = 1; S <= 8; ++S) {
+        if (S > 1 && nc / S < 16) break;
+        const double rounds = (double)(((int64_t)n_bins * S + n_cu - 1) / n_cu) / S;
+        const double cost = rounds * (1.0 + 0.015 * (S - 1));      // prologue/epilogue + combine traffic per part
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = S; }
+    }
+    if (e && atoi(e) >= 1 && atoi(e) <= 8 && (atoi(e) == 1 || nc / atoi(e) >= 1)) best = atoi(e);
+    return best;
+}
+
+static int fused_setup(const void* d_X, const sc_spectra_desc* desc, uint32_t planes, FusedArgs* a, ScAxes* ax) {
+    SC_REQUIRE(desc, "NULL argument");
     SC_REQUIRE((planes & (SC_PLANE_CSM | SC_PLANE_ABS_IM)) == (SC_PLANE_CSM | SC_PLANE_ABS_IM),
                "planes must contain SC_PLANE_CSM and SC_PLANE_ABS_IM");
-    ScAxes ax;
-    sc_make_axes(desc, &ax);
-    SC_REQUIRE(ax.C >= 1 && ax.F >= 1 && ax.n_obs >= 1 && ax.n_groups >= 1, "empty dimension");
-    if (!fused_ok(d_X, ax)) {
-        sc_set_error("fused CSM+|Im| kernel needs an even n_signals <= 128 and 16-byte aligned rows (got C=%d)", ax.C);
+    sc_make_axes(desc, ax);
+    SC_REQUIRE(ax->C >= 1 && ax->F >= 1 && ax->n_obs >= 1 && ax->n_groups >= 1, "empty dimension");
+    if (!fused_ok(d_X, *ax)) {
+        sc_set_error("fused CSM+|Im| kernel needs an even n_signals <= 128 and 16-byte aligned rows (got C=%d)", ax->C);
         return SC_EUNSUPPORTED;
     }
+    a->NB = sc_n_blocks(ax->C);
+    a->n_tiles = sc_n_tiles(a->NB);
+    a->NB32 = (ax->C + 31) / 32;
+    a->n_blocks32 = a->NB32 * (a->NB32 + 1) / 2;
+    a->n_sets = fu_nsets(a->NB32);
+    a->n_bins = ax->n_groups * ax->F;
+    a->F = ax->F;
+    a->floats_per_bin = (int64_t)sc_plane_count(planes) * a->n_tiles * SC_TILE_ELEMS;
+    a->csm_plane = sc_plane_offset(planes, SC_PLANE_CSM);
+    a->abs_plane = sc_plane_offset(planes, SC_PLANE_ABS_IM);
+    a->n_split = 1;
+    a->ws = nullptr;
+    return SC_OK;
+}
+
+extern "C" int64_t sc_fused_workspace_bytes(const sc_spectra_desc* desc, uint32_t planes) {
     FusedArgs a;
-    a.NB = sc_n_blocks(ax.C);
-    a.n_tiles = sc_n_tiles(a.NB);
-    a.NB32 = (ax.C + 31) / 32;
-    a.n_blocks32 = a.NB32 * (a.NB32 + 1) / 2;
-    a.n_sets = fu_nsets(a.NB32);
-    a.n_bins = ax.n_groups * ax.F;
-    a.F = ax.F;
-    a.floats_per_bin = (int64_t)sc_plane_count(planes) * a.n_tiles * SC_TILE_ELEMS;
-    a.csm_plane = sc_plane_offset(planes, SC_PLANE_CSM);
-    a.abs_plane = sc_plane_offset(planes, SC_PLANE_ABS_IM);
+    ScAxes ax;
+    if (fused_setup(nullptr, desc, planes, &a, &ax) != SC_OK) return 0;
+    const int S = fused_pick_split(a.n_bins, ax.n_obs);
+    return (int64_t)(S - 1) * a.n_bins * a.floats_per_bin * (int64_t)sizeof(float);
+}
+
+extern "C" int sc_fused_csm_absim_ws_f32(const void* d_X, const sc_spectra_desc* desc, uint32_t planes,
+                                         float* d_accum, void* d_workspace, int64_t workspace_bytes, void* stream) {
+    SC_REQUIRE(d_X && desc && d_accum, "NULL argument");
+    FusedArgs a;
+    ScAxes ax;
+    const int rc = fused_setup(d_X, desc, planes, &a, &ax);
+    if (rc != SC_OK) return rc;
     a.accum = d_accum;
     a.st.base = (const float2*)d_X;
     a.st.ax = ax;
@@ -635,6 +711,14 @@ extern "C" int sc_fused_csm_absim_f32(const void* d_X, const sc_spectra_desc* de
         const char* dbg = getenv("SC_FUSED_DEBUG");
         a.debug_skip = dbg ? atoi(dbg) : 0;
     }
+    // as many parts per bin as the workspace allows (none: one workgroup per bin)
+    int S = fused_pick_split(a.n_bins, ax.n_obs);
+    const int64_t part_bytes = (int64_t)a.n_bins * a.floats_per_bin * (int64_t)sizeof(float);
+    if (!d_workspace) S = 1;
+    while (S > 1 && (int64_t)(S - 1) * part_bytes > workspace_bytes) --S;
+    SC_REQUIRE(S == 1 || ((uintptr_t)d_workspace % 16) == 0, "workspace must be 16-byte aligned");
+    a.n_split = S;
+    a.ws = (float*)d_workspace;
     hipStream_t s = (hipStream_t)stream;
     switch (a.NB32) {
     case 1: return launch_fused<1>(a, s);
@@ -642,4 +726,9 @@ extern "C" int sc_fused_csm_absim_f32(const void* d_X, const sc_spectra_desc* de
     case 3: return launch_fused<3>(a, s);
     default: return launch_fused<4>(a, s);
     }
+}
+
+extern "C" int sc_fused_csm_absim_f32(const void* d_X, const sc_spectra_desc* desc, uint32_t planes,
+                                      float* d_accum, void* stream) {
+    return sc_fused_csm_absim_ws_f32(d_X, desc, planes, d_accum, nullptr, 0, stream);
 }

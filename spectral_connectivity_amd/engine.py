@@ -148,6 +148,21 @@ def accum_layout(spectra, expectation_type, planes, n_freq=None):
     return n_bins.value, fpb.value, n_groups.value, n_obs.value
 
 
+_ws_cache = {}
+
+
+def _workspace(n_bytes, device):
+    """Scratch the fused stage-B kernel uses to split bins over workgroups (kept and reused per device)."""
+    if n_bytes <= 0:
+        return None
+    key = (device.type, device.index)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < n_bytes:
+        buf = torch.empty(n_bytes, dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
 def accumulate(spectra, expectation_type, planes, n_freq=None, mark=None, use_fused=None):
     """Stage B: un-normalised accumulator record tensor [n_bins, floats_per_bin] (float32)."""
     lib = _lib.load()
@@ -159,8 +174,11 @@ def accumulate(spectra, expectation_type, planes, n_freq=None, mark=None, use_fu
         use_fused = bool(lib.sc_fused_supported(spectra.C))
     if use_fused and (planes & both) == both:
         # one pass: CSM on the matrix cores + |Im s| on the VALU (sc_fused.hip)
-        _lib.check(lib.sc_fused_csm_absim_f32(_ptr(spectra.X), byref(d), planes, _ptr(accum), _stream()),
-                   "sc_fused_csm_absim_f32")
+        ws_bytes = int(lib.sc_fused_workspace_bytes(byref(d), planes))
+        ws = _workspace(ws_bytes, spectra.X.device)
+        _lib.check(lib.sc_fused_csm_absim_ws_f32(_ptr(spectra.X), byref(d), planes, _ptr(accum),
+                                                 _ptr(ws) if ws is not None else None, ws_bytes, _stream()),
+                   "sc_fused_csm_absim_ws_f32")
         if mark:
             mark("fused_csm_absim")
         nl = planes & ~both

@@ -215,6 +215,33 @@ def test_fused_stage_b_equals_separate_kernels(sc, C, R):
                 so.weighted_phase_lag_index(coef), what="wpli vs oracle")
 
 
+@pytest.mark.parametrize("C,R,split", [(128, 150, 3), (64, 130, 2), (128, 200, 5)])
+def test_fused_stage_b_split_bins(sc, C, R, split, monkeypatch):
+    """Several workgroups per bin (observation chunks split, partial records folded in a fixed order)
+    give the sums of the one-workgroup-per-bin launch up to fp32 re-association, and repeat bit-exactly."""
+    from spectral_connectivity_amd import _lib, engine
+    rng = np.random.default_rng(C + R)
+    x = rng.standard_normal((128, R, C))
+    m = sc.Multitaper(x, sampling_frequency=128.0, time_halfbandwidth_product=3,
+                      n_time_samples_per_window=64, n_time_samples_per_step=64)
+    sp = m.device_spectra()
+    planes = _lib.PLANE_CSM | _lib.PLANE_ABS_IM
+    monkeypatch.setenv("SC_FUSED_SPLIT", "1")
+    a_1, n = engine.accumulate(sp, "trials_tapers", planes, use_fused=True)
+    monkeypatch.setenv("SC_FUSED_SPLIT", str(split))
+    a_s, _ = engine.accumulate(sp, "trials_tapers", planes, use_fused=True)
+    a_s2, _ = engine.accumulate(sp, "trials_tapers", planes, use_fused=True)
+    assert bool((a_s == a_s2).all()), "split launch is not reproducible"
+    for which in (_lib.M_CSM, _lib.M_WPLI, _lib.M_COHERENCE_MAGNITUDE):
+        got = engine.measure(a_s, C, planes, n, which).cpu().numpy()
+        ref = engine.measure(a_1, C, planes, n, which).cpu().numpy()
+        close32(got, ref, rtol=2e-6, atol_scale=2e-6, what=f"split {split} vs 1, measure {which}")
+    coef, _ = so.multitaper_fft(x, fs=128.0, NW=3, n_time_samples_per_window=64, n_time_samples_per_step=64)
+    got = engine.measure(a_s, C, planes, n, _lib.M_COHERENCE_MAGNITUDE).cpu().numpy()
+    ref = so.coherence_magnitude(coef)
+    close32(got.reshape(ref.shape), ref, what="split coherence vs oracle")
+
+
 @pytest.mark.parametrize("tag,kw", [
     ("ding2", dict(time_halfbandwidth_product=1)),
     ("bacc3", dict(time_halfbandwidth_product=2, n_time_samples_per_window=250)),
