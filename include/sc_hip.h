@@ -222,6 +222,41 @@ int sc_wilson_factor_f64(const double* d_S, int64_t n_problems, int64_t N, doubl
                          int max_iterations, void* d_work, size_t work_bytes, void* d_G /*complex128*/,
                          int32_t* d_n_iter, int32_t* d_status, int32_t* h_summary, void* stream);
 
+/* ---- full C x C Wilson factor and the directed MVAR measures (fp64) ----------------------
+ * Replaces Connectivity._minimum_phase_factor / _transfer_function / _noise_covariance /
+ * _MVAR_Fourier_coefficients (connectivity.py:567-589), minimum_phase_decomposition() for any c
+ * (minimum_phase_decomposition.py:227-322) and directed_transfer_function, directed_coherence,
+ * partial_directed_coherence, generalized_partial_directed_coherence,
+ * direct_directed_transfer_function (connectivity.py:1237-1426).  All windows iterate together,
+ * converged windows are frozen; one (window, bin) matrix pair lives in LDS: n_signals <=
+ * sc_mvar_max_signals() (64), larger systems return SC_EUNSUPPORTED.
+ * sc_mvar_factor_f64: exactly one of d_accum (accumulator records holding SC_PLANE_CSM, N or N/2+1
+ * bins per window, real-input symmetry completes the rest) and d_S (complex128 [P][N][C][C], two-sided
+ * Hermitian spectra) is non-NULL.  d_G: complex128 [P][N][C][C].  d_status[p]: 1 converged, 0 not
+ * converged after max_iterations, -1 lag-0 covariance not positive definite; h_summary =
+ * {iterations run, windows still running}.  Synchronises the stream once per iteration.
+ * sc_mvar_measure_f64: d_G as above -> double [P][N/2+1][C][C] (SC_MVAR_DTF..DDTF), complex128
+ * [P][N/2+1][C][C] (SC_MVAR_TRANSFER, SC_MVAR_COEFFICIENTS) or double [P][C][C] (NOISE_COVARIANCE).
+ * The Tikhonov terms are the reference's: 1e-12 * mean(H0^2) over all windows, 1e-12 * mean(|H|^2)
+ * over all windows and non-negative bins.  One workspace size serves both calls. */
+#define SC_MVAR_DTF 0                /* connectivity.py:1237-1270 */
+#define SC_MVAR_DC 1                 /* connectivity.py:1272-1309 */
+#define SC_MVAR_PDC 2                /* connectivity.py:1311-1364 */
+#define SC_MVAR_GPDC 3               /* connectivity.py:1366-1400 */
+#define SC_MVAR_DDTF 4               /* connectivity.py:1402-1426 */
+#define SC_MVAR_TRANSFER 5           /* connectivity.py:1712-1748 */
+#define SC_MVAR_COEFFICIENTS 6       /* connectivity.py:581-589   */
+#define SC_MVAR_NOISE_COVARIANCE 7   /* connectivity.py:1679-1709 */
+int sc_mvar_max_signals(void);
+int sc_mvar_workspace_bytes(int64_t n_groups, int64_t n_signals, int64_t N, size_t* bytes);
+int sc_mvar_factor_f64(const float* d_accum, const void* d_S /*complex128*/, int64_t n_groups,
+                       int64_t n_freq_accum, int64_t N, int64_t n_signals, uint32_t planes,
+                       int64_t n_observations, double tolerance, int max_iterations, void* d_work,
+                       size_t work_bytes, void* d_G /*complex128*/, int32_t* d_n_iter, int32_t* d_status,
+                       int32_t* h_summary, void* stream);
+int sc_mvar_measure_f64(const void* d_G /*complex128*/, int64_t n_groups, int64_t N, int64_t n_signals,
+                        int which, void* d_out, void* d_work, size_t work_bytes, void* stream);
+
 /* ---- canonical coherence between channel groups (fp64, from the accumulated CSM) -------
  * Replaces Connectivity.canonical_coherence, _normalize_fourier_coefficients and
  * _estimate_canonical_coherence (connectivity.py:745-820, :1979-2032): per (bin, group pair)

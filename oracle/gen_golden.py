@@ -41,10 +41,57 @@ def save(name, **arrays):
     print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB, keys={len(arrays)}")
 
 
+def gen_f9_mvar(T, Cn, mpd, sim):
+    """F9: full C x C Wilson factor and the MVAR measures (DTF, directed coherence, PDC, gPDC, dDTF) on a
+    3-channel and a 5-channel VAR system, two time windows each."""
+    Multitaper, Connectivity = T.Multitaper, Cn.Connectivity
+
+    def simulate(coefs, cov, n_time, n_trials, seed):
+        rs = np.random.default_rng(seed)
+        return sim.simulate_MVAR(coefs, noise_covariance=cov, n_time_samples=n_time,
+                                 n_trials=n_trials, n_burnin_samples=200, random_state=rs)
+
+    coefs3 = np.zeros((2, 3, 3))
+    coefs3[0] = [[0.5, 0.3, 0.4], [-0.5, 0.3, 1.0], [0.0, -0.3, -0.2]]
+    coefs3[1] = [[-0.2, 0.0, 0.0], [0.3, -0.3, 0.0], [0.0, 0.0, 0.3]]
+    x3 = simulate(coefs3 * 0.6, np.diag([1.0, 0.5, 2.0]), 512, 12, 16)
+    # 5-channel system in the style of Baccala & Sameshima (2001), example 3
+    r2 = np.sqrt(2.0)
+    coefs5 = np.zeros((3, 5, 5))
+    coefs5[0, 0, 0] = 0.95 * r2
+    coefs5[1, 0, 0] = -0.9025
+    coefs5[1, 1, 0] = 0.5
+    coefs5[2, 2, 0] = -0.4
+    coefs5[1, 3, 0] = -0.5
+    coefs5[0, 3, 3] = 0.25 * r2
+    coefs5[0, 3, 4] = 0.25 * r2
+    coefs5[0, 4, 3] = -0.25 * r2
+    coefs5[0, 4, 4] = 0.25 * r2
+    x5 = simulate(coefs5, np.eye(5), 512, 10, 17)
+    arrs = {}
+    for tag, xs in (("var3", x3), ("var5", x5)):
+        m = Multitaper(xs, sampling_frequency=128.0, time_halfbandwidth_product=2, n_time_samples_per_window=256)
+        c = Connectivity.from_multitaper(m)
+        arrs[f"{tag}__x"] = xs
+        arrs[f"{tag}__csm"] = c._expectation_cross_spectral_matrix()
+        arrs[f"{tag}__minimum_phase_factor"] = c._minimum_phase_factor
+        arrs[f"{tag}__transfer_function"] = c._transfer_function
+        arrs[f"{tag}__noise_covariance"] = c._noise_covariance
+        arrs[f"{tag}__mvar_coefficients"] = c._MVAR_Fourier_coefficients
+        for name in ("directed_transfer_function", "directed_coherence", "partial_directed_coherence",
+                     "generalized_partial_directed_coherence", "direct_directed_transfer_function"):
+            arrs[f"{tag}__{name}"] = getattr(c, name)()
+    save("f9_mvar", **arrs)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     warnings.simplefilter("ignore")
     T, Cn, mpd, sim = import_reference()
+    if len(sys.argv) > 1:                      # python oracle/gen_golden.py f9 : only the named fixtures
+        for name in sys.argv[1:]:
+            {"f9": gen_f9_mvar}[name](T, Cn, mpd, sim)
+        return
     Multitaper, Connectivity = T.Multitaper, Cn.Connectivity
 
     # F1: BASELINE cfg1 -- 2 ch x 1 trial x 1024, sine + noise, NW=3, single window
@@ -186,6 +233,7 @@ def main():
         arrs[f"L{L}_NW{NW}__tapers"] = np.asarray(tap)
         arrs[f"L{L}_NW{NW}__eig"] = np.asarray(eig)
     save("f8_dpss", **arrs)
+    gen_f9_mvar(T, Cn, mpd, sim)
 
 
 if __name__ == "__main__":

@@ -377,6 +377,66 @@ def _noise_covariance(G):
     return np.matmul(H0, H0.swapaxes(-1, -2))
 
 
+def _mvar_fourier_coefficients(H):
+    """connectivity.py:581-589: (H + lam I)^-1 with lam = 1e-12 * mean(|H|^2) over the whole array."""
+    lam = 1e-12 * np.mean((np.conj(H) * H).real)
+    eye = np.eye(H.shape[-1], dtype=H.dtype)
+    return np.linalg.solve(H + lam * eye, eye)
+
+
+def mvar_quantities(coef, expectation_type="trials_tapers", csm=None):
+    """Full C x C Wilson factor of the two-sided CSM and what the MVAR measures derive from it
+    (connectivity.py:567-589): G (all N bins), H and A on the non-negative bins, noise covariance."""
+    if csm is None:
+        csm = expectation_csm_gemm(coef, expectation_type)
+    G = minimum_phase_decomposition(csm)
+    H = _take_nonneg(_transfer_function(G), -3)
+    return dict(G=G, H=H, A=_mvar_fourier_coefficients(H), noise_covariance=_noise_covariance(G))
+
+
+def _noise_variance(noise_covariance):
+    """connectivity.py:1904-1922: diag(Sigma) shaped (..., 1, C, 1): indexed by the ROW channel."""
+    return np.diagonal(noise_covariance, axis1=-1, axis2=-2)[..., np.newaxis, :, np.newaxis]
+
+
+def directed_transfer_function(coef, expectation_type="trials_tapers", q=None):
+    """connectivity.py:1237-1270: |H_ij|^2 / sum_j |H_ij|^2."""
+    q = q or mvar_quantities(coef, expectation_type)
+    p = np.abs(q["H"]) ** 2
+    return np.abs(q["H"] / np.sqrt(p.sum(axis=-1, keepdims=True))) ** 2
+
+
+def directed_coherence(coef, expectation_type="trials_tapers", q=None):
+    """connectivity.py:1272-1309: sqrt(nv_i) |H_ij|^2 / sqrt(sum_j nv_i |H_ij|^2), nv = diag(Sigma)."""
+    q = q or mvar_quantities(coef, expectation_type)
+    nv = _noise_variance(q["noise_covariance"])
+    p = np.abs(q["H"]) ** 2
+    return np.sqrt(nv) * p / np.sqrt((nv * p).sum(axis=-1, keepdims=True))
+
+
+def partial_directed_coherence(coef, expectation_type="trials_tapers", q=None):
+    """connectivity.py:1311-1364: |A_ij|^2 / sum_i |A_ij|^2, A = MVAR Fourier coefficients."""
+    q = q or mvar_quantities(coef, expectation_type)
+    p = np.abs(q["A"]) ** 2
+    return np.abs(q["A"] / np.sqrt(p.sum(axis=-2, keepdims=True))) ** 2
+
+
+def generalized_partial_directed_coherence(coef, expectation_type="trials_tapers", q=None):
+    """connectivity.py:1366-1400: |A_ij / sqrt(nv_i) / sqrt(sum_i |A_ij|^2 / nv_i)|^2."""
+    q = q or mvar_quantities(coef, expectation_type)
+    nv = _noise_variance(q["noise_covariance"])
+    p = np.abs(q["A"]) ** 2
+    return np.abs(q["A"] / np.sqrt(nv) / np.sqrt((p / nv).sum(axis=-2, keepdims=True))) ** 2
+
+
+def direct_directed_transfer_function(coef, expectation_type="trials_tapers", q=None):
+    """connectivity.py:1402-1426: |H_ij| / sqrt(sum_{f,j} |H_ij|^2) * sqrt(PDC_ij)."""
+    q = q or mvar_quantities(coef, expectation_type)
+    p = np.abs(q["H"]) ** 2
+    full = q["H"] / np.sqrt(p.sum(axis=(-1, -3), keepdims=True))
+    return np.abs(full) * np.sqrt(partial_directed_coherence(coef, expectation_type, q))
+
+
 def pairwise_spectral_granger_prediction(coef, expectation_type="trials_tapers", pairs=None):
     """connectivity.py:1161-1191 + :2282-2340 (one 2x2 Wilson problem per channel pair).
 
@@ -441,6 +501,14 @@ def canonical_coherence(coef, group_labels):
         out[..., a, b] = out[..., b, a] = np.abs(s) ** 2
     return out, labels
 
+
+MVAR_MEASURES = {
+    "directed_transfer_function": directed_transfer_function,
+    "directed_coherence": directed_coherence,
+    "partial_directed_coherence": partial_directed_coherence,
+    "generalized_partial_directed_coherence": generalized_partial_directed_coherence,
+    "direct_directed_transfer_function": direct_directed_transfer_function,
+}
 
 MEASURES = {
     "power": power,

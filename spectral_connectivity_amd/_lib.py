@@ -20,6 +20,7 @@ c_int64_p = POINTER(c_int64)
 # ---- constants mirrored from include/sc_hip.h -------------------------------------------
 SC_ABI_VERSION = 1
 DETREND = {None: 0, "constant": 1, "c": 1, "linear": 2, "l": 2}
+MVAR_DTF, MVAR_DC, MVAR_PDC, MVAR_GPDC, MVAR_DDTF, MVAR_TRANSFER, MVAR_COEFFICIENTS, MVAR_NOISE_COVARIANCE = range(8)
 PLANE_CSM, PLANE_ABS_IM, PLANE_IM_SQ, PLANE_SIGN_IM, PLANE_UNIT = 0x01, 0x02, 0x04, 0x08, 0x10
 (M_POWER, M_CSM, M_COHERENCY, M_COHERENCE_MAGNITUDE, M_COHERENCE_PHASE, M_IMAGINARY_COHERENCE,
  M_PLV, M_PLI, M_WPLI, M_DEBIASED_PLI2, M_DEBIASED_WPLI2, M_PPC, M_PLV_COMPLEX) = range(13)
@@ -70,6 +71,13 @@ SYMBOLS = {
                                         c_void_p, c_void_p, POINTER(c_int32), c_void_p]),
     "sc_wilson_factor_f64": (c_int, [c_void_p, c_int64, c_int64, c_double, c_int, c_void_p, c_size_t, c_void_p,
                                      c_void_p, c_void_p, POINTER(c_int32), c_void_p]),
+    "sc_mvar_max_signals": (c_int, []),
+    "sc_mvar_workspace_bytes": (c_int, [c_int64, c_int64, c_int64, POINTER(c_size_t)]),
+    "sc_mvar_factor_f64": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_uint32, c_int64,
+                                   c_double, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p,
+                                   POINTER(c_int32), c_void_p]),
+    "sc_mvar_measure_f64": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p, c_size_t,
+                                    c_void_p]),
     "sc_canonical_max_group": (c_int, []),
     "sc_canonical_coherence_f64": (c_int, [c_void_p, c_int64, c_int64, c_uint32, c_int64, c_void_p, c_void_p,
                                            c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -253,6 +253,81 @@ class Connectivity:
     def subset_pairwise_spectral_granger_prediction(self, pairs):
         return self._granger(np.asarray(pairs, dtype=np.int32))
 
+    # ---- full Wilson factor and the directed MVAR measures (reference connectivity.py:567-589,
+    # :1237-1426): one batched C x C factorisation on the device, cached, then one small kernel
+    # per measure ------------------------------------------------------------------------------
+    def _mvar_factor_device(self):
+        from . import engine
+        if getattr(self, "_mvar_G", None) is not None:
+            return self._mvar_G
+        sp = self._device()
+        N, C = self._shape5[3], self._shape5[4]
+        if C > _lib.load().sc_mvar_max_signals():
+            raise ValueError(f"the full Wilson factorisation supports n_signals <= "
+                             f"{_lib.load().sc_mvar_max_signals()} (got {C}); use the pairwise measures")
+        n_freq = sp.F if sp.real_input else N
+        planes = _lib.PLANE_CSM
+        key = ("granger", n_freq)
+        if key not in self._accum_cache:
+            accum, n_obs = engine.accumulate(sp, self.expectation_type, planes, n_freq=n_freq)
+            self._accum_cache[key] = (self._reduce_over_ranks(accum), n_obs)
+        accum, n_obs = self._accum_cache[key]
+        n_groups = accum.shape[0] // n_freq
+        G, n_iter, status, (iters, not_conv) = engine.mvar_factor(
+            n_groups, N, C, accum=accum, n_freq_accum=n_freq, planes=planes, n_obs=self._n_observations_total(n_obs))
+        st = status.cpu().numpy()
+        if (st < 0).any():
+            raise np.linalg.LinAlgError("lag-0 covariance of the cross-spectral matrix is not positive definite")
+        if not_conv:
+            logger.warning(f"Maximum iterations reached. {st.size - not_conv} of {st.size} converged")
+        self._last_wilson = dict(iterations=iters, not_converged=not_conv, n_iter=n_iter.cpu().numpy(), status=st)
+        self._mvar_G = G
+        return G
+
+    def _mvar(self, which, n_freq_axis=True):
+        from . import engine
+        out = engine.mvar_measure(self._mvar_factor_device(), which).cpu().numpy()
+        C = self._shape5[4]
+        tail = (self._shape5[3] // 2 + 1, C, C) if n_freq_axis else (C, C)
+        return out.reshape(self._kept_shape() + tail)
+
+    @property
+    def _minimum_phase_factor(self):
+        G = self._mvar_factor_device().cpu().numpy()
+        return G.reshape(self._kept_shape() + G.shape[1:])
+
+    @property
+    def _transfer_function(self):
+        return self._mvar(_lib.MVAR_TRANSFER)
+
+    @property
+    def _noise_covariance(self):
+        return self._mvar(_lib.MVAR_NOISE_COVARIANCE, n_freq_axis=False)
+
+    @property
+    def _MVAR_Fourier_coefficients(self):
+        return self._mvar(_lib.MVAR_COEFFICIENTS)
+
+    def directed_transfer_function(self):
+        """|H_ij|^2 normalised by the total inflow into node i; out[..., i, j] = j -> i, range [0, 1]."""
+        return self._mvar(_lib.MVAR_DTF)
+
+    def directed_coherence(self):
+        """Transfer-function coupling scaled by the noise variance, normalised by the inflow."""
+        return self._mvar(_lib.MVAR_DC)
+
+    def partial_directed_coherence(self, keep_cupy=False):
+        """|A_ij|^2 of the MVAR Fourier coefficients normalised by the total outflow of node j."""
+        return self._mvar(_lib.MVAR_PDC)
+
+    def generalized_partial_directed_coherence(self):
+        """Partial directed coherence with every row scaled by its noise variance."""
+        return self._mvar(_lib.MVAR_GPDC)
+
+    def direct_directed_transfer_function(self):
+        """Full-frequency directed transfer function times sqrt(partial directed coherence)."""
+        return self._mvar(_lib.MVAR_DDTF)
+
     # ---- canonical coherence (reference connectivity.py:745-820) --------------------------
     def canonical_coherence(self, group_labels):
         """Maximal coherence between linear combinations of each pair of channel groups.

@@ -242,6 +242,49 @@ def granger_pairwise(accum, n_groups, n_freq_accum, n_fft, n_signals, planes, n_
     return out, n_iter, status, (summary[0], summary[1])
 
 
+def _mvar_workspace(n_groups, n_signals, n_fft, dev):
+    lib = _lib.load()
+    nbytes = ctypes.c_size_t()
+    _lib.check(lib.sc_mvar_workspace_bytes(n_groups, n_signals, n_fft, byref(nbytes)), "sc_mvar_workspace_bytes")
+    return torch.empty((nbytes.value,), dtype=torch.uint8, device=dev), nbytes.value
+
+
+def mvar_factor(n_groups, n_fft, n_signals, accum=None, n_freq_accum=0, planes=0, n_obs=1, spectra=None,
+                tolerance=1e-8, max_iterations=60):
+    """Full C x C Wilson factor (sc_mvar.hip) of accumulator records or of a two-sided complex128 spectrum
+    tensor [n_groups, n_fft, C, C].  Returns (G [n_groups, n_fft, C, C] complex128, n_iter, status, summary)."""
+    lib = _lib.load()
+    src = accum if accum is not None else spectra
+    dev = src.device
+    work, nbytes = _mvar_workspace(n_groups, n_signals, n_fft, dev)
+    G = torch.empty((n_groups, n_fft, n_signals, n_signals), dtype=torch.complex128, device=dev)
+    n_iter = torch.empty((n_groups,), dtype=torch.int32, device=dev)
+    status = torch.empty((n_groups,), dtype=torch.int32, device=dev)
+    summary = (ctypes.c_int32 * 2)(0, 0)
+    _lib.check(lib.sc_mvar_factor_f64(_ptr(accum) if accum is not None else None,
+                                      _ptr(spectra) if spectra is not None else None, n_groups, n_freq_accum, n_fft,
+                                      n_signals, planes, n_obs, tolerance, max_iterations, _ptr(work), nbytes, _ptr(G),
+                                      _ptr(n_iter), _ptr(status), summary, _stream()), "sc_mvar_factor_f64")
+    return G, n_iter, status, (summary[0], summary[1])
+
+
+def mvar_measure(G, which):
+    """A directed MVAR measure / model quantity (``_lib.MVAR_*``) from the minimum-phase factor G."""
+    lib = _lib.load()
+    n_groups, n_fft, C, _ = G.shape
+    F = n_fft // 2 + 1
+    work, nbytes = _mvar_workspace(n_groups, C, n_fft, G.device)
+    if which == _lib.MVAR_NOISE_COVARIANCE:
+        out = torch.empty((n_groups, C, C), dtype=torch.float64, device=G.device)
+    elif which in (_lib.MVAR_TRANSFER, _lib.MVAR_COEFFICIENTS):
+        out = torch.empty((n_groups, F, C, C), dtype=torch.complex128, device=G.device)
+    else:
+        out = torch.empty((n_groups, F, C, C), dtype=torch.float64, device=G.device)
+    _lib.check(lib.sc_mvar_measure_f64(_ptr(G), n_groups, n_fft, C, which, _ptr(out), _ptr(work), nbytes, _stream()),
+               "sc_mvar_measure_f64")
+    return out
+
+
 def canonical_coherence(accum, n_signals, planes, n_obs, groups):
     """groups: list of int arrays (channel indices per group).  Returns ([n_bins, G, G] float64, n_fail)."""
     lib = _lib.load()

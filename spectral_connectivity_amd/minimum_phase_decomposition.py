@@ -1,10 +1,11 @@
 """Minimum-phase (Wilson) spectral factorisation on the GPU.
 
 Drop-in for ``spectral_connectivity.minimum_phase_decomposition.minimum_phase_decomposition``
-(reference minimum_phase_decomposition.py:227-322) for 1x1 and 2x2 cross-spectral matrices -- the
-sizes the hot path (pairwise spectral Granger prediction) uses.  All problems along the leading
-axes advance together in fp64 through ``sc_wilson_factor_f64`` (batched closed-form 2x2 solves,
-rocFFT Z2Z along the frequency axis).  There is no CPU fallback.
+(reference minimum_phase_decomposition.py:227-322).  1x1 and 2x2 cross-spectral matrices -- the
+sizes the hot path (pairwise spectral Granger prediction) uses -- advance together in fp64 through
+``sc_wilson_factor_f64`` (batched closed-form 2x2 solves, rocFFT Z2Z along the frequency axis);
+larger systems (up to ``sc_mvar_max_signals()`` = 64 signals) go through ``sc_mvar_factor_f64``
+(LU solves in LDS, one workgroup per window and frequency bin).  There is no CPU fallback.
 """
 import ctypes
 from ctypes import byref
@@ -18,8 +19,8 @@ logger = getLogger(__name__)
 def minimum_phase_decomposition(cross_spectral_matrix, tolerance=1e-8, max_iterations=60):
     """Minimum-phase square root G of a Hermitian spectral density, S = G G^H.
 
-    cross_spectral_matrix : complex array, shape (n_time, ..., n_fft_samples, c, c), c in {1, 2},
-        two-sided in frequency.  Returns an array of the same shape (complex128).
+    cross_spectral_matrix : complex array, shape (n_time, ..., n_fft_samples, c, c), two-sided in
+        frequency.  Returns an array of the same shape (complex128).
     Differences from the reference: every leading-axis problem stops at its own convergence (the
     reference freezes a window once it has converged -- same iterate); a lag-0 covariance that is not
     positive definite yields NaN for that problem instead of a random re-initialisation.
@@ -34,12 +35,26 @@ def minimum_phase_decomposition(cross_spectral_matrix, tolerance=1e-8, max_itera
     if csm.ndim < 3 or csm.shape[-1] != csm.shape[-2]:
         raise ValueError("cross_spectral_matrix must have shape (..., n_fft_samples, n_signals, n_signals)")
     c, N = csm.shape[-1], csm.shape[-3]
-    if c > 2:
-        raise NotImplementedError(
-            "the HIP Wilson kernel factorises 1x1 and 2x2 spectra (pairwise Granger); "
-            f"got n_signals={c}.  The full C x C factorisation is not part of this engine yet.")
     lead = csm.shape[:-3]
     P = int(np.prod(lead)) if lead else 1
+    if c > 2:
+        from . import engine
+        if c > lib.sc_mvar_max_signals():
+            raise NotImplementedError(f"the HIP Wilson kernels factorise up to {lib.sc_mvar_max_signals()} x "
+                                      f"{lib.sc_mvar_max_signals()} spectra; got n_signals={c}")
+        dev = torch.device("cuda", torch.cuda.current_device())
+        out = np.empty((P, N, c, c), dtype=np.complex128)
+        flat = np.ascontiguousarray(csm.reshape(P, N, c, c).astype(np.complex128))
+        step = 4096
+        for p0 in range(0, P, step):
+            n = min(step, P - p0)
+            G, _, status, (_, not_conv) = engine.mvar_factor(n, N, c, spectra=torch.from_numpy(flat[p0:p0 + n]).to(dev),
+                                                             tolerance=tolerance, max_iterations=max_iterations)
+            if not_conv:
+                logger.warning(f"Maximum iterations reached. {n - not_conv} of {n} converged")
+            out[p0:p0 + n] = G.cpu().numpy()
+            out[p0:p0 + n][status.cpu().numpy() < 0] = np.nan
+        return out.reshape(csm.shape)
     flat = csm.reshape(P, N, c, c).astype(np.complex128)
     S = np.empty((P, 4, N), dtype=np.float64)
     S[:, 0] = flat[:, :, 0, 0].real

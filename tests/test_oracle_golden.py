@@ -79,6 +79,21 @@ def test_f5_granger(golden, tag, kw):
     close(so.pairwise_spectral_granger_prediction(coef), g[f"{tag}__granger"], rtol=1e-6, atol=1e-9)
 
 
+@pytest.mark.parametrize("tag", ["var3", "var5"])
+def test_f9_mvar_measures(golden, tag):
+    """Full C x C Wilson factor and the directed MVAR measures against the real reference."""
+    g = golden("f9_mvar")
+    coef, _ = so.multitaper_fft(g[f"{tag}__x"], fs=128.0, NW=2, n_time_samples_per_window=256)
+    close(so.expectation_csm_gemm(coef), g[f"{tag}__csm"], atol=1e-12)
+    q = so.mvar_quantities(coef)
+    close(q["G"], g[f"{tag}__minimum_phase_factor"], rtol=1e-7, atol=1e-9)
+    close(q["H"], g[f"{tag}__transfer_function"], rtol=1e-7, atol=1e-9)
+    close(q["noise_covariance"], g[f"{tag}__noise_covariance"], rtol=1e-7, atol=1e-9)
+    close(q["A"], g[f"{tag}__mvar_coefficients"], rtol=1e-6, atol=1e-8)
+    for name, fn in so.MVAR_MEASURES.items():
+        close(fn(coef, q=q), g[f"{tag}__{name}"], rtol=1e-6, atol=1e-9)
+
+
 def test_f6_canonical(golden):
     g = golden("f6_canonical")
     coef, _ = so.multitaper_fft(g["x"], fs=float(g["fs"]), NW=float(g["NW"]),
