@@ -257,6 +257,22 @@ int sc_mvar_factor_f64(const float* d_accum, const void* d_S /*complex128*/, int
 int sc_mvar_measure_f64(const void* d_G /*complex128*/, int64_t n_groups, int64_t N, int64_t n_signals,
                         int which, void* d_out, void* d_work, size_t work_bytes, void* stream);
 
+/* ---- global coherence (fp64, from the accumulated CSM) --------------------------------------
+ * Replaces Connectivity.global_coherence / _estimate_global_coherence (connectivity.py:822-895,
+ * :2245-2279): the leading squared singular values / n_estimates and left singular vectors of the
+ * n_signals x (n_trials n_tapers) coefficient matrix per (window, two-sided bin) are the leading
+ * eigenpairs of the cross-spectral matrix; parallel cyclic Jacobi in LDS, n_signals <=
+ * sc_global_coherence_max_signals() (64).  d_accum: records with SC_PLANE_CSM accumulated over
+ * trials and tapers, N or N/2+1 bins per window (real-input symmetry completes the rest).
+ * d_values: double [n_groups][N][max_rank]; d_vectors: complex128 [n_groups][N][n_signals][max_rank],
+ * unit norm, largest component real positive (the reference's phase is LAPACK's/ARPACK's).
+ * ascending != 0 orders the max_rank largest values smallest-first (scipy svds, which the reference
+ * takes when max_rank < n_signals - 1). */
+int sc_global_coherence_max_signals(void);
+int sc_global_coherence_f64(const float* d_accum, int64_t n_groups, int64_t n_freq_accum, int64_t N,
+                            int64_t n_signals, uint32_t planes, int64_t n_observations, int max_rank,
+                            int ascending, double* d_values, void* d_vectors /*complex128*/, void* stream);
+
 /* ---- canonical coherence between channel groups (fp64, from the accumulated CSM) -------
  * Replaces Connectivity.canonical_coherence, _normalize_fourier_coefficients and
  * _estimate_canonical_coherence (connectivity.py:745-820, :1979-2032): per (bin, group pair)

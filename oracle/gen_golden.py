@@ -84,13 +84,29 @@ def gen_f9_mvar(T, Cn, mpd, sim):
     save("f9_mvar", **arrs)
 
 
+def gen_f10_global(T, Cn, mpd, sim):
+    """F10: global coherence (leading squared singular values / vectors per window and two-sided bin)."""
+    rng = np.random.default_rng(10)
+    t = np.arange(256) / 256.0
+    common = np.sin(2 * np.pi * 40 * t)
+    x = 0.6 * rng.standard_normal((256, 6, 5))
+    x += common[:, None, None] * np.array([1.0, 0.8, -0.6, 0.3, 0.0])[None, None, :]
+    m = T.Multitaper(x, sampling_frequency=256.0, time_halfbandwidth_product=2, n_time_samples_per_window=128)
+    c = Cn.Connectivity.from_multitaper(m)
+    arrs = dict(x=x)
+    for rank in (1, 2, 4, 5):
+        v, u = c.global_coherence(max_rank=rank)
+        arrs[f"rank{rank}__values"], arrs[f"rank{rank}__vectors"] = v, u
+    save("f10_global", **arrs)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     warnings.simplefilter("ignore")
     T, Cn, mpd, sim = import_reference()
     if len(sys.argv) > 1:                      # python oracle/gen_golden.py f9 : only the named fixtures
         for name in sys.argv[1:]:
-            {"f9": gen_f9_mvar}[name](T, Cn, mpd, sim)
+            {"f9": gen_f9_mvar, "f10": gen_f10_global}[name](T, Cn, mpd, sim)
         return
     Multitaper, Connectivity = T.Multitaper, Cn.Connectivity
 
@@ -234,6 +250,7 @@ def main():
         arrs[f"L{L}_NW{NW}__eig"] = np.asarray(eig)
     save("f8_dpss", **arrs)
     gen_f9_mvar(T, Cn, mpd, sim)
+    gen_f10_global(T, Cn, mpd, sim)
 
 
 if __name__ == "__main__":

@@ -502,6 +502,27 @@ def canonical_coherence(coef, group_labels):
     return out, labels
 
 
+def global_coherence(coef, max_rank=1):
+    """connectivity.py:822-895, :2245-2279: per (window, two-sided bin) the thin SVD of the
+    (n_signals, n_trials * n_tapers) coefficient matrix; squared singular values / n_estimates and the
+    left singular vectors.  The reference takes scipy's svds when max_rank < n_signals - 1, which
+    returns the max_rank largest values in ASCENDING order; otherwise numpy's svd (descending).
+    Singular vectors are defined up to a unit phase."""
+    W, R, K, N, C = coef.shape
+    vals = np.zeros((W, N, max_rank))
+    vecs = np.zeros((W, N, C, max_rank), dtype=np.complex128)
+    for w in range(W):
+        for n in range(N):
+            X = coef[w, :, :, n, :].reshape(R * K, C).T
+            U, s, _ = np.linalg.svd(X, full_matrices=False)
+            g = s[:max_rank] ** 2 / (R * K)
+            u = U[:, :max_rank]
+            if max_rank < C - 1:
+                g, u = g[::-1], u[:, ::-1]
+            vals[w, n], vecs[w, n] = g, u
+    return vals, vecs
+
+
 MVAR_MEASURES = {
     "directed_transfer_function": directed_transfer_function,
     "directed_coherence": directed_coherence,

@@ -78,6 +78,9 @@ SYMBOLS = {
                                    POINTER(c_int32), c_void_p]),
     "sc_mvar_measure_f64": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p, c_size_t,
                                     c_void_p]),
+    "sc_global_coherence_max_signals": (c_int, []),
+    "sc_global_coherence_f64": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_uint32, c_int64, c_int, c_int,
+                                        c_void_p, c_void_p, c_void_p]),
     "sc_canonical_max_group": (c_int, []),
     "sc_canonical_coherence_f64": (c_int, [c_void_p, c_int64, c_int64, c_uint32, c_int64, c_void_p, c_void_p,
                                            c_int, c_int, c_void_p, c_void_p, c_void_p]),

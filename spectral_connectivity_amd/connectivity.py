@@ -328,6 +328,36 @@ class Connectivity:
         """Full-frequency directed transfer function times sqrt(partial directed coherence)."""
         return self._mvar(_lib.MVAR_DDTF)
 
+    # ---- global coherence (reference connectivity.py:822-895) ------------------------------
+    def global_coherence(self, max_rank=1):
+        """Leading squared singular values (/ n_estimates) and left singular vectors of the signals x
+        (trials * tapers) coefficient matrix, per time window and (two-sided) frequency bin.
+
+        Returns (values (n_time_windows, n_fft_samples, max_rank), vectors (n_time_windows,
+        n_fft_samples, n_signals, max_rank)).  Computed as the leading eigenpairs of the cross-spectral
+        matrix that is already on the device.  Like the reference, the max_rank largest values come
+        smallest-first when max_rank < n_signals - 1 (scipy svds) and largest-first otherwise; vectors
+        are unit norm with their largest component real positive (the reference's phase is arbitrary).
+        """
+        from . import engine
+        sp = self._device()
+        W, R, K, N, C = self._shape5
+        max_rank = int(max_rank)
+        if not 1 <= max_rank <= min(C, R * K):
+            raise ValueError(f"max_rank must be between 1 and min(n_signals, n_trials * n_tapers) = {min(C, R * K)}")
+        if C > _lib.load().sc_global_coherence_max_signals():
+            raise ValueError(f"global_coherence supports n_signals <= {_lib.load().sc_global_coherence_max_signals()}")
+        n_freq = sp.F if sp.real_input else N
+        planes = _lib.PLANE_CSM
+        key = ("global", n_freq)
+        if key not in self._accum_cache:
+            accum, n_obs = engine.accumulate(sp, "trials_tapers", planes, n_freq=n_freq)
+            self._accum_cache[key] = (self._reduce_over_ranks(accum), n_obs)
+        accum, n_obs = self._accum_cache[key]
+        values, vectors = engine.global_coherence(accum, W, n_freq, N, C, planes, self._n_observations_total(n_obs),
+                                                  max_rank, ascending=max_rank < C - 1)
+        return values.cpu().numpy(), vectors.cpu().numpy()
+
     # ---- canonical coherence (reference connectivity.py:745-820) --------------------------
     def canonical_coherence(self, group_labels):
         """Maximal coherence between linear combinations of each pair of channel groups.

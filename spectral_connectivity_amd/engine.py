@@ -285,6 +285,18 @@ def mvar_measure(G, which):
     return out
 
 
+def global_coherence(accum, n_groups, n_freq_accum, n_fft, n_signals, planes, n_obs, max_rank, ascending):
+    """Leading eigenpairs of the CSM per (window, two-sided bin) (sc_global.hip)."""
+    lib = _lib.load()
+    dev = accum.device
+    values = torch.empty((n_groups, n_fft, max_rank), dtype=torch.float64, device=dev)
+    vectors = torch.empty((n_groups, n_fft, n_signals, max_rank), dtype=torch.complex128, device=dev)
+    _lib.check(lib.sc_global_coherence_f64(_ptr(accum), n_groups, n_freq_accum, n_fft, n_signals, planes, n_obs,
+                                           max_rank, int(ascending), _ptr(values), _ptr(vectors), _stream()),
+               "sc_global_coherence_f64")
+    return values, vectors
+
+
 def canonical_coherence(accum, n_signals, planes, n_obs, groups):
     """groups: list of int arrays (channel indices per group).  Returns ([n_bins, G, G] float64, n_fail)."""
     lib = _lib.load()

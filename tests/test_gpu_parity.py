@@ -353,3 +353,40 @@ def test_full_wilson_factor_standalone_fp64(sc, c, N, P):
     np.testing.assert_allclose(G @ np.conj(np.swapaxes(G, -1, -2)), S, rtol=0, atol=1e-7 * np.abs(S).max())
     if c <= 17:
         np.testing.assert_allclose(G, so.minimum_phase_decomposition(S), rtol=0, atol=1e-6 * np.abs(G).max())
+
+
+@pytest.mark.parametrize("rank", [1, 2, 4, 5])
+def test_f10_global_coherence_vs_reference(sc, golden, rank):
+    """Leading eigenpairs of the device CSM against the reference's SVD of the coefficient matrix."""
+    g = golden("f10_global")
+    m = sc.Multitaper(g["x"], sampling_frequency=256.0, time_halfbandwidth_product=2, n_time_samples_per_window=128)
+    c = sc.Connectivity.from_multitaper(m)
+    vals, vecs = c.global_coherence(max_rank=rank)
+    close32(vals, g[f"rank{rank}__values"], rtol=2e-5, atol_scale=2e-6, what=f"global coherence rank {rank}")
+    ref = g[f"rank{rank}__vectors"]
+    assert vecs.shape == ref.shape
+    np.testing.assert_allclose(np.linalg.norm(vecs, axis=-2), 1.0, atol=1e-10)
+    # same lines wherever the eigenvalue is separated from its neighbours (relative gap > 1e-2)
+    allv = g["rank5__values"]                                   # descending, every eigenvalue
+    ip = np.abs(np.sum(np.conj(vecs) * ref, axis=-2))
+    order = (np.arange(rank)[::-1] if rank < 4 else np.arange(rank))          # position in the descending list
+    for k in range(rank):
+        idx = order[k]
+        lam = allv[..., idx]
+        gap = np.minimum(np.abs(allv[..., max(idx - 1, 0)] - lam) if idx > 0 else np.inf,
+                         np.abs(allv[..., min(idx + 1, 4)] - lam) if idx < 4 else np.inf)
+        sep = gap > 1e-2 * allv[..., 0]
+        assert sep.mean() > 0.5
+        assert (ip[..., k][sep] > 1 - 1e-3).all(), f"vector {k}: min |<u, u_ref>| = {ip[..., k][sep].min()}"
+
+
+def test_global_coherence_large_even_and_odd(sc):
+    """33 and 64 signals against the oracle SVD (values), two windows."""
+    for C in (33, 64):
+        x = np.random.default_rng(C).standard_normal((128, 40, C))
+        x[:, :, : C // 2] += np.random.default_rng(1).standard_normal((128, 40, 1))
+        m = sc.Multitaper(x, sampling_frequency=128.0, time_halfbandwidth_product=2, n_time_samples_per_window=64)
+        vals, vecs = sc.Connectivity.from_multitaper(m).global_coherence(max_rank=3)
+        coef, _ = so.multitaper_fft(x, fs=128.0, NW=2, n_time_samples_per_window=64)
+        ref, _ = so.global_coherence(coef, max_rank=3)
+        close32(vals, ref, rtol=2e-5, atol_scale=2e-6, what=f"global coherence C={C}")

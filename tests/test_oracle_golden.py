@@ -94,6 +94,22 @@ def test_f9_mvar_measures(golden, tag):
         close(fn(coef, q=q), g[f"{tag}__{name}"], rtol=1e-6, atol=1e-9)
 
 
+def _same_up_to_phase(u, v, tol):
+    """Columns of u and v (..., C, k) span the same lines: |<u_k, v_k>| = |u_k| |v_k|."""
+    ip = np.abs(np.sum(np.conj(u) * v, axis=-2))
+    nu, nv = np.linalg.norm(u, axis=-2), np.linalg.norm(v, axis=-2)
+    np.testing.assert_allclose(ip, nu * nv, rtol=0, atol=tol)
+
+
+@pytest.mark.parametrize("rank", [1, 2, 4, 5])
+def test_f10_global_coherence(golden, rank):
+    g = golden("f10_global")
+    coef, _ = so.multitaper_fft(g["x"], fs=256.0, NW=2, n_time_samples_per_window=128)
+    vals, vecs = so.global_coherence(coef, max_rank=rank)
+    close(vals, g[f"rank{rank}__values"], rtol=1e-8, atol=1e-12)
+    _same_up_to_phase(vecs, g[f"rank{rank}__vectors"], 1e-6)
+
+
 def test_f6_canonical(golden):
     g = golden("f6_canonical")
     coef, _ = so.multitaper_fft(g["x"], fs=float(g["fs"]), NW=float(g["NW"]),
