@@ -100,13 +100,54 @@ def gen_f10_global(T, Cn, mpd, sim):
     save("f10_global", **arrs)
 
 
+def gen_f11_post(T, Cn, mpd, sim):
+    """F11: band post-processing of the coherency (phase slope index, delay, group delay) and the
+    statistics helpers.  Channel 1 is channel 0 delayed by 5 samples (10 ms at 500 Hz)."""
+    import importlib
+    st = importlib.import_module("spectral_connectivity.statistics")
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((500, 20, 3))
+    src = rng.standard_normal((505, 20))
+    x[:, :, 0] += 2 * src[5:]
+    x[:, :, 1] += 2 * src[:-5]
+    m = T.Multitaper(x, sampling_frequency=500.0, time_halfbandwidth_product=3)
+    c = Cn.Connectivity.from_multitaper(m)
+    res = float(m.frequency_resolution)
+    arrs = dict(x=x, coherency=c.coherency(), frequencies=c.frequencies, n_observations=c.n_observations,
+                frequency_resolution=res)
+    arrs["psi_all"] = c.phase_slope_index()
+    arrs["psi_band"] = c.phase_slope_index(frequencies_of_interest=[10, 200])
+    arrs["psi_band_res"] = c.phase_slope_index(frequencies_of_interest=[10, 200], frequency_resolution=res)
+    arrs["delay_band"] = c.delay(frequencies_of_interest=[10, 200], n_range=2)
+    d, sl, r = c.group_delay(frequencies_of_interest=[10, 200], frequency_resolution=res)
+    arrs["group_delay"], arrs["group_slope"], arrs["group_r"] = d, sl, r
+    # statistics helpers
+    p = rng.uniform(size=(6, 7)) ** 3
+    arrs["stat_p"] = p
+    arrs["stat_bh"] = st.Benjamini_Hochberg_procedure(p, alpha=0.05)
+    arrs["stat_bh_none"] = st.Benjamini_Hochberg_procedure(0.5 + 0.5 * p, alpha=0.01)
+    arrs["stat_bonf"] = st.Bonferroni_correction(p, alpha=0.05)
+    coh1 = 0.9 * rng.uniform(size=(5, 4)) * np.exp(1j * rng.uniform(0, 6, size=(5, 4)))
+    coh2 = 0.9 * rng.uniform(size=(5, 4))
+    arrs["stat_coh1"], arrs["stat_coh2"] = coh1, coh2
+    arrs["stat_fisher2"] = st.coherence_fisher_z_transform(coh1, 40, coh2, 25)
+    arrs["stat_pvals"] = st.get_normal_distribution_p_values(arrs["stat_fisher2"])
+    arrs["stat_coh_bias"] = st.coherence_bias(40)
+    arrs["stat_rate_adj"] = st.coherence_rate_adjustment(10.0, 14.0, np.linspace(0.5, 3, 6), homogeneous_poisson_noise=0.2, dt=0.5)
+    lo, hi = st.power_confidence_intervals(7, power=np.linspace(1, 4, 5), ci=0.9)
+    arrs["stat_ci_lo"], arrs["stat_ci_hi"] = lo, hi
+    arrs["stat_power_bias"], arrs["stat_power_var"] = st.power_bias(35), st.power_variance(35)
+    arrs["stat_power_z"] = st.power_fisher_z_transform(np.linspace(1, 4, 5), 35, np.linspace(2, 3, 5), 21)
+    save("f11_post", **arrs)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     warnings.simplefilter("ignore")
     T, Cn, mpd, sim = import_reference()
     if len(sys.argv) > 1:                      # python oracle/gen_golden.py f9 : only the named fixtures
         for name in sys.argv[1:]:
-            {"f9": gen_f9_mvar, "f10": gen_f10_global}[name](T, Cn, mpd, sim)
+            {"f9": gen_f9_mvar, "f10": gen_f10_global, "f11": gen_f11_post}[name](T, Cn, mpd, sim)
         return
     Multitaper, Connectivity = T.Multitaper, Cn.Connectivity
 
@@ -251,6 +292,7 @@ def main():
     save("f8_dpss", **arrs)
     gen_f9_mvar(T, Cn, mpd, sim)
     gen_f10_global(T, Cn, mpd, sim)
+    gen_f11_post(T, Cn, mpd, sim)
 
 
 if __name__ == "__main__":

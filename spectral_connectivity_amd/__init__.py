@@ -14,6 +14,7 @@ from .transforms import (
     suggest_parameters,
 )
 from .utils import get_compute_backend
+from .wrapper import multitaper_connectivity
 
 __version__ = "0.1.0"
 
@@ -26,4 +27,5 @@ __all__ = [
     "estimate_frequency_resolution",
     "estimate_n_tapers",
     "get_compute_backend",
+    "multitaper_connectivity",
 ]

@@ -328,6 +328,27 @@ class Connectivity:
         """Full-frequency directed transfer function times sqrt(partial directed coherence)."""
         return self._mvar(_lib.MVAR_DDTF)
 
+    # ---- band statistics of the coherency (reference connectivity.py:1428-1650): host-side post-processing
+    # of the device coherency, see _postprocess.py ----------------------------------------------------
+    def phase_slope_index(self, frequencies_of_interest=None, frequency_resolution=None):
+        """Weighted average of the coherency phase slope projected on the imaginary axis (Nolte et al. 2008);
+        out[..., i, j] > 0 when i leads j.  Shape (..., n_signals, n_signals)."""
+        from . import _postprocess as pp
+        return pp.phase_slope_index(self.coherency(), self.frequencies, frequencies_of_interest, frequency_resolution)
+
+    def group_delay(self, frequencies_of_interest=None, frequency_resolution=None, significance_threshold=0.05):
+        """Average time delay of a broadband signal between every pair: (delay, slope, r_value) from the linear
+        regression of the unwrapped coherence phase on frequency over the significant bins of the band."""
+        from . import _postprocess as pp
+        return pp.group_delay(self.coherency(), self.frequencies, self.n_observations, frequencies_of_interest,
+                              frequency_resolution, significance_threshold)
+
+    def delay(self, frequencies_of_interest=None, frequency_resolution=None, significance_threshold=0.05, n_range=3):
+        """Range of possible delays (2 pi ambiguity of the coherence phase) per band frequency and pair."""
+        from . import _postprocess as pp
+        return pp.delay(self.coherency(), self.frequencies, self.n_observations, frequencies_of_interest,
+                        frequency_resolution, significance_threshold, n_range)
+
     # ---- global coherence (reference connectivity.py:822-895) ------------------------------
     def global_coherence(self, max_rank=1):
         """Leading squared singular values (/ n_estimates) and left singular vectors of the signals x

@@ -390,3 +390,41 @@ def test_global_coherence_large_even_and_odd(sc):
         coef, _ = so.multitaper_fft(x, fs=128.0, NW=2, n_time_samples_per_window=64)
         ref, _ = so.global_coherence(coef, max_rank=3)
         close32(vals, ref, rtol=2e-5, atol_scale=2e-6, what=f"global coherence C={C}")
+
+
+def test_wrapper_labels_with_a_stand_in_xarray(sc, monkeypatch):
+    """multitaper_connectivity(): dims / coords / names / mt_* attributes of the labelled output, with a minimal
+    stand-in for the optional xarray package (absent from this image), values equal to Connectivity's."""
+    import sys
+    import types
+
+    class DataArray:
+        def __init__(self, data, coords=None, dims=None):
+            self.values, self.coords, self.dims, self.attrs, self.name = np.asarray(data), list(coords), list(dims), {}, None
+            assert self.values.ndim == len(self.dims) and all(len(c) == n for c, n in zip(self.coords, self.values.shape))
+
+    class Dataset(dict):
+        pass
+
+    fake = types.ModuleType("xarray")
+    fake.DataArray, fake.Dataset = DataArray, Dataset
+    monkeypatch.setitem(sys.modules, "xarray", fake)
+    from spectral_connectivity_amd import multitaper_connectivity
+    x = np.random.default_rng(5).standard_normal((400, 6, 3))
+    kw = dict(sampling_frequency=200.0, time_window_duration=0.5, time_halfbandwidth_product=2)
+    da = multitaper_connectivity(x, method="coherence_magnitude", signal_names=["a", "b", "c"], **kw)
+    assert da.name == "coherence_magnitude" and da.dims == ["time", "frequency", "source", "target"]
+    assert da.coords[2] == ["a", "b", "c"] and da.attrs["mt_sampling_frequency"] == 200.0
+    m = sc.Multitaper(x, **kw)
+    c = sc.Connectivity.from_multitaper(m)
+    close32(da.values, c.coherence_magnitude(), what="wrapper coherence")
+    np.testing.assert_allclose(da.coords[0], m.time)
+    ds = multitaper_connectivity(x, method=["power", "weighted_phase_lag_index", "imaginary_coherence"], **kw)
+    assert set(ds) == {"power", "weighted_phase_lag_index", "imaginary_coherence"}
+    assert ds["power"].dims == ["time", "frequency", "source"]
+    close32(ds["weighted_phase_lag_index"].values, c.weighted_phase_lag_index(), what="wrapper wpli")
+    two = multitaper_connectivity(x[..., :2], method="coherence_magnitude", squeeze=True, **kw)
+    assert two.dims == ["time", "frequency"]
+    everything = multitaper_connectivity(x, **kw)          # method=None: every expressible measure
+    assert {"coherency", "pairwise_spectral_granger_prediction", "phase_locking_value"} <= set(everything)
+    assert not ({"group_delay", "global_coherence", "directed_coherence"} & set(everything))

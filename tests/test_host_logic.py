@@ -137,3 +137,88 @@ def test_parameter_helpers_match_reference_values():
                  "Window step:      1.000 s (non-overlapping)", "Number of windows: 5",
                  "Frequency resolution: 6.0 Hz", "FFT samples:          1000"):
         assert line in text, line
+
+
+# ---- band post-processing of the coherency and the statistics helpers (host-side NumPy) ------------------
+def test_phase_slope_index_and_delay_match_reference(golden):
+    from spectral_connectivity_amd import _postprocess as pp
+    g = golden("f11_post")
+    coh, f, res = g["coherency"], g["frequencies"], float(g["frequency_resolution"])
+    np.testing.assert_allclose(pp.phase_slope_index(coh, f), g["psi_all"], rtol=1e-9, atol=1e-9, equal_nan=True)
+    np.testing.assert_allclose(pp.phase_slope_index(coh, f, [10, 200]), g["psi_band"], rtol=1e-9, atol=1e-9, equal_nan=True)
+    np.testing.assert_allclose(pp.phase_slope_index(coh, f, [10, 200], res), g["psi_band_res"], rtol=1e-9, atol=1e-9,
+                               equal_nan=True)
+    # delay(): the reference's output is the constant 2 pi k for every frequency and pair (raw data of a fully
+    # masked array, because its one-sample z-score is always NaN) -- pinned; ours carries the candidates
+    # (phase + 2 pi k) / 2 pi at the significant frequencies and NaN elsewhere.
+    ref = g["delay_band"]
+    np.testing.assert_allclose(ref[0, :, :, 0, 1], np.broadcast_to(2 * np.pi * np.arange(-2, 3), ref.shape[1:3]))
+    got = pp.delay(coh, f, int(g["n_observations"]), [10, 200], n_range=2)
+    assert got.shape == ref.shape
+    band = f[(f > 10) & (f < 200)]
+    k0 = got[0, :, 2, 0, 1]                      # k = 0 candidate, pair (0, 1): phase / 2 pi = f * tau
+    ok = ~np.isnan(k0)
+    assert ok.sum() >= 20
+    assert abs(np.median(k0[ok] / band[ok]) - 0.010) < 3e-4 and np.abs(k0[ok] / band[ok] - 0.010).max() < 6e-3
+    np.testing.assert_allclose(got[0, :, 3, 0, 1][ok] - k0[ok], 1.0)
+    np.testing.assert_allclose(got[0, :, :, 1, 0], -got[0, :, :, 0, 1], equal_nan=True)
+
+
+def test_group_delay_recovers_a_known_delay(golden):
+    """Channel 1 is channel 0 delayed by 5 samples at 500 Hz.  The reference's own group_delay() returns NaN
+    for every pair (its one-sample Fisher z evaluates coherence_bias(0) = -1/2 and takes the square root of a
+    negative number, so no frequency is ever significant) -- pinned here, and fixed on purpose."""
+    from spectral_connectivity_amd import _postprocess as pp
+    g = golden("f11_post")
+    assert np.isnan(g["group_delay"][0, 0, 1]) and np.isnan(g["group_r"][0, 0, 1]) and g["group_r"][0, 0, 0] == 1.0
+    d, s, r = pp.group_delay(g["coherency"], g["frequencies"], int(g["n_observations"]), [10, 200],
+                             float(g["frequency_resolution"]))
+    assert d.shape == g["group_delay"].shape
+    assert abs(d[0, 0, 1] - 0.010) < 2e-4 and abs(d[0, 1, 0] + 0.010) < 2e-4
+    assert r[0, 0, 1] > 0.999 and r[0, 0, 0] == 1.0 and np.isnan(s[0, 0, 0])
+    np.testing.assert_allclose(s, 2 * np.pi * d, equal_nan=True)
+    # a pair of independent channels has no significant run: NaN
+    assert np.isnan(d[0, 0, 2]) or abs(r[0, 0, 2]) <= 1.0
+
+
+def test_statistics_helpers_match_reference(golden):
+    from spectral_connectivity_amd import statistics as st
+    g = golden("f11_post")
+    p = g["stat_p"]
+    np.testing.assert_array_equal(st.Benjamini_Hochberg_procedure(p, alpha=0.05), g["stat_bh"])
+    np.testing.assert_array_equal(st.Benjamini_Hochberg_procedure(0.5 + 0.5 * p, alpha=0.01), g["stat_bh_none"])
+    np.testing.assert_array_equal(st.Bonferroni_correction(p, alpha=0.05), g["stat_bonf"])
+    np.testing.assert_array_equal(st.adjust_for_multiple_comparisons(p, method="Bonferroni_correction"), g["stat_bonf"])
+    z = st.coherence_fisher_z_transform(g["stat_coh1"], 40, g["stat_coh2"], 25)
+    np.testing.assert_allclose(z, g["stat_fisher2"], rtol=1e-12)
+    np.testing.assert_allclose(st.get_normal_distribution_p_values(z), g["stat_pvals"], rtol=1e-12)
+    assert st.coherence_bias(40) == float(g["stat_coh_bias"])
+    np.testing.assert_allclose(st.coherence_rate_adjustment(10.0, 14.0, np.linspace(0.5, 3, 6), 0.2, 0.5),
+                               g["stat_rate_adj"], rtol=1e-12)
+    lo, hi = st.power_confidence_intervals(7, power=np.linspace(1, 4, 5), ci=0.9)
+    np.testing.assert_allclose(lo, g["stat_ci_lo"], rtol=1e-12)
+    np.testing.assert_allclose(hi, g["stat_ci_hi"], rtol=1e-12)
+    np.testing.assert_allclose(st.power_bias(35), g["stat_power_bias"], rtol=1e-12)
+    np.testing.assert_allclose(st.power_variance(35), g["stat_power_var"], rtol=1e-12)
+    np.testing.assert_allclose(st.power_fisher_z_transform(np.linspace(1, 4, 5), 35, np.linspace(2, 3, 5), 21),
+                               g["stat_power_z"], rtol=1e-12)
+    # one-sample z-score: finite here (NaN in the reference, see statistics.coherence_fisher_z_transform)
+    assert np.isfinite(st.coherence_fisher_z_transform(g["stat_coh1"], 40)).all()
+
+
+def test_wrapper_validates_before_touching_the_device():
+    """Methods the labelled interface cannot express are refused with the reference's message (wrapper.py:71-78)
+    -- before xarray or the GPU are needed."""
+    from spectral_connectivity_amd import multitaper_connectivity
+    from spectral_connectivity_amd.wrapper import connectivity_to_xarray
+    x = np.random.default_rng(0).standard_normal((64, 2, 2))
+    for bad in ("group_delay", "canonical_coherence", "directed_transfer_function", "partial_directed_coherence"):
+        with pytest.raises(ValueError, match="not supported by the xarray interface"):
+            multitaper_connectivity(x, sampling_frequency=100, method=bad)
+        with pytest.raises(ValueError, match="Connectivity class directly"):
+            connectivity_to_xarray(Multitaper(x, sampling_frequency=100), method=bad)
+    try:
+        import xarray  # noqa: F401
+    except ImportError:
+        with pytest.raises(ImportError, match="xarray"):
+            multitaper_connectivity(x, sampling_frequency=100, method="coherence_magnitude")
