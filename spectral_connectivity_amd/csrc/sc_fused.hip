@@ -15,7 +15,7 @@
 // Workgroup = 12 waves = one output bin (C <= 128, even).  Every SIMD hosts 1 "CSM" wave and
 // 2 "abs" waves.  A chunk of 32 observation rows is staged HBM -> registers -> LDS as bf16 pieces
 // (h, m, l of Re and Im, exact 3-way split of every f32 coefficient) in ONE layout, double-buffered:
-//   planes [2][6][channel][obs] bf16
+//   planes [2][channel][6][obs] bf16        (6 = h, m, l of Re then of Im)
 // The CSM waves read it with K = observations: operand fragments of the rank-n_obs update
 // S += X^H X (v_mfma_f32_16x16x32_bf16, six leading cross terms hh hm mh mm hl lh per product,
 // f32 accumulate).  The abs waves read the same planes four observations at a time (one 8-byte
@@ -61,10 +61,13 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define FU_THREADS 768
 #define FU_MAXB 5
 #define FU_FLUSH 16         // chunks between folds of the MFMA accumulators into the output record
-#define FU_PSTRIDE 36       // bf16 per (plane, channel): 32 obs + 4 pad -> 72 B = 18 dwords: 16 consecutive
-                            // channels at one obs quad hit 16 distinct even banks, so the 8-byte reads of
-                            // both roles and the staging writes (channels 8 apart per 16 lanes) are
-                            // conflict-free
+#define FU_PLANE 36         // bf16 per (channel, plane): 32 obs + 4 pad = 72 B
+#define FU_CSTRIDE 220      // bf16 per channel: its 6 planes (432 B) + 8 B pad = 440 B = 110 dwords.  110 = 14
+                            // (mod 32): 16 consecutive channels at one obs quad hit 16 distinct even banks, so
+                            // the 8-byte reads of both roles and the staging writes (each 16-lane group mixes
+                            // the even and odd channel of its pairs) are conflict-free; and all six planes
+                            // of a channel sit within the 8-bit offsets of ds_read2_b64 -- one address add
+                            // per 16-channel fragment set instead of one per plane on this VALU-bound kernel
 
 struct FusedArgs {
     ScStage st;
@@ -139,7 +142,7 @@ __device__ __forceinline__ void fu_split(const float* raw, unsigned short* plane
     constexpr int CP = NB32 * 32;                  // channels staged (C rounded up to 32)
     if (2 * lane >= CP) return;
     // planes: 0 re_h 1 re_m 2 re_l 3 im_h 4 im_m 5 im_l ; element (plane, ch, obs)
-    constexpr int plane_elems = CP * FU_PSTRIDE;
+    constexpr int plane_elems = FU_PLANE;          // plane stride inside a channel
     const int first = (lane >> 3) & 1;
     float2 v[2][4];
 #pragma unroll
@@ -152,7 +155,7 @@ __device__ __forceinline__ void fu_split(const float* raw, unsigned short* plane
         float re[4], im[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) { re[k] = v[t][k].x; im[k] = v[t][k].y; }
-        unsigned short* base = planes + (2 * lane + (first ^ t)) * FU_PSTRIDE + vw * 4;
+        unsigned short* base = planes + (2 * lane + (first ^ t)) * FU_CSTRIDE + vw * 4;
         uint2 h, m, l;
         split4(re, h, m, l);
         *reinterpret_cast<uint2*>(base) = h;
@@ -185,10 +188,10 @@ __device__ __forceinline__ void fu_stage_first(const ScStage& st, float* raw, un
 template <int NB32>
 __device__ __forceinline__ void fu_stage_next(const ScStage& st, float* raw, unsigned short* planes, int vw,
                                               int o_lo, int ch, int n_chunks, bool loads) {
-    constexpr int plane_elems = NB32 * 32 * FU_PSTRIDE;
+    constexpr int buf_elems = NB32 * 32 * FU_CSTRIDE;
     if (ch + 1 < n_chunks) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // raw rows of chunk ch + 1 landed
-        fu_split<NB32>(raw, planes + ((ch + 1) & 1) * FU_NPLANES * plane_elems, vw);
+        fu_split<NB32>(raw, planes + ((ch + 1) & 1) * buf_elems, vw);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // raw rows read before the refill
         if (ch + 2 < n_chunks && loads) fu_fetch(st, raw, o_lo + (ch + 2) * FU_OC, vw);
     }
@@ -198,10 +201,18 @@ __device__ __forceinline__ unsigned perm_b32(unsigned a, unsigned b, unsigned se
     return __builtin_amdgcn_perm(a, b, sel);     // bytes 0-3 of sel pick from b, 4-7 from a
 }
 
+// sign flip of eight bf16: one v_xor_b32 per dword (spelled in asm: through the builtin vector types the
+// compiler legalises the xor per 16-bit half -- xor, sdwa xor and a permute for every dword)
 __device__ __forceinline__ bf16x8 neg8(bf16x8 v) {
-    u32x4 u = __builtin_bit_cast(u32x4, v);
-    u ^= 0x80008000u;
-    return __builtin_bit_cast(bf16x8, u);
+    const u32x4 u = __builtin_bit_cast(u32x4, v);
+    const unsigned m = 0x80008000u;
+    unsigned a, b, c, d;
+    asm("v_xor_b32 %0, %1, %2" : "=v"(a) : "v"(u[0]), "v"(m));
+    asm("v_xor_b32 %0, %1, %2" : "=v"(b) : "v"(u[1]), "v"(m));
+    asm("v_xor_b32 %0, %1, %2" : "=v"(c) : "v"(u[2]), "v"(m));
+    asm("v_xor_b32 %0, %1, %2" : "=v"(d) : "v"(u[3]), "v"(m));
+    const u32x4 r = {a, b, c, d};
+    return __builtin_bit_cast(bf16x8, r);
 }
 
 // eight consecutive observations of one (plane, channel): 72-byte channel stride -> two 8-byte reads
@@ -241,8 +252,8 @@ __device__ __forceinline__ void fused_mfma_role(const FusedArgs& p, const ScStag
 #pragma unroll
     for (int s = 0; s < MAXS; ++s) { re[s] = (f32x4){0.f, 0.f, 0.f, 0.f}; im[s] = re[s]; }
     const int n_chunks = (st.n_obs - o_lo + FU_OC - 1) / FU_OC;     // st.n_obs: end of this part
-    constexpr int plane_elems = NB32 * 32 * FU_PSTRIDE;
-    const unsigned short* frag00 = planes + (lane & 15) * FU_PSTRIDE + (lane >> 4) * 8;
+    constexpr int plane_elems = FU_PLANE, buf_elems = NB32 * 32 * FU_CSTRIDE;
+    const unsigned short* frag00 = planes + (lane & 15) * FU_CSTRIDE + (lane >> 4) * 8;
     float* out = rec + (int64_t)p.csm_plane * p.n_tiles * SC_TILE_ELEMS;
 #define FU_LD(ptr, k) fu_ld8((ptr) + (k) * plane_elems)
     // Staging is shared: the four CSM waves (VALU idle under their MFMA stream) stage observation
@@ -252,17 +263,17 @@ __device__ __forceinline__ void fused_mfma_role(const FusedArgs& p, const ScStag
     FU_BARRIER();                 // chunk 0 staged
     FU_T0();
     for (int ch = 0; ch < n_chunks; ++ch) {
-        const unsigned short* frag0 = frag00 + (ch & 1) * FU_NPLANES * plane_elems;
+        const unsigned short* frag0 = frag00 + (ch & 1) * buf_elems;
         if ((p.debug_skip & 1) == 0 && total > 0) {
             // opaque per-chunk copies: otherwise ~2 loop-invariant address VGPRs per tile stay live
             // across the chunk loop and spill at the 168-register budget
             int rA = rA_, rB = rB_, nA = nA_;
             asm volatile("" : "+s"(rA), "+s"(rB), "+s"(nA));
             bf16x8 arh, arm, arl, aih, aim, ail;                    // A fragments of the current row
-            bf16x8 brh, bih;                                        // first B fragments (prefetched)
-            {
-                const unsigned short* fb = frag0 + rA * 16 * FU_PSTRIDE;   // first tile (rA, rA)
-                brh = FU_LD(fb, 0); bih = FU_LD(fb, 3);
+            bf16x8 brh[2], bih[2];                                  // first B fragments, prefetched one tile
+            {                                                       // ahead into the other register set
+                const unsigned short* fb = frag0 + rA * 16 * FU_CSTRIDE;   // first tile (rA, rA)
+                brh[0] = FU_LD(fb, 0); bih[0] = FU_LD(fb, 3);
             }
 #pragma unroll
             for (int s = 0; s < MAXS; ++s) {
@@ -271,18 +282,19 @@ __device__ __forceinline__ void fused_mfma_role(const FusedArgs& p, const ScStag
                     const int row = in_a ? rA : rB;
                     const int col = row + (in_a ? s : s - nA);
                     if (s == 0 || s == nA) {
-                        const unsigned short* fa = frag0 + row * 16 * FU_PSTRIDE;
+                        const unsigned short* fa = frag0 + row * 16 * FU_CSTRIDE;
                         arh = FU_LD(fa, 0); arm = FU_LD(fa, 1); arl = FU_LD(fa, 2);
                         aih = FU_LD(fa, 3); aim = FU_LD(fa, 4); ail = FU_LD(fa, 5);
                     }
-                    const unsigned short* fb = frag0 + col * 16 * FU_PSTRIDE;
+                    const unsigned short* fb = frag0 + col * 16 * FU_CSTRIDE;
                     const bf16x8 cbrm = FU_LD(fb, 1), cbim = FU_LD(fb, 4), cbrl = FU_LD(fb, 2), cbil = FU_LD(fb, 5);
-                    const bf16x8 cbrh = brh, cbih = bih;
+                    const bf16x8& cbrh = brh[s & 1];
+                    const bf16x8& cbih = bih[s & 1];
                     if (s + 1 < total) {      // prefetch the next tile's first fragments
                         const bool na = (s + 1) < nA;
                         const int ncol = (na ? rA : rB) + (na ? s + 1 : s + 1 - nA);
-                        const unsigned short* fn = frag0 + ncol * 16 * FU_PSTRIDE;
-                        brh = FU_LD(fn, 0); bih = FU_LD(fn, 3);
+                        const unsigned short* fn = frag0 + ncol * 16 * FU_CSTRIDE;
+                        brh[(s + 1) & 1] = FU_LD(fn, 0); bih[(s + 1) & 1] = FU_LD(fn, 3);
                     }
                     // six leading terms of (h+m+l)(h+m+l): hh hm mh mm hl lh
                     // Re += ar*br + ai*bi ; Im += ai*br + ar*(-bi)   (two chains, interleaved; the sign
@@ -439,7 +451,7 @@ __device__ __forceinline__ void fused_valu_body(const FusedArgs& p, const ScStag
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[s][e] = 0.f;
     const int n_chunks = (st.n_obs - o_lo + FU_OC - 1) / FU_OC;
-    constexpr int plane_elems = NB32 * 32 * FU_PSTRIDE;
+    constexpr int plane_elems = FU_PLANE, buf_elems = NB32 * 32 * FU_CSTRIDE;
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const bool loads = !(p.debug_skip & 8);
     if (vw < 4) fu_stage_first<NB32>(st, raw, planes, 4 + vw, o_lo, n_chunks, loads);
@@ -448,12 +460,12 @@ __device__ __forceinline__ void fused_valu_body(const FusedArgs& p, const ScStag
     for (int ch = 0; ch < n_chunks; ++ch) {
         if (vw < 4) fu_stage_next<NB32>(st, raw, planes, 4 + vw, o_lo, ch, n_chunks, loads);
         FU_TICK(0);
-        const unsigned short* pb = planes + (ch & 1) * FU_NPLANES * plane_elems;
+        const unsigned short* pb = planes + (ch & 1) * buf_elems;
         // per-lane plane triples: A reads Im (lanes 0-31) / Re (32-63), B reads Re (lanes 0-31) / Im (32-63)
         const int cl = fu_lane(), ci32 = cl & 31, chf = cl >> 5;
         const unsigned negmask = chf ? 0x80008000u : 0u;
-        const int offA = (chf ? 0 : 3 * plane_elems) + ci32 * FU_PSTRIDE;
-        const int offB = (chf ? 3 * plane_elems : 0) + ci32 * FU_PSTRIDE;
+        const int offA = (chf ? 0 : 3 * plane_elems) + ci32 * FU_CSTRIDE;
+        const int offB = (chf ? 3 * plane_elems : 0) + ci32 * FU_CSTRIDE;
         // zero rows past n_obs contribute |0| = 0: no bound needed for this plane
         for (int oq2 = ((p.debug_skip & 2) ? 16 : 2 * rsub); oq2 < 16; oq2 += ((oq2 & 1) ? 2 * wps - 1 : 1)) {
             // two observation rows (one dword per plane) of this lane's channels in every needed block
@@ -464,10 +476,10 @@ __device__ __forceinline__ void fused_valu_body(const FusedArgs& p, const ScStag
                 for (int pl = 0; pl < 3; ++pl) {
                     if (Tab::tab.use_i[b])
                         NA[b][pl] = *reinterpret_cast<const unsigned*>(
-                            pb + offA + pl * plane_elems + b * 32 * FU_PSTRIDE + oq2 * 2);
+                            pb + offA + pl * plane_elems + b * 32 * FU_CSTRIDE + oq2 * 2);
                     if (Tab::tab.use_j[b])
                         NBq[b][pl] = *reinterpret_cast<const unsigned*>(
-                            pb + offB + pl * plane_elems + b * 32 * FU_PSTRIDE + oq2 * 2);
+                            pb + offB + pl * plane_elems + b * 32 * FU_CSTRIDE + oq2 * 2);
                 }
 #pragma unroll
             for (int k1 = 0; k1 < 2; ++k1) {
@@ -582,10 +594,12 @@ __global__ void __launch_bounds__(FU_THREADS) fused_csm_absim_kernel(FusedArgs p
     st.n_obs = o_hi < p.st.n_obs ? o_hi : p.st.n_obs;
     float* rec = (part == 0 ? p.accum : p.ws + (int64_t)(part - 1) * p.n_bins * p.floats_per_bin) +
                  (int64_t)bin * p.floats_per_bin;
-    // LDS: the f32 landing rows of the direct HBM->LDS loads, then the two plane buffers (also the
-    // scratch of the final tree reduction)
-    float* raw = reinterpret_cast<float*>(smem);
-    unsigned short* planes = reinterpret_cast<unsigned short*>(smem + FU_OC * FU_RAW_ROW * sizeof(float));
+    // LDS: the two plane buffers at offset 0 (also the scratch of the final tree reduction), then the f32
+    // landing rows of the direct HBM->LDS loads
+    unsigned short* planes = reinterpret_cast<unsigned short*>(smem);
+    constexpr size_t plane_bytes = (size_t)2 * NB32 * 32 * FU_CSTRIDE * 2;
+    constexpr size_t red_bytes = (size_t)4 * FU_MAXB * 16 * 64 * sizeof(float);
+    float* raw = reinterpret_cast<float*>(smem + (plane_bytes > red_bytes ? plane_bytes : red_bytes));
     if (wave < 4) fused_mfma_role<NB32>(p, st, planes, raw, tid, wave, rec, o_lo);
     else fused_valu_role<NB32>(p, st, planes, raw, tid, wave - 4, rec, o_lo);
 }
@@ -610,7 +624,7 @@ __global__ void __launch_bounds__(256) fused_combine_kernel(FusedArgs p) {
 
 template <int NB32>
 static int launch_fused(const FusedArgs& a, hipStream_t stream) {
-    size_t shmem = (size_t)2 * FU_NPLANES * a.st.CP * FU_PSTRIDE * 2;
+    size_t shmem = (size_t)2 * a.st.CP * FU_CSTRIDE * 2;
     const size_t red = (size_t)4 * FU_MAXB * 16 * 64 * sizeof(float);
     if (shmem < red) shmem = red;
     shmem += (size_t)FU_OC * FU_RAW_ROW * sizeof(float);
