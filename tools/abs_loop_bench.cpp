@@ -29,6 +29,7 @@ __device__ __forceinline__ void abs_wave(int iters, float* out, int lane) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[s - 1][e] += __builtin_fabsf(dprev[e]);
             }
+            if (!ADDS) asm volatile("" ::"v"(d));        // keep every MFMA alive
             dprev = d;
             a[1] ^= 1;   // keep the operands live and changing (one VALU op like the fragment permutes)
         }
