@@ -85,19 +85,17 @@ def one_step(x, h, cfg, geom, planes, world, timer=None):
     L, step, N, W = geom
     mark("start")
     sp = engine.multitaper_spectra(x, h, L, step, N, W, "constant", mark=mark)
+    if world > 1:
+        # trial shards: accumulate -> reduce-scatter -> epilogue -> gather on rank 0, pipelined over frequency
+        # groups so that only the last group's exchange is exposed (parallel.sharded_measures)
+        coh, wpli = parallel.sharded_measures(sp, planes, [_lib.M_COHERENCE_MAGNITUDE, _lib.M_WPLI],
+                                              n_groups=int(os.environ.get("SC_BENCH_GROUPS", "4")), mark=mark)
+        return coh, wpli
     accum, n_obs = engine.accumulate(sp, "trials_tapers", planes, mark=mark)
     del sp
-    n_bins = accum.shape[0]
-    shard, lo, hi = parallel.reduce_scatter_bins(accum)
-    n_total = n_obs * world          # equal shards (R divisible by world is enforced below)
-    mark("reduce_scatter")
-    coh = engine.measure(shard, cfg["C"], planes, n_total, _lib.M_COHERENCE_MAGNITUDE)
-    wpli = engine.measure(shard, cfg["C"], planes, n_total, _lib.M_WPLI)
+    coh = engine.measure(accum, cfg["C"], planes, n_obs, _lib.M_COHERENCE_MAGNITUDE)
+    wpli = engine.measure(accum, cfg["C"], planes, n_obs, _lib.M_WPLI)
     mark("measure_epilogue")
-    if world > 1:       # final measures assembled on rank 0 (the process a Connectivity user talks to)
-        coh = parallel.gather_bins(coh, n_bins, dst=0)
-        wpli = parallel.gather_bins(wpli, n_bins, dst=0)
-        mark("gather")
     return coh, wpli
 
 

@@ -69,6 +69,13 @@ class DeviceSpectra:
         self.n_fft = int(n_fft)
         self.real_input = bool(real_input)   # negative bins are conj mirrors of positive ones
 
+    def freq_slice(self, f0, f1):
+        """The bins [f0, f1) as a view (no copy): same strides, pointer advanced by f0 * stride_freq."""
+        assert 0 <= f0 < f1 <= self.F and self.X.is_contiguous()
+        flat = self.X.view(-1)[f0 * self.strides[0]:]
+        return DeviceSpectra(flat, (f1 - f0, self.W, self.R, self.K, self.C), self.strides, self.n_fft,
+                             self.real_input)
+
     def desc(self, expectation_type, n_freq=None):
         axes = EXPECTATION_AXES[expectation_type]
         sF, sW, sR, sK = self.strides

@@ -96,3 +96,70 @@ def total_observations(local_n_obs, group=None):
         t = t.cuda()
     dist.all_reduce(t, group=group)
     return int(t.item())
+
+
+_side_streams = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+    return _side_streams[key]
+
+
+def sharded_measures(spectra, planes, which, n_groups=4, dst=0, group=None, mark=None):
+    """Stage B + exchange + epilogue for trial-sharded spectra, pipelined over frequency groups.
+
+    Every rank holds the spectra of ITS trials.  The frequency axis is cut into ``n_groups`` ranges; for
+    each range the rank accumulates its un-normalised records on the launch stream, and a second stream
+    takes the range through reduce-scatter (sum over ranks, 1/N of the bins each) -> measures epilogue on
+    the owned bins -> gather on ``dst`` while the launch stream is already accumulating the next range:
+    only the last range's exchange is exposed.  ``which``: list of ``_lib.M_*`` measures.  Returns, on
+    ``dst``, one tensor per measure shaped [n_windows, n_freq, C, C] (None on the other ranks).
+    """
+    from . import engine
+    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    F, W, C = spectra.F, spectra.W, spectra.C
+    n_groups = max(1, min(int(n_groups), F))
+    main = torch.cuda.current_stream()
+    side = _side_stream(spectra.X.device) if world > 1 else main
+    parts = [[] for _ in which]
+    for g in range(n_groups):
+        f0, f1 = shard_bounds(F, n_groups, g)
+        accum, n_obs = engine.accumulate(spectra.freq_slice(f0, f1), "trials_tapers", planes, mark=mark)
+        n_bins = accum.shape[0]
+        if world > 1:
+            ready = torch.cuda.Event()
+            ready.record(main)
+            accum.record_stream(side)
+        with torch.cuda.stream(side):
+            if world > 1:
+                side.wait_event(ready)
+            shard, lo, hi = reduce_scatter_bins(accum, group)
+            n_total = total_observations_equal(n_obs, world)
+            for m, w in enumerate(which):
+                out = engine.measure(shard, C, planes, n_total, w)
+                if world > 1:
+                    out = gather_bins(out, n_bins, dst=dst, group=group)
+                if out is not None:
+                    parts[m].append(out.reshape(W, f1 - f0, *out.shape[1:]))
+    if world > 1:
+        main.wait_stream(side)
+    if mark:
+        mark("exchange_epilogue_tail")
+    if rank != dst:
+        return [None for _ in which]
+    result = []
+    for chunks in parts:
+        if world > 1:
+            for c in chunks:                  # produced on the side stream, consumed on the launch stream
+                c.record_stream(main)
+        result.append(chunks[0] if len(chunks) == 1 else torch.cat(chunks, dim=1))
+    return result
+
+
+def total_observations_equal(local_n_obs, world):
+    """n_observations of the job when every rank holds the same number of trials (no collective needed)."""
+    return int(local_n_obs) * int(world)

@@ -200,3 +200,18 @@ def test_cfg5_canonical_coherence_reduced_vs_oracle_and_full_size(sc):
     np.testing.assert_array_equal(cc, np.swapaxes(cc, -1, -2))
     f30 = int(round(30.0 / (FS / 1024)))
     assert cc[0, f30, 0, 1] > 0.5 and cc[0, f30, 0, 1] > 3 * np.nanmedian(cc[0, f30][2:, 2:][~np.eye(14, dtype=bool)])
+
+
+def test_trial_sharded_pipeline_two_ranks_one_gpu():
+    """parallel.sharded_measures (accumulate -> reduce-scatter -> epilogue -> gather, pipelined over frequency
+    groups on a second stream) with 2 ranks sharing this GPU over gloo equals the single-process result."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SC_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29541",
+                          os.path.join(root, "tools", "check_sharded.py")],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "sharded_measures OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
