@@ -335,11 +335,17 @@ __device__ __forceinline__ void fused_mfma_role(const FusedArgs& p, const ScStag
                     const bool in_a = s < nA_;
                     const int row = in_a ? rA_ : rB_;
                     const int col = row + (in_a ? s : s - nA_);
+                    // uniform (scalar) tile base + ONE 32-bit unsigned per-lane offset, re-materialised here:
+                    // SGPR-base addressing, no 64-bit address VGPRs kept alive (and spilled) across the chunk
+                    // loop -- a spill reload in front of these stores would wait on vmcnt, i.e. on the row
+                    // loads that were just put in flight
                     float* o_re = out + (int64_t)sc_tile_index(row, col, NB) * SC_TILE_ELEMS;
                     float* o_im = o_re + (int64_t)p.n_tiles * SC_TILE_ELEMS;
+                    const unsigned fl = (unsigned)fu_lane();
+                    const unsigned base_idx = (fl >> 4) * 64u + (fl & 15u);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int idx = ((lane >> 4) * 4 + r) * 16 + (lane & 15);
+                        const unsigned idx = base_idx + 16u * r;
                         // later folds are fire-and-forget L2 atomics issued by the record's only writer
                         // (same order every run): no global round trip inside the chunk loop
                         if (first) {
@@ -657,10 +663,15 @@ extern "C" int sc_fused_supported(int64_t n_signals) {
 static int fused_pick_split(int n_bins, int n_obs) {
     const char* e = getenv("SC_FUSED_SPLIT");
     const int nc = (n_obs + FU_OC - 1) / FU_OC;
+    static int cu_of_device[64] = {0};          // compute units per device, queried once
     int dev = 0, n_cu = 256;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-        n_cu = prop.multiProcessorCount;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+        if (cu_of_device[dev] == 0) {
+            int v = 0;
+            cu_of_device[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+        }
+        n_cu = cu_of_device[dev];
+    }
     int best = 1;
     double best_cost = 1e30;
     for (int S = 1; S <= 8; ++S) {
