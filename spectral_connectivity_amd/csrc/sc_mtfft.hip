@@ -240,6 +240,27 @@ __device__ __forceinline__ void dft16(float2 (&x)[16], float2 (&o)[16]) {
     }
 }
 
+// Optional phase timers (tools/mtfft_trace.py builds a copy of the library with -DMT_TRACE): shader-clock
+// cycles of wave 0 of workgroup 0, summed over the tapers: [load+detrend, wait at the top barrier, passes, split+store issue].
+#ifdef MT_TRACE
+__device__ unsigned long long mt_trace_buf[8];
+#define MT_T0() unsigned long long mt_t = __builtin_readcyclecounter()
+#define MT_TICK(slot)                                                                   \
+    do {                                                                                \
+        const unsigned long long mt_n = __builtin_readcyclecounter();                   \
+        if (blockIdx.x == 0 && blockIdx.y == 3 && blockIdx.z == 3 && threadIdx.x == 0) mt_trace_buf[slot] += mt_n - mt_t; \
+        mt_t = mt_n;                                                                    \
+    } while (0)
+extern "C" int sc_debug_mtfft_trace(unsigned long long* out, int reset) {
+    if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(mt_trace_buf), sizeof(unsigned long long) * 8);
+    if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(mt_trace_buf), z, sizeof z); }
+    return 0;
+}
+#else
+#define MT_T0() do {} while (0)
+#define MT_TICK(slot) do {} while (0)
+#endif
+
 template <int LOG2N>
 __global__ void __launch_bounds__(256, LOG2N == 8 ? 4 : 1) mtfft16_kernel(MtArgs p) {
     constexpr int N = 1 << LOG2N;
@@ -265,6 +286,7 @@ __global__ void __launch_bounds__(256, LOG2N == 8 ? 4 : 1) mtfft16_kernel(MtArgs
     constexpr bool WAVE_LOCAL = TPF <= 64;
 
     const int tid = threadIdx.x;
+    MT_T0();
     const int c0 = blockIdx.x * CT, r = blockIdx.y, w = blockIdx.z;
     const int L = p.L, C = p.C;
     const int64_t RC = (int64_t)p.R * C;
@@ -336,29 +358,42 @@ __global__ void __launch_bounds__(256, LOG2N == 8 ? 4 : 1) mtfft16_kernel(MtArgs
             red[512 + tid] = a;
             red[512 + CT + tid] = b;
         }
-        __syncthreads();
-        const double invL = 1.0 / (double)L;
-        for (int idx = tid; idx < L * CT; idx += 256) {
-            const int l = idx / CT, cc2 = idx - l * CT;
-            const double t = (double)(l + 1) * invL;
-            xt[l * XS + cc2] = (float)((double)xt[l * XS + cc2] - (red[512 + cc2] * t + red[512 + CT + cc2]));
-        }
+        // (the trend a t + b is subtracted below, while the samples are pulled into registers)
     }
+    __syncthreads();                                  // tile and trend coefficients visible
 
     const int pf = tid / TPF, i = tid - pf * TPF;     // FFT (channel pair) and butterfly index
     float2* zf = z + pf * ZS;
     const int F = N / 2 + 1;
     const int64_t sF = (int64_t)p.W * p.R * p.K * C;
     const bool vec_ok = (C % 2) == 0;
-    __syncthreads();                                  // detrended tile complete, scratch free
-    for (int i2 = tid; i2 < N; i2 += 256) tw[i2] = p.tw[i2];
-    if (resident)
-        for (int i2 = tid; i2 < p.K * p.L; i2 += 256) hk[i2] = p.tapers[i2];
     float2 xs[16];                                    // this thread's pass-1 inputs, all tapers
+    {
+        const bool detr = p.detrend != SC_DETREND_NONE;
+        const double invL = 1.0 / (double)L;
+        const double a0 = detr ? red[512 + 2 * pf] : 0.0, a1 = detr ? red[512 + 2 * pf + 1] : 0.0;
+        const double b0 = detr ? red[512 + CT + 2 * pf] : 0.0, b1 = detr ? red[512 + CT + 2 * pf + 1] : 0.0;
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        const int n = i + t * TPF;
-        xs[t] = (n < L) ? *reinterpret_cast<const float2*>(xt + n * XS + 2 * pf) : make_float2(0.f, 0.f);
+        for (int t = 0; t < 16; ++t) {
+            const int n = i + t * TPF;
+            float2 v = make_float2(0.f, 0.f);
+            if (n < L) {
+                v = *reinterpret_cast<const float2*>(xt + n * XS + 2 * pf);
+                if (detr) {           // same fp64 expression as a separate detrend pass would use
+                    const double tt = (double)(n + 1) * invL;
+                    v.x = (float)((double)v.x - (a0 * tt + b0));
+                    v.y = (float)((double)v.y - (a1 * tt + b1));
+                }
+            }
+            xs[t] = v;
+        }
+    }
+    __syncthreads();                                  // tile and detrend scratch consumed: their space is free
+    for (int i2 = tid; i2 < N; i2 += 256) tw[i2] = p.tw[i2];
+    if (resident) {
+        for (int i2 = tid; i2 < p.K * p.L; i2 += 256) hk[i2] = p.tapers[i2];
+    } else {
+        for (int i2 = tid; i2 < L; i2 += 256) hk[i2] = p.tapers[i2];          // taper 0 into buffer 0 of two
     }
 #define PHYS(idx) ((idx) + ((idx) >> 4))
 #define XBAR()                                                      \
@@ -371,15 +406,23 @@ __global__ void __launch_bounds__(256, LOG2N == 8 ? 4 : 1) mtfft16_kernel(MtArgs
             __syncthreads();                                        \
         }                                                           \
     } while (0)
+    MT_TICK(0);
     for (int k = 0; k < p.K; ++k) {
-        const float* hkk = hk;
-        if (resident) {
-            hkk = hk + k * L;
-        } else {
-            const float* hg = p.tapers + (int64_t)k * L;
-            for (int n = tid; n < L; n += 256) hk[n] = hg[n];
+        const float* hkk = resident ? hk + k * L : hk + (k & 1) * L;
+        // the next taper travels HBM/L2 -> registers under this taper's passes and is parked in the other
+        // LDS buffer before the stores go out (a load issued AFTER the stores would wait for them: vmcnt
+        // retires in order)
+        float hn[N / 256];
+        const bool fetch_next = !resident && k + 1 < p.K;
+        if (fetch_next) {
+#pragma unroll
+            for (int j = 0; j < N / 256; ++j) {
+                const int n = tid + 256 * j;
+                hn[j] = (n < L) ? p.tapers[(int64_t)(k + 1) * L + n] : 0.f;
+            }
         }
         __syncthreads();     // taper k visible; post of k-1 (and, first time, the tile reads) done
+        MT_TICK(1);
         float2 a[16], o[16];
         if (!(p.dbg & 2)) {
         // pass 1: radix 16, P = 1, inputs straight from the window tile
@@ -441,6 +484,15 @@ __global__ void __launch_bounds__(256, LOG2N == 8 ? 4 : 1) mtfft16_kernel(MtArgs
             __syncthreads();
         }
         } else { __syncthreads(); }
+        if (fetch_next) {
+            float* hnext = hk + ((k + 1) & 1) * L;
+#pragma unroll
+            for (int j = 0; j < N / 256; ++j) {
+                const int n = tid + 256 * j;
+                if (n < L) hnext[n] = hn[j];
+            }
+        }
+        MT_TICK(2);
         // split the packed pair, store X[f][w][r][k][c..c+1]
         if (p.dbg & 4) continue;
         float2* Xk = p.X + (((int64_t)w * p.R + r) * p.K + k) * C + c0;
@@ -479,6 +531,7 @@ __global__ void __launch_bounds__(256, LOG2N == 8 ? 4 : 1) mtfft16_kernel(MtArgs
             }
             if (last) put(N / 2, zn, zn);
         }
+        MT_TICK(3);
         // the barrier at the top of the next taper orders these reads before pass 1 rewrites z
     }
 #undef XBAR
@@ -521,12 +574,13 @@ static int launch_mt16(const MtArgs& a_in, hipStream_t stream) {
     constexpr int TPF = N / 16, NF = 256 / TPF, CT = 2 * NF;
     constexpr size_t xt_b = (size_t)N * (CT + 2) * 4, z_b = (size_t)NF * (N + N / 16 + 1) * 8;
     constexpr size_t uni = (xt_b > z_b ? xt_b : z_b), red_b = (size_t)(512 + 2 * CT) * 8;
-    static_assert(uni + (size_t)N * 12 <= 160 * 1024 && uni + red_b <= 160 * 1024, "LDS budget exceeded");
+    static_assert(uni + (size_t)N * 16 <= 160 * 1024 && uni + red_b <= 160 * 1024, "LDS budget exceeded");
     auto lds = [&](size_t kh, size_t L) { size_t t = (size_t)N * 8 + kh * L * 4; return uni + (t > red_b ? t : red_b); };
+    // not resident = two buffers: the next taper is parked while the current one is in use
     // Keep all K tapers in LDS when that does not cost a resident workgroup per CU.
     constexpr size_t cu_lds = 160 * 1024;
     MtArgs a = a_in;
-    const size_t one = lds(1, a.L), all = lds(a.K, a.L);
+    const size_t one = lds(2, a.L), all = lds(a.K, a.L);
     a.kh = (all <= cu_lds && cu_lds / all == cu_lds / one) ? a.K : 1;
     { const char* d = getenv("SC_MTFFT_DEBUG"); a.dbg = d ? atoi(d) : 0; }
     const size_t shmem = a.kh == a.K ? all : one;

@@ -1,0 +1,36 @@
+"""Profiling aid (GPU box): phase timers of the fused window/taper/FFT kernel (library rebuilt with -DMT_TRACE)."""
+import ctypes
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "tools", "libsc_trace_mt.so")
+
+if __name__ == "__main__":
+    sys.path.insert(0, ROOT)
+    if "--build" in sys.argv:
+        from spectral_connectivity_amd import _build
+        subprocess.run([_build._hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
+                        "-Wno-unused-result", "-fno-slp-vectorize", "-DMT_TRACE", *_build.sources(), "-lrocfft", "-o", LIB],
+                       check=True)
+        sys.exit(0)
+    os.environ["SC_HIP_LIB"] = LIB
+    import torch
+    from spectral_connectivity_amd import engine
+    x = torch.randn(1024, 1000, 128, device="cuda")
+    tap = torch.randn(7, 256, device="cuda")
+    engine.multitaper_spectra(x, tap, 256, 128, 256, 7, "constant")
+    torch.cuda.synchronize()
+    lib = ctypes.CDLL(LIB)
+    buf = (ctypes.c_ulonglong * 8)()
+    lib.sc_debug_mtfft_trace(None, 1)
+    engine.multitaper_spectra(x, tap, 256, 128, 256, 7, "constant")
+    torch.cuda.synchronize()
+    lib.sc_debug_mtfft_trace(buf, 0)
+    names = ["load + detrend + samples to registers", "waits at the per-taper barrier (7 tapers)",
+             "radix-16 passes (7 tapers)", "split + store issue (7 tapers)"]
+    tot = sum(buf[i] for i in range(4))
+    print("shader-clock cycles of wave 0 of one workgroup (c-tile 0, trial 3, window 3); total %d" % tot)
+    for i, n in enumerate(names):
+        print("  %-44s %8d  %5.1f %%" % (n, buf[i], 100.0 * buf[i] / max(tot, 1)))
