@@ -93,12 +93,27 @@ extern "C" int sc_fft_plan_work_bytes(const sc_fft_plan* plan, size_t* bytes) {
     return SC_OK;
 }
 
+// The DC and (even N) Nyquist coefficients of a real sequence are exactly real.  The reference's transform
+// (and the fused FFT kernels here) return them so, which is what makes PLI / wPLI exactly 0 at those bins
+// (connectivity.py:982-1028: weights < eps -> 1); a generic R2C leaves rounding noise in the imaginary part,
+// and sum Im / sum |Im| of noise is O(1).  X is [F][batch], row f = frequency bin.
+__global__ void real_bins_kernel(float2* X, int64_t batch, int64_t nyquist_row) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    X[b].y = 0.f;
+    if (nyquist_row > 0) X[nyquist_row * batch + b].y = 0.f;
+}
+
 extern "C" int sc_fft_execute(sc_fft_plan* plan, const float* d_y, void* d_X, void* stream) {
     SC_REQUIRE(plan && d_y && d_X, "NULL argument");
     SC_CHECK_FFT(rocfft_execution_info_set_stream(plan->info, stream));
     void* in[1] = {(void*)d_y};
     void* outb[1] = {d_X};
     SC_CHECK_FFT(rocfft_execute(plan->plan, in, outb, plan->info));
+    const int64_t nyq = (plan->N % 2 == 0) ? plan->N / 2 : 0;
+    hipLaunchKernelGGL(real_bins_kernel, dim3((unsigned)((plan->batch + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (float2*)d_X, plan->batch, nyq);
+    SC_CHECK_HIP(hipGetLastError());
     return SC_OK;
 }
 

@@ -1,0 +1,64 @@
+"""Seeded sweep over shapes: every fast path (fused FFT kernels, rocFFT path, fused / separate stage B, split bins)
+against the oracle on small random problems -- odd channel counts, windows shorter than the FFT length, single
+trial, single taper, few observations, every detrend mode and expectation type."""
+import numpy as np
+import pytest
+
+from oracle import spectral_oracle as so
+
+pytestmark = pytest.mark.gpu
+
+
+def _cases():
+    rng = np.random.default_rng(2024)
+    out = []
+    for k in range(36):
+        C = int(rng.choice([1, 2, 3, 5, 8, 16, 17, 31, 32, 33, 48, 64, 65, 96, 127, 128]))
+        L = int(rng.choice([16, 50, 64, 100, 128, 200, 256]))
+        step = int(rng.choice([L, max(L // 2, 1), max(L // 3, 1)]))
+        W = int(rng.integers(1, 4))
+        T = L + (W - 1) * step + int(rng.integers(0, max(step - 1, 1)))
+        R = int(rng.choice([1, 2, 3, 7, 20]))
+        NW = float(rng.choice([1.0, 2.0, 2.5, 4.0]))
+        det = [None, "constant", "linear"][k % 3]
+        et = ["trials_tapers", "trials", "tapers", "time", "time_trials", "time_tapers", "time_trials_tapers"][k % 7]
+        out.append(pytest.param(dict(C=C, L=L, step=step, T=T, R=R, NW=NW, det=det, et=et, seed=k), id=f"{k}-C{C}-L{L}-R{R}-{et}"))
+    return out
+
+
+def _close(a, b, tol, what):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, f"{what}: {a.shape} vs {b.shape}"
+    assert np.array_equal(np.isnan(a), np.isnan(b)), f"{what}: NaN pattern"
+    ok = ~np.isnan(b)
+    if ok.any():
+        scale = max(np.abs(b[ok]).max(), 1e-300)
+        err = np.abs(a[ok] - b[ok]).max()
+        assert err <= tol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e}"
+
+
+@pytest.mark.parametrize("cfg", _cases())
+def test_random_shapes_against_oracle(cfg):
+    import spectral_connectivity_amd as sc
+    rng = np.random.default_rng(cfg["seed"])
+    x = rng.standard_normal((cfg["T"], cfg["R"], cfg["C"]))
+    x += 0.7 * rng.standard_normal((cfg["T"], cfg["R"], 1))                 # shared component: non-trivial coherence
+    x += np.linspace(0, 2, cfg["T"])[:, None, None]                         # a trend for the detrend modes
+    kw = dict(sampling_frequency=250.0, time_halfbandwidth_product=cfg["NW"], detrend_type=cfg["det"],
+              n_time_samples_per_window=cfg["L"], n_time_samples_per_step=cfg["step"])
+    m = sc.Multitaper(x, **kw)
+    coef, info = so.multitaper_fft(x, fs=250.0, NW=cfg["NW"], detrend_type=cfg["det"],
+                                   n_time_samples_per_window=cfg["L"], n_time_samples_per_step=cfg["step"])
+    _close(m.fft(), coef, 2e-5, "fft")
+    c = sc.Connectivity.from_multitaper(m, expectation_type=cfg["et"])
+    n_obs = so.n_observations(coef, cfg["et"])
+    _close(c.power(), so.power(coef, cfg["et"]), 2e-5, "power")
+    if cfg["C"] >= 2:
+        _close(c.coherence_magnitude(), so.coherence_magnitude(coef, cfg["et"]), 3e-5, "coherence")
+        _close(c.imaginary_coherence(), so.imaginary_coherence(coef, cfg["et"]), 3e-5, "imaginary coherence")
+        if n_obs >= 2:                       # with one observation wPLI is +-1 and flips on f32 rounding of Im s ~ 0
+            # Im s is a difference of products: its f32 error is 1e-7 |s|, i.e. 1e-7 |s| / |Im s| relative, and the
+            # shared component + trend make |Im s| << |s| at low frequencies; a handful of observations do not
+            # average that out
+            _close(c.weighted_phase_lag_index(), so.weighted_phase_lag_index(coef, cfg["et"]),
+                   1e-4 if n_obs >= 8 else 1e-3, "wPLI")
