@@ -368,6 +368,8 @@ class Connectivity:
             raise ValueError(f"max_rank must be between 1 and min(n_signals, n_trials * n_tapers) = {min(C, R * K)}")
         if C > _lib.load().sc_global_coherence_max_signals():
             raise ValueError(f"global_coherence supports n_signals <= {_lib.load().sc_global_coherence_max_signals()}")
+        if C > 64 and max_rank > 4:
+            raise ValueError("global_coherence with more than 64 signals returns at most 4 components")
         n_freq = sp.F if sp.real_input else N
         planes = _lib.PLANE_CSM
         key = ("global", n_freq)

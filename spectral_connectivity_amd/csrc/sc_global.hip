@@ -7,7 +7,7 @@
 // engine already holds on the device, so the same numbers are the leading eigenpairs of that C x C
 // Hermitian matrix: one workgroup per (window, bin) runs a parallel cyclic Jacobi in fp64 on the
 // LDS-resident matrix (C / 2 disjoint rotations per step, round-robin pairing), accumulating the
-// eigenvectors.  Matrix + eigenvectors in LDS: C <= 64.
+// eigenvectors.  Matrix + eigenvectors in LDS: C <= 64; 64 < C <= 128: see global_coherence_big_kernel.
 #include "sc_common.h"
 
 typedef double2 cd;
@@ -173,7 +173,221 @@ __global__ void __launch_bounds__(256) global_coherence_kernel(GcArgs a) {
     }
 }
 
-extern "C" int sc_global_coherence_max_signals(void) { return GC_CMAX; }
+// ---- 64 < C <= 128: the matrix alone fills the LDS --------------------------------------------------
+// Upper triangle of the Hermitian matrix packed in LDS (C (C+1) / 2 complex128 = 132 KB at C = 128), no room
+// for the eigenvector matrix.  One thread per (pair a, pair b) 2x2 block of the round's pairing transforms
+// its four entries in place (B' = J_a^H B J_b: the disjoint rotations of a round act on disjoint blocks), and
+// the rotation angles of every round are logged to a global scratch; the requested eigenvectors are then
+// V e_k = J_1 J_2 ... J_m e_k, evaluated right to left on a single C-vector per eigenvector -- the C x C
+// eigenvector matrix is never formed.
+#define GC_BIG_CMAX 128
+#define GC_BIG_SWEEPS 12
+
+struct GcBigArgs {
+    GcArgs g;
+    double* log;           // [slots][GC_BIG_SWEEPS * (M - 1)][M / 2][3]  (cos, Re s, Im s)
+    int n_bins_total;
+};
+
+__device__ inline int gc_tri(int i, int j, int C) { return i * C - i * (i - 1) / 2 + (j - i); }   // i <= j
+__device__ inline cd gc_get(const cd* A, int i, int j, int C) {
+    if (i <= j) return A[gc_tri(i, j, C)];
+    const cd v = A[gc_tri(j, i, C)];
+    return make_double2(v.x, -v.y);
+}
+__device__ inline void gc_set(cd* A, int i, int j, int C, cd v) {
+    if (i <= j) A[gc_tri(i, j, C)] = v;
+    else A[gc_tri(j, i, C)] = make_double2(v.x, -v.y);
+}
+
+__global__ void __launch_bounds__(256) global_coherence_big_kernel(GcBigArgs b) {
+    extern __shared__ __align__(16) unsigned char gc_smem[];
+    const GcArgs& a = b.g;
+    const int C = a.C, M = C + (C & 1), H = M / 2;
+    cd* A = reinterpret_cast<cd*>(gc_smem);                            // packed upper triangle
+    double* rc = reinterpret_cast<double*>(A + (size_t)C * (C + 1) / 2);   // [H] cos
+    cd* rs = reinterpret_cast<cd*>(rc + H + (H & 1));                  // [H] sin e^{i phi}
+    int* rp = reinterpret_cast<int*>(rs + H);                          // [H][2]
+    double* ev = reinterpret_cast<double*>(rp + M + (M & 1));          // [C]
+    int* order = reinterpret_cast<int*>(ev + C);                       // [C]
+    unsigned short* blk_u = reinterpret_cast<unsigned short*>(order + C + (C & 1));   // [H (H+1) / 2] block -> pair u
+    unsigned short* blk_v = blk_u + H * (H + 1) / 2;                                  //                   pair v >= u
+    cd* xv = reinterpret_cast<cd*>((reinterpret_cast<uintptr_t>(blk_v + H * (H + 1) / 2) + 15) & ~(uintptr_t)15);
+                                                                       // [max_rank <= 4][C] back-applied vectors
+    __shared__ double red[2][256];
+    __shared__ int done, n_rounds;
+    const int tid = threadIdx.x;
+    double* mylog = b.log + (size_t)blockIdx.x * GC_BIG_SWEEPS * (M - 1) * H * 3;
+    for (int u = tid; u < H; u += 256) {               // block table, once per workgroup
+        const int start = u * H - u * (u - 1) / 2;
+        for (int v = u; v < H; ++v) { blk_u[start + v - u] = (unsigned short)u; blk_v[start + v - u] = (unsigned short)v; }
+    }
+    for (int item = blockIdx.x; item < b.n_bins_total; item += gridDim.x) {
+        const int64_t p = item / a.N, n = item - p * a.N;
+        int64_t bin = n;
+        bool conj = false;
+        if (!a.two_sided && n > a.N / 2) { bin = a.N - n; conj = true; }
+        const float* rec = a.accum + (p * a.F + bin) * a.floats_per_bin;
+        __syncthreads();
+        for (int e = tid; e < C * C; e += 256) {
+            const int i = e / C, j = e % C;
+            if (i > j) continue;
+            const int ti = i >> 4, tj = j >> 4, ii = i & 15, jj = j & 15;      // i <= j: upper triangle, no mirror
+            const int64_t off = (int64_t)sc_tile_index(ti, tj, a.NB) * SC_TILE_ELEMS + ii * 16 + jj;
+            const double re = (double)rec[(int64_t)a.p_csm * a.n_tiles * SC_TILE_ELEMS + off] / a.n_obs;
+            double im = (double)rec[(int64_t)(a.p_csm + 1) * a.n_tiles * SC_TILE_ELEMS + off] / a.n_obs;
+            if (conj) im = -im;
+            if (i == j) im = 0.0;
+            A[gc_tri(i, j, C)] = make_double2(re, im);
+        }
+        if (tid == 0) n_rounds = 0;
+        __syncthreads();
+        for (int sweep = 0; sweep < GC_BIG_SWEEPS; ++sweep) {
+            double off = 0.0, dia = 0.0;              // off = the whole packed triangle, dia = its diagonal
+            for (int i = tid; i < C; i += 256) { const cd v = A[gc_tri(i, i, C)]; dia += v.x * v.x; }
+            for (int e = tid; e < C * (C + 1) / 2; e += 256) off += A[e].x * A[e].x + A[e].y * A[e].y;
+            red[0][tid] = off; red[1][tid] = dia;
+            __syncthreads();
+            for (int s = 128; s > 0; s >>= 1) {
+                if (tid < s) { red[0][tid] += red[0][tid + s]; red[1][tid] += red[1][tid + s]; }
+                __syncthreads();
+            }
+            if (tid == 0) { const double o = red[0][0] - red[1][0]; done = (o <= 1e-28 * red[1][0] || o <= 0.0) ? 1 : 0; }
+            __syncthreads();
+            if (done) break;
+            for (int r = 0; r < M - 1; ++r) {
+                if (tid < H) {
+                    int x, y;
+                    if (tid == 0) { x = M - 1; y = r; }
+                    else { x = (r + tid) % (M - 1); y = (r - tid + (M - 1)) % (M - 1); }
+                    int pi = x < y ? x : y, qi = x < y ? y : x;
+                    double c = 1.0;
+                    cd se = make_double2(0.0, 0.0);
+                    if (qi < C) {
+                        const cd bb = A[gc_tri(pi, qi, C)];
+                        const double ab = hypot(bb.x, bb.y);
+                        if (ab >= 1e-300) {
+                            const double tau = (A[gc_tri(qi, qi, C)].x - A[gc_tri(pi, pi, C)].x) / (2.0 * ab);
+                            const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + hypot(1.0, tau));
+                            c = 1.0 / hypot(1.0, t);
+                            const double sn = t * c;
+                            se = make_double2(sn * bb.x / ab, sn * bb.y / ab);
+                        }
+                    } else {
+                        qi = -1;                      // the dummy player sits out (identity rotation)
+                    }
+                    rc[tid] = c; rs[tid] = se; rp[2 * tid] = pi; rp[2 * tid + 1] = qi;
+                    double* lg = mylog + ((size_t)(sweep * (M - 1) + r) * H + tid) * 3;
+                    lg[0] = c; lg[1] = se.x; lg[2] = se.y;
+                }
+                __syncthreads();
+                // 2x2 blocks (pair u <= pair v): B' = J_u^H B J_v with J = [[c, s], [-conj s, c]]
+                for (int blk = tid; blk < H * (H + 1) / 2; blk += 256) {
+                    const int u = blk_u[blk], v = blk_v[blk];
+                    const int up = rp[2 * u], uq = rp[2 * u + 1], vp = rp[2 * v], vq = rp[2 * v + 1];
+                    const double cu = rc[u], cv = rc[v];
+                    const cd su = rs[u], sv = rs[v];
+                    const bool uhas = uq >= 0, vhas = vq >= 0;
+                    // B = [[a(up,vp), a(up,vq)], [a(uq,vp), a(uq,vq)]]
+                    cd b00 = gc_get(A, up, vp, C);
+                    cd b01 = vhas ? gc_get(A, up, vq, C) : make_double2(0, 0);
+                    cd b10 = uhas ? gc_get(A, uq, vp, C) : make_double2(0, 0);
+                    cd b11 = (uhas && vhas) ? gc_get(A, uq, vq, C) : make_double2(0, 0);
+                    // T = B J_v : columns vp, vq
+                    const cd svc = make_double2(sv.x, -sv.y);
+                    cd t00 = make_double2(cv * b00.x - g_mul(svc, b01).x, cv * b00.y - g_mul(svc, b01).y);
+                    cd t01 = make_double2(g_mul(sv, b00).x + cv * b01.x, g_mul(sv, b00).y + cv * b01.y);
+                    cd t10 = make_double2(cv * b10.x - g_mul(svc, b11).x, cv * b10.y - g_mul(svc, b11).y);
+                    cd t11 = make_double2(g_mul(sv, b10).x + cv * b11.x, g_mul(sv, b10).y + cv * b11.y);
+                    // B' = J_u^H T : rows up, uq  (row p' = c row p - s row q ; row q' = conj(s) row p + c row q)
+                    const cd suc = make_double2(su.x, -su.y);
+                    const cd n00 = make_double2(cu * t00.x - g_mul(su, t10).x, cu * t00.y - g_mul(su, t10).y);
+                    const cd n01 = make_double2(cu * t01.x - g_mul(su, t11).x, cu * t01.y - g_mul(su, t11).y);
+                    const cd n10 = make_double2(g_mul(suc, t00).x + cu * t10.x, g_mul(suc, t00).y + cu * t10.y);
+                    const cd n11 = make_double2(g_mul(suc, t01).x + cu * t11.x, g_mul(suc, t01).y + cu * t11.y);
+                    if (u == v) {
+                        // diagonal block: Hermitian, off-diagonal annihilated by construction
+                        gc_set(A, up, up, C, make_double2(n00.x, 0.0));
+                        if (uhas) {
+                            gc_set(A, uq, uq, C, make_double2(n11.x, 0.0));
+                            gc_set(A, up, uq, C, make_double2(0.0, 0.0));
+                        }
+                    } else {
+                        gc_set(A, up, vp, C, n00);
+                        if (vhas) gc_set(A, up, vq, C, n01);
+                        if (uhas) gc_set(A, uq, vp, C, n10);
+                        if (uhas && vhas) gc_set(A, uq, vq, C, n11);
+                    }
+                }
+                __syncthreads();
+            }
+            if (tid == 0) n_rounds = (sweep + 1) * (M - 1);
+            __syncthreads();
+        }
+        // rank the eigenvalues (descending, ties by index)
+        for (int i = tid; i < C; i += 256) ev[i] = A[gc_tri(i, i, C)].x;
+        __syncthreads();
+        for (int i = tid; i < C; i += 256) {
+            int rank = 0;
+            for (int j = 0; j < C; ++j) rank += (ev[j] > ev[i] || (ev[j] == ev[i] && j < i)) ? 1 : 0;
+            order[rank] = i;
+        }
+        __syncthreads();
+        const int K = a.max_rank;
+        double* val = a.values + (p * a.N + n) * K;
+        cd* vec = a.vectors + (p * a.N + n) * (int64_t)C * K;
+        for (int k = tid; k < K; k += 256) {
+            const int src = a.ascending ? order[K - 1 - k] : order[k];
+            val[k] = ev[src] > 0.0 ? ev[src] : 0.0;
+        }
+        // eigenvectors: x = J_1 ... J_m e_src, right to left; thread (k, pair) rotates two entries per round
+        for (int e = tid; e < K * C; e += 256) {
+            const int k = e / C, i = e % C;
+            const int src = a.ascending ? order[K - 1 - k] : order[k];
+            xv[e] = make_double2(i == src ? 1.0 : 0.0, 0.0);
+        }
+        __syncthreads();
+        const int total_rounds = n_rounds;
+        for (int rr = total_rounds - 1; rr >= 0; --rr) {
+            const int r = rr % (M - 1);
+            for (int w = tid; w < K * H; w += 256) {
+                const int k = w / H, t = w % H;
+                int x, y;
+                if (t == 0) { x = M - 1; y = r; }
+                else { x = (r + t) % (M - 1); y = (r - t + (M - 1)) % (M - 1); }
+                const int pi = x < y ? x : y, qi = x < y ? y : x;
+                if (qi >= C) continue;
+                const double* lg = mylog + ((size_t)rr * H + t) * 3;
+                const double c = lg[0];
+                const cd se = make_double2(lg[1], lg[2]), sec = make_double2(lg[1], -lg[2]);
+                const cd xp = xv[k * C + pi], xq = xv[k * C + qi];
+                const cd t1 = g_mul(se, xq), t2 = g_mul(sec, xp);
+                xv[k * C + pi] = make_double2(c * xp.x + t1.x, c * xp.y + t1.y);
+                xv[k * C + qi] = make_double2(c * xq.x - t2.x, c * xq.y - t2.y);
+            }
+            __syncthreads();
+        }
+        for (int k = 0; k < K; ++k) {
+            __shared__ cd phase;
+            if (tid == 0) {
+                double best = -1.0;
+                cd bb = make_double2(1.0, 0.0);
+                for (int i = 0; i < C; ++i) {
+                    const cd v = xv[k * C + i];
+                    const double m2 = v.x * v.x + v.y * v.y;
+                    if (m2 > best) { best = m2; bb = v; }
+                }
+                const double ab = sqrt(best);
+                phase = ab > 0.0 ? make_double2(bb.x / ab, -bb.y / ab) : make_double2(1.0, 0.0);
+            }
+            __syncthreads();
+            for (int i = tid; i < C; i += 256) vec[(int64_t)i * K + k] = g_mul(xv[k * C + i], phase);
+            __syncthreads();
+        }
+    }
+}
+
+extern "C" int sc_global_coherence_max_signals(void) { return GC_BIG_CMAX; }
 
 extern "C" int sc_global_coherence_f64(const float* d_accum, int64_t n_groups, int64_t n_freq_accum, int64_t N,
                                        int64_t C, uint32_t planes, int64_t n_obs, int max_rank, int ascending,
@@ -182,9 +396,8 @@ extern "C" int sc_global_coherence_f64(const float* d_accum, int64_t n_groups, i
     SC_REQUIRE(planes & SC_PLANE_CSM, "accumulator record must contain SC_PLANE_CSM");
     SC_REQUIRE(n_freq_accum == N || n_freq_accum == N / 2 + 1, "accumulators must hold N or N/2+1 bins");
     SC_REQUIRE(n_groups >= 1 && n_groups <= 65535 && N >= 1 && n_obs >= 1, "bad problem size");
-    if (C < 1 || C > GC_CMAX) {
-        sc_set_error("global coherence keeps the C x C matrix and its eigenvectors in LDS: n_signals <= %d (got %lld)",
-                     GC_CMAX, (long long)C);
+    if (C < 1 || C > GC_BIG_CMAX) {
+        sc_set_error("global coherence keeps the C x C matrix in LDS: n_signals <= %d (got %lld)", GC_BIG_CMAX, (long long)C);
         return SC_EUNSUPPORTED;
     }
     SC_REQUIRE(max_rank >= 1 && max_rank <= C, "max_rank must be in 1..n_signals");
@@ -197,6 +410,30 @@ extern "C" int sc_global_coherence_f64(const float* d_accum, int64_t n_groups, i
     a.floats_per_bin = (int64_t)sc_plane_count(planes) * a.n_tiles * SC_TILE_ELEMS;
     a.max_rank = max_rank; a.ascending = ascending; a.n_obs = (double)n_obs;
     const int M = (int)C + ((int)C & 1);
+    if (C > GC_CMAX) {
+        // matrix only in LDS, rotation log in a device scratch owned by this call
+        SC_REQUIRE(max_rank <= 4, "n_signals > 64: at most 4 components");
+        const int H = M / 2;
+        const int64_t bins = n_groups * N;
+        const int slots = (int)(bins < 512 ? bins : 512);
+        const size_t log_bytes = (size_t)slots * GC_BIG_SWEEPS * (M - 1) * H * 3 * sizeof(double);
+        double* log = nullptr;
+        if (hipMalloc((void**)&log, log_bytes) != hipSuccess) { sc_set_error("global coherence: rotation log alloc failed"); return SC_ENOMEM; }
+        GcBigArgs b;
+        b.g = a; b.log = log; b.n_bins_total = (int)bins;
+        const size_t lds = (size_t)C * (C + 1) / 2 * sizeof(cd) + (size_t)(H + 2) * 8 + (size_t)H * 16 + (size_t)(M + 2) * 4 +
+                           (size_t)C * 8 + (size_t)(C + 4) * 4 + (size_t)H * (H + 1) * 2 + 16 + (size_t)4 * C * sizeof(cd) + 64;
+        (void)hipFuncSetAttribute((const void*)global_coherence_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(global_coherence_big_kernel, dim3((unsigned)slots), dim3(256), lds, (hipStream_t)stream, b);
+        const hipError_t e1 = hipGetLastError();
+        const hipError_t e2 = hipStreamSynchronize((hipStream_t)stream);       // the log is freed below
+        (void)hipFree(log);
+        if (e1 != hipSuccess || e2 != hipSuccess) {
+            sc_set_error("global coherence (n_signals > 64) failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+            return SC_EHIP;
+        }
+        return SC_OK;
+    }
     const size_t lds = (size_t)2 * C * C * sizeof(cd) + (size_t)(M / 2 + 2) * 8 + (size_t)(M / 2) * 16 + (size_t)(M + 2) * 4 +
                        (size_t)C * 8 + (size_t)C * 4 + 64;
     (void)hipFuncSetAttribute((const void*)global_coherence_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

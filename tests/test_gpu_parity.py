@@ -381,15 +381,20 @@ def test_f10_global_coherence_vs_reference(sc, golden, rank):
 
 
 def test_global_coherence_large_even_and_odd(sc):
-    """33 and 64 signals against the oracle SVD (values), two windows."""
-    for C in (33, 64):
+    """33, 64 (matrix + eigenvectors in LDS) and 65, 97, 128 signals (packed matrix in LDS, eigenvectors from the
+    logged rotations) against the oracle SVD: values, and vectors as lines for the dominant component."""
+    for C in (33, 64, 65, 97, 128):
         x = np.random.default_rng(C).standard_normal((128, 40, C))
         x[:, :, : C // 2] += np.random.default_rng(1).standard_normal((128, 40, 1))
         m = sc.Multitaper(x, sampling_frequency=128.0, time_halfbandwidth_product=2, n_time_samples_per_window=64)
         vals, vecs = sc.Connectivity.from_multitaper(m).global_coherence(max_rank=3)
         coef, _ = so.multitaper_fft(x, fs=128.0, NW=2, n_time_samples_per_window=64)
-        ref, _ = so.global_coherence(coef, max_rank=3)
+        ref, ref_vecs = so.global_coherence(coef, max_rank=3)
         close32(vals, ref, rtol=2e-5, atol_scale=2e-6, what=f"global coherence C={C}")
+        np.testing.assert_allclose(np.linalg.norm(vecs, axis=-2), 1.0, atol=1e-9)
+        # max_rank = 3 < C - 1: ascending order, the dominant component (shared source) is the last column
+        ip = np.abs(np.sum(np.conj(vecs[..., -1]) * ref_vecs[..., -1], axis=-1))
+        assert (ip > 1 - 1e-3).mean() > 0.9, f"C={C}: dominant vector differs ({ip.min()})"
 
 
 def test_wrapper_labels_with_a_stand_in_xarray(sc, monkeypatch):
