@@ -37,7 +37,7 @@ from spectral_connectivity_amd.transforms import _make_tapers  # noqa: E402
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32 dense peak
 # HBM bytes per launch of the dominant kernel, measured with rocprofv3 --pmc (profiles/r01_hbm_traffic.txt)
-MEASURED_TRAFFIC_BYTES = {("cfg3", "fused_csm_absim"): 7.49e9 + 0.39e9, ("cfg3", "mtfft_fused"): 7.27e9}
+MEASURED_TRAFFIC_BYTES = {("cfg3", "fused_csm_absim"): 7.42e9 + 0.39e9, ("cfg3", "mtfft_fused"): 7.22e9}
 
 CONFIGS = {
     # name: T, R, C, NW, L, step
