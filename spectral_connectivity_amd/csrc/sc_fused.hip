@@ -659,7 +659,7 @@ extern "C" int sc_fused_supported(int64_t n_signals) {
 // Workgroups per bin.  One workgroup fills a CU (LDS), so n_bins workgroups run in ceil(n_bins / n_cu)
 // rounds and the last round may be nearly empty (903 bins on 256 CUs: 4 rounds for 3.53 rounds of
 // work).  Splitting every bin's observations over S workgroups shortens the rounds; pick the S <= 8
-// with the fewest (rounds / S), keeping >= 16 chunks per part.
+// with the fewest (rounds / S), keeping >= 16 chunks per part (S <= 24: few bins with many observations).
 static int fused_pick_split(int n_bins, int n_obs) {
     const char* e = getenv("SC_FUSED_SPLIT");
     const int nc = (n_obs + FU_OC - 1) / FU_OC;
@@ -674,13 +674,13 @@ static int fused_pick_split(int n_bins, int n_obs) {
     }
     int best = 1;
     double best_cost = 1e30;
-    for (int S = 1; S <= 8; ++S) {
+    for (int S = 1; S <= 24; ++S) {
         if (S > 1 && nc / S < 16) break;
         const double rounds = (double)(((int64_t)n_bins * S + n_cu - 1) / n_cu) / S;
         const double cost = rounds * (1.0 + 0.015 * (S - 1));      // prologue/epilogue + combine traffic per part
         if (cost < best_cost - 1e-9) { best_cost = cost; best = S; }
     }
-    if (e && atoi(e) >= 1 && atoi(e) <= 8 && (atoi(e) == 1 || nc / atoi(e) >= 1)) best = atoi(e);
+    if (e && atoi(e) >= 1 && atoi(e) <= 24 && (atoi(e) == 1 || nc / atoi(e) >= 1)) best = atoi(e);
     return best;
 }
 

@@ -66,16 +66,20 @@ __device__ void mv_lu_forward(cd* M, cd* R, int C, int NR, int* piv) {
         const cd d = M[k * C + k];
         for (int i = k + 1 + tid; i < C; i += nt) M[i * C + k] = m_div(M[i * C + k], d);
         __syncthreads();
-        const int rows = C - k - 1, cols = (C - k - 1) + NR;
-        for (int idx = tid; idx < rows * cols; idx += nt) {
-            const int i = k + 1 + idx / cols, jj = idx % cols;
+        // trailing update of M and R: thread (ty, tx) walks rows ty, ty + nty, ... and columns tx, tx + 32, ...
+        // (no integer division in the O(C^3) loop)
+        const int tx = tid & 31, ty = tid >> 5, nty = nt >> 5 ? nt >> 5 : 1, ntx = nt < 32 ? nt : 32;
+        const int cm = C - k - 1;
+        for (int i = k + 1 + ty; i < C; i += nty) {
             const cd l = M[i * C + k];
-            if (jj < C - k - 1) {
-                const int j = k + 1 + jj;
-                M[i * C + j] = m_sub(M[i * C + j], m_mul(l, M[k * C + j]));
-            } else {
-                const int j = jj - (C - k - 1);
-                R[i * NR + j] = m_sub(R[i * NR + j], m_mul(l, R[k * NR + j]));
+            for (int jj = (nt < 32 ? tid : tx); jj < cm + NR; jj += ntx) {
+                if (jj < cm) {
+                    const int j = k + 1 + jj;
+                    M[i * C + j] = m_sub(M[i * C + j], m_mul(l, M[k * C + j]));
+                } else {
+                    const int j = jj - cm;
+                    R[i * NR + j] = m_sub(R[i * NR + j], m_mul(l, R[k * NR + j]));
+                }
             }
         }
         __syncthreads();
@@ -94,10 +98,10 @@ __device__ void mv_apply_forward(const cd* M, cd* R, int C, int NR, const int* p
         }
     __syncthreads();
     for (int k = 0; k < C; ++k) {
-        const int rows = C - k - 1;
-        for (int idx = tid; idx < rows * NR; idx += nt) {
-            const int i = k + 1 + idx / NR, j = idx % NR;
-            R[i * NR + j] = m_sub(R[i * NR + j], m_mul(M[i * C + k], R[k * NR + j]));
+        const int tx = tid & 31, ty = tid >> 5, nty = nt >> 5 ? nt >> 5 : 1, ntx = nt < 32 ? nt : 32;
+        for (int i = k + 1 + ty; i < C; i += nty) {
+            const cd l = M[i * C + k];
+            for (int j = (nt < 32 ? tid : tx); j < NR; j += ntx) R[i * NR + j] = m_sub(R[i * NR + j], m_mul(l, R[k * NR + j]));
         }
         __syncthreads();
     }
@@ -110,9 +114,10 @@ __device__ void mv_back_subst(const cd* M, cd* R, int C, int NR) {
         const cd d = M[k * C + k];
         for (int j = tid; j < NR; j += nt) R[k * NR + j] = m_div(R[k * NR + j], d);
         __syncthreads();
-        for (int idx = tid; idx < k * NR; idx += nt) {
-            const int i = idx / NR, j = idx % NR;
-            R[i * NR + j] = m_sub(R[i * NR + j], m_mul(M[i * C + k], R[k * NR + j]));
+        const int tx = tid & 31, ty = tid >> 5, nty = nt >> 5 ? nt >> 5 : 1, ntx = nt < 32 ? nt : 32;
+        for (int i = ty; i < k; i += nty) {
+            const cd l = M[i * C + k];
+            for (int j = (nt < 32 ? tid : tx); j < NR; j += ntx) R[i * NR + j] = m_sub(R[i * NR + j], m_mul(l, R[k * NR + j]));
         }
         __syncthreads();
     }
