@@ -658,7 +658,7 @@ extern "C" int sc_fused_supported(int64_t n_signals) {
 
 // Workgroups per bin.  One workgroup fills a CU (LDS), so n_bins workgroups run in ceil(n_bins / n_cu)
 // rounds and the last round may be nearly empty (903 bins on 256 CUs: 4 rounds for 3.53 rounds of
-// work).  Splitting every bin's observations over S workgroups shortens the rounds; pick the S <= 8
+// work).  Splitting every bin's observations over S workgroups shortens the rounds; pick the S
 // with the fewest (rounds / S), keeping >= 16 chunks per part (S <= 24: few bins with many observations).
 static int fused_pick_split(int n_bins, int n_obs) {
     const char* e = getenv("SC_FUSED_SPLIT");
