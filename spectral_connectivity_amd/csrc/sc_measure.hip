@@ -1,9 +1,10 @@
 // sc_measure.hip -- measures epilogue: accumulated sums -> connectivity measures.
 //
-// One thread per output element (bin, i, j).  Reads the packed upper-triangular tile
-// records (mirroring with conjugation for i-block > j-block), divides by n_observations
-// (AFTER any cross-GPU sum), and applies the reference's algebra literally, in fp64
-// (the epilogue touches W*F*C^2 elements once; it is HBM-bound and tiny next to stage B):
+// One workgroup per (bin, upper-triangular 16x16 tile): the tile's planes are read once, coalesced,
+// the measure is evaluated for the tile and for its mirror image (conjugate / sign rules per measure),
+// and both 16x16 output blocks are written as 64-byte rows (the mirror through an LDS transpose).
+// Divides by n_observations (AFTER any cross-GPU sum) and applies the reference's algebra literally,
+// in fp64 (the epilogue touches W*F*C^2 elements once; it is HBM-bound and tiny next to stage B):
 //   coherency   connectivity.py:632-657   S_ij / max(sqrt(P_i P_j), eps), diagonal NaN
 //   coherence   connectivity.py:675-702   clip(|coherency|^2, 0, 1)
 //   imag. coh.  connectivity.py:704-743   clip(|Im S_ij| / max(sqrt(P_i P_j), eps), 0, 1)
@@ -36,97 +37,137 @@ __device__ inline float tile_read(const float* bin_rec, int plane, int n_tiles, 
     return bin_rec[((int64_t)plane * n_tiles + sc_tile_index(ti, tj, NB)) * SC_TILE_ELEMS + ii * 16 + jj];
 }
 
-__global__ void __launch_bounds__(256) measure_kernel(MeasureArgs a) {
+// power: one thread per (bin, channel)
+__global__ void __launch_bounds__(256) power_kernel(MeasureArgs a) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= a.total) return;
-    const double NaN = nan("");
-    const double n = a.n_obs;
-    if (a.measure == SC_M_POWER) {
-        const int64_t bin = idx / a.C;
-        const int i = (int)(idx - bin * a.C);
-        bool m;
-        const float* rec = a.accum + bin * a.floats_per_bin;
-        ((float*)a.out)[idx] = (float)((double)tile_read(rec, a.p_csm, a.n_tiles, a.NB, i, i, &m) / n);
-        return;
-    }
-    const int64_t CC = (int64_t)a.C * a.C;
-    const int64_t bin = idx / CC;
-    const int rem = (int)(idx - bin * CC);
-    const int i = rem / a.C, j = rem - i * a.C;
-    const bool diag = i == j;
+    const int64_t bin = idx / a.C;
+    const int i = (int)(idx - bin * a.C);
+    bool m;
     const float* rec = a.accum + bin * a.floats_per_bin;
-    bool m = false;
-    double s_re = 0, s_im = 0, p_i = 0, p_j = 0;
-    if (a.p_csm >= 0) {
-        s_re = (double)tile_read(rec, a.p_csm, a.n_tiles, a.NB, i, j, &m) / n;
-        s_im = (double)tile_read(rec, a.p_csm + 1, a.n_tiles, a.NB, i, j, &m) / n;
-        if (m) s_im = -s_im;
-        if (diag) s_im = 0.0;
-        bool mm;
-        p_i = (double)tile_read(rec, a.p_csm, a.n_tiles, a.NB, i, i, &mm) / n;
-        p_j = (double)tile_read(rec, a.p_csm, a.n_tiles, a.NB, j, j, &mm) / n;
-    }
-    float* outf = (float*)a.out;
-    float2* outc = (float2*)a.out;
-    switch (a.measure) {
+    ((float*)a.out)[idx] = (float)((double)tile_read(rec, a.p_csm, a.n_tiles, a.NB, i, i, &m) / a.n_obs);
+}
+
+// raw (un-normalised) sums of one matrix entry (i, j), as stored for the upper triangle
+struct MeasureIn {
+    double s_re, s_im;     // sum x_i conj(x_j)
+    double p_i, p_j;       // sum |x_i|^2, sum |x_j|^2
+    double sa, sq, sg;     // sum |Im s|, sum (Im s)^2, sum sign Im s
+    double u_re, u_im;     // sum s / |s|
+};
+
+// the entry (j, i) from the sums of (i, j): s and the unit phasors are conjugated, sign Im s flips
+__device__ inline MeasureIn measure_mirror(MeasureIn v) {
+    MeasureIn w = v;
+    w.s_im = -v.s_im; w.u_im = -v.u_im; w.sg = -v.sg; w.p_i = v.p_j; w.p_j = v.p_i;
+    return w;
+}
+
+// one measure of one entry; complex measures return (re, im), real ones (value, 0)
+__device__ inline float2 measure_value(int measure, double n, MeasureIn v, bool diag) {
+    const double NaN = nan("");
+    double s_re = v.s_re / n, s_im = diag ? 0.0 : v.s_im / n;
+    const double p_i = v.p_i / n, p_j = v.p_j / n;
+    switch (measure) {
     case SC_M_CSM:
-        outc[idx] = make_float2((float)s_re, (float)s_im);
-        break;
+        return make_float2((float)s_re, (float)s_im);
     case SC_M_COHERENCY:
     case SC_M_COHERENCE_MAGNITUDE:
     case SC_M_COHERENCE_PHASE: {
         const double den = fmax(sqrt(p_i * p_j), SC_EPS64);
         double c_re = s_re / den, c_im = s_im / den;
         if (diag) { c_re = NaN; c_im = NaN; }
-        if (a.measure == SC_M_COHERENCY) outc[idx] = make_float2((float)c_re, (float)c_im);
-        else if (a.measure == SC_M_COHERENCE_MAGNITUDE) {
-            double mag = c_re * c_re + c_im * c_im;
-            outf[idx] = (float)(diag ? NaN : fmin(fmax(mag, 0.0), 1.0));
-        } else outf[idx] = (float)(diag ? NaN : atan2(c_im, c_re));
-        break;
+        if (measure == SC_M_COHERENCY) return make_float2((float)c_re, (float)c_im);
+        if (measure == SC_M_COHERENCE_MAGNITUDE) {
+            const double mag = c_re * c_re + c_im * c_im;
+            return make_float2((float)(diag ? NaN : fmin(fmax(mag, 0.0), 1.0)), 0.f);
+        }
+        return make_float2((float)(diag ? NaN : atan2(c_im, c_re)), 0.f);
     }
     case SC_M_IMAGINARY_COHERENCE: {
         const double den = fmax(sqrt(p_i * p_j), SC_EPS64);
-        outf[idx] = (float)fmin(fmax(fabs(s_im / den), 0.0), 1.0);
-        break;
+        return make_float2((float)fmin(fmax(fabs(s_im / den), 0.0), 1.0), 0.f);
     }
     case SC_M_PLV:
+        return make_float2((float)(sqrt(v.u_re * v.u_re + v.u_im * v.u_im) / n), 0.f);
     case SC_M_PLV_COMPLEX:
-    case SC_M_PPC: {
-        double u_re = (double)tile_read(rec, a.p_unit, a.n_tiles, a.NB, i, j, &m);
-        double u_im = (double)tile_read(rec, a.p_unit + 1, a.n_tiles, a.NB, i, j, &m);
-        if (m) u_im = -u_im;
-        if (a.measure == SC_M_PPC) outf[idx] = (float)((u_re * u_re + u_im * u_im - n) / (n * n - n));
-        else if (a.measure == SC_M_PLV) outf[idx] = (float)(sqrt(u_re * u_re + u_im * u_im) / n);
-        else outc[idx] = make_float2((float)(u_re / n), (float)(u_im / n));
-        break;
-    }
+        return make_float2((float)(v.u_re / n), (float)(v.u_im / n));
+    case SC_M_PPC:
+        return make_float2((float)((v.u_re * v.u_re + v.u_im * v.u_im - n) / (n * n - n)), 0.f);
     case SC_M_PLI:
     case SC_M_DEBIASED_PLI2: {
-        double sg = (double)tile_read(rec, a.p_sign, a.n_tiles, a.NB, i, j, &m);
-        if (m) sg = -sg;
-        if (diag) sg = 0.0;
-        const double pli = sg / n;
-        outf[idx] = (float)(a.measure == SC_M_PLI ? pli : (n * pli * pli - 1.0) / (n - 1.0));
-        break;
+        const double pli = (diag ? 0.0 : v.sg) / n;
+        return make_float2((float)(measure == SC_M_PLI ? pli : (n * pli * pli - 1.0) / (n - 1.0)), 0.f);
     }
     case SC_M_WPLI: {
-        double w = diag ? 0.0 : (double)tile_read(rec, a.p_abs, a.n_tiles, a.NB, i, j, &m) / n;
+        double w = diag ? 0.0 : v.sa / n;
         if (w < SC_EPS64) w = 1.0;
-        outf[idx] = (float)(s_im / w);
-        break;
+        return make_float2((float)(s_im / w), 0.f);
     }
     case SC_M_DEBIASED_WPLI2: {
         const double si = s_im * n;
-        const double sa = diag ? 0.0 : (double)tile_read(rec, a.p_abs, a.n_tiles, a.NB, i, j, &m);
-        const double sq = diag ? 0.0 : (double)tile_read(rec, a.p_sq, a.n_tiles, a.NB, i, j, &m);
+        const double sa = diag ? 0.0 : v.sa, sq = diag ? 0.0 : v.sq;
         double wgt = sa * sa - sq;
         if (wgt == 0.0 || n <= 1.0) wgt = NaN;
-        outf[idx] = (float)((si * si - sq) / wgt);
-        break;
+        return make_float2((float)((si * si - sq) / wgt), 0.f);
     }
     default:
-        break;
+        return make_float2(0.f, 0.f);
+    }
+}
+
+template <bool COMPLEX_OUT>
+__global__ void __launch_bounds__(256) measure_tile_kernel(MeasureArgs a) {
+    __shared__ MeasureIn raw[256];
+    __shared__ float2 mir[256];
+    const int tid = threadIdx.x, ii = tid >> 4, jj = tid & 15;
+    int ti = 0, len = a.NB, t = blockIdx.y;                 // upper-triangular tile (ti <= tj)
+    while (t >= len) { t -= len; ++ti; --len; }
+    const int tj = ti + t;
+    const int64_t bin = blockIdx.x;
+    const float* rec = a.accum + bin * a.floats_per_bin;
+    const int64_t plane = (int64_t)a.n_tiles * SC_TILE_ELEMS;
+    const float* tile = rec + (int64_t)blockIdx.y * SC_TILE_ELEMS + ii * 16 + jj;
+    MeasureIn v = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (a.p_csm >= 0) {
+        v.s_re = (double)tile[a.p_csm * plane];
+        v.s_im = (double)tile[(a.p_csm + 1) * plane];
+        v.p_i = (double)rec[a.p_csm * plane + (int64_t)sc_tile_index(ti, ti, a.NB) * SC_TILE_ELEMS + ii * 17];
+        v.p_j = (double)rec[a.p_csm * plane + (int64_t)sc_tile_index(tj, tj, a.NB) * SC_TILE_ELEMS + jj * 17];
+    }
+    if (a.p_abs >= 0 && (a.measure == SC_M_WPLI || a.measure == SC_M_DEBIASED_WPLI2)) v.sa = (double)tile[a.p_abs * plane];
+    if (a.p_sq >= 0 && a.measure == SC_M_DEBIASED_WPLI2) v.sq = (double)tile[a.p_sq * plane];
+    if (a.p_sign >= 0 && (a.measure == SC_M_PLI || a.measure == SC_M_DEBIASED_PLI2)) v.sg = (double)tile[a.p_sign * plane];
+    if (a.p_unit >= 0 && (a.measure == SC_M_PLV || a.measure == SC_M_PLV_COMPLEX || a.measure == SC_M_PPC)) {
+        v.u_re = (double)tile[a.p_unit * plane];
+        v.u_im = (double)tile[(a.p_unit + 1) * plane];
+    }
+    const bool dtile = ti == tj;
+    if (dtile) {
+        // lower triangle inside a diagonal tile comes from its mirror: the matrix cores fill the tile
+        // completely, but (i,j) and (j,i) differ by rounding; using one of them keeps every measure
+        // exactly (anti)symmetric like the reference
+        raw[tid] = v;
+        __syncthreads();
+        if (ii > jj) v = measure_mirror(raw[jj * 16 + ii]);
+    }
+    const int i = ti * 16 + ii, j = tj * 16 + jj;
+    float* outf = (float*)a.out;
+    float2* outc = (float2*)a.out;
+    const int64_t obase = bin * (int64_t)a.C * a.C;
+    const float2 direct = measure_value(a.measure, a.n_obs, v, i == j);
+    if (i < a.C && j < a.C) {
+        if (COMPLEX_OUT) outc[obase + (int64_t)i * a.C + j] = direct;
+        else outf[obase + (int64_t)i * a.C + j] = direct.x;
+    }
+    if (!dtile) {
+        mir[jj * 16 + ii] = measure_value(a.measure, a.n_obs, measure_mirror(v), false);
+        __syncthreads();
+        const int r = tj * 16 + ii, c = ti * 16 + jj;       // thread (ii, jj) now owns row ii of the mirrored block
+        if (r < a.C && c < a.C) {
+            if (COMPLEX_OUT) outc[obase + (int64_t)r * a.C + c] = mir[tid];
+            else outf[obase + (int64_t)r * a.C + c] = mir[tid].x;
+        }
     }
 }
 
@@ -163,10 +204,19 @@ extern "C" int sc_measure_f32(const float* d_accum, int64_t n_bins, int64_t n_si
         sc_set_error("measure %d needs accumulator planes 0x%x, record has 0x%x", measure, need, planes);
         return SC_EINVAL;
     }
-    a.total = measure == SC_M_POWER ? n_bins * n_signals : n_bins * n_signals * n_signals;
-    const int64_t blocks = (a.total + 255) / 256;
-    SC_REQUIRE(blocks < (int64_t)1 << 31, "output too large for one launch");
-    hipLaunchKernelGGL(measure_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    if (measure == SC_M_POWER) {
+        a.total = n_bins * n_signals;
+        const int64_t blocks = (a.total + 255) / 256;
+        SC_REQUIRE(blocks < (int64_t)1 << 31, "output too large for one launch");
+        hipLaunchKernelGGL(power_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    } else {
+        a.total = n_bins * n_signals * n_signals;
+        SC_REQUIRE(n_bins < (int64_t)1 << 31 && a.n_tiles <= 65535, "output too large for one launch");
+        const dim3 grid((unsigned)n_bins, (unsigned)a.n_tiles);
+        const bool cplx = measure == SC_M_CSM || measure == SC_M_COHERENCY || measure == SC_M_PLV_COMPLEX;
+        if (cplx) hipLaunchKernelGGL(measure_tile_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL(measure_tile_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    }
     SC_CHECK_HIP(hipGetLastError());
     return SC_OK;
 }
