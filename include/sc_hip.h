@@ -166,8 +166,9 @@ int sc_nonlinear_accumulate_f32(const void* d_X /*float2*/, const sc_spectra_des
                                 uint32_t planes, uint32_t which, float* d_accum, void* stream);
 
 /* Fused stage B for the headline pair coherence + wPLI: ONE pass over the spectra computes
- * the CSM planes on the matrix cores and the ABS_IM plane on the VALU concurrently (8-wave
- * workgroups, one MFMA wave + one VALU wave per SIMD, shared LDS staging).  Same results as
+ * the CSM planes AND the per-observation Im(x_i conj x_j) products of the ABS_IM plane on the bf16 matrix
+ * pipe (exact 3-way bf16 split of every f32 coefficient; 12-wave workgroups: one CSM wave and two |Im| waves
+ * per SIMD over one double-buffered LDS staging of the spectra, rows pulled HBM -> LDS directly).  Same results as
  * sc_csm_accumulate_f32 + sc_nonlinear_accumulate_f32(SC_PLANE_ABS_IM); n_signals <= 128. */
 int sc_fused_supported(int64_t n_signals);
 int sc_fused_csm_absim_f32(const void* d_X /*float2*/, const sc_spectra_desc* desc,

@@ -272,7 +272,8 @@ __global__ void __launch_bounds__(256, LOG2N == 8 ? 4 : 1) mtfft16_kernel(MtArgs
     extern __shared__ __align__(16) unsigned char smem[];
     // The window tile lives in LDS only until every thread has pulled its 16 x 2 samples into
     // registers (they are the same for all tapers); the exchange buffer z then reuses that space,
-    // so a workgroup needs ~44 KB instead of ~78 KB and three of them fit a CU.
+    // and the detrend scratch is later reused for the twiddle / taper tables: 39.6 KB per workgroup at N = 256,
+    // four workgroups (16 waves) per CU.
     constexpr size_t XT_BYTES = (size_t)N * XS * 4, Z_BYTES = (size_t)NF * ZS * 8;
     constexpr size_t UNION_BYTES = XT_BYTES > Z_BYTES ? XT_BYTES : Z_BYTES;
     float* xt = reinterpret_cast<float*>(smem);                                   // [N][XS]
