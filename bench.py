@@ -89,7 +89,8 @@ def one_step(x, h, cfg, geom, planes, world, timer=None):
         # trial shards: accumulate -> reduce-scatter -> epilogue -> gather on rank 0, pipelined over frequency
         # groups so that only the last group's exchange is exposed (parallel.sharded_measures)
         coh, wpli = parallel.sharded_measures(sp, planes, [_lib.M_COHERENCE_MAGNITUDE, _lib.M_WPLI],
-                                              n_groups=int(os.environ.get("SC_BENCH_GROUPS", "4")), mark=mark)
+                                              n_groups=int(os.environ.get("SC_BENCH_GROUPS", "4")), mark=mark,
+                                              equal_shards=True)   # R % world == 0 is asserted in main()
         return coh, wpli
     accum, n_obs = engine.accumulate(sp, "trials_tapers", planes, mark=mark)
     del sp

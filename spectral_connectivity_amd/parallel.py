@@ -108,7 +108,7 @@ def _side_stream(device):
     return _side_streams[key]
 
 
-def sharded_measures(spectra, planes, which, n_groups=4, dst=0, group=None, mark=None):
+def sharded_measures(spectra, planes, which, n_groups=4, dst=0, group=None, mark=None, equal_shards=False):
     """Stage B + exchange + epilogue for trial-sharded spectra, pipelined over frequency groups.
 
     Every rank holds the spectra of ITS trials.  The frequency axis is cut into ``n_groups`` ranges; for
@@ -117,6 +117,8 @@ def sharded_measures(spectra, planes, which, n_groups=4, dst=0, group=None, mark
     the owned bins -> gather on ``dst`` while the launch stream is already accumulating the next range:
     only the last range's exchange is exposed.  ``which``: list of ``_lib.M_*`` measures.  Returns, on
     ``dst``, one tensor per measure shaped [n_windows, n_freq, C, C] (None on the other ranks).
+    ``equal_shards``: every rank holds the same number of trials, so n_observations = local count x world
+    without a collective (otherwise one small all-reduce per call).
     """
     from . import engine
     world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
@@ -126,6 +128,8 @@ def sharded_measures(spectra, planes, which, n_groups=4, dst=0, group=None, mark
     main = torch.cuda.current_stream()
     side = _side_stream(spectra.X.device) if world > 1 else main
     parts = [[] for _ in which]
+    n_local = spectra.R * spectra.K
+    n_total = total_observations_equal(n_local, world) if equal_shards else total_observations(n_local, group)
     for g in range(n_groups):
         f0, f1 = shard_bounds(F, n_groups, g)
         accum, n_obs = engine.accumulate(spectra.freq_slice(f0, f1), "trials_tapers", planes, mark=mark)
@@ -138,7 +142,6 @@ def sharded_measures(spectra, planes, which, n_groups=4, dst=0, group=None, mark
             if world > 1:
                 side.wait_event(ready)
             shard, lo, hi = reduce_scatter_bins(accum, group)
-            n_total = total_observations_equal(n_obs, world)
             for m, w in enumerate(which):
                 out = engine.measure(shard, C, planes, n_total, w)
                 if world > 1:

@@ -22,7 +22,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
-    T, R, C, L, step, NW = 512, 24, 64, 128, 64, 3
+    T, R, C, L, step, NW = 512, 25, 64, 128, 64, 3      # 25 trials over 2 ranks: unequal shards
     W = int(np.floor(T / step - L / step + 1))
     tap, _ = dpss_windows(L, NW, 5, is_low_bias=False)
     h = torch.from_numpy(np.ascontiguousarray(np.asarray(tap) * np.sqrt(200.0) / 200.0, dtype=np.float32)).to(dev)
