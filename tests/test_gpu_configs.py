@@ -215,3 +215,21 @@ def test_trial_sharded_pipeline_two_ranks_one_gpu():
                           os.path.join(root, "tools", "check_sharded.py")],
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "sharded_measures OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+def test_hot_kernels_are_bit_reproducible():
+    """Stage A and stage B (split bins, L2-atomic folds, direct HBM->LDS row loads, one LDS-only barrier per chunk)
+    repeat bit-exactly: every sum has one writer and a fixed order, and a race would show up here."""
+    import torch
+    from spectral_connectivity_amd import _lib, engine
+    torch.manual_seed(0)
+    x = torch.randn(1024, 200, 128, device="cuda")
+    tap = torch.randn(7, 256, device="cuda")
+    sp = engine.multitaper_spectra(x, tap, 256, 128, 256, 7, "constant")
+    x0 = sp.X.clone()
+    planes = _lib.PLANE_CSM | _lib.PLANE_ABS_IM
+    a0 = engine.accumulate(sp, "trials_tapers", planes)[0].clone()
+    for _ in range(40):
+        sp2 = engine.multitaper_spectra(x, tap, 256, 128, 256, 7, "constant")
+        assert torch.equal(sp2.X, x0)
+        assert torch.equal(engine.accumulate(sp2, "trials_tapers", planes)[0], a0)
