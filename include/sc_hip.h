@@ -165,7 +165,8 @@ int sc_csm_accumulate_f32(const void* d_X /*float2*/, const sc_spectra_desc* des
 int sc_nonlinear_accumulate_f32(const void* d_X /*float2*/, const sc_spectra_desc* desc,
                                 uint32_t planes, uint32_t which, float* d_accum, void* stream);
 
-/* Fused stage B for the headline pair coherence + wPLI: ONE pass over the spectra computes
+/* Fused stage B for the headline pair coherence + wPLI (planes = CSM | ABS_IM; CSM alone is accepted too and
+ * then only the matrix-core update runs): ONE pass over the spectra computes
  * the CSM planes AND the per-observation Im(x_i conj x_j) products of the ABS_IM plane on the bf16 matrix
  * pipe (exact 3-way bf16 split of every f32 coefficient; 12-wave workgroups: one CSM wave and two |Im| waves
  * per SIMD over one double-buffered LDS staging of the spectra, rows pulled HBM -> LDS directly).  Same results as

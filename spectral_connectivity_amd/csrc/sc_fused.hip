@@ -259,7 +259,8 @@ __device__ __forceinline__ void fused_mfma_role(const FusedArgs& p, const ScStag
     // Staging is shared: the four CSM waves (VALU idle under their MFMA stream) stage observation
     // quads 0-3 AFTER their products, abs waves 0-3 stage quads 4-7 BEFORE theirs.
     const bool loads = !(p.debug_skip & 8);
-    fu_stage_first<NB32>(st, raw, planes, wave, o_lo, n_chunks, loads);
+    const bool csm_stages = p.abs_plane >= 0;       // CSM only: the eight other waves have nothing else to do
+    if (csm_stages) fu_stage_first<NB32>(st, raw, planes, wave, o_lo, n_chunks, loads);
     FU_BARRIER();                 // chunk 0 staged
     FU_T0();
     for (int ch = 0; ch < n_chunks; ++ch) {
@@ -317,7 +318,7 @@ __device__ __forceinline__ void fused_mfma_role(const FusedArgs& p, const ScStag
         }
         FU_TICK(1);
         // stage chunk ch + 1 into the other buffer, then put the loads of chunk ch + 2 in flight
-        fu_stage_next<NB32>(st, raw, planes, wave, o_lo, ch, n_chunks, loads);
+        if (csm_stages) fu_stage_next<NB32>(st, raw, planes, wave, o_lo, ch, n_chunks, loads);
         FU_TICK(0);
         // Two-level summation: every FU_FLUSH chunks (512 observations) the f32 accumulators of a tile
         // are folded into the output record (owned by this wave, L2-resident) and cleared, so no f32
@@ -460,11 +461,14 @@ __device__ __forceinline__ void fused_valu_body(const FusedArgs& p, const ScStag
     constexpr int plane_elems = FU_PLANE, buf_elems = NB32 * 32 * FU_CSTRIDE;
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const bool loads = !(p.debug_skip & 8);
-    if (vw < 4) fu_stage_first<NB32>(st, raw, planes, 4 + vw, o_lo, n_chunks, loads);
+    // with the |Im| plane: abs waves 0-3 stage quads 4-7 (the CSM waves take 0-3); CSM only: all eight stage
+    const bool all_stage = p.abs_plane < 0;
+    const int my_quad = all_stage ? vw : 4 + vw;
+    if (vw < 4 || all_stage) fu_stage_first<NB32>(st, raw, planes, my_quad, o_lo, n_chunks, loads);
     FU_BARRIER();                 // chunk 0 staged
     FU_T0();
     for (int ch = 0; ch < n_chunks; ++ch) {
-        if (vw < 4) fu_stage_next<NB32>(st, raw, planes, 4 + vw, o_lo, ch, n_chunks, loads);
+        if (vw < 4 || all_stage) fu_stage_next<NB32>(st, raw, planes, my_quad, o_lo, ch, n_chunks, loads);
         FU_TICK(0);
         const unsigned short* pb = planes + (ch & 1) * buf_elems;
         // per-lane plane triples: A reads Im (lanes 0-31) / Re (32-63), B reads Re (lanes 0-31) / Im (32-63)
@@ -473,7 +477,7 @@ __device__ __forceinline__ void fused_valu_body(const FusedArgs& p, const ScStag
         const int offA = (chf ? 0 : 3 * plane_elems) + ci32 * FU_CSTRIDE;
         const int offB = (chf ? 3 * plane_elems : 0) + ci32 * FU_CSTRIDE;
         // zero rows past n_obs contribute |0| = 0: no bound needed for this plane
-        for (int oq2 = ((p.debug_skip & 2) ? 16 : 2 * rsub); oq2 < 16; oq2 += ((oq2 & 1) ? 2 * wps - 1 : 1)) {
+        for (int oq2 = (((p.debug_skip & 2) || p.abs_plane < 0) ? 16 : 2 * rsub); oq2 < 16; oq2 += ((oq2 & 1) ? 2 * wps - 1 : 1)) {
             // two observation rows (one dword per plane) of this lane's channels in every needed block
             unsigned NA[NB32][3], NBq[NB32][3];
 #pragma unroll
@@ -549,7 +553,7 @@ __device__ __forceinline__ void fused_valu_body(const FusedArgs& p, const ScStag
         }
         __syncthreads();
     }
-    if (rsub == 0) {
+    if (rsub == 0 && p.abs_plane >= 0) {
         const int i32 = lane & 31, hf = lane >> 5;
         // D layout of v_mfma_f32_32x32x16_bf16: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
         float* out = rec + (int64_t)p.abs_plane * p.n_tiles * SC_TILE_ELEMS;
@@ -610,10 +614,10 @@ __global__ void __launch_bounds__(FU_THREADS) fused_csm_absim_kernel(FusedArgs p
     else fused_valu_role<NB32>(p, st, planes, raw, tid, wave - 4, rec, o_lo);
 }
 
-// accum[bin][plane] += ws[0][bin][plane] + ws[1][bin][plane] + ... for the CSM (re, im) and |Im| planes
+// accum[bin][plane] += ws[0][bin][plane] + ws[1][bin][plane] + ... for the CSM (re, im) and (if present) |Im| planes
 __global__ void __launch_bounds__(256) fused_combine_kernel(FusedArgs p) {
     const int64_t plane = (int64_t)p.n_tiles * SC_TILE_ELEMS;      // floats per plane (multiple of 256)
-    const int64_t per_bin = 3 * plane / 4;                          // float4 items per bin
+    const int64_t per_bin = (p.abs_plane >= 0 ? 3 : 2) * plane / 4;   // float4 items per bin
     const int64_t total = per_bin * p.n_bins;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t bin = i / per_bin, e = (i - bin * per_bin) * 4;
@@ -686,8 +690,7 @@ static int fused_pick_split(int n_bins, int n_obs) {
 
 static int fused_setup(const void* d_X, const sc_spectra_desc* desc, uint32_t planes, FusedArgs* a, ScAxes* ax) {
     SC_REQUIRE(desc, "NULL argument");
-    SC_REQUIRE((planes & (SC_PLANE_CSM | SC_PLANE_ABS_IM)) == (SC_PLANE_CSM | SC_PLANE_ABS_IM),
-               "planes must contain SC_PLANE_CSM and SC_PLANE_ABS_IM");
+    SC_REQUIRE(planes & SC_PLANE_CSM, "planes must contain SC_PLANE_CSM (SC_PLANE_ABS_IM is optional)");
     sc_make_axes(desc, ax);
     SC_REQUIRE(ax->C >= 1 && ax->F >= 1 && ax->n_obs >= 1 && ax->n_groups >= 1, "empty dimension");
     if (!fused_ok(d_X, *ax)) {
@@ -703,7 +706,7 @@ static int fused_setup(const void* d_X, const sc_spectra_desc* desc, uint32_t pl
     a->F = ax->F;
     a->floats_per_bin = (int64_t)sc_plane_count(planes) * a->n_tiles * SC_TILE_ELEMS;
     a->csm_plane = sc_plane_offset(planes, SC_PLANE_CSM);
-    a->abs_plane = sc_plane_offset(planes, SC_PLANE_ABS_IM);
+    a->abs_plane = (planes & SC_PLANE_ABS_IM) ? sc_plane_offset(planes, SC_PLANE_ABS_IM) : -1;   // -1: CSM only
     a->n_split = 1;
     a->ws = nullptr;
     return SC_OK;

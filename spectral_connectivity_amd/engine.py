@@ -179,8 +179,8 @@ def accumulate(spectra, expectation_type, planes, n_freq=None, mark=None, use_fu
     both = _lib.PLANE_CSM | _lib.PLANE_ABS_IM
     if use_fused is None:
         use_fused = bool(lib.sc_fused_supported(spectra.C))
-    if use_fused and (planes & both) == both:
-        # one pass: CSM on the matrix cores + |Im s| on the VALU (sc_fused.hip)
+    if use_fused and (planes & _lib.PLANE_CSM):
+        # one pass: CSM (and, when requested, the per-observation |Im s| products) on the bf16 matrix pipe (sc_fused.hip)
         ws_bytes = int(lib.sc_fused_workspace_bytes(byref(d), planes))
         ws = _workspace(ws_bytes, spectra.X.device)
         _lib.check(lib.sc_fused_csm_absim_ws_f32(_ptr(spectra.X), byref(d), planes, _ptr(accum),

@@ -209,6 +209,12 @@ def test_fused_stage_b_equals_separate_kernels(sc, C, R):
         got = engine.measure(a_f, C, planes, n, which).cpu().numpy()
         ref = engine.measure(a_s, C, planes, n, which).cpu().numpy()
         close32(got, ref, rtol=2e-6, atol_scale=2e-6, what=f"fused vs separate, measure {which}")
+    # CSM alone through the fused kernel (matrix-core role only)
+    c_f, _ = engine.accumulate(sp, "trials_tapers", _lib.PLANE_CSM, use_fused=True)
+    c_s, _ = engine.accumulate(sp, "trials_tapers", _lib.PLANE_CSM, use_fused=False)
+    close32(engine.measure(c_f, C, _lib.PLANE_CSM, n, _lib.M_CSM).cpu().numpy(),
+            engine.measure(c_s, C, _lib.PLANE_CSM, n, _lib.M_CSM).cpu().numpy(), rtol=2e-6, atol_scale=2e-6,
+            what="fused CSM only vs f32 MFMA kernel")
     coef, _ = so.multitaper_fft(x, fs=300.0, NW=3, n_time_samples_per_window=128, n_time_samples_per_step=64)
     if C <= 64:
         close32(sc.Connectivity.from_multitaper(m).weighted_phase_lag_index(),
