@@ -227,6 +227,14 @@ def main():
                 "note": ("f32-equivalent flops of the Hermitian rank-n_obs update (8*n_obs*C(C+1)/2 per bin, "
                          "triangle only) over the f32 MFMA peak; the kernel runs them as six bf16 cross terms "
                          "and also produces the per-observation |Im s| plane in the same launch"),
+                # the whole step against both rooflines of SURVEY section 8(d) (the binding one is the larger time):
+                # algorithmic bytes of the two-pass design over the HBM peak, triangle-only CSM flops over the f32 MFMA peak
+                "whole_path": (lambda t_hbm, t_mfma: {
+                    "t_hbm_ms": round(t_hbm, 4), "t_mfma_ms": round(t_mfma, 4),
+                    "hbm_frac": round(t_hbm / ms_per_step, 4), "mfma_frac": round(t_mfma / ms_per_step, 4)})(
+                    (4.0 * T * R_loc * C + 2 * 8.0 * F * W * R_loc * K * C + (8.0 + 2 * 4.0) * W * F * C * C / world)
+                    / (HBM_PEAK_GBS * 1e9) * 1e3,
+                    8.0 * n_obs_loc * (C * (C + 1) / 2) * W * F / (MFMA_F32_PEAK_TFLOPS * 1e12) * 1e3),
                 "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
                 "stages": {k: stage_roof(k) for k in stage_ms if k in stage_model}}
 
