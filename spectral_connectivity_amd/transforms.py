@@ -117,6 +117,47 @@ def prepare_time_series(time_series, axis=None):
 
 
 # ------------------------------------------------------------------------------ DPSS (host)
+def detrend(data, axis=-1, type="linear", bp=0, overwrite_data=False):
+    """Remove a constant or a (piecewise) linear trend along ``axis`` -- the host-side helper the reference exposes
+    (reference transforms.py:1798-1915, itself scipy.signal.detrend).  The device path detrends inside the fused
+    FFT kernel; this function is for callers that use it directly.
+
+    ``type``: 'constant' / 'c' subtracts the mean; 'linear' / 'l' subtracts the least-squares line of every segment
+    between the breakpoints ``bp`` (fitted on the abscissa (1..n)/n like the reference).
+    """
+    if type not in ("linear", "l", "constant", "c"):
+        raise ValueError(
+            f"Invalid trend type '{type}' is not supported.\n"
+            f"The detrend function only supports linear and constant detrending.\n"
+            f"Valid options are:\n"
+            f"  - 'linear' or 'l': Remove linear trend (best-fit line)\n"
+            f"  - 'constant' or 'c': Remove mean (DC offset)\n"
+            f"Example: detrend(data, type='linear')")
+    data = np.asarray(data)
+    if data.dtype.char not in "dfDF":
+        data = data.astype(np.float64)
+    if type in ("constant", "c"):
+        return data - np.mean(data, axis, keepdims=True)
+    n = data.shape[axis]
+    edges = np.unique(np.r_[0, bp, n])
+    if np.any(edges > n):
+        shown = [bp] if isinstance(bp, (int, np.integer)) else list(np.asarray(bp).tolist())
+        raise ValueError(
+            f"Breakpoint value(s) {edges[edges > n].tolist()} exceed data length.\n"
+            f"Data has {n} samples along axis {axis}, but breakpoint(s) are beyond this range.\n"
+            f"Breakpoints must be in the range [0, {n}).\n"
+            f"Check your breakpoint array: {shown}")
+    out = np.moveaxis(data if overwrite_data else data.copy(), axis, 0)
+    for lo, hi in zip(edges[:-1], edges[1:]):
+        seg = out[lo:hi]
+        m = hi - lo
+        t = (np.arange(1, m + 1) / m).reshape((m,) + (1,) * (seg.ndim - 1))
+        tc = t - t.mean()
+        slope = (tc * seg).sum(axis=0) / (tc * tc).sum() if m > 1 else np.zeros(seg.shape[1:], dtype=seg.dtype)
+        seg -= seg.mean(axis=0) + slope * tc
+    return np.moveaxis(out, 0, axis)
+
+
 def dpss_windows(n_time_samples_per_window, time_halfbandwidth_product, n_tapers, is_low_bias=True):
     """Discrete prolate spheroidal sequences and their concentration eigenvalues.
 

@@ -222,3 +222,16 @@ def test_wrapper_validates_before_touching_the_device():
     except ImportError:
         with pytest.raises(ImportError, match="xarray"):
             multitaper_connectivity(x, sampling_frequency=100, method="coherence_magnitude")
+
+
+def test_host_detrend_helper_matches_scipy_and_reference_messages():
+    """transforms.detrend (reference transforms.py:1798-1915, a restatement of scipy.signal.detrend)."""
+    import scipy.signal
+    from spectral_connectivity_amd.transforms import detrend
+    x = np.random.default_rng(0).standard_normal((50, 3, 7)) + np.linspace(0, 5, 50)[:, None, None]
+    for kw in (dict(axis=0), dict(axis=0, bp=[20, 35]), dict(axis=0, type="constant"), dict(axis=-1), dict(axis=1, type="l")):
+        np.testing.assert_allclose(detrend(x, **kw), scipy.signal.detrend(x, **kw), atol=1e-12)
+    with pytest.raises(ValueError, match="Invalid trend type 'cubic' is not supported"):
+        detrend(x, type="cubic")
+    with pytest.raises(ValueError, match="exceed data length"):
+        detrend(np.zeros(100), type="linear", bp=[150])
