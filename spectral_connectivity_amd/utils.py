@@ -3,8 +3,8 @@
 
 def get_compute_backend():
     """Describe the compute backend: always the HIP engine (no CPU fallback exists)."""
-    info = {"backend": "hip", "library": None, "gpu_available": False, "device_name": None,
-            "n_devices": 0, "message": ""}
+    info = {"backend": "hip", "gpu_enabled": True, "library": None, "gpu_available": False, "device_name": None,
+            "n_devices": 0, "message": ""}            # keys of the reference's report + library / n_devices
     try:
         import torch
 

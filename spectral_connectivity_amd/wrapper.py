@@ -42,7 +42,7 @@ def _check_method(method):
         raise ValueError(
             f"The method '{method}' is not supported by the xarray interface. "
             f"Please use the Connectivity class directly instead:\n\n"
-            f"from spectral_connectivity_amd import Connectivity\n"
+            f"from spectral_connectivity_amd import Connectivity  # in place of: from spectral_connectivity import Connectivity\n"
             f"conn = Connectivity.from_multitaper(m)\n"
             f"result = conn.{method}()\n")
 
