@@ -19,6 +19,10 @@ import numpy as np
 from . import _lib
 from .engine import EXPECTATION_AXES
 
+# scale of the Tikhonov terms in the MVAR quantities (reference connectivity.py: same name and value; applied on the
+# device in sc_mvar.hip / sc_wilson.hip)
+TIKHONOV_REGULARIZATION_FACTOR = 1e-12
+
 logger = getLogger(__name__)
 
 # kept for API parity with reference connectivity.py:67-75 (keys are what matters)

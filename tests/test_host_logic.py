@@ -235,3 +235,18 @@ def test_host_detrend_helper_matches_scipy_and_reference_messages():
         detrend(x, type="cubic")
     with pytest.raises(ValueError, match="exceed data length"):
         detrend(np.zeros(100), type="linear", bp=[150])
+
+
+def test_simulate_mvar_reproduces_a_known_var_process():
+    """simulate.simulate_MVAR: shape contract, determinism in the seed, and the lag-1 cross-covariance of a stable
+    VAR(1) (Gamma_1 = A Gamma_0) on a long realisation."""
+    from spectral_connectivity_amd.simulate import simulate_MVAR
+    A = np.array([[[0.5, 0.2], [-0.1, 0.4]]])
+    x = simulate_MVAR(A, n_time_samples=20000, n_trials=2, n_burnin_samples=200, random_state=1)
+    assert x.shape == (20000, 2, 2)
+    np.testing.assert_array_equal(x, simulate_MVAR(A, n_time_samples=20000, n_trials=2, n_burnin_samples=200,
+                                                   random_state=np.random.default_rng(1)))
+    z = x[:, 0]
+    g0 = z[:-1].T @ z[:-1] / (len(z) - 1)
+    g1 = z[1:].T @ z[:-1] / (len(z) - 1)
+    np.testing.assert_allclose(g1, A[0] @ g0, atol=0.05)
