@@ -158,7 +158,8 @@ def detrend(data, axis=-1, type="linear", bp=0, overwrite_data=False):
     return np.moveaxis(out, 0, axis)
 
 
-def dpss_windows(n_time_samples_per_window, time_halfbandwidth_product, n_tapers, is_low_bias=True):
+def dpss_windows(n_time_samples_per_window, time_halfbandwidth_product, n_tapers, is_low_bias=True,
+                 interp_from=None, interp_kind="linear"):
     """Discrete prolate spheroidal sequences and their concentration eigenvalues.
 
     Same definition and conventions as reference transforms.py:1539-1613: eigenvectors of
@@ -167,20 +168,28 @@ def dpss_windows(n_time_samples_per_window, time_halfbandwidth_product, n_tapers
     positive lobe (:1717-1745); concentration by the autocorrelation method (:1768-1795);
     ``is_low_bias`` keeps eigenvalue > 0.9, or the best one if none (:1758-1765).
     The eigenvectors come from LAPACK (stemr) instead of the reference's Python inverse
-    iteration.  Returns (tapers (K', L), eigenvalues (K',)).
+    iteration.  ``interp_from``: compute the tapers at that (shorter) length and interpolate them to
+    ``n_time_samples_per_window`` samples (scipy ``interp1d`` of kind ``interp_kind``), renormalised
+    (:1615-1651).  Returns (tapers (K', L), eigenvalues (K',)).
     """
     L = int(n_time_samples_per_window)
     K = int(n_tapers)
     half_bw = float(time_halfbandwidth_product) / L
     t = np.arange(L, dtype=np.float64)
-    diag = ((L - 1 - 2 * t) / 2.0) ** 2 * np.cos(2 * np.pi * half_bw)
-    off = t[1:] * (L - t[1:]) / 2.0
-    if L == 1:
-        vecs = np.ones((1, 1))
+    if interp_from is not None:
+        from scipy import interpolate
+        small, _ = dpss_windows(int(interp_from), time_halfbandwidth_product, K, is_low_bias=False)
+        grid = np.linspace(0, small.shape[-1] - 1, L, endpoint=False)
+        tapers = np.stack([interpolate.interp1d(np.arange(small.shape[-1]), row, kind=interp_kind)(grid) for row in small])
     else:
-        lo = max(L - K, 0)
-        _, vecs = eigh_tridiagonal(diag, off, select="i", select_range=(lo, L - 1))
-    tapers = np.ascontiguousarray(vecs[:, ::-1].T)            # largest eigenvalue first
+        diag = ((L - 1 - 2 * t) / 2.0) ** 2 * np.cos(2 * np.pi * half_bw)
+        off = t[1:] * (L - t[1:]) / 2.0
+        if L == 1:
+            vecs = np.ones((1, 1))
+        else:
+            lo = max(L - K, 0)
+            _, vecs = eigh_tridiagonal(diag, off, select="i", select_range=(lo, L - 1))
+        tapers = np.ascontiguousarray(vecs[:, ::-1].T)            # largest eigenvalue first
     tapers /= np.linalg.norm(tapers, axis=1, keepdims=True)
     # sign conventions
     neg = tapers[::2].sum(axis=1) < 0

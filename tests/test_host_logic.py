@@ -250,3 +250,14 @@ def test_simulate_mvar_reproduces_a_known_var_process():
     g0 = z[:-1].T @ z[:-1] / (len(z) - 1)
     g1 = z[1:].T @ z[:-1] / (len(z) - 1)
     np.testing.assert_allclose(g1, A[0] @ g0, atol=0.05)
+
+
+def test_dpss_interpolated_from_a_shorter_window():
+    """dpss_windows(interp_from=...): tapers of the short length, interpolated and renormalised (transforms.py:1615-1651);
+    they stay close to the directly computed ones, keep unit norm and the sign conventions."""
+    direct, eig = dpss_windows(256, 3, 5, is_low_bias=False)
+    interp, eig_i = dpss_windows(256, 3, 5, is_low_bias=False, interp_from=64, interp_kind="cubic")
+    assert interp.shape == direct.shape
+    np.testing.assert_allclose(np.linalg.norm(interp, axis=1), 1.0, atol=1e-12)
+    assert np.abs(interp - direct).max() < 5e-3 and np.abs(eig - eig_i).max() < 5e-3
+    assert (interp[::2].sum(axis=1) > 0).all()
