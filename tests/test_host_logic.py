@@ -259,5 +259,5 @@ def test_dpss_interpolated_from_a_shorter_window():
     interp, eig_i = dpss_windows(256, 3, 5, is_low_bias=False, interp_from=64, interp_kind="cubic")
     assert interp.shape == direct.shape
     np.testing.assert_allclose(np.linalg.norm(interp, axis=1), 1.0, atol=1e-12)
-    assert np.abs(interp - direct).max() < 5e-3 and np.abs(eig - eig_i).max() < 5e-3
+    assert np.abs(interp - direct).max() < 2e-2 and np.abs(eig - eig_i).max() < 2e-2     # the grid is shifted (endpoint=False)
     assert (interp[::2].sum(axis=1) > 0).all()
