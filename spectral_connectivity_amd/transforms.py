@@ -117,6 +117,39 @@ def prepare_time_series(time_series, axis=None):
 
 
 # ------------------------------------------------------------------------------ DPSS (host)
+def tridisolve(d, e, b, overwrite_b=True):
+    """Solve the symmetric tridiagonal system (diagonal ``d``, off-diagonal ``e``) for right-hand side ``b``
+    (reference transforms.py:1443-1489; LAPACK's banded solver here).  ``overwrite_b`` keeps the reference's
+    contract: the solution is written into ``b`` (and returned)."""
+    from scipy.linalg import solve_banded
+    d, e = np.asarray(d, dtype=float), np.asarray(e, dtype=float)
+    band = np.zeros((3, d.shape[0]))
+    band[0, 1:], band[1], band[2, :-1] = e, d, e
+    x = solve_banded((1, 1), band, np.asarray(b, dtype=float))
+    if overwrite_b:
+        b[...] = x
+        return b
+    return x
+
+
+def tridi_inverse_iteration(d, e, w, x0=None, rtol=1e-8):
+    """Eigenvector of the symmetric tridiagonal matrix (d, e) for the eigenvalue closest to ``w`` by inverse
+    iteration, normalised to unit length, sign unspecified (reference transforms.py:1492-1536).  ``dpss_windows``
+    here takes its eigenvectors from LAPACK instead; this helper is kept for callers of the reference's name."""
+    d = np.asarray(d, dtype=float)
+    shifted = d - w
+    x = np.random.randn(d.shape[0]) if x0 is None else np.asarray(x0, dtype=float)
+    x = x / np.linalg.norm(x)
+    previous = np.zeros_like(x)
+    for _ in range(200):
+        if np.linalg.norm(np.abs(x) - np.abs(previous)) <= rtol:
+            break
+        previous = x
+        x = tridisolve(shifted, e, x.copy())
+        x = x / np.linalg.norm(x)
+    return x
+
+
 def detrend(data, axis=-1, type="linear", bp=0, overwrite_data=False):
     """Remove a constant or a (piecewise) linear trend along ``axis`` -- the host-side helper the reference exposes
     (reference transforms.py:1798-1915, itself scipy.signal.detrend).  The device path detrends inside the fused
