@@ -141,13 +141,55 @@ def gen_f11_post(T, Cn, mpd, sim):
     save("f11_post", **arrs)
 
 
+def gen_api_surface(*_):
+    """Public names of the reference (functions, classes, methods, properties) with their argument names and default
+    values, as data: tests/golden/api_surface.json.  The drop-in mirrors exactly this surface."""
+    import ast
+    import json
+    root = "/root/reference/spectral_connectivity"
+
+    def describe(fn):
+        a = fn.args
+        pos = a.posonlyargs + a.args
+        dflt = [None] * (len(pos) - len(a.defaults)) + [ast.unparse(x) for x in a.defaults]
+        args = [[p.arg, d] for p, d in zip(pos, dflt)]
+        args += [[k.arg, ast.unparse(v) if v is not None else None] for k, v in zip(a.kwonlyargs, a.kw_defaults)]
+        return {"args": args, "vararg": bool(a.vararg), "kwarg": bool(a.kwarg)}
+
+    surface = {}
+    for f in sorted(os.listdir(root)):
+        if not f.endswith(".py") or f == "__init__.py":
+            continue
+        tree = ast.parse(open(os.path.join(root, f)).read())
+        mod = {}
+        for n in tree.body:
+            if isinstance(n, ast.FunctionDef) and not n.name.startswith("_"):
+                mod[n.name] = describe(n)
+            elif isinstance(n, ast.ClassDef) and not n.name.startswith("_"):
+                for m in n.body:
+                    if isinstance(m, ast.FunctionDef) and (not m.name.startswith("_") or m.name == "__init__"):
+                        mod[n.name + "." + m.name] = describe(m)
+            elif isinstance(n, ast.Assign):
+                for tg in n.targets:
+                    if isinstance(tg, ast.Name) and tg.id.isupper():
+                        mod[tg.id] = {"constant": ast.unparse(n.value)}
+        surface[f[:-3]] = mod
+    init = ast.parse(open(os.path.join(root, "__init__.py")).read())
+    for n in init.body:
+        if isinstance(n, ast.Assign) and any(isinstance(t, ast.Name) and t.id == "__all__" for t in n.targets):
+            surface["__all__"] = sorted(ast.literal_eval(n.value))
+    with open(os.path.join(OUT, "api_surface.json"), "w") as fh:
+        json.dump(surface, fh, indent=1, sort_keys=True)
+    print("api_surface:", sum(len(v) for k, v in surface.items() if k != "__all__"), "names")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     warnings.simplefilter("ignore")
     T, Cn, mpd, sim = import_reference()
     if len(sys.argv) > 1:                      # python oracle/gen_golden.py f9 : only the named fixtures
         for name in sys.argv[1:]:
-            {"f9": gen_f9_mvar, "f10": gen_f10_global, "f11": gen_f11_post}[name](T, Cn, mpd, sim)
+            {"f9": gen_f9_mvar, "f10": gen_f10_global, "f11": gen_f11_post, "api": gen_api_surface}[name](T, Cn, mpd, sim)
         return
     Multitaper, Connectivity = T.Multitaper, Cn.Connectivity
 
@@ -293,6 +335,7 @@ def main():
     gen_f9_mvar(T, Cn, mpd, sim)
     gen_f10_global(T, Cn, mpd, sim)
     gen_f11_post(T, Cn, mpd, sim)
+    gen_api_surface()
 
 
 if __name__ == "__main__":

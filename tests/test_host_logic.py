@@ -278,3 +278,56 @@ def test_tridiagonal_helpers():
     w, V = np.linalg.eigh(A)
     v = tridi_inverse_iteration(d, e, w[-1] + 1e-9, x0=np.ones(9))
     assert abs(abs(v @ V[:, -1]) - 1.0) < 1e-8 and abs(np.linalg.norm(v) - 1.0) < 1e-12
+
+
+def test_public_api_surface_matches_the_reference():
+    """Every public function, class, method / property and module constant of the reference exists here with the same
+    argument names, order and default values (tests/golden/api_surface.json, generated from the reference by
+    oracle/gen_golden.py api).  Only private helpers differ."""
+    import ast
+    import json
+    import os
+    import spectral_connectivity_amd as pkg
+    root = os.path.dirname(pkg.__file__)
+    ref = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "api_surface.json")))
+    assert set(ref["__all__"]) <= set(pkg.__all__)
+
+    def describe(fn):
+        a = fn.args
+        pos = a.posonlyargs + a.args
+        dflt = [None] * (len(pos) - len(a.defaults)) + [ast.unparse(x) for x in a.defaults]
+        args = [[p.arg, d] for p, d in zip(pos, dflt)]
+        args += [[k.arg, ast.unparse(v) if v is not None else None] for k, v in zip(a.kwonlyargs, a.kw_defaults)]
+        return args
+
+    problems = []
+    for module, names in ref.items():
+        if module == "__all__":
+            continue
+        path = os.path.join(root, module + ".py")
+        assert os.path.exists(path), f"module {module} missing"
+        tree = ast.parse(open(path).read())
+        have = {}
+        for n in tree.body:
+            if isinstance(n, ast.FunctionDef):
+                have[n.name] = describe(n)
+            elif isinstance(n, ast.ClassDef):
+                for m in n.body:
+                    if isinstance(m, ast.FunctionDef):
+                        have[n.name + "." + m.name] = describe(m)
+            elif isinstance(n, ast.Assign):
+                for tg in n.targets:
+                    if isinstance(tg, ast.Name):
+                        have[tg.id] = ast.unparse(n.value)
+        for name, spec in names.items():
+            if name not in have:
+                problems.append(f"{module}.{name} missing")
+            elif "constant" in spec:
+                if name == "TIKHONOV_REGULARIZATION_FACTOR":
+                    assert float(have[name]) == float(spec["constant"])
+            else:
+                mine = [[a, (d or "").replace("np.", "xp.") or None] for a, d in have[name]]
+                want = [[a, (d or "").replace("np.", "xp.") or None] for a, d in spec["args"]]
+                if mine != want:
+                    problems.append(f"{module}.{name}: {mine} != {want}")
+    assert not problems, "\\n".join(problems)
