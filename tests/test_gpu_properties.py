@@ -106,3 +106,38 @@ def test_zero_and_tiny_power_channels_do_not_produce_infinities():
         assert not np.isinf(v).any()
         fin = v[np.isfinite(v)]
         assert (np.abs(fin) <= 1 + 1e-6).all()
+
+
+def test_spectrogram_peak_follows_the_signal():
+    """A tone that jumps from 40 Hz to 90 Hz half way: every window's power peak sits at the tone of its time span, and
+    the window times are the window starts (the qualitative checks of reference tests/test_connectivity.py:735-797)."""
+    import spectral_connectivity_amd as sc
+    fs, T = 500.0, 2000
+    t = np.arange(T) / fs
+    f_inst = np.where(t < 2.0, 40.0, 90.0)
+    x = np.sin(2 * np.pi * np.cumsum(f_inst) / fs)[:, None, None] + 0.1 * np.random.default_rng(0).standard_normal((T, 3, 1))
+    m = sc.Multitaper(x, sampling_frequency=fs, time_halfbandwidth_product=2, time_window_duration=0.5,
+                      time_window_step=0.5)
+    c = sc.Connectivity.from_multitaper(m)
+    p = c.power()[..., 0]
+    peak = c.frequencies[np.argmax(p, axis=1)]
+    np.testing.assert_allclose(m.time, np.arange(8) * 0.5)
+    np.testing.assert_allclose(peak[:4], 40.0, atol=2.0)
+    np.testing.assert_allclose(peak[4:], 90.0, atol=2.0)
+
+
+@pytest.mark.parametrize("L", [64, 65, 100, 101])
+def test_nyquist_and_odd_lengths(L):
+    """Even and odd window lengths: n_fft // 2 + 1 non-negative frequencies, the even-length Nyquist bin reported
+    positive, finite measures in every bin (reference tests/test_connectivity.py:616-732)."""
+    import spectral_connectivity_amd as sc
+    x = np.random.default_rng(L).standard_normal((L, 6, 2))
+    m = sc.Multitaper(x, sampling_frequency=float(L), time_halfbandwidth_product=2)
+    c = sc.Connectivity.from_multitaper(m)
+    n_fft = m.n_fft_samples
+    assert c.frequencies.shape == (n_fft // 2 + 1,) and (c.frequencies >= 0).all()
+    if n_fft % 2 == 0:
+        assert c.frequencies[-1] == pytest.approx(L / 2)
+    coh = c.coherence_magnitude()
+    assert coh.shape == (1, n_fft // 2 + 1, 2, 2) and np.isfinite(coh[..., 0, 1]).all()
+    assert np.isfinite(c.power()).all() and (c.power() > 0).all()
