@@ -173,8 +173,10 @@ class Connectivity:
         have, (accum, n_obs) = self._accumulators(_lib.MEASURE_PLANES[which])
         C = self._shape5[4]
         out = engine.measure(accum, C, have, self._n_observations_total(n_obs), which)
-        host = out.cpu().numpy()
-        host = host.astype(np.complex128 if np.iscomplexobj(host) else np.float64)
+        import torch
+        # widened on the device (the reference returns float64 / complex128): a plain copy over PCIe is cheaper than a
+        # host-side astype of the whole array
+        host = out.to(torch.complex128 if out.is_complex() else torch.float64).cpu().numpy()
         tail = (C,) if which == _lib.M_POWER else (C, C)
         return host.reshape(self._kept_shape() + (self._n_freq,) + tail)
 
