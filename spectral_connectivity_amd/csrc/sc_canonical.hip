@@ -147,6 +147,247 @@ __global__ void __launch_bounds__(64) canonical_kernel(CanonArgs a) {
     o[gb * a.G + ga] = lmax;
 }
 
+// ---- one workgroup per bin (groups of at most 16 channels) ------------------------------------------
+// The thread-per-problem kernel above keeps three 16x16 complex matrices per lane in scratch memory and
+// factors every group's block once per PAIR.  Here a workgroup (4 waves) owns a bin: the Cholesky factor
+// of every group is computed (and inverted) once into LDS, then the waves take the group pairs in turn, each with its
+// own LDS scratch -- whitening by the inverse factors as two dense 16x16 products, B = M M^H (a lane per entry) and a
+// parallel cyclic Jacobi on B (a lane per 2x2 block of the round's pairing).  Everything inside a wave
+// is ordered by the wave's in-order LDS pipe: no workgroup barrier after the factors are ready.
+#define CB_C 16
+#define CB_WSYNC()                                                  \
+    do {                                                            \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      \
+        __builtin_amdgcn_wave_barrier();                            \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      \
+    } while (0)
+
+__device__ inline cd cb_get(const cd* B, int i, int j) {           // Hermitian, upper triangle stored
+    if (i <= j) return B[i * CB_C + j];
+    const cd v = B[j * CB_C + i];
+    return make_double2(v.x, -v.y);
+}
+__device__ inline void cb_set(cd* B, int i, int j, cd v) {
+    if (i <= j) B[i * CB_C + j] = v;
+    else B[j * CB_C + i] = make_double2(v.x, -v.y);
+}
+__device__ inline double cb_wave_sum(double v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+#define CB_WAVES 8
+#ifndef CB_SWEEPS
+#define CB_SWEEPS 12
+#endif
+__global__ void __launch_bounds__(64 * CB_WAVES) canonical_bin_kernel(CanonArgs a) {
+    extern __shared__ __align__(16) unsigned char cb_smem[];
+    const int G = a.G;
+    cd* Ls = reinterpret_cast<cd*>(cb_smem);                                   // [G][16][16] lower Cholesky factors
+    cd* scratch = Ls + (size_t)G * CB_C * CB_C;                                // per wave: M, B [16][16]
+    int* okg = reinterpret_cast<int*>(scratch + CB_WAVES * 2 * CB_C * CB_C);   // [G]
+    double* rot = reinterpret_cast<double*>(okg + ((G + 3) & ~3));             // per wave: [8] cos, [8][2] sin (16-byte aligned)
+    int* rpair = reinterpret_cast<int*>(rot + CB_WAVES * 24);                  // per wave: [8][2]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int64_t bin = blockIdx.x;
+    const float* rec = a.accum + bin * a.floats_per_bin;
+
+    // phase 1: L_g for every group (a wave per group, left-looking Cholesky, a lane per row)
+    for (int g = wave; g < G; g += CB_WAVES) {
+        const int n = a.sizes[g];
+        const int32_t* mg = a.members + g * CB_C;
+        cd* L = Ls + (size_t)g * CB_C * CB_C;
+        for (int e = lane; e < CB_C * CB_C; e += 64) {
+            const int i = e / CB_C, j = e % CB_C;
+            L[e] = (i < n && j < n) ? csm_read(rec, a, mg[i], mg[j]) : make_double2(0.0, 0.0);
+        }
+        CB_WSYNC();
+        int ok = 1;
+        for (int j = 0; j < n; ++j) {
+            double d = L[j * CB_C + j].x;                                   // every lane: the pivot of column j
+            for (int k = 0; k < j; ++k) { const cd v = L[j * CB_C + k]; d -= v.x * v.x + v.y * v.y; }
+            if (!(d > 0.0)) { ok = 0; d = 1.0; }
+            const double ljj = sqrt(d);
+            const int i = j + 1 + lane;
+            cd s = make_double2(0.0, 0.0);
+            if (i < n) {
+                s = L[i * CB_C + j];
+                for (int k = 0; k < j; ++k) { const cd t = zmulc(L[i * CB_C + k], L[j * CB_C + k]); s.x -= t.x; s.y -= t.y; }
+            }
+            CB_WSYNC();
+            if (lane == 0) L[j * CB_C + j] = make_double2(ljj, 0.0);
+            if (i < n) L[i * CB_C + j] = make_double2(s.x / ljj, s.y / ljj);
+            CB_WSYNC();
+        }
+        // L <- L^-1 (lower triangular): the whitening of a pair is then two dense 16x16 products with no dependent
+        // chains instead of two triangular solves per pair.  Column `lane` of the inverse, top to bottom, kept in
+        // registers until every lane is done with L.
+        cd inv[CB_C];
+#pragma unroll
+        for (int i = 0; i < CB_C; ++i) inv[i] = make_double2(0.0, 0.0);
+        if (lane < n) {
+#pragma unroll
+            for (int i = 0; i < CB_C; ++i) {
+                if (i >= lane && i < n) {
+                    cd sv = make_double2(i == lane ? 1.0 : 0.0, 0.0);
+#pragma unroll
+                    for (int k = 0; k < CB_C; ++k)
+                        if (k >= lane && k < i) { const cd t = zmul(L[i * CB_C + k], inv[k]); sv.x -= t.x; sv.y -= t.y; }
+                    const double d = L[i * CB_C + i].x;
+                    inv[i] = make_double2(sv.x / d, sv.y / d);
+                }
+            }
+        }
+        CB_WSYNC();
+        if (lane < CB_C) {
+#pragma unroll
+            for (int i = 0; i < CB_C; ++i) L[i * CB_C + lane] = (lane < n && i < n) ? inv[i] : make_double2(0.0, 0.0);
+        }
+        CB_WSYNC();
+        if (lane == 0) okg[g] = ok;
+    }
+    __syncthreads();
+
+    // phase 2: group pairs, a wave each
+    cd* M = scratch + (size_t)wave * 2 * CB_C * CB_C;
+    cd* B = M + CB_C * CB_C;
+    double* rc = rot + wave * 24;
+    cd* rs = reinterpret_cast<cd*>(rc + 8);
+    int* rp = rpair + wave * 16;
+    for (int pr = wave; pr < a.n_gpairs; pr += CB_WAVES) {
+        int gp = pr, ga = 0, len = G - 1;
+        while (gp >= len) { gp -= len; ++ga; --len; }
+        const int gb = ga + 1 + gp;
+        const int na = a.sizes[ga], nb = a.sizes[gb];
+        const int32_t* ma = a.members + ga * CB_C;
+        const int32_t* mb = a.members + gb * CB_C;
+        const cd* La = Ls + (size_t)ga * CB_C * CB_C;
+        const cd* Lb = Ls + (size_t)gb * CB_C * CB_C;
+        const bool ok = okg[ga] && okg[gb];
+        for (int e = lane; e < CB_C * CB_C; e += 64) {
+            const int i = e / CB_C, j = e % CB_C;
+            M[e] = (i < na && j < nb) ? csm_read(rec, a, ma[i], mb[j]) : make_double2(0.0, 0.0);
+        }
+        CB_WSYNC();
+        // M <- Linv_a M Linv_b^H as two dense products through B (both factors are lower triangular inverses)
+        for (int e = lane; e < CB_C * CB_C; e += 64) {
+            const int i = e / CB_C, j = e % CB_C;
+            cd sv = make_double2(0.0, 0.0);
+            for (int k = 0; k <= i; ++k) { const cd t = zmul(La[i * CB_C + k], M[k * CB_C + j]); sv.x += t.x; sv.y += t.y; }
+            B[e] = sv;
+        }
+        CB_WSYNC();
+        for (int e = lane; e < CB_C * CB_C; e += 64) {
+            const int i = e / CB_C, j = e % CB_C;
+            cd sv = make_double2(0.0, 0.0);
+            for (int k = 0; k <= j; ++k) { const cd t = zmulc(B[i * CB_C + k], Lb[j * CB_C + k]); sv.x += t.x; sv.y += t.y; }
+            M[e] = sv;
+        }
+        CB_WSYNC();
+        for (int e = lane; e < CB_C * CB_C; e += 64) {      // B = M M^H, upper triangle
+            const int i = e / CB_C, j = e % CB_C;
+            if (i <= j && j < na) {
+                cd sv = make_double2(0.0, 0.0);
+                for (int k = 0; k < nb; ++k) { const cd t = zmulc(M[i * CB_C + k], M[j * CB_C + k]); sv.x += t.x; sv.y += t.y; }
+                if (i == j) sv.y = 0.0;
+                B[e] = sv;
+            }
+        }
+        CB_WSYNC();
+        // parallel cyclic Jacobi, eigenvalues only
+        const int Mp = na + (na & 1), H = Mp / 2;
+        for (int sweep = 0; sweep < CB_SWEEPS && na > 1; ++sweep) {
+            double off = 0.0, dia = 0.0;
+            for (int e = lane; e < CB_C * CB_C; e += 64) {
+                const int i = e / CB_C, j = e % CB_C;
+                if (j < na && i <= j) {
+                    const double v = B[e].x * B[e].x + B[e].y * B[e].y;
+                    if (i == j) dia += v; else off += v;
+                }
+            }
+            off = cb_wave_sum(off); dia = cb_wave_sum(dia);
+            if (off <= 1e-24 * dia || off == 0.0) break;      // eigenvalues to ~1e-12 relative (quadratic convergence)
+            for (int r = 0; r < Mp - 1; ++r) {
+                if (lane < H) {
+                    int x, y;
+                    if (lane == 0) { x = Mp - 1; y = r; }
+                    else { x = (r + lane) % (Mp - 1); y = (r - lane + (Mp - 1)) % (Mp - 1); }
+                    const int pi = x < y ? x : y;
+                    int qi = x < y ? y : x;
+                    double c = 1.0;
+                    cd se = make_double2(0.0, 0.0);
+                    if (qi < na) {
+                        // Rotation angle in f32 (one v_sqrt / v_rcp each instead of fp64 Newton sequences on 8 lanes),
+                        // then (c, s) re-normalised in fp64 to first order: the rotation is unitary to 1e-14, it merely
+                        // leaves ~1e-7 of the pivot behind, which the next sweep removes.
+                        const cd bb = B[pi * CB_C + qi];
+                        const float bx = (float)bb.x, by = (float)bb.y;
+                        const float ab = sqrtf(bx * bx + by * by);
+                        if (ab > 1e-30f) {
+                            const float tau = (float)(B[qi * CB_C + qi].x - B[pi * CB_C + pi].x) / (2.0f * ab);
+                            const float t = (tau >= 0.f ? 1.f : -1.f) / (fabsf(tau) + sqrtf(1.f + tau * tau));
+                            const float cf = 1.f / sqrtf(1.f + t * t);
+                            const float sn = t * cf / ab;
+                            double cd0 = (double)cf, sx = (double)(sn * bx), sy = (double)(sn * by);
+                            const double fix = 1.5 - 0.5 * (cd0 * cd0 + sx * sx + sy * sy);     // 1 / sqrt(r), r = 1 + O(1e-7)
+                            c = cd0 * fix;
+                            se = make_double2(sx * fix, sy * fix);
+                        }
+                    } else {
+                        qi = -1;
+                    }
+                    rc[lane] = c; rs[lane] = se; rp[2 * lane] = pi; rp[2 * lane + 1] = qi;
+                }
+                CB_WSYNC();
+                if (lane < H * (H + 1) / 2) {              // 2x2 block (pair u <= pair v): B' = J_u^H B J_v
+                    int u = 0, ln = H, t2 = lane;
+                    while (t2 >= ln) { t2 -= ln; ++u; --ln; }
+                    const int v = u + t2;
+                    const int up = rp[2 * u], uq = rp[2 * u + 1], vp = rp[2 * v], vq = rp[2 * v + 1];
+                    const double cu = rc[u], cv = rc[v];
+                    const cd su = rs[u], sv = rs[v];
+                    const bool uhas = uq >= 0, vhas = vq >= 0;
+                    const cd b00 = cb_get(B, up, vp);
+                    const cd b01 = vhas ? cb_get(B, up, vq) : make_double2(0, 0);
+                    const cd b10 = uhas ? cb_get(B, uq, vp) : make_double2(0, 0);
+                    const cd b11 = (uhas && vhas) ? cb_get(B, uq, vq) : make_double2(0, 0);
+                    const cd svc = make_double2(sv.x, -sv.y), suc = make_double2(su.x, -su.y);
+                    const cd t00 = make_double2(cv * b00.x - zmul(svc, b01).x, cv * b00.y - zmul(svc, b01).y);
+                    const cd t01 = make_double2(zmul(sv, b00).x + cv * b01.x, zmul(sv, b00).y + cv * b01.y);
+                    const cd t10 = make_double2(cv * b10.x - zmul(svc, b11).x, cv * b10.y - zmul(svc, b11).y);
+                    const cd t11 = make_double2(zmul(sv, b10).x + cv * b11.x, zmul(sv, b10).y + cv * b11.y);
+                    const cd n00 = make_double2(cu * t00.x - zmul(su, t10).x, cu * t00.y - zmul(su, t10).y);
+                    const cd n01 = make_double2(cu * t01.x - zmul(su, t11).x, cu * t01.y - zmul(su, t11).y);
+                    const cd n10 = make_double2(zmul(suc, t00).x + cu * t10.x, zmul(suc, t00).y + cu * t10.y);
+                    const cd n11 = make_double2(zmul(suc, t01).x + cu * t11.x, zmul(suc, t01).y + cu * t11.y);
+                    CB_WSYNC();                        // every block has read its inputs before anyone writes
+                    if (u == v) {
+                        cb_set(B, up, up, make_double2(n00.x, 0.0));
+                        if (uhas) { cb_set(B, uq, uq, make_double2(n11.x, 0.0)); cb_set(B, up, uq, make_double2(0.0, 0.0)); }
+                    } else {
+                        cb_set(B, up, vp, n00);
+                        if (vhas) cb_set(B, up, vq, n01);
+                        if (uhas) cb_set(B, uq, vp, n10);
+                        if (uhas && vhas) cb_set(B, uq, vq, n11);
+                    }
+                } else {
+                    CB_WSYNC();
+                }
+                CB_WSYNC();
+            }
+        }
+        if (lane == 0) {
+            double lmax = B[0].x;
+            for (int q = 1; q < na; ++q) lmax = fmax(lmax, B[q * CB_C + q].x);
+            if (!ok) { lmax = nan(""); atomicAdd(a.fail, 1); }
+            double* o = a.out + bin * G * G;
+            o[ga * G + gb] = lmax;
+            o[gb * G + ga] = lmax;
+        }
+        CB_WSYNC();
+    }
+}
+
 __global__ void canon_fill_nan(double* out, int64_t total) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < total) out[i] = nan("");
@@ -180,7 +421,13 @@ extern "C" int sc_canonical_coherence_f64(const float* d_accum, int64_t n_bins, 
     if (threads > 0) {
         const unsigned blocks = (unsigned)((threads + 63) / 64);
         // members stride must match the instantiated CMAX
-        if (max_group_size <= 16)
+        const size_t lds_bin = (size_t)(n_groups + 2 * CB_WAVES) * CB_C * CB_C * sizeof(cd) + (size_t)((n_groups + 3) & ~3) * 4 +
+                               CB_WAVES * 24 * 8 + CB_WAVES * 16 * 4 + 64;
+        if (max_group_size <= 16 && lds_bin <= 150 * 1024) {
+            // one workgroup per bin: group factors once, pairs on the waves (LDS-resident)
+            (void)hipFuncSetAttribute((const void*)canonical_bin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bin);
+            hipLaunchKernelGGL(canonical_bin_kernel, dim3((unsigned)n_bins), dim3(64 * CB_WAVES), lds_bin, st, a);
+        } else if (max_group_size <= 16)
             hipLaunchKernelGGL(canonical_kernel<16>, dim3(blocks), dim3(64), 0, st, a);
         else
             hipLaunchKernelGGL(canonical_kernel<32>, dim3(blocks), dim3(64), 0, st, a);
