@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsc_hip.so")
 SOURCES = ["sc_api.hip", "sc_taper.hip", "sc_mtfft.hip", "sc_csm.hip", "sc_nonlinear.hip", "sc_fused.hip", "sc_measure.hip",
-           "sc_wilson.hip", "sc_mvar.hip", "sc_global.hip", "sc_canonical.hip"]
+           "sc_wilson.hip", "sc_wilson_fft.hip", "sc_mvar.hip", "sc_global.hip", "sc_canonical.hip"]
 HEADERS = ["sc_common.h", "sc_stage.h", os.path.join("..", "..", "include", "sc_hip.h")]
 
 

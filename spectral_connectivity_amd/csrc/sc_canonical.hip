@@ -416,7 +416,7 @@ extern "C" int sc_canonical_coherence_f64(const float* d_accum, int64_t n_bins, 
     a.n_obs = (double)n_observations;
     const int64_t total_out = n_bins * n_groups * n_groups;
     hipLaunchKernelGGL(canon_fill_nan, dim3((unsigned)((total_out + 255) / 256)), dim3(256), 0, st, d_out, total_out);
-    hipMemsetAsync(d_fail, 0, 4, st);
+    (void)hipMemsetAsync(d_fail, 0, 4, st);
     const int64_t threads = n_bins * a.n_gpairs;
     if (threads > 0) {
         const unsigned blocks = (unsigned)((threads + 63) / 64);

@@ -7,6 +7,11 @@
 
 void sc_set_error(const char* fmt, ...);
 
+// sc_wilson_fft.hip: A <- fft(causal(ifft(A))) in one kernel, for the lengths `supported` accepts
+bool sc_internal_causal_fft_supported(int64_t N);
+int sc_internal_causal_fft_pair(void* d_A, const int32_t* d_status, int64_t n_problems, int C, int64_t N,
+                                hipStream_t st);
+
 #define SC_CHECK_HIP(expr)                                                        \
     do {                                                                          \
         hipError_t e_ = (expr);                                                   \

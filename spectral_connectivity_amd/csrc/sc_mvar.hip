@@ -577,28 +577,35 @@ extern "C" int sc_mvar_factor_f64(const float* d_accum, const void* d_S, int64_t
     const size_t lds = mv_pair_lds((int)C);
     const dim3 gridB((unsigned)N, (unsigned)P);
     int iters = 0, running = (int)P;
+    const bool fused = sc_internal_causal_fft_supported(N);
     (void)hipFuncSetAttribute((const void*)m_predict, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)m_update, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if ((rc = mv_make_z2z(&fwd, rocfft_transform_type_complex_forward, (size_t)N, (size_t)E * P)) != SC_OK) goto done;
-    if ((rc = mv_make_z2z(&inv, rocfft_transform_type_complex_inverse, (size_t)N, (size_t)E * P)) != SC_OK) goto done;
-    MV_CHECK_FFT(rocfft_plan_get_work_buffer_size(fwd, &ws_f));
-    MV_CHECK_FFT(rocfft_plan_get_work_buffer_size(inv, &ws_i));
-    MV_CHECK_FFT(rocfft_execution_info_create(&info));
-    if (ws_f < ws_i) ws_f = ws_i;
-    if (ws_f) {
-        if (hipMalloc(&fft_work, ws_f) != hipSuccess) { sc_set_error("rocFFT work buffer alloc failed"); rc = SC_ENOMEM; goto done; }
-        MV_CHECK_FFT(rocfft_execution_info_set_work_buffer(info, fft_work, ws_f));
+    if (!fused) {
+        if ((rc = mv_make_z2z(&fwd, rocfft_transform_type_complex_forward, (size_t)N, (size_t)E * P)) != SC_OK) goto done;
+        if ((rc = mv_make_z2z(&inv, rocfft_transform_type_complex_inverse, (size_t)N, (size_t)E * P)) != SC_OK) goto done;
+        MV_CHECK_FFT(rocfft_plan_get_work_buffer_size(fwd, &ws_f));
+        MV_CHECK_FFT(rocfft_plan_get_work_buffer_size(inv, &ws_i));
+        MV_CHECK_FFT(rocfft_execution_info_create(&info));
+        if (ws_f < ws_i) ws_f = ws_i;
+        if (ws_f) {
+            if (hipMalloc(&fft_work, ws_f) != hipSuccess) { sc_set_error("rocFFT work buffer alloc failed"); rc = SC_ENOMEM; goto done; }
+            MV_CHECK_FFT(rocfft_execution_info_set_work_buffer(info, fft_work, ws_f));
+        }
+        MV_CHECK_FFT(rocfft_execution_info_set_stream(info, st));
     }
-    MV_CHECK_FFT(rocfft_execution_info_set_stream(info, st));
     (void)hipMemsetAsync(err, 0, (size_t)P * 8, st);
     (void)hipMemsetAsync(d_n_iter, 0, (size_t)P * 4, st);
     hipLaunchKernelGGL(m_init, dim3((unsigned)P), dim3(256), (size_t)E * 8, st, S, G, d_status, N, (int)C);
     for (iters = 0; iters < max_iter; ++iters) {
         void* bufs[1] = {A};
         hipLaunchKernelGGL(m_predict, gridB, dim3(nt), lds, st, S, G, d_status, A, N, (int)C);
-        MV_CHECK_FFT(rocfft_execute(inv, bufs, nullptr, info));
-        hipLaunchKernelGGL(m_causal, gridE, dim3(256), 0, st, A, N, (int)C);
-        MV_CHECK_FFT(rocfft_execute(fwd, bufs, nullptr, info));
+        if (fused) {        // ifft -> causal mask -> fft in one kernel (sc_wilson_fft.hip)
+            if ((rc = sc_internal_causal_fft_pair(A, d_status, P, (int)C, N, st)) != SC_OK) goto done;
+        } else {
+            MV_CHECK_FFT(rocfft_execute(inv, bufs, nullptr, info));
+            hipLaunchKernelGGL(m_causal, gridE, dim3(256), 0, st, A, N, (int)C);
+            MV_CHECK_FFT(rocfft_execute(fwd, bufs, nullptr, info));
+        }
         hipLaunchKernelGGL(m_update, gridB, dim3(nt), lds, st, G, A, d_status, err, N, (int)C);
         (void)hipMemsetAsync(n_running, 0, 4, st);
         hipLaunchKernelGGL(m_flags, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, d_status, d_n_iter, err, tol, P,

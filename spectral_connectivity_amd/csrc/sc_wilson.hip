@@ -7,10 +7,10 @@
 //   k_init     G0 = chol(Re ifft_n(S)[lag 0])^H                 (minimum_phase...py:48-77)
 //   loop <= max_iter, all problems at once:
 //     k_predict  A = G^-1 (G^-1 S)^H + I, closed-form 2x2       (:184-224)
-//     rocFFT     a = ifft_n(A)              batched Z2Z, unit stride, 4 series per problem
-//     k_causal   a[0] *= 1/2, strict lower of a[0] = 0, a[n >= (N+1)/2] = 0   (:96-142)
-//     rocFFT     A+ = fft_n(a)
-//     k_update   G <- G A+ unless the problem already converged; err = max |G - G_old| (:145-181, :301-315)
+//     N = 256..4096: causal_fft_pair_kernel (sc_wilson_fft.hip)  A+ = fft(mask(ifft(A))) in one pass;
+//       otherwise rocFFT ifft, k_causal (a[0] *= 1/2, strict lower of a[0] = 0, a[n >= (N+1)/2] = 0; :96-142), rocFFT fft
+//     k_update   G <- G A+ unless the problem already converged; err = max |G - G_old| (:145-181, :301-315);
+//                on the fused path the next iteration's k_predict rides in the same pass
 //   k_h0 / k_granger   H0 = Re ifft_n(G)[0]; H = G (H0 + lam I)^-1; Sigma = H0 H0^T;
 //                      GP = log P - log(P - rot |H|^2)          (connectivity.py:1679-1779, :1825-1848)
 // Everything is fp64: the reference's convergence test (max |dG| < 1e-8 absolute) is not
@@ -98,13 +98,8 @@ __global__ void __launch_bounds__(256) k_init(const double* S, cd* G, int32_t* s
     }
 }
 
-__global__ void k_predict(const double* S, const cd* G, const int32_t* status, cd* A, int64_t N) {
-    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t p = blockIdx.y;
-    if (n >= N || status[p] != 0) return;
-    const double* Sp = S + p * 4 * N;
-    const cd* Gp = G + p * 4 * N;
-    const cd g00 = Gp[n], g01 = Gp[N + n], g10 = Gp[2 * N + n], g11 = Gp[3 * N + n];
+// A = G^-1 (G^-1 S)^H + I at one frequency, closed-form 2x2
+__device__ __forceinline__ void predict2x2(cd g00, cd g01, cd g10, cd g11, const double* Sp, cd* Ap, int64_t n, int64_t N) {
     const cd s00 = make_double2(Sp[n], 0), s11 = make_double2(Sp[N + n], 0);
     const cd s01 = make_double2(Sp[2 * N + n], Sp[3 * N + n]), s10 = cconj(s01);
     const cd det = csub(cmul(g00, g11), cmul(g01, g10));
@@ -116,13 +111,20 @@ __global__ void k_predict(const double* S, const cd* G, const int32_t* status, c
     const cd x10 = cadd(cmul(i10, s00), cmul(i11, s10)), x11 = cadd(cmul(i10, s01), cmul(i11, s11));
     // Y = Ginv X^H ; A = Y + I
     const cd h00 = cconj(x00), h01 = cconj(x10), h10 = cconj(x01), h11 = cconj(x11);
-    cd* Ap = A + p * 4 * N;
     cd a00 = cadd(cmul(i00, h00), cmul(i01, h10)); a00.x += 1.0;
     cd a11 = cadd(cmul(i10, h01), cmul(i11, h11)); a11.x += 1.0;
     Ap[n] = a00;
     Ap[N + n] = cadd(cmul(i00, h01), cmul(i01, h11));
     Ap[2 * N + n] = cadd(cmul(i10, h00), cmul(i11, h10));
     Ap[3 * N + n] = a11;
+}
+
+__global__ void k_predict(const double* S, const cd* G, const int32_t* status, cd* A, int64_t N) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t p = blockIdx.y;
+    if (n >= N || status[p] != 0) return;
+    const cd* Gp = G + p * 4 * N;
+    predict2x2(Gp[n], Gp[N + n], Gp[2 * N + n], Gp[3 * N + n], S + p * 4 * N, A + p * 4 * N, n, N);
 }
 
 // after the (unnormalised) inverse FFT: 1/N, halve lag 0, zero strict lower triangle at lag 0,
@@ -148,14 +150,18 @@ __device__ inline void atomic_max_nonneg(double* addr, double v) {
     atomicMax(reinterpret_cast<unsigned long long*>(addr), (unsigned long long)__double_as_longlong(v));
 }
 
-__global__ void __launch_bounds__(256) k_update(cd* G, const cd* Aplus, const int32_t* status, double* err, int64_t N) {
+// G <- G A+ and err = max |G - G_old|; with PREDICT the next iteration's A = predict(G_new) overwrites A+ in the
+// same pass (a problem that turns out to have converged leaves an A nobody reads).
+template <bool PREDICT>
+__global__ void __launch_bounds__(256) k_update(cd* G, cd* Aplus, const double* S, const int32_t* status, double* err,
+                                                int64_t N) {
     __shared__ double red[256];
     const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t p = blockIdx.y;
     double e = 0.0;
     if (n < N && status[p] == 0) {
         cd* Gp = G + p * 4 * N;
-        const cd* Ap = Aplus + p * 4 * N;
+        cd* Ap = Aplus + p * 4 * N;
         const cd g00 = Gp[n], g01 = Gp[N + n], g10 = Gp[2 * N + n], g11 = Gp[3 * N + n];
         const cd a00 = Ap[n], a01 = Ap[N + n], a10 = Ap[2 * N + n], a11 = Ap[3 * N + n];
         const cd n00 = cadd(cmul(g00, a00), cmul(g01, a10)), n01 = cadd(cmul(g00, a01), cmul(g01, a11));
@@ -166,6 +172,7 @@ __global__ void __launch_bounds__(256) k_update(cd* G, const cd* Aplus, const in
         d = csub(n10, g10); e = fmax(e, hypot(d.x, d.y));
         d = csub(n11, g11); e = fmax(e, hypot(d.x, d.y));
         Gp[n] = n00; Gp[N + n] = n01; Gp[2 * N + n] = n10; Gp[3 * N + n] = n11;
+        if constexpr (PREDICT) predict2x2(n00, n01, n10, n11, S + p * 4 * N, Ap, n, N);
     }
     red[threadIdx.x] = e;
     __syncthreads();
@@ -333,29 +340,39 @@ static int wilson_iterate(const WilsonWork& k, int64_t P, int64_t N, double tol,
     if (!rocfft_ready) { rocfft_setup(); rocfft_ready = 1; }
     const dim3 gridN((unsigned)((N + 255) / 256), (unsigned)P);
     int iters = 0, running = (int)P;
+    const bool fused = sc_internal_causal_fft_supported(N);
 
-    if ((rc = make_z2z(&fwd, rocfft_transform_type_complex_forward, N, 4 * P)) != SC_OK) goto done;
-    if ((rc = make_z2z(&inv, rocfft_transform_type_complex_inverse, N, 4 * P)) != SC_OK) goto done;
-    SC_CHECK_FFT2(rocfft_plan_get_work_buffer_size(fwd, &ws_f));
-    SC_CHECK_FFT2(rocfft_plan_get_work_buffer_size(inv, &ws_i));
-    SC_CHECK_FFT2(rocfft_execution_info_create(&info));
-    if (ws_f < ws_i) ws_f = ws_i;
-    if (ws_f) {
-        if (hipMalloc(&fft_work, ws_f) != hipSuccess) { sc_set_error("rocFFT work buffer alloc failed"); rc = SC_ENOMEM; goto done; }
-        SC_CHECK_FFT2(rocfft_execution_info_set_work_buffer(info, fft_work, ws_f));
+    if (!fused) {
+        if ((rc = make_z2z(&fwd, rocfft_transform_type_complex_forward, N, 4 * P)) != SC_OK) goto done;
+        if ((rc = make_z2z(&inv, rocfft_transform_type_complex_inverse, N, 4 * P)) != SC_OK) goto done;
+        SC_CHECK_FFT2(rocfft_plan_get_work_buffer_size(fwd, &ws_f));
+        SC_CHECK_FFT2(rocfft_plan_get_work_buffer_size(inv, &ws_i));
+        SC_CHECK_FFT2(rocfft_execution_info_create(&info));
+        if (ws_f < ws_i) ws_f = ws_i;
+        if (ws_f) {
+            if (hipMalloc(&fft_work, ws_f) != hipSuccess) { sc_set_error("rocFFT work buffer alloc failed"); rc = SC_ENOMEM; goto done; }
+            SC_CHECK_FFT2(rocfft_execution_info_set_work_buffer(info, fft_work, ws_f));
+        }
+        SC_CHECK_FFT2(rocfft_execution_info_set_stream(info, st));
     }
-    SC_CHECK_FFT2(rocfft_execution_info_set_stream(info, st));
-    hipMemsetAsync(k.err, 0, (size_t)P * 8, st);
-    hipMemsetAsync(d_n_iter, 0, (size_t)P * 4, st);
+    (void)hipMemsetAsync(k.err, 0, (size_t)P * 8, st);
+    (void)hipMemsetAsync(d_n_iter, 0, (size_t)P * 4, st);
     hipLaunchKernelGGL(k_init, dim3((unsigned)P), dim3(256), 0, st, k.S, k.G, d_status, N);
+    if (fused) hipLaunchKernelGGL(k_predict, gridN, dim3(256), 0, st, k.S, k.G, d_status, k.A, N);
     for (iters = 0; iters < max_iter; ++iters) {
-        void* bufs[1] = {k.A};
-        hipLaunchKernelGGL(k_predict, gridN, dim3(256), 0, st, k.S, k.G, d_status, k.A, N);
-        SC_CHECK_FFT2(rocfft_execute(inv, bufs, nullptr, info));
-        hipLaunchKernelGGL(k_causal, gridN, dim3(256), 0, st, k.A, N);
-        SC_CHECK_FFT2(rocfft_execute(fwd, bufs, nullptr, info));
-        hipLaunchKernelGGL(k_update, gridN, dim3(256), 0, st, k.G, k.A, d_status, k.err, N);
-        hipMemsetAsync(k.n_running, 0, 4, st);
+        if (fused) {
+            // one kernel for ifft -> causal mask -> fft, then G <- G A+ with the next A = predict(G) in the same pass
+            if ((rc = sc_internal_causal_fft_pair(k.A, d_status, P, 2, N, st)) != SC_OK) goto done;
+            hipLaunchKernelGGL(k_update<true>, gridN, dim3(256), 0, st, k.G, k.A, k.S, d_status, k.err, N);
+        } else {
+            void* bufs[1] = {k.A};
+            hipLaunchKernelGGL(k_predict, gridN, dim3(256), 0, st, k.S, k.G, d_status, k.A, N);
+            SC_CHECK_FFT2(rocfft_execute(inv, bufs, nullptr, info));
+            hipLaunchKernelGGL(k_causal, gridN, dim3(256), 0, st, k.A, N);
+            SC_CHECK_FFT2(rocfft_execute(fwd, bufs, nullptr, info));
+            hipLaunchKernelGGL(k_update<false>, gridN, dim3(256), 0, st, k.G, k.A, k.S, d_status, k.err, N);
+        }
+        (void)hipMemsetAsync(k.n_running, 0, 4, st);
         hipLaunchKernelGGL(k_flags, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, d_status, d_n_iter, k.err, tol, P,
                            k.n_running);
         if (hipMemcpyAsync(&running, k.n_running, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||

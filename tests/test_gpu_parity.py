@@ -361,6 +361,35 @@ def test_full_wilson_factor_standalone_fp64(sc, c, N, P):
         np.testing.assert_allclose(G, so.minimum_phase_decomposition(S), rtol=0, atol=1e-6 * np.abs(G).max())
 
 
+@pytest.mark.parametrize("c,N,P", [(2, 256, 5), (2, 512, 3), (2, 1024, 3), (2, 2048, 2), (2, 4096, 2),
+                                   (3, 256, 2), (4, 512, 1), (3, 2048, 1), (5, 4096, 1)])
+def test_wilson_fused_causal_fft_vs_library_path(sc, monkeypatch, c, N, P):
+    """Lengths 256..4096 run ifft -> causal mask -> fft as one fp64 LDS kernel (csrc/sc_wilson_fft.hip); every
+    other length, and SC_WILSON_FFT=rocfft, takes rocFFT + a pointwise kernel.  Both must produce the same
+    factor (fp64 rounding apart), reconstruct S, and match the oracle where it is quick."""
+    from spectral_connectivity_amd.minimum_phase_decomposition import minimum_phase_decomposition
+    rng = np.random.default_rng(c * N + P)
+    S = np.empty((P, N, c, c), dtype=np.complex128)
+    z = np.exp(-2j * np.pi * np.arange(N) / N)
+    for p in range(P):
+        B1 = rng.standard_normal((c, c)); B1 *= 0.6 / np.linalg.norm(B1, 2)
+        B2 = rng.standard_normal((c, c)); B2 *= 0.25 / np.linalg.norm(B2, 2)
+        L = np.linalg.cholesky(np.eye(c) + 0.3 * np.ones((c, c)) / c)
+        Fz = (np.eye(c)[None] + B1[None] * z[:, None, None] + B2[None] * (z ** 2)[:, None, None]) @ L
+        S[p] = Fz @ np.conj(np.swapaxes(Fz, -1, -2))
+    monkeypatch.delenv("SC_WILSON_FFT", raising=False)
+    G = minimum_phase_decomposition(S)
+    monkeypatch.setenv("SC_WILSON_FFT", "rocfft")
+    G_lib = minimum_phase_decomposition(S)
+    monkeypatch.delenv("SC_WILSON_FFT", raising=False)
+    assert G.shape == S.shape and np.isfinite(G).all()
+    scale = np.abs(G).max()
+    np.testing.assert_allclose(G, G_lib, rtol=0, atol=1e-10 * scale)
+    np.testing.assert_allclose(G @ np.conj(np.swapaxes(G, -1, -2)), S, rtol=0, atol=1e-7 * np.abs(S).max())
+    if N <= 512:
+        np.testing.assert_allclose(G, so.minimum_phase_decomposition(S), rtol=0, atol=1e-6 * scale)
+
+
 @pytest.mark.parametrize("rank", [1, 2, 4, 5])
 def test_f10_global_coherence_vs_reference(sc, golden, rank):
     """Leading eigenpairs of the device CSM against the reference's SVD of the coefficient matrix."""
