@@ -10,7 +10,7 @@
 //     N = 256..4096: causal_fft_pair_kernel (sc_wilson_fft.hip)  A+ = fft(mask(ifft(A))) in one pass;
 //       otherwise rocFFT ifft, k_causal (a[0] *= 1/2, strict lower of a[0] = 0, a[n >= (N+1)/2] = 0; :96-142), rocFFT fft
 //     k_update   G <- G A+ unless the problem already converged; err = max |G - G_old| (:145-181, :301-315);
-//                on the fused path the next iteration's k_predict rides in the same pass
+//                the next iteration's predict rides in the same pass
 //   k_h0 / k_granger   H0 = Re ifft_n(G)[0]; H = G (H0 + lam I)^-1; Sigma = H0 H0^T;
 //                      GP = log P - log(P - rot |H|^2)          (connectivity.py:1679-1779, :1825-1848)
 // Everything is fp64: the reference's convergence test (max |dG| < 1e-8 absolute) is not
@@ -150,9 +150,8 @@ __device__ inline void atomic_max_nonneg(double* addr, double v) {
     atomicMax(reinterpret_cast<unsigned long long*>(addr), (unsigned long long)__double_as_longlong(v));
 }
 
-// G <- G A+ and err = max |G - G_old|; with PREDICT the next iteration's A = predict(G_new) overwrites A+ in the
-// same pass (a problem that turns out to have converged leaves an A nobody reads).
-template <bool PREDICT>
+// G <- G A+ and err = max |G - G_old|; the next iteration's A = predict(G_new) overwrites A+ in the same pass
+// (a problem that turns out to have converged leaves an A nobody reads).
 __global__ void __launch_bounds__(256) k_update(cd* G, cd* Aplus, const double* S, const int32_t* status, double* err,
                                                 int64_t N) {
     __shared__ double red[256];
@@ -172,7 +171,7 @@ __global__ void __launch_bounds__(256) k_update(cd* G, cd* Aplus, const double* 
         d = csub(n10, g10); e = fmax(e, hypot(d.x, d.y));
         d = csub(n11, g11); e = fmax(e, hypot(d.x, d.y));
         Gp[n] = n00; Gp[N + n] = n01; Gp[2 * N + n] = n10; Gp[3 * N + n] = n11;
-        if constexpr (PREDICT) predict2x2(n00, n01, n10, n11, S + p * 4 * N, Ap, n, N);
+        predict2x2(n00, n01, n10, n11, S + p * 4 * N, Ap, n, N);
     }
     red[threadIdx.x] = e;
     __syncthreads();
@@ -358,20 +357,18 @@ static int wilson_iterate(const WilsonWork& k, int64_t P, int64_t N, double tol,
     (void)hipMemsetAsync(k.err, 0, (size_t)P * 8, st);
     (void)hipMemsetAsync(d_n_iter, 0, (size_t)P * 4, st);
     hipLaunchKernelGGL(k_init, dim3((unsigned)P), dim3(256), 0, st, k.S, k.G, d_status, N);
-    if (fused) hipLaunchKernelGGL(k_predict, gridN, dim3(256), 0, st, k.S, k.G, d_status, k.A, N);
+    hipLaunchKernelGGL(k_predict, gridN, dim3(256), 0, st, k.S, k.G, d_status, k.A, N);
     for (iters = 0; iters < max_iter; ++iters) {
-        if (fused) {
-            // one kernel for ifft -> causal mask -> fft, then G <- G A+ with the next A = predict(G) in the same pass
+        if (fused) {        // one kernel for ifft -> causal mask -> fft
             if ((rc = sc_internal_causal_fft_pair(k.A, d_status, P, 2, N, st)) != SC_OK) goto done;
-            hipLaunchKernelGGL(k_update<true>, gridN, dim3(256), 0, st, k.G, k.A, k.S, d_status, k.err, N);
         } else {
             void* bufs[1] = {k.A};
-            hipLaunchKernelGGL(k_predict, gridN, dim3(256), 0, st, k.S, k.G, d_status, k.A, N);
             SC_CHECK_FFT2(rocfft_execute(inv, bufs, nullptr, info));
             hipLaunchKernelGGL(k_causal, gridN, dim3(256), 0, st, k.A, N);
             SC_CHECK_FFT2(rocfft_execute(fwd, bufs, nullptr, info));
-            hipLaunchKernelGGL(k_update<false>, gridN, dim3(256), 0, st, k.G, k.A, k.S, d_status, k.err, N);
         }
+        // G <- G A+ with the next iteration's A = predict(G) in the same pass
+        hipLaunchKernelGGL(k_update, gridN, dim3(256), 0, st, k.G, k.A, k.S, d_status, k.err, N);
         (void)hipMemsetAsync(k.n_running, 0, 4, st);
         hipLaunchKernelGGL(k_flags, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, d_status, d_n_iter, k.err, tol, P,
                            k.n_running);
