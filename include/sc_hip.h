@@ -284,7 +284,9 @@ int sc_global_coherence_f64(const float* d_accum, int64_t n_groups, int64_t n_fr
  *               max_group_size <= 16 else 32 (max supported: sc_canonical_max_group())
  *   d_sizes     int32 [n_groups]
  *   d_out       double [n_bins][n_groups][n_groups], symmetric, NaN diagonal
- *   d_fail      int32 [1]: number of group blocks that were not positive definite */
+ *   d_fail      int32 [1]: number of group blocks that were not positive definite
+ * Groups of <= 16 channels take a stream-ordered workspace of n_bins * n_groups * 4 KB for the
+ * inverted group factors (hipMallocAsync / hipFreeAsync on `stream`); SC_ENOMEM if that fails. */
 int sc_canonical_max_group(void);
 int sc_canonical_coherence_f64(const float* d_accum, int64_t n_bins, int64_t n_signals, uint32_t planes,
                                int64_t n_observations, const int32_t* d_members, const int32_t* d_sizes,

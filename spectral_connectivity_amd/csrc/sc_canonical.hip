@@ -12,6 +12,7 @@
 // One thread per (bin, group pair), fp64, matrices in per-lane scratch: the work is
 // O(bins * pairs * c^3) and tiny next to stage B.
 #include <math.h>
+#include <stdlib.h>
 #include "sc_common.h"
 
 typedef double2 cd;
@@ -26,6 +27,7 @@ struct CanonArgs {
     int32_t* fail;            // [1] count of non positive-definite group blocks
     int64_t n_bins, floats_per_bin;
     int G, n_gpairs, NB, n_tiles, p_csm;
+    double jtol;
     double n_obs;
 };
 
@@ -147,13 +149,19 @@ __global__ void __launch_bounds__(64) canonical_kernel(CanonArgs a) {
     o[gb * a.G + ga] = lmax;
 }
 
-// ---- one workgroup per bin (groups of at most 16 channels) ------------------------------------------
+// ---- groups of at most 16 channels: factor kernel + pair kernel ------------------------------------
 // The thread-per-problem kernel above keeps three 16x16 complex matrices per lane in scratch memory and
-// factors every group's block once per PAIR.  Here a workgroup (4 waves) owns a bin: the Cholesky factor
-// of every group is computed (and inverted) once into LDS, then the waves take the group pairs in turn, each with its
-// own LDS scratch -- whitening by the inverse factors as two dense 16x16 products, B = M M^H (a lane per entry) and a
-// parallel cyclic Jacobi on B (a lane per 2x2 block of the round's pairing).  Everything inside a wave
-// is ordered by the wave's in-order LDS pipe: no workgroup barrier after the factors are ready.
+// factors every group's block once per PAIR.  Here
+//   canonical_factor_kernel  one workgroup per bin, a wave per group: Cholesky factor, inverted in place
+//                            (so whitening a pair is two dense 16x16 products with no dependent chains),
+//                            written to a [bin][group][16][16] workspace (L2-resident: 4 KB per group);
+//   canonical_pair_kernel    a WAVE per (bin, group pair), eight to a workgroup: whitening, B = M M^H
+//                            (a lane per entry) and a parallel cyclic Jacobi on B (a lane per 2x2 block of
+//                            the round's pairing) in the wave's own 8 KB of LDS, ordered by the wave's
+//                            in-order LDS pipe -- no workgroup barrier at all.
+// Pair-granular workgroups (7695 at cfg5) fill the 256 CUs evenly and two fit a CU; one workgroup per bin
+// with the factors kept in LDS (the first version of this path) left a 513-bin problem waiting for a third
+// generation of a single workgroup.
 #define CB_C 16
 #define CB_WSYNC()                                                  \
     do {                                                            \
@@ -180,14 +188,10 @@ __device__ inline double cb_wave_sum(double v) {
 #ifndef CB_SWEEPS
 #define CB_SWEEPS 12
 #endif
-__global__ void __launch_bounds__(64 * CB_WAVES) canonical_bin_kernel(CanonArgs a) {
+__global__ void __launch_bounds__(64 * CB_WAVES) canonical_factor_kernel(CanonArgs a, cd* Lg, int* okb) {
     extern __shared__ __align__(16) unsigned char cb_smem[];
     const int G = a.G;
-    cd* Ls = reinterpret_cast<cd*>(cb_smem);                                   // [G][16][16] lower Cholesky factors
-    cd* scratch = Ls + (size_t)G * CB_C * CB_C;                                // per wave: M, B [16][16]
-    int* okg = reinterpret_cast<int*>(scratch + CB_WAVES * 2 * CB_C * CB_C);   // [G]
-    double* rot = reinterpret_cast<double*>(okg + ((G + 3) & ~3));             // per wave: [8] cos, [8][2] sin (16-byte aligned)
-    int* rpair = reinterpret_cast<int*>(rot + CB_WAVES * 24);                  // per wave: [8][2]
+    cd* Ls = reinterpret_cast<cd*>(cb_smem);                                   // [wave][16][16]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int64_t bin = blockIdx.x;
     const float* rec = a.accum + bin * a.floats_per_bin;
@@ -196,7 +200,7 @@ __global__ void __launch_bounds__(64 * CB_WAVES) canonical_bin_kernel(CanonArgs 
     for (int g = wave; g < G; g += CB_WAVES) {
         const int n = a.sizes[g];
         const int32_t* mg = a.members + g * CB_C;
-        cd* L = Ls + (size_t)g * CB_C * CB_C;
+        cd* L = Ls + (size_t)wave * CB_C * CB_C;
         for (int e = lane; e < CB_C * CB_C; e += 64) {
             const int i = e / CB_C, j = e % CB_C;
             L[e] = (i < n && j < n) ? csm_read(rec, a, mg[i], mg[j]) : make_double2(0.0, 0.0);
@@ -244,17 +248,32 @@ __global__ void __launch_bounds__(64 * CB_WAVES) canonical_bin_kernel(CanonArgs 
             for (int i = 0; i < CB_C; ++i) L[i * CB_C + lane] = (lane < n && i < n) ? inv[i] : make_double2(0.0, 0.0);
         }
         CB_WSYNC();
-        if (lane == 0) okg[g] = ok;
+        cd* out = Lg + ((size_t)bin * G + g) * CB_C * CB_C;
+        for (int e = lane; e < CB_C * CB_C; e += 64) out[e] = L[e];
+        if (lane == 0) okb[bin * G + g] = ok;
+        CB_WSYNC();                                                // L is reused for this wave's next group
     }
-    __syncthreads();
+}
 
-    // phase 2: group pairs, a wave each
+__global__ void __launch_bounds__(64 * CB_WAVES) canonical_pair_kernel(CanonArgs a, const cd* Lg, const int* okb) {
+    extern __shared__ __align__(16) unsigned char cb_smem[];
+    const int G = a.G;
+    cd* scratch = reinterpret_cast<cd*>(cb_smem);                              // per wave: M, B [16][16]
+    double* rot = reinterpret_cast<double*>(scratch + CB_WAVES * 2 * CB_C * CB_C);   // per wave: [8] cos, [8][2] sin
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int n_chunks = (a.n_gpairs + CB_WAVES - 1) / CB_WAVES;
+    const int64_t bin = blockIdx.x / n_chunks;
+    const int chunk = blockIdx.x % n_chunks;
+    const float* rec = a.accum + bin * a.floats_per_bin;
+    const cd* Ls = Lg + (size_t)bin * G * CB_C * CB_C;
+    const int* okg = okb + bin * G;
     cd* M = scratch + (size_t)wave * 2 * CB_C * CB_C;
     cd* B = M + CB_C * CB_C;
     double* rc = rot + wave * 24;
     cd* rs = reinterpret_cast<cd*>(rc + 8);
-    int* rp = rpair + wave * 16;
-    for (int pr = wave; pr < a.n_gpairs; pr += CB_WAVES) {
+    {
+        const int pr = chunk * CB_WAVES + wave;
+        if (pr >= a.n_gpairs) return;                              // no workgroup barriers below
         int gp = pr, ga = 0, len = G - 1;
         while (gp >= len) { gp -= len; ++ga; --len; }
         const int gb = ga + 1 + gp;
@@ -269,109 +288,128 @@ __global__ void __launch_bounds__(64 * CB_WAVES) canonical_bin_kernel(CanonArgs 
             M[e] = (i < na && j < nb) ? csm_read(rec, a, ma[i], mb[j]) : make_double2(0.0, 0.0);
         }
         CB_WSYNC();
-        // M <- Linv_a M Linv_b^H as two dense products through B (both factors are lower triangular inverses)
+        // M <- Linv_a M Linv_b^H as two dense products through B.  The inverse factors come from the workspace (L2):
+        // a row of sixteen independent loads per output element, issued together (their upper triangles are zero).
         for (int e = lane; e < CB_C * CB_C; e += 64) {
             const int i = e / CB_C, j = e % CB_C;
+            cd la[CB_C];
+#pragma unroll
+            for (int k = 0; k < CB_C; ++k) la[k] = La[i * CB_C + k];
             cd sv = make_double2(0.0, 0.0);
-            for (int k = 0; k <= i; ++k) { const cd t = zmul(La[i * CB_C + k], M[k * CB_C + j]); sv.x += t.x; sv.y += t.y; }
+#pragma unroll
+            for (int k = 0; k < CB_C; ++k) { const cd t = zmul(la[k], M[k * CB_C + j]); sv.x += t.x; sv.y += t.y; }
             B[e] = sv;
         }
         CB_WSYNC();
         for (int e = lane; e < CB_C * CB_C; e += 64) {
             const int i = e / CB_C, j = e % CB_C;
+            cd lb[CB_C];
+#pragma unroll
+            for (int k = 0; k < CB_C; ++k) lb[k] = Lb[j * CB_C + k];
             cd sv = make_double2(0.0, 0.0);
-            for (int k = 0; k <= j; ++k) { const cd t = zmulc(B[i * CB_C + k], Lb[j * CB_C + k]); sv.x += t.x; sv.y += t.y; }
+#pragma unroll
+            for (int k = 0; k < CB_C; ++k) { const cd t = zmulc(B[i * CB_C + k], lb[k]); sv.x += t.x; sv.y += t.y; }
             M[e] = sv;
         }
         CB_WSYNC();
-        for (int e = lane; e < CB_C * CB_C; e += 64) {      // B = M M^H, upper triangle
+        for (int e = lane; e < CB_C * CB_C; e += 64) {      // B = M M^H, both triangles, zero outside na x na
             const int i = e / CB_C, j = e % CB_C;
-            if (i <= j && j < na) {
-                cd sv = make_double2(0.0, 0.0);
-                for (int k = 0; k < nb; ++k) { const cd t = zmulc(M[i * CB_C + k], M[j * CB_C + k]); sv.x += t.x; sv.y += t.y; }
+            cd sv = make_double2(0.0, 0.0);
+            if (i < na && j < na) {
+#pragma unroll
+                for (int k = 0; k < CB_C; ++k) { const cd t = zmulc(M[i * CB_C + k], M[j * CB_C + k]); sv.x += t.x; sv.y += t.y; }
                 if (i == j) sv.y = 0.0;
-                B[e] = sv;
             }
+            B[e] = sv;
         }
         CB_WSYNC();
-        // parallel cyclic Jacobi, eigenvalues only
-        const int Mp = na + (na & 1), H = Mp / 2;
+        // Parallel cyclic Jacobi, eigenvalues only.  Round r of a sweep pairs the Mp indices by the circle method
+        // (index Mp-1 fixed, the others rotating); pair k of the round is rotated by lane k, and lane (u, v) applies
+        // B' = J_u^H B J_v to the 2x2 block (pair u) x (pair v).  An odd na pairs one
+        // index with the zero row na: zero pivot, identity rotation, no special case.
+        const int Mp = na + (na & 1), H = Mp / 2, Q = Mp - 1;
+        const bool has_block = lane < H * H;               // every block of the H x H grid has a lane: no mirror writes
+        const int bu = has_block ? lane / H : 0, bv = has_block ? lane % H : 0;
+        // circle method, kept incrementally: pair k of round r is (r + k, r - k) mod Q, pair 0 is (Q, r); the
+        // positions advance by one per round and return to the start after the Q rounds of a sweep
+        auto start_x = [Q](int k) { return k == 0 ? Q : k; };
+        auto start_y = [Q](int k) { return k == 0 ? 0 : Q - k; };
+        auto advance = [Q](int k, int& x, int& y) {
+            const int x1 = x + 1, y1 = y + 1;
+            if (k != 0) x = x1 == Q ? 0 : x1;
+            y = y1 == Q ? 0 : y1;
+        };
+        int xa = start_x(lane < H ? lane : 0), ya = start_y(lane < H ? lane : 0);
+        int xu = start_x(bu), yu = start_y(bu), xv = start_x(bv), yv = start_y(bv);
         for (int sweep = 0; sweep < CB_SWEEPS && na > 1; ++sweep) {
             double off = 0.0, dia = 0.0;
             for (int e = lane; e < CB_C * CB_C; e += 64) {
                 const int i = e / CB_C, j = e % CB_C;
-                if (j < na && i <= j) {
-                    const double v = B[e].x * B[e].x + B[e].y * B[e].y;
-                    if (i == j) dia += v; else off += v;
-                }
+                const double v = B[e].x * B[e].x + B[e].y * B[e].y;
+                if (i == j) dia += v; else off += 0.5 * v;
             }
             off = cb_wave_sum(off); dia = cb_wave_sum(dia);
-            if (off <= 1e-24 * dia || off == 0.0) break;      // eigenvalues to ~1e-12 relative (quadratic convergence)
-            for (int r = 0; r < Mp - 1; ++r) {
+            if (off <= a.jtol * dia || off == 0.0) break;
+            for (int r = 0; r < Q; ++r) {
                 if (lane < H) {
-                    int x, y;
-                    if (lane == 0) { x = Mp - 1; y = r; }
-                    else { x = (r + lane) % (Mp - 1); y = (r - lane + (Mp - 1)) % (Mp - 1); }
-                    const int pi = x < y ? x : y;
-                    int qi = x < y ? y : x;
+                    const int pi = xa < ya ? xa : ya, qi = xa < ya ? ya : xa;
+                    advance(lane, xa, ya);
                     double c = 1.0;
                     cd se = make_double2(0.0, 0.0);
-                    if (qi < na) {
-                        // Rotation angle in f32 (one v_sqrt / v_rcp each instead of fp64 Newton sequences on 8 lanes),
-                        // then (c, s) re-normalised in fp64 to first order: the rotation is unitary to 1e-14, it merely
-                        // leaves ~1e-7 of the pivot behind, which the next sweep removes.
-                        const cd bb = B[pi * CB_C + qi];
-                        const float bx = (float)bb.x, by = (float)bb.y;
-                        const float ab = sqrtf(bx * bx + by * by);
-                        if (ab > 1e-30f) {
-                            const float tau = (float)(B[qi * CB_C + qi].x - B[pi * CB_C + pi].x) / (2.0f * ab);
-                            const float t = (tau >= 0.f ? 1.f : -1.f) / (fabsf(tau) + sqrtf(1.f + tau * tau));
-                            const float cf = 1.f / sqrtf(1.f + t * t);
-                            const float sn = t * cf / ab;
-                            double cd0 = (double)cf, sx = (double)(sn * bx), sy = (double)(sn * by);
-                            const double fix = 1.5 - 0.5 * (cd0 * cd0 + sx * sx + sy * sy);     // 1 / sqrt(r), r = 1 + O(1e-7)
-                            c = cd0 * fix;
-                            se = make_double2(sx * fix, sy * fix);
-                        }
-                    } else {
-                        qi = -1;
+                    // Rotation angle in f32 with the hardware's 1-ulp rcp / rsq (no IEEE division sequences, no fp64
+                    // Newton steps on 8 lanes), then (c, s) re-normalised in fp64 to first order: the rotation is
+                    // unitary to 1e-14, it merely leaves ~1e-7 of the pivot behind, which the next sweep removes.
+                    const cd bb = B[pi * CB_C + qi];
+                    const float bx = (float)bb.x, by = (float)bb.y;
+                    const float ab2 = bx * bx + by * by;
+                    if (ab2 > 1e-37f) {
+                        const float rab = __builtin_amdgcn_rsqf(ab2);                       // 1 / |b|
+                        const float tau = 0.5f * (float)(B[qi * CB_C + qi].x - B[pi * CB_C + pi].x) * rab;
+                        const float den = fabsf(tau) + __builtin_amdgcn_sqrtf(1.f + tau * tau);
+                        const float t = __builtin_copysignf(__builtin_amdgcn_rcpf(den), tau);
+                        const float cf = __builtin_amdgcn_rsqf(1.f + t * t);
+                        const float sn = t * cf * rab;
+                        const double cd0 = (double)cf, sx = (double)(sn * bx), sy = (double)(sn * by);
+                        const double fix = 1.5 - 0.5 * (cd0 * cd0 + sx * sx + sy * sy);     // 1 / sqrt(r), r = 1 + O(1e-7)
+                        c = cd0 * fix;
+                        se = make_double2(sx * fix, sy * fix);
                     }
-                    rc[lane] = c; rs[lane] = se; rp[2 * lane] = pi; rp[2 * lane + 1] = qi;
+                    rc[lane] = c; rs[lane] = se;
                 }
                 CB_WSYNC();
-                if (lane < H * (H + 1) / 2) {              // 2x2 block (pair u <= pair v): B' = J_u^H B J_v
-                    int u = 0, ln = H, t2 = lane;
-                    while (t2 >= ln) { t2 -= ln; ++u; --ln; }
-                    const int v = u + t2;
-                    const int up = rp[2 * u], uq = rp[2 * u + 1], vp = rp[2 * v], vq = rp[2 * v + 1];
-                    const double cu = rc[u], cv = rc[v];
-                    const cd su = rs[u], sv = rs[v];
-                    const bool uhas = uq >= 0, vhas = vq >= 0;
-                    const cd b00 = cb_get(B, up, vp);
-                    const cd b01 = vhas ? cb_get(B, up, vq) : make_double2(0, 0);
-                    const cd b10 = uhas ? cb_get(B, uq, vp) : make_double2(0, 0);
-                    const cd b11 = (uhas && vhas) ? cb_get(B, uq, vq) : make_double2(0, 0);
+                const int up = xu < yu ? xu : yu, uq = xu < yu ? yu : xu, vp = xv < yv ? xv : yv, vq = xv < yv ? yv : xv;
+                advance(bu, xu, yu);
+                advance(bv, xv, yv);
+                cd n00, n01, n10, n11;
+                if (has_block) {
+                    const double cu = rc[bu], cv = rc[bv];
+                    const cd su = rs[bu], sv = rs[bv];
+                    const cd b00 = B[up * CB_C + vp], b01 = B[up * CB_C + vq], b10 = B[uq * CB_C + vp], b11 = B[uq * CB_C + vq];
                     const cd svc = make_double2(sv.x, -sv.y), suc = make_double2(su.x, -su.y);
-                    const cd t00 = make_double2(cv * b00.x - zmul(svc, b01).x, cv * b00.y - zmul(svc, b01).y);
-                    const cd t01 = make_double2(zmul(sv, b00).x + cv * b01.x, zmul(sv, b00).y + cv * b01.y);
-                    const cd t10 = make_double2(cv * b10.x - zmul(svc, b11).x, cv * b10.y - zmul(svc, b11).y);
-                    const cd t11 = make_double2(zmul(sv, b10).x + cv * b11.x, zmul(sv, b10).y + cv * b11.y);
-                    const cd n00 = make_double2(cu * t00.x - zmul(su, t10).x, cu * t00.y - zmul(su, t10).y);
-                    const cd n01 = make_double2(cu * t01.x - zmul(su, t11).x, cu * t01.y - zmul(su, t11).y);
-                    const cd n10 = make_double2(zmul(suc, t00).x + cu * t10.x, zmul(suc, t00).y + cu * t10.y);
-                    const cd n11 = make_double2(zmul(suc, t01).x + cu * t11.x, zmul(suc, t01).y + cu * t11.y);
-                    CB_WSYNC();                        // every block has read its inputs before anyone writes
-                    if (u == v) {
-                        cb_set(B, up, up, make_double2(n00.x, 0.0));
-                        if (uhas) { cb_set(B, uq, uq, make_double2(n11.x, 0.0)); cb_set(B, up, uq, make_double2(0.0, 0.0)); }
+                    const cd a0 = zmul(svc, b01), a1 = zmul(sv, b00), a2 = zmul(svc, b11), a3 = zmul(sv, b10);
+                    const cd t00 = make_double2(cv * b00.x - a0.x, cv * b00.y - a0.y);
+                    const cd t01 = make_double2(a1.x + cv * b01.x, a1.y + cv * b01.y);
+                    const cd t10 = make_double2(cv * b10.x - a2.x, cv * b10.y - a2.y);
+                    const cd t11 = make_double2(a3.x + cv * b11.x, a3.y + cv * b11.y);
+                    const cd c0 = zmul(su, t10), c1 = zmul(su, t11), c2 = zmul(suc, t00), c3 = zmul(suc, t01);
+                    n00 = make_double2(cu * t00.x - c0.x, cu * t00.y - c0.y);
+                    n01 = make_double2(cu * t01.x - c1.x, cu * t01.y - c1.y);
+                    n10 = make_double2(c2.x + cu * t10.x, c2.y + cu * t10.y);
+                    n11 = make_double2(c3.x + cu * t11.x, c3.y + cu * t11.y);
+                }
+                CB_WSYNC();                            // every block has read its inputs before anyone writes
+                if (has_block) {
+                    if (bu == bv) {
+                        B[up * CB_C + up] = make_double2(n00.x, 0.0);
+                        B[uq * CB_C + uq] = make_double2(n11.x, 0.0);
+                        B[up * CB_C + uq] = make_double2(0.0, 0.0);
+                        B[uq * CB_C + up] = make_double2(0.0, 0.0);
                     } else {
-                        cb_set(B, up, vp, n00);
-                        if (vhas) cb_set(B, up, vq, n01);
-                        if (uhas) cb_set(B, uq, vp, n10);
-                        if (uhas && vhas) cb_set(B, uq, vq, n11);
+                        B[up * CB_C + vp] = n00;
+                        B[up * CB_C + vq] = n01;
+                        B[uq * CB_C + vp] = n10;
+                        B[uq * CB_C + vq] = n11;
                     }
-                } else {
-                    CB_WSYNC();
                 }
                 CB_WSYNC();
             }
@@ -384,7 +422,6 @@ __global__ void __launch_bounds__(64 * CB_WAVES) canonical_bin_kernel(CanonArgs 
             o[ga * G + gb] = lmax;
             o[gb * G + ga] = lmax;
         }
-        CB_WSYNC();
     }
 }
 
@@ -414,6 +451,7 @@ extern "C" int sc_canonical_coherence_f64(const float* d_accum, int64_t n_bins, 
     a.floats_per_bin = (int64_t)sc_plane_count(planes) * a.n_tiles * SC_TILE_ELEMS;
     a.p_csm = sc_plane_offset(planes, SC_PLANE_CSM);
     a.n_obs = (double)n_observations;
+    a.jtol = 1e-24;          // off^2 <= jtol dia^2: eigenvalues to ~1e-12 relative (quadratic convergence)
     const int64_t total_out = n_bins * n_groups * n_groups;
     hipLaunchKernelGGL(canon_fill_nan, dim3((unsigned)((total_out + 255) / 256)), dim3(256), 0, st, d_out, total_out);
     (void)hipMemsetAsync(d_fail, 0, 4, st);
@@ -421,16 +459,29 @@ extern "C" int sc_canonical_coherence_f64(const float* d_accum, int64_t n_bins, 
     if (threads > 0) {
         const unsigned blocks = (unsigned)((threads + 63) / 64);
         // members stride must match the instantiated CMAX
-        const size_t lds_bin = (size_t)(n_groups + 2 * CB_WAVES) * CB_C * CB_C * sizeof(cd) + (size_t)((n_groups + 3) & ~3) * 4 +
-                               CB_WAVES * 24 * 8 + CB_WAVES * 16 * 4 + 64;
-        if (max_group_size <= 16 && lds_bin <= 150 * 1024) {
-            // one workgroup per bin: group factors once, pairs on the waves (LDS-resident)
-            (void)hipFuncSetAttribute((const void*)canonical_bin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bin);
-            hipLaunchKernelGGL(canonical_bin_kernel, dim3((unsigned)n_bins), dim3(64 * CB_WAVES), lds_bin, st, a);
-        } else if (max_group_size <= 16)
-            hipLaunchKernelGGL(canonical_kernel<16>, dim3(blocks), dim3(64), 0, st, a);
-        else
+        if (max_group_size <= 16) {
+            // group factors once per bin into a stream-ordered workspace, then a wave per (bin, group pair)
+            cd* Lg = nullptr;
+            const size_t lg_bytes = (size_t)n_bins * n_groups * CB_C * CB_C * sizeof(cd);
+            const size_t ok_bytes = (((size_t)n_bins * n_groups * sizeof(int)) + 255) & ~(size_t)255;
+            if (hipMallocAsync((void**)&Lg, lg_bytes + ok_bytes, st) != hipSuccess) {
+                sc_set_error("canonical coherence: workspace allocation of %zu bytes failed", lg_bytes + ok_bytes);
+                return SC_ENOMEM;
+            }
+            int* okb = reinterpret_cast<int*>(reinterpret_cast<char*>(Lg) + lg_bytes);
+            const size_t lds_f = (size_t)CB_WAVES * CB_C * CB_C * sizeof(cd);
+            const size_t lds_p = (size_t)CB_WAVES * 2 * CB_C * CB_C * sizeof(cd) + CB_WAVES * 24 * 8;
+            (void)hipFuncSetAttribute((const void*)canonical_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p);
+            hipLaunchKernelGGL(canonical_factor_kernel, dim3((unsigned)n_bins), dim3(64 * CB_WAVES), lds_f, st, a, Lg, okb);
+            const int64_t n_gp = a.n_gpairs;
+            const int64_t n_wg = ((n_gp + CB_WAVES - 1) / CB_WAVES) * n_bins;
+            if (n_wg > 0x7fffffffLL) { (void)hipFreeAsync(Lg, st); sc_set_error("canonical coherence: too many (bin, pair) tasks"); return SC_EINVAL; }
+            hipLaunchKernelGGL(canonical_pair_kernel, dim3((unsigned)n_wg), dim3(64 * CB_WAVES), lds_p, st, a, (const cd*)Lg,
+                               (const int*)okb);
+            (void)hipFreeAsync(Lg, st);
+        } else {
             hipLaunchKernelGGL(canonical_kernel<32>, dim3(blocks), dim3(64), 0, st, a);
+        }
     }
     SC_CHECK_HIP(hipGetLastError());
     return SC_OK;

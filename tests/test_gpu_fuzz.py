@@ -120,3 +120,28 @@ def test_random_var_systems_directed_measures(C, T, R, L, seed):
         got, lab = c.canonical_coherence(labels)
         ref, _ = so.canonical_coherence(coef, labels)
         _close(got, ref, 1e-4, "canonical coherence")
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_group_structures_canonical_coherence(seed):
+    """Canonical coherence over shuffled labels with 2-9 groups of 1-16 channels each (the per-bin kernel's whole
+    range: single-channel groups, a full 16-channel group, equal and ragged sizes) against the oracle's SVD form."""
+    import spectral_connectivity_amd as sc
+    rng = np.random.default_rng(1000 + seed)
+    G = int(rng.integers(2, 10))
+    sizes = rng.integers(1, 17, G)
+    if seed % 4 == 0:
+        sizes[:] = rng.integers(1, 4)
+    if seed % 3 == 0:
+        sizes[rng.integers(G)] = 16
+    C = int(sizes.sum())
+    labels = np.repeat(np.arange(G), sizes)[rng.permutation(C)]
+    T = int(rng.choice([64, 100, 128]))
+    R = int(rng.integers(max(3, (sizes.max() + 2) // 3 + 1), 12))       # n_obs = 3 R >= largest group
+    x = rng.standard_normal((T, R, C)) @ (rng.standard_normal((C, C)) * 0.4 + np.eye(C)).T
+    m = sc.Multitaper(x, sampling_frequency=100.0, time_halfbandwidth_product=2)
+    got, lab = sc.Connectivity.from_multitaper(m).canonical_coherence(labels)
+    coef, _ = so.multitaper_fft(x, fs=100.0, NW=2)
+    ref, ref_lab = so.canonical_coherence(coef, labels)
+    assert list(lab) == list(ref_lab)
+    _close(got, ref, 5e-5, f"canonical coherence, group sizes {list(sizes)}")
