@@ -27,7 +27,7 @@ struct CsmArgs {
 };
 
 template <int MAX_SLOTS, int OC, int CPMAX, bool VEC>
-__global__ void __launch_bounds__(256) csm_mfma_kernel(CsmArgs p) {
+__global__ void __launch_bounds__(256, (CPMAX == 256 && MAX_SLOTS <= 5) ? 2 : 1) csm_mfma_kernel(CsmArgs p) {
     extern __shared__ __align__(16) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -174,5 +174,9 @@ extern "C" int sc_csm_accumulate_f32(const void* d_X, const sc_spectra_desc* des
         if (need <= 5) return launch_csm<5, 32, 128>(a, vec, st);
         return launch_csm<9, 32, 128>(a, vec, st);
     }
-    return launch_csm<9, 16, 256>(a, vec, st);
+    // 129..256 channels: five tile slots per wave keep the kernel within 256 registers (arch + acc), so two
+    // workgroups share a CU.  Nine slots take 455 and run ONE wave per SIMD -- nothing overlaps the MFMA chain's
+    // operand waits and VALU work: 7.1 ms against 5.2 ms at 256 ch x 2500 observations x 513 bins.
+    return launch_csm<5, 16, 256>(a, vec, st);
 }
+
