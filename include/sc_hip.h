@@ -109,8 +109,9 @@ int sc_device_count(int* count);
 /* ---- stage A: window extraction + detrend + taper multiply (custom HIP) ---------------
  * Replaces _sliding_window (transforms.py:1311-1374), detrend (:1798-1915) and the taper
  * broadcast-multiply of _multitaper_fft (:1402-1404), fused, no window copy.
- *   y[n][w][r][k][c] = (x[w*step+n][r][c] - trend) * h[k][n]   for n <  min(L, N)
+ *   y[w][r][k][c][n] = (x[w*step+n][r][c] - trend) * h[k][n]   for n <  min(L, N)
  *                    = 0                                        for min(L,N) <= n < N
+ * (one row of N samples per transform, n fastest: the layout rocFFT streams at full rate)
  * The caller folds the reference's sqrt(fs) taper scaling and the 1/fs of
  * transforms.py:1405 into h (h = tapers^T / fs). */
 int sc_taper_windows_f32(const float* d_x, int64_t T, int64_t R, int64_t C,
@@ -120,8 +121,11 @@ int sc_taper_windows_f32(const float* d_x, int64_t T, int64_t R, int64_t C,
 
 /* ---- stage A: batched real-to-complex FFT (rocFFT) -----------------------------------
  * Replaces fft(projected, n=N, axis=-2) of transforms.py:1405 (scipy.fft / cupyx.scipy.fft).
- * Input  y[N][batch] float  (stride batch along time, distance 1 between transforms),
- * output X[F][batch] float2 (F = N/2+1), i.e. both sides keep "batch fastest". */
+ * Input  y[batch][N] float (the rows sc_taper_windows_f32 writes), output X[F][batch] float2
+ * (F = N/2+1, frequency-major like every spectra tensor here).  The plan transforms the rows in
+ * unit-stride chunks into a scratch it owns (64 MB, cache-resident) and a tiled transpose moves
+ * each chunk into X, zeroing the imaginary part of the DC / Nyquist rows on the way;
+ * sc_fft_plan_work_bytes reports the device memory the plan holds. */
 int sc_fft_plan_create(sc_fft_plan** plan, int64_t N, int64_t batch);
 int sc_fft_plan_work_bytes(const sc_fft_plan* plan, size_t* bytes);
 int sc_fft_execute(sc_fft_plan* plan, const float* d_y, void* d_X /*float2*/, void* stream);

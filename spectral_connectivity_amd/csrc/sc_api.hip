@@ -26,12 +26,16 @@ extern "C" int sc_device_count(int* count) {
 }
 
 // ------------------------------------------------------------------------------- rocFFT
+// A plan transforms `chunk` rows at a time (unit stride on both sides: the layout rocFFT streams at full rate)
+// into a scratch Z[chunk][F] it owns, and a tiled transpose moves every chunk into the frequency-major X.  The
+// scratch is sized to stay inside the 256 MB memory-side cache, so the transpose reads it back without touching HBM.
 struct sc_fft_plan {
-    rocfft_plan plan;
+    rocfft_plan plan, tail_plan;          // chunk rows; the last batch % chunk rows
     rocfft_execution_info info;
-    void* work;
+    void* work;                           // rocFFT work buffer (the larger of the two plans')
+    float2* Z;                            // [chunk][F]
     size_t work_bytes;
-    int64_t N, batch;
+    int64_t N, batch, chunk, tail;
 };
 
 static int g_rocfft_ready = 0;
@@ -46,6 +50,27 @@ static int g_rocfft_ready = 0;
         }                                                                           \
     } while (0)
 
+static int make_r2c_rows(rocfft_plan* plan, int64_t N, int64_t rows) {
+    rocfft_plan_description desc = nullptr;
+    SC_CHECK_FFT(rocfft_plan_description_create(&desc));
+    size_t one[1] = {1};
+    const size_t F = (size_t)(N / 2 + 1);
+    SC_CHECK_FFT(rocfft_plan_description_set_data_layout(
+        desc, rocfft_array_type_real, rocfft_array_type_hermitian_interleaved, nullptr, nullptr,
+        1, one, (size_t)N, 1, one, F));
+    size_t lengths[1] = {(size_t)N};
+    const rocfft_status s = rocfft_plan_create(plan, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
+                                               rocfft_precision_single, 1, lengths, (size_t)rows, desc);
+    rocfft_plan_description_destroy(desc);
+    if (s != rocfft_status_success) {
+        sc_set_error("rocfft_plan_create(N=%lld, rows=%lld) failed: status %d", (long long)N, (long long)rows, (int)s);
+        return SC_EFFT;
+    }
+    return SC_OK;
+}
+
+extern "C" int sc_fft_plan_destroy(sc_fft_plan* plan);
+
 extern "C" int sc_fft_plan_create(sc_fft_plan** out, int64_t N, int64_t batch) {
     SC_REQUIRE(out != nullptr, "plan out pointer is NULL");
     SC_REQUIRE(N >= 1 && batch >= 1, "N and batch must be positive");
@@ -53,35 +78,35 @@ extern "C" int sc_fft_plan_create(sc_fft_plan** out, int64_t N, int64_t batch) {
     sc_fft_plan* p = new sc_fft_plan();
     memset(p, 0, sizeof(*p));
     p->N = N; p->batch = batch;
-    rocfft_plan_description desc = nullptr;
-    SC_CHECK_FFT(rocfft_plan_description_create(&desc));
-    // both sides "batch fastest": element stride = batch, distance between transforms = 1
-    size_t stride[1] = {(size_t)batch};
-    SC_CHECK_FFT(rocfft_plan_description_set_data_layout(
-        desc, rocfft_array_type_real, rocfft_array_type_hermitian_interleaved, nullptr, nullptr,
-        1, stride, 1, 1, stride, 1));
-    size_t lengths[1] = {(size_t)N};
-    rocfft_status s = rocfft_plan_create(&p->plan, rocfft_placement_notinplace,
-                                         rocfft_transform_type_real_forward, rocfft_precision_single,
-                                         1, lengths, (size_t)batch, desc);
-    rocfft_plan_description_destroy(desc);
-    if (s != rocfft_status_success) {
-        sc_set_error("rocfft_plan_create(N=%lld, batch=%lld) failed: status %d", (long long)N,
-                     (long long)batch, (int)s);
-        delete p;
+    const int64_t F = N / 2 + 1;
+    int64_t chunk = ((int64_t)(64u << 20) / (F * 8)) & ~(int64_t)63;      // 64 MB of Z, whole 64-row tiles
+    if (chunk < 64) chunk = 64;
+    if (chunk > batch) chunk = batch;
+    p->chunk = chunk;
+    p->tail = batch % chunk;
+    int rc = make_r2c_rows(&p->plan, N, chunk);
+    if (rc == SC_OK && p->tail) rc = make_r2c_rows(&p->tail_plan, N, p->tail);
+    if (rc != SC_OK) { sc_fft_plan_destroy(p); return rc; }
+    size_t w1 = 0, w2 = 0;
+    if (rocfft_plan_get_work_buffer_size(p->plan, &w1) != rocfft_status_success ||
+        (p->tail_plan && rocfft_plan_get_work_buffer_size(p->tail_plan, &w2) != rocfft_status_success) ||
+        rocfft_execution_info_create(&p->info) != rocfft_status_success) {
+        sc_set_error("rocFFT work-buffer query failed (N=%lld)", (long long)N);
+        sc_fft_plan_destroy(p);
         return SC_EFFT;
     }
-    SC_CHECK_FFT(rocfft_plan_get_work_buffer_size(p->plan, &p->work_bytes));
-    SC_CHECK_FFT(rocfft_execution_info_create(&p->info));
-    if (p->work_bytes) {
-        if (hipMalloc(&p->work, p->work_bytes) != hipSuccess) {
-            sc_set_error("hipMalloc of %zu-byte rocFFT work buffer failed", p->work_bytes);
-            rocfft_execution_info_destroy(p->info);
-            rocfft_plan_destroy(p->plan);
-            delete p;
-            return SC_ENOMEM;
-        }
-        SC_CHECK_FFT(rocfft_execution_info_set_work_buffer(p->info, p->work, p->work_bytes));
+    p->work_bytes = w1 > w2 ? w1 : w2;
+    if ((p->work_bytes && hipMalloc(&p->work, p->work_bytes) != hipSuccess) ||
+        hipMalloc((void**)&p->Z, (size_t)chunk * F * sizeof(float2)) != hipSuccess) {
+        sc_set_error("hipMalloc of the FFT plan's buffers failed (%zu + %zu bytes)", p->work_bytes,
+                     (size_t)chunk * F * sizeof(float2));
+        sc_fft_plan_destroy(p);
+        return SC_ENOMEM;
+    }
+    if (p->work_bytes && rocfft_execution_info_set_work_buffer(p->info, p->work, p->work_bytes) != rocfft_status_success) {
+        sc_set_error("rocfft_execution_info_set_work_buffer failed");
+        sc_fft_plan_destroy(p);
+        return SC_EFFT;
     }
     *out = p;
     return SC_OK;
@@ -89,30 +114,56 @@ extern "C" int sc_fft_plan_create(sc_fft_plan** out, int64_t N, int64_t batch) {
 
 extern "C" int sc_fft_plan_work_bytes(const sc_fft_plan* plan, size_t* bytes) {
     SC_REQUIRE(plan && bytes, "NULL argument");
-    *bytes = plan->work_bytes;
+    *bytes = plan->work_bytes + (size_t)plan->chunk * (plan->N / 2 + 1) * sizeof(float2);
     return SC_OK;
 }
 
+// Z[rows][F] -> X[f][b_off + row] through a 64 x 32 LDS tile: 256-byte reads along f, 512-byte writes along the batch.
 // The DC and (even N) Nyquist coefficients of a real sequence are exactly real.  The reference's transform
 // (and the fused FFT kernels here) return them so, which is what makes PLI / wPLI exactly 0 at those bins
 // (connectivity.py:982-1028: weights < eps -> 1); a generic R2C leaves rounding noise in the imaginary part,
-// and sum Im / sum |Im| of noise is O(1).  X is [F][batch], row f = frequency bin.
-__global__ void real_bins_kernel(float2* X, int64_t batch, int64_t nyquist_row) {
-    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= batch) return;
-    X[b].y = 0.f;
-    if (nyquist_row > 0) X[nyquist_row * batch + b].y = 0.f;
+// and sum Im / sum |Im| of noise is O(1): the transpose zeroes it on the way through.
+__global__ void __launch_bounds__(256) rows_to_bins_kernel(const float2* __restrict__ Z, float2* __restrict__ X, int64_t rows,
+                                                            int64_t F, int64_t batch, int64_t b_off, int64_t nyquist_row) {
+    __shared__ float2 tile[64][33];
+    const int t = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * 64, f0 = (int64_t)blockIdx.y * 32;
+    {
+        const int fi = t & 31, ri = t >> 5;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t r = r0 + ri + 8 * j, f = f0 + fi;
+            if (r < rows && f < F) tile[ri + 8 * j][fi] = Z[r * F + f];
+        }
+    }
+    __syncthreads();
+    {
+        const int ri = t & 63, fi = t >> 6;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t f = f0 + fi + 4 * j, r = r0 + ri;
+            if (r < rows && f < F) {
+                float2 v = tile[ri][fi + 4 * j];
+                if (f == 0 || f == nyquist_row) v.y = 0.f;
+                X[f * batch + b_off + r] = v;
+            }
+        }
+    }
 }
 
 extern "C" int sc_fft_execute(sc_fft_plan* plan, const float* d_y, void* d_X, void* stream) {
     SC_REQUIRE(plan && d_y && d_X, "NULL argument");
     SC_CHECK_FFT(rocfft_execution_info_set_stream(plan->info, stream));
-    void* in[1] = {(void*)d_y};
-    void* outb[1] = {d_X};
-    SC_CHECK_FFT(rocfft_execute(plan->plan, in, outb, plan->info));
-    const int64_t nyq = (plan->N % 2 == 0) ? plan->N / 2 : 0;
-    hipLaunchKernelGGL(real_bins_kernel, dim3((unsigned)((plan->batch + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (float2*)d_X, plan->batch, nyq);
+    const int64_t F = plan->N / 2 + 1;
+    const int64_t nyq = (plan->N % 2 == 0) ? plan->N / 2 : -1;
+    for (int64_t off = 0; off < plan->batch; off += plan->chunk) {
+        const int64_t rows = plan->batch - off < plan->chunk ? plan->batch - off : plan->chunk;
+        void* in[1] = {(void*)(d_y + off * plan->N)};
+        void* outb[1] = {plan->Z};
+        SC_CHECK_FFT(rocfft_execute(rows == plan->chunk ? plan->plan : plan->tail_plan, in, outb, plan->info));
+        hipLaunchKernelGGL(rows_to_bins_kernel, dim3((unsigned)((rows + 63) / 64), (unsigned)((F + 31) / 32)), dim3(256), 0,
+                           (hipStream_t)stream, (const float2*)plan->Z, (float2*)d_X, rows, F, plan->batch, off, nyq);
+    }
     SC_CHECK_HIP(hipGetLastError());
     return SC_OK;
 }
@@ -121,7 +172,9 @@ extern "C" int sc_fft_plan_destroy(sc_fft_plan* plan) {
     if (!plan) return SC_OK;
     if (plan->info) rocfft_execution_info_destroy(plan->info);
     if (plan->plan) rocfft_plan_destroy(plan->plan);
+    if (plan->tail_plan) rocfft_plan_destroy(plan->tail_plan);
     if (plan->work) (void)hipFree(plan->work);
+    if (plan->Z) (void)hipFree(plan->Z);
     delete plan;
     return SC_OK;
 }

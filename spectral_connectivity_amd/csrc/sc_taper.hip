@@ -1,12 +1,14 @@
-// sc_taper.hip -- fused sliding-window extraction + detrend + DPSS taper multiply.
+// sc_taper.hip -- fused sliding-window extraction + detrend + DPSS taper multiply (any window length; the
+// power-of-two lengths take sc_mtfft.hip instead and never materialise the tapered windows).
 //
-// One workgroup = one window w and 64 consecutive (trial, channel) columns of x[t][r*C+c];
-// lanes run along the channel-fastest axis, so every global load/store of a wave is one
-// contiguous segment (x is (T,R,C) with C fastest -- no transpose, no LDS staging needed).
-// The 4 waves of the group split the L samples of the window: pass 1 accumulates the trend
-// sums in fp64 (a DC offset >> signal would otherwise leak through an fp32 mean), LDS
-// combines the 4 partial sums, pass 2 re-reads its slice (L2-resident), subtracts the trend
-// and writes the K tapered copies time-major: y[n][w][r][k][c].
+// One workgroup = one window w and 64 consecutive (trial, channel) columns of x[t][r*C+c]; lanes run along the
+// channel-fastest axis for the loads, so every global load of a wave is one contiguous segment.  The 4 waves
+// split the L samples of the window: pass 1 accumulates the trend sums in fp64 (a DC offset >> signal would
+// otherwise leak through an fp32 mean), LDS combines the 4 partial sums.  Pass 2 re-reads the window (L2-
+// resident) 64 samples at a time into an LDS tile, subtracts the trend, and writes the K tapered copies ROW-major,
+//     y[w][r][k][c][n],   n fastest,
+// with the lanes along n: rocFFT's unit-stride batched real transform runs at stream rate on that layout, while
+// its strided plans (time-major y) spend 8x the transform's own time in gather / scatter kernels.
 #include "sc_common.h"
 
 __global__ void __launch_bounds__(256)
@@ -15,10 +17,12 @@ taper_windows_kernel(const float* __restrict__ x, float* __restrict__ y,
                      int W, int N, int detrend) {
     __shared__ double s_sum[4][64];
     __shared__ double s_sumt[4][64];
+    __shared__ float tile[64][65];
     const int lane = threadIdx.x & 63;
     const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave id: slice of L
     const int w = blockIdx.y;
-    const int64_t rc = (int64_t)blockIdx.x * 64 + lane;
+    const int64_t rc0 = (int64_t)blockIdx.x * 64;
+    const int64_t rc = rc0 + lane;
     const bool live = rc < RC;
     const int lq0 = (int)(((int64_t)L * q) / 4), lq1 = (int)(((int64_t)L * (q + 1)) / 4);
     const float* xw = x + (int64_t)w * step * RC + (live ? rc : 0);
@@ -49,26 +53,37 @@ taper_windows_kernel(const float* __restrict__ x, float* __restrict__ y,
             b = (sum - a * St) / n;
         }
     }
-    if (!live) return;
-    const int r = (int)(rc / C), c = (int)(rc % C);
-    const int64_t WRKC = (int64_t)W * (RC / C) * K * C;   // elements per time sample of y
-    float* yb = y + ((int64_t)w * (RC / C) + r) * K * C + c;
+    const int64_t R = RC / C;
     const int nmax = L < N ? L : N;
     const double invL = 1.0 / (double)L;
-    for (int l = lq0; l < lq1 && l < nmax; ++l) {
-        const double t = (double)(l + 1) * invL;
-        const float v = (float)((double)xw[(int64_t)l * RC] - (a * t + b));
-        float* yl = yb + (int64_t)l * WRKC;
-        for (int k = 0; k < K; ++k) yl[(int64_t)k * C] = v * tapers[(int64_t)k * L + l];
-    }
-    // zero padding L <= n < N, split over the 4 waves like the samples
-    if (N > L) {
-        const int pad = N - L;
-        const int p0 = L + (int)(((int64_t)pad * q) / 4), p1 = L + (int)(((int64_t)pad * (q + 1)) / 4);
-        for (int n = p0; n < p1; ++n) {
-            float* yl = yb + (int64_t)n * WRKC;
-            for (int k = 0; k < K; ++k) yl[(int64_t)k * C] = 0.0f;
+    for (int l0 = 0; l0 < N; l0 += 64) {
+        // 16 samples per wave into the tile, lanes along the columns
+#pragma unroll 4
+        for (int j = 0; j < 16; ++j) {
+            const int l = l0 + q * 16 + j;
+            float v = 0.0f;                                   // zero padding nmax <= n < N
+            if (live && l < nmax) {
+                const double t = (double)(l + 1) * invL;
+                v = (float)((double)xw[(int64_t)l * RC] - (a * t + b));
+            }
+            tile[q * 16 + j][lane] = v;
         }
+        __syncthreads();
+        // 16 columns per wave out of the tile, lanes along n
+        const int n = l0 + lane;
+        if (n < N) {
+            for (int k = 0; k < K; ++k) {
+                const float h = (n < nmax) ? tapers[(int64_t)k * L + n] : 0.0f;
+                for (int jc = 0; jc < 16; ++jc) {
+                    const int col = q * 16 + jc;
+                    const int64_t rcc = rc0 + col;
+                    if (rcc >= RC) break;
+                    const int64_t r = rcc / C, c = rcc - r * C;
+                    y[((((int64_t)w * R + r) * K + k) * C + c) * N + n] = tile[lane][col] * h;
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 

@@ -36,7 +36,7 @@ def _ptr(t):
 
 
 def fft_plan(n_fft, batch):
-    """rocFFT real-forward plan, 'batch fastest' on both sides (cached per (N, batch, device))."""
+    """rocFFT real-forward plan: rows [batch][N] in, frequency-major [F][batch] out (cached per (N, batch, device))."""
     key = (int(n_fft), int(batch), torch.cuda.current_device())
     plan = _plan_cache.get(key)
     if plan is None:
@@ -124,7 +124,7 @@ def multitaper_spectra(x, tapers_over_fs, n_window, n_step, n_fft, n_windows, de
             mark("mtfft_fused")
         return DeviceSpectra(X, (F, n_windows, R, K, C), strides, n_fft, real_input=True)
     batch = n_windows * R * K * C
-    y = torch.empty((n_fft, batch), dtype=torch.float32, device=x.device)
+    y = torch.empty((batch, n_fft), dtype=torch.float32, device=x.device)
     _lib.check(lib.sc_taper_windows_f32(_ptr(x), T, R, C, L, n_step, n_windows, n_fft,
                                         _ptr(tapers_over_fs), K, _lib.DETREND[detrend_type],
                                         _ptr(y), _stream()), "sc_taper_windows_f32")
