@@ -203,8 +203,8 @@ __global__ void __launch_bounds__(256) mtfft_kernel(MtArgs p) {
 }
 
 // ----------------------------------------------------------------------------------------
-// Radix-16 variant for N = 256 (16x16), 1024 (16x16x4), 4096 (16x16x16): every thread owns 16
-// points per pass, so a 256-point transform is TWO register-resident radix-16 butterflies with
+// Radix-16 variant for N = 64 (16x4), 128 (16x8), 256 (16x16), 512 (16x16x2), 1024 (16x16x4), 4096 (16x16x16):
+// every thread owns 16 points per pass, so a 256-point transform is TWO register-resident radix-16 butterflies with
 // one LDS exchange between them (the radix-4 kernel above needs four passes, eight barriers and
 // a separate pack pass).  Pass 1 reads the detrended window tile directly (x * taper, packed two
 // channels per complex sequence), so the tapered sequences are never materialised.  The exchange
@@ -240,6 +240,21 @@ __device__ __forceinline__ void dft16(float2 (&x)[16], float2 (&o)[16]) {
     }
 }
 
+// forward 8-point DFT, natural order in and out: even/odd 4-point DFTs, X[k] = E[k] + W8^k O[k]
+__device__ __forceinline__ void dft8r(float2 (&x)[8]) {
+    constexpr float H = 0.70710678118654752f;
+    float2 e0 = x[0], e1 = x[2], e2 = x[4], e3 = x[6], o0 = x[1], o1 = x[3], o2 = x[5], o3 = x[7];
+    dft4r(e0, e1, e2, e3);
+    dft4r(o0, o1, o2, o3);
+    o1 = cmulc(o1, H, -H);
+    o2 = make_float2(o2.y, -o2.x);
+    o3 = cmulc(o3, -H, -H);
+    x[0] = make_float2(e0.x + o0.x, e0.y + o0.y); x[4] = make_float2(e0.x - o0.x, e0.y - o0.y);
+    x[1] = make_float2(e1.x + o1.x, e1.y + o1.y); x[5] = make_float2(e1.x - o1.x, e1.y - o1.y);
+    x[2] = make_float2(e2.x + o2.x, e2.y + o2.y); x[6] = make_float2(e2.x - o2.x, e2.y - o2.y);
+    x[3] = make_float2(e3.x + o3.x, e3.y + o3.y); x[7] = make_float2(e3.x - o3.x, e3.y - o3.y);
+}
+
 // Optional phase timers (tools/mtfft_trace.py builds a copy of the library with -DMT_TRACE): shader-clock
 // cycles of wave 0 of workgroup 0, summed over the tapers: [load+detrend, wait at the top barrier, passes, split+store issue].
 #ifdef MT_TRACE
@@ -262,7 +277,7 @@ extern "C" int sc_debug_mtfft_trace(unsigned long long* out, int reset) {
 #endif
 
 template <int LOG2N>
-__global__ void __launch_bounds__(256, LOG2N == 8 ? 4 : 1) mtfft16_kernel(MtArgs p) {
+__global__ void __launch_bounds__(256, LOG2N <= 8 ? 4 : (LOG2N == 9 ? 3 : 1)) mtfft16_kernel(MtArgs p) {
     constexpr int N = 1 << LOG2N;
     constexpr int TPF = N / 16;          // threads per FFT: 16 points each
     constexpr int NF = 256 / TPF;        // complex FFTs (channel pairs) per workgroup
@@ -413,11 +428,12 @@ __global__ void __launch_bounds__(256, LOG2N == 8 ? 4 : 1) mtfft16_kernel(MtArgs
         // the next taper travels HBM/L2 -> registers under this taper's passes and is parked in the other
         // LDS buffer before the stores go out (a load issued AFTER the stores would wait for them: vmcnt
         // retires in order)
-        float hn[N / 256];
+        constexpr int HN = (N + 255) / 256;
+        float hn[HN];
         const bool fetch_next = !resident && k + 1 < p.K;
         if (fetch_next) {
 #pragma unroll
-            for (int j = 0; j < N / 256; ++j) {
+            for (int j = 0; j < HN; ++j) {
                 const int n = tid + 256 * j;
                 hn[j] = (n < L) ? p.tapers[(int64_t)(k + 1) * L + n] : 0.f;
             }
@@ -437,6 +453,31 @@ __global__ void __launch_bounds__(256, LOG2N == 8 ? 4 : 1) mtfft16_kernel(MtArgs
 #pragma unroll
         for (int u = 0; u < 16; ++u) zf[PHYS(16 * i + u)] = o[u];
         XBAR();
+        if constexpr (LOG2N < 8) {
+            // N = 16 R2 (R2 = 4, 8): pass 2 is radix R2 with P = 16 -- thread i takes the outputs u = i + R2 b:
+            // X[u + 16 v] = sum_j W_N^(j u) W_R2^(j v) Y[j][u], in place (it writes back exactly the slots it read)
+            constexpr int R2 = N / 16;
+#pragma unroll
+            for (int b = 0; b < 16 / R2; ++b) {
+                const int u = i + R2 * b;
+                float2 q[R2];
+#pragma unroll
+                for (int j = 0; j < R2; ++j) {
+                    const float2 v = zf[PHYS(16 * j + u)];
+                    q[j] = (j == 0) ? v : cmul(v, tw[j * u]);
+                }
+                if constexpr (R2 == 4) dft4r(q[0], q[1], q[2], q[3]); else dft8r(q);
+#pragma unroll
+                for (int v = 0; v < R2; ++v) a[b * R2 + v] = q[v];
+            }
+#pragma unroll
+            for (int b = 0; b < 16 / R2; ++b) {
+                const int u = i + R2 * b;
+#pragma unroll
+                for (int v = 0; v < R2; ++v) zf[PHYS(u + 16 * v)] = a[b * R2 + v];
+            }
+            __syncthreads();
+        } else
         // pass 2: radix 16, P = 16
         {
             const int kk = i & 15;
@@ -451,6 +492,23 @@ __global__ void __launch_bounds__(256, LOG2N == 8 ? 4 : 1) mtfft16_kernel(MtArgs
 #pragma unroll
             for (int u = 0; u < 16; ++u) zf[PHYS(j + 16 * u)] = o[u];
             if constexpr (LOG2N == 8) __syncthreads(); else XBAR();
+        }
+        if constexpr (LOG2N == 9) {         // pass 3: radix 2, P = 256, eight butterflies per thread
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const int ib = i + b * TPF;            // 0..255, k = ib
+                const float2 u0 = zf[PHYS(ib)], u1 = cmul(zf[PHYS(ib + 256)], tw[ib]);
+                a[2 * b] = make_float2(u0.x + u1.x, u0.y + u1.y);
+                a[2 * b + 1] = make_float2(u0.x - u1.x, u0.y - u1.y);
+            }
+            // in place: every thread writes back exactly the slots it read
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const int ib = i + b * TPF;
+                zf[PHYS(ib)] = a[2 * b];
+                zf[PHYS(ib + 256)] = a[2 * b + 1];
+            }
+            __syncthreads();
         }
         if constexpr (LOG2N == 10) {        // pass 3: radix 4, P = 256, four butterflies per thread
 #pragma unroll
@@ -488,7 +546,7 @@ __global__ void __launch_bounds__(256, LOG2N == 8 ? 4 : 1) mtfft16_kernel(MtArgs
         if (fetch_next) {
             float* hnext = hk + ((k + 1) & 1) * L;
 #pragma unroll
-            for (int j = 0; j < N / 256; ++j) {
+            for (int j = 0; j < HN; ++j) {
                 const int n = tid + 256 * j;
                 if (n < L) hnext[n] = hn[j];
             }
@@ -615,10 +673,10 @@ extern "C" int sc_multitaper_fft_f32(const float* d_x, int64_t T, int64_t R, int
              (int)step, (int)W, (int)K, detrend_type};
     hipStream_t s = (hipStream_t)stream;
     switch (N) {
-    case 64: return launch_mt<6, 64>(a, s);
-    case 128: return launch_mt<7, 64>(a, s);
+    case 64: return launch_mt16<6>(a, s);
+    case 128: return launch_mt16<7>(a, s);
     case 256: return launch_mt16<8>(a, s);
-    case 512: return launch_mt<9, 16>(a, s);
+    case 512: return launch_mt16<9>(a, s);
     case 1024: return launch_mt16<10>(a, s);
     case 2048: return launch_mt<11, 8>(a, s);
     case 4096: return launch_mt16<12>(a, s);
