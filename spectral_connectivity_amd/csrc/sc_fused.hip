@@ -649,6 +649,166 @@ static int launch_fused(const FusedArgs& a, hipStream_t stream) {
     return SC_OK;
 }
 
+// ---- up to 48 channels: f32 VALU kernel ------------------------------------------------------------------
+// The MFMA kernel above stages 32-row chunks of 32-channel blocks whatever C is, so its cost per observation row
+// does not fall with C: at 32 channels it runs 1.0 TB/s of input, at 8 channels 0.3 TB/s, where the arithmetic
+// (C (C+1) / 2 pairs x 6 flops-ish per row) would leave the stream HBM-bound.  Here a thread owns a 2 x 2 block of
+// channel pairs and every S-th observation: two 16-byte LDS reads and 24 VALU operations per row for four
+// cross-spectra (re, im) and their |Im| sums, exact f32 products, two-level f32 sums (512 rows per first-level
+// chain).  S = 448 / #blocks slices share a workgroup (7 waves) and are summed in a fixed order at the end.
+// At the cfg3 input volume (6.5 GB) it takes 1.1-1.3 ms for 2-8 channels (5-6 TB/s: the read stream), 1.8 ms
+// for 16, 2.9 ms for 32 (VALU-bound from ~16 channels on) against 41 / 20 / 10 / 6.3 ms on the MFMA kernel.
+// Rows are staged HBM -> registers -> LDS in chunks (double buffered, one barrier per chunk).  Same records,
+// same (bin, part) split and the same combine kernel as the MFMA path.
+#define SM_THREADS 448
+#define SM_CHUNK_BYTES (24 * 1024)
+
+template <bool ABS>
+__global__ void __launch_bounds__(SM_THREADS) small_csm_absim_kernel(FusedArgs p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int bin = blockIdx.x / p.n_split, part = blockIdx.x - bin * p.n_split;
+    const int g = bin / p.F, f = bin - g * p.F;
+    ScStage st = p.st;
+    st.base = p.st.base + (int64_t)f * st.ax.sF + sc_group_offset(st.ax, g);
+    const int nc32 = (p.st.n_obs + FU_OC - 1) / FU_OC;
+    const int o_lo = (int)((int64_t)part * nc32 / p.n_split) * FU_OC;
+    int o_hi = (int)((int64_t)(part + 1) * nc32 / p.n_split) * FU_OC;
+    if (o_hi > p.st.n_obs) o_hi = p.st.n_obs;
+    float* rec = (part == 0 ? p.accum : p.ws + (int64_t)(part - 1) * p.n_bins * p.floats_per_bin) +
+                 (int64_t)bin * p.floats_per_bin;
+
+    const int C = st.C, B = C >> 1, nbk = B * (B + 1) / 2;     // C even: 2 x 2 blocks of pairs (bi <= bj)
+    const int S = SM_THREADS / nbk;                             // observation slices (>= 1: nbk <= 300)
+    const int s = tid / nbk, b = tid - s * nbk;
+    const bool active = s < S;
+    int bi = 0, bj = 0;
+    { int rem = b, len = B; while (rem >= len) { rem -= len; ++bi; --len; } bj = bi + rem; }
+    const int RS = 2 * C;                                       // floats per staged row
+    const int half = C >> 1;                                    // float4 per row
+    int OC = SM_CHUNK_BYTES / (RS * 4);
+    OC -= OC % S;                                               // every slice gets the same number of rows per chunk
+    if (OC > 16 * S) OC = 16 * S;
+    const int per_thread = OC / S;
+    float* buf0 = reinterpret_cast<float*>(smem);
+    float* buf1 = buf0 + (size_t)OC * RS;
+    const int total4 = OC * half;
+    constexpr int EMAX = (SM_CHUNK_BYTES / 16 + SM_THREADS - 1) / SM_THREADS;
+    float4 stage[EMAX];
+    auto load = [&](int o0) {
+#pragma unroll
+        for (int i = 0; i < EMAX; ++i) {
+            const int e = tid + i * SM_THREADS;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < total4) {
+                const int row = e / half, q = e - row * half, o = o0 + row;
+                if (o < o_hi) v = *reinterpret_cast<const float4*>(st.base + sc_stage_obs_offset(st, o) + 2 * q);
+            }
+            stage[i] = v;
+        }
+    };
+    auto store = [&](float* dst) {
+#pragma unroll
+        for (int i = 0; i < EMAX; ++i) {
+            const int e = tid + i * SM_THREADS;
+            if (e < total4) {
+                const int row = e / half, q = e - row * half;
+                *reinterpret_cast<float4*>(dst + row * RS + 4 * q) = stage[i];
+            }
+        }
+    };
+
+    float re[4] = {0.f, 0.f, 0.f, 0.f}, im[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
+    float re2[4] = {0.f, 0.f, 0.f, 0.f}, im2[4] = {0.f, 0.f, 0.f, 0.f}, ab2[4] = {0.f, 0.f, 0.f, 0.f};
+    const int n_chunks = (o_hi - o_lo + OC - 1) / OC;
+    const int fold_every = (512 + per_thread - 1) / per_thread;        // chunks per first-level chain
+    if (n_chunks > 0) { load(o_lo); store(buf0); }
+    __syncthreads();
+    for (int ch = 0; ch < n_chunks; ++ch) {
+        const float* cur = (ch & 1) ? buf1 : buf0;
+        float* nxt = (ch & 1) ? buf0 : buf1;
+        const bool more = ch + 1 < n_chunks;
+        if (more) load(o_lo + (ch + 1) * OC);
+        if (active) {
+            const float* ra = cur + 4 * bi;
+            const float* rb = cur + 4 * bj;
+            for (int k = 0; k < per_thread; ++k) {
+                const int row = s + S * k;
+                const float4 xa = *reinterpret_cast<const float4*>(ra + row * RS);     // x_{2bi}, x_{2bi+1}
+                const float4 xb = *reinterpret_cast<const float4*>(rb + row * RS);     // x_{2bj}, x_{2bj+1}
+                const float ar[2] = {xa.x, xa.z}, ai[2] = {xa.y, xa.w}, br[2] = {xb.x, xb.z}, bm[2] = {xb.y, xb.w};
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int v = 0; v < 2; ++v) {
+                        const int e = 2 * u + v;
+                        re[e] = fmaf(ar[u], br[v], fmaf(ai[u], bm[v], re[e]));
+                        const float d = fmaf(ai[u], br[v], -(ar[u] * bm[v]));
+                        im[e] += d;
+                        if constexpr (ABS) ab[e] += fabsf(d);
+                    }
+            }
+        }
+        if ((ch + 1) % fold_every == 0 || !more) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                re2[e] += re[e]; im2[e] += im[e]; ab2[e] += ab[e];
+                re[e] = 0.f; im[e] = 0.f; ab[e] = 0.f;
+            }
+        }
+        if (more) store(nxt);
+        __syncthreads();
+    }
+    // slices -> one total per (block, quantity), summed in slice order; then the record image (zero padded tiles,
+    // both triangles of the diagonal tiles like an MFMA tile) is assembled in LDS and copied out coalesced
+    float* red = reinterpret_cast<float*>(smem);                         // [12][SM_THREADS]
+    float* image = red + 12 * SM_THREADS;                                // [3][n_tiles][256]
+    const int plane_f = p.n_tiles * SC_TILE_ELEMS;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        red[(e) * SM_THREADS + tid] = active ? re2[e] : 0.f;
+        red[(4 + e) * SM_THREADS + tid] = active ? im2[e] : 0.f;
+        red[(8 + e) * SM_THREADS + tid] = active ? ab2[e] : 0.f;
+    }
+    for (int i = tid; i < 3 * plane_f; i += SM_THREADS) image[i] = 0.f;
+    __syncthreads();
+    for (int item = tid; item < 12 * nbk; item += SM_THREADS) {
+        const int q = item / nbk, bb = item - q * nbk;                  // q = quantity * 4 + element
+        float acc = 0.f;
+        for (int ss = 0; ss < S; ++ss) acc += red[q * SM_THREADS + ss * nbk + bb];
+        int ti = 0, tj = 0;
+        { int rem = bb, len = B; while (rem >= len) { rem -= len; ++ti; --len; } tj = ti + rem; }
+        const int qty = q >> 2, e = q & 3, i = 2 * ti + (e >> 1), j = 2 * tj + (e & 1);
+        if (i > j) continue;                                             // lower half of a diagonal 2 x 2 block
+        float* pl = image + qty * plane_f + sc_tile_index(i >> 4, j >> 4, p.NB) * SC_TILE_ELEMS;
+        pl[(i & 15) * 16 + (j & 15)] = (qty == 1 && i == j) ? 0.f : acc;
+        if ((i >> 4) == (j >> 4) && i != j) pl[(j & 15) * 16 + (i & 15)] = (qty == 1) ? -acc : acc;
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * plane_f; i += SM_THREADS) rec[(int64_t)p.csm_plane * plane_f + i] = image[i];
+    if constexpr (ABS)
+        for (int i = tid; i < plane_f; i += SM_THREADS) rec[(int64_t)p.abs_plane * plane_f + i] = image[2 * plane_f + i];
+}
+
+static int launch_small(const FusedArgs& a, hipStream_t stream) {
+    size_t shmem = 2 * (size_t)SM_CHUNK_BYTES;
+    const size_t tail = (size_t)(12 * SM_THREADS + 3 * a.n_tiles * SC_TILE_ELEMS) * sizeof(float);
+    if (shmem < tail) shmem = tail;
+    if (a.abs_plane >= 0) {
+        (void)hipFuncSetAttribute((const void*)small_csm_absim_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        hipLaunchKernelGGL(small_csm_absim_kernel<true>, dim3((unsigned)(a.n_bins * a.n_split)), dim3(SM_THREADS), shmem, stream, a);
+    } else {
+        (void)hipFuncSetAttribute((const void*)small_csm_absim_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        hipLaunchKernelGGL(small_csm_absim_kernel<false>, dim3((unsigned)(a.n_bins * a.n_split)), dim3(SM_THREADS), shmem, stream, a);
+    }
+    SC_CHECK_HIP(hipGetLastError());
+    if (a.n_split > 1) {
+        hipLaunchKernelGGL(fused_combine_kernel, dim3(2048), dim3(256), 0, stream, a);
+        SC_CHECK_HIP(hipGetLastError());
+    }
+    return SC_OK;
+}
+
 // d_X may be NULL when only the shape is known: alignment is then assumed.
 static bool fused_ok(const void* d_X, const ScAxes& ax) {
     if (ax.C < 1 || ax.C > 128 || (ax.C & 1)) return false;
@@ -748,6 +908,9 @@ extern "C" int sc_fused_csm_absim_ws_f32(const void* d_X, const sc_spectra_desc*
     a.n_split = S;
     a.ws = (float*)d_workspace;
     hipStream_t s = (hipStream_t)stream;
+    // f32 VALU kernel below the measured crossover (same input volume as cfg3: 4.7 vs 5.1 ms at 48 channels with the
+    // |Im| plane, 3.0 vs 3.9 ms at 40 channels without; the MFMA kernel wins from 56 / 44 channels on)
+    if (ax.C <= (a.abs_plane >= 0 ? 48 : 42)) return launch_small(a, s);
     switch (a.NB32) {
     case 1: return launch_fused<1>(a, s);
     case 2: return launch_fused<2>(a, s);

@@ -204,10 +204,12 @@ def test_fused_fft_matches_oracle_and_rocfft(sc, N, L, C, det):
     close32(got, coef[..., : N // 2 + 1, :], what=f"rocfft N={N}")
 
 
-@pytest.mark.parametrize("C,R", [(128, 9), (96, 5), (64, 6), (24, 11), (6, 4), (128, 40)])
+@pytest.mark.parametrize("C,R", [(128, 9), (96, 5), (64, 6), (24, 11), (6, 4), (128, 40), (2, 50), (16, 300), (32, 7),
+                                 (34, 5), (42, 9), (44, 4), (48, 6), (50, 3)])
 def test_fused_stage_b_equals_separate_kernels(sc, C, R):
-    """Fused MFMA+VALU kernel against the separate CSM and |Im| kernels on the same spectra
-    (identical fp32 arithmetic per plane up to summation order of the VALU row split)."""
+    """The one-pass stage-B kernels -- bf16 MFMA + VALU from 50 channels on (44 without the |Im| plane), f32 VALU
+    below -- against the separate f32-MFMA CSM and |Im| kernels on the same spectra (identical fp32 arithmetic per
+    plane up to summation order)."""
     import torch
     from spectral_connectivity_amd import _lib, engine
     rng = np.random.default_rng(C)
@@ -234,7 +236,7 @@ def test_fused_stage_b_equals_separate_kernels(sc, C, R):
                 so.weighted_phase_lag_index(coef), what="wpli vs oracle")
 
 
-@pytest.mark.parametrize("C,R,split", [(128, 150, 3), (64, 130, 2), (128, 200, 5)])
+@pytest.mark.parametrize("C,R,split", [(128, 150, 3), (64, 130, 2), (128, 200, 5), (16, 400, 4), (40, 130, 3), (4, 900, 7)])
 def test_fused_stage_b_split_bins(sc, C, R, split, monkeypatch):
     """Several workgroups per bin (observation chunks split, partial records folded in a fixed order)
     give the sums of the one-workgroup-per-bin launch up to fp32 re-association, and repeat bit-exactly."""
