@@ -185,6 +185,17 @@ int64_t sc_fused_workspace_bytes(const sc_spectra_desc* desc, uint32_t planes);
 int sc_fused_csm_absim_ws_f32(const void* d_X /*float2*/, const sc_spectra_desc* desc, uint32_t planes,
                               float* d_accum, void* d_workspace, int64_t workspace_bytes, void* stream);
 
+/* SC_PLANE_UNIT of the record, sum over observations of s/|s| (phase_locking_value,
+ * pairwise_phase_consistency: connectivity.py:897-981), through the same kernels: s/|s| factorises into
+ * (x_i/|x_i|) conj(x_j/|x_j|), so the sum is the cross-spectral matrix of the unit phasors x/|x|
+ * (0/0 -> NaN like the reference's x/abs(x)).  Up to 42 channels the normalisation happens while the
+ * rows are staged; above, a normalised copy of the spectra goes to d_scratch first
+ * (sc_fused_unit_scratch_bytes, 0 when none is needed).  Shapes, workspace and split as above. */
+int64_t sc_fused_unit_scratch_bytes(const sc_spectra_desc* desc);
+int sc_fused_unit_ws_f32(const void* d_X /*float2*/, const sc_spectra_desc* desc, uint32_t planes,
+                         float* d_accum, void* d_workspace, int64_t workspace_bytes, void* d_scratch,
+                         int64_t scratch_bytes, void* stream);
+
 /* ---- stage C: measures epilogue ------------------------------------------------------
  * Elementwise measure algebra on accumulated sums (connectivity.py:612-1159): divides by
  * n_observations AFTER any cross-GPU reduction, applies the reference's eps clamps, NaN /

@@ -65,6 +65,9 @@ SYMBOLS = {
     "sc_fused_workspace_bytes": (c_int64, [POINTER(SpectraDesc), c_uint32]),
     "sc_fused_csm_absim_ws_f32": (c_int, [c_void_p, POINTER(SpectraDesc), c_uint32, c_void_p, c_void_p, c_int64,
                                           c_void_p]),
+    "sc_fused_unit_scratch_bytes": (c_int64, [POINTER(SpectraDesc)]),
+    "sc_fused_unit_ws_f32": (c_int, [c_void_p, POINTER(SpectraDesc), c_uint32, c_void_p, c_void_p, c_int64, c_void_p,
+                                     c_int64, c_void_p]),
     "sc_granger_workspace_bytes": (c_int, [c_int64, c_int64, c_int64, POINTER(c_size_t)]),
     "sc_granger_pairwise_f64": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_uint32, c_int64,
                                         c_void_p, c_int64, c_double, c_int, c_void_p, c_size_t, c_void_p,

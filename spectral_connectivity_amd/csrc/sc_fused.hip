@@ -663,7 +663,7 @@ static int launch_fused(const FusedArgs& a, hipStream_t stream) {
 #define SM_THREADS 448
 #define SM_CHUNK_BYTES (24 * 1024)
 
-template <bool ABS>
+template <bool ABS, bool NORM>
 __global__ void __launch_bounds__(SM_THREADS) small_csm_absim_kernel(FusedArgs p) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -702,7 +702,13 @@ __global__ void __launch_bounds__(SM_THREADS) small_csm_absim_kernel(FusedArgs p
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (e < total4) {
                 const int row = e / half, q = e - row * half, o = o0 + row;
-                if (o < o_hi) v = *reinterpret_cast<const float4*>(st.base + sc_stage_obs_offset(st, o) + 2 * q);
+                if (o < o_hi) {
+                    v = *reinterpret_cast<const float4*>(st.base + sc_stage_obs_offset(st, o) + 2 * q);
+                    if constexpr (NORM) {          // x / |x|: the CSM of these is sum s / |s| (0 / 0 -> NaN like the reference)
+                        const float ia = rsqrtf(v.x * v.x + v.y * v.y), ib = rsqrtf(v.z * v.z + v.w * v.w);
+                        v = make_float4(v.x * ia, v.y * ia, v.z * ib, v.w * ib);
+                    }
+                }
             }
             stage[i] = v;
         }
@@ -790,23 +796,35 @@ __global__ void __launch_bounds__(SM_THREADS) small_csm_absim_kernel(FusedArgs p
         for (int i = tid; i < plane_f; i += SM_THREADS) rec[(int64_t)p.abs_plane * plane_f + i] = image[2 * plane_f + i];
 }
 
-static int launch_small(const FusedArgs& a, hipStream_t stream) {
+template <bool ABS, bool NORM>
+static void launch_small_inst(const FusedArgs& a, size_t shmem, hipStream_t stream) {
+    auto k = small_csm_absim_kernel<ABS, NORM>;
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    hipLaunchKernelGGL(k, dim3((unsigned)(a.n_bins * a.n_split)), dim3(SM_THREADS), shmem, stream, a);
+}
+
+static int launch_small(const FusedArgs& a, bool normalize, hipStream_t stream) {
     size_t shmem = 2 * (size_t)SM_CHUNK_BYTES;
     const size_t tail = (size_t)(12 * SM_THREADS + 3 * a.n_tiles * SC_TILE_ELEMS) * sizeof(float);
     if (shmem < tail) shmem = tail;
-    if (a.abs_plane >= 0) {
-        (void)hipFuncSetAttribute((const void*)small_csm_absim_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        hipLaunchKernelGGL(small_csm_absim_kernel<true>, dim3((unsigned)(a.n_bins * a.n_split)), dim3(SM_THREADS), shmem, stream, a);
-    } else {
-        (void)hipFuncSetAttribute((const void*)small_csm_absim_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        hipLaunchKernelGGL(small_csm_absim_kernel<false>, dim3((unsigned)(a.n_bins * a.n_split)), dim3(SM_THREADS), shmem, stream, a);
-    }
+    if (normalize) launch_small_inst<false, true>(a, shmem, stream);
+    else if (a.abs_plane >= 0) launch_small_inst<true, false>(a, shmem, stream);
+    else launch_small_inst<false, false>(a, shmem, stream);
     SC_CHECK_HIP(hipGetLastError());
     if (a.n_split > 1) {
         hipLaunchKernelGGL(fused_combine_kernel, dim3(2048), dim3(256), 0, stream, a);
         SC_CHECK_HIP(hipGetLastError());
     }
     return SC_OK;
+}
+
+// U = X / |X| elementwise (0 -> NaN), the input of the unit-phasor accumulation on the matrix-core path
+__global__ void __launch_bounds__(256) unit_normalize_kernel(const float4* __restrict__ X, float4* __restrict__ U, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 v = X[i];
+        const float ia = rsqrtf(v.x * v.x + v.y * v.y), ib = rsqrtf(v.z * v.z + v.w * v.w);
+        U[i] = make_float4(v.x * ia, v.y * ia, v.z * ib, v.w * ib);
+    }
 }
 
 // d_X may be NULL when only the shape is known: alignment is then assumed.
@@ -848,9 +866,10 @@ static int fused_pick_split(int n_bins, int n_obs) {
     return best;
 }
 
-static int fused_setup(const void* d_X, const sc_spectra_desc* desc, uint32_t planes, FusedArgs* a, ScAxes* ax) {
+static int fused_setup(const void* d_X, const sc_spectra_desc* desc, uint32_t planes, bool unit, FusedArgs* a, ScAxes* ax) {
     SC_REQUIRE(desc, "NULL argument");
-    SC_REQUIRE(planes & SC_PLANE_CSM, "planes must contain SC_PLANE_CSM (SC_PLANE_ABS_IM is optional)");
+    if (unit) SC_REQUIRE(planes & SC_PLANE_UNIT, "planes must contain SC_PLANE_UNIT");
+    else SC_REQUIRE(planes & SC_PLANE_CSM, "planes must contain SC_PLANE_CSM (SC_PLANE_ABS_IM is optional)");
     sc_make_axes(desc, ax);
     SC_REQUIRE(ax->C >= 1 && ax->F >= 1 && ax->n_obs >= 1 && ax->n_groups >= 1, "empty dimension");
     if (!fused_ok(d_X, *ax)) {
@@ -867,6 +886,10 @@ static int fused_setup(const void* d_X, const sc_spectra_desc* desc, uint32_t pl
     a->floats_per_bin = (int64_t)sc_plane_count(planes) * a->n_tiles * SC_TILE_ELEMS;
     a->csm_plane = sc_plane_offset(planes, SC_PLANE_CSM);
     a->abs_plane = (planes & SC_PLANE_ABS_IM) ? sc_plane_offset(planes, SC_PLANE_ABS_IM) : -1;   // -1: CSM only
+    if (unit) {          // sum s / |s| = the CSM of x / |x|: the same kernels, pointed at the unit-phasor planes
+        a->csm_plane = sc_plane_offset(planes, SC_PLANE_UNIT);
+        a->abs_plane = -1;
+    }
     a->n_split = 1;
     a->ws = nullptr;
     return SC_OK;
@@ -875,17 +898,23 @@ static int fused_setup(const void* d_X, const sc_spectra_desc* desc, uint32_t pl
 extern "C" int64_t sc_fused_workspace_bytes(const sc_spectra_desc* desc, uint32_t planes) {
     FusedArgs a;
     ScAxes ax;
-    if (fused_setup(nullptr, desc, planes, &a, &ax) != SC_OK) return 0;
+    if (fused_setup(nullptr, desc, planes, !(planes & SC_PLANE_CSM), &a, &ax) != SC_OK) return 0;
     const int S = fused_pick_split(a.n_bins, ax.n_obs);
     return (int64_t)(S - 1) * a.n_bins * a.floats_per_bin * (int64_t)sizeof(float);
 }
 
-extern "C" int sc_fused_csm_absim_ws_f32(const void* d_X, const sc_spectra_desc* desc, uint32_t planes,
-                                         float* d_accum, void* d_workspace, int64_t workspace_bytes, void* stream) {
+// elements (float2) from the base pointer to the end of the last row the descriptor addresses
+static int64_t fused_span(const ScAxes& ax) {
+    return (int64_t)(ax.F - 1) * ax.sF + (int64_t)(ax.W - 1) * ax.sW + (int64_t)(ax.R - 1) * ax.sR +
+           (int64_t)(ax.K - 1) * ax.sK + ax.C;
+}
+
+static int fused_run(const void* d_X, const sc_spectra_desc* desc, uint32_t planes, bool unit, float* d_accum,
+                     void* d_workspace, int64_t workspace_bytes, void* d_scratch, int64_t scratch_bytes, void* stream) {
     SC_REQUIRE(d_X && desc && d_accum, "NULL argument");
     FusedArgs a;
     ScAxes ax;
-    const int rc = fused_setup(d_X, desc, planes, &a, &ax);
+    const int rc = fused_setup(d_X, desc, planes, unit, &a, &ax);
     if (rc != SC_OK) return rc;
     a.accum = d_accum;
     a.st.base = (const float2*)d_X;
@@ -910,13 +939,44 @@ extern "C" int sc_fused_csm_absim_ws_f32(const void* d_X, const sc_spectra_desc*
     hipStream_t s = (hipStream_t)stream;
     // f32 VALU kernel below the measured crossover (same input volume as cfg3: 4.7 vs 5.1 ms at 48 channels with the
     // |Im| plane, 3.0 vs 3.9 ms at 40 channels without; the MFMA kernel wins from 56 / 44 channels on)
-    if (ax.C <= (a.abs_plane >= 0 ? 48 : 42)) return launch_small(a, s);
+    if (ax.C <= (a.abs_plane >= 0 ? 48 : 42)) return launch_small(a, unit, s);
+    if (unit) {
+        // the matrix-core kernel takes its rows straight from HBM into LDS: normalise a copy of the spectra first
+        const int64_t span = fused_span(ax);
+        SC_REQUIRE(d_scratch && scratch_bytes >= span * 8 && ((uintptr_t)d_scratch % 16) == 0,
+                   "unit-phasor accumulation above 42 channels needs sc_fused_unit_scratch_bytes() of 16-byte aligned scratch");
+        const int64_t n4 = (span + 1) / 2;
+        hipLaunchKernelGGL(unit_normalize_kernel, dim3(4096), dim3(256), 0, s, (const float4*)d_X, (float4*)d_scratch, n4);
+        SC_CHECK_HIP(hipGetLastError());
+        a.st.base = (const float2*)d_scratch;
+    }
     switch (a.NB32) {
     case 1: return launch_fused<1>(a, s);
     case 2: return launch_fused<2>(a, s);
     case 3: return launch_fused<3>(a, s);
     default: return launch_fused<4>(a, s);
     }
+}
+
+extern "C" int sc_fused_csm_absim_ws_f32(const void* d_X, const sc_spectra_desc* desc, uint32_t planes,
+                                         float* d_accum, void* d_workspace, int64_t workspace_bytes, void* stream) {
+    return fused_run(d_X, desc, planes, false, d_accum, d_workspace, workspace_bytes, nullptr, 0, stream);
+}
+
+// Scratch sc_fused_unit_ws_f32 needs for this shape: a normalised copy of the spectra above 42 channels, else none.
+extern "C" int64_t sc_fused_unit_scratch_bytes(const sc_spectra_desc* desc) {
+    ScAxes ax;
+    if (!desc || sc_make_axes(desc, &ax) != SC_OK || !fused_ok(nullptr, ax) || ax.C <= 42) return 0;
+    return ((fused_span(ax) + 1) / 2) * 16;
+}
+
+// SC_PLANE_UNIT of the record: sum over observations of s / |s| = x_i conj(x_j) / (|x_i| |x_j|), i.e. the cross-
+// spectral matrix of the unit phasors x / |x| (phase_locking_value, pairwise_phase_consistency: connectivity.py:
+// 897-981).  Same shapes, workspace and split as sc_fused_csm_absim_ws_f32.
+extern "C" int sc_fused_unit_ws_f32(const void* d_X, const sc_spectra_desc* desc, uint32_t planes, float* d_accum,
+                                    void* d_workspace, int64_t workspace_bytes, void* d_scratch, int64_t scratch_bytes,
+                                    void* stream) {
+    return fused_run(d_X, desc, planes, true, d_accum, d_workspace, workspace_bytes, d_scratch, scratch_bytes, stream);
 }
 
 extern "C" int sc_fused_csm_absim_f32(const void* d_X, const sc_spectra_desc* desc, uint32_t planes,

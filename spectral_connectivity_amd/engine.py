@@ -179,16 +179,31 @@ def accumulate(spectra, expectation_type, planes, n_freq=None, mark=None, use_fu
     both = _lib.PLANE_CSM | _lib.PLANE_ABS_IM
     if use_fused is None:
         use_fused = bool(lib.sc_fused_supported(spectra.C))
-    if use_fused and (planes & _lib.PLANE_CSM):
-        # one pass: CSM (and, when requested, the per-observation |Im s| products) on the bf16 matrix pipe (sc_fused.hip)
+    one_pass = planes & (both | _lib.PLANE_UNIT) if use_fused else 0
+    if one_pass & _lib.PLANE_ABS_IM and not one_pass & _lib.PLANE_CSM:
+        one_pass &= ~_lib.PLANE_ABS_IM          # |Im s| rides on the CSM pass only
+    if one_pass:
         ws_bytes = int(lib.sc_fused_workspace_bytes(byref(d), planes))
         ws = _workspace(ws_bytes, spectra.X.device)
-        _lib.check(lib.sc_fused_csm_absim_ws_f32(_ptr(spectra.X), byref(d), planes, _ptr(accum),
-                                                 _ptr(ws) if ws is not None else None, ws_bytes, _stream()),
-                   "sc_fused_csm_absim_ws_f32")
-        if mark:
-            mark("fused_csm_absim")
-        nl = planes & ~both
+        if one_pass & _lib.PLANE_CSM:
+            # one pass: CSM (and, when requested, the per-observation |Im s| products): bf16 matrix pipe, or the f32
+            # VALU kernel for few channels (sc_fused.hip)
+            _lib.check(lib.sc_fused_csm_absim_ws_f32(_ptr(spectra.X), byref(d), planes, _ptr(accum),
+                                                     _ptr(ws) if ws is not None else None, ws_bytes, _stream()),
+                       "sc_fused_csm_absim_ws_f32")
+            if mark:
+                mark("fused_csm_absim")
+        if one_pass & _lib.PLANE_UNIT:
+            # sum s/|s| = the CSM of the unit phasors x/|x|: the same kernels on normalised rows
+            sb = int(lib.sc_fused_unit_scratch_bytes(byref(d)))
+            scratch = torch.empty((sb,), dtype=torch.uint8, device=spectra.X.device) if sb else None
+            _lib.check(lib.sc_fused_unit_ws_f32(_ptr(spectra.X), byref(d), planes, _ptr(accum),
+                                                _ptr(ws) if ws is not None else None, ws_bytes,
+                                                _ptr(scratch) if scratch is not None else None, sb, _stream()),
+                       "sc_fused_unit_ws_f32")
+            if mark:
+                mark("fused_unit")
+        nl = planes & ~one_pass
         if nl:
             _lib.check(lib.sc_nonlinear_accumulate_f32(_ptr(spectra.X), byref(d), planes, nl, _ptr(accum),
                                                        _stream()), "sc_nonlinear_accumulate_f32")
