@@ -75,6 +75,8 @@ struct FusedArgs {
     int64_t floats_per_bin;
     int n_bins, F, NB, n_tiles, NB32, n_blocks32, n_sets;
     int csm_plane, abs_plane;
+    int sq_plane, sign_plane;   // small-channel kernel only: sum (Im s)^2, sum sign(Im s); -1 = absent
+    int fold[6], n_fold;        // small-channel kernel only: the record planes a launch writes (folded over the parts)
     int n_split;         // workgroups per bin: part k sums the chunks [k NC / n_split, (k+1) NC / n_split)
     float* ws;           // partial records of parts 1 .. n_split-1: [n_split-1][n_bins][floats_per_bin]
     int debug_skip;      // profiling aid (env SC_FUSED_DEBUG, bit mask; results are WRONG when set):
@@ -632,6 +634,24 @@ __global__ void __launch_bounds__(256) fused_combine_kernel(FusedArgs p) {
     }
 }
 
+// the same fold for an arbitrary list of planes (small-channel kernel)
+__global__ void __launch_bounds__(256) planes_combine_kernel(FusedArgs p) {
+    const int64_t plane = (int64_t)p.n_tiles * SC_TILE_ELEMS;
+    const int64_t per_bin = p.n_fold * plane / 4;                  // float4 items per bin
+    const int64_t total = per_bin * p.n_bins;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t bin = i / per_bin, e = (i - bin * per_bin) * 4;
+        const int which = (int)(e / plane);
+        const int64_t off = bin * p.floats_per_bin + (int64_t)p.fold[which] * plane + (e - which * plane);
+        float4 a = *reinterpret_cast<const float4*>(p.accum + off);
+        for (int k = 0; k + 1 < p.n_split; ++k) {
+            const float4 b = *reinterpret_cast<const float4*>(p.ws + (int64_t)k * p.n_bins * p.floats_per_bin + off);
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        *reinterpret_cast<float4*>(p.accum + off) = a;
+    }
+}
+
 template <int NB32>
 static int launch_fused(const FusedArgs& a, hipStream_t stream) {
     size_t shmem = (size_t)2 * a.st.CP * FU_CSTRIDE * 2;
@@ -663,7 +683,7 @@ static int launch_fused(const FusedArgs& a, hipStream_t stream) {
 #define SM_THREADS 448
 #define SM_CHUNK_BYTES (24 * 1024)
 
-template <bool ABS, bool NORM>
+template <bool ABS, bool SQ, bool SGN, bool NORM>
 __global__ void __launch_bounds__(SM_THREADS) small_csm_absim_kernel(FusedArgs p) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -726,6 +746,7 @@ __global__ void __launch_bounds__(SM_THREADS) small_csm_absim_kernel(FusedArgs p
 
     float re[4] = {0.f, 0.f, 0.f, 0.f}, im[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
     float re2[4] = {0.f, 0.f, 0.f, 0.f}, im2[4] = {0.f, 0.f, 0.f, 0.f}, ab2[4] = {0.f, 0.f, 0.f, 0.f};
+    float sq[4] = {0.f, 0.f, 0.f, 0.f}, sg[4] = {0.f, 0.f, 0.f, 0.f}, sq2[4] = {0.f, 0.f, 0.f, 0.f}, sg2[4] = {0.f, 0.f, 0.f, 0.f};
     const int n_chunks = (o_hi - o_lo + OC - 1) / OC;
     const int fold_every = (512 + per_thread - 1) / per_thread;        // chunks per first-level chain
     if (n_chunks > 0) { load(o_lo); store(buf0); }
@@ -752,14 +773,16 @@ __global__ void __launch_bounds__(SM_THREADS) small_csm_absim_kernel(FusedArgs p
                         const float d = fmaf(ai[u], br[v], -(ar[u] * bm[v]));
                         im[e] += d;
                         if constexpr (ABS) ab[e] += fabsf(d);
+                        if constexpr (SQ) sq[e] = fmaf(d, d, sq[e]);
+                        if constexpr (SGN) sg[e] += (d > 0.f ? 1.f : 0.f) - (d < 0.f ? 1.f : 0.f);     // sign(0) = 0
                     }
             }
         }
         if ((ch + 1) % fold_every == 0 || !more) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                re2[e] += re[e]; im2[e] += im[e]; ab2[e] += ab[e];
-                re[e] = 0.f; im[e] = 0.f; ab[e] = 0.f;
+                re2[e] += re[e]; im2[e] += im[e]; ab2[e] += ab[e]; sq2[e] += sq[e]; sg2[e] += sg[e];
+                re[e] = 0.f; im[e] = 0.f; ab[e] = 0.f; sq[e] = 0.f; sg[e] = 0.f;
             }
         }
         if (more) store(nxt);
@@ -767,18 +790,21 @@ __global__ void __launch_bounds__(SM_THREADS) small_csm_absim_kernel(FusedArgs p
     }
     // slices -> one total per (block, quantity), summed in slice order; then the record image (zero padded tiles,
     // both triangles of the diagonal tiles like an MFMA tile) is assembled in LDS and copied out coalesced
-    float* red = reinterpret_cast<float*>(smem);                         // [12][SM_THREADS]
-    float* image = red + 12 * SM_THREADS;                                // [3][n_tiles][256]
+    constexpr int NQ = 5;                                                // re, im, |im|, im^2, sign(im)
+    float* red = reinterpret_cast<float*>(smem);                         // [NQ * 4][SM_THREADS]
+    float* image = red + NQ * 4 * SM_THREADS;                            // [NQ][n_tiles][256]
     const int plane_f = p.n_tiles * SC_TILE_ELEMS;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         red[(e) * SM_THREADS + tid] = active ? re2[e] : 0.f;
         red[(4 + e) * SM_THREADS + tid] = active ? im2[e] : 0.f;
         red[(8 + e) * SM_THREADS + tid] = active ? ab2[e] : 0.f;
+        red[(12 + e) * SM_THREADS + tid] = active ? sq2[e] : 0.f;
+        red[(16 + e) * SM_THREADS + tid] = active ? sg2[e] : 0.f;
     }
-    for (int i = tid; i < 3 * plane_f; i += SM_THREADS) image[i] = 0.f;
+    for (int i = tid; i < NQ * plane_f; i += SM_THREADS) image[i] = 0.f;
     __syncthreads();
-    for (int item = tid; item < 12 * nbk; item += SM_THREADS) {
+    for (int item = tid; item < NQ * 4 * nbk; item += SM_THREADS) {
         const int q = item / nbk, bb = item - q * nbk;                  // q = quantity * 4 + element
         float acc = 0.f;
         for (int ss = 0; ss < S; ++ss) acc += red[q * SM_THREADS + ss * nbk + bb];
@@ -786,33 +812,47 @@ __global__ void __launch_bounds__(SM_THREADS) small_csm_absim_kernel(FusedArgs p
         { int rem = bb, len = B; while (rem >= len) { rem -= len; ++ti; --len; } tj = ti + rem; }
         const int qty = q >> 2, e = q & 3, i = 2 * ti + (e >> 1), j = 2 * tj + (e & 1);
         if (i > j) continue;                                             // lower half of a diagonal 2 x 2 block
+        const bool odd = qty == 1 || qty == 4;                           // Im s and sign(Im s) change sign under i <-> j
         float* pl = image + qty * plane_f + sc_tile_index(i >> 4, j >> 4, p.NB) * SC_TILE_ELEMS;
-        pl[(i & 15) * 16 + (j & 15)] = (qty == 1 && i == j) ? 0.f : acc;
-        if ((i >> 4) == (j >> 4) && i != j) pl[(j & 15) * 16 + (i & 15)] = (qty == 1) ? -acc : acc;
+        pl[(i & 15) * 16 + (j & 15)] = (odd && i == j) ? 0.f : acc;
+        if ((i >> 4) == (j >> 4) && i != j) pl[(j & 15) * 16 + (i & 15)] = odd ? -acc : acc;
     }
     __syncthreads();
-    for (int i = tid; i < 2 * plane_f; i += SM_THREADS) rec[(int64_t)p.csm_plane * plane_f + i] = image[i];
+    if (p.csm_plane >= 0)
+        for (int i = tid; i < 2 * plane_f; i += SM_THREADS) rec[(int64_t)p.csm_plane * plane_f + i] = image[i];
     if constexpr (ABS)
         for (int i = tid; i < plane_f; i += SM_THREADS) rec[(int64_t)p.abs_plane * plane_f + i] = image[2 * plane_f + i];
+    if constexpr (SQ)
+        for (int i = tid; i < plane_f; i += SM_THREADS) rec[(int64_t)p.sq_plane * plane_f + i] = image[3 * plane_f + i];
+    if constexpr (SGN)
+        for (int i = tid; i < plane_f; i += SM_THREADS) rec[(int64_t)p.sign_plane * plane_f + i] = image[4 * plane_f + i];
 }
 
-template <bool ABS, bool NORM>
+template <bool ABS, bool SQ, bool SGN, bool NORM>
 static void launch_small_inst(const FusedArgs& a, size_t shmem, hipStream_t stream) {
-    auto k = small_csm_absim_kernel<ABS, NORM>;
+    auto k = small_csm_absim_kernel<ABS, SQ, SGN, NORM>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     hipLaunchKernelGGL(k, dim3((unsigned)(a.n_bins * a.n_split)), dim3(SM_THREADS), shmem, stream, a);
 }
 
-static int launch_small(const FusedArgs& a, bool normalize, hipStream_t stream) {
+static int launch_small(const FusedArgs& a_in, bool normalize, hipStream_t stream) {
+    FusedArgs a = a_in;
     size_t shmem = 2 * (size_t)SM_CHUNK_BYTES;
-    const size_t tail = (size_t)(12 * SM_THREADS + 3 * a.n_tiles * SC_TILE_ELEMS) * sizeof(float);
+    const size_t tail = (size_t)(20 * SM_THREADS + 5 * a.n_tiles * SC_TILE_ELEMS) * sizeof(float);
     if (shmem < tail) shmem = tail;
-    if (normalize) launch_small_inst<false, true>(a, shmem, stream);
-    else if (a.abs_plane >= 0) launch_small_inst<true, false>(a, shmem, stream);
-    else launch_small_inst<false, false>(a, shmem, stream);
+    a.n_fold = 0;
+    if (a.csm_plane >= 0) { a.fold[a.n_fold++] = a.csm_plane; a.fold[a.n_fold++] = a.csm_plane + 1; }
+    if (a.abs_plane >= 0) a.fold[a.n_fold++] = a.abs_plane;
+    if (a.sq_plane >= 0) a.fold[a.n_fold++] = a.sq_plane;
+    if (a.sign_plane >= 0) a.fold[a.n_fold++] = a.sign_plane;
+    if (normalize) launch_small_inst<false, false, false, true>(a, shmem, stream);
+    else if (a.sign_plane >= 0) launch_small_inst<false, false, true, false>(a, shmem, stream);
+    else if (a.sq_plane >= 0) launch_small_inst<true, true, false, false>(a, shmem, stream);
+    else if (a.abs_plane >= 0) launch_small_inst<true, false, false, false>(a, shmem, stream);
+    else launch_small_inst<false, false, false, false>(a, shmem, stream);
     SC_CHECK_HIP(hipGetLastError());
     if (a.n_split > 1) {
-        hipLaunchKernelGGL(fused_combine_kernel, dim3(2048), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(planes_combine_kernel, dim3(2048), dim3(256), 0, stream, a);
         SC_CHECK_HIP(hipGetLastError());
     }
     return SC_OK;
@@ -833,6 +873,10 @@ static bool fused_ok(const void* d_X, const ScAxes& ax) {
     if ((ax.sW | ax.sR | ax.sK | ax.sF) & 1) return false;
     return d_X == nullptr || (((uintptr_t)d_X) % 16 == 0);
 }
+
+// The f32 VALU kernel below the measured crossover (same input volume as cfg3: 4.7 vs 5.1 ms at 48 channels with a
+// per-observation non-linear plane, 3.0 vs 3.9 ms at 40 channels without; the MFMA kernel wins from 56 / 44 on).
+static bool small_ok(const ScAxes& ax, bool nonlinear_plane) { return ax.C <= (nonlinear_plane ? 48 : 42); }
 
 extern "C" int sc_fused_supported(int64_t n_signals) {
     return (n_signals >= 2 && n_signals <= 128 && (n_signals % 2) == 0) ? 1 : 0;
@@ -866,9 +910,11 @@ static int fused_pick_split(int n_bins, int n_obs) {
     return best;
 }
 
-static int fused_setup(const void* d_X, const sc_spectra_desc* desc, uint32_t planes, bool unit, FusedArgs* a, ScAxes* ax) {
+enum { FU_MODE_CSM = 0, FU_MODE_UNIT = 1, FU_MODE_SIGN = 2 };
+static int fused_setup(const void* d_X, const sc_spectra_desc* desc, uint32_t planes, int mode, FusedArgs* a, ScAxes* ax) {
     SC_REQUIRE(desc, "NULL argument");
-    if (unit) SC_REQUIRE(planes & SC_PLANE_UNIT, "planes must contain SC_PLANE_UNIT");
+    if (mode == FU_MODE_UNIT) SC_REQUIRE(planes & SC_PLANE_UNIT, "planes must contain SC_PLANE_UNIT");
+    else if (mode == FU_MODE_SIGN) SC_REQUIRE(planes & SC_PLANE_SIGN_IM, "planes must contain SC_PLANE_SIGN_IM");
     else SC_REQUIRE(planes & SC_PLANE_CSM, "planes must contain SC_PLANE_CSM (SC_PLANE_ABS_IM is optional)");
     sc_make_axes(desc, ax);
     SC_REQUIRE(ax->C >= 1 && ax->F >= 1 && ax->n_obs >= 1 && ax->n_groups >= 1, "empty dimension");
@@ -886,9 +932,17 @@ static int fused_setup(const void* d_X, const sc_spectra_desc* desc, uint32_t pl
     a->floats_per_bin = (int64_t)sc_plane_count(planes) * a->n_tiles * SC_TILE_ELEMS;
     a->csm_plane = sc_plane_offset(planes, SC_PLANE_CSM);
     a->abs_plane = (planes & SC_PLANE_ABS_IM) ? sc_plane_offset(planes, SC_PLANE_ABS_IM) : -1;   // -1: CSM only
-    if (unit) {          // sum s / |s| = the CSM of x / |x|: the same kernels, pointed at the unit-phasor planes
+    a->sq_plane = -1;
+    a->sign_plane = -1;
+    if (mode == FU_MODE_UNIT) {   // sum s / |s| = the CSM of x / |x|: the same kernels, pointed at the unit-phasor planes
         a->csm_plane = sc_plane_offset(planes, SC_PLANE_UNIT);
         a->abs_plane = -1;
+    } else if (mode == FU_MODE_SIGN) {
+        a->csm_plane = -1;
+        a->abs_plane = -1;
+        a->sign_plane = sc_plane_offset(planes, SC_PLANE_SIGN_IM);
+    } else if (small_ok(*ax, true) && (planes & SC_PLANE_ABS_IM) && (planes & SC_PLANE_IM_SQ)) {
+        a->sq_plane = sc_plane_offset(planes, SC_PLANE_IM_SQ);       // rides along on the small-channel kernel
     }
     a->n_split = 1;
     a->ws = nullptr;
@@ -898,7 +952,8 @@ static int fused_setup(const void* d_X, const sc_spectra_desc* desc, uint32_t pl
 extern "C" int64_t sc_fused_workspace_bytes(const sc_spectra_desc* desc, uint32_t planes) {
     FusedArgs a;
     ScAxes ax;
-    if (fused_setup(nullptr, desc, planes, !(planes & SC_PLANE_CSM), &a, &ax) != SC_OK) return 0;
+    const int mode = (planes & SC_PLANE_CSM) ? FU_MODE_CSM : (planes & SC_PLANE_UNIT) ? FU_MODE_UNIT : FU_MODE_SIGN;
+    if (fused_setup(nullptr, desc, planes, mode, &a, &ax) != SC_OK) return 0;
     const int S = fused_pick_split(a.n_bins, ax.n_obs);
     return (int64_t)(S - 1) * a.n_bins * a.floats_per_bin * (int64_t)sizeof(float);
 }
@@ -909,12 +964,13 @@ static int64_t fused_span(const ScAxes& ax) {
            (int64_t)(ax.K - 1) * ax.sK + ax.C;
 }
 
-static int fused_run(const void* d_X, const sc_spectra_desc* desc, uint32_t planes, bool unit, float* d_accum,
+static int fused_run(const void* d_X, const sc_spectra_desc* desc, uint32_t planes, int mode, float* d_accum,
                      void* d_workspace, int64_t workspace_bytes, void* d_scratch, int64_t scratch_bytes, void* stream) {
     SC_REQUIRE(d_X && desc && d_accum, "NULL argument");
     FusedArgs a;
     ScAxes ax;
-    const int rc = fused_setup(d_X, desc, planes, unit, &a, &ax);
+    const bool unit = mode == FU_MODE_UNIT;
+    const int rc = fused_setup(d_X, desc, planes, mode, &a, &ax);
     if (rc != SC_OK) return rc;
     a.accum = d_accum;
     a.st.base = (const float2*)d_X;
@@ -937,9 +993,11 @@ static int fused_run(const void* d_X, const sc_spectra_desc* desc, uint32_t plan
     a.n_split = S;
     a.ws = (float*)d_workspace;
     hipStream_t s = (hipStream_t)stream;
-    // f32 VALU kernel below the measured crossover (same input volume as cfg3: 4.7 vs 5.1 ms at 48 channels with the
-    // |Im| plane, 3.0 vs 3.9 ms at 40 channels without; the MFMA kernel wins from 56 / 44 channels on)
-    if (ax.C <= (a.abs_plane >= 0 ? 48 : 42)) return launch_small(a, unit, s);
+    if (small_ok(ax, a.abs_plane >= 0 || mode == FU_MODE_SIGN)) return launch_small(a, unit, s);
+    if (mode == FU_MODE_SIGN) {
+        sc_set_error("sum sign(Im s) in one pass is built for up to 48 channels (got %d): use sc_nonlinear_accumulate_f32", ax.C);
+        return SC_EUNSUPPORTED;
+    }
     if (unit) {
         // the matrix-core kernel takes its rows straight from HBM into LDS: normalise a copy of the spectra first
         const int64_t span = fused_span(ax);
@@ -960,7 +1018,28 @@ static int fused_run(const void* d_X, const sc_spectra_desc* desc, uint32_t plan
 
 extern "C" int sc_fused_csm_absim_ws_f32(const void* d_X, const sc_spectra_desc* desc, uint32_t planes,
                                          float* d_accum, void* d_workspace, int64_t workspace_bytes, void* stream) {
-    return fused_run(d_X, desc, planes, false, d_accum, d_workspace, workspace_bytes, nullptr, 0, stream);
+    return fused_run(d_X, desc, planes, FU_MODE_CSM, d_accum, d_workspace, workspace_bytes, nullptr, 0, stream);
+}
+
+// The planes of `planes` that the one-pass entry points fill for this shape: CSM, |Im s| (with CSM), s/|s| always;
+// (Im s)^2 (with CSM and |Im s|) and sign(Im s) up to 48 channels.  The rest is sc_nonlinear_accumulate_f32's.
+extern "C" uint32_t sc_fused_planes_covered(const sc_spectra_desc* desc, uint32_t planes) {
+    ScAxes ax;
+    if (!desc || sc_make_axes(desc, &ax) != SC_OK || !fused_ok(nullptr, ax)) return 0;
+    uint32_t got = planes & (SC_PLANE_CSM | SC_PLANE_UNIT);
+    if ((planes & SC_PLANE_CSM) && (planes & SC_PLANE_ABS_IM)) got |= SC_PLANE_ABS_IM;
+    if (small_ok(ax, true)) {
+        if ((got & SC_PLANE_ABS_IM) && (planes & SC_PLANE_IM_SQ)) got |= SC_PLANE_IM_SQ;
+        got |= planes & SC_PLANE_SIGN_IM;
+    }
+    return got;
+}
+
+// SC_PLANE_SIGN_IM of the record (phase_lag_index, debiased_squared_phase_lag_index: connectivity.py:983-1079) on the
+// small-channel kernel; SC_EUNSUPPORTED above 48 channels.
+extern "C" int sc_fused_sign_ws_f32(const void* d_X, const sc_spectra_desc* desc, uint32_t planes, float* d_accum,
+                                    void* d_workspace, int64_t workspace_bytes, void* stream) {
+    return fused_run(d_X, desc, planes, FU_MODE_SIGN, d_accum, d_workspace, workspace_bytes, nullptr, 0, stream);
 }
 
 // Scratch sc_fused_unit_ws_f32 needs for this shape: a normalised copy of the spectra above 42 channels, else none.
@@ -976,7 +1055,7 @@ extern "C" int64_t sc_fused_unit_scratch_bytes(const sc_spectra_desc* desc) {
 extern "C" int sc_fused_unit_ws_f32(const void* d_X, const sc_spectra_desc* desc, uint32_t planes, float* d_accum,
                                     void* d_workspace, int64_t workspace_bytes, void* d_scratch, int64_t scratch_bytes,
                                     void* stream) {
-    return fused_run(d_X, desc, planes, true, d_accum, d_workspace, workspace_bytes, d_scratch, scratch_bytes, stream);
+    return fused_run(d_X, desc, planes, FU_MODE_UNIT, d_accum, d_workspace, workspace_bytes, d_scratch, scratch_bytes, stream);
 }
 
 extern "C" int sc_fused_csm_absim_f32(const void* d_X, const sc_spectra_desc* desc, uint32_t planes,

@@ -179,26 +179,29 @@ def accumulate(spectra, expectation_type, planes, n_freq=None, mark=None, use_fu
     both = _lib.PLANE_CSM | _lib.PLANE_ABS_IM
     if use_fused is None:
         use_fused = bool(lib.sc_fused_supported(spectra.C))
-    one_pass = planes & (both | _lib.PLANE_UNIT) if use_fused else 0
-    if one_pass & _lib.PLANE_ABS_IM and not one_pass & _lib.PLANE_CSM:
-        one_pass &= ~_lib.PLANE_ABS_IM          # |Im s| rides on the CSM pass only
+    # planes the one-pass kernels fill for this shape (sc_fused.hip): CSM, |Im s|, s/|s|; for few channels also
+    # (Im s)^2 and sign(Im s).  Whatever is left goes to the per-plane VALU kernel.
+    one_pass = int(lib.sc_fused_planes_covered(byref(d), planes)) if use_fused else 0
     if one_pass:
         ws_bytes = int(lib.sc_fused_workspace_bytes(byref(d), planes))
         ws = _workspace(ws_bytes, spectra.X.device)
+        ws_ptr = _ptr(ws) if ws is not None else None
         if one_pass & _lib.PLANE_CSM:
-            # one pass: CSM (and, when requested, the per-observation |Im s| products): bf16 matrix pipe, or the f32
-            # VALU kernel for few channels (sc_fused.hip)
-            _lib.check(lib.sc_fused_csm_absim_ws_f32(_ptr(spectra.X), byref(d), planes, _ptr(accum),
-                                                     _ptr(ws) if ws is not None else None, ws_bytes, _stream()),
-                       "sc_fused_csm_absim_ws_f32")
+            # CSM (+ the per-observation |Im s| products, + (Im s)^2): bf16 matrix pipe, or the f32 VALU kernel
+            _lib.check(lib.sc_fused_csm_absim_ws_f32(_ptr(spectra.X), byref(d), planes, _ptr(accum), ws_ptr, ws_bytes,
+                                                     _stream()), "sc_fused_csm_absim_ws_f32")
             if mark:
                 mark("fused_csm_absim")
+        if one_pass & _lib.PLANE_SIGN_IM:
+            _lib.check(lib.sc_fused_sign_ws_f32(_ptr(spectra.X), byref(d), planes, _ptr(accum), ws_ptr, ws_bytes,
+                                                _stream()), "sc_fused_sign_ws_f32")
+            if mark:
+                mark("fused_sign")
         if one_pass & _lib.PLANE_UNIT:
             # sum s/|s| = the CSM of the unit phasors x/|x|: the same kernels on normalised rows
             sb = int(lib.sc_fused_unit_scratch_bytes(byref(d)))
             scratch = torch.empty((sb,), dtype=torch.uint8, device=spectra.X.device) if sb else None
-            _lib.check(lib.sc_fused_unit_ws_f32(_ptr(spectra.X), byref(d), planes, _ptr(accum),
-                                                _ptr(ws) if ws is not None else None, ws_bytes,
+            _lib.check(lib.sc_fused_unit_ws_f32(_ptr(spectra.X), byref(d), planes, _ptr(accum), ws_ptr, ws_bytes,
                                                 _ptr(scratch) if scratch is not None else None, sb, _stream()),
                        "sc_fused_unit_ws_f32")
             if mark:

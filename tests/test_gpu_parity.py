@@ -236,6 +236,32 @@ def test_fused_stage_b_equals_separate_kernels(sc, C, R):
                 so.weighted_phase_lag_index(coef), what="wpli vs oracle")
 
 
+@pytest.mark.parametrize("C,R", [(2, 40), (6, 9), (16, 120), (34, 5), (48, 7), (64, 6), (128, 5)])
+def test_one_pass_nonlinear_planes_equal_the_per_plane_kernel(sc, C, R):
+    """(Im s)^2 and sign(Im s) ride on the small-channel one-pass kernel (<= 48 channels) and the unit phasors s/|s| go
+    through the one-pass kernels as the cross-spectral matrix of x/|x| at every size: the same accumulator records as the
+    per-plane VALU kernel (sc_nonlinear.hip) up to f32 summation order -- sign sums exactly."""
+    from spectral_connectivity_amd import _lib, engine
+    rng = np.random.default_rng(100 + C)
+    x = rng.standard_normal((200, R, C)) + 0.5 * rng.standard_normal((200, R, 1))
+    m = sc.Multitaper(x, sampling_frequency=200.0, time_halfbandwidth_product=3,
+                      n_time_samples_per_window=64, n_time_samples_per_step=32)
+    sp = m.device_spectra()
+    for planes, which in ((_lib.PLANE_CSM | _lib.PLANE_ABS_IM | _lib.PLANE_IM_SQ, _lib.M_DEBIASED_WPLI2),
+                          (_lib.PLANE_SIGN_IM, _lib.M_PLI), (_lib.PLANE_SIGN_IM, _lib.M_DEBIASED_PLI2),
+                          (_lib.PLANE_UNIT, _lib.M_PLV), (_lib.PLANE_UNIT, _lib.M_PPC)):
+        for et in ("trials_tapers", "time_trials_tapers"):
+            a_f, n = engine.accumulate(sp, et, planes, use_fused=True)
+            a_s, _ = engine.accumulate(sp, et, planes, use_fused=False)
+            got = engine.measure(a_f, C, planes, n, which).cpu().numpy()
+            ref = engine.measure(a_s, C, planes, n, which).cpu().numpy()
+            if planes == _lib.PLANE_SIGN_IM:
+                assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.array_equal(got[~np.isnan(got)], ref[~np.isnan(ref)])
+            else:
+                tol = 2e-5 if which == _lib.M_DEBIASED_WPLI2 else 3e-6     # the debiased ratio amplifies re-association
+                close32(got, ref, rtol=tol, atol_scale=tol, what=f"planes {planes:#x} measure {which} {et}")
+
+
 @pytest.mark.parametrize("C,R,split", [(128, 150, 3), (64, 130, 2), (128, 200, 5), (16, 400, 4), (40, 130, 3), (4, 900, 7)])
 def test_fused_stage_b_split_bins(sc, C, R, split, monkeypatch):
     """Several workgroups per bin (observation chunks split, partial records folded in a fixed order)
