@@ -13,7 +13,9 @@ def main(path):
             max(s.sgpr_count), max(d.group_segment_size)
             from rocpd_kernel_dispatch{suf} d join rocpd_info_kernel_symbol{suf} s on d.kernel_id=s.id
             group by s.kernel_name order by 6 desc limit 15"""
-    print(f"{'kernel':64s} {'calls':>5s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'total_us':>11s} vgpr agpr sgpr lds")
+    print(f"{'kernel':64s} {'calls':>5s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'total_us':>11s} vgpr* agpr sgpr lds")
+    print("# vgpr* = rocpd's arch_vgpr_count; on gfx950 it reads HALF the wave64 allocation in the code-object metadata "
+          "(.vgpr_count: e.g. 84 here = 168 there)")
     for r in c.execute(q):
         print(f"{r[0][:64]:64s} {r[1]:5d} {r[2]:10.1f} {r[3]:10.1f} {r[4]:10.1f} {r[5]:11.1f} {r[6]} {r[7]} {r[8]} {r[9]}")
     try:
