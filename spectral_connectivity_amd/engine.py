@@ -59,28 +59,38 @@ class DeviceSpectra:
     """One-sided (or caller-described) Fourier coefficients resident in HBM.
 
     ``X`` is a complex64 tensor; ``dims`` = (F, W, R, K, C) logical sizes and ``strides`` =
-    element strides of (freq, window, trial, taper) -- channel stride is 1.
+    element strides of (freq, window, trial, taper) -- channel stride is 1.  ``C_alloc`` >= C channels are
+    stored per row: an odd channel count gets one all-zero channel appended, so that rows stay 16-byte
+    aligned and the one-pass stage-B kernels (even channel counts) apply; a record accumulated over C_alloc
+    channels IS the record of the first C (same 16 x 16 tiling, the extra row / column lies in tile padding).
     """
 
-    def __init__(self, X, dims, strides, n_fft, real_input):
+    def __init__(self, X, dims, strides, n_fft, real_input, C_alloc=None):
         self.X = X
         self.F, self.W, self.R, self.K, self.C = (int(d) for d in dims)
+        self.C_alloc = self.C if C_alloc is None else int(C_alloc)
+        assert self.C_alloc in (self.C, self.C + 1) and -(-self.C_alloc // 16) == -(-self.C // 16)
         self.strides = tuple(int(s) for s in strides)
         self.n_fft = int(n_fft)
         self.real_input = bool(real_input)   # negative bins are conj mirrors of positive ones
+
+    def coefficients(self):
+        """The spectra as a (F, W, R, K, C) tensor view of a contiguous X (the zero pad channel dropped)."""
+        return self.X.view(self.F, self.W, self.R, self.K, self.C_alloc)[..., :self.C]
 
     def freq_slice(self, f0, f1):
         """The bins [f0, f1) as a view (no copy): same strides, pointer advanced by f0 * stride_freq."""
         assert 0 <= f0 < f1 <= self.F and self.X.is_contiguous()
         flat = self.X.view(-1)[f0 * self.strides[0]:]
         return DeviceSpectra(flat, (f1 - f0, self.W, self.R, self.K, self.C), self.strides, self.n_fft,
-                             self.real_input)
+                             self.real_input, C_alloc=self.C_alloc)
 
-    def desc(self, expectation_type, n_freq=None):
+    def desc(self, expectation_type, n_freq=None, padded=False):
+        """Descriptor of the spectra; ``padded``: with the zero pad channel counted as a signal."""
         axes = EXPECTATION_AXES[expectation_type]
         sF, sW, sR, sK = self.strides
         return SpectraDesc(n_freq=self.F if n_freq is None else n_freq, n_windows=self.W,
-                           n_trials=self.R, n_tapers=self.K, n_signals=self.C, stride_freq=sF,
+                           n_trials=self.R, n_tapers=self.K, n_signals=self.C_alloc if padded else self.C, stride_freq=sF,
                            stride_window=sW, stride_trial=sR, stride_taper=sK,
                            reduce_window=int(0 in axes), reduce_trial=int(1 in axes),
                            reduce_taper=int(2 in axes), reserved=0)
@@ -106,6 +116,9 @@ def multitaper_spectra(x, tapers_over_fs, n_window, n_step, n_fft, n_windows, de
     (folds the sqrt(fs) of transforms.py:1440 and the /fs of transforms.py:1405).
     """
     lib = _lib.load()
+    T, R, C_real = x.shape
+    if C_real % 2 and C_real + 1 <= 128:
+        x = torch.nn.functional.pad(x, (0, 1))       # odd channel count: one zero channel (see DeviceSpectra)
     T, R, C = x.shape
     K, L = tapers_over_fs.shape
     assert L == n_window
@@ -122,7 +135,7 @@ def multitaper_spectra(x, tapers_over_fs, n_window, n_step, n_fft, n_windows, de
                    "sc_multitaper_fft_f32")
         if mark:
             mark("mtfft_fused")
-        return DeviceSpectra(X, (F, n_windows, R, K, C), strides, n_fft, real_input=True)
+        return DeviceSpectra(X, (F, n_windows, R, K, C_real), strides, n_fft, real_input=True, C_alloc=C)
     batch = n_windows * R * K * C
     y = torch.empty((batch, n_fft), dtype=torch.float32, device=x.device)
     _lib.check(lib.sc_taper_windows_f32(_ptr(x), T, R, C, L, n_step, n_windows, n_fft,
@@ -135,15 +148,19 @@ def multitaper_spectra(x, tapers_over_fs, n_window, n_step, n_fft, n_windows, de
     if mark:
         mark("rocfft_r2c")
     del y
-    return DeviceSpectra(X, (F, n_windows, R, K, C), strides, n_fft, real_input=True)
+    return DeviceSpectra(X, (F, n_windows, R, K, C_real), strides, n_fft, real_input=True, C_alloc=C)
 
 
 def upload_coefficients(coef, device="cuda"):
     """Reference-layout (W,R,K,N,C) complex coefficients -> DeviceSpectra (all N bins, as given)."""
     coef = np.asarray(coef)
-    W, R, K, N, C = coef.shape
-    X = torch.from_numpy(np.ascontiguousarray(coef, dtype=np.complex64)).to(device)
-    return DeviceSpectra(X, (N, W, R, K, C), (C, R * K * N * C, K * N * C, N * C), N, real_input=False)
+    W, R, K, N, C_real = coef.shape
+    coef = np.ascontiguousarray(coef, dtype=np.complex64)
+    if C_real % 2 and C_real + 1 <= 128:
+        coef = np.concatenate([coef, np.zeros(coef.shape[:-1] + (1,), dtype=np.complex64)], axis=-1)
+    C = coef.shape[-1]
+    X = torch.from_numpy(coef).to(device)
+    return DeviceSpectra(X, (N, W, R, K, C_real), (C, R * K * N * C, K * N * C, N * C), N, real_input=False, C_alloc=C)
 
 
 def accum_layout(spectra, expectation_type, planes, n_freq=None):
@@ -176,11 +193,12 @@ def accumulate(spectra, expectation_type, planes, n_freq=None, mark=None, use_fu
     d = spectra.desc(expectation_type, n_freq)
     n_bins, fpb, _, n_obs = accum_layout(spectra, expectation_type, planes, n_freq)
     accum = torch.empty((n_bins, fpb), dtype=torch.float32, device=spectra.X.device)
-    both = _lib.PLANE_CSM | _lib.PLANE_ABS_IM
     if use_fused is None:
-        use_fused = bool(lib.sc_fused_supported(spectra.C))
+        use_fused = bool(lib.sc_fused_supported(spectra.C_alloc))
     # planes the one-pass kernels fill for this shape (sc_fused.hip): CSM, |Im s|, s/|s|; for few channels also
-    # (Im s)^2 and sign(Im s).  Whatever is left goes to the per-plane VALU kernel.
+    # (Im s)^2 and sign(Im s).  Whatever is left goes to the per-plane VALU kernel.  The one-pass kernels see the zero
+    # pad channel of an odd channel count as a signal: same record (DeviceSpectra).
+    d_real, d = d, spectra.desc(expectation_type, n_freq, padded=True)
     one_pass = int(lib.sc_fused_planes_covered(byref(d), planes)) if use_fused else 0
     if one_pass:
         ws_bytes = int(lib.sc_fused_workspace_bytes(byref(d), planes))
@@ -208,11 +226,12 @@ def accumulate(spectra, expectation_type, planes, n_freq=None, mark=None, use_fu
                 mark("fused_unit")
         nl = planes & ~one_pass
         if nl:
-            _lib.check(lib.sc_nonlinear_accumulate_f32(_ptr(spectra.X), byref(d), planes, nl, _ptr(accum),
+            _lib.check(lib.sc_nonlinear_accumulate_f32(_ptr(spectra.X), byref(d_real), planes, nl, _ptr(accum),
                                                        _stream()), "sc_nonlinear_accumulate_f32")
             if mark:
                 mark("nonlinear_valu")
         return accum, n_obs
+    d = d_real
     if planes & _lib.PLANE_CSM:
         _lib.check(lib.sc_csm_accumulate_f32(_ptr(spectra.X), byref(d), planes, _ptr(accum), _stream()),
                    "sc_csm_accumulate_f32")

@@ -509,7 +509,7 @@ class Multitaper:
         conjugate mirror (real input) and is filled on the host only for this export.
         """
         sp = self.device_spectra()
-        one = sp.X.cpu().numpy().astype(np.complex128)          # (F, W, R, K, C)
+        one = sp.coefficients().cpu().numpy().astype(np.complex128)          # (F, W, R, K, C)
         one = np.moveaxis(one, 0, 3)                            # (W, R, K, F, C)
         N = self.n_fft_samples
         out = np.empty(one.shape[:3] + (N, one.shape[-1]), dtype=np.complex128)

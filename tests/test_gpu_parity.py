@@ -200,7 +200,7 @@ def test_fused_fft_matches_oracle_and_rocfft(sc, N, L, C, det):
     xd = torch.from_numpy(x.astype(np.float32)).cuda()
     h = torch.from_numpy(np.ascontiguousarray(m.tapers.T / 200.0, dtype=np.float32)).cuda()
     sp = engine.multitaper_spectra(xd, h, L, step, N, m.n_time_windows, det, use_fused=False)
-    got = np.moveaxis(sp.X.cpu().numpy(), 0, 3)
+    got = np.moveaxis(sp.coefficients().cpu().numpy(), 0, 3)
     close32(got, coef[..., : N // 2 + 1, :], what=f"rocfft N={N}")
 
 
