@@ -176,7 +176,7 @@ class Connectivity:
         import torch
         # widened on the device (the reference returns float64 / complex128): a plain copy over PCIe is cheaper than a
         # host-side astype of the whole array
-        host = out.to(torch.complex128 if out.is_complex() else torch.float64).cpu().numpy()
+        host = engine.to_host(out.to(torch.complex128 if out.is_complex() else torch.float64))
         tail = (C,) if which == _lib.M_POWER else (C, C)
         return host.reshape(self._kept_shape() + (self._n_freq,) + tail)
 
@@ -246,7 +246,7 @@ class Connectivity:
             logger.warning(f"Maximum iterations reached. {status.numel() - not_conv} of {status.numel()} converged")
         self._last_wilson = dict(iterations=iters, not_converged=not_conv,
                                  n_iter=n_iter.cpu().numpy(), status=status.cpu().numpy())
-        return out.cpu().numpy().reshape(self._kept_shape() + (N // 2 + 1, C, C))
+        return engine.to_host(out).reshape(self._kept_shape() + (N // 2 + 1, C, C))
 
     def pairwise_spectral_granger_prediction(self):
         """Power at node i explained by node j, out[..., i, j] = j -> i (diagonal NaN)."""
@@ -292,14 +292,15 @@ class Connectivity:
 
     def _mvar(self, which, n_freq_axis=True):
         from . import engine
-        out = engine.mvar_measure(self._mvar_factor_device(), which).cpu().numpy()
+        out = engine.to_host(engine.mvar_measure(self._mvar_factor_device(), which))
         C = self._shape5[4]
         tail = (self._shape5[3] // 2 + 1, C, C) if n_freq_axis else (C, C)
         return out.reshape(self._kept_shape() + tail)
 
     @property
     def _minimum_phase_factor(self):
-        G = self._mvar_factor_device().cpu().numpy()
+        from . import engine
+        G = engine.to_host(self._mvar_factor_device())
         return G.reshape(self._kept_shape() + G.shape[1:])
 
     @property

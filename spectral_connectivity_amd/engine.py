@@ -35,6 +35,23 @@ def _ptr(t):
     return c_void_p(t.data_ptr())
 
 
+def to_host(t):
+    """Device tensor -> NumPy array through a page-locked buffer (the caching host allocator keeps and reuses the
+    blocks): a pageable copy of a large result runs at ~6 GB/s, a pinned one at link rate.  The array owns its
+    buffer (it is the pinned tensor's memory, kept alive by the array)."""
+    t = t.contiguous()
+    n_bytes = t.numel() * t.element_size()
+    if (1 << 20) <= n_bytes <= (2 << 30):
+        try:
+            h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            h.copy_(t, non_blocking=True)
+            torch.cuda.current_stream(t.device).synchronize()
+            return h.numpy()
+        except RuntimeError:
+            pass
+    return t.cpu().numpy()
+
+
 def fft_plan(n_fft, batch):
     """rocFFT real-forward plan: rows [batch][N] in, frequency-major [F][batch] out (cached per (N, batch, device))."""
     key = (int(n_fft), int(batch), torch.cuda.current_device())
