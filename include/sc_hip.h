@@ -193,7 +193,7 @@ int sc_fused_csm_absim_ws_f32(const void* d_X /*float2*/, const sc_spectra_desc*
  * (sc_fused_unit_scratch_bytes, 0 when none is needed).  Shapes, workspace and split as above. */
 /* Which planes of `planes` the one-pass entry points fill for this shape: CSM, |Im s| (with CSM) and
  * s/|s| for every supported shape; (Im s)^2 (with CSM and |Im s|, filled by sc_fused_csm_absim_ws_f32) and
- * sign(Im s) (sc_fused_sign_ws_f32: phase_lag_index, connectivity.py:983-1079) up to 48 channels, where
+ * sign(Im s) (sc_fused_sign_ws_f32: phase_lag_index, connectivity.py:983-1079) up to 58 channels, where
  * the path is an f32 VALU kernel.  The remaining planes are sc_nonlinear_accumulate_f32's. */
 uint32_t sc_fused_planes_covered(const sc_spectra_desc* desc, uint32_t planes);
 int sc_fused_sign_ws_f32(const void* d_X /*float2*/, const sc_spectra_desc* desc, uint32_t planes,

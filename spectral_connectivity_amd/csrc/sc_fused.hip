@@ -669,7 +669,7 @@ static int launch_fused(const FusedArgs& a, hipStream_t stream) {
     return SC_OK;
 }
 
-// ---- up to 48 channels: f32 VALU kernel ------------------------------------------------------------------
+// ---- up to 48 channels (58 for the planes with no matrix-core form): f32 VALU kernel -------------------------
 // The MFMA kernel above stages 32-row chunks of 32-channel blocks whatever C is, so its cost per observation row
 // does not fall with C: at 32 channels it runs 1.0 TB/s of input, at 8 channels 0.3 TB/s, where the arithmetic
 // (C (C+1) / 2 pairs x 6 flops-ish per row) would leave the stream HBM-bound.  Here a thread owns a 2 x 2 block of
@@ -877,6 +877,9 @@ static bool fused_ok(const void* d_X, const ScAxes& ax) {
 // The f32 VALU kernel below the measured crossover (same input volume as cfg3: 4.7 vs 5.1 ms at 48 channels with a
 // per-observation non-linear plane, 3.0 vs 3.9 ms at 40 channels without; the MFMA kernel wins from 56 / 44 on).
 static bool small_ok(const ScAxes& ax, bool nonlinear_plane) { return ax.C <= (nonlinear_plane ? 48 : 42); }
+// (Im s)^2 and sign(Im s) have no matrix-core form: the alternative above this kernel's range is the per-plane VALU
+// kernel, so it keeps them as far as one thread per 2 x 2 block goes (58 channels = 435 blocks).
+static bool small_ok_planes(const ScAxes& ax) { return ax.C <= 58; }
 
 extern "C" int sc_fused_supported(int64_t n_signals) {
     return (n_signals >= 2 && n_signals <= 128 && (n_signals % 2) == 0) ? 1 : 0;
@@ -941,7 +944,7 @@ static int fused_setup(const void* d_X, const sc_spectra_desc* desc, uint32_t pl
         a->csm_plane = -1;
         a->abs_plane = -1;
         a->sign_plane = sc_plane_offset(planes, SC_PLANE_SIGN_IM);
-    } else if (small_ok(*ax, true) && (planes & SC_PLANE_ABS_IM) && (planes & SC_PLANE_IM_SQ)) {
+    } else if (small_ok_planes(*ax) && (planes & SC_PLANE_ABS_IM) && (planes & SC_PLANE_IM_SQ)) {
         a->sq_plane = sc_plane_offset(planes, SC_PLANE_IM_SQ);       // rides along on the small-channel kernel
     }
     a->n_split = 1;
@@ -993,9 +996,10 @@ static int fused_run(const void* d_X, const sc_spectra_desc* desc, uint32_t plan
     a.n_split = S;
     a.ws = (float*)d_workspace;
     hipStream_t s = (hipStream_t)stream;
-    if (small_ok(ax, a.abs_plane >= 0 || mode == FU_MODE_SIGN)) return launch_small(a, unit, s);
+    if (small_ok(ax, a.abs_plane >= 0) || ((a.sq_plane >= 0 || mode == FU_MODE_SIGN) && small_ok_planes(ax)))
+        return launch_small(a, unit, s);
     if (mode == FU_MODE_SIGN) {
-        sc_set_error("sum sign(Im s) in one pass is built for up to 48 channels (got %d): use sc_nonlinear_accumulate_f32", ax.C);
+        sc_set_error("sum sign(Im s) in one pass is built for up to 58 channels (got %d): use sc_nonlinear_accumulate_f32", ax.C);
         return SC_EUNSUPPORTED;
     }
     if (unit) {
@@ -1022,13 +1026,13 @@ extern "C" int sc_fused_csm_absim_ws_f32(const void* d_X, const sc_spectra_desc*
 }
 
 // The planes of `planes` that the one-pass entry points fill for this shape: CSM, |Im s| (with CSM), s/|s| always;
-// (Im s)^2 (with CSM and |Im s|) and sign(Im s) up to 48 channels.  The rest is sc_nonlinear_accumulate_f32's.
+// (Im s)^2 (with CSM and |Im s|) and sign(Im s) up to 58 channels.  The rest is sc_nonlinear_accumulate_f32's.
 extern "C" uint32_t sc_fused_planes_covered(const sc_spectra_desc* desc, uint32_t planes) {
     ScAxes ax;
     if (!desc || sc_make_axes(desc, &ax) != SC_OK || !fused_ok(nullptr, ax)) return 0;
     uint32_t got = planes & (SC_PLANE_CSM | SC_PLANE_UNIT);
     if ((planes & SC_PLANE_CSM) && (planes & SC_PLANE_ABS_IM)) got |= SC_PLANE_ABS_IM;
-    if (small_ok(ax, true)) {
+    if (small_ok_planes(ax)) {
         if ((got & SC_PLANE_ABS_IM) && (planes & SC_PLANE_IM_SQ)) got |= SC_PLANE_IM_SQ;
         got |= planes & SC_PLANE_SIGN_IM;
     }
@@ -1036,7 +1040,7 @@ extern "C" uint32_t sc_fused_planes_covered(const sc_spectra_desc* desc, uint32_
 }
 
 // SC_PLANE_SIGN_IM of the record (phase_lag_index, debiased_squared_phase_lag_index: connectivity.py:983-1079) on the
-// small-channel kernel; SC_EUNSUPPORTED above 48 channels.
+// small-channel kernel; SC_EUNSUPPORTED above 58 channels.
 extern "C" int sc_fused_sign_ws_f32(const void* d_X, const sc_spectra_desc* desc, uint32_t planes, float* d_accum,
                                     void* d_workspace, int64_t workspace_bytes, void* stream) {
     return fused_run(d_X, desc, planes, FU_MODE_SIGN, d_accum, d_workspace, workspace_bytes, nullptr, 0, stream);

@@ -236,9 +236,9 @@ def test_fused_stage_b_equals_separate_kernels(sc, C, R):
                 so.weighted_phase_lag_index(coef), what="wpli vs oracle")
 
 
-@pytest.mark.parametrize("C,R", [(2, 40), (6, 9), (16, 120), (34, 5), (48, 7), (64, 6), (128, 5)])
+@pytest.mark.parametrize("C,R", [(2, 40), (6, 9), (16, 120), (34, 5), (48, 7), (50, 4), (58, 6), (60, 3), (64, 6), (128, 5)])
 def test_one_pass_nonlinear_planes_equal_the_per_plane_kernel(sc, C, R):
-    """(Im s)^2 and sign(Im s) ride on the small-channel one-pass kernel (<= 48 channels) and the unit phasors s/|s| go
+    """(Im s)^2 and sign(Im s) ride on the small-channel one-pass kernel (<= 58 channels) and the unit phasors s/|s| go
     through the one-pass kernels as the cross-spectral matrix of x/|x| at every size: the same accumulator records as the
     per-plane VALU kernel (sc_nonlinear.hip) up to f32 summation order -- sign sums exactly."""
     from spectral_connectivity_amd import _lib, engine
