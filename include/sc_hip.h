@@ -191,6 +191,12 @@ int sc_fused_csm_absim_ws_f32(const void* d_X /*float2*/, const sc_spectra_desc*
  * (0/0 -> NaN like the reference's x/abs(x)).  Up to 42 channels the normalisation happens while the
  * rows are staged; above, a normalised copy of the spectra goes to d_scratch first
  * (sc_fused_unit_scratch_bytes, 0 when none is needed).  Shapes, workspace and split as above. */
+/* SC_PLANE_UNIT for shapes the one-pass kernels do not take (> 128 channels): a normalised copy of the
+ * spectra (x/|x|, 0 -> NaN) in d_scratch (sc_unit_scratch_bytes) goes through the f32-MFMA CSM kernel. */
+int64_t sc_unit_scratch_bytes(const sc_spectra_desc* desc);
+int sc_unit_accumulate_f32(const void* d_X /*float2*/, const sc_spectra_desc* desc, uint32_t planes,
+                           float* d_accum, void* d_scratch, int64_t scratch_bytes, void* stream);
+
 /* Which planes of `planes` the one-pass entry points fill for this shape: CSM, |Im s| (with CSM) and
  * s/|s| for every supported shape; (Im s)^2 (with CSM and |Im s|, filled by sc_fused_csm_absim_ws_f32) and
  * sign(Im s) (sc_fused_sign_ws_f32: phase_lag_index, connectivity.py:983-1079) up to 58 channels, where

@@ -65,6 +65,8 @@ SYMBOLS = {
     "sc_fused_workspace_bytes": (c_int64, [POINTER(SpectraDesc), c_uint32]),
     "sc_fused_csm_absim_ws_f32": (c_int, [c_void_p, POINTER(SpectraDesc), c_uint32, c_void_p, c_void_p, c_int64,
                                           c_void_p]),
+    "sc_unit_scratch_bytes": (c_int64, [POINTER(SpectraDesc)]),
+    "sc_unit_accumulate_f32": (c_int, [c_void_p, POINTER(SpectraDesc), c_uint32, c_void_p, c_void_p, c_int64, c_void_p]),
     "sc_fused_planes_covered": (c_uint32, [POINTER(SpectraDesc), c_uint32]),
     "sc_fused_sign_ws_f32": (c_int, [c_void_p, POINTER(SpectraDesc), c_uint32, c_void_p, c_void_p, c_int64, c_void_p]),
     "sc_fused_unit_scratch_bytes": (c_int64, [POINTER(SpectraDesc)]),

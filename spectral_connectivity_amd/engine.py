@@ -210,6 +210,7 @@ def accumulate(spectra, expectation_type, planes, n_freq=None, mark=None, use_fu
     d = spectra.desc(expectation_type, n_freq)
     n_bins, fpb, _, n_obs = accum_layout(spectra, expectation_type, planes, n_freq)
     accum = torch.empty((n_bins, fpb), dtype=torch.float32, device=spectra.X.device)
+    per_plane_only = use_fused is False        # explicit request (tests): every plane through its separate kernel
     if use_fused is None:
         use_fused = bool(lib.sc_fused_supported(spectra.C_alloc))
     # planes the one-pass kernels fill for this shape (sc_fused.hip): CSM, |Im s|, s/|s|; for few channels also
@@ -255,6 +256,15 @@ def accumulate(spectra, expectation_type, planes, n_freq=None, mark=None, use_fu
         if mark:
             mark("csm_mfma")
     nl = planes & ~_lib.PLANE_CSM
+    if nl & _lib.PLANE_UNIT and not per_plane_only:
+        # sum s/|s| as the CSM of a normalised copy of the spectra (f32 MFMA) instead of a per-pair rsqrt on the VALU
+        sb = int(lib.sc_unit_scratch_bytes(byref(d)))
+        scratch = torch.empty((sb,), dtype=torch.uint8, device=spectra.X.device)
+        _lib.check(lib.sc_unit_accumulate_f32(_ptr(spectra.X), byref(d), planes, _ptr(accum), _ptr(scratch), sb,
+                                              _stream()), "sc_unit_accumulate_f32")
+        nl &= ~_lib.PLANE_UNIT
+        if mark:
+            mark("unit_mfma")
     if nl:
         _lib.check(lib.sc_nonlinear_accumulate_f32(_ptr(spectra.X), byref(d), planes, nl, _ptr(accum),
                                                    _stream()), "sc_nonlinear_accumulate_f32")

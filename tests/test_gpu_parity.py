@@ -236,7 +236,8 @@ def test_fused_stage_b_equals_separate_kernels(sc, C, R):
                 so.weighted_phase_lag_index(coef), what="wpli vs oracle")
 
 
-@pytest.mark.parametrize("C,R", [(2, 40), (6, 9), (16, 120), (34, 5), (48, 7), (50, 4), (58, 6), (60, 3), (64, 6), (128, 5)])
+@pytest.mark.parametrize("C,R", [(2, 40), (6, 9), (16, 120), (34, 5), (48, 7), (50, 4), (58, 6), (60, 3), (64, 6), (128, 5),
+                                 (129, 3), (160, 4), (255, 2)])
 def test_one_pass_nonlinear_planes_equal_the_per_plane_kernel(sc, C, R):
     """(Im s)^2 and sign(Im s) ride on the small-channel one-pass kernel (<= 58 channels) and the unit phasors s/|s| go
     through the one-pass kernels as the cross-spectral matrix of x/|x| at every size: the same accumulator records as the
@@ -251,7 +252,7 @@ def test_one_pass_nonlinear_planes_equal_the_per_plane_kernel(sc, C, R):
                           (_lib.PLANE_SIGN_IM, _lib.M_PLI), (_lib.PLANE_SIGN_IM, _lib.M_DEBIASED_PLI2),
                           (_lib.PLANE_UNIT, _lib.M_PLV), (_lib.PLANE_UNIT, _lib.M_PPC)):
         for et in ("trials_tapers", "time_trials_tapers"):
-            a_f, n = engine.accumulate(sp, et, planes, use_fused=True)
+            a_f, n = engine.accumulate(sp, et, planes, use_fused=None if C > 128 else True)
             a_s, _ = engine.accumulate(sp, et, planes, use_fused=False)
             got = engine.measure(a_f, C, planes, n, which).cpu().numpy()
             ref = engine.measure(a_s, C, planes, n, which).cpu().numpy()
