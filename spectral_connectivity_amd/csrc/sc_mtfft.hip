@@ -9,11 +9,11 @@
 // tapered-window round trip through HBM.  rocFFT stays the transform for every other length.
 //
 // Workgroup = one (window w, trial r, tile of CT channels).  The L x CT window tile is loaded
-// once into LDS with coalesced rows (channels are the fastest axis of x), detrended in place
-// (fp64 trend sums), and then for every taper k the CT real sequences are packed two-by-two
-// (channels c, c+1) into CT/2 complex sequences ("two-for-one" real FFT), transformed by an
-// in-LDS Stockham autosort FFT (radix-4 passes + one radix-2 pass when log2 N is odd, fp32,
-// twiddles from an LDS table rounded from fp64), separated by conjugate symmetry
+// once into LDS with coalesced rows (channels are the fastest axis of x), the trend sums are taken in fp64,
+// and then for every taper k the CT real sequences are packed two-by-two (channels c, c+1) into CT/2 complex
+// sequences ("two-for-one" real FFT), transformed by register-resident radix-16 butterflies with LDS
+// exchanges between the passes (fp32, twiddles from an LDS table rounded from fp64), separated by
+// conjugate symmetry
 //   A[f] = (Z[f] + conj Z[N-f]) / 2,   B[f] = (Z[f] - conj Z[N-f]) / (2i)
 // (DC and Nyquist come out exactly real, like the reference's real input), and stored as
 // float4 (A, B) so a wave writes contiguous CT*8-byte segments per frequency.
@@ -35,178 +35,11 @@ __device__ inline float2 cmul(float2 a, float2 b) {
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 
-template <int LOG2N, int CT>
-__global__ void __launch_bounds__(256) mtfft_kernel(MtArgs p) {
-    constexpr int N = 1 << LOG2N;
-    constexpr int NF = CT / 2;           // complex FFTs in flight (channel pairs)
-    constexpr int TPF = 256 / NF;        // threads per FFT
-    constexpr int BPT = (N / 4) / TPF;   // radix-4 butterflies per thread per pass
-    constexpr int ZS = N + 1;            // z row stride (float2): odd -> conflict-free columns
-    static_assert(BPT >= 1, "tile too wide for this N");
-    extern __shared__ __align__(16) unsigned char smem[];
-    float* xt = reinterpret_cast<float*>(smem);                       // [L][CT]  (N rows reserved)
-    float2* z = reinterpret_cast<float2*>(smem + (size_t)N * CT * 4); // [NF][ZS]
-    float2* tw = z + NF * ZS;                                         // [N]
-    double* red = reinterpret_cast<double*>(tw + N);                  // [2][256] then trend [2][CT]
-
-    const int tid = threadIdx.x;
-    const int c0 = blockIdx.x * CT, r = blockIdx.y, w = blockIdx.z;
-    const int L = p.L, C = p.C;
-    const int64_t RC = (int64_t)p.R * C;
-
-    for (int i = tid; i < N; i += 256) tw[i] = p.tw[i];
-    // 1. window tile, rows are contiguous in x (channel fastest)
-    const float* xw = p.x + ((int64_t)w * p.step * p.R + r) * C + c0;
-    for (int idx = tid; idx < L * CT; idx += 256) {
-        const int l = idx / CT, cc = idx - l * CT;
-        xt[idx] = (c0 + cc < C) ? xw[(int64_t)l * RC + cc] : 0.f;
-    }
-    __syncthreads();
-    // 2. detrend in place: per-column sums in fp64 over 256/CT row slices
-    if (p.detrend != SC_DETREND_NONE) {
-        constexpr int SL = 256 / CT;
-        const int cc = tid % CT, sl = tid / CT;
-        double s = 0.0, st = 0.0;
-        for (int l = sl; l < L; l += SL) {
-            const double v = (double)xt[l * CT + cc];
-            s += v;
-            st += v * (double)(l + 1);
-        }
-        red[tid] = s;
-        red[256 + tid] = st;
-        __syncthreads();
-        if (tid < CT) {
-            double sum = 0.0, sumt = 0.0;
-            for (int q = 0; q < SL; ++q) { sum += red[q * CT + tid]; sumt += red[256 + q * CT + tid]; }
-            sumt /= (double)L;
-            const double n = (double)L;
-            double a = 0.0, b;
-            if (p.detrend == SC_DETREND_CONSTANT) {
-                b = sum / n;
-            } else {  // least-squares line on abscissa (l+1)/L (reference transforms.py:1903-1909)
-                const double St = (n + 1.0) * 0.5, Stt = (n + 1.0) * (2.0 * n + 1.0) / (6.0 * n);
-                const double den = n * Stt - St * St;
-                a = (den != 0.0) ? (n * sumt - St * sum) / den : 0.0;
-                b = (sum - a * St) / n;
-            }
-            red[512 + tid] = a;
-            red[512 + CT + tid] = b;
-        }
-        __syncthreads();
-        const double invL = 1.0 / (double)L;
-        for (int idx = tid; idx < L * CT; idx += 256) {
-            const int l = idx / CT, cc2 = idx - l * CT;
-            const double t = (double)(l + 1) * invL;
-            xt[idx] = (float)((double)xt[idx] - (red[512 + cc2] * t + red[512 + CT + cc2]));
-        }
-        __syncthreads();
-    }
-
-    const int fft = tid / TPF, jt = tid - fft * TPF;
-    float2* zf = z + fft * ZS;
-    const int F = N / 2 + 1;
-    for (int k = 0; k < p.K; ++k) {
-        // 3a. z[pair][n] = (x[n][2p] h[n], x[n][2p+1] h[n]), zero padded to N
-        const float* hk = p.tapers + (int64_t)k * L;
-        for (int idx = tid; idx < N * NF; idx += 256) {
-            const int n = idx / NF, pr = idx - n * NF;
-            float2 v = make_float2(0.f, 0.f);
-            if (n < L) {
-                const float h = hk[n];
-                const float2 xv = *reinterpret_cast<const float2*>(xt + n * CT + 2 * pr);
-                v = make_float2(xv.x * h, xv.y * h);
-            }
-            z[pr * ZS + n] = v;
-        }
-        __syncthreads();
-        // 3b. Stockham autosort passes, in place through registers
-        int P = 1;
-#pragma unroll
-        for (int pass = 0; pass < LOG2N / 2; ++pass) {
-            float2 o[BPT][4];
-#pragma unroll
-            for (int b = 0; b < BPT; ++b) {
-                const int i = jt + b * TPF;
-                const int kk = i & (P - 1);
-                const int tstep = kk * (N / 4 / P);          // twiddle index step kk * N/(4P)
-                const float2 a0 = zf[i];
-                const float2 a1 = cmul(zf[i + N / 4], tw[tstep]);
-                const float2 a2 = cmul(zf[i + N / 2], tw[2 * tstep]);
-                const float2 a3 = cmul(zf[i + 3 * N / 4], tw[3 * tstep]);
-                const float2 b0 = make_float2(a0.x + a2.x, a0.y + a2.y);
-                const float2 b1 = make_float2(a0.x - a2.x, a0.y - a2.y);
-                const float2 b2 = make_float2(a1.x + a3.x, a1.y + a3.y);
-                const float2 b3 = make_float2(a1.y - a3.y, a3.x - a1.x);   // -i (a1 - a3)
-                o[b][0] = make_float2(b0.x + b2.x, b0.y + b2.y);
-                o[b][1] = make_float2(b1.x + b3.x, b1.y + b3.y);
-                o[b][2] = make_float2(b0.x - b2.x, b0.y - b2.y);
-                o[b][3] = make_float2(b1.x - b3.x, b1.y - b3.y);
-            }
-            __syncthreads();
-#pragma unroll
-            for (int b = 0; b < BPT; ++b) {
-                const int i = jt + b * TPF;
-                const int kk = i & (P - 1);
-                const int j = ((i - kk) << 2) + kk;
-                zf[j] = o[b][0];
-                zf[j + P] = o[b][1];
-                zf[j + 2 * P] = o[b][2];
-                zf[j + 3 * P] = o[b][3];
-            }
-            __syncthreads();
-            P <<= 2;
-        }
-        if constexpr (LOG2N & 1) {
-            float2 o[2 * BPT][2];
-#pragma unroll
-            for (int b = 0; b < 2 * BPT; ++b) {
-                const int i = jt + b * TPF;
-                const int kk = i & (P - 1);
-                const float2 u0 = zf[i];
-                const float2 u1 = cmul(zf[i + N / 2], tw[kk * (N / 2 / P)]);
-                o[b][0] = make_float2(u0.x + u1.x, u0.y + u1.y);
-                o[b][1] = make_float2(u0.x - u1.x, u0.y - u1.y);
-            }
-            __syncthreads();
-#pragma unroll
-            for (int b = 0; b < 2 * BPT; ++b) {
-                const int i = jt + b * TPF;
-                const int kk = i & (P - 1);
-                const int j = ((i - kk) << 1) + kk;
-                zf[j] = o[b][0];
-                zf[j + P] = o[b][1];
-            }
-            __syncthreads();
-        }
-        // 3c. split the packed pair, store X[f][w][r][k][c..c+1]
-        float2* Xk = p.X + (((int64_t)w * p.R + r) * p.K + k) * C + c0;
-        const int64_t sF = (int64_t)p.W * p.R * p.K * C;
-        const bool vec_ok = (C % 2) == 0;
-        for (int idx = tid; idx < F * NF; idx += 256) {
-            const int f = idx / NF, pr = idx - f * NF;
-            const int c = c0 + 2 * pr;
-            if (c >= C) continue;
-            const float2 z1 = z[pr * ZS + f];
-            const float2 z2 = z[pr * ZS + ((N - f) & (N - 1))];
-            const float2 A = make_float2(0.5f * (z1.x + z2.x), 0.5f * (z1.y - z2.y));
-            const float2 B = make_float2(0.5f * (z1.y + z2.y), 0.5f * (z2.x - z1.x));
-            float2* dst = Xk + (int64_t)f * sF + 2 * pr;
-            if (vec_ok) {
-                *reinterpret_cast<float4*>(dst) = make_float4(A.x, A.y, B.x, B.y);
-            } else {
-                dst[0] = A;
-                if (c + 1 < C) dst[1] = B;
-            }
-        }
-        __syncthreads();
-    }
-}
-
 // ----------------------------------------------------------------------------------------
-// Radix-16 variant for N = 64 (16x4), 128 (16x8), 256 (16x16), 512 (16x16x2), 1024 (16x16x4), 4096 (16x16x16):
+// N = 64 (16x4), 128 (16x8), 256 (16x16), 512 (16x16x2), 1024 (16x16x4), 2048 (16x16x8), 4096 (16x16x16):
 // every thread owns 16 points per pass, so a 256-point transform is TWO register-resident radix-16 butterflies with
-// one LDS exchange between them (the radix-4 kernel above needs four passes, eight barriers and
-// a separate pack pass).  Pass 1 reads the detrended window tile directly (x * taper, packed two
+// one LDS exchange between them (a radix-4 Stockham kernel, the first version of this file, needed four passes,
+// eight barriers and a separate pack pass: 1.3-2.1 TB/s stored where this one reaches 3.0-3.8).  Pass 1 reads the detrended window tile directly (x * taper, packed two
 // channels per complex sequence), so the tapered sequences are never materialised.  The exchange
 // buffer is skewed, phys(idx) = idx + idx/16, which makes the stride-16 writes of pass 1 and the
 // stride-N/16 reads of pass 2 both conflict-free; window rows are padded by 2 floats for the same
@@ -510,6 +343,29 @@ __global__ void __launch_bounds__(256, LOG2N <= 8 ? 4 : (LOG2N == 9 ? 3 : 1)) mt
             }
             __syncthreads();
         }
+        if constexpr (LOG2N == 11) {        // pass 3: radix 8, P = 256, two butterflies per thread
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int ib = i + b * TPF;            // 0..255, k = ib
+                float2 q[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const float2 v = zf[PHYS(ib + t * 256)];
+                    q[t] = (t == 0) ? v : cmul(v, tw[t * ib]);
+                }
+                dft8r(q);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a[8 * b + u] = q[u];
+            }
+            // in place: every thread writes back exactly the slots it read
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int ib = i + b * TPF;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) zf[PHYS(ib + 256 * u)] = a[8 * b + u];
+            }
+            __syncthreads();
+        }
         if constexpr (LOG2N == 10) {        // pass 3: radix 4, P = 256, four butterflies per thread
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
@@ -613,20 +469,6 @@ extern "C" int sc_fft_twiddles_f32(int64_t N, void* d_tw, void* stream) {
     return SC_OK;
 }
 
-template <int LOG2N, int CT>
-static int launch_mt(const MtArgs& a, hipStream_t stream) {
-    constexpr int N = 1 << LOG2N;
-    constexpr size_t shmem = (size_t)N * CT * 4 + (size_t)(CT / 2) * (N + 1) * 8 + (size_t)N * 8 +
-                             (size_t)(512 + 2 * CT) * 8;
-    static_assert(shmem <= 160 * 1024, "LDS budget exceeded");
-    auto k = mtfft_kernel<LOG2N, CT>;
-    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    dim3 grid((unsigned)((a.C + CT - 1) / CT), (unsigned)a.R, (unsigned)a.W);
-    hipLaunchKernelGGL(k, grid, dim3(256), shmem, stream, a);
-    SC_CHECK_HIP(hipGetLastError());
-    return SC_OK;
-}
-
 template <int LOG2N>
 static int launch_mt16(const MtArgs& a_in, hipStream_t stream) {
     constexpr int N = 1 << LOG2N;
@@ -678,7 +520,7 @@ extern "C" int sc_multitaper_fft_f32(const float* d_x, int64_t T, int64_t R, int
     case 256: return launch_mt16<8>(a, s);
     case 512: return launch_mt16<9>(a, s);
     case 1024: return launch_mt16<10>(a, s);
-    case 2048: return launch_mt<11, 8>(a, s);
+    case 2048: return launch_mt16<11>(a, s);
     case 4096: return launch_mt16<12>(a, s);
     }
     return SC_EUNSUPPORTED;
