@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(256, LOG2N <= 8 ? 4 : (LOG2N == 9 ? 3 : 1)) mt
     if (resident) {
         for (int i2 = tid; i2 < p.K * p.L; i2 += 256) hk[i2] = p.tapers[i2];
     } else {
-        for (int i2 = tid; i2 < L; i2 += 256) hk[i2] = p.tapers[i2];          // taper 0 into buffer 0 of two
+        for (int i2 = tid; i2 < L; i2 += 256) hk[i2] = p.tapers[i2];          // taper 0 into buffer 0
     }
 #define PHYS(idx) ((idx) + ((idx) >> 4))
 #define XBAR()                                                      \
@@ -257,7 +257,12 @@ __global__ void __launch_bounds__(256, LOG2N <= 8 ? 4 : (LOG2N == 9 ? 3 : 1)) mt
     } while (0)
     MT_TICK(0);
     for (int k = 0; k < p.K; ++k) {
-        const float* hkk = resident ? hk + k * L : hk + (k & 1) * L;
+        // Two taper buffers when the exchanges are wave-local (a fast wave parks taper k + 1 while a slow one still
+        // reads taper k in pass 1); from N = 2048 on every pass ends in a workgroup barrier, so by the time anyone parks
+        // the next taper all of pass 1 is done and ONE buffer is enough -- which puts N = 2048 under 80 KB of LDS,
+        // two workgroups per CU.
+        constexpr int TWO = WAVE_LOCAL ? 1 : 0;
+        const float* hkk = resident ? hk + k * L : hk + (k & TWO) * L;
         // the next taper travels HBM/L2 -> registers under this taper's passes and is parked in the other
         // LDS buffer before the stores go out (a load issued AFTER the stores would wait for them: vmcnt
         // retires in order)
@@ -400,7 +405,7 @@ __global__ void __launch_bounds__(256, LOG2N <= 8 ? 4 : (LOG2N == 9 ? 3 : 1)) mt
         }
         } else { __syncthreads(); }
         if (fetch_next) {
-            float* hnext = hk + ((k + 1) & 1) * L;
+            float* hnext = hk + ((k + 1) & TWO) * L;
 #pragma unroll
             for (int j = 0; j < HN; ++j) {
                 const int n = tid + 256 * j;
@@ -481,7 +486,7 @@ static int launch_mt16(const MtArgs& a_in, hipStream_t stream) {
     // Keep all K tapers in LDS when that does not cost a resident workgroup per CU.
     constexpr size_t cu_lds = 160 * 1024;
     MtArgs a = a_in;
-    const size_t one = lds(2, a.L), all = lds(a.K, a.L);
+    const size_t one = lds(TPF <= 64 ? 2 : 1, a.L), all = lds(a.K, a.L);
     a.kh = (all <= cu_lds && cu_lds / all == cu_lds / one) ? a.K : 1;
     { const char* d = getenv("SC_MTFFT_DEBUG"); a.dbg = d ? atoi(d) : 0; }
     const size_t shmem = a.kh == a.K ? all : one;
