@@ -151,6 +151,14 @@ __global__ void __launch_bounds__(256) rows_to_bins_kernel(const float2* __restr
     }
 }
 
+int sc_internal_rows_to_bins(const void* d_Z, void* d_X, int64_t rows, int64_t F, int64_t batch, int64_t b_off,
+                             int64_t nyquist_row, hipStream_t st) {
+    hipLaunchKernelGGL(rows_to_bins_kernel, dim3((unsigned)((rows + 63) / 64), (unsigned)((F + 31) / 32)), dim3(256), 0, st,
+                       (const float2*)d_Z, (float2*)d_X, rows, F, batch, b_off, nyquist_row);
+    SC_CHECK_HIP(hipGetLastError());
+    return SC_OK;
+}
+
 extern "C" int sc_fft_execute(sc_fft_plan* plan, const float* d_y, void* d_X, void* stream) {
     SC_REQUIRE(plan && d_y && d_X, "NULL argument");
     SC_CHECK_FFT(rocfft_execution_info_set_stream(plan->info, stream));

@@ -7,6 +7,10 @@
 
 void sc_set_error(const char* fmt, ...);
 
+// sc_api.hip: Z[rows][F] -> X[f][b_off + row] (X has `batch` columns), imaginary part of rows 0 and nyquist_row zeroed
+int sc_internal_rows_to_bins(const void* d_Z, void* d_X, int64_t rows, int64_t F, int64_t batch, int64_t b_off,
+                             int64_t nyquist_row, hipStream_t st);
+
 // sc_wilson_fft.hip: A <- fft(causal(ifft(A))) in one kernel, for the lengths `supported` accepts
 bool sc_internal_causal_fft_supported(int64_t N);
 int sc_internal_causal_fft_pair(void* d_A, const int32_t* d_status, int64_t n_problems, int C, int64_t N,

@@ -26,6 +26,8 @@ struct MtArgs {
     const float2* tw;      // [N] exp(-2 pi i m / N)
     float2* X;             // [F][W][R][K][C]
     int T, R, C, L, step, W, K, detrend;
+    float2* Z;             // long windows (N >= 2048): row-major output [w][r - r_off][k][c][F], transposed into X afterwards
+    int r_off, Rc;         //   trials [r_off, r_off + Rc) of this launch
     int kh;                // tapers resident in LDS (K, or 1 = reload per taper)
     int dbg;               // profiling aid (env SC_MTFFT_DEBUG bit mask, results WRONG when set):
                            // 1 = no HBM stores, 2 = skip both radix-16 passes, 4 = skip the split/store loop
@@ -110,7 +112,7 @@ extern "C" int sc_debug_mtfft_trace(unsigned long long* out, int reset) {
 #endif
 
 template <int LOG2N>
-__global__ void __launch_bounds__(256, LOG2N <= 8 ? 4 : (LOG2N == 9 ? 3 : 1)) mtfft16_kernel(MtArgs p) {
+__global__ void __launch_bounds__(256, LOG2N <= 8 ? 4 : (LOG2N == 9 ? 3 : (LOG2N >= 11 ? 3 : 1))) mtfft16_kernel(MtArgs p) {
     constexpr int N = 1 << LOG2N;
     constexpr int TPF = N / 16;          // threads per FFT: 16 points each
     constexpr int NF = 256 / TPF;        // complex FFTs (channel pairs) per workgroup
@@ -122,7 +124,13 @@ __global__ void __launch_bounds__(256, LOG2N <= 8 ? 4 : (LOG2N == 9 ? 3 : 1)) mt
     // registers (they are the same for all tapers); the exchange buffer z then reuses that space,
     // and the detrend scratch is later reused for the twiddle / taper tables: 39.6 KB per workgroup at N = 256,
     // four workgroups (16 waves) per CU.
-    constexpr size_t XT_BYTES = (size_t)N * XS * 4, Z_BYTES = (size_t)NF * ZS * 8;
+    // Long windows (N >= 2048, 2-4 channels per workgroup) keep NO window tile, twiddle table or taper buffer in LDS --
+    // samples and taper values come straight from HBM / L2 into registers, twiddles from two 64-entry tables -- so
+    // that two workgroups share a CU (45 KB each instead of 131 KB at N = 4096), and they store every channel's spectrum
+    // as one contiguous row that a tiled transpose turns into the frequency-major X (16-32-byte pieces per frequency
+    // row otherwise).
+    constexpr bool LONG = LOG2N >= 11;
+    constexpr size_t XT_BYTES = LONG ? 0 : (size_t)N * XS * 4, Z_BYTES = (size_t)NF * ZS * 8;
     constexpr size_t UNION_BYTES = XT_BYTES > Z_BYTES ? XT_BYTES : Z_BYTES;
     float* xt = reinterpret_cast<float*>(smem);                                   // [N][XS]
     float2* z = reinterpret_cast<float2*>(smem);                                  // [NF][ZS] (aliases xt)
@@ -130,120 +138,202 @@ __global__ void __launch_bounds__(256, LOG2N <= 8 ? 4 : (LOG2N == 9 ? 3 : 1)) mt
     double* red = reinterpret_cast<double*>(smem + UNION_BYTES);                  // [2][256] + trend [2][CT]
     float2* tw = reinterpret_cast<float2*>(smem + UNION_BYTES);                   // [N]   (aliases red)
     float* hk = reinterpret_cast<float*>(tw + N);                                 // [kh][L] tapers
+    float2* tlo = reinterpret_cast<float2*>(smem + UNION_BYTES + 4 * 256 * sizeof(double));   // LONG: W_N^j, j < 64
+    float2* thi = tlo + 64;                                                        // LONG: W_N^(64 q), q < N / 64
     // An FFT's 16 x TPF points are exchanged between lanes of ONE wavefront when TPF <= 64, and
     // LDS executes a wave's instructions in order: those exchanges need no workgroup barrier.
     constexpr bool WAVE_LOCAL = TPF <= 64;
 
     const int tid = threadIdx.x;
     MT_T0();
-    const int c0 = blockIdx.x * CT, r = blockIdx.y, w = blockIdx.z;
+    int c0, r, w;
+    if constexpr (LONG) {
+        // A thread reads 8 bytes of every window row, so the channel tiles of one (window, trial) share every line they
+        // fetch: keep them on ONE XCD (block b runs on XCD b % 8) and that XCD's L2 fetches each line from HBM once.
+        const int n_ct = (p.C + CT - 1) / CT;
+        const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
+        const int g = (j / n_ct) * 8 + xcd;                 // (window, trial of this launch)
+        if (g >= p.W * p.Rc) return;
+        c0 = (j % n_ct) * CT; w = g / p.Rc; r = p.r_off + (g - w * p.Rc);
+    } else {
+        c0 = blockIdx.x * CT; r = blockIdx.y; w = blockIdx.z;
+    }
     const int L = p.L, C = p.C;
     const int64_t RC = (int64_t)p.R * C;
     const bool resident = p.kh == p.K;
     const float* xw = p.x + ((int64_t)w * p.step * p.R + r) * C + c0;
-    if constexpr (CT % 4 == 0) {
-        // 16-byte loads, all of a thread's rows in flight at once (the tile is N x CT floats = 16 KB x 2)
-        constexpr int V = CT / 4, ROUNDS = N * V / 256;
-        const bool vec = (C % 4) == 0;
-        float4 v[ROUNDS];
-#pragma unroll
-        for (int it = 0; it < ROUNDS; ++it) {
-            const int idx = tid + it * 256, l = idx / V, cc = 4 * (idx - l * V);
-            const float* src = xw + (int64_t)l * RC + cc;
-            v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (l < L) {
-                if (vec && c0 + cc + 3 < C) {
-                    v[it] = *reinterpret_cast<const float4*>(src);
-                } else {
-                    if (c0 + cc < C) v[it].x = src[0];
-                    if (c0 + cc + 1 < C) v[it].y = src[1];
-                    if (c0 + cc + 2 < C) v[it].z = src[2];
-                    if (c0 + cc + 3 < C) v[it].w = src[3];
-                }
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < ROUNDS; ++it) {
-            const int idx = tid + it * 256, l = idx / V, cc = 4 * (idx - l * V);
-            if (l < L) {
-                float2* d = reinterpret_cast<float2*>(xt + l * XS + cc);
-                d[0] = make_float2(v[it].x, v[it].y);
-                d[1] = make_float2(v[it].z, v[it].w);
-            }
-        }
-    } else {
-        for (int idx = tid; idx < L * CT; idx += 256) {
-            const int l = idx / CT, cc = idx - l * CT;
-            xt[l * XS + cc] = (c0 + cc < C) ? xw[(int64_t)l * RC + cc] : 0.f;
-        }
-    }
-    __syncthreads();
-    if (p.detrend != SC_DETREND_NONE) {
-        constexpr int SL = 256 / CT;
-        const int cc = tid % CT, sl = tid / CT;
-        double s = 0.0, st = 0.0;
-        for (int l = sl; l < L; l += SL) {
-            const double v = (double)xt[l * XS + cc];
-            s += v;
-            st += v * (double)(l + 1);
-        }
-        red[tid] = s;
-        red[256 + tid] = st;
-        __syncthreads();
-        if (tid < CT) {
-            double sum = 0.0, sumt = 0.0;
-            for (int q = 0; q < SL; ++q) { sum += red[q * CT + tid]; sumt += red[256 + q * CT + tid]; }
-            sumt /= (double)L;
-            const double n = (double)L;
-            double a = 0.0, b;
-            if (p.detrend == SC_DETREND_CONSTANT) {
-                b = sum / n;
-            } else {
-                const double St = (n + 1.0) * 0.5, Stt = (n + 1.0) * (2.0 * n + 1.0) / (6.0 * n);
-                const double den = n * Stt - St * St;
-                a = (den != 0.0) ? (n * sumt - St * sum) / den : 0.0;
-                b = (sum - a * St) / n;
-            }
-            red[512 + tid] = a;
-            red[512 + CT + tid] = b;
-        }
-        // (the trend a t + b is subtracted below, while the samples are pulled into registers)
-    }
-    __syncthreads();                                  // tile and trend coefficients visible
-
     const int pf = tid / TPF, i = tid - pf * TPF;     // FFT (channel pair) and butterfly index
     float2* zf = z + pf * ZS;
     const int F = N / 2 + 1;
     const int64_t sF = (int64_t)p.W * p.R * p.K * C;
     const bool vec_ok = (C % 2) == 0;
     float2 xs[16];                                    // this thread's pass-1 inputs, all tapers
-    {
-        const bool detr = p.detrend != SC_DETREND_NONE;
-        const double invL = 1.0 / (double)L;
-        const double a0 = detr ? red[512 + 2 * pf] : 0.0, a1 = detr ? red[512 + 2 * pf + 1] : 0.0;
-        const double b0 = detr ? red[512 + CT + 2 * pf] : 0.0, b1 = detr ? red[512 + CT + 2 * pf + 1] : 0.0;
+    if constexpr (LONG) {
+        const int c = c0 + 2 * pf;
+        const float* src0 = xw + 2 * pf;
+        const bool pair = vec_ok && c + 1 < C;
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             const int n = i + t * TPF;
             float2 v = make_float2(0.f, 0.f);
-            if (n < L) {
-                v = *reinterpret_cast<const float2*>(xt + n * XS + 2 * pf);
-                if (detr) {           // same fp64 expression as a separate detrend pass would use
-                    const double tt = (double)(n + 1) * invL;
-                    v.x = (float)((double)v.x - (a0 * tt + b0));
-                    v.y = (float)((double)v.y - (a1 * tt + b1));
-                }
+            if (n < L && c < C) {
+                const float* src = src0 + (int64_t)n * RC;
+                if (pair) v = *reinterpret_cast<const float2*>(src);
+                else { v.x = src[0]; if (c + 1 < C) v.y = src[1]; }
             }
             xs[t] = v;
         }
+        if (p.detrend != SC_DETREND_NONE) {
+            // trend sums in fp64: a thread's 16 samples, then a tree over the TPF threads of the transform
+            double s0 = 0.0, t0 = 0.0, s1 = 0.0, t1 = 0.0;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const double l1 = (double)(i + t * TPF + 1);
+                s0 += (double)xs[t].x; t0 += (double)xs[t].x * l1;
+                s1 += (double)xs[t].y; t1 += (double)xs[t].y * l1;
+            }
+            red[tid] = s0; red[256 + tid] = t0; red[512 + tid] = s1; red[768 + tid] = t1;
+            __syncthreads();
+            for (int h = TPF / 2; h > 0; h >>= 1) {
+                if (i < h) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) red[q * 256 + tid] += red[q * 256 + tid + h];
+                }
+                __syncthreads();
+            }
+            const double n = (double)L, invL = 1.0 / n;
+            const double St = (n + 1.0) * 0.5, Stt = (n + 1.0) * (2.0 * n + 1.0) / (6.0 * n), den = n * Stt - St * St;
+            double ab[2][2];
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) {
+                const double sum = red[(2 * ch) * 256 + pf * TPF], sumt = red[(2 * ch + 1) * 256 + pf * TPF] / n;
+                double a = 0.0, b;
+                if (p.detrend == SC_DETREND_CONSTANT) {
+                    b = sum / n;
+                } else {
+                    a = (den != 0.0) ? (n * sumt - St * sum) / den : 0.0;
+                    b = (sum - a * St) / n;
+                }
+                ab[ch][0] = a; ab[ch][1] = b;
+            }
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int nn = i + t * TPF;
+                if (nn < L) {
+                    const double tt = (double)(nn + 1) * invL;
+                    xs[t].x = (float)((double)xs[t].x - (ab[0][0] * tt + ab[0][1]));
+                    xs[t].y = (float)((double)xs[t].y - (ab[1][0] * tt + ab[1][1]));
+                }
+            }
+        }
+        if (tid < 64) tlo[tid] = p.tw[tid];
+        else if (tid < 64 + N / 64) thi[tid - 64] = p.tw[(tid - 64) * 64];
+    } else {
+        if constexpr (CT % 4 == 0) {
+            // 16-byte loads, all of a thread's rows in flight at once (the tile is N x CT floats = 16 KB x 2)
+            constexpr int V = CT / 4, ROUNDS = N * V / 256;
+            const bool vec = (C % 4) == 0;
+            float4 v[ROUNDS];
+    #pragma unroll
+            for (int it = 0; it < ROUNDS; ++it) {
+                const int idx = tid + it * 256, l = idx / V, cc = 4 * (idx - l * V);
+                const float* src = xw + (int64_t)l * RC + cc;
+                v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (l < L) {
+                    if (vec && c0 + cc + 3 < C) {
+                        v[it] = *reinterpret_cast<const float4*>(src);
+                    } else {
+                        if (c0 + cc < C) v[it].x = src[0];
+                        if (c0 + cc + 1 < C) v[it].y = src[1];
+                        if (c0 + cc + 2 < C) v[it].z = src[2];
+                        if (c0 + cc + 3 < C) v[it].w = src[3];
+                    }
+                }
+            }
+    #pragma unroll
+            for (int it = 0; it < ROUNDS; ++it) {
+                const int idx = tid + it * 256, l = idx / V, cc = 4 * (idx - l * V);
+                if (l < L) {
+                    float2* d = reinterpret_cast<float2*>(xt + l * XS + cc);
+                    d[0] = make_float2(v[it].x, v[it].y);
+                    d[1] = make_float2(v[it].z, v[it].w);
+                }
+            }
+        } else {
+            for (int idx = tid; idx < L * CT; idx += 256) {
+                const int l = idx / CT, cc = idx - l * CT;
+                xt[l * XS + cc] = (c0 + cc < C) ? xw[(int64_t)l * RC + cc] : 0.f;
+            }
+        }
+        __syncthreads();
+        if (p.detrend != SC_DETREND_NONE) {
+            constexpr int SL = 256 / CT;
+            const int cc = tid % CT, sl = tid / CT;
+            double s = 0.0, st = 0.0;
+            for (int l = sl; l < L; l += SL) {
+                const double v = (double)xt[l * XS + cc];
+                s += v;
+                st += v * (double)(l + 1);
+            }
+            red[tid] = s;
+            red[256 + tid] = st;
+            __syncthreads();
+            if (tid < CT) {
+                double sum = 0.0, sumt = 0.0;
+                for (int q = 0; q < SL; ++q) { sum += red[q * CT + tid]; sumt += red[256 + q * CT + tid]; }
+                sumt /= (double)L;
+                const double n = (double)L;
+                double a = 0.0, b;
+                if (p.detrend == SC_DETREND_CONSTANT) {
+                    b = sum / n;
+                } else {
+                    const double St = (n + 1.0) * 0.5, Stt = (n + 1.0) * (2.0 * n + 1.0) / (6.0 * n);
+                    const double den = n * Stt - St * St;
+                    a = (den != 0.0) ? (n * sumt - St * sum) / den : 0.0;
+                    b = (sum - a * St) / n;
+                }
+                red[512 + tid] = a;
+                red[512 + CT + tid] = b;
+            }
+            // (the trend a t + b is subtracted below, while the samples are pulled into registers)
+        }
+        __syncthreads();                                  // tile and trend coefficients visible
+
+        {
+            const bool detr = p.detrend != SC_DETREND_NONE;
+            const double invL = 1.0 / (double)L;
+            const double a0 = detr ? red[512 + 2 * pf] : 0.0, a1 = detr ? red[512 + 2 * pf + 1] : 0.0;
+            const double b0 = detr ? red[512 + CT + 2 * pf] : 0.0, b1 = detr ? red[512 + CT + 2 * pf + 1] : 0.0;
+    #pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int n = i + t * TPF;
+                float2 v = make_float2(0.f, 0.f);
+                if (n < L) {
+                    v = *reinterpret_cast<const float2*>(xt + n * XS + 2 * pf);
+                    if (detr) {           // same fp64 expression as a separate detrend pass would use
+                        const double tt = (double)(n + 1) * invL;
+                        v.x = (float)((double)v.x - (a0 * tt + b0));
+                        v.y = (float)((double)v.y - (a1 * tt + b1));
+                    }
+                }
+                xs[t] = v;
+            }
+        }
     }
     __syncthreads();                                  // tile and detrend scratch consumed: their space is free
-    for (int i2 = tid; i2 < N; i2 += 256) tw[i2] = p.tw[i2];
-    if (resident) {
-        for (int i2 = tid; i2 < p.K * p.L; i2 += 256) hk[i2] = p.tapers[i2];
-    } else {
-        for (int i2 = tid; i2 < L; i2 += 256) hk[i2] = p.tapers[i2];          // taper 0 into buffer 0
+    if constexpr (!LONG) {
+        for (int i2 = tid; i2 < N; i2 += 256) tw[i2] = p.tw[i2];
+        if (resident) {
+            for (int i2 = tid; i2 < p.K * p.L; i2 += 256) hk[i2] = p.tapers[i2];
+        } else {
+            for (int i2 = tid; i2 < L; i2 += 256) hk[i2] = p.tapers[i2];          // taper 0 into buffer 0
+        }
     }
+    // W_N^m: the LDS table, or (long windows) the product of the two 64-entry tables
+    auto TW = [&](int m) -> float2 {
+        if constexpr (LONG) return cmul(tlo[m & 63], thi[m >> 6]);
+        else return tw[m];
+    };
 #define PHYS(idx) ((idx) + ((idx) >> 4))
 #define XBAR()                                                      \
     do {                                                            \
@@ -268,7 +358,15 @@ __global__ void __launch_bounds__(256, LOG2N <= 8 ? 4 : (LOG2N == 9 ? 3 : 1)) mt
         // retires in order)
         constexpr int HN = (N + 255) / 256;
         float hn[HN];
-        const bool fetch_next = !resident && k + 1 < p.K;
+        const bool fetch_next = !LONG && !resident && k + 1 < p.K;
+        float hl[LONG ? 16 : 1];                      // long windows: this taper's 16 values, straight from L2
+        if constexpr (LONG) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int n = i + t * TPF;
+                hl[t] = (n < L) ? p.tapers[(int64_t)k * L + n] : 0.f;
+            }
+        }
         if (fetch_next) {
 #pragma unroll
             for (int j = 0; j < HN; ++j) {
@@ -284,7 +382,8 @@ __global__ void __launch_bounds__(256, LOG2N <= 8 ? 4 : (LOG2N == 9 ? 3 : 1)) mt
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             const int n = i + t * TPF;
-            const float h = (n < L) ? hkk[n] : 0.f;
+            float h;
+            if constexpr (LONG) h = hl[t]; else h = (n < L) ? hkk[n] : 0.f;
             a[t] = make_float2(xs[t].x * h, xs[t].y * h);
         }
         dft16(a, o);
@@ -302,7 +401,7 @@ __global__ void __launch_bounds__(256, LOG2N <= 8 ? 4 : (LOG2N == 9 ? 3 : 1)) mt
 #pragma unroll
                 for (int j = 0; j < R2; ++j) {
                     const float2 v = zf[PHYS(16 * j + u)];
-                    q[j] = (j == 0) ? v : cmul(v, tw[j * u]);
+                    q[j] = (j == 0) ? v : cmul(v, TW(j * u));
                 }
                 if constexpr (R2 == 4) dft4r(q[0], q[1], q[2], q[3]); else dft8r(q);
 #pragma unroll
@@ -322,7 +421,7 @@ __global__ void __launch_bounds__(256, LOG2N <= 8 ? 4 : (LOG2N == 9 ? 3 : 1)) mt
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
                 const float2 v = zf[PHYS(i + t * TPF)];
-                a[t] = (t == 0) ? v : cmul(v, tw[t * kk * (N / 256)]);
+                a[t] = (t == 0) ? v : cmul(v, TW(t * kk * (N / 256)));
             }
             dft16(a, o);
             if constexpr (LOG2N != 8) XBAR();      // N = 256 writes back exactly the slots it read
@@ -335,7 +434,7 @@ __global__ void __launch_bounds__(256, LOG2N <= 8 ? 4 : (LOG2N == 9 ? 3 : 1)) mt
 #pragma unroll
             for (int b = 0; b < 8; ++b) {
                 const int ib = i + b * TPF;            // 0..255, k = ib
-                const float2 u0 = zf[PHYS(ib)], u1 = cmul(zf[PHYS(ib + 256)], tw[ib]);
+                const float2 u0 = zf[PHYS(ib)], u1 = cmul(zf[PHYS(ib + 256)], TW(ib));
                 a[2 * b] = make_float2(u0.x + u1.x, u0.y + u1.y);
                 a[2 * b + 1] = make_float2(u0.x - u1.x, u0.y - u1.y);
             }
@@ -356,7 +455,7 @@ __global__ void __launch_bounds__(256, LOG2N <= 8 ? 4 : (LOG2N == 9 ? 3 : 1)) mt
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
                     const float2 v = zf[PHYS(ib + t * 256)];
-                    q[t] = (t == 0) ? v : cmul(v, tw[t * ib]);
+                    q[t] = (t == 0) ? v : cmul(v, TW(t * ib));
                 }
                 dft8r(q);
 #pragma unroll
@@ -378,7 +477,7 @@ __global__ void __launch_bounds__(256, LOG2N <= 8 ? 4 : (LOG2N == 9 ? 3 : 1)) mt
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const float2 v = zf[PHYS(ib + t * 256)];
-                    a[4 * b + t] = (t == 0) ? v : cmul(v, tw[t * ib]);
+                    a[4 * b + t] = (t == 0) ? v : cmul(v, TW(t * ib));
                 }
                 dft4r(a[4 * b], a[4 * b + 1], a[4 * b + 2], a[4 * b + 3]);
             }
@@ -395,7 +494,7 @@ __global__ void __launch_bounds__(256, LOG2N <= 8 ? 4 : (LOG2N == 9 ? 3 : 1)) mt
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
                 const float2 v = zf[PHYS(i + t * TPF)];
-                a[t] = (t == 0) ? v : cmul(v, tw[t * i]);
+                a[t] = (t == 0) ? v : cmul(v, TW(t * i));
             }
             dft16(a, o);
             __syncthreads();
@@ -428,8 +527,14 @@ __global__ void __launch_bounds__(256, LOG2N <= 8 ? 4 : (LOG2N == 9 ? 3 : 1)) mt
             auto put = [&](int f, float2 u1, float2 u2) {
                 const float2 A = make_float2(0.5f * (u1.x + u2.x), 0.5f * (u1.y - u2.y));
                 const float2 B = make_float2(0.5f * (u1.y + u2.y), 0.5f * (u2.x - u1.x));
-                float2* dst = dst0 + (int64_t)f * sF;
                 if ((p.dbg & 1) && A.x != 12345.f) return;
+                if constexpr (LONG) {
+                    float2* row = p.Z + (((((int64_t)w * p.Rc + (r - p.r_off)) * p.K + k) * C + c) * (int64_t)(N / 2 + 1));
+                    row[f] = A;
+                    if (c + 1 < C) row[(N / 2 + 1) + f] = B;
+                    return;
+                }
+                float2* dst = dst0 + (int64_t)f * sF;
                 if (vec_ok) {
                     *reinterpret_cast<float4*>(dst) = make_float4(A.x, A.y, B.x, B.y);
                 } else {
@@ -492,6 +597,35 @@ static int launch_mt16(const MtArgs& a_in, hipStream_t stream) {
     const size_t shmem = a.kh == a.K ? all : one;
     auto k = mtfft16_kernel<LOG2N>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if constexpr (LOG2N >= 11) {
+        // long windows: row-major spectra of a range of trials into a stream-ordered scratch (<= 2 GB), then one tiled
+        // transpose per window into the frequency-major X
+        const size_t lds_long = z_b + 4 * 256 * sizeof(double) + (64 + N / 64) * sizeof(float2);
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_long);
+        const int64_t F = N / 2 + 1, rows_trial = (int64_t)a.K * a.C, batch = (int64_t)a.W * a.R * rows_trial;
+        int64_t rc = ((int64_t)2 << 30) / ((int64_t)a.W * rows_trial * F * 8);
+        rc = rc < 1 ? 1 : (rc > a.R ? a.R : rc);
+        float2* Z = nullptr;
+        if (hipMallocAsync((void**)&Z, (size_t)(a.W * rc * rows_trial * F) * sizeof(float2), stream) != hipSuccess) {
+            sc_set_error("multitaper FFT (N=%d): scratch allocation failed", N);
+            return SC_ENOMEM;
+        }
+        a.Z = Z;
+        int rc_ret = SC_OK;
+        for (int64_t r0 = 0; r0 < a.R && rc_ret == SC_OK; r0 += rc) {
+            const int64_t n = a.R - r0 < rc ? a.R - r0 : rc;
+            a.r_off = (int)r0; a.Rc = (int)n;
+            const int64_t n_ct = (a.C + CT - 1) / CT, groups8 = (a.W * n + 7) / 8 * 8;
+            hipLaunchKernelGGL(k, dim3((unsigned)(groups8 * n_ct)), dim3(256), lds_long, stream, a);
+            for (int64_t w = 0; w < a.W && rc_ret == SC_OK; ++w)
+                rc_ret = sc_internal_rows_to_bins(Z + w * n * rows_trial * F, a.X, n * rows_trial, F, batch,
+                                                  (w * a.R + r0) * rows_trial, N / 2, stream);
+        }
+        (void)hipFreeAsync(Z, stream);
+        if (rc_ret != SC_OK) return rc_ret;
+        SC_CHECK_HIP(hipGetLastError());
+        return SC_OK;
+    }
     dim3 grid((unsigned)((a.C + CT - 1) / CT), (unsigned)a.R, (unsigned)a.W);
     hipLaunchKernelGGL(k, grid, dim3(256), shmem, stream, a);
     SC_CHECK_HIP(hipGetLastError());
