@@ -183,7 +183,9 @@ def test_seeded_vs_oracle_multi_tile(sc, C, R, et):
 
 @pytest.mark.parametrize("N,L,C,det", [(64, 64, 5, "constant"), (128, 100, 70, "linear"), (256, 256, 33, None),
                                        (512, 300, 16, "constant"), (1024, 1024, 18, "linear"),
-                                       (2048, 2048, 6, "constant"), (4096, 4000, 3, "constant")])
+                                       (2048, 2048, 6, "constant"), (4096, 4000, 3, "constant"),
+                                       (2048, 1500, 5, "linear"), (4096, 4096, 7, None), (2048, 2048, 130, "constant"),
+                                       (4096, 3000, 1, "linear"), (1024, 700, 11, "constant")])
 def test_fused_fft_matches_oracle_and_rocfft(sc, N, L, C, det):
     """Fused HIP transform (power-of-two N, zero padding, odd channel counts, every detrend)
     against the float64 oracle, and the rocFFT fallback path against the same oracle."""
