@@ -233,3 +233,57 @@ def test_hot_kernels_are_bit_reproducible():
         sp2 = engine.multitaper_spectra(x, tap, 256, 128, 256, 7, "constant")
         assert torch.equal(sp2.X, x0)
         assert torch.equal(engine.accumulate(sp2, "trials_tapers", planes)[0], a0)
+
+
+@pytest.mark.parametrize("C,R", [(4, 12000), (16, 3000), (47, 1000)])
+def test_small_channel_kernel_at_full_observation_counts(sc, C, R):
+    """The f32 VALU stage-B kernel (<= 48 channels, odd counts through the zero pad channel) at observation counts of
+    the BASELINE scale -- up to 84 000 rows per bin, split over slices and workgroups -- against fp64 contractions of the
+    same device spectra (torch, GPU): CSM, sum |Im s|, sum (Im s)^2 and sum sign(Im s) per (window, bin, pair)."""
+    import torch
+    from spectral_connectivity_amd import _lib, engine
+    rng = np.random.default_rng(C)
+    x = (rng.standard_normal((384, R, C)) + 0.6 * rng.standard_normal((384, R, 1))).astype(np.float32)
+    m = sc.Multitaper(x, sampling_frequency=FS, time_halfbandwidth_product=4, n_time_samples_per_window=128,
+                      n_time_samples_per_step=128)
+    sp = m.device_spectra()
+    W, K, F = 3, 7, 65
+    X = sp.coefficients().to(torch.complex128).reshape(F, W, R * K, C)           # (f, w, o, c)
+    n_obs = R * K
+    csm = torch.zeros((F, W, C, C), dtype=torch.complex128, device="cuda")
+    ab = torch.zeros((F, W, C, C), dtype=torch.float64, device="cuda")
+    sq = torch.zeros_like(ab)
+    sg = torch.zeros_like(ab)
+    step = max(1, (1 << 22) // (C * C * W))
+    for f0 in range(0, F, 4):
+        for o0 in range(0, n_obs, step):
+            Xc = X[f0:f0 + 4, :, o0:o0 + step]
+            sc_ = Xc[..., :, None] * Xc[..., None, :].conj()                          # (f, w, o, c, d)
+            csm[f0:f0 + 4] += sc_.sum(2)
+            ab[f0:f0 + 4] += sc_.imag.abs().sum(2)
+            sq[f0:f0 + 4] += (sc_.imag ** 2).sum(2)
+            sg[f0:f0 + 4] += torch.sign(sc_.imag).sum(2)
+            del sc_
+    planes = _lib.PLANE_CSM | _lib.PLANE_ABS_IM | _lib.PLANE_IM_SQ
+    a, n = engine.accumulate(sp, "trials_tapers", planes)
+    assert n == n_obs
+    got = engine.measure(a, C, planes, n, _lib.M_CSM).reshape(W, F, C, C).cpu().numpy()
+    ref = (csm / n_obs).permute(1, 0, 2, 3).cpu().numpy()
+    assert np.abs(got - ref).max() <= 3e-6 * np.abs(ref).max()
+    # wPLI = |sum Im| / sum |Im|, debiased = (|sum Im|^2 - sum Im^2) / ((sum |Im|)^2 - sum Im^2): exercises both planes
+    off = ~np.eye(C, dtype=bool)
+    im = csm.imag.permute(1, 0, 2, 3).cpu().numpy()
+    abn, sqn = ab.permute(1, 0, 2, 3).cpu().numpy(), sq.permute(1, 0, 2, 3).cpu().numpy()
+    wpli_ref = im / np.where(abn > 0, abn, 1.0)
+    got = engine.measure(a, C, planes, n, _lib.M_WPLI).reshape(W, F, C, C).cpu().numpy()
+    inner = slice(1, F - 1)                                   # DC / Nyquist: Im s = 0 exactly
+    assert np.abs(got[:, inner][..., off] - wpli_ref[:, inner][..., off]).max() <= 1e-5
+    with np.errstate(invalid="ignore", divide="ignore"):
+        deb_ref = (im ** 2 - sqn) / (abn ** 2 - sqn)              # 0 / 0 on the (masked) diagonal
+    got = engine.measure(a, C, planes, n, _lib.M_DEBIASED_WPLI2).reshape(W, F, C, C).cpu().numpy()
+    assert np.abs(got[:, inner][..., off] - deb_ref[:, inner][..., off]).max() <= 1e-5
+    a2, _ = engine.accumulate(sp, "trials_tapers", _lib.PLANE_SIGN_IM)
+    got = engine.measure(a2, C, _lib.PLANE_SIGN_IM, n, _lib.M_PLI).reshape(W, F, C, C).cpu().numpy()
+    pli_ref = (sg / n_obs).permute(1, 0, 2, 3).cpu().numpy()
+    # sign() of an f32 product vs of an fp64 product: they differ only where |Im s| is within rounding of 0
+    assert np.abs(np.abs(got[:, inner][..., off]) - np.abs(pli_ref[:, inner][..., off])).max() <= 8.0 / n_obs
