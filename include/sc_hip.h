@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define SC_ABI_VERSION 1
+#define SC_ABI_VERSION 2
 
 /* error codes */
 #define SC_OK 0
@@ -231,23 +231,30 @@ int sc_measure_f32(const float* d_accum, int64_t n_bins, int64_t n_signals, uint
  *   d_out       double [n_groups][N/2+1][C][C]; out[.., i, j] = influence j -> i, NaN
  *               elsewhere (diagonal, pairs not requested, non-positive values)
  *   d_n_iter    int32 [n_groups*n_pairs] Wilson iterations used per problem
- *   d_status    int32 [n_groups*n_pairs]: 1 converged, 0 hit max_iter, -1 lag-0 covariance
- *               not positive definite (pair left NaN)
- *   h_summary   optional HOST int32[2]: {iterations run, problems not converged}
- * Unlike every other entry point this one SYNCHRONISES the stream once per Wilson iteration
- * (to stop when every problem has converged, like the reference loop). */
+ *   d_status    int32 [n_groups*n_pairs]: 1 converged, 0 hit max_iter
+ *   h_summary   optional HOST int32[3]: {iterations run, problems not converged, problems whose lag-0
+ *               covariance was not positive definite}.  The reference starts those from the Cholesky factor of a
+ *               random Wishart draw around the identity (minimum_phase_decomposition.py:78-93, global NumPy
+ *               generator); here they start from its expectation, the identity.
+ *   flags       SC_GRANGER_KEEP_OUTPUT: do not NaN-fill d_out first (the caller walks a long pair list in chunks
+ *               that share one output; any number of (group, pair) problems is accepted per call, the workspace
+ *               is what grows: n_groups * n_pairs * N * 160 bytes)
+ * Unlike every other entry point this one SYNCHRONISES the stream, once per four Wilson iterations (to stop
+ * when every problem has converged, like the reference loop; converged problems are skipped by every kernel,
+ * so the iterations queued past the last convergence are empty launches). */
+#define SC_GRANGER_KEEP_OUTPUT 1
 int sc_granger_workspace_bytes(int64_t n_groups, int64_t n_pairs, int64_t N, size_t* bytes);
 int sc_granger_pairwise_f64(const float* d_accum, int64_t n_groups, int64_t n_freq_accum,
                             int64_t N, int64_t n_signals, uint32_t planes, int64_t n_observations,
                             const int32_t* d_pairs, int64_t n_pairs, double tolerance, int max_iterations,
-                            void* d_work, size_t work_bytes, double* d_out, int32_t* d_n_iter,
+                            void* d_work, size_t work_bytes, int flags, double* d_out, int32_t* d_n_iter,
                             int32_t* d_status, int32_t* h_summary, void* stream);
 
 /* Minimum-phase (Wilson) factor of caller-supplied two-sided 2x2 Hermitian spectra: replaces
  * minimum_phase_decomposition() (minimum_phase_decomposition.py:227-322) for c <= 2 (a 1x1
  * spectrum is embedded as diag(s, 1)).  d_S: double [P][4][N] = (s00, s11, Re s01, Im s01) per bin;
  * d_G: complex128 [P][4][N] = (g00, g01, g10, g11), S = G G^H.  Workspace as for n_groups = 1,
- * n_pairs = P of sc_granger_workspace_bytes.  Synchronises the stream (see above). */
+ * n_pairs = P of sc_granger_workspace_bytes.  h_summary: HOST int32[3] as above.  Synchronises the stream (see above). */
 int sc_wilson_factor_f64(const double* d_S, int64_t n_problems, int64_t N, double tolerance,
                          int max_iterations, void* d_work, size_t work_bytes, void* d_G /*complex128*/,
                          int32_t* d_n_iter, int32_t* d_status, int32_t* h_summary, void* stream);

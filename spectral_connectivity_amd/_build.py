@@ -3,18 +3,26 @@
 ``python -m spectral_connectivity_amd._build`` or ``__graft_entry__.build()``.
 hipcc cross-compiles for gfx950 without a GPU; the resulting .so sits next to this file so
 that it travels with the source tree (no JIT cache, nothing in site-packages).
+
+Every source is compiled to its own object under ``build/`` (in parallel, re-used while the source, the
+headers and the flags are unchanged -- the key is a hash of their contents), then linked.
 """
+import hashlib
 import os
 import shutil
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsc_hip.so")
+OBJ_DIR = os.path.join(os.path.dirname(HERE), "build", "obj")
 SOURCES = ["sc_api.hip", "sc_taper.hip", "sc_mtfft.hip", "sc_csm.hip", "sc_nonlinear.hip", "sc_fused.hip", "sc_measure.hip",
-           "sc_wilson.hip", "sc_wilson_fft.hip", "sc_mvar.hip", "sc_global.hip", "sc_canonical.hip"]
+           "sc_wilson.hip", "sc_wilson_fft.hip", "sc_mvar.hip", "sc_global.hip", "sc_canonical.hip", "sc_f64.hip",
+           "sc_timing.hip"]
 HEADERS = ["sc_common.h", "sc_stage.h", os.path.join("..", "..", "include", "sc_hip.h")]
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wno-unused-result", "-fno-slp-vectorize"]
 
 
 def _hipcc():
@@ -36,17 +44,49 @@ def is_stale():
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
-    """Compile every HIP source for gfx950 into spectral_connectivity_amd/libsc_hip.so."""
-    if not force and not is_stale():
+def _digest(paths, extra):
+    h = hashlib.sha256(" ".join(extra).encode())
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:20]
+
+
+def build(force=False, verbose=True, extra_flags=(), out=None):
+    """Compile every HIP source for gfx950 into spectral_connectivity_amd/libsc_hip.so (or ``out``)."""
+    out = out or LIB
+    if not force and out == LIB and not is_stale():
         return LIB
-    cmd = [_hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
-           "-Wno-unused-result", "-fno-slp-vectorize", *sources(), "-lrocfft", "-o", LIB + ".tmp"]
+    hipcc = _hipcc()
+    flags = FLAGS + list(extra_flags)
+    headers = [os.path.join(CSRC, h) for h in HEADERS if os.path.exists(os.path.join(CSRC, h))]
+    if force and os.path.isdir(OBJ_DIR) and not extra_flags:
+        shutil.rmtree(OBJ_DIR)                        # a forced build really compiles every source
+    os.makedirs(OBJ_DIR, exist_ok=True)
+
+    def compile_one(src):
+        obj = os.path.join(OBJ_DIR, f"{os.path.basename(src)}.{_digest([src] + headers, flags)}.o")
+        if not os.path.exists(obj):
+            cmd = [hipcc, *flags, "-c", src, "-o", obj + ".tmp"]
+            if verbose:
+                print("[spectral_connectivity_amd] " + " ".join(cmd), file=sys.stderr)
+            subprocess.run(cmd, check=True)
+            os.replace(obj + ".tmp", obj)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=max(1, min(8, os.cpu_count() or 1))) as pool:
+        objs = list(pool.map(compile_one, sources()))
+    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", *objs, "-lrocfft", "-o", out + ".tmp"]
     if verbose:
         print("[spectral_connectivity_amd] " + " ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
-    os.replace(LIB + ".tmp", LIB)
-    return LIB
+    os.replace(out + ".tmp", out)
+    keep = set(objs)                                  # objects of superseded sources are dropped
+    for name in os.listdir(OBJ_DIR):
+        path = os.path.join(OBJ_DIR, name)
+        if path not in keep and name.endswith(".o") and not extra_flags:
+            os.remove(path)
+    return out
 
 
 if __name__ == "__main__":

@@ -18,7 +18,8 @@ from . import _build
 c_int64_p = POINTER(c_int64)
 
 # ---- constants mirrored from include/sc_hip.h -------------------------------------------
-SC_ABI_VERSION = 1
+SC_ABI_VERSION = 2
+GRANGER_KEEP_OUTPUT = 1
 DETREND = {None: 0, "constant": 1, "c": 1, "linear": 2, "l": 2}
 MVAR_DTF, MVAR_DC, MVAR_PDC, MVAR_GPDC, MVAR_DDTF, MVAR_TRANSFER, MVAR_COEFFICIENTS, MVAR_NOISE_COVARIANCE = range(8)
 PLANE_CSM, PLANE_ABS_IM, PLANE_IM_SQ, PLANE_SIGN_IM, PLANE_UNIT = 0x01, 0x02, 0x04, 0x08, 0x10
@@ -74,7 +75,7 @@ SYMBOLS = {
                                      c_int64, c_void_p]),
     "sc_granger_workspace_bytes": (c_int, [c_int64, c_int64, c_int64, POINTER(c_size_t)]),
     "sc_granger_pairwise_f64": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_uint32, c_int64,
-                                        c_void_p, c_int64, c_double, c_int, c_void_p, c_size_t, c_void_p,
+                                        c_void_p, c_int64, c_double, c_int, c_void_p, c_size_t, c_int, c_void_p,
                                         c_void_p, c_void_p, POINTER(c_int32), c_void_p]),
     "sc_wilson_factor_f64": (c_int, [c_void_p, c_int64, c_int64, c_double, c_int, c_void_p, c_size_t, c_void_p,
                                      c_void_p, c_void_p, POINTER(c_int32), c_void_p]),

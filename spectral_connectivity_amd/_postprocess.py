@@ -117,14 +117,20 @@ def delay(coherency, frequencies, n_observations, frequencies_of_interest=None, 
           significance_threshold=0.05, n_range=3):
     """Candidate delays (phase + 2 pi k) / 2 pi, k = -n_range .. n_range, per band frequency and channel pair
     (connectivity.py:1520-1590); shape (..., n_frequencies, 2 n_range + 1, n_signals, n_signals), NaN at the
-    frequencies where the pair's coherence is not significant.  (The reference stores its masked array into a
-    plain one, which keeps the raw data of the masked entries: with its always-NaN one-sample z-score that
-    leaves the constants 2 pi k everywhere; see statistics.coherence_fisher_z_transform.)"""
+    frequencies where the pair's coherence is not significant.
+
+    The reference computes on a masked array and stores it into a plain one, which keeps the RAW data of the masked
+    entries -- the untouched first operand 2 pi k; with its always-NaN one-sample z-score (see
+    statistics.coherence_fisher_z_transform) every entry is masked, so its output is the constant 2 pi k
+    everywhere.  With options.one_sample_fisher_z == "reference" (default) the non-significant entries carry that same
+    raw value, so the output equals the reference's; "unbiased" marks them NaN."""
+    from . import options
     phase, significant, _, pairs = _pair_phase(coherency, frequencies, n_observations, frequencies_of_interest,
                                                frequency_resolution, significance_threshold)
-    phase = np.where(significant, phase, np.nan)
     turns = np.arange(-n_range, n_range + 1)
-    cand = np.moveaxis((2 * np.pi * turns + phase[..., np.newaxis]) / (2 * np.pi), -1, -2)   # (..., F, R, P)
+    cand = (2 * np.pi * turns + phase[..., np.newaxis]) / (2 * np.pi)                         # (..., F, P, R)
+    masked = 2 * np.pi * turns if options.one_sample_fisher_z == "reference" else np.nan
+    cand = np.moveaxis(np.where(significant[..., np.newaxis], cand, masked), -1, -2)          # (..., F, R, P)
     n_signals = coherency.shape[-1]
     out = np.full(cand.shape[:-1] + (n_signals, n_signals), np.nan)
     out[..., pairs[:, 0], pairs[:, 1]] = cand

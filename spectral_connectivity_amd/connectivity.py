@@ -240,11 +240,15 @@ class Connectivity:
             self._accum_cache[key] = (self._reduce_over_ranks(accum), n_obs)
         accum, n_obs = self._accum_cache[key]
         n_groups = accum.shape[0] // n_freq
-        out, n_iter, status, (iters, not_conv) = engine.granger_pairwise(
+        out, n_iter, status, (iters, not_conv, fallback) = engine.granger_pairwise(
             accum, n_groups, n_freq, N, C, planes, self._n_observations_total(n_obs), pairs)
+        if fallback:
+            # reference minimum_phase_decomposition.py:78-93 (there the start is a random draw around the identity)
+            logger.warning("Computing the initial conditions using the Cholesky failed. "
+                           f"Using the identity as initial condition ({fallback} problems).")
         if not_conv:
             logger.warning(f"Maximum iterations reached. {status.numel() - not_conv} of {status.numel()} converged")
-        self._last_wilson = dict(iterations=iters, not_converged=not_conv,
+        self._last_wilson = dict(iterations=iters, not_converged=not_conv, cholesky_fallbacks=fallback,
                                  n_iter=n_iter.cpu().numpy(), status=status.cpu().numpy())
         return engine.to_host(out).reshape(self._kept_shape() + (N // 2 + 1, C, C))
 
@@ -257,7 +261,28 @@ class Connectivity:
         return self._granger(pairs)
 
     def subset_pairwise_spectral_granger_prediction(self, pairs):
-        return self._granger(np.asarray(pairs, dtype=np.int32))
+        """Granger prediction for the listed (i, j) channel pairs only; every other entry is NaN
+        (reference connectivity.py:1193-1213).  Indices follow NumPy rules: negative indices count from the end,
+        anything outside [-n_signals, n_signals) raises IndexError."""
+        C = self._shape5[4]
+        pairs = np.asarray(pairs)
+        if pairs.size == 0:
+            return np.full(self._kept_shape() + (self._n_freq, C, C), np.nan)
+        if pairs.ndim != 2 or pairs.shape[1] != 2:
+            raise ValueError(f"pairs must be a sequence of (i, j) index pairs, got shape {pairs.shape}")
+        if not np.issubdtype(pairs.dtype, np.integer):
+            if not np.all(pairs == np.floor(pairs)):
+                raise IndexError("pair indices must be integers")
+            pairs = pairs.astype(np.int64)
+        bad = (pairs < -C) | (pairs >= C)
+        if bad.any():
+            raise IndexError(f"index {int(pairs[bad][0])} is out of bounds for axis with size {C}")
+        pairs = np.where(pairs < 0, pairs + C, pairs).astype(np.int32)
+        # a channel paired with itself is a singular 2 x 2 problem; its only entries lie on the (NaN) diagonal
+        pairs = pairs[pairs[:, 0] != pairs[:, 1]]
+        if pairs.size == 0:
+            return np.full(self._kept_shape() + (self._n_freq, C, C), np.nan)
+        return self._granger(pairs)
 
     # ---- full Wilson factor and the directed MVAR measures (reference connectivity.py:567-589,
     # :1237-1426): one batched C x C factorisation on the device, cached, then one small kernel

@@ -31,6 +31,13 @@ __device__ inline cd cdivi(cd a, cd b) {
     return make_double2((a.x * b.x + a.y * b.y) / d, (a.y * b.x - a.x * b.y) / d);
 }
 
+// (group, pair) problem of a block: gridDim.y holds at most 65535 problems, gridDim.z the rest
+#define WILSON_PMAX 65535
+__device__ __forceinline__ int64_t wilson_problem() { return (int64_t)blockIdx.z * WILSON_PMAX + blockIdx.y; }
+static inline dim3 wilson_grid(unsigned gx, int64_t P) {
+    return dim3(gx, (unsigned)(P < WILSON_PMAX ? P : WILSON_PMAX), (unsigned)((P + WILSON_PMAX - 1) / WILSON_PMAX));
+}
+
 struct WilsonDims {
     int64_t P;       // problems = n_groups * n_pairs
     int64_t N;       // two-sided FFT length
@@ -53,8 +60,8 @@ __device__ inline float acc_read(const float* rec, int plane, int n_tiles, int N
 
 __global__ void k_build(const float* accum, const int32_t* pairs, WilsonDims d, double* S) {
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t p = blockIdx.y;
-    if (n >= d.N) return;
+    const int64_t p = wilson_problem();
+    if (n >= d.N || p >= d.P) return;
     const int64_t g = p / d.n_pairs, pr = p % d.n_pairs;
     const int i = pairs[2 * pr], j = pairs[2 * pr + 1];
     int64_t bin = n;
@@ -72,8 +79,12 @@ __global__ void k_build(const float* accum, const int32_t* pairs, WilsonDims d, 
     Sp[n] = s00; Sp[d.N + n] = s11; Sp[2 * d.N + n] = re; Sp[3 * d.N + n] = im;
 }
 
-// one block per problem: lag-0 covariance = mean_n Re S[n]; G0 = chol(R0)^H broadcast over n
-__global__ void __launch_bounds__(256) k_init(const double* S, cd* G, int32_t* status, int64_t N) {
+// one block per problem: lag-0 covariance = mean_n Re S[n]; G0 = chol(R0)^H broadcast over n.
+// Where the covariance is not positive definite the reference (minimum_phase_decomposition.py:78-93) logs a
+// warning and starts from the Cholesky factor of a random Wishart matrix -- mean of 1000 outer products of
+// standard normal vectors, i.e. the identity plus O(3 %) noise drawn from the GLOBAL NumPy generator.  Here such a
+// problem starts from the expectation of that draw, G0 = I (deterministic), and is counted in *n_fallback.
+__global__ void __launch_bounds__(256) k_init(const double* S, cd* G, int32_t* status, int32_t* n_fallback, int64_t N) {
     __shared__ double red[3][256];
     const int64_t p = blockIdx.x;
     const double* Sp = S + p * 4 * N;
@@ -88,9 +99,15 @@ __global__ void __launch_bounds__(256) k_init(const double* S, cd* G, int32_t* s
     }
     const double r00 = red[0][0] / (double)N, r11 = red[1][0] / (double)N, r01 = red[2][0] / (double)N;
     // lower Cholesky L of [[r00, r01],[r01, r11]]; G0 = L^T (upper triangular, real)
-    const double l00 = sqrt(r00), l10 = r01 / l00, t = r11 - l10 * l10, l11 = sqrt(t);
+    double l00 = sqrt(r00), l10 = r01 / l00;
+    const double t = r11 - l10 * l10;
+    double l11 = sqrt(t);
     const bool bad = !(r00 > 0.0) || !(t > 0.0);
-    if (threadIdx.x == 0) status[p] = bad ? -1 : 0;      // -1: not positive definite (LinAlgError)
+    if (bad) { l00 = 1.0; l10 = 0.0; l11 = 1.0; }
+    if (threadIdx.x == 0) {
+        status[p] = 0;
+        if (bad) atomicAdd(n_fallback, 1);
+    }
     cd* Gp = G + p * 4 * N;
     for (int64_t n = threadIdx.x; n < N; n += 256) {
         Gp[n] = make_double2(l00, 0); Gp[N + n] = make_double2(l10, 0);
@@ -119,20 +136,20 @@ __device__ __forceinline__ void predict2x2(cd g00, cd g01, cd g10, cd g11, const
     Ap[3 * N + n] = a11;
 }
 
-__global__ void k_predict(const double* S, const cd* G, const int32_t* status, cd* A, int64_t N) {
+__global__ void k_predict(const double* S, const cd* G, const int32_t* status, cd* A, int64_t N, int64_t P) {
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t p = blockIdx.y;
-    if (n >= N || status[p] != 0) return;
+    const int64_t p = wilson_problem();
+    if (n >= N || p >= P || status[p] != 0) return;
     const cd* Gp = G + p * 4 * N;
     predict2x2(Gp[n], Gp[N + n], Gp[2 * N + n], Gp[3 * N + n], S + p * 4 * N, A + p * 4 * N, n, N);
 }
 
 // after the (unnormalised) inverse FFT: 1/N, halve lag 0, zero strict lower triangle at lag 0,
 // zero the non-causal half
-__global__ void k_causal(cd* A, int64_t N) {
+__global__ void k_causal(cd* A, int64_t N, int64_t P) {
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t p = blockIdx.y;
-    if (n >= N) return;
+    const int64_t p = wilson_problem();
+    if (n >= N || p >= P) return;
     cd* Ap = A + p * 4 * N;
     const double invN = 1.0 / (double)N;
     const bool keep = n < (N + 1) / 2;
@@ -153,10 +170,11 @@ __device__ inline void atomic_max_nonneg(double* addr, double v) {
 // G <- G A+ and err = max |G - G_old|; the next iteration's A = predict(G_new) overwrites A+ in the same pass
 // (a problem that turns out to have converged leaves an A nobody reads).
 __global__ void __launch_bounds__(256) k_update(cd* G, cd* Aplus, const double* S, const int32_t* status, double* err,
-                                                int64_t N) {
+                                                int64_t N, int64_t P) {
     __shared__ double red[256];
     const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t p = blockIdx.y;
+    const int64_t p = wilson_problem();
+    if (p >= P) return;                                // the whole block shares p
     double e = 0.0;
     if (n < N && status[p] == 0) {
         cd* Gp = G + p * 4 * N;
@@ -182,7 +200,8 @@ __global__ void __launch_bounds__(256) k_update(cd* G, cd* Aplus, const double* 
     if (threadIdx.x == 0 && red[0] > 0.0) atomic_max_nonneg(err + p, red[0]);
 }
 
-// status: 0 running -> 1 converged (err < tol); counts iterations; clears err; *n_running = #still 0
+// status: 0 running -> 1 converged (err < tol); counts iterations; clears err; *n_running = #still 0 (one slot per
+// iteration: the host reads the slots of a whole batch of iterations at once)
 __global__ void k_flags(int32_t* status, int32_t* n_iter, double* err, double tol, int64_t P, int32_t* n_running) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
@@ -217,10 +236,16 @@ __global__ void __launch_bounds__(256) k_h0(const cd* G, double* h0, int64_t N) 
 __global__ void k_pair_consts(const double* h0, double* hinv, double* rot, int64_t n_groups, int64_t n_pairs) {
     const int64_t pr = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (pr >= n_pairs) return;
+    // groups whose factor came out non-finite (a degenerate window) are left out of the mean, so that only they
+    // are NaN in the output
     double m = 0.0;
-    for (int64_t g = 0; g < n_groups; ++g)
-        for (int e = 0; e < 4; ++e) { const double v = h0[(g * n_pairs + pr) * 4 + e]; m += v * v; }
-    const double lam = 1e-12 * m / (double)(4 * n_groups);
+    int64_t n_ok = 0;
+    for (int64_t g = 0; g < n_groups; ++g) {
+        const double* h = h0 + (g * n_pairs + pr) * 4;
+        const double q = h[0] * h[0] + h[1] * h[1] + h[2] * h[2] + h[3] * h[3];
+        if (isfinite(q)) { m += q; ++n_ok; }
+    }
+    const double lam = n_ok ? 1e-12 * m / (double)(4 * n_ok) : 0.0;
     for (int64_t g = 0; g < n_groups; ++g) {
         const int64_t p = g * n_pairs + pr;
         const double a = h0[p * 4], b = h0[p * 4 + 1], c = h0[p * 4 + 2], d = h0[p * 4 + 3];
@@ -242,14 +267,13 @@ __global__ void k_fill_nan(double* out, int64_t total) {
 __global__ void k_granger(const cd* G, const double* S, const double* hinv, const double* rot,
                           const int32_t* status, const int32_t* pairs, WilsonDims d, int64_t Fout, double* out) {
     const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t p = blockIdx.y;
-    if (f >= Fout) return;
+    const int64_t p = wilson_problem();
+    if (f >= Fout || p >= d.P) return;
     const int64_t g = p / d.n_pairs, pr = p % d.n_pairs;
     const int i = pairs[2 * pr], j = pairs[2 * pr + 1];
     const int idx[2] = {i, j};
     const int64_t N = d.N;
     double* o = out + ((g * Fout + f) * d.C) * d.C;
-    if (status[p] < 0) return;                       // Cholesky failed: pair stays NaN
     const cd* Gp = G + p * 4 * N;
     const double* Sp = S + p * 4 * N;
     const cd gg[4] = {Gp[f], Gp[N + f], Gp[2 * N + f], Gp[3 * N + f]};
@@ -292,11 +316,13 @@ static int make_z2z(rocfft_plan* plan, rocfft_transform_type type, size_t N, siz
     return SC_OK;
 }
 
+#define WILSON_HIST 1024     // iterations whose "still running" counts the workspace can log (max_iterations <= this)
+#define WILSON_POLL 4        // iterations queued between two looks at the counts
 extern "C" int sc_granger_workspace_bytes(int64_t n_groups, int64_t n_pairs, int64_t N, size_t* bytes) {
     SC_REQUIRE(bytes && n_groups >= 1 && n_pairs >= 1 && N >= 2, "bad workspace query");
     const size_t P = (size_t)n_groups * n_pairs;
     // S (4 doubles) + G (4 complex) + A (4 complex) per (problem, bin) + per-problem scalars
-    *bytes = P * (size_t)N * (4 * 8 + 4 * 16 + 4 * 16) + P * (8 + 4 + 4 + 4 * 8 * 3) + 256;
+    *bytes = P * (size_t)N * (4 * 8 + 4 * 16 + 4 * 16) + P * (8 + 4 + 4 + 4 * 8 * 3) + 256 + WILSON_HIST * 4;
     return SC_OK;
 }
 
@@ -310,7 +336,9 @@ extern "C" int sc_granger_workspace_bytes(int64_t n_groups, int64_t n_pairs, int
     } while (0)
 
 struct WilsonWork {
-    double* S; cd* G; cd* A; double* err; double* h0; double* hinv; double* rot; int32_t* n_running;
+    double* S; cd* G; cd* A; double* err; double* h0; double* hinv; double* rot;
+    int32_t* n_fallback;     // problems started from the identity (lag-0 covariance not positive definite)
+    int32_t* n_running;      // [WILSON_HIST] problems still running after iteration i
 };
 
 static WilsonWork wilson_carve(void* d_work, int64_t P, int64_t N) {
@@ -323,13 +351,17 @@ static WilsonWork wilson_carve(void* d_work, int64_t P, int64_t N) {
     k.h0 = (double*)w; w += (size_t)P * 32;
     k.hinv = (double*)w; w += (size_t)P * 32;
     k.rot = (double*)w; w += (size_t)P * 32;
+    k.n_fallback = (int32_t*)w; w += 256;
     k.n_running = (int32_t*)w;
     return k;
 }
 
-// k_init + the Wilson iteration on work.S -> work.G.  Synchronises the stream once per iteration.
+// k_init + the Wilson iteration on work.S -> work.G.  The stream is synchronised once per WILSON_POLL iterations:
+// every iteration logs how many problems are still running into its own slot, converged problems are skipped by
+// every kernel, so queueing a few iterations past the last convergence changes nothing but costs empty launches.
 static int wilson_iterate(const WilsonWork& k, int64_t P, int64_t N, double tol, int max_iter,
-                          int32_t* d_n_iter, int32_t* d_status, int* iters_out, int* running_out, hipStream_t st) {
+                          int32_t* d_n_iter, int32_t* d_status, int* iters_out, int* running_out, int* fallback_out,
+                          hipStream_t st) {
     int rc = SC_OK;
     rocfft_plan fwd = nullptr, inv = nullptr;
     rocfft_execution_info info = nullptr;
@@ -337,9 +369,11 @@ static int wilson_iterate(const WilsonWork& k, int64_t P, int64_t N, double tol,
     size_t ws_f = 0, ws_i = 0;
     static int rocfft_ready = 0;
     if (!rocfft_ready) { rocfft_setup(); rocfft_ready = 1; }
-    const dim3 gridN((unsigned)((N + 255) / 256), (unsigned)P);
-    int iters = 0, running = (int)P;
+    const dim3 gridN = wilson_grid((unsigned)((N + 255) / 256), P);
+    int iters = 0, running = (int)P, queued = 0;
+    int32_t hist[WILSON_POLL];
     const bool fused = sc_internal_causal_fft_supported(N);
+    if (max_iter > WILSON_HIST) max_iter = WILSON_HIST;
 
     if (!fused) {
         if ((rc = make_z2z(&fwd, rocfft_transform_type_complex_forward, N, 4 * P)) != SC_OK) goto done;
@@ -349,35 +383,47 @@ static int wilson_iterate(const WilsonWork& k, int64_t P, int64_t N, double tol,
         SC_CHECK_FFT2(rocfft_execution_info_create(&info));
         if (ws_f < ws_i) ws_f = ws_i;
         if (ws_f) {
-            if (hipMalloc(&fft_work, ws_f) != hipSuccess) { sc_set_error("rocFFT work buffer alloc failed"); rc = SC_ENOMEM; goto done; }
+            if (hipMallocAsync(&fft_work, ws_f, st) != hipSuccess) { sc_set_error("rocFFT work buffer alloc failed"); rc = SC_ENOMEM; goto done; }
             SC_CHECK_FFT2(rocfft_execution_info_set_work_buffer(info, fft_work, ws_f));
         }
         SC_CHECK_FFT2(rocfft_execution_info_set_stream(info, st));
     }
     (void)hipMemsetAsync(k.err, 0, (size_t)P * 8, st);
     (void)hipMemsetAsync(d_n_iter, 0, (size_t)P * 4, st);
-    hipLaunchKernelGGL(k_init, dim3((unsigned)P), dim3(256), 0, st, k.S, k.G, d_status, N);
-    hipLaunchKernelGGL(k_predict, gridN, dim3(256), 0, st, k.S, k.G, d_status, k.A, N);
-    for (iters = 0; iters < max_iter; ++iters) {
-        if (fused) {        // one kernel for ifft -> causal mask -> fft
-            if ((rc = sc_internal_causal_fft_pair(k.A, d_status, P, 2, N, st)) != SC_OK) goto done;
-        } else {
-            void* bufs[1] = {k.A};
-            SC_CHECK_FFT2(rocfft_execute(inv, bufs, nullptr, info));
-            hipLaunchKernelGGL(k_causal, gridN, dim3(256), 0, st, k.A, N);
-            SC_CHECK_FFT2(rocfft_execute(fwd, bufs, nullptr, info));
+    (void)hipMemsetAsync(k.n_fallback, 0, 256 + (size_t)WILSON_HIST * 4, st);      // fallback count + the slots
+    hipLaunchKernelGGL(k_init, dim3((unsigned)P), dim3(256), 0, st, k.S, k.G, d_status, k.n_fallback, N);
+    hipLaunchKernelGGL(k_predict, gridN, dim3(256), 0, st, k.S, k.G, d_status, k.A, N, P);
+    while (queued < max_iter && running > 0) {
+        const int first = queued;
+        for (int b = 0; b < WILSON_POLL && queued < max_iter; ++b, ++queued) {
+            if (fused) {        // one kernel for ifft -> causal mask -> fft
+                if ((rc = sc_internal_causal_fft_pair(k.A, d_status, P, 2, N, st)) != SC_OK) goto done;
+            } else {
+                void* bufs[1] = {k.A};
+                SC_CHECK_FFT2(rocfft_execute(inv, bufs, nullptr, info));
+                hipLaunchKernelGGL(k_causal, gridN, dim3(256), 0, st, k.A, N, P);
+                SC_CHECK_FFT2(rocfft_execute(fwd, bufs, nullptr, info));
+            }
+            // G <- G A+ with the next iteration's A = predict(G) in the same pass
+            hipLaunchKernelGGL(k_update, gridN, dim3(256), 0, st, k.G, k.A, k.S, d_status, k.err, N, P);
+            hipLaunchKernelGGL(k_flags, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, d_status, d_n_iter, k.err, tol, P,
+                               k.n_running + queued);
         }
-        // G <- G A+ with the next iteration's A = predict(G) in the same pass
-        hipLaunchKernelGGL(k_update, gridN, dim3(256), 0, st, k.G, k.A, k.S, d_status, k.err, N);
-        (void)hipMemsetAsync(k.n_running, 0, 4, st);
-        hipLaunchKernelGGL(k_flags, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, d_status, d_n_iter, k.err, tol, P,
-                           k.n_running);
-        if (hipMemcpyAsync(&running, k.n_running, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        if (hipMemcpyAsync(hist, k.n_running + first, (size_t)(queued - first) * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
             hipStreamSynchronize(st) != hipSuccess) {
-            sc_set_error("Wilson iteration %d: %s", iters, hipGetErrorString(hipGetLastError()));
+            sc_set_error("Wilson iterations %d..%d: %s", first, queued, hipGetErrorString(hipGetLastError()));
             rc = SC_EHIP; goto done;
         }
-        if (running == 0) { ++iters; break; }
+        for (int b = 0; b < queued - first; ++b) {
+            running = hist[b];
+            iters = first + b + 1;
+            if (running == 0) break;
+        }
+    }
+    if (hipMemcpyAsync(fallback_out, k.n_fallback, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) {
+        sc_set_error("Wilson: %s", hipGetErrorString(hipGetLastError()));
+        rc = SC_EHIP; goto done;
     }
     *iters_out = iters;
     *running_out = running;
@@ -385,19 +431,19 @@ done:
     if (info) rocfft_execution_info_destroy(info);
     if (fwd) rocfft_plan_destroy(fwd);
     if (inv) rocfft_plan_destroy(inv);
-    if (fft_work) (void)hipFree(fft_work);
+    if (fft_work) (void)hipFreeAsync(fft_work, st);
     return rc;
 }
 
 extern "C" int sc_granger_pairwise_f64(const float* d_accum, int64_t n_groups, int64_t n_freq_accum,
                                        int64_t N, int64_t C, uint32_t planes, int64_t n_obs,
                                        const int32_t* d_pairs, int64_t n_pairs, double tol, int max_iter,
-                                       void* d_work, size_t work_bytes, double* d_out, int32_t* d_n_iter,
+                                       void* d_work, size_t work_bytes, int flags, double* d_out, int32_t* d_n_iter,
                                        int32_t* d_status, int32_t* h_summary, void* stream) {
     SC_REQUIRE(d_accum && d_pairs && d_work && d_out && d_n_iter && d_status, "NULL argument");
     SC_REQUIRE(planes & SC_PLANE_CSM, "accumulator record must contain SC_PLANE_CSM");
     SC_REQUIRE(n_freq_accum == N || n_freq_accum == N / 2 + 1, "accumulators must hold N or N/2+1 bins");
-    SC_REQUIRE(n_groups * n_pairs <= 65535, "too many (group, pair) problems for one launch");
+    SC_REQUIRE(n_groups >= 1 && n_pairs >= 1 && n_groups * n_pairs <= (int64_t)WILSON_PMAX * WILSON_PMAX, "bad problem count");
     size_t need = 0;
     sc_granger_workspace_bytes(n_groups, n_pairs, N, &need);
     SC_REQUIRE(work_bytes >= need, "workspace too small");
@@ -411,12 +457,13 @@ extern "C" int sc_granger_pairwise_f64(const float* d_accum, int64_t n_groups, i
     d.n_obs = (double)n_obs;
     const int64_t P = d.P, Fout = N / 2 + 1;
     const WilsonWork k = wilson_carve(d_work, P, N);
-    const dim3 gridN((unsigned)((N + 255) / 256), (unsigned)P), gridF((unsigned)((Fout + 255) / 256), (unsigned)P);
-    hipLaunchKernelGGL(k_fill_nan, dim3((unsigned)((n_groups * Fout * C * C + 255) / 256)), dim3(256), 0, st, d_out,
-                       n_groups * Fout * C * C);
+    const dim3 gridN = wilson_grid((unsigned)((N + 255) / 256), P), gridF = wilson_grid((unsigned)((Fout + 255) / 256), P);
+    if (!(flags & SC_GRANGER_KEEP_OUTPUT))
+        hipLaunchKernelGGL(k_fill_nan, dim3((unsigned)((n_groups * Fout * C * C + 255) / 256)), dim3(256), 0, st, d_out,
+                           n_groups * Fout * C * C);
     hipLaunchKernelGGL(k_build, gridN, dim3(256), 0, st, d_accum, d_pairs, d, k.S);
-    int iters = 0, running = 0;
-    const int rc = wilson_iterate(k, P, N, tol, max_iter, d_n_iter, d_status, &iters, &running, st);
+    int iters = 0, running = 0, fallback = 0;
+    const int rc = wilson_iterate(k, P, N, tol, max_iter, d_n_iter, d_status, &iters, &running, &fallback, st);
     if (rc != SC_OK) return rc;
     hipLaunchKernelGGL(k_h0, dim3((unsigned)P), dim3(256), 0, st, k.G, k.h0, N);
     hipLaunchKernelGGL(k_pair_consts, dim3((unsigned)((n_pairs + 63) / 64)), dim3(64), 0, st, k.h0, k.hinv, k.rot,
@@ -426,7 +473,7 @@ extern "C" int sc_granger_pairwise_f64(const float* d_accum, int64_t n_groups, i
         sc_set_error("Granger epilogue failed: %s", hipGetErrorString(hipGetLastError()));
         return SC_EHIP;
     }
-    if (h_summary) { h_summary[0] = iters; h_summary[1] = running; }
+    if (h_summary) { h_summary[0] = iters; h_summary[1] = running; h_summary[2] = fallback; }
     return SC_OK;
 }
 
@@ -437,18 +484,18 @@ extern "C" int sc_wilson_factor_f64(const double* d_S, int64_t n_problems, int64
                                     void* d_work, size_t work_bytes, void* d_G, int32_t* d_n_iter,
                                     int32_t* d_status, int32_t* h_summary, void* stream) {
     SC_REQUIRE(d_S && d_work && d_G && d_n_iter && d_status, "NULL argument");
-    SC_REQUIRE(n_problems >= 1 && n_problems <= 65535 && N >= 2, "bad problem size");
+    SC_REQUIRE(n_problems >= 1 && n_problems <= (int64_t)WILSON_PMAX * WILSON_PMAX && N >= 2, "bad problem size");
     size_t need = 0;
     sc_granger_workspace_bytes(1, n_problems, N, &need);
     SC_REQUIRE(work_bytes >= need, "workspace too small");
     hipStream_t st = (hipStream_t)stream;
     const WilsonWork k = wilson_carve(d_work, n_problems, N);
     SC_CHECK_HIP(hipMemcpyAsync(k.S, d_S, (size_t)n_problems * N * 4 * 8, hipMemcpyDeviceToDevice, st));
-    int iters = 0, running = 0;
-    const int rc = wilson_iterate(k, n_problems, N, tol, max_iter, d_n_iter, d_status, &iters, &running, st);
+    int iters = 0, running = 0, fallback = 0;
+    const int rc = wilson_iterate(k, n_problems, N, tol, max_iter, d_n_iter, d_status, &iters, &running, &fallback, st);
     if (rc != SC_OK) return rc;
     SC_CHECK_HIP(hipMemcpyAsync(d_G, k.G, (size_t)n_problems * N * 4 * 16, hipMemcpyDeviceToDevice, st));
     SC_CHECK_HIP(hipStreamSynchronize(st));
-    if (h_summary) { h_summary[0] = iters; h_summary[1] = running; }
+    if (h_summary) { h_summary[0] = iters; h_summary[1] = running; h_summary[2] = fallback; }
     return SC_OK;
 }

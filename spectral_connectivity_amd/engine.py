@@ -291,26 +291,45 @@ def measure(accum, n_signals, planes, n_obs, which, out=None):
     return out
 
 
+GRANGER_WORK_BYTES = 8 << 30      # workspace bound of one sc_granger_pairwise_f64 call (160 bytes per problem and bin)
+
+
 def granger_pairwise(accum, n_groups, n_freq_accum, n_fft, n_signals, planes, n_obs, pairs,
                      tolerance=1e-8, max_iterations=60):
-    """Batched 2x2 Wilson + spectral Granger (sc_wilson.hip).  Returns (out, n_iter, status, summary)."""
+    """Batched 2x2 Wilson + spectral Granger (sc_wilson.hip).  Returns (out, n_iter, status, summary) with
+    summary = (iterations run, problems not converged, problems started from the identity because their lag-0
+    covariance was not positive definite).  A long pair list is walked in chunks that bound the workspace; every
+    chunk writes its pairs into the same output."""
     lib = _lib.load()
     dev = accum.device
-    pairs_t = torch.as_tensor(np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)).to(dev)
-    n_pairs = pairs_t.shape[0]
-    nbytes = ctypes.c_size_t()
-    _lib.check(lib.sc_granger_workspace_bytes(n_groups, n_pairs, n_fft, byref(nbytes)), "sc_granger_workspace_bytes")
-    work = torch.empty((nbytes.value,), dtype=torch.uint8, device=dev)
+    pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+    n_pairs = pairs.shape[0]
     F = n_fft // 2 + 1
     out = torch.empty((n_groups, F, n_signals, n_signals), dtype=torch.float64, device=dev)
-    n_iter = torch.empty((n_groups * n_pairs,), dtype=torch.int32, device=dev)
-    status = torch.empty((n_groups * n_pairs,), dtype=torch.int32, device=dev)
-    summary = (ctypes.c_int32 * 2)(0, 0)
-    _lib.check(lib.sc_granger_pairwise_f64(_ptr(accum), n_groups, n_freq_accum, n_fft, n_signals, planes, n_obs,
-                                           _ptr(pairs_t), n_pairs, tolerance, max_iterations, _ptr(work),
-                                           nbytes.value, _ptr(out), _ptr(n_iter), _ptr(status), summary, _stream()),
-               "sc_granger_pairwise_f64")
-    return out, n_iter, status, (summary[0], summary[1])
+    n_iter = torch.empty((n_groups, n_pairs), dtype=torch.int32, device=dev)
+    status = torch.empty((n_groups, n_pairs), dtype=torch.int32, device=dev)
+    per_pair = n_groups * n_fft * 160
+    chunk = int(max(1, min(n_pairs, GRANGER_WORK_BYTES // per_pair)))
+    nbytes = ctypes.c_size_t()
+    _lib.check(lib.sc_granger_workspace_bytes(n_groups, chunk, n_fft, byref(nbytes)), "sc_granger_workspace_bytes")
+    work = torch.empty((nbytes.value,), dtype=torch.uint8, device=dev)
+    iters = not_conv = fallback = 0
+    for p0 in range(0, n_pairs, chunk):
+        n = min(chunk, n_pairs - p0)
+        pairs_t = torch.from_numpy(pairs[p0:p0 + n]).to(dev)
+        it_c = torch.empty((n_groups * n,), dtype=torch.int32, device=dev)
+        st_c = torch.empty((n_groups * n,), dtype=torch.int32, device=dev)
+        summary = (ctypes.c_int32 * 3)(0, 0, 0)
+        _lib.check(lib.sc_granger_pairwise_f64(_ptr(accum), n_groups, n_freq_accum, n_fft, n_signals, planes, n_obs,
+                                               _ptr(pairs_t), n, tolerance, max_iterations, _ptr(work), nbytes.value,
+                                               _lib.GRANGER_KEEP_OUTPUT if p0 else 0, _ptr(out), _ptr(it_c),
+                                               _ptr(st_c), summary, _stream()), "sc_granger_pairwise_f64")
+        n_iter[:, p0:p0 + n] = it_c.view(n_groups, n)
+        status[:, p0:p0 + n] = st_c.view(n_groups, n)
+        iters = max(iters, summary[0])
+        not_conv += summary[1]
+        fallback += summary[2]
+    return out, n_iter.reshape(-1), status.reshape(-1), (iters, not_conv, fallback)
 
 
 def _mvar_workspace(n_groups, n_signals, n_fft, dev):

@@ -22,8 +22,9 @@ def minimum_phase_decomposition(cross_spectral_matrix, tolerance=1e-8, max_itera
     cross_spectral_matrix : complex array, shape (n_time, ..., n_fft_samples, c, c), two-sided in
         frequency.  Returns an array of the same shape (complex128).
     Differences from the reference: every leading-axis problem stops at its own convergence (the
-    reference freezes a window once it has converged -- same iterate); a lag-0 covariance that is not
-    positive definite yields NaN for that problem instead of a random re-initialisation.
+    reference freezes a window once it has converged -- same iterate); a 1 x 1 / 2 x 2 problem whose lag-0
+    covariance is not positive definite starts from the identity -- the expectation of the reference's random
+    Wishart start (minimum_phase_decomposition.py:78-93) -- with the same warning.
     """
     import torch
 
@@ -67,7 +68,7 @@ def minimum_phase_decomposition(cross_spectral_matrix, tolerance=1e-8, max_itera
         S[:, 2:] = 0.0
     dev = torch.device("cuda", torch.cuda.current_device())
     out = np.empty((P, N, c, c), dtype=np.complex128)
-    step = 65535
+    step = max(1, min(P, (4 << 30) // (N * 160)))
     for p0 in range(0, P, step):
         n = min(step, P - p0)
         S_d = torch.from_numpy(S[p0:p0 + n]).to(dev)
@@ -77,17 +78,18 @@ def minimum_phase_decomposition(cross_spectral_matrix, tolerance=1e-8, max_itera
         G_d = torch.empty((n, 4, N), dtype=torch.complex128, device=dev)
         n_iter = torch.empty((n,), dtype=torch.int32, device=dev)
         status = torch.empty((n,), dtype=torch.int32, device=dev)
-        summary = (ctypes.c_int32 * 2)(0, 0)
+        summary = (ctypes.c_int32 * 3)(0, 0, 0)
         _lib.check(lib.sc_wilson_factor_f64(_ptr(S_d), n, N, tolerance, max_iterations, _ptr(work), nbytes.value,
                                             _ptr(G_d), _ptr(n_iter), _ptr(status), summary, _stream()),
                    "sc_wilson_factor_f64")
+        if summary[2]:
+            logger.warning("Computing the initial conditions using the Cholesky failed. "
+                           f"Using the identity as initial condition ({summary[2]} problems).")
         if summary[1]:
             logger.warning(f"Maximum iterations reached. {n - summary[1]} of {n} converged")
         G = G_d.cpu().numpy()                                   # (n, 4, N)
-        bad = status.cpu().numpy() < 0
         if c == 2:
             out[p0:p0 + n] = np.moveaxis(G, 1, -1).reshape(n, N, 2, 2)
         else:
             out[p0:p0 + n, :, 0, 0] = G[:, 0]
-        out[p0:p0 + n][bad] = np.nan
     return out.reshape(csm.shape)

@@ -1,0 +1,41 @@
+"""Package-wide switches.  Plain module attributes: set them before the objects they affect are built.
+
+precision
+    Which device engine ``Multitaper`` / ``Connectivity`` run on.
+    ``"dtype"`` (default): the ``dtype`` argument of ``Connectivity`` / ``Connectivity.from_multitaper`` decides, as it
+    decides the arithmetic of the reference's cross-spectral products (connectivity.py:277-285, :1799-1822) --
+    ``numpy.complex128`` (the reference's default) runs the float64 engine (float64 transform, fp64 matrix-core
+    cross-spectra, float64 measures: the reference's own arithmetic), ``numpy.complex64`` the float32 engine (the
+    headline path: fused f32 transform, bf16x3 / f32 matrix-core cross-spectra, fp64 epilogue).  A bare
+    ``Multitaper.fft()`` is float64 like the reference's.
+    ``"float32"`` / ``"float64"``: force one engine whatever ``dtype`` says.
+    Environment: ``SC_HIP_PRECISION`` sets the initial value.
+
+one_sample_fisher_z
+    ``"reference"`` (default): ``statistics.coherence_fisher_z_transform(c, n)`` evaluates ``coherence_bias(0) = -1/2``
+    for the absent second sample exactly like the reference (statistics.py:147-203), so one-sample z-scores are NaN,
+    ``Connectivity.group_delay()`` is NaN for every pair and ``Connectivity.delay()`` returns the constants 2 pi k --
+    the reference's outputs, pinned by tests/golden/f11_post.npz.
+    ``"unbiased"``: the absent sample has no bias; group_delay / delay then report the delays they describe.
+"""
+import os
+
+precision = os.environ.get("SC_HIP_PRECISION", "dtype")
+one_sample_fisher_z = "reference"
+
+
+def engine_precision(dtype=None):
+    """'float32' or 'float64' for a Connectivity ``dtype`` (None: no dtype in play -> the reference's float64)."""
+    import numpy as np
+    if precision in ("float32", "float64"):
+        return precision
+    if precision != "dtype":
+        raise ValueError(f"options.precision must be 'dtype', 'float32' or 'float64', got {precision!r}")
+    if dtype is None:
+        return "float64"
+    dt = np.dtype(dtype)
+    if dt == np.complex64:
+        return "float32"
+    if dt == np.complex128:
+        return "float64"
+    raise ValueError(f"dtype must be numpy.complex64 or numpy.complex128, got {dt}")

@@ -55,12 +55,18 @@ def coherence_fisher_z_transform(coherency1, n_obs1, coherency2=0, n_obs2=0):
         mag[mag >= 1] = _ONE_MINUS_EPS
         return np.arctanh(mag) - bias
 
-    # One-sample test (n_obs2 = 0): there is no second estimate, hence no second bias.  The reference
-    # evaluates coherence_bias(0) = -1/2 here, which makes sqrt(bias1 + bias2) -- and with it every
-    # one-sample z-score, group_delay() and the significance mask of delay() -- NaN; fixed on purpose.
+    # One-sample test (n_obs2 = 0): the reference evaluates coherence_bias(0) = -1/2 for the absent second
+    # estimate, which makes sqrt(bias1 + bias2) -- and with it every one-sample z-score, group_delay() and the
+    # significance mask of delay() -- NaN.  That is the default here too (drop-in, pinned by
+    # tests/golden/f11_post.npz); options.one_sample_fisher_z = "unbiased" gives the absent sample no bias.
+    from . import options
     b1 = coherence_bias(n_obs1)
-    b2 = coherence_bias(n_obs2) if n_obs2 else 0.0
-    return (fisher(coherency1, b1) - fisher(coherency2, b2)) / np.sqrt(b1 + b2)
+    if n_obs2 or options.one_sample_fisher_z == "reference":
+        b2 = coherence_bias(n_obs2)
+    else:
+        b2 = 0.0
+    with np.errstate(invalid="ignore"):
+        return (fisher(coherency1, b1) - fisher(coherency2, b2)) / np.sqrt(b1 + b2)
 
 
 def get_normal_distribution_p_values(data, mean=0, std_deviation=1):

@@ -149,12 +149,32 @@ def test_phase_slope_index_and_delay_match_reference(golden):
     np.testing.assert_allclose(pp.phase_slope_index(coh, f, [10, 200], res), g["psi_band_res"], rtol=1e-9, atol=1e-9,
                                equal_nan=True)
     # delay(): the reference's output is the constant 2 pi k for every frequency and pair (raw data of a fully
-    # masked array, because its one-sample z-score is always NaN) -- pinned; ours carries the candidates
-    # (phase + 2 pi k) / 2 pi at the significant frequencies and NaN elsewhere.
+    # masked array, because its one-sample z-score is always NaN) -- reproduced by default
     ref = g["delay_band"]
     np.testing.assert_allclose(ref[0, :, :, 0, 1], np.broadcast_to(2 * np.pi * np.arange(-2, 3), ref.shape[1:3]))
     got = pp.delay(coh, f, int(g["n_observations"]), [10, 200], n_range=2)
-    assert got.shape == ref.shape
+    np.testing.assert_allclose(got, ref, rtol=1e-12, atol=0, equal_nan=True)
+    d, s_, r = pp.group_delay(coh, f, int(g["n_observations"]), [10, 200], res)
+    for a, b in ((d, g["group_delay"]), (s_, g["group_slope"]), (r, g["group_r"])):
+        np.testing.assert_allclose(a, b, rtol=1e-12, atol=0, equal_nan=True)
+
+
+@pytest.fixture
+def unbiased_one_sample_z():
+    from spectral_connectivity_amd import options
+    options.one_sample_fisher_z = "unbiased"
+    yield
+    options.one_sample_fisher_z = "reference"
+
+
+def test_delay_with_the_unbiased_one_sample_z(golden, unbiased_one_sample_z):
+    """options.one_sample_fisher_z = "unbiased": delay() carries the candidates (phase + 2 pi k) / 2 pi at the
+    significant frequencies and NaN elsewhere."""
+    from spectral_connectivity_amd import _postprocess as pp
+    g = golden("f11_post")
+    coh, f = g["coherency"], g["frequencies"]
+    got = pp.delay(coh, f, int(g["n_observations"]), [10, 200], n_range=2)
+    assert got.shape == g["delay_band"].shape
     band = f[(f > 10) & (f < 200)]
     k0 = got[0, :, 2, 0, 1]                      # k = 0 candidate, pair (0, 1): phase / 2 pi = f * tau
     ok = ~np.isnan(k0)
@@ -164,10 +184,11 @@ def test_phase_slope_index_and_delay_match_reference(golden):
     np.testing.assert_allclose(got[0, :, :, 1, 0], -got[0, :, :, 0, 1], equal_nan=True)
 
 
-def test_group_delay_recovers_a_known_delay(golden):
+def test_group_delay_recovers_a_known_delay(golden, unbiased_one_sample_z):
     """Channel 1 is channel 0 delayed by 5 samples at 500 Hz.  The reference's own group_delay() returns NaN
     for every pair (its one-sample Fisher z evaluates coherence_bias(0) = -1/2 and takes the square root of a
-    negative number, so no frequency is ever significant) -- pinned here, and fixed on purpose."""
+    negative number, so no frequency is ever significant) -- the default here as well; with
+    options.one_sample_fisher_z = "unbiased" the regression recovers the delay."""
     from spectral_connectivity_amd import _postprocess as pp
     g = golden("f11_post")
     assert np.isnan(g["group_delay"][0, 0, 1]) and np.isnan(g["group_r"][0, 0, 1]) and g["group_r"][0, 0, 0] == 1.0
@@ -202,8 +223,14 @@ def test_statistics_helpers_match_reference(golden):
     np.testing.assert_allclose(st.power_variance(35), g["stat_power_var"], rtol=1e-12)
     np.testing.assert_allclose(st.power_fisher_z_transform(np.linspace(1, 4, 5), 35, np.linspace(2, 3, 5), 21),
                                g["stat_power_z"], rtol=1e-12)
-    # one-sample z-score: finite here (NaN in the reference, see statistics.coherence_fisher_z_transform)
-    assert np.isfinite(st.coherence_fisher_z_transform(g["stat_coh1"], 40)).all()
+    # one-sample z-score: NaN like the reference's by default, finite with the unbiased option
+    from spectral_connectivity_amd import options
+    assert np.isnan(st.coherence_fisher_z_transform(g["stat_coh1"], 40)).all()
+    options.one_sample_fisher_z = "unbiased"
+    try:
+        assert np.isfinite(st.coherence_fisher_z_transform(g["stat_coh1"], 40)).all()
+    finally:
+        options.one_sample_fisher_z = "reference"
 
 
 def test_wrapper_validates_before_touching_the_device():

@@ -11,9 +11,7 @@ LIB = os.path.join(ROOT, "tools", "libsc_trace.so")
 def build():
     sys.path.insert(0, ROOT)
     from spectral_connectivity_amd import _build
-    cmd = [_build._hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-Wno-unused-result",
-           "-fno-slp-vectorize", "-DFU_TRACE", *_build.sources(), "-lrocfft", "-o", LIB]
-    subprocess.run(cmd, check=True)
+    _build.build(extra_flags=["-DFU_TRACE"], out=LIB)
 
 
 if __name__ == "__main__":

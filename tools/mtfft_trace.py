@@ -11,9 +11,7 @@ if __name__ == "__main__":
     sys.path.insert(0, ROOT)
     if "--build" in sys.argv:
         from spectral_connectivity_amd import _build
-        subprocess.run([_build._hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
-                        "-Wno-unused-result", "-fno-slp-vectorize", "-DMT_TRACE", *_build.sources(), "-lrocfft", "-o", LIB],
-                       check=True)
+        _build.build(extra_flags=["-DMT_TRACE"], out=LIB)
         sys.exit(0)
     os.environ["SC_HIP_LIB"] = LIB
     import torch

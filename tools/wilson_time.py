@@ -32,7 +32,7 @@ work = torch.empty((nbytes.value,), dtype=torch.uint8, device=dev)
 G = torch.empty((P, 4, N), dtype=torch.complex128, device=dev)
 n_iter = torch.empty((P,), dtype=torch.int32, device=dev)
 status = torch.empty((P,), dtype=torch.int32, device=dev)
-summary = (ctypes.c_int32 * 2)(0, 0)
+summary = (ctypes.c_int32 * 3)(0, 0, 0)
 
 
 def run():
