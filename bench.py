@@ -36,8 +36,32 @@ from spectral_connectivity_amd.transforms import _make_tapers  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32 dense peak
-# HBM bytes per launch of the dominant kernel, measured with rocprofv3 --pmc (profiles/r01_hbm_traffic.txt)
-MEASURED_TRAFFIC_BYTES = {("cfg3", "fused_csm_absim"): 7.42e9 + 0.39e9, ("cfg3", "mtfft_fused"): 7.22e9}
+# HBM bytes per launch from the PMC counters: a PMC pass cannot run inside this process, so `roofline.traffic` is read
+# from the committed summary of the rocprofv3 --pmc passes over THIS command (tools/profile_round.py writes it next to
+# the kernel-trace stats; it records the source hash of the kernels it measured) and is null when that file is
+# missing or was measured on other kernel sources.
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
+
+
+def kernel_source_hash():
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "spectral_connectivity_amd", "csrc")
+    for name in ("sc_fused.hip", "sc_mtfft.hip", "sc_measure.hip", "sc_stage.h", "sc_common.h"):
+        with open(os.path.join(csrc, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(config, stage):
+    try:
+        rec = json.load(open(TRAFFIC_FILE))
+    except (OSError, ValueError):
+        return None, None
+    if rec.get("kernel_source_hash") != kernel_source_hash():
+        return None, "profiles/r02_hbm_traffic.json was measured on other kernel sources"
+    v = rec.get(config, {}).get(stage)
+    return (float(v) if v is not None else None), rec.get("source")
 
 CONFIGS = {
     # name: T, R, C, NW, L, step
@@ -63,40 +87,23 @@ def synth(cfg, r_lo, r_hi, device, seed):
     return x
 
 
-class StageTimer:
-    def __init__(self):
-        self.events = []
-
-    def mark(self, name):
-        ev = torch.cuda.Event(enable_timing=True)
-        ev.record()
-        self.events.append((name, ev))
-
-    def durations(self):
-        out = {}
-        for (n0, e0), (n1, e1) in zip(self.events[:-1], self.events[1:]):
-            out[n1] = out.get(n1, 0.0) + e0.elapsed_time(e1)
-        return out
-
-
-def one_step(x, h, cfg, geom, planes, world, timer=None):
-    lib = _lib.load()
-    mark = timer.mark if timer else (lambda name: None)
+def one_step(x, h, cfg, geom, planes, world, exchange=None):
+    """One pass of the hot path.  Stage durations come from the library's own hipEvent timers (sc_last_timing: every
+    entry point brackets its launches on the stream it was given); `exchange` collects the collective breakout of the
+    N > 1 path."""
     L, step, N, W = geom
-    mark("start")
-    sp = engine.multitaper_spectra(x, h, L, step, N, W, "constant", mark=mark)
+    sp = engine.multitaper_spectra(x, h, L, step, N, W, "constant")
     if world > 1:
         # trial shards: accumulate -> reduce-scatter -> epilogue -> gather on rank 0, pipelined over frequency
         # groups so that only the last group's exchange is exposed (parallel.sharded_measures)
         coh, wpli = parallel.sharded_measures(sp, planes, [_lib.M_COHERENCE_MAGNITUDE, _lib.M_WPLI],
-                                              n_groups=int(os.environ.get("SC_BENCH_GROUPS", "4")), mark=mark,
-                                              equal_shards=True)   # R % world == 0 is asserted in main()
+                                              n_groups=int(os.environ.get("SC_BENCH_GROUPS", "4")),
+                                              equal_shards=True, timing=exchange)   # R % world == 0: asserted in main()
         return coh, wpli
-    accum, n_obs = engine.accumulate(sp, "trials_tapers", planes, mark=mark)
+    accum, n_obs = engine.accumulate(sp, "trials_tapers", planes)
     del sp
     coh = engine.measure(accum, cfg["C"], planes, n_obs, _lib.M_COHERENCE_MAGNITUDE)
     wpli = engine.measure(accum, cfg["C"], planes, n_obs, _lib.M_WPLI)
-    mark("measure_epilogue")
     return coh, wpli
 
 
@@ -200,14 +207,15 @@ def main():
     for _ in range(args.warmup):
         one_step(x, h, cfg, geom, planes, world)
     sync()
-    timers = []
+    _lib.timing_enable(True)                  # hipEvent pairs inside the library from here on (sc_timing.hip)
+    exchange = [] if world > 1 else None
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        tm = StageTimer()
-        one_step(x, h, cfg, geom, planes, world, tm)
-        timers.append(tm)
+        one_step(x, h, cfg, geom, planes, world, exchange)
     sync()
     elapsed = time.perf_counter() - t0
+    timing = _lib.last_timing()
+    _lib.timing_enable(False)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -216,11 +224,10 @@ def main():
     units = W * F * C * C                                   # channel-pair x frequency bins
     value = units / (elapsed / args.steps)
 
-    # per-stage kernel durations (HIP events on the launch stream), averaged over steps
+    # per-stage durations: the library's hipEvent pairs (sc_last_timing), summed per entry point, averaged over steps
     stage_ms = {}
-    for tm in timers:
-        for k, v in tm.durations().items():
-            stage_ms[k] = stage_ms.get(k, 0.0) + v / len(timers)
+    for name, ms in timing:
+        stage_ms[name] = stage_ms.get(name, 0.0) + ms / args.steps
     R_loc = r_hi - r_lo
     n_obs_loc = R_loc * K
     # algorithmic work per launch on this rank (DESIGN.md "Roofline")
@@ -228,7 +235,7 @@ def main():
         "mtfft_fused": ("hbm", 4.0 * T * R_loc * C + 8.0 * F * W * R_loc * K * C),
         "taper_windows": ("hbm", 4.0 * T * R_loc * C + 4.0 * N * W * R_loc * K * C),
         "rocfft_r2c": ("hbm", 4.0 * N * W * R_loc * K * C + 8.0 * F * W * R_loc * K * C),
-        "fused_csm_absim": ("mfma", 8.0 * n_obs_loc * (C * (C + 1) / 2) * W * F),
+        "fused_stage_b": ("mfma", 8.0 * n_obs_loc * (C * (C + 1) / 2) * W * F),
         "csm_mfma": ("mfma", 8.0 * n_obs_loc * (C * (C + 1) / 2) * W * F),
         "nonlinear_valu": ("hbm", 8.0 * F * W * R_loc * K * C + 4.0 * W * F * C * (C + 1) / 2),
         "measure_epilogue": ("hbm", (3 * 4.0 * C * (C + 1) / 2 + 2 * 4.0 * C * C) * W * F / world),
@@ -249,11 +256,15 @@ def main():
         return {"bound": b, "achieved": round(wk / d / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(wk / d / 1e9 / HBM_PEAK_GBS, 4)}
 
-    roofline = {"kernel": dominant, "bound": bound, "achieved": round(achieved, 3), "peak": peak,
+    traffic, traffic_src = measured_traffic(args.config, dominant) if world == 1 else (None, None)
+    KERNEL_OF = {"fused_stage_b": "fused_csm_absim_kernel (+ fused_combine_kernel)", "mtfft_fused": "mtfft16_kernel",
+                 "measure_epilogue": "measure_tile_kernel"}
+    roofline = {"kernel": KERNEL_OF.get(dominant, dominant), "entry_point": dominant, "bound": bound,
+                "achieved": round(achieved, 3), "peak": peak,
                 "unit": unit, "frac": round(achieved / peak, 4),
-                # HBM bytes per launch from rocprofv3 PMC (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE),
-                # collected offline: profiles/r01_hbm_traffic.txt; null when the dominant kernel differs
-                "traffic": MEASURED_TRAFFIC_BYTES.get((args.config, dominant)) if world == 1 else None,
+                # HBM bytes per launch from the rocprofv3 PMC passes over this command (FETCH_SIZE x2 gfx950 correction +
+                # WRITE_SIZE), read from profiles/r02_hbm_traffic.json; null when absent / measured on other sources
+                "traffic": traffic, "traffic_source": traffic_src,
                 "kernel_ms": round(stage_ms[dominant], 4),
                 "note": ("f32-equivalent flops of the Hermitian rank-n_obs update (8*n_obs*C(C+1)/2 per bin, "
                          "triangle only) over the f32 MFMA peak; the kernel runs them as six bf16 cross terms "
@@ -306,6 +317,13 @@ def main():
                        "trials_per_gpu": R_loc, "n_tapers": K, "n_windows": W, "n_freq_bins": F,
                        "units_per_step": units, "parallelism": f"trials sharded over {world} GPU(s)"},
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_restructured": cpu_strong,
+            # N > 1: time inside the RCCL collectives of one step on the exchange stream (reduce-scatter of the records,
+            # gather of the measures) and the part of the exchange + epilogue the launch stream had to wait for
+            "exchange": None if exchange is None else {
+                "collective_ms": round(sum(e["collective_ms"] for e in exchange) / max(len(exchange), 1), 4),
+                "exposed_exchange_ms": round(sum(e["exposed_ms"] for e in exchange) / max(len(exchange), 1), 4),
+                "bytes_reduced_per_rank": exchange[-1]["bytes_reduced"] if exchange else None,
+                "n_frequency_groups": exchange[-1]["n_groups"] if exchange else None},
         }))
     if world > 1:
         dist.destroy_process_group()

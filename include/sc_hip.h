@@ -10,9 +10,19 @@
  *
  * Conventions
  *  - extern "C", plain pointers and sizes.  Every `dev_*`/`d_*` pointer is DEVICE memory
- *    owned by the caller (the Python host allocates it with torch); the library never
- *    allocates or frees caller buffers and keeps no pointer past the call.  The only
- *    library-owned objects are opaque `sc_fft_plan` handles (rocFFT plan + work buffer).
+ *    owned by the caller (the Python host allocates it with torch); the library never frees or
+ *    retains caller buffers past the call.  Device memory the library allocates ITSELF, all of it
+ *    released before the owning call returns or with the owning handle:
+ *      - `sc_fft_plan` handles (sc_fft_plan_create*): the rocFFT plan, its work buffer and a <= 64 MB
+ *        transform scratch (hipMalloc; freed by sc_fft_plan_destroy; sc_fft_plan_work_bytes reports it);
+ *      - stream-ordered scratch (hipMallocAsync / hipFreeAsync on the call's stream) inside
+ *        sc_multitaper_fft_f32 for N >= 2048 (row-major spectra before the transpose, <= 2 GB),
+ *        sc_canonical_coherence_f64 (inverted group factors, n_bins * n_groups * 4 KB),
+ *        sc_global_coherence_f64 above 64 signals (rotation log) and the rocFFT work buffers of
+ *        sc_granger_pairwise_f64 / sc_wilson_factor_f64 / sc_mvar_factor_f64 for lengths their fused
+ *        transform kernel does not take.
+ *    Everything else (spectra, records, workspaces, outputs) is caller memory with sizes the
+ *    *_bytes / sc_accum_layout queries report.
  *  - `stream` is a hipStream_t passed as void* (NULL = default stream).  All calls are
  *    asynchronous on that stream; nothing synchronises the device.
  *  - Return value: 0 on success, negative SC_E* otherwise; sc_last_error() returns a
@@ -27,7 +37,8 @@
  *  - spectra          X[F][W][R][K][C]                float2  (one-sided, F = N/2+1) -- or any
  *                     layout described by sc_spectra_desc strides (e.g. the reference's
  *                     own (W,R,K,N,C) order for uploaded coefficients)
- *  - accumulators     A[bin][plane][tile][16][16]     float   bin = group*F + f ; upper-triangular
+ *  - accumulators     A[bin][plane][tile][16][16]     float (double when SC_RECORD_F64 is set in `planes`: the
+ *                     float64 engine)   bin = group*F + f ; upper-triangular
  *                     16x16 channel tiles (bi <= bj), tile index = bi*NB - bi*(bi-1)/2 + (bj-bi);
  *                     UN-normalised sums over observations (so trial shards can be summed)
  *  - measures         M[bin][C][C]                    float (or float2 for complex measures)
@@ -64,6 +75,10 @@ extern "C" {
 #define SC_PLANE_IM_SQ 0x04u    /* sum (Im s)^2                 : 1 plane            connectivity.py:1096-1102 */
 #define SC_PLANE_SIGN_IM 0x08u  /* sum sign(Im s)               : 1 plane            connectivity.py:970-980 */
 #define SC_PLANE_UNIT 0x10u     /* sum s/|s|                    : 2 planes (re, im)  connectivity.py:899-903 */
+/* record format flag, OR-ed into `planes` wherever accumulator records are handed to a consumer (sc_measure_*,
+ * sc_granger_pairwise_f64, sc_mvar_factor_f64, sc_global_coherence_f64, sc_canonical_coherence_f64): the records
+ * hold doubles (written by sc_accumulate_f64) instead of floats */
+#define SC_RECORD_F64 0x100u
 
 /* measures of sc_measure_f32 (all on non-negative frequency bins the caller accumulated) */
 #define SC_M_POWER 0                 /* connectivity.py:612-630   out float [bin][C]        */
@@ -118,6 +133,11 @@ int sc_taper_windows_f32(const float* d_x, int64_t T, int64_t R, int64_t C,
                          int64_t L, int64_t step, int64_t W, int64_t N,
                          const float* d_tapers, int64_t K, int detrend_type,
                          float* d_y, void* stream);
+/* float64 engine: the reference's own precision (it promotes every input to float64, transforms.py:1402-1405) */
+int sc_taper_windows_f64(const double* d_x, int64_t T, int64_t R, int64_t C,
+                         int64_t L, int64_t step, int64_t W, int64_t N,
+                         const double* d_tapers, int64_t K, int detrend_type,
+                         double* d_y, void* stream);
 
 /* ---- stage A: batched real-to-complex FFT (rocFFT) -----------------------------------
  * Replaces fft(projected, n=N, axis=-2) of transforms.py:1405 (scipy.fft / cupyx.scipy.fft).
@@ -130,6 +150,9 @@ int sc_fft_plan_create(sc_fft_plan** plan, int64_t N, int64_t batch);
 int sc_fft_plan_work_bytes(const sc_fft_plan* plan, size_t* bytes);
 int sc_fft_execute(sc_fft_plan* plan, const float* d_y, void* d_X /*float2*/, void* stream);
 int sc_fft_plan_destroy(sc_fft_plan* plan);
+/* double-precision plans of the float64 engine: y double rows in, X[F][batch] double2 out */
+int sc_fft_plan_create_f64(sc_fft_plan** plan, int64_t N, int64_t batch);
+int sc_fft_execute_f64(sc_fft_plan* plan, const double* d_y, void* d_X /*double2*/, void* stream);
 
 /* ---- stage A, fused fast path (custom HIP, power-of-two N) ---------------------------
  * Window extraction + detrend + taper multiply + real FFT + transposed store in ONE kernel:
@@ -214,8 +237,32 @@ int sc_fused_unit_ws_f32(const void* d_X /*float2*/, const sc_spectra_desc* desc
  * n_observations AFTER any cross-GPU reduction, applies the reference's eps clamps, NaN /
  * zero diagonals and clips, mirrors the triangle into the full C x C matrix.
  * d_out: float [n_bins][C][C] (float2 for complex measures, float [n_bins][C] for power). */
-int sc_measure_f32(const float* d_accum, int64_t n_bins, int64_t n_signals, uint32_t planes,
+int sc_measure_f32(const void* d_accum, int64_t n_bins, int64_t n_signals, uint32_t planes,
                    int64_t n_observations, int measure, void* d_out, void* stream);
+/* The same measures written as double / double2 -- what the reference returns (float64 / complex128) -- from float
+ * or (SC_RECORD_F64) double records: no widening pass over the result. */
+int sc_measure_f64(const void* d_accum, int64_t n_bins, int64_t n_signals, uint32_t planes,
+                   int64_t n_observations, int measure, void* d_out, void* stream);
+
+/* ---- stage B of the float64 engine -----------------------------------------------------
+ * Replaces the same reference code as sc_csm_accumulate_f32 / sc_nonlinear_accumulate_f32 (connectivity.py:447-526,
+ * :897-1159, :1799-1822) in the reference's own arithmetic: complex128 spectra (any sc_spectra_desc layout, 16-byte
+ * aligned), the cross-spectral matrix on the fp64 matrix cores (v_mfma_f64_16x16x4_f64), the per-observation planes on
+ * the fp64 VALU, double records of the same tile layout.  `which` names the planes to fill (subset of `planes`).
+ * Selected by Connectivity(dtype=numpy.complex128), the reference's default dtype. */
+int sc_accumulate_f64(const void* d_X /*double2*/, const sc_spectra_desc* desc, uint32_t planes, uint32_t which,
+                      double* d_accum, void* stream);
+
+/* ---- timing ------------------------------------------------------------------------------
+ * hipEvent timers inside the library: after sc_timing_enable(1) every compute entry point brackets its launches with
+ * two events on the stream it was given; sc_last_timing waits for them, writes (name, milliseconds) in call order
+ * (at most max_entries) and forgets them.  sc_timing_enable(0) stops recording.  One timing session per process. */
+typedef struct sc_timing {
+    char name[48];
+    float ms;
+} sc_timing;
+int sc_timing_enable(int on);
+int sc_last_timing(sc_timing* out, int max_entries, int* n_entries);
 
 /* ---- pairwise spectral Granger prediction (batched 2x2 Wilson factorisation, fp64) -----
  * Replaces Connectivity.pairwise_spectral_granger_prediction / subset_... and the Python
@@ -244,7 +291,7 @@ int sc_measure_f32(const float* d_accum, int64_t n_bins, int64_t n_signals, uint
  * so the iterations queued past the last convergence are empty launches). */
 #define SC_GRANGER_KEEP_OUTPUT 1
 int sc_granger_workspace_bytes(int64_t n_groups, int64_t n_pairs, int64_t N, size_t* bytes);
-int sc_granger_pairwise_f64(const float* d_accum, int64_t n_groups, int64_t n_freq_accum,
+int sc_granger_pairwise_f64(const void* d_accum, int64_t n_groups, int64_t n_freq_accum,
                             int64_t N, int64_t n_signals, uint32_t planes, int64_t n_observations,
                             const int32_t* d_pairs, int64_t n_pairs, double tolerance, int max_iterations,
                             void* d_work, size_t work_bytes, int flags, double* d_out, int32_t* d_n_iter,
@@ -286,7 +333,7 @@ int sc_wilson_factor_f64(const double* d_S, int64_t n_problems, int64_t N, doubl
 #define SC_MVAR_NOISE_COVARIANCE 7   /* connectivity.py:1679-1709 */
 int sc_mvar_max_signals(void);
 int sc_mvar_workspace_bytes(int64_t n_groups, int64_t n_signals, int64_t N, size_t* bytes);
-int sc_mvar_factor_f64(const float* d_accum, const void* d_S /*complex128*/, int64_t n_groups,
+int sc_mvar_factor_f64(const void* d_accum, const void* d_S /*complex128*/, int64_t n_groups,
                        int64_t n_freq_accum, int64_t N, int64_t n_signals, uint32_t planes,
                        int64_t n_observations, double tolerance, int max_iterations, void* d_work,
                        size_t work_bytes, void* d_G /*complex128*/, int32_t* d_n_iter, int32_t* d_status,
@@ -307,7 +354,7 @@ int sc_mvar_measure_f64(const void* d_G /*complex128*/, int64_t n_groups, int64_
  * ascending != 0 orders the max_rank largest values smallest-first (scipy svds, which the reference
  * takes when max_rank < n_signals - 1). */
 int sc_global_coherence_max_signals(void);
-int sc_global_coherence_f64(const float* d_accum, int64_t n_groups, int64_t n_freq_accum, int64_t N,
+int sc_global_coherence_f64(const void* d_accum, int64_t n_groups, int64_t n_freq_accum, int64_t N,
                             int64_t n_signals, uint32_t planes, int64_t n_observations, int max_rank,
                             int ascending, double* d_values, void* d_vectors /*complex128*/, void* stream);
 
@@ -323,7 +370,7 @@ int sc_global_coherence_f64(const float* d_accum, int64_t n_groups, int64_t n_fr
  * Groups of <= 16 channels take a stream-ordered workspace of n_bins * n_groups * 4 KB for the
  * inverted group factors (hipMallocAsync / hipFreeAsync on `stream`); SC_ENOMEM if that fails. */
 int sc_canonical_max_group(void);
-int sc_canonical_coherence_f64(const float* d_accum, int64_t n_bins, int64_t n_signals, uint32_t planes,
+int sc_canonical_coherence_f64(const void* d_accum, int64_t n_bins, int64_t n_signals, uint32_t planes,
                                int64_t n_observations, const int32_t* d_members, const int32_t* d_sizes,
                                int n_groups, int max_group_size, double* d_out, int32_t* d_fail,
                                void* stream);

@@ -23,6 +23,7 @@ GRANGER_KEEP_OUTPUT = 1
 DETREND = {None: 0, "constant": 1, "c": 1, "linear": 2, "l": 2}
 MVAR_DTF, MVAR_DC, MVAR_PDC, MVAR_GPDC, MVAR_DDTF, MVAR_TRANSFER, MVAR_COEFFICIENTS, MVAR_NOISE_COVARIANCE = range(8)
 PLANE_CSM, PLANE_ABS_IM, PLANE_IM_SQ, PLANE_SIGN_IM, PLANE_UNIT = 0x01, 0x02, 0x04, 0x08, 0x10
+RECORD_F64 = 0x100          # OR-ed into `planes` when the records handed to a consumer hold doubles (float64 engine)
 (M_POWER, M_CSM, M_COHERENCY, M_COHERENCE_MAGNITUDE, M_COHERENCE_PHASE, M_IMAGINARY_COHERENCE,
  M_PLV, M_PLI, M_WPLI, M_DEBIASED_PLI2, M_DEBIASED_WPLI2, M_PPC, M_PLV_COMPLEX) = range(13)
 COMPLEX_MEASURES = {M_CSM, M_COHERENCY, M_PLV_COMPLEX}
@@ -33,6 +34,10 @@ MEASURE_PLANES = {
     M_PLI: PLANE_SIGN_IM, M_DEBIASED_PLI2: PLANE_SIGN_IM,
     M_WPLI: PLANE_CSM | PLANE_ABS_IM, M_DEBIASED_WPLI2: PLANE_CSM | PLANE_ABS_IM | PLANE_IM_SQ,
 }
+
+
+class Timing(Structure):
+    _fields_ = [("name", ctypes.c_char * 48), ("ms", c_float)]
 
 
 class SpectraDesc(Structure):
@@ -50,6 +55,14 @@ SYMBOLS = {
     "sc_device_count": (c_int, [POINTER(c_int)]),
     "sc_taper_windows_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64,
                                      c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "sc_taper_windows_f64": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64,
+                                     c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "sc_fft_plan_create_f64": (c_int, [POINTER(c_void_p), c_int64, c_int64]),
+    "sc_fft_execute_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sc_accumulate_f64": (c_int, [c_void_p, POINTER(SpectraDesc), c_uint32, c_uint32, c_void_p, c_void_p]),
+    "sc_measure_f64": (c_int, [c_void_p, c_int64, c_int64, c_uint32, c_int64, c_int, c_void_p, c_void_p]),
+    "sc_timing_enable": (c_int, [c_int]),
+    "sc_last_timing": (c_int, [POINTER(Timing), c_int, POINTER(c_int)]),
     "sc_multitaper_fft_supported": (c_int, [c_int64, c_int64]),
     "sc_fft_twiddles_f32": (c_int, [c_int64, c_void_p, c_void_p]),
     "sc_multitaper_fft_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64,
@@ -147,10 +160,55 @@ def device_count():
     return n.value
 
 
+ENABLE_GPU_ENV = "SPECTRAL_CONNECTIVITY_ENABLE_GPU"
+
+
+def gpu_switch():
+    """The reference's import-time backend switch (transforms.py:405-439, connectivity.py:31-65,
+    minimum_phase_decomposition.py:14-26), read the way the reference reads it: the string "true" asks for the GPU
+    backend, anything else for NumPy.  Returns True ("true": the HIP engine was asked for by name), None (unset: this
+    package only has the HIP engine, nothing to choose) or False (set to something else: the caller asked for the
+    CPU path, which this package does not have)."""
+    v = os.environ.get(ENABLE_GPU_ENV)
+    return None if v is None else v == "true"
+
+
+def honour_gpu_switch():
+    """Import-time half of the switch (called from transforms.py like the reference's module-level block): with
+    SPECTRAL_CONNECTIVITY_ENABLE_GPU=true the engine must be there NOW -- a missing / unbuildable libsc_hip.so raises
+    RuntimeError at import, like the reference's missing CuPy does (transforms.py:429-434)."""
+    if gpu_switch():
+        try:
+            load()
+        except Exception as exc:
+            raise RuntimeError(
+                f"GPU support was explicitly requested via {ENABLE_GPU_ENV}='true', but the HIP engine "
+                f"libsc_hip.so could not be loaded ({exc}). Build it with "
+                "'python -m spectral_connectivity_amd._build' on a machine with ROCm's hipcc.") from exc
+
+
 def require_gpu():
     """The product path runs on an MI355X only: fail loudly when none is visible."""
+    if gpu_switch() is False:
+        raise RuntimeError(
+            f"{ENABLE_GPU_ENV}={os.environ.get(ENABLE_GPU_ENV)!r} selects the reference's NumPy backend, which "
+            "spectral_connectivity_amd does not have: every computation here runs on the HIP engine. Unset the "
+            "variable or set it to 'true' (or use the reference package for a CPU run).")
     if not torch.cuda.is_available():
         raise RuntimeError(
             "spectral_connectivity_amd: no ROCm GPU is visible (torch.cuda.is_available() is False). "
             "This engine has no CPU fallback; run on an MI355X host.")
     load()
+
+
+def timing_enable(on=True):
+    """Library-side stage timers (hipEvents on the launch stream, sc_timing.hip)."""
+    check(load().sc_timing_enable(int(bool(on))), "sc_timing_enable")
+
+
+def last_timing(max_entries=4096):
+    """[(entry point, milliseconds)] of the calls since the previous read, in call order (waits for them)."""
+    buf = (Timing * max_entries)()
+    n = c_int(0)
+    check(load().sc_last_timing(buf, max_entries, byref(n)), "sc_last_timing")
+    return [(buf[i].name.decode(), float(buf[i].ms)) for i in range(n.value)]

@@ -38,13 +38,21 @@ class Connectivity:
     :class:`~spectral_connectivity_amd.transforms.Multitaper` (no host round trip).
 
     ``blocks`` is accepted for compatibility and ignored: the engine never materialises the
-    per-observation cross-spectra the reference blocks over.  ``dtype`` is accepted; the
-    device pipeline computes in complex64/float32 with fp64 epilogue algebra.
+    per-observation cross-spectra the reference blocks over.
+
+    ``dtype`` selects the device arithmetic, as it selects the arithmetic of the reference's cross-spectral products
+    (connectivity.py:277-285, :1799-1822): ``numpy.complex128`` (the default, like the reference) runs the float64
+    engine -- float64 transform, cross-spectra on the fp64 matrix cores, float64 measures: results equal to the
+    reference's to ~1e-12 --, ``numpy.complex64`` the float32 engine of the headline path (fused f32 transform, bf16x3
+    / f32 matrix cores, fp64 epilogue: ~1e-6 on power, ~1e-7 of the array maximum on cross-spectral measures, 2-3x
+    faster).  ``options.precision`` can force either engine for the whole process.
     """
 
     def __init__(self, fourier_coefficients, expectation_type="trials_tapers", frequencies=None,
                  time=None, blocks=None, dtype=np.complex128):
+        from . import options
         from .engine import DeviceSpectra
+        self._precision = options.engine_precision(dtype)
         self._spectra = None
         self._host_coefficients = None
         self._multitaper = None
@@ -95,9 +103,10 @@ class Connectivity:
     def from_multitaper(cls, multitaper_instance, expectation_type="trials_tapers", blocks=None,
                         dtype=np.complex128):
         """Reference connectivity.py:366-400, but the coefficients never leave the device."""
-        obj = cls(multitaper_instance.device_spectra(), expectation_type=expectation_type,
-                  time=multitaper_instance.time, frequencies=multitaper_instance.frequencies,
-                  blocks=blocks, dtype=dtype)
+        from . import options
+        obj = cls(multitaper_instance.device_spectra(precision=options.engine_precision(dtype)),
+                  expectation_type=expectation_type, time=multitaper_instance.time,
+                  frequencies=multitaper_instance.frequencies, blocks=blocks, dtype=dtype)
         obj._multitaper = multitaper_instance
         return obj
 
@@ -140,7 +149,7 @@ class Connectivity:
         if self._spectra is None:
             from . import engine
             _lib.require_gpu()
-            self._spectra = engine.upload_coefficients(self._host_coefficients)
+            self._spectra = engine.upload_coefficients(self._host_coefficients, f64=self._precision == "float64")
         return self._spectra
 
     @property
@@ -159,8 +168,24 @@ class Connectivity:
         self._accum_cache[planes] = (accum, n_obs)
         return planes, (accum, n_obs)
 
+    def _csm_records(self, tag, expectation_type=None, two_sided=True):
+        """CSM records for the consumers that read every bin (Granger, MVAR, global / canonical coherence), cached and
+        summed over the trial shards: (records, n_observations of this process, bins per group).  ``two_sided``:
+        uploaded coefficients are accumulated on all N bins (real-input spectra hold 0..N/2, mirrored on the device)."""
+        from . import engine
+        sp = self._device()
+        N = self._shape5[3]
+        n_freq = (sp.F if sp.real_input else N) if two_sided else self._n_freq
+        key = (tag, n_freq)
+        if key not in self._accum_cache:
+            accum, n_obs = engine.accumulate(sp, expectation_type or self.expectation_type, _lib.PLANE_CSM, n_freq=n_freq)
+            self._accum_cache[key] = (self._reduce_over_ranks(accum), n_obs)
+        accum, n_obs = self._accum_cache[key]
+        return accum, n_obs, n_freq
+
     def _reduce_over_ranks(self, accum):
-        """Hook for trial-sharded multi-GPU runs (see parallel.ShardedConnectivity)."""
+        """Sum of the records over the processes that hold the trials: nothing to add here; parallel.ShardedConnectivity
+        (one process per GPU, trials sharded) all-reduces."""
         return accum
 
     def _kept_shape(self):
@@ -172,11 +197,8 @@ class Connectivity:
         from . import engine
         have, (accum, n_obs) = self._accumulators(_lib.MEASURE_PLANES[which])
         C = self._shape5[4]
-        out = engine.measure(accum, C, have, self._n_observations_total(n_obs), which)
-        import torch
-        # widened on the device (the reference returns float64 / complex128): a plain copy over PCIe is cheaper than a
-        # host-side astype of the whole array
-        host = engine.to_host(out.to(torch.complex128 if out.is_complex() else torch.float64))
+        # the epilogue writes float64 / complex128 (what the reference returns) itself: no widening pass
+        host = engine.to_host(engine.measure(accum, C, have, self._n_observations_total(n_obs), which, wide=True))
         tail = (C,) if which == _lib.M_POWER else (C, C)
         return host.reshape(self._kept_shape() + (self._n_freq,) + tail)
 
@@ -228,17 +250,15 @@ class Connectivity:
     # ---- pairwise spectral Granger (reference connectivity.py:1161-1213) -----------------
     def _granger(self, pairs):
         from . import engine
-        sp = self._device()
         N, C = self._shape5[3], self._shape5[4]
-        # real-input spectra hold bins 0..N/2 (negative bins are mirrored on device);
-        # uploaded coefficients are accumulated on all N bins
-        n_freq = sp.F if sp.real_input else N
+        return engine.to_host(self._granger_device(pairs)).reshape(self._kept_shape() + (N // 2 + 1, C, C))
+
+    def _granger_device(self, pairs):
+        """Device tensor [n_groups, N/2+1, C, C] float64: the listed pairs filled in, NaN elsewhere."""
+        from . import engine
+        N, C = self._shape5[3], self._shape5[4]
         planes = _lib.PLANE_CSM
-        key = ("granger", n_freq)
-        if key not in self._accum_cache:
-            accum, n_obs = engine.accumulate(sp, self.expectation_type, planes, n_freq=n_freq)
-            self._accum_cache[key] = (self._reduce_over_ranks(accum), n_obs)
-        accum, n_obs = self._accum_cache[key]
+        accum, n_obs, n_freq = self._csm_records("granger")
         n_groups = accum.shape[0] // n_freq
         out, n_iter, status, (iters, not_conv, fallback) = engine.granger_pairwise(
             accum, n_groups, n_freq, N, C, planes, self._n_observations_total(n_obs), pairs)
@@ -250,7 +270,7 @@ class Connectivity:
             logger.warning(f"Maximum iterations reached. {status.numel() - not_conv} of {status.numel()} converged")
         self._last_wilson = dict(iterations=iters, not_converged=not_conv, cholesky_fallbacks=fallback,
                                  n_iter=n_iter.cpu().numpy(), status=status.cpu().numpy())
-        return engine.to_host(out).reshape(self._kept_shape() + (N // 2 + 1, C, C))
+        return out
 
     def pairwise_spectral_granger_prediction(self):
         """Power at node i explained by node j, out[..., i, j] = j -> i (diagonal NaN)."""
@@ -296,13 +316,8 @@ class Connectivity:
         if C > _lib.load().sc_mvar_max_signals():
             raise ValueError(f"the full Wilson factorisation supports n_signals <= "
                              f"{_lib.load().sc_mvar_max_signals()} (got {C}); use the pairwise measures")
-        n_freq = sp.F if sp.real_input else N
         planes = _lib.PLANE_CSM
-        key = ("granger", n_freq)
-        if key not in self._accum_cache:
-            accum, n_obs = engine.accumulate(sp, self.expectation_type, planes, n_freq=n_freq)
-            self._accum_cache[key] = (self._reduce_over_ranks(accum), n_obs)
-        accum, n_obs = self._accum_cache[key]
+        accum, n_obs, n_freq = self._csm_records("granger")
         n_groups = accum.shape[0] // n_freq
         G, n_iter, status, (iters, not_conv) = engine.mvar_factor(
             n_groups, N, C, accum=accum, n_freq_accum=n_freq, planes=planes, n_obs=self._n_observations_total(n_obs))
@@ -402,13 +417,8 @@ class Connectivity:
             raise ValueError(f"global_coherence supports n_signals <= {_lib.load().sc_global_coherence_max_signals()}")
         if C > 64 and max_rank > 4:
             raise ValueError("global_coherence with more than 64 signals returns at most 4 components")
-        n_freq = sp.F if sp.real_input else N
         planes = _lib.PLANE_CSM
-        key = ("global", n_freq)
-        if key not in self._accum_cache:
-            accum, n_obs = engine.accumulate(sp, "trials_tapers", planes, n_freq=n_freq)
-            self._accum_cache[key] = (self._reduce_over_ranks(accum), n_obs)
-        accum, n_obs = self._accum_cache[key]
+        accum, n_obs, n_freq = self._csm_records("global", "trials_tapers")
         values, vectors = engine.global_coherence(accum, W, n_freq, N, C, planes, self._n_observations_total(n_obs),
                                                   max_rank, ascending=max_rank < C - 1)
         return values.cpu().numpy(), vectors.cpu().numpy()
@@ -424,22 +434,31 @@ class Connectivity:
         group_labels = np.asarray(group_labels)
         labels = np.unique(group_labels)
         groups = [np.flatnonzero(np.isin(group_labels, lab)) for lab in labels]
-        sp = self._device()
         planes = _lib.PLANE_CSM
-        key = ("canonical", self._n_freq)
-        if key not in self._accum_cache:
-            accum, n_obs = engine.accumulate(sp, "trials_tapers", planes, n_freq=self._n_freq)
-            self._accum_cache[key] = (self._reduce_over_ranks(accum), n_obs)
-        accum, n_obs = self._accum_cache[key]
+        accum, n_obs, _ = self._csm_records("canonical", "trials_tapers", two_sided=False)
         n_total = self._n_observations_total(n_obs)
         if max(len(g) for g in groups) > n_total:
             raise ValueError("canonical_coherence needs n_trials * n_tapers >= the largest group size "
                              "(the cross-spectral blocks are rank deficient otherwise)")
-        out, n_fail = engine.canonical_coherence(accum, self._shape5[4], planes, n_total, groups)
+        lo, hi, per = self._canonical_bins(accum.shape[0])
+        if hi > lo:
+            out, n_fail = engine.canonical_coherence(accum[lo:hi], self._shape5[4], planes, n_total, groups)
+        else:                                  # more processes than bins: this one has nothing to evaluate
+            import torch
+            out, n_fail = torch.empty((0, len(groups), len(groups)), dtype=torch.float64, device=accum.device), 0
+        out = self._canonical_gather(out, accum.shape[0], per)
         if n_fail:
             logger.warning(f"{n_fail} group cross-spectral blocks were not positive definite (NaN output)")
         W = self._shape5[0]
         return out.cpu().numpy().reshape(W, self._n_freq, len(labels), len(labels)), labels
+
+    def _canonical_bins(self, n_bins):
+        """Bins [lo, hi) this process evaluates and the per-process count (all of them here; 1/N of them in
+        parallel.ShardedConnectivity)."""
+        return 0, n_bins, n_bins
+
+    def _canonical_gather(self, part, n_bins, per):
+        return part
 
     def conditional_spectral_granger_prediction(self):
         raise NotImplementedError   # reference connectivity.py:1215-1224 raises too

@@ -33,9 +33,10 @@ struct sc_fft_plan {
     rocfft_plan plan, tail_plan;          // chunk rows; the last batch % chunk rows
     rocfft_execution_info info;
     void* work;                           // rocFFT work buffer (the larger of the two plans')
-    float2* Z;                            // [chunk][F]
+    void* Z;                              // [chunk][F] float2 (or double2: f64 plans)
     size_t work_bytes;
     int64_t N, batch, chunk, tail;
+    int f64;                              // double-precision plan (the f64 engine)
 };
 
 static int g_rocfft_ready = 0;
@@ -50,7 +51,7 @@ static int g_rocfft_ready = 0;
         }                                                                           \
     } while (0)
 
-static int make_r2c_rows(rocfft_plan* plan, int64_t N, int64_t rows) {
+static int make_r2c_rows(rocfft_plan* plan, int64_t N, int64_t rows, bool f64) {
     rocfft_plan_description desc = nullptr;
     SC_CHECK_FFT(rocfft_plan_description_create(&desc));
     size_t one[1] = {1};
@@ -60,7 +61,8 @@ static int make_r2c_rows(rocfft_plan* plan, int64_t N, int64_t rows) {
         1, one, (size_t)N, 1, one, F));
     size_t lengths[1] = {(size_t)N};
     const rocfft_status s = rocfft_plan_create(plan, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
-                                               rocfft_precision_single, 1, lengths, (size_t)rows, desc);
+                                               f64 ? rocfft_precision_double : rocfft_precision_single, 1, lengths,
+                                               (size_t)rows, desc);
     rocfft_plan_description_destroy(desc);
     if (s != rocfft_status_success) {
         sc_set_error("rocfft_plan_create(N=%lld, rows=%lld) failed: status %d", (long long)N, (long long)rows, (int)s);
@@ -71,21 +73,22 @@ static int make_r2c_rows(rocfft_plan* plan, int64_t N, int64_t rows) {
 
 extern "C" int sc_fft_plan_destroy(sc_fft_plan* plan);
 
-extern "C" int sc_fft_plan_create(sc_fft_plan** out, int64_t N, int64_t batch) {
+static int fft_plan_create(sc_fft_plan** out, int64_t N, int64_t batch, bool f64) {
     SC_REQUIRE(out != nullptr, "plan out pointer is NULL");
     SC_REQUIRE(N >= 1 && batch >= 1, "N and batch must be positive");
     if (!g_rocfft_ready) { SC_CHECK_FFT(rocfft_setup()); g_rocfft_ready = 1; }
     sc_fft_plan* p = new sc_fft_plan();
     memset(p, 0, sizeof(*p));
-    p->N = N; p->batch = batch;
+    p->N = N; p->batch = batch; p->f64 = f64 ? 1 : 0;
     const int64_t F = N / 2 + 1;
-    int64_t chunk = ((int64_t)(64u << 20) / (F * 8)) & ~(int64_t)63;      // 64 MB of Z, whole 64-row tiles
+    const size_t zsize = f64 ? sizeof(double2) : sizeof(float2);
+    int64_t chunk = ((int64_t)(64u << 20) / (F * (int64_t)zsize)) & ~(int64_t)63;      // 64 MB of Z, whole 64-row tiles
     if (chunk < 64) chunk = 64;
     if (chunk > batch) chunk = batch;
     p->chunk = chunk;
     p->tail = batch % chunk;
-    int rc = make_r2c_rows(&p->plan, N, chunk);
-    if (rc == SC_OK && p->tail) rc = make_r2c_rows(&p->tail_plan, N, p->tail);
+    int rc = make_r2c_rows(&p->plan, N, chunk, f64);
+    if (rc == SC_OK && p->tail) rc = make_r2c_rows(&p->tail_plan, N, p->tail, f64);
     if (rc != SC_OK) { sc_fft_plan_destroy(p); return rc; }
     size_t w1 = 0, w2 = 0;
     if (rocfft_plan_get_work_buffer_size(p->plan, &w1) != rocfft_status_success ||
@@ -97,9 +100,9 @@ extern "C" int sc_fft_plan_create(sc_fft_plan** out, int64_t N, int64_t batch) {
     }
     p->work_bytes = w1 > w2 ? w1 : w2;
     if ((p->work_bytes && hipMalloc(&p->work, p->work_bytes) != hipSuccess) ||
-        hipMalloc((void**)&p->Z, (size_t)chunk * F * sizeof(float2)) != hipSuccess) {
+        hipMalloc((void**)&p->Z, (size_t)chunk * F * zsize) != hipSuccess) {
         sc_set_error("hipMalloc of the FFT plan's buffers failed (%zu + %zu bytes)", p->work_bytes,
-                     (size_t)chunk * F * sizeof(float2));
+                     (size_t)chunk * F * zsize);
         sc_fft_plan_destroy(p);
         return SC_ENOMEM;
     }
@@ -112,9 +115,12 @@ extern "C" int sc_fft_plan_create(sc_fft_plan** out, int64_t N, int64_t batch) {
     return SC_OK;
 }
 
+extern "C" int sc_fft_plan_create(sc_fft_plan** out, int64_t N, int64_t batch) { return fft_plan_create(out, N, batch, false); }
+extern "C" int sc_fft_plan_create_f64(sc_fft_plan** out, int64_t N, int64_t batch) { return fft_plan_create(out, N, batch, true); }
+
 extern "C" int sc_fft_plan_work_bytes(const sc_fft_plan* plan, size_t* bytes) {
     SC_REQUIRE(plan && bytes, "NULL argument");
-    *bytes = plan->work_bytes + (size_t)plan->chunk * (plan->N / 2 + 1) * sizeof(float2);
+    *bytes = plan->work_bytes + (size_t)plan->chunk * (plan->N / 2 + 1) * (plan->f64 ? sizeof(double2) : sizeof(float2));
     return SC_OK;
 }
 
@@ -123,9 +129,10 @@ extern "C" int sc_fft_plan_work_bytes(const sc_fft_plan* plan, size_t* bytes) {
 // (and the fused FFT kernels here) return them so, which is what makes PLI / wPLI exactly 0 at those bins
 // (connectivity.py:982-1028: weights < eps -> 1); a generic R2C leaves rounding noise in the imaginary part,
 // and sum Im / sum |Im| of noise is O(1): the transpose zeroes it on the way through.
-__global__ void __launch_bounds__(256) rows_to_bins_kernel(const float2* __restrict__ Z, float2* __restrict__ X, int64_t rows,
+template <typename T2>
+__global__ void __launch_bounds__(256) rows_to_bins_kernel(const T2* __restrict__ Z, T2* __restrict__ X, int64_t rows,
                                                             int64_t F, int64_t batch, int64_t b_off, int64_t nyquist_row) {
-    __shared__ float2 tile[64][33];
+    __shared__ T2 tile[64][33];
     const int t = threadIdx.x;
     const int64_t r0 = (int64_t)blockIdx.x * 64, f0 = (int64_t)blockIdx.y * 32;
     {
@@ -143,8 +150,8 @@ __global__ void __launch_bounds__(256) rows_to_bins_kernel(const float2* __restr
         for (int j = 0; j < 8; ++j) {
             const int64_t f = f0 + fi + 4 * j, r = r0 + ri;
             if (r < rows && f < F) {
-                float2 v = tile[ri][fi + 4 * j];
-                if (f == 0 || f == nyquist_row) v.y = 0.f;
+                T2 v = tile[ri][fi + 4 * j];
+                if (f == 0 || f == nyquist_row) v.y = 0;
                 X[f * batch + b_off + r] = v;
             }
         }
@@ -153,27 +160,41 @@ __global__ void __launch_bounds__(256) rows_to_bins_kernel(const float2* __restr
 
 int sc_internal_rows_to_bins(const void* d_Z, void* d_X, int64_t rows, int64_t F, int64_t batch, int64_t b_off,
                              int64_t nyquist_row, hipStream_t st) {
-    hipLaunchKernelGGL(rows_to_bins_kernel, dim3((unsigned)((rows + 63) / 64), (unsigned)((F + 31) / 32)), dim3(256), 0, st,
+    hipLaunchKernelGGL(rows_to_bins_kernel<float2>, dim3((unsigned)((rows + 63) / 64), (unsigned)((F + 31) / 32)), dim3(256), 0, st,
                        (const float2*)d_Z, (float2*)d_X, rows, F, batch, b_off, nyquist_row);
     SC_CHECK_HIP(hipGetLastError());
     return SC_OK;
 }
 
-extern "C" int sc_fft_execute(sc_fft_plan* plan, const float* d_y, void* d_X, void* stream) {
+static int fft_execute(sc_fft_plan* plan, const void* d_y, void* d_X, bool f64, void* stream) {
+    ScTimed timed_("fft_execute", stream);
     SC_REQUIRE(plan && d_y && d_X, "NULL argument");
+    SC_REQUIRE((plan->f64 != 0) == f64, "plan precision does not match the call");
     SC_CHECK_FFT(rocfft_execution_info_set_stream(plan->info, stream));
     const int64_t F = plan->N / 2 + 1;
     const int64_t nyq = (plan->N % 2 == 0) ? plan->N / 2 : -1;
     for (int64_t off = 0; off < plan->batch; off += plan->chunk) {
         const int64_t rows = plan->batch - off < plan->chunk ? plan->batch - off : plan->chunk;
-        void* in[1] = {(void*)(d_y + off * plan->N)};
+        void* in[1] = {(void*)((const char*)d_y + off * plan->N * (f64 ? 8 : 4))};
         void* outb[1] = {plan->Z};
         SC_CHECK_FFT(rocfft_execute(rows == plan->chunk ? plan->plan : plan->tail_plan, in, outb, plan->info));
-        hipLaunchKernelGGL(rows_to_bins_kernel, dim3((unsigned)((rows + 63) / 64), (unsigned)((F + 31) / 32)), dim3(256), 0,
-                           (hipStream_t)stream, (const float2*)plan->Z, (float2*)d_X, rows, F, plan->batch, off, nyq);
+        const dim3 grid((unsigned)((rows + 63) / 64), (unsigned)((F + 31) / 32));
+        if (f64)
+            hipLaunchKernelGGL(rows_to_bins_kernel<double2>, grid, dim3(256), 0, (hipStream_t)stream, (const double2*)plan->Z,
+                               (double2*)d_X, rows, F, plan->batch, off, nyq);
+        else
+            hipLaunchKernelGGL(rows_to_bins_kernel<float2>, grid, dim3(256), 0, (hipStream_t)stream, (const float2*)plan->Z,
+                               (float2*)d_X, rows, F, plan->batch, off, nyq);
     }
     SC_CHECK_HIP(hipGetLastError());
     return SC_OK;
+}
+
+extern "C" int sc_fft_execute(sc_fft_plan* plan, const float* d_y, void* d_X, void* stream) {
+    return fft_execute(plan, d_y, d_X, false, stream);
+}
+extern "C" int sc_fft_execute_f64(sc_fft_plan* plan, const double* d_y, void* d_X, void* stream) {
+    return fft_execute(plan, d_y, d_X, true, stream);
 }
 
 extern "C" int sc_fft_plan_destroy(sc_fft_plan* plan) {

@@ -20,7 +20,7 @@ __device__ inline cd zmul(cd a, cd b) { return make_double2(a.x * b.x - a.y * b.
 __device__ inline cd zmulc(cd a, cd b) { return make_double2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }  // a conj(b)
 
 struct CanonArgs {
-    const float* accum;
+    ScRec accum;
     const int32_t* members;   // [G][CMAX] channel indices, -1 padded
     const int32_t* sizes;     // [G]
     double* out;              // [n_bins][G][G]
@@ -31,7 +31,7 @@ struct CanonArgs {
     double n_obs;
 };
 
-__device__ inline cd csm_read(const float* rec, const CanonArgs& a, int i, int j) {
+__device__ inline cd csm_read(ScRec rec, const CanonArgs& a, int i, int j) {
     int ti = i >> 4, tj = j >> 4, ii = i & 15, jj = j & 15;
     const bool m = (ti > tj) || (ti == tj && ii > jj);
     if (m) { int t = ti; ti = tj; tj = t; t = ii; ii = jj; jj = t; }
@@ -74,7 +74,7 @@ __global__ void __launch_bounds__(64) canonical_kernel(CanonArgs a) {
     const int na = a.sizes[ga], nb = a.sizes[gb];
     const int32_t* ma = a.members + ga * CMAX;
     const int32_t* mb = a.members + gb * CMAX;
-    const float* rec = a.accum + bin * a.floats_per_bin;
+    const ScRec rec = a.accum + bin * a.floats_per_bin;
 
     cd La[CMAX][CMAX], Lb[CMAX][CMAX], M[CMAX][CMAX];
     for (int i = 0; i < na; ++i)
@@ -194,7 +194,7 @@ __global__ void __launch_bounds__(64 * CB_WAVES) canonical_factor_kernel(CanonAr
     cd* Ls = reinterpret_cast<cd*>(cb_smem);                                   // [wave][16][16]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int64_t bin = blockIdx.x;
-    const float* rec = a.accum + bin * a.floats_per_bin;
+    const ScRec rec = a.accum + bin * a.floats_per_bin;
 
     // phase 1: L_g for every group (a wave per group, left-looking Cholesky, a lane per row)
     for (int g = wave; g < G; g += CB_WAVES) {
@@ -264,7 +264,7 @@ __global__ void __launch_bounds__(64 * CB_WAVES) canonical_pair_kernel(CanonArgs
     const int n_chunks = (a.n_gpairs + CB_WAVES - 1) / CB_WAVES;
     const int64_t bin = blockIdx.x / n_chunks;
     const int chunk = blockIdx.x % n_chunks;
-    const float* rec = a.accum + bin * a.floats_per_bin;
+    const ScRec rec = a.accum + bin * a.floats_per_bin;
     const cd* Ls = Lg + (size_t)bin * G * CB_C * CB_C;
     const int* okg = okb + bin * G;
     cd* M = scratch + (size_t)wave * 2 * CB_C * CB_C;
@@ -432,10 +432,11 @@ __global__ void canon_fill_nan(double* out, int64_t total) {
 
 extern "C" int sc_canonical_max_group(void) { return 32; }
 
-extern "C" int sc_canonical_coherence_f64(const float* d_accum, int64_t n_bins, int64_t n_signals, uint32_t planes,
+extern "C" int sc_canonical_coherence_f64(const void* d_accum, int64_t n_bins, int64_t n_signals, uint32_t planes,
                                           int64_t n_observations, const int32_t* d_members, const int32_t* d_sizes,
                                           int n_groups, int max_group_size, double* d_out, int32_t* d_fail,
                                           void* stream) {
+    ScTimed timed_("canonical_coherence", stream);
     SC_REQUIRE(d_accum && d_members && d_sizes && d_out && d_fail, "NULL argument");
     SC_REQUIRE(planes & SC_PLANE_CSM, "accumulator record must contain SC_PLANE_CSM");
     SC_REQUIRE(n_groups >= 1 && n_bins >= 1, "empty problem");
@@ -445,7 +446,7 @@ extern "C" int sc_canonical_coherence_f64(const float* d_accum, int64_t n_bins, 
     }
     hipStream_t st = (hipStream_t)stream;
     CanonArgs a;
-    a.accum = d_accum; a.members = d_members; a.sizes = d_sizes; a.out = d_out; a.fail = d_fail;
+    a.accum = sc_rec(d_accum, planes); a.members = d_members; a.sizes = d_sizes; a.out = d_out; a.fail = d_fail;
     a.n_bins = n_bins; a.G = n_groups; a.n_gpairs = n_groups * (n_groups - 1) / 2;
     a.NB = sc_n_blocks(n_signals); a.n_tiles = sc_n_tiles(a.NB);
     a.floats_per_bin = (int64_t)sc_plane_count(planes) * a.n_tiles * SC_TILE_ELEMS;

@@ -16,6 +16,16 @@ bool sc_internal_causal_fft_supported(int64_t N);
 int sc_internal_causal_fft_pair(void* d_A, const int32_t* d_status, int64_t n_problems, int C, int64_t N,
                                 hipStream_t st);
 
+// sc_timing.hip: brackets the launches of an entry point with two hipEvents on its stream while sc_timing_enable(1)
+struct ScTimed {
+    int slot;
+    void* st;
+    ScTimed(const char* name, void* stream);
+    ~ScTimed();
+    ScTimed(const ScTimed&) = delete;
+    ScTimed& operator=(const ScTimed&) = delete;
+};
+
 #define SC_CHECK_HIP(expr)                                                        \
     do {                                                                          \
         hipError_t e_ = (expr);                                                   \
@@ -33,6 +43,18 @@ int sc_internal_causal_fft_pair(void* d_A, const int32_t* d_status, int64_t n_pr
             return SC_EINVAL;                                                     \
         }                                                                         \
     } while (0)
+
+// Accumulator records as their consumers see them: float elements (f32 engine) or double elements (f64 engine,
+// SC_RECORD_F64 set in `planes`).  Pointer arithmetic in elements, loads widened to double.
+struct ScRec {
+    const void* p;
+    int f64;
+    __host__ __device__ ScRec operator+(int64_t n) const { return ScRec{(const char*)p + n * (f64 ? 8 : 4), f64}; }
+    __device__ double operator[](int64_t i) const {
+        return f64 ? ((const double*)p)[i] : (double)((const float*)p)[i];
+    }
+};
+__host__ inline ScRec sc_rec(const void* d_accum, uint32_t planes) { return ScRec{d_accum, (planes & SC_RECORD_F64) ? 1 : 0}; }
 
 #define SC_TILE 16            // channel tile edge of the accumulator layout
 #define SC_TILE_ELEMS 256

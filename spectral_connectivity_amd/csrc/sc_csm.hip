@@ -139,6 +139,7 @@ static int launch_csm(const CsmArgs& a, bool vec, hipStream_t stream) {
 
 static int csm_accumulate(const void* d_X, const sc_spectra_desc* desc, uint32_t planes, uint32_t into, float* d_accum,
                           void* stream) {
+    ScTimed timed_("csm_mfma", stream);
     SC_REQUIRE(d_X && desc && d_accum, "NULL argument");
     SC_REQUIRE(planes & into, "planes must contain the plane to fill");
     ScAxes ax;

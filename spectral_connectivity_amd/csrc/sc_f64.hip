@@ -1,0 +1,359 @@
+// sc_f64.hip -- stage B of the float64 engine: the reference's own arithmetic on the device.
+//
+// The reference is float64 / complex128 end to end (transforms.py:1402-1405, connectivity.py:277-285, :1799-1822).
+// The headline path computes in float32 (north_star's tolerance: 1e-5); measured at the full BASELINE depths that
+// gives power to ~1e-6 relative but cancellation-small cross-spectra (coherency of nearly independent channels, the
+// Im S numerator of wPLI) only to ~1e-7 of the array scale, i.e. 3e-5 ... 1e-4 relative on entries 1000x below the
+// maximum (tests/test_gpu_full_depth.py).  `Connectivity(dtype=complex128)` -- the reference's default -- therefore runs
+// THIS engine: float64 transform (sc_taper_windows_f64 + rocFFT double), complex128 spectra, the cross-spectral matrix
+// on the fp64 matrix cores (v_mfma_f64_16x16x4_f64), the per-observation non-linear planes on the fp64 VALU, double
+// accumulator records (SC_RECORD_F64) and sc_measure_f64.  Elementwise relative error ~1e-13.
+//
+//   csm_f64_kernel        S += X^H X per (group, bin): Re S_ij = sum ar_i ar_j + ai_i ai_j, Im S_ij = sum ai_i ar_j - ar_i ai_j,
+//                         four real fp64 MFMAs per 16x16 channel tile and 4 observations (connectivity.py:447-492)
+//   nonlinear_f64_kernel  sum |Im s|, (Im s)^2, sign(Im s), s/|s| per observation (connectivity.py:897-1159)
+// Same record layout as the f32 engine (upper-triangular 16x16 tiles, un-normalised sums: trial shards add), double
+// elements.  Workgroup = 4 waves = one bin x one tile group; observation rows staged HBM -> registers -> LDS in chunks
+// of 16 (double buffered, one barrier per chunk); XCD-aware blockIdx -> (bin, tile group) like sc_csm.hip.
+#include "sc_common.h"
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+#define F64_OC 16            // observation rows per staged chunk
+
+struct F64Args {
+    const double2* base;     // X (group / bin offsets are added in-kernel)
+    ScAxes ax;
+    int64_t obs_stride;      // > 0: offset(o) = o * obs_stride
+    double* accum;
+    int64_t elems_per_bin;
+    int n_bins, F, C, CP, NB, n_tiles, n_groups_of_tiles;
+    int NB32, n_blocks32;
+    int plane;               // record plane the CSM kernel fills (re; im = plane + 1)
+    uint32_t planes;
+    int n_obs;
+};
+
+__device__ __forceinline__ int64_t f64_obs_offset(const F64Args& p, int o) {
+    return p.obs_stride > 0 ? (int64_t)o * p.obs_stride : sc_obs_offset(p.ax, o);
+}
+
+// E double2 elements per thread cover F64_OC rows x CP channels (CP <= 256: E = 16)
+template <int E>
+__device__ __forceinline__ void f64_load(const F64Args& p, const double2* base, int o0, int tid, double2 (&r)[E]) {
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+        const int e = tid + i * 256;
+        double2 v = make_double2(0.0, 0.0);
+        if (e < F64_OC * p.CP) {
+            const int row = e / p.CP, c = e - row * p.CP, o = o0 + row;
+            if (o < p.n_obs && c < p.C) v = base[f64_obs_offset(p, o) + c];
+        }
+        r[i] = v;
+    }
+}
+template <int E>
+__device__ __forceinline__ void f64_store(const F64Args& p, double2* lds, int tid, const double2 (&r)[E]) {
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+        const int e = tid + i * 256;
+        if (e < F64_OC * p.CP) lds[e] = r[i];          // row stride = CP
+    }
+}
+
+template <int MAX_SLOTS, int E>
+__global__ void __launch_bounds__(256) csm_f64_kernel(F64Args p) {
+    extern __shared__ __align__(16) unsigned char f64_smem[];
+    double2* lds = reinterpret_cast<double2*>(f64_smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int id = blockIdx.x;
+    const int xcd = id & 7, j = id >> 3;
+    const int tg = j % p.n_groups_of_tiles;
+    const int bin = (j / p.n_groups_of_tiles) * 8 + xcd;
+    if (bin >= p.n_bins) return;
+    const int g = bin / p.F, f = bin - g * p.F;
+    const double2* base = p.base + (int64_t)f * p.ax.sF + sc_group_offset(p.ax, g);
+
+    int bi[MAX_SLOTS], bj[MAX_SLOTS];
+    bool valid[MAX_SLOTS];
+#pragma unroll
+    for (int s = 0; s < MAX_SLOTS; ++s) {
+        const int t = (tg * MAX_SLOTS + s) * 4 + wave;
+        valid[s] = t < p.n_tiles;
+        int r = 0, rem = valid[s] ? t : 0, len = p.NB;
+        while (rem >= len) { rem -= len; ++r; --len; }
+        bi[s] = r; bj[s] = r + rem;
+    }
+    f64x4 re[MAX_SLOTS], im[MAX_SLOTS];
+#pragma unroll
+    for (int s = 0; s < MAX_SLOTS; ++s) { re[s] = (f64x4){0.0, 0.0, 0.0, 0.0}; im[s] = re[s]; }
+
+    const int buf = F64_OC * p.CP;
+    const int n_chunks = (p.n_obs + F64_OC - 1) / F64_OC;
+    double2 regs[E];
+    f64_load<E>(p, base, 0, tid, regs);
+    f64_store<E>(p, lds, tid, regs);
+    __syncthreads();
+    // A operand: lane l holds A[i = l & 15][k = l >> 4]; B operand: B[k = l >> 4][j = l & 15]  (one f64 each)
+    const int k = lane >> 4, c16 = lane & 15;
+    for (int ch = 0; ch < n_chunks; ++ch) {
+        const double2* cur = lds + (ch & 1) * buf;
+        double2* nxt = lds + ((ch + 1) & 1) * buf;
+        const bool more = ch + 1 < n_chunks;
+        if (more) f64_load<E>(p, base, (ch + 1) * F64_OC, tid, regs);
+#pragma unroll
+        for (int kk = 0; kk < F64_OC / 4; ++kk) {
+            const double2* rowp = cur + (kk * 4 + k) * p.CP + c16;
+#pragma unroll
+            for (int s = 0; s < MAX_SLOTS; ++s) {       // invalid slots recompute tile (0, 0) and are never stored
+                const double2 a = rowp[16 * bi[s]];
+                const double2 b = rowp[16 * bj[s]];
+                re[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.x, re[s], 0, 0, 0);
+                im[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b.x, im[s], 0, 0, 0);
+                re[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b.y, re[s], 0, 0, 0);
+                im[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.x, b.y, im[s], 0, 0, 0);
+            }
+        }
+        if (more) f64_store<E>(p, nxt, tid, regs);
+        __syncthreads();
+    }
+    // C/D of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg  (NOT the f32 map)
+    double* out = p.accum + (int64_t)bin * p.elems_per_bin + (int64_t)p.plane * p.n_tiles * SC_TILE_ELEMS;
+#pragma unroll
+    for (int s = 0; s < MAX_SLOTS; ++s) {
+        if (!valid[s]) continue;
+        const int t = (tg * MAX_SLOTS + s) * 4 + wave;
+        double* o_re = out + (int64_t)t * SC_TILE_ELEMS;
+        double* o_im = o_re + (int64_t)p.n_tiles * SC_TILE_ELEMS;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int idx = ((lane >> 4) + 4 * r) * 16 + (lane & 15);
+            o_re[idx] = re[s][r];
+            o_im[idx] = im[s][r];
+        }
+    }
+}
+
+// ---- per-observation non-linear planes, fp64 VALU ---------------------------------------------------------------
+// Workgroup = one bin and MAXB upper-triangular 32x32 channel blocks; a wave is an 8x8 lane grid, a lane owns a 4x4
+// tile of pairs; the 4 waves take observation rows o = wave (mod 4) of every chunk and are summed through LDS.
+template <uint32_t WHICH>
+struct F64Planes {
+    static constexpr int N = ((WHICH & SC_PLANE_ABS_IM) ? 1 : 0) + ((WHICH & SC_PLANE_IM_SQ) ? 1 : 0) +
+                             ((WHICH & SC_PLANE_SIGN_IM) ? 1 : 0) + ((WHICH & SC_PLANE_UNIT) ? 2 : 0);
+};
+
+template <uint32_t WHICH, int MAXB, int E>
+__global__ void __launch_bounds__(256) nonlinear_f64_kernel(F64Args p) {
+    extern __shared__ __align__(16) unsigned char f64_smem[];
+    double2* lds = reinterpret_cast<double2*>(f64_smem);
+    constexpr int NP = F64Planes<WHICH>::N;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int id = blockIdx.x;
+    const int xcd = id & 7, jj = id >> 3;
+    const int n_sets = (p.n_blocks32 + MAXB - 1) / MAXB;
+    const int bs = jj % n_sets;
+    const int bin = (jj / n_sets) * 8 + xcd;
+    if (bin >= p.n_bins) return;
+    const int g = bin / p.F, f = bin - g * p.F;
+    const double2* base = p.base + (int64_t)f * p.ax.sF + sc_group_offset(p.ax, g);
+
+    int BI[MAXB], BJ[MAXB];
+    bool valid[MAXB];
+#pragma unroll
+    for (int s = 0; s < MAXB; ++s) {
+        const int t = bs * MAXB + s;
+        valid[s] = t < p.n_blocks32;
+        int r = 0, rem = valid[s] ? t : 0, len = p.NB32;
+        while (rem >= len) { rem -= len; ++r; --len; }
+        BI[s] = r; BJ[s] = r + rem;
+    }
+    double acc[MAXB][NP][16];
+#pragma unroll
+    for (int s = 0; s < MAXB; ++s)
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[s][q][e] = 0.0;
+
+    const int li = lane >> 3, lj = lane & 7;
+    const int buf = F64_OC * p.CP;
+    const int n_chunks = (p.n_obs + F64_OC - 1) / F64_OC;
+    double2 regs[E];
+    f64_load<E>(p, base, 0, tid, regs);
+    f64_store<E>(p, lds, tid, regs);
+    __syncthreads();
+    for (int ch = 0; ch < n_chunks; ++ch) {
+        const double2* cur = lds + (ch & 1) * buf;
+        double2* nxt = lds + ((ch + 1) & 1) * buf;
+        const bool more = ch + 1 < n_chunks;
+        if (more) f64_load<E>(p, base, (ch + 1) * F64_OC, tid, regs);
+        // rows past n_obs are zero: +0 for every plane except UNIT (0 / 0 = NaN), so bound the loop by the real count
+        const int rows = min(F64_OC, p.n_obs - ch * F64_OC);
+        for (int row = wave; row < rows; row += 4) {
+            const double2* rp = cur + row * p.CP;
+#pragma unroll
+            for (int s = 0; s < MAXB; ++s) {
+                double2 xi[4], xj[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) { xi[a] = rp[BI[s] * 32 + li * 4 + a]; xj[a] = rp[BJ[s] * 32 + lj * 4 + a]; }
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const double imv = xi[a].y * xj[b].x - xi[a].x * xj[b].y;
+                        int q = 0;
+                        if constexpr (WHICH & SC_PLANE_ABS_IM) { acc[s][q][a * 4 + b] += fabs(imv); ++q; }
+                        if constexpr (WHICH & SC_PLANE_IM_SQ) { acc[s][q][a * 4 + b] += imv * imv; ++q; }
+                        if constexpr (WHICH & SC_PLANE_SIGN_IM) {
+                            acc[s][q][a * 4 + b] += (imv > 0.0 ? 1.0 : 0.0) - (imv < 0.0 ? 1.0 : 0.0);
+                            ++q;
+                        }
+                        if constexpr (WHICH & SC_PLANE_UNIT) {
+                            const double rev = xi[a].x * xj[b].x + xi[a].y * xj[b].y;
+                            const double mag = sqrt(rev * rev + imv * imv);       // 0 / 0 -> NaN like the reference
+                            acc[s][q][a * 4 + b] += rev / mag;
+                            acc[s][q + 1][a * 4 + b] += imv / mag;
+                        }
+                    }
+            }
+        }
+        if (more) f64_store<E>(p, nxt, tid, regs);
+        __syncthreads();
+    }
+    // cross-wave sum through LDS in a fixed order, one (block, plane) at a time: 4 waves x 16 x 64 doubles
+    double* red = reinterpret_cast<double*>(f64_smem);
+    double* out_bin = p.accum + (int64_t)bin * p.elems_per_bin;
+#pragma unroll
+    for (int s = 0; s < MAXB; ++s) {
+        if (!valid[s]) continue;       // identical for all 4 waves
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) red[(wave * 16 + e) * 64 + lane] = acc[s][q][e];
+            __syncthreads();
+            int plane = -1;
+            {
+                int kq = 0;
+                if constexpr (WHICH & SC_PLANE_ABS_IM) { if (q == kq) plane = sc_plane_offset(p.planes, SC_PLANE_ABS_IM); ++kq; }
+                if constexpr (WHICH & SC_PLANE_IM_SQ) { if (q == kq) plane = sc_plane_offset(p.planes, SC_PLANE_IM_SQ); ++kq; }
+                if constexpr (WHICH & SC_PLANE_SIGN_IM) { if (q == kq) plane = sc_plane_offset(p.planes, SC_PLANE_SIGN_IM); ++kq; }
+                if constexpr (WHICH & SC_PLANE_UNIT) {
+                    if (q == kq) plane = sc_plane_offset(p.planes, SC_PLANE_UNIT);
+                    if (q == kq + 1) plane = sc_plane_offset(p.planes, SC_PLANE_UNIT) + 1;
+                }
+            }
+            double* out = out_bin + (int64_t)plane * p.n_tiles * SC_TILE_ELEMS;
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) {
+                const int e = wave * 4 + e4;
+                const double v = red[(0 * 16 + e) * 64 + lane] + red[(1 * 16 + e) * 64 + lane] +
+                                 red[(2 * 16 + e) * 64 + lane] + red[(3 * 16 + e) * 64 + lane];
+                const int i = BI[s] * 32 + li * 4 + (e >> 2), jx = BJ[s] * 32 + lj * 4 + (e & 3);
+                const int ti = i >> 4, tj = jx >> 4;
+                if (ti <= tj && tj < p.NB)
+                    out[(int64_t)sc_tile_index(ti, tj, p.NB) * SC_TILE_ELEMS + (i & 15) * 16 + (jx & 15)] = v;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- host side
+static int f64_setup(const void* d_X, const sc_spectra_desc* desc, uint32_t planes, double* d_accum, F64Args* a) {
+    SC_REQUIRE(d_X && desc && d_accum, "NULL argument");
+    SC_REQUIRE(((uintptr_t)d_X % 16) == 0, "complex128 spectra must be 16-byte aligned");
+    ScAxes ax;
+    sc_make_axes(desc, &ax);
+    SC_REQUIRE(ax.C >= 1 && ax.F >= 1 && ax.n_obs >= 1 && ax.n_groups >= 1, "empty dimension");
+    if (ax.C > SC_MAX_SIGNALS) {
+        sc_set_error("n_signals=%d exceeds SC_MAX_SIGNALS=%d", ax.C, SC_MAX_SIGNALS);
+        return SC_EUNSUPPORTED;
+    }
+    a->base = (const double2*)d_X;
+    a->ax = ax;
+    {   // are the reduced axes one linear run?  (same rule as sc_stage_linear_stride)
+        int64_t s = 0, span = 1;
+        bool ok = true;
+        if (ax.rK > 1) { s = ax.sK; span = ax.rK; }
+        if (ax.rR > 1) { if (span == 1) { s = ax.sR; span = ax.rR; } else { ok = ok && (ax.sR == s * span); span *= ax.rR; } }
+        if (ax.rW > 1) { if (span == 1) { s = ax.sW; span = ax.rW; } else { ok = ok && (ax.sW == s * span); span *= ax.rW; } }
+        a->obs_stride = span == 1 ? 1 : ((ok && s > 0) ? s : 0);
+    }
+    a->accum = d_accum;
+    a->C = ax.C;
+    a->NB = sc_n_blocks(ax.C);
+    a->n_tiles = sc_n_tiles(a->NB);
+    a->NB32 = (ax.C + 31) / 32;
+    a->n_blocks32 = a->NB32 * (a->NB32 + 1) / 2;
+    a->CP = a->NB32 * 32;
+    a->n_bins = ax.n_groups * ax.F;
+    a->F = ax.F;
+    a->elems_per_bin = (int64_t)sc_plane_count(planes) * a->n_tiles * SC_TILE_ELEMS;
+    a->planes = planes;
+    a->n_obs = ax.n_obs;
+    a->plane = 0;
+    a->n_groups_of_tiles = 1;
+    return SC_OK;
+}
+
+template <int MAX_SLOTS>
+static int launch_csm_f64(F64Args a, hipStream_t st) {
+    a.n_groups_of_tiles = (a.n_tiles + 4 * MAX_SLOTS - 1) / (4 * MAX_SLOTS);
+    const unsigned grid = (unsigned)(((a.n_bins + 7) / 8) * 8 * a.n_groups_of_tiles);
+    const size_t shmem = (size_t)2 * F64_OC * a.CP * sizeof(double2);
+    auto k = csm_f64_kernel<MAX_SLOTS, 16>;
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), shmem, st, a);
+    SC_CHECK_HIP(hipGetLastError());
+    return SC_OK;
+}
+
+template <uint32_t WHICH, int MAXB>
+static int launch_nl_f64(const F64Args& a, hipStream_t st) {
+    const int n_sets = (a.n_blocks32 + MAXB - 1) / MAXB;
+    const unsigned grid = (unsigned)(((a.n_bins + 7) / 8) * 8 * n_sets);
+    size_t shmem = (size_t)2 * F64_OC * a.CP * sizeof(double2);
+    if (shmem < (size_t)4 * 16 * 64 * sizeof(double)) shmem = (size_t)4 * 16 * 64 * sizeof(double);
+    auto k = nonlinear_f64_kernel<WHICH, MAXB, 16>;
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), shmem, st, a);
+    SC_CHECK_HIP(hipGetLastError());
+    return SC_OK;
+}
+
+// Fills the planes named by `which` (a subset of `planes`) of the double records in d_accum.  SC_PLANE_CSM runs on the
+// fp64 matrix cores, every other plane on the fp64 VALU.
+extern "C" int sc_accumulate_f64(const void* d_X, const sc_spectra_desc* desc, uint32_t planes, uint32_t which,
+                                 double* d_accum, void* stream) {
+    ScTimed timed_("accumulate_f64", stream);
+    planes &= ~SC_RECORD_F64;
+    which &= ~SC_RECORD_F64;
+    SC_REQUIRE(which != 0 && (which & planes) == which, "which must be a non-empty subset of planes");
+    F64Args a;
+    const int rc0 = f64_setup(d_X, desc, planes, d_accum, &a);
+    if (rc0 != SC_OK) return rc0;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = SC_OK;
+    if (which & SC_PLANE_CSM) {
+        a.plane = sc_plane_offset(planes, SC_PLANE_CSM);
+        const int need = (a.n_tiles + 3) / 4;
+        if (need <= 1) rc = launch_csm_f64<1>(a, st);
+        else if (need <= 3) rc = launch_csm_f64<3>(a, st);
+        else if (need <= 5) rc = launch_csm_f64<5>(a, st);
+        else rc = launch_csm_f64<9>(a, st);
+        if (rc) return rc;
+    }
+    uint32_t w = which & ~SC_PLANE_CSM;
+    if ((w & (SC_PLANE_ABS_IM | SC_PLANE_IM_SQ)) == (SC_PLANE_ABS_IM | SC_PLANE_IM_SQ)) {
+        if ((rc = launch_nl_f64<SC_PLANE_ABS_IM | SC_PLANE_IM_SQ, 2>(a, st))) return rc;
+        w &= ~(SC_PLANE_ABS_IM | SC_PLANE_IM_SQ);
+    }
+    if (w & SC_PLANE_ABS_IM) { if ((rc = launch_nl_f64<SC_PLANE_ABS_IM, 3>(a, st))) return rc; }
+    if (w & SC_PLANE_IM_SQ) { if ((rc = launch_nl_f64<SC_PLANE_IM_SQ, 3>(a, st))) return rc; }
+    if (w & SC_PLANE_SIGN_IM) { if ((rc = launch_nl_f64<SC_PLANE_SIGN_IM, 3>(a, st))) return rc; }
+    if (w & SC_PLANE_UNIT) { if ((rc = launch_nl_f64<SC_PLANE_UNIT, 2>(a, st))) return rc; }
+    return rc;
+}

@@ -969,6 +969,7 @@ static int64_t fused_span(const ScAxes& ax) {
 
 static int fused_run(const void* d_X, const sc_spectra_desc* desc, uint32_t planes, int mode, float* d_accum,
                      void* d_workspace, int64_t workspace_bytes, void* d_scratch, int64_t scratch_bytes, void* stream) {
+    ScTimed timed_("fused_stage_b", stream);
     SC_REQUIRE(d_X && desc && d_accum, "NULL argument");
     FusedArgs a;
     ScAxes ax;

@@ -16,7 +16,7 @@ __device__ inline cd g_mul(cd a, cd b) { return make_double2(a.x * b.x - a.y * b
 #define GC_CMAX 64
 
 struct GcArgs {
-    const float* accum;
+    ScRec accum;
     double* values;        // [P][N][max_rank]
     cd* vectors;           // [P][N][C][max_rank]
     int64_t N, F, floats_per_bin;
@@ -41,7 +41,7 @@ __global__ void __launch_bounds__(256) global_coherence_kernel(GcArgs a) {
     int64_t bin = n;
     bool conj = false;
     if (!a.two_sided && n > a.N / 2) { bin = a.N - n; conj = true; }   // real input: S(-f) = conj S(f)
-    const float* rec = a.accum + (p * a.F + bin) * a.floats_per_bin;
+    const ScRec rec = a.accum + (p * a.F + bin) * a.floats_per_bin;
     for (int e = tid; e < C * C; e += 256) {
         const int i = e / C, j = e % C;
         int ti = i >> 4, tj = j >> 4, ii = i & 15, jj = j & 15;
@@ -227,7 +227,7 @@ __global__ void __launch_bounds__(256) global_coherence_big_kernel(GcBigArgs b) 
         int64_t bin = n;
         bool conj = false;
         if (!a.two_sided && n > a.N / 2) { bin = a.N - n; conj = true; }
-        const float* rec = a.accum + (p * a.F + bin) * a.floats_per_bin;
+        const ScRec rec = a.accum + (p * a.F + bin) * a.floats_per_bin;
         __syncthreads();
         for (int e = tid; e < C * C; e += 256) {
             const int i = e / C, j = e % C;
@@ -389,9 +389,10 @@ __global__ void __launch_bounds__(256) global_coherence_big_kernel(GcBigArgs b) 
 
 extern "C" int sc_global_coherence_max_signals(void) { return GC_BIG_CMAX; }
 
-extern "C" int sc_global_coherence_f64(const float* d_accum, int64_t n_groups, int64_t n_freq_accum, int64_t N,
+extern "C" int sc_global_coherence_f64(const void* d_accum, int64_t n_groups, int64_t n_freq_accum, int64_t N,
                                        int64_t C, uint32_t planes, int64_t n_obs, int max_rank, int ascending,
                                        double* d_values, void* d_vectors, void* stream) {
+    ScTimed timed_("global_coherence", stream);
     SC_REQUIRE(d_accum && d_values && d_vectors, "NULL argument");
     SC_REQUIRE(planes & SC_PLANE_CSM, "accumulator record must contain SC_PLANE_CSM");
     SC_REQUIRE(n_freq_accum == N || n_freq_accum == N / 2 + 1, "accumulators must hold N or N/2+1 bins");
@@ -402,7 +403,7 @@ extern "C" int sc_global_coherence_f64(const float* d_accum, int64_t n_groups, i
     }
     SC_REQUIRE(max_rank >= 1 && max_rank <= C, "max_rank must be in 1..n_signals");
     GcArgs a;
-    a.accum = d_accum; a.values = d_values; a.vectors = (cd*)d_vectors;
+    a.accum = sc_rec(d_accum, planes); a.values = d_values; a.vectors = (cd*)d_vectors;
     a.N = N; a.F = n_freq_accum; a.C = (int)C;
     a.NB = sc_n_blocks(C); a.n_tiles = sc_n_tiles(a.NB);
     a.p_csm = sc_plane_offset(planes, SC_PLANE_CSM);

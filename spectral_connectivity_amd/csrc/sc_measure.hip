@@ -16,7 +16,7 @@
 #define SC_EPS64 2.220446049250313e-16
 
 struct MeasureArgs {
-    const float* accum;
+    ScRec accum;
     void* out;
     int64_t n_bins, floats_per_bin, total;
     int C, NB, n_tiles;
@@ -25,7 +25,7 @@ struct MeasureArgs {
     int measure;
 };
 
-__device__ inline float tile_read(const float* bin_rec, int plane, int n_tiles, int NB, int i, int j,
+__device__ inline double tile_read(ScRec bin_rec, int plane, int n_tiles, int NB, int i, int j,
                                   bool* mirrored) {
     int ti = i >> 4, tj = j >> 4, ii = i & 15, jj = j & 15;
     // lower triangle (tile-wise AND inside diagonal tiles) is read from its mirror: the matrix
@@ -38,14 +38,15 @@ __device__ inline float tile_read(const float* bin_rec, int plane, int n_tiles, 
 }
 
 // power: one thread per (bin, channel)
+template <typename OutT>
 __global__ void __launch_bounds__(256) power_kernel(MeasureArgs a) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= a.total) return;
     const int64_t bin = idx / a.C;
     const int i = (int)(idx - bin * a.C);
     bool m;
-    const float* rec = a.accum + bin * a.floats_per_bin;
-    ((float*)a.out)[idx] = (float)((double)tile_read(rec, a.p_csm, a.n_tiles, a.NB, i, i, &m) / a.n_obs);
+    const ScRec rec = a.accum + bin * a.floats_per_bin;
+    ((OutT*)a.out)[idx] = (OutT)(tile_read(rec, a.p_csm, a.n_tiles, a.NB, i, i, &m) / a.n_obs);
 }
 
 // raw (un-normalised) sums of one matrix entry (i, j), as stored for the upper triangle
@@ -64,70 +65,70 @@ __device__ inline MeasureIn measure_mirror(MeasureIn v) {
 }
 
 // one measure of one entry; complex measures return (re, im), real ones (value, 0)
-__device__ inline float2 measure_value(int measure, double n, MeasureIn v, bool diag) {
+__device__ inline double2 measure_value(int measure, double n, MeasureIn v, bool diag) {
     const double NaN = nan("");
     double s_re = v.s_re / n, s_im = diag ? 0.0 : v.s_im / n;
     const double p_i = v.p_i / n, p_j = v.p_j / n;
     switch (measure) {
     case SC_M_CSM:
-        return make_float2((float)s_re, (float)s_im);
+        return make_double2(s_re, s_im);
     case SC_M_COHERENCY:
     case SC_M_COHERENCE_MAGNITUDE:
     case SC_M_COHERENCE_PHASE: {
         const double den = fmax(sqrt(p_i * p_j), SC_EPS64);
         double c_re = s_re / den, c_im = s_im / den;
         if (diag) { c_re = NaN; c_im = NaN; }
-        if (measure == SC_M_COHERENCY) return make_float2((float)c_re, (float)c_im);
+        if (measure == SC_M_COHERENCY) return make_double2(c_re, c_im);
         if (measure == SC_M_COHERENCE_MAGNITUDE) {
             const double mag = c_re * c_re + c_im * c_im;
-            return make_float2((float)(diag ? NaN : fmin(fmax(mag, 0.0), 1.0)), 0.f);
+            return make_double2((diag ? NaN : fmin(fmax(mag, 0.0), 1.0)), 0.0);
         }
-        return make_float2((float)(diag ? NaN : atan2(c_im, c_re)), 0.f);
+        return make_double2((diag ? NaN : atan2(c_im, c_re)), 0.0);
     }
     case SC_M_IMAGINARY_COHERENCE: {
         const double den = fmax(sqrt(p_i * p_j), SC_EPS64);
-        return make_float2((float)fmin(fmax(fabs(s_im / den), 0.0), 1.0), 0.f);
+        return make_double2(fmin(fmax(fabs(s_im / den), 0.0), 1.0), 0.0);
     }
     case SC_M_PLV:
-        return make_float2((float)(sqrt(v.u_re * v.u_re + v.u_im * v.u_im) / n), 0.f);
+        return make_double2((sqrt(v.u_re * v.u_re + v.u_im * v.u_im) / n), 0.0);
     case SC_M_PLV_COMPLEX:
-        return make_float2((float)(v.u_re / n), (float)(v.u_im / n));
+        return make_double2((v.u_re / n), (v.u_im / n));
     case SC_M_PPC:
-        return make_float2((float)((v.u_re * v.u_re + v.u_im * v.u_im - n) / (n * n - n)), 0.f);
+        return make_double2(((v.u_re * v.u_re + v.u_im * v.u_im - n) / (n * n - n)), 0.0);
     case SC_M_PLI:
     case SC_M_DEBIASED_PLI2: {
         const double pli = (diag ? 0.0 : v.sg) / n;
-        return make_float2((float)(measure == SC_M_PLI ? pli : (n * pli * pli - 1.0) / (n - 1.0)), 0.f);
+        return make_double2((measure == SC_M_PLI ? pli : (n * pli * pli - 1.0) / (n - 1.0)), 0.0);
     }
     case SC_M_WPLI: {
         double w = diag ? 0.0 : v.sa / n;
         if (w < SC_EPS64) w = 1.0;
-        return make_float2((float)(s_im / w), 0.f);
+        return make_double2((s_im / w), 0.0);
     }
     case SC_M_DEBIASED_WPLI2: {
         const double si = s_im * n;
         const double sa = diag ? 0.0 : v.sa, sq = diag ? 0.0 : v.sq;
         double wgt = sa * sa - sq;
         if (wgt == 0.0 || n <= 1.0) wgt = NaN;
-        return make_float2((float)((si * si - sq) / wgt), 0.f);
+        return make_double2(((si * si - sq) / wgt), 0.0);
     }
     default:
-        return make_float2(0.f, 0.f);
+        return make_double2(0.f, 0.0);
     }
 }
 
-template <bool COMPLEX_OUT>
+template <bool COMPLEX_OUT, typename OutT, typename OutT2>
 __global__ void __launch_bounds__(256) measure_tile_kernel(MeasureArgs a) {
     __shared__ MeasureIn raw[256];
-    __shared__ float2 mir[256];
+    __shared__ double2 mir[256];
     const int tid = threadIdx.x, ii = tid >> 4, jj = tid & 15;
     int ti = 0, len = a.NB, t = blockIdx.y;                 // upper-triangular tile (ti <= tj)
     while (t >= len) { t -= len; ++ti; --len; }
     const int tj = ti + t;
     const int64_t bin = blockIdx.x;
-    const float* rec = a.accum + bin * a.floats_per_bin;
+    const ScRec rec = a.accum + bin * a.floats_per_bin;
     const int64_t plane = (int64_t)a.n_tiles * SC_TILE_ELEMS;
-    const float* tile = rec + (int64_t)blockIdx.y * SC_TILE_ELEMS + ii * 16 + jj;
+    const ScRec tile = rec + ((int64_t)blockIdx.y * SC_TILE_ELEMS + ii * 16 + jj);
     MeasureIn v = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (a.p_csm >= 0) {
         v.s_re = (double)tile[a.p_csm * plane];
@@ -152,32 +153,33 @@ __global__ void __launch_bounds__(256) measure_tile_kernel(MeasureArgs a) {
         if (ii > jj) v = measure_mirror(raw[jj * 16 + ii]);
     }
     const int i = ti * 16 + ii, j = tj * 16 + jj;
-    float* outf = (float*)a.out;
-    float2* outc = (float2*)a.out;
+    OutT* outf = (OutT*)a.out;
+    OutT2* outc = (OutT2*)a.out;
     const int64_t obase = bin * (int64_t)a.C * a.C;
-    const float2 direct = measure_value(a.measure, a.n_obs, v, i == j);
+    const double2 direct = measure_value(a.measure, a.n_obs, v, i == j);
     if (i < a.C && j < a.C) {
-        if (COMPLEX_OUT) outc[obase + (int64_t)i * a.C + j] = direct;
-        else outf[obase + (int64_t)i * a.C + j] = direct.x;
+        if (COMPLEX_OUT) outc[obase + (int64_t)i * a.C + j] = OutT2{(OutT)direct.x, (OutT)direct.y};
+        else outf[obase + (int64_t)i * a.C + j] = (OutT)direct.x;
     }
     if (!dtile) {
         mir[jj * 16 + ii] = measure_value(a.measure, a.n_obs, measure_mirror(v), false);
         __syncthreads();
         const int r = tj * 16 + ii, c = ti * 16 + jj;       // thread (ii, jj) now owns row ii of the mirrored block
         if (r < a.C && c < a.C) {
-            if (COMPLEX_OUT) outc[obase + (int64_t)r * a.C + c] = mir[tid];
-            else outf[obase + (int64_t)r * a.C + c] = mir[tid].x;
+            if (COMPLEX_OUT) outc[obase + (int64_t)r * a.C + c] = OutT2{(OutT)mir[tid].x, (OutT)mir[tid].y};
+            else outf[obase + (int64_t)r * a.C + c] = (OutT)mir[tid].x;
         }
     }
 }
 
-extern "C" int sc_measure_f32(const float* d_accum, int64_t n_bins, int64_t n_signals, uint32_t planes,
-                              int64_t n_observations, int measure, void* d_out, void* stream) {
+static int measure_run(const void* d_accum, int64_t n_bins, int64_t n_signals, uint32_t planes,
+                       int64_t n_observations, int measure, void* d_out, bool wide, void* stream) {
+    ScTimed timed_("measure_epilogue", stream);
     SC_REQUIRE(d_accum && d_out, "NULL argument");
     SC_REQUIRE(n_bins >= 1 && n_signals >= 1 && n_observations >= 1, "dimensions must be positive");
     SC_REQUIRE(measure >= SC_M_POWER && measure <= SC_M_PLV_COMPLEX, "unknown measure");
     MeasureArgs a;
-    a.accum = d_accum;
+    a.accum = sc_rec(d_accum, planes);
     a.out = d_out;
     a.n_bins = n_bins;
     a.C = (int)n_signals;
@@ -208,15 +210,30 @@ extern "C" int sc_measure_f32(const float* d_accum, int64_t n_bins, int64_t n_si
         a.total = n_bins * n_signals;
         const int64_t blocks = (a.total + 255) / 256;
         SC_REQUIRE(blocks < (int64_t)1 << 31, "output too large for one launch");
-        hipLaunchKernelGGL(power_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+        if (wide) hipLaunchKernelGGL(power_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL(power_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     } else {
         a.total = n_bins * n_signals * n_signals;
         SC_REQUIRE(n_bins < (int64_t)1 << 31 && a.n_tiles <= 65535, "output too large for one launch");
         const dim3 grid((unsigned)n_bins, (unsigned)a.n_tiles);
         const bool cplx = measure == SC_M_CSM || measure == SC_M_COHERENCY || measure == SC_M_PLV_COMPLEX;
-        if (cplx) hipLaunchKernelGGL(measure_tile_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL(measure_tile_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+        hipStream_t st = (hipStream_t)stream;
+        if (cplx && wide) hipLaunchKernelGGL((measure_tile_kernel<true, double, double2>), grid, dim3(256), 0, st, a);
+        else if (cplx) hipLaunchKernelGGL((measure_tile_kernel<true, float, float2>), grid, dim3(256), 0, st, a);
+        else if (wide) hipLaunchKernelGGL((measure_tile_kernel<false, double, double2>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((measure_tile_kernel<false, float, float2>), grid, dim3(256), 0, st, a);
     }
     SC_CHECK_HIP(hipGetLastError());
     return SC_OK;
+}
+
+extern "C" int sc_measure_f32(const void* d_accum, int64_t n_bins, int64_t n_signals, uint32_t planes,
+                              int64_t n_observations, int measure, void* d_out, void* stream) {
+    return measure_run(d_accum, n_bins, n_signals, planes, n_observations, measure, d_out, false, stream);
+}
+
+// the same measures written as double / complex128: what the reference returns, without a widening pass
+extern "C" int sc_measure_f64(const void* d_accum, int64_t n_bins, int64_t n_signals, uint32_t planes,
+                              int64_t n_observations, int measure, void* d_out, void* stream) {
+    return measure_run(d_accum, n_bins, n_signals, planes, n_observations, measure, d_out, true, stream);
 }

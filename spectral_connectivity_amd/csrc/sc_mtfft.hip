@@ -640,6 +640,7 @@ extern "C" int sc_multitaper_fft_supported(int64_t L, int64_t N) {
 extern "C" int sc_multitaper_fft_f32(const float* d_x, int64_t T, int64_t R, int64_t C, int64_t L,
                                      int64_t step, int64_t W, int64_t N, const float* d_tapers, int64_t K,
                                      int detrend_type, const void* d_twiddles, void* d_X, void* stream) {
+    ScTimed timed_("mtfft_fused", stream);
     SC_REQUIRE(d_x && d_tapers && d_twiddles && d_X, "NULL device pointer");
     SC_REQUIRE(T >= 1 && R >= 1 && C >= 1 && L >= 1 && step >= 1 && W >= 1 && K >= 1, "dimensions must be positive");
     SC_REQUIRE((W - 1) * step + L <= T, "windows exceed the time series");

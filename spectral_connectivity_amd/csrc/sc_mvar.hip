@@ -147,7 +147,7 @@ struct MvDims {
 };
 
 // S[p][e][n] from the accumulator records (upper-triangular 16x16 tiles, un-normalised sums)
-__global__ void m_build(const float* accum, MvDims d, cd* S) {
+__global__ void m_build(ScRec accum, MvDims d, cd* S) {
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int e = blockIdx.y;
     const int64_t p = blockIdx.z;
@@ -156,7 +156,7 @@ __global__ void m_build(const float* accum, MvDims d, cd* S) {
     int64_t bin = n;
     bool conj = false;
     if (!d.two_sided && n > d.N / 2) { bin = d.N - n; conj = true; }   // real input: S(-f) = conj S(f)
-    const float* rec = accum + (p * d.F + bin) * d.floats_per_bin;
+    const ScRec rec = accum + (p * d.F + bin) * d.floats_per_bin;
     int ti = i >> 4, tj = j >> 4, ii = i & 15, jj = j & 15;
     const bool m = (ti > tj) || (ti == tj && ii > jj);
     if (m) { int t = ti; ti = tj; tj = t; t = ii; ii = jj; jj = t; }
@@ -527,10 +527,11 @@ extern "C" int sc_mvar_workspace_bytes(int64_t n_groups, int64_t C, int64_t N, s
 }
 
 // d_accum (accumulator records) or d_S ([P][N][C][C] complex128, two-sided) -> d_G [P][N][C][C] complex128
-extern "C" int sc_mvar_factor_f64(const float* d_accum, const void* d_S, int64_t n_groups, int64_t n_freq_accum,
+extern "C" int sc_mvar_factor_f64(const void* d_accum, const void* d_S, int64_t n_groups, int64_t n_freq_accum,
                                   int64_t N, int64_t C, uint32_t planes, int64_t n_obs, double tol, int max_iter,
                                   void* d_work, size_t work_bytes, void* d_G, int32_t* d_n_iter, int32_t* d_status,
                                   int32_t* h_summary, void* stream) {
+    ScTimed timed_("mvar_factor", stream);
     SC_REQUIRE((d_accum != nullptr) != (d_S != nullptr), "pass exactly one of d_accum and d_S");
     SC_REQUIRE(d_work && d_G && d_n_iter && d_status, "NULL argument");
     SC_REQUIRE(n_groups >= 1 && n_groups <= 65535 && N >= 2 && N <= 1 << 24, "bad problem size");
@@ -562,7 +563,7 @@ extern "C" int sc_mvar_factor_f64(const float* d_accum, const void* d_S, int64_t
         d.two_sided = (n_freq_accum == N && N > 1) ? 1 : 0;
         d.floats_per_bin = (int64_t)sc_plane_count(planes) * d.n_tiles * SC_TILE_ELEMS;
         d.n_obs = (double)n_obs;
-        hipLaunchKernelGGL(m_build, gridE, dim3(256), 0, st, d_accum, d, S);
+        hipLaunchKernelGGL(m_build, gridE, dim3(256), 0, st, sc_rec(d_accum, planes), d, S);
     } else {
         hipLaunchKernelGGL(m_to_series, gridE, dim3(256), 0, st, (const cd*)d_S, S, N, E);
     }
@@ -637,6 +638,7 @@ done:
 //   SC_MVAR_NOISE_COVARIANCE : double [P][C][C]
 extern "C" int sc_mvar_measure_f64(const void* d_G, int64_t n_groups, int64_t N, int64_t C, int which, void* d_out,
                                    void* d_work, size_t work_bytes, void* stream) {
+    ScTimed timed_("mvar_measure", stream);
     SC_REQUIRE(d_G && d_out && d_work, "NULL argument");
     SC_REQUIRE(which >= SC_MVAR_DTF && which <= SC_MVAR_NOISE_COVARIANCE, "unknown MVAR quantity");
     if (C < 1 || C > MV_CMAX) {

@@ -188,6 +188,7 @@ static int dispatch_nl(const NlArgs& a, bool vec, hipStream_t stream) {
 
 extern "C" int sc_nonlinear_accumulate_f32(const void* d_X, const sc_spectra_desc* desc, uint32_t planes,
                                            uint32_t which, float* d_accum, void* stream) {
+    ScTimed timed_("nonlinear_valu", stream);
     SC_REQUIRE(d_X && desc && d_accum, "NULL argument");
     const uint32_t nl_mask = SC_PLANE_ABS_IM | SC_PLANE_IM_SQ | SC_PLANE_SIGN_IM | SC_PLANE_UNIT;
     SC_REQUIRE((which & ~nl_mask) == 0 && which != 0, "which must name non-linear planes only");

@@ -11,13 +11,15 @@
 // its strided plans (time-major y) spend 8x the transform's own time in gather / scatter kernels.
 #include "sc_common.h"
 
+// T = float (f32 engine) or double (f64 engine: the reference's own arithmetic, transforms.py:1377-1405)
+template <typename T>
 __global__ void __launch_bounds__(256)
-taper_windows_kernel(const float* __restrict__ x, float* __restrict__ y,
-                     const float* __restrict__ tapers, int64_t RC, int C, int K, int L, int step,
+taper_windows_kernel(const T* __restrict__ x, T* __restrict__ y,
+                     const T* __restrict__ tapers, int64_t RC, int C, int K, int L, int step,
                      int W, int N, int detrend) {
     __shared__ double s_sum[4][64];
     __shared__ double s_sumt[4][64];
-    __shared__ float tile[64][65];
+    __shared__ T tile[64][65];
     const int lane = threadIdx.x & 63;
     const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave id: slice of L
     const int w = blockIdx.y;
@@ -25,7 +27,7 @@ taper_windows_kernel(const float* __restrict__ x, float* __restrict__ y,
     const int64_t rc = rc0 + lane;
     const bool live = rc < RC;
     const int lq0 = (int)(((int64_t)L * q) / 4), lq1 = (int)(((int64_t)L * (q + 1)) / 4);
-    const float* xw = x + (int64_t)w * step * RC + (live ? rc : 0);
+    const T* xw = x + (int64_t)w * step * RC + (live ? rc : 0);
 
     double a = 0.0, b = 0.0;  // trend = a * t_l + b, t_l = (l+1)/L
     if (detrend != SC_DETREND_NONE) {
@@ -61,10 +63,10 @@ taper_windows_kernel(const float* __restrict__ x, float* __restrict__ y,
 #pragma unroll 4
         for (int j = 0; j < 16; ++j) {
             const int l = l0 + q * 16 + j;
-            float v = 0.0f;                                   // zero padding nmax <= n < N
+            T v = (T)0;                                       // zero padding nmax <= n < N
             if (live && l < nmax) {
                 const double t = (double)(l + 1) * invL;
-                v = (float)((double)xw[(int64_t)l * RC] - (a * t + b));
+                v = (T)((double)xw[(int64_t)l * RC] - (a * t + b));
             }
             tile[q * 16 + j][lane] = v;
         }
@@ -73,7 +75,7 @@ taper_windows_kernel(const float* __restrict__ x, float* __restrict__ y,
         const int n = l0 + lane;
         if (n < N) {
             for (int k = 0; k < K; ++k) {
-                const float h = (n < nmax) ? tapers[(int64_t)k * L + n] : 0.0f;
+                const T h = (n < nmax) ? tapers[(int64_t)k * L + n] : (T)0;
                 for (int jc = 0; jc < 16; ++jc) {
                     const int col = q * 16 + jc;
                     const int64_t rcc = rc0 + col;
@@ -87,9 +89,11 @@ taper_windows_kernel(const float* __restrict__ x, float* __restrict__ y,
     }
 }
 
-extern "C" int sc_taper_windows_f32(const float* d_x, int64_t T, int64_t R, int64_t C, int64_t L,
-                                    int64_t step, int64_t W, int64_t N, const float* d_tapers,
-                                    int64_t K, int detrend_type, float* d_y, void* stream) {
+template <typename Real>
+static int taper_windows(const Real* d_x, int64_t T, int64_t R, int64_t C, int64_t L,
+                         int64_t step, int64_t W, int64_t N, const Real* d_tapers,
+                         int64_t K, int detrend_type, Real* d_y, void* stream) {
+    ScTimed timed_("taper_windows", stream);
     SC_REQUIRE(d_x && d_tapers && d_y, "NULL device pointer");
     SC_REQUIRE(T >= 1 && R >= 1 && C >= 1 && L >= 1 && step >= 1 && W >= 1 && N >= 1 && K >= 1,
                "dimensions must be positive");
@@ -98,8 +102,20 @@ extern "C" int sc_taper_windows_f32(const float* d_x, int64_t T, int64_t R, int6
     SC_REQUIRE(W <= 65535, "too many windows for one launch");
     const int64_t RC = R * C;
     dim3 grid((unsigned)((RC + 63) / 64), (unsigned)W);
-    hipLaunchKernelGGL(taper_windows_kernel, grid, dim3(256), 0, (hipStream_t)stream, d_x, d_y,
+    hipLaunchKernelGGL(taper_windows_kernel<Real>, grid, dim3(256), 0, (hipStream_t)stream, d_x, d_y,
                        d_tapers, RC, (int)C, (int)K, (int)L, (int)step, (int)W, (int)N, detrend_type);
     SC_CHECK_HIP(hipGetLastError());
     return SC_OK;
+}
+
+extern "C" int sc_taper_windows_f32(const float* d_x, int64_t T, int64_t R, int64_t C, int64_t L,
+                                    int64_t step, int64_t W, int64_t N, const float* d_tapers,
+                                    int64_t K, int detrend_type, float* d_y, void* stream) {
+    return taper_windows<float>(d_x, T, R, C, L, step, W, N, d_tapers, K, detrend_type, d_y, stream);
+}
+
+extern "C" int sc_taper_windows_f64(const double* d_x, int64_t T, int64_t R, int64_t C, int64_t L,
+                                    int64_t step, int64_t W, int64_t N, const double* d_tapers,
+                                    int64_t K, int detrend_type, double* d_y, void* stream) {
+    return taper_windows<double>(d_x, T, R, C, L, step, W, N, d_tapers, K, detrend_type, d_y, stream);
 }

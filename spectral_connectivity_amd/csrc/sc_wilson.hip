@@ -50,7 +50,7 @@ struct WilsonDims {
     double n_obs;
 };
 
-__device__ inline float acc_read(const float* rec, int plane, int n_tiles, int NB, int i, int j, bool* mirrored) {
+__device__ inline double acc_read(ScRec rec, int plane, int n_tiles, int NB, int i, int j, bool* mirrored) {
     int ti = i >> 4, tj = j >> 4, ii = i & 15, jj = j & 15;
     const bool m = (ti > tj) || (ti == tj && ii > jj);
     if (m) { int t = ti; ti = tj; tj = t; t = ii; ii = jj; jj = t; }
@@ -58,7 +58,7 @@ __device__ inline float acc_read(const float* rec, int plane, int n_tiles, int N
     return rec[((int64_t)plane * n_tiles + sc_tile_index(ti, tj, NB)) * SC_TILE_ELEMS + ii * 16 + jj];
 }
 
-__global__ void k_build(const float* accum, const int32_t* pairs, WilsonDims d, double* S) {
+__global__ void k_build(ScRec accum, const int32_t* pairs, WilsonDims d, double* S) {
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t p = wilson_problem();
     if (n >= d.N || p >= d.P) return;
@@ -67,7 +67,7 @@ __global__ void k_build(const float* accum, const int32_t* pairs, WilsonDims d, 
     int64_t bin = n;
     bool conj = false;
     if (!d.two_sided && n > d.N / 2) { bin = d.N - n; conj = true; }   // real input: S(-f) = conj S(f)
-    const float* rec = accum + (g * d.F + bin) * d.floats_per_bin;
+    const ScRec rec = accum + (g * d.F + bin) * d.floats_per_bin;
     bool m, mm;
     const double s00 = (double)acc_read(rec, d.p_csm, d.n_tiles, d.NB, i, i, &mm) / d.n_obs;
     const double s11 = (double)acc_read(rec, d.p_csm, d.n_tiles, d.NB, j, j, &mm) / d.n_obs;
@@ -435,11 +435,12 @@ done:
     return rc;
 }
 
-extern "C" int sc_granger_pairwise_f64(const float* d_accum, int64_t n_groups, int64_t n_freq_accum,
+extern "C" int sc_granger_pairwise_f64(const void* d_accum, int64_t n_groups, int64_t n_freq_accum,
                                        int64_t N, int64_t C, uint32_t planes, int64_t n_obs,
                                        const int32_t* d_pairs, int64_t n_pairs, double tol, int max_iter,
                                        void* d_work, size_t work_bytes, int flags, double* d_out, int32_t* d_n_iter,
                                        int32_t* d_status, int32_t* h_summary, void* stream) {
+    ScTimed timed_("granger_pairwise", stream);
     SC_REQUIRE(d_accum && d_pairs && d_work && d_out && d_n_iter && d_status, "NULL argument");
     SC_REQUIRE(planes & SC_PLANE_CSM, "accumulator record must contain SC_PLANE_CSM");
     SC_REQUIRE(n_freq_accum == N || n_freq_accum == N / 2 + 1, "accumulators must hold N or N/2+1 bins");
@@ -461,7 +462,7 @@ extern "C" int sc_granger_pairwise_f64(const float* d_accum, int64_t n_groups, i
     if (!(flags & SC_GRANGER_KEEP_OUTPUT))
         hipLaunchKernelGGL(k_fill_nan, dim3((unsigned)((n_groups * Fout * C * C + 255) / 256)), dim3(256), 0, st, d_out,
                            n_groups * Fout * C * C);
-    hipLaunchKernelGGL(k_build, gridN, dim3(256), 0, st, d_accum, d_pairs, d, k.S);
+    hipLaunchKernelGGL(k_build, gridN, dim3(256), 0, st, sc_rec(d_accum, planes), d_pairs, d, k.S);
     int iters = 0, running = 0, fallback = 0;
     const int rc = wilson_iterate(k, P, N, tol, max_iter, d_n_iter, d_status, &iters, &running, &fallback, st);
     if (rc != SC_OK) return rc;
@@ -483,6 +484,7 @@ extern "C" int sc_granger_pairwise_f64(const float* d_accum, int64_t n_groups, i
 extern "C" int sc_wilson_factor_f64(const double* d_S, int64_t n_problems, int64_t N, double tol, int max_iter,
                                     void* d_work, size_t work_bytes, void* d_G, int32_t* d_n_iter,
                                     int32_t* d_status, int32_t* h_summary, void* stream) {
+    ScTimed timed_("wilson_factor", stream);
     SC_REQUIRE(d_S && d_work && d_G && d_n_iter && d_status, "NULL argument");
     SC_REQUIRE(n_problems >= 1 && n_problems <= (int64_t)WILSON_PMAX * WILSON_PMAX && N >= 2, "bad problem size");
     size_t need = 0;

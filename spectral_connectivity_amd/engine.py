@@ -23,7 +23,10 @@ EXPECTATION_AXES = {
     "time_trials_tapers": (0, 1, 2),
 }
 
-_plan_cache = {}
+import collections
+
+_plan_cache = collections.OrderedDict()     # (N, batch, device, f64) -> sc_fft_plan handle, least recently used first
+PLAN_CACHE_SIZE = 4                          # every plan owns a rocFFT work buffer and up to 64 MB of transform scratch
 _twiddle_cache = {}
 
 
@@ -52,21 +55,31 @@ def to_host(t):
     return t.cpu().numpy()
 
 
-def fft_plan(n_fft, batch):
-    """rocFFT real-forward plan: rows [batch][N] in, frequency-major [F][batch] out (cached per (N, batch, device))."""
-    key = (int(n_fft), int(batch), torch.cuda.current_device())
+def fft_plan(n_fft, batch, f64=False):
+    """rocFFT real-forward plan: rows [batch][N] in, frequency-major [F][batch] out.  A small LRU keeps the plans of
+    the last few (N, batch, device, precision) shapes; an evicted plan is destroyed after the device has drained (its
+    scratch may still be in use by queued work), so a sweep over window lengths does not pile up plan buffers."""
+    key = (int(n_fft), int(batch), torch.cuda.current_device(), bool(f64))
     plan = _plan_cache.get(key)
-    if plan is None:
-        lib = _lib.load()
-        handle = c_void_p()
-        _lib.check(lib.sc_fft_plan_create(byref(handle), n_fft, batch), "sc_fft_plan_create")
-        plan = handle
-        _plan_cache[key] = plan
-    return plan
+    if plan is not None:
+        _plan_cache.move_to_end(key)
+        return plan
+    lib = _lib.load()
+    while len(_plan_cache) >= PLAN_CACHE_SIZE:
+        _, old = _plan_cache.popitem(last=False)
+        torch.cuda.synchronize()
+        lib.sc_fft_plan_destroy(old)
+    handle = c_void_p()
+    create = lib.sc_fft_plan_create_f64 if f64 else lib.sc_fft_plan_create
+    _lib.check(create(byref(handle), n_fft, batch), "sc_fft_plan_create")
+    _plan_cache[key] = handle
+    return handle
 
 
 def clear_plan_cache():
     lib = _lib.load()
+    if _plan_cache:
+        torch.cuda.synchronize()
     for plan in _plan_cache.values():
         lib.sc_fft_plan_destroy(plan)
     _plan_cache.clear()
@@ -75,7 +88,8 @@ def clear_plan_cache():
 class DeviceSpectra:
     """One-sided (or caller-described) Fourier coefficients resident in HBM.
 
-    ``X`` is a complex64 tensor; ``dims`` = (F, W, R, K, C) logical sizes and ``strides`` =
+    ``X`` is a complex64 tensor (float32 engine) or a complex128 tensor (float64 engine, ``f64``: no pad channel,
+    every consumer takes the fp64 kernels of sc_f64.hip); ``dims`` = (F, W, R, K, C) logical sizes and ``strides`` =
     element strides of (freq, window, trial, taper) -- channel stride is 1.  ``C_alloc`` >= C channels are
     stored per row: an odd channel count gets one all-zero channel appended, so that rows stay 16-byte
     aligned and the one-pass stage-B kernels (even channel counts) apply; a record accumulated over C_alloc
@@ -90,6 +104,7 @@ class DeviceSpectra:
         self.strides = tuple(int(s) for s in strides)
         self.n_fft = int(n_fft)
         self.real_input = bool(real_input)   # negative bins are conj mirrors of positive ones
+        self.f64 = X.dtype == torch.complex128
 
     def coefficients(self):
         """The spectra as a (F, W, R, K, C) tensor view of a contiguous X (the zero pad channel dropped)."""
@@ -168,10 +183,38 @@ def multitaper_spectra(x, tapers_over_fs, n_window, n_step, n_fft, n_windows, de
     return DeviceSpectra(X, (F, n_windows, R, K, C_real), strides, n_fft, real_input=True, C_alloc=C)
 
 
-def upload_coefficients(coef, device="cuda"):
+def multitaper_spectra_f64(x, tapers_over_fs, n_window, n_step, n_fft, n_windows, detrend_type, mark=None):
+    """Stage A of the float64 engine: (T,R,C) float64 tensor -> complex128 DeviceSpectra [F][W][R][K][C]
+    (sc_taper_windows_f64 + double-precision rocFFT + transpose; any window / FFT length)."""
+    lib = _lib.load()
+    T, R, C = x.shape
+    K, L = tapers_over_fs.shape
+    assert L == n_window and x.dtype == torch.float64 and tapers_over_fs.dtype == torch.float64
+    F = n_fft // 2 + 1
+    strides = (n_windows * R * K * C, R * K * C, K * C, C)
+    batch = n_windows * R * K * C
+    y = torch.empty((batch, n_fft), dtype=torch.float64, device=x.device)
+    _lib.check(lib.sc_taper_windows_f64(_ptr(x), T, R, C, L, n_step, n_windows, n_fft, _ptr(tapers_over_fs), K,
+                                        _lib.DETREND[detrend_type], _ptr(y), _stream()), "sc_taper_windows_f64")
+    if mark:
+        mark("taper_windows_f64")
+    X = torch.empty((F, n_windows, R, K, C), dtype=torch.complex128, device=x.device)
+    _lib.check(lib.sc_fft_execute_f64(fft_plan(n_fft, batch, f64=True), _ptr(y), _ptr(X), _stream()),
+               "sc_fft_execute_f64")
+    if mark:
+        mark("rocfft_d2z")
+    del y
+    return DeviceSpectra(X, (F, n_windows, R, K, C), strides, n_fft, real_input=True)
+
+
+def upload_coefficients(coef, device="cuda", f64=False):
     """Reference-layout (W,R,K,N,C) complex coefficients -> DeviceSpectra (all N bins, as given)."""
     coef = np.asarray(coef)
     W, R, K, N, C_real = coef.shape
+    if f64:
+        X = torch.from_numpy(np.ascontiguousarray(coef, dtype=np.complex128)).to(device)
+        return DeviceSpectra(X, (N, W, R, K, C_real), (C_real, R * K * N * C_real, K * N * C_real, N * C_real), N,
+                             real_input=False)
     coef = np.ascontiguousarray(coef, dtype=np.complex64)
     if C_real % 2 and C_real + 1 <= 128:
         coef = np.concatenate([coef, np.zeros(coef.shape[:-1] + (1,), dtype=np.complex64)], axis=-1)
@@ -209,6 +252,14 @@ def accumulate(spectra, expectation_type, planes, n_freq=None, mark=None, use_fu
     lib = _lib.load()
     d = spectra.desc(expectation_type, n_freq)
     n_bins, fpb, _, n_obs = accum_layout(spectra, expectation_type, planes, n_freq)
+    if spectra.f64:
+        # float64 engine: fp64 matrix cores for the CSM planes, fp64 VALU for the others, double records
+        accum = torch.empty((n_bins, fpb), dtype=torch.float64, device=spectra.X.device)
+        _lib.check(lib.sc_accumulate_f64(_ptr(spectra.X), byref(d), planes, planes, _ptr(accum), _stream()),
+                   "sc_accumulate_f64")
+        if mark:
+            mark("accumulate_f64")
+        return accum, n_obs
     accum = torch.empty((n_bins, fpb), dtype=torch.float32, device=spectra.X.device)
     per_plane_only = use_fused is False        # explicit request (tests): every plane through its separate kernel
     if use_fused is None:
@@ -273,21 +324,31 @@ def accumulate(spectra, expectation_type, planes, n_freq=None, mark=None, use_fu
     return accum, n_obs
 
 
-def measure(accum, n_signals, planes, n_obs, which, out=None):
-    """Stage C: one measure from an accumulator tensor (after any cross-GPU sum)."""
+def rec_planes(accum, planes):
+    """`planes` as the consumers of a record tensor want it: with SC_RECORD_F64 when the records are doubles."""
+    return (planes | _lib.RECORD_F64) if accum.dtype == torch.float64 else (planes & ~_lib.RECORD_F64)
+
+
+def measure(accum, n_signals, planes, n_obs, which, out=None, wide=None):
+    """Stage C: one measure from an accumulator tensor (after any cross-GPU sum).  ``wide``: write float64 /
+    complex128 (what the reference returns) straight from the epilogue; default: wide for double records."""
     lib = _lib.load()
     n_bins = accum.shape[0]
     C = n_signals
+    if wide is None:
+        wide = accum.dtype == torch.float64
+    real_t, cplx_t = (torch.float64, torch.complex128) if wide else (torch.float32, torch.complex64)
     if which == _lib.M_POWER:
-        shape, dtype = (n_bins, C), torch.float32
+        shape, dtype = (n_bins, C), real_t
     elif which in _lib.COMPLEX_MEASURES:
-        shape, dtype = (n_bins, C, C), torch.complex64
+        shape, dtype = (n_bins, C, C), cplx_t
     else:
-        shape, dtype = (n_bins, C, C), torch.float32
+        shape, dtype = (n_bins, C, C), real_t
     if out is None:
         out = torch.empty(shape, dtype=dtype, device=accum.device)
-    _lib.check(lib.sc_measure_f32(_ptr(accum), n_bins, C, planes, n_obs, which, _ptr(out), _stream()),
-               "sc_measure_f32")
+    fn = lib.sc_measure_f64 if wide else lib.sc_measure_f32
+    _lib.check(fn(_ptr(accum), n_bins, C, rec_planes(accum, planes), n_obs, which, _ptr(out), _stream()),
+               "sc_measure")
     return out
 
 
@@ -320,7 +381,8 @@ def granger_pairwise(accum, n_groups, n_freq_accum, n_fft, n_signals, planes, n_
         it_c = torch.empty((n_groups * n,), dtype=torch.int32, device=dev)
         st_c = torch.empty((n_groups * n,), dtype=torch.int32, device=dev)
         summary = (ctypes.c_int32 * 3)(0, 0, 0)
-        _lib.check(lib.sc_granger_pairwise_f64(_ptr(accum), n_groups, n_freq_accum, n_fft, n_signals, planes, n_obs,
+        _lib.check(lib.sc_granger_pairwise_f64(_ptr(accum), n_groups, n_freq_accum, n_fft, n_signals,
+                                               rec_planes(accum, planes), n_obs,
                                                _ptr(pairs_t), n, tolerance, max_iterations, _ptr(work), nbytes.value,
                                                _lib.GRANGER_KEEP_OUTPUT if p0 else 0, _ptr(out), _ptr(it_c),
                                                _ptr(st_c), summary, _stream()), "sc_granger_pairwise_f64")
@@ -353,7 +415,8 @@ def mvar_factor(n_groups, n_fft, n_signals, accum=None, n_freq_accum=0, planes=0
     summary = (ctypes.c_int32 * 2)(0, 0)
     _lib.check(lib.sc_mvar_factor_f64(_ptr(accum) if accum is not None else None,
                                       _ptr(spectra) if spectra is not None else None, n_groups, n_freq_accum, n_fft,
-                                      n_signals, planes, n_obs, tolerance, max_iterations, _ptr(work), nbytes, _ptr(G),
+                                      n_signals, rec_planes(accum, planes) if accum is not None else planes, n_obs,
+                                      tolerance, max_iterations, _ptr(work), nbytes, _ptr(G),
                                       _ptr(n_iter), _ptr(status), summary, _stream()), "sc_mvar_factor_f64")
     return G, n_iter, status, (summary[0], summary[1])
 
@@ -381,7 +444,8 @@ def global_coherence(accum, n_groups, n_freq_accum, n_fft, n_signals, planes, n_
     dev = accum.device
     values = torch.empty((n_groups, n_fft, max_rank), dtype=torch.float64, device=dev)
     vectors = torch.empty((n_groups, n_fft, n_signals, max_rank), dtype=torch.complex128, device=dev)
-    _lib.check(lib.sc_global_coherence_f64(_ptr(accum), n_groups, n_freq_accum, n_fft, n_signals, planes, n_obs,
+    _lib.check(lib.sc_global_coherence_f64(_ptr(accum), n_groups, n_freq_accum, n_fft, n_signals,
+                                           rec_planes(accum, planes), n_obs,
                                            max_rank, int(ascending), _ptr(values), _ptr(vectors), _stream()),
                "sc_global_coherence_f64")
     return values, vectors
@@ -402,7 +466,8 @@ def canonical_coherence(accum, n_signals, planes, n_obs, groups):
     n_bins = accum.shape[0]
     out = torch.empty((n_bins, G, G), dtype=torch.float64, device=dev)
     fail = torch.zeros((1,), dtype=torch.int32, device=dev)
-    _lib.check(lib.sc_canonical_coherence_f64(_ptr(accum), n_bins, n_signals, planes, n_obs, _ptr(members_t),
+    _lib.check(lib.sc_canonical_coherence_f64(_ptr(accum), n_bins, n_signals, rec_planes(accum, planes), n_obs,
+                                              _ptr(members_t),
                                               _ptr(sizes_t), G, int(cmax), _ptr(out), _ptr(fail), _stream()),
                "sc_canonical_coherence_f64")
     return out, int(fail.item())

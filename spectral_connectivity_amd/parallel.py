@@ -108,7 +108,8 @@ def _side_stream(device):
     return _side_streams[key]
 
 
-def sharded_measures(spectra, planes, which, n_groups=4, dst=0, group=None, mark=None, equal_shards=False):
+def sharded_measures(spectra, planes, which, n_groups=4, dst=0, group=None, mark=None, equal_shards=False,
+                     timing=None):
     """Stage B + exchange + epilogue for trial-sharded spectra, pipelined over frequency groups.
 
     Every rank holds the spectra of ITS trials.  The frequency axis is cut into ``n_groups`` ranges; for
@@ -119,6 +120,10 @@ def sharded_measures(spectra, planes, which, n_groups=4, dst=0, group=None, mark
     ``dst``, one tensor per measure shaped [n_windows, n_freq, C, C] (None on the other ranks).
     ``equal_shards``: every rank holds the same number of trials, so n_observations = local count x world
     without a collective (otherwise one small all-reduce per call).
+    ``timing``: a list; one dict per call is appended with ``collective_ms`` (time inside reduce-scatter and gather on
+    the exchange stream), ``exposed_ms`` (what the launch stream waited for after its last accumulation: the part of
+    exchange + epilogue that did not hide behind stage B), ``bytes_reduced`` and ``n_groups`` -- read after the next
+    device synchronisation (the values are filled in lazily from events).
     """
     from . import engine
     world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
@@ -130,6 +135,13 @@ def sharded_measures(spectra, planes, which, n_groups=4, dst=0, group=None, mark
     parts = [[] for _ in which]
     n_local = spectra.R * spectra.K
     n_total = total_observations_equal(n_local, world) if equal_shards else total_observations(n_local, group)
+    coll_events, bytes_reduced = [], 0
+
+    def ev(stream):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(stream)
+        return e
+
     for g in range(n_groups):
         f0, f1 = shard_bounds(F, n_groups, g)
         accum, n_obs = engine.accumulate(spectra.freq_slice(f0, f1), "trials_tapers", planes, mark=mark)
@@ -141,17 +153,28 @@ def sharded_measures(spectra, planes, which, n_groups=4, dst=0, group=None, mark
         with torch.cuda.stream(side):
             if world > 1:
                 side.wait_event(ready)
+            t0 = ev(side) if timing is not None else None
             shard, lo, hi = reduce_scatter_bins(accum, group)
+            if timing is not None:
+                coll_events.append((t0, ev(side)))
+                bytes_reduced += accum.numel() * accum.element_size()
             for m, w in enumerate(which):
                 out = engine.measure(shard, C, planes, n_total, w)
                 if world > 1:
+                    t0 = ev(side) if timing is not None else None
                     out = gather_bins(out, n_bins, dst=dst, group=group)
+                    if timing is not None:
+                        coll_events.append((t0, ev(side)))
                 if out is not None:
                     parts[m].append(out.reshape(W, f1 - f0, *out.shape[1:]))
+    tail0 = ev(main) if timing is not None else None
     if world > 1:
         main.wait_stream(side)
     if mark:
         mark("exchange_epilogue_tail")
+    if timing is not None:
+        tail1 = ev(main)
+        timing.append(_LazyExchangeTiming(coll_events, tail0, tail1, bytes_reduced, n_groups))
     if rank != dst:
         return [None for _ in which]
     result = []
@@ -163,6 +186,172 @@ def sharded_measures(spectra, planes, which, n_groups=4, dst=0, group=None, mark
     return result
 
 
+class _LazyExchangeTiming(dict):
+    """Exchange breakout of one sharded_measures call; the event arithmetic happens on first access (after a sync)."""
+
+    def __init__(self, coll_events, tail0, tail1, bytes_reduced, n_groups):
+        super().__init__(bytes_reduced=bytes_reduced, n_groups=n_groups)
+        self._pending = (coll_events, tail0, tail1)
+
+    def __missing__(self, key):
+        coll_events, tail0, tail1 = self._pending
+        tail1.synchronize()
+        self["collective_ms"] = float(sum(a.elapsed_time(b) for a, b in coll_events))
+        self["exposed_ms"] = float(tail0.elapsed_time(tail1))
+        return self[key]
+
+
 def total_observations_equal(local_n_obs, world):
     """n_observations of the job when every rank holds the same number of trials (no collective needed)."""
     return int(local_n_obs) * int(world)
+
+
+# ---- a Connectivity whose trials live on several GPUs ------------------------------------------------------
+def all_reduce_sum_(t, group=None):
+    """In-place sum over ranks (gloo moves device tensors through the host)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return t
+    if dist.get_backend(group) == "gloo" and t.is_cuda:
+        host = t.cpu()
+        dist.all_reduce(host, group=group)
+        t.copy_(host)
+    else:
+        dist.all_reduce(t, group=group)
+    return t
+
+
+def merge_disjoint(values, group=None):
+    """Every rank filled a DISJOINT subset of the entries of a float64 array and left NaN elsewhere (channel pairs of
+    the Granger prediction dealt out over the ranks): the union on every rank, NaN where nobody wrote.  One sum of the
+    NaN-cleared values and one of the written-flags."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return values
+    written = ~torch.isnan(values)
+    vals = torch.where(written, values, torch.zeros_like(values))
+    count = written.to(values.dtype)
+    all_reduce_sum_(vals, group)
+    all_reduce_sum_(count, group)
+    return torch.where(count > 0, vals, torch.full_like(vals, float("nan")))
+
+
+def deal(items, world_size, rank):
+    """Round-robin share of a work list (pairs, (bin, group pair) tasks): cost per item is uniform, and a round-robin
+    deal needs no knowledge of the list's length on the other ranks."""
+    return items[rank::world_size]
+
+
+def _connectivity_base():
+    from .connectivity import Connectivity
+    return Connectivity
+
+
+class ShardedConnectivity(_connectivity_base()):
+    """``Connectivity`` over trials that are spread across the GPUs of a node.
+
+    Every rank (one process per GPU, ``torch.distributed`` initialised, backend ``nccl`` = RCCL) builds it from ITS
+    trials -- ``ShardedConnectivity.from_multitaper(Multitaper(x[:, lo:hi]))`` with ``lo, hi = shard_bounds(R, world,
+    rank)`` -- and calls the measures collectively; every rank gets the full result.
+
+    * expectation measures (power ... pairwise_phase_consistency): local un-normalised records -> reduce-scatter
+      over bins -> epilogue on the owned 1/N of the bins with the job-wide n_observations -> all-gather;
+    * pairwise spectral Granger: records all-reduced once, the channel pairs dealt out over the ranks, each rank
+      factorises its pairs, one merge of the disjoint outputs;
+    * canonical coherence: records all-reduced once, the bins split over the ranks, all-gather of the owned bins;
+    * the full Wilson factor / MVAR measures and global coherence: records all-reduced, then computed redundantly
+      (one C x C problem per window: nothing to deal out below the window count).
+
+    ``expectation_type`` must average over trials ("trials", "time_trials", "trials_tapers",
+    "time_trials_tapers"): a kept trial axis would make the output itself sharded.
+    """
+
+    def __init__(self, *args, process_group=None, **kwargs):
+        super().__init__(*args, **kwargs)
+        if "trials" not in self.expectation_type.split("_"):
+            raise ValueError("ShardedConnectivity shards the trials: expectation_type must average over them "
+                             f"(got {self.expectation_type!r})")
+        self._group = process_group
+        self._world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self._rank = dist.get_rank(process_group) if self._world > 1 else 0
+        self._sharded_cache = {}
+
+    @classmethod
+    def from_multitaper(cls, multitaper_instance, expectation_type="trials_tapers", blocks=None, dtype=None,
+                        process_group=None):
+        import numpy as np
+        obj = cls(multitaper_instance.device_spectra(), expectation_type=expectation_type,
+                  time=multitaper_instance.time, frequencies=multitaper_instance.frequencies, blocks=blocks,
+                  dtype=np.complex128 if dtype is None else dtype, process_group=process_group)
+        obj._multitaper = multitaper_instance
+        return obj
+
+    @property
+    def n_observations(self):
+        """Of the whole job (reference connectivity.py:594-610 over all trials)."""
+        return self._n_observations_total(super().n_observations)
+
+    def _n_observations_total(self, local_n_obs):
+        if "n_total" not in self._sharded_cache:
+            self._sharded_cache["n_total"] = total_observations(local_n_obs, self._group)
+        return self._sharded_cache["n_total"]
+
+    def _reduce_over_ranks(self, accum):
+        """Replicated sum of the records (Granger, canonical, MVAR, global coherence read every bin)."""
+        return all_reduce_sum_(accum, self._group)
+
+    def _measure(self, which):
+        """Reduce-scatter over bins, epilogue on the owned bins, all-gather; the scattered shard is kept per plane
+        set, so several measures share one exchange."""
+        from . import _lib, engine
+        planes = _lib.MEASURE_PLANES[which]
+        key = None
+        for have in self._sharded_cache:
+            if isinstance(have, int) and have & planes == planes:
+                key = have
+                break
+        if key is None:
+            sp = self._device()
+            accum, n_obs = engine.accumulate(sp, self.expectation_type, planes, n_freq=self._n_freq)
+            shard, lo, hi = reduce_scatter_bins(accum, self._group)
+            key = planes
+            self._sharded_cache[key] = (shard, accum.shape[0], self._n_observations_total(n_obs))
+        shard, n_bins, n_total = self._sharded_cache[key]
+        C = self._shape5[4]
+        out = all_gather_bins(engine.measure(shard, C, key, n_total, which, wide=True), n_bins, self._group)
+        tail = (C,) if which == _lib.M_POWER else (C, C)
+        return engine.to_host(out).reshape(self._kept_shape() + (self._n_freq,) + tail)
+
+    def _granger(self, pairs):
+        """This rank's share of the pairs, then one merge of the disjoint outputs."""
+        import numpy as np
+        accum, _, n_freq = self._csm_records("granger")          # collective: every rank takes part, pairs or not
+        mine = deal(np.asarray(pairs, dtype=np.int32).reshape(-1, 2), self._world, self._rank)
+        N, C = self._shape5[3], self._shape5[4]
+        if len(mine):
+            out = self._granger_device(mine)
+        else:
+            out = torch.full((accum.shape[0] // n_freq, N // 2 + 1, C, C), float("nan"), dtype=torch.float64,
+                             device=accum.device)
+        merged = merge_disjoint(out, self._group)
+        return engine_to_host(merged).reshape(self._kept_shape() + (N // 2 + 1, C, C))
+
+    def _canonical_bins(self, n_bins):
+        """The bins this rank evaluates: a contiguous 1/N, padded so that every rank holds the same count."""
+        per = padded_bins(n_bins, self._world) // self._world
+        lo = min(self._rank * per, n_bins)
+        return lo, min(lo + per, n_bins), per
+
+    def _canonical_gather(self, part, n_bins, per):
+        if self._world == 1:
+            return part
+        if part.shape[0] < per:
+            pad = torch.full((per - part.shape[0],) + tuple(part.shape[1:]), float("nan"), dtype=part.dtype,
+                             device=part.device)
+            part = torch.cat([part, pad], dim=0)
+        if dist.get_backend(self._group) == "gloo" and part.is_cuda:
+            return all_gather_bins(part.cpu(), n_bins, self._group).to(part.device)
+        return all_gather_bins(part, n_bins, self._group)
+
+
+def engine_to_host(t):
+    from . import engine
+    return engine.to_host(t)

@@ -7,6 +7,7 @@ real FFT (rocFFT) -- runs on an MI355X through ``libsc_hip.so`` and the coeffici
 resident in HBM for ``Connectivity.from_multitaper``.  Host code here is parameter logic
 and the (tiny, once-per-object, float64) DPSS taper generation only.
 """
+import os
 import warnings
 from logging import getLogger
 from typing import TypedDict
@@ -17,6 +18,17 @@ from scipy.fft import fftfreq, ifft as _host_ifft, next_fast_len
 from scipy.linalg import eigh_tridiagonal
 
 logger = getLogger(__name__)
+
+# The reference's backend plug point (transforms.py:405-439): SPECTRAL_CONNECTIVITY_ENABLE_GPU == "true" asks for the
+# GPU backend at import time and a missing backend is a RuntimeError right here.  This package has one backend, the
+# HIP engine: "true" loads libsc_hip.so now (RuntimeError if that fails), unset loads it on first use, any other value
+# (the reference's NumPy path) is refused at the first computation (_lib.require_gpu).
+if os.environ.get("SPECTRAL_CONNECTIVITY_ENABLE_GPU") == "true":
+    from . import _lib as _hip_lib
+    _hip_lib.honour_gpu_switch()
+    logger.info("Using GPU for spectral_connectivity: HIP engine " + _hip_lib.library_path())
+else:
+    logger.info("spectral_connectivity_amd: the HIP engine loads on first use (no CPU backend)")
 
 MIN_EIGENVALUE_THRESHOLD = 0.9   # reference transforms.py:22
 TAPER_MULTIPLIER = 2.0           # reference transforms.py:30
@@ -481,35 +493,56 @@ class Multitaper:
         return self.sampling_frequency / 2
 
     # ---- device path ---------------------------------------------------------------------
-    def device_spectra(self, device=None):
-        """Run stage A on the GPU; returns (and caches) the HBM-resident one-sided spectra."""
+    def device_spectra(self, device=None, precision=None):
+        """Run stage A on the GPU; returns (and caches, per precision) the HBM-resident one-sided spectra.
+
+        ``precision``: "float32" -- the fused f32 transform of the headline path (complex64 spectra) -- or "float64" --
+        the reference's own arithmetic (float64 windows, tapers and FFT; complex128 spectra).  None: what
+        ``options.precision`` gives for a call without a dtype, i.e. float64 like the reference unless forced."""
+        from . import options
+        if precision is None:
+            precision = options.engine_precision(None)
         if self._device_spectra is None:
+            self._device_spectra = {}
+        if precision not in self._device_spectra:
             import torch
             from . import _lib, engine
             _lib.require_gpu()
             if self.detrend_type not in _lib.DETREND:
                 raise ValueError(f"Invalid trend type '{self.detrend_type}' is not supported.\n"
                                  "Valid options are 'linear'/'l', 'constant'/'c' or None.")
+            if np.iscomplexobj(self.time_series):
+                # the reference's generic fft takes complex series (transforms.py:1402-1405); the device transforms are
+                # real-input (one-sided spectra, conjugate-mirrored negative bins): refuse rather than drop Im x
+                raise TypeError("complex-valued time series are not supported by the HIP engine: its transforms are "
+                                "real-to-complex (one-sided spectra). Analyse the real and imaginary parts as separate "
+                                "signals, or use the reference package for analytic signals.")
             dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
-            x = torch.from_numpy(np.ascontiguousarray(self.time_series, dtype=np.float32)).to(dev)
             tapers = np.asarray(self.tapers, dtype=np.float64)             # (L, K), * sqrt(fs)
-            h = np.ascontiguousarray(tapers.T / self.sampling_frequency, dtype=np.float32)
-            h = torch.from_numpy(h).to(dev)
             logger.info(self)
-            self._device_spectra = engine.multitaper_spectra(
-                x, h, self.n_time_samples_per_window, self.n_time_samples_per_step,
-                self.n_fft_samples, self.n_time_windows, self.detrend_type)
-        return self._device_spectra
+            if precision == "float64":
+                x = torch.from_numpy(np.ascontiguousarray(self.time_series, dtype=np.float64)).to(dev)
+                h = torch.from_numpy(np.ascontiguousarray(tapers.T / self.sampling_frequency)).to(dev)
+                self._device_spectra[precision] = engine.multitaper_spectra_f64(
+                    x, h, self.n_time_samples_per_window, self.n_time_samples_per_step,
+                    self.n_fft_samples, self.n_time_windows, self.detrend_type)
+            else:
+                x = torch.from_numpy(np.ascontiguousarray(self.time_series, dtype=np.float32)).to(dev)
+                h = torch.from_numpy(np.ascontiguousarray(tapers.T / self.sampling_frequency, dtype=np.float32)).to(dev)
+                self._device_spectra[precision] = engine.multitaper_spectra(
+                    x, h, self.n_time_samples_per_window, self.n_time_samples_per_step,
+                    self.n_fft_samples, self.n_time_windows, self.detrend_type)
+        return self._device_spectra[precision]
 
     def fft(self):
         """Fourier coefficients (n_time_windows, n_trials, n_tapers, n_fft_samples, n_signals).
 
-        Drop-in for reference transforms.py:1147-1171: complex128, two-sided.  Computed on
-        the device as a one-sided real transform; the negative-frequency half is the
-        conjugate mirror (real input) and is filled on the host only for this export.
+        Drop-in for reference transforms.py:1147-1171: complex128, two-sided, computed in float64 on the device
+        (float32 if ``options.precision == "float32"``) as a one-sided real transform; the negative-frequency half is
+        the conjugate mirror (real input) and is filled on the host only for this export.
         """
         sp = self.device_spectra()
-        one = sp.coefficients().cpu().numpy().astype(np.complex128)          # (F, W, R, K, C)
+        one = sp.coefficients().cpu().numpy().astype(np.complex128, copy=False)          # (F, W, R, K, C)
         one = np.moveaxis(one, 0, 3)                            # (W, R, K, F, C)
         N = self.n_fft_samples
         out = np.empty(one.shape[:3] + (N, one.shape[-1]), dtype=np.complex128)

@@ -3,7 +3,9 @@
 
 def get_compute_backend():
     """Describe the compute backend: always the HIP engine (no CPU fallback exists)."""
-    info = {"backend": "hip", "gpu_enabled": True, "library": None, "gpu_available": False, "device_name": None,
+    import os
+    info = {"backend": "hip", "gpu_enabled": True, "gpu_switch": os.environ.get("SPECTRAL_CONNECTIVITY_ENABLE_GPU"),
+            "library": None, "gpu_available": False, "device_name": None,
             "n_devices": 0, "message": ""}            # keys of the reference's report + library / n_devices
     try:
         import torch

@@ -22,3 +22,15 @@ def load_golden(name):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+@pytest.fixture(autouse=True)
+def _engine_precision(request):
+    """Test modules exercise the float32 engine (the headline path, north_star's tolerance) unless they declare
+    ``SC_PRECISION``: tests/test_gpu_fp64.py runs with "dtype" -- the package default, where ``dtype=complex128`` (the
+    reference's default) selects the float64 engine."""
+    from spectral_connectivity_amd import options
+    old = options.precision
+    options.precision = getattr(request.module, "SC_PRECISION", "float32")
+    yield
+    options.precision = old

@@ -61,3 +61,29 @@ def test_no_cpu_fallback_without_gpu():
     m = Multitaper(np.zeros((64, 2, 2)), sampling_frequency=100)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m.fft()
+
+
+def test_gpu_switch_of_the_reference_is_honoured():
+    """SPECTRAL_CONNECTIVITY_ENABLE_GPU (reference transforms.py:405-439): "true" loads the HIP engine at import and a
+    library that cannot be loaded is a RuntimeError right there; any other value asks for the NumPy backend this
+    package does not have and is refused at the first computation; unset means load on first use."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(code, **env):
+        e = dict(os.environ, **env)
+        return subprocess.run([sys.executable, "-c", code], cwd=root, env=e, capture_output=True, text=True, timeout=300)
+
+    ok = run("import spectral_connectivity_amd, sys; from spectral_connectivity_amd import _lib; "
+             "print(_lib._lib is not None)", SPECTRAL_CONNECTIVITY_ENABLE_GPU="true")
+    assert ok.returncode == 0 and ok.stdout.strip().endswith("True"), ok.stderr[-2000:]
+    bad = run("import spectral_connectivity_amd", SPECTRAL_CONNECTIVITY_ENABLE_GPU="true",
+              SC_HIP_LIB="/nonexistent/libsc_hip.so")
+    assert bad.returncode != 0 and "explicitly requested via SPECTRAL_CONNECTIVITY_ENABLE_GPU='true'" in bad.stderr
+    cpu = run("import numpy as np, spectral_connectivity_amd as sc\n"
+              "m = sc.Multitaper(np.zeros((64, 1, 2)))\n"
+              "try:\n    m.fft()\nexcept RuntimeError as exc:\n    print('refused:', exc)\n",
+              SPECTRAL_CONNECTIVITY_ENABLE_GPU="false")
+    assert cpu.returncode == 0 and "refused:" in cpu.stdout and "NumPy backend" in cpu.stdout, cpu.stdout + cpu.stderr[-2000:]

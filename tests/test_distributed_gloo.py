@@ -79,7 +79,7 @@ def worker(rank, world, port, x, ref_rec, ref_power, errors):
         raise
 
 
-@pytest.mark.parametrize("world,R", [(2, 6), (2, 5)])
+@pytest.mark.parametrize("world,R", [(2, 6), (2, 5), (4, 7)])
 def test_trial_sharded_reduce_scatter_matches_single_process(world, R):
     sys.path.insert(0, ROOT)
     from oracle import spectral_oracle as so
@@ -116,3 +116,81 @@ def test_shard_bounds_cover_everything():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans[:-1], spans[1:]))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def merge_worker(rank, world, port, errors):
+    """Helpers of parallel.ShardedConnectivity on 4 gloo ranks: Granger pairs dealt out round-robin, every rank fills
+    ITS pairs of a NaN array, merge_disjoint returns the union everywhere; canonical-coherence bins split with padding
+    and gathered; the replicated sum of unequal record shards."""
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from spectral_connectivity_amd import parallel
+        C, F = 7, 5
+        pairs = np.array([(i, j) for i in range(C) for j in range(i + 1, C)], dtype=np.int32)     # 21 pairs over 4 ranks
+        mine = parallel.deal(pairs, world, rank)
+        assert len(mine) in (5, 6)
+        out = torch.full((2, F, C, C), float("nan"), dtype=torch.float64)
+        for i, j in mine:
+            out[:, :, i, j] = 100.0 * i + j + torch.arange(F, dtype=torch.float64)[None, :]
+            out[:, :, j, i] = -(100.0 * i + j)
+        merged = parallel.merge_disjoint(out).numpy()
+        ref = np.full((2, F, C, C), np.nan)
+        for i, j in pairs:
+            ref[:, :, i, j] = 100.0 * i + j + np.arange(F)[None, :]
+            ref[:, :, j, i] = -(100.0 * i + j)
+        np.testing.assert_array_equal(merged, ref)
+        # fewer items than ranks: some ranks get nothing and still take part in the collective
+        few = parallel.deal(pairs[:3], world, rank)
+        o2 = torch.full((1, 1, C, C), float("nan"), dtype=torch.float64)
+        for i, j in few:
+            o2[0, 0, i, j] = 1.0
+        m2 = parallel.merge_disjoint(o2).numpy()
+        assert np.nansum(m2) == 3.0 and np.isnan(m2).sum() == C * C - 3
+        # records of unequal shards add up on every rank
+        rec = torch.full((11, 8), float(rank + 1), dtype=torch.float32)
+        parallel.all_reduce_sum_(rec)
+        assert float(rec[0, 0]) == sum(range(1, world + 1))
+        # bins split 1/N with padding: 10 bins over 4 ranks -> 3, 3, 3, 1
+        n_bins = 10
+        per = parallel.padded_bins(n_bins, world) // world
+        lo = min(rank * per, n_bins)
+        hi = min(lo + per, n_bins)
+        part = torch.arange(lo, hi, dtype=torch.float64)[:, None].repeat(1, 2)
+        if part.shape[0] < per:
+            part = torch.cat([part, torch.full((per - part.shape[0], 2), float("nan"), dtype=torch.float64)])
+        full = parallel.all_gather_bins(part, n_bins).numpy()
+        np.testing.assert_array_equal(full[:, 0], np.arange(n_bins))
+        dist.destroy_process_group()
+    except Exception as exc:
+        errors.put(f"rank {rank}: {exc!r}")
+        raise
+
+
+def test_sharded_connectivity_helpers_four_ranks():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    errors = ctx.Queue()
+    procs = [ctx.Process(target=merge_worker, args=(r, 4, port, errors)) for r in range(4)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+    msgs = []
+    while not errors.empty():
+        msgs.append(errors.get())
+    assert not msgs, msgs
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+
+
+def test_sharded_connectivity_refuses_a_kept_trial_axis():
+    from spectral_connectivity_amd import parallel
+    coef = np.ones((2, 3, 2, 8, 2), complex)
+    with pytest.raises(ValueError, match="must average over them"):
+        parallel.ShardedConnectivity(coef, expectation_type="tapers")
+    c = parallel.ShardedConnectivity(coef, expectation_type="trials_tapers")
+    assert c._world == 1 and c._canonical_bins(9) == (0, 9, 9)

@@ -202,19 +202,22 @@ def test_cfg5_canonical_coherence_reduced_vs_oracle_and_full_size(sc):
     assert cc[0, f30, 0, 1] > 0.5 and cc[0, f30, 0, 1] > 3 * np.nanmedian(cc[0, f30][2:, 2:][~np.eye(14, dtype=bool)])
 
 
-def test_trial_sharded_pipeline_two_ranks_one_gpu():
+@pytest.mark.parametrize("world", [2, 3])
+def test_trial_sharded_pipeline_ranks_share_one_gpu(world):
     """parallel.sharded_measures (accumulate -> reduce-scatter -> epilogue -> gather, pipelined over frequency
-    groups on a second stream) with 2 ranks sharing this GPU over gloo equals the single-process result."""
+    groups on a second stream) and parallel.ShardedConnectivity (measures, Granger pairs dealt out over the ranks,
+    canonical-coherence bins split) with 2 / 3 ranks sharing this GPU over gloo equal the single-process results."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, SC_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29541",
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                          "--master-addr", "127.0.0.1", "--master-port", str(29541 + world),
                           os.path.join(root, "tools", "check_sharded.py")],
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "sharded_measures OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+    assert "ShardedConnectivity OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
 def test_hot_kernels_are_bit_reproducible():

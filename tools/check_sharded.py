@@ -51,7 +51,47 @@ def main():
         dist.barrier()
     if rank == 0:
         print("sharded_measures OK")
+    sharded_connectivity(world, rank, dev)
     dist.destroy_process_group()
+
+
+def sharded_connectivity(world, rank, dev):
+    """parallel.ShardedConnectivity: every rank builds it from ITS trials and calls the measures collectively; every
+    rank must get what a single process gets from all the trials -- expectation measures (reduce-scatter, epilogue on
+    the owned bins, all-gather), Granger (pairs dealt out over the ranks), canonical coherence (bins split)."""
+    import spectral_connectivity_amd as sc
+    rng = np.random.default_rng(11)
+    T, R, C = 512, 13, 12                                     # 13 trials: unequal shards
+    e = rng.standard_normal((T, R, C))
+    x = np.zeros_like(e)
+    for t in range(2, T):
+        x[t] = 0.4 * x[t - 1] - 0.2 * x[t - 2] + e[t]
+        x[t, :, 1:] += 0.3 * x[t - 1, :, :-1]
+    kw = dict(sampling_frequency=200.0, time_halfbandwidth_product=2, n_time_samples_per_window=256)
+    labels = np.repeat(np.arange(3), 4)
+    lo, hi = parallel.shard_bounds(R, world, rank)
+    for dtype, tol in ((np.complex64, 3e-5), (np.complex128, 1e-9)):
+        mine = parallel.ShardedConnectivity.from_multitaper(sc.Multitaper(x[:, lo:hi], **kw), dtype=dtype)
+        whole = sc.Connectivity.from_multitaper(sc.Multitaper(x, **kw), dtype=dtype)
+        assert mine.n_observations == whole.n_observations
+        for name in ("power", "coherency", "weighted_phase_lag_index", "phase_locking_value", "phase_lag_index"):
+            a, b = getattr(mine, name)(), getattr(whole, name)()
+            assert a.shape == b.shape and np.array_equal(np.isnan(a), np.isnan(b)), name
+            ok = ~np.isnan(b)
+            err = np.abs(a[ok] - b[ok]).max() / np.abs(b[ok]).max()
+            bound = 4.0 / whole.n_observations if name == "phase_lag_index" else tol
+            assert err <= bound, f"{name} ({np.dtype(dtype)}): {err}"
+        a, b = mine.pairwise_spectral_granger_prediction(), whole.pairwise_spectral_granger_prediction()
+        both = ~np.isnan(a) & ~np.isnan(b)
+        assert (np.isnan(a) != np.isnan(b)).mean() < 0.01 and np.abs(a[both] - b[both]).max() <= 10 * tol * np.nanmax(b)
+        a, la = mine.canonical_coherence(labels)
+        b, lb = whole.canonical_coherence(labels)
+        ok = ~np.isnan(b)
+        assert np.array_equal(la, lb) and np.array_equal(np.isnan(a), np.isnan(b))
+        assert np.abs(a[ok] - b[ok]).max() <= 10 * tol
+    dist.barrier()
+    if rank == 0:
+        print("ShardedConnectivity OK")
 
 
 if __name__ == "__main__":
