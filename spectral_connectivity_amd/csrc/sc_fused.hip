@@ -77,6 +77,9 @@ struct FusedArgs {
     int csm_plane, abs_plane;
     int sq_plane, sign_plane;   // small-channel kernel only: sum (Im s)^2, sum sign(Im s); -1 = absent
     int fold[6], n_fold;        // small-channel kernel only: the record planes a launch writes (folded over the parts)
+    int nl_op;           // what the abs waves accumulate from the per-observation d = Im(x_i conj x_j) into record plane
+                         // `abs_plane`: FU_OP_ABS |d| (with the CSM planes, one pass), FU_OP_SQ d^2, FU_OP_SIGN sign(d)
+                         // (plane passes: csm_plane = -1, the four CSM waves only stage)
     int n_split;         // workgroups per bin: part k sums the chunks [k NC / n_split, (k+1) NC / n_split)
     float* ws;           // partial records of parts 1 .. n_split-1: [n_split-1][n_bins][floats_per_bin]
     int debug_skip;      // profiling aid (env SC_FUSED_DEBUG, bit mask; results are WRONG when set):
@@ -229,6 +232,7 @@ __device__ __forceinline__ bf16x8 fu_ld8(const unsigned short* ptr) {
 #define FU_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 #define FU_MFMA(a, b, c) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+enum { FU_OP_ABS = 0, FU_OP_SQ = 1, FU_OP_SIGN = 2 };
 
 static_assert(2 * 4 + 1 <= FU_FLUSH, "one fold slot per tile of a wave");
 // The two roles are separate functions so their accumulators never coexist in registers.
@@ -262,12 +266,13 @@ __device__ __forceinline__ void fused_mfma_role(const FusedArgs& p, const ScStag
     // quads 0-3 AFTER their products, abs waves 0-3 stage quads 4-7 BEFORE theirs.
     const bool loads = !(p.debug_skip & 8);
     const bool csm_stages = p.abs_plane >= 0;       // CSM only: the eight other waves have nothing else to do
+    const bool do_csm = p.csm_plane >= 0 && (p.debug_skip & 1) == 0;      // plane passes: staging only
     if (csm_stages) fu_stage_first<NB32>(st, raw, planes, wave, o_lo, n_chunks, loads);
     FU_BARRIER();                 // chunk 0 staged
     FU_T0();
     for (int ch = 0; ch < n_chunks; ++ch) {
         const unsigned short* frag0 = frag00 + (ch & 1) * buf_elems;
-        if ((p.debug_skip & 1) == 0 && total > 0) {
+        if (do_csm && total > 0) {
             // opaque per-chunk copies: otherwise ~2 loop-invariant address VGPRs per tile stay live
             // across the chunk loop and spill at the 168-register budget
             int rA = rA_, rB = rB_, nA = nA_;
@@ -333,7 +338,7 @@ __device__ __forceinline__ void fused_mfma_role(const FusedArgs& p, const ScStag
             for (int s = 0; s < MAXS; ++s) {
                 const int f_s = FU_FLUSH - 1 - s;              // chunk of this tile's first scheduled fold
                 const bool due = ((ch + 1 + s) % FU_FLUSH) == 0;
-                if (s < total && (due || last)) {
+                if (s < total && (due || last) && p.csm_plane >= 0) {
                     const bool first = ch <= f_s;
                     const bool in_a = s < nA_;
                     const int row = in_a ? rA_ : rB_;
@@ -447,7 +452,24 @@ __device__ __forceinline__ FuFragB fu_frag_b(unsigned h, unsigned m, unsigned l,
     return f;
 }
 
-template <int NB32, int SET>
+// acc <- acc (+) f(d) for one output register of a 32x32 block: |d| (wPLI weights), d^2 (debiased wPLI), sign(d) (PLI)
+template <int OP>
+__device__ __forceinline__ float fu_accumulate(float acc, float d) {
+    if constexpr (OP == FU_OP_ABS) return acc + fabsf(d);
+    else if constexpr (OP == FU_OP_SQ) return fmaf(d, d, acc);
+    else {
+        // sign(d) in {-1, 0, 1} summed as an INTEGER in the accumulator's bits: the bit pattern of a float orders like a
+        // signed integer with +0 = 0, so clamping it to [-1, 1] is the sign (one v_med3_i32 + one v_add_u32 per value; the
+        // MFMA's C input is +0, so an exact zero comes out as +0).  Converted to float once, after the last chunk.
+        int a = __float_as_int(acc), t;
+        // one temporary per value, consumed at once (left to the compiler, sixteen clamps are scheduled ahead of their
+        // adds and the 168-register budget of a 12-wave workgroup spills)
+        asm("v_med3_i32 %1, %2, -1, 1\n\tv_add_u32 %0, %0, %1" : "+v"(a), "=&v"(t) : "v"(d));
+        return __int_as_float(a);
+    }
+}
+
+template <int NB32, int SET, int OP>
 __device__ __forceinline__ void fused_valu_body(const FusedArgs& p, const ScStage& st, unsigned short* planes,
                                                 float* raw, int tid, int vw, int rsub, int wps, float* rec,
                                                 int o_lo) {
@@ -522,18 +544,24 @@ __device__ __forceinline__ void fused_valu_body(const FusedArgs& p, const ScStag
                     }
                     if (s > 0) {
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) acc[s - 1][e] += fabsf(dprev[e]);
+                        for (int e = 0; e < 16; ++e) acc[s - 1][e] = fu_accumulate<OP>(acc[s - 1][e], dprev[e]);
                     }
                     dprev = d;
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[NBLK - 1][e] += fabsf(dprev[e]);
+                for (int e = 0; e < 16; ++e) acc[NBLK - 1][e] = fu_accumulate<OP>(acc[NBLK - 1][e], dprev[e]);
             }
         }
         FU_TICK(1);
         FU_BARRIER();             // chunk ch consumed by both roles, chunk ch + 1 staged
         FU_TICK(3);
+    }
+    if constexpr (OP == FU_OP_SIGN) {          // integer sums -> float (exact: |sum| <= n_obs < 2^24)
+#pragma unroll
+        for (int s = 0; s < NBLK; ++s)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[s][e] = (float)__float_as_int(acc[s][e]);
     }
     // tree-sum the row-split partials of a set through LDS (planes region, 20 KB per writer)
     float* red = reinterpret_cast<float*>(planes);
@@ -573,7 +601,7 @@ __device__ __forceinline__ void fused_valu_body(const FusedArgs& p, const ScStag
     }
 }
 
-template <int NB32>
+template <int NB32, int OP>
 __device__ __forceinline__ void fused_valu_role(const FusedArgs& p, const ScStage& st,
                                                 unsigned short* planes, float* raw, int tid, int vw, float* rec,
                                                 int o_lo) {
@@ -581,14 +609,14 @@ __device__ __forceinline__ void fused_valu_role(const FusedArgs& p, const ScStag
     constexpr int wps = 8 / NSETS;                        // VALU waves per block set (8 or 4)
     const int set = vw / wps, rsub = vw % wps;
     if constexpr (NSETS == 1) {
-        fused_valu_body<NB32, 0>(p, st, planes, raw, tid, vw, rsub, wps, rec, o_lo);
+        fused_valu_body<NB32, 0, OP>(p, st, planes, raw, tid, vw, rsub, wps, rec, o_lo);
     } else {
-        if (set == 0) fused_valu_body<NB32, 0>(p, st, planes, raw, tid, vw, rsub, wps, rec, o_lo);
-        else fused_valu_body<NB32, 1>(p, st, planes, raw, tid, vw, rsub, wps, rec, o_lo);
+        if (set == 0) fused_valu_body<NB32, 0, OP>(p, st, planes, raw, tid, vw, rsub, wps, rec, o_lo);
+        else fused_valu_body<NB32, 1, OP>(p, st, planes, raw, tid, vw, rsub, wps, rec, o_lo);
     }
 }
 
-template <int NB32>
+template <int NB32, int OP>
 __global__ void __launch_bounds__(FU_THREADS) fused_csm_absim_kernel(FusedArgs p) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -613,7 +641,7 @@ __global__ void __launch_bounds__(FU_THREADS) fused_csm_absim_kernel(FusedArgs p
     constexpr size_t red_bytes = (size_t)4 * FU_MAXB * 16 * 64 * sizeof(float);
     float* raw = reinterpret_cast<float*>(smem + (plane_bytes > red_bytes ? plane_bytes : red_bytes));
     if (wave < 4) fused_mfma_role<NB32>(p, st, planes, raw, tid, wave, rec, o_lo);
-    else fused_valu_role<NB32>(p, st, planes, raw, tid, wave - 4, rec, o_lo);
+    else fused_valu_role<NB32, OP>(p, st, planes, raw, tid, wave - 4, rec, o_lo);
 }
 
 // accum[bin][plane] += ws[0][bin][plane] + ws[1][bin][plane] + ... for the CSM (re, im) and (if present) |Im| planes
@@ -652,21 +680,41 @@ __global__ void __launch_bounds__(256) planes_combine_kernel(FusedArgs p) {
     }
 }
 
-template <int NB32>
-static int launch_fused(const FusedArgs& a, hipStream_t stream) {
+template <int NB32, int OP>
+static int launch_fused_op(const FusedArgs& a, hipStream_t stream) {
     size_t shmem = (size_t)2 * a.st.CP * FU_CSTRIDE * 2;
     const size_t red = (size_t)4 * FU_MAXB * 16 * 64 * sizeof(float);
     if (shmem < red) shmem = red;
     shmem += (size_t)FU_OC * FU_RAW_ROW * sizeof(float);
-    auto k = fused_csm_absim_kernel<NB32>;
+    auto k = fused_csm_absim_kernel<NB32, OP>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     hipLaunchKernelGGL(k, dim3((unsigned)(a.n_bins * a.n_split)), dim3(FU_THREADS), shmem, stream, a);
     SC_CHECK_HIP(hipGetLastError());
     if (a.n_split > 1) {
-        hipLaunchKernelGGL(fused_combine_kernel, dim3(2048), dim3(256), 0, stream, a);
+        if (OP == FU_OP_ABS) hipLaunchKernelGGL(fused_combine_kernel, dim3(2048), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL(planes_combine_kernel, dim3(2048), dim3(256), 0, stream, a);     // one plane: a.fold
         SC_CHECK_HIP(hipGetLastError());
     }
     return SC_OK;
+}
+
+// One pass of the matrix-core kernel: op = FU_OP_ABS is the headline launch (CSM planes, and |Im s| if a.abs_plane >= 0);
+// FU_OP_SQ / FU_OP_SIGN are plane passes (a.csm_plane = -1, a.abs_plane = the plane to fill): the abs waves accumulate
+// d^2 / sign(d) of the same per-observation matrix-core products, the CSM waves only stage.
+static int launch_fused(const FusedArgs& a, int op, hipStream_t stream) {
+#define FU_CASE(NB32)                                                             \
+    case NB32:                                                                    \
+        if (op == FU_OP_SQ) return launch_fused_op<NB32, FU_OP_SQ>(a, stream);    \
+        if (op == FU_OP_SIGN) return launch_fused_op<NB32, FU_OP_SIGN>(a, stream); \
+        return launch_fused_op<NB32, FU_OP_ABS>(a, stream);
+    switch (a.NB32) {
+        FU_CASE(1)
+        FU_CASE(2)
+        FU_CASE(3)
+    default:
+        FU_CASE(4)
+    }
+#undef FU_CASE
 }
 
 // ---- up to 48 channels (58 for the planes with no matrix-core form): f32 VALU kernel -------------------------
@@ -944,9 +992,11 @@ static int fused_setup(const void* d_X, const sc_spectra_desc* desc, uint32_t pl
         a->csm_plane = -1;
         a->abs_plane = -1;
         a->sign_plane = sc_plane_offset(planes, SC_PLANE_SIGN_IM);
-    } else if (small_ok_planes(*ax) && (planes & SC_PLANE_ABS_IM) && (planes & SC_PLANE_IM_SQ)) {
-        a->sq_plane = sc_plane_offset(planes, SC_PLANE_IM_SQ);       // rides along on the small-channel kernel
+    } else if ((planes & SC_PLANE_ABS_IM) && (planes & SC_PLANE_IM_SQ)) {
+        // rides along on the small-channel kernel; a plane pass of the matrix-core kernel above its range
+        a->sq_plane = sc_plane_offset(planes, SC_PLANE_IM_SQ);
     }
+    a->nl_op = FU_OP_ABS;
     a->n_split = 1;
     a->ws = nullptr;
     return SC_OK;
@@ -1000,8 +1050,14 @@ static int fused_run(const void* d_X, const sc_spectra_desc* desc, uint32_t plan
     if (small_ok(ax, a.abs_plane >= 0) || ((a.sq_plane >= 0 || mode == FU_MODE_SIGN) && small_ok_planes(ax)))
         return launch_small(a, unit, s);
     if (mode == FU_MODE_SIGN) {
-        sc_set_error("sum sign(Im s) in one pass is built for up to 58 channels (got %d): use sc_nonlinear_accumulate_f32", ax.C);
-        return SC_EUNSUPPORTED;
+        // plane pass: sign(d) of the per-observation matrix-core products, summed as integers by the abs waves
+        FusedArgs b = a;
+        b.csm_plane = -1;
+        b.abs_plane = a.sign_plane;
+        b.nl_op = FU_OP_SIGN;
+        b.fold[0] = b.abs_plane;
+        b.n_fold = 1;
+        return launch_fused(b, FU_OP_SIGN, s);
     }
     if (unit) {
         // the matrix-core kernel takes its rows straight from HBM into LDS: normalise a copy of the spectra first
@@ -1013,12 +1069,17 @@ static int fused_run(const void* d_X, const sc_spectra_desc* desc, uint32_t plan
         SC_CHECK_HIP(hipGetLastError());
         a.st.base = (const float2*)d_scratch;
     }
-    switch (a.NB32) {
-    case 1: return launch_fused<1>(a, s);
-    case 2: return launch_fused<2>(a, s);
-    case 3: return launch_fused<3>(a, s);
-    default: return launch_fused<4>(a, s);
-    }
+    const int rc_main = launch_fused(a, FU_OP_ABS, s);
+    if (rc_main != SC_OK || a.sq_plane < 0) return rc_main;
+    // debiased wPLI: sum (Im s)^2 as a second pass of the same kernel (the abs waves hold 80 accumulator registers
+    // per plane; two planes do not fit next to the matrix-core role's)
+    FusedArgs b = a;
+    b.csm_plane = -1;
+    b.abs_plane = a.sq_plane;
+    b.nl_op = FU_OP_SQ;
+    b.fold[0] = b.abs_plane;
+    b.n_fold = 1;
+    return launch_fused(b, FU_OP_SQ, s);
 }
 
 extern "C" int sc_fused_csm_absim_ws_f32(const void* d_X, const sc_spectra_desc* desc, uint32_t planes,
@@ -1033,10 +1094,8 @@ extern "C" uint32_t sc_fused_planes_covered(const sc_spectra_desc* desc, uint32_
     if (!desc || sc_make_axes(desc, &ax) != SC_OK || !fused_ok(nullptr, ax)) return 0;
     uint32_t got = planes & (SC_PLANE_CSM | SC_PLANE_UNIT);
     if ((planes & SC_PLANE_CSM) && (planes & SC_PLANE_ABS_IM)) got |= SC_PLANE_ABS_IM;
-    if (small_ok_planes(ax)) {
-        if ((got & SC_PLANE_ABS_IM) && (planes & SC_PLANE_IM_SQ)) got |= SC_PLANE_IM_SQ;
-        got |= planes & SC_PLANE_SIGN_IM;
-    }
+    if ((got & SC_PLANE_ABS_IM) && (planes & SC_PLANE_IM_SQ)) got |= SC_PLANE_IM_SQ;
+    got |= planes & SC_PLANE_SIGN_IM;
     return got;
 }
 

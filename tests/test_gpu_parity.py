@@ -259,7 +259,15 @@ def test_one_pass_nonlinear_planes_equal_the_per_plane_kernel(sc, C, R):
             got = engine.measure(a_f, C, planes, n, which).cpu().numpy()
             ref = engine.measure(a_s, C, planes, n, which).cpu().numpy()
             if planes == _lib.PLANE_SIGN_IM:
-                assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.array_equal(got[~np.isnan(got)], ref[~np.isnan(ref)])
+                assert np.array_equal(np.isnan(got), np.isnan(ref))
+                if C <= 58 or C > 128:       # both kernels form Im s with the same f32 operations: identical sign sums
+                    assert np.array_equal(got[~np.isnan(got)], ref[~np.isnan(ref)])
+                else:
+                    # 60 ... 128 channels: the signs come from the matrix-core products (six bf16 cross terms, f32
+                    # sums) instead of an f32 FMA pair -- an observation whose |Im s| is within f32 rounding of zero
+                    # may land on the other side: a handful of entries off by one or two flipped observations
+                    diff = np.abs(got - ref)[~np.isnan(ref)]
+                    assert (diff > 0).mean() < 1e-3 and diff.max() <= 8.0 / n, (C, et, (diff > 0).sum(), diff.max())
             else:
                 tol = 2e-5 if which == _lib.M_DEBIASED_WPLI2 else 3e-6     # the debiased ratio amplifies re-association
                 close32(got, ref, rtol=tol, atol_scale=tol, what=f"planes {planes:#x} measure {which} {et}")
