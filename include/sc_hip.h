@@ -220,10 +220,11 @@ int64_t sc_unit_scratch_bytes(const sc_spectra_desc* desc);
 int sc_unit_accumulate_f32(const void* d_X /*float2*/, const sc_spectra_desc* desc, uint32_t planes,
                            float* d_accum, void* d_scratch, int64_t scratch_bytes, void* stream);
 
-/* Which planes of `planes` the one-pass entry points fill for this shape: CSM, |Im s| (with CSM) and
- * s/|s| for every supported shape; (Im s)^2 (with CSM and |Im s|, filled by sc_fused_csm_absim_ws_f32) and
- * sign(Im s) (sc_fused_sign_ws_f32: phase_lag_index, connectivity.py:983-1079) up to 58 channels, where
- * the path is an f32 VALU kernel.  The remaining planes are sc_nonlinear_accumulate_f32's. */
+/* Which planes of `planes` the one-pass entry points fill for this shape (even n_signals <= 128): CSM, |Im s| (with
+ * CSM) and s/|s|; (Im s)^2 (with CSM and |Im s|, filled by sc_fused_csm_absim_ws_f32: in the same pass up to 52 channels,
+ * as a second pass of the matrix-core kernel above) and sign(Im s) (sc_fused_sign_ws_f32: phase_lag_index,
+ * connectivity.py:933-980; f32 VALU kernel up to 40 channels, above it a pass of the matrix-core kernel whose |Im| waves
+ * sum sign(d) of the per-observation products).  Whatever is left is sc_nonlinear_accumulate_f32's. */
 uint32_t sc_fused_planes_covered(const sc_spectra_desc* desc, uint32_t planes);
 int sc_fused_sign_ws_f32(const void* d_X /*float2*/, const sc_spectra_desc* desc, uint32_t planes,
                          float* d_accum, void* d_workspace, int64_t workspace_bytes, void* stream);

@@ -925,9 +925,11 @@ static bool fused_ok(const void* d_X, const ScAxes& ax) {
 // The f32 VALU kernel below the measured crossover (same input volume as cfg3: 4.7 vs 5.1 ms at 48 channels with a
 // per-observation non-linear plane, 3.0 vs 3.9 ms at 40 channels without; the MFMA kernel wins from 56 / 44 on).
 static bool small_ok(const ScAxes& ax, bool nonlinear_plane) { return ax.C <= (nonlinear_plane ? 48 : 42); }
-// (Im s)^2 and sign(Im s) have no matrix-core form: the alternative above this kernel's range is the per-plane VALU
-// kernel, so it keeps them as far as one thread per 2 x 2 block goes (58 channels = 435 blocks).
-static bool small_ok_planes(const ScAxes& ax) { return ax.C <= 58; }
+// (Im s)^2 rides along with CSM + |Im s| on this kernel up to 52 channels, sign(Im s) runs on it up to 40: above, a
+// plane pass of the matrix-core kernel is faster (measured at the cfg3 volume: 50 channels, sign 9.9 ms here against
+// ~5.3 ms there; CSM + |Im| + Im^2 8.2 ms in one pass here against 5.3 + ~4 ms in two there).
+static bool small_ok_sq(const ScAxes& ax) { return ax.C <= 52; }
+static bool small_ok_sign(const ScAxes& ax) { return ax.C <= 40; }
 
 extern "C" int sc_fused_supported(int64_t n_signals) {
     return (n_signals >= 2 && n_signals <= 128 && (n_signals % 2) == 0) ? 1 : 0;
@@ -1047,7 +1049,7 @@ static int fused_run(const void* d_X, const sc_spectra_desc* desc, uint32_t plan
     a.n_split = S;
     a.ws = (float*)d_workspace;
     hipStream_t s = (hipStream_t)stream;
-    if (small_ok(ax, a.abs_plane >= 0) || ((a.sq_plane >= 0 || mode == FU_MODE_SIGN) && small_ok_planes(ax)))
+    if (small_ok(ax, a.abs_plane >= 0) || (a.sq_plane >= 0 && small_ok_sq(ax)) || (mode == FU_MODE_SIGN && small_ok_sign(ax)))
         return launch_small(a, unit, s);
     if (mode == FU_MODE_SIGN) {
         // plane pass: sign(d) of the per-observation matrix-core products, summed as integers by the abs waves
@@ -1087,8 +1089,8 @@ extern "C" int sc_fused_csm_absim_ws_f32(const void* d_X, const sc_spectra_desc*
     return fused_run(d_X, desc, planes, FU_MODE_CSM, d_accum, d_workspace, workspace_bytes, nullptr, 0, stream);
 }
 
-// The planes of `planes` that the one-pass entry points fill for this shape: CSM, |Im s| (with CSM), s/|s| always;
-// (Im s)^2 (with CSM and |Im s|) and sign(Im s) up to 58 channels.  The rest is sc_nonlinear_accumulate_f32's.
+// The planes of `planes` that the one-pass entry points fill for this shape (even n_signals <= 128): CSM, |Im s| (with
+// CSM), s/|s|, (Im s)^2 (with CSM and |Im s|) and sign(Im s).  Everything else is sc_nonlinear_accumulate_f32's.
 extern "C" uint32_t sc_fused_planes_covered(const sc_spectra_desc* desc, uint32_t planes) {
     ScAxes ax;
     if (!desc || sc_make_axes(desc, &ax) != SC_OK || !fused_ok(nullptr, ax)) return 0;
@@ -1099,8 +1101,9 @@ extern "C" uint32_t sc_fused_planes_covered(const sc_spectra_desc* desc, uint32_
     return got;
 }
 
-// SC_PLANE_SIGN_IM of the record (phase_lag_index, debiased_squared_phase_lag_index: connectivity.py:983-1079) on the
-// small-channel kernel; SC_EUNSUPPORTED above 58 channels.
+// SC_PLANE_SIGN_IM of the record (phase_lag_index, debiased_squared_phase_lag_index: connectivity.py:983-1079): the
+// small-channel kernel up to 40 channels, above it a plane pass of the matrix-core kernel (the abs waves sum
+// sign(d) of the per-observation products as integers).
 extern "C" int sc_fused_sign_ws_f32(const void* d_X, const sc_spectra_desc* desc, uint32_t planes, float* d_accum,
                                     void* d_workspace, int64_t workspace_bytes, void* stream) {
     return fused_run(d_X, desc, planes, FU_MODE_SIGN, d_accum, d_workspace, workspace_bytes, nullptr, 0, stream);

@@ -238,11 +238,12 @@ def test_fused_stage_b_equals_separate_kernels(sc, C, R):
                 so.weighted_phase_lag_index(coef), what="wpli vs oracle")
 
 
-@pytest.mark.parametrize("C,R", [(2, 40), (6, 9), (16, 120), (34, 5), (48, 7), (50, 4), (58, 6), (60, 3), (64, 6), (128, 5),
+@pytest.mark.parametrize("C,R", [(2, 40), (6, 9), (16, 120), (34, 5), (40, 6), (42, 5), (48, 7), (50, 4), (52, 5), (54, 4), (58, 6), (60, 3), (64, 6), (96, 4), (128, 5),
                                  (129, 3), (160, 4), (255, 2)])
 def test_one_pass_nonlinear_planes_equal_the_per_plane_kernel(sc, C, R):
-    """(Im s)^2 and sign(Im s) ride on the small-channel one-pass kernel (<= 58 channels) and the unit phasors s/|s| go
-    through the one-pass kernels as the cross-spectral matrix of x/|x| at every size: the same accumulator records as the
+    """(Im s)^2 and sign(Im s) ride on the small-channel one-pass kernel (<= 52 / <= 40 channels) or are plane passes of the
+    matrix-core kernel (up to 128), and the unit phasors s/|s| go through the one-pass kernels as the cross-spectral
+    matrix of x/|x| at every size: the same accumulator records as the
     per-plane VALU kernel (sc_nonlinear.hip) up to f32 summation order -- sign sums exactly."""
     from spectral_connectivity_amd import _lib, engine
     rng = np.random.default_rng(100 + C)
@@ -260,10 +261,10 @@ def test_one_pass_nonlinear_planes_equal_the_per_plane_kernel(sc, C, R):
             ref = engine.measure(a_s, C, planes, n, which).cpu().numpy()
             if planes == _lib.PLANE_SIGN_IM:
                 assert np.array_equal(np.isnan(got), np.isnan(ref))
-                if C <= 58 or C > 128:       # both kernels form Im s with the same f32 operations: identical sign sums
+                if C <= 40 or C > 128:       # both kernels form Im s with the same f32 operations: identical sign sums
                     assert np.array_equal(got[~np.isnan(got)], ref[~np.isnan(ref)])
                 else:
-                    # 60 ... 128 channels: the signs come from the matrix-core products (six bf16 cross terms, f32
+                    # 42 ... 128 channels: the signs come from the matrix-core products (six bf16 cross terms, f32
                     # sums) instead of an f32 FMA pair -- an observation whose |Im s| is within f32 rounding of zero
                     # may land on the other side: a handful of entries off by one or two flipped observations
                     diff = np.abs(got - ref)[~np.isnan(ref)]
