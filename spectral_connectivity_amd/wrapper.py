@@ -5,7 +5,8 @@ arguments, dimension names (``time``, ``frequency``, ``source``, ``target``), ``
 error behaviour.  Differences: every requested measure is computed from ONE ``Connectivity`` object, so
 the spectra are transformed once and measures that share accumulator planes share one device pass (the
 reference builds a new ``Connectivity`` -- and re-reduces the coefficients -- per method); and ``xarray``
-is imported on first use, because it is an optional dependency of this engine.
+is optional: when it cannot be imported the results are the minimal labelled arrays of ``_labelled.py`` (same
+``values`` / ``dims`` / ``coords`` / ``attrs`` / ``name``).
 """
 import inspect
 from logging import getLogger
@@ -29,12 +30,14 @@ _MT_SKIP = {"time_series", "fft", "tapers", "frequencies", "time"}
 
 
 def _xarray():
+    """``xarray`` when it can be imported (the reference's dependency), else the vendored minimal labelled arrays of
+    ``_labelled.py`` -- same attribute names (values / dims / coords / attrs / name), ``sel`` / ``isel`` / ``squeeze``."""
     try:
         import xarray
-    except ImportError as exc:          # pragma: no cover - depends on the environment
-        raise ImportError("the labelled interface (connectivity_to_xarray, multitaper_connectivity) needs the "
-                          "optional package 'xarray'; the Multitaper / Connectivity classes work without it") from exc
-    return xarray
+        return xarray
+    except ImportError:
+        from . import _labelled
+        return _labelled
 
 
 def _check_method(method):

@@ -204,3 +204,17 @@ def test_full_depth_elementwise_relative(sc, cfg):
         print(f"  {name}: max rel err {mx:.2e} (99.9th pct {q999:.2e}) over {100 * frac:.2f} % of the entries")
         close64(got, ref[name], rtol=1e-5, floor=1e-13, what=f"{cfg} {name}")
         assert mx < 1e-7, f"{cfg} {name}: {mx}"
+
+
+def test_f11_band_statistics_float64(sc, golden):
+    """phase_slope_index / group_delay / delay on the float64 engine's coherency: equal to the reference's outputs."""
+    g = golden("f11_post")
+    c = sc.Connectivity.from_multitaper(sc.Multitaper(g["x"], sampling_frequency=500.0, time_halfbandwidth_product=3))
+    close64(c.coherency(), g["coherency"], what="f11 coherency")
+    res = float(g["frequency_resolution"])
+    close64(c.phase_slope_index(), g["psi_all"], rtol=1e-8, floor=1e-10, what="psi")
+    close64(c.phase_slope_index([10, 200], res), g["psi_band_res"], rtol=1e-8, floor=1e-10, what="psi band")
+    d, s_, r = c.group_delay([10, 200], res)
+    for a, key in ((d, "group_delay"), (s_, "group_slope"), (r, "group_r")):
+        np.testing.assert_allclose(a, g[key], rtol=1e-12, atol=0, equal_nan=True, err_msg=key)
+    np.testing.assert_allclose(c.delay([10, 200], n_range=2), g["delay_band"], rtol=1e-12, atol=0, equal_nan=True)

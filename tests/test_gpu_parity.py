@@ -485,39 +485,64 @@ def test_global_coherence_large_even_and_odd(sc):
         assert (ip > 1 - 1e-3).mean() > 0.9, f"C={C}: dominant vector differs ({ip.min()})"
 
 
-def test_wrapper_labels_with_a_stand_in_xarray(sc, monkeypatch):
-    """multitaper_connectivity(): dims / coords / names / mt_* attributes of the labelled output, with a minimal
-    stand-in for the optional xarray package (absent from this image), values equal to Connectivity's."""
-    import sys
-    import types
-
-    class DataArray:
-        def __init__(self, data, coords=None, dims=None):
-            self.values, self.coords, self.dims, self.attrs, self.name = np.asarray(data), list(coords), list(dims), {}, None
-            assert self.values.ndim == len(self.dims) and all(len(c) == n for c, n in zip(self.coords, self.values.shape))
-
-    class Dataset(dict):
-        pass
-
-    fake = types.ModuleType("xarray")
-    fake.DataArray, fake.Dataset = DataArray, Dataset
-    monkeypatch.setitem(sys.modules, "xarray", fake)
+def test_wrapper_labelled_outputs_against_the_oracle(sc):
+    """multitaper_connectivity() / connectivity_to_xarray() (reference wrapper.py:17-287): dims / coords / names / mt_*
+    attributes of the labelled output -- real xarray objects where the package is installed, the vendored minimal
+    labelled arrays (spectral_connectivity_amd/_labelled.py) otherwise -- and VALUES against the CPU oracle, not against
+    this package's own Connectivity."""
     from spectral_connectivity_amd import multitaper_connectivity
+    from spectral_connectivity_amd.wrapper import connectivity_to_xarray
     x = np.random.default_rng(5).standard_normal((400, 6, 3))
+    x[:, :, 1] += 0.8 * np.roll(x[:, :, 0], 3, axis=0)
     kw = dict(sampling_frequency=200.0, time_window_duration=0.5, time_halfbandwidth_product=2)
+    coef, info = so.multitaper_fft(x, fs=200.0, NW=2, time_window_duration=0.5)
+    freqs = so.nonneg_frequencies(np.fft.fftfreq(coef.shape[3], 1 / 200.0))
     da = multitaper_connectivity(x, method="coherence_magnitude", signal_names=["a", "b", "c"], **kw)
-    assert da.name == "coherence_magnitude" and da.dims == ["time", "frequency", "source", "target"]
-    assert da.coords[2] == ["a", "b", "c"] and da.attrs["mt_sampling_frequency"] == 200.0
-    m = sc.Multitaper(x, **kw)
-    c = sc.Connectivity.from_multitaper(m)
-    close32(da.values, c.coherence_magnitude(), what="wrapper coherence")
-    np.testing.assert_allclose(da.coords[0], m.time)
+    assert da.name == "coherence_magnitude" and tuple(da.dims) == ("time", "frequency", "source", "target")
+    assert list(np.asarray(da["source"])) == ["a", "b", "c"] and da.attrs["mt_sampling_frequency"] == 200.0
+    assert da.attrs["mt_n_tapers"] == 3 and da.attrs["mt_time_halfbandwidth_product"] == 2
+    close32(np.asarray(da.values), so.coherence_magnitude(coef), what="wrapper coherence vs oracle")
+    np.testing.assert_allclose(np.asarray(da["frequency"]), freqs)
+    np.testing.assert_allclose(np.asarray(da["time"]), np.arange(coef.shape[0]) * 0.5)
+    ab = da.sel(source="a", target="b")
+    close32(np.asarray(ab.values), so.coherence_magnitude(coef)[..., 0, 1], what="sel(source, target)")
     ds = multitaper_connectivity(x, method=["power", "weighted_phase_lag_index", "imaginary_coherence"], **kw)
     assert set(ds) == {"power", "weighted_phase_lag_index", "imaginary_coherence"}
-    assert ds["power"].dims == ["time", "frequency", "source"]
-    close32(ds["weighted_phase_lag_index"].values, c.weighted_phase_lag_index(), what="wrapper wpli")
+    assert tuple(ds["power"].dims) == ("time", "frequency", "source")
+    close32(np.asarray(ds["power"].values), so.power(coef), what="wrapper power vs oracle")
+    close32(np.asarray(ds["weighted_phase_lag_index"].values), so.weighted_phase_lag_index(coef), what="wrapper wpli vs oracle")
+    close32(np.asarray(ds["imaginary_coherence"].values), so.imaginary_coherence(coef), what="wrapper imag coh vs oracle")
     two = multitaper_connectivity(x[..., :2], method="coherence_magnitude", squeeze=True, **kw)
-    assert two.dims == ["time", "frequency"]
+    assert tuple(two.dims) == ("time", "frequency")
+    coef2, _ = so.multitaper_fft(x[..., :2], fs=200.0, NW=2, time_window_duration=0.5)
+    close32(np.asarray(two.values), so.coherence_magnitude(coef2)[..., 0, -1], what="squeezed pair vs oracle")
+    one = connectivity_to_xarray(sc.Multitaper(x, **kw), method="phase_locking_value")
+    close32(np.asarray(one.values), so.phase_locking_value(coef), rtol=3e-5, atol_scale=3e-5, what="connectivity_to_xarray plv")
     everything = multitaper_connectivity(x, **kw)          # method=None: every expressible measure
     assert {"coherency", "pairwise_spectral_granger_prediction", "phase_locking_value"} <= set(everything)
     assert not ({"group_delay", "global_coherence", "directed_coherence"} & set(everything))
+
+
+def test_f11_band_statistics_on_the_device_coherency(sc, golden):
+    """SURVEY 8(f)-4 on the GPU: phase_slope_index / group_delay / delay of `Connectivity` -- host post-processing of
+    the DEVICE coherency -- for the f11 input against the real reference's outputs (tests/golden/f11_post.npz).
+    group_delay / delay reproduce the reference by default (NaN / the constants 2 pi k: its one-sample Fisher z is
+    always NaN, see options.one_sample_fisher_z)."""
+    g = golden("f11_post")
+    m = sc.Multitaper(g["x"], sampling_frequency=500.0, time_halfbandwidth_product=3)
+    c = sc.Connectivity.from_multitaper(m)
+    assert c.n_observations == int(g["n_observations"])
+    np.testing.assert_allclose(c.frequencies, g["frequencies"])
+    close32(c.coherency(), g["coherency"], what="f11 coherency")
+    res = float(g["frequency_resolution"])
+    for got, key in ((c.phase_slope_index(), "psi_all"), (c.phase_slope_index([10, 200]), "psi_band"),
+                     (c.phase_slope_index([10, 200], res), "psi_band_res")):
+        ref = g[key]
+        assert got.shape == ref.shape and np.array_equal(np.isnan(got), np.isnan(ref)), key
+        ok = ~np.isnan(ref)
+        # a sum over ~100 bin pairs of products of f32-accurate coherencies
+        assert np.abs(got[ok] - ref[ok]).max() <= 2e-5 * np.abs(ref[ok]).max(), key
+    d, s_, r = c.group_delay([10, 200], res)
+    for a, key in ((d, "group_delay"), (s_, "group_slope"), (r, "group_r")):
+        np.testing.assert_allclose(a, g[key], rtol=1e-12, atol=0, equal_nan=True, err_msg=key)
+    np.testing.assert_allclose(c.delay([10, 200], n_range=2), g["delay_band"], rtol=1e-12, atol=0, equal_nan=True)

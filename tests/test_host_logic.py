@@ -244,11 +244,29 @@ def test_wrapper_validates_before_touching_the_device():
             multitaper_connectivity(x, sampling_frequency=100, method=bad)
         with pytest.raises(ValueError, match="Connectivity class directly"):
             connectivity_to_xarray(Multitaper(x, sampling_frequency=100), method=bad)
-    try:
-        import xarray  # noqa: F401
-    except ImportError:
-        with pytest.raises(ImportError, match="xarray"):
-            multitaper_connectivity(x, sampling_frequency=100, method="coherence_magnitude")
+
+
+def test_vendored_labelled_arrays():
+    """_labelled.DataArray / Dataset: what the front end returns when the optional xarray package is absent."""
+    from spectral_connectivity_amd._labelled import DataArray, Dataset
+    v = np.arange(2 * 3 * 2 * 2, dtype=float).reshape(2, 3, 2, 2)
+    a = DataArray(v, coords=[[0.0, 0.5], [0.0, 10.0, 20.0], ["a", "b"], ["a", "b"]],
+                  dims=["time", "frequency", "source", "target"], name="coherence_magnitude", attrs={"mt_n_tapers": 5})
+    assert a.dims == ("time", "frequency", "source", "target") and a.shape == (2, 3, 2, 2) and a.name == "coherence_magnitude"
+    np.testing.assert_array_equal(a["frequency"], [0.0, 10.0, 20.0])
+    np.testing.assert_array_equal(a.sel(source="a", target="b").values, v[:, :, 0, 1])
+    assert a.sel(source="a", target="b").dims == ("time", "frequency")
+    np.testing.assert_array_equal(a.sel(frequency=12.0, method="nearest").values, v[:, 1])
+    np.testing.assert_array_equal(a.isel(time=1, frequency=[0, 2]).values, v[1][[0, 2]])
+    assert a.isel(time=[0]).squeeze().dims == ("frequency", "source", "target")
+    np.testing.assert_array_equal(np.asarray(a), v)
+    with pytest.raises(KeyError):
+        a.sel(source="zz")
+    with pytest.raises(ValueError, match="coordinate 'frequency'"):
+        DataArray(v, coords=[[0, 1], [0, 1], ["a", "b"], ["a", "b"]], dims=["time", "frequency", "source", "target"])
+    ds = Dataset()
+    ds["coherence_magnitude"] = a
+    assert list(ds) == ["coherence_magnitude"] and ds.data_vars is ds and ds.attrs == {"mt_n_tapers": 5}
 
 
 def test_host_detrend_helper_matches_scipy_and_reference_messages():
