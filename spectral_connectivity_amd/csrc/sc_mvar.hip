@@ -298,6 +298,232 @@ __global__ void m_update(cd* G, const cd* Aplus, const int32_t* status, double* 
     if (threadIdx.x == 0 && red[0] > 0.0) mv_atomic_max_nonneg(err + p, red[0]);
 }
 
+// ---- predict / update of the Wilson iteration, second generation ------------------------------------------------
+// m_predict (LU with partial pivoting on an LDS-resident matrix pair, three LDS accesses per complex FMA) was 3.2 ms per
+// launch for 1792 problems of 64 x 64: LDS-bandwidth bound at 3 % of the fp64 rate.  m_predict_gj keeps the WHOLE
+// augmented matrix [G | S] in registers: the 256 threads of a workgroup form a 16 x 16 grid, thread (ty, tx) owns rows
+// ty + 16 a and columns tx + 16 b (a, b < Q, C <= 16 Q), i.e. Q^2 complex elements of G and of S.  Gauss-Jordan with
+// partial pivoting, one column per step: the owners of column k publish it (and |.|^2 of the rows that have not been
+// pivots yet) in LDS, every wave finds the pivot row with a butterfly of shuffles, the owners of that row publish it
+// scaled by 1 / pivot, and every thread updates its own block from registers: four LDS reads of a column value and
+// eight of a row value per step against 2 Q^2 complex FMAs -- the kernel runs at the fp64 VALU rate (which on MI355X
+// IS the fp64 matrix rate: 78.6 TFLOP/s both, so a rank-4 v_mfma_f64 formulation of the elimination has nothing to
+// gain).  No row is ever moved: after C steps G has become a permutation matrix, row pr_k of the right-hand side holds
+// row k of Y = G^-1 S.  The second factor of A = G^-1 S G^-H + I re-uses the elimination instead of a second solve:
+// with E = E_C ... E_1 the recorded row operations (E G = P), A - I = P^T (Y' E^H) P, and Y' E^H is the same sequence
+// applied as COLUMN operations (column pr_k scaled by conj(1 / pivot), column r reduced by conj(m_r) times it) to the
+// block the thread already holds -- half the work of the first pass, multipliers read back from LDS (C^2 complex).
+// 2 syncs per step in the first pass, 1 in the second; 70 KB of LDS and ~180 registers: two workgroups per CU.
+template <int Q>
+__global__ void __launch_bounds__(256, 2) m_predict_gj(const cd* __restrict__ S, const cd* __restrict__ G,
+                                                       const int32_t* __restrict__ status, cd* __restrict__ A,
+                                                       int64_t N, int C) {
+    constexpr int CP = 16 * Q;
+    extern __shared__ __align__(16) unsigned char mv_smem[];
+    cd* mult = reinterpret_cast<cd*>(mv_smem);             // [C][CP] multipliers m_r of step k (0 for the pivot row)
+    cd* colbuf = mult + CP * CP;                           // [2][CP]  column k (double buffered)
+    cd* rowbuf = colbuf + 2 * CP;                          // [2 CP]   scaled pivot row of G, then of S
+    cd* pinv = rowbuf + 2 * CP;                            // [CP]     1 / pivot of step k
+    double* mag = reinterpret_cast<double*>(pinv + CP);    // [CP]     |column k|^2, -1 for rows that were pivots
+    int* prow = reinterpret_cast<int*>(mag + CP);          // [CP]     pivot row of step k
+    int* pos = prow + CP;                                  // [CP]     step at which row r was the pivot
+    const int64_t n = blockIdx.x, p = blockIdx.y;
+    if (status[p] != 0) return;
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15, lane = tid & 63;
+    const int E = C * C;
+    cd g[Q][Q], s[Q][Q];
+#pragma unroll
+    for (int a = 0; a < Q; ++a)
+#pragma unroll
+        for (int b = 0; b < Q; ++b) {
+            const int r = ty + 16 * a, c = tx + 16 * b;
+            if (r < C && c < C) {
+                g[a][b] = G[((int64_t)p * E + r * C + c) * N + n];
+                s[a][b] = S[((int64_t)p * E + r * C + c) * N + n];
+            } else {
+                g[a][b] = make_double2(r == c ? 1.0 : 0.0, 0.0);
+                s[a][b] = make_double2(0.0, 0.0);
+            }
+        }
+    unsigned used = 0;                                     // bit a: row ty + 16 a has been a pivot
+    if (tid < CP) pos[tid] = tid < C ? tid : 0;            // (only a NaN input leaves an entry at this default)
+    // ---- pass 1: row operations on [G | S] ----
+#pragma unroll
+    for (int kb = 0; kb < Q; ++kb) {
+        for (int kx = 0; kx < 16; ++kx) {
+            const int k = 16 * kb + kx;
+            if (k >= C) break;
+            cd* cb = colbuf + (k & 1) * CP;
+            if (tx == kx) {
+#pragma unroll
+                for (int a = 0; a < Q; ++a) {
+                    const int r = ty + 16 * a;
+                    const cd v = g[a][kb];
+                    cb[r] = v;
+                    mag[r] = (((used >> a) & 1u) || r >= C) ? -1.0 : v.x * v.x + v.y * v.y;
+                }
+            }
+            __syncthreads();
+            // pivot row: arg max over the candidate rows, found by every wave for itself (CP <= 64 = one per lane)
+            double best = lane < CP ? mag[lane] : -1.0;
+            int pr = lane;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const double ob = __shfl_xor(best, off);
+                const int oi = __shfl_xor(pr, off);
+                if (ob > best || (ob == best && oi < pr)) { best = ob; pr = oi; }
+            }
+            const cd piv = cb[pr];
+            const double pden = piv.x * piv.x + piv.y * piv.y;
+            const cd inv = make_double2(piv.x / pden, -piv.y / pden);
+            if (ty == (pr & 15)) {
+#pragma unroll
+                for (int a = 0; a < Q; ++a)
+                    if (ty + 16 * a == pr) {
+#pragma unroll
+                        for (int b = 0; b < Q; ++b) {
+                            rowbuf[tx + 16 * b] = m_mul(g[a][b], inv);
+                            rowbuf[CP + tx + 16 * b] = m_mul(s[a][b], inv);
+                        }
+                    }
+            }
+            if (tid == 0) { prow[k] = pr; pinv[k] = inv; pos[pr] = k; }
+            __syncthreads();
+            cd wg[Q], ws[Q];
+#pragma unroll
+            for (int b = 0; b < Q; ++b) { wg[b] = rowbuf[tx + 16 * b]; ws[b] = rowbuf[CP + tx + 16 * b]; }
+#pragma unroll
+            for (int a = 0; a < Q; ++a) {
+                const int r = ty + 16 * a;
+                cd m = cb[r];
+                if (r == pr) m = make_double2(0.0, 0.0);
+                if (tx == 0) mult[k * CP + r] = m;
+#pragma unroll
+                for (int b = 0; b < Q; ++b) {
+                    g[a][b].x = fma(-m.x, wg[b].x, fma(m.y, wg[b].y, g[a][b].x));
+                    g[a][b].y = fma(-m.x, wg[b].y, fma(-m.y, wg[b].x, g[a][b].y));
+                    s[a][b].x = fma(-m.x, ws[b].x, fma(m.y, ws[b].y, s[a][b].x));
+                    s[a][b].y = fma(-m.x, ws[b].y, fma(-m.y, ws[b].x, s[a][b].y));
+                }
+                if (r == pr) {
+#pragma unroll
+                    for (int b = 0; b < Q; ++b) { g[a][b] = wg[b]; s[a][b] = ws[b]; }
+                    used |= 1u << a;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- pass 2: the same elimination as column operations on Y' (held in s) ----
+    for (int k = 0; k < C; ++k) {
+        const int pr = prow[k];
+        const cd cinv = m_conj(pinv[k]);
+        cd* cb = colbuf + (k & 1) * CP;
+        if (tx == (pr & 15)) {
+#pragma unroll
+            for (int b = 0; b < Q; ++b)
+                if (tx + 16 * b == pr) {
+#pragma unroll
+                    for (int a = 0; a < Q; ++a) {
+                        s[a][b] = m_mul(s[a][b], cinv);
+                        cb[ty + 16 * a] = s[a][b];
+                    }
+                }
+        }
+        __syncthreads();
+        cd mc[Q];
+#pragma unroll
+        for (int b = 0; b < Q; ++b) mc[b] = mult[k * CP + tx + 16 * b];        // 0 for the pivot column itself
+#pragma unroll
+        for (int a = 0; a < Q; ++a) {
+            const cd v = cb[ty + 16 * a];
+#pragma unroll
+            for (int b = 0; b < Q; ++b) {
+                // s -= conj(m) v
+                s[a][b].x = fma(-mc[b].x, v.x, fma(-mc[b].y, v.y, s[a][b].x));
+                s[a][b].y = fma(-mc[b].x, v.y, fma(mc[b].y, v.x, s[a][b].y));
+            }
+        }
+    }
+    // A[i][j] = W[pr_i][pr_j] + delta_ij: element (r, c) of the block belongs to i = pos[r], j = pos[c]
+#pragma unroll
+    for (int a = 0; a < Q; ++a)
+#pragma unroll
+        for (int b = 0; b < Q; ++b) {
+            const int r = ty + 16 * a, c = tx + 16 * b;
+            if (r < C && c < C) {
+                const int i = pos[r], j = pos[c];
+                cd v = s[a][b];
+                if (i == j) v.x += 1.0;
+                A[((int64_t)p * E + i * C + j) * N + n] = v;
+            }
+        }
+}
+
+// G <- G A+ and err = max |G_new - G| on the fp64 matrix cores: complex C x C x C product per (window, bin) as four real
+// v_mfma_f64_16x16x4_f64 per 16 x 16 tile and 4-deep slice of the inner dimension; both operands staged in LDS (row
+// stride CP + 1 complex: the A-operand reads walk 16 rows at one column).  Wave w owns tile rows w, w + 4, ...
+typedef double mv_f64x4 __attribute__((ext_vector_type(4)));
+template <int Q>
+__global__ void __launch_bounds__(256) m_update_mfma(cd* __restrict__ G, const cd* __restrict__ Aplus,
+                                                     const int32_t* __restrict__ status, double* __restrict__ err,
+                                                     int64_t N, int C) {
+    constexpr int CP = 16 * Q, LS = CP + 1;
+    extern __shared__ __align__(16) unsigned char mv_smem[];
+    cd* Gl = reinterpret_cast<cd*>(mv_smem);
+    cd* Al = Gl + CP * LS;
+    __shared__ double red[4];
+    const int64_t n = blockIdx.x, p = blockIdx.y;
+    if (status[p] != 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int E = C * C;
+    for (int e = tid; e < CP * CP; e += 256) {
+        const int i = e / CP, j = e - i * CP;
+        const bool in = i < C && j < C;
+        Gl[i * LS + j] = in ? G[((int64_t)p * E + i * C + j) * N + n] : make_double2(0.0, 0.0);
+        Al[i * LS + j] = in ? Aplus[((int64_t)p * E + i * C + j) * N + n] : make_double2(0.0, 0.0);
+    }
+    __syncthreads();
+    const int li = lane & 15, lk = lane >> 4;
+    double emax = 0.0;
+    for (int ti = wave; ti < Q; ti += 4) {
+        mv_f64x4 re[Q], im[Q];
+#pragma unroll
+        for (int tj = 0; tj < Q; ++tj) { re[tj] = (mv_f64x4){0.0, 0.0, 0.0, 0.0}; im[tj] = re[tj]; }
+        for (int kk = 0; kk < CP / 4; ++kk) {
+            const cd a = Gl[(16 * ti + li) * LS + 4 * kk + lk];         // A operand: row li, inner index lk
+#pragma unroll
+            for (int tj = 0; tj < Q; ++tj) {
+                const cd b = Al[(4 * kk + lk) * LS + 16 * tj + li];     // B operand: inner index lk, column li
+                re[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.x, re[tj], 0, 0, 0);
+                re[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.y, b.y, re[tj], 0, 0, 0);
+                im[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.y, im[tj], 0, 0, 0);
+                im[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b.x, im[tj], 0, 0, 0);
+            }
+        }
+        // C/D of v_mfma_f64_16x16x4_f64: column = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+        for (int tj = 0; tj < Q; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * ti + lk + 4 * r, j = 16 * tj + li;
+                if (i < C && j < C) {
+                    const cd old = Gl[i * LS + j];
+                    emax = fmax(emax, hypot(re[tj][r] - old.x, im[tj][r] - old.y));
+                    G[((int64_t)p * E + i * C + j) * N + n] = make_double2(re[tj][r], im[tj][r]);
+                }
+            }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) emax = fmax(emax, __shfl_xor(emax, off));
+    if (lane == 0) red[wave] = emax;
+    __syncthreads();
+    if (tid == 0) {
+        const double e4 = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+        if (e4 > 0.0) mv_atomic_max_nonneg(err + p, e4);
+    }
+}
+
 __global__ void m_flags(int32_t* status, int32_t* n_iter, double* err, double tol, int64_t P, int32_t* n_running) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
@@ -507,6 +733,41 @@ static int mv_make_z2z(rocfft_plan* plan, rocfft_transform_type type, size_t N, 
         }                                                                                        \
     } while (0)
 
+#define MV_HIST 1024          // iterations whose "still running" counts the workspace logs (max_iterations <= this)
+#define MV_POLL 4             // iterations queued between two looks at the counts
+
+static size_t mv_gj_lds(int Q) {
+    const size_t CP = 16 * (size_t)Q;
+    return (CP * CP + 2 * CP + 2 * CP + CP) * sizeof(cd) + CP * sizeof(double) + 2 * CP * sizeof(int) + 64;
+}
+static int mv_launch_predict(int Q, dim3 grid, hipStream_t st, const cd* S, const cd* G, const int32_t* status, cd* A,
+                             int64_t N, int C) {
+    const size_t lds = mv_gj_lds(Q);
+#define MV_PRED(QQ)                                                                                          \
+    case QQ:                                                                                                 \
+        (void)hipFuncSetAttribute((const void*)m_predict_gj<QQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(m_predict_gj<QQ>, grid, dim3(256), lds, st, S, G, status, A, N, C);              \
+        break;
+    switch (Q) { MV_PRED(1) MV_PRED(2) MV_PRED(3) default: MV_PRED(4) }
+#undef MV_PRED
+    SC_CHECK_HIP(hipGetLastError());
+    return SC_OK;
+}
+static int mv_launch_update(int Q, dim3 grid, hipStream_t st, cd* G, const cd* Aplus, const int32_t* status, double* err,
+                            int64_t N, int C) {
+    const size_t CP = 16 * (size_t)Q;
+    const size_t lds = 2 * CP * (CP + 1) * sizeof(cd);
+#define MV_UPD(QQ)                                                                                           \
+    case QQ:                                                                                                 \
+        (void)hipFuncSetAttribute((const void*)m_update_mfma<QQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(m_update_mfma<QQ>, grid, dim3(256), lds, st, G, Aplus, status, err, N, C);       \
+        break;
+    switch (Q) { MV_UPD(1) MV_UPD(2) MV_UPD(3) default: MV_UPD(4) }
+#undef MV_UPD
+    SC_CHECK_HIP(hipGetLastError());
+    return SC_OK;
+}
+
 static int mv_threads(int C) {
     const int e = C * C;
     return e >= 256 ? 256 : (e > 128 ? 256 : (e > 64 ? 128 : 64));
@@ -520,7 +781,7 @@ extern "C" int sc_mvar_workspace_bytes(int64_t n_groups, int64_t C, int64_t N, s
     SC_REQUIRE(bytes && n_groups >= 1 && C >= 1 && N >= 2, "bad workspace query");
     const size_t E = (size_t)C * C, P = (size_t)n_groups, F = (size_t)N / 2 + 1;
     // factor: S, G, A series; measures: H, A_mvar natural + small per-window arrays
-    const size_t factor = 3 * P * E * (size_t)N * sizeof(cd) + P * 16 + 64;
+    const size_t factor = 3 * P * E * (size_t)N * sizeof(cd) + P * 16 + 64 + (size_t)MV_HIST * 4;
     const size_t meas = 2 * P * F * E * sizeof(cd) + P * E * 8 * 3 + P * F * 8 + P * (size_t)C * 8 + P * 8 + 256;
     *bytes = (factor > meas ? factor : meas) + 256;
     return SC_OK;
@@ -574,13 +835,12 @@ extern "C" int sc_mvar_factor_f64(const void* d_accum, const void* d_S, int64_t 
     size_t ws_f = 0, ws_i = 0;
     static int rocfft_ready = 0;
     if (!rocfft_ready) { rocfft_setup(); rocfft_ready = 1; }
-    const int nt = mv_threads((int)C);
-    const size_t lds = mv_pair_lds((int)C);
     const dim3 gridB((unsigned)N, (unsigned)P);
-    int iters = 0, running = (int)P;
+    int iters = 0, running = (int)P, queued = 0;
+    int32_t hist[MV_POLL];
     const bool fused = sc_internal_causal_fft_supported(N);
-    (void)hipFuncSetAttribute((const void*)m_predict, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)m_update, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int Q = (int)((C + 15) / 16);
+    if (max_iter > MV_HIST) max_iter = MV_HIST;
     if (!fused) {
         if ((rc = mv_make_z2z(&fwd, rocfft_transform_type_complex_forward, (size_t)N, (size_t)E * P)) != SC_OK) goto done;
         if ((rc = mv_make_z2z(&inv, rocfft_transform_type_complex_inverse, (size_t)N, (size_t)E * P)) != SC_OK) goto done;
@@ -589,34 +849,44 @@ extern "C" int sc_mvar_factor_f64(const void* d_accum, const void* d_S, int64_t 
         MV_CHECK_FFT(rocfft_execution_info_create(&info));
         if (ws_f < ws_i) ws_f = ws_i;
         if (ws_f) {
-            if (hipMalloc(&fft_work, ws_f) != hipSuccess) { sc_set_error("rocFFT work buffer alloc failed"); rc = SC_ENOMEM; goto done; }
+            if (hipMallocAsync(&fft_work, ws_f, st) != hipSuccess) { sc_set_error("rocFFT work buffer alloc failed"); rc = SC_ENOMEM; goto done; }
             MV_CHECK_FFT(rocfft_execution_info_set_work_buffer(info, fft_work, ws_f));
         }
         MV_CHECK_FFT(rocfft_execution_info_set_stream(info, st));
     }
     (void)hipMemsetAsync(err, 0, (size_t)P * 8, st);
     (void)hipMemsetAsync(d_n_iter, 0, (size_t)P * 4, st);
+    (void)hipMemsetAsync(n_running, 0, (size_t)MV_HIST * 4, st);
     hipLaunchKernelGGL(m_init, dim3((unsigned)P), dim3(256), (size_t)E * 8, st, S, G, d_status, N, (int)C);
-    for (iters = 0; iters < max_iter; ++iters) {
-        void* bufs[1] = {A};
-        hipLaunchKernelGGL(m_predict, gridB, dim3(nt), lds, st, S, G, d_status, A, N, (int)C);
-        if (fused) {        // ifft -> causal mask -> fft in one kernel (sc_wilson_fft.hip)
-            if ((rc = sc_internal_causal_fft_pair(A, d_status, P, (int)C, N, st)) != SC_OK) goto done;
-        } else {
-            MV_CHECK_FFT(rocfft_execute(inv, bufs, nullptr, info));
-            hipLaunchKernelGGL(m_causal, gridE, dim3(256), 0, st, A, N, (int)C);
-            MV_CHECK_FFT(rocfft_execute(fwd, bufs, nullptr, info));
+    // The stream is synchronised once per MV_POLL iterations: every iteration logs how many windows are still running
+    // into its own slot; converged windows are skipped by every kernel, so the iterations queued past the last
+    // convergence are empty launches.
+    while (queued < max_iter && running > 0) {
+        const int first = queued;
+        for (int b = 0; b < MV_POLL && queued < max_iter; ++b, ++queued) {
+            void* bufs[1] = {A};
+            if ((rc = mv_launch_predict(Q, gridB, st, S, G, d_status, A, N, (int)C)) != SC_OK) goto done;
+            if (fused) {        // ifft -> causal mask -> fft in one kernel (sc_wilson_fft.hip)
+                if ((rc = sc_internal_causal_fft_pair(A, d_status, P, (int)C, N, st)) != SC_OK) goto done;
+            } else {
+                MV_CHECK_FFT(rocfft_execute(inv, bufs, nullptr, info));
+                hipLaunchKernelGGL(m_causal, gridE, dim3(256), 0, st, A, N, (int)C);
+                MV_CHECK_FFT(rocfft_execute(fwd, bufs, nullptr, info));
+            }
+            if ((rc = mv_launch_update(Q, gridB, st, G, A, d_status, err, N, (int)C)) != SC_OK) goto done;
+            hipLaunchKernelGGL(m_flags, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, d_status, d_n_iter, err, tol, P,
+                               n_running + queued);
         }
-        hipLaunchKernelGGL(m_update, gridB, dim3(nt), lds, st, G, A, d_status, err, N, (int)C);
-        (void)hipMemsetAsync(n_running, 0, 4, st);
-        hipLaunchKernelGGL(m_flags, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, d_status, d_n_iter, err, tol, P,
-                           n_running);
-        if (hipMemcpyAsync(&running, n_running, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        if (hipMemcpyAsync(hist, n_running + first, (size_t)(queued - first) * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
             hipStreamSynchronize(st) != hipSuccess) {
-            sc_set_error("Wilson iteration %d: %s", iters, hipGetErrorString(hipGetLastError()));
+            sc_set_error("Wilson iterations %d..%d: %s", first, queued, hipGetErrorString(hipGetLastError()));
             rc = SC_EHIP; goto done;
         }
-        if (running == 0) { ++iters; break; }
+        for (int b = 0; b < queued - first; ++b) {
+            running = hist[b];
+            iters = first + b + 1;
+            if (running == 0) break;
+        }
     }
     hipLaunchKernelGGL(m_to_natural, gridE, dim3(256), 0, st, G, (cd*)d_G, N, E);
     if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) {
@@ -628,7 +898,7 @@ done:
     if (info) rocfft_execution_info_destroy(info);
     if (fwd) rocfft_plan_destroy(fwd);
     if (inv) rocfft_plan_destroy(inv);
-    if (fft_work) (void)hipFree(fft_work);
+    if (fft_work) (void)hipFreeAsync(fft_work, st);
     return rc;
 }
 

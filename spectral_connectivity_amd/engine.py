@@ -141,16 +141,24 @@ def twiddles(n_fft, device):
 
 
 def multitaper_spectra(x, tapers_over_fs, n_window, n_step, n_fft, n_windows, detrend_type, mark=None,
-                       use_fused=None):
+                       use_fused=None, n_signals=None):
     """Stage A on device: (T,R,C) float32 tensor -> DeviceSpectra [F][W][R][K][C].
 
     ``tapers_over_fs``: (K, L) float32 device tensor = reference tapers^T / fs
     (folds the sqrt(fs) of transforms.py:1440 and the /fs of transforms.py:1405).
+    ``n_signals``: number of real channels when ``x`` already carries the all-zero pad channel of an odd channel count
+    (appended on the host before the upload, transforms.Multitaper.device_spectra); a device tensor with an odd channel
+    count that arrives unpadded is copied into a padded buffer here (one strided device copy).
     """
     lib = _lib.load()
     T, R, C_real = x.shape
-    if C_real % 2 and C_real + 1 <= 128:
-        x = torch.nn.functional.pad(x, (0, 1))       # odd channel count: one zero channel (see DeviceSpectra)
+    if n_signals is not None:
+        assert n_signals in (C_real, C_real - 1)
+        C_real = int(n_signals)
+    elif C_real % 2 and C_real + 1 <= 128:
+        padded = torch.zeros((T, R, C_real + 1), dtype=x.dtype, device=x.device)
+        padded[..., :C_real].copy_(x)                # odd channel count: one zero channel (see DeviceSpectra)
+        x = padded
     T, R, C = x.shape
     K, L = tapers_over_fs.shape
     assert L == n_window

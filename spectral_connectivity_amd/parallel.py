@@ -132,7 +132,9 @@ def sharded_measures(spectra, planes, which, n_groups=4, dst=0, group=None, mark
     n_groups = max(1, min(int(n_groups), F))
     main = torch.cuda.current_stream()
     side = _side_stream(spectra.X.device) if world > 1 else main
-    parts = [[] for _ in which]
+    # the measures of every frequency range land in ONE preallocated [W, F, ...] tensor per measure on `dst` (a strided
+    # device copy per range), not in a list that is concatenated afterwards
+    result = [None for _ in which]
     n_local = spectra.R * spectra.K
     n_total = total_observations_equal(n_local, world) if equal_shards else total_observations(n_local, group)
     coll_events, bytes_reduced = [], 0
@@ -166,7 +168,11 @@ def sharded_measures(spectra, planes, which, n_groups=4, dst=0, group=None, mark
                     if timing is not None:
                         coll_events.append((t0, ev(side)))
                 if out is not None:
-                    parts[m].append(out.reshape(W, f1 - f0, *out.shape[1:]))
+                    if result[m] is None:
+                        result[m] = torch.empty((W, F) + tuple(out.shape[1:]), dtype=out.dtype, device=out.device)
+                        if world > 1:
+                            result[m].record_stream(main)       # filled on the exchange stream, used on the launch stream
+                    result[m][:, f0:f1].copy_(out.reshape(W, f1 - f0, *out.shape[1:]))
     tail0 = ev(main) if timing is not None else None
     if world > 1:
         main.wait_stream(side)
@@ -177,12 +183,6 @@ def sharded_measures(spectra, planes, which, n_groups=4, dst=0, group=None, mark
         timing.append(_LazyExchangeTiming(coll_events, tail0, tail1, bytes_reduced, n_groups))
     if rank != dst:
         return [None for _ in which]
-    result = []
-    for chunks in parts:
-        if world > 1:
-            for c in chunks:                  # produced on the side stream, consumed on the launch stream
-                c.record_stream(main)
-        result.append(chunks[0] if len(chunks) == 1 else torch.cat(chunks, dim=1))
     return result
 
 

@@ -527,11 +527,17 @@ class Multitaper:
                     x, h, self.n_time_samples_per_window, self.n_time_samples_per_step,
                     self.n_fft_samples, self.n_time_windows, self.detrend_type)
             else:
-                x = torch.from_numpy(np.ascontiguousarray(self.time_series, dtype=np.float32)).to(dev)
+                x_host = np.ascontiguousarray(self.time_series, dtype=np.float32)
+                n_signals = x_host.shape[2]
+                if n_signals % 2 and n_signals + 1 <= 128:
+                    # odd channel count: ONE all-zero channel is appended on the host, before the upload, so that the
+                    # rows of the spectra stay 16-byte aligned for the one-pass stage-B kernels (engine.DeviceSpectra)
+                    x_host = np.concatenate([x_host, np.zeros(x_host.shape[:2] + (1,), dtype=np.float32)], axis=2)
+                x = torch.from_numpy(x_host).to(dev)
                 h = torch.from_numpy(np.ascontiguousarray(tapers.T / self.sampling_frequency, dtype=np.float32)).to(dev)
                 self._device_spectra[precision] = engine.multitaper_spectra(
                     x, h, self.n_time_samples_per_window, self.n_time_samples_per_step,
-                    self.n_fft_samples, self.n_time_windows, self.detrend_type)
+                    self.n_fft_samples, self.n_time_windows, self.detrend_type, n_signals=n_signals)
         return self._device_spectra[precision]
 
     def fft(self):
