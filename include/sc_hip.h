@@ -318,8 +318,11 @@ int sc_wilson_factor_f64(const double* d_S, int64_t n_problems, int64_t N, doubl
  * sc_mvar_factor_f64: exactly one of d_accum (accumulator records holding SC_PLANE_CSM, N or N/2+1
  * bins per window, real-input symmetry completes the rest) and d_S (complex128 [P][N][C][C], two-sided
  * Hermitian spectra) is non-NULL.  d_G: complex128 [P][N][C][C].  d_status[p]: 1 converged, 0 not
- * converged after max_iterations, -1 lag-0 covariance not positive definite; h_summary =
- * {iterations run, windows still running}.  Synchronises the stream once per iteration.
+ * converged after max_iterations; h_summary = HOST int32[3] {iterations run, windows still running, windows whose
+ * lag-0 covariance was not positive definite and that started from the identity (see sc_granger_pairwise_f64)}.
+ * Synchronises the stream once per four iterations.  Per iteration: A = G^-1 S G^-H + I by a register-resident
+ * Gauss-Jordan elimination per (window, bin), the causal transform pair along frequency, G <- G A+ on the fp64
+ * matrix cores (v_mfma_f64_16x16x4_f64).
  * sc_mvar_measure_f64: d_G as above -> double [P][N/2+1][C][C] (SC_MVAR_DTF..DDTF), complex128
  * [P][N/2+1][C][C] (SC_MVAR_TRANSFER, SC_MVAR_COEFFICIENTS) or double [P][C][C] (NOISE_COVARIANCE).
  * The Tikhonov terms are the reference's: 1e-12 * mean(H0^2) over all windows, 1e-12 * mean(|H|^2)

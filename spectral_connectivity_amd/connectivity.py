@@ -319,14 +319,17 @@ class Connectivity:
         planes = _lib.PLANE_CSM
         accum, n_obs, n_freq = self._csm_records("granger")
         n_groups = accum.shape[0] // n_freq
-        G, n_iter, status, (iters, not_conv) = engine.mvar_factor(
+        G, n_iter, status, (iters, not_conv, fallback) = engine.mvar_factor(
             n_groups, N, C, accum=accum, n_freq_accum=n_freq, planes=planes, n_obs=self._n_observations_total(n_obs))
         st = status.cpu().numpy()
-        if (st < 0).any():
-            raise np.linalg.LinAlgError("lag-0 covariance of the cross-spectral matrix is not positive definite")
+        if fallback:
+            # reference minimum_phase_decomposition.py:78-93 (there the start is a random draw around the identity)
+            logger.warning("Computing the initial conditions using the Cholesky failed. "
+                           f"Using the identity as initial condition ({fallback} windows).")
         if not_conv:
             logger.warning(f"Maximum iterations reached. {st.size - not_conv} of {st.size} converged")
-        self._last_wilson = dict(iterations=iters, not_converged=not_conv, n_iter=n_iter.cpu().numpy(), status=st)
+        self._last_wilson = dict(iterations=iters, not_converged=not_conv, cholesky_fallbacks=fallback,
+                                 n_iter=n_iter.cpu().numpy(), status=st)
         self._mvar_G = G
         return G
 

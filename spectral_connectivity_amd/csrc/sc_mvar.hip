@@ -183,19 +183,29 @@ __global__ void m_to_natural(const cd* ser, cd* nat, int64_t N, int E) {
     if (n < N) nat[(p * N + n) * E + e] = ser[(p * E + e) * N + n];
 }
 
-// one block per window: R0 = Re mean_n S[n]; lower Cholesky; G0 = L^T for every n; status -1 if not PD
-__global__ void __launch_bounds__(256) m_init(const cd* S, cd* G, int32_t* status, int64_t N, int C) {
+// R0[p][e] = Re mean_n S[p][e][n]: one wave per series, lanes along n (unit stride)
+__global__ void __launch_bounds__(256) m_lag0(const cd* __restrict__ S, double* __restrict__ r0, int64_t N, int64_t n_series) {
+    const int64_t series = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (series >= n_series) return;
+    const int lane = threadIdx.x & 63;
+    const cd* s = S + series * N;
+    double a = 0.0;
+    for (int64_t n = lane; n < N; n += 64) a += s[n].x;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+    if (lane == 0) r0[series] = a / (double)N;
+}
+
+// one block per window: lower Cholesky of R0 in LDS, G0 = L^T written back over r0 (upper triangular, real); a lag-0
+// covariance that is not positive definite leaves the identity there (the expectation of the reference's random
+// Wishart start, minimum_phase_decomposition.py:78-93) and is counted in *n_fallback
+__global__ void __launch_bounds__(256) m_chol(double* __restrict__ r0g, int32_t* status, int32_t* n_fallback, int C) {
     extern __shared__ double r0[];        // [C][C]
     __shared__ int bad;
     const int64_t p = blockIdx.x;
     const int E = C * C;
     if (threadIdx.x == 0) bad = 0;
-    for (int e = threadIdx.x; e < E; e += blockDim.x) {
-        const cd* s = S + (p * E + e) * N;
-        double a = 0.0;
-        for (int64_t n = 0; n < N; ++n) a += s[n].x;
-        r0[e] = a / (double)N;
-    }
+    for (int e = threadIdx.x; e < E; e += blockDim.x) r0[e] = r0g[p * E + e];
     __syncthreads();
     for (int k = 0; k < C; ++k) {
         if (threadIdx.x == 0) {
@@ -214,13 +224,22 @@ __global__ void __launch_bounds__(256) m_init(const cd* S, cd* G, int32_t* statu
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) status[p] = bad ? -1 : 0;       // -1: not positive definite (LinAlgError)
-    for (int e = 0; e < E; ++e) {
-        const int i = e / C, j = e % C;
-        const double v = (j >= i) ? r0[j * C + i] : 0.0;   // upper triangular L^T
-        cd* g = G + (p * E + e) * N;
-        for (int64_t n = threadIdx.x; n < N; n += blockDim.x) g[n] = make_double2(v, 0.0);
+    if (threadIdx.x == 0) {
+        status[p] = 0;
+        if (bad) atomicAdd(n_fallback, 1);
     }
+    for (int e = threadIdx.x; e < E; e += blockDim.x) {
+        const int i = e / C, j = e % C;
+        r0g[p * E + e] = bad ? (i == j ? 1.0 : 0.0) : ((j >= i) ? r0[j * C + i] : 0.0);      // upper triangular L^T
+    }
+}
+
+// G[p][e][n] = G0[p][e] for every n
+__global__ void m_fill(const double* __restrict__ g0, cd* __restrict__ G, int64_t N, int E) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = blockIdx.y;
+    const int64_t p = blockIdx.z;
+    if (n < N) G[(p * E + e) * N + n] = make_double2(g0[p * E + e], 0.0);
 }
 
 __global__ void m_predict(const cd* S, const cd* G, const int32_t* status, cd* A, int64_t N, int C) {
@@ -314,6 +333,92 @@ __global__ void m_update(cd* G, const cd* Aplus, const int32_t* status, double* 
 // applied as COLUMN operations (column pr_k scaled by conj(1 / pivot), column r reduced by conj(m_r) times it) to the
 // block the thread already holds -- half the work of the first pass, multipliers read back from LDS (C^2 complex).
 // 2 syncs per step in the first pass, 1 in the second; 70 KB of LDS and ~180 registers: two workgroups per CU.
+// maximum of one unsigned per lane over the wave, as a scalar
+__device__ __forceinline__ unsigned mv_wave_max_u32(unsigned v) {
+    // inside each row of 16 lanes: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_ror:4, row_ror:8
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xF, 0xF, false));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, false));
+    const unsigned r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
+    const unsigned r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
+    return max(max(r0, r1), max(r2, r3));
+}
+
+// Pass 1 of the Gauss-Jordan elimination on the register-resident [G | S] (see m_predict_gj): row operations with
+// partial pivoting, multipliers / pivots / pivot rows logged in LDS.  All 256 threads of the workgroup must call.
+template <int Q>
+__device__ __forceinline__ void mv_gj_eliminate(cd (&g)[Q][Q], cd (&s)[Q][Q], cd* mult, cd* colbuf, cd* rowbuf, cd* pinv,
+                                                unsigned* key, int* prow, int* pos, int C) {
+    constexpr int CP = 16 * Q;
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15, lane = tid & 63;
+    unsigned used = 0;                                     // bit a: row ty + 16 a has been a pivot
+    if (tid < CP) pos[tid] = tid < C ? tid : 0;            // (only a NaN input leaves an entry at this default)
+#pragma unroll
+    for (int kb = 0; kb < Q; ++kb) {
+        for (int kx = 0; kx < 16; ++kx) {
+            const int k = 16 * kb + kx;
+            if (k >= C) break;
+            cd* cb = colbuf + (k & 1) * CP;
+            if (tx == kx) {
+#pragma unroll
+                for (int a = 0; a < Q; ++a) {
+                    const int r = ty + 16 * a;
+                    const cd v = g[a][kb];
+                    cb[r] = v;
+                    // key = leading 26 bits of |v|^2 (sign, exponent, 14 mantissa bits of the double: order preserving)
+                    // over 63 - row: the maximum is the largest candidate, the lowest row among near-ties
+                    const unsigned hi = (unsigned)(__double_as_longlong(v.x * v.x + v.y * v.y) >> 32);
+                    key[r] = (((used >> a) & 1u) || r >= C) ? 0u : (((hi & ~63u) | (unsigned)(63 - r)) | 0x40u);
+                }
+            }
+            __syncthreads();
+            // pivot row: maximum key over the candidate rows, found by every wave for itself (CP <= 64: one key per
+            // lane): four DPP steps inside each row of 16 lanes, then the four row maxima through scalar registers
+            const int pr = 63 - (int)(mv_wave_max_u32(lane < CP ? key[lane] : 0u) & 63u);
+            const cd piv = cb[pr];
+            const double pden = piv.x * piv.x + piv.y * piv.y;
+            const cd inv = make_double2(piv.x / pden, -piv.y / pden);
+            if (ty == (pr & 15)) {         // one wave in four: the owners scale the pivot row in place and publish it
+#pragma unroll
+                for (int a = 0; a < Q; ++a)
+                    if (ty + 16 * a == pr) {
+#pragma unroll
+                        for (int b = 0; b < Q; ++b) {
+                            g[a][b] = m_mul(g[a][b], inv);
+                            s[a][b] = m_mul(s[a][b], inv);
+                            rowbuf[tx + 16 * b] = g[a][b];
+                            rowbuf[CP + tx + 16 * b] = s[a][b];
+                        }
+                        used |= 1u << a;
+                    }
+            }
+            if (tid == 0) { prow[k] = pr; pinv[k] = inv; pos[pr] = k; }
+            __syncthreads();
+            cd wg[Q], ws[Q];
+#pragma unroll
+            for (int b = 0; b < Q; ++b) { wg[b] = rowbuf[tx + 16 * b]; ws[b] = rowbuf[CP + tx + 16 * b]; }
+#pragma unroll
+            for (int a = 0; a < Q; ++a) {
+                const int r = ty + 16 * a;
+                cd m = cb[r];
+                if (r == pr) m = make_double2(0.0, 0.0);
+                if (tx == 0) mult[k * CP + r] = m;
+#pragma unroll
+                for (int b = 0; b < Q; ++b) {
+                    if (b >= kb) {      // columns tx + 16 b with b < kb were eliminated in earlier blocks: the pivot row is 0 there
+                        g[a][b].x = fma(-m.x, wg[b].x, fma(m.y, wg[b].y, g[a][b].x));
+                        g[a][b].y = fma(-m.x, wg[b].y, fma(-m.y, wg[b].x, g[a][b].y));
+                    }
+                    s[a][b].x = fma(-m.x, ws[b].x, fma(m.y, ws[b].y, s[a][b].x));
+                    s[a][b].y = fma(-m.x, ws[b].y, fma(-m.y, ws[b].x, s[a][b].y));
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
 template <int Q>
 __global__ void __launch_bounds__(256, 2) m_predict_gj(const cd* __restrict__ S, const cd* __restrict__ G,
                                                        const int32_t* __restrict__ status, cd* __restrict__ A,
@@ -324,8 +429,8 @@ __global__ void __launch_bounds__(256, 2) m_predict_gj(const cd* __restrict__ S,
     cd* colbuf = mult + CP * CP;                           // [2][CP]  column k (double buffered)
     cd* rowbuf = colbuf + 2 * CP;                          // [2 CP]   scaled pivot row of G, then of S
     cd* pinv = rowbuf + 2 * CP;                            // [CP]     1 / pivot of step k
-    double* mag = reinterpret_cast<double*>(pinv + CP);    // [CP]     |column k|^2, -1 for rows that were pivots
-    int* prow = reinterpret_cast<int*>(mag + CP);          // [CP]     pivot row of step k
+    unsigned* key = reinterpret_cast<unsigned*>(pinv + CP);   // [CP]  pivot-search keys of column k (0: row not a candidate)
+    int* prow = reinterpret_cast<int*>(key + 2 * CP);      // [CP]     pivot row of step k
     int* pos = prow + CP;                                  // [CP]     step at which row r was the pivot
     const int64_t n = blockIdx.x, p = blockIdx.y;
     if (status[p] != 0) return;
@@ -345,75 +450,7 @@ __global__ void __launch_bounds__(256, 2) m_predict_gj(const cd* __restrict__ S,
                 s[a][b] = make_double2(0.0, 0.0);
             }
         }
-    unsigned used = 0;                                     // bit a: row ty + 16 a has been a pivot
-    if (tid < CP) pos[tid] = tid < C ? tid : 0;            // (only a NaN input leaves an entry at this default)
-    // ---- pass 1: row operations on [G | S] ----
-#pragma unroll
-    for (int kb = 0; kb < Q; ++kb) {
-        for (int kx = 0; kx < 16; ++kx) {
-            const int k = 16 * kb + kx;
-            if (k >= C) break;
-            cd* cb = colbuf + (k & 1) * CP;
-            if (tx == kx) {
-#pragma unroll
-                for (int a = 0; a < Q; ++a) {
-                    const int r = ty + 16 * a;
-                    const cd v = g[a][kb];
-                    cb[r] = v;
-                    mag[r] = (((used >> a) & 1u) || r >= C) ? -1.0 : v.x * v.x + v.y * v.y;
-                }
-            }
-            __syncthreads();
-            // pivot row: arg max over the candidate rows, found by every wave for itself (CP <= 64 = one per lane)
-            double best = lane < CP ? mag[lane] : -1.0;
-            int pr = lane;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const double ob = __shfl_xor(best, off);
-                const int oi = __shfl_xor(pr, off);
-                if (ob > best || (ob == best && oi < pr)) { best = ob; pr = oi; }
-            }
-            const cd piv = cb[pr];
-            const double pden = piv.x * piv.x + piv.y * piv.y;
-            const cd inv = make_double2(piv.x / pden, -piv.y / pden);
-            if (ty == (pr & 15)) {
-#pragma unroll
-                for (int a = 0; a < Q; ++a)
-                    if (ty + 16 * a == pr) {
-#pragma unroll
-                        for (int b = 0; b < Q; ++b) {
-                            rowbuf[tx + 16 * b] = m_mul(g[a][b], inv);
-                            rowbuf[CP + tx + 16 * b] = m_mul(s[a][b], inv);
-                        }
-                    }
-            }
-            if (tid == 0) { prow[k] = pr; pinv[k] = inv; pos[pr] = k; }
-            __syncthreads();
-            cd wg[Q], ws[Q];
-#pragma unroll
-            for (int b = 0; b < Q; ++b) { wg[b] = rowbuf[tx + 16 * b]; ws[b] = rowbuf[CP + tx + 16 * b]; }
-#pragma unroll
-            for (int a = 0; a < Q; ++a) {
-                const int r = ty + 16 * a;
-                cd m = cb[r];
-                if (r == pr) m = make_double2(0.0, 0.0);
-                if (tx == 0) mult[k * CP + r] = m;
-#pragma unroll
-                for (int b = 0; b < Q; ++b) {
-                    g[a][b].x = fma(-m.x, wg[b].x, fma(m.y, wg[b].y, g[a][b].x));
-                    g[a][b].y = fma(-m.x, wg[b].y, fma(-m.y, wg[b].x, g[a][b].y));
-                    s[a][b].x = fma(-m.x, ws[b].x, fma(m.y, ws[b].y, s[a][b].x));
-                    s[a][b].y = fma(-m.x, ws[b].y, fma(-m.y, ws[b].x, s[a][b].y));
-                }
-                if (r == pr) {
-#pragma unroll
-                    for (int b = 0; b < Q; ++b) { g[a][b] = wg[b]; s[a][b] = ws[b]; }
-                    used |= 1u << a;
-                }
-            }
-        }
-    }
-    __syncthreads();
+    mv_gj_eliminate<Q>(g, s, mult, colbuf, rowbuf, pinv, key, prow, pos, C);
     // ---- pass 2: the same elimination as column operations on Y' (held in s) ----
     for (int k = 0; k < C; ++k) {
         const int pr = prow[k];
@@ -457,6 +494,48 @@ __global__ void __launch_bounds__(256, 2) m_predict_gj(const cd* __restrict__ S,
                 if (i == j) v.x += 1.0;
                 A[((int64_t)p * E + i * C + j) * N + n] = v;
             }
+        }
+}
+
+// out[b] = (M[b] + lam I)^-1 for natural-layout C x C matrices M[b][e] (A_mvar = (H + lam' I)^-1, connectivity.py:581-589):
+// the same register-resident elimination with the identity as right-hand side; row pr_k of it holds row k of the inverse
+template <int Q>
+__global__ void __launch_bounds__(256, 2) m_inverse_gj(const cd* __restrict__ M, const double* __restrict__ lam,
+                                                       cd* __restrict__ out, int C) {
+    constexpr int CP = 16 * Q;
+    extern __shared__ __align__(16) unsigned char mv_smem[];
+    cd* mult = reinterpret_cast<cd*>(mv_smem);
+    cd* colbuf = mult + CP * CP;
+    cd* rowbuf = colbuf + 2 * CP;
+    cd* pinv = rowbuf + 2 * CP;
+    unsigned* key = reinterpret_cast<unsigned*>(pinv + CP);
+    int* prow = reinterpret_cast<int*>(key + 2 * CP);
+    int* pos = prow + CP;
+    const int64_t bidx = blockIdx.x;
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    const int E = C * C;
+    const double l0 = lam[0];
+    cd g[Q][Q], s[Q][Q];
+#pragma unroll
+    for (int a = 0; a < Q; ++a)
+#pragma unroll
+        for (int b = 0; b < Q; ++b) {
+            const int r = ty + 16 * a, c = tx + 16 * b;
+            if (r < C && c < C) {
+                g[a][b] = M[bidx * E + r * C + c];
+                if (r == c) g[a][b].x += l0;
+            } else {
+                g[a][b] = make_double2(r == c ? 1.0 : 0.0, 0.0);
+            }
+            s[a][b] = make_double2(r == c ? 1.0 : 0.0, 0.0);
+        }
+    mv_gj_eliminate<Q>(g, s, mult, colbuf, rowbuf, pinv, key, prow, pos, C);
+#pragma unroll
+    for (int a = 0; a < Q; ++a)
+#pragma unroll
+        for (int b = 0; b < Q; ++b) {
+            const int r = ty + 16 * a, c = tx + 16 * b;
+            if (r < C && c < C) out[bidx * E + pos[r] * C + c] = s[a][b];
         }
 }
 
@@ -536,17 +615,19 @@ __global__ void m_flags(int32_t* status, int32_t* n_iter, double* err, double to
 }
 
 // ---- measures -----------------------------------------------------------------------------------
-// one block per window: H0 = Re mean_n G[n] (natural layout [p][n][e]); partial sum of H0^2
+// H0 = Re mean_n G[n] (natural layout [p][n][e]: threads along e read unit stride); partial sums of H0^2 per block:
+// grid (P, n_chunks), chunk c covers elements [256 c, 256 c + 256)
 __global__ void __launch_bounds__(256) m_h0(const cd* G, double* h0, double* sq, int64_t N, int E) {
     __shared__ double red[256];
     const int64_t p = blockIdx.x;
+    const int e = blockIdx.y * 256 + threadIdx.x;
     double s2 = 0.0;
-    for (int e = threadIdx.x; e < E; e += blockDim.x) {
+    if (e < E) {
         double a = 0.0;
         for (int64_t n = 0; n < N; ++n) a += G[(p * N + n) * E + e].x;
         a /= (double)N;
         h0[p * E + e] = a;
-        s2 += a * a;
+        s2 = a * a;
     }
     red[threadIdx.x] = s2;
     __syncthreads();
@@ -554,7 +635,7 @@ __global__ void __launch_bounds__(256) m_h0(const cd* G, double* h0, double* sq,
         if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x == 0) sq[p] = red[0];
+    if (threadIdx.x == 0) sq[p * gridDim.y + blockIdx.y] = red[0];
 }
 
 // serial, fixed-order sum of a short array (per-window / per-bin partials): out[0] = scale * sum
@@ -738,7 +819,7 @@ static int mv_make_z2z(rocfft_plan* plan, rocfft_transform_type type, size_t N, 
 
 static size_t mv_gj_lds(int Q) {
     const size_t CP = 16 * (size_t)Q;
-    return (CP * CP + 2 * CP + 2 * CP + CP) * sizeof(cd) + CP * sizeof(double) + 2 * CP * sizeof(int) + 64;
+    return (CP * CP + 2 * CP + 2 * CP + CP) * sizeof(cd) + 2 * CP * sizeof(unsigned) + 2 * CP * sizeof(int) + 64;
 }
 static int mv_launch_predict(int Q, dim3 grid, hipStream_t st, const cd* S, const cd* G, const int32_t* status, cd* A,
                              int64_t N, int C) {
@@ -781,8 +862,8 @@ extern "C" int sc_mvar_workspace_bytes(int64_t n_groups, int64_t C, int64_t N, s
     SC_REQUIRE(bytes && n_groups >= 1 && C >= 1 && N >= 2, "bad workspace query");
     const size_t E = (size_t)C * C, P = (size_t)n_groups, F = (size_t)N / 2 + 1;
     // factor: S, G, A series; measures: H, A_mvar natural + small per-window arrays
-    const size_t factor = 3 * P * E * (size_t)N * sizeof(cd) + P * 16 + 64 + (size_t)MV_HIST * 4;
-    const size_t meas = 2 * P * F * E * sizeof(cd) + P * E * 8 * 3 + P * F * 8 + P * (size_t)C * 8 + P * 8 + 256;
+    const size_t factor = 3 * P * E * (size_t)N * sizeof(cd) + P * 16 + P * E * 8 + 128 + (size_t)MV_HIST * 4;
+    const size_t meas = 2 * P * F * E * sizeof(cd) + P * E * 8 * 3 + P * (F > 16 ? F : 16) * 8 + P * (size_t)C * 8 + P * 8 + 256;
     *bytes = (factor > meas ? factor : meas) + 256;
     return SC_OK;
 }
@@ -812,6 +893,8 @@ extern "C" int sc_mvar_factor_f64(const void* d_accum, const void* d_S, int64_t 
     cd* G = (cd*)w; w += (size_t)P * E * N * sizeof(cd);
     cd* A = (cd*)w; w += (size_t)P * E * N * sizeof(cd);
     double* err = (double*)w; w += (size_t)P * 8;
+    double* g0 = (double*)w; w += (size_t)P * E * 8;
+    int32_t* n_fallback = (int32_t*)w; w += 64;
     int32_t* n_running = (int32_t*)w;
     const dim3 gridE((unsigned)((N + 255) / 256), (unsigned)E, (unsigned)P);
     if (d_accum) {
@@ -856,8 +939,11 @@ extern "C" int sc_mvar_factor_f64(const void* d_accum, const void* d_S, int64_t 
     }
     (void)hipMemsetAsync(err, 0, (size_t)P * 8, st);
     (void)hipMemsetAsync(d_n_iter, 0, (size_t)P * 4, st);
-    (void)hipMemsetAsync(n_running, 0, (size_t)MV_HIST * 4, st);
-    hipLaunchKernelGGL(m_init, dim3((unsigned)P), dim3(256), (size_t)E * 8, st, S, G, d_status, N, (int)C);
+    (void)hipMemsetAsync(n_fallback, 0, 64 + (size_t)MV_HIST * 4, st);
+    // G0 = chol(Re ifft_n(S)[lag 0])^H broadcast over the bins (minimum_phase_decomposition.py:48-77)
+    hipLaunchKernelGGL(m_lag0, dim3((unsigned)(((int64_t)P * E + 3) / 4)), dim3(256), 0, st, S, g0, N, (int64_t)P * E);
+    hipLaunchKernelGGL(m_chol, dim3((unsigned)P), dim3(256), (size_t)E * 8, st, g0, d_status, n_fallback, (int)C);
+    hipLaunchKernelGGL(m_fill, gridE, dim3(256), 0, st, g0, G, N, E);
     // The stream is synchronised once per MV_POLL iterations: every iteration logs how many windows are still running
     // into its own slot; converged windows are skipped by every kernel, so the iterations queued past the last
     // convergence are empty launches.
@@ -893,7 +979,11 @@ extern "C" int sc_mvar_factor_f64(const void* d_accum, const void* d_S, int64_t 
         sc_set_error("Wilson factor copy-out failed: %s", hipGetErrorString(hipGetLastError()));
         rc = SC_EHIP; goto done;
     }
-    if (h_summary) { h_summary[0] = iters; h_summary[1] = running; }
+    if (h_summary) {
+        int fb = 0;
+        (void)hipMemcpy(&fb, n_fallback, 4, hipMemcpyDeviceToHost);      // the stream was synchronised just above
+        h_summary[0] = iters; h_summary[1] = running; h_summary[2] = fb;
+    }
 done:
     if (info) rocfft_execution_info_destroy(info);
     if (fwd) rocfft_plan_destroy(fwd);
@@ -927,7 +1017,7 @@ extern "C" int sc_mvar_measure_f64(const void* d_G, int64_t n_groups, int64_t N,
     double* h0 = (double*)w; w += (size_t)P * E * 8;
     double* hinv = (double*)w; w += (size_t)P * E * 8;
     double* sigma = (double*)w; w += (size_t)P * E * 8;
-    double* sq = (double*)w; w += (size_t)P * F * 8;
+    double* sq = (double*)w; w += (size_t)P * (F > 16 ? F : 16) * 8;      // per (window, bin) or per (window, 256-element chunk)
     double* tot = (double*)w; w += (size_t)P * C * 8;
     double* lam = (double*)w;                         // [0] lam of H0, [1] lam' of H
     const int nt = mv_threads((int)C);
@@ -936,8 +1026,9 @@ extern "C" int sc_mvar_measure_f64(const void* d_G, int64_t n_groups, int64_t N,
     (void)hipFuncSetAttribute((const void*)m_transfer, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)m_mvar_inverse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const cd* G = (const cd*)d_G;
-    hipLaunchKernelGGL(m_h0, dim3((unsigned)P), dim3(256), 0, st, G, h0, sq, N, E);
-    hipLaunchKernelGGL(m_sum, dim3(1), dim3(64), 0, st, sq, P, 1e-12 / (double)(P * E), lam);
+    const int h0_chunks = (E + 255) / 256;
+    hipLaunchKernelGGL(m_h0, dim3((unsigned)P, (unsigned)h0_chunks), dim3(256), 0, st, G, h0, sq, N, E);
+    hipLaunchKernelGGL(m_sum, dim3(1), dim3(64), 0, st, sq, P * h0_chunks, 1e-12 / (double)(P * E), lam);
     hipLaunchKernelGGL(m_h0_inverse, dim3((unsigned)P), dim3(nt), lds, st, h0, lam, hinv, sigma, (int)C);
     if (which == SC_MVAR_NOISE_COVARIANCE) {
         SC_CHECK_HIP(hipMemcpyAsync(d_out, sigma, (size_t)P * E * 8, hipMemcpyDeviceToDevice, st));
@@ -951,7 +1042,17 @@ extern "C" int sc_mvar_measure_f64(const void* d_G, int64_t n_groups, int64_t N,
         return SC_OK;
     }
     hipLaunchKernelGGL(m_sum, dim3(1), dim3(64), 0, st, sq, P * F, 1e-12 / (double)(P * F * E), lam + 1);
-    hipLaunchKernelGGL(m_mvar_inverse, dim3((unsigned)(P * F)), dim3(nt), lds, st, H, lam + 1, Amv, (int)C);
+    {
+        const int Q = (int)((C + 15) / 16);
+        const size_t glds = mv_gj_lds(Q);
+#define MV_INV(QQ)                                                                                              \
+    case QQ:                                                                                                    \
+        (void)hipFuncSetAttribute((const void*)m_inverse_gj<QQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds); \
+        hipLaunchKernelGGL(m_inverse_gj<QQ>, dim3((unsigned)(P * F)), dim3(256), glds, st, H, lam + 1, Amv, (int)C); \
+        break;
+        switch (Q) { MV_INV(1) MV_INV(2) MV_INV(3) default: MV_INV(4) }
+#undef MV_INV
+    }
     if (which == SC_MVAR_COEFFICIENTS) {
         SC_CHECK_HIP(hipMemcpyAsync(d_out, Amv, (size_t)P * F * E * sizeof(cd), hipMemcpyDeviceToDevice, st));
         SC_CHECK_HIP(hipStreamSynchronize(st));

@@ -420,13 +420,13 @@ def mvar_factor(n_groups, n_fft, n_signals, accum=None, n_freq_accum=0, planes=0
     G = torch.empty((n_groups, n_fft, n_signals, n_signals), dtype=torch.complex128, device=dev)
     n_iter = torch.empty((n_groups,), dtype=torch.int32, device=dev)
     status = torch.empty((n_groups,), dtype=torch.int32, device=dev)
-    summary = (ctypes.c_int32 * 2)(0, 0)
+    summary = (ctypes.c_int32 * 3)(0, 0, 0)
     _lib.check(lib.sc_mvar_factor_f64(_ptr(accum) if accum is not None else None,
                                       _ptr(spectra) if spectra is not None else None, n_groups, n_freq_accum, n_fft,
                                       n_signals, rec_planes(accum, planes) if accum is not None else planes, n_obs,
                                       tolerance, max_iterations, _ptr(work), nbytes, _ptr(G),
                                       _ptr(n_iter), _ptr(status), summary, _stream()), "sc_mvar_factor_f64")
-    return G, n_iter, status, (summary[0], summary[1])
+    return G, n_iter, status, (summary[0], summary[1], summary[2])
 
 
 def mvar_measure(G, which):

@@ -49,12 +49,15 @@ def minimum_phase_decomposition(cross_spectral_matrix, tolerance=1e-8, max_itera
         step = 4096
         for p0 in range(0, P, step):
             n = min(step, P - p0)
-            G, _, status, (_, not_conv) = engine.mvar_factor(n, N, c, spectra=torch.from_numpy(flat[p0:p0 + n]).to(dev),
-                                                             tolerance=tolerance, max_iterations=max_iterations)
+            G, _, status, (_, not_conv, fallback) = engine.mvar_factor(
+                n, N, c, spectra=torch.from_numpy(flat[p0:p0 + n]).to(dev), tolerance=tolerance,
+                max_iterations=max_iterations)
+            if fallback:
+                logger.warning("Computing the initial conditions using the Cholesky failed. "
+                               f"Using the identity as initial condition ({fallback} problems).")
             if not_conv:
                 logger.warning(f"Maximum iterations reached. {n - not_conv} of {n} converged")
             out[p0:p0 + n] = G.cpu().numpy()
-            out[p0:p0 + n][status.cpu().numpy() < 0] = np.nan
         return out.reshape(csm.shape)
     flat = csm.reshape(P, N, c, c).astype(np.complex128)
     S = np.empty((P, 4, N), dtype=np.float64)
