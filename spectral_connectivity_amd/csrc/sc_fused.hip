@@ -56,6 +56,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define FU_OC 32            // observation rows per chunk (= K of the bf16 MFMA)
 #define FU_THREADS 768
@@ -69,8 +70,23 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
                             // of a channel sit within the 8-bit offsets of ds_read2_b64 -- one address add
                             // per 16-channel fragment set instead of one per plane on this VALU-bound kernel
 
+// Which channels a workgroup stages and where its tiles live in the record.  The 128 staged channel slots are two
+// halves of 64: the first holds n0 channels starting at st.base, the second n1 channels starting ch1 elements further
+// (64: one contiguous range -- every launch up to 128 channels).  Local 16-channel tile b < 4 is tile t0 + b of the
+// record, b >= 4 tile t1 + (b - 4); NBr = tile rows of the record.  129 ... 256 channels are covered by several
+// launches over 64-channel quarters (see fused_run): contiguous ranges for the diagonal part, a quarter of the first
+// half paired with one of the second (cross = 1: only the tiles BETWEEN the two halves) for the rest.
+struct FuMap {
+    int n0, n1, ch1;
+    int t0, t1, nb0, nb1, NBr;
+    int cross;
+};
+__host__ __device__ inline int fu_gt(const FuMap& m, int b) { return b < 4 ? m.t0 + b : m.t1 + (b - 4); }
+__host__ __device__ inline bool fu_tile_ok(const FuMap& m, int b) { return b < 4 ? b < m.nb0 : (b - 4) < m.nb1; }
+
 struct FusedArgs {
     ScStage st;
+    FuMap map;
     float* accum;
     int64_t floats_per_bin;
     int n_bins, F, NB, n_tiles, NB32, n_blocks32, n_sets;
@@ -120,17 +136,19 @@ __device__ __forceinline__ int fu_lane() {
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
     return l;
 }
-__device__ __forceinline__ void fu_fetch(const ScStage& st, float* raw, int o0, int vw) {
+__device__ __forceinline__ void fu_fetch(const ScStage& st, const FuMap& mp, float* raw, int o0, int vw) {
     const int lane = fu_lane();
     const int c = 2 * lane;
+    const bool have = lane < 32 ? c < mp.n0 : c - 64 < mp.n1;            // this lane's channel pair exists
+    const int goff = lane < 32 ? c : mp.ch1 + (c - 64);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int row = 4 * vw + k, o = o0 + row;
         float* dst = raw + row * FU_RAW_ROW;             // wave-uniform
         if (o < st.n_obs) {
-            if (c < st.C)
+            if (have)
                 __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void*)(st.base + sc_stage_obs_offset(st, o) + c),
+                    (const __attribute__((address_space(1))) void*)(st.base + sc_stage_obs_offset(st, o) + goff),
                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         } else {
             *reinterpret_cast<float4*>(dst + 4 * lane) = make_float4(0.f, 0.f, 0.f, 0.f);   // rows past n_obs
@@ -176,29 +194,29 @@ __device__ __forceinline__ void fu_split(const float* raw, unsigned short* plane
 // Prologue of a staging wave (quad vw): clear its raw rows (slots of absent channels stay zero for
 // good), fetch and stage chunk 0, put chunk 1 in flight.
 template <int NB32>
-__device__ __forceinline__ void fu_stage_first(const ScStage& st, float* raw, unsigned short* planes, int vw,
+__device__ __forceinline__ void fu_stage_first(const ScStage& st, const FuMap& mp, float* raw, unsigned short* planes, int vw,
                                                int o_lo, int n_chunks, bool loads) {
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         *reinterpret_cast<float4*>(raw + (4 * vw + k) * FU_RAW_ROW + 4 * fu_lane()) = make_float4(0.f, 0.f, 0.f, 0.f);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    fu_fetch(st, raw, o_lo, vw);       // (debug "no HBM loads" keeps re-using this chunk: realistic operand values)
+    fu_fetch(st, mp, raw, o_lo, vw);   // (debug "no HBM loads" keeps re-using this chunk: realistic operand values)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     fu_split<NB32>(raw, planes, vw);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (n_chunks > 1 && loads) fu_fetch(st, raw, o_lo + FU_OC, vw);
+    if (n_chunks > 1 && loads) fu_fetch(st, mp, raw, o_lo + FU_OC, vw);
 }
 
 // Stage chunk ch + 1 into the other plane buffer, then put the loads of chunk ch + 2 in flight.
 template <int NB32>
-__device__ __forceinline__ void fu_stage_next(const ScStage& st, float* raw, unsigned short* planes, int vw,
+__device__ __forceinline__ void fu_stage_next(const ScStage& st, const FuMap& mp, float* raw, unsigned short* planes, int vw,
                                               int o_lo, int ch, int n_chunks, bool loads) {
     constexpr int buf_elems = NB32 * 32 * FU_CSTRIDE;
     if (ch + 1 < n_chunks) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // raw rows of chunk ch + 1 landed
         fu_split<NB32>(raw, planes + ((ch + 1) & 1) * buf_elems, vw);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // raw rows read before the refill
-        if (ch + 2 < n_chunks && loads) fu_fetch(st, raw, o_lo + (ch + 2) * FU_OC, vw);
+        if (ch + 2 < n_chunks && loads) fu_fetch(st, mp, raw, o_lo + (ch + 2) * FU_OC, vw);
     }
 }
 
@@ -250,10 +268,14 @@ __device__ __forceinline__ void fused_mfma_role(const FusedArgs& p, const ScStag
     constexpr int MAXS = 2 * NB32 + 1;
     const int lane = tid & 63;
     const int NB = p.NB;
-    const int rA_ = wave, rB_ = NB - 1 - wave;
-    const int nA_ = (rA_ <= rB_) ? NB - rA_ : 0;      // tiles in row rA (0: this wave has no tiles)
-    const int nB_ = (rB_ > rA_) ? NB - rB_ : 0;
+    // triangular launches: wave w owns tile rows w and NB-1-w; cross launches: row w of the first half against the
+    // tiles 4 ... 4 + nb1 - 1 of the second
+    const bool cross = p.map.cross != 0;
+    const int rA_ = wave, rB_ = cross ? NB : NB - 1 - wave;
+    const int nA_ = cross ? (wave < p.map.nb0 ? p.map.nb1 : 0) : ((rA_ <= rB_) ? NB - rA_ : 0);   // tiles in row rA
+    const int nB_ = (!cross && rB_ > rA_) ? NB - rB_ : 0;
     const int total = nA_ + nB_;
+    const int cA_ = cross ? 4 : rA_;                  // first tile column of row rA
     f32x4 re[MAXS], im[MAXS];
 #pragma unroll
     for (int s = 0; s < MAXS; ++s) { re[s] = (f32x4){0.f, 0.f, 0.f, 0.f}; im[s] = re[s]; }
@@ -267,7 +289,7 @@ __device__ __forceinline__ void fused_mfma_role(const FusedArgs& p, const ScStag
     const bool loads = !(p.debug_skip & 8);
     const bool csm_stages = p.abs_plane >= 0;       // CSM only: the eight other waves have nothing else to do
     const bool do_csm = p.csm_plane >= 0 && (p.debug_skip & 1) == 0;      // plane passes: staging only
-    if (csm_stages) fu_stage_first<NB32>(st, raw, planes, wave, o_lo, n_chunks, loads);
+    if (csm_stages) fu_stage_first<NB32>(st, p.map, raw, planes, wave, o_lo, n_chunks, loads);
     FU_BARRIER();                 // chunk 0 staged
     FU_T0();
     for (int ch = 0; ch < n_chunks; ++ch) {
@@ -275,12 +297,12 @@ __device__ __forceinline__ void fused_mfma_role(const FusedArgs& p, const ScStag
         if (do_csm && total > 0) {
             // opaque per-chunk copies: otherwise ~2 loop-invariant address VGPRs per tile stay live
             // across the chunk loop and spill at the 168-register budget
-            int rA = rA_, rB = rB_, nA = nA_;
-            asm volatile("" : "+s"(rA), "+s"(rB), "+s"(nA));
+            int rA = rA_, rB = rB_, nA = nA_, cA = cA_;
+            asm volatile("" : "+s"(rA), "+s"(rB), "+s"(nA), "+s"(cA));
             bf16x8 arh, arm, arl, aih, aim, ail, nrh, nrm, nrl;     // A fragments of the current row (and -Re)
             bf16x8 brh[2], bih[2];                                  // first B fragments, prefetched one tile
             {                                                       // ahead into the other register set
-                const unsigned short* fb = frag0 + rA * 16 * FU_CSTRIDE;   // first tile (rA, rA)
+                const unsigned short* fb = frag0 + cA * 16 * FU_CSTRIDE;   // first tile (rA, cA)
                 brh[0] = FU_LD(fb, 0); bih[0] = FU_LD(fb, 3);
             }
 #pragma unroll
@@ -288,7 +310,7 @@ __device__ __forceinline__ void fused_mfma_role(const FusedArgs& p, const ScStag
                 if (s < total) {
                     const bool in_a = s < nA;
                     const int row = in_a ? rA : rB;
-                    const int col = row + (in_a ? s : s - nA);
+                    const int col = in_a ? cA + s : rB + (s - nA);
                     if (s == 0 || s == nA) {
                         const unsigned short* fa = frag0 + row * 16 * FU_CSTRIDE;
                         arh = FU_LD(fa, 0); arm = FU_LD(fa, 1); arl = FU_LD(fa, 2);
@@ -301,7 +323,7 @@ __device__ __forceinline__ void fused_mfma_role(const FusedArgs& p, const ScStag
                     const bf16x8& cbih = bih[s & 1];
                     if (s + 1 < total) {      // prefetch the next tile's first fragments
                         const bool na = (s + 1) < nA;
-                        const int ncol = (na ? rA : rB) + (na ? s + 1 : s + 1 - nA);
+                        const int ncol = na ? cA + s + 1 : rB + (s + 1 - nA);
                         const unsigned short* fn = frag0 + ncol * 16 * FU_CSTRIDE;
                         brh[(s + 1) & 1] = FU_LD(fn, 0); bih[(s + 1) & 1] = FU_LD(fn, 3);
                     }
@@ -325,7 +347,7 @@ __device__ __forceinline__ void fused_mfma_role(const FusedArgs& p, const ScStag
         }
         FU_TICK(1);
         // stage chunk ch + 1 into the other buffer, then put the loads of chunk ch + 2 in flight
-        if (csm_stages) fu_stage_next<NB32>(st, raw, planes, wave, o_lo, ch, n_chunks, loads);
+        if (csm_stages) fu_stage_next<NB32>(st, p.map, raw, planes, wave, o_lo, ch, n_chunks, loads);
         FU_TICK(0);
         // Two-level summation: every FU_FLUSH chunks (512 observations) the f32 accumulators of a tile
         // are folded into the output record (owned by this wave, L2-resident) and cleared, so no f32
@@ -342,12 +364,12 @@ __device__ __forceinline__ void fused_mfma_role(const FusedArgs& p, const ScStag
                     const bool first = ch <= f_s;
                     const bool in_a = s < nA_;
                     const int row = in_a ? rA_ : rB_;
-                    const int col = row + (in_a ? s : s - nA_);
+                    const int col = in_a ? cA_ + s : rB_ + (s - nA_);
                     // uniform (scalar) tile base + ONE 32-bit unsigned per-lane offset, re-materialised here:
                     // SGPR-base addressing, no 64-bit address VGPRs kept alive (and spilled) across the chunk
                     // loop -- a spill reload in front of these stores would wait on vmcnt, i.e. on the row
                     // loads that were just put in flight
-                    float* o_re = out + (int64_t)sc_tile_index(row, col, NB) * SC_TILE_ELEMS;
+                    float* o_re = out + (int64_t)sc_tile_index(fu_gt(p.map, row), fu_gt(p.map, col), p.map.NBr) * SC_TILE_ELEMS;
                     float* o_im = o_re + (int64_t)p.n_tiles * SC_TILE_ELEMS;
                     const unsigned fl = (unsigned)fu_lane();
                     const unsigned base_idx = (fl >> 4) * 64u + (fl & 15u);
@@ -399,15 +421,16 @@ template <int NB32, int SET>
 struct FuTab {
     static constexpr int PER = fu_per_set(NB32);
     static constexpr int T0 = SET * PER;
-    static constexpr int NBLK = (fu_nblocks(NB32) - T0) < PER ? (fu_nblocks(NB32) - T0) : PER;   // blocks of this set
+    // SET == 2: the cross launch of 129 ... 256 channels -- the four 32 x 32 blocks between the two staged halves
+    static constexpr int NBLK = SET == 2 ? 4 : ((fu_nblocks(NB32) - T0) < PER ? (fu_nblocks(NB32) - T0) : PER);   // blocks of this set
     struct Arr { int bi[FU_MAXB]; int bj[FU_MAXB]; bool use_i[4]; bool use_j[4]; };
     static constexpr Arr make() {
         Arr a{};
         for (int s = 0; s < FU_MAXB; ++s) { a.bi[s] = 0; a.bj[s] = 0; }
         for (int b = 0; b < 4; ++b) { a.use_i[b] = false; a.use_j[b] = false; }
         for (int s = 0; s < NBLK; ++s) {
-            a.bi[s] = fu_bi(NB32, T0 + s);
-            a.bj[s] = fu_bj(NB32, T0 + s);
+            a.bi[s] = SET == 2 ? s / 2 : fu_bi(NB32, T0 + s);
+            a.bj[s] = SET == 2 ? 2 + s % 2 : fu_bj(NB32, T0 + s);
             a.use_i[a.bi[s]] = true;
             a.use_j[a.bj[s]] = true;
         }
@@ -422,7 +445,6 @@ struct FuTab {
     static constexpr int NUSE_I = count(true), NUSE_J = count(false);
 };
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // "abs" role: per observation row and 32x32 channel block ONE v_mfma_f32_32x32x16_bf16 with C = 0
 // yields d = Im(x_i conj x_j) for the 1024 pairs of the block (K = 16 slots: lanes 0-31 carry the
@@ -461,11 +483,32 @@ __device__ __forceinline__ float fu_accumulate(float acc, float d) {
         // sign(d) in {-1, 0, 1} summed as an INTEGER in the accumulator's bits: the bit pattern of a float orders like a
         // signed integer with +0 = 0, so clamping it to [-1, 1] is the sign (one v_med3_i32 + one v_add_u32 per value; the
         // MFMA's C input is +0, so an exact zero comes out as +0).  Converted to float once, after the last chunk.
-        int a = __float_as_int(acc), t;
-        // one temporary per value, consumed at once (left to the compiler, sixteen clamps are scheduled ahead of their
-        // adds and the 168-register budget of a 12-wave workgroup spills)
-        asm("v_med3_i32 %1, %2, -1, 1\n\tv_add_u32 %0, %0, %1" : "+v"(a), "=&v"(t) : "v"(d));
+        const int b = __float_as_int(d);
+        const int sg = b < -1 ? -1 : (b > 1 ? 1 : b);
+        const int a = __float_as_int(acc) + sg;
         return __int_as_float(a);
+    }
+}
+// The sixteen results of one 32x32 block.  sign(d): written out by the compiler, the sixteen clamps are scheduled ahead of
+// their adds and the 168-register budget of a 12-wave workgroup spills, so fifteen of them are two-instruction asm blocks
+// with one temporary each.  But the wait states between an MFMA write and a VALU read are the COMPILER's job, and it
+// pads only in front of instructions it can see (an asm block straight after a lone MFMA read stale registers: wrong sign
+// sums at <= 32 channels): element 0 goes first as ordinary code -- the compiler waits for the MFMA there -- and a
+// scheduling barrier keeps the asm blocks behind it.
+template <int OP>
+__device__ __forceinline__ void fu_accumulate16(f32x16& acc, const f32x16& d) {
+    if constexpr (OP != FU_OP_SIGN) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = fu_accumulate<OP>(acc[e], d[e]);
+    } else {
+        acc[0] = fu_accumulate<OP>(acc[0], d[0]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 1; e < 16; ++e) {
+            int a = __float_as_int(acc[e]), t;
+            asm("v_med3_i32 %1, %2, -1, 1\n\tv_add_u32 %0, %0, %1" : "+v"(a), "=&v"(t) : "v"(d[e]));
+            acc[e] = __int_as_float(a);
+        }
     }
 }
 
@@ -488,11 +531,11 @@ __device__ __forceinline__ void fused_valu_body(const FusedArgs& p, const ScStag
     // with the |Im| plane: abs waves 0-3 stage quads 4-7 (the CSM waves take 0-3); CSM only: all eight stage
     const bool all_stage = p.abs_plane < 0;
     const int my_quad = all_stage ? vw : 4 + vw;
-    if (vw < 4 || all_stage) fu_stage_first<NB32>(st, raw, planes, my_quad, o_lo, n_chunks, loads);
+    if (vw < 4 || all_stage) fu_stage_first<NB32>(st, p.map, raw, planes, my_quad, o_lo, n_chunks, loads);
     FU_BARRIER();                 // chunk 0 staged
     FU_T0();
     for (int ch = 0; ch < n_chunks; ++ch) {
-        if (vw < 4 || all_stage) fu_stage_next<NB32>(st, raw, planes, my_quad, o_lo, ch, n_chunks, loads);
+        if (vw < 4 || all_stage) fu_stage_next<NB32>(st, p.map, raw, planes, my_quad, o_lo, ch, n_chunks, loads);
         FU_TICK(0);
         const unsigned short* pb = planes + (ch & 1) * buf_elems;
         // per-lane plane triples: A reads Im (lanes 0-31) / Re (32-63), B reads Re (lanes 0-31) / Im (32-63)
@@ -543,14 +586,12 @@ __device__ __forceinline__ void fused_valu_body(const FusedArgs& p, const ScStag
                         if (Tab::tab.bj[s + 1] != Tab::tab.bj[s]) fb = frag_b(Tab::tab.bj[s + 1]);
                     }
                     if (s > 0) {
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) acc[s - 1][e] = fu_accumulate<OP>(acc[s - 1][e], dprev[e]);
+                        fu_accumulate16<OP>(acc[s - 1], dprev);
                     }
                     dprev = d;
                 }
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[NBLK - 1][e] = fu_accumulate<OP>(acc[NBLK - 1][e], dprev[e]);
+                fu_accumulate16<OP>(acc[NBLK - 1], dprev);
             }
         }
         FU_TICK(1);
@@ -567,7 +608,7 @@ __device__ __forceinline__ void fused_valu_body(const FusedArgs& p, const ScStag
     float* red = reinterpret_cast<float*>(planes);
     for (int half = wps >> 1; half >= 1; half >>= 1) {
         if (rsub >= half && rsub < 2 * half) {
-            float* dst = red + (size_t)(SET * (wps >> 1) + (rsub - half)) * (FU_MAXB * 16 * 64);
+            float* dst = red + (size_t)((SET == 2 ? 0 : SET) * (wps >> 1) + (rsub - half)) * (FU_MAXB * 16 * 64);
 #pragma unroll
             for (int s = 0; s < NBLK; ++s)
 #pragma unroll
@@ -575,7 +616,7 @@ __device__ __forceinline__ void fused_valu_body(const FusedArgs& p, const ScStag
         }
         __syncthreads();
         if (rsub < half) {
-            const float* src = red + (size_t)(SET * (wps >> 1) + rsub) * (FU_MAXB * 16 * 64);
+            const float* src = red + (size_t)((SET == 2 ? 0 : SET) * (wps >> 1) + rsub) * (FU_MAXB * 16 * 64);
 #pragma unroll
             for (int s = 0; s < NBLK; ++s)
 #pragma unroll
@@ -594,21 +635,24 @@ __device__ __forceinline__ void fused_valu_body(const FusedArgs& p, const ScStag
             for (int e = 0; e < 16; ++e) {
                 const int i = BIs * 32 + (e & 3) + 8 * (e >> 2) + 4 * hf, j = BJs * 32 + i32;
                 const int ti = i >> 4, tj = j >> 4;
-                if (ti <= tj && tj < p.NB)
-                    out[(int64_t)sc_tile_index(ti, tj, p.NB) * SC_TILE_ELEMS + (i & 15) * 16 + (j & 15)] = acc[s][e];
+                if (ti <= tj && fu_tile_ok(p.map, ti) && fu_tile_ok(p.map, tj))
+                    out[(int64_t)sc_tile_index(fu_gt(p.map, ti), fu_gt(p.map, tj), p.map.NBr) * SC_TILE_ELEMS + (i & 15) * 16 +
+                        (j & 15)] = acc[s][e];
             }
         }
     }
 }
 
-template <int NB32, int OP>
+template <int NB32, int OP, bool CROSS>
 __device__ __forceinline__ void fused_valu_role(const FusedArgs& p, const ScStage& st,
                                                 unsigned short* planes, float* raw, int tid, int vw, float* rec,
                                                 int o_lo) {
-    constexpr int NSETS = fu_nsets(NB32);
+    constexpr int NSETS = CROSS ? 1 : fu_nsets(NB32);
     constexpr int wps = 8 / NSETS;                        // VALU waves per block set (8 or 4)
     const int set = vw / wps, rsub = vw % wps;
-    if constexpr (NSETS == 1) {
+    if constexpr (CROSS) {
+        fused_valu_body<NB32, 2, OP>(p, st, planes, raw, tid, vw, rsub, wps, rec, o_lo);
+    } else if constexpr (NSETS == 1) {
         fused_valu_body<NB32, 0, OP>(p, st, planes, raw, tid, vw, rsub, wps, rec, o_lo);
     } else {
         if (set == 0) fused_valu_body<NB32, 0, OP>(p, st, planes, raw, tid, vw, rsub, wps, rec, o_lo);
@@ -616,7 +660,7 @@ __device__ __forceinline__ void fused_valu_role(const FusedArgs& p, const ScStag
     }
 }
 
-template <int NB32, int OP>
+template <int NB32, int OP, bool CROSS>
 __global__ void __launch_bounds__(FU_THREADS) fused_csm_absim_kernel(FusedArgs p) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -641,7 +685,7 @@ __global__ void __launch_bounds__(FU_THREADS) fused_csm_absim_kernel(FusedArgs p
     constexpr size_t red_bytes = (size_t)4 * FU_MAXB * 16 * 64 * sizeof(float);
     float* raw = reinterpret_cast<float*>(smem + (plane_bytes > red_bytes ? plane_bytes : red_bytes));
     if (wave < 4) fused_mfma_role<NB32>(p, st, planes, raw, tid, wave, rec, o_lo);
-    else fused_valu_role<NB32, OP>(p, st, planes, raw, tid, wave - 4, rec, o_lo);
+    else fused_valu_role<NB32, OP, CROSS>(p, st, planes, raw, tid, wave - 4, rec, o_lo);
 }
 
 // accum[bin][plane] += ws[0][bin][plane] + ws[1][bin][plane] + ... for the CSM (re, im) and (if present) |Im| planes
@@ -680,33 +724,42 @@ __global__ void __launch_bounds__(256) planes_combine_kernel(FusedArgs p) {
     }
 }
 
-template <int NB32, int OP>
-static int launch_fused_op(const FusedArgs& a, hipStream_t stream) {
-    size_t shmem = (size_t)2 * a.st.CP * FU_CSTRIDE * 2;
-    const size_t red = (size_t)4 * FU_MAXB * 16 * 64 * sizeof(float);
-    if (shmem < red) shmem = red;
-    shmem += (size_t)FU_OC * FU_RAW_ROW * sizeof(float);
-    auto k = fused_csm_absim_kernel<NB32, OP>;
-    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    hipLaunchKernelGGL(k, dim3((unsigned)(a.n_bins * a.n_split)), dim3(FU_THREADS), shmem, stream, a);
-    SC_CHECK_HIP(hipGetLastError());
+static int launch_fused_combine(const FusedArgs& a, int op, hipStream_t stream) {
     if (a.n_split > 1) {
-        if (OP == FU_OP_ABS) hipLaunchKernelGGL(fused_combine_kernel, dim3(2048), dim3(256), 0, stream, a);
+        if (op == FU_OP_ABS) hipLaunchKernelGGL(fused_combine_kernel, dim3(2048), dim3(256), 0, stream, a);
         else hipLaunchKernelGGL(planes_combine_kernel, dim3(2048), dim3(256), 0, stream, a);     // one plane: a.fold
         SC_CHECK_HIP(hipGetLastError());
     }
     return SC_OK;
 }
 
+template <int NB32, int OP, bool CROSS>
+static int launch_fused_op(const FusedArgs& a, bool combine, hipStream_t stream) {
+    size_t shmem = (size_t)2 * a.st.CP * FU_CSTRIDE * 2;
+    const size_t red = (size_t)4 * FU_MAXB * 16 * 64 * sizeof(float);
+    if (shmem < red) shmem = red;
+    shmem += (size_t)FU_OC * FU_RAW_ROW * sizeof(float);
+    auto k = fused_csm_absim_kernel<NB32, OP, CROSS>;
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    hipLaunchKernelGGL(k, dim3((unsigned)(a.n_bins * a.n_split)), dim3(FU_THREADS), shmem, stream, a);
+    SC_CHECK_HIP(hipGetLastError());
+    return combine ? launch_fused_combine(a, OP, stream) : SC_OK;
+}
+
 // One pass of the matrix-core kernel: op = FU_OP_ABS is the headline launch (CSM planes, and |Im s| if a.abs_plane >= 0);
 // FU_OP_SQ / FU_OP_SIGN are plane passes (a.csm_plane = -1, a.abs_plane = the plane to fill): the abs waves accumulate
 // d^2 / sign(d) of the same per-observation matrix-core products, the CSM waves only stage.
-static int launch_fused(const FusedArgs& a, int op, hipStream_t stream) {
+static int launch_fused(const FusedArgs& a, int op, hipStream_t stream, bool combine) {
+    if (a.map.cross) {      // the tiles between two 64-channel quarters: always the full 128 staged slots
+        if (op == FU_OP_SQ) return launch_fused_op<4, FU_OP_SQ, true>(a, combine, stream);
+        if (op == FU_OP_SIGN) return launch_fused_op<4, FU_OP_SIGN, true>(a, combine, stream);
+        return launch_fused_op<4, FU_OP_ABS, true>(a, combine, stream);
+    }
 #define FU_CASE(NB32)                                                             \
     case NB32:                                                                    \
-        if (op == FU_OP_SQ) return launch_fused_op<NB32, FU_OP_SQ>(a, stream);    \
-        if (op == FU_OP_SIGN) return launch_fused_op<NB32, FU_OP_SIGN>(a, stream); \
-        return launch_fused_op<NB32, FU_OP_ABS>(a, stream);
+        if (op == FU_OP_SQ) return launch_fused_op<NB32, FU_OP_SQ, false>(a, combine, stream);    \
+        if (op == FU_OP_SIGN) return launch_fused_op<NB32, FU_OP_SIGN, false>(a, combine, stream); \
+        return launch_fused_op<NB32, FU_OP_ABS, false>(a, combine, stream);
     switch (a.NB32) {
         FU_CASE(1)
         FU_CASE(2)
@@ -917,7 +970,7 @@ __global__ void __launch_bounds__(256) unit_normalize_kernel(const float4* __res
 
 // d_X may be NULL when only the shape is known: alignment is then assumed.
 static bool fused_ok(const void* d_X, const ScAxes& ax) {
-    if (ax.C < 1 || ax.C > 128 || (ax.C & 1)) return false;
+    if (ax.C < 1 || ax.C > 256 || (ax.C & 1)) return false;
     if ((ax.sW | ax.sR | ax.sK | ax.sF) & 1) return false;
     return d_X == nullptr || (((uintptr_t)d_X) % 16 == 0);
 }
@@ -932,7 +985,7 @@ static bool small_ok_sq(const ScAxes& ax) { return ax.C <= 52; }
 static bool small_ok_sign(const ScAxes& ax) { return ax.C <= 40; }
 
 extern "C" int sc_fused_supported(int64_t n_signals) {
-    return (n_signals >= 2 && n_signals <= 128 && (n_signals % 2) == 0) ? 1 : 0;
+    return (n_signals >= 2 && n_signals <= 256 && (n_signals % 2) == 0) ? 1 : 0;
 }
 
 // Workgroups per bin.  One workgroup fills a CU (LDS), so n_bins workgroups run in ceil(n_bins / n_cu)
@@ -963,6 +1016,66 @@ static int fused_pick_split(int n_bins, int n_obs) {
     return best;
 }
 
+// One launch over the contiguous channel range [c_lo, c_lo + n), n <= 128: the upper triangle of that range
+static FusedArgs fu_args_range(const FusedArgs& full, int c_lo, int n) {
+    FusedArgs a = full;
+    a.st.base = full.st.base + c_lo;
+    a.st.C = n;
+    a.NB = sc_n_blocks(n);
+    a.NB32 = (n + 31) / 32;
+    a.n_blocks32 = a.NB32 * (a.NB32 + 1) / 2;
+    a.n_sets = fu_nsets(a.NB32);
+    a.st.CP = a.NB32 * 32;
+    a.st.RS = sc_row_stride(a.st.CP);
+    a.map.n0 = n < 64 ? n : 64;
+    a.map.n1 = n > 64 ? n - 64 : 0;
+    a.map.ch1 = 64;
+    a.map.t0 = c_lo / 16;
+    a.map.t1 = c_lo / 16 + 4;
+    a.map.nb0 = (a.map.n0 + 15) / 16;
+    a.map.nb1 = (a.map.n1 + 15) / 16;
+    a.map.NBr = sc_n_blocks(full.st.C);
+    a.map.cross = 0;
+    return a;
+}
+// One launch over the 64 channels from qa against the nb (<= 64) channels from qb (qa + 64 <= qb): only the tiles between them
+static FusedArgs fu_args_cross(const FusedArgs& full, int qa, int qb, int nb) {
+    FusedArgs a = full;
+    a.st.base = full.st.base + qa;
+    a.st.C = 128;
+    a.NB = 8;
+    a.NB32 = 4;
+    a.n_blocks32 = 4;
+    a.n_sets = 1;
+    a.st.CP = 128;
+    a.st.RS = sc_row_stride(128);
+    a.map.n0 = 64;
+    a.map.n1 = nb;
+    a.map.ch1 = qb - qa;
+    a.map.t0 = qa / 16;
+    a.map.t1 = qb / 16;
+    a.map.nb0 = 4;
+    a.map.nb1 = (nb + 15) / 16;
+    a.map.NBr = sc_n_blocks(full.st.C);
+    a.map.cross = 1;
+    return a;
+}
+static int launch_fused(const FusedArgs& a, int op, hipStream_t stream, bool combine);
+// Every tile of the record once: one triangular launch up to 128 channels; above, the two 128-channel halves as
+// triangular launches and each 64-channel quarter of the first half against each quarter of the second as cross
+// launches (136 = 36 + 36 + 4 x 16 tiles at 256 channels), the split-bin partial records folded once at the end.
+static int launch_fused_all(const FusedArgs& full, int op, hipStream_t s) {
+    const int C = full.st.C;
+    if (C <= 128) return launch_fused(fu_args_range(full, 0, C), op, s, true);
+    int rc = launch_fused(fu_args_range(full, 0, 128), op, s, false);
+    if (rc == SC_OK) rc = launch_fused(fu_args_range(full, 128, C - 128), op, s, false);
+    for (int qa = 0; qa < 128 && rc == SC_OK; qa += 64)
+        for (int qb = 128; qb < C && rc == SC_OK; qb += 64)
+            rc = launch_fused(fu_args_cross(full, qa, qb, C - qb < 64 ? C - qb : 64), op, s, false);
+    if (rc == SC_OK) rc = launch_fused_combine(full, op, s);
+    return rc;
+}
+
 enum { FU_MODE_CSM = 0, FU_MODE_UNIT = 1, FU_MODE_SIGN = 2 };
 static int fused_setup(const void* d_X, const sc_spectra_desc* desc, uint32_t planes, int mode, FusedArgs* a, ScAxes* ax) {
     SC_REQUIRE(desc, "NULL argument");
@@ -972,7 +1085,7 @@ static int fused_setup(const void* d_X, const sc_spectra_desc* desc, uint32_t pl
     sc_make_axes(desc, ax);
     SC_REQUIRE(ax->C >= 1 && ax->F >= 1 && ax->n_obs >= 1 && ax->n_groups >= 1, "empty dimension");
     if (!fused_ok(d_X, *ax)) {
-        sc_set_error("fused CSM+|Im| kernel needs an even n_signals <= 128 and 16-byte aligned rows (got C=%d)", ax->C);
+        sc_set_error("fused CSM+|Im| kernel needs an even n_signals <= 256 and 16-byte aligned rows (got C=%d)", ax->C);
         return SC_EUNSUPPORTED;
     }
     a->NB = sc_n_blocks(ax->C);
@@ -1049,7 +1162,9 @@ static int fused_run(const void* d_X, const sc_spectra_desc* desc, uint32_t plan
     a.n_split = S;
     a.ws = (float*)d_workspace;
     hipStream_t s = (hipStream_t)stream;
-    if (small_ok(ax, a.abs_plane >= 0) || (a.sq_plane >= 0 && small_ok_sq(ax)) || (mode == FU_MODE_SIGN && small_ok_sign(ax)))
+    const char* no_small = getenv("SC_FUSED_NO_SMALL");       // diagnostic: every shape through the matrix-core kernel
+    if (!(no_small && atoi(no_small)) &&
+        (small_ok(ax, a.abs_plane >= 0) || (a.sq_plane >= 0 && small_ok_sq(ax)) || (mode == FU_MODE_SIGN && small_ok_sign(ax))))
         return launch_small(a, unit, s);
     if (mode == FU_MODE_SIGN) {
         // plane pass: sign(d) of the per-observation matrix-core products, summed as integers by the abs waves
@@ -1059,7 +1174,7 @@ static int fused_run(const void* d_X, const sc_spectra_desc* desc, uint32_t plan
         b.nl_op = FU_OP_SIGN;
         b.fold[0] = b.abs_plane;
         b.n_fold = 1;
-        return launch_fused(b, FU_OP_SIGN, s);
+        return launch_fused_all(b, FU_OP_SIGN, s);
     }
     if (unit) {
         // the matrix-core kernel takes its rows straight from HBM into LDS: normalise a copy of the spectra first
@@ -1071,7 +1186,7 @@ static int fused_run(const void* d_X, const sc_spectra_desc* desc, uint32_t plan
         SC_CHECK_HIP(hipGetLastError());
         a.st.base = (const float2*)d_scratch;
     }
-    const int rc_main = launch_fused(a, FU_OP_ABS, s);
+    const int rc_main = launch_fused_all(a, FU_OP_ABS, s);
     if (rc_main != SC_OK || a.sq_plane < 0) return rc_main;
     // debiased wPLI: sum (Im s)^2 as a second pass of the same kernel (the abs waves hold 80 accumulator registers
     // per plane; two planes do not fit next to the matrix-core role's)
@@ -1081,7 +1196,7 @@ static int fused_run(const void* d_X, const sc_spectra_desc* desc, uint32_t plan
     b.nl_op = FU_OP_SQ;
     b.fold[0] = b.abs_plane;
     b.n_fold = 1;
-    return launch_fused(b, FU_OP_SQ, s);
+    return launch_fused_all(b, FU_OP_SQ, s);
 }
 
 extern "C" int sc_fused_csm_absim_ws_f32(const void* d_X, const sc_spectra_desc* desc, uint32_t planes,

@@ -155,7 +155,7 @@ def multitaper_spectra(x, tapers_over_fs, n_window, n_step, n_fft, n_windows, de
     if n_signals is not None:
         assert n_signals in (C_real, C_real - 1)
         C_real = int(n_signals)
-    elif C_real % 2 and C_real + 1 <= 128:
+    elif C_real % 2 and C_real + 1 <= 256:
         padded = torch.zeros((T, R, C_real + 1), dtype=x.dtype, device=x.device)
         padded[..., :C_real].copy_(x)                # odd channel count: one zero channel (see DeviceSpectra)
         x = padded
@@ -224,7 +224,7 @@ def upload_coefficients(coef, device="cuda", f64=False):
         return DeviceSpectra(X, (N, W, R, K, C_real), (C_real, R * K * N * C_real, K * N * C_real, N * C_real), N,
                              real_input=False)
     coef = np.ascontiguousarray(coef, dtype=np.complex64)
-    if C_real % 2 and C_real + 1 <= 128:
+    if C_real % 2 and C_real + 1 <= 256:
         coef = np.concatenate([coef, np.zeros(coef.shape[:-1] + (1,), dtype=np.complex64)], axis=-1)
     C = coef.shape[-1]
     X = torch.from_numpy(coef).to(device)

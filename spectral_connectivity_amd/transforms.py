@@ -529,7 +529,7 @@ class Multitaper:
             else:
                 x_host = np.ascontiguousarray(self.time_series, dtype=np.float32)
                 n_signals = x_host.shape[2]
-                if n_signals % 2 and n_signals + 1 <= 128:
+                if n_signals % 2 and n_signals + 1 <= 256:
                     # odd channel count: ONE all-zero channel is appended on the host, before the upload, so that the
                     # rows of the spectra stay 16-byte aligned for the one-pass stage-B kernels (engine.DeviceSpectra)
                     x_host = np.concatenate([x_host, np.zeros(x_host.shape[:2] + (1,), dtype=np.float32)], axis=2)

@@ -207,7 +207,8 @@ def test_fused_fft_matches_oracle_and_rocfft(sc, N, L, C, det):
 
 
 @pytest.mark.parametrize("C,R", [(128, 9), (96, 5), (64, 6), (24, 11), (6, 4), (128, 40), (2, 50), (16, 300), (32, 7),
-                                 (34, 5), (42, 9), (44, 4), (48, 6), (50, 3)])
+                                 (34, 5), (42, 9), (44, 4), (48, 6), (50, 3), (130, 4), (160, 6), (192, 3), (208, 4), (250, 3),
+                                 (256, 5)])
 def test_fused_stage_b_equals_separate_kernels(sc, C, R):
     """The one-pass stage-B kernels -- bf16 MFMA + VALU from 50 channels on (44 without the |Im| plane), f32 VALU
     below -- against the separate f32-MFMA CSM and |Im| kernels on the same spectra (identical fp32 arithmetic per
@@ -239,7 +240,7 @@ def test_fused_stage_b_equals_separate_kernels(sc, C, R):
 
 
 @pytest.mark.parametrize("C,R", [(2, 40), (6, 9), (16, 120), (34, 5), (40, 6), (42, 5), (48, 7), (50, 4), (52, 5), (54, 4), (58, 6), (60, 3), (64, 6), (96, 4), (128, 5),
-                                 (129, 3), (160, 4), (255, 2)])
+                                 (129, 3), (130, 3), (160, 4), (192, 3), (224, 2), (255, 2), (256, 2)])
 def test_one_pass_nonlinear_planes_equal_the_per_plane_kernel(sc, C, R):
     """(Im s)^2 and sign(Im s) ride on the small-channel one-pass kernel (<= 52 / <= 40 channels) or are plane passes of the
     matrix-core kernel (up to 128), and the unit phasors s/|s| go through the one-pass kernels as the cross-spectral
@@ -255,16 +256,16 @@ def test_one_pass_nonlinear_planes_equal_the_per_plane_kernel(sc, C, R):
                           (_lib.PLANE_SIGN_IM, _lib.M_PLI), (_lib.PLANE_SIGN_IM, _lib.M_DEBIASED_PLI2),
                           (_lib.PLANE_UNIT, _lib.M_PLV), (_lib.PLANE_UNIT, _lib.M_PPC)):
         for et in ("trials_tapers", "time_trials_tapers"):
-            a_f, n = engine.accumulate(sp, et, planes, use_fused=None if C > 128 else True)
+            a_f, n = engine.accumulate(sp, et, planes, use_fused=True)
             a_s, _ = engine.accumulate(sp, et, planes, use_fused=False)
             got = engine.measure(a_f, C, planes, n, which).cpu().numpy()
             ref = engine.measure(a_s, C, planes, n, which).cpu().numpy()
             if planes == _lib.PLANE_SIGN_IM:
                 assert np.array_equal(np.isnan(got), np.isnan(ref))
-                if C <= 40 or C > 128:       # both kernels form Im s with the same f32 operations: identical sign sums
+                if C <= 40:                  # both kernels form Im s with the same f32 operations: identical sign sums
                     assert np.array_equal(got[~np.isnan(got)], ref[~np.isnan(ref)])
                 else:
-                    # 42 ... 128 channels: the signs come from the matrix-core products (six bf16 cross terms, f32
+                    # 42 ... 256 channels: the signs come from the matrix-core products (six bf16 cross terms, f32
                     # sums) instead of an f32 FMA pair -- an observation whose |Im s| is within f32 rounding of zero
                     # may land on the other side: a handful of entries off by one or two flipped observations
                     diff = np.abs(got - ref)[~np.isnan(ref)]
@@ -546,3 +547,32 @@ def test_f11_band_statistics_on_the_device_coherency(sc, golden):
     for a, key in ((d, "group_delay"), (s_, "group_slope"), (r, "group_r")):
         np.testing.assert_allclose(a, g[key], rtol=1e-12, atol=0, equal_nan=True, err_msg=key)
     np.testing.assert_allclose(c.delay([10, 200], n_range=2), g["delay_band"], rtol=1e-12, atol=0, equal_nan=True)
+
+
+@pytest.mark.parametrize("C,R", [(2, 9), (16, 7), (32, 30), (40, 5), (64, 4)])
+def test_matrix_core_kernel_below_its_crossover(sc, C, R, monkeypatch):
+    """SC_FUSED_NO_SMALL=1 sends every shape through the matrix-core kernel (normally <= 40-52 channels take the f32 VALU
+    kernel): the one-block table of <= 32 channels -- a lone MFMA per observation row, whose results the |Im| waves read
+    straight away -- and every plane pass (|Im s|, (Im s)^2, sign(Im s)) against the per-plane kernels.  (The sign pass
+    once read its MFMA results from inline asm without the wait states the compiler pads for instructions it can see:
+    wrong sums at <= 32 channels only.)"""
+    from spectral_connectivity_amd import _lib, engine
+    monkeypatch.setenv("SC_FUSED_NO_SMALL", "1")
+    rng = np.random.default_rng(200 + C)
+    x = rng.standard_normal((200, R, C)) + 0.5 * rng.standard_normal((200, R, 1))
+    m = sc.Multitaper(x, sampling_frequency=200.0, time_halfbandwidth_product=3,
+                      n_time_samples_per_window=64, n_time_samples_per_step=32)
+    sp = m.device_spectra()
+    for planes, which, tol in ((_lib.PLANE_CSM | _lib.PLANE_ABS_IM, _lib.M_WPLI, 3e-6),
+                               (_lib.PLANE_CSM | _lib.PLANE_ABS_IM | _lib.PLANE_IM_SQ, _lib.M_DEBIASED_WPLI2, 2e-5),
+                               (_lib.PLANE_SIGN_IM, _lib.M_PLI, None)):
+        a_f, n = engine.accumulate(sp, "trials_tapers", planes, use_fused=True)
+        a_s, _ = engine.accumulate(sp, "trials_tapers", planes, use_fused=False)
+        got = engine.measure(a_f, C, planes, n, which).cpu().numpy()
+        ref = engine.measure(a_s, C, planes, n, which).cpu().numpy()
+        if tol is None:
+            assert np.array_equal(np.isnan(got), np.isnan(ref))
+            diff = np.abs(got - ref)[~np.isnan(ref)]
+            assert (diff > 0).mean() < 1e-3 and diff.max() <= 8.0 / n, (C, (diff > 0).sum(), diff.max())
+        else:
+            close32(got, ref, rtol=tol, atol_scale=tol, what=f"C={C} planes {planes:#x}")
