@@ -15,6 +15,15 @@
 
 #define SC_EPS64 2.220446049250313e-16
 
+// records as float (f32 engine) or double (f64 engine) elements: the element type is a template parameter of the kernels
+// here (the epilogue is launched on the headline path; a run-time switch per load cost 20 %)
+template <typename AccT>
+struct RecT {
+    const AccT* p;
+    __device__ RecT operator+(int64_t n) const { return RecT{p + n}; }
+    __device__ double operator[](int64_t i) const { return (double)p[i]; }
+};
+
 struct MeasureArgs {
     ScRec accum;
     void* out;
@@ -25,7 +34,8 @@ struct MeasureArgs {
     int measure;
 };
 
-__device__ inline double tile_read(ScRec bin_rec, int plane, int n_tiles, int NB, int i, int j,
+template <typename Rec>
+__device__ inline double tile_read(Rec bin_rec, int plane, int n_tiles, int NB, int i, int j,
                                   bool* mirrored) {
     int ti = i >> 4, tj = j >> 4, ii = i & 15, jj = j & 15;
     // lower triangle (tile-wise AND inside diagonal tiles) is read from its mirror: the matrix
@@ -38,14 +48,14 @@ __device__ inline double tile_read(ScRec bin_rec, int plane, int n_tiles, int NB
 }
 
 // power: one thread per (bin, channel)
-template <typename OutT>
+template <typename OutT, typename AccT>
 __global__ void __launch_bounds__(256) power_kernel(MeasureArgs a) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= a.total) return;
     const int64_t bin = idx / a.C;
     const int i = (int)(idx - bin * a.C);
     bool m;
-    const ScRec rec = a.accum + bin * a.floats_per_bin;
+    const RecT<AccT> rec = RecT<AccT>{(const AccT*)a.accum.p} + bin * a.floats_per_bin;
     ((OutT*)a.out)[idx] = (OutT)(tile_read(rec, a.p_csm, a.n_tiles, a.NB, i, i, &m) / a.n_obs);
 }
 
@@ -117,7 +127,7 @@ __device__ inline double2 measure_value(int measure, double n, MeasureIn v, bool
     }
 }
 
-template <bool COMPLEX_OUT, typename OutT, typename OutT2>
+template <bool COMPLEX_OUT, typename OutT, typename OutT2, typename AccT>
 __global__ void __launch_bounds__(256) measure_tile_kernel(MeasureArgs a) {
     __shared__ MeasureIn raw[256];
     __shared__ double2 mir[256];
@@ -126,9 +136,9 @@ __global__ void __launch_bounds__(256) measure_tile_kernel(MeasureArgs a) {
     while (t >= len) { t -= len; ++ti; --len; }
     const int tj = ti + t;
     const int64_t bin = blockIdx.x;
-    const ScRec rec = a.accum + bin * a.floats_per_bin;
+    const RecT<AccT> rec = RecT<AccT>{(const AccT*)a.accum.p} + bin * a.floats_per_bin;
     const int64_t plane = (int64_t)a.n_tiles * SC_TILE_ELEMS;
-    const ScRec tile = rec + ((int64_t)blockIdx.y * SC_TILE_ELEMS + ii * 16 + jj);
+    const RecT<AccT> tile = rec + ((int64_t)blockIdx.y * SC_TILE_ELEMS + ii * 16 + jj);
     MeasureIn v = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (a.p_csm >= 0) {
         v.s_re = (double)tile[a.p_csm * plane];
@@ -210,18 +220,31 @@ static int measure_run(const void* d_accum, int64_t n_bins, int64_t n_signals, u
         a.total = n_bins * n_signals;
         const int64_t blocks = (a.total + 255) / 256;
         SC_REQUIRE(blocks < (int64_t)1 << 31, "output too large for one launch");
-        if (wide) hipLaunchKernelGGL(power_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL(power_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+        hipStream_t st = (hipStream_t)stream;
+        const dim3 g((unsigned)blocks);
+        if (wide && a.accum.f64) hipLaunchKernelGGL((power_kernel<double, double>), g, dim3(256), 0, st, a);
+        else if (wide) hipLaunchKernelGGL((power_kernel<double, float>), g, dim3(256), 0, st, a);
+        else if (a.accum.f64) hipLaunchKernelGGL((power_kernel<float, double>), g, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((power_kernel<float, float>), g, dim3(256), 0, st, a);
     } else {
         a.total = n_bins * n_signals * n_signals;
         SC_REQUIRE(n_bins < (int64_t)1 << 31 && a.n_tiles <= 65535, "output too large for one launch");
         const dim3 grid((unsigned)n_bins, (unsigned)a.n_tiles);
         const bool cplx = measure == SC_M_CSM || measure == SC_M_COHERENCY || measure == SC_M_PLV_COMPLEX;
         hipStream_t st = (hipStream_t)stream;
-        if (cplx && wide) hipLaunchKernelGGL((measure_tile_kernel<true, double, double2>), grid, dim3(256), 0, st, a);
-        else if (cplx) hipLaunchKernelGGL((measure_tile_kernel<true, float, float2>), grid, dim3(256), 0, st, a);
-        else if (wide) hipLaunchKernelGGL((measure_tile_kernel<false, double, double2>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((measure_tile_kernel<false, float, float2>), grid, dim3(256), 0, st, a);
+#define MT_LAUNCH(C, O, O2, A) hipLaunchKernelGGL((measure_tile_kernel<C, O, O2, A>), grid, dim3(256), 0, st, a)
+        if (a.accum.f64) {
+            if (cplx && wide) MT_LAUNCH(true, double, double2, double);
+            else if (cplx) MT_LAUNCH(true, float, float2, double);
+            else if (wide) MT_LAUNCH(false, double, double2, double);
+            else MT_LAUNCH(false, float, float2, double);
+        } else {
+            if (cplx && wide) MT_LAUNCH(true, double, double2, float);
+            else if (cplx) MT_LAUNCH(true, float, float2, float);
+            else if (wide) MT_LAUNCH(false, double, double2, float);
+            else MT_LAUNCH(false, float, float2, float);
+        }
+#undef MT_LAUNCH
     }
     SC_CHECK_HIP(hipGetLastError());
     return SC_OK;

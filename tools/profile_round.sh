@@ -1,0 +1,31 @@
+#!/bin/bash
+# Round-2 profile collection (run on the GPU box from the repo root; raw outputs under gpurun_out/r02/, summaries are
+# written into profiles/ by tools/profile_round.py afterwards):
+#   1. the bench line itself                                 python bench.py
+#   2. per-kernel durations of the same command              rocprofv3 --kernel-trace --stats
+#   3. HBM traffic, two separate PMC passes                  rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE
+#   4. SQ counters of the dominant kernel                    rocprofv3 --kernel-trace --pmc SQ_...
+# (counters in their own runs with --kernel-trace only: MI355X_MICROARCH.md, rocprofv3 PMC slots)
+set -u
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/r02
+mkdir -p $OUT
+cd $ROOT
+python bench.py --steps 20 --warmup 5 > $OUT/bench_line.json 2> $OUT/bench_line.err
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats -d $OUT/kt -- $BENCH > $OUT/bench_under_rocprof.json 2> $OUT/kt.err
+SHORT="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -- $SHORT > /dev/null 2> $OUT/fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -- $SHORT > /dev/null 2> $OUT/write.err
+rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -d $OUT/sq -- $SHORT > /dev/null 2> $OUT/sq.err
+cd $ROOT
+for d in kt fetch write sq; do
+    db=$(find $OUT/$d -name "*.db" | head -1)
+    [ -n "$db" ] && python tools/rocpd_summary.py $db > $OUT/$d.txt 2>&1
+done
+python tools/mvar_time.py 64 1792 256 > $OUT/mvar_64ch.txt 2>&1
+python tools/plane_pass_time.py > $OUT/plane_pass.txt 2>&1
+python tools/shape_sweep.py > $OUT/shape_sweep.txt 2>&1
+python tools/fused_ablation.py > $OUT/fused_ablation.txt 2>&1
+ls -la $OUT
