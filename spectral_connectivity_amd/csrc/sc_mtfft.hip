@@ -632,9 +632,428 @@ static int launch_mt16(const MtArgs& a_in, hipStream_t stream) {
     return SC_OK;
 }
 
+// ----------------------------------------------------------------------------------------
+// Window lengths off the power-of-two list whose only prime factors are 2, 3 and 5 (250, 500, 1000, 200, 300, 1500 ...:
+// what scipy.fft.next_fast_len, transforms.py:1024-1036, hands the reference for the usual sampling rates): the same
+// fusion -- window extraction + detrend + taper + real FFT + transposed store in ONE kernel -- with a mixed-radix
+// Stockham transform in LDS instead of the register-resident radix-16 passes.  rocFFT took these lengths in three
+// passes over HBM (tapered windows out, transform, transposed copy: 8.8 ms at 250 samples for the cfg3 volume).
+// Workgroup = (window, trial, tile of CT = 2 NF channels), 512 threads.  The detrended window tile stays in LDS for all
+// tapers; per taper the NF packed channel pairs (z = x_c h + i x_{c+1} h) go through log-many passes of radix 5 / 4 / 3 /
+// 2 butterflies between two LDS buffers (autosort: natural order out, no bit reversal), twiddles from an LDS copy of
+// the fp64-rounded table exp(-2 pi i m / N), then the pair is separated by conjugate symmetry and stored like the
+// radix-16 kernel stores (DC / Nyquist exactly real).
+struct MxArgs {
+    const float* x;
+    const float* tapers;   // [K][L], already divided by fs
+    const float2* tw;      // [N] exp(-2 pi i m / N)
+    float2* X;             // [F][W][R][K][C]
+    int T, R, C, L, step, W, K, detrend;
+    int N, NF, n_pass;
+    int radix[16];
+};
+
+__device__ __forceinline__ float2 mx_add(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 mx_sub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+
+// one radix-R butterfly of a Stockham pass: inputs src[b + t m] (twiddled by W^(t k tw_step), k = b mod Ls), DFT_R in registers
+template <int R>
+__device__ __forceinline__ void mx_bfly_compute(const float2* __restrict__ src, const float2* __restrict__ tw, int b, int m,
+                                                int Ls, int tw_step, float2 (&v)[R]) {
+    const int k = b % Ls;
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+        v[t] = src[b + t * m];
+        if (t > 0 && Ls > 1) v[t] = cmul(v[t], tw[t * k * tw_step]);
+    }
+    if constexpr (R == 2) {
+        const float2 a = v[0], c = v[1];
+        v[0] = mx_add(a, c); v[1] = mx_sub(a, c);
+    } else if constexpr (R == 3) {
+        constexpr float S3 = 0.86602540378443865f;
+        const float2 s = mx_add(v[1], v[2]), d = mx_sub(v[1], v[2]);
+        const float2 t = make_float2(v[0].x - 0.5f * s.x, v[0].y - 0.5f * s.y);
+        v[0] = mx_add(v[0], s);
+        v[1] = make_float2(t.x + S3 * d.y, t.y - S3 * d.x);      // t - i S3 d
+        v[2] = make_float2(t.x - S3 * d.y, t.y + S3 * d.x);      // t + i S3 d
+    } else if constexpr (R == 4) {
+        dft4r(v[0], v[1], v[2], v[3]);
+    } else {
+        constexpr float C1 = 0.30901699437494742f, C2 = -0.80901699437494742f;
+        constexpr float S1 = 0.95105651629515357f, S2 = 0.58778525229247313f;
+        const float2 a1 = mx_add(v[1], v[4]), a2 = mx_add(v[2], v[3]), b1 = mx_sub(v[1], v[4]), b2 = mx_sub(v[2], v[3]);
+        const float2 p1 = make_float2(v[0].x + C1 * a1.x + C2 * a2.x, v[0].y + C1 * a1.y + C2 * a2.y);
+        const float2 p2 = make_float2(v[0].x + C2 * a1.x + C1 * a2.x, v[0].y + C2 * a1.y + C1 * a2.y);
+        const float2 q1 = make_float2(S1 * b1.x + S2 * b2.x, S1 * b1.y + S2 * b2.y);
+        const float2 q2 = make_float2(S2 * b1.x - S1 * b2.x, S2 * b1.y - S1 * b2.y);
+        v[0] = mx_add(v[0], mx_add(a1, a2));
+        v[1] = make_float2(p1.x + q1.y, p1.y - q1.x);            // p1 - i q1
+        v[4] = make_float2(p1.x - q1.y, p1.y + q1.x);            // p1 + i q1
+        v[2] = make_float2(p2.x + q2.y, p2.y - q2.x);            // p2 - i q2
+        v[3] = make_float2(p2.x - q2.y, p2.y + q2.x);            // p2 + i q2
+    }
+}
+// ... and its outputs: dst[(b - k) R + k + t Ls] (autosort: natural order after the last pass)
+template <int R>
+__device__ __forceinline__ void mx_bfly_store(float2* __restrict__ dst, int b, int Ls, const float2 (&v)[R]) {
+    const int k = b % Ls, base = (b - k) * R + k;
+#pragma unroll
+    for (int t = 0; t < R; ++t) dst[base + t * Ls] = v[t];
+}
+template <int R>
+__device__ __forceinline__ void mx_butterfly(const float2* __restrict__ src, float2* __restrict__ dst, const float2* __restrict__ tw,
+                                             int b, int m, int Ls, int tw_step) {
+    float2 v[R];
+    mx_bfly_compute<R>(src, tw, b, m, Ls, tw_step, v);
+    mx_bfly_store<R>(dst, b, Ls, v);
+}
+
+// A transform whose length is known at compile time, ONE WAVE per packed channel pair, in place: every lane takes the
+// butterflies b = lane, lane + 64, ... of the pass into registers, the wave meets (LDS executes a wave's instructions in
+// order: no workgroup barrier), and writes them back to the same buffer.  Radix, butterfly count and twiddle stride are
+// constants: the index arithmetic compiles to multiply-shift sequences and the rounds unroll.
+template <int N, int LS>
+__device__ __forceinline__ void mx_passes_wave(float2* z, const float2* tw, int lane) {
+    if constexpr (LS < N) {
+        constexpr int rem = N / LS;
+        constexpr int R = rem % 5 == 0 ? 5 : (rem % 4 == 0 ? 4 : (rem % 3 == 0 ? 3 : 2));
+        constexpr int m = N / R, tw_step = N / (LS * R), ROUNDS = (m + 63) / 64;
+        float2 v[ROUNDS][R];
+#pragma unroll
+        for (int j = 0; j < ROUNDS; ++j) {
+            const int b = lane + 64 * j;
+            if (b < m) mx_bfly_compute<R>(z, tw, b, m, LS, tw_step, v[j]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int j = 0; j < ROUNDS; ++j) {
+            const int b = lane + 64 * j;
+            if (b < m) mx_bfly_store<R>(z, b, LS, v[j]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        mx_passes_wave<N, LS * R>(z, tw, lane);
+    }
+}
+
+// The passes of a transform whose length is known at compile time: radix, butterfly count and twiddle stride are
+// constants, the index arithmetic of every butterfly (q / m, b % Ls) compiles to multiply-shift sequences and the loops
+// unroll.  (With run-time N the same kernel spends most of its instructions on integer division: 8.0 ms against
+// rocFFT's 8.7 at 250 samples; the common lengths are instantiated, the rest take the run-time version.)
+template <int N, int LS>
+__device__ __forceinline__ float2* mx_passes(float2* src, float2* dst, const float2* tw, int NF, int tid) {
+    if constexpr (LS >= N) {
+        return src;
+    } else {
+        constexpr int rem = N / LS;
+        constexpr int R = rem % 5 == 0 ? 5 : (rem % 4 == 0 ? 4 : (rem % 3 == 0 ? 3 : 2));
+        constexpr int m = N / R, tw_step = N / (LS * R);
+        const int total = NF * m;
+        for (int q = tid; q < total; q += 512) {
+            const int pr = q / m, b = q - pr * m;
+            mx_butterfly<R>(src + pr * N, dst + pr * N, tw, b, m, LS, tw_step);
+        }
+        __syncthreads();
+        return mx_passes<N, LS * R>(dst, src, tw, NF, tid);
+    }
+}
+
+template <int NT>
+__global__ void __launch_bounds__(512) mtfft_mixed_kernel(MxArgs p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int N = NT > 0 ? NT : p.N;
+    const int NF = p.NF, CT = 2 * NF, XS = CT + 2, L = p.L, C = p.C;
+    const int lnf = 31 - __clz(NF), lct = lnf + 1;                // NF and CT are powers of two: shifts, not divisions
+    float2* zA = reinterpret_cast<float2*>(smem);                 // [NF][N]
+    float2* zB = zA + NF * N;                                     // [NF][N]
+    float2* tw = zB + NF * N;                                     // [N]
+    float* tile = reinterpret_cast<float*>(tw + N);               // [L][XS]
+    double* red = reinterpret_cast<double*>(tile + ((L * XS + 1) & ~1));   // [2][512] + trend [2][CT]
+    const int tid = threadIdx.x;
+    const int c0 = blockIdx.x * CT, r = blockIdx.y, w = blockIdx.z;
+    const int64_t RC = (int64_t)p.R * C;
+    const float* xw = p.x + ((int64_t)w * p.step * p.R + r) * C + c0;
+    for (int idx = tid; idx < L * CT; idx += 512) {
+        const int l = idx >> lct, cc = idx & (CT - 1);
+        tile[l * XS + cc] = (c0 + cc < C) ? xw[(int64_t)l * RC + cc] : 0.f;
+    }
+    for (int i = tid; i < N; i += 512) tw[i] = p.tw[i];
+    __syncthreads();
+    if (p.detrend != SC_DETREND_NONE) {
+        // trend sums in fp64, SL slices of the window per channel, then one thread per channel
+        const int SL = 512 >> lct, cc = tid & (CT - 1), sl = tid >> lct;
+        double s = 0.0, st = 0.0;
+        if (sl < SL)
+            for (int l = sl; l < L; l += SL) {
+                const double v = (double)tile[l * XS + cc];
+                s += v;
+                st += v * (double)(l + 1);
+            }
+        red[tid] = s;
+        red[512 + tid] = st;
+        __syncthreads();
+        if (tid < CT) {
+            double sum = 0.0, sumt = 0.0;
+            for (int q = 0; q < SL; ++q) { sum += red[q * CT + tid]; sumt += red[512 + q * CT + tid]; }
+            sumt /= (double)L;
+            const double n = (double)L;
+            double a = 0.0, b;
+            if (p.detrend == SC_DETREND_CONSTANT) {
+                b = sum / n;
+            } else {            // least-squares line on abscissa (l + 1) / L  (transforms.py:1903-1909)
+                const double St = (n + 1.0) * 0.5, Stt = (n + 1.0) * (2.0 * n + 1.0) / (6.0 * n);
+                const double den = n * Stt - St * St;
+                a = (den != 0.0) ? (n * sumt - St * sum) / den : 0.0;
+                b = (sum - a * St) / n;
+            }
+            red[1024 + tid] = a;
+            red[1024 + CT + tid] = b;
+        }
+        __syncthreads();
+        const double invL = 1.0 / (double)L;
+        for (int idx = tid; idx < L * CT; idx += 512) {
+            const int l = idx >> lct, cc2 = idx & (CT - 1);
+            const double tt = (double)(l + 1) * invL;
+            tile[l * XS + cc2] = (float)((double)tile[l * XS + cc2] - (red[1024 + cc2] * tt + red[1024 + CT + cc2]));
+        }
+        __syncthreads();
+    }
+    const int F = N / 2 + 1;
+    const int64_t sF = (int64_t)p.W * p.R * p.K * C;
+    const bool vec_ok = (C % 2) == 0;
+    for (int k = 0; k < p.K; ++k) {
+        const float* hk = p.tapers + (int64_t)k * L;
+        for (int idx = tid; idx < NF * N; idx += 512) {
+            const int pr = idx / N, n = idx - pr * N;
+            float2 v = make_float2(0.f, 0.f);
+            if (n < L) {
+                const float h = hk[n];
+                const float2 xv = *reinterpret_cast<const float2*>(tile + n * XS + 2 * pr);
+                v = make_float2(xv.x * h, xv.y * h);
+            }
+            zA[idx] = v;
+        }
+        __syncthreads();
+        float2* src = zA;
+        if constexpr (NT > 0) {
+            src = mx_passes<(NT > 0 ? NT : 2), 1>(zA, zB, tw, NF, tid);
+        } else {
+            float2* dst = zB;
+            int Ls = 1;
+            for (int ps = 0; ps < p.n_pass; ++ps) {
+                const int R = p.radix[ps], m = N / R, tw_step = N / (Ls * R);
+                for (int q = tid; q < NF * m; q += 512) {
+                    const int pr = q / m, b = q - pr * m;
+                    const float2* s0 = src + pr * N;
+                    float2* d0 = dst + pr * N;
+                    if (R == 5) mx_butterfly<5>(s0, d0, tw, b, m, Ls, tw_step);
+                    else if (R == 4) mx_butterfly<4>(s0, d0, tw, b, m, Ls, tw_step);
+                    else if (R == 3) mx_butterfly<3>(s0, d0, tw, b, m, Ls, tw_step);
+                    else mx_butterfly<2>(s0, d0, tw, b, m, Ls, tw_step);
+                }
+                __syncthreads();
+                float2* t = src; src = dst; dst = t;
+                Ls *= R;
+            }
+        }
+        // split the packed pair: A[f] = (Z[f] + conj Z[N-f]) / 2, B[f] = (Z[f] - conj Z[N-f]) / (2 i); store X[f][w][r][k][c..c+1]
+        float2* Xk = p.X + (((int64_t)w * p.R + r) * p.K + k) * C + c0;
+        for (int idx = tid; idx < F * NF; idx += 512) {
+            const int f = idx >> lnf, pr = idx & (NF - 1), c = c0 + 2 * pr;
+            if (c >= C) continue;
+            const float2 u1 = src[pr * N + f], u2 = src[pr * N + (f == 0 ? 0 : N - f)];
+            const float2 A = make_float2(0.5f * (u1.x + u2.x), 0.5f * (u1.y - u2.y));
+            const float2 B = make_float2(0.5f * (u1.y + u2.y), 0.5f * (u2.x - u1.x));
+            float2* d = Xk + (int64_t)f * sF + 2 * pr;
+            if (vec_ok) {
+                *reinterpret_cast<float4*>(d) = make_float4(A.x, A.y, B.x, B.y);
+            } else {
+                d[0] = A;
+                if (c + 1 < C) d[1] = B;
+            }
+        }
+        __syncthreads();     // the next taper refills zA
+    }
+}
+
+// The common lengths up to 1000 samples: N and the number of packed pairs NF are compile-time, ONE WAVE per pair runs the
+// whole transform in place on its own slice of a single LDS buffer (mx_passes_wave), so the passes need no workgroup
+// barrier; only the conjugate-symmetry split + store (coalesced across the pairs of a frequency row) and the refill
+// for the next taper are fenced by one each.  64 NF threads per workgroup.
+template <int N, int NF>
+__global__ void __launch_bounds__(64 * NF) mtfft_mixed_wave_kernel(MxArgs p) {
+    constexpr int NT = 64 * NF, CT = 2 * NF, XS = CT + 2, F = N / 2 + 1;
+    constexpr int LCT = CT == 32 ? 5 : (CT == 16 ? 4 : (CT == 8 ? 3 : 2)), LNF = LCT - 1;
+    extern __shared__ __align__(16) unsigned char smem[];
+    float2* z = reinterpret_cast<float2*>(smem);                  // [NF][N]; the detrend scratch aliases it
+    double* red = reinterpret_cast<double*>(smem);                // [2][NT] + trend [2][CT]
+    float2* tw = z + (NF * N > (2 * NT + 2 * CT) ? NF * N : (2 * NT + 2 * CT));   // [N]
+    float* tile = reinterpret_cast<float*>(tw + N);               // [L][XS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int L = p.L, C = p.C;
+    const int c0 = blockIdx.x * CT, r = blockIdx.y, w = blockIdx.z;
+    const int64_t RC = (int64_t)p.R * C;
+    const float* xw = p.x + ((int64_t)w * p.step * p.R + r) * C + c0;
+    for (int idx = tid; idx < L * CT; idx += NT) {
+        const int l = idx >> LCT, cc = idx & (CT - 1);
+        tile[l * XS + cc] = (c0 + cc < C) ? xw[(int64_t)l * RC + cc] : 0.f;
+    }
+    for (int i = tid; i < N; i += NT) tw[i] = p.tw[i];
+    __syncthreads();
+    if (p.detrend != SC_DETREND_NONE) {
+        constexpr int SL = NT / CT;
+        const int cc = tid & (CT - 1), sl = tid >> LCT;
+        double s = 0.0, st = 0.0;
+        for (int l = sl; l < L; l += SL) {
+            const double v = (double)tile[l * XS + cc];
+            s += v;
+            st += v * (double)(l + 1);
+        }
+        red[tid] = s;
+        red[NT + tid] = st;
+        __syncthreads();
+        if (tid < CT) {
+            double sum = 0.0, sumt = 0.0;
+            for (int q = 0; q < SL; ++q) { sum += red[q * CT + tid]; sumt += red[NT + q * CT + tid]; }
+            sumt /= (double)L;
+            const double n = (double)L;
+            double a = 0.0, b;
+            if (p.detrend == SC_DETREND_CONSTANT) {
+                b = sum / n;
+            } else {            // least-squares line on abscissa (l + 1) / L  (transforms.py:1903-1909)
+                const double St = (n + 1.0) * 0.5, Stt = (n + 1.0) * (2.0 * n + 1.0) / (6.0 * n);
+                const double den = n * Stt - St * St;
+                a = (den != 0.0) ? (n * sumt - St * sum) / den : 0.0;
+                b = (sum - a * St) / n;
+            }
+            red[2 * NT + tid] = a;
+            red[2 * NT + CT + tid] = b;
+        }
+        __syncthreads();
+        const double invL = 1.0 / (double)L;
+        for (int idx = tid; idx < L * CT; idx += NT) {
+            const int l = idx >> LCT, cc2 = idx & (CT - 1);
+            const double tt = (double)(l + 1) * invL;
+            tile[l * XS + cc2] = (float)((double)tile[l * XS + cc2] - (red[2 * NT + cc2] * tt + red[2 * NT + CT + cc2]));
+        }
+        __syncthreads();                                          // the scratch is free: z takes its place
+    }
+    const int64_t sF = (int64_t)p.W * p.R * p.K * C;
+    const bool vec_ok = (C % 2) == 0;
+    float2* zw = z + wave * N;                                    // this wave's pair
+    for (int k = 0; k < p.K; ++k) {
+        const float* hk = p.tapers + (int64_t)k * L;
+        for (int n = lane; n < N; n += 64) {
+            float2 v = make_float2(0.f, 0.f);
+            if (n < L) {
+                const float h = hk[n];
+                const float2 xv = *reinterpret_cast<const float2*>(tile + n * XS + 2 * wave);
+                v = make_float2(xv.x * h, xv.y * h);
+            }
+            zw[n] = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        mx_passes_wave<N, 1>(zw, tw, lane);
+        __syncthreads();                                          // every pair transformed
+        float2* Xk = p.X + (((int64_t)w * p.R + r) * p.K + k) * C + c0;
+        for (int idx = tid; idx < F * NF; idx += NT) {
+            const int f = idx >> LNF, pr = idx & (NF - 1), c = c0 + 2 * pr;
+            if (c >= C) continue;
+            const float2 u1 = z[pr * N + f], u2 = z[pr * N + (f == 0 ? 0 : N - f)];
+            const float2 A = make_float2(0.5f * (u1.x + u2.x), 0.5f * (u1.y - u2.y));
+            const float2 B = make_float2(0.5f * (u1.y + u2.y), 0.5f * (u2.x - u1.x));
+            float2* d = Xk + (int64_t)f * sF + 2 * pr;
+            if (vec_ok) {
+                *reinterpret_cast<float4*>(d) = make_float4(A.x, A.y, B.x, B.y);
+            } else {
+                d[0] = A;
+                if (c + 1 < C) d[1] = B;
+            }
+        }
+        __syncthreads();                                          // the next taper refills z
+    }
+}
+
+template <int N, int NF>
+static int launch_mixed_wave(const MxArgs& m_in, hipStream_t stream) {
+    MxArgs m = m_in;
+    m.NF = NF;
+    constexpr int NT = 64 * NF, CT = 2 * NF;
+    const size_t zb = (size_t)(NF * N > (2 * NT + 2 * CT) ? NF * N : (2 * NT + 2 * CT)) * 8;
+    const size_t lds = zb + (size_t)N * 8 + (size_t)m.L * (CT + 2) * 4 + 16;
+    auto k = mtfft_mixed_wave_kernel<N, NF>;
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dim3 grid((unsigned)((m.C + CT - 1) / CT), (unsigned)m.R, (unsigned)m.W);
+    hipLaunchKernelGGL(k, grid, dim3(NT), lds, stream, m);
+    SC_CHECK_HIP(hipGetLastError());
+    return SC_OK;
+}
+
+// N = 2^a 3^b 5^c, not a power of two, 8 <= N <= 2048: the radix list (5s, 4s, 3s, then a 2) or 0 if N has another factor
+static int mx_radices(int64_t N, int* radix) {
+    if (N < 8 || N > 2048 || (N & (N - 1)) == 0) return 0;
+    int n = 0;
+    int64_t rem = N;
+    while (rem % 5 == 0) { radix[n++] = 5; rem /= 5; }
+    while (rem % 4 == 0) { radix[n++] = 4; rem /= 4; }
+    while (rem % 3 == 0) { radix[n++] = 3; rem /= 3; }
+    while (rem % 2 == 0) { radix[n++] = 2; rem /= 2; }
+    return rem == 1 ? n : 0;
+}
+
+static int launch_mixed(const MtArgs& a, int64_t N, hipStream_t stream) {
+    MxArgs m;
+    m.x = a.x; m.tapers = a.tapers; m.tw = a.tw; m.X = a.X;
+    m.T = a.T; m.R = a.R; m.C = a.C; m.L = a.L; m.step = a.step; m.W = a.W; m.K = a.K; m.detrend = a.detrend;
+    m.N = (int)N;
+    m.n_pass = mx_radices(N, m.radix);
+    int nf = 16;
+    while (nf > 2 && (int64_t)nf * N > 4096) nf >>= 1;
+    if (N <= 512 && (int64_t)nf * N > 2048) nf >>= 1;       // short windows: 128-byte store segments are enough, two workgroups per CU
+    while (nf > 1 && 2 * (nf >> 1) >= a.C) nf >>= 1;           // few channels: no wider than the data
+    m.NF = nf;
+    const int CT = 2 * nf;
+    const size_t lds = (size_t)2 * nf * N * 8 + (size_t)N * 8 + (((size_t)a.L * (CT + 2) + 1) & ~(size_t)1) * 4 +
+                       (size_t)(1024 + 2 * CT) * 8;
+    if (lds > 160 * 1024) { sc_set_error("multitaper FFT (N=%lld): window tile does not fit LDS", (long long)N); return SC_EUNSUPPORTED; }
+    switch (N) {        // one wave per channel pair, in place (mtfft_mixed_wave_kernel): the common lengths up to 1000 samples
+    case 200: return launch_mixed_wave<200, 8>(m, stream);
+    case 250: return launch_mixed_wave<250, 8>(m, stream);
+    case 300: return launch_mixed_wave<300, 8>(m, stream);
+    case 400: return launch_mixed_wave<400, 8>(m, stream);
+    case 500: return launch_mixed_wave<500, 8>(m, stream);
+    case 600: return launch_mixed_wave<600, 4>(m, stream);
+    case 750: return launch_mixed_wave<750, 4>(m, stream);
+    case 800: return launch_mixed_wave<800, 4>(m, stream);
+    case 1000: return launch_mixed_wave<1000, 4>(m, stream);
+    default: break;
+    }
+    dim3 grid((unsigned)((a.C + CT - 1) / CT), (unsigned)a.R, (unsigned)a.W);
+#define MX_CASE(NN)                                                                                             \
+    case NN:                                                                                                    \
+        (void)hipFuncSetAttribute((const void*)mtfft_mixed_kernel<NN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(mtfft_mixed_kernel<NN>, grid, dim3(512), lds, stream, m);                            \
+        break;
+    switch (N) {        // the lengths next_fast_len hands out for window durations in round numbers of ms at 200 Hz ... 2 kHz
+        MX_CASE(1200) MX_CASE(1250) MX_CASE(1500) MX_CASE(2000)
+    default:
+        MX_CASE(0)
+    }
+#undef MX_CASE
+    SC_CHECK_HIP(hipGetLastError());
+    return SC_OK;
+}
+
 extern "C" int sc_multitaper_fft_supported(int64_t L, int64_t N) {
-    if (N < 64 || N > 4096 || (N & (N - 1)) != 0) return 0;
-    return (L >= 1 && L <= N) ? 1 : 0;
+    if (L < 1 || L > N) return 0;
+    if (N >= 64 && N <= 4096 && (N & (N - 1)) == 0) return 1;      // radix-16 kernel
+    int radix[16];
+    return mx_radices(N, radix) > 0 ? 1 : 0;                          // mixed-radix kernel: 2^a 3^b 5^c up to 2048
 }
 
 extern "C" int sc_multitaper_fft_f32(const float* d_x, int64_t T, int64_t R, int64_t C, int64_t L,
@@ -647,13 +1066,14 @@ extern "C" int sc_multitaper_fft_f32(const float* d_x, int64_t T, int64_t R, int
     SC_REQUIRE(detrend_type >= 0 && detrend_type <= 2, "unknown detrend_type");
     SC_REQUIRE(R <= 65535 && W <= 65535, "too many trials/windows for one launch");
     if (!sc_multitaper_fft_supported(L, N)) {
-        sc_set_error("fused multitaper FFT needs a power-of-two 64 <= N <= 4096 and L <= N (got L=%lld N=%lld); "
-                     "use sc_taper_windows_f32 + sc_fft_execute", (long long)L, (long long)N);
+        sc_set_error("fused multitaper FFT needs L <= N and N a power of two in 64 ... 4096 or 2^a 3^b 5^c in 8 ... 2048 "
+                     "(got L=%lld N=%lld); use sc_taper_windows_f32 + sc_fft_execute", (long long)L, (long long)N);
         return SC_EUNSUPPORTED;
     }
     MtArgs a{d_x, d_tapers, (const float2*)d_twiddles, (float2*)d_X, (int)T, (int)R, (int)C, (int)L,
              (int)step, (int)W, (int)K, detrend_type};
     hipStream_t s = (hipStream_t)stream;
+    if ((N & (N - 1)) != 0) return launch_mixed(a, N, s);
     switch (N) {
     case 64: return launch_mt16<6>(a, s);
     case 128: return launch_mt16<7>(a, s);

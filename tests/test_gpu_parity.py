@@ -576,3 +576,32 @@ def test_matrix_core_kernel_below_its_crossover(sc, C, R, monkeypatch):
             assert (diff > 0).mean() < 1e-3 and diff.max() <= 8.0 / n, (C, (diff > 0).sum(), diff.max())
         else:
             close32(got, ref, rtol=tol, atol_scale=tol, what=f"C={C} planes {planes:#x}")
+
+
+@pytest.mark.parametrize("N,L,C,det", [(250, 250, 5, "constant"), (200, 200, 70, "linear"), (300, 250, 33, None),
+                                       (1000, 1000, 18, "linear"), (1500, 1500, 6, "constant"), (2000, 1800, 3, "constant"),
+                                       (75, 75, 9, "constant"), (120, 100, 2, "linear"), (12, 12, 4, None), (45, 40, 1, "constant"),
+                                       (960, 960, 128, "constant"), (500, 500, 17, "linear"), (1280, 1280, 7, None),
+                                       (1875, 1875, 4, "constant"), (384, 384, 40, "constant"), (18, 18, 130, "linear")])
+def test_mixed_radix_fused_fft_matches_oracle_and_rocfft(sc, N, L, C, det):
+    """Window lengths 2^a 3^b 5^c off the power-of-two list (what next_fast_len gives for the usual sampling rates) take
+    the mixed-radix fused kernel: against the float64 oracle (zero padding, odd and > 128 channel counts, every detrend),
+    and the rocFFT path -- still the transform of every other length -- against the same oracle."""
+    import torch
+    from spectral_connectivity_amd import _lib, engine
+    assert _lib.load().sc_multitaper_fft_supported(L, N) == 1
+    rng = np.random.default_rng(N + C)
+    R, step = 3, max(L // 2, 1)
+    T = L + 2 * step
+    x = rng.standard_normal((T, R, C)) + 5.0 + np.linspace(0, 2, T)[:, None, None]
+    kw = dict(n_time_samples_per_window=L, n_time_samples_per_step=step, n_fft_samples=N)
+    coef, info = so.multitaper_fft(x, fs=200.0, NW=2.5, detrend_type=det, **kw)
+    m = sc.Multitaper(x, sampling_frequency=200.0, time_halfbandwidth_product=2.5, detrend_type=det, **kw)
+    close32(m.fft(), coef, what=f"mixed-radix N={N}")
+    xd = torch.from_numpy(x.astype(np.float32)).cuda()
+    h = torch.from_numpy(np.ascontiguousarray(m.tapers.T / 200.0, dtype=np.float32)).cuda()
+    sp = engine.multitaper_spectra(xd, h, L, step, N, m.n_time_windows, det, use_fused=False)
+    got = np.moveaxis(sp.coefficients().cpu().numpy(), 0, 3)
+    close32(got, coef[..., : N // 2 + 1, :], what=f"rocfft N={N}")
+    # lengths with another prime factor stay on rocFFT
+    assert _lib.load().sc_multitaper_fft_supported(14, 14) == 0 and _lib.load().sc_multitaper_fft_supported(2310, 2310) == 0
