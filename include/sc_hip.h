@@ -154,14 +154,17 @@ int sc_fft_plan_destroy(sc_fft_plan* plan);
 int sc_fft_plan_create_f64(sc_fft_plan** plan, int64_t N, int64_t batch);
 int sc_fft_execute_f64(sc_fft_plan* plan, const double* d_y, void* d_X /*double2*/, void* stream);
 
-/* ---- stage A, fused fast path (custom HIP, power-of-two N) ---------------------------
+/* ---- stage A, fused fast path (custom HIP) ---------------------------------------------
  * Window extraction + detrend + taper multiply + real FFT + transposed store in ONE kernel:
  * replaces _sliding_window, detrend, _multitaper_fft and the swapaxes of Multitaper.fft
  * (transforms.py:1147-1171, :1311-1405) with a single read of x and a single write of
  *   X[f][w][r][k][c],  f = 0..N/2   (one-sided; the negative bins of a real input are
  *                                    conjugate mirrors and are never materialised).
- * Supported when sc_multitaper_fft_supported(L, N) != 0 (power-of-two 64 <= N <= 4096,
- * L <= N); otherwise use sc_taper_windows_f32 + sc_fft_execute (rocFFT, any length).
+ * Supported when sc_multitaper_fft_supported(L, N) != 0: L <= N and N either a power of two in
+ * 64 ... 4096 (register-resident radix-16 passes) or 2^a 3^b 5^c in 8 ... 2048 (mixed-radix Stockham
+ * passes in LDS: the lengths next_fast_len, transforms.py:1024-1036, returns for the usual window
+ * durations -- 200, 250, 500, 1000 ...); otherwise use sc_taper_windows_f32 + sc_fft_execute
+ * (rocFFT, any length).
  * d_twiddles: float2[N] device table filled once by sc_fft_twiddles_f32(N, ...). */
 int sc_multitaper_fft_supported(int64_t L, int64_t N);
 int sc_fft_twiddles_f32(int64_t N, void* d_twiddles /*float2[N]*/, void* stream);
@@ -197,7 +200,9 @@ int sc_nonlinear_accumulate_f32(const void* d_X /*float2*/, const sc_spectra_des
  * the CSM planes AND the per-observation Im(x_i conj x_j) products of the ABS_IM plane on the bf16 matrix
  * pipe (exact 3-way bf16 split of every f32 coefficient; 12-wave workgroups: one CSM wave and two |Im| waves
  * per SIMD over one double-buffered LDS staging of the spectra, rows pulled HBM -> LDS directly).  Same results as
- * sc_csm_accumulate_f32 + sc_nonlinear_accumulate_f32(SC_PLANE_ABS_IM); n_signals <= 128. */
+ * sc_csm_accumulate_f32 + sc_nonlinear_accumulate_f32(SC_PLANE_ABS_IM); even n_signals <= 256 (above 128 channels
+ * the record is filled by several launches over 64-channel quarters: the two 128-channel halves, then every quarter
+ * of the first half against every quarter of the second). */
 int sc_fused_supported(int64_t n_signals);
 int sc_fused_csm_absim_f32(const void* d_X /*float2*/, const sc_spectra_desc* desc,
                            uint32_t planes, float* d_accum, void* stream);
@@ -214,13 +219,13 @@ int sc_fused_csm_absim_ws_f32(const void* d_X /*float2*/, const sc_spectra_desc*
  * (0/0 -> NaN like the reference's x/abs(x)).  Up to 42 channels the normalisation happens while the
  * rows are staged; above, a normalised copy of the spectra goes to d_scratch first
  * (sc_fused_unit_scratch_bytes, 0 when none is needed).  Shapes, workspace and split as above. */
-/* SC_PLANE_UNIT for shapes the one-pass kernels do not take (> 128 channels): a normalised copy of the
+/* SC_PLANE_UNIT for shapes the one-pass kernels do not take (odd channel counts without a pad channel): a normalised copy of the
  * spectra (x/|x|, 0 -> NaN) in d_scratch (sc_unit_scratch_bytes) goes through the f32-MFMA CSM kernel. */
 int64_t sc_unit_scratch_bytes(const sc_spectra_desc* desc);
 int sc_unit_accumulate_f32(const void* d_X /*float2*/, const sc_spectra_desc* desc, uint32_t planes,
                            float* d_accum, void* d_scratch, int64_t scratch_bytes, void* stream);
 
-/* Which planes of `planes` the one-pass entry points fill for this shape (even n_signals <= 128): CSM, |Im s| (with
+/* Which planes of `planes` the one-pass entry points fill for this shape (even n_signals <= 256): CSM, |Im s| (with
  * CSM) and s/|s|; (Im s)^2 (with CSM and |Im s|, filled by sc_fused_csm_absim_ws_f32: in the same pass up to 52 channels,
  * as a second pass of the matrix-core kernel above) and sign(Im s) (sc_fused_sign_ws_f32: phase_lag_index,
  * connectivity.py:933-980; f32 VALU kernel up to 40 channels, above it a pass of the matrix-core kernel whose |Im| waves
