@@ -143,8 +143,14 @@ __global__ void __launch_bounds__(256, LOG2N <= 8 ? 4 : (LOG2N == 9 ? 3 : (LOG2N
     // An FFT's 16 x TPF points are exchanged between lanes of ONE wavefront when TPF <= 64, and
     // LDS executes a wave's instructions in order: those exchanges need no workgroup barrier.
     constexpr bool WAVE_LOCAL = TPF <= 64;
+    // A channel whose (detrended) window is identically zero must come out as exact zeros, like the reference's
+    // per-channel transform gives (its measures turn NaN on zero power): the conjugate-symmetry split of a packed pair
+    // would leave the rounding noise of its partner there.  One flag per channel of the tile.
+    __shared__ int nzf[CT];
 
     const int tid = threadIdx.x;
+    if (tid < CT) nzf[tid] = 0;
+    if constexpr (LONG) __syncthreads();
     MT_T0();
     int c0, r, w;
     if constexpr (LONG) {
@@ -320,7 +326,15 @@ __global__ void __launch_bounds__(256, LOG2N <= 8 ? 4 : (LOG2N == 9 ? 3 : (LOG2N
             }
         }
     }
+    {
+        bool n0 = false, n1 = false;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) { n0 |= xs[t].x != 0.f; n1 |= xs[t].y != 0.f; }
+        if (n0) nzf[2 * pf] = 1;
+        if (n1) nzf[2 * pf + 1] = 1;
+    }
     __syncthreads();                                  // tile and detrend scratch consumed: their space is free
+    const bool za = nzf[2 * (tid & (NF - 1))] == 0, zb = nzf[2 * (tid & (NF - 1)) + 1] == 0;   // of the pair this thread stores
     if constexpr (!LONG) {
         for (int i2 = tid; i2 < N; i2 += 256) tw[i2] = p.tw[i2];
         if (resident) {
@@ -525,8 +539,10 @@ __global__ void __launch_bounds__(256, LOG2N <= 8 ? 4 : (LOG2N == 9 ? 3 : (LOG2N
             if (last) zn = zp[PHYS(N / 2)];
             float2* dst0 = Xk + 2 * pr;
             auto put = [&](int f, float2 u1, float2 u2) {
-                const float2 A = make_float2(0.5f * (u1.x + u2.x), 0.5f * (u1.y - u2.y));
-                const float2 B = make_float2(0.5f * (u1.y + u2.y), 0.5f * (u2.x - u1.x));
+                float2 A = make_float2(0.5f * (u1.x + u2.x), 0.5f * (u1.y - u2.y));
+                float2 B = make_float2(0.5f * (u1.y + u2.y), 0.5f * (u2.x - u1.x));
+                if (za) A = make_float2(0.f, 0.f);
+                if (zb) B = make_float2(0.f, 0.f);
                 if ((p.dbg & 1) && A.x != 12345.f) return;
                 if constexpr (LONG) {
                     float2* row = p.Z + (((((int64_t)w * p.Rc + (r - p.r_off)) * p.K + k) * C + c) * (int64_t)(N / 2 + 1));
@@ -589,19 +605,19 @@ static int launch_mt16(const MtArgs& a_in, hipStream_t stream) {
     auto lds = [&](size_t kh, size_t L) { size_t t = (size_t)N * 8 + kh * L * 4; return uni + (t > red_b ? t : red_b); };
     // not resident = two buffers: the next taper is parked while the current one is in use
     // Keep all K tapers in LDS when that does not cost a resident workgroup per CU.
-    constexpr size_t cu_lds = 160 * 1024;
+    constexpr size_t cu_lds = 160 * 1024 - 16 * ((CT * 4 + 15) / 16);     // minus the kernel's static zero-channel flags
     MtArgs a = a_in;
     const size_t one = lds(TPF <= 64 ? 2 : 1, a.L), all = lds(a.K, a.L);
     a.kh = (all <= cu_lds && cu_lds / all == cu_lds / one) ? a.K : 1;
     { const char* d = getenv("SC_MTFFT_DEBUG"); a.dbg = d ? atoi(d) : 0; }
     const size_t shmem = a.kh == a.K ? all : one;
     auto k = mtfft16_kernel<LOG2N>;
-    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if constexpr (LOG2N < 11) SC_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     if constexpr (LOG2N >= 11) {
         // long windows: row-major spectra of a range of trials into a stream-ordered scratch (<= 2 GB), then one tiled
         // transpose per window into the frequency-major X
         const size_t lds_long = z_b + 4 * 256 * sizeof(double) + (64 + N / 64) * sizeof(float2);
-        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_long);
+        SC_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_long));
         const int64_t F = N / 2 + 1, rows_trial = (int64_t)a.K * a.C, batch = (int64_t)a.W * a.R * rows_trial;
         int64_t rc = ((int64_t)2 << 30) / ((int64_t)a.W * rows_trial * F * 8);
         rc = rc < 1 ? 1 : (rc > a.R ? a.R : rc);
@@ -772,7 +788,9 @@ __global__ void __launch_bounds__(512) mtfft_mixed_kernel(MxArgs p) {
     float2* tw = zB + NF * N;                                     // [N]
     float* tile = reinterpret_cast<float*>(tw + N);               // [L][XS]
     double* red = reinterpret_cast<double*>(tile + ((L * XS + 1) & ~1));   // [2][512] + trend [2][CT]
+    __shared__ int nzf[32];                                       // channel not identically zero (see mtfft16_kernel)
     const int tid = threadIdx.x;
+    if (tid < 32) nzf[tid] = 0;
     const int c0 = blockIdx.x * CT, r = blockIdx.y, w = blockIdx.z;
     const int64_t RC = (int64_t)p.R * C;
     const float* xw = p.x + ((int64_t)w * p.step * p.R + r) * C + c0;
@@ -821,6 +839,14 @@ __global__ void __launch_bounds__(512) mtfft_mixed_kernel(MxArgs p) {
         }
         __syncthreads();
     }
+    {
+        const int SL = 512 >> lct, cc = tid & (CT - 1), sl = tid >> lct;
+        bool nz = false;
+        if (sl < SL)
+            for (int l = sl; l < L; l += SL) nz |= tile[l * XS + cc] != 0.f;
+        if (nz) nzf[cc] = 1;
+        __syncthreads();
+    }
     const int F = N / 2 + 1;
     const int64_t sF = (int64_t)p.W * p.R * p.K * C;
     const bool vec_ok = (C % 2) == 0;
@@ -865,8 +891,10 @@ __global__ void __launch_bounds__(512) mtfft_mixed_kernel(MxArgs p) {
             const int f = idx >> lnf, pr = idx & (NF - 1), c = c0 + 2 * pr;
             if (c >= C) continue;
             const float2 u1 = src[pr * N + f], u2 = src[pr * N + (f == 0 ? 0 : N - f)];
-            const float2 A = make_float2(0.5f * (u1.x + u2.x), 0.5f * (u1.y - u2.y));
-            const float2 B = make_float2(0.5f * (u1.y + u2.y), 0.5f * (u2.x - u1.x));
+            float2 A = make_float2(0.5f * (u1.x + u2.x), 0.5f * (u1.y - u2.y));
+            float2 B = make_float2(0.5f * (u1.y + u2.y), 0.5f * (u2.x - u1.x));
+            if (nzf[2 * pr] == 0) A = make_float2(0.f, 0.f);         // identically zero channel: exact zeros
+            if (nzf[2 * pr + 1] == 0) B = make_float2(0.f, 0.f);
             float2* d = Xk + (int64_t)f * sF + 2 * pr;
             if (vec_ok) {
                 *reinterpret_cast<float4*>(d) = make_float4(A.x, A.y, B.x, B.y);
@@ -892,7 +920,9 @@ __global__ void __launch_bounds__(64 * NF) mtfft_mixed_wave_kernel(MxArgs p) {
     double* red = reinterpret_cast<double*>(smem);                // [2][NT] + trend [2][CT]
     float2* tw = z + (NF * N > (2 * NT + 2 * CT) ? NF * N : (2 * NT + 2 * CT));   // [N]
     float* tile = reinterpret_cast<float*>(tw + N);               // [L][XS]
+    __shared__ int nzf[CT];                                       // channel not identically zero (see mtfft16_kernel)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < CT) nzf[tid] = 0;
     const int L = p.L, C = p.C;
     const int c0 = blockIdx.x * CT, r = blockIdx.y, w = blockIdx.z;
     const int64_t RC = (int64_t)p.R * C;
@@ -941,6 +971,14 @@ __global__ void __launch_bounds__(64 * NF) mtfft_mixed_wave_kernel(MxArgs p) {
         }
         __syncthreads();                                          // the scratch is free: z takes its place
     }
+    {
+        constexpr int SL = NT / CT;
+        const int cc = tid & (CT - 1), sl = tid >> LCT;
+        bool nz = false;
+        for (int l = sl; l < L; l += SL) nz |= tile[l * XS + cc] != 0.f;
+        if (nz) nzf[cc] = 1;
+        __syncthreads();
+    }
     const int64_t sF = (int64_t)p.W * p.R * p.K * C;
     const bool vec_ok = (C % 2) == 0;
     float2* zw = z + wave * N;                                    // this wave's pair
@@ -965,8 +1003,10 @@ __global__ void __launch_bounds__(64 * NF) mtfft_mixed_wave_kernel(MxArgs p) {
             const int f = idx >> LNF, pr = idx & (NF - 1), c = c0 + 2 * pr;
             if (c >= C) continue;
             const float2 u1 = z[pr * N + f], u2 = z[pr * N + (f == 0 ? 0 : N - f)];
-            const float2 A = make_float2(0.5f * (u1.x + u2.x), 0.5f * (u1.y - u2.y));
-            const float2 B = make_float2(0.5f * (u1.y + u2.y), 0.5f * (u2.x - u1.x));
+            float2 A = make_float2(0.5f * (u1.x + u2.x), 0.5f * (u1.y - u2.y));
+            float2 B = make_float2(0.5f * (u1.y + u2.y), 0.5f * (u2.x - u1.x));
+            if (nzf[2 * pr] == 0) A = make_float2(0.f, 0.f);         // identically zero channel: exact zeros
+            if (nzf[2 * pr + 1] == 0) B = make_float2(0.f, 0.f);
             float2* d = Xk + (int64_t)f * sF + 2 * pr;
             if (vec_ok) {
                 *reinterpret_cast<float4*>(d) = make_float4(A.x, A.y, B.x, B.y);
@@ -1020,7 +1060,7 @@ static int launch_mixed(const MtArgs& a, int64_t N, hipStream_t stream) {
     const int CT = 2 * nf;
     const size_t lds = (size_t)2 * nf * N * 8 + (size_t)N * 8 + (((size_t)a.L * (CT + 2) + 1) & ~(size_t)1) * 4 +
                        (size_t)(1024 + 2 * CT) * 8;
-    if (lds > 160 * 1024) { sc_set_error("multitaper FFT (N=%lld): window tile does not fit LDS", (long long)N); return SC_EUNSUPPORTED; }
+    if (lds > 160 * 1024 - 128) { sc_set_error("multitaper FFT (N=%lld): window tile does not fit LDS", (long long)N); return SC_EUNSUPPORTED; }
     switch (N) {        // one wave per channel pair, in place (mtfft_mixed_wave_kernel): the common lengths up to 1000 samples
     case 200: return launch_mixed_wave<200, 8>(m, stream);
     case 250: return launch_mixed_wave<250, 8>(m, stream);

@@ -605,3 +605,34 @@ def test_mixed_radix_fused_fft_matches_oracle_and_rocfft(sc, N, L, C, det):
     close32(got, coef[..., : N // 2 + 1, :], what=f"rocfft N={N}")
     # lengths with another prime factor stay on rocFFT
     assert _lib.load().sc_multitaper_fft_supported(14, 14) == 0 and _lib.load().sc_multitaper_fft_supported(2310, 2310) == 0
+
+
+@pytest.mark.parametrize("N", [64, 256, 512, 1024, 2048, 200, 250, 1000, 100, 1500, 140])
+def test_silent_and_constant_channels_give_exact_zero_spectra(sc, N):
+    """The reference transforms every channel on its own, so a silent channel (or a constant one under the default
+    constant detrend) has EXACTLY zero coefficients, zero power and exactly zero coherence with every other channel.  The
+    fused kernels transform channels in packed pairs: the split must not leave the partner's rounding noise there
+    (radix-16, long-window, mixed-radix compile-time / run-time lengths and the rocFFT route, float32 engine)."""
+    import torch
+    from spectral_connectivity_amd import engine
+    rng = np.random.default_rng(N)
+    C, R = 6, 4
+    x = rng.standard_normal((N, R, C)) * 3.0 + 1.0
+    x[:, :, 2] = 0.0
+    x[:, :, 5] = 0.75
+    m = sc.Multitaper(x, sampling_frequency=100.0, time_halfbandwidth_product=2)
+    xd = torch.from_numpy(x.astype(np.float32)).cuda()
+    h = torch.from_numpy(np.ascontiguousarray(m.tapers.T / 100.0, dtype=np.float32)).cuda()
+    sp = engine.multitaper_spectra(xd, h, N, N, N, 1, "constant")
+    X = sp.coefficients().cpu().numpy()                       # (F, W, R, K, C)
+    assert np.all(X[..., 2] == 0) and np.all(X[..., 5] == 0), np.abs(X[..., [2, 5]]).max()
+    assert np.abs(X[..., [0, 1, 3, 4]]).min() > 0
+    c = sc.Connectivity.from_multitaper(m, dtype=np.complex64)
+    coh = c.coherence_magnitude()[0]
+    off = ~np.eye(C, dtype=bool)
+    for ch in (2, 5):                                         # 0 / eps = 0 off the diagonal, NaN on it (connectivity.py:640-670)
+        assert np.all(coh[:, ch, off[ch]] == 0) and np.all(coh[:, off[ch], ch] == 0)
+    assert np.all(np.isnan(coh[:, np.arange(C), np.arange(C)]))
+    ok = [0, 1, 3, 4]
+    assert np.all(coh[:, ok][:, :, ok][:, ~np.eye(4, dtype=bool)] > 0)
+    assert np.all(c.power()[0][:, [2, 5]] == 0)
