@@ -318,16 +318,17 @@ int sc_wilson_factor_f64(const double* d_S, int64_t n_problems, int64_t N, doubl
  * (minimum_phase_decomposition.py:227-322) and directed_transfer_function, directed_coherence,
  * partial_directed_coherence, generalized_partial_directed_coherence,
  * direct_directed_transfer_function (connectivity.py:1237-1426).  All windows iterate together,
- * converged windows are frozen; one (window, bin) matrix pair lives in LDS: n_signals <=
- * sc_mvar_max_signals() (64), larger systems return SC_EUNSUPPORTED.
+ * converged windows are frozen; the C x C factor of one (window, bin) lives in the registers of one workgroup:
+ * n_signals <= sc_mvar_max_signals() (128), larger systems return SC_EUNSUPPORTED.
  * sc_mvar_factor_f64: exactly one of d_accum (accumulator records holding SC_PLANE_CSM, N or N/2+1
  * bins per window, real-input symmetry completes the rest) and d_S (complex128 [P][N][C][C], two-sided
  * Hermitian spectra) is non-NULL.  d_G: complex128 [P][N][C][C].  d_status[p]: 1 converged, 0 not
  * converged after max_iterations; h_summary = HOST int32[3] {iterations run, windows still running, windows whose
  * lag-0 covariance was not positive definite and that started from the identity (see sc_granger_pairwise_f64)}.
  * Synchronises the stream once per four iterations.  Per iteration: A = G^-1 S G^-H + I by a register-resident
- * Gauss-Jordan elimination per (window, bin), the causal transform pair along frequency, G <- G A+ on the fp64
- * matrix cores (v_mfma_f64_16x16x4_f64).
+ * Gauss-Jordan elimination per (window, bin) -- of [G | S] up to 64 signals; of G alone, followed by two matrix-core
+ * products, for 65 ... 128 (five instead of three C^2 N complex128 arrays of workspace per window) --, the causal
+ * transform pair along frequency, G <- G A+ on the fp64 matrix cores (v_mfma_f64_16x16x4_f64).
  * sc_mvar_measure_f64: d_G as above -> double [P][N/2+1][C][C] (SC_MVAR_DTF..DDTF), complex128
  * [P][N/2+1][C][C] (SC_MVAR_TRANSFER, SC_MVAR_COEFFICIENTS) or double [P][C][C] (NOISE_COVARIANCE).
  * The Tikhonov terms are the reference's: 1e-12 * mean(H0^2) over all windows, 1e-12 * mean(|H|^2)

@@ -32,7 +32,8 @@ __device__ inline cd m_div(cd a, cd b) {
     return make_double2((a.x * b.x + a.y * b.y) / d, (a.y * b.x - a.x * b.y) / d);
 }
 
-#define MV_CMAX 64
+#define MV_CMAX 128          // <= 64: register-resident [G | S] elimination; 65 ... 128: explicit inverse + matrix-core products
+#define MV_CSMALL 64
 
 // ---- dense complex linear algebra on LDS-resident matrices (one workgroup, any block size) ------
 // LU with partial pivoting of M (C x C, row-major), in place: unit-lower multipliers below the diagonal,
@@ -147,7 +148,7 @@ struct MvDims {
 };
 
 // S[p][e][n] from the accumulator records (upper-triangular 16x16 tiles, un-normalised sums)
-__global__ void m_build(ScRec accum, MvDims d, cd* S) {
+__global__ void m_build(ScRec accum, MvDims d, cd* S, int64_t sn, int64_t se) {
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int e = blockIdx.y;
     const int64_t p = blockIdx.z;
@@ -166,7 +167,7 @@ __global__ void m_build(ScRec accum, MvDims d, cd* S) {
     if (m) im = -im;
     if (conj) im = -im;
     if (i == j) im = 0.0;
-    S[(p * d.C * d.C + e) * d.N + n] = make_double2(re, im);
+    S[p * d.C * d.C * d.N + n * sn + e * se] = make_double2(re, im);      // series: sn = 1, se = N; natural: sn = C^2, se = 1
 }
 
 // natural [p][n][e] <-> series [p][e][n]
@@ -194,6 +195,21 @@ __global__ void __launch_bounds__(256) m_lag0(const cd* __restrict__ S, double* 
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
     if (lane == 0) r0[series] = a / (double)N;
+}
+
+// the same for the natural layout [p][n][e] (beyond 64 signals): threads along e
+__global__ void __launch_bounds__(256) m_lag0_nat(const cd* __restrict__ S, double* __restrict__ r0, int64_t N, int E) {
+    const int64_t p = blockIdx.y;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= E) return;
+    double a = 0.0;
+    for (int64_t n = 0; n < N; ++n) a += S[(p * N + n) * E + e].x;
+    r0[p * E + e] = a / (double)N;
+}
+__global__ void m_fill_nat(const double* __restrict__ g0, cd* __restrict__ G, int64_t N, int E) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int64_t n = blockIdx.y, p = blockIdx.z;
+    if (e < E) G[(p * N + n) * E + e] = make_double2(g0[p * E + e], 0.0);
 }
 
 // one block per window: lower Cholesky of R0 in LDS, G0 = L^T written back over r0 (upper triangular, real); a lag-0
@@ -603,6 +619,271 @@ __global__ void __launch_bounds__(256) m_update_mfma(cd* __restrict__ G, const c
     }
 }
 
+// ---- systems of 65 ... 128 signals ---------------------------------------------------------------------------------
+// [G | S] of 128 channels is 512 KB -- the whole register file of a CU -- so the augmented elimination of m_predict_gj
+// stops at 64.  Beyond, the prediction step is written as A = G^-1 S G^-H + I (S is Hermitian, so (G^-1 S)^H = S G^-H)
+// with an EXPLICIT inverse: G alone (256 KB at 128 channels: half the register file, one workgroup per CU) is inverted
+// in place in registers by the same pivoted Gauss-Jordan, and the three C x C x C products of an iteration
+// (G^-1 S, (.) G^-H, G A+) run on the fp64 matrix cores from K-slices staged in LDS (m_gemm_mfma).  The Wilson
+// iteration is a fixed-point iteration -- it corrects the rounding of the explicit inverse like any other perturbation.
+struct MvMat {
+    cd* p;
+    int64_t sp, sn, se;      // element e = i C + j of problem (window p, bin n) lives at p * sp + n * sn + e * se
+};
+__device__ __forceinline__ int64_t mv_at(const MvMat& m, int64_t p, int64_t n) { return p * m.sp + n * m.sn; }
+// Bin of workgroup blockIdx.x.  In the series layout the eight bins 8 m ... 8 m + 7 of an element share one 128-byte line;
+// workgroups are dealt to the eight XCDs round-robin, so with n = blockIdx.x every XCD would pull every line into its
+// own L2 for 16 of its bytes.  XCD x takes the contiguous bins [x N / 8, (x + 1) N / 8) instead.
+__device__ __forceinline__ int64_t mv_bin_of_block() {
+    const unsigned bx = blockIdx.x, N = gridDim.x;
+    return (N & 63u) == 0 ? (int64_t)(bx & 7u) * (N >> 3) + (bx >> 3) : (int64_t)bx;
+}
+
+// Out = (M + lam I)^-1, in place in registers: 512 threads form a 32 x 16 grid, thread (ty, tx) owns rows ty + 32 a,
+// columns tx + 16 b (16 complex elements of a 128 x 128 matrix: 128 registers, two waves per SIMD).  Step k: column k is published and the pivot row chosen as in mv_gj_eliminate (no row ever moves); the
+// pivot row is scaled by 1 / pivot, its column-k slot takes 1 / pivot itself and the column-k slots of the other rows
+// are cleared before the rank-1 update, so that slot k ends up holding column pr_k of the accumulated row operations E
+// (E M = P, P[pr_k][k] = 1): M^-1[k][pr_j] = slot[pr_k][j].
+template <int Q>
+__global__ void __launch_bounds__(512) m_inverse_inplace(MvMat M, const double* __restrict__ lam, MvMat Out,
+                                                         const int32_t* __restrict__ status, int C) {
+    constexpr int CP = 16 * Q, RB = CP <= 64 ? 64 : 128, TY = 32, RA = (CP + TY - 1) / TY;
+    __shared__ cd colbuf[2][RA * TY];
+    __shared__ cd rowbuf[CP];
+    __shared__ unsigned key[RB];
+    __shared__ int prow[CP], pos[RA * TY];
+    const int64_t n = mv_bin_of_block(), p = blockIdx.y;
+    if (status && status[p] != 0) return;
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15, lane = tid & 63;
+    const cd* src = M.p + mv_at(M, p, n);
+    const double l0 = lam ? lam[0] : 0.0;
+    cd g[RA][Q];
+#pragma unroll
+    for (int a = 0; a < RA; ++a)
+#pragma unroll
+        for (int b = 0; b < Q; ++b) {
+            const int r = ty + TY * a, c = tx + 16 * b;
+            if (r < C && c < C) {
+                g[a][b] = src[(int64_t)(r * C + c) * M.se];
+                if (r == c) g[a][b].x += l0;
+            } else {
+                g[a][b] = make_double2(r == c ? 1.0 : 0.0, 0.0);
+            }
+        }
+    unsigned used = 0;
+    if (tid < CP) { pos[tid] = tid < C ? tid : 0; prow[tid] = tid < C ? tid : 0; }
+    if (tid < RB) key[tid] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int kb = 0; kb < Q; ++kb) {
+        for (int kx = 0; kx < 16; ++kx) {
+            const int k = 16 * kb + kx;
+            if (k >= C) break;
+            cd* cb = colbuf[k & 1];
+            if (tx == kx) {
+#pragma unroll
+                for (int a = 0; a < RA; ++a) {
+                    const int r = ty + TY * a;
+                    const cd v = g[a][kb];
+                    cb[r] = v;
+                    const unsigned hi = (unsigned)(__double_as_longlong(v.x * v.x + v.y * v.y) >> 32);
+                    if (r < RB)
+                        key[r] = (((used >> a) & 1u) || r >= C) ? 0u
+                                 : ((hi & ~(unsigned)(2 * RB - 1)) | (unsigned)RB | (unsigned)(RB - 1 - r));
+                }
+            }
+            __syncthreads();
+            unsigned kv = key[lane];
+            if constexpr (RB > 64) kv = max(kv, key[lane + 64]);
+            const int pr = RB - 1 - (int)(mv_wave_max_u32(kv) & (unsigned)(RB - 1));
+            if (ty == (pr & (TY - 1))) {       // (the reciprocal is the owners' business: one wave in eight pays for it)
+                const cd piv = cb[pr];
+                const double pden = piv.x * piv.x + piv.y * piv.y;
+                const cd inv = make_double2(piv.x / pden, -piv.y / pden);
+#pragma unroll
+                for (int a = 0; a < RA; ++a)
+                    if (ty + TY * a == pr) {
+#pragma unroll
+                        for (int b = 0; b < Q; ++b) {
+                            g[a][b] = (b == kb && tx == kx) ? inv : m_mul(g[a][b], inv);
+                            rowbuf[tx + 16 * b] = g[a][b];
+                        }
+                        used |= 1u << a;
+                    }
+            }
+            if (tid == 0) { prow[k] = pr; pos[pr] = k; }
+            __syncthreads();
+            cd w[Q];
+#pragma unroll
+            for (int b = 0; b < Q; ++b) w[b] = rowbuf[tx + 16 * b];
+#pragma unroll
+            for (int a = 0; a < RA; ++a) {
+                const int r = ty + TY * a;
+                cd m = cb[r];
+                if (r == pr) m = make_double2(0.0, 0.0);
+                else if (tx == kx) g[a][kb] = make_double2(0.0, 0.0);
+#pragma unroll
+                for (int b = 0; b < Q; ++b) {
+                    g[a][b].x = fma(-m.x, w[b].x, fma(m.y, w[b].y, g[a][b].x));
+                    g[a][b].y = fma(-m.x, w[b].y, fma(-m.y, w[b].x, g[a][b].y));
+                }
+            }
+        }
+    }
+    __syncthreads();
+    cd* dst = Out.p + mv_at(Out, p, n);
+#pragma unroll
+    for (int a = 0; a < RA; ++a)
+#pragma unroll
+        for (int b = 0; b < Q; ++b) {
+            const int r = ty + TY * a, c = tx + 16 * b;
+            if (r < C && c < C) dst[(int64_t)(pos[r] * C + prow[c]) * Out.se] = g[a][b];
+        }
+}
+
+// O = X Y (BH: X Y^H; ADD_I: + I; ERR: err[p] = max |O - X| elementwise, O may alias X) per (window, bin), C <= 16 Q <=
+// 128, on the fp64 matrix cores.  K-slices of 16: X[:, k0 : k0 + 16] and Y[k0 : k0 + 16, :] wait in LDS (68 KB) while the
+// next slice travels HBM / L2 -> registers; 512 threads, wave w owns tile row w and every tile column of it: 8 tiles x
+// (re, im) x 4 = 64 accumulator doubles per lane at 128 channels, two waves per SIMD -- 32 independent MFMAs per 4-deep
+// step and wave.
+template <int Q, bool BH, bool ADD_I, bool ERR>
+__global__ void __launch_bounds__(512) m_gemm_mfma(MvMat X, MvMat Y, MvMat O, const int32_t* __restrict__ status,
+                                                   double* __restrict__ err, int C) {
+    static_assert(Q % 2 == 0 && Q <= 8, "even tile count, one tile row per wave");
+    constexpr int CP = 16 * Q, KS = 16, LSX = KS + 1, LSY = CP + 1, NU = Q / 2;
+    extern __shared__ __align__(16) unsigned char mv_smem[];
+    cd* Xs = reinterpret_cast<cd*>(mv_smem);      // [CP][LSX]
+    cd* Ys = Xs + CP * LSX;                       // [KS][LSY]
+    __shared__ double red[8];
+    const int64_t n = mv_bin_of_block(), p = blockIdx.y;
+    if (status && status[p] != 0) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const cd* xb = X.p + mv_at(X, p, n);
+    const cd* yb = Y.p + mv_at(Y, p, n);
+    cd rx[NU], ry[NU];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int idx = tid + 512 * u;
+            {
+                const int i = idx >> 4, k = k0 + (idx & 15);
+                rx[u] = (i < C && k < C) ? xb[(int64_t)(i * C + k) * X.se] : make_double2(0.0, 0.0);
+            }
+            if constexpr (BH) {
+                const int j = idx >> 4, k = k0 + (idx & 15);
+                ry[u] = (j < C && k < C) ? yb[(int64_t)(j * C + k) * Y.se] : make_double2(0.0, 0.0);
+            } else {
+                const int kr = idx / CP, j = idx - kr * CP, k = k0 + kr;
+                ry[u] = (k < C && j < C) ? yb[(int64_t)(k * C + j) * Y.se] : make_double2(0.0, 0.0);
+            }
+        }
+    };
+    auto park = [&]() {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int idx = tid + 512 * u;
+            Xs[(idx >> 4) * LSX + (idx & 15)] = rx[u];
+            if constexpr (BH) Ys[(idx & 15) * LSY + (idx >> 4)] = m_conj(ry[u]);
+            else { const int kr = idx / CP; Ys[kr * LSY + (idx - kr * CP)] = ry[u]; }
+        }
+    };
+    mv_f64x4 re[Q], im[Q];
+#pragma unroll
+    for (int tj = 0; tj < Q; ++tj) { re[tj] = (mv_f64x4){0.0, 0.0, 0.0, 0.0}; im[tj] = re[tj]; }
+    const int li = lane & 15, lk = lane >> 4;
+    const int Cr = (C + 15) & ~15;
+    const bool mine = wave < Q;
+    fetch(0);
+    park();
+    __syncthreads();
+    for (int k0 = 0; k0 < Cr; k0 += KS) {
+        const bool more = k0 + KS < Cr;
+        if (more) fetch(k0 + KS);
+        if (mine) {
+#pragma unroll
+            for (int kk = 0; kk < KS / 4; ++kk) {
+                const cd av = Xs[(16 * wave + li) * LSX + 4 * kk + lk];
+#pragma unroll
+                for (int tj = 0; tj < Q; ++tj) {
+                    const cd b = Ys[(4 * kk + lk) * LSY + 16 * tj + li];
+                    re[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, b.x, re[tj], 0, 0, 0);
+                    re[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(-av.y, b.y, re[tj], 0, 0, 0);
+                    im[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, b.y, im[tj], 0, 0, 0);
+                    im[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, b.x, im[tj], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                 // slice consumed
+        if (more) { park(); __syncthreads(); }
+    }
+    cd* ob = O.p + mv_at(O, p, n);
+    double emax = 0.0;
+    if (mine) {
+#pragma unroll
+        for (int tj = 0; tj < Q; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * wave + lk + 4 * r, j = 16 * tj + li;
+                if (i < C && j < C) {
+                    cd v = make_double2(re[tj][r], im[tj][r]);
+                    if (ADD_I && i == j) v.x += 1.0;
+                    if constexpr (ERR) {
+                        const cd old = xb[(int64_t)(i * C + j) * X.se];
+                        emax = fmax(emax, hypot(v.x - old.x, v.y - old.y));
+                    }
+                    ob[(int64_t)(i * C + j) * O.se] = v;
+                }
+            }
+    }
+    if constexpr (ERR) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) emax = fmax(emax, __shfl_xor(emax, off));
+        if (lane == 0) red[wave] = emax;
+        __syncthreads();
+        if (tid == 0) {
+            double e8 = red[0];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) e8 = fmax(e8, red[q]);
+            if (e8 > 0.0) mv_atomic_max_nonneg(err + p, e8);
+        }
+    }
+}
+
+// small helpers of the measures beyond 64 signals
+__global__ void m_real_to_cd(const double* __restrict__ a, cd* __restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = make_double2(a[i], 0.0);
+}
+__global__ void m_cd_to_real(const cd* __restrict__ a, double* __restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i].x;
+}
+// Sigma = H0 H0^T (connectivity.py:1703-1708): one thread per element
+__global__ void m_sigma(const double* __restrict__ h0, double* __restrict__ sigma, int C) {
+    const int64_t p = blockIdx.y;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x, E = C * C;
+    if (e >= E) return;
+    const int i = e / C, j = e % C;
+    double s = 0.0;
+    for (int k = 0; k < C; ++k) s += h0[p * E + i * C + k] * h0[p * E + j * C + k];
+    sigma[p * E + e] = s;
+}
+// sq[b] = sum_e |H[b][e]|^2 in a fixed order: one block per (window, bin)
+__global__ void __launch_bounds__(256) m_sumsq(const cd* __restrict__ H, double* __restrict__ sq, int E) {
+    __shared__ double red[256];
+    const int64_t b = blockIdx.x;
+    double s2 = 0.0;
+    for (int e = threadIdx.x; e < E; e += 256) { const cd v = H[b * E + e]; s2 += v.x * v.x + v.y * v.y; }
+    red[threadIdx.x] = s2;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sq[b] = red[0];
+}
+
 __global__ void m_flags(int32_t* status, int32_t* n_iter, double* err, double tol, int64_t P, int32_t* n_running) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
@@ -849,6 +1130,43 @@ static int mv_launch_update(int Q, dim3 grid, hipStream_t st, cd* G, const cd* A
     return SC_OK;
 }
 
+static MvMat mv_series(cd* b, int64_t N, int E) { return MvMat{b, (int64_t)E * N, 1, N}; }
+static MvMat mv_natural(cd* b, int64_t N, int E) { return MvMat{b, N * (int64_t)E, (int64_t)E, 1}; }
+static int mv_big_q(int64_t C) { return C <= 96 ? 6 : 8; }
+
+static int mv_launch_inverse_big(int64_t C, dim3 grid, hipStream_t st, MvMat M, const double* lam, MvMat Out,
+                                 const int32_t* status) {
+    if (mv_big_q(C) == 6) hipLaunchKernelGGL(m_inverse_inplace<6>, grid, dim3(512), 0, st, M, lam, Out, status, (int)C);
+    else hipLaunchKernelGGL(m_inverse_inplace<8>, grid, dim3(512), 0, st, M, lam, Out, status, (int)C);
+    SC_CHECK_HIP(hipGetLastError());
+    return SC_OK;
+}
+
+enum { MV_GEMM_PLAIN = 0, MV_GEMM_BH_I = 1, MV_GEMM_ERR = 2 };
+template <int Q>
+static int mv_launch_gemm_q(int mode, dim3 grid, hipStream_t st, MvMat X, MvMat Y, MvMat O, const int32_t* status,
+                            double* err, int C) {
+    constexpr size_t CP = 16 * Q;
+    const size_t lds = (CP * 17 + 16 * (CP + 1)) * sizeof(cd);
+#define MV_GEMM(BH, ADDI, ERRF)                                                                                     \
+    do {                                                                                                            \
+        auto k = m_gemm_mfma<Q, BH, ADDI, ERRF>;                                                                    \
+        SC_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
+        hipLaunchKernelGGL(k, grid, dim3(512), lds, st, X, Y, O, status, err, C);                                   \
+    } while (0)
+    if (mode == MV_GEMM_PLAIN) MV_GEMM(false, false, false);
+    else if (mode == MV_GEMM_BH_I) MV_GEMM(true, true, false);
+    else MV_GEMM(false, false, true);
+#undef MV_GEMM
+    SC_CHECK_HIP(hipGetLastError());
+    return SC_OK;
+}
+static int mv_launch_gemm(int64_t C, int mode, dim3 grid, hipStream_t st, MvMat X, MvMat Y, MvMat O,
+                          const int32_t* status, double* err) {
+    return mv_big_q(C) == 6 ? mv_launch_gemm_q<6>(mode, grid, st, X, Y, O, status, err, (int)C)
+                            : mv_launch_gemm_q<8>(mode, grid, st, X, Y, O, status, err, (int)C);
+}
+
 static int mv_threads(int C) {
     const int e = C * C;
     return e >= 256 ? 256 : (e > 128 ? 256 : (e > 64 ? 128 : 64));
@@ -861,8 +1179,9 @@ extern "C" int sc_mvar_max_signals(void) { return MV_CMAX; }
 extern "C" int sc_mvar_workspace_bytes(int64_t n_groups, int64_t C, int64_t N, size_t* bytes) {
     SC_REQUIRE(bytes && n_groups >= 1 && C >= 1 && N >= 2, "bad workspace query");
     const size_t E = (size_t)C * C, P = (size_t)n_groups, F = (size_t)N / 2 + 1;
-    // factor: S, G, A series; measures: H, A_mvar natural + small per-window arrays
-    const size_t factor = 3 * P * E * (size_t)N * sizeof(cd) + P * 16 + P * E * 8 + 128 + (size_t)MV_HIST * 4;
+    // factor: S, G, A series (beyond 64 signals also G^-1 and G^-1 S); measures: H, A_mvar natural + small per-window arrays
+    const size_t n_big = C > MV_CSMALL ? 5 : 3;
+    const size_t factor = n_big * P * E * (size_t)N * sizeof(cd) + P * 16 + P * E * 8 + 128 + (size_t)MV_HIST * 4;
     const size_t meas = 2 * P * F * E * sizeof(cd) + P * E * 8 * 3 + P * (F > 16 ? F : 16) * 8 + P * (size_t)C * 8 + P * 8 + 256;
     *bytes = (factor > meas ? factor : meas) + 256;
     return SC_OK;
@@ -878,8 +1197,8 @@ extern "C" int sc_mvar_factor_f64(const void* d_accum, const void* d_S, int64_t 
     SC_REQUIRE(d_work && d_G && d_n_iter && d_status, "NULL argument");
     SC_REQUIRE(n_groups >= 1 && n_groups <= 65535 && N >= 2 && N <= 1 << 24, "bad problem size");
     if (C < 1 || C > MV_CMAX) {
-        sc_set_error("full Wilson factorisation keeps a C x C matrix pair in LDS: n_signals <= %d (got %lld)", MV_CMAX,
-                     (long long)C);
+        sc_set_error("full Wilson factorisation keeps the C x C factor in one workgroup's registers: n_signals <= %d (got %lld)",
+                     MV_CMAX, (long long)C);
         return SC_EUNSUPPORTED;
     }
     size_t need = 0;
@@ -892,6 +1211,13 @@ extern "C" int sc_mvar_factor_f64(const void* d_accum, const void* d_S, int64_t 
     cd* S = (cd*)w; w += (size_t)P * E * N * sizeof(cd);
     cd* G = (cd*)w; w += (size_t)P * E * N * sizeof(cd);
     cd* A = (cd*)w; w += (size_t)P * E * N * sizeof(cd);
+    const bool big = C > MV_CSMALL;
+    cd* Ginv = nullptr;
+    cd* T = nullptr;
+    if (big) {
+        Ginv = (cd*)w; w += (size_t)P * E * N * sizeof(cd);
+        T = (cd*)w; w += (size_t)P * E * N * sizeof(cd);
+    }
     double* err = (double*)w; w += (size_t)P * 8;
     double* g0 = (double*)w; w += (size_t)P * E * 8;
     int32_t* n_fallback = (int32_t*)w; w += 64;
@@ -907,7 +1233,10 @@ extern "C" int sc_mvar_factor_f64(const void* d_accum, const void* d_S, int64_t 
         d.two_sided = (n_freq_accum == N && N > 1) ? 1 : 0;
         d.floats_per_bin = (int64_t)sc_plane_count(planes) * d.n_tiles * SC_TILE_ELEMS;
         d.n_obs = (double)n_obs;
-        hipLaunchKernelGGL(m_build, gridE, dim3(256), 0, st, sc_rec(d_accum, planes), d, S);
+        hipLaunchKernelGGL(m_build, gridE, dim3(256), 0, st, sc_rec(d_accum, planes), d, S, big ? (int64_t)E : (int64_t)1,
+                           big ? (int64_t)1 : N);
+    } else if (big) {
+        SC_CHECK_HIP(hipMemcpyAsync(S, d_S, (size_t)P * E * N * sizeof(cd), hipMemcpyDeviceToDevice, st));
     } else {
         hipLaunchKernelGGL(m_to_series, gridE, dim3(256), 0, st, (const cd*)d_S, S, N, E);
     }
@@ -941,9 +1270,12 @@ extern "C" int sc_mvar_factor_f64(const void* d_accum, const void* d_S, int64_t 
     (void)hipMemsetAsync(d_n_iter, 0, (size_t)P * 4, st);
     (void)hipMemsetAsync(n_fallback, 0, 64 + (size_t)MV_HIST * 4, st);
     // G0 = chol(Re ifft_n(S)[lag 0])^H broadcast over the bins (minimum_phase_decomposition.py:48-77)
-    hipLaunchKernelGGL(m_lag0, dim3((unsigned)(((int64_t)P * E + 3) / 4)), dim3(256), 0, st, S, g0, N, (int64_t)P * E);
+    if (big) hipLaunchKernelGGL(m_lag0_nat, dim3((unsigned)((E + 255) / 256), (unsigned)P), dim3(256), 0, st, S, g0, N, E);
+    else hipLaunchKernelGGL(m_lag0, dim3((unsigned)(((int64_t)P * E + 3) / 4)), dim3(256), 0, st, S, g0, N, (int64_t)P * E);
+    SC_CHECK_HIP(hipFuncSetAttribute((const void*)m_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)E * 8)));
     hipLaunchKernelGGL(m_chol, dim3((unsigned)P), dim3(256), (size_t)E * 8, st, g0, d_status, n_fallback, (int)C);
-    hipLaunchKernelGGL(m_fill, gridE, dim3(256), 0, st, g0, G, N, E);
+    if (big) hipLaunchKernelGGL(m_fill_nat, dim3((unsigned)((E + 255) / 256), (unsigned)N, (unsigned)P), dim3(256), 0, st, g0, G, N, E);
+    else hipLaunchKernelGGL(m_fill, gridE, dim3(256), 0, st, g0, G, N, E);
     // The stream is synchronised once per MV_POLL iterations: every iteration logs how many windows are still running
     // into its own slot; converged windows are skipped by every kernel, so the iterations queued past the last
     // convergence are empty launches.
@@ -951,7 +1283,14 @@ extern "C" int sc_mvar_factor_f64(const void* d_accum, const void* d_S, int64_t 
         const int first = queued;
         for (int b = 0; b < MV_POLL && queued < max_iter; ++b, ++queued) {
             void* bufs[1] = {A};
-            if ((rc = mv_launch_predict(Q, gridB, st, S, G, d_status, A, N, (int)C)) != SC_OK) goto done;
+            if (big) {          // A = G^-1 S G^-H + I: explicit inverse, two matrix-core products
+                // (G, S, G^-1 and G^-1 S in the natural layout [p][n][e]: coalesced; only A crosses the transform as series)
+                if ((rc = mv_launch_inverse_big(C, gridB, st, mv_natural(G, N, E), nullptr, mv_natural(Ginv, N, E), d_status)) != SC_OK) goto done;
+                if ((rc = mv_launch_gemm(C, MV_GEMM_PLAIN, gridB, st, mv_natural(Ginv, N, E), mv_natural(S, N, E),
+                                         mv_natural(T, N, E), d_status, nullptr)) != SC_OK) goto done;
+                if ((rc = mv_launch_gemm(C, MV_GEMM_BH_I, gridB, st, mv_natural(T, N, E), mv_natural(Ginv, N, E),
+                                         mv_series(A, N, E), d_status, nullptr)) != SC_OK) goto done;
+            } else if ((rc = mv_launch_predict(Q, gridB, st, S, G, d_status, A, N, (int)C)) != SC_OK) goto done;
             if (fused) {        // ifft -> causal mask -> fft in one kernel (sc_wilson_fft.hip)
                 if ((rc = sc_internal_causal_fft_pair(A, d_status, P, (int)C, N, st)) != SC_OK) goto done;
             } else {
@@ -959,7 +1298,10 @@ extern "C" int sc_mvar_factor_f64(const void* d_accum, const void* d_S, int64_t 
                 hipLaunchKernelGGL(m_causal, gridE, dim3(256), 0, st, A, N, (int)C);
                 MV_CHECK_FFT(rocfft_execute(fwd, bufs, nullptr, info));
             }
-            if ((rc = mv_launch_update(Q, gridB, st, G, A, d_status, err, N, (int)C)) != SC_OK) goto done;
+            if (big) {
+                if ((rc = mv_launch_gemm(C, MV_GEMM_ERR, gridB, st, mv_natural(G, N, E), mv_series(A, N, E), mv_natural(G, N, E),
+                                         d_status, err)) != SC_OK) goto done;
+            } else if ((rc = mv_launch_update(Q, gridB, st, G, A, d_status, err, N, (int)C)) != SC_OK) goto done;
             hipLaunchKernelGGL(m_flags, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, d_status, d_n_iter, err, tol, P,
                                n_running + queued);
         }
@@ -974,7 +1316,8 @@ extern "C" int sc_mvar_factor_f64(const void* d_accum, const void* d_S, int64_t 
             if (running == 0) break;
         }
     }
-    hipLaunchKernelGGL(m_to_natural, gridE, dim3(256), 0, st, G, (cd*)d_G, N, E);
+    if (big) (void)hipMemcpyAsync(d_G, G, (size_t)P * E * N * sizeof(cd), hipMemcpyDeviceToDevice, st);
+    else hipLaunchKernelGGL(m_to_natural, gridE, dim3(256), 0, st, G, (cd*)d_G, N, E);
     if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) {
         sc_set_error("Wilson factor copy-out failed: %s", hipGetErrorString(hipGetLastError()));
         rc = SC_EHIP; goto done;
@@ -1002,7 +1345,7 @@ extern "C" int sc_mvar_measure_f64(const void* d_G, int64_t n_groups, int64_t N,
     SC_REQUIRE(d_G && d_out && d_work, "NULL argument");
     SC_REQUIRE(which >= SC_MVAR_DTF && which <= SC_MVAR_NOISE_COVARIANCE, "unknown MVAR quantity");
     if (C < 1 || C > MV_CMAX) {
-        sc_set_error("MVAR measures keep a C x C matrix pair in LDS: n_signals <= %d (got %lld)", MV_CMAX, (long long)C);
+        sc_set_error("MVAR measures: n_signals <= %d (got %lld)", MV_CMAX, (long long)C);
         return SC_EUNSUPPORTED;
     }
     size_t need = 0;
@@ -1021,28 +1364,57 @@ extern "C" int sc_mvar_measure_f64(const void* d_G, int64_t n_groups, int64_t N,
     double* tot = (double*)w; w += (size_t)P * C * 8;
     double* lam = (double*)w;                         // [0] lam of H0, [1] lam' of H
     const int nt = mv_threads((int)C);
-    const size_t lds = mv_pair_lds((int)C);
-    (void)hipFuncSetAttribute((const void*)m_h0_inverse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)m_transfer, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)m_mvar_inverse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const bool big = C > MV_CSMALL;
+    const size_t lds = big ? 0 : mv_pair_lds((int)C);
+    if (!big) {
+        (void)hipFuncSetAttribute((const void*)m_h0_inverse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)m_transfer, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)m_mvar_inverse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
     const cd* G = (const cd*)d_G;
     const int h0_chunks = (E + 255) / 256;
     hipLaunchKernelGGL(m_h0, dim3((unsigned)P, (unsigned)h0_chunks), dim3(256), 0, st, G, h0, sq, N, E);
     hipLaunchKernelGGL(m_sum, dim3(1), dim3(64), 0, st, sq, P * h0_chunks, 1e-12 / (double)(P * E), lam);
-    hipLaunchKernelGGL(m_h0_inverse, dim3((unsigned)P), dim3(nt), lds, st, h0, lam, hinv, sigma, (int)C);
+    // beyond 64 signals the LDS-resident LU kernels give way to the in-register inverse and the matrix-core product;
+    // (H0 + lam I)^-1 as a complex matrix with zero imaginary part, parked in the (still unused) A_mvar buffer
+    cd* h0c = Amv;
+    cd* hinvc = Amv + (size_t)P * E;
+    if (big) {
+        const unsigned nb = (unsigned)(((int64_t)P * E + 255) / 256);
+        hipLaunchKernelGGL(m_real_to_cd, dim3(nb), dim3(256), 0, st, h0, h0c, (int64_t)P * E);
+        int rcb = mv_launch_inverse_big(C, dim3(1, (unsigned)P), st, MvMat{h0c, (int64_t)E, 0, 1}, lam,
+                                        MvMat{hinvc, (int64_t)E, 0, 1}, nullptr);
+        if (rcb != SC_OK) return rcb;
+        hipLaunchKernelGGL(m_cd_to_real, dim3(nb), dim3(256), 0, st, hinvc, hinv, (int64_t)P * E);
+        hipLaunchKernelGGL(m_sigma, dim3((unsigned)((E + 255) / 256), (unsigned)P), dim3(256), 0, st, h0, sigma, (int)C);
+    } else {
+        hipLaunchKernelGGL(m_h0_inverse, dim3((unsigned)P), dim3(nt), lds, st, h0, lam, hinv, sigma, (int)C);
+    }
     if (which == SC_MVAR_NOISE_COVARIANCE) {
         SC_CHECK_HIP(hipMemcpyAsync(d_out, sigma, (size_t)P * E * 8, hipMemcpyDeviceToDevice, st));
         SC_CHECK_HIP(hipStreamSynchronize(st));
         return SC_OK;
     }
-    hipLaunchKernelGGL(m_transfer, dim3((unsigned)F, (unsigned)P), dim3(nt), lds, st, G, hinv, H, sq, N, F, (int)C);
+    if (big) {          // H = G (H0 + lam I)^-1 on the non-negative bins, then the per-(window, bin) sums of |H|^2
+        int rcb = mv_launch_gemm(C, MV_GEMM_PLAIN, dim3((unsigned)F, (unsigned)P), st,
+                                 MvMat{const_cast<cd*>(G), N * (int64_t)E, (int64_t)E, 1}, MvMat{hinvc, (int64_t)E, 0, 1},
+                                 MvMat{H, F * (int64_t)E, (int64_t)E, 1}, nullptr, nullptr);
+        if (rcb != SC_OK) return rcb;
+        hipLaunchKernelGGL(m_sumsq, dim3((unsigned)(P * F)), dim3(256), 0, st, H, sq, E);
+    } else {
+        hipLaunchKernelGGL(m_transfer, dim3((unsigned)F, (unsigned)P), dim3(nt), lds, st, G, hinv, H, sq, N, F, (int)C);
+    }
     if (which == SC_MVAR_TRANSFER) {
         SC_CHECK_HIP(hipMemcpyAsync(d_out, H, (size_t)P * F * E * sizeof(cd), hipMemcpyDeviceToDevice, st));
         SC_CHECK_HIP(hipStreamSynchronize(st));
         return SC_OK;
     }
     hipLaunchKernelGGL(m_sum, dim3(1), dim3(64), 0, st, sq, P * F, 1e-12 / (double)(P * F * E), lam + 1);
-    {
+    if (big) {          // A_mvar = (H + lam' I)^-1 per (window, bin); the launch overwrites the parked H0 matrices last
+        int rcb = mv_launch_inverse_big(C, dim3((unsigned)F, (unsigned)P), st, MvMat{H, F * (int64_t)E, (int64_t)E, 1}, lam + 1,
+                                        MvMat{Amv, F * (int64_t)E, (int64_t)E, 1}, nullptr);
+        if (rcb != SC_OK) return rcb;
+    } else {
         const int Q = (int)((C + 15) / 16);
         const size_t glds = mv_gj_lds(Q);
 #define MV_INV(QQ)                                                                                              \
@@ -1059,6 +1431,7 @@ extern "C" int sc_mvar_measure_f64(const void* d_G, int64_t n_groups, int64_t N,
         return SC_OK;
     }
     if (which == SC_MVAR_DDTF) hipLaunchKernelGGL(m_inflow_all, dim3((unsigned)P), dim3(64), 0, st, H, tot, F, (int)C);
+    SC_CHECK_HIP(hipFuncSetAttribute((const void*)m_measure, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)(E + C) * 8)));
     hipLaunchKernelGGL(m_measure, dim3((unsigned)(P * F)), dim3(nt), (size_t)(E + C) * 8, st, H, Amv, sigma, tot, which,
                        (double*)d_out, F, (int)C);
     if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) {

@@ -366,7 +366,7 @@ def test_minimum_phase_decomposition_vs_reference_and_known_filters(sc, golden):
     G = minimum_phase_decomposition(np.tile(np.eye(3, dtype=complex), (1, 8, 1, 1)))   # white spectrum: G = I
     np.testing.assert_allclose(G, np.tile(np.eye(3, dtype=complex), (1, 8, 1, 1)), atol=1e-12)
     with pytest.raises(NotImplementedError):
-        minimum_phase_decomposition(np.tile(np.eye(65, dtype=complex), (1, 4, 1, 1)))
+        minimum_phase_decomposition(np.tile(np.eye(129, dtype=complex), (1, 4, 1, 1)))
 
 
 @pytest.mark.parametrize("tag", ["var3", "var5"])
@@ -393,7 +393,8 @@ def test_f9_mvar_measures_vs_reference(sc, golden, tag):
     assert c._last_wilson["not_converged"] == 0
 
 
-@pytest.mark.parametrize("c,N,P", [(3, 64, 2), (8, 128, 3), (17, 64, 1), (40, 32, 2)])
+@pytest.mark.parametrize("c,N,P", [(3, 64, 2), (8, 128, 3), (17, 64, 1), (40, 32, 2), (64, 32, 1),
+                                   (65, 32, 2), (80, 48, 1), (96, 64, 1), (97, 32, 1), (128, 32, 2), (100, 256, 1)])
 def test_full_wilson_factor_standalone_fp64(sc, c, N, P):
     """minimum_phase_decomposition() for c > 2 on exactly representable fp64 spectra of known
     minimum-phase filters: S = F F^H with F(z) = I + B z^-1 (||B|| < 1) factors back to F Q with the
@@ -411,8 +412,40 @@ def test_full_wilson_factor_standalone_fp64(sc, c, N, P):
     G = minimum_phase_decomposition(S)
     assert G.shape == S.shape and np.isfinite(G).all()
     np.testing.assert_allclose(G @ np.conj(np.swapaxes(G, -1, -2)), S, rtol=0, atol=1e-7 * np.abs(S).max())
-    if c <= 17:
+    if c <= 17 or (c, N) in ((65, 32), (128, 32)):      # (beyond 64 signals: explicit inverse + matrix-core products)
         np.testing.assert_allclose(G, so.minimum_phase_decomposition(S), rtol=0, atol=1e-6 * np.abs(G).max())
+
+
+@pytest.mark.parametrize("C", [72, 128])
+def test_mvar_measures_beyond_64_signals_vs_oracle(sc, C):
+    """65 ... 128 signals: Wilson factor, transfer function, noise covariance, MVAR coefficients and the directed
+    measures through the explicit-inverse / matrix-core kernels (sc_mvar.hip), float64 engine, against the oracle."""
+    rng = np.random.default_rng(C)
+    T, R = 64, 90
+    e = rng.standard_normal((T + 8, R, C))
+    x = e.copy()
+    for t in range(2, T + 8):                                 # a sparse stable VAR(2): neighbours drive each other
+        x[t] += 0.35 * x[t - 1] - 0.2 * x[t - 2]
+        x[t, :, 1:] += 0.25 * x[t - 1, :, :-1]
+    x = x[8:]
+    kw = dict(sampling_frequency=128.0, time_halfbandwidth_product=2)
+    c = sc.Connectivity.from_multitaper(sc.Multitaper(x, **kw), dtype=np.complex128)
+    coef, _ = so.multitaper_fft(x, fs=128.0, NW=2)
+    q = so.mvar_quantities(coef)
+
+    def close(a, b, what, tol=1e-6):
+        a, b = np.asarray(a), np.asarray(b)
+        assert a.shape == b.shape, (what, a.shape, b.shape)
+        err = np.abs(a - b).max() / np.abs(b).max()
+        assert err < tol, f"{what}: {err:.2e}"
+    close(c._minimum_phase_factor, q["G"], "minimum phase factor")
+    close(c._noise_covariance, q["noise_covariance"], "noise covariance")
+    close(c._transfer_function, q["H"], "transfer function")
+    close(c._MVAR_Fourier_coefficients, q["A"], "MVAR coefficients", tol=1e-5)
+    close(c.directed_transfer_function(), so.directed_transfer_function(coef, q=q), "DTF")
+    close(c.partial_directed_coherence(), so.partial_directed_coherence(coef, q=q), "PDC", tol=1e-5)
+    close(c.direct_directed_transfer_function(), so.direct_directed_transfer_function(coef, q=q), "dDTF", tol=1e-5)
+    assert c._last_wilson["not_converged"] == 0 and c._last_wilson["iterations"] < 60
 
 
 @pytest.mark.parametrize("c,N,P", [(2, 256, 5), (2, 512, 3), (2, 1024, 3), (2, 2048, 2), (2, 4096, 2),

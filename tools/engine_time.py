@@ -38,13 +38,18 @@ def main():
     dev = torch.device("cuda", 0)
     _lib.timing_enable(True)
     print("# tools/engine_time.py: ms per pass (library hipEvent timers, median of 5 after 2 warm-up passes)")
+    only = sys.argv[1:]                                        # e.g. "cfg3 float64" restricts the table (profiling)
     for name, cfg in CONFIGS.items():
+        if only and name not in only:
+            continue
         K = int(2 * cfg["NW"] - 1)
         tap, _ = dpss_windows(cfg["L"], cfg["NW"], K, is_low_bias=False)
         tap = np.asarray(tap)
         if tap.shape[0] != K:
             tap = tap.T
         for f64 in (False, True):
+            if only and not ({"float32", "float64"} & set(only)) <= {"float64" if f64 else "float32"}:
+                continue
             real = torch.float64 if f64 else torch.float32
             h = torch.from_numpy(np.ascontiguousarray(tap * np.sqrt(FS) / FS)).to(dev, real)
             x = torch.randn((cfg["T"], cfg["R"], cfg["C"]), device=dev, dtype=real)

@@ -1,5 +1,4 @@
-"""Full C x C Wilson factorisation + DTF at 64 channels (the largest the LDS-resident LU takes): 40 trials x 512
-samples, N = 512 two-sided bins.  Usage: python tools/mvar_time.py [C T window].  Run under `rocprofv3 --kernel-trace --stats` for the per-kernel split."""
+"""Full C x C Wilson factorisation + DTF (up to 128 channels): 40 trials x 512 samples, N = 512 two-sided bins.  Usage: python tools/mvar_time.py [C T window].  Run under `rocprofv3 --kernel-trace --stats` for the per-kernel split."""
 import os
 import sys
 import time

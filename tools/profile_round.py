@@ -96,6 +96,9 @@ if sq:
     open(os.path.join(P, "r02_pmc_fused.txt"), "w").write("\n".join(h2 + sq) + "\n")
 
 for src, dst, head in (("mvar_64ch.txt", "r02_mvar_64ch.txt", "# tools/mvar_time.py 64 1792 256: full 64 x 64 Wilson factorisation + DTF, 7 windows x 256 bins (round 2)"),
+                       ("mvar_128ch.txt", "r02_mvar_128ch.txt", "# tools/mvar_time.py 128 1792 256: full 128 x 128 Wilson factorisation + DTF, 7 windows x 256 bins (round 2)"),
+                       ("engine_time.txt", "r02_engine_time.txt", "# float32 and float64 engine on the BASELINE configurations (round 2)"),
+                       ("stage_a.txt", "r02_stage_a.txt", "# tools/stage_a_breakdown.py: stage A per window length, cfg3 data volume (round 2)"),
                        ("plane_pass.txt", "r02_plane_pass.txt", "# tools/plane_pass_time.py: stage B per plane family, cfg3 data volume, round 2"),
                        ("shape_sweep.txt", "r02_shape_sweep.txt", "# tools/shape_sweep.py, round 2"),
                        ("fused_ablation.txt", "r02_fused_ablation.txt", "# tools/fused_ablation.py, round 2 (SC_FUSED_DEBUG; results WRONG when set)")):

@@ -25,6 +25,9 @@ for d in kt fetch write sq; do
     [ -n "$db" ] && python tools/rocpd_summary.py $db > $OUT/$d.txt 2>&1
 done
 python tools/mvar_time.py 64 1792 256 > $OUT/mvar_64ch.txt 2>&1
+python tools/mvar_time.py 128 1792 256 > $OUT/mvar_128ch.txt 2>&1
+python tools/engine_time.py > $OUT/engine_time.txt 2>&1
+python tools/stage_a_breakdown.py > $OUT/stage_a.txt 2>&1
 python tools/plane_pass_time.py > $OUT/plane_pass.txt 2>&1
 python tools/shape_sweep.py > $OUT/shape_sweep.txt 2>&1
 python tools/fused_ablation.py > $OUT/fused_ablation.txt 2>&1
