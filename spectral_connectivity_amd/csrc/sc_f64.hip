@@ -15,6 +15,7 @@
 // Same record layout as the f32 engine (upper-triangular 16x16 tiles, un-normalised sums: trial shards add), double
 // elements.  Workgroup = 4 waves = one bin x one tile group; observation rows staged HBM -> registers -> LDS in chunks
 // of 16 (double buffered, one barrier per chunk); XCD-aware blockIdx -> (bin, tile group) like sc_csm.hip.
+#include <cstdlib>
 #include "sc_common.h"
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
@@ -38,18 +39,26 @@ __device__ __forceinline__ int64_t f64_obs_offset(const F64Args& p, int o) {
     return p.obs_stride > 0 ? (int64_t)o * p.obs_stride : sc_obs_offset(p.ax, o);
 }
 
-// E double2 elements per thread cover F64_OC rows x CP channels (CP <= 256: E = 16)
+// E double2 elements per thread cover E rows x CP channels (CP <= 256); element e = tid + 256 i sits in row e / CP --
+// walked incrementally from (row0, c0) = (tid / CP, tid % CP), computed once per kernel: no division per element
+struct F64Walk { int row0, c0, dq, dr; };
+__device__ __forceinline__ F64Walk f64_walk(const F64Args& p, int tid) {
+    F64Walk w;
+    w.row0 = tid / p.CP; w.c0 = tid - w.row0 * p.CP;
+    w.dq = 256 / p.CP; w.dr = 256 - w.dq * p.CP;
+    return w;
+}
 template <int E>
-__device__ __forceinline__ void f64_load(const F64Args& p, const double2* base, int o0, int tid, double2 (&r)[E]) {
+__device__ __forceinline__ void f64_load(const F64Args& p, const F64Walk& w, const double2* base, int o0, double2 (&r)[E]) {
+    int row = w.row0, c = w.c0;
 #pragma unroll
     for (int i = 0; i < E; ++i) {
-        const int e = tid + i * 256;
         double2 v = make_double2(0.0, 0.0);
-        if (e < F64_OC * p.CP) {
-            const int row = e / p.CP, c = e - row * p.CP, o = o0 + row;
-            if (o < p.n_obs && c < p.C) v = base[f64_obs_offset(p, o) + c];
-        }
+        const int o = o0 + row;
+        if (row < E && o < p.n_obs && c < p.C) v = base[f64_obs_offset(p, o) + c];
         r[i] = v;
+        row += w.dq; c += w.dr;
+        if (c >= p.CP) { c -= p.CP; ++row; }
     }
 }
 template <int E>
@@ -57,12 +66,12 @@ __device__ __forceinline__ void f64_store(const F64Args& p, double2* lds, int ti
 #pragma unroll
     for (int i = 0; i < E; ++i) {
         const int e = tid + i * 256;
-        if (e < F64_OC * p.CP) lds[e] = r[i];          // row stride = CP
+        if (e < E * p.CP) lds[e] = r[i];          // row stride = CP
     }
 }
 
 template <int MAX_SLOTS, int E>
-__global__ void __launch_bounds__(256) csm_f64_kernel(F64Args p) {
+__global__ void __launch_bounds__(256, MAX_SLOTS <= 9 ? 2 : 1) csm_f64_kernel(F64Args p) {
     extern __shared__ __align__(16) unsigned char f64_smem[];
     double2* lds = reinterpret_cast<double2*>(f64_smem);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -89,10 +98,11 @@ __global__ void __launch_bounds__(256) csm_f64_kernel(F64Args p) {
 #pragma unroll
     for (int s = 0; s < MAX_SLOTS; ++s) { re[s] = (f64x4){0.0, 0.0, 0.0, 0.0}; im[s] = re[s]; }
 
-    const int buf = F64_OC * p.CP;
-    const int n_chunks = (p.n_obs + F64_OC - 1) / F64_OC;
+    const int buf = E * p.CP;
+    const int n_chunks = (p.n_obs + E - 1) / E;
+    const F64Walk walk = f64_walk(p, tid);
     double2 regs[E];
-    f64_load<E>(p, base, 0, tid, regs);
+    f64_load<E>(p, walk, base, 0, regs);
     f64_store<E>(p, lds, tid, regs);
     __syncthreads();
     // A operand: lane l holds A[i = l & 15][k = l >> 4]; B operand: B[k = l >> 4][j = l & 15]  (one f64 each)
@@ -101,9 +111,9 @@ __global__ void __launch_bounds__(256) csm_f64_kernel(F64Args p) {
         const double2* cur = lds + (ch & 1) * buf;
         double2* nxt = lds + ((ch + 1) & 1) * buf;
         const bool more = ch + 1 < n_chunks;
-        if (more) f64_load<E>(p, base, (ch + 1) * F64_OC, tid, regs);
+        if (more) f64_load<E>(p, walk, base, (ch + 1) * E, regs);
 #pragma unroll
-        for (int kk = 0; kk < F64_OC / 4; ++kk) {
+        for (int kk = 0; kk < E / 4; ++kk) {
             const double2* rowp = cur + (kk * 4 + k) * p.CP + c16;
 #pragma unroll
             for (int s = 0; s < MAX_SLOTS; ++s) {       // invalid slots recompute tile (0, 0) and are never stored
@@ -181,15 +191,17 @@ __global__ void __launch_bounds__(256) nonlinear_f64_kernel(F64Args p) {
     const int li = lane >> 3, lj = lane & 7;
     const int buf = F64_OC * p.CP;
     const int n_chunks = (p.n_obs + F64_OC - 1) / F64_OC;
+    static_assert(E == F64_OC, "one staged row per register");
+    const F64Walk walk = f64_walk(p, tid);
     double2 regs[E];
-    f64_load<E>(p, base, 0, tid, regs);
+    f64_load<E>(p, walk, base, 0, regs);
     f64_store<E>(p, lds, tid, regs);
     __syncthreads();
     for (int ch = 0; ch < n_chunks; ++ch) {
         const double2* cur = lds + (ch & 1) * buf;
         double2* nxt = lds + ((ch + 1) & 1) * buf;
         const bool more = ch + 1 < n_chunks;
-        if (more) f64_load<E>(p, base, (ch + 1) * F64_OC, tid, regs);
+        if (more) f64_load<E>(p, walk, base, (ch + 1) * F64_OC, regs);
         // rows past n_obs are zero: +0 for every plane except UNIT (0 / 0 = NaN), so bound the loop by the real count
         const int rows = min(F64_OC, p.n_obs - ch * F64_OC);
         for (int row = wave; row < rows; row += 4) {
@@ -261,6 +273,117 @@ __global__ void __launch_bounds__(256) nonlinear_f64_kernel(F64Args p) {
     }
 }
 
+// ---- the same planes for 48+ channels: 64 x 64 channel blocks, 8 x 8 pairs per lane ---------------------------------
+// nonlinear_f64_kernel reads (4 + 4) x 16 bytes of LDS per 16 pairs and observation -- 2.7 bytes per fp64 instruction
+// against the 2 the LDS pipe delivers at the fp64 VALU rate -- keeps 264 registers (one wave per SIMD) and spends as
+// many instructions on the integer divisions of its staging as on the products: 20 ms for the |Im s| plane of cfg3.  Here a
+// workgroup owns ONE upper-triangular 64 x 64 block of a bin (blocks of a bin on the same XCD: they re-read the same
+// rows), a wave is an 8 x 8 lane grid and a lane owns the 8 x 8 pairs (li + 8 a, lj + 8 b): 16 reads of 16 bytes per 64
+// pairs (1.3 bytes per instruction), lanes of a read walk consecutive channels (no bank conflicts); the four waves take
+// the observation rows of a 16-row chunk round-robin and are summed through LDS in a fixed order at the end.  Staging:
+// thread t pulls channel t & 127 (64 of the block's row range, 64 of its column range) of rows t >> 7, + 2, ...: whole
+// 2 KB runs, no division.
+#define F64B_OC 16
+template <uint32_t WHICH>
+__global__ void __launch_bounds__(256, 2) nonlinear_f64_block_kernel(F64Args p) {
+    static_assert(WHICH == SC_PLANE_ABS_IM || WHICH == SC_PLANE_IM_SQ || WHICH == SC_PLANE_SIGN_IM, "one plane per launch");
+    extern __shared__ __align__(16) unsigned char f64_smem[];
+    double2* lds = reinterpret_cast<double2*>(f64_smem);            // [2][F64B_OC][128]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NB64 = (p.C + 63) >> 6, n_blk = NB64 * (NB64 + 1) / 2;
+    const int id = blockIdx.x, xcd = id & 7, jj = id >> 3;
+    const int blk = jj % n_blk;
+    const int bin = (jj / n_blk) * 8 + xcd;
+    if (bin >= p.n_bins) return;
+    int BI = 0, BJ = 0;
+    { int rem = blk, len = NB64; while (rem >= len) { rem -= len; ++BI; --len; } BJ = BI + rem; }
+    const int g = bin / p.F, f = bin - g * p.F;
+    const double2* base = p.base + (int64_t)f * p.ax.sF + sc_group_offset(p.ax, g);
+    // staging: channel slot cs = tid & 127 (0-63: row range of the block, 64-127: its column range), rows tid >> 7 + 2 u
+    const int cs = tid & 127, r0 = tid >> 7;
+    const int cg = (cs < 64 ? BI * 64 + cs : BJ * 64 + (cs - 64));
+    const bool have = cg < p.C && (BI != BJ || cs < 64);          // a diagonal block reads its row range for both operands
+    double2 regs[F64B_OC / 2];
+    auto fetch = [&](int o0) {
+#pragma unroll
+        for (int u = 0; u < F64B_OC / 2; ++u) {
+            const int o = o0 + r0 + 2 * u;
+            regs[u] = (have && o < p.n_obs) ? base[f64_obs_offset(p, o) + cg] : make_double2(0.0, 0.0);
+        }
+    };
+    auto park = [&](double2* dst) {
+#pragma unroll
+        for (int u = 0; u < F64B_OC / 2; ++u) dst[(r0 + 2 * u) * 128 + cs] = regs[u];
+    };
+    double acc[64];
+#pragma unroll
+    for (int e = 0; e < 64; ++e) acc[e] = 0.0;
+    const int li = lane >> 3, lj = lane & 7;
+    const int joff = BI == BJ ? 0 : 64;
+    const int n_chunks = (p.n_obs + F64B_OC - 1) / F64B_OC;
+    fetch(0);
+    park(lds);
+    __syncthreads();
+    for (int ch = 0; ch < n_chunks; ++ch) {
+        const double2* cur = lds + (ch & 1) * (F64B_OC * 128);
+        const bool more = ch + 1 < n_chunks;
+        if (more) fetch((ch + 1) * F64B_OC);
+        // rows past n_obs are zero: they add |0|, 0^2, sign(0) = 0
+#pragma unroll 1
+        for (int row = wave; row < F64B_OC; row += 4) {
+            const double2* rp = cur + row * 128;
+            // all sixteen operands of the row are requested before the first product (one LDS round trip per row, hidden by
+            // the SIMD's other wave; loaded one column at a time the compiler waits for each of them)
+            double2 xi[8], xjv[8];
+#pragma unroll
+            for (int a = 0; a < 8; ++a) xi[a] = rp[li + 8 * a];
+#pragma unroll
+            for (int b = 0; b < 8; ++b) xjv[b] = rp[joff + lj + 8 * b];
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const double2 xj = xjv[b];
+#pragma unroll
+                for (int a = 0; a < 8; ++a) {
+                    const double imv = xi[a].y * xj.x - xi[a].x * xj.y;
+                    if constexpr (WHICH == SC_PLANE_ABS_IM) acc[a * 8 + b] += fabs(imv);
+                    else if constexpr (WHICH == SC_PLANE_IM_SQ) acc[a * 8 + b] = fma(imv, imv, acc[a * 8 + b]);
+                    else acc[a * 8 + b] += (imv > 0.0 ? 1.0 : 0.0) - (imv < 0.0 ? 1.0 : 0.0);
+                }
+            }
+        }
+        if (more) park(lds + ((ch + 1) & 1) * (F64B_OC * 128));
+        __syncthreads();
+    }
+    // waves 1-3 -> LDS, wave 0 adds them in a fixed order; two halves of 32 accumulators (3 x 32 x 64 doubles = 48 KB)
+    double* red = reinterpret_cast<double*>(f64_smem);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (wave > 0) {
+#pragma unroll
+            for (int e = 0; e < 32; ++e) red[((wave - 1) * 32 + e) * 64 + lane] = acc[h * 32 + e];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int e = 0; e < 32; ++e)
+                acc[h * 32 + e] += red[(0 * 32 + e) * 64 + lane] + red[(1 * 32 + e) * 64 + lane] + red[(2 * 32 + e) * 64 + lane];
+        }
+        __syncthreads();
+    }
+    if (wave != 0) return;
+    double* out = p.accum + (int64_t)bin * p.elems_per_bin + (int64_t)sc_plane_offset(p.planes, WHICH) * p.n_tiles * SC_TILE_ELEMS;
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const int i = BI * 64 + li + 8 * a, jx = BJ * 64 + lj + 8 * b;
+            const int ti = i >> 4, tj = jx >> 4;
+            if (ti <= tj && tj < p.NB)
+                out[(int64_t)sc_tile_index(ti, tj, p.NB) * SC_TILE_ELEMS + (i & 15) * 16 + (jx & 15)] = acc[a * 8 + b];
+        }
+}
+
 // ---------------------------------------------------------------------------------------------- host side
 static int f64_setup(const void* d_X, const sc_spectra_desc* desc, uint32_t planes, double* d_accum, F64Args* a) {
     SC_REQUIRE(d_X && desc && d_accum, "NULL argument");
@@ -303,8 +426,9 @@ template <int MAX_SLOTS>
 static int launch_csm_f64(F64Args a, hipStream_t st) {
     a.n_groups_of_tiles = (a.n_tiles + 4 * MAX_SLOTS - 1) / (4 * MAX_SLOTS);
     const unsigned grid = (unsigned)(((a.n_bins + 7) / 8) * 8 * a.n_groups_of_tiles);
-    const size_t shmem = (size_t)2 * F64_OC * a.CP * sizeof(double2);
-    auto k = csm_f64_kernel<MAX_SLOTS, 16>;
+    constexpr int OC = 8;          // observation rows per staged chunk: 8 registers of staging, two workgroups per CU
+    const size_t shmem = (size_t)2 * OC * a.CP * sizeof(double2);
+    auto k = csm_f64_kernel<MAX_SLOTS, OC>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), shmem, st, a);
     SC_CHECK_HIP(hipGetLastError());
@@ -324,6 +448,18 @@ static int launch_nl_f64(const F64Args& a, hipStream_t st) {
     return SC_OK;
 }
 
+template <uint32_t WHICH>
+static int launch_nl_f64_block(const F64Args& a, hipStream_t st) {
+    const int NB64 = (a.C + 63) / 64, n_blk = NB64 * (NB64 + 1) / 2;
+    const unsigned grid = (unsigned)(((a.n_bins + 7) / 8) * 8 * n_blk);
+    const size_t shmem = (size_t)2 * F64B_OC * 128 * sizeof(double2);      // 64 KB (the final reduction needs 48 KB)
+    auto k = nonlinear_f64_block_kernel<WHICH>;
+    SC_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), shmem, st, a);
+    SC_CHECK_HIP(hipGetLastError());
+    return SC_OK;
+}
+
 // Fills the planes named by `which` (a subset of `planes`) of the double records in d_accum.  SC_PLANE_CSM runs on the
 // fp64 matrix cores, every other plane on the fp64 VALU.
 extern "C" int sc_accumulate_f64(const void* d_X, const sc_spectra_desc* desc, uint32_t planes, uint32_t which,
@@ -337,6 +473,28 @@ extern "C" int sc_accumulate_f64(const void* d_X, const sc_spectra_desc* desc, u
     if (rc0 != SC_OK) return rc0;
     hipStream_t st = (hipStream_t)stream;
     int rc = SC_OK;
+    // With both the CSM and per-observation planes requested, the plane kernels go to a side stream forked from and
+    // joined back into the caller's: they fill the CUs the CSM kernel's tail leaves idle (-1 ms of 19 at cfg3).  There is
+    // no more to gain from overlapping them: forced to share every CU (one workgroup of each) the pair runs SLOWER
+    // (22 ms) -- on MI355X the fp64 matrix rate equals the fp64 vector rate, the two kernels compete for the same
+    // arithmetic, and their sum, 0.47 T lane-operations at cfg3 = 11.9 ms at 2.4 GHz, is the bound of this engine.
+    static hipStream_t side = nullptr;
+    static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    const bool fork = (which & SC_PLANE_CSM) && (which & ~SC_PLANE_CSM) && a.C >= 48 && !getenv("SC_F64_NO_FORK");
+    if (fork && !side) {
+        if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess) {
+            sc_set_error("sc_accumulate_f64: side stream creation failed");
+            return SC_EHIP;
+        }
+    }
+    hipStream_t st_nl = st;
+    if (fork) {
+        SC_CHECK_HIP(hipEventRecord(ev_fork, st));
+        SC_CHECK_HIP(hipStreamWaitEvent(side, ev_fork, 0));
+        st_nl = side;
+    }
     if (which & SC_PLANE_CSM) {
         a.plane = sc_plane_offset(planes, SC_PLANE_CSM);
         const int need = (a.n_tiles + 3) / 4;
@@ -347,6 +505,12 @@ extern "C" int sc_accumulate_f64(const void* d_X, const sc_spectra_desc* desc, u
         if (rc) return rc;
     }
     uint32_t w = which & ~SC_PLANE_CSM;
+    st = st_nl;
+    if (a.C >= 48 && !getenv("SC_F64_NO_BLOCK")) {      // 64 x 64 blocks, one plane per launch (see nonlinear_f64_block_kernel)
+        if (w & SC_PLANE_ABS_IM) { if ((rc = launch_nl_f64_block<SC_PLANE_ABS_IM>(a, st))) return rc; w &= ~SC_PLANE_ABS_IM; }
+        if (w & SC_PLANE_IM_SQ) { if ((rc = launch_nl_f64_block<SC_PLANE_IM_SQ>(a, st))) return rc; w &= ~SC_PLANE_IM_SQ; }
+        if (w & SC_PLANE_SIGN_IM) { if ((rc = launch_nl_f64_block<SC_PLANE_SIGN_IM>(a, st))) return rc; w &= ~SC_PLANE_SIGN_IM; }
+    }
     if ((w & (SC_PLANE_ABS_IM | SC_PLANE_IM_SQ)) == (SC_PLANE_ABS_IM | SC_PLANE_IM_SQ)) {
         if ((rc = launch_nl_f64<SC_PLANE_ABS_IM | SC_PLANE_IM_SQ, 2>(a, st))) return rc;
         w &= ~(SC_PLANE_ABS_IM | SC_PLANE_IM_SQ);
@@ -355,5 +519,9 @@ extern "C" int sc_accumulate_f64(const void* d_X, const sc_spectra_desc* desc, u
     if (w & SC_PLANE_IM_SQ) { if ((rc = launch_nl_f64<SC_PLANE_IM_SQ, 3>(a, st))) return rc; }
     if (w & SC_PLANE_SIGN_IM) { if ((rc = launch_nl_f64<SC_PLANE_SIGN_IM, 3>(a, st))) return rc; }
     if (w & SC_PLANE_UNIT) { if ((rc = launch_nl_f64<SC_PLANE_UNIT, 2>(a, st))) return rc; }
+    if (fork) {
+        SC_CHECK_HIP(hipEventRecord(ev_join, side));
+        SC_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, ev_join, 0));
+    }
     return rc;
 }

@@ -527,7 +527,15 @@ class Multitaper:
                     x, h, self.n_time_samples_per_window, self.n_time_samples_per_step,
                     self.n_fft_samples, self.n_time_windows, self.detrend_type)
             else:
-                x_host = np.ascontiguousarray(self.time_series, dtype=np.float32)
+                ts = np.asarray(self.time_series)
+                if self.detrend_type is not None and ts.dtype == np.float64 and ts.size:
+                    # Every window's own detrend removes any constant, so one per (trial, signal) may be taken out in
+                    # float64 BEFORE the cast: a DC offset 1e5 times the signal (raw EEG / MEG) would otherwise cost the
+                    # float32 copy all but two digits of the signal.  (detrend_type None keeps the samples as given.)
+                    x_host = np.empty(ts.shape, dtype=np.float32)
+                    np.subtract(ts, ts.mean(axis=0, keepdims=True), out=x_host, casting="unsafe")
+                else:
+                    x_host = np.ascontiguousarray(ts, dtype=np.float32)
                 n_signals = x_host.shape[2]
                 if n_signals % 2 and n_signals + 1 <= 256:
                     # odd channel count: ONE all-zero channel is appended on the host, before the upload, so that the

@@ -669,3 +669,22 @@ def test_silent_and_constant_channels_give_exact_zero_spectra(sc, N):
     ok = [0, 1, 3, 4]
     assert np.all(coh[:, ok][:, :, ok][:, ~np.eye(4, dtype=bool)] > 0)
     assert np.all(c.power()[0][:, [2, 5]] == 0)
+
+
+def test_large_dc_offset_float32_engine(sc):
+    """A DC offset 1e5 times the signal: the float32 engine removes a per-(trial, signal) constant in float64 on the host
+    before its float32 cast (every window's detrend removes any constant anyway), so the cast does not eat the signal."""
+    rng = np.random.default_rng(5)
+    T, R, C = 512, 6, 5
+    x = rng.standard_normal((T, R, C))
+    x[:, :, 1] += 0.7 * x[:, :, 0]
+    x += 1e5 * (1.0 + rng.random((1, R, C)))
+    kw = dict(n_time_samples_per_window=128, n_time_samples_per_step=64)
+    coef, _ = so.multitaper_fft(x, fs=250.0, NW=3, **kw)
+    for det in ("constant", "linear"):
+        coef, _ = so.multitaper_fft(x, fs=250.0, NW=3, detrend_type=det, **kw)
+        m = sc.Multitaper(x, sampling_frequency=250.0, time_halfbandwidth_product=3, detrend_type=det, **kw)
+        c = sc.Connectivity.from_multitaper(m, dtype=np.complex64)
+        close32(c.power(), so.power(coef), what=f"power, DC offset, detrend={det}")
+        close32(c.coherence_magnitude(), so.coherence_magnitude(coef), rtol=2e-5, atol_scale=2e-5,
+                what=f"coherence, DC offset, detrend={det}")
