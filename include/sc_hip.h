@@ -172,6 +172,15 @@ int sc_multitaper_fft_f32(const float* d_x, int64_t T, int64_t R, int64_t C,
                           int64_t L, int64_t step, int64_t W, int64_t N,
                           const float* d_tapers, int64_t K, int detrend_type,
                           const void* d_twiddles, void* d_X /*float2*/, void* stream);
+/* float64 engine, the same fusion in doubles (sc_mtfft_f64.hip): complex128 spectra X[f][w][r][k][c], one wave per
+ * packed channel pair, in-place mixed-radix passes in LDS, twiddles computed by the kernel.  Lengths with a compiled
+ * transform: 64, 128, 256, 512, 1024 and 200, 250, 400, 500, 1000 (sc_multitaper_fft_f64_supported); every other
+ * length: sc_taper_windows_f64 + sc_fft_execute_f64. */
+int sc_multitaper_fft_f64_supported(int64_t L, int64_t N);
+int sc_multitaper_fft_f64(const double* d_x, int64_t T, int64_t R, int64_t C,
+                          int64_t L, int64_t step, int64_t W, int64_t N,
+                          const double* d_tapers, int64_t K, int detrend_type,
+                          void* d_X /*double2*/, void* stream);
 
 /* ---- stage B: accumulators -----------------------------------------------------------
  * Number of floats of one bin record for `planes`, and total bins (groups * F). */

@@ -67,6 +67,9 @@ SYMBOLS = {
     "sc_fft_twiddles_f32": (c_int, [c_int64, c_void_p, c_void_p]),
     "sc_multitaper_fft_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64,
                                       c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
+    "sc_multitaper_fft_f64_supported": (c_int, [c_int64, c_int64]),
+    "sc_multitaper_fft_f64": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64,
+                                      c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "sc_fft_plan_create": (c_int, [POINTER(c_void_p), c_int64, c_int64]),
     "sc_fft_plan_work_bytes": (c_int, [c_void_p, POINTER(c_size_t)]),
     "sc_fft_execute": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),

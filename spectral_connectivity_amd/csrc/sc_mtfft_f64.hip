@@ -1,0 +1,266 @@
+// sc_mtfft_f64.hip -- stage A of the float64 engine as ONE kernel: window extraction + detrend + taper + real FFT +
+// transposed store (transforms.py:1147-1171, 1311-1405, 1798-1915), complex128 spectra X[f][w][r][k][c].
+//
+// The float64 engine first took the three-pass route of the odd window lengths (sc_taper_windows_f64 -> double-precision
+// rocFFT in chunks -> rows_to_bins transpose): every sample crosses HBM five times as a double, 14.9 ms for the cfg3
+// volume against 1.5 ms for the float32 kernel.  This is the wave-per-pair scheme of mtfft_mixed_wave_kernel
+// (sc_mtfft.hip) in doubles: a workgroup owns (window, trial, tile of 2 NF channels); the detrended window tile stays in
+// LDS for all tapers; wave w packs channels (2 w, 2 w + 1) of the tile into one complex series, runs the whole
+// autosort (Stockham) transform -- radix 5 / 4 / 3 / 2 passes, so powers of two and the next_fast_len lengths alike --
+// IN PLACE on its own slice of LDS (a wave's LDS instructions execute in order: no workgroup barrier between passes),
+// and the pairs are separated by conjugate symmetry on the way out (DC / Nyquist exactly real, an identically zero
+// channel exactly zero), 32 bytes per pair and frequency row, 32 NF bytes contiguous per row.  Twiddles exp(-2 pi i m / N)
+// are computed by the workgroup itself (sincospi in fp64, N values: 0.1 ms over the whole launch).
+#include "sc_common.h"
+
+typedef double2 zd;
+__device__ __forceinline__ zd zd_add(zd a, zd b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ zd zd_sub(zd a, zd b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ zd zd_mul(zd a, zd b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+
+struct MdArgs {
+    const double* x;
+    const double* tapers;   // [K][L], already divided by fs
+    zd* X;                  // [F][W][R][K][C]
+    int T, R, C, L, step, W, K, detrend;
+};
+
+// one radix-R butterfly of a Stockham pass: inputs src[b + t m] (twiddled by W^(t k tw_step), k = b mod Ls), DFT_R in registers
+template <int R>
+__device__ __forceinline__ void md_bfly_compute(const zd* __restrict__ src, const zd* __restrict__ tw, int b, int m, int Ls,
+                                                int tw_step, zd (&v)[R]) {
+    const int k = b % Ls;
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+        v[t] = src[b + t * m];
+        if (t > 0 && Ls > 1) v[t] = zd_mul(v[t], tw[t * k * tw_step]);
+    }
+    if constexpr (R == 2) {
+        const zd a = v[0], c = v[1];
+        v[0] = zd_add(a, c); v[1] = zd_sub(a, c);
+    } else if constexpr (R == 3) {
+        constexpr double S3 = 0.86602540378443864676;
+        const zd s = zd_add(v[1], v[2]), d = zd_sub(v[1], v[2]);
+        const zd t = make_double2(v[0].x - 0.5 * s.x, v[0].y - 0.5 * s.y);
+        v[0] = zd_add(v[0], s);
+        v[1] = make_double2(t.x + S3 * d.y, t.y - S3 * d.x);      // t - i S3 d
+        v[2] = make_double2(t.x - S3 * d.y, t.y + S3 * d.x);      // t + i S3 d
+    } else if constexpr (R == 4) {
+        const zd s02 = zd_add(v[0], v[2]), d02 = zd_sub(v[0], v[2]), s13 = zd_add(v[1], v[3]), d13 = zd_sub(v[1], v[3]);
+        v[0] = zd_add(s02, s13);
+        v[2] = zd_sub(s02, s13);
+        v[1] = make_double2(d02.x + d13.y, d02.y - d13.x);        // d02 - i d13
+        v[3] = make_double2(d02.x - d13.y, d02.y + d13.x);        // d02 + i d13
+    } else {
+        constexpr double C1 = 0.30901699437494742410, C2 = -0.80901699437494742410;
+        constexpr double S1 = 0.95105651629515357212, S2 = 0.58778525229247312917;
+        const zd a1 = zd_add(v[1], v[4]), a2 = zd_add(v[2], v[3]), b1 = zd_sub(v[1], v[4]), b2 = zd_sub(v[2], v[3]);
+        const zd p1 = make_double2(v[0].x + C1 * a1.x + C2 * a2.x, v[0].y + C1 * a1.y + C2 * a2.y);
+        const zd p2 = make_double2(v[0].x + C2 * a1.x + C1 * a2.x, v[0].y + C2 * a1.y + C1 * a2.y);
+        const zd q1 = make_double2(S1 * b1.x + S2 * b2.x, S1 * b1.y + S2 * b2.y);
+        const zd q2 = make_double2(S2 * b1.x - S1 * b2.x, S2 * b1.y - S1 * b2.y);
+        v[0] = zd_add(v[0], zd_add(a1, a2));
+        v[1] = make_double2(p1.x + q1.y, p1.y - q1.x);            // p1 - i q1
+        v[4] = make_double2(p1.x - q1.y, p1.y + q1.x);            // p1 + i q1
+        v[2] = make_double2(p2.x + q2.y, p2.y - q2.x);            // p2 - i q2
+        v[3] = make_double2(p2.x - q2.y, p2.y + q2.x);            // p2 + i q2
+    }
+}
+// ... and its outputs: dst[(b - k) R + k + t Ls] (autosort: natural order after the last pass)
+template <int R>
+__device__ __forceinline__ void md_bfly_store(zd* __restrict__ dst, int b, int Ls, const zd (&v)[R]) {
+    const int k = b % Ls, base = (b - k) * R + k;
+#pragma unroll
+    for (int t = 0; t < R; ++t) dst[base + t * Ls] = v[t];
+}
+
+#define MD_WAVE_SYNC()                                          \
+    do {                                                        \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  \
+        __builtin_amdgcn_wave_barrier();                        \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  \
+    } while (0)
+
+// all passes of one transform, in place, by one wave: a lane pulls the butterflies b = lane, lane + 64, ... of the pass into
+// registers, the wave meets, and writes them back
+template <int N, int LS>
+__device__ __forceinline__ void md_passes_wave(zd* z, const zd* tw, int lane) {
+    if constexpr (LS < N) {
+        constexpr int rem = N / LS;
+        constexpr int R = rem % 5 == 0 ? 5 : (rem % 4 == 0 ? 4 : (rem % 3 == 0 ? 3 : 2));
+        constexpr int m = N / R, tw_step = N / (LS * R), ROUNDS = (m + 63) / 64;
+        // In place needs every input of the pass read before any output is written: all ROUNDS butterflies of a lane live
+        // in registers at once (N = 1024, radix 4: 4 rounds x 4 x 4 registers = 64).
+        zd v[ROUNDS][R];
+#pragma unroll
+        for (int j = 0; j < ROUNDS; ++j) {
+            const int b = lane + 64 * j;
+            if (b < m) md_bfly_compute<R>(z, tw, b, m, LS, tw_step, v[j]);
+        }
+        MD_WAVE_SYNC();
+#pragma unroll
+        for (int j = 0; j < ROUNDS; ++j) {
+            const int b = lane + 64 * j;
+            if (b < m) md_bfly_store<R>(z, b, LS, v[j]);
+        }
+        MD_WAVE_SYNC();
+        md_passes_wave<N, LS * R>(z, tw, lane);
+    }
+}
+
+template <int N, int NF>
+__global__ void __launch_bounds__(64 * NF) mtfft_f64_kernel(MdArgs p) {
+    constexpr int NT = 64 * NF, CT = 2 * NF, XS = CT + 1, F = N / 2 + 1;
+    constexpr int LCT = CT == 32 ? 5 : (CT == 16 ? 4 : (CT == 8 ? 3 : 2)), LNF = LCT - 1;
+    extern __shared__ __align__(16) unsigned char smem[];
+    zd* z = reinterpret_cast<zd*>(smem);                          // [NF][N]; the detrend scratch aliases it
+    double* red = reinterpret_cast<double*>(smem);                // [2][NT] + trend [2][CT]
+    zd* tw = z + (NF * N > (NT + CT) ? NF * N : (NT + CT));       // [N]
+    double* tile = reinterpret_cast<double*>(tw + N);             // [L][XS] (odd stride: the column walks of the trend sums)
+    __shared__ int nzf[CT];                                       // channel not identically zero after the detrend
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < CT) nzf[tid] = 0;
+    const int L = p.L, C = p.C;
+    const int c0 = blockIdx.x * CT, r = blockIdx.y, w = blockIdx.z;
+    const int64_t RC = (int64_t)p.R * C;
+    const double* xw = p.x + ((int64_t)w * p.step * p.R + r) * C + c0;
+    for (int idx = tid; idx < L * CT; idx += NT) {
+        const int l = idx >> LCT, cc = idx & (CT - 1);
+        tile[l * XS + cc] = (c0 + cc < C) ? xw[(int64_t)l * RC + cc] : 0.0;
+    }
+    for (int i = tid; i < N; i += NT) {
+        double s, c;
+        sincospi(-2.0 * (double)i / (double)N, &s, &c);
+        tw[i] = make_double2(c, s);
+    }
+    __syncthreads();
+    constexpr int SL = NT / CT;
+    const int cc = tid & (CT - 1), sl = tid >> LCT;
+    if (p.detrend != SC_DETREND_NONE) {
+        double s = 0.0, st = 0.0;
+        for (int l = sl; l < L; l += SL) {
+            const double v = tile[l * XS + cc];
+            s += v;
+            st += v * (double)(l + 1);
+        }
+        red[tid] = s;
+        red[NT + tid] = st;
+        __syncthreads();
+        if (tid < CT) {
+            double sum = 0.0, sumt = 0.0;
+            for (int q = 0; q < SL; ++q) { sum += red[q * CT + tid]; sumt += red[NT + q * CT + tid]; }
+            sumt /= (double)L;
+            const double n = (double)L;
+            double a = 0.0, b;
+            if (p.detrend == SC_DETREND_CONSTANT) {
+                b = sum / n;
+            } else {            // least-squares line on abscissa (l + 1) / L  (transforms.py:1903-1909)
+                const double St = (n + 1.0) * 0.5, Stt = (n + 1.0) * (2.0 * n + 1.0) / (6.0 * n);
+                const double den = n * Stt - St * St;
+                a = (den != 0.0) ? (n * sumt - St * sum) / den : 0.0;
+                b = (sum - a * St) / n;
+            }
+            red[2 * NT + tid] = a;
+            red[2 * NT + CT + tid] = b;
+        }
+        __syncthreads();
+        const double invL = 1.0 / (double)L;
+        for (int idx = tid; idx < L * CT; idx += NT) {
+            const int l = idx >> LCT, cc2 = idx & (CT - 1);
+            const double tt = (double)(l + 1) * invL;
+            tile[l * XS + cc2] -= red[2 * NT + cc2] * tt + red[2 * NT + CT + cc2];
+        }
+        __syncthreads();                                          // the scratch is free: z takes its place
+    }
+    {
+        bool nz = false;
+        for (int l = sl; l < L; l += SL) nz |= tile[l * XS + cc] != 0.0;
+        if (nz) nzf[cc] = 1;
+        __syncthreads();
+    }
+    const int64_t sF = (int64_t)p.W * p.R * p.K * C;
+    zd* zw = z + wave * N;                                        // this wave's pair
+    for (int k = 0; k < p.K; ++k) {
+        const double* hk = p.tapers + (int64_t)k * L;
+        for (int n = lane; n < N; n += 64) {
+            zd v = make_double2(0.0, 0.0);
+            if (n < L) {
+                const double h = hk[n];
+                v = make_double2(tile[n * XS + 2 * wave] * h, tile[n * XS + 2 * wave + 1] * h);
+            }
+            zw[n] = v;
+        }
+        MD_WAVE_SYNC();
+        md_passes_wave<N, 1>(zw, tw, lane);
+        __syncthreads();                                          // every pair transformed
+        zd* Xk = p.X + (((int64_t)w * p.R + r) * p.K + k) * C + c0;
+        for (int idx = tid; idx < F * NF; idx += NT) {
+            const int f = idx >> LNF, pr = idx & (NF - 1), c = c0 + 2 * pr;
+            if (c >= C) continue;
+            const zd u1 = z[pr * N + f], u2 = z[pr * N + (f == 0 ? 0 : N - f)];
+            zd A = make_double2(0.5 * (u1.x + u2.x), 0.5 * (u1.y - u2.y));
+            zd B = make_double2(0.5 * (u1.y + u2.y), 0.5 * (u2.x - u1.x));
+            if (nzf[2 * pr] == 0) A = make_double2(0.0, 0.0);
+            if (nzf[2 * pr + 1] == 0) B = make_double2(0.0, 0.0);
+            zd* d = Xk + (int64_t)f * sF + 2 * pr;
+            d[0] = A;
+            if (c + 1 < C) d[1] = B;
+        }
+        __syncthreads();                                          // the next taper refills z
+    }
+}
+
+template <int N, int NF>
+static int launch_md(const MdArgs& m, hipStream_t stream) {
+    constexpr int NT = 64 * NF, CT = 2 * NF;
+    const size_t zb = (size_t)(NF * N > (NT + CT) ? NF * N : (NT + CT)) * 16;
+    const size_t lds = zb + (size_t)N * 16 + (size_t)m.L * (CT + 1) * 8 + 16;
+    if (lds + 4 * CT > 160 * 1024) { sc_set_error("float64 multitaper FFT (N=%d): tile does not fit LDS", N); return SC_EUNSUPPORTED; }
+    auto k = mtfft_f64_kernel<N, NF>;
+    SC_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dim3 grid((unsigned)((m.C + CT - 1) / CT), (unsigned)m.R, (unsigned)m.W);
+    hipLaunchKernelGGL(k, grid, dim3(NT), lds, stream, m);
+    SC_CHECK_HIP(hipGetLastError());
+    return SC_OK;
+}
+
+// lengths with a compiled transform (powers of two and the lengths next_fast_len hands out); every other length keeps
+// sc_taper_windows_f64 + sc_fft_execute_f64
+extern "C" int sc_multitaper_fft_f64_supported(int64_t L, int64_t N) {
+    if (L < 1 || L > N) return 0;
+    switch (N) {
+    case 64: case 128: case 256: case 512: case 1024: case 200: case 250: case 400: case 500: case 1000: return 1;
+    default: return 0;
+    }
+}
+
+extern "C" int sc_multitaper_fft_f64(const double* d_x, int64_t T, int64_t R, int64_t C, int64_t L, int64_t step,
+                                     int64_t W, int64_t N, const double* d_tapers, int64_t K, int detrend_type,
+                                     void* d_X, void* stream) {
+    ScTimed timed_("mtfft_fused_f64", stream);
+    SC_REQUIRE(d_x && d_tapers && d_X, "NULL device pointer");
+    SC_REQUIRE(T >= 1 && R >= 1 && C >= 1 && L >= 1 && step >= 1 && W >= 1 && K >= 1, "dimensions must be positive");
+    SC_REQUIRE((W - 1) * step + L <= T, "windows exceed the time series");
+    SC_REQUIRE(detrend_type >= 0 && detrend_type <= 2, "unknown detrend_type");
+    SC_REQUIRE(R <= 65535 && W <= 65535, "too many trials/windows for one launch");
+    if (!sc_multitaper_fft_f64_supported(L, N)) {
+        sc_set_error("fused float64 multitaper FFT: no compiled transform for N=%lld (L=%lld); use sc_taper_windows_f64 + "
+                     "sc_fft_execute_f64", (long long)N, (long long)L);
+        return SC_EUNSUPPORTED;
+    }
+    MdArgs m{d_x, d_tapers, (zd*)d_X, (int)T, (int)R, (int)C, (int)L, (int)step, (int)W, (int)K, detrend_type};
+    hipStream_t s = (hipStream_t)stream;
+    switch (N) {
+    case 64: return launch_md<64, 8>(m, s);
+    case 128: return launch_md<128, 8>(m, s);
+    case 256: return launch_md<256, 8>(m, s);
+    case 512: return launch_md<512, 4>(m, s);
+    case 1024: return launch_md<1024, 4>(m, s);
+    case 200: return launch_md<200, 8>(m, s);
+    case 250: return launch_md<250, 8>(m, s);
+    case 400: return launch_md<400, 4>(m, s);
+    case 500: return launch_md<500, 4>(m, s);
+    case 1000: return launch_md<1000, 4>(m, s);
+    }
+    return SC_EUNSUPPORTED;
+}

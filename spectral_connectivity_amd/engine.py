@@ -191,9 +191,10 @@ def multitaper_spectra(x, tapers_over_fs, n_window, n_step, n_fft, n_windows, de
     return DeviceSpectra(X, (F, n_windows, R, K, C_real), strides, n_fft, real_input=True, C_alloc=C)
 
 
-def multitaper_spectra_f64(x, tapers_over_fs, n_window, n_step, n_fft, n_windows, detrend_type, mark=None):
-    """Stage A of the float64 engine: (T,R,C) float64 tensor -> complex128 DeviceSpectra [F][W][R][K][C]
-    (sc_taper_windows_f64 + double-precision rocFFT + transpose; any window / FFT length)."""
+def multitaper_spectra_f64(x, tapers_over_fs, n_window, n_step, n_fft, n_windows, detrend_type, mark=None, use_fused=None):
+    """Stage A of the float64 engine: (T,R,C) float64 tensor -> complex128 DeviceSpectra [F][W][R][K][C].  One fused kernel
+    (sc_multitaper_fft_f64) for the lengths it compiles; sc_taper_windows_f64 + double-precision rocFFT + transpose for
+    any other window / FFT length."""
     lib = _lib.load()
     T, R, C = x.shape
     K, L = tapers_over_fs.shape
@@ -201,6 +202,15 @@ def multitaper_spectra_f64(x, tapers_over_fs, n_window, n_step, n_fft, n_windows
     F = n_fft // 2 + 1
     strides = (n_windows * R * K * C, R * K * C, K * C, C)
     batch = n_windows * R * K * C
+    if use_fused is None:
+        use_fused = bool(lib.sc_multitaper_fft_f64_supported(L, n_fft)) and R <= 65535 and n_windows <= 65535
+    if use_fused:
+        X = torch.empty((F, n_windows, R, K, C), dtype=torch.complex128, device=x.device)
+        _lib.check(lib.sc_multitaper_fft_f64(_ptr(x), T, R, C, L, n_step, n_windows, n_fft, _ptr(tapers_over_fs), K,
+                                             _lib.DETREND[detrend_type], _ptr(X), _stream()), "sc_multitaper_fft_f64")
+        if mark:
+            mark("mtfft_fused_f64")
+        return DeviceSpectra(X, (F, n_windows, R, K, C), strides, n_fft, real_input=True)
     y = torch.empty((batch, n_fft), dtype=torch.float64, device=x.device)
     _lib.check(lib.sc_taper_windows_f64(_ptr(x), T, R, C, L, n_step, n_windows, n_fft, _ptr(tapers_over_fs), K,
                                         _lib.DETREND[detrend_type], _ptr(y), _stream()), "sc_taper_windows_f64")

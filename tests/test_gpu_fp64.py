@@ -218,3 +218,43 @@ def test_f11_band_statistics_float64(sc, golden):
     for a, key in ((d, "group_delay"), (s_, "group_slope"), (r, "group_r")):
         np.testing.assert_allclose(a, g[key], rtol=1e-12, atol=0, equal_nan=True, err_msg=key)
     np.testing.assert_allclose(c.delay([10, 200], n_range=2), g["delay_band"], rtol=1e-12, atol=0, equal_nan=True)
+
+
+@pytest.mark.parametrize("N,L,C,det", [(256, 256, 128, "constant"), (64, 50, 5, "linear"), (128, 128, 33, None),
+                                       (512, 400, 18, "constant"), (1024, 1024, 7, "linear"), (200, 200, 70, "linear"),
+                                       (250, 250, 3, "constant"), (400, 300, 9, None), (500, 500, 16, "constant"),
+                                       (1000, 1000, 6, "linear"), (256, 256, 1, "constant")])
+def test_fused_float64_transform_matches_oracle_and_rocfft(sc, N, L, C, det):
+    """Stage A of the float64 engine as one kernel (sc_mtfft_f64.hip) against the float64 oracle -- 1e-12 of the spectrum's
+    scale -- and against the three-pass route it replaces (still the path of every other length)."""
+    import torch
+    from oracle import spectral_oracle as so
+    from spectral_connectivity_amd import _lib, engine
+    assert _lib.load().sc_multitaper_fft_f64_supported(L, N) == 1
+    assert _lib.load().sc_multitaper_fft_f64_supported(300, 300) == 0
+    rng = np.random.default_rng(N + C)
+    R, step = 3, max(L // 2, 1)
+    T = L + 2 * step
+    x = rng.standard_normal((T, R, C)) + 5.0 + np.linspace(0, 2, T)[:, None, None]
+    if C >= 4:
+        x[:, :, 2] = 0.0                                      # a silent channel: exact zeros
+    kw = dict(n_time_samples_per_window=L, n_time_samples_per_step=step, n_fft_samples=N)
+    coef, _ = so.multitaper_fft(x, fs=200.0, NW=2.5, detrend_type=det, **kw)
+    m = sc.Multitaper(x, sampling_frequency=200.0, time_halfbandwidth_product=2.5, detrend_type=det, **kw)
+    xd = torch.from_numpy(x).cuda()
+    h = torch.from_numpy(np.ascontiguousarray(m.tapers.T / 200.0)).cuda()
+    W = m.n_time_windows
+    ref = coef[..., : N // 2 + 1, :]
+    scale = np.abs(ref).max()
+    got = {}
+    for fused in (True, False):
+        sp = engine.multitaper_spectra_f64(xd, h, L, step, N, W, det, use_fused=fused)
+        got[fused] = np.moveaxis(sp.coefficients().cpu().numpy(), 0, 3)
+        assert got[fused].shape == ref.shape
+        assert np.abs(got[fused] - ref).max() <= 1e-12 * scale, (fused, np.abs(got[fused] - ref).max() / scale)
+    if C >= 4 and det != "linear":
+        assert np.all(got[True][..., 2] == 0)
+    assert np.all(got[True][..., 0, :].imag == 0)            # DC exactly real
+    if N % 2 == 0:
+        assert np.all(got[True][..., N // 2, :].imag == 0)   # Nyquist exactly real
+    close64(m.fft(), coef, rtol=1e-9, floor=1e-12, what="Multitaper.fft()")
