@@ -126,9 +126,9 @@ __global__ void __launch_bounds__(256, LOG2N <= 8 ? 4 : (LOG2N == 9 ? 3 : (LOG2N
     // four workgroups (16 waves) per CU.
     // Long windows (N >= 2048, 2-4 channels per workgroup) keep NO window tile, twiddle table or taper buffer in LDS --
     // samples and taper values come straight from HBM / L2 into registers, twiddles from two 64-entry tables -- so
-    // that two workgroups share a CU (45 KB each instead of 131 KB at N = 4096), and they store every channel's spectrum
-    // as one contiguous row that a tiled transpose turns into the frequency-major X (16-32-byte pieces per frequency
-    // row otherwise).
+    // that two workgroups share a CU (45 KB each instead of 131 KB at N = 4096).  N = 4096 stores every channel's spectrum
+    // as one contiguous row that a tiled transpose turns into the frequency-major X (16-byte pieces per frequency row
+    // otherwise); N = 2048 stores its 32-byte pieces directly, the tiles of a line on one XCD.
     constexpr bool LONG = LOG2N >= 11;
     constexpr size_t XT_BYTES = LONG ? 0 : (size_t)N * XS * 4, Z_BYTES = (size_t)NF * ZS * 8;
     constexpr size_t UNION_BYTES = XT_BYTES > Z_BYTES ? XT_BYTES : Z_BYTES;
@@ -153,7 +153,9 @@ __global__ void __launch_bounds__(256, LOG2N <= 8 ? 4 : (LOG2N == 9 ? 3 : (LOG2N
     if constexpr (LONG) __syncthreads();
     MT_T0();
     int c0, r, w;
-    if constexpr (LONG) {
+    constexpr bool XCDMAP = LOG2N >= 10;         // N = 1024 stores 64-byte pieces of a frequency row: the tiles that complete a
+                                                 // 128-byte line must meet in ONE XCD's L2 as well
+    if constexpr (XCDMAP) {
         // A thread reads 8 bytes of every window row, so the channel tiles of one (window, trial) share every line they
         // fetch: keep them on ONE XCD (block b runs on XCD b % 8) and that XCD's L2 fetches each line from HBM once.
         const int n_ct = (p.C + CT - 1) / CT;
@@ -544,7 +546,7 @@ __global__ void __launch_bounds__(256, LOG2N <= 8 ? 4 : (LOG2N == 9 ? 3 : (LOG2N
                 if (za) A = make_float2(0.f, 0.f);
                 if (zb) B = make_float2(0.f, 0.f);
                 if ((p.dbg & 1) && A.x != 12345.f) return;
-                if constexpr (LONG) {
+                if constexpr (LOG2N >= 12) {
                     float2* row = p.Z + (((((int64_t)w * p.Rc + (r - p.r_off)) * p.K + k) * C + c) * (int64_t)(N / 2 + 1));
                     row[f] = A;
                     if (c + 1 < C) row[(N / 2 + 1) + f] = B;
@@ -618,6 +620,17 @@ static int launch_mt16(const MtArgs& a_in, hipStream_t stream) {
         // transpose per window into the frequency-major X
         const size_t lds_long = z_b + 4 * 256 * sizeof(double) + (64 + N / 64) * sizeof(float2);
         SC_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_long));
+        if constexpr (LOG2N == 11) {
+            // 2048 samples: 32-byte pieces of a frequency row per workgroup, and the four tiles that complete a 128-byte
+            // line run back to back on one XCD -- its L2 merges them: 4.2 ms for the volume the row store + transpose
+            // below takes 4.7 ms for.  (At 4096 samples, 16-byte pieces of eight tiles, the transpose still wins: 9.7
+            // against 10.6 ms.)
+            a.Z = nullptr; a.r_off = 0; a.Rc = a.R;
+            const int64_t n_ct = (a.C + CT - 1) / CT, groups8 = ((int64_t)a.W * a.R + 7) / 8 * 8;
+            hipLaunchKernelGGL(k, dim3((unsigned)(groups8 * n_ct)), dim3(256), lds_long, stream, a);
+            SC_CHECK_HIP(hipGetLastError());
+            return SC_OK;
+        }
         const int64_t F = N / 2 + 1, rows_trial = (int64_t)a.K * a.C, batch = (int64_t)a.W * a.R * rows_trial;
         int64_t rc = ((int64_t)2 << 30) / ((int64_t)a.W * rows_trial * F * 8);
         rc = rc < 1 ? 1 : (rc > a.R ? a.R : rc);
@@ -639,6 +652,13 @@ static int launch_mt16(const MtArgs& a_in, hipStream_t stream) {
         }
         (void)hipFreeAsync(Z, stream);
         if (rc_ret != SC_OK) return rc_ret;
+        SC_CHECK_HIP(hipGetLastError());
+        return SC_OK;
+    }
+    if constexpr (LOG2N >= 10) {        // one-dimensional grid, channel tiles of a (window, trial) on one XCD (see the kernel)
+        a.r_off = 0; a.Rc = a.R;
+        const int64_t n_ct = (a.C + CT - 1) / CT, groups8 = ((int64_t)a.W * a.R + 7) / 8 * 8;
+        hipLaunchKernelGGL(k, dim3((unsigned)(groups8 * n_ct)), dim3(256), shmem, stream, a);
         SC_CHECK_HIP(hipGetLastError());
         return SC_OK;
     }
