@@ -944,7 +944,18 @@ __global__ void __launch_bounds__(64 * NF) mtfft_mixed_wave_kernel(MxArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < CT) nzf[tid] = 0;
     const int L = p.L, C = p.C;
-    const int c0 = blockIdx.x * CT, r = blockIdx.y, w = blockIdx.z;
+    int c0, r, w;
+    if constexpr (NF < 8) {
+        // 64-byte pieces of a frequency row per workgroup: the two channel tiles that complete a 128-byte line run back
+        // to back on ONE XCD (block b runs on XCD b % 8), whose L2 merges them -- see mtfft16_kernel
+        const int n_ct = (C + CT - 1) / CT;
+        const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
+        const int g = (j / n_ct) * 8 + xcd;
+        if (g >= p.W * p.R) return;
+        c0 = (j % n_ct) * CT; w = g / p.R; r = g - w * p.R;
+    } else {
+        c0 = blockIdx.x * CT; r = blockIdx.y; w = blockIdx.z;
+    }
     const int64_t RC = (int64_t)p.R * C;
     const float* xw = p.x + ((int64_t)w * p.step * p.R + r) * C + c0;
     for (int idx = tid; idx < L * CT; idx += NT) {
@@ -1049,6 +1060,7 @@ static int launch_mixed_wave(const MxArgs& m_in, hipStream_t stream) {
     auto k = mtfft_mixed_wave_kernel<N, NF>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     dim3 grid((unsigned)((m.C + CT - 1) / CT), (unsigned)m.R, (unsigned)m.W);
+    if (NF < 8) grid = dim3((unsigned)((((int64_t)m.W * m.R + 7) / 8 * 8) * ((m.C + CT - 1) / CT)));
     hipLaunchKernelGGL(k, grid, dim3(NT), lds, stream, m);
     SC_CHECK_HIP(hipGetLastError());
     return SC_OK;
