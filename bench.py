@@ -161,6 +161,7 @@ def main():
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
     ap.add_argument("--trials", type=int, default=None, help="override total trial count (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-f64", action="store_true", help="skip the float64-engine side measurement")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -307,6 +308,40 @@ def main():
                                  f"threads, blocked vectorised |Im s| plane; float64) on {n_sample} of {cfg['R']} trials, linear "
                                  f"in trials; the |Im s| plane is single-threaded NumPy arithmetic, BLAS threads = {threads}")}
 
+    # Beside the line (never `value`): the float64 engine -- the reference's default dtype, the path that meets 1e-5 on
+    # every element at this depth -- on the same workload, a few passes after the timed region.
+    f64 = None
+    if rank == 0 and world == 1 and not args.no_f64:
+        del x, h
+        torch.cuda.empty_cache()
+        xd = synth(cfg, r_lo, r_hi, device, seed=3).to(torch.float64)
+        hd = torch.from_numpy(np.ascontiguousarray(tapers.T / FS)).to(device)
+
+        def f64_step():
+            sp = engine.multitaper_spectra_f64(xd, hd, L, step, N, W, "constant")
+            accum, n_obs = engine.accumulate(sp, "trials_tapers", planes)
+            del sp
+            return (engine.measure(accum, C, planes, n_obs, _lib.M_COHERENCE_MAGNITUDE, wide=True),
+                    engine.measure(accum, C, planes, n_obs, _lib.M_WPLI, wide=True))
+        for _ in range(2):
+            f64_step()
+        torch.cuda.synchronize()
+        _lib.timing_enable(True)
+        n64 = 5
+        t1 = time.perf_counter()
+        for _ in range(n64):
+            f64_step()
+        torch.cuda.synchronize()
+        dt64 = (time.perf_counter() - t1) / n64
+        st64 = {}
+        for name, ms in _lib.last_timing():
+            st64[name] = st64.get(name, 0.0) + ms / n64
+        _lib.timing_enable(False)
+        f64 = {"ms_per_step": round(dt64 * 1e3, 3), "value": round(units / dt64, 1), "dtype": "f64", "steps": n64,
+               "stage_ms": {k: round(v, 4) for k, v in st64.items()},
+               "note": "Connectivity(dtype=complex128): float64 transform, fp64 matrix-core CSM, fp64 VALU |Im s| plane, "
+                       "float64 measures; reported beside the float32 line, not as the metric"}
+
     if rank == 0:
         print(json.dumps({
             "metric": "channel-pair*freq-bins/s for CSM+coherence(+wPLI)",
@@ -317,6 +352,7 @@ def main():
                        "trials_per_gpu": R_loc, "n_tapers": K, "n_windows": W, "n_freq_bins": F,
                        "units_per_step": units, "parallelism": f"trials sharded over {world} GPU(s)"},
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_restructured": cpu_strong,
+            "float64_engine": f64,
             # N > 1: time inside the RCCL collectives of one step on the exchange stream (reduce-scatter of the records,
             # gather of the measures) and the part of the exchange + epilogue the launch stream had to wait for
             "exchange": None if exchange is None else {
