@@ -102,8 +102,7 @@ def one_step(x, h, cfg, geom, planes, world, exchange=None):
         return coh, wpli
     accum, n_obs = engine.accumulate(sp, "trials_tapers", planes)
     del sp
-    coh = engine.measure(accum, cfg["C"], planes, n_obs, _lib.M_COHERENCE_MAGNITUDE)
-    wpli = engine.measure(accum, cfg["C"], planes, n_obs, _lib.M_WPLI)
+    coh, wpli = engine.measure_multi(accum, cfg["C"], planes, n_obs, [_lib.M_COHERENCE_MAGNITUDE, _lib.M_WPLI])
     return coh, wpli
 
 
@@ -239,6 +238,7 @@ def main():
         "fused_stage_b": ("mfma", 8.0 * n_obs_loc * (C * (C + 1) / 2) * W * F),
         "csm_mfma": ("mfma", 8.0 * n_obs_loc * (C * (C + 1) / 2) * W * F),
         "nonlinear_valu": ("hbm", 8.0 * F * W * R_loc * K * C + 4.0 * W * F * C * (C + 1) / 2),
+        # (one launch for both measures: the three record planes are read once)
         "measure_epilogue": ("hbm", (3 * 4.0 * C * (C + 1) / 2 + 2 * 4.0 * C * C) * W * F / world),
     }
     dominant = max((k for k in stage_model if k in stage_ms), key=lambda k: stage_ms[k])
@@ -321,8 +321,7 @@ def main():
             sp = engine.multitaper_spectra_f64(xd, hd, L, step, N, W, "constant")
             accum, n_obs = engine.accumulate(sp, "trials_tapers", planes)
             del sp
-            return (engine.measure(accum, C, planes, n_obs, _lib.M_COHERENCE_MAGNITUDE, wide=True),
-                    engine.measure(accum, C, planes, n_obs, _lib.M_WPLI, wide=True))
+            return engine.measure_multi(accum, C, planes, n_obs, [_lib.M_COHERENCE_MAGNITUDE, _lib.M_WPLI], wide=True)
         for _ in range(2):
             f64_step()
         torch.cuda.synchronize()

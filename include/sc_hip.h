@@ -258,6 +258,16 @@ int sc_measure_f32(const void* d_accum, int64_t n_bins, int64_t n_signals, uint3
  * or (SC_RECORD_F64) double records: no widening pass over the result. */
 int sc_measure_f64(const void* d_accum, int64_t n_bins, int64_t n_signals, uint32_t planes,
                    int64_t n_observations, int measure, void* d_out, void* stream);
+/* Up to SC_MEASURE_MULTI_MAX real-valued C x C measures (coherence magnitude / phase, imaginary coherence, PLV, PPC,
+ * PLI, wPLI and the debiased variants) of ONE record in one launch: the record is read once.  measures, d_outs: HOST
+ * arrays of n_measures entries; d_outs[m]: float (_f32) or double (_f64) [n_bins][C][C]. */
+#define SC_MEASURE_MULTI_MAX 4
+int sc_measure_multi_f32(const void* d_accum, int64_t n_bins, int64_t n_signals, uint32_t planes,
+                         int64_t n_observations, int n_measures, const int* measures, void* const* d_outs,
+                         void* stream);
+int sc_measure_multi_f64(const void* d_accum, int64_t n_bins, int64_t n_signals, uint32_t planes,
+                         int64_t n_observations, int n_measures, const int* measures, void* const* d_outs,
+                         void* stream);
 
 /* ---- stage B of the float64 engine -----------------------------------------------------
  * Replaces the same reference code as sc_csm_accumulate_f32 / sc_nonlinear_accumulate_f32 (connectivity.py:447-526,

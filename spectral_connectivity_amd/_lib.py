@@ -61,6 +61,10 @@ SYMBOLS = {
     "sc_fft_execute_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "sc_accumulate_f64": (c_int, [c_void_p, POINTER(SpectraDesc), c_uint32, c_uint32, c_void_p, c_void_p]),
     "sc_measure_f64": (c_int, [c_void_p, c_int64, c_int64, c_uint32, c_int64, c_int, c_void_p, c_void_p]),
+    "sc_measure_multi_f32": (c_int, [c_void_p, c_int64, c_int64, c_uint32, c_int64, c_int, POINTER(c_int),
+                                     POINTER(c_void_p), c_void_p]),
+    "sc_measure_multi_f64": (c_int, [c_void_p, c_int64, c_int64, c_uint32, c_int64, c_int, POINTER(c_int),
+                                     POINTER(c_void_p), c_void_p]),
     "sc_timing_enable": (c_int, [c_int]),
     "sc_last_timing": (c_int, [POINTER(Timing), c_int, POINTER(c_int)]),
     "sc_multitaper_fft_supported": (c_int, [c_int64, c_int64]),

@@ -32,6 +32,9 @@ struct MeasureArgs {
     int p_csm, p_abs, p_sq, p_sign, p_unit;  // plane offsets or -1
     double n_obs;
     int measure;
+    int n_multi;                 // measure_tile_multi_kernel: the real-valued measures of one launch ...
+    int multi[SC_MEASURE_MULTI_MAX];
+    void* multi_out[SC_MEASURE_MULTI_MAX];      // ... and where each goes
 };
 
 template <typename Rec>
@@ -180,6 +183,149 @@ __global__ void __launch_bounds__(256) measure_tile_kernel(MeasureArgs a) {
             else outf[obase + (int64_t)r * a.C + c] = (OutT)mir[tid].x;
         }
     }
+}
+
+// Several real-valued measures of the same record in ONE launch: the tile's planes are read once (every plane any of the
+// measures needs), each measure is evaluated for the tile and its mirror image like measure_tile_kernel does.
+#define MEASURE_MULTI_TPW 4       // tiles per workgroup: a tile is 3-5 KB of reads and 2 KB of writes per measure -- too little per launch slot
+template <typename OutT, typename AccT>
+__global__ void __launch_bounds__(256) measure_tile_multi_kernel(MeasureArgs a) {
+    __shared__ MeasureIn raw[256];
+    __shared__ double mir[256];
+    const int tid = threadIdx.x, ii = tid >> 4, jj = tid & 15;
+    const int64_t bin = blockIdx.x;
+    const RecT<AccT> rec = RecT<AccT>{(const AccT*)a.accum.p} + bin * a.floats_per_bin;
+    const int64_t plane = (int64_t)a.n_tiles * SC_TILE_ELEMS;
+    const int64_t obase = bin * (int64_t)a.C * a.C;
+    int ti = 0, len = a.NB, t = blockIdx.y * MEASURE_MULTI_TPW;          // upper-triangular tile (ti <= tj), row-major
+    while (t >= len) { t -= len; ++ti; --len; }
+    for (int u = 0; u < MEASURE_MULTI_TPW; ++u) {
+        const int tile_id = blockIdx.y * MEASURE_MULTI_TPW + u;
+        if (tile_id >= a.n_tiles) break;
+        const int tj = ti + t;
+        const RecT<AccT> tile = rec + ((int64_t)tile_id * SC_TILE_ELEMS + ii * 16 + jj);
+        MeasureIn v = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (a.p_csm >= 0) {
+            v.s_re = (double)tile[a.p_csm * plane];
+            v.s_im = (double)tile[(a.p_csm + 1) * plane];
+            v.p_i = (double)rec[a.p_csm * plane + (int64_t)sc_tile_index(ti, ti, a.NB) * SC_TILE_ELEMS + ii * 17];
+            v.p_j = (double)rec[a.p_csm * plane + (int64_t)sc_tile_index(tj, tj, a.NB) * SC_TILE_ELEMS + jj * 17];
+        }
+        if (a.p_abs >= 0) v.sa = (double)tile[a.p_abs * plane];
+        if (a.p_sq >= 0) v.sq = (double)tile[a.p_sq * plane];
+        if (a.p_sign >= 0) v.sg = (double)tile[a.p_sign * plane];
+        if (a.p_unit >= 0) {
+            v.u_re = (double)tile[a.p_unit * plane];
+            v.u_im = (double)tile[(a.p_unit + 1) * plane];
+        }
+        const bool dtile = ti == tj;
+        if (dtile) {
+            raw[tid] = v;
+            __syncthreads();
+            if (ii > jj) v = measure_mirror(raw[jj * 16 + ii]);
+            __syncthreads();
+        }
+        const int i = ti * 16 + ii, j = tj * 16 + jj;
+        for (int m = 0; m < a.n_multi; ++m) {
+            OutT* outf = (OutT*)a.multi_out[m];
+            const int w = a.multi[m];
+            const double direct = measure_value(w, a.n_obs, v, i == j).x;
+            if (i < a.C && j < a.C) outf[obase + (int64_t)i * a.C + j] = (OutT)direct;
+            if (!dtile) {
+                // entry (j, i): every real-valued measure is even or odd under (i, j) -> (j, i) (conjugated s, swapped
+                // powers), bit for bit what measure_value(measure_mirror(v)) returns -- the fp64 algebra (sqrt, divisions)
+                // is what this kernel spends its time on, so it runs once per pair
+                const double sgn = (w == SC_M_COHERENCE_PHASE || w == SC_M_PLI || w == SC_M_WPLI) ? -1.0 : 1.0;
+                mir[jj * 16 + ii] = sgn * direct;
+                __syncthreads();
+                const int r = tj * 16 + ii, c = ti * 16 + jj;
+                if (r < a.C && c < a.C) outf[obase + (int64_t)r * a.C + c] = (OutT)mir[tid];
+                __syncthreads();
+            }
+        }
+        if (++t >= len) { t = 0; ++ti; --len; }
+    }
+}
+
+static uint32_t measure_needs(int measure) {
+    switch (measure) {
+    case SC_M_POWER: case SC_M_CSM: case SC_M_COHERENCY: case SC_M_COHERENCE_MAGNITUDE:
+    case SC_M_COHERENCE_PHASE: case SC_M_IMAGINARY_COHERENCE: return SC_PLANE_CSM;
+    case SC_M_PLV: case SC_M_PLV_COMPLEX: case SC_M_PPC: return SC_PLANE_UNIT;
+    case SC_M_PLI: case SC_M_DEBIASED_PLI2: return SC_PLANE_SIGN_IM;
+    case SC_M_WPLI: return SC_PLANE_CSM | SC_PLANE_ABS_IM;
+    case SC_M_DEBIASED_WPLI2: return SC_PLANE_CSM | SC_PLANE_ABS_IM | SC_PLANE_IM_SQ;
+    }
+    return 0;
+}
+
+static int measure_multi_run(const void* d_accum, int64_t n_bins, int64_t n_signals, uint32_t planes,
+                             int64_t n_observations, int n_measures, const int* measures, void* const* d_outs,
+                             bool wide, void* stream) {
+    ScTimed timed_("measure_epilogue", stream);
+    SC_REQUIRE(d_accum && measures && d_outs, "NULL argument");
+    SC_REQUIRE(n_bins >= 1 && n_signals >= 1 && n_observations >= 1, "dimensions must be positive");
+    SC_REQUIRE(n_measures >= 1 && n_measures <= SC_MEASURE_MULTI_MAX, "1 ... SC_MEASURE_MULTI_MAX measures per launch");
+    MeasureArgs a;
+    a.accum = sc_rec(d_accum, planes);
+    a.out = nullptr;
+    a.n_bins = n_bins;
+    a.C = (int)n_signals;
+    a.NB = sc_n_blocks(n_signals);
+    a.n_tiles = sc_n_tiles(a.NB);
+    a.floats_per_bin = (int64_t)sc_plane_count(planes) * a.n_tiles * SC_TILE_ELEMS;
+    uint32_t need = 0;
+    for (int m = 0; m < n_measures; ++m) {
+        const int w = measures[m];
+        const bool real_matrix = w == SC_M_COHERENCE_MAGNITUDE || w == SC_M_COHERENCE_PHASE || w == SC_M_IMAGINARY_COHERENCE ||
+                                 w == SC_M_PLV || w == SC_M_PPC || w == SC_M_PLI || w == SC_M_DEBIASED_PLI2 ||
+                                 w == SC_M_WPLI || w == SC_M_DEBIASED_WPLI2;
+        if (!real_matrix) {
+            sc_set_error("sc_measure_multi: measure %d is not a real-valued C x C measure (use sc_measure_f32 / _f64)", w);
+            return SC_EINVAL;
+        }
+        SC_REQUIRE(d_outs[m] != nullptr, "NULL output");
+        need |= measure_needs(w);
+        a.multi[m] = w;
+        a.multi_out[m] = d_outs[m];
+    }
+    a.n_multi = n_measures;
+    if ((planes & need) != need) {
+        sc_set_error("measures need accumulator planes 0x%x, record has 0x%x", need, planes);
+        return SC_EINVAL;
+    }
+    // only the planes some measure reads are fetched
+    a.p_csm = (need & SC_PLANE_CSM) ? sc_plane_offset(planes, SC_PLANE_CSM) : -1;
+    a.p_abs = (need & SC_PLANE_ABS_IM) ? sc_plane_offset(planes, SC_PLANE_ABS_IM) : -1;
+    a.p_sq = (need & SC_PLANE_IM_SQ) ? sc_plane_offset(planes, SC_PLANE_IM_SQ) : -1;
+    a.p_sign = (need & SC_PLANE_SIGN_IM) ? sc_plane_offset(planes, SC_PLANE_SIGN_IM) : -1;
+    a.p_unit = (need & SC_PLANE_UNIT) ? sc_plane_offset(planes, SC_PLANE_UNIT) : -1;
+    a.n_obs = (double)n_observations;
+    a.measure = measures[0];
+    a.total = n_bins * n_signals * n_signals;
+    SC_REQUIRE(n_bins < (int64_t)1 << 31 && a.n_tiles <= 65535, "output too large for one launch");
+    const dim3 grid((unsigned)n_bins, (unsigned)((a.n_tiles + MEASURE_MULTI_TPW - 1) / MEASURE_MULTI_TPW));
+    hipStream_t st = (hipStream_t)stream;
+    if (a.accum.f64) {
+        if (wide) hipLaunchKernelGGL((measure_tile_multi_kernel<double, double>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((measure_tile_multi_kernel<float, double>), grid, dim3(256), 0, st, a);
+    } else {
+        if (wide) hipLaunchKernelGGL((measure_tile_multi_kernel<double, float>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((measure_tile_multi_kernel<float, float>), grid, dim3(256), 0, st, a);
+    }
+    SC_CHECK_HIP(hipGetLastError());
+    return SC_OK;
+}
+
+extern "C" int sc_measure_multi_f32(const void* d_accum, int64_t n_bins, int64_t n_signals, uint32_t planes,
+                                    int64_t n_observations, int n_measures, const int* measures, void* const* d_outs,
+                                    void* stream) {
+    return measure_multi_run(d_accum, n_bins, n_signals, planes, n_observations, n_measures, measures, d_outs, false, stream);
+}
+extern "C" int sc_measure_multi_f64(const void* d_accum, int64_t n_bins, int64_t n_signals, uint32_t planes,
+                                    int64_t n_observations, int n_measures, const int* measures, void* const* d_outs,
+                                    void* stream) {
+    return measure_multi_run(d_accum, n_bins, n_signals, planes, n_observations, n_measures, measures, d_outs, true, stream);
 }
 
 static int measure_run(const void* d_accum, int64_t n_bins, int64_t n_signals, uint32_t planes,

@@ -370,6 +370,29 @@ def measure(accum, n_signals, planes, n_obs, which, out=None, wide=None):
     return out
 
 
+MEASURE_MULTI_MAX = 4
+
+
+def measure_multi(accum, n_signals, planes, n_obs, which, wide=None):
+    """Stage C for several real-valued C x C measures of one record: ONE launch reads the record once
+    (sc_measure_multi_*); complex measures / power, or more than four, go through measure()."""
+    which = list(which)
+    simple = [w for w in which if w != _lib.M_POWER and w not in _lib.COMPLEX_MEASURES]
+    if len(simple) != len(which) or not 2 <= len(which) <= MEASURE_MULTI_MAX:
+        return [measure(accum, n_signals, planes, n_obs, w, wide=wide) for w in which]
+    lib = _lib.load()
+    n_bins, C = accum.shape[0], n_signals
+    if wide is None:
+        wide = accum.dtype == torch.float64
+    outs = [torch.empty((n_bins, C, C), dtype=torch.float64 if wide else torch.float32, device=accum.device) for _ in which]
+    ids = (ctypes.c_int * len(which))(*which)
+    ptrs = (ctypes.c_void_p * len(which))(*[o.data_ptr() for o in outs])
+    fn = lib.sc_measure_multi_f64 if wide else lib.sc_measure_multi_f32
+    _lib.check(fn(_ptr(accum), n_bins, C, rec_planes(accum, planes), n_obs, len(which), ids, ptrs, _stream()),
+               "sc_measure_multi")
+    return outs
+
+
 GRANGER_WORK_BYTES = 8 << 30      # workspace bound of one sc_granger_pairwise_f64 call (160 bytes per problem and bin)
 
 

@@ -160,8 +160,9 @@ def sharded_measures(spectra, planes, which, n_groups=4, dst=0, group=None, mark
             if timing is not None:
                 coll_events.append((t0, ev(side)))
                 bytes_reduced += accum.numel() * accum.element_size()
+            outs = engine.measure_multi(shard, C, planes, n_total, which)     # one launch where the measures allow it
             for m, w in enumerate(which):
-                out = engine.measure(shard, C, planes, n_total, w)
+                out = outs[m]
                 if world > 1:
                     t0 = ev(side) if timing is not None else None
                     out = gather_bins(out, n_bins, dst=dst, group=group)

@@ -688,3 +688,32 @@ def test_large_dc_offset_float32_engine(sc):
         close32(c.power(), so.power(coef), what=f"power, DC offset, detrend={det}")
         close32(c.coherence_magnitude(), so.coherence_magnitude(coef), rtol=2e-5, atol_scale=2e-5,
                 what=f"coherence, DC offset, detrend={det}")
+
+
+def test_multi_measure_epilogue_equals_single_launches(sc):
+    """sc_measure_multi_*: several real-valued measures of one record in one launch, bit-identical to one launch each
+    (float32 and float64 output, float and double records, odd channel count, mirrored tiles)."""
+    import torch
+    from spectral_connectivity_amd import _lib, engine
+    rng = np.random.default_rng(17)
+    for C, f64 in ((37, False), (64, True)):
+        x = rng.standard_normal((256, 9, C))
+        kw = dict(sampling_frequency=100.0, time_halfbandwidth_product=2, n_time_samples_per_window=64)
+        m = sc.Multitaper(x, **kw)
+        sp = m.device_spectra(precision="float64" if f64 else "float32")
+        planes = _lib.PLANE_CSM | _lib.PLANE_ABS_IM | _lib.PLANE_IM_SQ | _lib.PLANE_SIGN_IM
+        accum, n_obs = engine.accumulate(sp, "trials_tapers", planes)
+        which = [_lib.M_COHERENCE_MAGNITUDE, _lib.M_WPLI, _lib.M_DEBIASED_WPLI2, _lib.M_PLI]
+        for wide in (False, True):
+            multi = engine.measure_multi(accum, C, planes, n_obs, which, wide=wide)
+            for w, got in zip(which, multi):
+                one = engine.measure(accum, C, planes, n_obs, w, wide=wide)
+                assert got.dtype == one.dtype and got.shape == one.shape
+                assert torch.equal(torch.nan_to_num(got, nan=-7.0), torch.nan_to_num(one, nan=-7.0)), (C, wide, w)
+        for grp in ([_lib.M_COHERENCE_PHASE, _lib.M_IMAGINARY_COHERENCE, _lib.M_DEBIASED_PLI2], [_lib.M_PLI, _lib.M_WPLI]):
+            for w, got in zip(grp, engine.measure_multi(accum, C, planes, n_obs, grp)):
+                one = engine.measure(accum, C, planes, n_obs, w)
+                assert torch.equal(torch.nan_to_num(got, nan=-7.0), torch.nan_to_num(one, nan=-7.0)), (C, w)
+        # complex measures and power fall back to one launch each
+        mixed = engine.measure_multi(accum, C, planes, n_obs, [_lib.M_COHERENCY, _lib.M_WPLI])
+        assert mixed[0].is_complex() and not mixed[1].is_complex()
