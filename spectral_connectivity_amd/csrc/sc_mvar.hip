@@ -7,19 +7,19 @@
 // partial_directed_coherence, generalized_partial_directed_coherence,
 // direct_directed_transfer_function (connectivity.py:1237-1426, helpers :1679-1748, :1873-1950).
 //
-//   m_build / m_upload   two-sided Hermitian spectra S[p][e][n] (e = i C + j, n fastest)
-//   m_init               G0 = chol(Re ifft_n(S)[lag 0])^H, broadcast over n
-//   loop <= max_iter (all windows at once, converged windows frozen):
-//     m_predict          A = G^-1 (G^-1 S)^H + I          one workgroup per (window, bin): LU with
-//                                                          partial pivoting in LDS, two solves
-//     rocFFT Z2Z         a = ifft_n(A)                     C^2 unit-stride series per window
-//     m_causal           1/N, a[0] *= 1/2, strict lower triangle of a[0] = 0, a[n >= (N+1)/2] = 0
-//     rocFFT Z2Z         A+ = fft_n(a)
-//     m_update           G <- G A+, err = max |G - G_old|  one workgroup per (window, bin)
-//   measures             H0 = Re mean_n G; H = G (H0 + lam I)^-1 on the non-negative bins;
-//                        A_mvar = (H + lam' I)^-1; Sigma = H0 H0^T; DTF / DC / PDC / gPDC / dDTF.
-// Everything is fp64 (the reference's convergence test max |dG| < 1e-8 is out of fp32's reach).
-// One matrix pair lives in LDS: C <= 64 (2 x 64 KB).  Larger systems are rejected, not emulated.
+//   m_build / m_to_series   two-sided Hermitian spectra S[p][e][n] (e = i C + j, n fastest) from the records / from d_S
+//   m_lag0, m_chol, m_fill  G0 = chol(Re ifft_n(S)[lag 0])^H, broadcast over n (identity where the Cholesky fails)
+//   loop <= max_iter (all windows at once, converged windows frozen, convergence polled every 4 iterations):
+//     m_predict_gj          A = G^-1 S G^-H + I: one workgroup per (window, bin), [G | S] in registers, Gauss-Jordan
+//                           with partial pivoting, the second factor as column operations from the logged multipliers
+//                           (65 ... 128 signals: m_inverse_inplace + two m_gemm_mfma products)
+//     causal transform pair a = ifft_n(A), 1/N, a[0] *= 1/2, strict lower triangle of a[0] = 0, a[n >= (N+1)/2] = 0,
+//                           A+ = fft_n(a): one kernel (sc_wilson_fft.hip) for N = 256 ... 4096, else rocFFT Z2Z + m_causal
+//     m_update_mfma         G <- G A+, err = max |G - G_old| on the fp64 matrix cores (m_gemm_mfma beyond 64 signals)
+//   measures                H0 = Re mean_n G; H = G (H0 + lam I)^-1 on the non-negative bins;
+//                           A_mvar = (H + lam' I)^-1; Sigma = H0 H0^T; DTF / DC / PDC / gPDC / dDTF.
+// Everything is fp64 (the reference's convergence test max |dG| < 1e-8 is out of fp32's reach).  The C x C factor of one
+// (window, bin) lives in the registers of one workgroup: C <= 128.  Larger systems are rejected, not emulated.
 #include <rocfft/rocfft.h>
 #include "sc_common.h"
 
@@ -87,27 +87,6 @@ __device__ void mv_lu_forward(cd* M, cd* R, int C, int NR, int* piv) {
     }
 }
 
-// R <- L^-1 P R for a NEW right-hand side, with the factors and pivots left by mv_lu_forward.  The
-// stored multipliers went through every later row swap (LAPACK layout, P M = L U), so ALL swaps are
-// applied to R first and the unit-lower solve follows.
-__device__ void mv_apply_forward(const cd* M, cd* R, int C, int NR, const int* piv) {
-    const int tid = threadIdx.x, nt = blockDim.x;
-    for (int j = tid; j < NR; j += nt)          // a thread owns whole columns: the swaps need no barrier
-        for (int k = 0; k < C; ++k) {
-            const int pv = piv[k];
-            if (pv != k) { const cd t = R[k * NR + j]; R[k * NR + j] = R[pv * NR + j]; R[pv * NR + j] = t; }
-        }
-    __syncthreads();
-    for (int k = 0; k < C; ++k) {
-        const int tx = tid & 31, ty = tid >> 5, nty = nt >> 5 ? nt >> 5 : 1, ntx = nt < 32 ? nt : 32;
-        for (int i = k + 1 + ty; i < C; i += nty) {
-            const cd l = M[i * C + k];
-            for (int j = (nt < 32 ? tid : tx); j < NR; j += ntx) R[i * NR + j] = m_sub(R[i * NR + j], m_mul(l, R[k * NR + j]));
-        }
-        __syncthreads();
-    }
-}
-
 // R <- U^-1 R
 __device__ void mv_back_subst(const cd* M, cd* R, int C, int NR) {
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -122,21 +101,6 @@ __device__ void mv_back_subst(const cd* M, cd* R, int C, int NR) {
         }
         __syncthreads();
     }
-}
-
-// in-place conjugate transpose of a C x C matrix
-__device__ void mv_ctranspose(cd* X, int C) {
-    for (int idx = threadIdx.x; idx < C * C; idx += blockDim.x) {
-        const int i = idx / C, j = idx % C;
-        if (i < j) {
-            const cd a = X[i * C + j], b = X[j * C + i];
-            X[i * C + j] = m_conj(b);
-            X[j * C + i] = m_conj(a);
-        } else if (i == j) {
-            X[idx] = m_conj(X[idx]);
-        }
-    }
-    __syncthreads();
 }
 
 // ---- spectra in, factor out ---------------------------------------------------------------------
@@ -258,31 +222,6 @@ __global__ void m_fill(const double* __restrict__ g0, cd* __restrict__ G, int64_
     if (n < N) G[(p * E + e) * N + n] = make_double2(g0[p * E + e], 0.0);
 }
 
-__global__ void m_predict(const cd* S, const cd* G, const int32_t* status, cd* A, int64_t N, int C) {
-    extern __shared__ __align__(16) unsigned char mv_smem[];
-    cd* Gl = reinterpret_cast<cd*>(mv_smem);
-    cd* X = Gl + C * C;
-    int* piv = reinterpret_cast<int*>(X + C * C);
-    const int64_t n = blockIdx.x, p = blockIdx.y;
-    if (status[p] != 0) return;
-    const int E = C * C;
-    for (int e = threadIdx.x; e < E; e += blockDim.x) {
-        Gl[e] = G[(p * E + e) * N + n];
-        X[e] = S[(p * E + e) * N + n];
-    }
-    __syncthreads();
-    mv_lu_forward(Gl, X, C, C, piv);       // X = L^-1 P S
-    mv_back_subst(Gl, X, C, C);            // X = G^-1 S
-    mv_ctranspose(X, C);                   // X = (G^-1 S)^H
-    mv_apply_forward(Gl, X, C, C, piv);
-    mv_back_subst(Gl, X, C, C);            // X = G^-1 (G^-1 S)^H
-    for (int e = threadIdx.x; e < E; e += blockDim.x) {
-        cd v = X[e];
-        if (e / C == e % C) v.x += 1.0;
-        A[(p * E + e) * N + n] = v;
-    }
-}
-
 __global__ void m_causal(cd* A, int64_t N, int C) {
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int e = blockIdx.y;
@@ -299,43 +238,9 @@ __device__ inline void mv_atomic_max_nonneg(double* addr, double v) {
     atomicMax(reinterpret_cast<unsigned long long*>(addr), (unsigned long long)__double_as_longlong(v));
 }
 
-__global__ void m_update(cd* G, const cd* Aplus, const int32_t* status, double* err, int64_t N, int C) {
-    extern __shared__ __align__(16) unsigned char mv_smem[];
-    cd* Gl = reinterpret_cast<cd*>(mv_smem);
-    cd* Al = Gl + C * C;
-    __shared__ double red[256];
-    const int64_t n = blockIdx.x, p = blockIdx.y;
-    if (status[p] != 0) return;
-    const int E = C * C;
-    for (int e = threadIdx.x; e < E; e += blockDim.x) {
-        Gl[e] = G[(p * E + e) * N + n];
-        Al[e] = Aplus[(p * E + e) * N + n];
-    }
-    __syncthreads();
-    double emax = 0.0;
-    for (int e = threadIdx.x; e < E; e += blockDim.x) {
-        const int i = e / C, j = e % C;
-        cd acc = make_double2(0.0, 0.0);
-        for (int k = 0; k < C; ++k) {
-            const cd t = m_mul(Gl[i * C + k], Al[k * C + j]);
-            acc.x += t.x; acc.y += t.y;
-        }
-        const cd dlt = m_sub(acc, Gl[e]);
-        emax = fmax(emax, hypot(dlt.x, dlt.y));
-        G[(p * E + e) * N + n] = acc;
-    }
-    red[threadIdx.x] = emax;
-    __syncthreads();
-    for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s]);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0 && red[0] > 0.0) mv_atomic_max_nonneg(err + p, red[0]);
-}
-
 // ---- predict / update of the Wilson iteration, second generation ------------------------------------------------
-// m_predict (LU with partial pivoting on an LDS-resident matrix pair, three LDS accesses per complex FMA) was 3.2 ms per
-// launch for 1792 problems of 64 x 64: LDS-bandwidth bound at 3 % of the fp64 rate.  m_predict_gj keeps the WHOLE
+// The first version (LU with partial pivoting on an LDS-resident matrix pair, three LDS accesses per complex FMA) was 3.2 ms
+// per launch for 1792 problems of 64 x 64: LDS-bandwidth bound at 3 % of the fp64 rate.  m_predict_gj keeps the WHOLE
 // augmented matrix [G | S] in registers: the 256 threads of a workgroup form a 16 x 16 grid, thread (ty, tx) owns rows
 // ty + 16 a and columns tx + 16 b (a, b < Q, C <= 16 Q), i.e. Q^2 complex elements of G and of S.  Gauss-Jordan with
 // partial pivoting, one column per step: the owners of column k publish it (and |.|^2 of the rows that have not been
@@ -977,27 +882,6 @@ __global__ void m_transfer(const cd* G, const double* hinv, cd* H, double* sq, i
     if (threadIdx.x == 0) sq[p * F + f] = red[0];
 }
 
-// A_mvar[p][f] = (H + lam' I)^-1   (connectivity.py:581-589)
-__global__ void m_mvar_inverse(const cd* H, const double* lam, cd* Amv, int C) {
-    extern __shared__ __align__(16) unsigned char mv_smem[];
-    cd* M = reinterpret_cast<cd*>(mv_smem);
-    cd* R = M + C * C;
-    int* piv = reinterpret_cast<int*>(R + C * C);
-    const int64_t b = blockIdx.x;                 // p * F + f
-    const int E = C * C;
-    for (int e = threadIdx.x; e < E; e += blockDim.x) {
-        const int i = e / C, j = e % C;
-        cd v = H[b * E + e];
-        if (i == j) v.x += lam[0];
-        M[e] = v;
-        R[e] = make_double2(i == j ? 1.0 : 0.0, 0.0);
-    }
-    __syncthreads();
-    mv_lu_forward(M, R, C, C, piv);
-    mv_back_subst(M, R, C, C);
-    for (int e = threadIdx.x; e < E; e += blockDim.x) Amv[b * E + e] = R[e];
-}
-
 // inflow over frequencies and sources: tot[p][i] = sum_f sum_j |H_ij|^2 (dDTF, connectivity.py:1420-1422)
 __global__ void m_inflow_all(const cd* H, double* tot, int64_t F, int C) {
     const int64_t p = blockIdx.x;
@@ -1369,7 +1253,6 @@ extern "C" int sc_mvar_measure_f64(const void* d_G, int64_t n_groups, int64_t N,
     if (!big) {
         (void)hipFuncSetAttribute((const void*)m_h0_inverse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute((const void*)m_transfer, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)m_mvar_inverse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
     const cd* G = (const cd*)d_G;
     const int h0_chunks = (E + 255) / 256;

@@ -57,7 +57,7 @@ open(os.path.join(P, "r02_bench_kernel_stats.txt"), "w").write("\n".join(hdr + l
 
 fetch, write = pmc("fetch.txt", "FETCH_SIZE"), pmc("write.txt", "WRITE_SIZE")
 rows = [("fused_csm_absim_kernel", "_Z22fused_csm_absim", True), ("fused_combine_kernel", "_Z20fused_combine", True),
-        ("mtfft16_kernel", "_Z14mtfft16", False), ("measure_tile_kernel", "_Z19measure_tile", False)]
+        ("mtfft16_kernel", "_Z14mtfft16", False), ("measure_tile_multi_kernel", "measure_tile_multi", False)]
 txt = ["# rocprofv3 --kernel-trace --pmc FETCH_SIZE  /  --pmc WRITE_SIZE (separate passes, MI355X_MICROARCH.md), python bench.py --steps 2",
        "# --warmup 1 (cfg3, 1x MI355X), round 2 (tools/profile_round.sh).  Counter values are KB per dispatch.  gfx950 correction: FETCH_SIZE",
        "# reports half of a wide (16 B / lane) coalesced read stream -> doubled for the kernels whose reads are such streams (marked x2);",
@@ -77,7 +77,7 @@ if "fused_csm_absim_kernel" in traffic:
            "source": "profiles/r02_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 on gfx950)",
            "cfg3": {"fused_stage_b": traffic["fused_csm_absim_kernel"] + traffic.get("fused_combine_kernel", 0.0),
                     "mtfft_fused": traffic.get("mtfft16_kernel"),
-                    "measure_epilogue": traffic.get("measure_tile_kernel")}}
+                    "measure_epilogue": traffic.get("measure_tile_multi_kernel")}}
     json.dump(rec, open(os.path.join(P, "r02_hbm_traffic.json"), "w"), indent=1)
 
 sq = lines("sq.txt")
