@@ -204,6 +204,26 @@ def test_full_depth_elementwise_relative(sc, cfg):
         print(f"  {name}: max rel err {mx:.2e} (99.9th pct {q999:.2e}) over {100 * frac:.2f} % of the entries")
         close64(got, ref[name], rtol=1e-5, floor=1e-13, what=f"{cfg} {name}")
         assert mx < 1e-7, f"{cfg} {name}: {mx}"
+    if cfg == "cfg5":
+        # canonical coherence of the 16 groups x 513 bins at full depth: sigma_max(L_g^-1 S_gh L_h^-H)^2 from the float64
+        # reference spectra in NumPy (equal to the reference's SVD form when n_obs >= group size: pinned against the oracle
+        # at 24 trials in tests/test_gpu_configs.py), element by element
+        labels = np.repeat(np.arange(16), 16)
+        S = (csm / n_obs).cpu().numpy()[0]                                   # (F, C, C)
+        Linv = []
+        for g in range(16):
+            sl = slice(16 * g, 16 * g + 16)
+            Linv.append(np.linalg.inv(np.linalg.cholesky(S[:, sl, sl])))
+        ref_cc = np.full((S.shape[0], 16, 16), np.nan)
+        for g in range(16):
+            for h in range(g + 1, 16):
+                M = Linv[g] @ S[:, 16 * g:16 * g + 16, 16 * h:16 * h + 16] @ np.conj(np.swapaxes(Linv[h], -1, -2))
+                ref_cc[:, g, h] = ref_cc[:, h, g] = np.linalg.svd(M, compute_uv=False)[:, 0] ** 2
+        cc, lab = c.canonical_coherence(labels)
+        assert np.array_equal(lab, np.arange(16)) and cc.shape == (1,) + ref_cc.shape
+        mx, q999, frac = relative_error_report(cc[0], ref_cc, floor=1e-9)
+        print(f"  canonical_coherence: max rel err {mx:.2e} (99.9th pct {q999:.2e}) over {100 * frac:.2f} % of the entries")
+        close64(cc[0], ref_cc, rtol=1e-6, floor=1e-13, what="cfg5 canonical coherence")
 
 
 def test_f11_band_statistics_float64(sc, golden):
@@ -258,3 +278,39 @@ def test_fused_float64_transform_matches_oracle_and_rocfft(sc, N, L, C, det):
     if N % 2 == 0:
         assert np.all(got[True][..., N // 2, :].imag == 0)   # Nyquist exactly real
     close64(m.fft(), coef, rtol=1e-9, floor=1e-12, what="Multitaper.fft()")
+
+
+def test_cfg4_full_size_granger_elementwise(sc):
+    """BASELINE configs[3] at full size (64 ch x 200 trials x 4096 samples): pairwise spectral Granger prediction of the
+    float64 engine against the oracle, element by element.  A pair's prediction depends on its two channels only, so the
+    CPU oracle is handed just the channels of the pairs checked (the full coefficient array would be 34 GB)."""
+    from oracle import spectral_oracle as so
+    rng = np.random.default_rng(4)
+    C, T, R = 64, 4096, 200
+    e = rng.standard_normal((T + 200, R, C))
+    y = np.zeros_like(e)
+    for t in range(2, T + 200):
+        y[t] = 0.5 * y[t - 1] - 0.3 * y[t - 2] + e[t]
+        y[t, :, 1:] += 0.35 * y[t - 1, :, :-1]
+        y[t, :, 5:] += 0.25 * y[t - 2, :, :-5]
+    x = y[200:]
+    m = sc.Multitaper(x, sampling_frequency=1000.0, time_halfbandwidth_product=3)
+    c = sc.Connectivity.from_multitaper(m, dtype=np.complex128)
+    pairs = [(0, 1), (3, 8), (10, 40), (62, 63)]
+    got = c.subset_pairwise_spectral_granger_prediction(pairs)
+    assert got.shape == (1, 2049, C, C) and c._last_wilson["not_converged"] == 0
+    chans = sorted({ch for p in pairs for ch in p})
+    pos = {ch: k for k, ch in enumerate(chans)}
+    coef, _ = so.multitaper_fft(x[:, :, chans], fs=1000.0, NW=3)
+    ref = so.pairwise_spectral_granger_prediction(coef, pairs=[(pos[i], pos[j]) for i, j in pairs])
+    worst = 0.0
+    for i, j in pairs:
+        for a, b in ((i, j), (j, i)):
+            g, r = got[0, :, a, b], ref[0, :, pos[a], pos[b]]
+            both = ~np.isnan(g) & ~np.isnan(r)
+            assert (np.isnan(g) != np.isnan(r)).mean() < 0.01      # values within rounding of 0 flip to NaN (gp <= 0)
+            big = both & (np.abs(r) > 1e-3 * np.nanmax(r))
+            worst = max(worst, (np.abs(g[big] - r[big]) / np.abs(r[big])).max())
+            assert np.abs(g[both] - r[both]).max() <= 1e-7 * np.nanmax(r)
+    print(f"  cfg4 full size, Granger: worst elementwise relative error {worst:.2e} on entries above 1e-3 of the maximum")
+    assert worst < 1e-5
