@@ -502,23 +502,24 @@ extern "C" int sc_accumulate_f64(const void* d_X, const sc_spectra_desc* desc, u
         else if (need <= 3) rc = launch_csm_f64<3>(a, st);
         else if (need <= 5) rc = launch_csm_f64<5>(a, st);
         else rc = launch_csm_f64<9>(a, st);
-        if (rc) return rc;
     }
-    uint32_t w = which & ~SC_PLANE_CSM;
+    uint32_t w = rc ? 0u : (which & ~SC_PLANE_CSM);
     st = st_nl;
-    if (a.C >= 48 && !getenv("SC_F64_NO_BLOCK")) {      // 64 x 64 blocks, one plane per launch (see nonlinear_f64_block_kernel)
-        if (w & SC_PLANE_ABS_IM) { if ((rc = launch_nl_f64_block<SC_PLANE_ABS_IM>(a, st))) return rc; w &= ~SC_PLANE_ABS_IM; }
-        if (w & SC_PLANE_IM_SQ) { if ((rc = launch_nl_f64_block<SC_PLANE_IM_SQ>(a, st))) return rc; w &= ~SC_PLANE_IM_SQ; }
-        if (w & SC_PLANE_SIGN_IM) { if ((rc = launch_nl_f64_block<SC_PLANE_SIGN_IM>(a, st))) return rc; w &= ~SC_PLANE_SIGN_IM; }
-    }
-    if ((w & (SC_PLANE_ABS_IM | SC_PLANE_IM_SQ)) == (SC_PLANE_ABS_IM | SC_PLANE_IM_SQ)) {
-        if ((rc = launch_nl_f64<SC_PLANE_ABS_IM | SC_PLANE_IM_SQ, 2>(a, st))) return rc;
-        w &= ~(SC_PLANE_ABS_IM | SC_PLANE_IM_SQ);
-    }
-    if (w & SC_PLANE_ABS_IM) { if ((rc = launch_nl_f64<SC_PLANE_ABS_IM, 3>(a, st))) return rc; }
-    if (w & SC_PLANE_IM_SQ) { if ((rc = launch_nl_f64<SC_PLANE_IM_SQ, 3>(a, st))) return rc; }
-    if (w & SC_PLANE_SIGN_IM) { if ((rc = launch_nl_f64<SC_PLANE_SIGN_IM, 3>(a, st))) return rc; }
-    if (w & SC_PLANE_UNIT) { if ((rc = launch_nl_f64<SC_PLANE_UNIT, 2>(a, st))) return rc; }
+    do {        // (one exit: the side stream is joined below whether or not a launch failed)
+        if (a.C >= 48 && !getenv("SC_F64_NO_BLOCK")) {      // 64 x 64 blocks, one plane per launch (see nonlinear_f64_block_kernel)
+            if (w & SC_PLANE_ABS_IM) { if ((rc = launch_nl_f64_block<SC_PLANE_ABS_IM>(a, st))) break; w &= ~SC_PLANE_ABS_IM; }
+            if (w & SC_PLANE_IM_SQ) { if ((rc = launch_nl_f64_block<SC_PLANE_IM_SQ>(a, st))) break; w &= ~SC_PLANE_IM_SQ; }
+            if (w & SC_PLANE_SIGN_IM) { if ((rc = launch_nl_f64_block<SC_PLANE_SIGN_IM>(a, st))) break; w &= ~SC_PLANE_SIGN_IM; }
+        }
+        if ((w & (SC_PLANE_ABS_IM | SC_PLANE_IM_SQ)) == (SC_PLANE_ABS_IM | SC_PLANE_IM_SQ)) {
+            if ((rc = launch_nl_f64<SC_PLANE_ABS_IM | SC_PLANE_IM_SQ, 2>(a, st))) break;
+            w &= ~(SC_PLANE_ABS_IM | SC_PLANE_IM_SQ);
+        }
+        if (w & SC_PLANE_ABS_IM) { if ((rc = launch_nl_f64<SC_PLANE_ABS_IM, 3>(a, st))) break; }
+        if (w & SC_PLANE_IM_SQ) { if ((rc = launch_nl_f64<SC_PLANE_IM_SQ, 3>(a, st))) break; }
+        if (w & SC_PLANE_SIGN_IM) { if ((rc = launch_nl_f64<SC_PLANE_SIGN_IM, 3>(a, st))) break; }
+        if (w & SC_PLANE_UNIT) { if ((rc = launch_nl_f64<SC_PLANE_UNIT, 2>(a, st))) break; }
+    } while (0);
     if (fork) {
         SC_CHECK_HIP(hipEventRecord(ev_join, side));
         SC_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, ev_join, 0));
