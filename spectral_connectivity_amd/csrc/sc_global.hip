@@ -180,12 +180,15 @@ __global__ void __launch_bounds__(256) global_coherence_kernel(GcArgs a) {
 // the rotation angles of every round are logged to a global scratch; the requested eigenvectors are then
 // V e_k = J_1 J_2 ... J_m e_k, evaluated right to left on a single C-vector per eigenvector -- the C x C
 // eigenvector matrix is never formed.
-#define GC_BIG_CMAX 128
+#define GC_BIG_CMAX 128      // packed triangle in LDS
+#define GC_HUGE_CMAX 256     // packed triangle (526 KB at 256 signals) in a per-workgroup global scratch: the same kernel on
+                             // an L2-resident matrix, an order of magnitude slower per rotation but no new algorithm
 #define GC_BIG_SWEEPS 12
 
 struct GcBigArgs {
     GcArgs g;
     double* log;           // [slots][GC_BIG_SWEEPS * (M - 1)][M / 2][3]  (cos, Re s, Im s)
+    cd* scratch;           // [slots][C (C + 1) / 2] packed triangles when they do not fit LDS (n_signals > 128), else NULL
     int n_bins_total;
 };
 
@@ -204,8 +207,11 @@ __global__ void __launch_bounds__(256) global_coherence_big_kernel(GcBigArgs b) 
     extern __shared__ __align__(16) unsigned char gc_smem[];
     const GcArgs& a = b.g;
     const int C = a.C, M = C + (C & 1), H = M / 2;
-    cd* A = reinterpret_cast<cd*>(gc_smem);                            // packed upper triangle
-    double* rc = reinterpret_cast<double*>(A + (size_t)C * (C + 1) / 2);   // [H] cos
+    const size_t tri = (size_t)C * (C + 1) / 2;
+    // packed upper triangle: in LDS, or (n_signals > 128) this workgroup's slice of the global scratch -- a workgroup's
+    // waves share one L1, and __syncthreads orders its global writes like its LDS writes
+    cd* A = b.scratch ? b.scratch + (size_t)blockIdx.x * tri : reinterpret_cast<cd*>(gc_smem);
+    double* rc = b.scratch ? reinterpret_cast<double*>(gc_smem) : reinterpret_cast<double*>(A + tri);   // [H] cos
     cd* rs = reinterpret_cast<cd*>(rc + H + (H & 1));                  // [H] sin e^{i phi}
     int* rp = reinterpret_cast<int*>(rs + H);                          // [H][2]
     double* ev = reinterpret_cast<double*>(rp + M + (M & 1));          // [C]
@@ -387,7 +393,7 @@ __global__ void __launch_bounds__(256) global_coherence_big_kernel(GcBigArgs b) 
     }
 }
 
-extern "C" int sc_global_coherence_max_signals(void) { return GC_BIG_CMAX; }
+extern "C" int sc_global_coherence_max_signals(void) { return GC_HUGE_CMAX; }
 
 extern "C" int sc_global_coherence_f64(const void* d_accum, int64_t n_groups, int64_t n_freq_accum, int64_t N,
                                        int64_t C, uint32_t planes, int64_t n_obs, int max_rank, int ascending,
@@ -397,8 +403,8 @@ extern "C" int sc_global_coherence_f64(const void* d_accum, int64_t n_groups, in
     SC_REQUIRE(planes & SC_PLANE_CSM, "accumulator record must contain SC_PLANE_CSM");
     SC_REQUIRE(n_freq_accum == N || n_freq_accum == N / 2 + 1, "accumulators must hold N or N/2+1 bins");
     SC_REQUIRE(n_groups >= 1 && n_groups <= 65535 && N >= 1 && n_obs >= 1, "bad problem size");
-    if (C < 1 || C > GC_BIG_CMAX) {
-        sc_set_error("global coherence keeps the C x C matrix in LDS: n_signals <= %d (got %lld)", GC_BIG_CMAX, (long long)C);
+    if (C < 1 || C > GC_HUGE_CMAX) {
+        sc_set_error("global coherence: n_signals <= %d (got %lld)", GC_HUGE_CMAX, (long long)C);
         return SC_EUNSUPPORTED;
     }
     SC_REQUIRE(max_rank >= 1 && max_rank <= C, "max_rank must be in 1..n_signals");
@@ -416,13 +422,20 @@ extern "C" int sc_global_coherence_f64(const void* d_accum, int64_t n_groups, in
         SC_REQUIRE(max_rank <= 4, "n_signals > 64: at most 4 components");
         const int H = M / 2;
         const int64_t bins = n_groups * N;
-        const int slots = (int)(bins < 512 ? bins : 512);
+        const bool huge = C > GC_BIG_CMAX;
+        const int max_slots = huge ? 256 : 512;
+        const int slots = (int)(bins < max_slots ? bins : max_slots);
+        const size_t tri_bytes = (size_t)C * (C + 1) / 2 * sizeof(cd);
         const size_t log_bytes = (size_t)slots * GC_BIG_SWEEPS * (M - 1) * H * 3 * sizeof(double);
         double* log = nullptr;
-        if (hipMalloc((void**)&log, log_bytes) != hipSuccess) { sc_set_error("global coherence: rotation log alloc failed"); return SC_ENOMEM; }
+        if (hipMalloc((void**)&log, log_bytes + (huge ? slots * tri_bytes : 0)) != hipSuccess) {
+            sc_set_error("global coherence: rotation log alloc failed");
+            return SC_ENOMEM;
+        }
         GcBigArgs b;
         b.g = a; b.log = log; b.n_bins_total = (int)bins;
-        const size_t lds = (size_t)C * (C + 1) / 2 * sizeof(cd) + (size_t)(H + 2) * 8 + (size_t)H * 16 + (size_t)(M + 2) * 4 +
+        b.scratch = huge ? reinterpret_cast<cd*>(reinterpret_cast<char*>(log) + log_bytes) : nullptr;
+        const size_t lds = (huge ? 0 : tri_bytes) + (size_t)(H + 2) * 8 + (size_t)H * 16 + (size_t)(M + 2) * 4 +
                            (size_t)C * 8 + (size_t)(C + 4) * 4 + (size_t)H * (H + 1) * 2 + 16 + (size_t)4 * C * sizeof(cd) + 64;
         (void)hipFuncSetAttribute((const void*)global_coherence_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(global_coherence_big_kernel, dim3((unsigned)slots), dim3(256), lds, (hipStream_t)stream, b);

@@ -314,3 +314,19 @@ def test_cfg4_full_size_granger_elementwise(sc):
             assert np.abs(g[both] - r[both]).max() <= 1e-7 * np.nanmax(r)
     print(f"  cfg4 full size, Granger: worst elementwise relative error {worst:.2e} on entries above 1e-3 of the maximum")
     assert worst < 1e-5
+
+
+@pytest.mark.parametrize("C", [65, 128, 129, 256])
+def test_global_coherence_large_float64(sc, C):
+    """Global coherence of 65 ... 256 signals from double records (packed Jacobi in LDS up to 128 signals, in a global
+    scratch beyond): squared singular values of the oracle to 1e-11, dominant vector as a line."""
+    from oracle import spectral_oracle as so
+    x = np.random.default_rng(C).standard_normal((64, 110, C))
+    x[:, :, : C // 2] += np.random.default_rng(1).standard_normal((64, 110, 1))
+    kw = dict(sampling_frequency=128.0, time_halfbandwidth_product=2, n_time_samples_per_window=32)
+    coef, _ = so.multitaper_fft(x, fs=128.0, NW=2, n_time_samples_per_window=32)
+    ref, ref_vecs = so.global_coherence(coef, max_rank=3)
+    vals, vecs = sc.Connectivity.from_multitaper(sc.Multitaper(x, **kw)).global_coherence(max_rank=3)
+    close64(vals, ref, rtol=1e-11, floor=1e-12, what=f"global coherence C={C}")
+    ip = np.abs(np.sum(np.conj(vecs[..., -1]) * ref_vecs[..., -1], axis=-1))
+    assert (ip > 1 - 1e-6).mean() > 0.9, f"C={C}: dominant vector differs ({ip.min()})"

@@ -519,6 +519,23 @@ def test_global_coherence_large_even_and_odd(sc):
         assert (ip > 1 - 1e-3).mean() > 0.9, f"C={C}: dominant vector differs ({ip.min()})"
 
 
+@pytest.mark.parametrize("C", [129, 200, 255, 256])
+def test_global_coherence_beyond_128_signals(sc, C):
+    """129 ... 256 signals: the packed matrix no longer fits LDS and lives in a global scratch (the same Jacobi kernel on
+    an L2-resident triangle); values and the dominant vector against the oracle's SVD (float64 engine:
+    tests/test_gpu_fp64.py)."""
+    x = np.random.default_rng(C).standard_normal((64, 110, C))
+    x[:, :, : C // 2] += np.random.default_rng(1).standard_normal((64, 110, 1))
+    kw = dict(sampling_frequency=128.0, time_halfbandwidth_product=2, n_time_samples_per_window=32)
+    coef, _ = so.multitaper_fft(x, fs=128.0, NW=2, n_time_samples_per_window=32)
+    ref, ref_vecs = so.global_coherence(coef, max_rank=3)
+    vals, vecs = sc.Connectivity.from_multitaper(sc.Multitaper(x, **kw)).global_coherence(max_rank=3)
+    close32(vals, ref, rtol=2e-5, atol_scale=2e-6, what=f"global coherence C={C}")
+    np.testing.assert_allclose(np.linalg.norm(vecs, axis=-2), 1.0, atol=1e-9)
+    ip = np.abs(np.sum(np.conj(vecs[..., -1]) * ref_vecs[..., -1], axis=-1))
+    assert (ip > 1 - 1e-3).mean() > 0.9, f"C={C}: dominant vector differs ({ip.min()})"
+
+
 def test_wrapper_labelled_outputs_against_the_oracle(sc):
     """multitaper_connectivity() / connectivity_to_xarray() (reference wrapper.py:17-287): dims / coords / names / mt_*
     attributes of the labelled output -- real xarray objects where the package is installed, the vendored minimal
