@@ -16,11 +16,15 @@
  *      - `sc_fft_plan` handles (sc_fft_plan_create*): the rocFFT plan, its work buffer and a <= 64 MB
  *        transform scratch (hipMalloc; freed by sc_fft_plan_destroy; sc_fft_plan_work_bytes reports it);
  *      - stream-ordered scratch (hipMallocAsync / hipFreeAsync on the call's stream) inside
- *        sc_multitaper_fft_f32 for N >= 2048 (row-major spectra before the transpose, <= 2 GB),
- *        sc_canonical_coherence_f64 (inverted group factors, n_bins * n_groups * 4 KB),
- *        sc_global_coherence_f64 above 64 signals (rotation log) and the rocFFT work buffers of
+ *        sc_multitaper_fft_f32 for N = 4096 (row-major spectra before the transpose, <= 2 GB),
+ *        sc_canonical_coherence_f64 (inverted group factors, n_bins * n_groups * 4 KB; groups beyond 32 channels:
+ *        the blocks of the pairs in flight, <= 192 MB),
+ *        sc_global_coherence_f64 above 64 signals (rotation log; above 128 signals also the packed matrices) and the
+ *        rocFFT work buffers of
  *        sc_granger_pairwise_f64 / sc_wilson_factor_f64 / sc_mvar_factor_f64 for lengths their fused
  *        transform kernel does not take.
+ *      - one side stream + two events (created on first use, kept) of sc_accumulate_f64, which forks its
+ *        per-observation plane kernels from the caller's stream and joins them back before it returns.
  *    Everything else (spectra, records, workspaces, outputs) is caller memory with sizes the
  *    *_bytes / sc_accum_layout queries report.
  *  - `stream` is a hipStream_t passed as void* (NULL = default stream).  All calls are
@@ -392,12 +396,13 @@ int sc_global_coherence_f64(const void* d_accum, int64_t n_groups, int64_t n_fre
  * _estimate_canonical_coherence (connectivity.py:745-820, :1979-2032): per (bin, group pair)
  * the squared largest singular value of L_g^-1 S_gh L_h^-H with S_gg = L_g L_g^H.
  *   d_members   int32 [n_groups][stride] channel indices of every group, stride = 16 if
- *               max_group_size <= 16 else 32 (max supported: sc_canonical_max_group())
+ *               max_group_size <= 16, 32 if <= 32, else 128 (max supported: sc_canonical_max_group() = 128)
  *   d_sizes     int32 [n_groups]
  *   d_out       double [n_bins][n_groups][n_groups], symmetric, NaN diagonal
  *   d_fail      int32 [1]: number of group blocks that were not positive definite
  * Groups of <= 16 channels take a stream-ordered workspace of n_bins * n_groups * 4 KB for the
- * inverted group factors (hipMallocAsync / hipFreeAsync on `stream`); SC_ENOMEM if that fails. */
+ * inverted group factors, groups beyond 32 channels one of 768 KB per persistent workgroup (<= 256) for the blocks of
+ * the pair in flight (hipMallocAsync / hipFreeAsync on `stream`); SC_ENOMEM if that fails. */
 int sc_canonical_max_group(void);
 int sc_canonical_coherence_f64(const void* d_accum, int64_t n_bins, int64_t n_signals, uint32_t planes,
                                int64_t n_observations, const int32_t* d_members, const int32_t* d_sizes,

@@ -14,6 +14,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include "sc_common.h"
+#include "sc_jacobi.h"
 
 typedef double2 cd;
 __device__ inline cd zmul(cd a, cd b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
@@ -430,7 +431,140 @@ __global__ void canon_fill_nan(double* out, int64_t total) {
     if (i < total) out[i] = nan("");
 }
 
-extern "C" int sc_canonical_max_group(void) { return 32; }
+// ---- groups of 33 ... 128 channels: a workgroup per (bin, group pair) -------------------------------------------------
+// Three C x C matrices per problem no longer fit a lane's scratch (or the LDS): the group blocks S_aa, S_bb and the cross
+// block S_ab of a problem live in a per-workgroup global scratch (L2-resident: 3 x 256 KB at 128 channels), factored and
+// whitened by the workgroup's 256 threads in place -- right-looking Cholesky (one column per step), M <- L_a^-1 M with a
+// thread per column, M <- M L_b^-H with a thread per row --, then B = M M^H goes into LDS as a packed upper triangle and
+// the parallel cyclic Jacobi of the global-coherence kernel (sc_jacobi.h) diagonalises it: its largest diagonal entry
+// is the squared canonical coherence.  Persistent workgroups (one per CU) walk the (bin, pair) list.
+#define CBIG_C 128
+#define CBIG_SWEEPS 14
+
+// in-place lower Cholesky of the n x n Hermitian matrix L (row-major, stride CBIG_C, lower triangle valid), all 256 threads
+__device__ inline bool cbig_cholesky(cd* L, int n, int* bad) {
+    const int tid = threadIdx.x;
+    for (int k = 0; k < n; ++k) {
+        if (tid == 0) {
+            const double d = L[k * CBIG_C + k].x;
+            if (!(d > 0.0)) *bad = 1;
+            L[k * CBIG_C + k] = make_double2(sqrt(d > 0.0 ? d : 1.0), 0.0);
+        }
+        __syncthreads();
+        const double dk = L[k * CBIG_C + k].x;
+        for (int i = k + 1 + tid; i < n; i += 256) {
+            const cd v = L[i * CBIG_C + k];
+            L[i * CBIG_C + k] = make_double2(v.x / dk, v.y / dk);
+        }
+        __syncthreads();
+        // trailing update of the lower triangle: L[i][j] -= L[i][k] conj(L[j][k]), k < j <= i
+        const int m = n - k - 1;
+        for (int e = tid; e < m * m; e += 256) {
+            const int i = k + 1 + e / m, j = k + 1 + e % m;
+            if (j <= i) {
+                const cd t = zmulc(L[i * CBIG_C + k], L[j * CBIG_C + k]);
+                cd v = L[i * CBIG_C + j];
+                v.x -= t.x; v.y -= t.y;
+                L[i * CBIG_C + j] = v;
+            }
+        }
+        __syncthreads();
+    }
+    return *bad == 0;
+}
+
+__global__ void __launch_bounds__(256) canonical_big_kernel(CanonArgs a, cd* scratch, int64_t n_items) {
+    extern __shared__ __align__(16) unsigned char cb_smem[];
+    cd* B = reinterpret_cast<cd*>(cb_smem);                                  // packed upper triangle, <= 128 x 129 / 2
+    constexpr int HM = CBIG_C / 2;
+    double* rc = reinterpret_cast<double*>(B + (size_t)CBIG_C * (CBIG_C + 1) / 2);    // [HM]
+    cd* rs = reinterpret_cast<cd*>(rc + HM);                                 // [HM]
+    int* rp = reinterpret_cast<int*>(rs + HM);                               // [2 HM]
+    unsigned short* blk_u = reinterpret_cast<unsigned short*>(rp + 2 * HM);  // [HM (HM + 1) / 2]
+    unsigned short* blk_v = blk_u + HM * (HM + 1) / 2;
+    __shared__ double red[2][256];
+    __shared__ int done, n_rounds, bad, tab_for;
+    const int tid = threadIdx.x;
+    cd* La = scratch + (size_t)blockIdx.x * 3 * CBIG_C * CBIG_C;
+    cd* Lb = La + CBIG_C * CBIG_C;
+    cd* M = Lb + CBIG_C * CBIG_C;
+    if (tid == 0) tab_for = -1;
+    __syncthreads();
+    for (int64_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int64_t bin = item / a.n_gpairs;
+        int gp = (int)(item - bin * a.n_gpairs);
+        int ga = 0, len = a.G - 1;
+        while (gp >= len) { gp -= len; ++ga; --len; }
+        int gb = ga + 1 + gp;
+        // the Jacobi runs on the SMALLER group's side: B = M M^H is n_a x n_a with the same non-zero spectrum either way
+        if (a.sizes[gb] < a.sizes[ga]) { const int t = ga; ga = gb; gb = t; }
+        const int na = a.sizes[ga], nb = a.sizes[gb];
+        const int32_t* ma = a.members + ga * CBIG_C;
+        const int32_t* mb = a.members + gb * CBIG_C;
+        const ScRec rec = a.accum + bin * a.floats_per_bin;
+        if (tid == 0) bad = 0;
+        for (int e = tid; e < na * na; e += 256) { const int i = e / na, j = e % na; if (j <= i) La[i * CBIG_C + j] = csm_read(rec, a, ma[i], ma[j]); }
+        for (int e = tid; e < nb * nb; e += 256) { const int i = e / nb, j = e % nb; if (j <= i) Lb[i * CBIG_C + j] = csm_read(rec, a, mb[i], mb[j]); }
+        for (int e = tid; e < na * nb; e += 256) { const int i = e / nb, j = e % nb; M[i * CBIG_C + j] = csm_read(rec, a, ma[i], mb[j]); }
+        __syncthreads();
+        cbig_cholesky(La, na, &bad);
+        cbig_cholesky(Lb, nb, &bad);
+        // M <- La^-1 M: thread j owns column j (forward substitution down the rows)
+        for (int j = tid; j < nb; j += 256)
+            for (int i = 0; i < na; ++i) {
+                cd sacc = M[i * CBIG_C + j];
+                for (int k = 0; k < i; ++k) { const cd t = zmul(La[i * CBIG_C + k], M[k * CBIG_C + j]); sacc.x -= t.x; sacc.y -= t.y; }
+                const double d = La[i * CBIG_C + i].x;
+                M[i * CBIG_C + j] = make_double2(sacc.x / d, sacc.y / d);
+            }
+        __syncthreads();
+        // M <- M Lb^-H: thread i owns row i (forward substitution along the columns)
+        for (int i = tid; i < na; i += 256)
+            for (int j = 0; j < nb; ++j) {
+                cd sacc = M[i * CBIG_C + j];
+                for (int k = 0; k < j; ++k) { const cd t = zmulc(M[i * CBIG_C + k], Lb[j * CBIG_C + k]); sacc.x -= t.x; sacc.y -= t.y; }
+                const double d = Lb[j * CBIG_C + j].x;
+                M[i * CBIG_C + j] = make_double2(sacc.x / d, sacc.y / d);
+            }
+        __syncthreads();
+        // B = M M^H, packed upper triangle in LDS
+        for (int e = tid; e < na * na; e += 256) {
+            const int i = e / na, j = e % na;
+            if (i > j) continue;
+            cd sacc = make_double2(0.0, 0.0);
+            for (int k = 0; k < nb; ++k) { const cd t = zmulc(M[i * CBIG_C + k], M[j * CBIG_C + k]); sacc.x += t.x; sacc.y += t.y; }
+            if (i == j) sacc.y = 0.0;
+            B[gc_tri(i, j, na)] = sacc;
+        }
+        const int H = (na + (na & 1)) / 2;
+        if (tab_for != H) {                        // pairing table of this group size (rebuilt only when the size changes)
+            __syncthreads();
+            gc_block_table(blk_u, blk_v, H, tid);
+            if (tid == 0) tab_for = H;
+        }
+        __syncthreads();
+        gc_jacobi(B, na, rc, rs, rp, blk_u, blk_v, red, &done, &n_rounds, nullptr, CBIG_SWEEPS);
+        __syncthreads();
+        double lmax = -1.0;
+        for (int i = tid; i < na; i += 256) lmax = fmax(lmax, B[gc_tri(i, i, na)].x);
+        red[0][tid] = lmax;
+        __syncthreads();
+        for (int s2 = 128; s2 > 0; s2 >>= 1) {
+            if (tid < s2) red[0][tid] = fmax(red[0][tid], red[0][tid + s2]);
+            __syncthreads();
+        }
+        if (tid == 0) {
+            double v = red[0][0];
+            if (bad) { v = nan(""); atomicAdd(a.fail, 1); }
+            double* o = a.out + bin * a.G * a.G;
+            o[ga * a.G + gb] = v;
+            o[gb * a.G + ga] = v;
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int sc_canonical_max_group(void) { return CBIG_C; }
 
 extern "C" int sc_canonical_coherence_f64(const void* d_accum, int64_t n_bins, int64_t n_signals, uint32_t planes,
                                           int64_t n_observations, const int32_t* d_members, const int32_t* d_sizes,
@@ -440,8 +574,8 @@ extern "C" int sc_canonical_coherence_f64(const void* d_accum, int64_t n_bins, i
     SC_REQUIRE(d_accum && d_members && d_sizes && d_out && d_fail, "NULL argument");
     SC_REQUIRE(planes & SC_PLANE_CSM, "accumulator record must contain SC_PLANE_CSM");
     SC_REQUIRE(n_groups >= 1 && n_bins >= 1, "empty problem");
-    if (max_group_size > 32) {
-        sc_set_error("canonical coherence supports groups of at most 32 channels (got %d)", max_group_size);
+    if (max_group_size > CBIG_C) {
+        sc_set_error("canonical coherence supports groups of at most %d channels (got %d)", CBIG_C, max_group_size);
         return SC_EUNSUPPORTED;
     }
     hipStream_t st = (hipStream_t)stream;
@@ -480,8 +614,23 @@ extern "C" int sc_canonical_coherence_f64(const void* d_accum, int64_t n_bins, i
             hipLaunchKernelGGL(canonical_pair_kernel, dim3((unsigned)n_wg), dim3(64 * CB_WAVES), lds_p, st, a, (const cd*)Lg,
                                (const int*)okb);
             (void)hipFreeAsync(Lg, st);
-        } else {
+        } else if (max_group_size <= 32) {
             hipLaunchKernelGGL(canonical_kernel<32>, dim3(blocks), dim3(64), 0, st, a);
+        } else {
+            // (members stride CBIG_C) persistent workgroups, three C x C matrices each in a stream-ordered scratch
+            const int slots = (int)(threads < 256 ? threads : 256);
+            cd* scratch = nullptr;
+            const size_t sbytes = (size_t)slots * 3 * CBIG_C * CBIG_C * sizeof(cd);
+            if (hipMallocAsync((void**)&scratch, sbytes, st) != hipSuccess) {
+                sc_set_error("canonical coherence: scratch allocation of %zu bytes failed", sbytes);
+                return SC_ENOMEM;
+            }
+            constexpr size_t HM = CBIG_C / 2;
+            const size_t lds = (size_t)CBIG_C * (CBIG_C + 1) / 2 * sizeof(cd) + HM * 8 + HM * 16 + 2 * HM * 4 +
+                               HM * (HM + 1) * 2 + 64;
+            SC_CHECK_HIP(hipFuncSetAttribute((const void*)canonical_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(canonical_big_kernel, dim3((unsigned)slots), dim3(256), lds, st, a, scratch, threads);
+            (void)hipFreeAsync(scratch, st);
         }
     }
     SC_CHECK_HIP(hipGetLastError());

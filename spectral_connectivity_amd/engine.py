@@ -498,7 +498,7 @@ def canonical_coherence(accum, n_signals, planes, n_obs, groups):
     dev = accum.device
     G = len(groups)
     cmax = max(len(g) for g in groups)
-    stride = 16 if cmax <= 16 else 32
+    stride = 16 if cmax <= 16 else (32 if cmax <= 32 else 128)      # member-table stride of the kernel that takes this size
     members = np.full((G, stride), -1, dtype=np.int32)
     for i, g in enumerate(groups):
         members[i, : min(len(g), stride)] = np.asarray(g, dtype=np.int32)[:stride]

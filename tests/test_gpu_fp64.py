@@ -330,3 +330,18 @@ def test_global_coherence_large_float64(sc, C):
     close64(vals, ref, rtol=1e-11, floor=1e-12, what=f"global coherence C={C}")
     ip = np.abs(np.sum(np.conj(vecs[..., -1]) * ref_vecs[..., -1], axis=-1))
     assert (ip > 1 - 1e-6).mean() > 0.9, f"C={C}: dominant vector differs ({ip.min()})"
+
+
+@pytest.mark.parametrize("sizes", [(33, 40), (128, 70)])
+def test_canonical_coherence_large_groups_float64(sc, sizes):
+    """Canonical coherence of groups beyond 32 channels from double records: the oracle's SVD form to 1e-7."""
+    from oracle import spectral_oracle as so
+    C = sum(sizes)
+    labels = np.repeat(np.arange(len(sizes)), sizes)
+    rng = np.random.default_rng(C)
+    x = rng.standard_normal((64, 60, C)) + 0.7 * rng.standard_normal((64, 60, 1))
+    kw = dict(sampling_frequency=128.0, time_halfbandwidth_product=2, n_time_samples_per_window=32)
+    coef, _ = so.multitaper_fft(x, fs=128.0, NW=2, n_time_samples_per_window=32)
+    ref, _ = so.canonical_coherence(coef, labels)
+    got, _ = sc.Connectivity.from_multitaper(sc.Multitaper(x, **kw)).canonical_coherence(labels)
+    close64(got, ref, rtol=1e-7, floor=1e-9, what=f"canonical coherence, groups {sizes}")

@@ -536,6 +536,27 @@ def test_global_coherence_beyond_128_signals(sc, C):
     assert (ip > 1 - 1e-3).mean() > 0.9, f"C={C}: dominant vector differs ({ip.min()})"
 
 
+@pytest.mark.parametrize("sizes", [(33, 40), (64, 64, 20), (128, 70), (100, 1, 57)])
+def test_canonical_coherence_groups_beyond_32_channels(sc, sizes):
+    """Groups of 33 ... 128 channels: a workgroup per (bin, group pair) with the blocks in a global scratch and the
+    packed Jacobi of sc_jacobi.h, against the oracle's SVD form (n_obs >= every group size)."""
+    C = sum(sizes)
+    labels = np.repeat(np.arange(len(sizes)), sizes)
+    rng = np.random.default_rng(C)
+    x = rng.standard_normal((64, 60, C))
+    x += 0.7 * rng.standard_normal((64, 60, 1))
+    x[:, :, : sizes[0]] += 0.8 * rng.standard_normal((64, 60, 1))
+    perm = rng.permutation(C)                                  # groups interleaved over the channel axis
+    x, labels = x[:, :, perm], labels[perm]
+    kw = dict(sampling_frequency=128.0, time_halfbandwidth_product=2, n_time_samples_per_window=32)
+    coef, _ = so.multitaper_fft(x, fs=128.0, NW=2, n_time_samples_per_window=32)
+    ref, ref_lab = so.canonical_coherence(coef, labels)
+    got, lab = sc.Connectivity.from_multitaper(sc.Multitaper(x, **kw)).canonical_coherence(labels)
+    assert np.array_equal(lab, ref_lab)
+    close32(got, ref, rtol=5e-5, atol_scale=5e-5, what=f"canonical coherence, groups {sizes}")
+    np.testing.assert_array_equal(got, np.swapaxes(got, -1, -2))
+
+
 def test_wrapper_labelled_outputs_against_the_oracle(sc):
     """multitaper_connectivity() / connectivity_to_xarray() (reference wrapper.py:17-287): dims / coords / names / mt_*
     attributes of the labelled output -- real xarray objects where the package is installed, the vendored minimal
