@@ -112,18 +112,29 @@ __global__ void __launch_bounds__(256, MAX_SLOTS <= 9 ? 2 : 1) csm_f64_kernel(F6
         double2* nxt = lds + ((ch + 1) & 1) * buf;
         const bool more = ch + 1 < n_chunks;
         if (more) f64_load<E>(p, walk, base, (ch + 1) * E, regs);
+        // operands of slot s + 1 are requested before the four MFMAs of slot s are issued (left to itself the compiler
+        // reloads one register pair per slot and waits for it: an LDS round trip between every two groups of MFMAs)
+        constexpr int NSTEP = (E / 4) * MAX_SLOTS;
+        double2 an, bn;
+        {
+            const double2* rowp = cur + k * p.CP + c16;
+            an = rowp[16 * bi[0]];
+            bn = rowp[16 * bj[0]];
+        }
 #pragma unroll
-        for (int kk = 0; kk < E / 4; ++kk) {
-            const double2* rowp = cur + (kk * 4 + k) * p.CP + c16;
-#pragma unroll
-            for (int s = 0; s < MAX_SLOTS; ++s) {       // invalid slots recompute tile (0, 0) and are never stored
-                const double2 a = rowp[16 * bi[s]];
-                const double2 b = rowp[16 * bj[s]];
-                re[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.x, re[s], 0, 0, 0);
-                im[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b.x, im[s], 0, 0, 0);
-                re[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b.y, re[s], 0, 0, 0);
-                im[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.x, b.y, im[s], 0, 0, 0);
+        for (int st = 0; st < NSTEP; ++st) {            // invalid slots recompute tile (0, 0) and are never stored
+            const int s = st % MAX_SLOTS;
+            const double2 a = an, b = bn;
+            if (st + 1 < NSTEP) {
+                const int kk1 = (st + 1) / MAX_SLOTS, s1 = (st + 1) % MAX_SLOTS;
+                const double2* rowp = cur + (kk1 * 4 + k) * p.CP + c16;
+                an = rowp[16 * bi[s1]];
+                bn = rowp[16 * bj[s1]];
             }
+            re[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.x, re[s], 0, 0, 0);
+            im[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b.x, im[s], 0, 0, 0);
+            re[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b.y, re[s], 0, 0, 0);
+            im[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.x, b.y, im[s], 0, 0, 0);
         }
         if (more) f64_store<E>(p, nxt, tid, regs);
         __syncthreads();
