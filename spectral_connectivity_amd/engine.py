@@ -265,20 +265,32 @@ def _workspace(n_bytes, device):
     return buf
 
 
-def accumulate(spectra, expectation_type, planes, n_freq=None, mark=None, use_fused=None):
-    """Stage B: un-normalised accumulator record tensor [n_bins, floats_per_bin] (float32)."""
+def _record_tensor(n_bins, fpb, dtype, device, row_multiple):
+    """[n_bins, fpb] records; with row_multiple > 1 the allocation is rounded up to that many rows (zeroed tail) and
+    the first n_bins rows are returned as a view of it -- the padded buffer (``._base``) is what a reduce-scatter over
+    bins takes, without a concatenation."""
+    rows = -(-n_bins // row_multiple) * row_multiple
+    full = torch.empty((rows, fpb), dtype=dtype, device=device)
+    if rows > n_bins:
+        full[n_bins:].zero_()
+    return full[:n_bins]
+
+
+def accumulate(spectra, expectation_type, planes, n_freq=None, mark=None, use_fused=None, row_multiple=1):
+    """Stage B: un-normalised accumulator record tensor [n_bins, floats_per_bin] (float32; float64 records from
+    complex128 spectra).  ``row_multiple``: see _record_tensor (trial-sharded callers pass the world size)."""
     lib = _lib.load()
     d = spectra.desc(expectation_type, n_freq)
     n_bins, fpb, _, n_obs = accum_layout(spectra, expectation_type, planes, n_freq)
     if spectra.f64:
         # float64 engine: fp64 matrix cores for the CSM planes, fp64 VALU for the others, double records
-        accum = torch.empty((n_bins, fpb), dtype=torch.float64, device=spectra.X.device)
+        accum = _record_tensor(n_bins, fpb, torch.float64, spectra.X.device, row_multiple)
         _lib.check(lib.sc_accumulate_f64(_ptr(spectra.X), byref(d), planes, planes, _ptr(accum), _stream()),
                    "sc_accumulate_f64")
         if mark:
             mark("accumulate_f64")
         return accum, n_obs
-    accum = torch.empty((n_bins, fpb), dtype=torch.float32, device=spectra.X.device)
+    accum = _record_tensor(n_bins, fpb, torch.float32, spectra.X.device, row_multiple)
     per_plane_only = use_fused is False        # explicit request (tests): every plane through its separate kernel
     if use_fused is None:
         use_fused = bool(lib.sc_fused_supported(spectra.C_alloc))

@@ -37,8 +37,13 @@ def reduce_scatter_bins(accum, group=None):
     n_bins, fpb = accum.shape
     per = padded_bins(n_bins, world) // world
     if per * world != n_bins:
-        pad = torch.zeros((per * world - n_bins, fpb), dtype=accum.dtype, device=accum.device)
-        accum = torch.cat([accum, pad], dim=0)
+        base = accum._base
+        if (base is not None and base.dim() == 2 and base.shape == (per * world, fpb) and base.is_contiguous()
+                and base.data_ptr() == accum.data_ptr()):
+            accum = base                       # engine.accumulate(row_multiple=world): the zeroed tail rows are already there
+        else:
+            pad = torch.zeros((per * world - n_bins, fpb), dtype=accum.dtype, device=accum.device)
+            accum = torch.cat([accum, pad], dim=0)
     lo = rank * per
     hi = min(lo + per, n_bins)
     if dist.get_backend(group) == "gloo":      # CPU tests / debug runs: gloo has no reduce_scatter
@@ -80,11 +85,14 @@ def gather_bins(shard_out, n_bins, dst=0, group=None):
     shard_out = shard_out.contiguous()
     if dist.get_backend(group) == "gloo" and shard_out.is_cuda:
         shard_out = shard_out.cpu()
-    parts = [torch.empty_like(shard_out) for _ in range(world)] if rank == dst else None
+    # the shards land in consecutive slices of ONE buffer on dst: no concatenation afterwards
+    full = torch.empty((world * shard_out.shape[0],) + tuple(shard_out.shape[1:]), dtype=shard_out.dtype,
+                       device=shard_out.device) if rank == dst else None
+    parts = list(full.split(shard_out.shape[0], dim=0)) if rank == dst else None
     dist.gather(shard_out, parts, dst=dst, group=group)
     if rank != dst:
         return None
-    return torch.cat(parts, dim=0)[:n_bins].to(dev)
+    return full[:n_bins].to(dev)
 
 
 def total_observations(local_n_obs, group=None):
@@ -146,7 +154,7 @@ def sharded_measures(spectra, planes, which, n_groups=4, dst=0, group=None, mark
 
     for g in range(n_groups):
         f0, f1 = shard_bounds(F, n_groups, g)
-        accum, n_obs = engine.accumulate(spectra.freq_slice(f0, f1), "trials_tapers", planes, mark=mark)
+        accum, n_obs = engine.accumulate(spectra.freq_slice(f0, f1), "trials_tapers", planes, mark=mark, row_multiple=world)
         n_bins = accum.shape[0]
         if world > 1:
             ready = torch.cuda.Event()
