@@ -295,26 +295,29 @@ __global__ void __launch_bounds__(256) nonlinear_f64_kernel(F64Args p) {
 // thread t pulls channel t & 127 (64 of the block's row range, 64 of its column range) of rows t >> 7, + 2, ...: whole
 // 2 KB runs, no division.
 #define F64B_OC 16
-template <uint32_t WHICH>
+template <uint32_t WHICH, bool DIAG>
 __global__ void __launch_bounds__(256, 2) nonlinear_f64_block_kernel(F64Args p) {
     static_assert(WHICH == SC_PLANE_ABS_IM || WHICH == SC_PLANE_IM_SQ || WHICH == SC_PLANE_SIGN_IM, "one plane per launch");
     extern __shared__ __align__(16) unsigned char f64_smem[];
     double2* lds = reinterpret_cast<double2*>(f64_smem);            // [2][F64B_OC][128]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int NB64 = (p.C + 63) >> 6, n_blk = NB64 * (NB64 + 1) / 2;
+    // diagonal blocks and off-diagonal blocks are separate launches (DIAG): their loop nests differ, and both in one
+    // kernel cost 300 spilled registers
+    const int NB64 = (p.C + 63) >> 6, n_blk = DIAG ? NB64 : NB64 * (NB64 - 1) / 2;
     const int id = blockIdx.x, xcd = id & 7, jj = id >> 3;
     const int blk = jj % n_blk;
     const int bin = (jj / n_blk) * 8 + xcd;
     if (bin >= p.n_bins) return;
     int BI = 0, BJ = 0;
-    { int rem = blk, len = NB64; while (rem >= len) { rem -= len; ++BI; --len; } BJ = BI + rem; }
+    if constexpr (DIAG) { BI = BJ = blk; }
+    else { int rem = blk, len = NB64 - 1; while (rem >= len) { rem -= len; ++BI; --len; } BJ = BI + 1 + rem; }
     const int g = bin / p.F, f = bin - g * p.F;
     const double2* base = p.base + (int64_t)f * p.ax.sF + sc_group_offset(p.ax, g);
     // staging: channel slot cs = tid & 127 (0-63: row range of the block, 64-127: its column range), rows tid >> 7 + 2 u
     const int cs = tid & 127, r0 = tid >> 7;
     const int cg = (cs < 64 ? BI * 64 + cs : BJ * 64 + (cs - 64));
-    const bool have = cg < p.C && (BI != BJ || cs < 64);          // a diagonal block reads its row range for both operands
+    const bool have = cg < p.C && (!DIAG || cs < 64);             // a diagonal block reads its row range for both operands
     double2 regs[F64B_OC / 2];
     auto fetch = [&](int o0) {
 #pragma unroll
@@ -331,7 +334,7 @@ __global__ void __launch_bounds__(256, 2) nonlinear_f64_block_kernel(F64Args p) 
 #pragma unroll
     for (int e = 0; e < 64; ++e) acc[e] = 0.0;
     const int li = lane >> 3, lj = lane & 7;
-    const int joff = BI == BJ ? 0 : 64;
+    constexpr int joff = DIAG ? 0 : 64;
     const int n_chunks = (p.n_obs + F64B_OC - 1) / F64B_OC;
     fetch(0);
     park(lds);
@@ -351,15 +354,31 @@ __global__ void __launch_bounds__(256, 2) nonlinear_f64_block_kernel(F64Args p) 
             for (int a = 0; a < 8; ++a) xi[a] = rp[li + 8 * a];
 #pragma unroll
             for (int b = 0; b < 8; ++b) xjv[b] = rp[joff + lj + 8 * b];
+            // A diagonal block needs i <= j only: with i = li + 8 a, j = lj + 8 b every pair of a sub-tile a > b lies below
+            // the diagonal -- 28 of a lane's 64 sub-tiles are skipped there (their mirror images are filled on the way out).
+            if constexpr (DIAG) {
 #pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                const double2 xj = xjv[b];
+                for (int b = 0; b < 8; ++b) {
+                    const double2 xj = xjv[b];
 #pragma unroll
-                for (int a = 0; a < 8; ++a) {
-                    const double imv = xi[a].y * xj.x - xi[a].x * xj.y;
-                    if constexpr (WHICH == SC_PLANE_ABS_IM) acc[a * 8 + b] += fabs(imv);
-                    else if constexpr (WHICH == SC_PLANE_IM_SQ) acc[a * 8 + b] = fma(imv, imv, acc[a * 8 + b]);
-                    else acc[a * 8 + b] += (imv > 0.0 ? 1.0 : 0.0) - (imv < 0.0 ? 1.0 : 0.0);
+                    for (int a = 0; a <= b; ++a) {
+                        const double imv = xi[a].y * xj.x - xi[a].x * xj.y;
+                        if constexpr (WHICH == SC_PLANE_ABS_IM) acc[a * 8 + b] += fabs(imv);
+                        else if constexpr (WHICH == SC_PLANE_IM_SQ) acc[a * 8 + b] = fma(imv, imv, acc[a * 8 + b]);
+                        else acc[a * 8 + b] += (imv > 0.0 ? 1.0 : 0.0) - (imv < 0.0 ? 1.0 : 0.0);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    const double2 xj = xjv[b];
+#pragma unroll
+                    for (int a = 0; a < 8; ++a) {
+                        const double imv = xi[a].y * xj.x - xi[a].x * xj.y;
+                        if constexpr (WHICH == SC_PLANE_ABS_IM) acc[a * 8 + b] += fabs(imv);
+                        else if constexpr (WHICH == SC_PLANE_IM_SQ) acc[a * 8 + b] = fma(imv, imv, acc[a * 8 + b]);
+                        else acc[a * 8 + b] += (imv > 0.0 ? 1.0 : 0.0) - (imv < 0.0 ? 1.0 : 0.0);
+                    }
                 }
             }
         }
@@ -388,10 +407,17 @@ __global__ void __launch_bounds__(256, 2) nonlinear_f64_block_kernel(F64Args p) 
     for (int a = 0; a < 8; ++a)
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
+            if (DIAG && a > b) continue;                  // not computed in a diagonal block (mirror image written below)
             const int i = BI * 64 + li + 8 * a, jx = BJ * 64 + lj + 8 * b;
             const int ti = i >> 4, tj = jx >> 4;
-            if (ti <= tj && tj < p.NB)
-                out[(int64_t)sc_tile_index(ti, tj, p.NB) * SC_TILE_ELEMS + (i & 15) * 16 + (jx & 15)] = acc[a * 8 + b];
+            if (ti <= tj && tj < p.NB) {
+                double* tile = out + (int64_t)sc_tile_index(ti, tj, p.NB) * SC_TILE_ELEMS;
+                tile[(i & 15) * 16 + (jx & 15)] = acc[a * 8 + b];
+                // the lower half of a diagonal 16 x 16 tile (no consumer reads it -- they mirror the upper half -- but it
+                // is not left uninitialised): |Im s| and (Im s)^2 are symmetric, sign(Im s) antisymmetric
+                if (DIAG && a < b && ti == tj)
+                    tile[(jx & 15) * 16 + (i & 15)] = (WHICH == SC_PLANE_SIGN_IM) ? -acc[a * 8 + b] : acc[a * 8 + b];
+            }
         }
 }
 
@@ -461,12 +487,15 @@ static int launch_nl_f64(const F64Args& a, hipStream_t st) {
 
 template <uint32_t WHICH>
 static int launch_nl_f64_block(const F64Args& a, hipStream_t st) {
-    const int NB64 = (a.C + 63) / 64, n_blk = NB64 * (NB64 + 1) / 2;
-    const unsigned grid = (unsigned)(((a.n_bins + 7) / 8) * 8 * n_blk);
+    const int NB64 = (a.C + 63) / 64, n_off = NB64 * (NB64 - 1) / 2;
+    const unsigned bins8 = (unsigned)(((a.n_bins + 7) / 8) * 8);
     const size_t shmem = (size_t)2 * F64B_OC * 128 * sizeof(double2);      // 64 KB (the final reduction needs 48 KB)
-    auto k = nonlinear_f64_block_kernel<WHICH>;
-    SC_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    hipLaunchKernelGGL(k, dim3(grid), dim3(256), shmem, st, a);
+    auto kd = nonlinear_f64_block_kernel<WHICH, true>;
+    auto ko = nonlinear_f64_block_kernel<WHICH, false>;
+    SC_CHECK_HIP(hipFuncSetAttribute((const void*)kd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    SC_CHECK_HIP(hipFuncSetAttribute((const void*)ko, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    if (n_off > 0) hipLaunchKernelGGL(ko, dim3(bins8 * n_off), dim3(256), shmem, st, a);
+    hipLaunchKernelGGL(kd, dim3(bins8 * NB64), dim3(256), shmem, st, a);
     SC_CHECK_HIP(hipGetLastError());
     return SC_OK;
 }
