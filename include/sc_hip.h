@@ -229,9 +229,9 @@ int sc_fused_csm_absim_ws_f32(const void* d_X /*float2*/, const sc_spectra_desc*
 /* SC_PLANE_UNIT of the record, sum over observations of s/|s| (phase_locking_value,
  * pairwise_phase_consistency: connectivity.py:897-981), through the same kernels: s/|s| factorises into
  * (x_i/|x_i|) conj(x_j/|x_j|), so the sum is the cross-spectral matrix of the unit phasors x/|x|
- * (0/0 -> NaN like the reference's x/abs(x)).  Up to 42 channels the normalisation happens while the
- * rows are staged; above, a normalised copy of the spectra goes to d_scratch first
- * (sc_fused_unit_scratch_bytes, 0 when none is needed).  Shapes, workspace and split as above. */
+ * (0/0 -> NaN like the reference's x/abs(x)).  The normalisation happens while the rows are staged, in both kernels:
+ * no copy of the spectra, d_scratch / scratch_bytes are ignored and sc_fused_unit_scratch_bytes returns 0 (both kept
+ * for ABI v2 callers).  Shapes, workspace and split as above. */
 /* SC_PLANE_UNIT for shapes the one-pass kernels do not take (odd channel counts without a pad channel): a normalised copy of the
  * spectra (x/|x|, 0 -> NaN) in d_scratch (sc_unit_scratch_bytes) goes through the f32-MFMA CSM kernel. */
 int64_t sc_unit_scratch_bytes(const sc_spectra_desc* desc);

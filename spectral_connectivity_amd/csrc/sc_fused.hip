@@ -159,8 +159,13 @@ __device__ __forceinline__ void fu_fetch(const ScStage& st, const FuMap& mp, flo
 // lane l stages channel pair l of the wave's four rows.  Half of each 16-lane group takes the even
 // channel of its pair first and the other half the odd one: the 8-byte raw reads and the 8-byte plane
 // writes (channel stride 18 dwords) then touch every LDS bank exactly once.
-template <int NB32>
-__device__ __forceinline__ void fu_split(const float* raw, unsigned short* planes, int vw) {
+// UNIT: the rows are normalised to unit phasors x / |x| on the way (phase_locking_value, pairwise_phase_consistency:
+// the sum of s / |s| is the cross-spectral matrix of the unit phasors) -- rsq + two multiplies per coefficient on the
+// staging waves instead of a normalised copy of the spectra in HBM.  0 / 0 is NaN like the reference's; zero-filled rows
+// past n_obs (rows_valid) and slots of absent channels stay zero.
+template <int NB32, bool UNIT = false>
+__device__ __forceinline__ void fu_split(const float* raw, unsigned short* planes, int vw, const FuMap* mp = nullptr,
+                                         int rows_valid = FU_OC) {
     const int lane = fu_lane();
     constexpr int CP = NB32 * 32;                  // channels staged (C rounded up to 32)
     if (2 * lane >= CP) return;
@@ -173,6 +178,18 @@ __device__ __forceinline__ void fu_split(const float* raw, unsigned short* plane
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             v[t][k] = *reinterpret_cast<const float2*>(raw + (4 * vw + k) * FU_RAW_ROW + 4 * lane + 2 * (first ^ t));
+    if constexpr (UNIT) {
+        const int c = 2 * lane;                                     // (both channels of a pair exist or neither: even counts)
+        const bool have = lane < 32 ? c < mp->n0 : c - 64 < mp->n1;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (have && 4 * vw + k < rows_valid) {
+                    const float ia = rsqrtf(v[t][k].x * v[t][k].x + v[t][k].y * v[t][k].y);
+                    v[t][k].x *= ia; v[t][k].y *= ia;
+                }
+    }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         float re[4], im[4];
@@ -193,7 +210,7 @@ __device__ __forceinline__ void fu_split(const float* raw, unsigned short* plane
 
 // Prologue of a staging wave (quad vw): clear its raw rows (slots of absent channels stay zero for
 // good), fetch and stage chunk 0, put chunk 1 in flight.
-template <int NB32>
+template <int NB32, bool UNIT = false>
 __device__ __forceinline__ void fu_stage_first(const ScStage& st, const FuMap& mp, float* raw, unsigned short* planes, int vw,
                                                int o_lo, int n_chunks, bool loads) {
 #pragma unroll
@@ -202,19 +219,19 @@ __device__ __forceinline__ void fu_stage_first(const ScStage& st, const FuMap& m
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     fu_fetch(st, mp, raw, o_lo, vw);   // (debug "no HBM loads" keeps re-using this chunk: realistic operand values)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    fu_split<NB32>(raw, planes, vw);
+    fu_split<NB32, UNIT>(raw, planes, vw, &mp, st.n_obs - o_lo);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (n_chunks > 1 && loads) fu_fetch(st, mp, raw, o_lo + FU_OC, vw);
 }
 
 // Stage chunk ch + 1 into the other plane buffer, then put the loads of chunk ch + 2 in flight.
-template <int NB32>
+template <int NB32, bool UNIT = false>
 __device__ __forceinline__ void fu_stage_next(const ScStage& st, const FuMap& mp, float* raw, unsigned short* planes, int vw,
                                               int o_lo, int ch, int n_chunks, bool loads) {
     constexpr int buf_elems = NB32 * 32 * FU_CSTRIDE;
     if (ch + 1 < n_chunks) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // raw rows of chunk ch + 1 landed
-        fu_split<NB32>(raw, planes + ((ch + 1) & 1) * buf_elems, vw);
+        fu_split<NB32, UNIT>(raw, planes + ((ch + 1) & 1) * buf_elems, vw, &mp, st.n_obs - (o_lo + (ch + 1) * FU_OC));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // raw rows read before the refill
         if (ch + 2 < n_chunks && loads) fu_fetch(st, mp, raw, o_lo + (ch + 2) * FU_OC, vw);
     }
@@ -250,7 +267,7 @@ __device__ __forceinline__ bf16x8 fu_ld8(const unsigned short* ptr) {
 #define FU_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 #define FU_MFMA(a, b, c) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
-enum { FU_OP_ABS = 0, FU_OP_SQ = 1, FU_OP_SIGN = 2 };
+enum { FU_OP_ABS = 0, FU_OP_SQ = 1, FU_OP_SIGN = 2, FU_OP_UNIT = 3 };     // UNIT: CSM role only, rows normalised at staging
 
 static_assert(2 * 4 + 1 <= FU_FLUSH, "one fold slot per tile of a wave");
 // The two roles are separate functions so their accumulators never coexist in registers.
@@ -477,7 +494,7 @@ __device__ __forceinline__ FuFragB fu_frag_b(unsigned h, unsigned m, unsigned l,
 // acc <- acc (+) f(d) for one output register of a 32x32 block: |d| (wPLI weights), d^2 (debiased wPLI), sign(d) (PLI)
 template <int OP>
 __device__ __forceinline__ float fu_accumulate(float acc, float d) {
-    if constexpr (OP == FU_OP_ABS) return acc + fabsf(d);
+    if constexpr (OP == FU_OP_ABS || OP == FU_OP_UNIT) return acc + fabsf(d);
     else if constexpr (OP == FU_OP_SQ) return fmaf(d, d, acc);
     else {
         // sign(d) in {-1, 0, 1} summed as an INTEGER in the accumulator's bits: the bit pattern of a float orders like a
@@ -531,11 +548,12 @@ __device__ __forceinline__ void fused_valu_body(const FusedArgs& p, const ScStag
     // with the |Im| plane: abs waves 0-3 stage quads 4-7 (the CSM waves take 0-3); CSM only: all eight stage
     const bool all_stage = p.abs_plane < 0;
     const int my_quad = all_stage ? vw : 4 + vw;
-    if (vw < 4 || all_stage) fu_stage_first<NB32>(st, p.map, raw, planes, my_quad, o_lo, n_chunks, loads);
+    constexpr bool UNIT = OP == FU_OP_UNIT;
+    if (vw < 4 || all_stage) fu_stage_first<NB32, UNIT>(st, p.map, raw, planes, my_quad, o_lo, n_chunks, loads);
     FU_BARRIER();                 // chunk 0 staged
     FU_T0();
     for (int ch = 0; ch < n_chunks; ++ch) {
-        if (vw < 4 || all_stage) fu_stage_next<NB32>(st, p.map, raw, planes, my_quad, o_lo, ch, n_chunks, loads);
+        if (vw < 4 || all_stage) fu_stage_next<NB32, UNIT>(st, p.map, raw, planes, my_quad, o_lo, ch, n_chunks, loads);
         FU_TICK(0);
         const unsigned short* pb = planes + (ch & 1) * buf_elems;
         // per-lane plane triples: A reads Im (lanes 0-31) / Re (32-63), B reads Re (lanes 0-31) / Im (32-63)
@@ -726,7 +744,7 @@ __global__ void __launch_bounds__(256) planes_combine_kernel(FusedArgs p) {
 
 static int launch_fused_combine(const FusedArgs& a, int op, hipStream_t stream) {
     if (a.n_split > 1) {
-        if (op == FU_OP_ABS) hipLaunchKernelGGL(fused_combine_kernel, dim3(2048), dim3(256), 0, stream, a);
+        if (op == FU_OP_ABS || op == FU_OP_UNIT) hipLaunchKernelGGL(fused_combine_kernel, dim3(2048), dim3(256), 0, stream, a);
         else hipLaunchKernelGGL(planes_combine_kernel, dim3(2048), dim3(256), 0, stream, a);     // one plane: a.fold
         SC_CHECK_HIP(hipGetLastError());
     }
@@ -753,12 +771,14 @@ static int launch_fused(const FusedArgs& a, int op, hipStream_t stream, bool com
     if (a.map.cross) {      // the tiles between two 64-channel quarters: always the full 128 staged slots
         if (op == FU_OP_SQ) return launch_fused_op<4, FU_OP_SQ, true>(a, combine, stream);
         if (op == FU_OP_SIGN) return launch_fused_op<4, FU_OP_SIGN, true>(a, combine, stream);
+        if (op == FU_OP_UNIT) return launch_fused_op<4, FU_OP_UNIT, true>(a, combine, stream);
         return launch_fused_op<4, FU_OP_ABS, true>(a, combine, stream);
     }
 #define FU_CASE(NB32)                                                             \
     case NB32:                                                                    \
         if (op == FU_OP_SQ) return launch_fused_op<NB32, FU_OP_SQ, false>(a, combine, stream);    \
         if (op == FU_OP_SIGN) return launch_fused_op<NB32, FU_OP_SIGN, false>(a, combine, stream); \
+        if (op == FU_OP_UNIT) return launch_fused_op<NB32, FU_OP_UNIT, false>(a, combine, stream); \
         return launch_fused_op<NB32, FU_OP_ABS, false>(a, combine, stream);
     switch (a.NB32) {
         FU_CASE(1)
@@ -959,15 +979,6 @@ static int launch_small(const FusedArgs& a_in, bool normalize, hipStream_t strea
     return SC_OK;
 }
 
-// U = X / |X| elementwise (0 -> NaN), the input of the unit-phasor accumulation on the matrix-core path
-__global__ void __launch_bounds__(256) unit_normalize_kernel(const float4* __restrict__ X, float4* __restrict__ U, int64_t n4) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        const float4 v = X[i];
-        const float ia = rsqrtf(v.x * v.x + v.y * v.y), ib = rsqrtf(v.z * v.z + v.w * v.w);
-        U[i] = make_float4(v.x * ia, v.y * ia, v.z * ib, v.w * ib);
-    }
-}
-
 // d_X may be NULL when only the shape is known: alignment is then assumed.
 static bool fused_ok(const void* d_X, const ScAxes& ax) {
     if (ax.C < 1 || ax.C > 256 || (ax.C & 1)) return false;
@@ -1126,12 +1137,6 @@ extern "C" int64_t sc_fused_workspace_bytes(const sc_spectra_desc* desc, uint32_
     return (int64_t)(S - 1) * a.n_bins * a.floats_per_bin * (int64_t)sizeof(float);
 }
 
-// elements (float2) from the base pointer to the end of the last row the descriptor addresses
-static int64_t fused_span(const ScAxes& ax) {
-    return (int64_t)(ax.F - 1) * ax.sF + (int64_t)(ax.W - 1) * ax.sW + (int64_t)(ax.R - 1) * ax.sR +
-           (int64_t)(ax.K - 1) * ax.sK + ax.C;
-}
-
 static int fused_run(const void* d_X, const sc_spectra_desc* desc, uint32_t planes, int mode, float* d_accum,
                      void* d_workspace, int64_t workspace_bytes, void* d_scratch, int64_t scratch_bytes, void* stream) {
     ScTimed timed_("fused_stage_b", stream);
@@ -1176,17 +1181,10 @@ static int fused_run(const void* d_X, const sc_spectra_desc* desc, uint32_t plan
         b.n_fold = 1;
         return launch_fused_all(b, FU_OP_SIGN, s);
     }
-    if (unit) {
-        // the matrix-core kernel takes its rows straight from HBM into LDS: normalise a copy of the spectra first
-        const int64_t span = fused_span(ax);
-        SC_REQUIRE(d_scratch && scratch_bytes >= span * 8 && ((uintptr_t)d_scratch % 16) == 0,
-                   "unit-phasor accumulation above 42 channels needs sc_fused_unit_scratch_bytes() of 16-byte aligned scratch");
-        const int64_t n4 = (span + 1) / 2;
-        hipLaunchKernelGGL(unit_normalize_kernel, dim3(4096), dim3(256), 0, s, (const float4*)d_X, (float4*)d_scratch, n4);
-        SC_CHECK_HIP(hipGetLastError());
-        a.st.base = (const float2*)d_scratch;
-    }
-    const int rc_main = launch_fused_all(a, FU_OP_ABS, s);
+    // unit phasors (PLV / PPC): the staging waves normalise the rows on the way into LDS (FU_OP_UNIT) -- no normalised
+    // copy of the spectra, no scratch (d_scratch / scratch_bytes are accepted and ignored)
+    (void)d_scratch; (void)scratch_bytes;
+    const int rc_main = launch_fused_all(a, unit ? FU_OP_UNIT : FU_OP_ABS, s);
     if (rc_main != SC_OK || a.sq_plane < 0) return rc_main;
     // debiased wPLI: sum (Im s)^2 as a second pass of the same kernel (the abs waves hold 80 accumulator registers
     // per plane; two planes do not fit next to the matrix-core role's)
@@ -1224,11 +1222,10 @@ extern "C" int sc_fused_sign_ws_f32(const void* d_X, const sc_spectra_desc* desc
     return fused_run(d_X, desc, planes, FU_MODE_SIGN, d_accum, d_workspace, workspace_bytes, nullptr, 0, stream);
 }
 
-// Scratch sc_fused_unit_ws_f32 needs for this shape: a normalised copy of the spectra above 42 channels, else none.
+// Scratch sc_fused_unit_ws_f32 needs for this shape: none since the rows are normalised at staging (kept for ABI v2).
 extern "C" int64_t sc_fused_unit_scratch_bytes(const sc_spectra_desc* desc) {
-    ScAxes ax;
-    if (!desc || sc_make_axes(desc, &ax) != SC_OK || !fused_ok(nullptr, ax) || ax.C <= 42) return 0;
-    return ((fused_span(ax) + 1) / 2) * 16;
+    (void)desc;
+    return 0;
 }
 
 // SC_PLANE_UNIT of the record: sum over observations of s / |s| = x_i conj(x_j) / (|x_i| |x_j|), i.e. the cross-

@@ -755,3 +755,29 @@ def test_multi_measure_epilogue_equals_single_launches(sc):
         # complex measures and power fall back to one launch each
         mixed = engine.measure_multi(accum, C, planes, n_obs, [_lib.M_COHERENCY, _lib.M_WPLI])
         assert mixed[0].is_complex() and not mixed[1].is_complex()
+
+
+@pytest.mark.parametrize("C", [48, 64, 128, 160])
+def test_unit_phasor_plane_with_split_bins(sc, C):
+    """PLV / PPC above the small-channel kernel: the staging waves of the matrix-core kernel normalise the rows to unit
+    phasors on the way into LDS.  Few bins and many observations, so every bin is split over several workgroups (partial
+    records folded by the combine kernel): against a float64 contraction of the same spectra on the device, with a zero
+    coefficient (0 / 0 = NaN like the reference) in one channel of one observation."""
+    import torch
+    from spectral_connectivity_amd import _lib, engine
+    F, W, R, K = 5, 2, 700, 3
+    g = torch.Generator(device="cuda").manual_seed(C)
+    X = torch.view_as_complex(torch.randn((F, W, R, K, C, 2), generator=g, dtype=torch.float32, device="cuda"))
+    X[1, 0, 3, 1, 5] = 0
+    sp = engine.DeviceSpectra(X, (F, W, R, K, C), (W * R * K * C, R * K * C, K * C, C), 8, True, C_alloc=C)
+    planes = _lib.PLANE_UNIT
+    accum, n_obs = engine.accumulate(sp, "trials_tapers", planes)
+    plv = engine.measure(accum, C, planes, n_obs, _lib.M_PLV).cpu().numpy().reshape(W, F, C, C)
+    Xd = X.to(torch.complex128)
+    U = Xd / Xd.abs()
+    ref = torch.einsum("fwrkc,fwrkd->wfcd", U, U.conj()).abs().cpu().numpy() / n_obs
+    bad = np.isnan(ref)
+    assert bad[0, 1, 5, :].all() and bad[0, 1, :, 5].all() and bad.sum() == 2 * C - 1
+    assert np.array_equal(np.isnan(plv), bad)
+    off = ~np.eye(C, dtype=bool)
+    np.testing.assert_allclose(plv[:, :, off][~bad[:, :, off]], ref[:, :, off][~bad[:, :, off]], rtol=3e-5, atol=3e-6)
