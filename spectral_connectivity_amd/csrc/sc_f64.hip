@@ -48,14 +48,22 @@ __device__ __forceinline__ F64Walk f64_walk(const F64Args& p, int tid) {
     w.dq = 256 / p.CP; w.dr = 256 - w.dq * p.CP;
     return w;
 }
-template <int E>
+// UNIT: the coefficient is replaced by its unit phasor x / |x| (0 / 0 = NaN like the reference's x / abs(x)); the zero
+// fill of rows past n_obs and of absent channels stays zero
+template <int E, bool UNIT = false>
 __device__ __forceinline__ void f64_load(const F64Args& p, const F64Walk& w, const double2* base, int o0, double2 (&r)[E]) {
     int row = w.row0, c = w.c0;
 #pragma unroll
     for (int i = 0; i < E; ++i) {
         double2 v = make_double2(0.0, 0.0);
         const int o = o0 + row;
-        if (row < E && o < p.n_obs && c < p.C) v = base[f64_obs_offset(p, o) + c];
+        if (row < E && o < p.n_obs && c < p.C) {
+            v = base[f64_obs_offset(p, o) + c];
+            if constexpr (UNIT) {
+                const double ia = 1.0 / sqrt(v.x * v.x + v.y * v.y);
+                v = make_double2(v.x * ia, v.y * ia);
+            }
+        }
         r[i] = v;
         row += w.dq; c += w.dr;
         if (c >= p.CP) { c -= p.CP; ++row; }
@@ -70,7 +78,7 @@ __device__ __forceinline__ void f64_store(const F64Args& p, double2* lds, int ti
     }
 }
 
-template <int MAX_SLOTS, int E>
+template <int MAX_SLOTS, int E, bool UNIT>
 __global__ void __launch_bounds__(256, MAX_SLOTS <= 9 ? 2 : 1) csm_f64_kernel(F64Args p) {
     extern __shared__ __align__(16) unsigned char f64_smem[];
     double2* lds = reinterpret_cast<double2*>(f64_smem);
@@ -102,7 +110,7 @@ __global__ void __launch_bounds__(256, MAX_SLOTS <= 9 ? 2 : 1) csm_f64_kernel(F6
     const int n_chunks = (p.n_obs + E - 1) / E;
     const F64Walk walk = f64_walk(p, tid);
     double2 regs[E];
-    f64_load<E>(p, walk, base, 0, regs);
+    f64_load<E, UNIT>(p, walk, base, 0, regs);
     f64_store<E>(p, lds, tid, regs);
     __syncthreads();
     // A operand: lane l holds A[i = l & 15][k = l >> 4]; B operand: B[k = l >> 4][j = l & 15]  (one f64 each)
@@ -111,7 +119,7 @@ __global__ void __launch_bounds__(256, MAX_SLOTS <= 9 ? 2 : 1) csm_f64_kernel(F6
         const double2* cur = lds + (ch & 1) * buf;
         double2* nxt = lds + ((ch + 1) & 1) * buf;
         const bool more = ch + 1 < n_chunks;
-        if (more) f64_load<E>(p, walk, base, (ch + 1) * E, regs);
+        if (more) f64_load<E, UNIT>(p, walk, base, (ch + 1) * E, regs);
         // operands of slot s + 1 are requested before the four MFMAs of slot s are issued (left to itself the compiler
         // reloads one register pair per slot and waits for it: an LDS round trip between every two groups of MFMAs)
         constexpr int NSTEP = (E / 4) * MAX_SLOTS;
@@ -459,13 +467,13 @@ static int f64_setup(const void* d_X, const sc_spectra_desc* desc, uint32_t plan
     return SC_OK;
 }
 
-template <int MAX_SLOTS>
+template <int MAX_SLOTS, bool UNIT = false>
 static int launch_csm_f64(F64Args a, hipStream_t st) {
     a.n_groups_of_tiles = (a.n_tiles + 4 * MAX_SLOTS - 1) / (4 * MAX_SLOTS);
     const unsigned grid = (unsigned)(((a.n_bins + 7) / 8) * 8 * a.n_groups_of_tiles);
     constexpr int OC = 8;          // observation rows per staged chunk: 8 registers of staging, two workgroups per CU
     const size_t shmem = (size_t)2 * OC * a.CP * sizeof(double2);
-    auto k = csm_f64_kernel<MAX_SLOTS, OC>;
+    auto k = csm_f64_kernel<MAX_SLOTS, OC, UNIT>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), shmem, st, a);
     SC_CHECK_HIP(hipGetLastError());
@@ -558,7 +566,19 @@ extern "C" int sc_accumulate_f64(const void* d_X, const sc_spectra_desc* desc, u
         if (w & SC_PLANE_ABS_IM) { if ((rc = launch_nl_f64<SC_PLANE_ABS_IM, 3>(a, st))) break; }
         if (w & SC_PLANE_IM_SQ) { if ((rc = launch_nl_f64<SC_PLANE_IM_SQ, 3>(a, st))) break; }
         if (w & SC_PLANE_SIGN_IM) { if ((rc = launch_nl_f64<SC_PLANE_SIGN_IM, 3>(a, st))) break; }
-        if (w & SC_PLANE_UNIT) { if ((rc = launch_nl_f64<SC_PLANE_UNIT, 2>(a, st))) break; }
+        if (w & SC_PLANE_UNIT) {
+            // sum s / |s| = the cross-spectral matrix of the unit phasors x / |x|: the matrix-core kernel with the
+            // normalisation in its staging (per pair and observation on the VALU -- square root and two divisions in
+            // fp64 -- it took 130 ms at cfg3 against 9 for the CSM)
+            F64Args u = a;
+            u.plane = sc_plane_offset(planes, SC_PLANE_UNIT);
+            const int need = (u.n_tiles + 3) / 4;
+            if (need <= 1) rc = launch_csm_f64<1, true>(u, st);
+            else if (need <= 3) rc = launch_csm_f64<3, true>(u, st);
+            else if (need <= 5) rc = launch_csm_f64<5, true>(u, st);
+            else rc = launch_csm_f64<9, true>(u, st);
+            if (rc) break;
+        }
     } while (0);
     if (fork) {
         SC_CHECK_HIP(hipEventRecord(ev_join, side));
