@@ -163,8 +163,18 @@ class Connectivity:
             if isinstance(have, int) and have & planes == planes:
                 return have, rec
         sp = self._device()
-        accum, n_obs = engine.accumulate(sp, self.expectation_type, planes, n_freq=self._n_freq)
+        have = None
+        if sp.f64 and self._reduce_over_ranks.__func__ is Connectivity._reduce_over_ranks:
+            # float64 engine, single process: families a cached record already holds are copied, not recomputed
+            best = max((h for h in self._accum_cache if isinstance(h, int) and h & planes), key=lambda h: bin(h & planes).count("1"),
+                       default=None)
+            if best is not None:
+                planes |= best                     # the new record supersedes the old one
+                have = (best, self._accum_cache[best][0])
+        accum, n_obs = engine.accumulate(sp, self.expectation_type, planes, n_freq=self._n_freq, have=have)
         accum = self._reduce_over_ranks(accum)
+        if have is not None:
+            del self._accum_cache[have[0]]
         self._accum_cache[planes] = (accum, n_obs)
         return planes, (accum, n_obs)
 

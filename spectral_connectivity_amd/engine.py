@@ -276,17 +276,45 @@ def _record_tensor(n_bins, fpb, dtype, device, row_multiple):
     return full[:n_bins]
 
 
-def accumulate(spectra, expectation_type, planes, n_freq=None, mark=None, use_fused=None, row_multiple=1):
+_PLANE_WIDTH = ((_lib.PLANE_CSM, 2), (_lib.PLANE_ABS_IM, 1), (_lib.PLANE_IM_SQ, 1), (_lib.PLANE_SIGN_IM, 1),
+                (_lib.PLANE_UNIT, 2))          # record order and planes per family (sc_common.h: sc_plane_offset)
+
+
+def plane_slots(planes):
+    """{family bit: (first plane index, n planes)} of a record with the families ``planes``."""
+    out, n = {}, 0
+    for bit, width in _PLANE_WIDTH:
+        if planes & bit:
+            out[bit] = (n, width)
+            n += width
+    return out
+
+
+def accumulate(spectra, expectation_type, planes, n_freq=None, mark=None, use_fused=None, row_multiple=1, have=None):
     """Stage B: un-normalised accumulator record tensor [n_bins, floats_per_bin] (float32; float64 records from
-    complex128 spectra).  ``row_multiple``: see _record_tensor (trial-sharded callers pass the world size)."""
+    complex128 spectra).  ``row_multiple``: see _record_tensor (trial-sharded callers pass the world size).
+    ``have`` = (planes_old, record_old), float64 engine only: families already accumulated for the same spectra and
+    expectation are copied over (a strided device copy) and only the missing ones are computed -- its CSM and
+    per-observation planes are separate kernels, so a wPLI after a coherence costs the |Im s| plane alone."""
     lib = _lib.load()
     d = spectra.desc(expectation_type, n_freq)
     n_bins, fpb, _, n_obs = accum_layout(spectra, expectation_type, planes, n_freq)
     if spectra.f64:
         # float64 engine: fp64 matrix cores for the CSM planes, fp64 VALU for the others, double records
         accum = _record_tensor(n_bins, fpb, torch.float64, spectra.X.device, row_multiple)
-        _lib.check(lib.sc_accumulate_f64(_ptr(spectra.X), byref(d), planes, planes, _ptr(accum), _stream()),
-                   "sc_accumulate_f64")
+        which = planes
+        if have is not None and have[1].dtype == torch.float64 and have[1].shape[0] == n_bins and (have[0] & planes):
+            old_planes, old = have
+            new_slots, old_slots = plane_slots(planes), plane_slots(old_planes)
+            n_new, n_old = sum(w for _, w in new_slots.values()), sum(w for _, w in old_slots.values())
+            new_v, old_v = accum.view(n_bins, n_new, fpb // n_new), old.view(n_bins, n_old, old.shape[1] // n_old)
+            for bit, (i_new, width) in new_slots.items():
+                if bit in old_slots:
+                    new_v[:, i_new:i_new + width].copy_(old_v[:, old_slots[bit][0]:old_slots[bit][0] + width])
+                    which &= ~bit
+        if which:
+            _lib.check(lib.sc_accumulate_f64(_ptr(spectra.X), byref(d), planes, which, _ptr(accum), _stream()),
+                       "sc_accumulate_f64")
         if mark:
             mark("accumulate_f64")
         return accum, n_obs

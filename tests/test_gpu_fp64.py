@@ -345,3 +345,25 @@ def test_canonical_coherence_large_groups_float64(sc, sizes):
     ref, _ = so.canonical_coherence(coef, labels)
     got, _ = sc.Connectivity.from_multitaper(sc.Multitaper(x, **kw)).canonical_coherence(labels)
     close64(got, ref, rtol=1e-7, floor=1e-9, what=f"canonical coherence, groups {sizes}")
+
+
+def test_incremental_records_equal_fresh_ones(sc):
+    """float64 engine: a measure asked for after others re-uses the record families already accumulated (copied into the
+    wider record) and computes only the missing ones -- bit for bit what a fresh Connectivity returns."""
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal((256, 30, 70))
+    x[:, :, 1:] += 0.4 * x[:, :, :-1]
+    kw = dict(sampling_frequency=200.0, time_halfbandwidth_product=2, n_time_samples_per_window=64)
+    order = ["coherence_magnitude", "weighted_phase_lag_index", "phase_locking_value", "debiased_squared_weighted_phase_lag_index",
+             "phase_lag_index", "power", "pairwise_phase_consistency"]
+    c = sc.Connectivity.from_multitaper(sc.Multitaper(x, **kw))
+    for name in order:
+        got = getattr(c, name)()
+        fresh = getattr(sc.Connectivity.from_multitaper(sc.Multitaper(x, **kw)), name)()
+        assert np.array_equal(np.nan_to_num(got, nan=-7.0), np.nan_to_num(fresh, nan=-7.0)), name
+    ints = [k for k in c._accum_cache if isinstance(k, int)]
+    union = 0
+    for k in ints:
+        assert union & k == 0, ints                 # no family is held (or was computed) twice
+        union |= k
+    assert bin(union).count("1") == 5, ints
