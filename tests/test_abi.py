@@ -1,6 +1,5 @@
 """CPU-only checks of the drop-in boundary: libsc_hip.so loads and exports every symbol that
 include/sc_hip.h declares; argument validation works without a GPU (no compute calls)."""
-import ctypes
 import os
 import re
 from ctypes import byref, c_int64

@@ -1,7 +1,6 @@
 """Profiling aid (GPU box): per-wave phase timers of the fused stage-B kernel (library rebuilt with -DFU_TRACE)."""
 import ctypes
 import os
-import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,7 +1,6 @@
 """Profiling aid (GPU box): phase timers of the fused window/taper/FFT kernel (library rebuilt with -DMT_TRACE)."""
 import ctypes
 import os
-import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -4,7 +4,6 @@ import hashlib
 import json
 import os
 import re
-import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 F = os.path.join(ROOT, "gpurun_out", "r02")
