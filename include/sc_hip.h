@@ -143,6 +143,13 @@ int sc_taper_windows_f64(const double* d_x, int64_t T, int64_t R, int64_t C,
                          const double* d_tapers, int64_t K, int detrend_type,
                          double* d_y, void* stream);
 
+/* float64 time series [T][R][C] -> the float32 copy [T][R][C_out] the float32 engine transforms (C_out >= C: channels
+ * beyond C are zero, the pad channel of odd counts).  remove_mean != 0 subtracts the per-(trial, channel) mean over time
+ * in float64 BEFORE the cast -- every window's detrend (transforms.py:1798-1915) removes any constant anyway, so only the
+ * rounding changes: a DC offset many times the signal no longer costs the float32 copy its digits. */
+int sc_timeseries_to_f32(const double* d_x, int64_t T, int64_t R, int64_t C, int remove_mean, float* d_y,
+                         int64_t C_out, void* stream);
+
 /* ---- stage A: batched real-to-complex FFT (rocFFT) -----------------------------------
  * Replaces fft(projected, n=N, axis=-2) of transforms.py:1405 (scipy.fft / cupyx.scipy.fft).
  * Input  y[batch][N] float (the rows sc_taper_windows_f32 writes), output X[F][batch] float2

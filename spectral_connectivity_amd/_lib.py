@@ -71,6 +71,7 @@ SYMBOLS = {
     "sc_fft_twiddles_f32": (c_int, [c_int64, c_void_p, c_void_p]),
     "sc_multitaper_fft_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64,
                                       c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
+    "sc_timeseries_to_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p]),
     "sc_multitaper_fft_f64_supported": (c_int, [c_int64, c_int64]),
     "sc_multitaper_fft_f64": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64,
                                       c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p]),

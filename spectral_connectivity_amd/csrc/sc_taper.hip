@@ -119,3 +119,43 @@ extern "C" int sc_taper_windows_f64(const double* d_x, int64_t T, int64_t R, int
                                     int64_t K, int detrend_type, double* d_y, void* stream) {
     return taper_windows<double>(d_x, T, R, C, L, step, W, N, d_tapers, K, detrend_type, d_y, stream);
 }
+
+// ---- float64 time series -> the float32 copy the float32 engine transforms ------------------------------------------
+// y[t][r][c] = (float)(x[t][r][c] - m[r][c]), m = the mean over time in fp64 when remove_mean (every window's own detrend
+// removes any constant, so taking one out BEFORE the cast changes nothing but the rounding: a DC offset 1e5 times the signal
+// -- raw EEG / MEG -- would otherwise cost the float32 copy all but two digits of the signal); channels C ... C_out - 1 of
+// y are zero (the pad channel of odd channel counts).  One thread per (trial, channel): the loads of a wave are one
+// contiguous run per time step; x is read twice (2 x 8 bytes per sample: 0.7 ms for 1 GB).
+__global__ void __launch_bounds__(256) timeseries_to_f32_kernel(const double* __restrict__ x, float* __restrict__ y, int64_t T,
+                                                                int64_t R, int64_t C, int64_t C_out, int remove_mean, int t_split) {
+    const int64_t rc = (int64_t)blockIdx.x * 256 + threadIdx.x;          // (trial, output channel)
+    if (rc >= R * C_out) return;
+    const int64_t r = rc / C_out, c = rc - r * C_out;
+    const int64_t t0 = (int64_t)blockIdx.y * T / t_split, t1 = (int64_t)(blockIdx.y + 1) * T / t_split;
+    if (c >= C) {
+        for (int64_t t = t0; t < t1; ++t) y[(t * R + r) * C_out + c] = 0.f;
+        return;
+    }
+    double m = 0.0;
+    if (remove_mean) {
+        for (int64_t t = 0; t < T; ++t) m += x[(t * R + r) * C + c];      // every time slice sums the whole series: same mean
+        m /= (double)T;
+    }
+    for (int64_t t = t0; t < t1; ++t) y[(t * R + r) * C_out + c] = (float)(x[(t * R + r) * C + c] - m);
+}
+
+extern "C" int sc_timeseries_to_f32(const double* d_x, int64_t T, int64_t R, int64_t C, int remove_mean, float* d_y,
+                                    int64_t C_out, void* stream) {
+    ScTimed timed_("timeseries_to_f32", stream);
+    SC_REQUIRE(d_x && d_y, "NULL device pointer");
+    SC_REQUIRE(T >= 1 && R >= 1 && C >= 1 && C_out >= C, "bad dimensions");
+    const int64_t blocks = (R * C_out + 255) / 256;
+    SC_REQUIRE(blocks < (int64_t)1 << 31, "too many (trial, channel) series for one launch");
+    // few series (a handful of trials x channels): the time axis is cut into slices so that the launch still fills the chip
+    int t_split = 1;
+    while (blocks * t_split < 512 && t_split * 64 <= T && t_split < 64) t_split *= 2;      // (every slice re-reads the series for the mean)
+    hipLaunchKernelGGL(timeseries_to_f32_kernel, dim3((unsigned)blocks, (unsigned)t_split), dim3(256), 0, (hipStream_t)stream,
+                       d_x, d_y, T, R, C, C_out, remove_mean, t_split);
+    SC_CHECK_HIP(hipGetLastError());
+    return SC_OK;
+}

@@ -528,27 +528,26 @@ class Multitaper:
                     self.n_fft_samples, self.n_time_windows, self.detrend_type)
             else:
                 ts = np.asarray(self.time_series)
-                offset = False
-                if self.detrend_type is not None and ts.dtype == np.float64 and ts.size:
-                    # Every window's own detrend removes any constant, so one per (trial, signal) may be taken out in
-                    # float64 BEFORE the cast: a DC offset 1e5 times the signal (raw EEG / MEG) would otherwise cost the
-                    # float32 copy all but two digits of the signal.  (detrend_type None keeps the samples as given.)
-                    # Decided on 64 evenly spaced samples: an offset below 16 standard deviations costs the cast nothing
-                    # that matters (1e-6 of the signal) and the two extra passes over the data are skipped.
-                    probe = ts[:: max(1, ts.shape[0] // 64)]
-                    with np.errstate(invalid="ignore", divide="ignore"):
-                        offset = bool(np.any(np.abs(probe.mean(axis=0)) > 16.0 * probe.std(axis=0)))
-                if offset:
-                    x_host = np.empty(ts.shape, dtype=np.float32)
-                    np.subtract(ts, ts.mean(axis=0, keepdims=True), out=x_host, casting="unsafe")
+                n_signals = ts.shape[2]
+                n_alloc = n_signals + 1 if (n_signals % 2 and n_signals + 1 <= 256) else n_signals
+                if ts.dtype == np.float64 and ts.size:
+                    # float64 input: uploaded as it is and converted on the device (sc_timeseries_to_f32), which also takes a
+                    # per-(trial, signal) constant out in float64 BEFORE the cast when a detrend is active -- every window's
+                    # own detrend removes any constant, and a DC offset 1e5 times the signal (raw EEG / MEG) would otherwise
+                    # cost the float32 copy all but two digits of the signal -- and appends the zero pad channel of odd counts
+                    xd = torch.from_numpy(np.ascontiguousarray(ts)).to(dev)
+                    x = torch.empty(ts.shape[:2] + (n_alloc,), dtype=torch.float32, device=dev)
+                    _lib.check(_lib.load().sc_timeseries_to_f32(xd.data_ptr(), ts.shape[0], ts.shape[1], n_signals,
+                                                                int(self.detrend_type is not None), x.data_ptr(), n_alloc,
+                                                                torch.cuda.current_stream().cuda_stream), "sc_timeseries_to_f32")
+                    del xd
                 else:
                     x_host = np.ascontiguousarray(ts, dtype=np.float32)
-                n_signals = x_host.shape[2]
-                if n_signals % 2 and n_signals + 1 <= 256:
-                    # odd channel count: ONE all-zero channel is appended on the host, before the upload, so that the
-                    # rows of the spectra stay 16-byte aligned for the one-pass stage-B kernels (engine.DeviceSpectra)
-                    x_host = np.concatenate([x_host, np.zeros(x_host.shape[:2] + (1,), dtype=np.float32)], axis=2)
-                x = torch.from_numpy(x_host).to(dev)
+                    if n_alloc != n_signals:
+                        # odd channel count: ONE all-zero channel is appended on the host, before the upload, so that the
+                        # rows of the spectra stay 16-byte aligned for the one-pass stage-B kernels (engine.DeviceSpectra)
+                        x_host = np.concatenate([x_host, np.zeros(x_host.shape[:2] + (1,), dtype=np.float32)], axis=2)
+                    x = torch.from_numpy(x_host).to(dev)
                 h = torch.from_numpy(np.ascontiguousarray(tapers.T / self.sampling_frequency, dtype=np.float32)).to(dev)
                 self._device_spectra[precision] = engine.multitaper_spectra(
                     x, h, self.n_time_samples_per_window, self.n_time_samples_per_step,
