@@ -340,7 +340,10 @@ class Multitaper:
                 f"Your time series has only {n_time} time points but {n_signals} signals. "
                 "This seems unusual and your data may be transposed.\n"
                 "Expected shape: (n_time_samples, n_trials, n_signals)", UserWarning, stacklevel=2)
-        if not np.all(np.isfinite(self.time_series)):
+        # (a finite sum proves every sample finite -- NaN and inf propagate -- in one pass without a boolean temporary;
+        # only a non-finite sum, which overflow could also produce, needs the element-wise check)
+        if not (self.time_series.dtype.kind == "f" and self.time_series.size and np.isfinite(self.time_series.sum())) \
+                and not np.all(np.isfinite(self.time_series)):
             warnings.warn(
                 "Input time_series contains NaN or infinite values.\n"
                 "This will produce invalid spectral estimates.", UserWarning, stacklevel=2)
