@@ -215,6 +215,26 @@ class Connectivity:
     def _n_observations_total(self, local_n_obs):
         return local_n_obs
 
+    # accumulator families behind the expectation-type measures of the public interface
+    _METHOD_PLANES = {
+        "power": _lib.PLANE_CSM, "coherency": _lib.PLANE_CSM, "coherence_phase": _lib.PLANE_CSM,
+        "coherence_magnitude": _lib.PLANE_CSM, "imaginary_coherence": _lib.PLANE_CSM,
+        "phase_locking_value": _lib.PLANE_UNIT, "pairwise_phase_consistency": _lib.PLANE_UNIT,
+        "phase_lag_index": _lib.PLANE_SIGN_IM, "debiased_squared_phase_lag_index": _lib.PLANE_SIGN_IM,
+        "weighted_phase_lag_index": _lib.PLANE_CSM | _lib.PLANE_ABS_IM,
+        "debiased_squared_weighted_phase_lag_index": _lib.PLANE_CSM | _lib.PLANE_ABS_IM | _lib.PLANE_IM_SQ,
+        "phase_slope_index": _lib.PLANE_CSM, "group_delay": _lib.PLANE_CSM, "delay": _lib.PLANE_CSM,
+    }
+
+    def _prepare(self, methods):
+        """One record with every accumulator family the named measures need (one pass over the spectra per family)
+        instead of a record per measure, each re-accumulating the families it shares with the others."""
+        planes = 0
+        for name in methods:
+            planes |= self._METHOD_PLANES.get(name, 0)
+        if planes and bin(planes).count("1") > 1:
+            self._accumulators(planes)
+
     # ---- measures (reference connectivity.py:612-1159) -----------------------------------
     def power(self):
         """Power spectral density, non-negative frequencies: (..., n_freq, n_signals)."""

@@ -101,6 +101,8 @@ def multitaper_connectivity(time_series, sampling_frequency, time_window_duratio
     m = Multitaper(time_series=time_series, sampling_frequency=sampling_frequency,
                    time_window_duration=time_window_duration, **kwargs)
     connectivity = Connectivity.from_multitaper(m)       # shared: one transform, shared accumulator passes
+    if len(methods) > 1:
+        connectivity._prepare(methods)
     out = xr.Dataset()
     for name in methods:
         try:
