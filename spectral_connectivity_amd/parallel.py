@@ -287,9 +287,11 @@ class ShardedConnectivity(_connectivity_base()):
     def from_multitaper(cls, multitaper_instance, expectation_type="trials_tapers", blocks=None, dtype=None,
                         process_group=None):
         import numpy as np
-        obj = cls(multitaper_instance.device_spectra(), expectation_type=expectation_type,
-                  time=multitaper_instance.time, frequencies=multitaper_instance.frequencies, blocks=blocks,
-                  dtype=np.complex128 if dtype is None else dtype, process_group=process_group)
+        from . import options
+        dtype = np.complex128 if dtype is None else dtype
+        obj = cls(multitaper_instance.device_spectra(precision=options.engine_precision(dtype)),
+                  expectation_type=expectation_type, time=multitaper_instance.time,
+                  frequencies=multitaper_instance.frequencies, blocks=blocks, dtype=dtype, process_group=process_group)
         obj._multitaper = multitaper_instance
         return obj
 
