@@ -152,6 +152,26 @@ def cpu_baseline(cfg, geom, budget_trials=4):
     return dt
 
 
+def self_launch(n_ranks):
+    """Re-run this command under torch.distributed.run with n_ranks local ranks (rendezvous on 127.0.0.1).  With fewer
+    visible GPUs than ranks (a debug run on a 1-GPU box) the ranks share devices over gloo -- said on stderr and in the
+    line's "backend" field: such a number exercises the N > 1 control flow, it is not a scaling measurement."""
+    import socket
+    import subprocess
+    env = dict(os.environ)
+    n_dev = torch.cuda.device_count()
+    if n_dev < n_ranks and "SC_BENCH_BACKEND" not in env:
+        print(f"bench.py: {n_ranks} ranks requested, {n_dev} GPU(s) visible: ranks share devices over gloo "
+              "(control-flow rehearsal, not a scaling measurement)", file=sys.stderr)
+        env["SC_BENCH_BACKEND"] = "gloo"
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -162,6 +182,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f64", action="store_true", help="skip the float64-engine side measurement")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU), the same
+        # command the driver's torchrun form runs; rank 0 prints the one JSON line, the exit code is the job's.
+        sys.exit(self_launch(args.gpus))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -352,6 +377,7 @@ def main():
                        "units_per_step": units, "parallelism": f"trials sharded over {world} GPU(s)"},
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_restructured": cpu_strong,
             "float64_engine": f64,
+            "backend": None if world == 1 else ("rccl" if backend == "nccl" else backend + " (ranks share GPUs: rehearsal only)"),
             # N > 1: time inside the RCCL collectives of one step on the exchange stream (reduce-scatter of the records,
             # gather of the measures) and the part of the exchange + epilogue the launch stream had to wait for
             "exchange": None if exchange is None else {

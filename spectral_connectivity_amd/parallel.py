@@ -10,8 +10,19 @@ user-facing result (or an all-gather when every rank needs them) -- (N-1)/N of t
 per link instead of the 2x of an all-reduce followed by a redundant epilogue.  Division by
 n_observations happens after the sum (never average ratios).
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def _no_exchange(group=None):
+    """True when there is nothing to exchange: no process group, or a single rank.  SC_FORCE_EXCHANGE=1 sends a
+    one-rank group through the collectives anyway -- the rehearsal of the RCCL calls, streams and buffers on a box
+    with one GPU (tests/test_gpu_configs.py::test_rccl_exchange_path_world_one)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return True
+    return dist.get_world_size(group) == 1 and os.environ.get("SC_FORCE_EXCHANGE", "0") != "1"
 
 
 def shard_bounds(n_items, world_size, rank):
@@ -31,7 +42,7 @@ def reduce_scatter_bins(accum, group=None):
     ``accum``: [n_bins, floats_per_bin] float32.  Bins are padded to a multiple of the
     world size so every rank owns the same count; ``bin_hi`` is clipped to n_bins.
     """
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if _no_exchange(group):
         return accum, 0, accum.shape[0]
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     n_bins, fpb = accum.shape
@@ -62,7 +73,7 @@ def reduce_scatter_bins(accum, group=None):
 
 def all_gather_bins(shard_out, n_bins, group=None):
     """Assemble per-rank measure shards [per, ...] into the full [n_bins, ...] tensor."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if _no_exchange(group):
         return shard_out[:n_bins]
     world = dist.get_world_size(group)
     full = torch.empty((shard_out.shape[0] * world,) + tuple(shard_out.shape[1:]),
@@ -78,7 +89,7 @@ def gather_bins(shard_out, n_bins, dst=0, group=None):
     1/N of the data) instead of the N-1 ring steps of an all-gather.  Returns the [n_bins, ...] tensor
     on `dst`, None elsewhere.
     """
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if _no_exchange(group):
         return shard_out[:n_bins]
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     dev = shard_out.device
@@ -97,7 +108,7 @@ def gather_bins(shard_out, n_bins, dst=0, group=None):
 
 def total_observations(local_n_obs, group=None):
     """n_observations of the whole job = sum of the shards' counts (trials differ per rank)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if _no_exchange(group):
         return int(local_n_obs)
     t = torch.tensor([int(local_n_obs)], dtype=torch.int64)
     if dist.get_backend(group) != "gloo":
@@ -136,10 +147,11 @@ def sharded_measures(spectra, planes, which, n_groups=4, dst=0, group=None, mark
     from . import engine
     world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
     rank = dist.get_rank(group) if world > 1 else 0
+    xchg = not _no_exchange(group)             # world > 1, or a one-rank rehearsal of the exchange
     F, W, C = spectra.F, spectra.W, spectra.C
     n_groups = max(1, min(int(n_groups), F))
     main = torch.cuda.current_stream()
-    side = _side_stream(spectra.X.device) if world > 1 else main
+    side = _side_stream(spectra.X.device) if xchg else main
     # the measures of every frequency range land in ONE preallocated [W, F, ...] tensor per measure on `dst` (a strided
     # device copy per range), not in a list that is concatenated afterwards
     result = [None for _ in which]
@@ -156,12 +168,12 @@ def sharded_measures(spectra, planes, which, n_groups=4, dst=0, group=None, mark
         f0, f1 = shard_bounds(F, n_groups, g)
         accum, n_obs = engine.accumulate(spectra.freq_slice(f0, f1), "trials_tapers", planes, mark=mark, row_multiple=world)
         n_bins = accum.shape[0]
-        if world > 1:
+        if xchg:
             ready = torch.cuda.Event()
             ready.record(main)
             accum.record_stream(side)
         with torch.cuda.stream(side):
-            if world > 1:
+            if xchg:
                 side.wait_event(ready)
             t0 = ev(side) if timing is not None else None
             shard, lo, hi = reduce_scatter_bins(accum, group)
@@ -171,7 +183,7 @@ def sharded_measures(spectra, planes, which, n_groups=4, dst=0, group=None, mark
             outs = engine.measure_multi(shard, C, planes, n_total, which)     # one launch where the measures allow it
             for m, w in enumerate(which):
                 out = outs[m]
-                if world > 1:
+                if xchg:
                     t0 = ev(side) if timing is not None else None
                     out = gather_bins(out, n_bins, dst=dst, group=group)
                     if timing is not None:
@@ -179,11 +191,11 @@ def sharded_measures(spectra, planes, which, n_groups=4, dst=0, group=None, mark
                 if out is not None:
                     if result[m] is None:
                         result[m] = torch.empty((W, F) + tuple(out.shape[1:]), dtype=out.dtype, device=out.device)
-                        if world > 1:
+                        if xchg:
                             result[m].record_stream(main)       # filled on the exchange stream, used on the launch stream
                     result[m][:, f0:f1].copy_(out.reshape(W, f1 - f0, *out.shape[1:]))
     tail0 = ev(main) if timing is not None else None
-    if world > 1:
+    if xchg:
         main.wait_stream(side)
     if mark:
         mark("exchange_epilogue_tail")
@@ -218,7 +230,7 @@ def total_observations_equal(local_n_obs, world):
 # ---- a Connectivity whose trials live on several GPUs ------------------------------------------------------
 def all_reduce_sum_(t, group=None):
     """In-place sum over ranks (gloo moves device tensors through the host)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if _no_exchange(group):
         return t
     if dist.get_backend(group) == "gloo" and t.is_cuda:
         host = t.cpu()
@@ -233,7 +245,7 @@ def merge_disjoint(values, group=None):
     """Every rank filled a DISJOINT subset of the entries of a float64 array and left NaN elsewhere (channel pairs of
     the Granger prediction dealt out over the ranks): the union on every rank, NaN where nobody wrote.  One sum of the
     NaN-cleared values and one of the written-flags."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if _no_exchange(group):
         return values
     written = ~torch.isnan(values)
     vals = torch.where(written, values, torch.zeros_like(values))
@@ -282,6 +294,12 @@ class ShardedConnectivity(_connectivity_base()):
         self._world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self._rank = dist.get_rank(process_group) if self._world > 1 else 0
         self._sharded_cache = {}
+        # trials of the whole job: ONE collective, at construction (which every rank takes part in anyway), so that no
+        # later call -- whatever its expectation type, on whichever subset of the ranks -- needs another one
+        self._n_trials_local = int(self._shape5[1])
+        if self._n_trials_local < 1:
+            raise ValueError("ShardedConnectivity needs at least one trial on every rank")
+        self._n_trials_total = total_observations(self._n_trials_local, process_group)
 
     @classmethod
     def from_multitaper(cls, multitaper_instance, expectation_type="trials_tapers", blocks=None, dtype=None,
@@ -301,9 +319,12 @@ class ShardedConnectivity(_connectivity_base()):
         return self._n_observations_total(super().n_observations)
 
     def _n_observations_total(self, local_n_obs):
-        if "n_total" not in self._sharded_cache:
-            self._sharded_cache["n_total"] = total_observations(local_n_obs, self._group)
-        return self._sharded_cache["n_total"]
+        """Every expectation type that averages over trials counts (trials) x (windows and / or tapers): the local count
+        is the local trial count times a factor that is the same on every rank, whichever type the caller accumulated
+        with (the measures use self.expectation_type, canonical / global coherence always trials x tapers)."""
+        per_trial, rem = divmod(int(local_n_obs), self._n_trials_local)
+        assert rem == 0, "n_observations of a trial-averaging expectation is a multiple of the trial count"
+        return per_trial * self._n_trials_total
 
     def _reduce_over_ranks(self, accum):
         """Replicated sum of the records (Granger, canonical, MVAR, global coherence read every bin)."""
@@ -352,7 +373,7 @@ class ShardedConnectivity(_connectivity_base()):
         return lo, min(lo + per, n_bins), per
 
     def _canonical_gather(self, part, n_bins, per):
-        if self._world == 1:
+        if _no_exchange(self._group):
             return part
         if part.shape[0] < per:
             pad = torch.full((per - part.shape[0],) + tuple(part.shape[1:]), float("nan"), dtype=part.dtype,

@@ -163,6 +163,17 @@ def merge_worker(rank, world, port, errors):
             part = torch.cat([part, torch.full((per - part.shape[0], 2), float("nan"), dtype=torch.float64)])
         full = parallel.all_gather_bins(part, n_bins).numpy()
         np.testing.assert_array_equal(full[:, 0], np.arange(n_bins))
+        # n_observations of the whole job for EVERY expectation type, whatever is asked first (round-2 advisor finding:
+        # the first call's count was cached for all): unequal trial counts 2, 3, 4, 5; W = 3 windows, K = 2 tapers
+        W, K, R_loc = 3, 2, rank + 2
+        R_tot = sum(r + 2 for r in range(world))
+        coef = np.ones((W, R_loc, K, 8, 2), complex)
+        for etype, order in (("time_trials_tapers", (K, W * K, 1)), ("trials", (K, 1)), ("trials_tapers", (1, K, K))):
+            c = parallel.ShardedConnectivity(coef, expectation_type=etype)
+            for factor in order:           # canonical / global coherence ask with trials x tapers, measures with etype
+                assert c._n_observations_total(R_loc * factor) == R_tot * factor
+            per_trial = {"time_trials_tapers": W * K, "trials": 1, "trials_tapers": K}[etype]
+            assert c.n_observations == R_tot * per_trial
         dist.destroy_process_group()
     except Exception as exc:
         errors.put(f"rank {rank}: {exc!r}")

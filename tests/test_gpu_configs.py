@@ -220,6 +220,41 @@ def test_trial_sharded_pipeline_ranks_share_one_gpu(world):
     assert "ShardedConnectivity OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
+def test_rccl_exchange_path_world_one():
+    """The RCCL calls of the N > 1 path (reduce_scatter_tensor, gather, all_gather_into_tensor, all_reduce on the
+    `nccl` backend, exchange stream, padded buffers) rehearsed with the one GPU a test box has: a one-rank nccl group,
+    SC_FORCE_EXCHANGE=1 so that nothing short-cuts the collectives."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SC_BENCH_BACKEND="nccl", SC_FORCE_EXCHANGE="1", MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                          "--master-addr", "127.0.0.1", "--master-port", "29547",
+                          os.path.join(root, "tools", "check_sharded.py")],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "sharded_measures OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+    assert "ShardedConnectivity OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (the form the driver uses) starts its own ranks and prints
+    ONE JSON line from rank 0; on this 1-GPU box the ranks share the device over gloo (said in the line)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SC_BENCH_BACKEND")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--trials", "64"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["exchange"] is not None and rec["value"] > 0
+
+
 def test_hot_kernels_are_bit_reproducible():
     """Stage A and stage B (split bins, L2-atomic folds, direct HBM->LDS row loads, one LDS-only barrier per chunk)
     repeat bit-exactly: every sum has one writer and a fixed order, and a race would show up here."""

@@ -89,6 +89,19 @@ def sharded_connectivity(world, rank, dev):
         ok = ~np.isnan(b)
         assert np.array_equal(la, lb) and np.array_equal(np.isnan(a), np.isnan(b))
         assert np.abs(a[ok] - b[ok]).max() <= 10 * tol
+    # n_observations per expectation type (round-2 advisor finding): sliding windows, "time_trials_tapers", canonical
+    # coherence (always trials x tapers) BEFORE power (windows x trials x tapers) -- each must use its own count
+    kw2 = dict(sampling_frequency=200.0, time_halfbandwidth_product=2, n_time_samples_per_window=128,
+               n_time_samples_per_step=128)
+    mine = parallel.ShardedConnectivity.from_multitaper(sc.Multitaper(x[:, lo:hi], **kw2),
+                                                        expectation_type="time_trials_tapers")
+    whole = sc.Connectivity.from_multitaper(sc.Multitaper(x, **kw2), expectation_type="time_trials_tapers")
+    a, _ = mine.canonical_coherence(labels)
+    b, _ = whole.canonical_coherence(labels)
+    ok = ~np.isnan(b)
+    assert np.array_equal(np.isnan(a), np.isnan(b)) and np.abs(a[ok] - b[ok]).max() <= 1e-8
+    a, b = mine.power(), whole.power()
+    assert mine.n_observations == whole.n_observations and np.abs(a - b).max() <= 1e-9 * np.abs(b).max()
     dist.barrier()
     if rank == 0:
         print("ShardedConnectivity OK")
