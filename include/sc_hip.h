@@ -57,7 +57,7 @@
 extern "C" {
 #endif
 
-#define SC_ABI_VERSION 2
+#define SC_ABI_VERSION 3
 
 /* error codes */
 #define SC_OK 0
@@ -415,6 +415,34 @@ int sc_canonical_coherence_f64(const void* d_accum, int64_t n_bins, int64_t n_si
                                int64_t n_observations, const int32_t* d_members, const int32_t* d_sizes,
                                int n_groups, int max_group_size, double* d_out, int32_t* d_fail,
                                void* stream);
+
+/* ---- host-pointer side of the boundary: memory, copies, streams (sc_memory.hip, ABI v3) ---------------------
+ * What the reference's CuPy backend does with `xp.asarray(time_series)` on the way in and `.get()` on the way out
+ * (transforms.py:405-439, connectivity.py:31-65): with these a host that has only ctypes + NumPy drives the whole path
+ * (spectral_connectivity_amd/numpy_host.py); a PyTorch host may keep its own allocator -- every compute entry point
+ * takes raw device pointers from either.
+ *   sc_device_alloc / sc_device_free   stream-ordered pool allocation (hipMallocAsync / hipFreeAsync on `stream`)
+ *   sc_host_alloc / sc_host_free       page-locked host memory (copies at link rate, asynchronous on their stream)
+ *   sc_host_register / _unregister     pin a buffer the host already owns (a NumPy array) for the same effect
+ *   sc_memcpy_h2d / sc_memcpy_d2h      asynchronous on `stream` for page-locked host memory; from / to pageable memory
+ *                                      the runtime stages the copy and returns when the host buffer is reusable
+ *   sc_memset_zero, sc_stream_create (non-blocking), sc_stream_destroy, sc_stream_synchronize
+ * sc_nonfinite_f32 / _f64: the constructor's NaN / infinity scan of the time series (transforms.py:746-753) on the
+ * device: *d_flag |= 1 if any of the n samples is not finite (caller zeroes the flag, reads it after a sync). */
+int sc_device_alloc(void** d_ptr, size_t bytes, void* stream);
+int sc_device_free(void* d_ptr, void* stream);
+int sc_host_alloc(void** h_ptr, size_t bytes);
+int sc_host_free(void* h_ptr);
+int sc_host_register(void* h_ptr, size_t bytes);
+int sc_host_unregister(void* h_ptr);
+int sc_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes, void* stream);
+int sc_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes, void* stream);
+int sc_memset_zero(void* d_ptr, size_t bytes, void* stream);
+int sc_stream_create(void** stream);
+int sc_stream_destroy(void* stream);
+int sc_stream_synchronize(void* stream);
+int sc_nonfinite_f32(const float* d_x, int64_t n, int32_t* d_flag, void* stream);
+int sc_nonfinite_f64(const double* d_x, int64_t n, int32_t* d_flag, void* stream);
 
 #ifdef __cplusplus
 }

@@ -3,29 +3,44 @@
 Drop-in for the ``Multitaper`` / ``Connectivity`` hot path of
 Eden-Kramer-Lab/spectral_connectivity (reference __init__.py:34-44 export list), executed
 by hand-written HIP kernels for gfx950 + rocFFT behind the C ABI of ``include/sc_hip.h``.
+
+The public names are resolved on first use (PEP 562): ``import spectral_connectivity_amd.numpy_host`` -- the torch-free
+ctypes + NumPy host of the same library -- must not drag in the PyTorch host that ``Connectivity`` sits on.
 """
-from .connectivity import Connectivity
-from .transforms import (
-    Multitaper,
-    MultitaperParameters,
-    estimate_frequency_resolution,
-    estimate_n_tapers,
-    prepare_time_series,
-    suggest_parameters,
-)
-from .utils import get_compute_backend
-from .wrapper import multitaper_connectivity
+import importlib
 
 __version__ = "0.1.0"
 
-__all__ = [
-    "Connectivity",
-    "Multitaper",
-    "MultitaperParameters",
-    "prepare_time_series",
-    "suggest_parameters",
-    "estimate_frequency_resolution",
-    "estimate_n_tapers",
-    "get_compute_backend",
-    "multitaper_connectivity",
-]
+_EXPORTS = {
+    "Connectivity": ".connectivity",
+    "Multitaper": ".transforms",
+    "MultitaperParameters": ".transforms",
+    "prepare_time_series": ".transforms",
+    "suggest_parameters": ".transforms",
+    "estimate_frequency_resolution": ".transforms",
+    "estimate_n_tapers": ".transforms",
+    "get_compute_backend": ".utils",
+    "multitaper_connectivity": ".wrapper",
+}
+__all__ = list(_EXPORTS)
+
+# the reference's import-time backend switch (transforms.py:405-439): SPECTRAL_CONNECTIVITY_ENABLE_GPU=true loads the
+# engine NOW and fails here if it cannot be loaded; unset / anything else costs nothing at import
+from . import _lib as _binding  # noqa: E402  (ctypes table only: no torch, no library load)
+
+_binding.honour_gpu_switch()
+
+
+def __getattr__(name):
+    if name in _EXPORTS:
+        value = getattr(importlib.import_module(_EXPORTS[name], __name__), name)
+        globals()[name] = value
+        return value
+    try:                                   # submodules: spectral_connectivity_amd.transforms, .engine, ...
+        return importlib.import_module("." + name, __name__)
+    except ModuleNotFoundError:
+        raise AttributeError(f"module {__name__!r} has no attribute {name!r}") from None
+
+
+def __dir__():
+    return sorted(set(globals()) | set(__all__))

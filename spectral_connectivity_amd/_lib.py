@@ -3,22 +3,25 @@
 The HIP library is the ONLY compute path of this package: if it cannot be loaded the import
 of any compute entry point raises -- there is no NumPy/CPU fallback.
 
-torch is imported BEFORE the library on purpose: the PyTorch-ROCm wheel ships its own HIP
-runtime / rocFFT (same SONAMEs as /opt/rocm); loading it first makes libsc_hip.so bind to
-that single runtime, so device pointers of torch tensors are valid inside our kernels.
+Two hosts sit on this binding.  The PyTorch host (engine.py: torch owns HBM buffers, streams and the RCCL collectives)
+imports torch BEFORE the library on purpose: the PyTorch-ROCm wheel ships its own HIP runtime / rocFFT (same SONAMEs
+as /opt/rocm); loading it first makes libsc_hip.so bind to that single runtime, so device pointers of torch tensors
+are valid inside our kernels.  The NumPy host (numpy_host.py: memory, copies and streams through the library's own
+sc_device_alloc / sc_memcpy_* / sc_stream_* calls) never imports torch; the library then binds to /opt/rocm's runtime.
+One process uses one of the two: whichever loads the library first decides the runtime it is bound to.
 """
 import ctypes
 import os
 from ctypes import POINTER, Structure, byref, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_uint32, c_void_p
 
-import torch  # noqa: F401  (must precede CDLL, see module docstring)
+import sys
 
 from . import _build
 
 c_int64_p = POINTER(c_int64)
 
 # ---- constants mirrored from include/sc_hip.h -------------------------------------------
-SC_ABI_VERSION = 2
+SC_ABI_VERSION = 3
 GRANGER_KEEP_OUTPUT = 1
 DETREND = {None: 0, "constant": 1, "c": 1, "linear": 2, "l": 2}
 MVAR_DTF, MVAR_DC, MVAR_PDC, MVAR_GPDC, MVAR_DDTF, MVAR_TRANSFER, MVAR_COEFFICIENTS, MVAR_NOISE_COVARIANCE = range(8)
@@ -114,9 +117,25 @@ SYMBOLS = {
     "sc_canonical_coherence_f64": (c_int, [c_void_p, c_int64, c_int64, c_uint32, c_int64, c_void_p, c_void_p,
                                            c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "sc_measure_f32": (c_int, [c_void_p, c_int64, c_int64, c_uint32, c_int64, c_int, c_void_p, c_void_p]),
+    # host-pointer side (sc_memory.hip)
+    "sc_device_alloc": (c_int, [POINTER(c_void_p), c_size_t, c_void_p]),
+    "sc_device_free": (c_int, [c_void_p, c_void_p]),
+    "sc_host_alloc": (c_int, [POINTER(c_void_p), c_size_t]),
+    "sc_host_free": (c_int, [c_void_p]),
+    "sc_host_register": (c_int, [c_void_p, c_size_t]),
+    "sc_host_unregister": (c_int, [c_void_p]),
+    "sc_memcpy_h2d": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "sc_memcpy_d2h": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "sc_memset_zero": (c_int, [c_void_p, c_size_t, c_void_p]),
+    "sc_stream_create": (c_int, [POINTER(c_void_p)]),
+    "sc_stream_destroy": (c_int, [c_void_p]),
+    "sc_stream_synchronize": (c_int, [c_void_p]),
+    "sc_nonfinite_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "sc_nonfinite_f64": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
 }
 
 _lib = None
+_bound_with_torch = None        # True / False once the library is loaded: which HIP runtime it is bound to
 
 
 class HipEngineError(RuntimeError):
@@ -127,11 +146,20 @@ def library_path():
     return os.environ.get("SC_HIP_LIB", _build.LIB)
 
 
-def load():
-    """Load (building in-tree if the sources are newer) and type libsc_hip.so.  Raises if impossible."""
-    global _lib
+def load(torch_host=True):
+    """Load (building in-tree if the sources are newer) and type libsc_hip.so.  Raises if impossible.
+    ``torch_host``: the caller hands torch tensors' device pointers to the library, so torch's HIP runtime must be the
+    one the library binds to (torch imported first); numpy_host passes False and never imports torch."""
+    global _lib, _bound_with_torch
     if _lib is not None:
+        if torch_host and not _bound_with_torch:
+            raise RuntimeError(
+                "libsc_hip.so was loaded by the NumPy host (spectral_connectivity_amd.numpy_host) and is bound to "
+                "/opt/rocm's HIP runtime; the PyTorch host cannot share it in the same process (torch ships its own "
+                "runtime). Import spectral_connectivity_amd (or torch) before numpy_host, or use separate processes.")
         return _lib
+    if torch_host or "torch" in sys.modules:
+        import torch  # noqa: F401  (must precede CDLL, see module docstring)
     path = library_path()
     if path == _build.LIB and _build.is_stale():
         try:
@@ -153,18 +181,24 @@ def load():
     if lib.sc_abi_version() != SC_ABI_VERSION:
         raise RuntimeError(f"{path}: ABI version {lib.sc_abi_version()} != {SC_ABI_VERSION}")
     _lib = lib
+    _bound_with_torch = "torch" in sys.modules
     return lib
+
+
+def _handle():
+    """The loaded library, whichever host loaded it (the PyTorch host's load() on first use otherwise)."""
+    return _lib if _lib is not None else load()
 
 
 def check(status, what=""):
     if status != 0:
-        msg = load().sc_last_error()
+        msg = _handle().sc_last_error()
         raise HipEngineError(f"{what} failed with status {status}: {msg.decode() if msg else ''}")
 
 
 def device_count():
     n = c_int(0)
-    check(load().sc_device_count(byref(n)), "sc_device_count")
+    check(_handle().sc_device_count(byref(n)), "sc_device_count")
     return n.value
 
 
@@ -202,6 +236,7 @@ def require_gpu():
             f"{ENABLE_GPU_ENV}={os.environ.get(ENABLE_GPU_ENV)!r} selects the reference's NumPy backend, which "
             "spectral_connectivity_amd does not have: every computation here runs on the HIP engine. Unset the "
             "variable or set it to 'true' (or use the reference package for a CPU run).")
+    import torch
     if not torch.cuda.is_available():
         raise RuntimeError(
             "spectral_connectivity_amd: no ROCm GPU is visible (torch.cuda.is_available() is False). "
@@ -211,12 +246,12 @@ def require_gpu():
 
 def timing_enable(on=True):
     """Library-side stage timers (hipEvents on the launch stream, sc_timing.hip)."""
-    check(load().sc_timing_enable(int(bool(on))), "sc_timing_enable")
+    check(_handle().sc_timing_enable(int(bool(on))), "sc_timing_enable")
 
 
 def last_timing(max_entries=4096):
     """[(entry point, milliseconds)] of the calls since the previous read, in call order (waits for them)."""
     buf = (Timing * max_entries)()
     n = c_int(0)
-    check(load().sc_last_timing(buf, max_entries, byref(n)), "sc_last_timing")
+    check(_handle().sc_last_timing(buf, max_entries, byref(n)), "sc_last_timing")
     return [(buf[i].name.decode(), float(buf[i].ms)) for i in range(n.value)]

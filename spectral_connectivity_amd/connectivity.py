@@ -207,13 +207,31 @@ class Connectivity:
         from . import engine
         have, (accum, n_obs) = self._accumulators(_lib.MEASURE_PLANES[which])
         C = self._shape5[4]
-        # the epilogue writes float64 / complex128 (what the reference returns) itself: no widening pass
-        host = engine.to_host(engine.measure(accum, C, have, self._n_observations_total(n_obs), which, wide=True))
+        # the epilogue writes the dtype the reference returns (_wide_output) itself: no widening pass on the way out
+        host = engine.to_host(engine.measure(accum, C, have, self._n_observations_total(n_obs), which,
+                                             wide=self._wide_output(which)))
         tail = (C,) if which == _lib.M_POWER else (C, C)
         return host.reshape(self._kept_shape() + (self._n_freq,) + tail)
 
     def _n_observations_total(self, local_n_obs):
         return local_n_obs
+
+    # the measures whose arithmetic the reference runs in `dtype` from the first product on (the per-observation
+    # cross-spectra of _complex_inner_product(dtype=...), connectivity.py:1799-1822, then fcn and the expectation)
+    _DTYPE_MEASURES = frozenset((_lib.M_PLV, _lib.M_PLV_COMPLEX, _lib.M_PLI, _lib.M_WPLI, _lib.M_DEBIASED_PLI2,
+                                 _lib.M_DEBIASED_WPLI2, _lib.M_PPC))
+
+    def _wide_output(self, which):
+        """True: float64 / complex128 results, False: float32 / complex64 -- what the reference returns for this
+        measure: the phase-lag / phase-locking family comes out in the real type of ``dtype`` (float32 for
+        ``dtype=complex64``); power and the coherency family divide by the power, which is computed from the
+        coefficients themselves, so they come out in the coefficients' precision (complex128 from ``Multitaper.fft``,
+        whatever ``dtype`` says; float32 only for uploaded complex64 coefficients)."""
+        if which in self._DTYPE_MEASURES:
+            return np.dtype(self._dtype) != np.complex64
+        if self._multitaper is None and self._host_coefficients is not None:
+            return self._host_coefficients.dtype != np.complex64
+        return True
 
     # accumulator families behind the expectation-type measures of the public interface
     _METHOD_PLANES = {

@@ -1,0 +1,309 @@
+"""The thin host BASELINE.json's north_star names: ctypes + NumPy over the C ABI of ``include/sc_hip.h`` -- no torch.
+
+``spectral_connectivity_amd.Connectivity`` sits on a PyTorch host (torch owns HBM buffers, streams and the RCCL
+collectives of the multi-GPU path).  This module drives the SAME library with nothing but NumPy arrays: device and
+page-locked memory, copies and the stream come from the library's own ``sc_device_alloc`` / ``sc_host_alloc`` /
+``sc_memcpy_*`` / ``sc_stream_*`` entry points (sc_memory.hip), the way the reference's CuPy backend uploads with
+``xp.asarray`` and downloads with ``.get()`` (reference transforms.py:405-439, connectivity.py:31-65).
+
+    from spectral_connectivity_amd.numpy_host import NumpyHost
+    host = NumpyHost()
+    out = host.connectivity(time_series, sampling_frequency=1000, time_halfbandwidth_product=4,
+                            n_time_samples_per_window=256, n_time_samples_per_step=128,
+                            measures=("coherence_magnitude", "weighted_phase_lag_index"))
+
+Scope: the float32 engine's hot path -- stage A (fused transform, or tapered windows + rocFFT for the lengths the fused
+kernel does not take), stage B (every accumulator plane), the expectation-type measures of the reference
+(connectivity.py:612-1159), ``expectation_type`` as in the reference.  Results are float64 / complex128 NumPy arrays
+shaped like the reference's.  Everything else (Granger, canonical / global coherence, the float64 engine, multi-GPU)
+lives on the PyTorch host.  One process uses one host: see _lib.load().
+"""
+import ctypes
+from ctypes import byref, c_int32, c_int64, c_size_t, c_void_p
+
+import numpy as np
+
+from . import _lib
+from ._lib import SpectraDesc
+
+EXPECTATION_AXES = {"time": (0,), "trials": (1,), "tapers": (2,), "time_trials": (0, 1), "time_tapers": (0, 2),
+                    "trials_tapers": (1, 2), "time_trials_tapers": (0, 1, 2)}
+MEASURES = {
+    "power": _lib.M_POWER, "coherency": _lib.M_COHERENCY, "coherence_magnitude": _lib.M_COHERENCE_MAGNITUDE,
+    "coherence_phase": _lib.M_COHERENCE_PHASE, "imaginary_coherence": _lib.M_IMAGINARY_COHERENCE,
+    "phase_locking_value": _lib.M_PLV, "phase_lag_index": _lib.M_PLI, "weighted_phase_lag_index": _lib.M_WPLI,
+    "debiased_squared_phase_lag_index": _lib.M_DEBIASED_PLI2,
+    "debiased_squared_weighted_phase_lag_index": _lib.M_DEBIASED_WPLI2, "pairwise_phase_consistency": _lib.M_PPC,
+}
+
+
+class DeviceBuffer:
+    """``n_bytes`` of HBM from the library's stream-ordered pool; freed on the same stream when dropped."""
+
+    def __init__(self, host, n_bytes):
+        self._host, self.n_bytes = host, int(n_bytes)
+        p = c_void_p()
+        _lib.check(host.lib.sc_device_alloc(byref(p), self.n_bytes, host.stream), "sc_device_alloc")
+        self.ptr = p
+
+    def free(self):
+        if self.ptr is not None and self.ptr.value:
+            self._host.lib.sc_device_free(self.ptr, self._host.stream)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class PinnedArray(np.ndarray):
+    """A NumPy array over page-locked memory of sc_host_alloc.  Page-locking is the expensive part (20 ms per 100 MB
+    on the MI355X host, 12 ms to release), so the block goes back to a small pool with the last view of the array and
+    the next result of that size reuses it: a steady-state download costs the copy alone (57 GB/s)."""
+
+    _pool = {}                      # n_bytes -> [address, ...] of released blocks
+    _pooled_bytes = 0
+    POOL_LIMIT = 4 << 30
+
+    @classmethod
+    def empty(cls, lib, shape, dtype):
+        dtype = np.dtype(dtype)
+        n_bytes = max(int(np.prod(shape, dtype=np.int64)) * dtype.itemsize, 1)
+        free = cls._pool.get(n_bytes)
+        if free:
+            address = free.pop()
+            cls._pooled_bytes -= n_bytes
+        else:
+            p = c_void_p()
+            _lib.check(lib.sc_host_alloc(byref(p), n_bytes), "sc_host_alloc")
+            address = p.value
+        raw = (ctypes.c_char * n_bytes).from_address(address)
+        arr = np.frombuffer(raw, dtype=dtype, count=n_bytes // dtype.itemsize).reshape(shape).view(cls)
+        arr._owner = _PinnedOwner(lib, address, n_bytes)
+        return arr
+
+    def __array_finalize__(self, obj):
+        self._owner = getattr(obj, "_owner", None)
+
+    @classmethod
+    def trim(cls, lib):
+        """Release the pooled blocks."""
+        for blocks in cls._pool.values():
+            for address in blocks:
+                lib.sc_host_free(c_void_p(address))
+        cls._pool.clear()
+        cls._pooled_bytes = 0
+
+
+class _PinnedOwner:
+    def __init__(self, lib, address, n_bytes):
+        self.lib, self.address, self.n_bytes = lib, address, n_bytes
+
+    def __del__(self):
+        try:
+            if PinnedArray._pooled_bytes + self.n_bytes <= PinnedArray.POOL_LIMIT:
+                PinnedArray._pool.setdefault(self.n_bytes, []).append(self.address)
+                PinnedArray._pooled_bytes += self.n_bytes
+            else:
+                self.lib.sc_host_free(c_void_p(self.address))
+        except Exception:
+            pass
+
+
+class NumpyHost:
+    """One stream on the current device, buffers from the library, NumPy in and out."""
+
+    def __init__(self):
+        self.lib = _lib.load(torch_host=False)
+        if _lib.gpu_switch() is False:
+            raise RuntimeError(f"{_lib.ENABLE_GPU_ENV} selects the reference's NumPy backend, which this package does "
+                               "not have: every computation runs on the HIP engine.")
+        if _lib.device_count() < 1:
+            raise RuntimeError("spectral_connectivity_amd: no ROCm GPU is visible. This engine has no CPU fallback; "
+                               "run on an MI355X host.")
+        s = c_void_p()
+        _lib.check(self.lib.sc_stream_create(byref(s)), "sc_stream_create")
+        self.stream = s
+        self._twiddles = {}
+
+    def close(self):
+        if self.stream is not None:
+            self._twiddles.clear()
+            self.synchronize()
+            PinnedArray.trim(self.lib)
+            self.lib.sc_stream_destroy(self.stream)
+            self.stream = None
+
+    def synchronize(self):
+        _lib.check(self.lib.sc_stream_synchronize(self.stream), "sc_stream_synchronize")
+
+    # ---- memory -------------------------------------------------------------------------------------------------
+    def alloc(self, n_bytes):
+        return DeviceBuffer(self, n_bytes)
+
+    def upload(self, array):
+        """Contiguous NumPy array -> device buffer (asynchronous when the array is page-locked)."""
+        a = np.ascontiguousarray(array)
+        buf = self.alloc(a.nbytes)
+        _lib.check(self.lib.sc_memcpy_h2d(buf.ptr, a.ctypes.data_as(c_void_p), a.nbytes, self.stream), "sc_memcpy_h2d")
+        if not isinstance(a, PinnedArray):
+            self.synchronize()             # a pageable source may be reused by the caller as soon as this returns
+        return buf
+
+    def download(self, buf, shape, dtype):
+        """Device buffer -> NumPy array in page-locked memory (the copy runs at link rate)."""
+        out = PinnedArray.empty(self.lib, shape, dtype)
+        _lib.check(self.lib.sc_memcpy_d2h(out.ctypes.data_as(c_void_p), buf.ptr, out.nbytes, self.stream), "sc_memcpy_d2h")
+        self.synchronize()
+        return out
+
+    def has_nonfinite(self, buf, n, f64=False):
+        """The constructor's NaN / infinity scan (reference transforms.py:746-753) on the uploaded series."""
+        flag = self.alloc(4)
+        _lib.check(self.lib.sc_memset_zero(flag.ptr, 4, self.stream), "sc_memset_zero")
+        fn = self.lib.sc_nonfinite_f64 if f64 else self.lib.sc_nonfinite_f32
+        _lib.check(fn(buf.ptr, n, flag.ptr, self.stream), "sc_nonfinite")
+        return bool(self.download(flag, (1,), np.int32)[0])
+
+    # ---- stage A ------------------------------------------------------------------------------------------------
+    def spectra(self, multitaper):
+        """Stage A for a ``transforms.Multitaper`` (host geometry, tapers): dict with the device spectra
+        X[F][W][R][K][C_alloc] complex64 and their sizes."""
+        import warnings
+        m, lib = multitaper, self.lib
+        if np.iscomplexobj(m.time_series):
+            raise TypeError("complex-valued time series are not supported by the HIP engine")
+        if m.detrend_type not in _lib.DETREND:
+            raise ValueError(f"Invalid trend type '{m.detrend_type}' is not supported.\n"
+                             "Valid options are 'linear'/'l', 'constant'/'c' or None.")
+        ts = np.asarray(m.time_series)
+        T, R, C = ts.shape
+        C_alloc = C + 1 if (C % 2 and C + 1 <= 256) else C
+        L, step, N, W = m.n_time_samples_per_window, m.n_time_samples_per_step, m.n_fft_samples, m.n_time_windows
+        tapers = np.asarray(m.tapers, dtype=np.float64)                                   # (L, K), * sqrt(fs)
+        K = tapers.shape[1]
+        h = self.upload(np.ascontiguousarray(tapers.T / m.sampling_frequency, dtype=np.float32))
+        if ts.dtype == np.float64 and ts.size:
+            # float64 series: converted on the device, the per-(trial, signal) constant taken out in float64 first
+            xd = self.upload(ts)
+            x = self.alloc(T * R * C_alloc * 4)
+            _lib.check(lib.sc_timeseries_to_f32(xd.ptr, T, R, C, int(m.detrend_type is not None), x.ptr, C_alloc,
+                                                self.stream), "sc_timeseries_to_f32")
+            xd.free()
+        else:
+            xh = np.ascontiguousarray(ts, dtype=np.float32)
+            if C_alloc != C:
+                xh = np.concatenate([xh, np.zeros(xh.shape[:2] + (1,), dtype=np.float32)], axis=2)
+            x = self.upload(xh)
+        if getattr(m, "_finite_checked", True) is False and self.has_nonfinite(x, T * R * C_alloc):
+            warnings.warn("Input time_series contains NaN or infinite values.\n"
+                          "This will produce invalid spectral estimates.", UserWarning, stacklevel=3)
+        F = N // 2 + 1
+        X = self.alloc(F * W * R * K * C_alloc * 8)
+        detrend = _lib.DETREND[m.detrend_type]
+        if lib.sc_multitaper_fft_supported(L, N):
+            if N not in self._twiddles:
+                tw = self.alloc(N * 8)
+                _lib.check(lib.sc_fft_twiddles_f32(N, tw.ptr, self.stream), "sc_fft_twiddles_f32")
+                self._twiddles[N] = tw
+            _lib.check(lib.sc_multitaper_fft_f32(x.ptr, T, R, C_alloc, L, step, W, N, h.ptr, K, detrend,
+                                                 self._twiddles[N].ptr, X.ptr, self.stream), "sc_multitaper_fft_f32")
+        else:
+            batch = W * R * K * C_alloc
+            y = self.alloc(batch * N * 4)
+            _lib.check(lib.sc_taper_windows_f32(x.ptr, T, R, C_alloc, L, step, W, N, h.ptr, K, detrend, y.ptr,
+                                                self.stream), "sc_taper_windows_f32")
+            plan = c_void_p()
+            _lib.check(lib.sc_fft_plan_create(byref(plan), N, batch), "sc_fft_plan_create")
+            try:
+                _lib.check(lib.sc_fft_execute(plan, y.ptr, X.ptr, self.stream), "sc_fft_execute")
+                self.synchronize()
+            finally:
+                lib.sc_fft_plan_destroy(plan)
+            y.free()
+        x.free()
+        h.free()
+        return dict(X=X, F=F, W=W, R=R, K=K, C=C, C_alloc=C_alloc, N=N)
+
+    # ---- stages B and C -----------------------------------------------------------------------------------------
+    @staticmethod
+    def _desc(sp, expectation_type, padded):
+        axes = EXPECTATION_AXES[expectation_type]
+        W, R, K, Ca = sp["W"], sp["R"], sp["K"], sp["C_alloc"]
+        return SpectraDesc(n_freq=sp["F"], n_windows=W, n_trials=R, n_tapers=K, n_signals=Ca if padded else sp["C"],
+                           stride_freq=W * R * K * Ca, stride_window=R * K * Ca, stride_trial=K * Ca, stride_taper=Ca,
+                           reduce_window=int(0 in axes), reduce_trial=int(1 in axes), reduce_taper=int(2 in axes),
+                           reserved=0)
+
+    def accumulate(self, sp, expectation_type, planes):
+        """Stage B: un-normalised records [n_bins][floats_per_bin] float32 on the device."""
+        lib = self.lib
+        d_real, d_pad = self._desc(sp, expectation_type, False), self._desc(sp, expectation_type, True)
+        n_bins, fpb, n_groups, n_obs = c_int64(), c_int64(), c_int64(), c_int64()
+        _lib.check(lib.sc_accum_layout(byref(d_real), planes, byref(n_bins), byref(fpb), byref(n_groups), byref(n_obs)),
+                   "sc_accum_layout")
+        accum = self.alloc(n_bins.value * fpb.value * 4)
+        one_pass = int(lib.sc_fused_planes_covered(byref(d_pad), planes)) if lib.sc_fused_supported(sp["C_alloc"]) else 0
+        X, st = sp["X"].ptr, self.stream
+        if one_pass:
+            ws_bytes = int(lib.sc_fused_workspace_bytes(byref(d_pad), planes))
+            ws = self.alloc(ws_bytes) if ws_bytes else None
+            ws_ptr = ws.ptr if ws else None
+            if one_pass & _lib.PLANE_CSM:
+                _lib.check(lib.sc_fused_csm_absim_ws_f32(X, byref(d_pad), planes, accum.ptr, ws_ptr, ws_bytes, st),
+                           "sc_fused_csm_absim_ws_f32")
+            if one_pass & _lib.PLANE_SIGN_IM:
+                _lib.check(lib.sc_fused_sign_ws_f32(X, byref(d_pad), planes, accum.ptr, ws_ptr, ws_bytes, st),
+                           "sc_fused_sign_ws_f32")
+            if one_pass & _lib.PLANE_UNIT:
+                _lib.check(lib.sc_fused_unit_ws_f32(X, byref(d_pad), planes, accum.ptr, ws_ptr, ws_bytes, None, 0, st),
+                           "sc_fused_unit_ws_f32")
+            if ws:
+                ws.free()
+        elif planes & _lib.PLANE_CSM:
+            _lib.check(lib.sc_csm_accumulate_f32(X, byref(d_real), planes, accum.ptr, st), "sc_csm_accumulate_f32")
+            one_pass = _lib.PLANE_CSM
+        rest = planes & ~one_pass
+        if rest:
+            _lib.check(lib.sc_nonlinear_accumulate_f32(X, byref(d_real), planes, rest, accum.ptr, st),
+                       "sc_nonlinear_accumulate_f32")
+        return accum, n_bins.value, n_obs.value
+
+    def connectivity(self, time_series, measures=("coherence_magnitude",), expectation_type="trials_tapers", **multitaper_kwargs):
+        """NumPy time series (n_time, n_trials, n_signals) -> {measure name: NumPy array} shaped like the reference's
+        ``Connectivity.<measure>()`` results (non-negative frequencies)."""
+        from .transforms import Multitaper
+        if expectation_type not in EXPECTATION_AXES:
+            raise ValueError(f"Invalid expectation_type '{expectation_type}'. Must be one of: "
+                             + ", ".join(f"'{k}'" for k in EXPECTATION_AXES))
+        unknown = [name for name in measures if name not in MEASURES]
+        if unknown:
+            raise ValueError(f"unknown measures {unknown}; available: {sorted(MEASURES)}")
+        m = Multitaper(time_series, **multitaper_kwargs)
+        sp = self.spectra(m)
+        planes = 0
+        for name in measures:
+            planes |= _lib.MEASURE_PLANES[MEASURES[name]]
+        accum, n_bins, n_obs = self.accumulate(sp, expectation_type, planes)
+        sp["X"].free()
+        C, F = sp["C"], sp["F"]
+        axes = EXPECTATION_AXES[expectation_type]
+        kept = tuple(n for i, n in enumerate((sp["W"], sp["R"], sp["K"])) if i not in axes)
+        out = {}
+        for name in measures:
+            which = MEASURES[name]
+            tail = (C,) if which == _lib.M_POWER else (C, C)
+            dtype = np.complex128 if which in _lib.COMPLEX_MEASURES else np.float64
+            dev = self.alloc(n_bins * int(np.prod(tail)) * np.dtype(dtype).itemsize)
+            _lib.check(self.lib.sc_measure_f64(accum.ptr, n_bins, C, planes, n_obs, which, dev.ptr, self.stream),
+                       "sc_measure_f64")
+            out[name] = self.download(dev, kept + (F,) + tail, dtype)
+            dev.free()
+        accum.free()
+        out["frequencies"] = np.asarray(m.frequencies)[:F].copy()
+        if F and out["frequencies"][-1] < 0:
+            out["frequencies"][-1] = abs(out["frequencies"][-1])
+        out["time"] = np.asarray(m.time)
+        return out

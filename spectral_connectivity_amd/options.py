@@ -17,11 +17,20 @@ one_sample_fisher_z
     ``Connectivity.group_delay()`` is NaN for every pair and ``Connectivity.delay()`` returns the constants 2 pi k --
     the reference's outputs, pinned by tests/golden/f11_post.npz.
     ``"unbiased"``: the absent sample has no bias; group_delay / delay then report the delays they describe.
+
+finite_check
+    Where the constructor's NaN / infinity scan of the time series (reference transforms.py:746-753) runs.
+    ``"device"`` (default): series of at least ``FINITE_CHECK_DEVICE_MIN`` samples are scanned on the device next to
+    their upload (one read at HBM rate instead of 18 ms of one core at the cfg3 shape) and the reference's warning is
+    raised by the first transform; smaller series are scanned by the constructor like the reference's.
+    ``"host"``: always in the constructor.  Environment: ``SC_HIP_FINITE_CHECK``.
 """
 import os
 
 precision = os.environ.get("SC_HIP_PRECISION", "dtype")
 one_sample_fisher_z = "reference"
+finite_check = os.environ.get("SC_HIP_FINITE_CHECK", "device")
+FINITE_CHECK_DEVICE_MIN = 1 << 22
 
 
 def engine_precision(dtype=None):

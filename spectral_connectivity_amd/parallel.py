@@ -348,7 +348,7 @@ class ShardedConnectivity(_connectivity_base()):
             self._sharded_cache[key] = (shard, accum.shape[0], self._n_observations_total(n_obs))
         shard, n_bins, n_total = self._sharded_cache[key]
         C = self._shape5[4]
-        out = all_gather_bins(engine.measure(shard, C, key, n_total, which, wide=True), n_bins, self._group)
+        out = all_gather_bins(engine.measure(shard, C, key, n_total, which, wide=self._wide_output(which)), n_bins, self._group)
         tail = (C,) if which == _lib.M_POWER else (C, C)
         return engine.to_host(out).reshape(self._kept_shape() + (self._n_freq,) + tail)
 

@@ -286,6 +286,10 @@ _SHAPE_HELP_2D = (
     "or add the missing axis manually with np.newaxis.")
 
 
+_NONFINITE_WARNING = ("Input time_series contains NaN or infinite values.\n"
+                      "This will produce invalid spectral estimates.")
+
+
 class Multitaper:
     """Multitaper spectral transform on an MI355X (drop-in for the reference class).
 
@@ -340,13 +344,20 @@ class Multitaper:
                 f"Your time series has only {n_time} time points but {n_signals} signals. "
                 "This seems unusual and your data may be transposed.\n"
                 "Expected shape: (n_time_samples, n_trials, n_signals)", UserWarning, stacklevel=2)
-        # (a finite sum proves every sample finite -- NaN and inf propagate -- in one pass without a boolean temporary;
-        # only a non-finite sum, which overflow could also produce, needs the element-wise check)
-        if not (self.time_series.dtype.kind == "f" and self.time_series.size and np.isfinite(self.time_series.sum())) \
+        # The reference scans the whole series here (transforms.py:746-753).  Small series: the same scan on the host (a
+        # finite sum proves every sample finite -- NaN and inf propagate -- in one pass without a boolean temporary; only a
+        # non-finite sum, which overflow could also produce, needs the element-wise check).  Large real series (the scan
+        # of cfg3's 131 M samples costs 18 ms of one core, more than the whole device pipeline): the scan runs on the
+        # DEVICE next to the upload (sc_nonfinite_f32 / _f64, one read at HBM rate) and the same warning is raised by
+        # the first transform; options.finite_check = "host" keeps the constructor-time scan for every size.
+        from . import options as _options
+        self._finite_checked = True
+        if (_options.finite_check == "device" and self.time_series.dtype.kind == "f"
+                and self.time_series.size >= _options.FINITE_CHECK_DEVICE_MIN):
+            self._finite_checked = False
+        elif not (self.time_series.dtype.kind == "f" and self.time_series.size and np.isfinite(self.time_series.sum())) \
                 and not np.all(np.isfinite(self.time_series)):
-            warnings.warn(
-                "Input time_series contains NaN or infinite values.\n"
-                "This will produce invalid spectral estimates.", UserWarning, stacklevel=2)
+            warnings.warn(_NONFINITE_WARNING, UserWarning, stacklevel=2)
 
         self.sampling_frequency = sampling_frequency
         self.time_halfbandwidth_product = time_halfbandwidth_product
@@ -523,8 +534,21 @@ class Multitaper:
             dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
             tapers = np.asarray(self.tapers, dtype=np.float64)             # (L, K), * sqrt(fs)
             logger.info(self)
+            def device_scan(t):
+                # the constructor's NaN / infinity scan, deferred to the uploaded copy (see __init__)
+                if self._finite_checked:
+                    return
+                self._finite_checked = True
+                flag = torch.zeros((1,), dtype=torch.int32, device=dev)
+                fn = _lib.load().sc_nonfinite_f64 if t.dtype == torch.float64 else _lib.load().sc_nonfinite_f32
+                _lib.check(fn(t.data_ptr(), t.numel(), flag.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                           "sc_nonfinite")
+                if int(flag.item()):
+                    warnings.warn(_NONFINITE_WARNING, UserWarning, stacklevel=4)
+
             if precision == "float64":
                 x = torch.from_numpy(np.ascontiguousarray(self.time_series, dtype=np.float64)).to(dev)
+                device_scan(x)
                 h = torch.from_numpy(np.ascontiguousarray(tapers.T / self.sampling_frequency)).to(dev)
                 self._device_spectra[precision] = engine.multitaper_spectra_f64(
                     x, h, self.n_time_samples_per_window, self.n_time_samples_per_step,
@@ -539,6 +563,7 @@ class Multitaper:
                     # own detrend removes any constant, and a DC offset 1e5 times the signal (raw EEG / MEG) would otherwise
                     # cost the float32 copy all but two digits of the signal -- and appends the zero pad channel of odd counts
                     xd = torch.from_numpy(np.ascontiguousarray(ts)).to(dev)
+                    device_scan(xd)
                     x = torch.empty(ts.shape[:2] + (n_alloc,), dtype=torch.float32, device=dev)
                     _lib.check(_lib.load().sc_timeseries_to_f32(xd.data_ptr(), ts.shape[0], ts.shape[1], n_signals,
                                                                 int(self.detrend_type is not None), x.data_ptr(), n_alloc,
@@ -551,6 +576,7 @@ class Multitaper:
                         # rows of the spectra stay 16-byte aligned for the one-pass stage-B kernels (engine.DeviceSpectra)
                         x_host = np.concatenate([x_host, np.zeros(x_host.shape[:2] + (1,), dtype=np.float32)], axis=2)
                     x = torch.from_numpy(x_host).to(dev)
+                    device_scan(x)
                 h = torch.from_numpy(np.ascontiguousarray(tapers.T / self.sampling_frequency, dtype=np.float32)).to(dev)
                 self._device_spectra[precision] = engine.multitaper_spectra(
                     x, h, self.n_time_samples_per_window, self.n_time_samples_per_step,

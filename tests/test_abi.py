@@ -86,3 +86,88 @@ def test_gpu_switch_of_the_reference_is_honoured():
               "try:\n    m.fft()\nexcept RuntimeError as exc:\n    print('refused:', exc)\n",
               SPECTRAL_CONNECTIVITY_ENABLE_GPU="false")
     assert cpu.returncode == 0 and "refused:" in cpu.stdout and "NumPy backend" in cpu.stdout, cpu.stdout + cpu.stderr[-2000:]
+
+
+NUMPY_HOST_CODE = r'''
+import sys, time
+import numpy as np
+from spectral_connectivity_amd.numpy_host import NumpyHost
+from oracle import spectral_oracle as so
+assert "torch" not in sys.modules, "the NumPy host must not import torch"
+host = NumpyHost()
+rng = np.random.default_rng(5)
+T, R, C = 512, 9, 7                               # odd channel count: the zero pad channel goes through too
+t = np.arange(T) / 500.0
+x = rng.standard_normal((T, R, C))
+x += 0.8 * np.sin(2 * np.pi * 40 * t)[:, None, None] * np.cos(np.arange(C))[None, None, :]
+kw = dict(sampling_frequency=500.0, time_halfbandwidth_product=3, n_time_samples_per_window=128, n_time_samples_per_step=64)
+names = ("power", "coherency", "coherence_magnitude", "weighted_phase_lag_index", "phase_locking_value", "phase_lag_index",
+         "debiased_squared_weighted_phase_lag_index", "pairwise_phase_consistency")
+for xin in (x.astype(np.float32), x):             # float32 upload, and float64 upload converted on the device
+    got = host.connectivity(xin, measures=names, **kw)
+    coef, _ = so.multitaper_fft(np.asarray(xin, dtype=np.float64), fs=500.0, NW=3, n_time_samples_per_window=128,
+                                n_time_samples_per_step=64)
+    F = coef.shape[3] // 2 + 1
+    for name in names:
+        ref = getattr(so, name)(coef)[..., :F, :, :] if name != "power" else so.power(coef)[..., :F, :]
+        a = got[name]
+        assert a.shape == ref.shape, (name, a.shape, ref.shape)
+        assert np.array_equal(np.isnan(a), np.isnan(ref)), name
+        ok = ~np.isnan(ref)
+        tol = 8.0 / (R * 5) if name == "phase_lag_index" else 3e-5
+        err = np.abs(a[ok] - ref[ok]).max() / np.abs(ref[ok]).max()
+        assert err <= tol, (name, err)
+# a window length the fused transform does not take (7 is a prime factor above 5): tapered windows + rocFFT
+got = host.connectivity(x[:448].astype(np.float32), measures=("coherence_magnitude",), sampling_frequency=500.0,
+                        time_halfbandwidth_product=2, n_time_samples_per_window=224)
+coef, _ = so.multitaper_fft(x[:448].astype(np.float32).astype(np.float64), fs=500.0, NW=2, n_time_samples_per_window=224)
+ref = so.coherence_magnitude(coef)[..., :coef.shape[3] // 2 + 1, :, :]
+ok = ~np.isnan(ref)
+assert np.abs(got["coherence_magnitude"][ok] - ref[ok]).max() < 3e-5
+# NaN in a large series: the scan runs on the device, the reference's warning comes with the first transform
+import warnings
+big = rng.standard_normal((4096, 16, 64)).astype(np.float32)
+big[100, 3, 5] = np.nan
+with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter("always")
+    host.connectivity(big, measures=("power",), sampling_frequency=1000.0, n_time_samples_per_window=256)
+assert any("NaN or infinite" in str(i.message) for i in w), [str(i.message) for i in w]
+# copy rates through the library's own pinned buffers (cfg3's 0.52 GB series, one 118 MB measure)
+from spectral_connectivity_amd.numpy_host import PinnedArray
+src = PinnedArray.empty(host.lib, (1024, 1000, 128), np.float32)
+src[:] = 1.0
+host.upload(src); host.synchronize()
+t0 = time.perf_counter(); d = host.upload(src); host.synchronize(); t1 = time.perf_counter()
+back = host.download(d, src.shape, np.float32)
+t2 = time.perf_counter(); back = host.download(d, src.shape, np.float32); t3 = time.perf_counter()
+assert float(back[5, 7, 9]) == 1.0
+print("h2d %.1f GB/s  d2h %.1f GB/s (pinned, incl. allocation of the pinned result)" % (src.nbytes / (t1 - t0) / 1e9, src.nbytes / (t3 - t2) / 1e9))
+host.close()
+assert "torch" not in sys.modules
+print("numpy host OK")
+'''
+
+
+@pytest.mark.gpu
+def test_numpy_only_host_drives_the_hot_path_end_to_end():
+    """A host with ctypes + NumPy and nothing else (no torch in the process): upload through sc_memcpy_h2d, stage A,
+    stage B, epilogue, download through page-locked memory -- every expectation-type measure against the oracle."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, "-c", NUMPY_HOST_CODE], cwd=ROOT, capture_output=True, text=True, timeout=900,
+                         env=dict(os.environ, PYTHONPATH=ROOT))
+    assert out.returncode == 0 and "numpy host OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+    print(out.stdout)
+
+
+def test_numpy_host_imports_without_torch_and_refuses_without_a_gpu():
+    import subprocess
+    import sys
+    code = ("import sys\nfrom spectral_connectivity_amd import numpy_host, transforms\n"
+            "assert 'torch' not in sys.modules\n"
+            "try:\n    numpy_host.NumpyHost()\n    print('constructed')\n"
+            "except RuntimeError as exc:\n    print('refused:', exc)\n"
+            "assert 'torch' not in sys.modules\n")
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "constructed" in out.stdout or "no CPU fallback" in out.stdout, out.stdout

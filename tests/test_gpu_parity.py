@@ -781,3 +781,30 @@ def test_unit_phasor_plane_with_split_bins(sc, C):
     assert np.array_equal(np.isnan(plv), bad)
     off = ~np.eye(C, dtype=bool)
     np.testing.assert_allclose(plv[:, :, off][~bad[:, :, off]], ref[:, :, off][~bad[:, :, off]], rtol=3e-5, atol=3e-6)
+
+
+def test_output_dtypes_are_the_references(sc):
+    """What the reference returns for every expectation-type measure (observed by running it in the build container,
+    numpy 2.2.6): the phase-lag / phase-locking family in the real type of ``dtype``; power and the coherency family in
+    the precision of the coefficients (complex128 from Multitaper.fft whatever ``dtype`` is; complex64 coefficients
+    handed to the constructor give float32 / complex64)."""
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((256, 5, 4))
+    m = sc.Multitaper(x, sampling_frequency=100, time_halfbandwidth_product=2)
+    family = {"phase_locking_value", "phase_lag_index", "weighted_phase_lag_index", "debiased_squared_phase_lag_index",
+              "debiased_squared_weighted_phase_lag_index", "pairwise_phase_consistency"}
+
+    def expect(name, dtype_is_64, coef_is_64):
+        wide = dtype_is_64 if name in family else coef_is_64
+        if name == "coherency":
+            return np.complex128 if wide else np.complex64
+        return np.float64 if wide else np.float32
+
+    c64 = sc.Connectivity.from_multitaper(m, dtype=np.complex64)
+    c128 = sc.Connectivity.from_multitaper(m)
+    raw64 = sc.Connectivity(m.fft().astype(np.complex64), dtype=np.complex64)
+    for name in MEASURE_NAMES:
+        assert getattr(c64, name)().dtype == expect(name, False, True), name
+        assert getattr(c128, name)().dtype == expect(name, True, True), name
+        assert getattr(raw64, name)().dtype == expect(name, False, False), name
+        close32(getattr(c64, name)(), getattr(c128, name)(), rtol=3e-5, atol_scale=3e-5, what=name)
