@@ -7,11 +7,17 @@ x 1024 samples, NW=4 (7 tapers), sliding 256-sample windows with 128-sample step
 F=129), coherence_magnitude + weighted_phase_lag_index, expectation over trials x tapers.
 
 One "step" = one full pass of the hot path over the synthetic batch, inputs resident in HBM:
-  stage A  window/detrend/taper (HIP) + batched R2C FFT (rocFFT)
-  stage B  cross-spectral accumulation (MFMA) + |Im s| plane (VALU)
+  stage A  window + detrend + taper + FFT + transposed store, one fused HIP kernel (mtfft16_kernel)
+  stage B  cross-spectral accumulation AND the per-observation |Im s| plane on the bf16 matrix pipe, one pass
   (N>1)    reduce-scatter of the accumulator records over RCCL
   stage C  coherence + wPLI epilogue on the owned bins, (N>1) gather of the measures on rank 0
-N GPUs: the 1000 trials are sharded over the ranks (strong scaling), one process per GPU.
+N GPUs: the 1000 trials are sharded over the ranks (strong scaling), one process per GPU.  `python bench.py --gpus N`
+starts its own ranks (torch.distributed.run, 127.0.0.1); under the driver's torchrun form it joins the given world.
+
+`--config cfg2 | cfg4 | cfg5` (N = 1) times the other BASELINE.json configurations with their own metric beside the
+headline: cfg2 CSM + coherency (pair*bins/s), cfg4 pairwise spectral Granger of all 2016 pairs through the batched
+Wilson kernels (channel-pairs/s), cfg5 canonical coherence of 16 groups (bin*group-pairs/s) -- each line carries its
+`roofline` and `cpu_baseline`.
 
 Prints ONE JSON line on rank 0 (see the driver contract), with `roofline` for the dominant
 kernel (durations from HIP events on the launch stream) and `cpu_baseline` (the NumPy
@@ -36,11 +42,13 @@ from spectral_connectivity_amd.transforms import _make_tapers  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32 dense peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (the pipe the one-pass stage B actually runs on)
+F64_PEAK_TFLOPS = 78.6        # fp64 vector = fp64 matrix rate
 # HBM bytes per launch from the PMC counters: a PMC pass cannot run inside this process, so `roofline.traffic` is read
 # from the committed summary of the rocprofv3 --pmc passes over THIS command (tools/profile_round.py writes it next to
 # the kernel-trace stats; it records the source hash of the kernels it measured) and is null when that file is
 # missing or was measured on other kernel sources.
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")
 
 
 def kernel_source_hash():
@@ -59,18 +67,23 @@ def measured_traffic(config, stage):
     except (OSError, ValueError):
         return None, None
     if rec.get("kernel_source_hash") != kernel_source_hash():
-        return None, "profiles/r02_hbm_traffic.json was measured on other kernel sources"
+        return None, "profiles/r03_hbm_traffic.json was measured on other kernel sources"
     v = rec.get(config, {}).get(stage)
     return (float(v) if v is not None else None), rec.get("source")
 
 CONFIGS = {
-    # name: T, R, C, NW, L, step
-    "cfg3": dict(T=1024, R=1000, C=128, NW=4.0, L=256, step=128, tone=60.0,
+    # name: T, R, C, NW, L, step; kind = what a step computes after stages A and B
+    "cfg3": dict(T=1024, R=1000, C=128, NW=4.0, L=256, step=128, tone=60.0, kind="measures",
                  label="128ch x 1000 trials x 1024 samples, NW=4 (7 tapers), 256-pt windows step 128 "
                        "(W=7, F=129), coherence_magnitude + weighted_phase_lag_index"),
-    "cfg2": dict(T=1024, R=100, C=32, NW=3.0, L=1024, step=1024, tone=40.0,
-                 label="32ch x 100 trials x 1024 samples, NW=3 (5 tapers), single window, "
-                       "coherence_magnitude + weighted_phase_lag_index"),
+    "cfg2": dict(T=1024, R=100, C=32, NW=3.0, L=1024, step=1024, tone=40.0, kind="coherency",
+                 label="32ch x 100 trials x 1024 samples, NW=3 (5 tapers), single window, CSM + coherency"),
+    "cfg4": dict(T=4096, R=200, C=64, NW=3.0, L=4096, step=4096, tone=30.0, kind="granger",
+                 label="64ch x 200 trials x 4096 samples, NW=3 (5 tapers), single window, "
+                       "pairwise_spectral_granger_prediction of all 2016 channel pairs (batched 2x2 Wilson, fp64)"),
+    "cfg5": dict(T=1024, R=500, C=256, NW=3.0, L=1024, step=1024, tone=30.0, kind="canonical",
+                 label="256ch x 500 trials x 1024 samples, NW=3 (5 tapers), single window, canonical_coherence "
+                       "between 16 groups of 16 channels (513 bins x 120 group pairs, fp64)"),
 }
 FS = 1000.0
 
@@ -152,6 +165,146 @@ def cpu_baseline(cfg, geom, budget_trials=4):
     return dt
 
 
+def run_side_config(args, cfg, device):
+    """cfg2 / cfg4 / cfg5 of BASELINE.json on one GPU: the same stages A and B, then the configuration's own consumer --
+    coherency, the batched 2x2 Wilson factorisation + Granger prediction of every channel pair, or canonical coherence
+    between the channel groups.  One JSON line with the configuration's own metric, `roofline` for the kernel that takes
+    the largest share of the step, and `cpu_baseline` (the oracle on a bounded sample)."""
+    from oracle import spectral_oracle as so
+    T, R, C, L, step = cfg["T"], cfg["R"], cfg["C"], cfg["L"], cfg["step"]
+    N, W = L, int(np.floor(T / step - L / step + 1))
+    F = N // 2 + 1
+    tapers = _make_tapers(L, FS, cfg["NW"], int(np.floor(2 * cfg["NW"] - 1)))
+    K = tapers.shape[1]
+    h = torch.from_numpy(np.ascontiguousarray(tapers.T / FS, dtype=np.float32)).to(device)
+    x = synth(cfg, 0, R, device, seed=3)
+    kind = cfg["kind"]
+    planes = _lib.PLANE_CSM
+    n_obs_loc = R * K
+    pairs = np.array([(i, j) for i in range(C) for j in range(i + 1, C)], dtype=np.int32)
+    groups = [np.arange(g * 16, (g + 1) * 16) for g in range(C // 16)]
+    info = {}
+
+    def one():
+        sp = engine.multitaper_spectra(x, h, L, step, N, W, "constant")
+        accum, n_obs = engine.accumulate(sp, "trials_tapers", planes)
+        del sp
+        if kind == "coherency":
+            return engine.measure(accum, C, planes, n_obs, _lib.M_COHERENCY)
+        if kind == "granger":
+            out, _, _, summary = engine.granger_pairwise(accum, W, F, N, C, planes, n_obs, pairs)
+            info["wilson"] = summary
+            return out
+        out, n_fail = engine.canonical_coherence(accum, C, planes, n_obs, groups)
+        info["canonical_failures"] = n_fail
+        return out
+
+    for _ in range(args.warmup):
+        one()
+    torch.cuda.synchronize()
+    _lib.timing_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timing = _lib.last_timing()
+    _lib.timing_enable(False)
+    ms_per_step = elapsed / args.steps * 1e3
+    stage_ms = {}
+    for name, ms in timing:
+        stage_ms[name] = stage_ms.get(name, 0.0) + ms / args.steps
+
+    tri_flops = 8.0 * n_obs_loc * (C * (C + 1) / 2) * W * F
+    iters = info.get("wilson", (0, 0, 0))[0]
+    n_gp = len(groups) * (len(groups) - 1) // 2
+    # algorithmic work per launch (DESIGN.md section 5)
+    stage_model = {
+        "mtfft_fused": ("hbm", 4.0 * T * R * C + 8.0 * F * W * R * K * C),
+        "fused_stage_b": ("mfma", tri_flops),
+        "csm_mfma": ("mfma", tri_flops),
+        "measure_epilogue": ("hbm", (2 * 4.0 * C * (C + 1) / 2 + 8.0 * C * C) * W * F),
+        # batched Wilson: per (problem, bin, iteration) the fused causal transform pair reads A and writes A+ (2 x 64 B),
+        # the pointwise pass reads A+, G, S and writes G, A (64 + 64 + 32 + 64 + 64 B): 416 B; plus the records read and
+        # the prediction written once
+        "granger_pairwise": ("hbm", 416.0 * len(pairs) * W * N * max(iters, 1)),
+        # canonical coherence (approximate fp64 flop model, per (bin, group pair) of 16-channel groups: two 16^3 complex
+        # whitening products + M M^H (3 x 32.8 kflop) + ~6 cyclic Jacobi sweeps of 120 rotations on 16 x 16 (~0.74 Mflop))
+        "canonical_coherence": ("f64", 0.84e6 * W * F * n_gp),
+    }
+
+    def stage_roof(name):
+        b, wk = stage_model[name]
+        d = stage_ms[name] * 1e-3
+        peak, unit, scale = {"mfma": (MFMA_F32_PEAK_TFLOPS, "TFLOP/s", 1e12), "f64": (F64_PEAK_TFLOPS, "TFLOP/s", 1e12),
+                             "hbm": (HBM_PEAK_GBS, "GB/s", 1e9)}[b]
+        return {"bound": "mfma" if b == "f64" else b, "achieved": round(wk / d / scale, 3), "peak": peak, "unit": unit,
+                "frac": round(wk / d / scale / peak, 4), "kernel_ms": round(stage_ms[name], 4)}
+
+    dominant = max((k for k in stage_model if k in stage_ms), key=lambda k: stage_ms[k])
+    roofline = dict(stage_roof(dominant), entry_point=dominant, traffic=None,
+                    stage_ms={k: round(v, 4) for k, v in stage_ms.items()},
+                    stages={k: stage_roof(k) for k in stage_ms if k in stage_model})
+    if dominant == "granger_pairwise":
+        roofline["note"] = (f"batched 2x2 Wilson: {len(pairs) * W} problems x {N} bins x {iters} iterations x 416 algorithmic "
+                            "bytes (fused causal transform pair + pointwise update), over the whole entry point "
+                            "(initialisation, convergence polling and the prediction included)")
+    elif dominant == "canonical_coherence":
+        roofline["note"] = "approximate fp64 flop model of the Cholesky whitening + parallel Jacobi per (bin, group pair); fp64 vector peak"
+
+    if kind == "coherency":
+        units, unit = float(W * F * C * C), "channel-pair*freq-bins/s"
+        metric = "channel-pair*freq-bins/s for CSM+coherency"
+    elif kind == "granger":
+        units, unit = float(len(pairs) * W), "channel-pairs/s"
+        metric = f"channel-pairs/s for pairwise spectral Granger prediction ({N}-sample windows, {F} bins per pair)"
+    else:
+        units, unit = float(W * F * n_gp), "bin*group-pairs/s"
+        metric = "frequency-bin*group-pairs/s for canonical coherence (16 groups of 16 channels)"
+    value = units / (elapsed / args.steps)
+
+    cpu = None
+    if not args.no_cpu_baseline:
+        # the oracle on a bounded sample of the same workload, one core; what the sample was is said in `sample`
+        if kind == "coherency":
+            xs = synth(cfg, 0, 8, "cpu", seed=3).numpy().astype(np.float64)
+            t1 = time.perf_counter()
+            coef, _ = so.multitaper_fft(xs, fs=FS, NW=cfg["NW"], n_time_samples_per_window=L)
+            so.coherency(coef)
+            dt = time.perf_counter() - t1
+            cpu_value, sample = units / (dt * R / 8), (f"oracle faithful path (per-observation outer product + mean) on 8 of "
+                                                        f"{R} trials, linear in trials")
+        elif kind == "granger":
+            xs = synth(dict(cfg, C=4), 0, 20, "cpu", seed=3).numpy().astype(np.float64)
+            t1 = time.perf_counter()
+            coef, _ = so.multitaper_fft(xs, fs=FS, NW=cfg["NW"], n_time_samples_per_window=L)
+            so.pairwise_spectral_granger_prediction(coef)
+            dt = time.perf_counter() - t1
+            cpu_value, sample = 6.0 / dt, ("oracle: 6 pairs (4 channels) x 20 trials of the same window length -- the cost of a "
+                                           "pair is its Wilson iteration over the 4096 bins, independent of the trial count")
+        else:
+            Ts = 128
+            xs = synth(dict(cfg, T=Ts), 0, R, "cpu", seed=3).numpy().astype(np.float64)
+            t1 = time.perf_counter()
+            coef, _ = so.multitaper_fft(xs, fs=FS, NW=cfg["NW"], n_time_samples_per_window=Ts)
+            so.canonical_coherence(coef, np.arange(C) // 16)
+            dt = time.perf_counter() - t1
+            cpu_value, sample = (Ts // 2 + 1) * n_gp / dt, (f"oracle (per-bin SVDs) with all {R} trials and {C} channels on {Ts}-sample "
+                                                            f"windows ({Ts // 2 + 1} of {F} bins): the cost is linear in the bins")
+        cpu = {"value": round(cpu_value, 3), "unit": unit, "cores": 1, "kind": "port",
+               "measured_seconds_on_sample": round(dt, 3), "sample": sample + f"; os.cpu_count()={os.cpu_count()}"}
+
+    print(json.dumps({
+        "metric": metric, "value": value, "unit": unit, "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32" if kind == "coherency" else "f32 spectra + records, f64 " + ("Wilson iteration" if kind == "granger" else "whitening + Jacobi"),
+        "data": "synthetic",
+        "config": {"workload": cfg["label"], "name": args.config, "trials_total": R, "n_tapers": K, "n_windows": W,
+                   "n_freq_bins": F, "units_per_step": units,
+                   **({"wilson_iterations": iters, "wilson_not_converged": info["wilson"][1]} if kind == "granger" else {})},
+        "roofline": roofline, "cpu_baseline": cpu}))
+
+
 def self_launch(n_ranks):
     """Re-run this command under torch.distributed.run with n_ranks local ranks (rendezvous on 127.0.0.1).  With fewer
     visible GPUs than ranks (a debug run on a 1-GPU box) the ranks share devices over gloo -- said on stderr and in the
@@ -209,6 +362,9 @@ def main():
     cfg = dict(CONFIGS[args.config])
     if args.trials:
         cfg["R"] = args.trials
+    if cfg["kind"] != "measures":
+        assert world == 1, f"--config {args.config} is a single-GPU line; the scaling bench is cfg3"
+        return run_side_config(args, cfg, device)
     assert cfg["R"] % world == 0, "trials must divide evenly over ranks"
     r_lo, r_hi = parallel.shard_bounds(cfg["R"], world, rank)
     T, C, L, step = cfg["T"], cfg["C"], cfg["L"], cfg["step"]
@@ -289,12 +445,21 @@ def main():
                 "achieved": round(achieved, 3), "peak": peak,
                 "unit": unit, "frac": round(achieved / peak, 4),
                 # HBM bytes per launch from the rocprofv3 PMC passes over this command (FETCH_SIZE x2 gfx950 correction +
-                # WRITE_SIZE), read from profiles/r02_hbm_traffic.json; null when absent / measured on other sources
+                # WRITE_SIZE), read from profiles/r03_hbm_traffic.json; null when absent / measured on other sources
                 "traffic": traffic, "traffic_source": traffic_src,
                 "kernel_ms": round(stage_ms[dominant], 4),
-                "note": ("f32-equivalent flops of the Hermitian rank-n_obs update (8*n_obs*C(C+1)/2 per bin, "
-                         "triangle only) over the f32 MFMA peak; the kernel runs them as six bf16 cross terms "
-                         "and also produces the per-observation |Im s| plane in the same launch"),
+                "frac_is": ("f32-equivalent flops of the Hermitian rank-n_obs update, upper triangle only "
+                            "(8*n_obs*C(C+1)/2 per bin), over the f32 MFMA peak" if bound == "mfma" else
+                            "algorithmic bytes over the HBM peak"),
+                "note": ("the kernel runs the update as six bf16 cross terms on the bf16 matrix pipe and also produces the "
+                         "per-observation |Im s| plane in the same launch; the other normalisations are beside `frac`"),
+                **({} if bound != "mfma" else {
+                    "flops_triangle": work,
+                    # SURVEY 8(d) counts the full C x C matrix (the mirror is free on this design): same time, twice the flops
+                    "flops_full_matrix": 8.0 * n_obs_loc * C * C * W * F,
+                    "frac_full_matrix": round(8.0 * n_obs_loc * C * C * W * F / dur_s / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                    # the pipe the products really run on: 6 bf16 cross terms per f32-equivalent product
+                    "frac_bf16_pipe": round(6.0 * work / dur_s / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)}),
                 # the whole step against both rooflines of SURVEY section 8(d) (the binding one is the larger time):
                 # algorithmic bytes of the two-pass design over the HBM peak, triangle-only CSM flops over the f32 MFMA peak
                 "whole_path": (lambda t_hbm, t_mfma: {

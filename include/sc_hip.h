@@ -315,10 +315,12 @@ int sc_last_timing(sc_timing* out, int max_entries, int* n_entries);
  *               elsewhere (diagonal, pairs not requested, non-positive values)
  *   d_n_iter    int32 [n_groups*n_pairs] Wilson iterations used per problem
  *   d_status    int32 [n_groups*n_pairs]: 1 converged, 0 hit max_iter
- *   h_summary   optional HOST int32[3]: {iterations run, problems not converged, problems whose lag-0
- *               covariance was not positive definite}.  The reference starts those from the Cholesky factor of a
- *               random Wishart draw around the identity (minimum_phase_decomposition.py:78-93, global NumPy
- *               generator); here they start from its expectation, the identity.
+ *   h_summary   optional HOST int32[3]: {iterations run, problems not converged, problems restarted because a lag-0
+ *               covariance of their batch was not positive definite}.  The reference's batched Cholesky fails as a
+ *               whole: every window of the channel pair then starts from the Cholesky factor of a random Wishart
+ *               draw around a multiple of the identity (minimum_phase_decomposition.py:78-93, global NumPy generator);
+ *               here every (group, pair) problem of such a pair starts from its expectation, the identity -- the
+ *               start matters, the fixed point reached at a finite N depends on it (tests/golden/f12_*).
  *   flags       SC_GRANGER_KEEP_OUTPUT: do not NaN-fill d_out first (the caller walks a long pair list in chunks
  *               that share one output; any number of (group, pair) problems is accepted per call, the workspace
  *               is what grows: n_groups * n_pairs * N * 160 bytes)

@@ -141,6 +141,28 @@ def gen_f11_post(T, Cn, mpd, sim):
     save("f11_post", **arrs)
 
 
+def gen_f12_cholesky_fallback(T, Cn, mpd, sim):
+    """F12: a window whose lag-0 covariance has no Cholesky factor (a channel silent in the second window).  The
+    reference then restarts EVERY window of the affected pairs from a random positive-definite matrix
+    (minimum_phase_decomposition.py:78-93): np.random.seed fixes the draw.  Stored: the prediction for two seeds -- what
+    the good windows converge to from a non-Cholesky start (seed-to-seed spread ~1e-5: the iteration stops on
+    max|dG| < 1e-8, not at the limit) and what the degenerate window gives (NaN, or 1e-15-size noise)."""
+    rng = np.random.default_rng(7)
+    n_t, R, C = 512, 30, 3
+    e = rng.standard_normal((n_t, R, C))
+    x = np.zeros_like(e)
+    for t in range(2, n_t):
+        x[t] = 0.5 * x[t - 1] - 0.3 * x[t - 2] + e[t]
+        x[t, :, 1] += 0.4 * x[t - 1, :, 0]
+    x[256:, :, 2] = 0.0
+    m = T.Multitaper(x, sampling_frequency=200, time_halfbandwidth_product=2, n_time_samples_per_window=256)
+    out = {}
+    for seed in (0, 1):
+        np.random.seed(seed)
+        out[f"granger_seed{seed}"] = Cn.Connectivity.from_multitaper(m).pairwise_spectral_granger_prediction()
+    save("f12_cholesky_fallback", x=x, fs=200.0, NW=2.0, L=256, **out)
+
+
 def gen_api_surface(*_):
     """Public names of the reference (functions, classes, methods, properties) with their argument names and default
     values, as data: tests/golden/api_surface.json.  The drop-in mirrors exactly this surface."""
@@ -189,7 +211,8 @@ def main():
     T, Cn, mpd, sim = import_reference()
     if len(sys.argv) > 1:                      # python oracle/gen_golden.py f9 : only the named fixtures
         for name in sys.argv[1:]:
-            {"f9": gen_f9_mvar, "f10": gen_f10_global, "f11": gen_f11_post, "api": gen_api_surface}[name](T, Cn, mpd, sim)
+            {"f9": gen_f9_mvar, "f10": gen_f10_global, "f11": gen_f11_post, "f12": gen_f12_cholesky_fallback,
+             "api": gen_api_surface}[name](T, Cn, mpd, sim)
         return
     Multitaper, Connectivity = T.Multitaper, Cn.Connectivity
 
@@ -335,6 +358,7 @@ def main():
     gen_f9_mvar(T, Cn, mpd, sim)
     gen_f10_global(T, Cn, mpd, sim)
     gen_f11_post(T, Cn, mpd, sim)
+    gen_f12_cholesky_fallback(T, Cn, mpd, sim)
     gen_api_surface()
 
 

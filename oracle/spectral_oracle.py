@@ -331,8 +331,9 @@ def minimum_phase_decomposition(csm, tolerance=1e-8, max_iterations=60, return_i
     """Wilson spectral factorisation, minimum_phase_decomposition.py:227-322.
 
     csm: (W, N, c, c) two-sided.  G0 = chol(Re ifft_n(S)[lag 0])^H broadcast over n
-    (:48-77; stored in a REAL array, :294-295 -- the reference's Cholesky-failure random
-    fallback is not restated: a LinAlgError propagates like connectivity.py:2333 expects).
+    (:48-77; stored in a REAL array, :294-295).  When that Cholesky fails for ANY window of the batch, every window
+    starts from the lower Cholesky factor of the mean of 1000 products Z Z^T of standard-normal matrices drawn
+    with numpy's GLOBAL generator (:78-93: np.random.seed pins it; no transpose on this branch).
     Iterate A = G^-1 (G^-1 S)^H + I (:184-224); a = ifft_n(A); a[0] *= 1/2; strict lower
     triangle of a[0] = 0; a[n >= (N+1)//2] = 0; A+ = fft_n(a) (:96-142); G <- G A+;
     windows already converged keep G (:310-312); converged(w) = max|G - G_old| < tol
@@ -341,7 +342,13 @@ def minimum_phase_decomposition(csm, tolerance=1e-8, max_iterations=60, return_i
     n_win, n_fft, c = csm.shape[0], csm.shape[-3], csm.shape[-1]
     eye = np.eye(c)
     converged = np.zeros(n_win, dtype=bool)
-    g0 = np.linalg.cholesky(ifft(csm, axis=-3)[..., 0:1, :, :].real).swapaxes(-1, -2)
+    try:
+        g0 = np.linalg.cholesky(ifft(csm, axis=-3)[..., 0:1, :, :].real).swapaxes(-1, -2)
+    except np.linalg.LinAlgError:
+        shape = list(csm.shape)
+        shape[-3] = 1000
+        z = np.random.standard_normal(size=shape)
+        g0 = np.linalg.cholesky(np.matmul(z, _ct(z)).mean(axis=-3, keepdims=True))
     G = np.zeros(csm.shape)                 # real on purpose (reference quirk)
     G[...] = g0
     lower = np.tril_indices(c, k=-1)

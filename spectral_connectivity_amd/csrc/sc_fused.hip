@@ -702,8 +702,13 @@ __global__ void __launch_bounds__(FU_THREADS) fused_csm_absim_kernel(FusedArgs p
     constexpr size_t plane_bytes = (size_t)2 * NB32 * 32 * FU_CSTRIDE * 2;
     constexpr size_t red_bytes = (size_t)4 * FU_MAXB * 16 * 64 * sizeof(float);
     float* raw = reinterpret_cast<float*>(smem + (plane_bytes > red_bytes ? plane_bytes : red_bytes));
-    if (wave < 4) fused_mfma_role<NB32>(p, st, planes, raw, tid, wave, rec, o_lo);
-    else fused_valu_role<NB32, OP, CROSS>(p, st, planes, raw, tid, wave - 4, rec, o_lo);
+    if (wave < 4) {
+        if (p.debug_skip & 32) __builtin_amdgcn_s_setprio(2);
+        fused_mfma_role<NB32>(p, st, planes, raw, tid, wave, rec, o_lo);
+    } else {
+        if (p.debug_skip & 16) __builtin_amdgcn_s_setprio(2);
+        fused_valu_role<NB32, OP, CROSS>(p, st, planes, raw, tid, wave - 4, rec, o_lo);
+    }
 }
 
 // accum[bin][plane] += ws[0][bin][plane] + ws[1][bin][plane] + ... for the CSM (re, im) and (if present) |Im| planes

@@ -214,6 +214,22 @@ __global__ void __launch_bounds__(256) m_chol(double* __restrict__ r0g, int32_t*
     }
 }
 
+// The reference's batched Cholesky fails as a whole (minimum_phase_decomposition.py:78-93): one window without a factor
+// restarts EVERY window from its random draw (expectation: a multiple of the identity), and at a finite FFT length the
+// fixed point depends on the start -- so one failing window puts the identity into all of them (see k_restart in
+// sc_wilson.hip); *n_fallback then counts the windows restarted.
+__global__ void __launch_bounds__(256) m_restart_all(double* __restrict__ r0g, int32_t* n_fallback, int64_t P, int C) {
+    if (*n_fallback == 0) return;
+    const int64_t total = P * C * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int e = (int)(i % ((int64_t)C * C));
+        r0g[i] = (e / C == e % C) ? 1.0 : 0.0;
+    }
+}
+__global__ void m_restart_count(int32_t* n_fallback, int32_t P) {
+    if (*n_fallback > 0) *n_fallback = P;
+}
+
 // G[p][e][n] = G0[p][e] for every n
 __global__ void m_fill(const double* __restrict__ g0, cd* __restrict__ G, int64_t N, int E) {
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1158,6 +1174,8 @@ extern "C" int sc_mvar_factor_f64(const void* d_accum, const void* d_S, int64_t 
     else hipLaunchKernelGGL(m_lag0, dim3((unsigned)(((int64_t)P * E + 3) / 4)), dim3(256), 0, st, S, g0, N, (int64_t)P * E);
     SC_CHECK_HIP(hipFuncSetAttribute((const void*)m_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)E * 8)));
     hipLaunchKernelGGL(m_chol, dim3((unsigned)P), dim3(256), (size_t)E * 8, st, g0, d_status, n_fallback, (int)C);
+    hipLaunchKernelGGL(m_restart_all, dim3(64), dim3(256), 0, st, g0, n_fallback, (int64_t)P, (int)C);
+    hipLaunchKernelGGL(m_restart_count, dim3(1), dim3(1), 0, st, n_fallback, (int32_t)P);
     if (big) hipLaunchKernelGGL(m_fill_nat, dim3((unsigned)((E + 255) / 256), (unsigned)N, (unsigned)P), dim3(256), 0, st, g0, G, N, E);
     else hipLaunchKernelGGL(m_fill, gridE, dim3(256), 0, st, g0, G, N, E);
     // The stream is synchronised once per MV_POLL iterations: every iteration logs how many windows are still running

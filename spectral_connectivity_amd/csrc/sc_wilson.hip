@@ -81,10 +81,16 @@ __global__ void k_build(ScRec accum, const int32_t* pairs, WilsonDims d, double*
 
 // one block per problem: lag-0 covariance = mean_n Re S[n]; G0 = chol(R0)^H broadcast over n.
 // Where the covariance is not positive definite the reference (minimum_phase_decomposition.py:78-93) logs a
-// warning and starts from the Cholesky factor of a random Wishart matrix -- mean of 1000 outer products of
-// standard normal vectors, i.e. the identity plus O(3 %) noise drawn from the GLOBAL NumPy generator.  Here such a
-// problem starts from the expectation of that draw, G0 = I (deterministic), and is counted in *n_fallback.
-__global__ void __launch_bounds__(256) k_init(const double* S, cd* G, int32_t* status, int32_t* n_fallback, int64_t N) {
+// warning and starts from the Cholesky factor of a random Wishart matrix -- mean of 1000 products Z Z^T of standard
+// normal matrices, i.e. c I plus O(3 %) noise drawn from the GLOBAL NumPy generator -- and it does so for the WHOLE
+// batch its batched Cholesky was called on: every window of that channel pair, the healthy ones included.  That
+// matters: at a finite FFT length the fixed point the iteration reaches depends on the start (measured on
+// tests/golden/f12: 2e-3 of the prediction between the Cholesky start and the restart, 2e-5 between restarts of any
+// scale or seed).  So a failing problem flags its batch (problems p with the same p % n_batch: the windows of one
+// pair; n_batch = 1: everything handed to sc_wilson_factor_f64) and k_restart puts the expectation of the reference's
+// draw, the identity, into every problem of a flagged batch; *n_fallback counts the problems restarted.
+__global__ void __launch_bounds__(256) k_init(const double* S, cd* G, int32_t* status, int32_t* batch_bad, int64_t n_batch,
+                                              int64_t N) {
     __shared__ double red[3][256];
     const int64_t p = blockIdx.x;
     const double* Sp = S + p * 4 * N;
@@ -106,12 +112,23 @@ __global__ void __launch_bounds__(256) k_init(const double* S, cd* G, int32_t* s
     if (bad) { l00 = 1.0; l10 = 0.0; l11 = 1.0; }
     if (threadIdx.x == 0) {
         status[p] = 0;
-        if (bad) atomicAdd(n_fallback, 1);
+        if (bad) atomicOr(batch_bad + p % n_batch, 1);
     }
     cd* Gp = G + p * 4 * N;
     for (int64_t n = threadIdx.x; n < N; n += 256) {
         Gp[n] = make_double2(l00, 0); Gp[N + n] = make_double2(l10, 0);
         Gp[2 * N + n] = make_double2(0, 0); Gp[3 * N + n] = make_double2(l11, 0);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_restart(cd* G, const int32_t* batch_bad, int64_t n_batch, int32_t* n_fallback, int64_t N) {
+    const int64_t p = blockIdx.x;
+    if (!batch_bad[p % n_batch]) return;
+    if (threadIdx.x == 0) atomicAdd(n_fallback, 1);
+    cd* Gp = G + p * 4 * N;
+    for (int64_t n = threadIdx.x; n < N; n += 256) {
+        Gp[n] = make_double2(1.0, 0); Gp[N + n] = make_double2(0, 0);
+        Gp[2 * N + n] = make_double2(0, 0); Gp[3 * N + n] = make_double2(1.0, 0);
     }
 }
 
@@ -359,7 +376,7 @@ static WilsonWork wilson_carve(void* d_work, int64_t P, int64_t N) {
 // k_init + the Wilson iteration on work.S -> work.G.  The stream is synchronised once per WILSON_POLL iterations:
 // every iteration logs how many problems are still running into its own slot, converged problems are skipped by
 // every kernel, so queueing a few iterations past the last convergence changes nothing but costs empty launches.
-static int wilson_iterate(const WilsonWork& k, int64_t P, int64_t N, double tol, int max_iter,
+static int wilson_iterate(const WilsonWork& k, int64_t P, int64_t n_batch, int64_t N, double tol, int max_iter,
                           int32_t* d_n_iter, int32_t* d_status, int* iters_out, int* running_out, int* fallback_out,
                           hipStream_t st) {
     int rc = SC_OK;
@@ -391,7 +408,10 @@ static int wilson_iterate(const WilsonWork& k, int64_t P, int64_t N, double tol,
     (void)hipMemsetAsync(k.err, 0, (size_t)P * 8, st);
     (void)hipMemsetAsync(d_n_iter, 0, (size_t)P * 4, st);
     (void)hipMemsetAsync(k.n_fallback, 0, 256 + (size_t)WILSON_HIST * 4, st);      // fallback count + the slots
-    hipLaunchKernelGGL(k_init, dim3((unsigned)P), dim3(256), 0, st, k.S, k.G, d_status, k.n_fallback, N);
+    // (the per-batch flags borrow the start of the error array: P doubles >= n_batch ints, cleared again below)
+    hipLaunchKernelGGL(k_init, dim3((unsigned)P), dim3(256), 0, st, k.S, k.G, d_status, (int32_t*)k.err, n_batch, N);
+    hipLaunchKernelGGL(k_restart, dim3((unsigned)P), dim3(256), 0, st, k.G, (const int32_t*)k.err, n_batch, k.n_fallback, N);
+    (void)hipMemsetAsync(k.err, 0, (size_t)P * 8, st);
     hipLaunchKernelGGL(k_predict, gridN, dim3(256), 0, st, k.S, k.G, d_status, k.A, N, P);
     while (queued < max_iter && running > 0) {
         const int first = queued;
@@ -464,7 +484,7 @@ extern "C" int sc_granger_pairwise_f64(const void* d_accum, int64_t n_groups, in
                            n_groups * Fout * C * C);
     hipLaunchKernelGGL(k_build, gridN, dim3(256), 0, st, sc_rec(d_accum, planes), d_pairs, d, k.S);
     int iters = 0, running = 0, fallback = 0;
-    const int rc = wilson_iterate(k, P, N, tol, max_iter, d_n_iter, d_status, &iters, &running, &fallback, st);
+    const int rc = wilson_iterate(k, P, n_pairs, N, tol, max_iter, d_n_iter, d_status, &iters, &running, &fallback, st);
     if (rc != SC_OK) return rc;
     hipLaunchKernelGGL(k_h0, dim3((unsigned)P), dim3(256), 0, st, k.G, k.h0, N);
     hipLaunchKernelGGL(k_pair_consts, dim3((unsigned)((n_pairs + 63) / 64)), dim3(64), 0, st, k.h0, k.hinv, k.rot,
@@ -494,7 +514,7 @@ extern "C" int sc_wilson_factor_f64(const double* d_S, int64_t n_problems, int64
     const WilsonWork k = wilson_carve(d_work, n_problems, N);
     SC_CHECK_HIP(hipMemcpyAsync(k.S, d_S, (size_t)n_problems * N * 4 * 8, hipMemcpyDeviceToDevice, st));
     int iters = 0, running = 0, fallback = 0;
-    const int rc = wilson_iterate(k, n_problems, N, tol, max_iter, d_n_iter, d_status, &iters, &running, &fallback, st);
+    const int rc = wilson_iterate(k, n_problems, 1, N, tol, max_iter, d_n_iter, d_status, &iters, &running, &fallback, st);
     if (rc != SC_OK) return rc;
     SC_CHECK_HIP(hipMemcpyAsync(d_G, k.G, (size_t)n_problems * N * 4 * 16, hipMemcpyDeviceToDevice, st));
     SC_CHECK_HIP(hipStreamSynchronize(st));

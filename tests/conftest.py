@@ -24,13 +24,59 @@ def golden():
     return load_golden
 
 
+def pytest_generate_tests(metafunc):
+    """A module that declares ``SC_PRECISIONS = ("float32", "dtype")`` runs every test once per engine selection: forced
+    float32 (the headline path) and the package default, where ``dtype=complex128`` -- the reference's default, what
+    every test that passes no dtype gets -- selects the float64 engine."""
+    precisions = getattr(metafunc.module, "SC_PRECISIONS", None)
+    if precisions and "_engine_precision" in metafunc.fixturenames:
+        metafunc.parametrize("_engine_precision", list(precisions), indirect=True,
+                             ids=["f32-engine" if p == "float32" else "default-engine" for p in precisions])
+
+
 @pytest.fixture(autouse=True)
 def _engine_precision(request):
     """Test modules exercise the float32 engine (the headline path, north_star's tolerance) unless they declare
-    ``SC_PRECISION``: tests/test_gpu_fp64.py runs with "dtype" -- the package default, where ``dtype=complex128`` (the
-    reference's default) selects the float64 engine."""
+    ``SC_PRECISION`` (tests/test_gpu_fp64.py runs with "dtype" -- the package default) or ``SC_PRECISIONS`` (both,
+    see pytest_generate_tests)."""
     from spectral_connectivity_amd import options
     old = options.precision
-    options.precision = getattr(request.module, "SC_PRECISION", "float32")
-    yield
+    options.precision = getattr(request, "param", None) or getattr(request.module, "SC_PRECISION", "float32")
+    yield options.precision
     options.precision = old
+
+
+def granger_close(got, ref, tol, what="granger"):
+    """Spectral Granger predictions against a reference: entries finite in both within ``tol`` of the array maximum;
+    an entry that is NaN in exactly one of the two is a prediction the reference's `gp[gp <= 0] = nan`
+    (connectivity.py:1825-1848) cut on one side only -- legitimate only where the value is within ``tol`` of zero, so
+    the finite one is held to that (not to a share of the entries)."""
+    got, ref = np.asarray(got), np.asarray(ref)
+    assert got.shape == ref.shape, f"{what}: shape {got.shape} != {ref.shape}"
+    scale = np.nanmax(ref)
+    both = ~np.isnan(got) & ~np.isnan(ref)
+    err = np.abs(got[both] - ref[both]).max() if both.any() else 0.0
+    assert err <= tol * scale, f"{what}: max err {err:.3e} > {tol:.1e} x {scale:.3e}"
+    only_ref, only_got = ~np.isnan(ref) & np.isnan(got), np.isnan(ref) & ~np.isnan(got)
+    worst = max(np.abs(ref[only_ref]).max() if only_ref.any() else 0.0, np.abs(got[only_got]).max() if only_got.any() else 0.0)
+    assert worst <= tol * scale, (f"{what}: an entry that is NaN on one side only has magnitude {worst:.3e} on the other "
+                                  f"(> {tol:.1e} x {scale:.3e}); {int(only_ref.sum() + only_got.sum())} one-sided NaNs")
+
+
+
+def unpack_record_planes(accum, C):
+    """Accumulator records [n_bins, n_planes * n_tiles * 256] (include/sc_hip.h: upper-triangular 16 x 16 channel tiles,
+    tile index = bi NB - bi (bi - 1) / 2 + (bj - bi)) -> [n_bins, n_planes, C, C] float64, NaN where no tile holds the
+    entry (below the diagonal tiles)."""
+    rec = np.asarray(accum, dtype=np.float64)
+    n_bins = rec.shape[0]
+    NB = (C + 15) // 16
+    n_tiles = NB * (NB + 1) // 2
+    n_planes = rec.shape[1] // (n_tiles * 256)
+    tiles = rec.reshape(n_bins, n_planes, n_tiles, 16, 16)
+    out = np.full((n_bins, n_planes, NB * 16, NB * 16), np.nan)
+    for bi in range(NB):
+        for bj in range(bi, NB):
+            t = bi * NB - bi * (bi - 1) // 2 + (bj - bi)
+            out[:, :, bi * 16:(bi + 1) * 16, bj * 16:(bj + 1) * 16] = tiles[:, :, t]
+    return out[:, :, :C, :C]

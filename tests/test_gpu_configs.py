@@ -149,9 +149,8 @@ def test_cfg4_granger_reduced_vs_oracle_and_full_size(sc):
     got = c.subset_pairwise_spectral_granger_prediction(pairs)
     coef, _ = so.multitaper_fft(x, fs=FS, NW=3)
     ref = so.pairwise_spectral_granger_prediction(coef, pairs=pairs)
-    both = ~np.isnan(got) & ~np.isnan(ref)
-    assert (np.isnan(got) != np.isnan(ref)).mean() < 0.01
-    assert np.abs(got[both] - ref[both]).max() <= 3e-5 * np.nanmax(ref)
+    from conftest import granger_close
+    granger_close(got, ref, 3e-5, what="cfg4 subset")
     # full size: 200 trials, every pair
     x = simulate(200).astype(np.float32)
     m = sc.Multitaper(x, sampling_frequency=FS, time_halfbandwidth_product=3)
