@@ -389,7 +389,7 @@ int sc_mvar_measure_f64(const void* d_G /*complex128*/, int64_t n_groups, int64_
  * n_signals x (n_trials n_tapers) coefficient matrix per (window, two-sided bin) are the leading
  * eigenpairs of the cross-spectral matrix; parallel cyclic Jacobi in LDS, n_signals <=
  * sc_global_coherence_max_signals() (256; beyond 64 signals the eigenvectors come from a logged rotation
- * sequence, max_rank <= 4, and the call synchronises the stream).  d_accum: records with SC_PLANE_CSM accumulated over
+ * sequence applied to batches of unit vectors, any max_rank <= n_signals, and the call synchronises the stream).  d_accum: records with SC_PLANE_CSM accumulated over
  * trials and tapers, N or N/2+1 bins per window (real-input symmetry completes the rest).
  * d_values: double [n_groups][N][max_rank]; d_vectors: complex128 [n_groups][N][n_signals][max_rank],
  * unit norm, largest component real positive (the reference's phase is LAPACK's/ARPACK's).

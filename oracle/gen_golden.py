@@ -163,6 +163,19 @@ def gen_f12_cholesky_fallback(T, Cn, mpd, sim):
     save("f12_cholesky_fallback", x=x, fs=200.0, NW=2.0, L=256, **out)
 
 
+def gen_f13_canonical_few_observations(T, Cn, mpd, sim):
+    """F13: canonical coherence with fewer observations than a group has channels (n_trials * n_tapers = 6; groups of 8,
+    4 and 2 channels, then 6, 6 and 2): every pair with such a group comes out 1, the others as usual."""
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((128, 2, 14))
+    x[:, :, 3] += x[:, :, 9]
+    m = T.Multitaper(x, sampling_frequency=100, time_halfbandwidth_product=2)
+    c = Cn.Connectivity.from_multitaper(m)
+    la, lb = np.array([0] * 8 + [1] * 4 + [2] * 2), np.array([0] * 6 + [1] * 6 + [2] * 2)
+    save("f13_canonical_few_obs", x=x, fs=100.0, NW=2.0, labels_a=la, labels_b=lb,
+         cc_a=c.canonical_coherence(la)[0], cc_b=c.canonical_coherence(lb)[0])
+
+
 def gen_api_surface(*_):
     """Public names of the reference (functions, classes, methods, properties) with their argument names and default
     values, as data: tests/golden/api_surface.json.  The drop-in mirrors exactly this surface."""
@@ -212,7 +225,7 @@ def main():
     if len(sys.argv) > 1:                      # python oracle/gen_golden.py f9 : only the named fixtures
         for name in sys.argv[1:]:
             {"f9": gen_f9_mvar, "f10": gen_f10_global, "f11": gen_f11_post, "f12": gen_f12_cholesky_fallback,
-             "api": gen_api_surface}[name](T, Cn, mpd, sim)
+             "f13": gen_f13_canonical_few_observations, "api": gen_api_surface}[name](T, Cn, mpd, sim)
         return
     Multitaper, Connectivity = T.Multitaper, Cn.Connectivity
 
@@ -359,6 +372,7 @@ def main():
     gen_f10_global(T, Cn, mpd, sim)
     gen_f11_post(T, Cn, mpd, sim)
     gen_f12_cholesky_fallback(T, Cn, mpd, sim)
+    gen_f13_canonical_few_observations(T, Cn, mpd, sim)
     gen_api_surface()
 
 

@@ -466,8 +466,6 @@ class Connectivity:
             raise ValueError(f"max_rank must be between 1 and min(n_signals, n_trials * n_tapers) = {min(C, R * K)}")
         if C > _lib.load().sc_global_coherence_max_signals():
             raise ValueError(f"global_coherence supports n_signals <= {_lib.load().sc_global_coherence_max_signals()}")
-        if C > 64 and max_rank > 4:
-            raise ValueError("global_coherence with more than 64 signals returns at most 4 components")
         planes = _lib.PLANE_CSM
         accum, n_obs, n_freq = self._csm_records("global", "trials_tapers")
         values, vectors = engine.global_coherence(accum, W, n_freq, N, C, planes, self._n_observations_total(n_obs),
@@ -488,15 +486,32 @@ class Connectivity:
         planes = _lib.PLANE_CSM
         accum, n_obs, _ = self._csm_records("canonical", "trials_tapers", two_sided=False)
         n_total = self._n_observations_total(n_obs)
-        if max(len(g) for g in groups) > n_total:
-            raise ValueError("canonical_coherence needs n_trials * n_tapers >= the largest group size "
-                             "(the cross-spectral blocks are rank deficient otherwise)")
+        # A group with at least as many channels as there are observations spans the whole observation space: the
+        # orthonormal row-space basis V_g the reference gets from its thin SVD (connectivity.py:1979-2032) is then the full
+        # n_obs-dimensional space, V_g^H V_h has orthonormal columns for ANY other group h, and every singular value of the
+        # pair is 1 -- the canonical coherence is 1 (the reference returns 1 +- 3e-15 there: generic, full-row-rank data).
+        # Such groups have no Cholesky factor (their cross-spectral block is rank deficient), so they stay out of the
+        # device kernel; the pairs among the remaining groups go through the CSM form as before.
+        small = [k for k, g in enumerate(groups) if len(g) < n_total]
+        max_group = int(_lib.load().sc_canonical_max_group())
+        if any(len(groups[k]) > max_group for k in small):
+            raise ValueError(f"canonical_coherence: groups of more than {max_group} channels need n_trials * n_tapers "
+                             "<= the group size (their coherence is then 1) -- the whitening kernel takes up to "
+                             f"{max_group} channels per group")
         lo, hi, per = self._canonical_bins(accum.shape[0])
+        n_g = len(groups)
+        import torch
         if hi > lo:
-            out, n_fail = engine.canonical_coherence(accum[lo:hi], self._shape5[4], planes, n_total, groups)
+            out = torch.ones((hi - lo, n_g, n_g), dtype=torch.float64, device=accum.device)
+            out[:, torch.arange(n_g), torch.arange(n_g)] = float("nan")
+            n_fail = 0
+            if len(small) >= 2:
+                sub, n_fail = engine.canonical_coherence(accum[lo:hi], self._shape5[4], planes, n_total,
+                                                         [groups[k] for k in small])
+                idx = torch.as_tensor(small, device=accum.device)
+                out[:, idx[:, None], idx[None, :]] = sub
         else:                                  # more processes than bins: this one has nothing to evaluate
-            import torch
-            out, n_fail = torch.empty((0, len(groups), len(groups)), dtype=torch.float64, device=accum.device), 0
+            out, n_fail = torch.empty((0, n_g, n_g), dtype=torch.float64, device=accum.device), 0
         out = self._canonical_gather(out, accum.shape[0], per)
         if n_fail:
             logger.warning(f"{n_fail} group cross-spectral blocks were not positive definite (NaN output)")

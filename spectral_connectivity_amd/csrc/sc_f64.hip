@@ -16,6 +16,7 @@
 // elements.  Workgroup = 4 waves = one bin x one tile group; observation rows staged HBM -> registers -> LDS in chunks
 // of 16 (double buffered, one barrier per chunk); XCD-aware blockIdx -> (bin, tile group) like sc_csm.hip.
 #include <cstdlib>
+#include <mutex>
 #include "sc_common.h"
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
@@ -356,7 +357,9 @@ __global__ void __launch_bounds__(256, 2) nonlinear_f64_block_kernel(F64Args p) 
         for (int row = wave; row < F64B_OC; row += 4) {
             const double2* rp = cur + row * 128;
             // all sixteen operands of the row are requested before the first product (one LDS round trip per row, hidden by
-            // the SIMD's other wave; loaded one column at a time the compiler waits for each of them)
+            // the SIMD's other wave; loaded one column at a time the compiler waits for each of them).  (Tried in round 3:
+            // the next row's operands requested under this row's products -- 128 accumulator + 2 x 64 operand + 32 staging
+            // registers exceed the 256 of a lane: 230-560 spilled dwords, not kept.)
             double2 xi[8], xjv[8];
 #pragma unroll
             for (int a = 0; a < 8; ++a) xi[a] = rp[li + 8 * a];
@@ -526,14 +529,33 @@ extern "C" int sc_accumulate_f64(const void* d_X, const sc_spectra_desc* desc, u
     // no more to gain from overlapping them: forced to share every CU (one workgroup of each) the pair runs SLOWER
     // (22 ms) -- on MI355X the fp64 matrix rate equals the fp64 vector rate, the two kernels compete for the same
     // arithmetic, and their sum, 0.47 T lane-operations at cfg3 = 11.9 ms at 2.4 GHz, is the bound of this engine.
-    static hipStream_t side = nullptr;
-    static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // One side stream per DEVICE (created under a lock on the device that is current at the call), and a fresh event
+    // pair per CALL: two host threads, or two devices, never share an event -- a shared pair would let one call's join
+    // wait on the other's record.
     const bool fork = (which & SC_PLANE_CSM) && (which & ~SC_PLANE_CSM) && a.C >= 48 && !getenv("SC_F64_NO_FORK");
-    if (fork && !side) {
-        if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    struct EventPair {            // destroyed when the call returns (hipEventDestroy defers the release past pending work)
+        hipEvent_t &a, &b;
+        ~EventPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    } ev_guard{ev_fork, ev_join};
+    if (fork) {
+        static std::mutex mu;
+        static hipStream_t side_of_device[64] = {nullptr};
+        int dev = 0;
+        SC_CHECK_HIP(hipGetDevice(&dev));
+        SC_REQUIRE(dev >= 0 && dev < 64, "device index out of range");
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (!side_of_device[dev] && hipStreamCreateWithFlags(&side_of_device[dev], hipStreamNonBlocking) != hipSuccess) {
+                sc_set_error("sc_accumulate_f64: side stream creation failed");
+                return SC_EHIP;
+            }
+            side = side_of_device[dev];
+        }
+        if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess) {
-            sc_set_error("sc_accumulate_f64: side stream creation failed");
+            sc_set_error("sc_accumulate_f64: event creation failed");
             return SC_EHIP;
         }
     }

@@ -190,9 +190,11 @@ struct GcBigArgs {
     double* log;           // [slots][GC_BIG_SWEEPS * (M - 1)][M / 2][3]  (cos, Re s, Im s)
     cd* scratch;           // [slots][C (C + 1) / 2] packed triangles when they do not fit LDS (n_signals > 128), else NULL
     int n_bins_total;
+    int batch;             // eigenvectors back-applied at a time (what the LDS holds)
 };
 
-__global__ void __launch_bounds__(256) global_coherence_big_kernel(GcBigArgs b) {
+template <int NT>
+__global__ void __launch_bounds__(NT) global_coherence_big_kernel(GcBigArgs b) {
     extern __shared__ __align__(16) unsigned char gc_smem[];
     const GcArgs& a = b.g;
     const int C = a.C, M = C + (C & 1), H = M / 2;
@@ -207,13 +209,15 @@ __global__ void __launch_bounds__(256) global_coherence_big_kernel(GcBigArgs b) 
     int* order = reinterpret_cast<int*>(ev + C);                       // [C]
     unsigned short* blk_u = reinterpret_cast<unsigned short*>(order + C + (C & 1));   // [H (H+1) / 2] block -> pair u
     unsigned short* blk_v = blk_u + H * (H + 1) / 2;                                  //                   pair v >= u
-    cd* xv = reinterpret_cast<cd*>((reinterpret_cast<uintptr_t>(blk_v + H * (H + 1) / 2) + 15) & ~(uintptr_t)15);
-                                                                       // [max_rank <= 4][C] back-applied vectors
-    __shared__ double red[2][256];
+    // back-applied vectors, a batch of b.batch at a time: behind the tables (matrix in the global scratch), or IN the
+    // space of the packed triangle, which is dead once its diagonal has been copied to ev (matrix in LDS)
+    cd* xv = b.scratch ? reinterpret_cast<cd*>((reinterpret_cast<uintptr_t>(blk_v + H * (H + 1) / 2) + 15) & ~(uintptr_t)15)
+                       : reinterpret_cast<cd*>(gc_smem);
+    __shared__ double red[2][NT];
     __shared__ int done, n_rounds;
     const int tid = threadIdx.x;
     double* mylog = b.log + (size_t)blockIdx.x * GC_BIG_SWEEPS * (M - 1) * H * 3;
-    gc_block_table(blk_u, blk_v, H, tid);               // once per workgroup
+    gc_block_table<NT>(blk_u, blk_v, H, tid);           // once per workgroup
     for (int item = blockIdx.x; item < b.n_bins_total; item += gridDim.x) {
         const int64_t p = item / a.N, n = item - p * a.N;
         int64_t bin = n;
@@ -221,7 +225,7 @@ __global__ void __launch_bounds__(256) global_coherence_big_kernel(GcBigArgs b) 
         if (!a.two_sided && n > a.N / 2) { bin = a.N - n; conj = true; }
         const ScRec rec = a.accum + (p * a.F + bin) * a.floats_per_bin;
         __syncthreads();
-        for (int e = tid; e < C * C; e += 256) {
+        for (int e = tid; e < C * C; e += NT) {
             const int i = e / C, j = e % C;
             if (i > j) continue;
             const int ti = i >> 4, tj = j >> 4, ii = i & 15, jj = j & 15;      // i <= j: upper triangle, no mirror
@@ -233,11 +237,11 @@ __global__ void __launch_bounds__(256) global_coherence_big_kernel(GcBigArgs b) 
             A[gc_tri(i, j, C)] = make_double2(re, im);
         }
         __syncthreads();
-        gc_jacobi(A, C, rc, rs, rp, blk_u, blk_v, red, &done, &n_rounds, mylog, GC_BIG_SWEEPS);
+        gc_jacobi<NT>(A, C, rc, rs, rp, blk_u, blk_v, red, &done, &n_rounds, mylog, GC_BIG_SWEEPS);
         // rank the eigenvalues (descending, ties by index)
-        for (int i = tid; i < C; i += 256) ev[i] = A[gc_tri(i, i, C)].x;
-        __syncthreads();
-        for (int i = tid; i < C; i += 256) {
+        for (int i = tid; i < C; i += NT) ev[i] = A[gc_tri(i, i, C)].x;
+        __syncthreads();                                // (from here on the triangle in LDS may be overwritten by xv)
+        for (int i = tid; i < C; i += NT) {
             int rank = 0;
             for (int j = 0; j < C; ++j) rank += (ev[j] > ev[i] || (ev[j] == ev[i] && j < i)) ? 1 : 0;
             order[rank] = i;
@@ -246,40 +250,43 @@ __global__ void __launch_bounds__(256) global_coherence_big_kernel(GcBigArgs b) 
         const int K = a.max_rank;
         double* val = a.values + (p * a.N + n) * K;
         cd* vec = a.vectors + (p * a.N + n) * (int64_t)C * K;
-        for (int k = tid; k < K; k += 256) {
+        for (int k = tid; k < K; k += NT) {
             const int src = a.ascending ? order[K - 1 - k] : order[k];
             val[k] = ev[src] > 0.0 ? ev[src] : 0.0;
         }
-        // eigenvectors: x = J_1 ... J_m e_src, right to left; thread (k, pair) rotates two entries per round
-        for (int e = tid; e < K * C; e += 256) {
-            const int k = e / C, i = e % C;
-            const int src = a.ascending ? order[K - 1 - k] : order[k];
-            xv[e] = make_double2(i == src ? 1.0 : 0.0, 0.0);
-        }
-        __syncthreads();
+        // eigenvectors: x = J_1 ... J_m e_src, right to left, for a batch of requested components at a time; work item
+        // (vector, pair of the round) rotates two entries.  Any max_rank up to n_signals (the reference's full SVD).
         const int total_rounds = n_rounds;
-        for (int rr = total_rounds - 1; rr >= 0; --rr) {
-            const int r = rr % (M - 1);
-            for (int w = tid; w < K * H; w += 256) {
-                const int k = w / H, t = w % H;
-                int x, y;
-                if (t == 0) { x = M - 1; y = r; }
-                else { x = (r + t) % (M - 1); y = (r - t + (M - 1)) % (M - 1); }
-                const int pi = x < y ? x : y, qi = x < y ? y : x;
-                if (qi >= C) continue;
-                const double* lg = mylog + ((size_t)rr * H + t) * 3;
-                const double c = lg[0];
-                const cd se = make_double2(lg[1], lg[2]), sec = make_double2(lg[1], -lg[2]);
-                const cd xp = xv[k * C + pi], xq = xv[k * C + qi];
-                const cd t1 = g_mul(se, xq), t2 = g_mul(sec, xp);
-                xv[k * C + pi] = make_double2(c * xp.x + t1.x, c * xp.y + t1.y);
-                xv[k * C + qi] = make_double2(c * xq.x - t2.x, c * xq.y - t2.y);
+        for (int k0 = 0; k0 < K; k0 += b.batch) {
+            const int kb = K - k0 < b.batch ? K - k0 : b.batch;
+            for (int e = tid; e < kb * C; e += NT) {
+                const int k = k0 + e / C, i = e % C;
+                const int src = a.ascending ? order[K - 1 - k] : order[k];
+                xv[e] = make_double2(i == src ? 1.0 : 0.0, 0.0);
             }
             __syncthreads();
-        }
-        for (int k = 0; k < K; ++k) {
-            __shared__ cd phase;
-            if (tid == 0) {
+            for (int rr = total_rounds - 1; rr >= 0; --rr) {
+                const int r = rr % (M - 1);
+                for (int w = tid; w < kb * H; w += NT) {
+                    const int k = w / H, t = w % H;
+                    int x, y;
+                    if (t == 0) { x = M - 1; y = r; }
+                    else { x = (r + t) % (M - 1); y = (r - t + (M - 1)) % (M - 1); }
+                    const int pi = x < y ? x : y, qi = x < y ? y : x;
+                    if (qi >= C) continue;
+                    const double* lg = mylog + ((size_t)rr * H + t) * 3;
+                    const double c = lg[0];
+                    const cd se = make_double2(lg[1], lg[2]), sec = make_double2(lg[1], -lg[2]);
+                    const cd xp = xv[k * C + pi], xq = xv[k * C + qi];
+                    const cd t1 = g_mul(se, xq), t2 = g_mul(sec, xp);
+                    xv[k * C + pi] = make_double2(c * xp.x + t1.x, c * xp.y + t1.y);
+                    xv[k * C + qi] = make_double2(c * xq.x - t2.x, c * xq.y - t2.y);
+                }
+                __syncthreads();
+            }
+            // unit phase: the largest component real and positive (one thread per vector finds it)
+            cd* phase = reinterpret_cast<cd*>(red);     // [kb <= NT]: the reduction scratch is idle here
+            for (int k = tid; k < kb; k += NT) {
                 double best = -1.0;
                 cd bb = make_double2(1.0, 0.0);
                 for (int i = 0; i < C; ++i) {
@@ -288,10 +295,13 @@ __global__ void __launch_bounds__(256) global_coherence_big_kernel(GcBigArgs b) 
                     if (m2 > best) { best = m2; bb = v; }
                 }
                 const double ab = sqrt(best);
-                phase = ab > 0.0 ? make_double2(bb.x / ab, -bb.y / ab) : make_double2(1.0, 0.0);
+                phase[k] = ab > 0.0 ? make_double2(bb.x / ab, -bb.y / ab) : make_double2(1.0, 0.0);
             }
             __syncthreads();
-            for (int i = tid; i < C; i += 256) vec[(int64_t)i * K + k] = g_mul(xv[k * C + i], phase);
+            for (int e = tid; e < kb * C; e += NT) {
+                const int k = e / C, i = e % C;
+                vec[(int64_t)i * K + k0 + k] = g_mul(xv[k * C + i], phase[k]);
+            }
             __syncthreads();
         }
     }
@@ -323,7 +333,6 @@ extern "C" int sc_global_coherence_f64(const void* d_accum, int64_t n_groups, in
     const int M = (int)C + ((int)C & 1);
     if (C > GC_CMAX) {
         // matrix only in LDS, rotation log in a device scratch owned by this call
-        SC_REQUIRE(max_rank <= 4, "n_signals > 64: at most 4 components");
         const int H = M / 2;
         const int64_t bins = n_groups * N;
         const bool huge = C > GC_BIG_CMAX;
@@ -339,10 +348,29 @@ extern "C" int sc_global_coherence_f64(const void* d_accum, int64_t n_groups, in
         GcBigArgs b;
         b.g = a; b.log = log; b.n_bins_total = (int)bins;
         b.scratch = huge ? reinterpret_cast<cd*>(reinterpret_cast<char*>(log) + log_bytes) : nullptr;
-        const size_t lds = (huge ? 0 : tri_bytes) + (size_t)(H + 2) * 8 + (size_t)H * 16 + (size_t)(M + 2) * 4 +
-                           (size_t)C * 8 + (size_t)(C + 4) * 4 + (size_t)H * (H + 1) * 2 + 16 + (size_t)4 * C * sizeof(cd) + 64;
-        (void)hipFuncSetAttribute((const void*)global_coherence_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(global_coherence_big_kernel, dim3((unsigned)slots), dim3(256), lds, (hipStream_t)stream, b);
+        const size_t tables = (size_t)(H + 2) * 8 + (size_t)H * 16 + (size_t)(M + 2) * 4 + (size_t)C * 8 + (size_t)(C + 4) * 4 +
+                              (size_t)H * (H + 1) * 2 + 16 + 64;
+        // eigenvector batches: in the dead triangle (matrix in LDS: (C + 1) / 2 vectors), or behind the tables, 96 KB
+        const size_t vec_bytes = (size_t)C * sizeof(cd);
+        size_t xv_bytes = 0;
+        if (huge) {
+            b.batch = (int)((size_t)(96 * 1024) / vec_bytes);        // (+ 33 KB of block tables + 16 KB of reduction scratch)
+            if (b.batch > max_rank) b.batch = max_rank;
+            xv_bytes = (size_t)b.batch * vec_bytes;
+        } else {
+            b.batch = (int)(tri_bytes / vec_bytes);
+        }
+        if (b.batch > 1024) b.batch = 1024;
+        const size_t lds = (huge ? 0 : tri_bytes) + tables + xv_bytes;
+        if (huge) {
+            auto k = global_coherence_big_kernel<1024>;
+            (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(k, dim3((unsigned)slots), dim3(1024), lds, (hipStream_t)stream, b);
+        } else {
+            auto k = global_coherence_big_kernel<256>;
+            (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(k, dim3((unsigned)slots), dim3(256), lds, (hipStream_t)stream, b);
+        }
         const hipError_t e1 = hipGetLastError();
         const hipError_t e2 = hipStreamSynchronize((hipStream_t)stream);       // the log is freed below
         (void)hipFree(log);

@@ -21,8 +21,9 @@ __device__ inline void gc_set(cd* A, int i, int j, int C, cd v) {
 }
 
 // block table of the round-robin pairing: block -> (pair u, pair v >= u); H = ceil(C / 2) pairs
+template <int NT = 256>
 __device__ inline void gc_block_table(unsigned short* blk_u, unsigned short* blk_v, int H, int tid) {
-    for (int u = tid; u < H; u += 256) {
+    for (int u = tid; u < H; u += NT) {
         const int start = u * H - u * (u - 1) / 2;
         for (int v = u; v < H; ++v) { blk_u[start + v - u] = (unsigned short)u; blk_v[start + v - u] = (unsigned short)v; }
     }
@@ -30,20 +31,23 @@ __device__ inline void gc_block_table(unsigned short* blk_u, unsigned short* blk
 
 // Sweeps until the off-diagonal mass is below 1e-14 of the diagonal's (or max_sweeps).  A: packed triangle (LDS or global);
 // rc [H], rs [H], rp [2 H]: rotation scratch; red [2][256], done, n_rounds: workgroup-shared; mylog: rotation log of this
-// workgroup ([max_sweeps (M - 1)][H][3]) or NULL.  All 256 threads must call; the diagonal of A holds the eigenvalues after.
+// workgroup ([max_sweeps (M - 1)][H][3]) or NULL.  All NT threads must call (NT >= H); the diagonal of A holds the
+// eigenvalues after.  NT = 1024 for matrices beyond 128 x 128: 8256 blocks per round at 256 signals are 32 dependent
+// global round trips per thread with 256 threads, 8 with 1024.
+template <int NT = 256>
 __device__ inline void gc_jacobi(cd* A, int C, double* rc, cd* rs, int* rp, const unsigned short* blk_u,
-                                 const unsigned short* blk_v, double (*red)[256], int* done, int* n_rounds, double* mylog,
+                                 const unsigned short* blk_v, double (*red)[NT], int* done, int* n_rounds, double* mylog,
                                  int max_sweeps) {
     const int tid = threadIdx.x, M = C + (C & 1), H = M / 2;
     if (tid == 0) *n_rounds = 0;
     __syncthreads();
     for (int sweep = 0; sweep < max_sweeps; ++sweep) {
         double off = 0.0, dia = 0.0;              // off = the whole packed triangle, dia = its diagonal
-        for (int i = tid; i < C; i += 256) { const cd v = A[gc_tri(i, i, C)]; dia += v.x * v.x; }
-        for (int e = tid; e < C * (C + 1) / 2; e += 256) off += A[e].x * A[e].x + A[e].y * A[e].y;
+        for (int i = tid; i < C; i += NT) { const cd v = A[gc_tri(i, i, C)]; dia += v.x * v.x; }
+        for (int e = tid; e < C * (C + 1) / 2; e += NT) off += A[e].x * A[e].x + A[e].y * A[e].y;
         red[0][tid] = off; red[1][tid] = dia;
         __syncthreads();
-        for (int s = 128; s > 0; s >>= 1) {
+        for (int s = NT / 2; s > 0; s >>= 1) {
             if (tid < s) { red[0][tid] += red[0][tid + s]; red[1][tid] += red[1][tid + s]; }
             __syncthreads();
         }
@@ -79,7 +83,7 @@ __device__ inline void gc_jacobi(cd* A, int C, double* rc, cd* rs, int* rp, cons
             }
             __syncthreads();
             // 2x2 blocks (pair u <= pair v): B' = J_u^H B J_v with J = [[c, s], [-conj s, c]]
-            for (int blk = tid; blk < H * (H + 1) / 2; blk += 256) {
+            for (int blk = tid; blk < H * (H + 1) / 2; blk += NT) {
                 const int u = blk_u[blk], v = blk_v[blk];
                 const int up = rp[2 * u], uq = rp[2 * u + 1], vp = rp[2 * v], vq = rp[2 * v + 1];
                 const double cu = rc[u], cv = rc[v];

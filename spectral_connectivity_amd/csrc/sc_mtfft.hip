@@ -111,11 +111,15 @@ extern "C" int sc_debug_mtfft_trace(unsigned long long* out, int reset) {
 #define MT_TICK(slot) do {} while (0)
 #endif
 
-template <int LOG2N>
-__global__ void __launch_bounds__(256, LOG2N <= 8 ? 4 : (LOG2N == 9 ? 3 : (LOG2N >= 11 ? 3 : 1))) mtfft16_kernel(MtArgs p) {
+// THREADS: 256 by default.  Long windows (N >= 1024) take 512-thread workgroups -- twice the transforms, so twice the
+// contiguous piece of a frequency row per store group (128 bytes at N = 1024: a full line) -- at the same number of
+// waves per CU; 1024 threads would need 128 registers per lane and spill (measured slower).
+template <int LOG2N, int THREADS = 256>
+__global__ void __launch_bounds__(THREADS, THREADS == 512 ? 2 : (LOG2N <= 8 ? 4 : (LOG2N == 9 ? 3 : (LOG2N >= 11 ? 3 : 1))))
+mtfft16_kernel(MtArgs p) {
     constexpr int N = 1 << LOG2N;
     constexpr int TPF = N / 16;          // threads per FFT: 16 points each
-    constexpr int NF = 256 / TPF;        // complex FFTs (channel pairs) per workgroup
+    constexpr int NF = THREADS / TPF;    // complex FFTs (channel pairs) per workgroup
     constexpr int CT = 2 * NF;           // channels per workgroup
     constexpr int XS = CT + 2;           // padded window-row stride (floats)
     constexpr int ZS = N + N / 16 + 1;   // skewed exchange buffer per FFT (float2), odd stride
@@ -130,15 +134,20 @@ __global__ void __launch_bounds__(256, LOG2N <= 8 ? 4 : (LOG2N == 9 ? 3 : (LOG2N
     // as one contiguous row that a tiled transpose turns into the frequency-major X (16-byte pieces per frequency row
     // otherwise); N = 2048 stores its 32-byte pieces directly, the tiles of a line on one XCD.
     constexpr bool LONG = LOG2N >= 11;
+    // (Tried at N = 1024 and dropped: the window tile through LDS in two halves + the small twiddle tables of the long
+    //  windows -- 43 KB, three workgroups per CU instead of two: 2.0 TB/s against 2.5.  The kernel is bound by VALU / LDS
+    //  instruction issue there, not by latency: the twiddle products cost more than the third workgroup returns.)
     constexpr size_t XT_BYTES = LONG ? 0 : (size_t)N * XS * 4, Z_BYTES = (size_t)NF * ZS * 8;
     constexpr size_t UNION_BYTES = XT_BYTES > Z_BYTES ? XT_BYTES : Z_BYTES;
     float* xt = reinterpret_cast<float*>(smem);                                   // [N][XS]
     float2* z = reinterpret_cast<float2*>(smem);                                  // [NF][ZS] (aliases xt)
     // The detrend scratch is dead once the tile is detrended; twiddles and tapers then take its place.
-    double* red = reinterpret_cast<double*>(smem + UNION_BYTES);                  // [2][256] + trend [2][CT]
+    // (long windows: the trend sums borrow the exchange buffer, which nobody has written yet -- four arrays of THREADS
+    //  doubles would not fit next to it)
+    double* red = reinterpret_cast<double*>(smem + (LONG ? 0 : UNION_BYTES));     // [2][THREADS] + trend [2][CT]; LONG: [4][THREADS]
     float2* tw = reinterpret_cast<float2*>(smem + UNION_BYTES);                   // [N]   (aliases red)
     float* hk = reinterpret_cast<float*>(tw + N);                                 // [kh][L] tapers
-    float2* tlo = reinterpret_cast<float2*>(smem + UNION_BYTES + 4 * 256 * sizeof(double));   // LONG: W_N^j, j < 64
+    float2* tlo = reinterpret_cast<float2*>(smem + UNION_BYTES);                  // LONG: W_N^j, j < 64
     float2* thi = tlo + 64;                                                        // LONG: W_N^(64 q), q < N / 64
     // An FFT's 16 x TPF points are exchanged between lanes of ONE wavefront when TPF <= 64, and
     // LDS executes a wave's instructions in order: those exchanges need no workgroup barrier.
@@ -153,6 +162,7 @@ __global__ void __launch_bounds__(256, LOG2N <= 8 ? 4 : (LOG2N == 9 ? 3 : (LOG2N
     if constexpr (LONG) __syncthreads();
     MT_T0();
     int c0, r, w;
+    constexpr bool ROWSTORE = LOG2N >= 12 && THREADS == 256;     // every channel's spectrum as one row of Z, transposed afterwards
     constexpr bool XCDMAP = LOG2N >= 10;         // N = 1024 stores 64-byte pieces of a frequency row: the tiles that complete a
                                                  // 128-byte line must meet in ONE XCD's L2 as well
     if constexpr (XCDMAP) {
@@ -200,12 +210,12 @@ __global__ void __launch_bounds__(256, LOG2N <= 8 ? 4 : (LOG2N == 9 ? 3 : (LOG2N
                 s0 += (double)xs[t].x; t0 += (double)xs[t].x * l1;
                 s1 += (double)xs[t].y; t1 += (double)xs[t].y * l1;
             }
-            red[tid] = s0; red[256 + tid] = t0; red[512 + tid] = s1; red[768 + tid] = t1;
+            red[tid] = s0; red[THREADS + tid] = t0; red[2 * THREADS + tid] = s1; red[3 * THREADS + tid] = t1;
             __syncthreads();
             for (int h = TPF / 2; h > 0; h >>= 1) {
                 if (i < h) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) red[q * 256 + tid] += red[q * 256 + tid + h];
+                    for (int q = 0; q < 4; ++q) red[q * THREADS + tid] += red[q * THREADS + tid + h];
                 }
                 __syncthreads();
             }
@@ -214,7 +224,7 @@ __global__ void __launch_bounds__(256, LOG2N <= 8 ? 4 : (LOG2N == 9 ? 3 : (LOG2N
             double ab[2][2];
 #pragma unroll
             for (int ch = 0; ch < 2; ++ch) {
-                const double sum = red[(2 * ch) * 256 + pf * TPF], sumt = red[(2 * ch + 1) * 256 + pf * TPF] / n;
+                const double sum = red[(2 * ch) * THREADS + pf * TPF], sumt = red[(2 * ch + 1) * THREADS + pf * TPF] / n;
                 double a = 0.0, b;
                 if (p.detrend == SC_DETREND_CONSTANT) {
                     b = sum / n;
@@ -236,15 +246,16 @@ __global__ void __launch_bounds__(256, LOG2N <= 8 ? 4 : (LOG2N == 9 ? 3 : (LOG2N
         }
         if (tid < 64) tlo[tid] = p.tw[tid];
         else if (tid < 64 + N / 64) thi[tid - 64] = p.tw[(tid - 64) * 64];
+        // (tlo / thi sit behind the exchange buffer; the trend sums in front of it are consumed before the barrier below)
     } else {
         if constexpr (CT % 4 == 0) {
             // 16-byte loads, all of a thread's rows in flight at once (the tile is N x CT floats = 16 KB x 2)
-            constexpr int V = CT / 4, ROUNDS = N * V / 256;
+            constexpr int V = CT / 4, ROUNDS = N * V / THREADS;
             const bool vec = (C % 4) == 0;
             float4 v[ROUNDS];
     #pragma unroll
             for (int it = 0; it < ROUNDS; ++it) {
-                const int idx = tid + it * 256, l = idx / V, cc = 4 * (idx - l * V);
+                const int idx = tid + it * THREADS, l = idx / V, cc = 4 * (idx - l * V);
                 const float* src = xw + (int64_t)l * RC + cc;
                 v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (l < L) {
@@ -260,7 +271,7 @@ __global__ void __launch_bounds__(256, LOG2N <= 8 ? 4 : (LOG2N == 9 ? 3 : (LOG2N
             }
     #pragma unroll
             for (int it = 0; it < ROUNDS; ++it) {
-                const int idx = tid + it * 256, l = idx / V, cc = 4 * (idx - l * V);
+                const int idx = tid + it * THREADS, l = idx / V, cc = 4 * (idx - l * V);
                 if (l < L) {
                     float2* d = reinterpret_cast<float2*>(xt + l * XS + cc);
                     d[0] = make_float2(v[it].x, v[it].y);
@@ -268,14 +279,14 @@ __global__ void __launch_bounds__(256, LOG2N <= 8 ? 4 : (LOG2N == 9 ? 3 : (LOG2N
                 }
             }
         } else {
-            for (int idx = tid; idx < L * CT; idx += 256) {
+            for (int idx = tid; idx < L * CT; idx += THREADS) {
                 const int l = idx / CT, cc = idx - l * CT;
                 xt[l * XS + cc] = (c0 + cc < C) ? xw[(int64_t)l * RC + cc] : 0.f;
             }
         }
         __syncthreads();
         if (p.detrend != SC_DETREND_NONE) {
-            constexpr int SL = 256 / CT;
+            constexpr int SL = THREADS / CT;
             const int cc = tid % CT, sl = tid / CT;
             double s = 0.0, st = 0.0;
             for (int l = sl; l < L; l += SL) {
@@ -284,11 +295,11 @@ __global__ void __launch_bounds__(256, LOG2N <= 8 ? 4 : (LOG2N == 9 ? 3 : (LOG2N
                 st += v * (double)(l + 1);
             }
             red[tid] = s;
-            red[256 + tid] = st;
+            red[THREADS + tid] = st;
             __syncthreads();
             if (tid < CT) {
                 double sum = 0.0, sumt = 0.0;
-                for (int q = 0; q < SL; ++q) { sum += red[q * CT + tid]; sumt += red[256 + q * CT + tid]; }
+                for (int q = 0; q < SL; ++q) { sum += red[q * CT + tid]; sumt += red[THREADS + q * CT + tid]; }
                 sumt /= (double)L;
                 const double n = (double)L;
                 double a = 0.0, b;
@@ -300,8 +311,8 @@ __global__ void __launch_bounds__(256, LOG2N <= 8 ? 4 : (LOG2N == 9 ? 3 : (LOG2N
                     a = (den != 0.0) ? (n * sumt - St * sum) / den : 0.0;
                     b = (sum - a * St) / n;
                 }
-                red[512 + tid] = a;
-                red[512 + CT + tid] = b;
+                red[2 * THREADS + tid] = a;
+                red[2 * THREADS + CT + tid] = b;
             }
             // (the trend a t + b is subtracted below, while the samples are pulled into registers)
         }
@@ -310,8 +321,8 @@ __global__ void __launch_bounds__(256, LOG2N <= 8 ? 4 : (LOG2N == 9 ? 3 : (LOG2N
         {
             const bool detr = p.detrend != SC_DETREND_NONE;
             const double invL = 1.0 / (double)L;
-            const double a0 = detr ? red[512 + 2 * pf] : 0.0, a1 = detr ? red[512 + 2 * pf + 1] : 0.0;
-            const double b0 = detr ? red[512 + CT + 2 * pf] : 0.0, b1 = detr ? red[512 + CT + 2 * pf + 1] : 0.0;
+            const double a0 = detr ? red[2 * THREADS + 2 * pf] : 0.0, a1 = detr ? red[2 * THREADS + 2 * pf + 1] : 0.0;
+            const double b0 = detr ? red[2 * THREADS + CT + 2 * pf] : 0.0, b1 = detr ? red[2 * THREADS + CT + 2 * pf + 1] : 0.0;
     #pragma unroll
             for (int t = 0; t < 16; ++t) {
                 const int n = i + t * TPF;
@@ -329,20 +340,35 @@ __global__ void __launch_bounds__(256, LOG2N <= 8 ? 4 : (LOG2N == 9 ? 3 : (LOG2N
         }
     }
     {
-        bool n0 = false, n1 = false;
+        // flag 1: the channel is not identically zero; flag 2: it holds a NaN / infinity.  The reference transforms every
+        // channel on its own, so a non-finite sample spoils that channel's spectrum only: such a channel leaves the packed
+        // transform (zeros in its place, its partner stays clean) and its bins are written as NaN.
+        bool n0 = false, n1 = false, b0 = false, b1 = false;
 #pragma unroll
-        for (int t = 0; t < 16; ++t) { n0 |= xs[t].x != 0.f; n1 |= xs[t].y != 0.f; }
-        if (n0) nzf[2 * pf] = 1;
-        if (n1) nzf[2 * pf + 1] = 1;
+        for (int t = 0; t < 16; ++t) {
+            n0 |= xs[t].x != 0.f; n1 |= xs[t].y != 0.f;
+            b0 |= !(fabsf(xs[t].x) <= 3.4028235e38f); b1 |= !(fabsf(xs[t].y) <= 3.4028235e38f);
+        }
+        if (n0 || b0) atomicMax(&nzf[2 * pf], b0 ? 2 : 1);
+        if (n1 || b1) atomicMax(&nzf[2 * pf + 1], b1 ? 2 : 1);
     }
     __syncthreads();                                  // tile and detrend scratch consumed: their space is free
-    const bool za = nzf[2 * (tid & (NF - 1))] == 0, zb = nzf[2 * (tid & (NF - 1)) + 1] == 0;   // of the pair this thread stores
+    if (nzf[2 * pf] == 2) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) xs[t].x = 0.f;
+    }
+    if (nzf[2 * pf + 1] == 2) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) xs[t].y = 0.f;
+    }
+    const int fla = nzf[2 * (tid & (NF - 1))], flb = nzf[2 * (tid & (NF - 1)) + 1];             // of the pair this thread stores
+    const bool za = fla == 0, zb = flb == 0, na = fla == 2, nb = flb == 2;
     if constexpr (!LONG) {
-        for (int i2 = tid; i2 < N; i2 += 256) tw[i2] = p.tw[i2];
+        for (int i2 = tid; i2 < N; i2 += THREADS) tw[i2] = p.tw[i2];
         if (resident) {
-            for (int i2 = tid; i2 < p.K * p.L; i2 += 256) hk[i2] = p.tapers[i2];
+            for (int i2 = tid; i2 < p.K * p.L; i2 += THREADS) hk[i2] = p.tapers[i2];
         } else {
-            for (int i2 = tid; i2 < L; i2 += 256) hk[i2] = p.tapers[i2];          // taper 0 into buffer 0
+            for (int i2 = tid; i2 < L; i2 += THREADS) hk[i2] = p.tapers[i2];          // taper 0 into buffer 0
         }
     }
     // W_N^m: the LDS table, or (long windows) the product of the two 64-entry tables
@@ -372,7 +398,7 @@ __global__ void __launch_bounds__(256, LOG2N <= 8 ? 4 : (LOG2N == 9 ? 3 : (LOG2N
         // the next taper travels HBM/L2 -> registers under this taper's passes and is parked in the other
         // LDS buffer before the stores go out (a load issued AFTER the stores would wait for them: vmcnt
         // retires in order)
-        constexpr int HN = (N + 255) / 256;
+        constexpr int HN = (N + THREADS - 1) / THREADS;
         float hn[HN];
         const bool fetch_next = !LONG && !resident && k + 1 < p.K;
         float hl[LONG ? 16 : 1];                      // long windows: this taper's 16 values, straight from L2
@@ -386,7 +412,7 @@ __global__ void __launch_bounds__(256, LOG2N <= 8 ? 4 : (LOG2N == 9 ? 3 : (LOG2N
         if (fetch_next) {
 #pragma unroll
             for (int j = 0; j < HN; ++j) {
-                const int n = tid + 256 * j;
+                const int n = tid + THREADS * j;
                 hn[j] = (n < L) ? p.tapers[(int64_t)(k + 1) * L + n] : 0.f;
             }
         }
@@ -523,7 +549,7 @@ __global__ void __launch_bounds__(256, LOG2N <= 8 ? 4 : (LOG2N == 9 ? 3 : (LOG2N
             float* hnext = hk + ((k + 1) & TWO) * L;
 #pragma unroll
             for (int j = 0; j < HN; ++j) {
-                const int n = tid + 256 * j;
+                const int n = tid + THREADS * j;
                 if (n < L) hnext[n] = hn[j];
             }
         }
@@ -545,8 +571,10 @@ __global__ void __launch_bounds__(256, LOG2N <= 8 ? 4 : (LOG2N == 9 ? 3 : (LOG2N
                 float2 B = make_float2(0.5f * (u1.y + u2.y), 0.5f * (u2.x - u1.x));
                 if (za) A = make_float2(0.f, 0.f);
                 if (zb) B = make_float2(0.f, 0.f);
+                if (na) A = make_float2(__int_as_float(0x7fc00000), __int_as_float(0x7fc00000));
+                if (nb) B = make_float2(__int_as_float(0x7fc00000), __int_as_float(0x7fc00000));
                 if ((p.dbg & 1) && A.x != 12345.f) return;
-                if constexpr (LOG2N >= 12) {
+                if constexpr (ROWSTORE) {
                     float2* row = p.Z + (((((int64_t)w * p.Rc + (r - p.r_off)) * p.K + k) * C + c) * (int64_t)(N / 2 + 1));
                     row[f] = A;
                     if (c + 1 < C) row[(N / 2 + 1) + f] = B;
@@ -565,12 +593,12 @@ __global__ void __launch_bounds__(256, LOG2N <= 8 ? 4 : (LOG2N == 9 ? 3 : (LOG2N
                 float2 z1[4], z2[4];
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
-                    const int f = fb + (h + it) * (256 / NF);
+                    const int f = fb + (h + it) * (THREADS / NF);
                     z1[it] = zp[PHYS(f)];
                     z2[it] = zp[PHYS((N - f) & (N - 1))];
                 }
 #pragma unroll
-                for (int it = 0; it < 4; ++it) put(fb + (h + it) * (256 / NF), z1[it], z2[it]);
+                for (int it = 0; it < 4; ++it) put(fb + (h + it) * (THREADS / NF), z1[it], z2[it]);
             }
             if (last) put(N / 2, zn, zn);
         }
@@ -597,13 +625,15 @@ extern "C" int sc_fft_twiddles_f32(int64_t N, void* d_tw, void* stream) {
     return SC_OK;
 }
 
-template <int LOG2N>
+template <int LOG2N, int THREADS = 256>
 static int launch_mt16(const MtArgs& a_in, hipStream_t stream) {
     constexpr int N = 1 << LOG2N;
-    constexpr int TPF = N / 16, NF = 256 / TPF, CT = 2 * NF;
-    constexpr size_t xt_b = (size_t)N * (CT + 2) * 4, z_b = (size_t)NF * (N + N / 16 + 1) * 8;
-    constexpr size_t uni = (xt_b > z_b ? xt_b : z_b), red_b = (size_t)(512 + 2 * CT) * 8;
-    static_assert(uni + (size_t)N * 16 <= 160 * 1024 && uni + red_b <= 160 * 1024, "LDS budget exceeded");
+    constexpr int TPF = N / 16, NF = THREADS / TPF, CT = 2 * NF;
+    constexpr bool LONG = LOG2N >= 11;
+    constexpr size_t xt_b = LONG ? 0 : (size_t)N * (CT + 2) * 4, z_b = (size_t)NF * (N + N / 16 + 1) * 8;
+    constexpr size_t uni = (xt_b > z_b ? xt_b : z_b), red_b = (size_t)(2 * THREADS + 2 * CT) * 8;
+    static_assert(LONG || (uni + (size_t)N * 16 <= 160 * 1024 && uni + red_b <= 160 * 1024), "LDS budget exceeded");
+    static_assert(!LONG || (z_b >= (size_t)4 * THREADS * 8 && z_b + (64 + N / 64) * 8 <= 160 * 1024), "LDS budget exceeded");
     auto lds = [&](size_t kh, size_t L) { size_t t = (size_t)N * 8 + kh * L * 4; return uni + (t > red_b ? t : red_b); };
     // not resident = two buffers: the next taper is parked while the current one is in use
     // Keep all K tapers in LDS when that does not cost a resident workgroup per CU.
@@ -613,21 +643,21 @@ static int launch_mt16(const MtArgs& a_in, hipStream_t stream) {
     a.kh = (all <= cu_lds && cu_lds / all == cu_lds / one) ? a.K : 1;
     { const char* d = getenv("SC_MTFFT_DEBUG"); a.dbg = d ? atoi(d) : 0; }
     const size_t shmem = a.kh == a.K ? all : one;
-    auto k = mtfft16_kernel<LOG2N>;
+    auto k = mtfft16_kernel<LOG2N, THREADS>;
     if constexpr (LOG2N < 11) SC_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     if constexpr (LOG2N >= 11) {
         // long windows: row-major spectra of a range of trials into a stream-ordered scratch (<= 2 GB), then one tiled
         // transpose per window into the frequency-major X
-        const size_t lds_long = z_b + 4 * 256 * sizeof(double) + (64 + N / 64) * sizeof(float2);
+        const size_t lds_long = z_b + (64 + N / 64) * sizeof(float2);
         SC_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_long));
-        if constexpr (LOG2N == 11) {
+        if constexpr (LOG2N == 11 || THREADS != 256) {
             // 2048 samples: 32-byte pieces of a frequency row per workgroup, and the four tiles that complete a 128-byte
             // line run back to back on one XCD -- its L2 merges them: 4.2 ms for the volume the row store + transpose
             // below takes 4.7 ms for.  (At 4096 samples, 16-byte pieces of eight tiles, the transpose still wins: 9.7
             // against 10.6 ms.)
             a.Z = nullptr; a.r_off = 0; a.Rc = a.R;
             const int64_t n_ct = (a.C + CT - 1) / CT, groups8 = ((int64_t)a.W * a.R + 7) / 8 * 8;
-            hipLaunchKernelGGL(k, dim3((unsigned)(groups8 * n_ct)), dim3(256), lds_long, stream, a);
+            hipLaunchKernelGGL(k, dim3((unsigned)(groups8 * n_ct)), dim3(THREADS), lds_long, stream, a);
             SC_CHECK_HIP(hipGetLastError());
             return SC_OK;
         }
@@ -645,7 +675,7 @@ static int launch_mt16(const MtArgs& a_in, hipStream_t stream) {
             const int64_t n = a.R - r0 < rc ? a.R - r0 : rc;
             a.r_off = (int)r0; a.Rc = (int)n;
             const int64_t n_ct = (a.C + CT - 1) / CT, groups8 = (a.W * n + 7) / 8 * 8;
-            hipLaunchKernelGGL(k, dim3((unsigned)(groups8 * n_ct)), dim3(256), lds_long, stream, a);
+            hipLaunchKernelGGL(k, dim3((unsigned)(groups8 * n_ct)), dim3(THREADS), lds_long, stream, a);
             for (int64_t w = 0; w < a.W && rc_ret == SC_OK; ++w)
                 rc_ret = sc_internal_rows_to_bins(Z + w * n * rows_trial * F, a.X, n * rows_trial, F, batch,
                                                   (w * a.R + r0) * rows_trial, N / 2, stream);
@@ -658,12 +688,12 @@ static int launch_mt16(const MtArgs& a_in, hipStream_t stream) {
     if constexpr (LOG2N >= 10) {        // one-dimensional grid, channel tiles of a (window, trial) on one XCD (see the kernel)
         a.r_off = 0; a.Rc = a.R;
         const int64_t n_ct = (a.C + CT - 1) / CT, groups8 = ((int64_t)a.W * a.R + 7) / 8 * 8;
-        hipLaunchKernelGGL(k, dim3((unsigned)(groups8 * n_ct)), dim3(256), shmem, stream, a);
+        hipLaunchKernelGGL(k, dim3((unsigned)(groups8 * n_ct)), dim3(THREADS), shmem, stream, a);
         SC_CHECK_HIP(hipGetLastError());
         return SC_OK;
     }
     dim3 grid((unsigned)((a.C + CT - 1) / CT), (unsigned)a.R, (unsigned)a.W);
-    hipLaunchKernelGGL(k, grid, dim3(256), shmem, stream, a);
+    hipLaunchKernelGGL(k, grid, dim3(THREADS), shmem, stream, a);
     SC_CHECK_HIP(hipGetLastError());
     return SC_OK;
 }
@@ -861,10 +891,14 @@ __global__ void __launch_bounds__(512) mtfft_mixed_kernel(MxArgs p) {
     }
     {
         const int SL = 512 >> lct, cc = tid & (CT - 1), sl = tid >> lct;
-        bool nz = false;
+        bool nz = false, bad = false;
         if (sl < SL)
-            for (int l = sl; l < L; l += SL) nz |= tile[l * XS + cc] != 0.f;
-        if (nz) nzf[cc] = 1;
+            for (int l = sl; l < L; l += SL) { const float v = tile[l * XS + cc]; nz |= v != 0.f; bad |= !(fabsf(v) <= 3.4028235e38f); }
+        if (nz || bad) atomicMax(&nzf[cc], bad ? 2 : 1);
+        __syncthreads();
+        // a channel with a NaN / infinity leaves the packed transform (see mtfft16_kernel): zeros in, NaN bins out
+        if (sl < SL && nzf[cc] == 2)
+            for (int l = sl; l < L; l += SL) tile[l * XS + cc] = 0.f;
         __syncthreads();
     }
     const int F = N / 2 + 1;
@@ -915,6 +949,8 @@ __global__ void __launch_bounds__(512) mtfft_mixed_kernel(MxArgs p) {
             float2 B = make_float2(0.5f * (u1.y + u2.y), 0.5f * (u2.x - u1.x));
             if (nzf[2 * pr] == 0) A = make_float2(0.f, 0.f);         // identically zero channel: exact zeros
             if (nzf[2 * pr + 1] == 0) B = make_float2(0.f, 0.f);
+            if (nzf[2 * pr] == 2) A = make_float2(__int_as_float(0x7fc00000), __int_as_float(0x7fc00000));   // non-finite channel
+            if (nzf[2 * pr + 1] == 2) B = make_float2(__int_as_float(0x7fc00000), __int_as_float(0x7fc00000));
             float2* d = Xk + (int64_t)f * sF + 2 * pr;
             if (vec_ok) {
                 *reinterpret_cast<float4*>(d) = make_float4(A.x, A.y, B.x, B.y);
@@ -1005,9 +1041,13 @@ __global__ void __launch_bounds__(64 * NF) mtfft_mixed_wave_kernel(MxArgs p) {
     {
         constexpr int SL = NT / CT;
         const int cc = tid & (CT - 1), sl = tid >> LCT;
-        bool nz = false;
-        for (int l = sl; l < L; l += SL) nz |= tile[l * XS + cc] != 0.f;
-        if (nz) nzf[cc] = 1;
+        bool nz = false, bad = false;
+        for (int l = sl; l < L; l += SL) { const float v = tile[l * XS + cc]; nz |= v != 0.f; bad |= !(fabsf(v) <= 3.4028235e38f); }
+        if (nz || bad) atomicMax(&nzf[cc], bad ? 2 : 1);
+        __syncthreads();
+        // a channel with a NaN / infinity leaves the packed transform (see mtfft16_kernel): zeros in, NaN bins out
+        if (nzf[cc] == 2)
+            for (int l = sl; l < L; l += SL) tile[l * XS + cc] = 0.f;
         __syncthreads();
     }
     const int64_t sF = (int64_t)p.W * p.R * p.K * C;
@@ -1038,6 +1078,8 @@ __global__ void __launch_bounds__(64 * NF) mtfft_mixed_wave_kernel(MxArgs p) {
             float2 B = make_float2(0.5f * (u1.y + u2.y), 0.5f * (u2.x - u1.x));
             if (nzf[2 * pr] == 0) A = make_float2(0.f, 0.f);         // identically zero channel: exact zeros
             if (nzf[2 * pr + 1] == 0) B = make_float2(0.f, 0.f);
+            if (nzf[2 * pr] == 2) A = make_float2(__int_as_float(0x7fc00000), __int_as_float(0x7fc00000));   // non-finite channel
+            if (nzf[2 * pr + 1] == 2) B = make_float2(__int_as_float(0x7fc00000), __int_as_float(0x7fc00000));
             float2* d = Xk + (int64_t)f * sF + 2 * pr;
             if (vec_ok) {
                 *reinterpret_cast<float4*>(d) = make_float4(A.x, A.y, B.x, B.y);
@@ -1121,6 +1163,11 @@ static int launch_mixed(const MtArgs& a, int64_t N, hipStream_t stream) {
     return SC_OK;
 }
 
+static int mt_wide() {
+    const char* e = getenv("SC_MTFFT_WIDE");
+    return e ? atoi(e) : 1;
+}
+
 extern "C" int sc_multitaper_fft_supported(int64_t L, int64_t N) {
     if (L < 1 || L > N) return 0;
     if (N >= 64 && N <= 4096 && (N & (N - 1)) == 0) return 1;      // radix-16 kernel
@@ -1151,9 +1198,12 @@ extern "C" int sc_multitaper_fft_f32(const float* d_x, int64_t T, int64_t R, int
     case 128: return launch_mt16<7>(a, s);
     case 256: return launch_mt16<8>(a, s);
     case 512: return launch_mt16<9>(a, s);
-    case 1024: return launch_mt16<10>(a, s);
-    case 2048: return launch_mt16<11>(a, s);
-    case 4096: return launch_mt16<12>(a, s);
+    // 512-thread workgroups from 1024 samples on: 16 / 8 / 4 channels per workgroup, i.e. 128- / 64- / 32-byte pieces of a
+    // frequency row per store group (2.5 -> 2.7, 1.6 -> 2.1, 1.3 -> 1.8 TB/s at N = 1024 / 2048 / 4096, the last without the
+    // row store + transpose pass; tools/stage_a_wide.py).  SC_MTFFT_WIDE=0 (diagnostic): the 256-thread workgroups.
+    case 1024: return mt_wide() && C >= 16 ? launch_mt16<10, 512>(a, s) : launch_mt16<10>(a, s);
+    case 2048: return mt_wide() && C >= 8 ? launch_mt16<11, 512>(a, s) : launch_mt16<11>(a, s);
+    case 4096: return mt_wide() && C >= 4 ? launch_mt16<12, 512>(a, s) : launch_mt16<12>(a, s);
     }
     return SC_EUNSUPPORTED;
 }

@@ -173,9 +173,15 @@ __global__ void __launch_bounds__(64 * NF) mtfft_f64_kernel(MdArgs p) {
         __syncthreads();                                          // the scratch is free: z takes its place
     }
     {
-        bool nz = false;
-        for (int l = sl; l < L; l += SL) nz |= tile[l * XS + cc] != 0.0;
-        if (nz) nzf[cc] = 1;
+        // flag 1: not identically zero; flag 2: holds a NaN / infinity.  The reference transforms every channel on its own
+        // (transforms.py:1402-1405), so a non-finite sample spoils that channel's spectrum only: such a channel leaves the
+        // packed transform (zeros in its place: its partner stays clean) and its bins are written as NaN.
+        bool nz = false, bad = false;
+        for (int l = sl; l < L; l += SL) { const double v = tile[l * XS + cc]; nz |= v != 0.0; bad |= !(fabs(v) <= 1.7976931348623157e308); }
+        if (nz || bad) atomicMax(&nzf[cc], bad ? 2 : 1);
+        __syncthreads();
+        if (nzf[cc] == 2)
+            for (int l = sl; l < L; l += SL) tile[l * XS + cc] = 0.0;
         __syncthreads();
     }
     const int64_t sF = (int64_t)p.W * p.R * p.K * C;
@@ -202,6 +208,8 @@ __global__ void __launch_bounds__(64 * NF) mtfft_f64_kernel(MdArgs p) {
             zd B = make_double2(0.5 * (u1.y + u2.y), 0.5 * (u2.x - u1.x));
             if (nzf[2 * pr] == 0) A = make_double2(0.0, 0.0);
             if (nzf[2 * pr + 1] == 0) B = make_double2(0.0, 0.0);
+            if (nzf[2 * pr] == 2) A = make_double2(__longlong_as_double(0x7ff8000000000000LL), __longlong_as_double(0x7ff8000000000000LL));
+            if (nzf[2 * pr + 1] == 2) B = make_double2(__longlong_as_double(0x7ff8000000000000LL), __longlong_as_double(0x7ff8000000000000LL));
             zd* d = Xk + (int64_t)f * sF + 2 * pr;
             d[0] = A;
             if (c + 1 < C) d[1] = B;

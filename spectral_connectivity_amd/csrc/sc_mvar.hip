@@ -1152,7 +1152,10 @@ extern "C" int sc_mvar_factor_f64(const void* d_accum, const void* d_S, int64_t 
     int32_t hist[MV_POLL];
     const bool fused = sc_internal_causal_fft_supported(N);
     const int Q = (int)((C + 15) / 16);
-    if (max_iter > MV_HIST) max_iter = MV_HIST;
+    if (max_iter > MV_HIST) {
+        sc_set_error("max_iterations = %d exceeds the %d iterations the workspace can log", max_iter, MV_HIST);
+        return SC_EINVAL;
+    }
     if (!fused) {
         if ((rc = mv_make_z2z(&fwd, rocfft_transform_type_complex_forward, (size_t)N, (size_t)E * P)) != SC_OK) goto done;
         if ((rc = mv_make_z2z(&inv, rocfft_transform_type_complex_inverse, (size_t)N, (size_t)E * P)) != SC_OK) goto done;

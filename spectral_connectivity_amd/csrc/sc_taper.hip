@@ -140,6 +140,9 @@ __global__ void __launch_bounds__(256) timeseries_to_f32_kernel(const double* __
     if (remove_mean) {
         for (int64_t t = 0; t < T; ++t) m += x[(t * R + r) * C + c];      // every time slice sums the whole series: same mean
         m /= (double)T;
+        // one NaN / infinite sample must cost only the windows that contain it (the reference's per-window detrend, and
+        // the float64 engine): a non-finite mean is not removed -- the per-window detrend takes the constant out anyway
+        if (!(fabs(m) <= 1.7976931348623157e308)) m = 0.0;
     }
     for (int64_t t = t0; t < t1; ++t) y[(t * R + r) * C_out + c] = (float)(x[(t * R + r) * C + c] - m);
 }

@@ -390,7 +390,10 @@ static int wilson_iterate(const WilsonWork& k, int64_t P, int64_t n_batch, int64
     int iters = 0, running = (int)P, queued = 0;
     int32_t hist[WILSON_POLL];
     const bool fused = sc_internal_causal_fft_supported(N);
-    if (max_iter > WILSON_HIST) max_iter = WILSON_HIST;
+    if (max_iter > WILSON_HIST) {
+        sc_set_error("max_iterations = %d exceeds the %d iterations the workspace can log", max_iter, WILSON_HIST);
+        return SC_EINVAL;
+    }
 
     if (!fused) {
         if ((rc = make_z2z(&fwd, rocfft_transform_type_complex_forward, N, 4 * P)) != SC_OK) goto done;

@@ -177,12 +177,10 @@ template <int LOG2N>
 static int wf_launch(void* d_A, const int32_t* d_status, int64_t n_series, int C, hipStream_t st) {
     constexpr int N = 1 << LOG2N, NF = 256 / (N / 16), ZS = N + N / 16;
     const size_t lds = ((size_t)NF * ZS + 64 + N / 64) * sizeof(cd);
-    static bool configured = false;
-    if (!configured) {
-        SC_CHECK_HIP(hipFuncSetAttribute((const void*)causal_fft_pair_kernel<LOG2N>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = true;
-    }
+    // (per call: the attribute belongs to the function ON THE CURRENT DEVICE, a process-wide "done" flag would skip the
+    //  second device of a multi-GPU process)
+    SC_CHECK_HIP(hipFuncSetAttribute((const void*)causal_fft_pair_kernel<LOG2N>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t blocks = (n_series + NF - 1) / NF;
     SC_REQUIRE(blocks <= 0x7fffffffLL, "too many series for one launch");
     hipLaunchKernelGGL(causal_fft_pair_kernel<LOG2N>, dim3((unsigned)blocks), dim3(256), lds, st, (cd*)d_A, d_status,

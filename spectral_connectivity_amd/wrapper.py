@@ -98,9 +98,13 @@ def multitaper_connectivity(time_series, sampling_frequency, time_window_duratio
     if len(methods) == 1:
         _check_method(methods[0])
     xr = _xarray()
+    # `dtype` (an extension: the reference's wrapper always builds its Connectivity with the default complex128) picks the
+    # engine like Connectivity.from_multitaper(dtype=...): numpy.complex64 = the float32 engine
+    dtype = kwargs.pop("dtype", None)
     m = Multitaper(time_series=time_series, sampling_frequency=sampling_frequency,
                    time_window_duration=time_window_duration, **kwargs)
-    connectivity = Connectivity.from_multitaper(m)       # shared: one transform, shared accumulator passes
+    # shared: one transform, shared accumulator passes
+    connectivity = Connectivity.from_multitaper(m) if dtype is None else Connectivity.from_multitaper(m, dtype=dtype)
     if len(methods) > 1:
         connectivity._prepare(methods)
     out = xr.Dataset()

@@ -852,3 +852,61 @@ def test_output_dtypes_are_the_references(sc):
         assert getattr(c128, name)().dtype == expect(name, True, True), name
         assert getattr(raw64, name)().dtype == expect(name, False, False), name
         close32(getattr(c64, name)(), getattr(c128, name)(), rtol=3e-5, atol_scale=3e-5, what=name)
+
+
+@pytest.mark.parametrize("L", [64, 256, 250, 1024, 2048, 120, 112])
+def test_nonfinite_sample_spoils_only_its_own_channel(sc, L):
+    """The fused transforms pack two channels into one complex sequence; a NaN / infinity in one of them must not leak
+    into its partner (the reference transforms every channel on its own, transforms.py:1402-1405): the bad channel's
+    bins of the windows that contain the sample are NaN, everything else equals the oracle's."""
+    rng = np.random.default_rng(L)
+    T, R, C = 2 * L, 3, 6
+    x = rng.standard_normal((T, R, C))
+    x[L // 3, 1, 2] = np.nan            # window 0, trial 1, channel 2 (partner: channel 3)
+    x[L + 5, 2, 5] = np.inf             # window 1, trial 2, channel 5 (partner: channel 4)
+    with pytest.warns(UserWarning, match="NaN or infinite"):
+        m = sc.Multitaper(x, sampling_frequency=500.0, time_halfbandwidth_product=2, n_time_samples_per_window=L)
+    got = m.fft()
+    clean = np.where(np.isfinite(x), x, 0.0)
+    ref, _ = so.multitaper_fft(clean, fs=500.0, NW=2, n_time_samples_per_window=L)
+    bad = np.zeros(got.shape, dtype=bool)
+    bad[0, 1, :, :, 2] = True
+    bad[1, 2, :, :, 5] = True
+    assert np.isnan(got[bad]).all()
+    assert np.isfinite(got[~bad]).all()
+    close32(np.where(bad, 0, got), np.where(bad, 0, ref), what=f"L={L}: channels beside a non-finite one")
+
+
+def test_f13_canonical_coherence_with_fewer_observations_than_channels(sc, golden):
+    """n_trials * n_tapers = 6 against groups of 8 / 6 channels: the reference's SVD form gives 1 for every pair with
+    such a group (it spans the whole observation space); the other pairs go through the whitening kernel as usual."""
+    g = golden("f13_canonical_few_obs")
+    m = sc.Multitaper(g["x"], sampling_frequency=float(g["fs"]), time_halfbandwidth_product=float(g["NW"]))
+    c = sc.Connectivity.from_multitaper(m)
+    for tag in ("a", "b"):
+        cc, _ = c.canonical_coherence(g[f"labels_{tag}"])
+        close32(cc, g[f"cc_{tag}"], rtol=2e-5, atol_scale=2e-5, what=f"canonical coherence, few observations ({tag})")
+
+
+@pytest.mark.parametrize("C,max_rank", [(72, 9), (96, 96), (128, 40), (130, 7), (160, 160)])
+def test_global_coherence_any_rank_beyond_64_signals(sc, C, max_rank):
+    """max_rank up to n_signals beyond 64 signals (the reference's full SVD, connectivity.py:2245-2279): every value
+    against the oracle, and G V = V diag(values) for the returned vectors (each column an eigenvector of the cross-
+    spectral matrix with its own value -- a statement that does not depend on how close neighbouring values are)."""
+    rng = np.random.default_rng(C + max_rank)
+    R = 60
+    x = rng.standard_normal((64, R, C)) * (1.0 + 0.3 * np.arange(C))[None, None, :]
+    x[:, :, : C // 2] += 2.0 * rng.standard_normal((64, R, 1))
+    kw = dict(sampling_frequency=128.0, time_halfbandwidth_product=2, n_time_samples_per_window=32)
+    coef, _ = so.multitaper_fft(x, fs=128.0, NW=2, n_time_samples_per_window=32)
+    ref, _ = so.global_coherence(coef, max_rank=max_rank)
+    vals, vecs = sc.Connectivity.from_multitaper(sc.Multitaper(x, **kw)).global_coherence(max_rank=max_rank)
+    assert vals.shape == ref.shape and vecs.shape == ref.shape[:2] + (C, max_rank)
+    close32(vals, ref, rtol=3e-5, atol_scale=3e-6, what=f"global coherence C={C} max_rank={max_rank}")
+    np.testing.assert_allclose(np.linalg.norm(vecs, axis=-2), 1.0, atol=1e-9)
+    W, R_, K, N, _ = coef.shape
+    Xm = np.moveaxis(coef.reshape(W, R_ * K, N, C), 1, -1)            # (W, N, C, n_obs)
+    G = Xm @ np.conj(np.swapaxes(Xm, -1, -2)) / (R_ * K)
+    resid = G @ vecs - vecs * vals[..., None, :]
+    scale = np.abs(vals).max()
+    assert np.abs(resid).max() <= 3e-5 * scale, f"eigen-residual {np.abs(resid).max():.2e} vs scale {scale:.2e}"

@@ -79,6 +79,14 @@ def test_f5_granger(golden, tag, kw):
     close(so.pairwise_spectral_granger_prediction(coef), g[f"{tag}__granger"], rtol=1e-6, atol=1e-9)
 
 
+def test_f13_canonical_coherence_few_observations(golden):
+    g = golden("f13_canonical_few_obs")
+    coef, _ = so.multitaper_fft(g["x"], fs=float(g["fs"]), NW=float(g["NW"]))
+    for tag in ("a", "b"):
+        cc, _ = so.canonical_coherence(coef, g[f"labels_{tag}"])
+        close(cc, g[f"cc_{tag}"], rtol=1e-9, atol=1e-12)
+
+
 def test_f12_cholesky_failure_random_restart(golden):
     """A window without a Cholesky factor: the oracle restates the reference's random restart (minimum_phase_
     decomposition.py:78-93) draw for draw, so with the same np.random.seed it lands on the reference's numbers."""
