@@ -21,7 +21,7 @@ b.record(); torch.cuda.synchronize()
 print("%.3f ms" % (a.elapsed_time(b) / 5))
 '''
 for dbg, name in [(0, "full"), (1, "no CSM MFMAs"), (2, "no abs products"), (3, "staging only"),
-                  (11, "staging only, no HBM loads"), (8, "no HBM loads"), (16, "abs waves s_setprio 2"), (32, "CSM waves s_setprio 2")]:
+                  (11, "staging only, no HBM loads"), (8, "no HBM loads")]:
     env = dict(os.environ, SC_FUSED_DEBUG=str(dbg))
     out = subprocess.run([sys.executable, "-c", CODE], env=env, capture_output=True, text=True)
     print("%-28s %s" % (name, out.stdout.strip() or out.stderr.strip()[-400:]))
