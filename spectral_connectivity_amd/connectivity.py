@@ -5,9 +5,13 @@ non-negative frequencies only) and error behaviour as
 ``spectral_connectivity.connectivity.Connectivity`` (reference connectivity.py:163-1650) for
 the hot-path measures.  All arithmetic runs on an MI355X through ``libsc_hip.so``:
 
-    expectation of the cross-spectral matrix   -> MFMA kernel        (sc_csm.hip)
-    |Im s|, (Im s)^2, sign Im s, s/|s| planes   -> VALU kernel        (sc_nonlinear.hip)
-    measure algebra, eps clamps, NaN diagonals  -> epilogue kernel    (sc_measure.hip)
+    expectation of the cross-spectral matrix and the per-observation planes |Im s|, (Im s)^2, sign Im s, s/|s|
+        float32 engine (dtype=complex64): one pass on the bf16 matrix pipe, bf16x3 split (sc_fused.hip), an f32 VALU kernel
+                       for few channels, the f32-MFMA / per-plane VALU kernels for strided spectra (sc_csm.hip, sc_nonlinear.hip)
+        float64 engine (dtype=complex128, the default): fp64 matrix cores + fp64 VALU, double records (sc_f64.hip)
+    measure algebra, eps clamps, NaN diagonals  -> fp64 epilogue, several measures per launch (sc_measure.hip)
+    pairwise Granger / full Wilson + MVAR measures / canonical / global coherence -> sc_wilson.hip, sc_wilson_fft.hip,
+        sc_mvar.hip, sc_canonical.hip, sc_global.hip (fp64)
 
 There is no NumPy fallback: without the HIP extension / a GPU every measure raises.
 """

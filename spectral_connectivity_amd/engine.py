@@ -413,9 +413,11 @@ def measure(accum, n_signals, planes, n_obs, which, out=None, wide=None):
 MEASURE_MULTI_MAX = 4
 
 
-def measure_multi(accum, n_signals, planes, n_obs, which, wide=None):
+def measure_multi(accum, n_signals, planes, n_obs, which, wide=None, stacked=False):
     """Stage C for several real-valued C x C measures of one record: ONE launch reads the record once
-    (sc_measure_multi_*); complex measures / power, or more than four, go through measure()."""
+    (sc_measure_multi_*); complex measures / power, or more than four, go through measure().
+    ``stacked``: the results are the slices of ONE [n_measures, n_bins, C, C] tensor (returned as ``outs[0]._base``'s
+    views) when the one-launch form applies -- the trial-sharded path then gathers all measures in one collective."""
     which = list(which)
     simple = [w for w in which if w != _lib.M_POWER and w not in _lib.COMPLEX_MEASURES]
     if len(simple) != len(which) or not 2 <= len(which) <= MEASURE_MULTI_MAX:
@@ -424,7 +426,11 @@ def measure_multi(accum, n_signals, planes, n_obs, which, wide=None):
     n_bins, C = accum.shape[0], n_signals
     if wide is None:
         wide = accum.dtype == torch.float64
-    outs = [torch.empty((n_bins, C, C), dtype=torch.float64 if wide else torch.float32, device=accum.device) for _ in which]
+    if stacked:
+        block = torch.empty((len(which), n_bins, C, C), dtype=torch.float64 if wide else torch.float32, device=accum.device)
+        outs = list(block.unbind(0))
+    else:
+        outs = [torch.empty((n_bins, C, C), dtype=torch.float64 if wide else torch.float32, device=accum.device) for _ in which]
     ids = (ctypes.c_int * len(which))(*which)
     ptrs = (ctypes.c_void_p * len(which))(*[o.data_ptr() for o in outs])
     fn = lib.sc_measure_multi_f64 if wide else lib.sc_measure_multi_f32

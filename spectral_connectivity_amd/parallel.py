@@ -180,7 +180,25 @@ def sharded_measures(spectra, planes, which, n_groups=4, dst=0, group=None, mark
             if timing is not None:
                 coll_events.append((t0, ev(side)))
                 bytes_reduced += accum.numel() * accum.element_size()
-            outs = engine.measure_multi(shard, C, planes, n_total, which)     # one launch where the measures allow it
+            outs = engine.measure_multi(shard, C, planes, n_total, which, stacked=xchg)   # one launch where the measures allow it
+            block = outs[0]._base if xchg and len(outs) > 1 else None
+            if block is not None and block.dim() == 4 and block.shape[0] == len(which) and all(
+                    o._base is block for o in outs):
+                # every measure of the range in ONE gather: the ranks' [n_measures, per, C, C] blocks land side by side on dst
+                t0 = ev(side) if timing is not None else None
+                full = gather_bins(block, block.shape[0] * world, dst=dst, group=group)     # [world * n_measures, per, C, C]
+                if timing is not None:
+                    coll_events.append((t0, ev(side)))
+                if full is not None:
+                    per = block.shape[1]
+                    full = full.reshape(world, len(which), per, *block.shape[2:])
+                    for m in range(len(which)):
+                        out = full[:, m].reshape(world * per, *block.shape[2:])[:n_bins]
+                        if result[m] is None:
+                            result[m] = torch.empty((W, F) + tuple(out.shape[1:]), dtype=out.dtype, device=out.device)
+                            result[m].record_stream(main)       # filled on the exchange stream, used on the launch stream
+                        result[m][:, f0:f1].copy_(out.reshape(W, f1 - f0, *out.shape[1:]))
+                continue
             for m, w in enumerate(which):
                 out = outs[m]
                 if xchg:

@@ -910,3 +910,32 @@ def test_global_coherence_any_rank_beyond_64_signals(sc, C, max_rank):
     resid = G @ vecs - vecs * vals[..., None, :]
     scale = np.abs(vals).max()
     assert np.abs(resid).max() <= 3e-5 * scale, f"eigen-residual {np.abs(resid).max():.2e} vs scale {scale:.2e}"
+
+
+def test_global_coherence_degenerate_eigenvalues_and_the_jacobi_cross_check(sc, monkeypatch):
+    """Beyond 64 signals the eigenpairs come from a Householder tridiagonalisation + bisection + inverse iteration.  Exactly
+    repeated eigenvalues (a block-diagonal cross-spectral matrix with two identical blocks) must still give an ORTHONORMAL
+    set of eigenvectors (vectors of a cluster are orthogonalised against each other like LAPACK's dstein does), and the
+    values must equal those of the parallel-Jacobi kernels of round 2 (SC_GLOBAL_EIG=jacobi keeps them reachable)."""
+    rng = np.random.default_rng(5)
+    half, n = 40, 60
+    z = rng.standard_normal((n, half)) + 1j * rng.standard_normal((n, half))
+    z *= (1.0 + np.arange(half))[None, :] ** 0.5
+    coef = np.zeros((1, 2 * n, 1, 4, 2 * half), complex)          # (windows, trials, tapers, bins, signals)
+    for f in range(4):
+        zz = z * np.exp(1j * f)
+        coef[0, :n, 0, f, :half] = zz                              # first n observations: block a
+        coef[0, n:, 0, f, half:] = zz                              # the others: block b, the same numbers
+    K = 12
+    c = sc.Connectivity(coef)
+    vals, vecs = c.global_coherence(max_rank=K)
+    G = np.einsum("oi,oj->ij", coef[0, :, 0, 0, :], coef[0, :, 0, 0, :].conj()) / (2 * n)
+    top = np.sort(np.linalg.eigvalsh(G))[::-1][:K][::-1]           # max_rank < C - 1: ascending, like scipy's svds
+    np.testing.assert_allclose(vals[0, 0], top, rtol=1e-4 if c._precision == "float32" else 1e-9)
+    np.testing.assert_allclose(vals[0, 0, 0::2], vals[0, 0, 1::2], rtol=1e-5)          # every value twice
+    V = vecs[0, 0]
+    np.testing.assert_allclose(V.conj().T @ V, np.eye(K), atol=1e-6)
+    assert np.abs(G @ V - V * vals[0, 0][None, :]).max() <= 1e-4 * np.abs(vals).max()
+    monkeypatch.setenv("SC_GLOBAL_EIG", "jacobi")
+    vals_j, _ = sc.Connectivity(coef).global_coherence(max_rank=4)
+    np.testing.assert_allclose(vals_j, vals[..., -4:], rtol=1e-6)

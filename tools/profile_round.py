@@ -1,12 +1,13 @@
-"""Turn the raw outputs of tools/profile_round.sh (gpurun_out/r02/) into the committed profiles/r02_* files, including
-profiles/r02_hbm_traffic.json -- the PMC-derived HBM bytes per launch that bench.py reports as roofline.traffic."""
+"""Turn the raw outputs of tools/profile_round.sh (gpurun_out/$ROUND/) into the committed profiles/$ROUND_* files, including
+profiles/$ROUND_hbm_traffic.json -- the PMC-derived HBM bytes per launch that bench.py reports as roofline.traffic."""
 import hashlib
 import json
 import os
 import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-F = os.path.join(ROOT, "gpurun_out", "r02")
+ROUND = os.environ.get("ROUND", "r03")
+F = os.path.join(ROOT, "gpurun_out", ROUND)
 P = os.path.join(ROOT, "profiles")
 
 
@@ -46,22 +47,22 @@ final = os.path.join(ROOT, "gpurun_out", "final_bench_line.json")      # a bench
 if os.path.exists(final) and os.path.getmtime(final) > os.path.getmtime(os.path.join(F, "bench_line.json")):
     bench = [l for l in open(final).read().split("\n") if l.startswith("{")] or bench
 if bench:
-    open(os.path.join(P, "r02_bench_line.json"), "w").write(bench[-1] + "\n")
+    open(os.path.join(P, ROUND + "_bench_line.json"), "w").write(bench[-1] + "\n")
 under = [l for l in lines("bench_under_rocprof.json") if l.startswith("{")]
-hdr = ["# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline   (cfg3, 1x MI355X, round 2; tools/profile_round.sh)"]
+hdr = ["# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline   (cfg3, 1x MI355X, round 3; tools/profile_round.sh)"]
 if under:
     st = json.loads(under[-1])
     sm = st["roofline"]["stage_ms"]
     hdr.append("# stage times of the same run from the library's own hipEvent timers (sc_last_timing): " +
                ", ".join(f"{k} {v:.3f} ms" for k, v in sm.items()) + f"; step {st['ms_per_step']:.2f} ms")
     hdr.append("# (fused_stage_b = fused_csm_absim_kernel + fused_combine_kernel; averages below include the 2 warm-up launches)")
-open(os.path.join(P, "r02_bench_kernel_stats.txt"), "w").write("\n".join(hdr + lines("kt.txt")[:12]) + "\n")
+open(os.path.join(P, ROUND + "_bench_kernel_stats.txt"), "w").write("\n".join(hdr + lines("kt.txt")[:12]) + "\n")
 
 fetch, write = pmc("fetch.txt", "FETCH_SIZE"), pmc("write.txt", "WRITE_SIZE")
 rows = [("fused_csm_absim_kernel", "_Z22fused_csm_absim", True), ("fused_combine_kernel", "_Z20fused_combine", True),
         ("mtfft16_kernel", "_Z14mtfft16", False), ("measure_tile_multi_kernel", "measure_tile_multi", False)]
 txt = ["# rocprofv3 --kernel-trace --pmc FETCH_SIZE  /  --pmc WRITE_SIZE (separate passes, MI355X_MICROARCH.md), python bench.py --steps 2",
-       "# --warmup 1 (cfg3, 1x MI355X), round 2 (tools/profile_round.sh).  Counter values are KB per dispatch.  gfx950 correction: FETCH_SIZE",
+       "# --warmup 1 (cfg3, 1x MI355X), round 3 (tools/profile_round.sh).  Counter values are KB per dispatch.  gfx950 correction: FETCH_SIZE",
        "# reports half of a wide (16 B / lane) coalesced read stream -> doubled for the kernels whose reads are such streams (marked x2);",
        "# WRITE_SIZE as is.",
        f"{'kernel':28s} {'FETCH_SIZE[KB]':>15s} {'WRITE_SIZE[KB]':>15s} {'HBM bytes (corrected)':>24s}"]
@@ -73,14 +74,14 @@ for name, prefix, wide in rows:
     total = (2 if wide else 1) * f_kb * 1024 + w_kb * 1024
     traffic[name] = total
     txt.append(f"{name:28s} {f_kb:15.4g} {w_kb:15.4g} {total / 1e9:20.3f} GB{'  (x2)' if wide else ''}")
-open(os.path.join(P, "r02_hbm_traffic.txt"), "w").write("\n".join(txt) + "\n")
+open(os.path.join(P, ROUND + "_hbm_traffic.txt"), "w").write("\n".join(txt) + "\n")
 if "fused_csm_absim_kernel" in traffic:
     rec = {"kernel_source_hash": kernel_source_hash(),
-           "source": "profiles/r02_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 on gfx950)",
+           "source": "profiles/" + ROUND + "_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 on gfx950)",
            "cfg3": {"fused_stage_b": traffic["fused_csm_absim_kernel"] + traffic.get("fused_combine_kernel", 0.0),
                     "mtfft_fused": traffic.get("mtfft16_kernel"),
                     "measure_epilogue": traffic.get("measure_tile_multi_kernel")}}
-    json.dump(rec, open(os.path.join(P, "r02_hbm_traffic.json"), "w"), indent=1)
+    json.dump(rec, open(os.path.join(P, ROUND + "_hbm_traffic.json"), "w"), indent=1)
 
 sq = lines("sq.txt")
 if sq:
@@ -90,21 +91,33 @@ if sq:
         if m and "fused_csm_absim" in m.group(1):
             vals[m.group(2)] = float(m.group(4))
     busy, valu, mf = vals.get("SQ_BUSY_CYCLES", 1.0), vals.get("SQ_INSTS_VALU", 0.0), vals.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
-    h2 = ["# rocprofv3 --kernel-trace --pmc (one pass of 8 SQ counters), cfg3, 1x MI355X, round 2 (tools/profile_round.sh).",
+    h2 = ["# rocprofv3 --kernel-trace --pmc (one pass of 8 SQ counters), cfg3, 1x MI355X, round 3 (tools/profile_round.sh).",
           "# Averages per dispatch PER SHADER ENGINE (32 SEs x 8 CUs = 32 SIMDs each): SQ_INSTS_* are wave instructions, SQ_BUSY_CYCLES and",
           "# SQ_VALU_MFMA_BUSY_CYCLES cycles, SQ_WAIT_* / SQ_ACTIVE_INST_* quad-cycles.",
           "# fused kernel: VALU issue = %.3g instr x 4 cycles / 32 SIMDs = %.3g of %.3g busy cycles = %.0f %%; matrix pipe = %.4g / 32 SIMDs = %.3g cycles = %.0f %%"
           % (valu, valu * 4 / 32, busy, 100 * valu * 4 / 32 / busy, mf, mf / 32, 100 * mf / 32 / busy)]
-    open(os.path.join(P, "r02_pmc_fused.txt"), "w").write("\n".join(h2 + sq) + "\n")
+    open(os.path.join(P, ROUND + "_pmc_fused.txt"), "w").write("\n".join(h2 + sq) + "\n")
 
-for src, dst, head in (("mvar_64ch.txt", "r02_mvar_64ch.txt", "# tools/mvar_time.py 64 1792 256: full 64 x 64 Wilson factorisation + DTF, 7 windows x 256 bins (round 2)"),
-                       ("mvar_128ch.txt", "r02_mvar_128ch.txt", "# tools/mvar_time.py 128 1792 256: full 128 x 128 Wilson factorisation + DTF, 7 windows x 256 bins (round 2)"),
-                       ("engine_time.txt", "r02_engine_time.txt", "# float32 and float64 engine on the BASELINE configurations (round 2)"),
-                       ("stage_a.txt", "r02_stage_a.txt", "# tools/stage_a_breakdown.py: stage A per window length, cfg3 data volume (round 2)"),
-                       ("plane_pass.txt", "r02_plane_pass.txt", "# tools/plane_pass_time.py: stage B per plane family, cfg3 data volume, round 2"),
-                       ("shape_sweep.txt", "r02_shape_sweep.txt", "# tools/shape_sweep.py, round 2"),
-                       ("fused_ablation.txt", "r02_fused_ablation.txt", "# tools/fused_ablation.py, round 2 (SC_FUSED_DEBUG; results WRONG when set)")):
+for src, dst, head in (("mvar_64ch.txt", ROUND + "_mvar_64ch.txt", "# tools/mvar_time.py 64 1792 256: full 64 x 64 Wilson factorisation + DTF, 7 windows x 256 bins (round 3)"),
+                       ("mvar_128ch.txt", ROUND + "_mvar_128ch.txt", "# tools/mvar_time.py 128 1792 256: full 128 x 128 Wilson factorisation + DTF, 7 windows x 256 bins (round 3)"),
+                       ("engine_time.txt", ROUND + "_engine_time.txt", "# float32 and float64 engine on the BASELINE configurations (round 3)"),
+                       ("stage_a.txt", ROUND + "_stage_a.txt", "# tools/stage_a_breakdown.py: stage A per window length, cfg3 data volume (round 3)"),
+                       ("plane_pass.txt", ROUND + "_plane_pass.txt", "# tools/plane_pass_time.py: stage B per plane family, cfg3 data volume, round 3"),
+                       ("shape_sweep.txt", ROUND + "_shape_sweep.txt", "# tools/shape_sweep.py, round 3"),
+                       ("fused_ablation.txt", ROUND + "_fused_ablation.txt", "# tools/fused_ablation.py, round 3 (SC_FUSED_DEBUG; results WRONG when set)")):
     body = [l for l in lines(src) if "amdgpu.ids" not in l]
     if body:
         open(os.path.join(P, dst), "w").write("\n".join([head] + body) + "\n")
-print("profiles written:", sorted(f for f in os.listdir(P) if f.startswith("r02_")))
+for src, dst, head in (("api_wall.txt", ROUND + "_api_wall.txt", "# tools/api_wall.py: NumPy time series -> NumPy results through the public API at the cfg3 shape (third call), and the torch-free NumPy host"),
+                       ("numpy_host.txt", ROUND + "_numpy_host.txt", "# tools/numpy_host_time.py: the torch-free host (ctypes + NumPy over sc_device_alloc / sc_memcpy_* / sc_stream_*), cfg3 shape"),
+                       ("stage_a_wide.txt", ROUND + "_stage_a_wide.txt", "# tools/stage_a_wide.py: stage A for long windows, 256-thread (wide=0) against 512-thread workgroups (wide=1, the default)"),
+                       ("global_canonical.txt", ROUND + "_global_canonical.txt", "# tools/global_time.py: global coherence (1024 two-sided bins) and canonical coherence with large groups at the cfg5 shape"),
+                       ("measure_table.txt", ROUND + "_measure_table.txt", "# tools/measure_table.py: every measure of the public interface at the cfg3 shape")):
+    body = [l for l in lines(src) if "amdgpu.ids" not in l]
+    if body:
+        open(os.path.join(P, dst), "w").write("\n".join([head] + body) + "\n")
+for cfg in ("cfg2", "cfg4", "cfg5"):
+    body = [l for l in lines(f"bench_{cfg}.json") if l.startswith("{")]
+    if body:
+        open(os.path.join(P, f"{ROUND}_bench_line_{cfg}.json"), "w").write(body[-1] + "\n")
+print("profiles written:", sorted(f for f in os.listdir(P) if f.startswith(ROUND + "_")))

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-2 profile collection (run on the GPU box from the repo root; raw outputs under gpurun_out/r02/, summaries are
+# Profile collection of a round (ROUND=r03 by default; run on the GPU box from the repo root; raw outputs under gpurun_out/$ROUND/, summaries are
 # written into profiles/ by tools/profile_round.py afterwards):
 #   1. the bench line itself                                 python bench.py
 #   2. per-kernel durations of the same command              rocprofv3 --kernel-trace --stats
@@ -8,7 +8,8 @@
 # (counters in their own runs with --kernel-trace only: MI355X_MICROARCH.md, rocprofv3 PMC slots)
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/r02
+ROUND=${ROUND:-r03}
+OUT=$ROOT/gpurun_out/$ROUND
 mkdir -p $OUT
 cd $ROOT
 python bench.py --steps 20 --warmup 5 > $OUT/bench_line.json 2> $OUT/bench_line.err
@@ -31,4 +32,10 @@ python tools/stage_a_breakdown.py > $OUT/stage_a.txt 2>&1
 python tools/plane_pass_time.py > $OUT/plane_pass.txt 2>&1
 python tools/shape_sweep.py > $OUT/shape_sweep.txt 2>&1
 python tools/fused_ablation.py > $OUT/fused_ablation.txt 2>&1
+for c in cfg2 cfg4 cfg5; do python bench.py --config $c --steps 10 --warmup 3 > $OUT/bench_$c.json 2> $OUT/bench_$c.err; done
+python tools/api_wall.py > $OUT/api_wall.txt 2>&1
+python tools/numpy_host_time.py > $OUT/numpy_host.txt 2>&1
+python tools/stage_a_wide.py > $OUT/stage_a_wide.txt 2>&1
+python tools/global_time.py > $OUT/global_canonical.txt 2>&1
+python tools/measure_table.py > $OUT/measure_table.txt 2>&1
 ls -la $OUT
