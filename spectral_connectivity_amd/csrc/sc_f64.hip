@@ -470,17 +470,23 @@ static int f64_setup(const void* d_X, const sc_spectra_desc* desc, uint32_t plan
     return SC_OK;
 }
 
-template <int MAX_SLOTS, bool UNIT = false>
-static int launch_csm_f64(F64Args a, hipStream_t st) {
+template <int MAX_SLOTS, bool UNIT, int OC>
+static int launch_csm_f64_oc(F64Args a, hipStream_t st) {
     a.n_groups_of_tiles = (a.n_tiles + 4 * MAX_SLOTS - 1) / (4 * MAX_SLOTS);
     const unsigned grid = (unsigned)(((a.n_bins + 7) / 8) * 8 * a.n_groups_of_tiles);
-    constexpr int OC = 8;          // observation rows per staged chunk: 8 registers of staging, two workgroups per CU
     const size_t shmem = (size_t)2 * OC * a.CP * sizeof(double2);
     auto k = csm_f64_kernel<MAX_SLOTS, OC, UNIT>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), shmem, st, a);
     SC_CHECK_HIP(hipGetLastError());
     return SC_OK;
+}
+template <int MAX_SLOTS, bool UNIT = false>
+static int launch_csm_f64(F64Args a, hipStream_t st) {
+    // observation rows per staged chunk: 8 registers of staging, two workgroups per CU (SC_F64_OC=16: diagnostic)
+    const char* e = getenv("SC_F64_OC");
+    if (e && atoi(e) == 16) return launch_csm_f64_oc<MAX_SLOTS, UNIT, 16>(a, st);
+    return launch_csm_f64_oc<MAX_SLOTS, UNIT, 8>(a, st);
 }
 
 template <uint32_t WHICH, int MAXB>

@@ -155,10 +155,10 @@ mtfft16_kernel(MtArgs p) {
     // A channel whose (detrended) window is identically zero must come out as exact zeros, like the reference's
     // per-channel transform gives (its measures turn NaN on zero power): the conjugate-symmetry split of a packed pair
     // would leave the rounding noise of its partner there.  One flag per channel of the tile.
-    __shared__ int nzf[CT];
+    __shared__ int nzf[CT], nbf[CT];       // (plain stores of a constant: many threads may set the same flag)
 
     const int tid = threadIdx.x;
-    if (tid < CT) nzf[tid] = 0;
+    if (tid < CT) { nzf[tid] = 0; nbf[tid] = 0; }
     if constexpr (LONG) __syncthreads();
     MT_T0();
     int c0, r, w;
@@ -343,26 +343,33 @@ mtfft16_kernel(MtArgs p) {
         // flag 1: the channel is not identically zero; flag 2: it holds a NaN / infinity.  The reference transforms every
         // channel on its own, so a non-finite sample spoils that channel's spectrum only: such a channel leaves the packed
         // transform (zeros in its place, its partner stays clean) and its bins are written as NaN.
-        bool n0 = false, n1 = false, b0 = false, b1 = false;
+        // (integer tests on the bit patterns -- OR of the magnitudes != 0: some sample is not zero; largest magnitude with
+        //  the exponent field all ones: NaN or infinity -- measured 10 % cheaper on the mixed-radix kernels than the
+        //  floating-point comparisons)
+        unsigned or0 = 0u, or1 = 0u, mx0 = 0u, mx1 = 0u;
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
-            n0 |= xs[t].x != 0.f; n1 |= xs[t].y != 0.f;
-            b0 |= !(fabsf(xs[t].x) <= 3.4028235e38f); b1 |= !(fabsf(xs[t].y) <= 3.4028235e38f);
+            const unsigned u0 = __float_as_uint(xs[t].x) & 0x7fffffffu, u1 = __float_as_uint(xs[t].y) & 0x7fffffffu;
+            or0 |= u0; or1 |= u1;
+            mx0 = mx0 > u0 ? mx0 : u0; mx1 = mx1 > u1 ? mx1 : u1;
         }
-        if (n0 || b0) atomicMax(&nzf[2 * pf], b0 ? 2 : 1);
-        if (n1 || b1) atomicMax(&nzf[2 * pf + 1], b1 ? 2 : 1);
+        const bool n0 = or0 != 0u, n1 = or1 != 0u, b0 = mx0 >= 0x7f800000u, b1 = mx1 >= 0x7f800000u;
+        if (n0) nzf[2 * pf] = 1;
+        if (n1) nzf[2 * pf + 1] = 1;
+        if (b0) nbf[2 * pf] = 1;
+        if (b1) nbf[2 * pf + 1] = 1;
     }
     __syncthreads();                                  // tile and detrend scratch consumed: their space is free
-    if (nzf[2 * pf] == 2) {
+    if (nbf[2 * pf]) {
 #pragma unroll
         for (int t = 0; t < 16; ++t) xs[t].x = 0.f;
     }
-    if (nzf[2 * pf + 1] == 2) {
+    if (nbf[2 * pf + 1]) {
 #pragma unroll
         for (int t = 0; t < 16; ++t) xs[t].y = 0.f;
     }
-    const int fla = nzf[2 * (tid & (NF - 1))], flb = nzf[2 * (tid & (NF - 1)) + 1];             // of the pair this thread stores
-    const bool za = fla == 0, zb = flb == 0, na = fla == 2, nb = flb == 2;
+    const int spr = 2 * (tid & (NF - 1));                                   // the pair this thread stores
+    const bool na = nbf[spr] != 0, nb = nbf[spr + 1] != 0, za = !na && nzf[spr] == 0, zb = !nb && nzf[spr + 1] == 0;
     if constexpr (!LONG) {
         for (int i2 = tid; i2 < N; i2 += THREADS) tw[i2] = p.tw[i2];
         if (resident) {
@@ -838,9 +845,9 @@ __global__ void __launch_bounds__(512) mtfft_mixed_kernel(MxArgs p) {
     float2* tw = zB + NF * N;                                     // [N]
     float* tile = reinterpret_cast<float*>(tw + N);               // [L][XS]
     double* red = reinterpret_cast<double*>(tile + ((L * XS + 1) & ~1));   // [2][512] + trend [2][CT]
-    __shared__ int nzf[32];                                       // channel not identically zero (see mtfft16_kernel)
+    __shared__ int nzf[32], nbf[32];                              // channel not identically zero / holds a non-finite sample (see mtfft16_kernel)
     const int tid = threadIdx.x;
-    if (tid < 32) nzf[tid] = 0;
+    if (tid < 32) { nzf[tid] = 0; nbf[tid] = 0; }
     const int c0 = blockIdx.x * CT, r = blockIdx.y, w = blockIdx.z;
     const int64_t RC = (int64_t)p.R * C;
     const float* xw = p.x + ((int64_t)w * p.step * p.R + r) * C + c0;
@@ -891,16 +898,24 @@ __global__ void __launch_bounds__(512) mtfft_mixed_kernel(MxArgs p) {
     }
     {
         const int SL = 512 >> lct, cc = tid & (CT - 1), sl = tid >> lct;
-        bool nz = false, bad = false;
+        // (integer tests on the bit patterns: OR of the magnitudes != 0 <=> some sample is not zero; largest magnitude with
+        //  the exponent field all ones <=> NaN or infinity)
+        unsigned orv = 0u, mxv = 0u;
         if (sl < SL)
-            for (int l = sl; l < L; l += SL) { const float v = tile[l * XS + cc]; nz |= v != 0.f; bad |= !(fabsf(v) <= 3.4028235e38f); }
-        if (nz || bad) atomicMax(&nzf[cc], bad ? 2 : 1);
+            for (int l = sl; l < L; l += SL) { const unsigned u = __float_as_uint(tile[l * XS + cc]) & 0x7fffffffu; orv |= u; mxv = mxv > u ? mxv : u; }
+        const bool nz = orv != 0u, bad = mxv >= 0x7f800000u;
+        if (nz) nzf[cc] = 1;
+        if (bad) nbf[cc] = 1;
         __syncthreads();
         // a channel with a NaN / infinity leaves the packed transform (see mtfft16_kernel): zeros in, NaN bins out
-        if (sl < SL && nzf[cc] == 2)
+        if (sl < SL && nbf[cc]) {
             for (int l = sl; l < L; l += SL) tile[l * XS + cc] = 0.f;
+            nzf[cc] = 0;           // the store loop writes exact zeros for it; the fix-up after it writes the NaNs
+        }
         __syncthreads();
     }
+    bool any_bad = false;
+    for (int q = 0; q < CT; ++q) any_bad |= nbf[q] != 0;          // uniform over the workgroup
     const int F = N / 2 + 1;
     const int64_t sF = (int64_t)p.W * p.R * p.K * C;
     const bool vec_ok = (C % 2) == 0;
@@ -949,14 +964,23 @@ __global__ void __launch_bounds__(512) mtfft_mixed_kernel(MxArgs p) {
             float2 B = make_float2(0.5f * (u1.y + u2.y), 0.5f * (u2.x - u1.x));
             if (nzf[2 * pr] == 0) A = make_float2(0.f, 0.f);         // identically zero channel: exact zeros
             if (nzf[2 * pr + 1] == 0) B = make_float2(0.f, 0.f);
-            if (nzf[2 * pr] == 2) A = make_float2(__int_as_float(0x7fc00000), __int_as_float(0x7fc00000));   // non-finite channel
-            if (nzf[2 * pr + 1] == 2) B = make_float2(__int_as_float(0x7fc00000), __int_as_float(0x7fc00000));
             float2* d = Xk + (int64_t)f * sF + 2 * pr;
             if (vec_ok) {
                 *reinterpret_cast<float4*>(d) = make_float4(A.x, A.y, B.x, B.y);
             } else {
                 d[0] = A;
                 if (c + 1 < C) d[1] = B;
+            }
+        }
+        if (any_bad) {       // rare: a channel of this tile held a NaN / infinity -- its bins become NaN (same thread, same
+                             // addresses as the store loop above, so the order is the program's)
+            const float qn = __int_as_float(0x7fc00000);
+            for (int idx = tid; idx < F * NF; idx += 512) {
+                const int f = idx >> lnf, pr = idx & (NF - 1), c = c0 + 2 * pr;
+                if (c >= C) continue;
+                float2* d = Xk + (int64_t)f * sF + 2 * pr;
+                if (nbf[2 * pr]) d[0] = make_float2(qn, qn);
+                if (nbf[2 * pr + 1] && c + 1 < C) d[1] = make_float2(qn, qn);
             }
         }
         __syncthreads();     // the next taper refills zA
@@ -976,9 +1000,9 @@ __global__ void __launch_bounds__(64 * NF) mtfft_mixed_wave_kernel(MxArgs p) {
     double* red = reinterpret_cast<double*>(smem);                // [2][NT] + trend [2][CT]
     float2* tw = z + (NF * N > (2 * NT + 2 * CT) ? NF * N : (2 * NT + 2 * CT));   // [N]
     float* tile = reinterpret_cast<float*>(tw + N);               // [L][XS]
-    __shared__ int nzf[CT];                                       // channel not identically zero (see mtfft16_kernel)
+    __shared__ int nzf[CT], nbf[CT];                              // channel not identically zero / holds a non-finite sample (see mtfft16_kernel)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid < CT) nzf[tid] = 0;
+    if (tid < CT) { nzf[tid] = 0; nbf[tid] = 0; }
     const int L = p.L, C = p.C;
     int c0, r, w;
     if constexpr (NF < 8) {
@@ -1041,15 +1065,24 @@ __global__ void __launch_bounds__(64 * NF) mtfft_mixed_wave_kernel(MxArgs p) {
     {
         constexpr int SL = NT / CT;
         const int cc = tid & (CT - 1), sl = tid >> LCT;
-        bool nz = false, bad = false;
-        for (int l = sl; l < L; l += SL) { const float v = tile[l * XS + cc]; nz |= v != 0.f; bad |= !(fabsf(v) <= 3.4028235e38f); }
-        if (nz || bad) atomicMax(&nzf[cc], bad ? 2 : 1);
+        // (integer tests on the bit patterns: OR of the magnitudes != 0 <=> some sample is not zero; largest magnitude with
+        //  the exponent field all ones <=> NaN or infinity)
+        unsigned orv = 0u, mxv = 0u;
+        for (int l = sl; l < L; l += SL) { const unsigned u = __float_as_uint(tile[l * XS + cc]) & 0x7fffffffu; orv |= u; mxv = mxv > u ? mxv : u; }
+        const bool nz = orv != 0u, bad = mxv >= 0x7f800000u;
+        if (nz) nzf[cc] = 1;
+        if (bad) nbf[cc] = 1;
         __syncthreads();
         // a channel with a NaN / infinity leaves the packed transform (see mtfft16_kernel): zeros in, NaN bins out
-        if (nzf[cc] == 2)
+        if (nbf[cc]) {
             for (int l = sl; l < L; l += SL) tile[l * XS + cc] = 0.f;
+            nzf[cc] = 0;           // the store loop writes exact zeros for it; the fix-up below overwrites them
+        }
         __syncthreads();
     }
+    bool any_bad = false;
+#pragma unroll
+    for (int q = 0; q < CT; ++q) any_bad |= nbf[q] != 0;          // uniform over the workgroup
     const int64_t sF = (int64_t)p.W * p.R * p.K * C;
     const bool vec_ok = (C % 2) == 0;
     float2* zw = z + wave * N;                                    // this wave's pair
@@ -1078,14 +1111,23 @@ __global__ void __launch_bounds__(64 * NF) mtfft_mixed_wave_kernel(MxArgs p) {
             float2 B = make_float2(0.5f * (u1.y + u2.y), 0.5f * (u2.x - u1.x));
             if (nzf[2 * pr] == 0) A = make_float2(0.f, 0.f);         // identically zero channel: exact zeros
             if (nzf[2 * pr + 1] == 0) B = make_float2(0.f, 0.f);
-            if (nzf[2 * pr] == 2) A = make_float2(__int_as_float(0x7fc00000), __int_as_float(0x7fc00000));   // non-finite channel
-            if (nzf[2 * pr + 1] == 2) B = make_float2(__int_as_float(0x7fc00000), __int_as_float(0x7fc00000));
             float2* d = Xk + (int64_t)f * sF + 2 * pr;
             if (vec_ok) {
                 *reinterpret_cast<float4*>(d) = make_float4(A.x, A.y, B.x, B.y);
             } else {
                 d[0] = A;
                 if (c + 1 < C) d[1] = B;
+            }
+        }
+        if (any_bad) {       // rare: a channel of this tile held a NaN / infinity -- its bins become NaN (same thread, same
+                             // addresses as the store loop above, so the order is the program's)
+            const float qn = __int_as_float(0x7fc00000);
+            for (int idx = tid; idx < F * NF; idx += NT) {
+                const int f = idx >> LNF, pr = idx & (NF - 1), c = c0 + 2 * pr;
+                if (c >= C) continue;
+                float2* d = Xk + (int64_t)f * sF + 2 * pr;
+                if (nbf[2 * pr]) d[0] = make_float2(qn, qn);
+                if (nbf[2 * pr + 1] && c + 1 < C) d[1] = make_float2(qn, qn);
             }
         }
         __syncthreads();                                          // the next taper refills z

@@ -117,9 +117,9 @@ __global__ void __launch_bounds__(64 * NF) mtfft_f64_kernel(MdArgs p) {
     double* red = reinterpret_cast<double*>(smem);                // [2][NT] + trend [2][CT]
     zd* tw = z + (NF * N > (NT + CT) ? NF * N : (NT + CT));       // [N]
     double* tile = reinterpret_cast<double*>(tw + N);             // [L][XS] (odd stride: the column walks of the trend sums)
-    __shared__ int nzf[CT];                                       // channel not identically zero after the detrend
+    __shared__ int nzf[CT], nbf[CT];                              // channel not identically zero after the detrend / holds a non-finite sample
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid < CT) nzf[tid] = 0;
+    if (tid < CT) { nzf[tid] = 0; nbf[tid] = 0; }
     const int L = p.L, C = p.C;
     const int c0 = blockIdx.x * CT, r = blockIdx.y, w = blockIdx.z;
     const int64_t RC = (int64_t)p.R * C;
@@ -173,17 +173,26 @@ __global__ void __launch_bounds__(64 * NF) mtfft_f64_kernel(MdArgs p) {
         __syncthreads();                                          // the scratch is free: z takes its place
     }
     {
-        // flag 1: not identically zero; flag 2: holds a NaN / infinity.  The reference transforms every channel on its own
+        // nzf: not identically zero; nbf: holds a NaN / infinity.  The reference transforms every channel on its own
         // (transforms.py:1402-1405), so a non-finite sample spoils that channel's spectrum only: such a channel leaves the
         // packed transform (zeros in its place: its partner stays clean) and its bins are written as NaN.
-        bool nz = false, bad = false;
-        for (int l = sl; l < L; l += SL) { const double v = tile[l * XS + cc]; nz |= v != 0.0; bad |= !(fabs(v) <= 1.7976931348623157e308); }
-        if (nz || bad) atomicMax(&nzf[cc], bad ? 2 : 1);
+        unsigned long long orv = 0ull, mxv = 0ull;              // integer tests on the bit patterns (see mtfft16_kernel)
+        for (int l = sl; l < L; l += SL) {
+            const unsigned long long u = (unsigned long long)__double_as_longlong(tile[l * XS + cc]) & 0x7fffffffffffffffull;
+            orv |= u; mxv = mxv > u ? mxv : u;
+        }
+        const bool nz = orv != 0ull, bad = mxv >= 0x7ff0000000000000ull;
+        if (nz) nzf[cc] = 1;                                      // (plain stores of a constant: many threads may set the same flag)
+        if (bad) nbf[cc] = 1;
         __syncthreads();
-        if (nzf[cc] == 2)
+        if (nbf[cc]) {
             for (int l = sl; l < L; l += SL) tile[l * XS + cc] = 0.0;
+        }
         __syncthreads();
     }
+    // flags of the pair this thread stores (the store loop advances by NT, a multiple of NF: the pair never changes)
+    const int spr = 2 * (tid & (NF - 1));
+    const bool na = nbf[spr] != 0, nb = nbf[spr + 1] != 0, za = !na && nzf[spr] == 0, zb = !nb && nzf[spr + 1] == 0;
     const int64_t sF = (int64_t)p.W * p.R * p.K * C;
     zd* zw = z + wave * N;                                        // this wave's pair
     for (int k = 0; k < p.K; ++k) {
@@ -206,10 +215,10 @@ __global__ void __launch_bounds__(64 * NF) mtfft_f64_kernel(MdArgs p) {
             const zd u1 = z[pr * N + f], u2 = z[pr * N + (f == 0 ? 0 : N - f)];
             zd A = make_double2(0.5 * (u1.x + u2.x), 0.5 * (u1.y - u2.y));
             zd B = make_double2(0.5 * (u1.y + u2.y), 0.5 * (u2.x - u1.x));
-            if (nzf[2 * pr] == 0) A = make_double2(0.0, 0.0);
-            if (nzf[2 * pr + 1] == 0) B = make_double2(0.0, 0.0);
-            if (nzf[2 * pr] == 2) A = make_double2(__longlong_as_double(0x7ff8000000000000LL), __longlong_as_double(0x7ff8000000000000LL));
-            if (nzf[2 * pr + 1] == 2) B = make_double2(__longlong_as_double(0x7ff8000000000000LL), __longlong_as_double(0x7ff8000000000000LL));
+            if (za) A = make_double2(0.0, 0.0);
+            if (zb) B = make_double2(0.0, 0.0);
+            if (na) A = make_double2(__longlong_as_double(0x7ff8000000000000LL), __longlong_as_double(0x7ff8000000000000LL));
+            if (nb) B = make_double2(__longlong_as_double(0x7ff8000000000000LL), __longlong_as_double(0x7ff8000000000000LL));
             zd* d = Xk + (int64_t)f * sF + 2 * pr;
             d[0] = A;
             if (c + 1 < C) d[1] = B;
