@@ -483,7 +483,8 @@ static int launch_csm_f64_oc(F64Args a, hipStream_t st) {
 }
 template <int MAX_SLOTS, bool UNIT = false>
 static int launch_csm_f64(F64Args a, hipStream_t st) {
-    // observation rows per staged chunk: 8 registers of staging, two workgroups per CU (SC_F64_OC=16: diagnostic)
+    // observation rows per staged chunk: 8 registers of staging, two workgroups per CU.  (SC_F64_OC=16, diagnostic: half
+    // the barriers, but 256 registers with 24 spilled and one workgroup per CU -- 11.2 against 8.8 ms at cfg3.)
     const char* e = getenv("SC_F64_OC");
     if (e && atoi(e) == 16) return launch_csm_f64_oc<MAX_SLOTS, UNIT, 16>(a, st);
     return launch_csm_f64_oc<MAX_SLOTS, UNIT, 8>(a, st);
