@@ -34,6 +34,13 @@ struct F64Args {
     int plane;               // record plane the CSM kernel fills (re; im = plane + 1)
     uint32_t planes;
     int n_obs;
+    // Observations of a bin split over n_split workgroups (matrix-core CSM kernel and the 64 x 64 block plane kernel): part k
+    // sums its share of the staged chunks into its own record -- part 0 into the caller's, the others into a stream-
+    // ordered scratch ws[k - 1][bin][...] -- and f64_combine_kernel adds them in a fixed order.  903 bins on 256 CUs x 2
+    // resident workgroups ran 2 rounds for 1.76 rounds of work; five parts per bin run 9 rounds of a fifth each (1.8).
+    int n_split;
+    double* ws;
+    int64_t ws_part;         // doubles per part: n_bins * elems_per_bin
 };
 
 __device__ __forceinline__ int64_t f64_obs_offset(const F64Args& p, int o) {
@@ -88,8 +95,9 @@ __global__ void __launch_bounds__(256, MAX_SLOTS <= 9 ? 2 : 1) csm_f64_kernel(F6
     const int id = blockIdx.x;
     const int xcd = id & 7, j = id >> 3;
     const int tg = j % p.n_groups_of_tiles;
-    const int bin = (j / p.n_groups_of_tiles) * 8 + xcd;
-    if (bin >= p.n_bins) return;
+    const int unit = (j / p.n_groups_of_tiles) * 8 + xcd;             // (bin, part)
+    if (unit >= p.n_bins * p.n_split) return;
+    const int bin = unit / p.n_split, part = unit - bin * p.n_split;
     const int g = bin / p.F, f = bin - g * p.F;
     const double2* base = p.base + (int64_t)f * p.ax.sF + sc_group_offset(p.ax, g);
 
@@ -108,10 +116,12 @@ __global__ void __launch_bounds__(256, MAX_SLOTS <= 9 ? 2 : 1) csm_f64_kernel(F6
     for (int s = 0; s < MAX_SLOTS; ++s) { re[s] = (f64x4){0.0, 0.0, 0.0, 0.0}; im[s] = re[s]; }
 
     const int buf = E * p.CP;
-    const int n_chunks = (p.n_obs + E - 1) / E;
+    const int all_chunks = (p.n_obs + E - 1) / E;
+    const int ch0 = (int)((int64_t)part * all_chunks / p.n_split), ch1 = (int)((int64_t)(part + 1) * all_chunks / p.n_split);
+    const int n_chunks = ch1 - ch0;                                   // this part's chunks: [ch0, ch1)
     const F64Walk walk = f64_walk(p, tid);
     double2 regs[E];
-    f64_load<E, UNIT>(p, walk, base, 0, regs);
+    f64_load<E, UNIT>(p, walk, base, ch0 * E, regs);
     f64_store<E>(p, lds, tid, regs);
     __syncthreads();
     // A operand: lane l holds A[i = l & 15][k = l >> 4]; B operand: B[k = l >> 4][j = l & 15]  (one f64 each)
@@ -120,7 +130,7 @@ __global__ void __launch_bounds__(256, MAX_SLOTS <= 9 ? 2 : 1) csm_f64_kernel(F6
         const double2* cur = lds + (ch & 1) * buf;
         double2* nxt = lds + ((ch + 1) & 1) * buf;
         const bool more = ch + 1 < n_chunks;
-        if (more) f64_load<E, UNIT>(p, walk, base, (ch + 1) * E, regs);
+        if (more) f64_load<E, UNIT>(p, walk, base, (ch0 + ch + 1) * E, regs);
         // operands of slot s + 1 are requested before the four MFMAs of slot s are issued (left to itself the compiler
         // reloads one register pair per slot and waits for it: an LDS round trip between every two groups of MFMAs)
         constexpr int NSTEP = (E / 4) * MAX_SLOTS;
@@ -149,7 +159,8 @@ __global__ void __launch_bounds__(256, MAX_SLOTS <= 9 ? 2 : 1) csm_f64_kernel(F6
         __syncthreads();
     }
     // C/D of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg  (NOT the f32 map)
-    double* out = p.accum + (int64_t)bin * p.elems_per_bin + (int64_t)p.plane * p.n_tiles * SC_TILE_ELEMS;
+    double* out = (part == 0 ? p.accum : p.ws + (int64_t)(part - 1) * p.ws_part) + (int64_t)bin * p.elems_per_bin +
+                  (int64_t)p.plane * p.n_tiles * SC_TILE_ELEMS;
 #pragma unroll
     for (int s = 0; s < MAX_SLOTS; ++s) {
         if (!valid[s]) continue;
@@ -316,8 +327,9 @@ __global__ void __launch_bounds__(256, 2) nonlinear_f64_block_kernel(F64Args p) 
     const int NB64 = (p.C + 63) >> 6, n_blk = DIAG ? NB64 : NB64 * (NB64 - 1) / 2;
     const int id = blockIdx.x, xcd = id & 7, jj = id >> 3;
     const int blk = jj % n_blk;
-    const int bin = (jj / n_blk) * 8 + xcd;
-    if (bin >= p.n_bins) return;
+    const int unit = (jj / n_blk) * 8 + xcd;                          // (bin, part): see F64Args::n_split
+    if (unit >= p.n_bins * p.n_split) return;
+    const int bin = unit / p.n_split, part = unit - bin * p.n_split;
     int BI = 0, BJ = 0;
     if constexpr (DIAG) { BI = BJ = blk; }
     else { int rem = blk, len = NB64 - 1; while (rem >= len) { rem -= len; ++BI; --len; } BJ = BI + 1 + rem; }
@@ -344,14 +356,16 @@ __global__ void __launch_bounds__(256, 2) nonlinear_f64_block_kernel(F64Args p) 
     for (int e = 0; e < 64; ++e) acc[e] = 0.0;
     const int li = lane >> 3, lj = lane & 7;
     constexpr int joff = DIAG ? 0 : 64;
-    const int n_chunks = (p.n_obs + F64B_OC - 1) / F64B_OC;
-    fetch(0);
+    const int all_chunks = (p.n_obs + F64B_OC - 1) / F64B_OC;
+    const int ch0 = (int)((int64_t)part * all_chunks / p.n_split), ch1 = (int)((int64_t)(part + 1) * all_chunks / p.n_split);
+    const int n_chunks = ch1 - ch0;                                   // this part's chunks: [ch0, ch1)
+    fetch(ch0 * F64B_OC);
     park(lds);
     __syncthreads();
     for (int ch = 0; ch < n_chunks; ++ch) {
         const double2* cur = lds + (ch & 1) * (F64B_OC * 128);
         const bool more = ch + 1 < n_chunks;
-        if (more) fetch((ch + 1) * F64B_OC);
+        if (more) fetch((ch0 + ch + 1) * F64B_OC);
         // rows past n_obs are zero: they add |0|, 0^2, sign(0) = 0
 #pragma unroll 1
         for (int row = wave; row < F64B_OC; row += 4) {
@@ -413,7 +427,8 @@ __global__ void __launch_bounds__(256, 2) nonlinear_f64_block_kernel(F64Args p) 
         __syncthreads();
     }
     if (wave != 0) return;
-    double* out = p.accum + (int64_t)bin * p.elems_per_bin + (int64_t)sc_plane_offset(p.planes, WHICH) * p.n_tiles * SC_TILE_ELEMS;
+    double* out = (part == 0 ? p.accum : p.ws + (int64_t)(part - 1) * p.ws_part) + (int64_t)bin * p.elems_per_bin +
+                  (int64_t)sc_plane_offset(p.planes, WHICH) * p.n_tiles * SC_TILE_ELEMS;
 #pragma unroll
     for (int a = 0; a < 8; ++a)
 #pragma unroll
@@ -467,17 +482,63 @@ static int f64_setup(const void* d_X, const sc_spectra_desc* desc, uint32_t plan
     a->n_obs = ax.n_obs;
     a->plane = 0;
     a->n_groups_of_tiles = 1;
+    a->n_split = 1;
+    a->ws = nullptr;
+    a->ws_part = (int64_t)a->n_bins * a->elems_per_bin;
     return SC_OK;
+}
+
+// accum[bin][plane0 .. plane0 + n_planes) += ws[0][bin][...] + ws[1][bin][...] + ... (fixed order)
+__global__ void __launch_bounds__(256) f64_combine_kernel(F64Args p, int plane0, int n_planes) {
+    const int64_t plane = (int64_t)p.n_tiles * SC_TILE_ELEMS, per_bin = (int64_t)n_planes * plane / 2;     // double2 items
+    const int64_t total = per_bin * p.n_bins;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t bin = i / per_bin, e = (i - bin * per_bin) * 2;
+        const int64_t off = bin * p.elems_per_bin + (int64_t)plane0 * plane + e;
+        double2 a = *reinterpret_cast<const double2*>(p.accum + off);
+        for (int k = 0; k + 1 < p.n_split; ++k) {
+            const double2 b = *reinterpret_cast<const double2*>(p.ws + (int64_t)k * p.ws_part + off);
+            a.x += b.x; a.y += b.y;
+        }
+        *reinterpret_cast<double2*>(p.accum + off) = a;
+    }
+}
+static void f64_combine(const F64Args& a, int plane0, int n_planes, hipStream_t st) {
+    if (a.n_split > 1) hipLaunchKernelGGL(f64_combine_kernel, dim3(2048), dim3(256), 0, st, a, plane0, n_planes);
+}
+
+// parts per bin for W workgroups per part on `slots` resident workgroups: the S with the fewest rounds / S, at least 16
+// staged chunks per part
+static int f64_pick_split(int64_t W, int n_obs, int rows_per_chunk) {
+    const char* e = getenv("SC_F64_SPLIT");
+    if (e && atoi(e) >= 1 && atoi(e) <= 16) return atoi(e);
+    int dev = 0, n_cu = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n_cu = v;
+    }
+    const int64_t slots = (int64_t)n_cu * 2;
+    const int nc = (n_obs + rows_per_chunk - 1) / rows_per_chunk;
+    int best = 1;
+    double best_cost = 1e30;
+    for (int S = 1; S <= 12; ++S) {
+        if (S > 1 && nc / S < 16) break;
+        const double cost = (double)((W * S + slots - 1) / slots) / S * (1.0 + 0.01 * (S - 1));
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = S; }
+    }
+    return best;
 }
 
 template <int MAX_SLOTS, bool UNIT, int OC>
 static int launch_csm_f64_oc(F64Args a, hipStream_t st) {
     a.n_groups_of_tiles = (a.n_tiles + 4 * MAX_SLOTS - 1) / (4 * MAX_SLOTS);
-    const unsigned grid = (unsigned)(((a.n_bins + 7) / 8) * 8 * a.n_groups_of_tiles);
+    const int64_t units = (int64_t)a.n_bins * a.n_split;
+    const unsigned grid = (unsigned)(((units + 7) / 8) * 8 * a.n_groups_of_tiles);
     const size_t shmem = (size_t)2 * OC * a.CP * sizeof(double2);
     auto k = csm_f64_kernel<MAX_SLOTS, OC, UNIT>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), shmem, st, a);
+    f64_combine(a, a.plane, 2, st);
     SC_CHECK_HIP(hipGetLastError());
     return SC_OK;
 }
@@ -506,7 +567,7 @@ static int launch_nl_f64(const F64Args& a, hipStream_t st) {
 template <uint32_t WHICH>
 static int launch_nl_f64_block(const F64Args& a, hipStream_t st) {
     const int NB64 = (a.C + 63) / 64, n_off = NB64 * (NB64 - 1) / 2;
-    const unsigned bins8 = (unsigned)(((a.n_bins + 7) / 8) * 8);
+    const unsigned bins8 = (unsigned)((((int64_t)a.n_bins * a.n_split + 7) / 8) * 8);        // (bin, part) units
     const size_t shmem = (size_t)2 * F64B_OC * 128 * sizeof(double2);      // 64 KB (the final reduction needs 48 KB)
     auto kd = nonlinear_f64_block_kernel<WHICH, true>;
     auto ko = nonlinear_f64_block_kernel<WHICH, false>;
@@ -514,6 +575,7 @@ static int launch_nl_f64_block(const F64Args& a, hipStream_t st) {
     SC_CHECK_HIP(hipFuncSetAttribute((const void*)ko, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     if (n_off > 0) hipLaunchKernelGGL(ko, dim3(bins8 * n_off), dim3(256), shmem, st, a);
     hipLaunchKernelGGL(kd, dim3(bins8 * NB64), dim3(256), shmem, st, a);
+    f64_combine(a, sc_plane_offset(a.planes, WHICH), 1, st);
     SC_CHECK_HIP(hipGetLastError());
     return SC_OK;
 }
@@ -566,6 +628,22 @@ extern "C" int sc_accumulate_f64(const void* d_X, const sc_spectra_desc* desc, u
             return SC_EHIP;
         }
     }
+    // observations of a bin split over several workgroups (F64Args::n_split): partial records in a stream-ordered scratch
+    // of this call, allocated BEFORE the fork (both streams write disjoint planes of it) and released after the join
+    const bool block_planes = a.C >= 48 && !getenv("SC_F64_NO_BLOCK") && (which & (SC_PLANE_ABS_IM | SC_PLANE_IM_SQ | SC_PLANE_SIGN_IM));
+    double* ws = nullptr;
+    if ((which & (SC_PLANE_CSM | SC_PLANE_UNIT)) || block_planes) {
+        int S = f64_pick_split((int64_t)a.n_bins * ((a.n_tiles + 35) / 36), a.n_obs, F64B_OC);
+        const int64_t part_bytes = a.ws_part * (int64_t)sizeof(double);
+        while (S > 1 && (int64_t)(S - 1) * part_bytes > ((int64_t)2 << 30)) --S;
+        if (S > 1 && hipMallocAsync((void**)&ws, (size_t)(S - 1) * part_bytes, st) == hipSuccess) {
+            a.n_split = S;
+            a.ws = ws;
+        } else {
+            (void)hipGetLastError();       // no scratch: one workgroup per bin, as before
+            ws = nullptr;
+        }
+    }
     hipStream_t st_nl = st;
     if (fork) {
         SC_CHECK_HIP(hipEventRecord(ev_fork, st));
@@ -613,5 +691,6 @@ extern "C" int sc_accumulate_f64(const void* d_X, const sc_spectra_desc* desc, u
         SC_CHECK_HIP(hipEventRecord(ev_join, side));
         SC_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, ev_join, 0));
     }
+    if (ws) (void)hipFreeAsync(ws, (hipStream_t)stream);
     return rc;
 }

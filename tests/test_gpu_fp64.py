@@ -368,3 +368,22 @@ def test_incremental_records_equal_fresh_ones(sc):
         assert union & k == 0, ints                 # no family is held (or was computed) twice
         union |= k
     assert bin(union).count("1") == 5, ints
+
+
+@pytest.mark.parametrize("L", [64, 128, 256, 512, 1024])
+def test_radix16_float64_transform_equals_the_wave_per_pair_kernel_and_the_oracle(sc, monkeypatch, L):
+    """Powers of two 64 ... 1024 take the register-resident radix-16 kernel in doubles (round 3); SC_MTFFT_F64=wave keeps the
+    radix-4 wave-per-pair kernel reachable: both against the oracle (1e-11 of the maximum) and against each other."""
+    from oracle import spectral_oracle as so
+    rng = np.random.default_rng(L)
+    C = 11 if L == 256 else 6                       # an odd channel count once: unpaired last channel
+    x = rng.standard_normal((L + L // 2, 3, C)) + np.linspace(0, 2, L + L // 2)[:, None, None]
+    kw = dict(sampling_frequency=500.0, time_halfbandwidth_product=3, n_time_samples_per_window=L, n_time_samples_per_step=L // 2,
+              detrend_type="linear")
+    got = sc.Multitaper(x, **kw).fft()
+    ref, _ = so.multitaper_fft(x, fs=500.0, NW=3, n_time_samples_per_window=L, n_time_samples_per_step=L // 2, detrend_type="linear")
+    scale = np.abs(ref).max()
+    assert np.abs(got - ref).max() <= 1e-11 * scale
+    monkeypatch.setenv("SC_MTFFT_F64", "wave")
+    wave = sc.Multitaper(x, **kw).fft()
+    assert np.abs(wave - got).max() <= 1e-12 * scale
