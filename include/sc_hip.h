@@ -23,8 +23,12 @@
  *        rocFFT work buffers of
  *        sc_granger_pairwise_f64 / sc_wilson_factor_f64 / sc_mvar_factor_f64 for lengths their fused
  *        transform kernel does not take.
- *      - one side stream + two events (created on first use, kept) of sc_accumulate_f64, which forks its
- *        per-observation plane kernels from the caller's stream and joins them back before it returns.
+ *      - sc_accumulate_f64: one side stream per device (created on first use, kept) and two events per call (destroyed
+ *        when it returns) -- it forks its per-observation plane kernels from the caller's stream and joins them back
+ *        before it returns --, and a stream-ordered scratch of (S - 1) records (<= 2 GB) for the partial sums of the S
+ *        workgroups that share a bin's observations (hipMallocAsync / hipFreeAsync on `stream`).
+ *      - sc_global_coherence_f64 beyond 64 signals: the matrices (n_signals^2 x 16 B per resident workgroup, <= 1024 of
+ *        them) and per-vector work arrays of its eigen-solver (hipMalloc / hipFree inside the call, which synchronises).
  *    Everything else (spectra, records, workspaces, outputs) is caller memory with sizes the
  *    *_bytes / sc_accum_layout queries report.
  *  - `stream` is a hipStream_t passed as void* (NULL = default stream).  All calls are
@@ -183,8 +187,9 @@ int sc_multitaper_fft_f32(const float* d_x, int64_t T, int64_t R, int64_t C,
                           int64_t L, int64_t step, int64_t W, int64_t N,
                           const float* d_tapers, int64_t K, int detrend_type,
                           const void* d_twiddles, void* d_X /*float2*/, void* stream);
-/* float64 engine, the same fusion in doubles (sc_mtfft_f64.hip): complex128 spectra X[f][w][r][k][c], one wave per
- * packed channel pair, in-place mixed-radix passes in LDS, twiddles computed by the kernel.  Lengths with a compiled
+/* float64 engine, the same fusion in doubles (sc_mtfft_f64.hip): complex128 spectra X[f][w][r][k][c]; powers of two
+ * 64 ... 1024: register-resident radix-16 passes like the float32 kernel; the next_fast_len lengths: one wave per
+ * packed channel pair, in-place mixed-radix passes in LDS; twiddles computed by the kernel.  Lengths with a compiled
  * transform: 64, 128, 256, 512, 1024 and 200, 250, 400, 500, 1000 (sc_multitaper_fft_f64_supported); every other
  * length: sc_taper_windows_f64 + sc_fft_execute_f64. */
 int sc_multitaper_fft_f64_supported(int64_t L, int64_t N);
