@@ -176,6 +176,25 @@ def gen_f13_canonical_few_observations(T, Cn, mpd, sim):
          cc_a=c.canonical_coherence(la)[0], cc_b=c.canonical_coherence(lb)[0])
 
 
+def gen_f14_complex_series(T, Cn, mpd, sim):
+    """F14: complex-valued time series (the reference's generic fft takes them, transforms.py:1402-1405): two-sided
+    coefficients for every detrend mode, and the measures of the non-negative bins."""
+    rng = np.random.default_rng(14)
+    x = rng.standard_normal((320, 3, 5)) + 1j * rng.standard_normal((320, 3, 5))
+    x[:, :, 1] += 0.6 * np.roll(x[:, :, 0], 2, axis=0)
+    x += (np.linspace(0, 1, 320) * (1 + 2j))[:, None, None]
+    out = dict(x=x, fs=200.0, NW=2.0, L=128, step=64)
+    for det in ("constant", "linear", None):
+        m = T.Multitaper(x, sampling_frequency=200.0, time_halfbandwidth_product=2, n_time_samples_per_window=128,
+                         n_time_samples_per_step=64, detrend_type=det)
+        out[f"fft_{det}"] = m.fft()
+    c = Cn.Connectivity.from_multitaper(m)       # detrend None: the last one
+    for name in ("power", "coherency", "coherence_magnitude", "weighted_phase_lag_index", "phase_locking_value",
+                 "pairwise_spectral_granger_prediction"):
+        out[name] = getattr(c, name)()
+    save("f14_complex_series", **out)
+
+
 def gen_api_surface(*_):
     """Public names of the reference (functions, classes, methods, properties) with their argument names and default
     values, as data: tests/golden/api_surface.json.  The drop-in mirrors exactly this surface."""
@@ -225,7 +244,7 @@ def main():
     if len(sys.argv) > 1:                      # python oracle/gen_golden.py f9 : only the named fixtures
         for name in sys.argv[1:]:
             {"f9": gen_f9_mvar, "f10": gen_f10_global, "f11": gen_f11_post, "f12": gen_f12_cholesky_fallback,
-             "f13": gen_f13_canonical_few_observations, "api": gen_api_surface}[name](T, Cn, mpd, sim)
+             "f13": gen_f13_canonical_few_observations, "f14": gen_f14_complex_series, "api": gen_api_surface}[name](T, Cn, mpd, sim)
         return
     Multitaper, Connectivity = T.Multitaper, Cn.Connectivity
 
@@ -373,6 +392,7 @@ def main():
     gen_f11_post(T, Cn, mpd, sim)
     gen_f12_cholesky_fallback(T, Cn, mpd, sim)
     gen_f13_canonical_few_observations(T, Cn, mpd, sim)
+    gen_f14_complex_series(T, Cn, mpd, sim)
     gen_api_surface()
 
 

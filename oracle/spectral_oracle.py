@@ -99,7 +99,8 @@ def detrend(windows, kind):
         L = windows.shape[-1]
         A = np.ones((L, 2))
         A[:, 0] = np.arange(1, L + 1) / L
-        flat = windows.reshape(-1, L).T.astype(np.float64)
+        # (complex series: the real regressors fit the real and the imaginary part separately, transforms.py:1903-1909)
+        flat = windows.reshape(-1, L).T.astype(np.complex128 if np.iscomplexobj(windows) else np.float64)
         coef = np.linalg.lstsq(A, flat, rcond=None)[0]
         return (flat - A @ coef).T.reshape(windows.shape)
     raise ValueError(f"Invalid trend type '{kind}'")

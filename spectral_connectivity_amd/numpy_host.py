@@ -174,7 +174,8 @@ class NumpyHost:
         import warnings
         m, lib = multitaper, self.lib
         if np.iscomplexobj(m.time_series):
-            raise TypeError("complex-valued time series are not supported by the HIP engine")
+            raise TypeError("complex-valued time series: use the PyTorch host (spectral_connectivity_amd.Multitaper), which "
+                            "transforms the real and imaginary parts and assembles the two-sided spectrum")
         if m.detrend_type not in _lib.DETREND:
             raise ValueError(f"Invalid trend type '{m.detrend_type}' is not supported.\n"
                              "Valid options are 'linear'/'l', 'constant'/'c' or None.")

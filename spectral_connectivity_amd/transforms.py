@@ -526,11 +526,9 @@ class Multitaper:
                 raise ValueError(f"Invalid trend type '{self.detrend_type}' is not supported.\n"
                                  "Valid options are 'linear'/'l', 'constant'/'c' or None.")
             if np.iscomplexobj(self.time_series):
-                # the reference's generic fft takes complex series (transforms.py:1402-1405); the device transforms are
-                # real-input (one-sided spectra, conjugate-mirrored negative bins): refuse rather than drop Im x
-                raise TypeError("complex-valued time series are not supported by the HIP engine: its transforms are "
-                                "real-to-complex (one-sided spectra). Analyse the real and imaginary parts as separate "
-                                "signals, or use the reference package for analytic signals.")
+                # the reference's generic fft takes complex series (transforms.py:1402-1405): see _complex_device_spectra
+                self._device_spectra[precision] = self._complex_device_spectra(device, precision)
+                return self._device_spectra[precision]
             dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
             tapers = np.asarray(self.tapers, dtype=np.float64)             # (L, K), * sqrt(fs)
             logger.info(self)
@@ -583,6 +581,37 @@ class Multitaper:
                     self.n_fft_samples, self.n_time_windows, self.detrend_type, n_signals=n_signals)
         return self._device_spectra[precision]
 
+    def _complex_device_spectra(self, device, precision):
+        """Complex-valued series z = a + i b.  Window extraction, detrend (real regressors: real and imaginary part are
+        fitted separately, transforms.py:1903-1909), taper and FFT are all linear, so Z = FFT(a) + i FFT(b): the device
+        transforms the 2 C real series (a | b) with the real-input kernels and a pointwise pass assembles the two-sided
+        spectrum -- bins 0 .. N/2 as A + i B, the others from the conjugate mirrors of A and B -- into a DeviceSpectra with
+        ``real_input=False`` (all N bins stored, like uploaded coefficients)."""
+        import torch
+        from . import engine
+        ts = np.asarray(self.time_series)
+        C = ts.shape[2]
+        parts = Multitaper(np.concatenate([ts.real, ts.imag], axis=2), sampling_frequency=self.sampling_frequency,
+                           time_halfbandwidth_product=self.time_halfbandwidth_product, detrend_type=self.detrend_type,
+                           start_time=self.start_time, n_fft_samples=self._n_fft_samples, tapers=self._tapers,
+                           n_tapers=self._n_tapers, n_time_samples_per_window=self.n_time_samples_per_window,
+                           n_time_samples_per_step=self.n_time_samples_per_step, is_low_bias=self.is_low_bias)
+        parts._finite_checked = self._finite_checked
+        sp2 = parts.device_spectra(device, precision)
+        self._finite_checked = True
+        X2 = sp2.coefficients()                                   # (F, W, R, K, 2 C) one-sided
+        N, F = sp2.n_fft, sp2.F
+        A, B = X2[..., :C], X2[..., C:]
+        mirror = torch.arange(N - F, 0, -1, device=X2.device)      # bin f = F .. N - 1 takes the conjugate of bin N - f
+        C_alloc = C if (sp2.f64 or C % 2 == 0 or C + 1 > 256) else C + 1
+        X = torch.zeros((N,) + tuple(X2.shape[1:4]) + (C_alloc,), dtype=X2.dtype, device=X2.device)
+        X[:F, ..., :C] = A + 1j * B
+        if N > F:
+            X[F:, ..., :C] = torch.conj(A[mirror]) + 1j * torch.conj(B[mirror])
+        W, R, K = X.shape[1:4]
+        return engine.DeviceSpectra(X, (N, W, R, K, C), (W * R * K * C_alloc, R * K * C_alloc, K * C_alloc, C_alloc), N,
+                                    real_input=False, C_alloc=C_alloc)
+
     def fft(self):
         """Fourier coefficients (n_time_windows, n_trials, n_tapers, n_fft_samples, n_signals).
 
@@ -593,6 +622,8 @@ class Multitaper:
         sp = self.device_spectra()
         one = sp.coefficients().cpu().numpy().astype(np.complex128, copy=False)          # (F, W, R, K, C)
         one = np.moveaxis(one, 0, 3)                            # (W, R, K, F, C)
+        if not sp.real_input:                                   # complex series: all N bins are stored
+            return np.ascontiguousarray(one)
         N = self.n_fft_samples
         out = np.empty(one.shape[:3] + (N, one.shape[-1]), dtype=np.complex128)
         F = one.shape[3]

@@ -25,10 +25,14 @@ def golden():
 
 
 def pytest_generate_tests(metafunc):
-    """A module that declares ``SC_PRECISIONS = ("float32", "dtype")`` runs every test once per engine selection: forced
+    """A module that declares ``SC_PRECISIONS = ("float32", "dtype")`` runs its tests (all of them, or those named in
+    ``SC_PRECISIONS_TESTS``) once per engine selection: forced
     float32 (the headline path) and the package default, where ``dtype=complex128`` -- the reference's default, what
     every test that passes no dtype gets -- selects the float64 engine."""
     precisions = getattr(metafunc.module, "SC_PRECISIONS", None)
+    only = getattr(metafunc.module, "SC_PRECISIONS_TESTS", None)      # optional: the tests of the module that run under both
+    if only is not None and metafunc.function.__name__ not in only:
+        precisions = None
     if precisions and "_engine_precision" in metafunc.fixturenames:
         metafunc.parametrize("_engine_precision", list(precisions), indirect=True,
                              ids=["f32-engine" if p == "float32" else "default-engine" for p in precisions])

@@ -50,8 +50,8 @@ def test_dtype_selects_the_engine(sc):
     close64(m.fft(), coef, what="Multitaper.fft() is float64 like the reference's")
     with pytest.raises(ValueError, match="complex64 or numpy.complex128"):
         sc.Connectivity.from_multitaper(m, dtype=np.float32)
-    with pytest.raises(TypeError, match="complex-valued time series"):
-        sc.Multitaper(x + 1j * x, sampling_frequency=100.0).fft()
+    zc, _ = so.multitaper_fft(x + 1j * x[::-1], fs=100.0, NW=2)                # complex series: two-sided, like the reference's
+    close64(sc.Multitaper(x + 1j * x[::-1], sampling_frequency=100.0, time_halfbandwidth_product=2).fft(), zc, what="complex series")
 
 
 def test_f1_f2_transform_and_measures(sc, golden):

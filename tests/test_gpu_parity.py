@@ -11,7 +11,20 @@ from conftest import granger_close
 from oracle import spectral_oracle as so
 
 pytestmark = pytest.mark.gpu
-SC_PRECISIONS = ("float32", "dtype")     # every test under the forced float32 engine AND the package default
+SC_PRECISIONS = ("float32", "dtype")     # under the forced float32 engine AND the package default (float64 engine for the
+# default dtype): every test against the reference's golden vectors, the labelled wrapper, the dtype / NaN / complex-input
+# behaviour and the eigen-solver.  The kernel-selection tests below exercise float32 kernels explicitly and run once
+# (their float64 counterparts live in tests/test_gpu_fp64.py).
+SC_PRECISIONS_TESTS = {
+    "test_f1_cfg1", "test_f2_detrend", "test_f3_every_measure_every_expectation", "test_f4_lengths", "test_f7_edges",
+    "test_known_answers_from_reference_unit_tests", "test_f5_granger_vs_reference", "test_granger_from_uploaded_two_sided_coefficients",
+    "test_f12_cholesky_failure_outcome", "test_f6_canonical_coherence", "test_f9_mvar_measures_vs_reference",
+    "test_f10_global_coherence_vs_reference", "test_wrapper_labelled_outputs_against_the_oracle",
+    "test_f11_band_statistics_on_the_device_coherency", "test_output_dtypes_are_the_references",
+    "test_nonfinite_sample_spoils_only_its_own_channel", "test_f13_canonical_coherence_with_fewer_observations_than_channels",
+    "test_global_coherence_any_rank_beyond_64_signals", "test_global_coherence_degenerate_eigenvalues_and_the_jacobi_cross_check",
+    "test_f14_complex_valued_time_series", "test_silent_and_constant_channels_give_exact_zero_spectra",
+}
 
 RTOL = 1e-5
 ATOL_SCALE = 1e-5
@@ -939,3 +952,20 @@ def test_global_coherence_degenerate_eigenvalues_and_the_jacobi_cross_check(sc, 
     monkeypatch.setenv("SC_GLOBAL_EIG", "jacobi")
     vals_j, _ = sc.Connectivity(coef).global_coherence(max_rank=4)
     np.testing.assert_allclose(vals_j, vals[..., -4:], rtol=1e-6)
+
+
+def test_f14_complex_valued_time_series(sc, golden):
+    """Complex series (the reference's generic fft takes them): two-sided coefficients for every detrend mode and the
+    measures of the non-negative bins, against vectors from the real reference.  The device transforms the real and the
+    imaginary parts as 2 C real series and assembles the two-sided spectrum (Multitaper._complex_device_spectra)."""
+    g = golden("f14_complex_series")
+    kw = dict(sampling_frequency=float(g["fs"]), time_halfbandwidth_product=float(g["NW"]),
+              n_time_samples_per_window=int(g["L"]), n_time_samples_per_step=int(g["step"]))
+    for det in ("constant", "linear", None):
+        m = sc.Multitaper(g["x"], detrend_type=det, **kw)
+        close32(m.fft(), g[f"fft_{det}"], what=f"complex series, detrend={det}")
+    c = sc.Connectivity.from_multitaper(m)
+    for name in ("power", "coherency", "coherence_magnitude", "weighted_phase_lag_index", "phase_locking_value"):
+        close32(getattr(c, name)(), g[name], rtol=3e-5, atol_scale=3e-5, what=f"complex series: {name}")
+    granger_close(c.pairwise_spectral_granger_prediction(), g["pairwise_spectral_granger_prediction"], 5e-5,
+                  what="complex series: Granger")

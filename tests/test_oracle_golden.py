@@ -200,3 +200,13 @@ def test_kat_coherency_pli_wpli():
     close(so.weighted_phase_lag_index(coef)[0, 0], [[0, 1], [-1, 0]], atol=1e-15)
     close(so.imaginary_coherence(_two_signal_coef(0.3, 0.3))[0, 0, 0, 1], 0.0, atol=1e-15)
     close(so.phase_locking_value(coef)[0, 0, 0, 1], 1.0)
+
+
+def test_f14_complex_valued_time_series(golden):
+    g = golden("f14_complex_series")
+    kw = dict(fs=float(g["fs"]), NW=float(g["NW"]), n_time_samples_per_window=int(g["L"]), n_time_samples_per_step=int(g["step"]))
+    for det in ("constant", "linear", None):
+        coef, _ = so.multitaper_fft(g["x"], detrend_type=det, **kw)
+        close(coef, g[f"fft_{det}"], rtol=1e-10, atol=1e-12)
+    close(so.coherence_magnitude(coef), g["coherence_magnitude"], atol=1e-10)
+    close(so.weighted_phase_lag_index(coef), g["weighted_phase_lag_index"], atol=1e-10)
