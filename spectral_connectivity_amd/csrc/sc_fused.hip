@@ -70,19 +70,23 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
                             // of a channel sit within the 8-bit offsets of ds_read2_b64 -- one address add
                             // per 16-channel fragment set instead of one per plane on this VALU-bound kernel
 
-// Which channels a workgroup stages and where its tiles live in the record.  The 128 staged channel slots are two
-// halves of 64: the first holds n0 channels starting at st.base, the second n1 channels starting ch1 elements further
-// (64: one contiguous range -- every launch up to 128 channels).  Local 16-channel tile b < 4 is tile t0 + b of the
-// record, b >= 4 tile t1 + (b - 4); NBr = tile rows of the record.  129 ... 256 channels are covered by several
-// launches over 64-channel quarters (see fused_run): contiguous ranges for the diagonal part, a quarter of the first
-// half paired with one of the second (cross = 1: only the tiles BETWEEN the two halves) for the rest.
+// Which channels a workgroup stages and where its tiles live in the record.  The 128 staged channel slots are four
+// blocks of 32: local block b holds n32[b] channels (even; every block ahead of the last staged one is full) starting
+// off32[b] elements from st.base, and its two 16-channel tiles are tiles t32[b], t32[b] + 1 of the record (NBr = tile
+// rows of the record).  One contiguous range is every launch up to 128 channels; 129 ... 256 channels are covered by
+// several launches whose staged blocks come from up to two ranges (see launch_fused_all).  Which of the staged blocks'
+// products a launch owns is a staircase of the local upper triangle: tile (r, c), r <= c, is active when c >= col_lo and
+// r < row_hi (in 16-channel tiles; the whole triangle: col_lo = 0, row_hi = NB).
+// The per-block values are packed one byte each (block b in bits 8 b ... 8 b + 7: one bit-field extract for a per-lane
+// b, where an indexed array in the kernel arguments would go through scratch): off32 in units of 32 channels.
 struct FuMap {
-    int n0, n1, ch1;
-    int t0, t1, nb0, nb1, NBr;
-    int cross;
+    unsigned off32, n32, t32;
+    int NBr;
+    int col_lo, row_hi;
 };
-__host__ __device__ inline int fu_gt(const FuMap& m, int b) { return b < 4 ? m.t0 + b : m.t1 + (b - 4); }
-__host__ __device__ inline bool fu_tile_ok(const FuMap& m, int b) { return b < 4 ? b < m.nb0 : (b - 4) < m.nb1; }
+__host__ __device__ inline int fu_byte(unsigned packed, int b) { return (int)((packed >> (8 * b)) & 0xffu); }
+__host__ __device__ inline int fu_gt(const FuMap& m, int b) { return fu_byte(m.t32, b >> 1) + (b & 1); }
+__host__ __device__ inline bool fu_tile_ok(const FuMap& m, int b) { return (b & 1) * 16 < fu_byte(m.n32, b >> 1); }
 
 struct FusedArgs {
     ScStage st;
@@ -90,12 +94,15 @@ struct FusedArgs {
     float* accum;
     int64_t floats_per_bin;
     int n_bins, F, NB, n_tiles, NB32, n_blocks32, n_sets;
+    int shape_col_lo, shape_row_hi;   // the launch's 32x32 blocks: bi <= bj, bj >= shape_col_lo, bi < shape_row_hi
     int csm_plane, abs_plane;
     int sq_plane, sign_plane;   // small-channel kernel only: sum (Im s)^2, sum sign(Im s); -1 = absent
     int fold[6], n_fold;        // small-channel kernel only: the record planes a launch writes (folded over the parts)
     int nl_op;           // what the abs waves accumulate from the per-observation d = Im(x_i conj x_j) into record plane
                          // `abs_plane`: FU_OP_ABS |d| (with the CSM planes, one pass), FU_OP_SQ d^2, FU_OP_SIGN sign(d)
                          // (plane passes: csm_plane = -1, the four CSM waves only stage)
+    unsigned seg0, seg1, seg2, seg3, seg_n;   // tiles of CSM wave w (fu_assign_rows): segw = row A | first column A << 4 |
+                         // row B << 8 | first column B << 12; byte w of seg_n = count A | count B << 4
     int n_split;         // workgroups per bin: part k sums the chunks [k NC / n_split, (k+1) NC / n_split)
     float* ws;           // partial records of parts 1 .. n_split-1: [n_split-1][n_bins][floats_per_bin]
     int debug_skip;      // profiling aid (env SC_FUSED_DEBUG, bit mask; results are WRONG when set):
@@ -138,9 +145,9 @@ __device__ __forceinline__ int fu_lane() {
 }
 __device__ __forceinline__ void fu_fetch(const ScStage& st, const FuMap& mp, float* raw, int o0, int vw) {
     const int lane = fu_lane();
-    const int c = 2 * lane;
-    const bool have = lane < 32 ? c < mp.n0 : c - 64 < mp.n1;            // this lane's channel pair exists
-    const int goff = lane < 32 ? c : mp.ch1 + (c - 64);
+    const int c = 2 * (lane & 15), b32 = lane >> 4;                     // channel pair c of local block b32
+    const bool have = c < fu_byte(mp.n32, b32);                         // this lane's channel pair exists
+    const int goff = fu_byte(mp.off32, b32) * 32 + c;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int row = 4 * vw + k, o = o0 + row;
@@ -179,8 +186,8 @@ __device__ __forceinline__ void fu_split(const float* raw, unsigned short* plane
         for (int k = 0; k < 4; ++k)
             v[t][k] = *reinterpret_cast<const float2*>(raw + (4 * vw + k) * FU_RAW_ROW + 4 * lane + 2 * (first ^ t));
     if constexpr (UNIT) {
-        const int c = 2 * lane;                                     // (both channels of a pair exist or neither: even counts)
-        const bool have = lane < 32 ? c < mp->n0 : c - 64 < mp->n1;
+        // (both channels of a pair exist or neither: even counts)
+        const bool have = 2 * (lane & 15) < fu_byte(mp->n32, lane >> 4);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -285,14 +292,15 @@ __device__ __forceinline__ void fused_mfma_role(const FusedArgs& p, const ScStag
     constexpr int MAXS = 2 * NB32 + 1;
     const int lane = tid & 63;
     const int NB = p.NB;
-    // triangular launches: wave w owns tile rows w and NB-1-w; cross launches: row w of the first half against the
-    // tiles 4 ... 4 + nb1 - 1 of the second
-    const bool cross = p.map.cross != 0;
-    const int rA_ = wave, rB_ = cross ? NB : NB - 1 - wave;
-    const int nA_ = cross ? (wave < p.map.nb0 ? p.map.nb1 : 0) : ((rA_ <= rB_) ? NB - rA_ : 0);   // tiles in row rA
-    const int nB_ = (!cross && rB_ > rA_) ? NB - rB_ : 0;
+    // this wave's tiles: nA in tile row rA from column cA, then nB in row rB from column cB (fu_assign_rows: rows w and
+    // R-1-w of the launch's R tile rows -- the whole triangle and the staircases of the > 128-channel launches alike)
+    // (one byte per field, one word per wave; scalar selects on the wave number)
+    const unsigned sg = (unsigned)__builtin_amdgcn_readfirstlane((int)(wave == 0 ? p.seg0 : (wave == 1 ? p.seg1 : (wave == 2 ? p.seg2 : p.seg3))));
+    const unsigned sg_n = (unsigned)__builtin_amdgcn_readfirstlane((int)((p.seg_n >> (8 * wave)) & 0xffu));
+    const int rA_ = sg & 0xf, cA_ = (sg >> 4) & 0xf, rB_ = (sg >> 8) & 0xf, cB_ = (sg >> 12) & 0xf;
+    const int nA_ = sg_n & 0xf, nB_ = sg_n >> 4;
     const int total = nA_ + nB_;
-    const int cA_ = cross ? 4 : rA_;                  // first tile column of row rA
+    (void)NB;
     f32x4 re[MAXS], im[MAXS];
 #pragma unroll
     for (int s = 0; s < MAXS; ++s) { re[s] = (f32x4){0.f, 0.f, 0.f, 0.f}; im[s] = re[s]; }
@@ -314,8 +322,8 @@ __device__ __forceinline__ void fused_mfma_role(const FusedArgs& p, const ScStag
         if (do_csm && total > 0) {
             // opaque per-chunk copies: otherwise ~2 loop-invariant address VGPRs per tile stay live
             // across the chunk loop and spill at the 168-register budget
-            int rA = rA_, rB = rB_, nA = nA_, cA = cA_;
-            asm volatile("" : "+s"(rA), "+s"(rB), "+s"(nA), "+s"(cA));
+            int rA = rA_, rB = rB_, nA = nA_, cA = cA_, cB = cB_;
+            asm volatile("" : "+s"(rA), "+s"(rB), "+s"(nA), "+s"(cA), "+s"(cB));
             bf16x8 arh, arm, arl, aih, aim, ail, nrh, nrm, nrl;     // A fragments of the current row (and -Re)
             bf16x8 brh[2], bih[2];                                  // first B fragments, prefetched one tile
             {                                                       // ahead into the other register set
@@ -327,7 +335,7 @@ __device__ __forceinline__ void fused_mfma_role(const FusedArgs& p, const ScStag
                 if (s < total) {
                     const bool in_a = s < nA;
                     const int row = in_a ? rA : rB;
-                    const int col = in_a ? cA + s : rB + (s - nA);
+                    const int col = in_a ? cA + s : cB + (s - nA);
                     if (s == 0 || s == nA) {
                         const unsigned short* fa = frag0 + row * 16 * FU_CSTRIDE;
                         arh = FU_LD(fa, 0); arm = FU_LD(fa, 1); arl = FU_LD(fa, 2);
@@ -340,7 +348,7 @@ __device__ __forceinline__ void fused_mfma_role(const FusedArgs& p, const ScStag
                     const bf16x8& cbih = bih[s & 1];
                     if (s + 1 < total) {      // prefetch the next tile's first fragments
                         const bool na = (s + 1) < nA;
-                        const int ncol = na ? cA + s + 1 : rB + (s + 1 - nA);
+                        const int ncol = na ? cA + s + 1 : cB + (s + 1 - nA);
                         const unsigned short* fn = frag0 + ncol * 16 * FU_CSTRIDE;
                         brh[(s + 1) & 1] = FU_LD(fn, 0); bih[(s + 1) & 1] = FU_LD(fn, 3);
                     }
@@ -381,7 +389,7 @@ __device__ __forceinline__ void fused_mfma_role(const FusedArgs& p, const ScStag
                     const bool first = ch <= f_s;
                     const bool in_a = s < nA_;
                     const int row = in_a ? rA_ : rB_;
-                    const int col = in_a ? cA_ + s : rB_ + (s - nA_);
+                    const int col = in_a ? cA_ + s : cB_ + (s - nA_);
                     // uniform (scalar) tile base + ONE 32-bit unsigned per-lane offset, re-materialised here:
                     // SGPR-base addressing, no 64-bit address VGPRs kept alive (and spilled) across the chunk
                     // loop -- a spill reload in front of these stores would wait on vmcnt, i.e. on the row
@@ -420,46 +428,57 @@ __device__ __forceinline__ void fused_mfma_role(const FusedArgs& p, const ScStag
 // Upper-triangular 32x32 blocks, row-major: t -> (BI, BJ).  Tables are compile-time (template on
 // the number of 32-channel blocks and the set) so that operand fragments shared by several blocks
 // of a set (same BI or same BJ) are loaded from LDS once per observation row.
-__host__ __device__ constexpr int fu_nblocks(int nb32) { return nb32 * (nb32 + 1) / 2; }
-__host__ __device__ constexpr int fu_nsets(int nb32) { return (fu_nblocks(nb32) + FU_MAXB - 1) / FU_MAXB; }
-__host__ __device__ constexpr int fu_per_set(int nb32) { return (fu_nblocks(nb32) + fu_nsets(nb32) - 1) / fu_nsets(nb32); }
-__host__ __device__ constexpr int fu_bi(int nb32, int t) {
-    int r = 0, len = nb32;
-    while (t >= len) { t -= len; ++r; --len; }
-    return r;
+// A launch's 32x32 blocks: (bi, bj), bi <= bj, bj >= COL_LO, bi < ROW_HI of the NB32 staged blocks, row-major, dealt
+// over one or two sets of at most FU_MAXB (a set = the blocks one abs wave accumulates).
+__host__ __device__ constexpr int fu_nblocks(int nb32, int col_lo, int row_hi) {
+    int n = 0;
+    for (int bi = 0; bi < nb32 && bi < row_hi; ++bi)
+        for (int bj = bi > col_lo ? bi : col_lo; bj < nb32; ++bj) ++n;
+    return n;
 }
-__host__ __device__ constexpr int fu_bj(int nb32, int t) {
-    int r = 0, len = nb32;
-    while (t >= len) { t -= len; ++r; --len; }
-    return r + t;
+// Up to four blocks: one set, its rows dealt over all eight abs waves; more: two sets of four waves, the first with
+// floor(n / 2) blocks (the sets of the 128-channel triangle, 5 + 5, are what fits the 168-register budget of a
+// 12-wave workgroup: five blocks in ONE set of a three-block launch spilled 28 registers, 5 + 4 in that order 6).
+__host__ __device__ constexpr int fu_nsets(int nb32, int col_lo, int row_hi) {
+    return fu_nblocks(nb32, col_lo, row_hi) > 4 ? 2 : 1;
+}
+__host__ __device__ constexpr int fu_set_first(int nb32, int col_lo, int row_hi, int set) {
+    return set == 0 ? 0 : fu_nblocks(nb32, col_lo, row_hi) / 2;
+}
+__host__ __device__ constexpr int fu_set_count(int nb32, int col_lo, int row_hi, int set) {
+    return fu_nsets(nb32, col_lo, row_hi) == 1 ? fu_nblocks(nb32, col_lo, row_hi)
+         : (set == 0 ? fu_nblocks(nb32, col_lo, row_hi) / 2 : fu_nblocks(nb32, col_lo, row_hi) - fu_nblocks(nb32, col_lo, row_hi) / 2);
+}
+// t-th block of the shape: returns bi * 4 + bj
+__host__ __device__ constexpr int fu_block(int nb32, int col_lo, int row_hi, int t) {
+    for (int bi = 0; bi < nb32 && bi < row_hi; ++bi)
+        for (int bj = bi > col_lo ? bi : col_lo; bj < nb32; ++bj) {
+            if (t == 0) return bi * 4 + bj;
+            --t;
+        }
+    return 0;
 }
 
-template <int NB32, int SET>
+template <int NB32, int COL_LO, int ROW_HI, int SET>
 struct FuTab {
-    static constexpr int PER = fu_per_set(NB32);
-    static constexpr int T0 = SET * PER;
-    // SET == 2: the cross launch of 129 ... 256 channels -- the four 32 x 32 blocks between the two staged halves
-    static constexpr int NBLK = SET == 2 ? 4 : ((fu_nblocks(NB32) - T0) < PER ? (fu_nblocks(NB32) - T0) : PER);   // blocks of this set
+    static constexpr int T0 = fu_set_first(NB32, COL_LO, ROW_HI, SET);
+    static constexpr int NBLK = fu_set_count(NB32, COL_LO, ROW_HI, SET);   // blocks of this set
+    static_assert(NBLK <= FU_MAXB, "a set holds at most FU_MAXB blocks");
     struct Arr { int bi[FU_MAXB]; int bj[FU_MAXB]; bool use_i[4]; bool use_j[4]; };
     static constexpr Arr make() {
         Arr a{};
         for (int s = 0; s < FU_MAXB; ++s) { a.bi[s] = 0; a.bj[s] = 0; }
         for (int b = 0; b < 4; ++b) { a.use_i[b] = false; a.use_j[b] = false; }
         for (int s = 0; s < NBLK; ++s) {
-            a.bi[s] = SET == 2 ? s / 2 : fu_bi(NB32, T0 + s);
-            a.bj[s] = SET == 2 ? 2 + s % 2 : fu_bj(NB32, T0 + s);
+            const int blk = fu_block(NB32, COL_LO, ROW_HI, T0 + s);
+            a.bi[s] = blk / 4;
+            a.bj[s] = blk % 4;
             a.use_i[a.bi[s]] = true;
             a.use_j[a.bj[s]] = true;
         }
         return a;
     }
     static constexpr Arr tab = make();
-    static constexpr int count(bool rows) {
-        int n = 0;
-        for (int b = 0; b < 4; ++b) n += (rows ? tab.use_i[b] : tab.use_j[b]) ? 1 : 0;
-        return n;
-    }
-    static constexpr int NUSE_I = count(true), NUSE_J = count(false);
 };
 
 
@@ -483,11 +502,11 @@ __device__ __forceinline__ FuFragA fu_frag_a(unsigned h, unsigned m, unsigned l)
     return f;
 }
 template <int ODD>
-__device__ __forceinline__ FuFragB fu_frag_b(unsigned h, unsigned m, unsigned l, unsigned negmask) {
+__device__ __forceinline__ FuFragB fu_frag_b(unsigned h, unsigned m, unsigned l) {
     constexpr unsigned SEL = ODD ? 0x07060302u : 0x05040100u;
     FuFragB f;
-    f.d0 = perm_b32(m, h, SEL) ^ negmask;       // (h, m)
-    f.d1 = perm_b32(l, h, SEL) ^ negmask;       // (h, l)
+    f.d0 = perm_b32(m, h, SEL);       // (h, m)
+    f.d1 = perm_b32(l, h, SEL);       // (h, l)
     return f;
 }
 
@@ -512,9 +531,20 @@ __device__ __forceinline__ float fu_accumulate(float acc, float d) {
 // pads only in front of instructions it can see (an asm block straight after a lone MFMA read stale registers: wrong sign
 // sums at <= 32 channels): element 0 goes first as ordinary code -- the compiler waits for the MFMA there -- and a
 // scheduling barrier keeps the asm blocks behind it.
-template <int OP>
+template <int OP, bool PACKED = false>
 __device__ __forceinline__ void fu_accumulate16(f32x16& acc, const f32x16& d) {
-    if constexpr (OP != FU_OP_SIGN) {
+    if constexpr (OP == FU_OP_SQ && PACKED) {
+        // two squares per instruction (v_pk_fma_f32 on the register pairs of the MFMA result): 8 issue slots per block and
+        // row instead of 16 -- |d| and sign(d) have no packed form (VOP3P carries no abs modifier).  Sets of up to four
+        // blocks only: with five, the aligned pairs do not fit the register budget (9 spilled pairs per row, 3.7 -> 9 ms)
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+            f32x2 a = {acc[e], acc[e + 1]};
+            const f32x2 v = {d[e], d[e + 1]};
+            a = __builtin_elementwise_fma(v, v, a);
+            acc[e] = a[0]; acc[e + 1] = a[1];
+        }
+    } else if constexpr (OP != FU_OP_SIGN) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = fu_accumulate<OP>(acc[e], d[e]);
     } else {
@@ -529,11 +559,11 @@ __device__ __forceinline__ void fu_accumulate16(f32x16& acc, const f32x16& d) {
     }
 }
 
-template <int NB32, int SET, int OP>
+template <int NB32, int COL_LO, int ROW_HI, int SET, int OP>
 __device__ __forceinline__ void fused_valu_body(const FusedArgs& p, const ScStage& st, unsigned short* planes,
                                                 float* raw, int tid, int vw, int rsub, int wps, float* rec,
                                                 int o_lo) {
-    using Tab = FuTab<NB32, SET>;
+    using Tab = FuTab<NB32, COL_LO, ROW_HI, SET>;
     constexpr int NBLK = Tab::NBLK;
     const int lane = tid & 63;
     f32x16 acc[NBLK > 0 ? NBLK : 1];
@@ -572,9 +602,11 @@ __device__ __forceinline__ void fused_valu_body(const FusedArgs& p, const ScStag
                     if (Tab::tab.use_i[b])
                         NA[b][pl] = *reinterpret_cast<const unsigned*>(
                             pb + offA + pl * plane_elems + b * 32 * FU_CSTRIDE + oq2 * 2);
+                    // (-Im x_j for lanes 32-63: the sign is flipped here, once per dword of two rows -- 3 to 6 xors per
+                    // row -- and not on the fragments built from it, 2 per block and row)
                     if (Tab::tab.use_j[b])
                         NBq[b][pl] = *reinterpret_cast<const unsigned*>(
-                            pb + offB + pl * plane_elems + b * 32 * FU_CSTRIDE + oq2 * 2);
+                            pb + offB + pl * plane_elems + b * 32 * FU_CSTRIDE + oq2 * 2) ^ negmask;
                 }
 #pragma unroll
             for (int k1 = 0; k1 < 2; ++k1) {
@@ -583,8 +615,7 @@ __device__ __forceinline__ void fused_valu_body(const FusedArgs& p, const ScStag
                     return k1 ? fu_frag_a<1>(NA[b][0], NA[b][1], NA[b][2]) : fu_frag_a<0>(NA[b][0], NA[b][1], NA[b][2]);
                 };
                 auto frag_b = [&](int b) {
-                    return k1 ? fu_frag_b<1>(NBq[b][0], NBq[b][1], NBq[b][2], negmask)
-                              : fu_frag_b<0>(NBq[b][0], NBq[b][1], NBq[b][2], negmask);
+                    return k1 ? fu_frag_b<1>(NBq[b][0], NBq[b][1], NBq[b][2]) : fu_frag_b<0>(NBq[b][0], NBq[b][1], NBq[b][2]);
                 };
                 FuFragA fa = frag_a(Tab::tab.bi[0]);
                 FuFragB fb = frag_b(Tab::tab.bj[0]);
@@ -604,12 +635,12 @@ __device__ __forceinline__ void fused_valu_body(const FusedArgs& p, const ScStag
                         if (Tab::tab.bj[s + 1] != Tab::tab.bj[s]) fb = frag_b(Tab::tab.bj[s + 1]);
                     }
                     if (s > 0) {
-                        fu_accumulate16<OP>(acc[s - 1], dprev);
+                        fu_accumulate16<OP, (NBLK <= 4)>(acc[s - 1], dprev);
                     }
                     dprev = d;
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                fu_accumulate16<OP>(acc[NBLK - 1], dprev);
+                fu_accumulate16<OP, (NBLK <= 4)>(acc[NBLK - 1], dprev);
             }
         }
         FU_TICK(1);
@@ -626,7 +657,7 @@ __device__ __forceinline__ void fused_valu_body(const FusedArgs& p, const ScStag
     float* red = reinterpret_cast<float*>(planes);
     for (int half = wps >> 1; half >= 1; half >>= 1) {
         if (rsub >= half && rsub < 2 * half) {
-            float* dst = red + (size_t)((SET == 2 ? 0 : SET) * (wps >> 1) + (rsub - half)) * (FU_MAXB * 16 * 64);
+            float* dst = red + (size_t)(SET * (wps >> 1) + (rsub - half)) * (FU_MAXB * 16 * 64);
 #pragma unroll
             for (int s = 0; s < NBLK; ++s)
 #pragma unroll
@@ -634,7 +665,7 @@ __device__ __forceinline__ void fused_valu_body(const FusedArgs& p, const ScStag
         }
         __syncthreads();
         if (rsub < half) {
-            const float* src = red + (size_t)((SET == 2 ? 0 : SET) * (wps >> 1) + rsub) * (FU_MAXB * 16 * 64);
+            const float* src = red + (size_t)(SET * (wps >> 1) + rsub) * (FU_MAXB * 16 * 64);
 #pragma unroll
             for (int s = 0; s < NBLK; ++s)
 #pragma unroll
@@ -661,24 +692,23 @@ __device__ __forceinline__ void fused_valu_body(const FusedArgs& p, const ScStag
     }
 }
 
-template <int NB32, int OP, bool CROSS>
+template <int NB32, int COL_LO, int ROW_HI, int OP>
 __device__ __forceinline__ void fused_valu_role(const FusedArgs& p, const ScStage& st,
                                                 unsigned short* planes, float* raw, int tid, int vw, float* rec,
                                                 int o_lo) {
-    constexpr int NSETS = CROSS ? 1 : fu_nsets(NB32);
+    constexpr int NSETS = fu_nsets(NB32, COL_LO, ROW_HI);
     constexpr int wps = 8 / NSETS;                        // VALU waves per block set (8 or 4)
     const int set = vw / wps, rsub = vw % wps;
-    if constexpr (CROSS) {
-        fused_valu_body<NB32, 2, OP>(p, st, planes, raw, tid, vw, rsub, wps, rec, o_lo);
-    } else if constexpr (NSETS == 1) {
-        fused_valu_body<NB32, 0, OP>(p, st, planes, raw, tid, vw, rsub, wps, rec, o_lo);
+    if constexpr (NSETS == 1) {
+        fused_valu_body<NB32, COL_LO, ROW_HI, 0, OP>(p, st, planes, raw, tid, vw, rsub, wps, rec, o_lo);
     } else {
-        if (set == 0) fused_valu_body<NB32, 0, OP>(p, st, planes, raw, tid, vw, rsub, wps, rec, o_lo);
-        else fused_valu_body<NB32, 1, OP>(p, st, planes, raw, tid, vw, rsub, wps, rec, o_lo);
+        if (set == 0) fused_valu_body<NB32, COL_LO, ROW_HI, 0, OP>(p, st, planes, raw, tid, vw, rsub, wps, rec, o_lo);
+        else fused_valu_body<NB32, COL_LO, ROW_HI, 1, OP>(p, st, planes, raw, tid, vw, rsub, wps, rec, o_lo);
     }
 }
 
-template <int NB32, int OP, bool CROSS>
+// NB32 staged 32-channel blocks; the launch's products are the blocks (bi <= bj, bj >= COL_LO, bi < ROW_HI) of them
+template <int NB32, int COL_LO, int ROW_HI, int OP>
 __global__ void __launch_bounds__(FU_THREADS) fused_csm_absim_kernel(FusedArgs p) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -707,7 +737,7 @@ __global__ void __launch_bounds__(FU_THREADS) fused_csm_absim_kernel(FusedArgs p
         fused_mfma_role<NB32>(p, st, planes, raw, tid, wave, rec, o_lo);
     } else {
         if (p.debug_skip & 16) __builtin_amdgcn_s_setprio(2);
-        fused_valu_role<NB32, OP, CROSS>(p, st, planes, raw, tid, wave - 4, rec, o_lo);
+        fused_valu_role<NB32, COL_LO, ROW_HI, OP>(p, st, planes, raw, tid, wave - 4, rec, o_lo);
     }
 }
 
@@ -756,13 +786,13 @@ static int launch_fused_combine(const FusedArgs& a, int op, hipStream_t stream) 
     return SC_OK;
 }
 
-template <int NB32, int OP, bool CROSS>
+template <int NB32, int COL_LO, int ROW_HI, int OP>
 static int launch_fused_op(const FusedArgs& a, bool combine, hipStream_t stream) {
     size_t shmem = (size_t)2 * a.st.CP * FU_CSTRIDE * 2;
     const size_t red = (size_t)4 * FU_MAXB * 16 * 64 * sizeof(float);
     if (shmem < red) shmem = red;
     shmem += (size_t)FU_OC * FU_RAW_ROW * sizeof(float);
-    auto k = fused_csm_absim_kernel<NB32, OP, CROSS>;
+    auto k = fused_csm_absim_kernel<NB32, COL_LO, ROW_HI, OP>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     hipLaunchKernelGGL(k, dim3((unsigned)(a.n_bins * a.n_split)), dim3(FU_THREADS), shmem, stream, a);
     SC_CHECK_HIP(hipGetLastError());
@@ -772,25 +802,22 @@ static int launch_fused_op(const FusedArgs& a, bool combine, hipStream_t stream)
 // One pass of the matrix-core kernel: op = FU_OP_ABS is the headline launch (CSM planes, and |Im s| if a.abs_plane >= 0);
 // FU_OP_SQ / FU_OP_SIGN are plane passes (a.csm_plane = -1, a.abs_plane = the plane to fill): the abs waves accumulate
 // d^2 / sign(d) of the same per-observation matrix-core products, the CSM waves only stage.
+// The launch shapes that exist (staged blocks, first block column, block rows): the triangles of 1 ... 4 blocks for up
+// to 128 channels, and the staircases launch_fused_all covers 129 ... 256 channels with.
+#define FU_SHAPES(X) X(1, 0, 1) X(2, 0, 2) X(3, 0, 3) X(4, 0, 4) X(4, 2, 2) X(3, 1, 3) X(4, 2, 4) X(4, 1, 4) X(4, 1, 1)
 static int launch_fused(const FusedArgs& a, int op, hipStream_t stream, bool combine) {
-    if (a.map.cross) {      // the tiles between two 64-channel quarters: always the full 128 staged slots
-        if (op == FU_OP_SQ) return launch_fused_op<4, FU_OP_SQ, true>(a, combine, stream);
-        if (op == FU_OP_SIGN) return launch_fused_op<4, FU_OP_SIGN, true>(a, combine, stream);
-        if (op == FU_OP_UNIT) return launch_fused_op<4, FU_OP_UNIT, true>(a, combine, stream);
-        return launch_fused_op<4, FU_OP_ABS, true>(a, combine, stream);
-    }
-#define FU_CASE(NB32)                                                             \
-    case NB32:                                                                    \
-        if (op == FU_OP_SQ) return launch_fused_op<NB32, FU_OP_SQ, false>(a, combine, stream);    \
-        if (op == FU_OP_SIGN) return launch_fused_op<NB32, FU_OP_SIGN, false>(a, combine, stream); \
-        if (op == FU_OP_UNIT) return launch_fused_op<NB32, FU_OP_UNIT, false>(a, combine, stream); \
-        return launch_fused_op<NB32, FU_OP_ABS, false>(a, combine, stream);
-    switch (a.NB32) {
-        FU_CASE(1)
-        FU_CASE(2)
-        FU_CASE(3)
+    const int shape = a.NB32 * 100 + a.shape_col_lo * 10 + a.shape_row_hi;
+#define FU_CASE(NB32, COL_LO, ROW_HI)                                                                          \
+    case NB32 * 100 + COL_LO * 10 + ROW_HI:                                                                    \
+        if (op == FU_OP_SQ) return launch_fused_op<NB32, COL_LO, ROW_HI, FU_OP_SQ>(a, combine, stream);        \
+        if (op == FU_OP_SIGN) return launch_fused_op<NB32, COL_LO, ROW_HI, FU_OP_SIGN>(a, combine, stream);    \
+        if (op == FU_OP_UNIT) return launch_fused_op<NB32, COL_LO, ROW_HI, FU_OP_UNIT>(a, combine, stream);    \
+        return launch_fused_op<NB32, COL_LO, ROW_HI, FU_OP_ABS>(a, combine, stream);
+    switch (shape) {
+        FU_SHAPES(FU_CASE)
     default:
-        FU_CASE(4)
+        sc_set_error("fused kernel: no launch shape (%d staged blocks, column %d, %d rows)", a.NB32, a.shape_col_lo, a.shape_row_hi);
+        return SC_EINVAL;
     }
 #undef FU_CASE
 }
@@ -808,6 +835,9 @@ static int launch_fused(const FusedArgs& a, int op, hipStream_t stream, bool com
 // same (bin, part) split and the same combine kernel as the MFMA path.
 #define SM_THREADS 448
 #define SM_CHUNK_BYTES (24 * 1024)
+
+template <bool ABS, bool SQ, bool SGN>
+struct SmallSlots { static constexpr int NQ = 2 + (ABS ? 1 : 0) + (SQ ? 1 : 0) + (SGN ? 1 : 0); };     // quantities summed
 
 template <bool ABS, bool SQ, bool SGN, bool NORM>
 __global__ void __launch_bounds__(SM_THREADS) small_csm_absim_kernel(FusedArgs p) {
@@ -916,7 +946,11 @@ __global__ void __launch_bounds__(SM_THREADS) small_csm_absim_kernel(FusedArgs p
     }
     // slices -> one total per (block, quantity), summed in slice order; then the record image (zero padded tiles,
     // both triangles of the diagonal tiles like an MFMA tile) is assembled in LDS and copied out coalesced
-    constexpr int NQ = 5;                                                // re, im, |im|, im^2, sign(im)
+    // Only the quantities of this instantiation get a slot (re, im, then |im|, im^2, sign(im) as present): with all five
+    // the tail needed 85 KB from 50 channels on (10 tiles) and one workgroup per CU instead of two -- CSM + |Im| + Im^2
+    // took 8.2 ms at 50 channels against 5.1 ms at 48.
+    constexpr int NQ = SmallSlots<ABS, SQ, SGN>::NQ;
+    constexpr int Q_AB = 2, Q_SQ = 2 + (ABS ? 1 : 0), Q_SG = 2 + (ABS ? 1 : 0) + (SQ ? 1 : 0);
     float* red = reinterpret_cast<float*>(smem);                         // [NQ * 4][SM_THREADS]
     float* image = red + NQ * 4 * SM_THREADS;                            // [NQ][n_tiles][256]
     const int plane_f = p.n_tiles * SC_TILE_ELEMS;
@@ -924,9 +958,9 @@ __global__ void __launch_bounds__(SM_THREADS) small_csm_absim_kernel(FusedArgs p
     for (int e = 0; e < 4; ++e) {
         red[(e) * SM_THREADS + tid] = active ? re2[e] : 0.f;
         red[(4 + e) * SM_THREADS + tid] = active ? im2[e] : 0.f;
-        red[(8 + e) * SM_THREADS + tid] = active ? ab2[e] : 0.f;
-        red[(12 + e) * SM_THREADS + tid] = active ? sq2[e] : 0.f;
-        red[(16 + e) * SM_THREADS + tid] = active ? sg2[e] : 0.f;
+        if constexpr (ABS) red[(4 * Q_AB + e) * SM_THREADS + tid] = active ? ab2[e] : 0.f;
+        if constexpr (SQ) red[(4 * Q_SQ + e) * SM_THREADS + tid] = active ? sq2[e] : 0.f;
+        if constexpr (SGN) red[(4 * Q_SG + e) * SM_THREADS + tid] = active ? sg2[e] : 0.f;
     }
     for (int i = tid; i < NQ * plane_f; i += SM_THREADS) image[i] = 0.f;
     __syncthreads();
@@ -938,7 +972,7 @@ __global__ void __launch_bounds__(SM_THREADS) small_csm_absim_kernel(FusedArgs p
         { int rem = bb, len = B; while (rem >= len) { rem -= len; ++ti; --len; } tj = ti + rem; }
         const int qty = q >> 2, e = q & 3, i = 2 * ti + (e >> 1), j = 2 * tj + (e & 1);
         if (i > j) continue;                                             // lower half of a diagonal 2 x 2 block
-        const bool odd = qty == 1 || qty == 4;                           // Im s and sign(Im s) change sign under i <-> j
+        const bool odd = qty == 1 || (SGN && qty == Q_SG);               // Im s and sign(Im s) change sign under i <-> j
         float* pl = image + qty * plane_f + sc_tile_index(i >> 4, j >> 4, p.NB) * SC_TILE_ELEMS;
         pl[(i & 15) * 16 + (j & 15)] = (odd && i == j) ? 0.f : acc;
         if ((i >> 4) == (j >> 4) && i != j) pl[(j & 15) * 16 + (i & 15)] = odd ? -acc : acc;
@@ -947,15 +981,19 @@ __global__ void __launch_bounds__(SM_THREADS) small_csm_absim_kernel(FusedArgs p
     if (p.csm_plane >= 0)
         for (int i = tid; i < 2 * plane_f; i += SM_THREADS) rec[(int64_t)p.csm_plane * plane_f + i] = image[i];
     if constexpr (ABS)
-        for (int i = tid; i < plane_f; i += SM_THREADS) rec[(int64_t)p.abs_plane * plane_f + i] = image[2 * plane_f + i];
+        for (int i = tid; i < plane_f; i += SM_THREADS) rec[(int64_t)p.abs_plane * plane_f + i] = image[Q_AB * plane_f + i];
     if constexpr (SQ)
-        for (int i = tid; i < plane_f; i += SM_THREADS) rec[(int64_t)p.sq_plane * plane_f + i] = image[3 * plane_f + i];
+        for (int i = tid; i < plane_f; i += SM_THREADS) rec[(int64_t)p.sq_plane * plane_f + i] = image[Q_SQ * plane_f + i];
     if constexpr (SGN)
-        for (int i = tid; i < plane_f; i += SM_THREADS) rec[(int64_t)p.sign_plane * plane_f + i] = image[4 * plane_f + i];
+        for (int i = tid; i < plane_f; i += SM_THREADS) rec[(int64_t)p.sign_plane * plane_f + i] = image[Q_SG * plane_f + i];
 }
 
 template <bool ABS, bool SQ, bool SGN, bool NORM>
-static void launch_small_inst(const FusedArgs& a, size_t shmem, hipStream_t stream) {
+static void launch_small_inst(const FusedArgs& a, hipStream_t stream) {
+    constexpr int NQ = SmallSlots<ABS, SQ, SGN>::NQ;
+    size_t shmem = 2 * (size_t)SM_CHUNK_BYTES;
+    const size_t tail = (size_t)(4 * NQ * SM_THREADS + NQ * a.n_tiles * SC_TILE_ELEMS) * sizeof(float);
+    if (shmem < tail) shmem = tail;
     auto k = small_csm_absim_kernel<ABS, SQ, SGN, NORM>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     hipLaunchKernelGGL(k, dim3((unsigned)(a.n_bins * a.n_split)), dim3(SM_THREADS), shmem, stream, a);
@@ -963,19 +1001,16 @@ static void launch_small_inst(const FusedArgs& a, size_t shmem, hipStream_t stre
 
 static int launch_small(const FusedArgs& a_in, bool normalize, hipStream_t stream) {
     FusedArgs a = a_in;
-    size_t shmem = 2 * (size_t)SM_CHUNK_BYTES;
-    const size_t tail = (size_t)(20 * SM_THREADS + 5 * a.n_tiles * SC_TILE_ELEMS) * sizeof(float);
-    if (shmem < tail) shmem = tail;
     a.n_fold = 0;
     if (a.csm_plane >= 0) { a.fold[a.n_fold++] = a.csm_plane; a.fold[a.n_fold++] = a.csm_plane + 1; }
     if (a.abs_plane >= 0) a.fold[a.n_fold++] = a.abs_plane;
     if (a.sq_plane >= 0) a.fold[a.n_fold++] = a.sq_plane;
     if (a.sign_plane >= 0) a.fold[a.n_fold++] = a.sign_plane;
-    if (normalize) launch_small_inst<false, false, false, true>(a, shmem, stream);
-    else if (a.sign_plane >= 0) launch_small_inst<false, false, true, false>(a, shmem, stream);
-    else if (a.sq_plane >= 0) launch_small_inst<true, true, false, false>(a, shmem, stream);
-    else if (a.abs_plane >= 0) launch_small_inst<true, false, false, false>(a, shmem, stream);
-    else launch_small_inst<false, false, false, false>(a, shmem, stream);
+    if (normalize) launch_small_inst<false, false, false, true>(a, stream);
+    else if (a.sign_plane >= 0) launch_small_inst<false, false, true, false>(a, stream);
+    else if (a.sq_plane >= 0) launch_small_inst<true, true, false, false>(a, stream);
+    else if (a.abs_plane >= 0) launch_small_inst<true, false, false, false>(a, stream);
+    else launch_small_inst<false, false, false, false>(a, stream);
     SC_CHECK_HIP(hipGetLastError());
     if (a.n_split > 1) {
         hipLaunchKernelGGL(planes_combine_kernel, dim3(2048), dim3(256), 0, stream, a);
@@ -997,8 +1032,8 @@ static bool small_ok(const ScAxes& ax, bool nonlinear_plane) { return ax.C <= (n
 // (Im s)^2 rides along with CSM + |Im s| on this kernel up to 52 channels, sign(Im s) runs on it up to 40: above, a
 // plane pass of the matrix-core kernel is faster (measured at the cfg3 volume: 50 channels, sign 9.9 ms here against
 // ~5.3 ms there; CSM + |Im| + Im^2 8.2 ms in one pass here against 5.3 + ~4 ms in two there).
-static bool small_ok_sq(const ScAxes& ax) { return ax.C <= 52; }
-static bool small_ok_sign(const ScAxes& ax) { return ax.C <= 40; }
+static bool small_ok_sq(const ScAxes& ax) { return ax.C <= 58; }
+static bool small_ok_sign(const ScAxes& ax) { return ax.C <= 44; }
 
 extern "C" int sc_fused_supported(int64_t n_signals) {
     return (n_signals >= 2 && n_signals <= 256 && (n_signals % 2) == 0) ? 1 : 0;
@@ -1032,62 +1067,90 @@ static int fused_pick_split(int n_bins, int n_obs) {
     return best;
 }
 
-// One launch over the contiguous channel range [c_lo, c_lo + n), n <= 128: the upper triangle of that range
-static FusedArgs fu_args_range(const FusedArgs& full, int c_lo, int n) {
-    FusedArgs a = full;
-    a.st.base = full.st.base + c_lo;
-    a.st.C = n;
-    a.NB = sc_n_blocks(n);
-    a.NB32 = (n + 31) / 32;
-    a.n_blocks32 = a.NB32 * (a.NB32 + 1) / 2;
-    a.n_sets = fu_nsets(a.NB32);
-    a.st.CP = a.NB32 * 32;
-    a.st.RS = sc_row_stride(a.st.CP);
-    a.map.n0 = n < 64 ? n : 64;
-    a.map.n1 = n > 64 ? n - 64 : 0;
-    a.map.ch1 = 64;
-    a.map.t0 = c_lo / 16;
-    a.map.t1 = c_lo / 16 + 4;
-    a.map.nb0 = (a.map.n0 + 15) / 16;
-    a.map.nb1 = (a.map.n1 + 15) / 16;
-    a.map.NBr = sc_n_blocks(full.st.C);
-    a.map.cross = 0;
-    return a;
+// The CSM waves' share of a launch: R = the tile rows that have tiles, row r with the columns max(r, col_lo) ... NB-1.
+// Five or more rows: wave w takes rows w and R-1-w (long with short: the triangle's 9 tiles per wave at 128 channels);
+// three or four: one row per wave; two rows: two waves per row, half the columns each; one row: a quarter each.
+static void fu_assign_rows(FusedArgs* a) {
+    const int NB = a->NB, col_lo = a->map.col_lo;
+    const int R = a->map.row_hi < NB ? a->map.row_hi : NB;
+    auto c0 = [&](int r) { return r > col_lo ? r : col_lo; };
+    unsigned packed[4];
+    a->seg_n = 0u;
+    for (int w = 0; w < 4; ++w) {
+        int sg[6] = {0, 0, 0, 0, 0, 0};
+        if (R >= 5) {
+            const int rA = w, rB = R - 1 - w;
+            if (rA <= rB) { sg[0] = rA; sg[1] = c0(rA); sg[2] = NB - c0(rA); }
+            if (rB > rA) { sg[3] = rB; sg[4] = c0(rB); sg[5] = NB - c0(rB); }
+        } else if (R >= 3) {
+            if (w < R) { sg[0] = w; sg[1] = c0(w); sg[2] = NB - c0(w); }
+        } else {
+            const int per_row = R == 2 ? 2 : 4, r = R == 2 ? (w & 1) : 0, k = R == 2 ? (w >> 1) : w;
+            const int n = NB - c0(r), lo = n * k / per_row, hi = n * (k + 1) / per_row;
+            sg[0] = r; sg[1] = c0(r) + lo; sg[2] = hi - lo;
+        }
+        packed[w] = (unsigned)sg[0] | (unsigned)sg[1] << 4 | (unsigned)sg[3] << 8 | (unsigned)sg[4] << 12;
+        a->seg_n |= ((unsigned)sg[2] | (unsigned)sg[5] << 4) << (8 * w);
+    }
+    a->seg0 = packed[0]; a->seg1 = packed[1]; a->seg2 = packed[2]; a->seg3 = packed[3];
 }
-// One launch over the 64 channels from qa against the nb (<= 64) channels from qb (qa + 64 <= qb): only the tiles between them
-static FusedArgs fu_args_cross(const FusedArgs& full, int qa, int qb, int nb) {
+
+// One launch that stages the nb (<= 4) 32-channel blocks `blocks` (ascending block numbers of the record's channels) and
+// owns the products (bi <= bj, bj >= col_lo, bi < row_hi) of them.
+static FusedArgs fu_args_blocks(const FusedArgs& full, const int* blocks, int nb, int col_lo, int row_hi) {
     FusedArgs a = full;
-    a.st.base = full.st.base + qa;
-    a.st.C = 128;
-    a.NB = 8;
-    a.NB32 = 4;
-    a.n_blocks32 = 4;
-    a.n_sets = 1;
-    a.st.CP = 128;
-    a.st.RS = sc_row_stride(128);
-    a.map.n0 = 64;
-    a.map.n1 = nb;
-    a.map.ch1 = qb - qa;
-    a.map.t0 = qa / 16;
-    a.map.t1 = qb / 16;
-    a.map.nb0 = 4;
-    a.map.nb1 = (nb + 15) / 16;
-    a.map.NBr = sc_n_blocks(full.st.C);
-    a.map.cross = 1;
+    const int C = full.st.C, c_lo = blocks[0] * 32;
+    a.st.base = full.st.base + c_lo;
+    int staged = 0, n_last = 0;
+    a.map.off32 = a.map.n32 = a.map.t32 = 0u;
+    for (int b = 0; b < nb; ++b) {
+        const int c = blocks[b] * 32;
+        n_last = C - c < 32 ? C - c : 32;
+        a.map.off32 |= (unsigned)(blocks[b] - blocks[0]) << (8 * b);
+        a.map.n32 |= (unsigned)n_last << (8 * b);
+        a.map.t32 |= (unsigned)(blocks[b] * 2) << (8 * b);
+        staged += n_last;
+    }
+    a.st.C = staged;
+    a.NB32 = nb;
+    a.NB = 2 * (nb - 1) + (n_last + 15) / 16;      // 16-channel tiles that exist (the last block may be partial)
+    a.shape_col_lo = col_lo;
+    a.shape_row_hi = row_hi;
+    a.n_blocks32 = fu_nblocks(nb, col_lo, row_hi);
+    a.n_sets = fu_nsets(nb, col_lo, row_hi);
+    a.st.CP = nb * 32;
+    a.st.RS = sc_row_stride(a.st.CP);
+    a.map.NBr = sc_n_blocks(C);
+    a.map.col_lo = 2 * col_lo;
+    a.map.row_hi = 2 * row_hi;
+    fu_assign_rows(&a);
     return a;
 }
 static int launch_fused(const FusedArgs& a, int op, hipStream_t stream, bool combine);
-// Every tile of the record once: one triangular launch up to 128 channels; above, the two 128-channel halves as
-// triangular launches and each 64-channel quarter of the first half against each quarter of the second as cross
-// launches (136 = 36 + 36 + 4 x 16 tiles at 256 channels), the split-bin partial records folded once at the end.
+// Every tile of the record once.  Up to 128 channels: one launch, the triangle of its 1 ... 4 blocks.  Above, a launch
+// can stage four of the n = 5 ... 8 blocks at a time, and the n (n + 1) / 2 block products are dealt over launches so
+// that few blocks are staged twice (each staging reads its channels from HBM again):
+//   n = 5   triangle {0,1,2};  {0,1} x {3,4};  {2} x {3,4} + triangle {3,4}                        15 products, 10 staged
+//   n = 6   triangle {0,1,2,3};  {0,1} x {4,5} + triangle {4,5};  {2,3} x {4,5}                     21 products, 12 staged
+//   n = 7   triangle {0,1,2,3};  {0} x {4,5,6} + triangle {4,5,6};  {1}, {2}, {3} x {4,5,6}         28 products, 20 staged
+//   n = 8   triangle {0..3};  triangle {4..7};  {0,1}, {2,3} x {4,5}, {6,7}                         36 products, 24 staged
+// (round 2 ran every count in 129 ... 255 as n = 8: 160 channels cost what 256 do).  The split-bin partial records are
+// folded once at the end.
 static int launch_fused_all(const FusedArgs& full, int op, hipStream_t s) {
-    const int C = full.st.C;
-    if (C <= 128) return launch_fused(fu_args_range(full, 0, C), op, s, true);
-    int rc = launch_fused(fu_args_range(full, 0, 128), op, s, false);
-    if (rc == SC_OK) rc = launch_fused(fu_args_range(full, 128, C - 128), op, s, false);
-    for (int qa = 0; qa < 128 && rc == SC_OK; qa += 64)
-        for (int qb = 128; qb < C && rc == SC_OK; qb += 64)
-            rc = launch_fused(fu_args_cross(full, qa, qb, C - qb < 64 ? C - qb : 64), op, s, false);
+    const int C = full.st.C, n = (C + 31) / 32;
+    struct Plan { int nb, blocks[4], col_lo, row_hi; };
+    static const Plan tri[4] = {{1, {0}, 0, 1}, {2, {0, 1}, 0, 2}, {3, {0, 1, 2}, 0, 3}, {4, {0, 1, 2, 3}, 0, 4}};
+    static const Plan p5[] = {{3, {0, 1, 2}, 0, 3}, {4, {0, 1, 3, 4}, 2, 2}, {3, {2, 3, 4}, 1, 3}};
+    static const Plan p6[] = {{4, {0, 1, 2, 3}, 0, 4}, {4, {0, 1, 4, 5}, 2, 4}, {4, {2, 3, 4, 5}, 2, 2}};
+    static const Plan p7[] = {{4, {0, 1, 2, 3}, 0, 4}, {4, {0, 4, 5, 6}, 1, 4}, {4, {1, 4, 5, 6}, 1, 1},
+                              {4, {2, 4, 5, 6}, 1, 1}, {4, {3, 4, 5, 6}, 1, 1}};
+    static const Plan p8[] = {{4, {0, 1, 2, 3}, 0, 4}, {4, {4, 5, 6, 7}, 0, 4}, {4, {0, 1, 4, 5}, 2, 2},
+                              {4, {0, 1, 6, 7}, 2, 2}, {4, {2, 3, 4, 5}, 2, 2}, {4, {2, 3, 6, 7}, 2, 2}};
+    const Plan* plan = n <= 4 ? &tri[n - 1] : n == 5 ? p5 : n == 6 ? p6 : n == 7 ? p7 : p8;
+    const int n_launch = n <= 4 ? 1 : n == 5 ? 3 : n == 6 ? 3 : n == 7 ? 5 : 6;
+    int rc = SC_OK;
+    for (int l = 0; l < n_launch && rc == SC_OK; ++l)
+        rc = launch_fused(fu_args_blocks(full, plan[l].blocks, plan[l].nb, plan[l].col_lo, plan[l].row_hi), op, s, false);
     if (rc == SC_OK) rc = launch_fused_combine(full, op, s);
     return rc;
 }
@@ -1108,7 +1171,7 @@ static int fused_setup(const void* d_X, const sc_spectra_desc* desc, uint32_t pl
     a->n_tiles = sc_n_tiles(a->NB);
     a->NB32 = (ax->C + 31) / 32;
     a->n_blocks32 = a->NB32 * (a->NB32 + 1) / 2;
-    a->n_sets = fu_nsets(a->NB32);
+    a->n_sets = 1;                            // (per launch: fu_args_blocks)
     a->n_bins = ax->n_groups * ax->F;
     a->F = ax->F;
     a->floats_per_bin = (int64_t)sc_plane_count(planes) * a->n_tiles * SC_TILE_ELEMS;

@@ -245,8 +245,8 @@ def test_fused_fft_matches_oracle_and_rocfft(sc, N, L, C, det):
 
 
 @pytest.mark.parametrize("C,R", [(128, 9), (96, 5), (64, 6), (24, 11), (6, 4), (128, 40), (2, 50), (16, 300), (32, 7),
-                                 (34, 5), (42, 9), (44, 4), (48, 6), (50, 3), (130, 4), (160, 6), (192, 3), (208, 4), (250, 3),
-                                 (256, 5)])
+                                 (34, 5), (42, 9), (44, 4), (48, 6), (50, 3), (52, 4), (56, 3), (130, 4), (160, 6), (162, 3), (176, 3),
+                                 (192, 3), (194, 3), (208, 4), (224, 3), (226, 2), (250, 3), (256, 5)])
 def test_fused_stage_b_equals_separate_kernels(sc, C, R):
     """The one-pass stage-B kernels -- bf16 MFMA + VALU from 50 channels on (44 without the |Im| plane), f32 VALU
     below -- against the separate f32-MFMA CSM and |Im| kernels on the same spectra (identical fp32 arithmetic per
@@ -278,7 +278,7 @@ def test_fused_stage_b_equals_separate_kernels(sc, C, R):
 
 
 @pytest.mark.parametrize("C,R", [(2, 40), (6, 9), (16, 120), (34, 5), (40, 6), (42, 5), (48, 7), (50, 4), (52, 5), (54, 4), (58, 6), (60, 3), (64, 6), (96, 4), (128, 5),
-                                 (129, 3), (130, 3), (160, 4), (192, 3), (224, 2), (255, 2), (256, 2)])
+                                 (129, 3), (130, 3), (160, 4), (162, 2), (192, 3), (194, 2), (224, 2), (226, 2), (255, 2), (256, 2)])
 def test_one_pass_nonlinear_planes_equal_the_per_plane_kernel(sc, C, R):
     """(Im s)^2 and sign(Im s) ride on the small-channel one-pass kernel (<= 52 / <= 40 channels) or are plane passes of the
     matrix-core kernel (up to 128), and the unit phasors s/|s| go through the one-pass kernels as the cross-spectral

@@ -25,7 +25,7 @@ def timed(f, reps=3):
 
 
 print("# stage A: 128 channels, 7 tapers, half-overlapping windows; output bytes / time")
-for (T, L, R) in ((1024, 64, 1000), (1024, 128, 1000), (1024, 256, 1000), (1024, 512, 1000), (2048, 1024, 1000),
+for (T, L, R) in () if os.environ.get("SC_SWEEP_STAGE_B_ONLY") else ((1024, 64, 1000), (1024, 128, 1000), (1024, 256, 1000), (1024, 512, 1000), (2048, 1024, 1000),
                   (4096, 2048, 250), (8192, 4096, 250), (1000, 250, 1000), (1000, 200, 1000), (3000, 1000, 300)):
     step, K, C = L // 2, 7, 128
     x = torch.randn((T, R, C), device=dev)
@@ -42,7 +42,10 @@ families = (("CSM (coherence)", _lib.PLANE_CSM), ("CSM+|Im| (wPLI)", _lib.PLANE_
             ("+Im^2 (debiased wPLI)", _lib.PLANE_CSM | _lib.PLANE_ABS_IM | _lib.PLANE_IM_SQ),
             ("sign Im (PLI)", _lib.PLANE_SIGN_IM), ("s/|s| (PLV, PPC)", _lib.PLANE_UNIT))
 print("channels  " + "  ".join(f"{n:>22s}" for n, _ in families))
-for C in (2, 4, 8, 16, 19, 32, 48, 50, 64, 96, 128, 160, 256):
+CHANNELS = (2, 4, 8, 16, 19, 32, 40, 44, 48, 50, 52, 56, 64, 96, 128, 130, 160, 192, 224, 256)
+if os.environ.get("SC_SWEEP_CHANNELS"):
+    CHANNELS = tuple(int(v) for v in os.environ["SC_SWEEP_CHANNELS"].split(","))
+for C in CHANNELS:
     R = max(4, int(1000 * 128 / C))
     x = torch.randn((8, R, C), device=dev)                    # only to build spectra of the right (padded) layout
     Cp = C + 1 if (C % 2 and C + 1 <= 128) else C
