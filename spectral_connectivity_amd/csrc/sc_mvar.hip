@@ -18,8 +18,10 @@
 //     m_update_mfma         G <- G A+, err = max |G - G_old| on the fp64 matrix cores (m_gemm_mfma beyond 64 signals)
 //   measures                H0 = Re mean_n G; H = G (H0 + lam I)^-1 on the non-negative bins;
 //                           A_mvar = (H + lam' I)^-1; Sigma = H0 H0^T; DTF / DC / PDC / gPDC / dDTF.
-// Everything is fp64 (the reference's convergence test max |dG| < 1e-8 is out of fp32's reach).  The C x C factor of one
-// (window, bin) lives in the registers of one workgroup: C <= 128.  Larger systems are rejected, not emulated.
+// Everything is fp64 (the reference's convergence test max |dG| < 1e-8 is out of fp32's reach).  Up to 128 signals the
+// C x C factor of one (window, bin) lives in the registers of one workgroup; 129 ... 256 signals (the most an accumulator
+// record holds) run the same iteration with the inverse as a panel-blocked Gauss-Jordan on the matrix in global memory
+// (m_inverse_global) and the products as 128 x 128 output blocks of m_gemm_mfma.
 #include <rocfft/rocfft.h>
 #include "sc_common.h"
 
@@ -32,8 +34,10 @@ __device__ inline cd m_div(cd a, cd b) {
     return make_double2((a.x * b.x + a.y * b.y) / d, (a.y * b.x - a.x * b.y) / d);
 }
 
-#define MV_CMAX 128          // <= 64: register-resident [G | S] elimination; 65 ... 128: explicit inverse + matrix-core products
-#define MV_CSMALL 64
+#define MV_CMAX 256          // <= 64: register-resident [G | S] elimination; 65 ... 128: explicit in-register inverse + matrix-
+#define MV_CSMALL 64         // core products; 129 ... 256: panel-blocked inverse in global memory + blocked products
+#define MV_CMID 128
+#define MV_GRID_Y 32768      // grid.y of the per-element kernels (C^2 = 65536 elements at 256 signals exceed the limit of 65535)
 
 // ---- dense complex linear algebra on LDS-resident matrices (one workgroup, any block size) ------
 // LU with partial pivoting of M (C x C, row-major), in place: unit-lower multipliers below the diagonal,
@@ -114,9 +118,9 @@ struct MvDims {
 // S[p][e][n] from the accumulator records (upper-triangular 16x16 tiles, un-normalised sums)
 __global__ void m_build(ScRec accum, MvDims d, cd* S, int64_t sn, int64_t se) {
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int e = blockIdx.y;
     const int64_t p = blockIdx.z;
     if (n >= d.N) return;
+    for (int e = blockIdx.y; e < d.C * d.C; e += gridDim.y) {
     const int i = e / d.C, j = e % d.C;
     int64_t bin = n;
     bool conj = false;
@@ -132,20 +136,21 @@ __global__ void m_build(ScRec accum, MvDims d, cd* S, int64_t sn, int64_t se) {
     if (conj) im = -im;
     if (i == j) im = 0.0;
     S[p * d.C * d.C * d.N + n * sn + e * se] = make_double2(re, im);      // series: sn = 1, se = N; natural: sn = C^2, se = 1
+    }
 }
 
 // natural [p][n][e] <-> series [p][e][n]
 __global__ void m_to_series(const cd* nat, cd* ser, int64_t N, int E) {
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int e = blockIdx.y;
     const int64_t p = blockIdx.z;
-    if (n < N) ser[(p * E + e) * N + n] = nat[(p * N + n) * E + e];
+    if (n < N)
+        for (int e = blockIdx.y; e < E; e += gridDim.y) ser[(p * E + e) * N + n] = nat[(p * N + n) * E + e];
 }
 __global__ void m_to_natural(const cd* ser, cd* nat, int64_t N, int E) {
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int e = blockIdx.y;
     const int64_t p = blockIdx.z;
-    if (n < N) nat[(p * N + n) * E + e] = ser[(p * E + e) * N + n];
+    if (n < N)
+        for (int e = blockIdx.y; e < E; e += gridDim.y) nat[(p * N + n) * E + e] = ser[(p * E + e) * N + n];
 }
 
 // R0[p][e] = Re mean_n S[p][e][n]: one wave per series, lanes along n (unit stride)
@@ -179,13 +184,16 @@ __global__ void m_fill_nat(const double* __restrict__ g0, cd* __restrict__ G, in
 // one block per window: lower Cholesky of R0 in LDS, G0 = L^T written back over r0 (upper triangular, real); a lag-0
 // covariance that is not positive definite leaves the identity there (the expectation of the reference's random
 // Wishart start, minimum_phase_decomposition.py:78-93) and is counted in *n_fallback
-__global__ void __launch_bounds__(256) m_chol(double* __restrict__ r0g, int32_t* status, int32_t* n_fallback, int C) {
-    extern __shared__ double r0[];        // [C][C]
+// (in_place: beyond 128 signals the matrix does not fit LDS -- the factor is built where it lies, in global memory)
+__global__ void __launch_bounds__(256) m_chol(double* r0g, int32_t* status, int32_t* n_fallback, int C, int in_place) {
+    extern __shared__ double r0_lds[];        // [C][C]
     __shared__ int bad;
     const int64_t p = blockIdx.x;
     const int E = C * C;
+    double* r0 = in_place ? r0g + p * E : r0_lds;
     if (threadIdx.x == 0) bad = 0;
-    for (int e = threadIdx.x; e < E; e += blockDim.x) r0[e] = r0g[p * E + e];
+    if (!in_place)
+        for (int e = threadIdx.x; e < E; e += blockDim.x) r0[e] = r0g[p * E + e];
     __syncthreads();
     for (int k = 0; k < C; ++k) {
         if (threadIdx.x == 0) {
@@ -207,6 +215,14 @@ __global__ void __launch_bounds__(256) m_chol(double* __restrict__ r0g, int32_t*
     if (threadIdx.x == 0) {
         status[p] = 0;
         if (bad) atomicAdd(n_fallback, 1);
+    }
+    if (in_place) {         // transpose the lower triangle into the upper one pair by pair
+        for (int e = threadIdx.x; e < E; e += blockDim.x) {
+            const int i = e / C, j = e % C;
+            if (j > i) { r0[i * C + j] = bad ? 0.0 : r0[j * C + i]; r0[j * C + i] = 0.0; }
+            else if (j == i && bad) r0[e] = 1.0;
+        }
+        return;
     }
     for (int e = threadIdx.x; e < E; e += blockDim.x) {
         const int i = e / C, j = e % C;
@@ -233,21 +249,22 @@ __global__ void m_restart_count(int32_t* n_fallback, int32_t P) {
 // G[p][e][n] = G0[p][e] for every n
 __global__ void m_fill(const double* __restrict__ g0, cd* __restrict__ G, int64_t N, int E) {
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int e = blockIdx.y;
     const int64_t p = blockIdx.z;
-    if (n < N) G[(p * E + e) * N + n] = make_double2(g0[p * E + e], 0.0);
+    if (n < N)
+        for (int e = blockIdx.y; e < E; e += gridDim.y) G[(p * E + e) * N + n] = make_double2(g0[p * E + e], 0.0);
 }
 
 __global__ void m_causal(cd* A, int64_t N, int C) {
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int e = blockIdx.y;
     const int64_t p = blockIdx.z;
     if (n >= N) return;
-    const int i = e / C, j = e % C;
-    double sc = (n < (N + 1) / 2) ? 1.0 / (double)N : 0.0;
-    if (n == 0) { sc *= 0.5; if (i > j) sc = 0.0; }
-    cd* a = A + (p * C * C + e) * N + n;
-    *a = make_double2(a->x * sc, a->y * sc);
+    for (int e = blockIdx.y; e < C * C; e += gridDim.y) {
+        const int i = e / C, j = e % C;
+        double sc = (n < (N + 1) / 2) ? 1.0 / (double)N : 0.0;
+        if (n == 0) { sc *= 0.5; if (i > j) sc = 0.0; }
+        cd* a = A + (p * C * C + e) * N + n;
+        *a = make_double2(a->x * sc, a->y * sc);
+    }
 }
 
 __device__ inline void mv_atomic_max_nonneg(double* addr, double v) {
@@ -662,11 +679,140 @@ __global__ void __launch_bounds__(512) m_inverse_inplace(MvMat M, const double* 
         }
 }
 
+// Out = (M + lam I)^-1 for 129 ... 256 signals: the matrix (1 MB at 256) lives in a global scratch W (one C x C row-major
+// matrix per (window, bin)) and is inverted in place by Gauss-Jordan with partial pivoting, sixteen pivots at a time so that
+// the matrix crosses the memory system once per PANEL instead of once per pivot:
+//   1. the panel's sixteen columns go to LDS and are eliminated there (pivot search over the rows not used yet, no row ever
+//      moves; the in-place trick of m_inverse_inplace: the pivot's column slot takes 1 / pivot, the other rows' slots are
+//      cleared before the update) -- afterwards column j of the panel holds column pr_j of the product E of the sixteen
+//      row operations;
+//   2. the sixteen pivot rows R = W[pr_j][:] (old values) go to LDS;
+//   3. every other column c:  W[r][c] <- (r is one of the pivot rows ? 0 : W[r][c]) + sum_j E[r][j] R[j][c]
+//      (E M = M + (E - I)[:, pivot rows] M[pivot rows, :]): 2 x 4 elements per thread and pass, 0.75 LDS reads per complex FMA;
+//   4. the panel is written back.
+// M^-1[k][pr_j] = W[pr_k][j] at the end.  1024 threads, 133 KB of LDS: one workgroup per CU.
+#define MV_PB 16
+__global__ void __launch_bounds__(1024) m_inverse_global(MvMat M, const double* __restrict__ lam, MvMat Out, cd* Work,
+                                                         const int32_t* __restrict__ status, int C) {
+    extern __shared__ __align__(16) unsigned char mv_smem[];
+    cd* Pn = reinterpret_cast<cd*>(mv_smem);          // [256][MV_PB]   the panel
+    cd* Rr = Pn + 256 * MV_PB;                        // [MV_PB][256]   the pivot rows
+    cd* colbuf = Rr + MV_PB * 256;                    // [256]          column j of the panel before step j
+    cd* rowbuf = colbuf + 256;                        // [MV_PB]        the scaled pivot row of step j
+    __shared__ unsigned key[256];
+    __shared__ int prow[256], pos[256];
+    __shared__ unsigned char used[256];
+    const int64_t n = mv_bin_of_block(), p = blockIdx.y;
+    if (status && status[p] != 0) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int E = C * C;
+    const cd* src = M.p + mv_at(M, p, n);
+    cd* W = Work + ((int64_t)p * gridDim.x + n) * E;
+    const double l0 = lam ? lam[0] : 0.0;
+    for (int e = tid; e < E; e += 1024) {
+        cd v = src[(int64_t)e * M.se];
+        if (e / C == e % C) v.x += l0;
+        W[e] = v;
+    }
+    if (tid < 256) { used[tid] = 0; prow[tid] = 0; pos[tid] = 0; key[tid] = 0u; }
+    __syncthreads();
+    for (int k0 = 0; k0 < C; k0 += MV_PB) {
+        const int nb = C - k0 < MV_PB ? C - k0 : MV_PB;
+        for (int idx = tid; idx < C * MV_PB; idx += 1024) {
+            const int r = idx / MV_PB, j = idx % MV_PB;
+            Pn[idx] = j < nb ? W[r * C + k0 + j] : make_double2(0.0, 0.0);
+        }
+        __syncthreads();
+        for (int j = 0; j < nb; ++j) {
+            if (tid < 256) {
+                const cd v = tid < C ? Pn[tid * MV_PB + j] : make_double2(0.0, 0.0);
+                colbuf[tid] = v;
+                const unsigned hi = (unsigned)(__double_as_longlong(v.x * v.x + v.y * v.y) >> 32);
+                key[tid] = (tid >= C || used[tid]) ? 0u : ((hi & ~511u) | 256u | (unsigned)(255 - tid));
+            }
+            __syncthreads();
+            const unsigned kv = max(max(key[lane], key[lane + 64]), max(key[lane + 128], key[lane + 192]));
+            const int pr = 255 - (int)(mv_wave_max_u32(kv) & 255u);
+            const cd piv = colbuf[pr];
+            const double pden = piv.x * piv.x + piv.y * piv.y;
+            const cd inv = make_double2(piv.x / pden, -piv.y / pden);
+            if (tid < MV_PB) rowbuf[tid] = tid == j ? inv : m_mul(Pn[pr * MV_PB + tid], inv);
+            if (tid == 0) { prow[k0 + j] = pr; pos[pr] = k0 + j; used[pr] = 1; }
+            __syncthreads();
+            for (int idx = tid; idx < C * MV_PB; idx += 1024) {
+                const int r = idx / MV_PB, jj = idx % MV_PB;
+                if (r == pr) { Pn[idx] = rowbuf[jj]; continue; }
+                const cd m = colbuf[r], w = rowbuf[jj];
+                cd g = jj == j ? make_double2(0.0, 0.0) : Pn[idx];
+                g.x = fma(-m.x, w.x, fma(m.y, w.y, g.x));
+                g.y = fma(-m.x, w.y, fma(-m.y, w.x, g.y));
+                Pn[idx] = g;
+            }
+            __syncthreads();
+        }
+        for (int idx = tid; idx < MV_PB * C; idx += 1024) {
+            const int j = idx / C, c = idx - j * C;
+            Rr[j * 256 + c] = j < nb ? W[prow[k0 + j] * C + c] : make_double2(0.0, 0.0);
+        }
+        __syncthreads();
+        {
+            const int ty = tid >> 6, tx = lane;          // rows ty + 16 a, columns tx + 64 b
+            for (int a = 0; a < 16; a += 2) {
+                const int r0 = ty + 16 * a, r1 = r0 + 16;
+                if (r0 >= C) break;
+                cd acc[2][4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int c = tx + 64 * b;
+                    const bool live = c < C && !(c >= k0 && c < k0 + nb);
+                    const bool p0 = used[r0] && pos[r0] >= k0;
+                    const bool p1 = r1 < C && used[r1] && pos[r1] >= k0;
+                    acc[0][b] = (live && !p0) ? W[r0 * C + c] : make_double2(0.0, 0.0);
+                    acc[1][b] = (live && r1 < C && !p1) ? W[r1 * C + c] : make_double2(0.0, 0.0);
+                }
+                for (int j = 0; j < nb; ++j) {
+                    const cd e0 = Pn[r0 * MV_PB + j], e1 = r1 < C ? Pn[r1 * MV_PB + j] : make_double2(0.0, 0.0);
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const cd w = Rr[j * 256 + tx + 64 * b];
+                        acc[0][b].x = fma(e0.x, w.x, fma(-e0.y, w.y, acc[0][b].x));
+                        acc[0][b].y = fma(e0.x, w.y, fma(e0.y, w.x, acc[0][b].y));
+                        acc[1][b].x = fma(e1.x, w.x, fma(-e1.y, w.y, acc[1][b].x));
+                        acc[1][b].y = fma(e1.x, w.y, fma(e1.y, w.x, acc[1][b].y));
+                    }
+                }
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int c = tx + 64 * b;
+                    if (c < C && !(c >= k0 && c < k0 + nb)) {
+                        W[r0 * C + c] = acc[0][b];
+                        if (r1 < C) W[r1 * C + c] = acc[1][b];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < C * MV_PB; idx += 1024) {
+            const int r = idx / MV_PB, j = idx % MV_PB;
+            if (j < nb) W[r * C + k0 + j] = Pn[idx];
+        }
+        __syncthreads();
+    }
+    cd* dst = Out.p + mv_at(Out, p, n);
+    for (int e = tid; e < E; e += 1024) {
+        const int r = e / C, c = e - r * C;
+        dst[(int64_t)(pos[r] * C + prow[c]) * Out.se] = W[e];
+    }
+}
+
 // O = X Y (BH: X Y^H; ADD_I: + I; ERR: err[p] = max |O - X| elementwise, O may alias X) per (window, bin), C <= 16 Q <=
 // 128, on the fp64 matrix cores.  K-slices of 16: X[:, k0 : k0 + 16] and Y[k0 : k0 + 16, :] wait in LDS (68 KB) while the
 // next slice travels HBM / L2 -> registers; 512 threads, wave w owns tile row w and every tile column of it: 8 tiles x
 // (re, im) x 4 = 64 accumulator doubles per lane at 128 channels, two waves per SIMD -- 32 independent MFMAs per 4-deep
 // step and wave.
+// Beyond 128 signals (Q = 8) the output is cut into 128 x 128 blocks, one workgroup each (blockIdx.z = 2 block row + block
+// column; every block runs the whole K range): O must then not alias X, and a frozen window is copied across so that the
+// caller can swap the two buffers.
 template <int Q, bool BH, bool ADD_I, bool ERR>
 __global__ void __launch_bounds__(512) m_gemm_mfma(MvMat X, MvMat Y, MvMat O, const int32_t* __restrict__ status,
                                                    double* __restrict__ err, int C) {
@@ -677,25 +823,35 @@ __global__ void __launch_bounds__(512) m_gemm_mfma(MvMat X, MvMat Y, MvMat O, co
     cd* Ys = Xs + CP * LSX;                       // [KS][LSY]
     __shared__ double red[8];
     const int64_t n = mv_bin_of_block(), p = blockIdx.y;
-    if (status && status[p] != 0) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const cd* xb = X.p + mv_at(X, p, n);
     const cd* yb = Y.p + mv_at(Y, p, n);
+    const int i0 = (int)(blockIdx.z >> 1) * CP, j0 = (int)(blockIdx.z & 1) * CP;      // output block (0, 0 up to 128 signals)
+    if (status && status[p] != 0) {
+        if (ERR && gridDim.z > 1) {              // frozen window, blocked launch: O <- X for this block
+            cd* ob = O.p + mv_at(O, p, n);
+            for (int idx = tid; idx < CP * CP; idx += 512) {
+                const int i = i0 + idx / CP, j = j0 + idx % CP;
+                if (i < C && j < C) ob[(int64_t)(i * C + j) * O.se] = xb[(int64_t)(i * C + j) * X.se];
+            }
+        }
+        return;
+    }
     cd rx[NU], ry[NU];
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             const int idx = tid + 512 * u;
             {
-                const int i = idx >> 4, k = k0 + (idx & 15);
+                const int i = i0 + (idx >> 4), k = k0 + (idx & 15);
                 rx[u] = (i < C && k < C) ? xb[(int64_t)(i * C + k) * X.se] : make_double2(0.0, 0.0);
             }
             if constexpr (BH) {
-                const int j = idx >> 4, k = k0 + (idx & 15);
+                const int j = j0 + (idx >> 4), k = k0 + (idx & 15);
                 ry[u] = (j < C && k < C) ? yb[(int64_t)(j * C + k) * Y.se] : make_double2(0.0, 0.0);
             } else {
-                const int kr = idx / CP, j = idx - kr * CP, k = k0 + kr;
+                const int kr = idx / CP, j = j0 + idx - kr * CP, k = k0 + kr;
                 ry[u] = (k < C && j < C) ? yb[(int64_t)(k * C + j) * Y.se] : make_double2(0.0, 0.0);
             }
         }
@@ -745,7 +901,7 @@ __global__ void __launch_bounds__(512) m_gemm_mfma(MvMat X, MvMat Y, MvMat O, co
         for (int tj = 0; tj < Q; ++tj)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int i = 16 * wave + lk + 4 * r, j = 16 * tj + li;
+                const int i = i0 + 16 * wave + lk + 4 * r, j = j0 + 16 * tj + li;
                 if (i < C && j < C) {
                     cd v = make_double2(re[tj][r], im[tj][r]);
                     if (ADD_I && i == j) v.x += 1.0;
@@ -911,13 +1067,14 @@ __global__ void m_inflow_all(const cd* H, double* tot, int64_t F, int C) {
 }
 
 // one block per (p, f): out[p][f][i][j]
+// (cache = 0, beyond 128 signals: the squared moduli do not fit LDS and are parked in `pw_global` [P F][C C] instead)
 __global__ void m_measure(const cd* H, const cd* Amv, const double* sigma, const double* tot, int which,
-                          double* out, int64_t F, int C) {
+                          double* out, int64_t F, int C, int cache, double* pw_global) {
     extern __shared__ __align__(16) unsigned char mv_smem[];
-    double* pw = reinterpret_cast<double*>(mv_smem);      // |H_ij|^2 or |A_ij|^2
-    double* nrm = pw + C * C;                               // per-row (inflow) or per-column (outflow) sums
     const int64_t b = blockIdx.x, p = b / F;
     const int E = C * C;
+    double* nrm = reinterpret_cast<double*>(mv_smem);                    // per-row (inflow) or per-column (outflow) sums
+    double* pw = cache ? nrm + C : pw_global + b * E;                    // |H_ij|^2 or |A_ij|^2
     const bool use_a = which == SC_MVAR_PDC || which == SC_MVAR_GPDC;
     for (int e = threadIdx.x; e < E; e += blockDim.x) {
         const cd v = use_a ? Amv[b * E + e] : H[b * E + e];
@@ -1034,8 +1191,17 @@ static MvMat mv_series(cd* b, int64_t N, int E) { return MvMat{b, (int64_t)E * N
 static MvMat mv_natural(cd* b, int64_t N, int E) { return MvMat{b, N * (int64_t)E, (int64_t)E, 1}; }
 static int mv_big_q(int64_t C) { return C <= 96 ? 6 : 8; }
 
+// (scratch: one C x C matrix per problem of the grid, beyond 128 signals only)
 static int mv_launch_inverse_big(int64_t C, dim3 grid, hipStream_t st, MvMat M, const double* lam, MvMat Out,
-                                 const int32_t* status) {
+                                 const int32_t* status, cd* scratch) {
+    if (C > MV_CMID) {
+        SC_REQUIRE(scratch, "inverse beyond 128 signals needs a scratch");
+        const size_t lds = (size_t)(2 * 256 * MV_PB + 256 + MV_PB) * sizeof(cd);
+        SC_CHECK_HIP(hipFuncSetAttribute((const void*)m_inverse_global, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(m_inverse_global, grid, dim3(1024), lds, st, M, lam, Out, scratch, status, (int)C);
+        SC_CHECK_HIP(hipGetLastError());
+        return SC_OK;
+    }
     if (mv_big_q(C) == 6) hipLaunchKernelGGL(m_inverse_inplace<6>, grid, dim3(512), 0, st, M, lam, Out, status, (int)C);
     else hipLaunchKernelGGL(m_inverse_inplace<8>, grid, dim3(512), 0, st, M, lam, Out, status, (int)C);
     SC_CHECK_HIP(hipGetLastError());
@@ -1063,6 +1229,10 @@ static int mv_launch_gemm_q(int mode, dim3 grid, hipStream_t st, MvMat X, MvMat 
 }
 static int mv_launch_gemm(int64_t C, int mode, dim3 grid, hipStream_t st, MvMat X, MvMat Y, MvMat O,
                           const int32_t* status, double* err) {
+    if (C > MV_CMID) {          // four 128 x 128 output blocks per problem; O must not alias X or Y
+        SC_REQUIRE(O.p != X.p && O.p != Y.p, "blocked product in place");
+        grid.z = 4;
+    }
     return mv_big_q(C) == 6 ? mv_launch_gemm_q<6>(mode, grid, st, X, Y, O, status, err, (int)C)
                             : mv_launch_gemm_q<8>(mode, grid, st, X, Y, O, status, err, (int)C);
 }
@@ -1082,7 +1252,9 @@ extern "C" int sc_mvar_workspace_bytes(int64_t n_groups, int64_t C, int64_t N, s
     // factor: S, G, A series (beyond 64 signals also G^-1 and G^-1 S); measures: H, A_mvar natural + small per-window arrays
     const size_t n_big = C > MV_CSMALL ? 5 : 3;
     const size_t factor = n_big * P * E * (size_t)N * sizeof(cd) + P * 16 + P * E * 8 + 128 + (size_t)MV_HIST * 4;
-    const size_t meas = 2 * P * F * E * sizeof(cd) + P * E * 8 * 3 + P * (F > 16 ? F : 16) * 8 + P * (size_t)C * 8 + P * 8 + 256;
+    // (beyond 128 signals: + the scratch of the blocked inverse, which also parks |H|^2 / |A|^2 for m_measure)
+    const size_t meas = (C > MV_CMID ? 3 : 2) * P * F * E * sizeof(cd) + P * E * 8 * 3 + P * (F > 16 ? F : 16) * 8 +
+                        P * (size_t)C * 8 + P * 8 + 256;
     *bytes = (factor > meas ? factor : meas) + 256;
     return SC_OK;
 }
@@ -1097,7 +1269,7 @@ extern "C" int sc_mvar_factor_f64(const void* d_accum, const void* d_S, int64_t 
     SC_REQUIRE(d_work && d_G && d_n_iter && d_status, "NULL argument");
     SC_REQUIRE(n_groups >= 1 && n_groups <= 65535 && N >= 2 && N <= 1 << 24, "bad problem size");
     if (C < 1 || C > MV_CMAX) {
-        sc_set_error("full Wilson factorisation keeps the C x C factor in one workgroup's registers: n_signals <= %d (got %lld)",
+        sc_set_error("full Wilson factorisation: n_signals <= %d, the most an accumulator record holds (got %lld)",
                      MV_CMAX, (long long)C);
         return SC_EUNSUPPORTED;
     }
@@ -1122,7 +1294,8 @@ extern "C" int sc_mvar_factor_f64(const void* d_accum, const void* d_S, int64_t 
     double* g0 = (double*)w; w += (size_t)P * E * 8;
     int32_t* n_fallback = (int32_t*)w; w += 64;
     int32_t* n_running = (int32_t*)w;
-    const dim3 gridE((unsigned)((N + 255) / 256), (unsigned)E, (unsigned)P);
+    const dim3 gridE((unsigned)((N + 255) / 256), (unsigned)(E < MV_GRID_Y ? E : MV_GRID_Y), (unsigned)P);
+    const bool huge = C > MV_CMID;
     if (d_accum) {
         SC_REQUIRE(planes & SC_PLANE_CSM, "accumulator record must contain SC_PLANE_CSM");
         SC_REQUIRE(n_freq_accum == N || n_freq_accum == N / 2 + 1, "accumulators must hold N or N/2+1 bins");
@@ -1175,8 +1348,9 @@ extern "C" int sc_mvar_factor_f64(const void* d_accum, const void* d_S, int64_t 
     // G0 = chol(Re ifft_n(S)[lag 0])^H broadcast over the bins (minimum_phase_decomposition.py:48-77)
     if (big) hipLaunchKernelGGL(m_lag0_nat, dim3((unsigned)((E + 255) / 256), (unsigned)P), dim3(256), 0, st, S, g0, N, E);
     else hipLaunchKernelGGL(m_lag0, dim3((unsigned)(((int64_t)P * E + 3) / 4)), dim3(256), 0, st, S, g0, N, (int64_t)P * E);
-    SC_CHECK_HIP(hipFuncSetAttribute((const void*)m_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)E * 8)));
-    hipLaunchKernelGGL(m_chol, dim3((unsigned)P), dim3(256), (size_t)E * 8, st, g0, d_status, n_fallback, (int)C);
+    if (!huge) SC_CHECK_HIP(hipFuncSetAttribute((const void*)m_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)E * 8)));
+    hipLaunchKernelGGL(m_chol, dim3((unsigned)P), dim3(256), huge ? (size_t)0 : (size_t)E * 8, st, g0, d_status, n_fallback, (int)C,
+                       huge ? 1 : 0);
     hipLaunchKernelGGL(m_restart_all, dim3(64), dim3(256), 0, st, g0, n_fallback, (int64_t)P, (int)C);
     hipLaunchKernelGGL(m_restart_count, dim3(1), dim3(1), 0, st, n_fallback, (int32_t)P);
     if (big) hipLaunchKernelGGL(m_fill_nat, dim3((unsigned)((E + 255) / 256), (unsigned)N, (unsigned)P), dim3(256), 0, st, g0, G, N, E);
@@ -1190,7 +1364,8 @@ extern "C" int sc_mvar_factor_f64(const void* d_accum, const void* d_S, int64_t 
             void* bufs[1] = {A};
             if (big) {          // A = G^-1 S G^-H + I: explicit inverse, two matrix-core products
                 // (G, S, G^-1 and G^-1 S in the natural layout [p][n][e]: coalesced; only A crosses the transform as series)
-                if ((rc = mv_launch_inverse_big(C, gridB, st, mv_natural(G, N, E), nullptr, mv_natural(Ginv, N, E), d_status)) != SC_OK) goto done;
+                // (beyond 128 signals T doubles as the scratch of the inverse: it is written only by the product after it)
+                if ((rc = mv_launch_inverse_big(C, gridB, st, mv_natural(G, N, E), nullptr, mv_natural(Ginv, N, E), d_status, T)) != SC_OK) goto done;
                 if ((rc = mv_launch_gemm(C, MV_GEMM_PLAIN, gridB, st, mv_natural(Ginv, N, E), mv_natural(S, N, E),
                                          mv_natural(T, N, E), d_status, nullptr)) != SC_OK) goto done;
                 if ((rc = mv_launch_gemm(C, MV_GEMM_BH_I, gridB, st, mv_natural(T, N, E), mv_natural(Ginv, N, E),
@@ -1203,7 +1378,11 @@ extern "C" int sc_mvar_factor_f64(const void* d_accum, const void* d_S, int64_t 
                 hipLaunchKernelGGL(m_causal, gridE, dim3(256), 0, st, A, N, (int)C);
                 MV_CHECK_FFT(rocfft_execute(fwd, bufs, nullptr, info));
             }
-            if (big) {
+            if (huge) {         // the blocked product cannot run in place: G A+ into T (frozen windows copied), then swap
+                if ((rc = mv_launch_gemm(C, MV_GEMM_ERR, gridB, st, mv_natural(G, N, E), mv_series(A, N, E), mv_natural(T, N, E),
+                                         d_status, err)) != SC_OK) goto done;
+                cd* t = G; G = T; T = t;
+            } else if (big) {
                 if ((rc = mv_launch_gemm(C, MV_GEMM_ERR, gridB, st, mv_natural(G, N, E), mv_series(A, N, E), mv_natural(G, N, E),
                                          d_status, err)) != SC_OK) goto done;
             } else if ((rc = mv_launch_update(Q, gridB, st, G, A, d_status, err, N, (int)C)) != SC_OK) goto done;
@@ -1250,7 +1429,7 @@ extern "C" int sc_mvar_measure_f64(const void* d_G, int64_t n_groups, int64_t N,
     SC_REQUIRE(d_G && d_out && d_work, "NULL argument");
     SC_REQUIRE(which >= SC_MVAR_DTF && which <= SC_MVAR_NOISE_COVARIANCE, "unknown MVAR quantity");
     if (C < 1 || C > MV_CMAX) {
-        sc_set_error("MVAR measures: n_signals <= %d (got %lld)", MV_CMAX, (long long)C);
+        sc_set_error("MVAR measures: n_signals <= %d, the most an accumulator record holds (got %lld)", MV_CMAX, (long long)C);
         return SC_EUNSUPPORTED;
     }
     size_t need = 0;
@@ -1267,7 +1446,10 @@ extern "C" int sc_mvar_measure_f64(const void* d_G, int64_t n_groups, int64_t N,
     double* sigma = (double*)w; w += (size_t)P * E * 8;
     double* sq = (double*)w; w += (size_t)P * (F > 16 ? F : 16) * 8;      // per (window, bin) or per (window, 256-element chunk)
     double* tot = (double*)w; w += (size_t)P * C * 8;
-    double* lam = (double*)w;                         // [0] lam of H0, [1] lam' of H
+    double* lam = (double*)w; w += 64;                // [0] lam of H0, [1] lam' of H
+    const bool huge = C > MV_CMID;
+    w += (16 - ((uintptr_t)w & 15)) & 15;
+    cd* scratch = huge ? (cd*)w : nullptr;            // [P][F][E]: the blocked inverse's matrices, then m_measure's squared moduli
     const int nt = mv_threads((int)C);
     const bool big = C > MV_CSMALL;
     const size_t lds = big ? 0 : mv_pair_lds((int)C);
@@ -1287,7 +1469,7 @@ extern "C" int sc_mvar_measure_f64(const void* d_G, int64_t n_groups, int64_t N,
         const unsigned nb = (unsigned)(((int64_t)P * E + 255) / 256);
         hipLaunchKernelGGL(m_real_to_cd, dim3(nb), dim3(256), 0, st, h0, h0c, (int64_t)P * E);
         int rcb = mv_launch_inverse_big(C, dim3(1, (unsigned)P), st, MvMat{h0c, (int64_t)E, 0, 1}, lam,
-                                        MvMat{hinvc, (int64_t)E, 0, 1}, nullptr);
+                                        MvMat{hinvc, (int64_t)E, 0, 1}, nullptr, scratch);
         if (rcb != SC_OK) return rcb;
         hipLaunchKernelGGL(m_cd_to_real, dim3(nb), dim3(256), 0, st, hinvc, hinv, (int64_t)P * E);
         hipLaunchKernelGGL(m_sigma, dim3((unsigned)((E + 255) / 256), (unsigned)P), dim3(256), 0, st, h0, sigma, (int)C);
@@ -1316,7 +1498,7 @@ extern "C" int sc_mvar_measure_f64(const void* d_G, int64_t n_groups, int64_t N,
     hipLaunchKernelGGL(m_sum, dim3(1), dim3(64), 0, st, sq, P * F, 1e-12 / (double)(P * F * E), lam + 1);
     if (big) {          // A_mvar = (H + lam' I)^-1 per (window, bin); the launch overwrites the parked H0 matrices last
         int rcb = mv_launch_inverse_big(C, dim3((unsigned)F, (unsigned)P), st, MvMat{H, F * (int64_t)E, (int64_t)E, 1}, lam + 1,
-                                        MvMat{Amv, F * (int64_t)E, (int64_t)E, 1}, nullptr);
+                                        MvMat{Amv, F * (int64_t)E, (int64_t)E, 1}, nullptr, scratch);
         if (rcb != SC_OK) return rcb;
     } else {
         const int Q = (int)((C + 15) / 16);
@@ -1335,9 +1517,10 @@ extern "C" int sc_mvar_measure_f64(const void* d_G, int64_t n_groups, int64_t N,
         return SC_OK;
     }
     if (which == SC_MVAR_DDTF) hipLaunchKernelGGL(m_inflow_all, dim3((unsigned)P), dim3(64), 0, st, H, tot, F, (int)C);
-    SC_CHECK_HIP(hipFuncSetAttribute((const void*)m_measure, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)(E + C) * 8)));
-    hipLaunchKernelGGL(m_measure, dim3((unsigned)(P * F)), dim3(nt), (size_t)(E + C) * 8, st, H, Amv, sigma, tot, which,
-                       (double*)d_out, F, (int)C);
+    const size_t mlds = huge ? (size_t)C * 8 : (size_t)(E + C) * 8;
+    SC_CHECK_HIP(hipFuncSetAttribute((const void*)m_measure, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
+    hipLaunchKernelGGL(m_measure, dim3((unsigned)(P * F)), dim3(nt), mlds, st, H, Amv, sigma, tot, which,
+                       (double*)d_out, F, (int)C, huge ? 0 : 1, (double*)scratch);
     if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) {
         sc_set_error("MVAR measure failed: %s", hipGetErrorString(hipGetLastError()));
         return SC_EHIP;

@@ -451,7 +451,8 @@ def test_f9_mvar_measures_vs_reference(sc, golden, tag):
 
 
 @pytest.mark.parametrize("c,N,P", [(3, 64, 2), (8, 128, 3), (17, 64, 1), (40, 32, 2), (64, 32, 1),
-                                   (65, 32, 2), (80, 48, 1), (96, 64, 1), (97, 32, 1), (128, 32, 2), (100, 256, 1)])
+                                   (65, 32, 2), (80, 48, 1), (96, 64, 1), (97, 32, 1), (128, 32, 2), (100, 256, 1),
+                                   (129, 32, 1), (160, 32, 2), (200, 256, 1), (250, 48, 1), (256, 32, 1)])
 def test_full_wilson_factor_standalone_fp64(sc, c, N, P):
     """minimum_phase_decomposition() for c > 2 on exactly representable fp64 spectra of known
     minimum-phase filters: S = F F^H with F(z) = I + B z^-1 (||B|| < 1) factors back to F Q with the
@@ -469,16 +470,18 @@ def test_full_wilson_factor_standalone_fp64(sc, c, N, P):
     G = minimum_phase_decomposition(S)
     assert G.shape == S.shape and np.isfinite(G).all()
     np.testing.assert_allclose(G @ np.conj(np.swapaxes(G, -1, -2)), S, rtol=0, atol=1e-7 * np.abs(S).max())
-    if c <= 17 or (c, N) in ((65, 32), (128, 32)):      # (beyond 64 signals: explicit inverse + matrix-core products)
+    # (beyond 64 signals: explicit inverse + matrix-core products; beyond 128: panel-blocked inverse in global memory)
+    if c <= 17 or (c, N) in ((65, 32), (128, 32), (129, 32), (160, 32), (256, 32)):
         np.testing.assert_allclose(G, so.minimum_phase_decomposition(S), rtol=0, atol=1e-6 * np.abs(G).max())
 
 
-@pytest.mark.parametrize("C", [72, 128])
+@pytest.mark.parametrize("C", [72, 128, 130, 160, 200])
 def test_mvar_measures_beyond_64_signals_vs_oracle(sc, C):
     """65 ... 128 signals: Wilson factor, transfer function, noise covariance, MVAR coefficients and the directed
-    measures through the explicit-inverse / matrix-core kernels (sc_mvar.hip), float64 engine, against the oracle."""
+    measures through the explicit-inverse / matrix-core kernels (sc_mvar.hip), float64 engine, against the oracle;
+    129 ... 256 signals: the same iteration on the panel-blocked inverse and the blocked products."""
     rng = np.random.default_rng(C)
-    T, R = 64, 90
+    T, R = 64, (90 if C <= 128 else C)
     e = rng.standard_normal((T + 8, R, C))
     x = e.copy()
     for t in range(2, T + 8):                                 # a sparse stable VAR(2): neighbours drive each other
@@ -495,11 +498,13 @@ def test_mvar_measures_beyond_64_signals_vs_oracle(sc, C):
         assert a.shape == b.shape, (what, a.shape, b.shape)
         err = np.abs(a - b).max() / np.abs(b).max()
         assert err < tol, f"{what}: {err:.2e}"
-    close(c._minimum_phase_factor, q["G"], "minimum phase factor")
-    close(c._noise_covariance, q["noise_covariance"], "noise covariance")
-    close(c._transfer_function, q["H"], "transfer function")
+    # (the iteration stops on max |dG| < 1e-8: device and oracle may stop one iteration apart, a few 1e-7 of the factor)
+    loose = 1e-6 if C <= 128 else 3e-6
+    close(c._minimum_phase_factor, q["G"], "minimum phase factor", tol=loose)
+    close(c._noise_covariance, q["noise_covariance"], "noise covariance", tol=loose)
+    close(c._transfer_function, q["H"], "transfer function", tol=loose)
     close(c._MVAR_Fourier_coefficients, q["A"], "MVAR coefficients", tol=1e-5)
-    close(c.directed_transfer_function(), so.directed_transfer_function(coef, q=q), "DTF")
+    close(c.directed_transfer_function(), so.directed_transfer_function(coef, q=q), "DTF", tol=loose)
     close(c.partial_directed_coherence(), so.partial_directed_coherence(coef, q=q), "PDC", tol=1e-5)
     close(c.direct_directed_transfer_function(), so.direct_directed_transfer_function(coef, q=q), "dDTF", tol=1e-5)
     assert c._last_wilson["not_converged"] == 0 and c._last_wilson["iterations"] < 60
