@@ -422,8 +422,10 @@ def test_minimum_phase_decomposition_vs_reference_and_known_filters(sc, golden):
     np.testing.assert_allclose(G * np.conj(G), S, rtol=1e-7, atol=1e-9)        # exact for a rational spectrum
     G = minimum_phase_decomposition(np.tile(np.eye(3, dtype=complex), (1, 8, 1, 1)))   # white spectrum: G = I
     np.testing.assert_allclose(G, np.tile(np.eye(3, dtype=complex), (1, 8, 1, 1)), atol=1e-12)
+    G = minimum_phase_decomposition(np.tile(np.eye(129, dtype=complex), (1, 4, 1, 1)))   # (round 3: up to 256 signals)
+    np.testing.assert_allclose(G, np.tile(np.eye(129, dtype=complex), (1, 4, 1, 1)), atol=1e-12)
     with pytest.raises(NotImplementedError):
-        minimum_phase_decomposition(np.tile(np.eye(129, dtype=complex), (1, 4, 1, 1)))
+        minimum_phase_decomposition(np.tile(np.eye(257, dtype=complex), (1, 4, 1, 1)))
 
 
 @pytest.mark.parametrize("tag", ["var3", "var5"])
