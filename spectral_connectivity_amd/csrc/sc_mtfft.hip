@@ -18,6 +18,7 @@
 // (DC and Nyquist come out exactly real, like the reference's real input), and stored as
 // float4 (A, B) so a wave writes contiguous CT*8-byte segments per frequency.
 #include <cstdlib>
+#include <type_traits>
 #include "sc_common.h"
 
 struct MtArgs {
@@ -30,7 +31,8 @@ struct MtArgs {
     int r_off, Rc;         //   trials [r_off, r_off + Rc) of this launch
     int kh;                // tapers resident in LDS (K, or 1 = reload per taper)
     int dbg;               // profiling aid (env SC_MTFFT_DEBUG bit mask, results WRONG when set):
-                           // 1 = no HBM stores, 2 = skip both radix-16 passes, 4 = skip the split/store loop
+                           // 1 = no HBM stores, 2 = skip both radix-16 passes, 4 = skip the split/store loop,
+                           // 8 = every wave takes the store loop with the silent / non-finite channel overrides (A/B of the fast loop)
 };
 
 __device__ inline float2 cmul(float2 a, float2 b) {
@@ -370,12 +372,14 @@ mtfft16_kernel(MtArgs p) {
     }
     const int spr = 2 * (tid & (NF - 1));                                   // the pair this thread stores
     const bool na = nbf[spr] != 0, nb = nbf[spr + 1] != 0, za = !na && nzf[spr] == 0, zb = !nb && nzf[spr + 1] == 0;
+    const bool any_flag = __builtin_amdgcn_ballot_w64(na || nb || za || zb) != 0ull || (p.dbg & 8);      // wave-uniform
     if constexpr (!LONG) {
         for (int i2 = tid; i2 < N; i2 += THREADS) tw[i2] = p.tw[i2];
         if (resident) {
-            for (int i2 = tid; i2 < p.K * p.L; i2 += THREADS) hk[i2] = p.tapers[i2];
+            // (tapers enter halved: the 1/2 of the conjugate-symmetry split, an exact scaling, leaves the store loop)
+            for (int i2 = tid; i2 < p.K * p.L; i2 += THREADS) hk[i2] = 0.5f * p.tapers[i2];
         } else {
-            for (int i2 = tid; i2 < L; i2 += THREADS) hk[i2] = p.tapers[i2];          // taper 0 into buffer 0
+            for (int i2 = tid; i2 < L; i2 += THREADS) hk[i2] = 0.5f * p.tapers[i2];          // taper 0 into buffer 0
         }
     }
     // W_N^m: the LDS table, or (long windows) the product of the two 64-entry tables
@@ -413,14 +417,14 @@ mtfft16_kernel(MtArgs p) {
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
                 const int n = i + t * TPF;
-                hl[t] = (n < L) ? p.tapers[(int64_t)k * L + n] : 0.f;
+                hl[t] = (n < L) ? 0.5f * p.tapers[(int64_t)k * L + n] : 0.f;
             }
         }
         if (fetch_next) {
 #pragma unroll
             for (int j = 0; j < HN; ++j) {
                 const int n = tid + THREADS * j;
-                hn[j] = (n < L) ? p.tapers[(int64_t)(k + 1) * L + n] : 0.f;
+                hn[j] = (n < L) ? 0.5f * p.tapers[(int64_t)(k + 1) * L + n] : 0.f;
             }
         }
         __syncthreads();     // taper k visible; post of k-1 (and, first time, the tile reads) done
@@ -573,13 +577,17 @@ mtfft16_kernel(MtArgs p) {
             float2 zn = make_float2(0.f, 0.f);
             if (last) zn = zp[PHYS(N / 2)];
             float2* dst0 = Xk + 2 * pr;
-            auto put = [&](int f, float2 u1, float2 u2) {
-                float2 A = make_float2(0.5f * (u1.x + u2.x), 0.5f * (u1.y - u2.y));
-                float2 B = make_float2(0.5f * (u1.y + u2.y), 0.5f * (u2.x - u1.x));
-                if (za) A = make_float2(0.f, 0.f);
-                if (zb) B = make_float2(0.f, 0.f);
-                if (na) A = make_float2(__int_as_float(0x7fc00000), __int_as_float(0x7fc00000));
-                if (nb) B = make_float2(__int_as_float(0x7fc00000), __int_as_float(0x7fc00000));
+            // (the silent / non-finite channel overrides cost eight selects per row of a thread -- a tenth of the kernel's
+            //  VALU instructions -- and almost never apply: a wave without a flagged channel takes the loop without them)
+            auto put_any = [&](auto flagged, int f, float2 u1, float2 u2) {
+                float2 A = make_float2(u1.x + u2.x, u1.y - u2.y);       // (Z[f] + conj Z[N-f]) / 2, the half already in the taper
+                float2 B = make_float2(u1.y + u2.y, u2.x - u1.x);       // (Z[f] - conj Z[N-f]) / (2 i)
+                if constexpr (decltype(flagged)::value) {
+                    if (za) A = make_float2(0.f, 0.f);
+                    if (zb) B = make_float2(0.f, 0.f);
+                    if (na) A = make_float2(__int_as_float(0x7fc00000), __int_as_float(0x7fc00000));
+                    if (nb) B = make_float2(__int_as_float(0x7fc00000), __int_as_float(0x7fc00000));
+                }
                 if ((p.dbg & 1) && A.x != 12345.f) return;
                 if constexpr (ROWSTORE) {
                     float2* row = p.Z + (((((int64_t)w * p.Rc + (r - p.r_off)) * p.K + k) * C + c) * (int64_t)(N / 2 + 1));
@@ -595,19 +603,22 @@ mtfft16_kernel(MtArgs p) {
                     if (c + 1 < C) dst[1] = B;
                 }
             };
+            auto store_all = [&](auto flagged) {
 #pragma unroll
-            for (int h = 0; h < 8; h += 4) {
-                float2 z1[4], z2[4];
+                for (int h = 0; h < 8; h += 4) {
+                    float2 z1[4], z2[4];
 #pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const int f = fb + (h + it) * (THREADS / NF);
-                    z1[it] = zp[PHYS(f)];
-                    z2[it] = zp[PHYS((N - f) & (N - 1))];
+                    for (int it = 0; it < 4; ++it) {
+                        const int f = fb + (h + it) * (THREADS / NF);
+                        z1[it] = zp[PHYS(f)];
+                        z2[it] = zp[PHYS((N - f) & (N - 1))];
+                    }
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) put_any(flagged, fb + (h + it) * (THREADS / NF), z1[it], z2[it]);
                 }
-#pragma unroll
-                for (int it = 0; it < 4; ++it) put(fb + (h + it) * (THREADS / NF), z1[it], z2[it]);
-            }
-            if (last) put(N / 2, zn, zn);
+                if (last) put_any(flagged, N / 2, zn, zn);
+            };
+            if (any_flag) store_all(std::true_type{}); else store_all(std::false_type{});
         }
         MT_TICK(3);
         // the barrier at the top of the next taper orders these reads before pass 1 rewrites z
