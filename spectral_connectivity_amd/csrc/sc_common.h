@@ -121,3 +121,24 @@ __device__ inline int64_t sc_obs_offset(const ScAxes& a, int o) {
     int orr = o % a.rR; o /= a.rR;
     return (int64_t)o * a.sW + (int64_t)orr * a.sR + (int64_t)ok * a.sK;
 }
+
+// Streaming stores of the spectra (written once, read by the next kernel from HBM: 6.5 GB at cfg3 against 32 MB of L2 and
+// 256 MB of MALL): the non-temporal hint keeps the lines from lingering in the write-back L2 -- stage A 1.553 -> 1.495 ms at
+// 256 samples, 1.605 -> 1.550 at 128, 2.188 -> 2.142 at 1024 (A/B inside one process, profiles/r03_stage_a_ab.txt).
+#ifdef __HIPCC__
+typedef float sc_f32x4 __attribute__((ext_vector_type(4)));
+typedef float sc_f32x2 __attribute__((ext_vector_type(2)));
+typedef double sc_f64x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void sc_stream_store(float2* p, float2 a, float2 b) {          // 16-byte aligned pair
+    const sc_f32x4 v = {a.x, a.y, b.x, b.y};
+    __builtin_nontemporal_store(v, reinterpret_cast<sc_f32x4*>(p));
+}
+__device__ __forceinline__ void sc_stream_store(float2* p, float2 a) {
+    const sc_f32x2 v = {a.x, a.y};
+    __builtin_nontemporal_store(v, reinterpret_cast<sc_f32x2*>(p));
+}
+__device__ __forceinline__ void sc_stream_store(double2* p, double2 a) {
+    const sc_f64x2 v = {a.x, a.y};
+    __builtin_nontemporal_store(v, reinterpret_cast<sc_f64x2*>(p));
+}
+#endif

@@ -32,7 +32,8 @@ struct MtArgs {
     int kh;                // tapers resident in LDS (K, or 1 = reload per taper)
     int dbg;               // profiling aid (env SC_MTFFT_DEBUG bit mask, results WRONG when set):
                            // 1 = no HBM stores, 2 = skip both radix-16 passes, 4 = skip the split/store loop,
-                           // 8 = every wave takes the store loop with the silent / non-finite channel overrides (A/B of the fast loop)
+                           // 8 = every wave takes the store loop with the silent / non-finite channel overrides (A/B of the fast loop),
+                           // 16 = plain instead of non-temporal stores (A/B)
 };
 
 __device__ inline float2 cmul(float2 a, float2 b) {
@@ -597,10 +598,11 @@ mtfft16_kernel(MtArgs p) {
                 }
                 float2* dst = dst0 + (int64_t)f * sF;
                 if (vec_ok) {
-                    *reinterpret_cast<float4*>(dst) = make_float4(A.x, A.y, B.x, B.y);
+                    if (p.dbg & 16) *reinterpret_cast<float4*>(dst) = make_float4(A.x, A.y, B.x, B.y);      // (A/B: plain stores)
+                    else sc_stream_store(dst, A, B);
                 } else {
-                    dst[0] = A;
-                    if (c + 1 < C) dst[1] = B;
+                    sc_stream_store(dst, A);
+                    if (c + 1 < C) sc_stream_store(dst + 1, B);
                 }
             };
             auto store_all = [&](auto flagged) {
@@ -977,10 +979,10 @@ __global__ void __launch_bounds__(512) mtfft_mixed_kernel(MxArgs p) {
             if (nzf[2 * pr + 1] == 0) B = make_float2(0.f, 0.f);
             float2* d = Xk + (int64_t)f * sF + 2 * pr;
             if (vec_ok) {
-                *reinterpret_cast<float4*>(d) = make_float4(A.x, A.y, B.x, B.y);
+                sc_stream_store(d, A, B);
             } else {
-                d[0] = A;
-                if (c + 1 < C) d[1] = B;
+                sc_stream_store(d, A);
+                if (c + 1 < C) sc_stream_store(d + 1, B);
             }
         }
         if (any_bad) {       // rare: a channel of this tile held a NaN / infinity -- its bins become NaN (same thread, same
@@ -1124,10 +1126,10 @@ __global__ void __launch_bounds__(64 * NF) mtfft_mixed_wave_kernel(MxArgs p) {
             if (nzf[2 * pr + 1] == 0) B = make_float2(0.f, 0.f);
             float2* d = Xk + (int64_t)f * sF + 2 * pr;
             if (vec_ok) {
-                *reinterpret_cast<float4*>(d) = make_float4(A.x, A.y, B.x, B.y);
+                sc_stream_store(d, A, B);
             } else {
-                d[0] = A;
-                if (c + 1 < C) d[1] = B;
+                sc_stream_store(d, A);
+                if (c + 1 < C) sc_stream_store(d + 1, B);
             }
         }
         if (any_bad) {       // rare: a channel of this tile held a NaN / infinity -- its bins become NaN (same thread, same

@@ -222,8 +222,8 @@ __global__ void __launch_bounds__(64 * NF) mtfft_f64_kernel(MdArgs p) {
             if (na) A = make_double2(__longlong_as_double(0x7ff8000000000000LL), __longlong_as_double(0x7ff8000000000000LL));
             if (nb) B = make_double2(__longlong_as_double(0x7ff8000000000000LL), __longlong_as_double(0x7ff8000000000000LL));
             zd* d = Xk + (int64_t)f * sF + 2 * pr;
-            d[0] = A;
-            if (c + 1 < C) d[1] = B;
+            sc_stream_store(d, A);
+            if (c + 1 < C) sc_stream_store(d + 1, B);
         }
         __syncthreads();                                          // the next taper refills z
     }
@@ -516,8 +516,8 @@ __global__ void __launch_bounds__(256, 2) mtfft16_f64_kernel(MdArgs p, int kh) {
                 if (na) A = make_double2(qnan, qnan);
                 if (nb) B = make_double2(qnan, qnan);
                 zd* dst = Xk + (int64_t)f * sF + 2 * pr;
-                dst[0] = A;
-                if (c + 1 < C) dst[1] = B;
+                sc_stream_store(dst, A);
+                if (c + 1 < C) sc_stream_store(dst + 1, B);
             };
 #pragma unroll
             for (int h = 0; h < 8; h += 4) {
