@@ -123,8 +123,10 @@ __device__ inline int64_t sc_obs_offset(const ScAxes& a, int o) {
 }
 
 // Streaming stores of the spectra (written once, read by the next kernel from HBM: 6.5 GB at cfg3 against 32 MB of L2 and
-// 256 MB of MALL): the non-temporal hint keeps the lines from lingering in the write-back L2 -- stage A 1.553 -> 1.495 ms at
-// 256 samples, 1.605 -> 1.550 at 128, 2.188 -> 2.142 at 1024 (A/B inside one process, profiles/r03_stage_a_ab.txt).
+// 256 MB of MALL): the non-temporal hint keeps the lines from lingering in the write-back L2 -- stage A 1.537 -> 1.471 ms at
+// 256 samples, 1.517 -> 1.406 at 128, 2.186 -> 2.141 at 1024 (A/B inside one process, profiles/r03_stage_a_ab.txt).  ONLY for
+// store groups that cover whole 128-byte lines: partial lines need the L2 to merge them (4096-sample windows, 32-byte
+// pieces: 0.91 -> 1.73 ms with the hint; the float64 transform's 16-byte halves: 4.1 -> 6.1 ms).
 #ifdef __HIPCC__
 typedef float sc_f32x4 __attribute__((ext_vector_type(4)));
 typedef float sc_f32x2 __attribute__((ext_vector_type(2)));

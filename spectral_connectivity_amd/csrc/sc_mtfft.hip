@@ -598,11 +598,14 @@ mtfft16_kernel(MtArgs p) {
                 }
                 float2* dst = dst0 + (int64_t)f * sF;
                 if (vec_ok) {
-                    if (p.dbg & 16) *reinterpret_cast<float4*>(dst) = make_float4(A.x, A.y, B.x, B.y);      // (A/B: plain stores)
+                    // non-temporal only where the NF pairs of a frequency row make whole 128-byte lines (NF >= 8: up to 1024
+                    // samples); the 64- / 32-byte pieces of 2048 / 4096 samples NEED the write-back L2 to merge them
+                    // (4096 samples: 0.91 -> 1.73 ms with the hint)
+                    if (NF < 8 || (p.dbg & 16)) *reinterpret_cast<float4*>(dst) = make_float4(A.x, A.y, B.x, B.y);
                     else sc_stream_store(dst, A, B);
                 } else {
-                    sc_stream_store(dst, A);
-                    if (c + 1 < C) sc_stream_store(dst + 1, B);
+                    dst[0] = A;
+                    if (c + 1 < C) dst[1] = B;
                 }
             };
             auto store_all = [&](auto flagged) {
@@ -979,10 +982,10 @@ __global__ void __launch_bounds__(512) mtfft_mixed_kernel(MxArgs p) {
             if (nzf[2 * pr + 1] == 0) B = make_float2(0.f, 0.f);
             float2* d = Xk + (int64_t)f * sF + 2 * pr;
             if (vec_ok) {
-                sc_stream_store(d, A, B);
+                *reinterpret_cast<float4*>(d) = make_float4(A.x, A.y, B.x, B.y);
             } else {
-                sc_stream_store(d, A);
-                if (c + 1 < C) sc_stream_store(d + 1, B);
+                d[0] = A;
+                if (c + 1 < C) d[1] = B;
             }
         }
         if (any_bad) {       // rare: a channel of this tile held a NaN / infinity -- its bins become NaN (same thread, same
@@ -1126,10 +1129,11 @@ __global__ void __launch_bounds__(64 * NF) mtfft_mixed_wave_kernel(MxArgs p) {
             if (nzf[2 * pr + 1] == 0) B = make_float2(0.f, 0.f);
             float2* d = Xk + (int64_t)f * sF + 2 * pr;
             if (vec_ok) {
-                sc_stream_store(d, A, B);
+                if constexpr (NF >= 8) sc_stream_store(d, A, B);        // whole 128-byte lines per frequency row
+                else *reinterpret_cast<float4*>(d) = make_float4(A.x, A.y, B.x, B.y);
             } else {
-                sc_stream_store(d, A);
-                if (c + 1 < C) sc_stream_store(d + 1, B);
+                d[0] = A;
+                if (c + 1 < C) d[1] = B;
             }
         }
         if (any_bad) {       // rare: a channel of this tile held a NaN / infinity -- its bins become NaN (same thread, same
