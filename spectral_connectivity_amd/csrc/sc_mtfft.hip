@@ -371,16 +371,20 @@ mtfft16_kernel(MtArgs p) {
 #pragma unroll
         for (int t = 0; t < 16; ++t) xs[t].y = 0.f;
     }
+    // The samples enter halved -- once per workgroup, they serve every taper: the 1/2 of the conjugate-symmetry split, an exact
+    // scaling, leaves the store loop.  (Halving the TAPERS instead put a multiply, i.e. a wait for the taper loads, in front
+    // of the barrier of the long-window kernels: 2048 samples 2.0 -> 2.6 ms, bisected with variant libraries.)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) { xs[t].x *= 0.5f; xs[t].y *= 0.5f; }
     const int spr = 2 * (tid & (NF - 1));                                   // the pair this thread stores
     const bool na = nbf[spr] != 0, nb = nbf[spr + 1] != 0, za = !na && nzf[spr] == 0, zb = !nb && nzf[spr + 1] == 0;
     const bool any_flag = __builtin_amdgcn_ballot_w64(na || nb || za || zb) != 0ull || (p.dbg & 8);      // wave-uniform
     if constexpr (!LONG) {
         for (int i2 = tid; i2 < N; i2 += THREADS) tw[i2] = p.tw[i2];
         if (resident) {
-            // (tapers enter halved: the 1/2 of the conjugate-symmetry split, an exact scaling, leaves the store loop)
-            for (int i2 = tid; i2 < p.K * p.L; i2 += THREADS) hk[i2] = 0.5f * p.tapers[i2];
+            for (int i2 = tid; i2 < p.K * p.L; i2 += THREADS) hk[i2] = p.tapers[i2];
         } else {
-            for (int i2 = tid; i2 < L; i2 += THREADS) hk[i2] = 0.5f * p.tapers[i2];          // taper 0 into buffer 0
+            for (int i2 = tid; i2 < L; i2 += THREADS) hk[i2] = p.tapers[i2];          // taper 0 into buffer 0
         }
     }
     // W_N^m: the LDS table, or (long windows) the product of the two 64-entry tables
@@ -418,14 +422,14 @@ mtfft16_kernel(MtArgs p) {
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
                 const int n = i + t * TPF;
-                hl[t] = (n < L) ? 0.5f * p.tapers[(int64_t)k * L + n] : 0.f;
+                hl[t] = (n < L) ? p.tapers[(int64_t)k * L + n] : 0.f;
             }
         }
         if (fetch_next) {
 #pragma unroll
             for (int j = 0; j < HN; ++j) {
                 const int n = tid + THREADS * j;
-                hn[j] = (n < L) ? 0.5f * p.tapers[(int64_t)(k + 1) * L + n] : 0.f;
+                hn[j] = (n < L) ? p.tapers[(int64_t)(k + 1) * L + n] : 0.f;
             }
         }
         __syncthreads();     // taper k visible; post of k-1 (and, first time, the tile reads) done

@@ -12,8 +12,11 @@ from spectral_connectivity_amd import engine      # noqa: E402
 
 variants = sys.argv[1:] or ["0", "8"]
 dev = torch.device("cuda:0")
-for (T, L, R) in ((1024, 256, 1000), (1024, 128, 1000), (2048, 1024, 500)):
-    step, K, C = L // 2, 7, 128
+SHAPES = ((1024, 256, 1000), (1024, 128, 1000), (2048, 1024, 500))
+if os.environ.get("SC_AB_LONG"):
+    SHAPES = ((2048, 2048, 500), (4096, 4096, 250))
+for (T, L, R) in SHAPES:
+    step, K, C = max(1, L // 2), 7, 128
     x = torch.randn((T, R, C), device=dev)
     tap = torch.randn((K, L), device=dev)
     W = (T - L) // step + 1
