@@ -113,7 +113,6 @@ for src, dst, head in (("api_wall.txt", ROUND + "_api_wall.txt", "# tools/api_wa
                        ("stage_a_wide.txt", ROUND + "_stage_a_wide.txt", "# tools/stage_a_wide.py: stage A for long windows, 256-thread (wide=0) against 512-thread workgroups (wide=1, the default)"),
                        ("global_canonical.txt", ROUND + "_global_canonical.txt", "# tools/global_time.py: global coherence (1024 two-sided bins) and canonical coherence with large groups at the cfg5 shape"),
                        ("measure_table.txt", ROUND + "_measure_table.txt", "# tools/measure_table.py: every measure of the public interface at the cfg3 shape"),
-                       ("mvar_256ch.txt", ROUND + "_mvar_256ch.txt", "# tools/mvar_time.py 256 1792 256: full 256 x 256 Wilson factorisation + DTF, 7 windows x 256 bins (round 3)"),
                        ("mvar_size_time.txt", ROUND + "_mvar_size_time.txt", "# tools/mvar_size_time.py: full Wilson factorisation + DTF across system sizes, one window x 256 bins, float64 records"),
                        ("stage_a_ab.txt", ROUND + "_stage_a_ab_final.txt", "# tools/stage_a_ab.py 0 16 8 1 2 4: stage A variants inside one process (SC_MTFFT_DEBUG: 16 = plain stores, 8 = store loop with the rare-channel overrides, 1 = no stores, 2 = no passes, 4 = no split/store loop)")):
     body = [l for l in lines(src) if "amdgpu.ids" not in l]

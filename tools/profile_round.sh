@@ -27,7 +27,6 @@ for d in kt fetch write sq; do
 done
 python tools/mvar_time.py 64 1792 256 > $OUT/mvar_64ch.txt 2>&1
 python tools/mvar_time.py 128 1792 256 > $OUT/mvar_128ch.txt 2>&1
-python tools/mvar_time.py 256 1792 256 > $OUT/mvar_256ch.txt 2>&1
 python tools/mvar_size_time.py > $OUT/mvar_size_time.txt 2>&1
 python tools/stage_a_ab.py 0 16 8 1 2 4 > $OUT/stage_a_ab.txt 2>&1
 python tools/engine_time.py > $OUT/engine_time.txt 2>&1
