@@ -17,7 +17,7 @@ def _cases():
     for k in range(n_cases):
         channels = [1, 2, 3, 5, 8, 16, 17, 31, 32, 33, 48, 64, 65, 96, 127, 128]
         if k >= 36:      # the extra cases also walk the kernel-selection boundaries (42 / 48 / 50 channels, odd counts)
-            channels += [4, 6, 7, 19, 34, 40, 41, 42, 43, 44, 46, 47, 49, 50, 51, 63, 100, 129, 130, 160]
+            channels += [4, 6, 7, 19, 34, 40, 41, 42, 43, 44, 46, 47, 49, 50, 51, 63, 100, 129, 130, 160, 162, 192, 200, 224, 226, 250, 256]
         C = int(rng.choice(channels))
         L = int(rng.choice([16, 50, 64, 100, 128, 200, 256]))
         step = int(rng.choice([L, max(L // 2, 1), max(L // 3, 1)]))
