@@ -549,7 +549,9 @@ def main():
                 "collective_ms": round(sum(e["collective_ms"] for e in exchange) / max(len(exchange), 1), 4),
                 "exposed_exchange_ms": round(sum(e["exposed_ms"] for e in exchange) / max(len(exchange), 1), 4),
                 "bytes_reduced_per_rank": exchange[-1]["bytes_reduced"] if exchange else None,
-                "n_frequency_groups": exchange[-1]["n_groups"] if exchange else None},
+                "n_frequency_groups": exchange[-1]["n_groups"] if exchange else None,
+                "reduce_scatter": ("direct: all_to_all_single of the 1/N bin blocks (one xGMI link each) + local sum in rank order"
+                                   if parallel.exchange_algorithm() == "direct" else "ring: reduce_scatter_tensor")},
         }))
     if world > 1:
         dist.destroy_process_group()

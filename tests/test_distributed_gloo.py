@@ -40,11 +40,12 @@ def unpack_diag_power(rec, C):
     return out
 
 
-def worker(rank, world, port, x, ref_rec, ref_power, errors):
+def worker(rank, world, port, x, ref_rec, ref_power, errors, algorithm="direct"):
     try:
         sys.path.insert(0, ROOT)
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
+        os.environ["SC_EXCHANGE"] = algorithm
         dist.init_process_group("gloo", rank=rank, world_size=world)
         from oracle import spectral_oracle as so
         from spectral_connectivity_amd import parallel
@@ -79,8 +80,10 @@ def worker(rank, world, port, x, ref_rec, ref_power, errors):
         raise
 
 
-@pytest.mark.parametrize("world,R", [(2, 6), (2, 5), (4, 7)])
-def test_trial_sharded_reduce_scatter_matches_single_process(world, R):
+@pytest.mark.parametrize("world,R,algorithm", [(2, 6, "direct"), (2, 5, "ring"), (4, 7, "direct"), (3, 4, "direct"), (4, 7, "ring")])
+def test_trial_sharded_reduce_scatter_matches_single_process(world, R, algorithm):
+    """Both exchange algorithms of parallel.reduce_scatter_bins: the direct all-to-all + rank-ordered local sum (default)
+    and the library reduce-scatter (gloo: all-reduce + slice), unequal and padded bin shards included."""
     sys.path.insert(0, ROOT)
     from oracle import spectral_oracle as so
     rng = np.random.default_rng(7)
@@ -96,7 +99,7 @@ def test_trial_sharded_reduce_scatter_matches_single_process(world, R):
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     errors = ctx.Queue()
-    procs = [ctx.Process(target=worker, args=(r, world, port, x, ref_rec, ref_power, errors)) for r in range(world)]
+    procs = [ctx.Process(target=worker, args=(r, world, port, x, ref_rec, ref_power, errors, algorithm)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:

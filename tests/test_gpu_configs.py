@@ -219,15 +219,16 @@ def test_trial_sharded_pipeline_ranks_share_one_gpu(world):
     assert "ShardedConnectivity OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
-def test_rccl_exchange_path_world_one():
-    """The RCCL calls of the N > 1 path (reduce_scatter_tensor, gather, all_gather_into_tensor, all_reduce on the
-    `nccl` backend, exchange stream, padded buffers) rehearsed with the one GPU a test box has: a one-rank nccl group,
-    SC_FORCE_EXCHANGE=1 so that nothing short-cuts the collectives."""
+@pytest.mark.parametrize("algorithm", ["direct", "ring"])
+def test_rccl_exchange_path_world_one(algorithm):
+    """The RCCL calls of the N > 1 path (all_to_all_single of the direct exchange / reduce_scatter_tensor of the ring one,
+    gather, all_gather_into_tensor, all_reduce on the `nccl` backend, exchange stream, padded buffers) rehearsed with the one
+    GPU a test box has: a one-rank nccl group, SC_FORCE_EXCHANGE=1 so that nothing short-cuts the collectives."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, SC_BENCH_BACKEND="nccl", SC_FORCE_EXCHANGE="1", MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, SC_BENCH_BACKEND="nccl", SC_FORCE_EXCHANGE="1", MASTER_ADDR="127.0.0.1", SC_EXCHANGE=algorithm)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
                           "--master-addr", "127.0.0.1", "--master-port", "29547",
                           os.path.join(root, "tools", "check_sharded.py")],
