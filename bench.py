@@ -106,7 +106,8 @@ def one_step(x, h, cfg, geom, planes, world, exchange=None):
     N > 1 path."""
     L, step, N, W = geom
     sp = engine.multitaper_spectra(x, h, L, step, N, W, "constant")
-    if world > 1:
+    if world > 1 or os.environ.get("SC_BENCH_FORCE_SHARDED") == "1":     # (the switch: the N > 1 code path on one rank,
+        # with SC_FORCE_EXCHANGE=1 through the collectives too -- what a rank's step costs beside the transfers)
         # trial shards: accumulate -> reduce-scatter -> epilogue -> gather on rank 0, pipelined over frequency
         # groups so that only the last group's exchange is exposed (parallel.sharded_measures)
         coh, wpli = parallel.sharded_measures(sp, planes, [_lib.M_COHERENCE_MAGNITUDE, _lib.M_WPLI],
