@@ -80,16 +80,19 @@ __device__ inline MeasureIn measure_mirror(MeasureIn v) {
 // one measure of one entry; complex measures return (re, im), real ones (value, 0)
 __device__ inline double2 measure_value(int measure, double n, MeasureIn v, bool diag) {
     const double NaN = nan("");
-    double s_re = v.s_re / n, s_im = diag ? 0.0 : v.s_im / n;
-    const double p_i = v.p_i / n, p_j = v.p_j / n;
+    // (the expectation = sum * (1 / n): ONE fp64 division for the five quantities of an entry instead of five -- an fp64
+    //  division is ~12 instructions at half rate, and they were most of this kernel's arithmetic; 1 ulp of fp64 apart from x / n)
+    const double rn = 1.0 / n;
+    double s_re = v.s_re * rn, s_im = diag ? 0.0 : v.s_im * rn;
+    const double p_i = v.p_i * rn, p_j = v.p_j * rn;
     switch (measure) {
     case SC_M_CSM:
         return make_double2(s_re, s_im);
     case SC_M_COHERENCY:
     case SC_M_COHERENCE_MAGNITUDE:
     case SC_M_COHERENCE_PHASE: {
-        const double den = fmax(sqrt(p_i * p_j), SC_EPS64);
-        double c_re = s_re / den, c_im = s_im / den;
+        const double rden = 1.0 / fmax(sqrt(p_i * p_j), SC_EPS64);       // (one division for both parts)
+        double c_re = s_re * rden, c_im = s_im * rden;
         if (diag) { c_re = NaN; c_im = NaN; }
         if (measure == SC_M_COHERENCY) return make_double2(c_re, c_im);
         if (measure == SC_M_COHERENCE_MAGNITUDE) {
@@ -103,18 +106,18 @@ __device__ inline double2 measure_value(int measure, double n, MeasureIn v, bool
         return make_double2(fmin(fmax(fabs(s_im / den), 0.0), 1.0), 0.0);
     }
     case SC_M_PLV:
-        return make_double2((sqrt(v.u_re * v.u_re + v.u_im * v.u_im) / n), 0.0);
+        return make_double2((sqrt(v.u_re * v.u_re + v.u_im * v.u_im) * rn), 0.0);
     case SC_M_PLV_COMPLEX:
-        return make_double2((v.u_re / n), (v.u_im / n));
+        return make_double2((v.u_re * rn), (v.u_im * rn));
     case SC_M_PPC:
         return make_double2(((v.u_re * v.u_re + v.u_im * v.u_im - n) / (n * n - n)), 0.0);
     case SC_M_PLI:
     case SC_M_DEBIASED_PLI2: {
-        const double pli = (diag ? 0.0 : v.sg) / n;
+        const double pli = (diag ? 0.0 : v.sg) * rn;
         return make_double2((measure == SC_M_PLI ? pli : (n * pli * pli - 1.0) / (n - 1.0)), 0.0);
     }
     case SC_M_WPLI: {
-        double w = diag ? 0.0 : v.sa / n;
+        double w = diag ? 0.0 : v.sa * rn;
         if (w < SC_EPS64) w = 1.0;
         return make_double2((s_im / w), 0.0);
     }
@@ -187,7 +190,12 @@ __global__ void __launch_bounds__(256) measure_tile_kernel(MeasureArgs a) {
 
 // Several real-valued measures of the same record in ONE launch: the tile's planes are read once (every plane any of the
 // measures needs), each measure is evaluated for the tile and its mirror image like measure_tile_kernel does.
-#define MEASURE_MULTI_TPW 4       // tiles per workgroup: a tile is 3-5 KB of reads and 2 KB of writes per measure -- too little per launch slot
+#ifndef MEASURE_MULTI_TPW
+#define MEASURE_MULTI_TPW 1       // tiles per workgroup.  (Four -- "a tile is too little per launch slot" -- measured slower: two measures
+                                  // at the cfg3 shape 0.139 ms with 4, 0.142 with 2, 0.143 with 9, 0.118 with ONE: the tiles of a
+                                  // workgroup run one after the other, each behind its own loads, and 32 508 small workgroups hide
+                                  // that latency better than 8 127 longer ones; tools/measure_ab.py over variant libraries)
+#endif
 template <typename OutT, typename AccT>
 __global__ void __launch_bounds__(256) measure_tile_multi_kernel(MeasureArgs a) {
     __shared__ MeasureIn raw[256];
