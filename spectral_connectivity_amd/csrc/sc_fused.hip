@@ -1029,9 +1029,10 @@ static bool fused_ok(const void* d_X, const ScAxes& ax) {
 // The f32 VALU kernel below the measured crossover (same input volume as cfg3: 4.7 vs 5.1 ms at 48 channels with a
 // per-observation non-linear plane, 3.0 vs 3.9 ms at 40 channels without; the MFMA kernel wins from 56 / 44 on).
 static bool small_ok(const ScAxes& ax, bool nonlinear_plane) { return ax.C <= (nonlinear_plane ? 48 : 42); }
-// (Im s)^2 rides along with CSM + |Im s| on this kernel up to 52 channels, sign(Im s) runs on it up to 40: above, a
-// plane pass of the matrix-core kernel is faster (measured at the cfg3 volume: 50 channels, sign 9.9 ms here against
-// ~5.3 ms there; CSM + |Im| + Im^2 8.2 ms in one pass here against 5.3 + ~4 ms in two there).
+// (Im s)^2 rides along with CSM + |Im s| on this kernel up to 58 channels (as far as its 448 threads reach), sign(Im s)
+// runs on it up to 44: above, a plane pass of the matrix-core kernel is faster.  (Round 3, with two workgroups per CU at
+// every size -- the LDS tail holds only the quantities in use --, same input volume as cfg3: CSM + |Im| + Im^2 in one pass
+// 5.2 / 5.1 / 5.4 ms at 50 / 52 / 58 channels against 4.7 + ~3.3 in two; sign 5.3 ms at 44 channels here, 5.7 at 48 there.)
 static bool small_ok_sq(const ScAxes& ax) { return ax.C <= 58; }
 static bool small_ok_sign(const ScAxes& ax) { return ax.C <= 44; }
 
@@ -1283,7 +1284,7 @@ extern "C" uint32_t sc_fused_planes_covered(const sc_spectra_desc* desc, uint32_
 }
 
 // SC_PLANE_SIGN_IM of the record (phase_lag_index, debiased_squared_phase_lag_index: connectivity.py:983-1079): the
-// small-channel kernel up to 40 channels, above it a plane pass of the matrix-core kernel (the abs waves sum
+// small-channel kernel up to 44 channels, above it a plane pass of the matrix-core kernel (the abs waves sum
 // sign(d) of the per-observation products as integers).
 extern "C" int sc_fused_sign_ws_f32(const void* d_X, const sc_spectra_desc* desc, uint32_t planes, float* d_accum,
                                     void* d_workspace, int64_t workspace_bytes, void* stream) {

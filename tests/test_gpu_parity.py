@@ -280,7 +280,7 @@ def test_fused_stage_b_equals_separate_kernels(sc, C, R):
 @pytest.mark.parametrize("C,R", [(2, 40), (6, 9), (16, 120), (34, 5), (40, 6), (42, 5), (48, 7), (50, 4), (52, 5), (54, 4), (58, 6), (60, 3), (64, 6), (96, 4), (128, 5),
                                  (129, 3), (130, 3), (160, 4), (162, 2), (192, 3), (194, 2), (224, 2), (226, 2), (255, 2), (256, 2)])
 def test_one_pass_nonlinear_planes_equal_the_per_plane_kernel(sc, C, R):
-    """(Im s)^2 and sign(Im s) ride on the small-channel one-pass kernel (<= 52 / <= 40 channels) or are plane passes of the
+    """(Im s)^2 and sign(Im s) ride on the small-channel one-pass kernel (<= 58 / <= 44 channels) or are plane passes of the
     matrix-core kernel (up to 128), and the unit phasors s/|s| go through the one-pass kernels as the cross-spectral
     matrix of x/|x| at every size: the same accumulator records as the
     per-plane VALU kernel (sc_nonlinear.hip) up to f32 summation order -- sign sums exactly."""
@@ -300,7 +300,7 @@ def test_one_pass_nonlinear_planes_equal_the_per_plane_kernel(sc, C, R):
             ref = engine.measure(a_s, C, planes, n, which).cpu().numpy()
             if planes == _lib.PLANE_SIGN_IM:
                 assert np.array_equal(np.isnan(got), np.isnan(ref))
-                if C <= 40:                  # both kernels form Im s with the same f32 operations: identical sign sums
+                if C <= 44:                  # both kernels form Im s with the same f32 operations: identical sign sums
                     assert np.array_equal(got[~np.isnan(got)], ref[~np.isnan(ref)])
                 else:
                     # 42 ... 256 channels: the signs come from the matrix-core products (six bf16 cross terms, f32
@@ -687,7 +687,7 @@ def test_f11_band_statistics_on_the_device_coherency(sc, golden):
 
 @pytest.mark.parametrize("C,R", [(2, 9), (16, 7), (32, 30), (40, 5), (64, 4)])
 def test_matrix_core_kernel_below_its_crossover(sc, C, R, monkeypatch):
-    """SC_FUSED_NO_SMALL=1 sends every shape through the matrix-core kernel (normally <= 40-52 channels take the f32 VALU
+    """SC_FUSED_NO_SMALL=1 sends every shape through the matrix-core kernel (normally <= 42-58 channels take the f32 VALU
     kernel): the one-block table of <= 32 channels -- a lone MFMA per observation row, whose results the |Im| waves read
     straight away -- and every plane pass (|Im s|, (Im s)^2, sign(Im s)) against the per-plane kernels.  (The sign pass
     once read its MFMA results from inline asm without the wait states the compiler pads for instructions it can see:
