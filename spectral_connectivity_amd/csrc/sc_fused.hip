@@ -30,6 +30,7 @@
 // once for both products.
 #include <stdlib.h>
 #include "sc_stage.h"
+#include "sc_fused_common.h"
 
 // Optional phase timers (tools/fused_trace.py builds a copy of the library with -DFU_TRACE): per wave of
 // workgroup 0, shader-clock cycles summed over the chunks for up to 4 phases.
@@ -52,16 +53,6 @@ extern "C" int sc_debug_fused_trace(unsigned long long* out, int reset) {
 #define FU_TICK(slot) do {} while (0)
 #endif
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-#define FU_OC 32            // observation rows per chunk (= K of the bf16 MFMA)
-#define FU_THREADS 768
-#define FU_MAXB 5
-#define FU_FLUSH 16         // chunks between folds of the MFMA accumulators into the output record
 #define FU_PLANE 36         // bf16 per (channel, plane): 32 obs + 4 pad = 72 B
 #define FU_CSTRIDE 220      // bf16 per channel: its 6 planes (432 B) + 8 B pad = 440 B = 110 dwords.  110 = 14
                             // (mod 32): 16 consecutive channels at one obs quad hit 16 distinct even banks, so
@@ -70,64 +61,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
                             // of a channel sit within the 8-bit offsets of ds_read2_b64 -- one address add
                             // per 16-channel fragment set instead of one per plane on this VALU-bound kernel
 
-// Which channels a workgroup stages and where its tiles live in the record.  The 128 staged channel slots are four
-// blocks of 32: local block b holds n32[b] channels (even; every block ahead of the last staged one is full) starting
-// off32[b] elements from st.base, and its two 16-channel tiles are tiles t32[b], t32[b] + 1 of the record (NBr = tile
-// rows of the record).  One contiguous range is every launch up to 128 channels; 129 ... 256 channels are covered by
-// several launches whose staged blocks come from up to two ranges (see launch_fused_all).  Which of the staged blocks'
-// products a launch owns is a staircase of the local upper triangle: tile (r, c), r <= c, is active when c >= col_lo and
-// r < row_hi (in 16-channel tiles; the whole triangle: col_lo = 0, row_hi = NB).
-// The per-block values are packed one byte each (block b in bits 8 b ... 8 b + 7: one bit-field extract for a per-lane
-// b, where an indexed array in the kernel arguments would go through scratch): off32 in units of 32 channels.
-struct FuMap {
-    unsigned off32, n32, t32;
-    int NBr;
-    int col_lo, row_hi;
-};
-__host__ __device__ inline int fu_byte(unsigned packed, int b) { return (int)((packed >> (8 * b)) & 0xffu); }
-__host__ __device__ inline int fu_gt(const FuMap& m, int b) { return fu_byte(m.t32, b >> 1) + (b & 1); }
-__host__ __device__ inline bool fu_tile_ok(const FuMap& m, int b) { return (b & 1) * 16 < fu_byte(m.n32, b >> 1); }
-
-struct FusedArgs {
-    ScStage st;
-    FuMap map;
-    float* accum;
-    int64_t floats_per_bin;
-    int n_bins, F, NB, n_tiles, NB32, n_blocks32, n_sets;
-    int shape_col_lo, shape_row_hi;   // the launch's 32x32 blocks: bi <= bj, bj >= shape_col_lo, bi < shape_row_hi
-    int csm_plane, abs_plane;
-    int sq_plane, sign_plane;   // small-channel kernel only: sum (Im s)^2, sum sign(Im s); -1 = absent
-    int fold[6], n_fold;        // small-channel kernel only: the record planes a launch writes (folded over the parts)
-    int nl_op;           // what the abs waves accumulate from the per-observation d = Im(x_i conj x_j) into record plane
-                         // `abs_plane`: FU_OP_ABS |d| (with the CSM planes, one pass), FU_OP_SQ d^2, FU_OP_SIGN sign(d)
-                         // (plane passes: csm_plane = -1, the four CSM waves only stage)
-    unsigned seg0, seg1, seg2, seg3, seg_n;   // tiles of CSM wave w (fu_assign_rows): segw = row A | first column A << 4 |
-                         // row B << 8 | first column B << 12; byte w of seg_n = count A | count B << 4
-    int n_split;         // workgroups per bin: part k sums the chunks [k NC / n_split, (k+1) NC / n_split)
-    float* ws;           // partial records of parts 1 .. n_split-1: [n_split-1][n_bins][floats_per_bin]
-    int debug_skip;      // profiling aid (env SC_FUSED_DEBUG, bit mask; results are WRONG when set):
-                         // 1 = CSM waves skip their MFMAs, 2 = abs waves skip theirs, 8 = no HBM loads after chunk 0
-};
-
-__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
-    unsigned r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
-}
-__device__ __forceinline__ float bf16lo_to_f32(unsigned p) { return __uint_as_float(p << 16); }
-__device__ __forceinline__ float bf16hi_to_f32(unsigned p) { return __uint_as_float(p & 0xffff0000u); }
-
-// 4 consecutive observations of one real component -> three 8-byte groups (h, m, l) of 4 bf16
-__device__ __forceinline__ void split4(const float x[4], uint2& h, uint2& m, uint2& l) {
-    h.x = cvt_pk_bf16(x[0], x[1]); h.y = cvt_pk_bf16(x[2], x[3]);
-    const float r0 = x[0] - bf16lo_to_f32(h.x), r1 = x[1] - bf16hi_to_f32(h.x);
-    const float r2 = x[2] - bf16lo_to_f32(h.y), r3 = x[3] - bf16hi_to_f32(h.y);
-    m.x = cvt_pk_bf16(r0, r1); m.y = cvt_pk_bf16(r2, r3);
-    const float s0 = r0 - bf16lo_to_f32(m.x), s1 = r1 - bf16hi_to_f32(m.x);
-    const float s2 = r2 - bf16lo_to_f32(m.y), s3 = r3 - bf16hi_to_f32(m.y);
-    l.x = cvt_pk_bf16(s0, s1); l.y = cvt_pk_bf16(s2, s3);
-}
-
 // Staging (done by the CSM waves, see fused_mfma_role).  A staging wave owns eight observation rows of
 // every chunk (two quads vw): it pulls them from HBM straight into an f32 LDS buffer (global_load_lds_dwordx4: lane l of the wave lands at base + 16 l,
 // i.e. one 1 KB row = 64 channel pairs per instruction, no VGPRs held while the loads are in flight),
@@ -135,14 +68,6 @@ __device__ __forceinline__ void split4(const float x[4], uint2& h, uint2& m, uin
 // those raw rows, re-filling them needs no barrier.
 #define FU_NPLANES 6
 #define FU_RAW_ROW 256      // floats per raw row: 64 slots x (Re, Im) x 2 channels
-// Lane id re-materialised on the spot (never CSE'd or hoisted): everything derived from it has a short
-// live range, so the register allocator does not carry -- and spill -- per-lane constants of one phase
-// across the other.  (A spill reload bumps vmcnt and would make the wave sit out the HBM->LDS loads.)
-__device__ __forceinline__ int fu_lane() {
-    int l;
-    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
-    return l;
-}
 __device__ __forceinline__ void fu_fetch(const ScStage& st, const FuMap& mp, float* raw, int o0, int vw) {
     const int lane = fu_lane();
     const int c = 2 * (lane & 15), b32 = lane >> 4;                     // channel pair c of local block b32
@@ -274,7 +199,6 @@ __device__ __forceinline__ bf16x8 fu_ld8(const unsigned short* ptr) {
 #define FU_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 #define FU_MFMA(a, b, c) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
-enum { FU_OP_ABS = 0, FU_OP_SQ = 1, FU_OP_SIGN = 2, FU_OP_UNIT = 3 };     // UNIT: CSM role only, rows normalised at staging
 
 static_assert(2 * 4 + 1 <= FU_FLUSH, "one fold slot per tile of a wave");
 // The two roles are separate functions so their accumulators never coexist in registers.
@@ -424,64 +348,6 @@ __device__ __forceinline__ void fused_mfma_role(const FusedArgs& p, const ScStag
     for (int half = wps >> 1; half >= 1; half >>= 1) { __syncthreads(); __syncthreads(); }
 }
 
-// ---- VALU role ---------------------------------------------------------------------------------
-// Upper-triangular 32x32 blocks, row-major: t -> (BI, BJ).  Tables are compile-time (template on
-// the number of 32-channel blocks and the set) so that operand fragments shared by several blocks
-// of a set (same BI or same BJ) are loaded from LDS once per observation row.
-// A launch's 32x32 blocks: (bi, bj), bi <= bj, bj >= COL_LO, bi < ROW_HI of the NB32 staged blocks, row-major, dealt
-// over one or two sets of at most FU_MAXB (a set = the blocks one abs wave accumulates).
-__host__ __device__ constexpr int fu_nblocks(int nb32, int col_lo, int row_hi) {
-    int n = 0;
-    for (int bi = 0; bi < nb32 && bi < row_hi; ++bi)
-        for (int bj = bi > col_lo ? bi : col_lo; bj < nb32; ++bj) ++n;
-    return n;
-}
-// Up to four blocks: one set, its rows dealt over all eight abs waves; more: two sets of four waves, the first with
-// floor(n / 2) blocks (the sets of the 128-channel triangle, 5 + 5, are what fits the 168-register budget of a
-// 12-wave workgroup: five blocks in ONE set of a three-block launch spilled 28 registers, 5 + 4 in that order 6).
-__host__ __device__ constexpr int fu_nsets(int nb32, int col_lo, int row_hi) {
-    return fu_nblocks(nb32, col_lo, row_hi) > 4 ? 2 : 1;
-}
-__host__ __device__ constexpr int fu_set_first(int nb32, int col_lo, int row_hi, int set) {
-    return set == 0 ? 0 : fu_nblocks(nb32, col_lo, row_hi) / 2;
-}
-__host__ __device__ constexpr int fu_set_count(int nb32, int col_lo, int row_hi, int set) {
-    return fu_nsets(nb32, col_lo, row_hi) == 1 ? fu_nblocks(nb32, col_lo, row_hi)
-         : (set == 0 ? fu_nblocks(nb32, col_lo, row_hi) / 2 : fu_nblocks(nb32, col_lo, row_hi) - fu_nblocks(nb32, col_lo, row_hi) / 2);
-}
-// t-th block of the shape: returns bi * 4 + bj
-__host__ __device__ constexpr int fu_block(int nb32, int col_lo, int row_hi, int t) {
-    for (int bi = 0; bi < nb32 && bi < row_hi; ++bi)
-        for (int bj = bi > col_lo ? bi : col_lo; bj < nb32; ++bj) {
-            if (t == 0) return bi * 4 + bj;
-            --t;
-        }
-    return 0;
-}
-
-template <int NB32, int COL_LO, int ROW_HI, int SET>
-struct FuTab {
-    static constexpr int T0 = fu_set_first(NB32, COL_LO, ROW_HI, SET);
-    static constexpr int NBLK = fu_set_count(NB32, COL_LO, ROW_HI, SET);   // blocks of this set
-    static_assert(NBLK <= FU_MAXB, "a set holds at most FU_MAXB blocks");
-    struct Arr { int bi[FU_MAXB]; int bj[FU_MAXB]; bool use_i[4]; bool use_j[4]; };
-    static constexpr Arr make() {
-        Arr a{};
-        for (int s = 0; s < FU_MAXB; ++s) { a.bi[s] = 0; a.bj[s] = 0; }
-        for (int b = 0; b < 4; ++b) { a.use_i[b] = false; a.use_j[b] = false; }
-        for (int s = 0; s < NBLK; ++s) {
-            const int blk = fu_block(NB32, COL_LO, ROW_HI, T0 + s);
-            a.bi[s] = blk / 4;
-            a.bj[s] = blk % 4;
-            a.use_i[a.bi[s]] = true;
-            a.use_j[a.bj[s]] = true;
-        }
-        return a;
-    }
-    static constexpr Arr tab = make();
-};
-
-
 // "abs" role: per observation row and 32x32 channel block ONE v_mfma_f32_32x32x16_bf16 with C = 0
 // yields d = Im(x_i conj x_j) for the 1024 pairs of the block (K = 16 slots: lanes 0-31 carry the
 // six cross terms of Im(x_i) Re(x_j), lanes 32-63 those of Re(x_i) (-Im(x_j))), then acc += |d|.
@@ -508,55 +374,6 @@ __device__ __forceinline__ FuFragB fu_frag_b(unsigned h, unsigned m, unsigned l)
     f.d0 = perm_b32(m, h, SEL);       // (h, m)
     f.d1 = perm_b32(l, h, SEL);       // (h, l)
     return f;
-}
-
-// acc <- acc (+) f(d) for one output register of a 32x32 block: |d| (wPLI weights), d^2 (debiased wPLI), sign(d) (PLI)
-template <int OP>
-__device__ __forceinline__ float fu_accumulate(float acc, float d) {
-    if constexpr (OP == FU_OP_ABS || OP == FU_OP_UNIT) return acc + fabsf(d);
-    else if constexpr (OP == FU_OP_SQ) return fmaf(d, d, acc);
-    else {
-        // sign(d) in {-1, 0, 1} summed as an INTEGER in the accumulator's bits: the bit pattern of a float orders like a
-        // signed integer with +0 = 0, so clamping it to [-1, 1] is the sign (one v_med3_i32 + one v_add_u32 per value; the
-        // MFMA's C input is +0, so an exact zero comes out as +0).  Converted to float once, after the last chunk.
-        const int b = __float_as_int(d);
-        const int sg = b < -1 ? -1 : (b > 1 ? 1 : b);
-        const int a = __float_as_int(acc) + sg;
-        return __int_as_float(a);
-    }
-}
-// The sixteen results of one 32x32 block.  sign(d): written out by the compiler, the sixteen clamps are scheduled ahead of
-// their adds and the 168-register budget of a 12-wave workgroup spills, so fifteen of them are two-instruction asm blocks
-// with one temporary each.  But the wait states between an MFMA write and a VALU read are the COMPILER's job, and it
-// pads only in front of instructions it can see (an asm block straight after a lone MFMA read stale registers: wrong sign
-// sums at <= 32 channels): element 0 goes first as ordinary code -- the compiler waits for the MFMA there -- and a
-// scheduling barrier keeps the asm blocks behind it.
-template <int OP, bool PACKED = false>
-__device__ __forceinline__ void fu_accumulate16(f32x16& acc, const f32x16& d) {
-    if constexpr (OP == FU_OP_SQ && PACKED) {
-        // two squares per instruction (v_pk_fma_f32 on the register pairs of the MFMA result): 8 issue slots per block and
-        // row instead of 16 -- |d| and sign(d) have no packed form (VOP3P carries no abs modifier).  Sets of up to four
-        // blocks only: with five, the aligned pairs do not fit the register budget (9 spilled pairs per row, 3.7 -> 9 ms)
-#pragma unroll
-        for (int e = 0; e < 16; e += 2) {
-            f32x2 a = {acc[e], acc[e + 1]};
-            const f32x2 v = {d[e], d[e + 1]};
-            a = __builtin_elementwise_fma(v, v, a);
-            acc[e] = a[0]; acc[e + 1] = a[1];
-        }
-    } else if constexpr (OP != FU_OP_SIGN) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = fu_accumulate<OP>(acc[e], d[e]);
-    } else {
-        acc[0] = fu_accumulate<OP>(acc[0], d[0]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int e = 1; e < 16; ++e) {
-            int a = __float_as_int(acc[e]), t;
-            asm("v_med3_i32 %1, %2, -1, 1\n\tv_add_u32 %0, %0, %1" : "+v"(a), "=&v"(t) : "v"(d[e]));
-            acc[e] = __int_as_float(a);
-        }
-    }
 }
 
 template <int NB32, int COL_LO, int ROW_HI, int SET, int OP>
@@ -777,7 +594,7 @@ __global__ void __launch_bounds__(256) planes_combine_kernel(FusedArgs p) {
     }
 }
 
-static int launch_fused_combine(const FusedArgs& a, int op, hipStream_t stream) {
+int sc_internal_fused_combine(const FusedArgs& a, int op, hipStream_t stream) {
     if (a.n_split > 1) {
         if (op == FU_OP_ABS || op == FU_OP_UNIT) hipLaunchKernelGGL(fused_combine_kernel, dim3(2048), dim3(256), 0, stream, a);
         else hipLaunchKernelGGL(planes_combine_kernel, dim3(2048), dim3(256), 0, stream, a);     // one plane: a.fold
@@ -796,7 +613,7 @@ static int launch_fused_op(const FusedArgs& a, bool combine, hipStream_t stream)
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     hipLaunchKernelGGL(k, dim3((unsigned)(a.n_bins * a.n_split)), dim3(FU_THREADS), shmem, stream, a);
     SC_CHECK_HIP(hipGetLastError());
-    return combine ? launch_fused_combine(a, OP, stream) : SC_OK;
+    return combine ? sc_internal_fused_combine(a, OP, stream) : SC_OK;
 }
 
 // One pass of the matrix-core kernel: op = FU_OP_ABS is the headline launch (CSM planes, and |Im s| if a.abs_plane >= 0);
@@ -1044,7 +861,7 @@ extern "C" int sc_fused_supported(int64_t n_signals) {
 // rounds and the last round may be nearly empty (903 bins on 256 CUs: 4 rounds for 3.53 rounds of
 // work).  Splitting every bin's observations over S workgroups shortens the rounds; pick the S
 // with the fewest (rounds / S), keeping >= 16 chunks per part (S <= 24: few bins with many observations).
-static int fused_pick_split(int n_bins, int n_obs) {
+int sc_internal_fused_pick_split(int n_bins, int n_obs) {
     const char* e = getenv("SC_FUSED_SPLIT");
     const int nc = (n_obs + FU_OC - 1) / FU_OC;
     static int cu_of_device[64] = {0};          // compute units per device, queried once
@@ -1071,7 +888,7 @@ static int fused_pick_split(int n_bins, int n_obs) {
 // The CSM waves' share of a launch: R = the tile rows that have tiles, row r with the columns max(r, col_lo) ... NB-1.
 // Five or more rows: wave w takes rows w and R-1-w (long with short: the triangle's 9 tiles per wave at 128 channels);
 // three or four: one row per wave; two rows: two waves per row, half the columns each; one row: a quarter each.
-static void fu_assign_rows(FusedArgs* a) {
+void sc_internal_fu_assign_rows(FusedArgs* a) {
     const int NB = a->NB, col_lo = a->map.col_lo;
     const int R = a->map.row_hi < NB ? a->map.row_hi : NB;
     auto c0 = [&](int r) { return r > col_lo ? r : col_lo; };
@@ -1124,7 +941,7 @@ static FusedArgs fu_args_blocks(const FusedArgs& full, const int* blocks, int nb
     a.map.NBr = sc_n_blocks(C);
     a.map.col_lo = 2 * col_lo;
     a.map.row_hi = 2 * row_hi;
-    fu_assign_rows(&a);
+    sc_internal_fu_assign_rows(&a);
     return a;
 }
 static int launch_fused(const FusedArgs& a, int op, hipStream_t stream, bool combine);
@@ -1152,7 +969,7 @@ static int launch_fused_all(const FusedArgs& full, int op, hipStream_t s) {
     int rc = SC_OK;
     for (int l = 0; l < n_launch && rc == SC_OK; ++l)
         rc = launch_fused(fu_args_blocks(full, plan[l].blocks, plan[l].nb, plan[l].col_lo, plan[l].row_hi), op, s, false);
-    if (rc == SC_OK) rc = launch_fused_combine(full, op, s);
+    if (rc == SC_OK) rc = sc_internal_fused_combine(full, op, s);
     return rc;
 }
 
@@ -1202,7 +1019,7 @@ extern "C" int64_t sc_fused_workspace_bytes(const sc_spectra_desc* desc, uint32_
     ScAxes ax;
     const int mode = (planes & SC_PLANE_CSM) ? FU_MODE_CSM : (planes & SC_PLANE_UNIT) ? FU_MODE_UNIT : FU_MODE_SIGN;
     if (fused_setup(nullptr, desc, planes, mode, &a, &ax) != SC_OK) return 0;
-    const int S = fused_pick_split(a.n_bins, ax.n_obs);
+    const int S = sc_internal_fused_pick_split(a.n_bins, ax.n_obs);
     return (int64_t)(S - 1) * a.n_bins * a.floats_per_bin * (int64_t)sizeof(float);
 }
 
@@ -1228,7 +1045,7 @@ static int fused_run(const void* d_X, const sc_spectra_desc* desc, uint32_t plan
         a.debug_skip = dbg ? atoi(dbg) : 0;
     }
     // as many parts per bin as the workspace allows (none: one workgroup per bin)
-    int S = fused_pick_split(a.n_bins, ax.n_obs);
+    int S = sc_internal_fused_pick_split(a.n_bins, ax.n_obs);
     const int64_t part_bytes = (int64_t)a.n_bins * a.floats_per_bin * (int64_t)sizeof(float);
     if (!d_workspace) S = 1;
     while (S > 1 && (int64_t)(S - 1) * part_bytes > workspace_bytes) --S;
