@@ -61,7 +61,7 @@
 extern "C" {
 #endif
 
-#define SC_ABI_VERSION 3
+#define SC_ABI_VERSION 4
 
 /* error codes */
 #define SC_OK 0
@@ -262,6 +262,26 @@ int64_t sc_fused_unit_scratch_bytes(const sc_spectra_desc* desc);
 int sc_fused_unit_ws_f32(const void* d_X /*float2*/, const sc_spectra_desc* desc, uint32_t planes,
                          float* d_accum, void* d_workspace, int64_t workspace_bytes, void* d_scratch,
                          int64_t scratch_bytes, void* stream);
+
+/* ---- planes format (ABI v4): every f32 coefficient stored as three bf16 pieces h + m + l = x (exact) ------------------
+ * The one-pass stage-B kernels multiply on the bf16 matrix pipe and split every coefficient while they stage it; stage A
+ * can store the pieces instead (sc_multitaper_fft_planes_f32), which turns stage B's staging into plain HBM -> LDS loads.
+ * Layout: dense rows [F][W][R][K] (bin, window, trial, taper), sc_planes_row_bytes(C) = 384 * ceil(C / 32) bytes each:
+ * [channel tile of 32][plane Re h, Re m, Re l, Im h, Im m, Im l][32 channels] bf16, absent channels zero.  Same
+ * coefficients as the complex64 spectra of _multitaper_fft (transforms.py:1377-1405); the conversions are lossless. */
+int64_t sc_planes_row_bytes(int64_t n_signals);
+/* complex64 spectra described by desc (strides in elements) <-> planes buffer (dense rows, desc's sizes) */
+int sc_planes_from_spectra_f32(const void* d_X /*float2*/, const sc_spectra_desc* desc, void* d_P, void* stream);
+int sc_spectra_from_planes_f32(const void* d_P, const sc_spectra_desc* desc, void* d_X /*float2*/, void* stream);
+/* Stage B on the planes format: the CSM planes and the |Im s| plane of every bin record in one pass, exactly what
+ * sc_fused_csm_absim_ws_f32 writes (replaces _expectation_cross_spectral_matrix with fcn = identity and abs(Im),
+ * connectivity.py:463-526, :982-1028).  desc: sizes and reduce flags (strides ignored: the rows are dense).  Takes
+ * planes == SC_PLANE_CSM | SC_PLANE_ABS_IM, up to 128 signals and bins of at least 512 observations (the |Im s| products
+ * use two of the three pieces: relative error of the sum ~1.5e-5 / sqrt(n_observations)); sc_fused2_supported tells.
+ * Workspace as for sc_fused_csm_absim_ws_f32 (sc_fused_workspace_bytes with the same desc). */
+int sc_fused2_supported(const sc_spectra_desc* desc, uint32_t planes);
+int sc_fused2_csm_absim_f32(const void* d_P, const sc_spectra_desc* desc, uint32_t planes, float* d_accum,
+                            void* d_workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- stage C: measures epilogue ------------------------------------------------------
  * Elementwise measure algebra on accumulated sums (connectivity.py:612-1159): divides by

@@ -21,7 +21,7 @@ from . import _build
 c_int64_p = POINTER(c_int64)
 
 # ---- constants mirrored from include/sc_hip.h -------------------------------------------
-SC_ABI_VERSION = 3
+SC_ABI_VERSION = 4
 GRANGER_KEEP_OUTPUT = 1
 DETREND = {None: 0, "constant": 1, "c": 1, "linear": 2, "l": 2}
 MVAR_DTF, MVAR_DC, MVAR_PDC, MVAR_GPDC, MVAR_DDTF, MVAR_TRANSFER, MVAR_COEFFICIENTS, MVAR_NOISE_COVARIANCE = range(8)
@@ -97,6 +97,11 @@ SYMBOLS = {
     "sc_fused_unit_scratch_bytes": (c_int64, [POINTER(SpectraDesc)]),
     "sc_fused_unit_ws_f32": (c_int, [c_void_p, POINTER(SpectraDesc), c_uint32, c_void_p, c_void_p, c_int64, c_void_p,
                                      c_int64, c_void_p]),
+    "sc_planes_row_bytes": (c_int64, [c_int64]),
+    "sc_planes_from_spectra_f32": (c_int, [c_void_p, POINTER(SpectraDesc), c_void_p, c_void_p]),
+    "sc_spectra_from_planes_f32": (c_int, [c_void_p, POINTER(SpectraDesc), c_void_p, c_void_p]),
+    "sc_fused2_supported": (c_int, [POINTER(SpectraDesc), c_uint32]),
+    "sc_fused2_csm_absim_f32": (c_int, [c_void_p, POINTER(SpectraDesc), c_uint32, c_void_p, c_void_p, c_int64, c_void_p]),
     "sc_granger_workspace_bytes": (c_int, [c_int64, c_int64, c_int64, POINTER(c_size_t)]),
     "sc_granger_pairwise_f64": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_uint32, c_int64,
                                         c_void_p, c_int64, c_double, c_int, c_void_p, c_size_t, c_int, c_void_p,

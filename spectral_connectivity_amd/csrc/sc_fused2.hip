@@ -1,0 +1,568 @@
+// sc_fused2.hip -- stage B on spectra that arrive as bf16 pieces ("planes format"), round 4.
+//
+// The one-pass kernel of sc_fused.hip spends a third of its vector-issue slots on work that is not the product: splitting
+// every f32 coefficient into three bf16 pieces while staging (208 of 2185 VALU instructions per SIMD and 32-row chunk),
+// re-assembling the operands of the per-observation |Im s| products with byte permutes (456; v_perm_b32 costs 4.3 cycles
+// against 2.1-2.6 for an add: profiles/r04_issue_rates.txt) and flipping signs (~100).  Here none of that is left:
+//   * the split is exact (x = h + m + l, three bf16 values), so stage A can store the pieces instead of the f32 value
+//     (sc_multitaper_fft_planes_f32: 12 bytes per coefficient instead of 8) and nothing is lost;
+//   * an observation row is [channel tile of 32][plane Re h, Re m, Re l, Im h, Im m, Im l][32 channels] bf16, and lands in
+//     LDS observation-major and plane-major by direct HBM -> LDS loads (global_load_lds_dwordx4, no VGPRs, no VALU);
+//   * BOTH roles read their matrix-core operands out of that one layout with the transposing LDS load
+//     ds_read_b64_tr_b16 (lane 4 r + q of a 16-lane group supplies row r, 8-byte chunk q; lane j receives column j of the
+//     four rows: profiles/r04_tr_load.txt): the CSM waves take rows = observations (K = 32 observations of one plane,
+//     v_mfma_f32_16x16x32_bf16), the |Im s| waves rows = PLANES of one observation (K = the cross terms of one
+//     observation, v_mfma_f32_32x32x8_bf16_1k) -- which plane sits in which K slot is just the address a lane passes;
+//   * the negated real part both roles need (Im s = Im x_i Re x_j - Re x_i Im x_j) is a fourth plane group in LDS, made by
+//     the wave that loaded the real planes (one xor per 8 coefficients and chunk).
+// LDS layout of a chunk of 32 observations (bytes):   addr(p, o, c) = p * 8512 + (o & 7) * 1056 + (o >> 3) * 256 + 2 c
+//   p = plane 0 .. 8 (Re h m l, Im h m l, -Re h m l), o = observation of the chunk, c = staged channel 0 .. 127
+// A direct load instruction fills one 1024-byte group (plane p, observations o7, o7 + 8, o7 + 16, o7 + 24); the 32 bytes of
+// padding behind every group and the 64 behind every plane shift the banks so that every transposing load of either role
+// is conflict-free (3.0 cycles per instruction measured, against 8-16 for unpadded rows) while every address stays an
+// affine function of (plane, observation, channel block): ONE address register per role and buffer, everything else
+// immediate offsets.
+// The |Im s| products use the two leading pieces only (h, m: four cross terms, error <= 2^-16 |x_i| |x_j| per
+// observation with random sign): the sum of |Im s| over n observations is off by ~1.5e-5 / sqrt(n) relative, so the entry
+// point takes bins with at least SC_FUSED2_MIN_OBS observations (512: 7e-7) and leaves the others to sc_fused.hip.  The
+// cross-spectral matrix itself keeps the six-term, f32-accurate product.
+#include <stdlib.h>
+#include "sc_fused_common.h"
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+#define F2_GROUP 1056                 // 4 observation rows of 256 B + 32 B
+#define F2_PLANE (8 * F2_GROUP + 64)  // 8512
+#define F2_NPL 9                      // Re h m l, Im h m l, -Re h m l
+#define F2_BUF (F2_NPL * F2_PLANE)    // 76608 B per chunk buffer
+#define F2_LDS (2 * F2_BUF)           // 153216 B
+#define F2_ROW_TILE 384               // bytes of one 32-channel tile of an observation row in HBM (6 planes x 64 B)
+#define F2_MIN_OBS 512
+
+extern "C" int64_t sc_planes_row_bytes(int64_t n_signals) { return (int64_t)F2_ROW_TILE * ((n_signals + 31) / 32); }
+
+// ---- conversions between complex64 spectra and the planes format (uploaded coefficients, consumers of complex64) -------
+struct PlanesConvArgs {
+    const float2* X;
+    unsigned char* P;
+    int64_t sF, sW, sR, sK;
+    int F, W, R, K, C, nct;
+    int64_t n_rows;
+};
+// one thread per channel pair of a row
+__global__ void __launch_bounds__(256) planes_from_spectra_kernel(PlanesConvArgs a) {
+    const int pairs_per_row = a.nct * 16;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n_rows * pairs_per_row) return;
+    const int64_t row = i / pairs_per_row;
+    const int pr = (int)(i - row * pairs_per_row), c = 2 * pr;
+    int64_t t = row;
+    const int k = (int)(t % a.K); t /= a.K;
+    const int r = (int)(t % a.R); t /= a.R;
+    const int w = (int)(t % a.W); t /= a.W;
+    const int f = (int)t;
+    const float2* src = a.X + (int64_t)f * a.sF + (int64_t)w * a.sW + (int64_t)r * a.sR + (int64_t)k * a.sK + c;
+    float2 v0 = make_float2(0.f, 0.f), v1 = v0;
+    if (c < a.C) v0 = src[0];
+    if (c + 1 < a.C) v1 = src[1];
+    unsigned* dst = reinterpret_cast<unsigned*>(a.P + row * (int64_t)a.nct * F2_ROW_TILE + (pr >> 4) * F2_ROW_TILE) + (pr & 15);
+    const unsigned rh = cvt_pk_bf16(v0.x, v1.x), ih = cvt_pk_bf16(v0.y, v1.y);
+    const float r0 = v0.x - bf16lo_to_f32(rh), r1 = v1.x - bf16hi_to_f32(rh);
+    const float i0 = v0.y - bf16lo_to_f32(ih), i1 = v1.y - bf16hi_to_f32(ih);
+    const unsigned rm = cvt_pk_bf16(r0, r1), im = cvt_pk_bf16(i0, i1);
+    const unsigned rl = cvt_pk_bf16(r0 - bf16lo_to_f32(rm), r1 - bf16hi_to_f32(rm));
+    const unsigned il = cvt_pk_bf16(i0 - bf16lo_to_f32(im), i1 - bf16hi_to_f32(im));
+    dst[0] = rh; dst[16] = rm; dst[32] = rl; dst[48] = ih; dst[64] = im; dst[80] = il;
+}
+__global__ void __launch_bounds__(256) spectra_from_planes_kernel(PlanesConvArgs a) {
+    const int pairs_per_row = a.nct * 16;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n_rows * pairs_per_row) return;
+    const int64_t row = i / pairs_per_row;
+    const int pr = (int)(i - row * pairs_per_row), c = 2 * pr;
+    if (c >= a.C) return;
+    int64_t t = row;
+    const int k = (int)(t % a.K); t /= a.K;
+    const int r = (int)(t % a.R); t /= a.R;
+    const int w = (int)(t % a.W); t /= a.W;
+    const int f = (int)t;
+    const unsigned* src = reinterpret_cast<const unsigned*>(a.P + row * (int64_t)a.nct * F2_ROW_TILE + (pr >> 4) * F2_ROW_TILE) + (pr & 15);
+    const unsigned rh = src[0], rm = src[16], rl = src[32], ih = src[48], im = src[64], il = src[80];
+    // h + m is exact in f32 (16 significant bits), and so is (h + m) + l = x
+    const float2 v0 = make_float2((bf16lo_to_f32(rh) + bf16lo_to_f32(rm)) + bf16lo_to_f32(rl),
+                                  (bf16lo_to_f32(ih) + bf16lo_to_f32(im)) + bf16lo_to_f32(il));
+    const float2 v1 = make_float2((bf16hi_to_f32(rh) + bf16hi_to_f32(rm)) + bf16hi_to_f32(rl),
+                                  (bf16hi_to_f32(ih) + bf16hi_to_f32(im)) + bf16hi_to_f32(il));
+    float2* dst = const_cast<float2*>(a.X) + (int64_t)f * a.sF + (int64_t)w * a.sW + (int64_t)r * a.sR + (int64_t)k * a.sK + c;
+    dst[0] = v0;
+    if (c + 1 < a.C) dst[1] = v1;
+}
+static int planes_conv(const void* d_X, const sc_spectra_desc* d, void* d_P, bool to_planes, void* stream) {
+    SC_REQUIRE(d_X && d && d_P, "NULL argument");
+    SC_REQUIRE(d->n_freq >= 1 && d->n_windows >= 1 && d->n_trials >= 1 && d->n_tapers >= 1 && d->n_signals >= 1, "empty dimension");
+    PlanesConvArgs a;
+    a.X = (const float2*)d_X; a.P = (unsigned char*)d_P;
+    a.sF = d->stride_freq; a.sW = d->stride_window; a.sR = d->stride_trial; a.sK = d->stride_taper;
+    a.F = (int)d->n_freq; a.W = (int)d->n_windows; a.R = (int)d->n_trials; a.K = (int)d->n_tapers; a.C = (int)d->n_signals;
+    a.nct = (a.C + 31) / 32;
+    a.n_rows = (int64_t)a.F * a.W * a.R * a.K;
+    const int64_t items = a.n_rows * a.nct * 16;
+    const unsigned blocks = (unsigned)((items + 255) / 256);
+    if (to_planes) hipLaunchKernelGGL(planes_from_spectra_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(spectra_from_planes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    SC_CHECK_HIP(hipGetLastError());
+    return SC_OK;
+}
+extern "C" int sc_planes_from_spectra_f32(const void* d_X, const sc_spectra_desc* desc, void* d_P, void* stream) {
+    ScTimed timed_("planes_from_spectra", stream);
+    return planes_conv(d_X, desc, d_P, true, stream);
+}
+extern "C" int sc_spectra_from_planes_f32(const void* d_P, const sc_spectra_desc* desc, void* d_X, void* stream) {
+    ScTimed timed_("spectra_from_planes", stream);
+    return planes_conv(d_X, desc, const_cast<void*>(d_P), false, stream);
+}
+
+// ---- the kernel ------------------------------------------------------------------------------------------------------------
+struct Fused2Args {
+    FusedArgs f;                  // record, map, tiles of the CSM waves, split; f.st.n_obs / f.st.ax as in sc_fused.hip (strides in ROWS)
+    const unsigned char* P;       // planes-format spectra, dense rows [F][W][R][K]
+    int64_t row_bytes;            // bytes per observation row (384 per 32-channel tile)
+    int64_t obs_rows;             // rows between consecutive observations of a bin (linear: checked on the host)
+};
+
+__device__ __forceinline__ s16x4 f2_tr(lds_u8* base, int off) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + off));
+}
+// operand fragment of v_mfma_f32_16x16x32_bf16 (8 K slots per lane): plane p, 16-channel tile s, observations
+// 8 (2 (g >> 1) + t) + 4 (g & 1) + r  for the two loads t = 0, 1 (g = lane >> 4, r = (lane >> 2) & 3, baked into `base`)
+__device__ __forceinline__ bf16x8 f2_frag(lds_u8* base, int p, int s) {
+    const s16x4 a = f2_tr(base, p * F2_PLANE + s * 32), b = f2_tr(base, p * F2_PLANE + s * 32 + 256);
+    const bf16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return v;
+}
+
+#define F2_MFMA(a, b, c) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+// Every wave has waited for its own HBM -> LDS loads (vmcnt) before it gets here; the barrier itself publishes LDS writes
+// only (a __syncthreads() would also wait for the fold atomics the CSM waves have just sent to L2: ~1 us per chunk).
+#define F2_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// Loads of one chunk: wave w (0 .. 11) fills plane w % 6 of the observation groups o7 = 4 (w / 6) .. + 3.  Lane l of an
+// instruction carries observation o7 + 8 (l >> 4), 16-byte piece l & 15 of the 256-byte row (channel tile (l & 15) >> 2).
+struct F2Loader {
+    const unsigned char* src;     // first row of this (bin, part), + the plane offset of this wave (wave-uniform)
+    unsigned voff;                // per-lane byte offset inside a chunk (the only per-lane state kept across the chunk loop)
+    int lds_off;                  // LDS offset of this wave's first group (plane, o7) inside a buffer (wave-uniform)
+    int o7_0, plane;              // wave-uniform
+};
+__device__ __forceinline__ F2Loader f2_loader(const Fused2Args& a, int wave, const unsigned char* part_base) {
+    F2Loader L;
+    const int lane = fu_lane();
+    const int piece = lane & 15, ct = piece >> 2;
+    L.plane = wave % 6;
+    L.o7_0 = 4 * (wave / 6);
+    L.voff = (unsigned)(8 * (lane >> 4) * a.obs_rows * a.row_bytes + fu_byte(a.f.map.off32, ct) * F2_ROW_TILE + (piece & 3) * 16);
+    L.src = part_base + L.plane * 64;
+    L.lds_off = L.plane * F2_PLANE + L.o7_0 * F2_GROUP;
+    return L;
+}
+// o0 = first observation of the chunk (relative to the part's first), n_left = observations left in the part from o0
+__device__ __forceinline__ void f2_issue(const Fused2Args& a, const F2Loader& L, lds_u8* buf, int o0, int n_left) {
+    const int lane = fu_lane();                                   // (re-materialised: short live ranges, see fu_lane)
+    const int ct = (lane & 15) >> 2;
+    const bool lane_ok = ct < a.f.NB32 && fu_byte(a.f.map.n32, ct) > 0;      // this lane's channel tile is staged
+    const int o_first = L.o7_0 + 8 * (lane >> 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        lds_u8* dst = buf + L.lds_off + i * F2_GROUP;             // wave-uniform
+        const unsigned char* src = L.src + (int64_t)(o0 + L.o7_0 + i) * a.obs_rows * a.row_bytes;   // wave-uniform
+        // Spelled in asm: behind the builtin the compiler's wait-count pass puts s_waitcnt vmcnt(0) in front of the next LDS
+        // read of ANY address (it cannot tell the other buffer from this one), i.e. the wave would sit out the loads it has
+        // just issued -- measured: load time and product time simply added up (2.15 + 1.3 + 1.6 ms).  The waves wait for
+        // their own loads explicitly (vmcnt) before f2_finish and the barrier that publishes the buffer.
+        if (lane_ok && o_first + i < n_left)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                         :: "s"((unsigned)reinterpret_cast<uintptr_t>(dst)), "v"(L.voff), "s"(src) : "memory", "m0");
+    }
+}
+// After the wave's loads have landed (vmcnt): rows past the end of the part become zeros, and the waves that loaded
+// real-part planes write the negated copies (planes 6 .. 8) -- one xor per 8 coefficients.
+__device__ __forceinline__ void f2_finish(const F2Loader& L, lds_u8* buf, int n_left) {
+    const int lane = fu_lane();
+    if (n_left < FU_OC) {                                          // wave-uniform: the last chunk of a part only
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int o = L.o7_0 + i + 8 * (lane >> 4);
+            if (o >= n_left)
+                *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(buf + L.lds_off + i * F2_GROUP + 16 * lane) = (u32x4){0u, 0u, 0u, 0u};
+        }
+    }
+    if (L.plane < 3) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            lds_u8* g = buf + L.lds_off + i * F2_GROUP + 16 * lane;
+            u32x4 v = *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(g);
+            v[0] ^= 0x80008000u; v[1] ^= 0x80008000u; v[2] ^= 0x80008000u; v[3] ^= 0x80008000u;
+            *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(g + 6 * F2_PLANE) = v;
+        }
+    }
+}
+
+static_assert(2 * 4 + 1 <= FU_FLUSH, "one fold slot per tile of a wave");
+// Matrix-core role: wave w owns the tiles fu_assign_rows gave it (tile rows w and R - 1 - w of the triangle).  Per tile and
+// chunk 24 v_mfma_f32_16x16x32_bf16: six leading cross terms x {Re Re, Im Im, Im Re, (-Re) Im}; every operand fragment is two
+// transposing LDS loads, no VALU.
+template <int NB32>
+__device__ __forceinline__ void f2_mfma_role(const Fused2Args& a, lds_u8* lds, const F2Loader& L, int wave, float* rec, int n_part) {
+    const FusedArgs& p = a.f;
+    constexpr int MAXS = 2 * NB32 + 1;
+    const unsigned sg = (unsigned)__builtin_amdgcn_readfirstlane((int)(wave == 0 ? p.seg0 : (wave == 1 ? p.seg1 : (wave == 2 ? p.seg2 : p.seg3))));
+    const unsigned sg_n = (unsigned)__builtin_amdgcn_readfirstlane((int)((p.seg_n >> (8 * wave)) & 0xffu));
+    const int rA_ = sg & 0xf, cA_ = (sg >> 4) & 0xf, rB_ = (sg >> 8) & 0xf, cB_ = (sg >> 12) & 0xf;
+    const int nA_ = sg_n & 0xf, nB_ = sg_n >> 4;
+    const int total = nA_ + nB_;
+    f32x4 re[MAXS], im[MAXS];
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s) { re[s] = (f32x4){0.f, 0.f, 0.f, 0.f}; im[s] = re[s]; }
+    const int n_chunks = (n_part + FU_OC - 1) / FU_OC;
+    float* out = rec + (int64_t)p.csm_plane * p.n_tiles * SC_TILE_ELEMS;
+    const bool do_csm = p.csm_plane >= 0 && (p.debug_skip & 1) == 0;
+    const bool loads = !(p.debug_skip & 8);
+    for (int ch = 0; ch < n_chunks; ++ch) {
+        lds_u8* cur = lds + (loads ? (ch & 1) : 0) * F2_BUF;
+        lds_u8* nxt = lds + ((ch + 1) & 1) * F2_BUF;
+        const bool more = ch + 1 < n_chunks && loads;
+        if (more) f2_issue(a, L, nxt, (ch + 1) * FU_OC, n_part - (ch + 1) * FU_OC);
+        if (do_csm && total > 0) {
+            int rA = rA_, rB = rB_, nA = nA_, cA = cA_, cB = cB_;
+            asm volatile("" : "+s"(rA), "+s"(rB), "+s"(nA), "+s"(cA), "+s"(cB));
+            const int lane = fu_lane(), g = lane >> 4;
+            lds_u8* b0 = cur + ((4 * (g & 1) + ((lane >> 2) & 3)) * F2_GROUP + 2 * (g >> 1) * 256 + (lane & 3) * 8);   // planes 0 .. 5
+            lds_u8* b6 = b0 + 6 * F2_PLANE;                                                                            // planes 6 .. 8
+            bf16x8 arh, arm, arl, aih, aim, ail, nrh, nrm, nrl;
+#pragma unroll
+            for (int s = 0; s < MAXS; ++s) {
+                if (s < total) {
+                    const bool in_a = s < nA;
+                    const int row = in_a ? rA : rB;
+                    const int col = in_a ? cA + s : cB + (s - nA);
+                    if (s == 0 || s == nA) {
+                        lds_u8* fa = b0 + row * 32;
+                        lds_u8* fn = b6 + row * 32;
+                        arh = f2_frag(fa, 0, 0); arm = f2_frag(fa, 1, 0); arl = f2_frag(fa, 2, 0);
+                        aih = f2_frag(fa, 3, 0); aim = f2_frag(fa, 4, 0); ail = f2_frag(fa, 5, 0);
+                        nrh = f2_frag(fn, 0, 0); nrm = f2_frag(fn, 1, 0); nrl = f2_frag(fn, 2, 0);
+                    }
+                    lds_u8* fb = b0 + col * 32;
+                    const bf16x8 cbrh = f2_frag(fb, 0, 0), cbih = f2_frag(fb, 3, 0), cbrm = f2_frag(fb, 1, 0), cbim = f2_frag(fb, 4, 0);
+                    const bf16x8 cbrl = f2_frag(fb, 2, 0), cbil = f2_frag(fb, 5, 0);
+                    // six leading terms of (h+m+l)(h+m+l): hh hm mh mm hl lh;  Re += ar*br + ai*bi ; Im += ai*br + (-ar)*bi
+                    F2_MFMA(arh, cbrh, re[s]);  F2_MFMA(aih, cbrh, im[s]);
+                    F2_MFMA(aih, cbih, re[s]);  F2_MFMA(nrh, cbih, im[s]);
+                    F2_MFMA(arh, cbrm, re[s]);  F2_MFMA(aih, cbrm, im[s]);
+                    F2_MFMA(aih, cbim, re[s]);  F2_MFMA(nrh, cbim, im[s]);
+                    F2_MFMA(arm, cbrh, re[s]);  F2_MFMA(aim, cbrh, im[s]);
+                    F2_MFMA(aim, cbih, re[s]);  F2_MFMA(nrm, cbih, im[s]);
+                    F2_MFMA(arm, cbrm, re[s]);  F2_MFMA(aim, cbrm, im[s]);
+                    F2_MFMA(aim, cbim, re[s]);  F2_MFMA(nrm, cbim, im[s]);
+                    F2_MFMA(arh, cbrl, re[s]);  F2_MFMA(aih, cbrl, im[s]);
+                    F2_MFMA(aih, cbil, re[s]);  F2_MFMA(nrh, cbil, im[s]);
+                    F2_MFMA(arl, cbrh, re[s]);  F2_MFMA(ail, cbrh, im[s]);
+                    F2_MFMA(ail, cbih, re[s]);  F2_MFMA(nrl, cbih, im[s]);
+                }
+            }
+        }
+        if (more) {       // (ahead of the fold: its atomics then travel under the next chunk)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            f2_finish(L, nxt, n_part - (ch + 1) * FU_OC);
+        }
+        // two-level summation exactly as in sc_fused.hip: a tile's accumulators are folded into the record every FU_FLUSH
+        // chunks (512 observations), the tiles taking turns
+        {
+            const bool last = ch + 1 == n_chunks;
+#pragma unroll
+            for (int s = 0; s < MAXS; ++s) {
+                const int f_s = FU_FLUSH - 1 - s;
+                const bool due = ((ch + 1 + s) % FU_FLUSH) == 0 && !(p.debug_skip & 64);
+                if (s < total && (due || last) && p.csm_plane >= 0) {
+                    const bool first = ch <= f_s || (p.debug_skip & 64);
+                    const bool in_a = s < nA_;
+                    const int row = in_a ? rA_ : rB_;
+                    const int col = in_a ? cA_ + s : cB_ + (s - nA_);
+                    float* o_re = out + (int64_t)sc_tile_index(fu_gt(p.map, row), fu_gt(p.map, col), p.map.NBr) * SC_TILE_ELEMS;
+                    float* o_im = o_re + (int64_t)p.n_tiles * SC_TILE_ELEMS;
+                    const unsigned fl = (unsigned)fu_lane();
+                    const unsigned base_idx = (fl >> 4) * 64u + (fl & 15u);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const unsigned idx = base_idx + 16u * r;
+                        if (first) {
+                            o_re[idx] = re[s][r];
+                            o_im[idx] = im[s][r];
+                        } else {
+                            unsafeAtomicAdd(o_re + idx, re[s][r]);
+                            unsafeAtomicAdd(o_im + idx, im[s][r]);
+                        }
+                    }
+                    re[s] = (f32x4){0.f, 0.f, 0.f, 0.f}; im[s] = re[s];
+                }
+            }
+        }
+        F2_BARRIER();
+    }
+    const int wps = 8 / p.n_sets;
+    for (int half = wps >> 1; half >= 1; half >>= 1) { __syncthreads(); __syncthreads(); }
+}
+
+// |Im s| role: per observation row and 32x32 channel block ONE v_mfma_f32_32x32x8_bf16_1k with C = 0 (K = 8 slots: lanes
+// 0-31 carry the four cross terms h.h h.m m.h m.m of Im x_i Re x_j, lanes 32-63 those of (-Re x_i) Im x_j), then
+// acc += |d|.  An operand is ONE transposing load whose four rows are planes of one observation:
+//   A (row channel i):  planes [h h m m] of Im (lanes 0-31) / -Re (lanes 32-63)
+//   B (col channel j):  planes [h m h m] of Re (lanes 0-31) /  Im (lanes 32-63)
+template <int NB32, int COL_LO, int ROW_HI, int SET, int OP>
+__device__ __forceinline__ void f2_valu_body(const Fused2Args& a, lds_u8* lds, unsigned char* smem, const F2Loader& L, int tid,
+                                             int rsub, int wps, float* rec, int n_part) {
+    const FusedArgs& p = a.f;
+    using Tab = FuTab<NB32, COL_LO, ROW_HI, SET>;
+    constexpr int NBLK = Tab::NBLK;
+    const int lane = tid & 63;
+    f32x16 acc[NBLK > 0 ? NBLK : 1];
+#pragma unroll
+    for (int s = 0; s < NBLK; ++s)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[s][e] = 0.f;
+    const int n_chunks = (n_part + FU_OC - 1) / FU_OC;
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool loads = !(p.debug_skip & 8);
+    const bool compute = !(p.debug_skip & 2) && p.abs_plane >= 0;
+    const int rpw = 8 / wps;                       // observation rows of an 8-row group this wave takes (1 or 2)
+    for (int ch = 0; ch < n_chunks; ++ch) {
+        lds_u8* cur = lds + (loads ? (ch & 1) : 0) * F2_BUF;
+        lds_u8* nxt = lds + ((ch + 1) & 1) * F2_BUF;
+        const bool more = ch + 1 < n_chunks && loads;
+        if (more) f2_issue(a, L, nxt, (ch + 1) * FU_OC, n_part - (ch + 1) * FU_OC);
+        if (compute) {
+            const int cl = fu_lane(), hf = cl >> 5, r = (cl >> 2) & 3;
+            const int pA = hf ? (r < 2 ? 6 : 7) : (r < 2 ? 3 : 4);
+            const int pB = hf ? ((r & 1) ? 4 : 3) : ((r & 1) ? 1 : 0);
+            const int common = rsub * rpw * F2_GROUP + ((cl >> 4) & 1) * 32 + (cl & 3) * 8;
+            lds_u8* bA = cur + (pA * F2_PLANE + common);
+            lds_u8* bB = cur + (pB * F2_PLANE + common);
+            // zero rows past the end of the part contribute |0| = 0: no bound needed
+#pragma unroll 1
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll 2
+                for (int k1 = 0; k1 < rpw; ++k1) {
+                    const int ro = k1 * F2_GROUP + j * 256;
+                    __builtin_amdgcn_sched_barrier(0);
+                    s16x4 FA[4], FB[4];
+#pragma unroll
+                    for (int b = 0; b < NB32; ++b) {
+                        if (Tab::tab.use_i[b]) FA[b] = f2_tr(bA, ro + b * 64);
+                        if (Tab::tab.use_j[b]) FB[b] = f2_tr(bB, ro + b * 64);
+                    }
+                    f32x16 dprev;
+#pragma unroll
+                    for (int s = 0; s < NBLK; ++s) {
+                        const f32x16 d = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(FA[Tab::tab.bi[s]], FB[Tab::tab.bj[s]], zero, 0, 0, 0);
+                        // software pipeline: the accumulation of block s - 1 is issued AFTER the MFMA of block s
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (s > 0) fu_accumulate16<OP, (NBLK <= 4)>(acc[s - 1], dprev);
+                        dprev = d;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    fu_accumulate16<OP, (NBLK <= 4)>(acc[NBLK - 1], dprev);
+                }
+            }
+        }
+        if (more) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            f2_finish(L, nxt, n_part - (ch + 1) * FU_OC);
+        }
+        F2_BARRIER();
+    }
+    if constexpr (OP == FU_OP_SIGN) {
+#pragma unroll
+        for (int s = 0; s < NBLK; ++s)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[s][e] = (float)__float_as_int(acc[s][e]);
+    }
+    // tree-sum the row-split partials of a set through LDS (20 KB per writer), as in sc_fused.hip
+    float* red = reinterpret_cast<float*>(smem);
+    for (int half = wps >> 1; half >= 1; half >>= 1) {
+        if (rsub >= half && rsub < 2 * half) {
+            float* dst = red + (size_t)(SET * (wps >> 1) + (rsub - half)) * (FU_MAXB * 16 * 64);
+#pragma unroll
+            for (int s = 0; s < NBLK; ++s)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) dst[(s * 16 + e) * 64 + lane] = acc[s][e];
+        }
+        __syncthreads();
+        if (rsub < half) {
+            const float* src = red + (size_t)(SET * (wps >> 1) + rsub) * (FU_MAXB * 16 * 64);
+#pragma unroll
+            for (int s = 0; s < NBLK; ++s)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[s][e] += src[(s * 16 + e) * 64 + lane];
+        }
+        __syncthreads();
+    }
+    if (rsub == 0 && p.abs_plane >= 0) {
+        const int i32 = lane & 31, hf = lane >> 5;
+        // D layout of the 32x32 MFMAs: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+        float* out = rec + (int64_t)p.abs_plane * p.n_tiles * SC_TILE_ELEMS;
+#pragma unroll
+        for (int s = 0; s < NBLK; ++s) {
+            const int BIs = Tab::tab.bi[s], BJs = Tab::tab.bj[s];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int i = BIs * 32 + (e & 3) + 8 * (e >> 2) + 4 * hf, j = BJs * 32 + i32;
+                const int ti = i >> 4, tj = j >> 4;
+                if (ti <= tj && fu_tile_ok(p.map, ti) && fu_tile_ok(p.map, tj))
+                    out[(int64_t)sc_tile_index(fu_gt(p.map, ti), fu_gt(p.map, tj), p.map.NBr) * SC_TILE_ELEMS + (i & 15) * 16 +
+                        (j & 15)] = acc[s][e];
+            }
+        }
+    }
+}
+
+template <int NB32, int COL_LO, int ROW_HI, int OP>
+__global__ void __launch_bounds__(FU_THREADS) fused2_kernel(Fused2Args a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const FusedArgs& p = a.f;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bin = blockIdx.x / p.n_split, part = blockIdx.x - bin * p.n_split;
+    const int g = bin / p.F, f = bin - g * p.F;
+    const int nc = (p.st.n_obs + FU_OC - 1) / FU_OC;
+    const int o_lo = (int)((int64_t)part * nc / p.n_split) * FU_OC;
+    int o_hi = (int)((int64_t)(part + 1) * nc / p.n_split) * FU_OC;
+    if (o_hi > p.st.n_obs) o_hi = p.st.n_obs;
+    const int n_part = o_hi - o_lo;
+    float* rec = (part == 0 ? p.accum : p.ws + (int64_t)(part - 1) * p.n_bins * p.floats_per_bin) + (int64_t)bin * p.floats_per_bin;
+    const unsigned char* part_base = a.P + ((int64_t)f * p.st.ax.sF + sc_group_offset(p.st.ax, g) + (int64_t)o_lo * a.obs_rows) * a.row_bytes;
+    lds_u8* lds = (lds_u8*)smem;
+    const F2Loader L = f2_loader(a, wave, part_base);
+    // slots of channel tiles that are not staged stay zero for good
+    for (int i = tid * 16; i < F2_LDS; i += FU_THREADS * 16)
+        *reinterpret_cast<u32x4*>(smem + i) = (u32x4){0u, 0u, 0u, 0u};
+    __syncthreads();
+    f2_issue(a, L, lds, 0, n_part);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    f2_finish(L, lds, n_part);
+    F2_BARRIER();
+    if (wave < 4) {
+        if (p.debug_skip & 32) __builtin_amdgcn_s_setprio(2);
+        f2_mfma_role<NB32>(a, lds, L, wave, rec, n_part);
+    } else {
+        if (p.debug_skip & 16) __builtin_amdgcn_s_setprio(2);
+        constexpr int NSETS = fu_nsets(NB32, COL_LO, ROW_HI);
+        constexpr int wps = 8 / NSETS;
+        const int vw = wave - 4, set = vw / wps, rsub = vw % wps;
+        if constexpr (NSETS == 1) {
+            f2_valu_body<NB32, COL_LO, ROW_HI, 0, OP>(a, lds, smem, L, tid, rsub, wps, rec, n_part);
+        } else {
+            if (set == 0) f2_valu_body<NB32, COL_LO, ROW_HI, 0, OP>(a, lds, smem, L, tid, rsub, wps, rec, n_part);
+            else f2_valu_body<NB32, COL_LO, ROW_HI, 1, OP>(a, lds, smem, L, tid, rsub, wps, rec, n_part);
+        }
+    }
+}
+
+// ---- host ---------------------------------------------------------------------------------------------------------------------
+static int fused2_setup(const sc_spectra_desc* desc, uint32_t planes, Fused2Args* out, ScAxes* ax_out) {
+    SC_REQUIRE(desc, "NULL argument");
+    sc_spectra_desc d = *desc;                 // rows of the planes buffer are dense [F][W][R][K]: strides in rows
+    d.stride_taper = 1; d.stride_trial = d.n_tapers; d.stride_window = d.n_trials * d.n_tapers;
+    d.stride_freq = d.n_windows * d.n_trials * d.n_tapers;
+    ScAxes ax;
+    sc_make_axes(&d, &ax);
+    SC_REQUIRE(ax.C >= 1 && ax.F >= 1 && ax.n_obs >= 1 && ax.n_groups >= 1, "empty dimension");
+    const uint32_t fam = planes & ~(uint32_t)SC_RECORD_F64;
+    if (fam != (SC_PLANE_CSM | SC_PLANE_ABS_IM) || (planes & SC_RECORD_F64) || ax.C > 128 || ax.n_obs < F2_MIN_OBS ||
+        sc_stage_linear_stride(ax) <= 0) {
+        sc_set_error("planes-format stage B takes CSM + |Im s| records of up to 128 signals with at least %d observations per bin "
+                     "(got planes 0x%x, %d signals, %d observations)", F2_MIN_OBS, planes, ax.C, ax.n_obs);
+        return SC_EUNSUPPORTED;
+    }
+    Fused2Args& a = *out;
+    FusedArgs& f = a.f;
+    f.st.base = nullptr; f.st.ax = ax; f.st.obs_stride = sc_stage_linear_stride(ax); f.st.C = ax.C; f.st.n_obs = ax.n_obs;
+    f.NB32 = (ax.C + 31) / 32;
+    f.st.CP = f.NB32 * 32; f.st.RS = 0;
+    f.NB = sc_n_blocks(ax.C);
+    f.n_tiles = sc_n_tiles(f.NB);
+    f.n_bins = ax.n_groups * ax.F;
+    f.F = ax.F;
+    f.floats_per_bin = (int64_t)sc_plane_count(planes) * f.n_tiles * SC_TILE_ELEMS;
+    f.csm_plane = sc_plane_offset(planes, SC_PLANE_CSM);
+    f.abs_plane = sc_plane_offset(planes, SC_PLANE_ABS_IM);
+    f.sq_plane = -1; f.sign_plane = -1; f.n_fold = 0;
+    f.nl_op = FU_OP_ABS;
+    f.shape_col_lo = 0; f.shape_row_hi = f.NB32;
+    f.n_blocks32 = fu_nblocks(f.NB32, 0, f.NB32);
+    f.n_sets = fu_nsets(f.NB32, 0, f.NB32);
+    f.map.off32 = f.map.n32 = f.map.t32 = 0u;
+    for (int b = 0; b < f.NB32; ++b) {
+        const int n = ax.C - 32 * b < 32 ? ax.C - 32 * b : 32;
+        f.map.off32 |= (unsigned)b << (8 * b);
+        f.map.n32 |= (unsigned)n << (8 * b);
+        f.map.t32 |= (unsigned)(2 * b) << (8 * b);
+    }
+    f.map.NBr = f.NB; f.map.col_lo = 0; f.map.row_hi = 2 * f.NB32;
+    sc_internal_fu_assign_rows(&f);
+    f.n_split = 1; f.ws = nullptr; f.debug_skip = 0;
+    a.row_bytes = sc_planes_row_bytes(ax.C);
+    a.obs_rows = f.st.obs_stride;
+    *ax_out = ax;
+    return SC_OK;
+}
+
+extern "C" int sc_fused2_supported(const sc_spectra_desc* desc, uint32_t planes) {
+    Fused2Args a;
+    ScAxes ax;
+    const int rc = fused2_setup(desc, planes, &a, &ax);
+    return rc == SC_OK ? 1 : 0;
+}
+
+extern "C" int sc_fused2_csm_absim_f32(const void* d_P, const sc_spectra_desc* desc, uint32_t planes, float* d_accum,
+                                       void* d_workspace, int64_t workspace_bytes, void* stream) {
+    ScTimed timed_("fused_stage_b", stream);
+    SC_REQUIRE(d_P && desc && d_accum, "NULL argument");
+    SC_REQUIRE(((uintptr_t)d_P % 16) == 0, "planes buffer must be 16-byte aligned");
+    Fused2Args a;
+    ScAxes ax;
+    const int rc = fused2_setup(desc, planes, &a, &ax);
+    if (rc != SC_OK) return rc;
+    FusedArgs& f = a.f;
+    a.P = (const unsigned char*)d_P;
+    f.accum = d_accum;
+    {
+        const char* dbg = getenv("SC_FUSED_DEBUG");
+        f.debug_skip = dbg ? atoi(dbg) : 0;
+    }
+    int S = sc_internal_fused_pick_split(f.n_bins, ax.n_obs);
+    const int64_t part_bytes = (int64_t)f.n_bins * f.floats_per_bin * (int64_t)sizeof(float);
+    if (!d_workspace) S = 1;
+    while (S > 1 && (int64_t)(S - 1) * part_bytes > workspace_bytes) --S;
+    SC_REQUIRE(S == 1 || ((uintptr_t)d_workspace % 16) == 0, "workspace must be 16-byte aligned");
+    f.n_split = S;
+    f.ws = (float*)d_workspace;
+    hipStream_t s = (hipStream_t)stream;
+#define F2_LAUNCH(NB32)                                                                                               \
+    case NB32: {                                                                                                      \
+        auto k = fused2_kernel<NB32, 0, NB32, FU_OP_ABS>;                                                            \
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F2_LDS);           \
+        hipLaunchKernelGGL(k, dim3((unsigned)(f.n_bins * f.n_split)), dim3(FU_THREADS), F2_LDS, s, a);                \
+        break;                                                                                                        \
+    }
+    switch (f.NB32) {
+        F2_LAUNCH(1) F2_LAUNCH(2) F2_LAUNCH(3) F2_LAUNCH(4)
+    default:
+        sc_set_error("planes-format stage B: %d staged blocks", f.NB32);
+        return SC_EINVAL;
+    }
+#undef F2_LAUNCH
+    SC_CHECK_HIP(hipGetLastError());
+    return sc_internal_fused_combine(f, FU_OP_ABS, s);
+}

@@ -1,0 +1,86 @@
+"""Stage B on the planes format (sc_fused2.hip) against the complex64 kernel (sc_fused.hip) on the same random spectra:
+records compared plane by plane, round trip of the format conversion, and the time of both at the cfg3 volume."""
+import os
+import sys
+import time
+from ctypes import byref
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from spectral_connectivity_amd import _lib, engine      # noqa: E402
+
+lib = _lib.load()
+dev = torch.device("cuda:0")
+planes = _lib.PLANE_CSM | _lib.PLANE_ABS_IM
+
+
+def run(C, R, F=5, W=2, K=7, timing=False):
+    torch.manual_seed(C * 1000 + R)
+    X = torch.view_as_complex(torch.randn((F, W, R, K, C, 2), dtype=torch.float32, device=dev))
+    X = X * (0.5 + torch.rand((1, 1, 1, 1, C), device=dev)) + 0.3 * X[..., :1]          # correlated channels
+    sp = engine.DeviceSpectra(X, (F, W, R, K, C), (W * R * K * C, R * K * C, K * C, C), 256, True, C_alloc=C)
+    d = sp.desc("trials_tapers")
+    rb = lib.sc_planes_row_bytes(C)
+    P = torch.empty((F * W * R * K * rb,), dtype=torch.uint8, device=dev)
+    _lib.check(lib.sc_planes_from_spectra_f32(X.data_ptr(), byref(d), P.data_ptr(), None), "to planes")
+    Xb = torch.zeros_like(X)
+    _lib.check(lib.sc_spectra_from_planes_f32(P.data_ptr(), byref(d), Xb.data_ptr(), None), "from planes")
+    torch.cuda.synchronize()
+    assert torch.equal(torch.view_as_real(X), torch.view_as_real(Xb)), "round trip is not lossless"
+    ok = lib.sc_fused2_supported(byref(d), planes)
+    ref, n_obs = engine.accumulate(sp, "trials_tapers", planes)
+    n_bins, fpb, _, _ = engine.accum_layout(sp, "trials_tapers", planes)
+    if not ok:
+        print(f"C={C} R={R}: not supported (n_obs={n_obs})")
+        return
+    ws_bytes = int(lib.sc_fused_workspace_bytes(byref(d), planes))
+    ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=dev)
+    out = torch.full((n_bins, fpb), float("nan"), dtype=torch.float32, device=dev)
+    _lib.check(lib.sc_fused2_csm_absim_f32(P.data_ptr(), byref(d), planes, out.data_ptr(), ws.data_ptr(), ws_bytes, None), "fused2")
+    torch.cuda.synchronize()
+    # fp64 truth of the three planes for the scale of the errors
+    Xd = X.to(torch.complex128)
+    S = torch.einsum("fwrkc,fwrkd->wfcd", Xd, Xd.conj())                       # [W][F][C][C]
+    absim = torch.einsum("fwrkc,fwrkd->fwrkcd", Xd, Xd.conj()).imag.abs().sum(dim=(2, 3)).permute(1, 0, 2, 3) if C <= 64 else None
+    nt = fpb // 3 // 256
+    a, b = out.view(n_bins, 3, nt, 256), ref.view(n_bins, 3, nt, 256)
+    NB = (C + 15) // 16
+    scale = S.abs().amax().item()
+    errs = []
+    for pl, name in ((0, "Re S"), (1, "Im S"), (2, "sum |Im s|")):
+        # only entries of real channels: compare tile by tile on the valid part
+        worst = 0.0
+        t = 0
+        for bi in range(NB):
+            for bj in range(bi, NB):
+                ni, nj = min(16, C - 16 * bi), min(16, C - 16 * bj)
+                ta = a[:, pl, t].view(n_bins, 16, 16)[:, :ni, :nj]
+                tb = b[:, pl, t].view(n_bins, 16, 16)[:, :ni, :nj]
+                if bi == bj:
+                    iu = torch.triu_indices(ni, nj, device=dev)
+                    ta, tb = ta[:, iu[0], iu[1]], tb[:, iu[0], iu[1]]
+                worst = max(worst, (ta - tb).abs().max().item())
+                t += 1
+        errs.append(worst / scale)
+    print(f"C={C:4d} R={R:5d} n_obs={n_obs:6d}: max |new - old| / max|S| per plane: " + "  ".join(f"{e:.2e}" for e in errs)
+          + ("  NaN!" if not torch.isfinite(out).all() else ""))
+    if timing:
+        for name, fn in (("old (complex64)", lambda: engine.accumulate(sp, "trials_tapers", planes)),
+                         ("new (planes)", lambda: _lib.check(lib.sc_fused2_csm_absim_f32(P.data_ptr(), byref(d), planes, out.data_ptr(), ws.data_ptr(), ws_bytes, None), "fused2"))):
+            ts = []
+            for rep in range(12):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                fn()
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            print(f"    {name}: {np.median(ts[2:]) * 1e3:.3f} ms")
+
+
+if __name__ == "__main__":
+    for C, R in ((128, 80), (64, 80), (96, 100), (32, 90), (100, 77), (128, 75)):
+        run(C, R)
+    run(128, 1000, F=129, W=7, timing=True)
+    run(64, 2000, F=129, W=7, timing=True)
