@@ -105,7 +105,7 @@ def one_step(x, h, cfg, geom, planes, world, exchange=None):
     entry point brackets its launches on the stream it was given); `exchange` collects the collective breakout of the
     N > 1 path."""
     L, step, N, W = geom
-    sp = engine.multitaper_spectra(x, h, L, step, N, W, "constant")
+    sp = engine.multitaper_spectra(x, h, L, step, N, W, "constant", planes_hint=planes)
     if world > 1 or os.environ.get("SC_BENCH_FORCE_SHARDED") == "1":     # (the switch: the N > 1 code path on one rank,
         # with SC_FORCE_EXCHANGE=1 through the collectives too -- what a rank's step costs beside the transfers)
         # trial shards: accumulate -> reduce-scatter -> epilogue -> gather on rank 0, pipelined over frequency

@@ -263,25 +263,43 @@ int sc_fused_unit_ws_f32(const void* d_X /*float2*/, const sc_spectra_desc* desc
                          float* d_accum, void* d_workspace, int64_t workspace_bytes, void* d_scratch,
                          int64_t scratch_bytes, void* stream);
 
-/* ---- planes format (ABI v4): every f32 coefficient stored as three bf16 pieces h + m + l = x (exact) ------------------
- * The one-pass stage-B kernels multiply on the bf16 matrix pipe and split every coefficient while they stage it; stage A
- * can store the pieces instead (sc_multitaper_fft_planes_f32), which turns stage B's staging into plain HBM -> LDS loads.
- * Layout: dense rows [F][W][R][K] (bin, window, trial, taper), sc_planes_row_bytes(C) = 384 * ceil(C / 32) bytes each:
- * [channel tile of 32][plane Re h, Re m, Re l, Im h, Im m, Im l][32 channels] bf16, absent channels zero.  Same
- * coefficients as the complex64 spectra of _multitaper_fft (transforms.py:1377-1405); the conversions are lossless. */
+/* ---- planes format (ABI v4): every real number stored as two f16 pieces, x * scale[c] = h + m ---------------------------
+ * The one-pass stage-B kernels multiply on the 16-bit matrix pipe and split every f32 coefficient while they stage it; stage A
+ * can store the pieces instead (sc_multitaper_fft_planes_f32): stage B's staging becomes plain HBM -> LDS loads and its
+ * products need three cross terms instead of six.  h = f16(x scale), m = f16(x scale - h): 22 significant bits; scale[c] is
+ * a power of two per channel that keeps every coefficient inside the f16 range (sc_planes_scales_*); records come out
+ * unscaled (exactly: powers of two).  Layout: dense rows [F][W][R][K] (bin, window, trial, taper) of
+ * sc_planes_row_bytes(C) = 256 * ceil(C / 32) bytes: [channel tile of 32][plane Re h, Re m, Im h, Im m][32 channels] f16,
+ * absent channels zero -- 8 bytes per coefficient, like the complex64 spectra of _multitaper_fft (transforms.py:1377-1405).
+ * d_scale: float[2 C] = the scales, then their reciprocals. */
 int64_t sc_planes_row_bytes(int64_t n_signals);
+/* scales from a bound on the spectra of a (T, R, C) time series: |X_k(f)| <= 8 max|x| * taper_abs_sum, taper_abs_sum =
+ * max_k sum_n |tapers[k][n]| (the tapers as passed to stage A, i.e. / fs); d_work: 4 C bytes of device scratch */
+int sc_planes_scales_from_series_f32(const float* d_x, int64_t T, int64_t R, int64_t C, double taper_abs_sum,
+                                     float* d_scale, void* d_work, void* stream);
+/* scales from the largest |Re|, |Im| of dense complex64 rows [n_rows][C] */
+int sc_planes_scales_from_spectra_f32(const void* d_X /*float2*/, int64_t n_rows, int64_t C, float* d_scale, void* d_work,
+                                      void* stream);
+/* Stage A straight into the planes format: sc_multitaper_fft_f32 with the spectra leaving as f16 pieces (same transform,
+ * same coefficients up to the 22-bit representation; window lengths N = 64 ... 1024, powers of two, even n_signals). */
+int sc_multitaper_fft_planes_supported(int64_t L, int64_t N, int64_t n_signals);
+int sc_multitaper_fft_planes_f32(const float* d_x, int64_t T, int64_t R, int64_t C, int64_t L, int64_t step, int64_t W,
+                                 int64_t N, const float* d_tapers, int64_t K, int detrend_type, const void* d_twiddles,
+                                 const float* d_scale, void* d_P, void* stream);
 /* complex64 spectra described by desc (strides in elements) <-> planes buffer (dense rows, desc's sizes) */
-int sc_planes_from_spectra_f32(const void* d_X /*float2*/, const sc_spectra_desc* desc, void* d_P, void* stream);
-int sc_spectra_from_planes_f32(const void* d_P, const sc_spectra_desc* desc, void* d_X /*float2*/, void* stream);
+int sc_planes_from_spectra_f32(const void* d_X /*float2*/, const sc_spectra_desc* desc, const float* d_scale, void* d_P,
+                               void* stream);
+int sc_spectra_from_planes_f32(const void* d_P, const sc_spectra_desc* desc, const float* d_scale, void* d_X /*float2*/,
+                               void* stream);
 /* Stage B on the planes format: the CSM planes and the |Im s| plane of every bin record in one pass, exactly what
  * sc_fused_csm_absim_ws_f32 writes (replaces _expectation_cross_spectral_matrix with fcn = identity and abs(Im),
  * connectivity.py:463-526, :982-1028).  desc: sizes and reduce flags (strides ignored: the rows are dense).  Takes
- * planes == SC_PLANE_CSM | SC_PLANE_ABS_IM, up to 128 signals and bins of at least 512 observations (the |Im s| products
- * use two of the three pieces: relative error of the sum ~1.5e-5 / sqrt(n_observations)); sc_fused2_supported tells.
+ * planes == SC_PLANE_CSM or SC_PLANE_CSM | SC_PLANE_ABS_IM, up to 128 signals, observations of a bin that form one linear
+ * run of rows (every expectation type but "time_tapers" with several trials); sc_fused2_supported tells.
  * Workspace as for sc_fused_csm_absim_ws_f32 (sc_fused_workspace_bytes with the same desc). */
 int sc_fused2_supported(const sc_spectra_desc* desc, uint32_t planes);
-int sc_fused2_csm_absim_f32(const void* d_P, const sc_spectra_desc* desc, uint32_t planes, float* d_accum,
-                            void* d_workspace, int64_t workspace_bytes, void* stream);
+int sc_fused2_csm_absim_f32(const void* d_P, const sc_spectra_desc* desc, const float* d_scale, uint32_t planes,
+                            float* d_accum, void* d_workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- stage C: measures epilogue ------------------------------------------------------
  * Elementwise measure algebra on accumulated sums (connectivity.py:612-1159): divides by

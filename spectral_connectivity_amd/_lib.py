@@ -98,10 +98,16 @@ SYMBOLS = {
     "sc_fused_unit_ws_f32": (c_int, [c_void_p, POINTER(SpectraDesc), c_uint32, c_void_p, c_void_p, c_int64, c_void_p,
                                      c_int64, c_void_p]),
     "sc_planes_row_bytes": (c_int64, [c_int64]),
-    "sc_planes_from_spectra_f32": (c_int, [c_void_p, POINTER(SpectraDesc), c_void_p, c_void_p]),
-    "sc_spectra_from_planes_f32": (c_int, [c_void_p, POINTER(SpectraDesc), c_void_p, c_void_p]),
+    "sc_multitaper_fft_planes_supported": (c_int, [c_int64, c_int64, c_int64]),
+    "sc_multitaper_fft_planes_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64,
+                                             c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sc_planes_scales_from_series_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_double, c_void_p, c_void_p, c_void_p]),
+    "sc_planes_scales_from_spectra_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+    "sc_planes_from_spectra_f32": (c_int, [c_void_p, POINTER(SpectraDesc), c_void_p, c_void_p, c_void_p]),
+    "sc_spectra_from_planes_f32": (c_int, [c_void_p, POINTER(SpectraDesc), c_void_p, c_void_p, c_void_p]),
     "sc_fused2_supported": (c_int, [POINTER(SpectraDesc), c_uint32]),
-    "sc_fused2_csm_absim_f32": (c_int, [c_void_p, POINTER(SpectraDesc), c_uint32, c_void_p, c_void_p, c_int64, c_void_p]),
+    "sc_fused2_csm_absim_f32": (c_int, [c_void_p, POINTER(SpectraDesc), c_void_p, c_uint32, c_void_p, c_void_p, c_int64,
+                                        c_void_p]),
     "sc_granger_workspace_bytes": (c_int, [c_int64, c_int64, c_int64, POINTER(c_size_t)]),
     "sc_granger_pairwise_f64": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_uint32, c_int64,
                                         c_void_p, c_int64, c_double, c_int, c_void_p, c_size_t, c_int, c_void_p,

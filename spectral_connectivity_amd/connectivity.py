@@ -33,6 +33,16 @@ logger = getLogger(__name__)
 EXPECTATION = dict.fromkeys(EXPECTATION_AXES)
 
 
+class _PendingSpectra:
+    """A float32-engine transform that has not run yet (Connectivity.from_multitaper): sizes only."""
+
+    def __init__(self, multitaper, precision):
+        self.multitaper, self.precision = multitaper, precision
+        ts = np.asarray(multitaper.time_series)
+        self.shape5 = (int(multitaper.n_time_windows), int(ts.shape[1]), int(multitaper.n_tapers),
+                       int(multitaper.n_fft_samples), int(ts.shape[2]))
+
+
 class Connectivity:
     """Frequency-domain connectivity measures computed on an MI355X.
 
@@ -58,10 +68,13 @@ class Connectivity:
         from .engine import DeviceSpectra
         self._precision = options.engine_precision(dtype)
         self._spectra = None
+        self._pending = None
         self._host_coefficients = None
         self._multitaper = None
         if isinstance(fourier_coefficients, DeviceSpectra):
             self._spectra = fourier_coefficients
+        elif isinstance(fourier_coefficients, _PendingSpectra):
+            self._pending = fourier_coefficients
         else:
             fourier_coefficients = np.asarray(fourier_coefficients)
             if fourier_coefficients.ndim != 5:
@@ -108,9 +121,17 @@ class Connectivity:
                         dtype=np.complex128):
         """Reference connectivity.py:366-400, but the coefficients never leave the device."""
         from . import options
-        obj = cls(multitaper_instance.device_spectra(precision=options.engine_precision(dtype)),
-                  expectation_type=expectation_type, time=multitaper_instance.time,
-                  frequencies=multitaper_instance.frequencies, blocks=blocks, dtype=dtype)
+        precision = options.engine_precision(dtype)
+        if precision == "float32" and not np.iscomplexobj(multitaper_instance.time_series):
+            # float32 engine: the transform runs when the first measure asks for its accumulators -- which families they
+            # are decides the device format of the spectra (CSM / |Im s|: f16 pieces for sc_fused2.hip, engine.multitaper_spectra)
+            multitaper_instance.check_device_path()
+            obj = cls(_PendingSpectra(multitaper_instance, precision), expectation_type=expectation_type,
+                      time=multitaper_instance.time, frequencies=multitaper_instance.frequencies, blocks=blocks, dtype=dtype)
+        else:
+            obj = cls(multitaper_instance.device_spectra(precision=precision),
+                      expectation_type=expectation_type, time=multitaper_instance.time,
+                      frequencies=multitaper_instance.frequencies, blocks=blocks, dtype=dtype)
         obj._multitaper = multitaper_instance
         return obj
 
@@ -125,6 +146,8 @@ class Connectivity:
     def _shape5(self):
         if self._host_coefficients is not None:
             return self._host_coefficients.shape
+        if self._spectra is None and self._pending is not None:
+            return self._pending.shape5
         s = self._spectra
         return (s.W, s.R, s.K, s.n_fft, s.C)
 
@@ -149,7 +172,12 @@ class Connectivity:
         return int(np.prod([self._shape5[a] for a in EXPECTATION_AXES[self.expectation_type]]))
 
     # ---- device plumbing -----------------------------------------------------------------
-    def _device(self):
+    def _device(self, planes_hint=None):
+        """The device spectra; ``planes_hint``: the accumulator families about to be requested (a pending transform writes
+        the format that suits them)."""
+        if self._spectra is None and self._pending is not None:
+            self._spectra = self._pending.multitaper.device_spectra(precision=self._pending.precision, planes_hint=planes_hint)
+            self._pending = None
         if self._spectra is None:
             from . import engine
             _lib.require_gpu()
@@ -166,7 +194,7 @@ class Connectivity:
         for have, rec in self._accum_cache.items():
             if isinstance(have, int) and have & planes == planes:
                 return have, rec
-        sp = self._device()
+        sp = self._device(planes_hint=planes)
         have = None
         if sp.f64 and self._reduce_over_ranks.__func__ is Connectivity._reduce_over_ranks:
             # float64 engine, single process: families a cached record already holds are copied, not recomputed

@@ -1,52 +1,164 @@
-// sc_fused2.hip -- stage B on spectra that arrive as bf16 pieces ("planes format"), round 4.
+// sc_fused2.hip -- stage B on spectra that arrive as f16 pieces ("planes format"), round 4.
 //
 // The one-pass kernel of sc_fused.hip spends a third of its vector-issue slots on work that is not the product: splitting
 // every f32 coefficient into three bf16 pieces while staging (208 of 2185 VALU instructions per SIMD and 32-row chunk),
 // re-assembling the operands of the per-observation |Im s| products with byte permutes (456; v_perm_b32 costs 4.3 cycles
-// against 2.1-2.6 for an add: profiles/r04_issue_rates.txt) and flipping signs (~100).  Here none of that is left:
-//   * the split is exact (x = h + m + l, three bf16 values), so stage A can store the pieces instead of the f32 value
-//     (sc_multitaper_fft_planes_f32: 12 bytes per coefficient instead of 8) and nothing is lost;
-//   * an observation row is [channel tile of 32][plane Re h, Re m, Re l, Im h, Im m, Im l][32 channels] bf16, and lands in
-//     LDS observation-major and plane-major by direct HBM -> LDS loads (global_load_lds_dwordx4, no VGPRs, no VALU);
+// against 2.1-2.6 for an add: profiles/r04_issue_rates.txt) and flipping signs (~100); and its matrix pipe runs SIX cross
+// terms per product.  Here:
+//   * every real number is stored as TWO f16 pieces, x * 2^e = h + m (h = f16(x 2^e), m = f16(x 2^e - h): 22 significant bits,
+//     error <= 2^-23 |x| + 2^-25 in scaled units), with one power-of-two scale per channel that keeps every coefficient
+//     inside the f16 range (sc_planes_scales_*: from a bound on the spectra, so nothing can overflow).  That is 8 bytes per
+//     complex coefficient -- the complex64 volume -- and products need THREE cross terms (h h, h m, m h; the dropped m m is
+//     2^-22 relative, with random sign over the observations) instead of six: half the matrix-pipe time of the cross-
+//     spectral matrix.  The scales are powers of two, taken out again exactly when a record is written;
+//   * an observation row is [channel tile of 32][plane Re h, Re m, Im h, Im m][32 channels] f16, and lands in LDS
+//     observation-major and plane-major by direct HBM -> LDS loads (global_load_lds_dwordx4, no VGPRs, no VALU);
 //   * BOTH roles read their matrix-core operands out of that one layout with the transposing LDS load
 //     ds_read_b64_tr_b16 (lane 4 r + q of a 16-lane group supplies row r, 8-byte chunk q; lane j receives column j of the
 //     four rows: profiles/r04_tr_load.txt): the CSM waves take rows = observations (K = 32 observations of one plane,
-//     v_mfma_f32_16x16x32_bf16), the |Im s| waves rows = PLANES of one observation (K = the cross terms of one
-//     observation, v_mfma_f32_32x32x8_bf16_1k) -- which plane sits in which K slot is just the address a lane passes;
-//   * the negated real part both roles need (Im s = Im x_i Re x_j - Re x_i Im x_j) is a fourth plane group in LDS, made by
-//     the wave that loaded the real planes (one xor per 8 coefficients and chunk).
+//     v_mfma_f32_16x16x32_f16), the |Im s| waves rows = PLANES of one observation (K = the four cross terms of one
+//     observation, v_mfma_f32_32x32x8_f16) -- which plane sits in which K slot is just the address a lane passes;
+//   * the negated real part both roles need (Im s = Im x_i Re x_j - Re x_i Im x_j) is a third plane pair in LDS, made by
+//     the waves that loaded the real planes (one xor per 8 coefficients and chunk).
 // LDS layout of a chunk of 32 observations (bytes):   addr(p, o, c) = p * 8512 + (o & 7) * 1056 + (o >> 3) * 256 + 2 c
-//   p = plane 0 .. 8 (Re h m l, Im h m l, -Re h m l), o = observation of the chunk, c = staged channel 0 .. 127
+//   p = plane 0 .. 5 (Re h m, Im h m, -Re h m), o = observation of the chunk, c = staged channel 0 .. 127
 // A direct load instruction fills one 1024-byte group (plane p, observations o7, o7 + 8, o7 + 16, o7 + 24); the 32 bytes of
 // padding behind every group and the 64 behind every plane shift the banks so that every transposing load of either role
 // is conflict-free (3.0 cycles per instruction measured, against 8-16 for unpadded rows) while every address stays an
 // affine function of (plane, observation, channel block): ONE address register per role and buffer, everything else
 // immediate offsets.
-// The |Im s| products use the two leading pieces only (h, m: four cross terms, error <= 2^-16 |x_i| |x_j| per
-// observation with random sign): the sum of |Im s| over n observations is off by ~1.5e-5 / sqrt(n) relative, so the entry
-// point takes bins with at least SC_FUSED2_MIN_OBS observations (512: 7e-7) and leaves the others to sc_fused.hip.  The
-// cross-spectral matrix itself keeps the six-term, f32-accurate product.
+// Accuracy: the representation error 2^-23 is half an f32 ulp; the dropped m m term is <= 2^-22 |x_i| |x_j| per observation
+// (typically a third of that) -- below the rounding of the f32 transform that produced the coefficients, whose error in a
+// weak bin is relative to the strongest one.  (First form of this file, three bf16 pieces and six terms: 12 bytes per
+// coefficient, stage B 5.1 -> 4.6 ms but stage A +0.6 ms: profiles/r04_fused2_bf16x3.txt.)
 #include <stdlib.h>
 #include "sc_fused_common.h"
 
-typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) unsigned char lds_u8;
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 #define F2_GROUP 1056                 // 4 observation rows of 256 B + 32 B
 #define F2_PLANE (8 * F2_GROUP + 64)  // 8512
-#define F2_NPL 9                      // Re h m l, Im h m l, -Re h m l
-#define F2_BUF (F2_NPL * F2_PLANE)    // 76608 B per chunk buffer
-#define F2_LDS (2 * F2_BUF)           // 153216 B
-#define F2_ROW_TILE 384               // bytes of one 32-channel tile of an observation row in HBM (6 planes x 64 B)
-#define F2_MIN_OBS 512
+#define F2_NPL 6                      // Re h m, Im h m, -Re h m
+#define F2_HPL 4                      // planes of a row in HBM
+#define F2_BUF (F2_NPL * F2_PLANE)    // 51072 B per chunk buffer
+#define F2_NBUF 3                        // chunk n + 2 is loaded while chunk n is multiplied
+#define F2_SCALE_OFF (F2_NBUF * F2_BUF)          // float[128]: 1 / scale of the staged channels (1 for absent ones)
+#define F2_LDS (F2_SCALE_OFF + 512)
+#define F2_ROW_TILE 256               // bytes of one 32-channel tile of an observation row in HBM (4 planes x 64 B)
 
 extern "C" int64_t sc_planes_row_bytes(int64_t n_signals) { return (int64_t)F2_ROW_TILE * ((n_signals + 31) / 32); }
+
+__device__ __forceinline__ unsigned f2_pack(float lo, float hi) {        // two f16 (round to nearest) in one dword
+    const h16x2 v = {(_Float16)lo, (_Float16)hi};
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ float f2_lo(unsigned p) { return (float)__builtin_bit_cast(h16x2, p)[0]; }
+__device__ __forceinline__ float f2_hi(unsigned p) { return (float)__builtin_bit_cast(h16x2, p)[1]; }
+// two scaled reals (channels c, c + 1 of one component) -> their h and m dwords
+__device__ __forceinline__ void f2_split2(float x0, float x1, unsigned& h, unsigned& m) {
+    h = f2_pack(x0, x1);
+    m = f2_pack(x0 - f2_lo(h), x1 - f2_hi(h));
+}
+
+// ---- scales -------------------------------------------------------------------------------------------------------------------
+// scale[c] = 2^e with bound_c * 2^e <= 2^15 (65504 is the largest f16), from a per-channel bound on |Re X|, |Im X|:
+//   from the time series: |X_k(f)| <= max_n |x - trend| * sum_n |h_k[n]| <= 8 max|x| * taper_abs_sum  (8: mean / line removed from
+//   bounded data stays within a few times its range);   from complex64 spectra: max(|Re X|, |Im X|) itself.
+// Zero / non-finite bounds give scale 1 (an all-zero channel stays zero; non-finite samples make non-finite coefficients in either
+// format).  d_scale: float[C] scale, float[C] 1 / scale behind it.
+// x: n_rows rows of `width` floats (width = C * comps); column col belongs to channel col / comps.  A block takes a slab of
+// rows; with width % 4 == 0 a thread reads 16 bytes of 4 rows per step (1-2 KB in flight per wave-instruction), the rows
+// of a column group meet in LDS, one atomic per column and block.
+__global__ void __launch_bounds__(256) planes_absmax_kernel(const float* x, int64_t n_rows, int width, int comps, unsigned* mx) {
+    __shared__ unsigned red[1024];
+    const int64_t rows_per_block = (n_rows + gridDim.x - 1) / gridDim.x;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = r0 + rows_per_block < n_rows ? r0 + rows_per_block : n_rows;
+    const int tid = threadIdx.x;
+    if ((width & 3) == 0 && width <= 1024 && (((uintptr_t)x) & 15) == 0) {
+        const int q = width >> 2;                      // float4 columns
+        const int rows_per_step = 256 / q;             // >= 1 for width <= 1024
+        const int cq = tid % q, ro = tid / q;
+        for (int i = tid; i < width; i += 256) red[i] = 0u;
+        __syncthreads();
+        float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ro < rows_per_step) {
+            int64_t r = r0 + ro;
+            for (; r + 3 * rows_per_step < r1; r += 4 * rows_per_step) {
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(x + (r + (int64_t)u * rows_per_step) * width + 4 * cq);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    m.x = fmaxf(m.x, fabsf(v[u].x)); m.y = fmaxf(m.y, fabsf(v[u].y));
+                    m.z = fmaxf(m.z, fabsf(v[u].z)); m.w = fmaxf(m.w, fabsf(v[u].w));
+                }
+            }
+            for (; r < r1; r += rows_per_step) {
+                const float4 v = *reinterpret_cast<const float4*>(x + r * width + 4 * cq);
+                m.x = fmaxf(m.x, fabsf(v.x)); m.y = fmaxf(m.y, fabsf(v.y)); m.z = fmaxf(m.z, fabsf(v.z)); m.w = fmaxf(m.w, fabsf(v.w));
+            }
+            atomicMax(red + 4 * cq, __float_as_uint(m.x)); atomicMax(red + 4 * cq + 1, __float_as_uint(m.y));
+            atomicMax(red + 4 * cq + 2, __float_as_uint(m.z)); atomicMax(red + 4 * cq + 3, __float_as_uint(m.w));
+        }
+        __syncthreads();
+        for (int col = tid; col < width; col += 256)
+            if (red[col]) atomicMax(mx + col / comps, red[col]);        // non-negative floats order like unsigned
+        return;
+    }
+    for (int col = tid; col < width; col += 256) {
+        float m = 0.f;
+        for (int64_t r = r0; r < r1; ++r) m = fmaxf(m, fabsf(x[r * width + col]));       // (fmaxf drops NaNs)
+        if (m > 0.f) atomicMax(mx + col / comps, __float_as_uint(m));
+    }
+}
+__global__ void planes_scale_kernel(const unsigned* mx, int C, float factor, float* scale) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float b = __uint_as_float(mx[c]) * factor;
+    float s = 1.f;
+    if (b > 0.f && b < 3.0e38f) {
+        int e;
+        (void)frexpf(b, &e);                       // b = f * 2^e, f in [0.5, 1): b <= 2^e
+        int k = 15 - e;
+        k = k < -100 ? -100 : (k > 100 ? 100 : k);
+        s = ldexpf(1.f, k);
+    }
+    scale[c] = s;
+    scale[C + c] = 1.f / s;
+}
+static int planes_scales(const float* d_x, int64_t n_rows, int C, int comps, float factor, float* d_scale, void* d_work, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    unsigned* mx = (unsigned*)d_work;
+    SC_CHECK_HIP(hipMemsetAsync(mx, 0, sizeof(unsigned) * C, s));
+    int64_t blocks = n_rows / 128;
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    hipLaunchKernelGGL(planes_absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, s, d_x, n_rows, C * comps, comps, mx);
+    hipLaunchKernelGGL(planes_scale_kernel, dim3((C + 63) / 64), dim3(64), 0, s, mx, C, factor, d_scale);
+    SC_CHECK_HIP(hipGetLastError());
+    return SC_OK;
+}
+// d_work: 4 * n_signals bytes of scratch
+extern "C" int sc_planes_scales_from_series_f32(const float* d_x, int64_t T, int64_t R, int64_t C, double taper_abs_sum,
+                                                float* d_scale, void* d_work, void* stream) {
+    ScTimed timed_("planes_scales", stream);
+    SC_REQUIRE(d_x && d_scale && d_work && T >= 1 && R >= 1 && C >= 1 && taper_abs_sum > 0.0, "bad argument");
+    return planes_scales(d_x, T * R, (int)C, 1, (float)(8.0 * taper_abs_sum), d_scale, d_work, stream);
+}
+extern "C" int sc_planes_scales_from_spectra_f32(const void* d_X, int64_t n_rows, int64_t C, float* d_scale, void* d_work, void* stream) {
+    SC_REQUIRE(d_X && d_scale && d_work && n_rows >= 1 && C >= 1, "bad argument");
+    return planes_scales((const float*)d_X, n_rows, (int)C, 2, 1.0f, d_scale, d_work, stream);          // dense rows of C complex64
+}
 
 // ---- conversions between complex64 spectra and the planes format (uploaded coefficients, consumers of complex64) -------
 struct PlanesConvArgs {
     const float2* X;
     unsigned char* P;
+    const float* scale;       // [C] scale, [C] 1 / scale
     int64_t sF, sW, sR, sK;
     int F, W, R, K, C, nct;
     int64_t n_rows;
@@ -65,16 +177,13 @@ __global__ void __launch_bounds__(256) planes_from_spectra_kernel(PlanesConvArgs
     const int f = (int)t;
     const float2* src = a.X + (int64_t)f * a.sF + (int64_t)w * a.sW + (int64_t)r * a.sR + (int64_t)k * a.sK + c;
     float2 v0 = make_float2(0.f, 0.f), v1 = v0;
-    if (c < a.C) v0 = src[0];
-    if (c + 1 < a.C) v1 = src[1];
+    if (c < a.C) { const float s0 = a.scale[c]; v0 = src[0]; v0.x *= s0; v0.y *= s0; }
+    if (c + 1 < a.C) { const float s1 = a.scale[c + 1]; v1 = src[1]; v1.x *= s1; v1.y *= s1; }
     unsigned* dst = reinterpret_cast<unsigned*>(a.P + row * (int64_t)a.nct * F2_ROW_TILE + (pr >> 4) * F2_ROW_TILE) + (pr & 15);
-    const unsigned rh = cvt_pk_bf16(v0.x, v1.x), ih = cvt_pk_bf16(v0.y, v1.y);
-    const float r0 = v0.x - bf16lo_to_f32(rh), r1 = v1.x - bf16hi_to_f32(rh);
-    const float i0 = v0.y - bf16lo_to_f32(ih), i1 = v1.y - bf16hi_to_f32(ih);
-    const unsigned rm = cvt_pk_bf16(r0, r1), im = cvt_pk_bf16(i0, i1);
-    const unsigned rl = cvt_pk_bf16(r0 - bf16lo_to_f32(rm), r1 - bf16hi_to_f32(rm));
-    const unsigned il = cvt_pk_bf16(i0 - bf16lo_to_f32(im), i1 - bf16hi_to_f32(im));
-    dst[0] = rh; dst[16] = rm; dst[32] = rl; dst[48] = ih; dst[64] = im; dst[80] = il;
+    unsigned rh, rm, ih, im;
+    f2_split2(v0.x, v1.x, rh, rm);
+    f2_split2(v0.y, v1.y, ih, im);
+    dst[0] = rh; dst[16] = rm; dst[32] = ih; dst[48] = im;
 }
 __global__ void __launch_bounds__(256) spectra_from_planes_kernel(PlanesConvArgs a) {
     const int pairs_per_row = a.nct * 16;
@@ -89,21 +198,19 @@ __global__ void __launch_bounds__(256) spectra_from_planes_kernel(PlanesConvArgs
     const int w = (int)(t % a.W); t /= a.W;
     const int f = (int)t;
     const unsigned* src = reinterpret_cast<const unsigned*>(a.P + row * (int64_t)a.nct * F2_ROW_TILE + (pr >> 4) * F2_ROW_TILE) + (pr & 15);
-    const unsigned rh = src[0], rm = src[16], rl = src[32], ih = src[48], im = src[64], il = src[80];
-    // h + m is exact in f32 (16 significant bits), and so is (h + m) + l = x
-    const float2 v0 = make_float2((bf16lo_to_f32(rh) + bf16lo_to_f32(rm)) + bf16lo_to_f32(rl),
-                                  (bf16lo_to_f32(ih) + bf16lo_to_f32(im)) + bf16lo_to_f32(il));
-    const float2 v1 = make_float2((bf16hi_to_f32(rh) + bf16hi_to_f32(rm)) + bf16hi_to_f32(rl),
-                                  (bf16hi_to_f32(ih) + bf16hi_to_f32(im)) + bf16hi_to_f32(il));
+    const unsigned rh = src[0], rm = src[16], ih = src[32], im = src[48];
+    const float i0 = a.scale[a.C + c], i1 = (c + 1 < a.C) ? a.scale[a.C + c + 1] : 1.f;
+    const float2 v0 = make_float2((f2_lo(rh) + f2_lo(rm)) * i0, (f2_lo(ih) + f2_lo(im)) * i0);      // h + m is exact in f32
+    const float2 v1 = make_float2((f2_hi(rh) + f2_hi(rm)) * i1, (f2_hi(ih) + f2_hi(im)) * i1);
     float2* dst = const_cast<float2*>(a.X) + (int64_t)f * a.sF + (int64_t)w * a.sW + (int64_t)r * a.sR + (int64_t)k * a.sK + c;
     dst[0] = v0;
     if (c + 1 < a.C) dst[1] = v1;
 }
-static int planes_conv(const void* d_X, const sc_spectra_desc* d, void* d_P, bool to_planes, void* stream) {
-    SC_REQUIRE(d_X && d && d_P, "NULL argument");
+static int planes_conv(const void* d_X, const sc_spectra_desc* d, const float* d_scale, void* d_P, bool to_planes, void* stream) {
+    SC_REQUIRE(d_X && d && d_P && d_scale, "NULL argument");
     SC_REQUIRE(d->n_freq >= 1 && d->n_windows >= 1 && d->n_trials >= 1 && d->n_tapers >= 1 && d->n_signals >= 1, "empty dimension");
     PlanesConvArgs a;
-    a.X = (const float2*)d_X; a.P = (unsigned char*)d_P;
+    a.X = (const float2*)d_X; a.P = (unsigned char*)d_P; a.scale = d_scale;
     a.sF = d->stride_freq; a.sW = d->stride_window; a.sR = d->stride_trial; a.sK = d->stride_taper;
     a.F = (int)d->n_freq; a.W = (int)d->n_windows; a.R = (int)d->n_trials; a.K = (int)d->n_tapers; a.C = (int)d->n_signals;
     a.nct = (a.C + 31) / 32;
@@ -115,60 +222,66 @@ static int planes_conv(const void* d_X, const sc_spectra_desc* d, void* d_P, boo
     SC_CHECK_HIP(hipGetLastError());
     return SC_OK;
 }
-extern "C" int sc_planes_from_spectra_f32(const void* d_X, const sc_spectra_desc* desc, void* d_P, void* stream) {
+extern "C" int sc_planes_from_spectra_f32(const void* d_X, const sc_spectra_desc* desc, const float* d_scale, void* d_P, void* stream) {
     ScTimed timed_("planes_from_spectra", stream);
-    return planes_conv(d_X, desc, d_P, true, stream);
+    return planes_conv(d_X, desc, d_scale, d_P, true, stream);
 }
-extern "C" int sc_spectra_from_planes_f32(const void* d_P, const sc_spectra_desc* desc, void* d_X, void* stream) {
+extern "C" int sc_spectra_from_planes_f32(const void* d_P, const sc_spectra_desc* desc, const float* d_scale, void* d_X, void* stream) {
     ScTimed timed_("spectra_from_planes", stream);
-    return planes_conv(d_X, desc, const_cast<void*>(d_P), false, stream);
+    return planes_conv(d_X, desc, d_scale, const_cast<void*>(d_P), false, stream);
 }
 
 // ---- the kernel ------------------------------------------------------------------------------------------------------------
 struct Fused2Args {
     FusedArgs f;                  // record, map, tiles of the CSM waves, split; f.st.n_obs / f.st.ax as in sc_fused.hip (strides in ROWS)
     const unsigned char* P;       // planes-format spectra, dense rows [F][W][R][K]
-    int64_t row_bytes;            // bytes per observation row (384 per 32-channel tile)
+    const float* inv_scale;       // [C] 1 / scale of the record's channels
+    int64_t row_bytes;            // bytes per observation row (256 per 32-channel tile)
     int64_t obs_rows;             // rows between consecutive observations of a bin (linear: checked on the host)
+    int terms4;                   // 1: the CSM products keep the m m term (few observations per bin: its error does not average out)
 };
 
-__device__ __forceinline__ s16x4 f2_tr(lds_u8* base, int off) {
-    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + off));
+__device__ __forceinline__ h16x4 f2_tr(lds_u8* base, int off) {
+    return __builtin_bit_cast(h16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + off)));
 }
-// operand fragment of v_mfma_f32_16x16x32_bf16 (8 K slots per lane): plane p, 16-channel tile s, observations
+// operand fragment of v_mfma_f32_16x16x32_f16 (8 K slots per lane): plane p, observations
 // 8 (2 (g >> 1) + t) + 4 (g & 1) + r  for the two loads t = 0, 1 (g = lane >> 4, r = (lane >> 2) & 3, baked into `base`)
-__device__ __forceinline__ bf16x8 f2_frag(lds_u8* base, int p, int s) {
-    const s16x4 a = f2_tr(base, p * F2_PLANE + s * 32), b = f2_tr(base, p * F2_PLANE + s * 32 + 256);
-    const bf16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+__device__ __forceinline__ h16x8 f2_frag(lds_u8* base, int p) {
+    const h16x4 a = f2_tr(base, p * F2_PLANE), b = f2_tr(base, p * F2_PLANE + 256);
+    const h16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
     return v;
 }
 
-#define F2_MFMA(a, b, c) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#define F2_MFMA(a, b, c) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
 // Every wave has waited for its own HBM -> LDS loads (vmcnt) before it gets here; the barrier itself publishes LDS writes
 // only (a __syncthreads() would also wait for the fold atomics the CSM waves have just sent to L2: ~1 us per chunk).
 #define F2_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
-// Loads of one chunk: wave w (0 .. 11) fills plane w % 6 of the observation groups o7 = 4 (w / 6) .. + 3.  Lane l of an
-// instruction carries observation o7 + 8 (l >> 4), 16-byte piece l & 15 of the 256-byte row (channel tile (l & 15) >> 2).
+// Loads of one chunk (32 instructions of 1 KB): the eight |Im s| waves (4 .. 11; no other memory traffic of theirs is in
+// flight, so their vmcnt counts these loads exactly) fill plane (w - 4) % 4 of the observation groups o7 = 4 ((w - 4) / 4) .. + 3.
+// Lane l of an instruction carries observation o7 + 8 (l >> 4), 16-byte piece l & 15 of the 256-byte row (channel tile
+// (l & 15) >> 2).
 struct F2Loader {
     const unsigned char* src;     // first row of this (bin, part), + the plane offset of this wave (wave-uniform)
     unsigned voff;                // per-lane byte offset inside a chunk (the only per-lane state kept across the chunk loop)
     int lds_off;                  // LDS offset of this wave's first group (plane, o7) inside a buffer (wave-uniform)
-    int o7_0, plane;              // wave-uniform
+    int o7_0, plane;              // wave-uniform; plane < 0: this wave loads nothing
 };
 __device__ __forceinline__ F2Loader f2_loader(const Fused2Args& a, int wave, const unsigned char* part_base) {
     F2Loader L;
     const int lane = fu_lane();
     const int piece = lane & 15, ct = piece >> 2;
-    L.plane = wave % 6;
-    L.o7_0 = 4 * (wave / 6);
+    L.plane = wave >= 4 ? ((wave - 4) & 3) : -1;
+    L.o7_0 = wave >= 4 ? 4 * ((wave - 4) >> 2) : 0;
     L.voff = (unsigned)(8 * (lane >> 4) * a.obs_rows * a.row_bytes + fu_byte(a.f.map.off32, ct) * F2_ROW_TILE + (piece & 3) * 16);
-    L.src = part_base + L.plane * 64;
-    L.lds_off = L.plane * F2_PLANE + L.o7_0 * F2_GROUP;
+    L.src = part_base + (L.plane < 0 ? 0 : L.plane) * 64;
+    // LDS planes: Re h m -> 0 1, Im h m -> 2 3 (-Re h m -> 4 5 are made in f2_finish)
+    L.lds_off = (L.plane < 0 ? 0 : L.plane) * F2_PLANE + L.o7_0 * F2_GROUP;
     return L;
 }
 // o0 = first observation of the chunk (relative to the part's first), n_left = observations left in the part from o0
 __device__ __forceinline__ void f2_issue(const Fused2Args& a, const F2Loader& L, lds_u8* buf, int o0, int n_left) {
+    if (L.plane < 0) return;
     const int lane = fu_lane();                                   // (re-materialised: short live ranges, see fu_lane)
     const int ct = (lane & 15) >> 2;
     const bool lane_ok = ct < a.f.NB32 && fu_byte(a.f.map.n32, ct) > 0;      // this lane's channel tile is staged
@@ -179,16 +292,17 @@ __device__ __forceinline__ void f2_issue(const Fused2Args& a, const F2Loader& L,
         const unsigned char* src = L.src + (int64_t)(o0 + L.o7_0 + i) * a.obs_rows * a.row_bytes;   // wave-uniform
         // Spelled in asm: behind the builtin the compiler's wait-count pass puts s_waitcnt vmcnt(0) in front of the next LDS
         // read of ANY address (it cannot tell the other buffer from this one), i.e. the wave would sit out the loads it has
-        // just issued -- measured: load time and product time simply added up (2.15 + 1.3 + 1.6 ms).  The waves wait for
-        // their own loads explicitly (vmcnt) before f2_finish and the barrier that publishes the buffer.
+        // just issued -- measured: load time and product time simply added up.  The waves wait for their own loads
+        // explicitly (vmcnt) before f2_finish and the barrier that publishes the buffer.
         if (lane_ok && o_first + i < n_left)
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
                          :: "s"((unsigned)reinterpret_cast<uintptr_t>(dst)), "v"(L.voff), "s"(src) : "memory", "m0");
     }
 }
 // After the wave's loads have landed (vmcnt): rows past the end of the part become zeros, and the waves that loaded
-// real-part planes write the negated copies (planes 6 .. 8) -- one xor per 8 coefficients.
+// real-part planes write the negated copies (planes 4, 5) -- one xor per 8 coefficients.
 __device__ __forceinline__ void f2_finish(const F2Loader& L, lds_u8* buf, int n_left) {
+    if (L.plane < 0) return;
     const int lane = fu_lane();
     if (n_left < FU_OC) {                                          // wave-uniform: the last chunk of a part only
 #pragma unroll
@@ -198,23 +312,41 @@ __device__ __forceinline__ void f2_finish(const F2Loader& L, lds_u8* buf, int n_
                 *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(buf + L.lds_off + i * F2_GROUP + 16 * lane) = (u32x4){0u, 0u, 0u, 0u};
         }
     }
-    if (L.plane < 3) {
+    if (L.plane < 2) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             lds_u8* g = buf + L.lds_off + i * F2_GROUP + 16 * lane;
             u32x4 v = *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(g);
             v[0] ^= 0x80008000u; v[1] ^= 0x80008000u; v[2] ^= 0x80008000u; v[3] ^= 0x80008000u;
-            *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(g + 6 * F2_PLANE) = v;
+            *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(g + 4 * F2_PLANE) = v;
         }
+    }
+}
+
+// instructions f2_issue really sends for a chunk with n_left observations (an instruction whose lanes are all past the end
+// is skipped): what vmcnt has to leave outstanding when the chunk BEHIND the awaited one is in flight too
+__device__ __forceinline__ int f2_issued(const F2Loader& L, int n_left) {
+    if (L.plane < 0) return 0;
+    const int k = n_left - L.o7_0;
+    return k < 0 ? 0 : (k > 4 ? 4 : k);
+}
+__device__ __forceinline__ void f2_wait_loads(int outstanding) {
+    switch (outstanding) {
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
 }
 
 static_assert(2 * 4 + 1 <= FU_FLUSH, "one fold slot per tile of a wave");
 // Matrix-core role: wave w owns the tiles fu_assign_rows gave it (tile rows w and R - 1 - w of the triangle).  Per tile and
-// chunk 24 v_mfma_f32_16x16x32_bf16: six leading cross terms x {Re Re, Im Im, Im Re, (-Re) Im}; every operand fragment is two
-// transposing LDS loads, no VALU.
+// chunk 12 v_mfma_f32_16x16x32_f16: the cross terms h h, h m, m h x {Re Re, Im Im, Im Re, (-Re) Im} (16 with the m m term);
+// every operand fragment is two transposing LDS loads, no VALU.
 template <int NB32>
-__device__ __forceinline__ void f2_mfma_role(const Fused2Args& a, lds_u8* lds, const F2Loader& L, int wave, float* rec, int n_part) {
+__device__ __forceinline__ void f2_mfma_role(const Fused2Args& a, lds_u8* lds, const unsigned char* lds_generic, const F2Loader& L,
+                                             int wave, float* rec, int n_part) {
     const FusedArgs& p = a.f;
     constexpr int MAXS = 2 * NB32 + 1;
     const unsigned sg = (unsigned)__builtin_amdgcn_readfirstlane((int)(wave == 0 ? p.seg0 : (wave == 1 ? p.seg1 : (wave == 2 ? p.seg2 : p.seg3))));
@@ -229,18 +361,15 @@ __device__ __forceinline__ void f2_mfma_role(const Fused2Args& a, lds_u8* lds, c
     float* out = rec + (int64_t)p.csm_plane * p.n_tiles * SC_TILE_ELEMS;
     const bool do_csm = p.csm_plane >= 0 && (p.debug_skip & 1) == 0;
     const bool loads = !(p.debug_skip & 8);
+    const bool t4 = a.terms4 != 0;
     for (int ch = 0; ch < n_chunks; ++ch) {
-        lds_u8* cur = lds + (loads ? (ch & 1) : 0) * F2_BUF;
-        lds_u8* nxt = lds + ((ch + 1) & 1) * F2_BUF;
-        const bool more = ch + 1 < n_chunks && loads;
-        if (more) f2_issue(a, L, nxt, (ch + 1) * FU_OC, n_part - (ch + 1) * FU_OC);
+        lds_u8* cur = lds + (loads ? (ch % F2_NBUF) : 0) * F2_BUF;
         if (do_csm && total > 0) {
             int rA = rA_, rB = rB_, nA = nA_, cA = cA_, cB = cB_;
             asm volatile("" : "+s"(rA), "+s"(rB), "+s"(nA), "+s"(cA), "+s"(cB));
             const int lane = fu_lane(), g = lane >> 4;
-            lds_u8* b0 = cur + ((4 * (g & 1) + ((lane >> 2) & 3)) * F2_GROUP + 2 * (g >> 1) * 256 + (lane & 3) * 8);   // planes 0 .. 5
-            lds_u8* b6 = b0 + 6 * F2_PLANE;                                                                            // planes 6 .. 8
-            bf16x8 arh, arm, arl, aih, aim, ail, nrh, nrm, nrl;
+            lds_u8* b0 = cur + ((4 * (g & 1) + ((lane >> 2) & 3)) * F2_GROUP + 2 * (g >> 1) * 256 + (lane & 3) * 8);
+            h16x8 arh, arm, aih, aim, nrh, nrm;
 #pragma unroll
             for (int s = 0; s < MAXS; ++s) {
                 if (s < total) {
@@ -249,36 +378,27 @@ __device__ __forceinline__ void f2_mfma_role(const Fused2Args& a, lds_u8* lds, c
                     const int col = in_a ? cA + s : cB + (s - nA);
                     if (s == 0 || s == nA) {
                         lds_u8* fa = b0 + row * 32;
-                        lds_u8* fn = b6 + row * 32;
-                        arh = f2_frag(fa, 0, 0); arm = f2_frag(fa, 1, 0); arl = f2_frag(fa, 2, 0);
-                        aih = f2_frag(fa, 3, 0); aim = f2_frag(fa, 4, 0); ail = f2_frag(fa, 5, 0);
-                        nrh = f2_frag(fn, 0, 0); nrm = f2_frag(fn, 1, 0); nrl = f2_frag(fn, 2, 0);
+                        arh = f2_frag(fa, 0); arm = f2_frag(fa, 1); aih = f2_frag(fa, 2); aim = f2_frag(fa, 3);
+                        nrh = f2_frag(fa, 4); nrm = f2_frag(fa, 5);
                     }
                     lds_u8* fb = b0 + col * 32;
-                    const bf16x8 cbrh = f2_frag(fb, 0, 0), cbih = f2_frag(fb, 3, 0), cbrm = f2_frag(fb, 1, 0), cbim = f2_frag(fb, 4, 0);
-                    const bf16x8 cbrl = f2_frag(fb, 2, 0), cbil = f2_frag(fb, 5, 0);
-                    // six leading terms of (h+m+l)(h+m+l): hh hm mh mm hl lh;  Re += ar*br + ai*bi ; Im += ai*br + (-ar)*bi
-                    F2_MFMA(arh, cbrh, re[s]);  F2_MFMA(aih, cbrh, im[s]);
-                    F2_MFMA(aih, cbih, re[s]);  F2_MFMA(nrh, cbih, im[s]);
-                    F2_MFMA(arh, cbrm, re[s]);  F2_MFMA(aih, cbrm, im[s]);
-                    F2_MFMA(aih, cbim, re[s]);  F2_MFMA(nrh, cbim, im[s]);
-                    F2_MFMA(arm, cbrh, re[s]);  F2_MFMA(aim, cbrh, im[s]);
-                    F2_MFMA(aim, cbih, re[s]);  F2_MFMA(nrm, cbih, im[s]);
-                    F2_MFMA(arm, cbrm, re[s]);  F2_MFMA(aim, cbrm, im[s]);
-                    F2_MFMA(aim, cbim, re[s]);  F2_MFMA(nrm, cbim, im[s]);
-                    F2_MFMA(arh, cbrl, re[s]);  F2_MFMA(aih, cbrl, im[s]);
-                    F2_MFMA(aih, cbil, re[s]);  F2_MFMA(nrh, cbil, im[s]);
-                    F2_MFMA(arl, cbrh, re[s]);  F2_MFMA(ail, cbrh, im[s]);
-                    F2_MFMA(ail, cbih, re[s]);  F2_MFMA(nrl, cbih, im[s]);
+                    const h16x8 brh = f2_frag(fb, 0), bih = f2_frag(fb, 2), brm = f2_frag(fb, 1), bim = f2_frag(fb, 3);
+                    // Re += ar*br + ai*bi ; Im += ai*br + (-ar)*bi   for the piece pairs h h, h m, m h (, m m)
+                    F2_MFMA(arh, brh, re[s]);  F2_MFMA(aih, brh, im[s]);
+                    F2_MFMA(aih, bih, re[s]);  F2_MFMA(nrh, bih, im[s]);
+                    F2_MFMA(arh, brm, re[s]);  F2_MFMA(aih, brm, im[s]);
+                    F2_MFMA(aih, bim, re[s]);  F2_MFMA(nrh, bim, im[s]);
+                    F2_MFMA(arm, brh, re[s]);  F2_MFMA(aim, brh, im[s]);
+                    F2_MFMA(aim, bih, re[s]);  F2_MFMA(nrm, bih, im[s]);
+                    if (t4) {
+                        F2_MFMA(arm, brm, re[s]);  F2_MFMA(aim, brm, im[s]);
+                        F2_MFMA(aim, bim, re[s]);  F2_MFMA(nrm, bim, im[s]);
+                    }
                 }
             }
         }
-        if (more) {       // (ahead of the fold: its atomics then travel under the next chunk)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            f2_finish(L, nxt, n_part - (ch + 1) * FU_OC);
-        }
         // two-level summation exactly as in sc_fused.hip: a tile's accumulators are folded into the record every FU_FLUSH
-        // chunks (512 observations), the tiles taking turns
+        // chunks (512 observations), the tiles taking turns; the channel scales (powers of two) come out here, exactly
         {
             const bool last = ch + 1 == n_chunks;
 #pragma unroll
@@ -294,15 +414,20 @@ __device__ __forceinline__ void f2_mfma_role(const Fused2Args& a, lds_u8* lds, c
                     float* o_im = o_re + (int64_t)p.n_tiles * SC_TILE_ELEMS;
                     const unsigned fl = (unsigned)fu_lane();
                     const unsigned base_idx = (fl >> 4) * 64u + (fl & 15u);
+                    // this lane's four entries: rows 4 (lane >> 4) + r, column lane & 15 of the tile
+                    const float* isc = reinterpret_cast<const float*>((const unsigned char*)lds_generic + F2_SCALE_OFF);
+                    const float sj = isc[col * 16 + (int)(fl & 15u)];
+                    const f32x4 si = *reinterpret_cast<const f32x4*>(isc + row * 16 + 4 * (int)(fl >> 4));
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const unsigned idx = base_idx + 16u * r;
+                        const float sc = sj * si[r];
                         if (first) {
-                            o_re[idx] = re[s][r];
-                            o_im[idx] = im[s][r];
+                            o_re[idx] = re[s][r] * sc;
+                            o_im[idx] = im[s][r] * sc;
                         } else {
-                            unsafeAtomicAdd(o_re + idx, re[s][r]);
-                            unsafeAtomicAdd(o_im + idx, im[s][r]);
+                            unsafeAtomicAdd(o_re + idx, re[s][r] * sc);
+                            unsafeAtomicAdd(o_im + idx, im[s][r] * sc);
                         }
                     }
                     re[s] = (f32x4){0.f, 0.f, 0.f, 0.f}; im[s] = re[s];
@@ -315,7 +440,7 @@ __device__ __forceinline__ void f2_mfma_role(const Fused2Args& a, lds_u8* lds, c
     for (int half = wps >> 1; half >= 1; half >>= 1) { __syncthreads(); __syncthreads(); }
 }
 
-// |Im s| role: per observation row and 32x32 channel block ONE v_mfma_f32_32x32x8_bf16_1k with C = 0 (K = 8 slots: lanes
+// |Im s| role: per observation row and 32x32 channel block ONE v_mfma_f32_32x32x8_f16 with C = 0 (K = 8 slots: lanes
 // 0-31 carry the four cross terms h.h h.m m.h m.m of Im x_i Re x_j, lanes 32-63 those of (-Re x_i) Im x_j), then
 // acc += |d|.  An operand is ONE transposing load whose four rows are planes of one observation:
 //   A (row channel i):  planes [h h m m] of Im (lanes 0-31) / -Re (lanes 32-63)
@@ -338,14 +463,15 @@ __device__ __forceinline__ void f2_valu_body(const Fused2Args& a, lds_u8* lds, u
     const bool compute = !(p.debug_skip & 2) && p.abs_plane >= 0;
     const int rpw = 8 / wps;                       // observation rows of an 8-row group this wave takes (1 or 2)
     for (int ch = 0; ch < n_chunks; ++ch) {
-        lds_u8* cur = lds + (loads ? (ch & 1) : 0) * F2_BUF;
-        lds_u8* nxt = lds + ((ch + 1) & 1) * F2_BUF;
-        const bool more = ch + 1 < n_chunks && loads;
-        if (more) f2_issue(a, L, nxt, (ch + 1) * FU_OC, n_part - (ch + 1) * FU_OC);
+        lds_u8* cur = lds + (loads ? (ch % F2_NBUF) : 0) * F2_BUF;
+        lds_u8* nxt = lds + ((ch + 1) % F2_NBUF) * F2_BUF;
+        const bool more = ch + 1 < n_chunks && loads, more2 = ch + 2 < n_chunks && loads;
+        // chunk ch + 2 into the buffer chunk ch - 1 was multiplied from (every wave is past that chunk's barrier)
+        if (more2) f2_issue(a, L, lds + ((ch + 2) % F2_NBUF) * F2_BUF, (ch + 2) * FU_OC, n_part - (ch + 2) * FU_OC);
         if (compute) {
             const int cl = fu_lane(), hf = cl >> 5, r = (cl >> 2) & 3;
-            const int pA = hf ? (r < 2 ? 6 : 7) : (r < 2 ? 3 : 4);
-            const int pB = hf ? ((r & 1) ? 4 : 3) : ((r & 1) ? 1 : 0);
+            const int pA = hf ? (r < 2 ? 4 : 5) : (r < 2 ? 2 : 3);
+            const int pB = hf ? ((r & 1) ? 3 : 2) : ((r & 1) ? 1 : 0);
             const int common = rsub * rpw * F2_GROUP + ((cl >> 4) & 1) * 32 + (cl & 3) * 8;
             lds_u8* bA = cur + (pA * F2_PLANE + common);
             lds_u8* bB = cur + (pB * F2_PLANE + common);
@@ -356,7 +482,7 @@ __device__ __forceinline__ void f2_valu_body(const Fused2Args& a, lds_u8* lds, u
                 for (int k1 = 0; k1 < rpw; ++k1) {
                     const int ro = k1 * F2_GROUP + j * 256;
                     __builtin_amdgcn_sched_barrier(0);
-                    s16x4 FA[4], FB[4];
+                    h16x4 FA[4], FB[4];
 #pragma unroll
                     for (int b = 0; b < NB32; ++b) {
                         if (Tab::tab.use_i[b]) FA[b] = f2_tr(bA, ro + b * 64);
@@ -365,7 +491,7 @@ __device__ __forceinline__ void f2_valu_body(const Fused2Args& a, lds_u8* lds, u
                     f32x16 dprev;
 #pragma unroll
                     for (int s = 0; s < NBLK; ++s) {
-                        const f32x16 d = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(FA[Tab::tab.bi[s]], FB[Tab::tab.bj[s]], zero, 0, 0, 0);
+                        const f32x16 d = __builtin_amdgcn_mfma_f32_32x32x8f16(FA[Tab::tab.bi[s]], FB[Tab::tab.bj[s]], zero, 0, 0, 0);
                         // software pipeline: the accumulation of block s - 1 is issued AFTER the MFMA of block s
                         __builtin_amdgcn_sched_barrier(0);
                         if (s > 0) fu_accumulate16<OP, (NBLK <= 4)>(acc[s - 1], dprev);
@@ -376,8 +502,8 @@ __device__ __forceinline__ void f2_valu_body(const Fused2Args& a, lds_u8* lds, u
                 }
             }
         }
-        if (more) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (more) {       // chunk ch + 1 has landed once only the loads of chunk ch + 2 are outstanding
+            f2_wait_loads(more2 ? f2_issued(L, n_part - (ch + 2) * FU_OC) : 0);
             f2_finish(L, nxt, n_part - (ch + 1) * FU_OC);
         }
         F2_BARRIER();
@@ -415,13 +541,19 @@ __device__ __forceinline__ void f2_valu_body(const Fused2Args& a, lds_u8* lds, u
 #pragma unroll
         for (int s = 0; s < NBLK; ++s) {
             const int BIs = Tab::tab.bi[s], BJs = Tab::tab.bj[s];
+            const int j = BJs * 32 + i32, tj = j >> 4;
+            const float* isc = reinterpret_cast<const float*>(smem + F2_SCALE_OFF);
+            const float sj = (OP == FU_OP_SIGN) ? 1.f : isc[j];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int i = BIs * 32 + (e & 3) + 8 * (e >> 2) + 4 * hf, j = BJs * 32 + i32;
-                const int ti = i >> 4, tj = j >> 4;
-                if (ti <= tj && fu_tile_ok(p.map, ti) && fu_tile_ok(p.map, tj))
+                const int i = BIs * 32 + (e & 3) + 8 * (e >> 2) + 4 * hf;
+                const int ti = i >> 4;
+                if (ti <= tj && fu_tile_ok(p.map, ti) && fu_tile_ok(p.map, tj)) {
+                    float sc = (OP == FU_OP_SIGN) ? 1.f : sj * isc[i];
+                    if (OP == FU_OP_SQ) sc *= sc;
                     out[(int64_t)sc_tile_index(fu_gt(p.map, ti), fu_gt(p.map, tj), p.map.NBr) * SC_TILE_ELEMS + (i & 15) * 16 +
-                        (j & 15)] = acc[s][e];
+                        (j & 15)] = acc[s][e] * sc;
+                }
             }
         }
     }
@@ -445,16 +577,23 @@ __global__ void __launch_bounds__(FU_THREADS) fused2_kernel(Fused2Args a) {
     lds_u8* lds = (lds_u8*)smem;
     const F2Loader L = f2_loader(a, wave, part_base);
     // slots of channel tiles that are not staged stay zero for good
-    for (int i = tid * 16; i < F2_LDS; i += FU_THREADS * 16)
+    for (int i = tid * 16; i < F2_SCALE_OFF; i += FU_THREADS * 16)
         *reinterpret_cast<u32x4*>(smem + i) = (u32x4){0u, 0u, 0u, 0u};
+    if (tid < 128) {        // staged channel slot -> reciprocal scale of the record's channel (folds read it from LDS)
+        const int gch = fu_byte(p.map.off32, tid >> 5) * 32 + (tid & 31);
+        reinterpret_cast<float*>(smem + F2_SCALE_OFF)[tid] = ((tid >> 5) < p.NB32 && (tid & 31) < fu_byte(p.map.n32, tid >> 5) && gch < p.st.C)
+                                                                 ? a.inv_scale[gch] : 1.f;
+    }
     __syncthreads();
     f2_issue(a, L, lds, 0, n_part);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const bool second = n_part > FU_OC && !(p.debug_skip & 8);
+    if (second) f2_issue(a, L, lds + F2_BUF, FU_OC, n_part - FU_OC);
+    f2_wait_loads(second ? f2_issued(L, n_part - FU_OC) : 0);
     f2_finish(L, lds, n_part);
     F2_BARRIER();
     if (wave < 4) {
         if (p.debug_skip & 32) __builtin_amdgcn_s_setprio(2);
-        f2_mfma_role<NB32>(a, lds, L, wave, rec, n_part);
+        f2_mfma_role<NB32>(a, lds, smem, L, wave, rec, n_part);
     } else {
         if (p.debug_skip & 16) __builtin_amdgcn_s_setprio(2);
         constexpr int NSETS = fu_nsets(NB32, COL_LO, ROW_HI);
@@ -479,10 +618,10 @@ static int fused2_setup(const sc_spectra_desc* desc, uint32_t planes, Fused2Args
     sc_make_axes(&d, &ax);
     SC_REQUIRE(ax.C >= 1 && ax.F >= 1 && ax.n_obs >= 1 && ax.n_groups >= 1, "empty dimension");
     const uint32_t fam = planes & ~(uint32_t)SC_RECORD_F64;
-    if (fam != (SC_PLANE_CSM | SC_PLANE_ABS_IM) || (planes & SC_RECORD_F64) || ax.C > 128 || ax.n_obs < F2_MIN_OBS ||
+    if ((fam != (SC_PLANE_CSM | SC_PLANE_ABS_IM) && fam != SC_PLANE_CSM) || (planes & SC_RECORD_F64) || ax.C > 128 ||
         sc_stage_linear_stride(ax) <= 0) {
-        sc_set_error("planes-format stage B takes CSM + |Im s| records of up to 128 signals with at least %d observations per bin "
-                     "(got planes 0x%x, %d signals, %d observations)", F2_MIN_OBS, planes, ax.C, ax.n_obs);
+        sc_set_error("planes-format stage B takes CSM (+ |Im s|) records of up to 128 signals whose observations are one linear run "
+                     "(got planes 0x%x, %d signals)", planes, ax.C);
         return SC_EUNSUPPORTED;
     }
     Fused2Args& a = *out;
@@ -496,7 +635,7 @@ static int fused2_setup(const sc_spectra_desc* desc, uint32_t planes, Fused2Args
     f.F = ax.F;
     f.floats_per_bin = (int64_t)sc_plane_count(planes) * f.n_tiles * SC_TILE_ELEMS;
     f.csm_plane = sc_plane_offset(planes, SC_PLANE_CSM);
-    f.abs_plane = sc_plane_offset(planes, SC_PLANE_ABS_IM);
+    f.abs_plane = (planes & SC_PLANE_ABS_IM) ? sc_plane_offset(planes, SC_PLANE_ABS_IM) : -1;
     f.sq_plane = -1; f.sign_plane = -1; f.n_fold = 0;
     f.nl_op = FU_OP_ABS;
     f.shape_col_lo = 0; f.shape_row_hi = f.NB32;
@@ -514,6 +653,7 @@ static int fused2_setup(const sc_spectra_desc* desc, uint32_t planes, Fused2Args
     f.n_split = 1; f.ws = nullptr; f.debug_skip = 0;
     a.row_bytes = sc_planes_row_bytes(ax.C);
     a.obs_rows = f.st.obs_stride;
+    a.terms4 = ax.n_obs < 256 ? 1 : 0;
     *ax_out = ax;
     return SC_OK;
 }
@@ -525,10 +665,10 @@ extern "C" int sc_fused2_supported(const sc_spectra_desc* desc, uint32_t planes)
     return rc == SC_OK ? 1 : 0;
 }
 
-extern "C" int sc_fused2_csm_absim_f32(const void* d_P, const sc_spectra_desc* desc, uint32_t planes, float* d_accum,
-                                       void* d_workspace, int64_t workspace_bytes, void* stream) {
+extern "C" int sc_fused2_csm_absim_f32(const void* d_P, const sc_spectra_desc* desc, const float* d_scale, uint32_t planes,
+                                       float* d_accum, void* d_workspace, int64_t workspace_bytes, void* stream) {
     ScTimed timed_("fused_stage_b", stream);
-    SC_REQUIRE(d_P && desc && d_accum, "NULL argument");
+    SC_REQUIRE(d_P && desc && d_accum && d_scale, "NULL argument");
     SC_REQUIRE(((uintptr_t)d_P % 16) == 0, "planes buffer must be 16-byte aligned");
     Fused2Args a;
     ScAxes ax;
@@ -536,10 +676,13 @@ extern "C" int sc_fused2_csm_absim_f32(const void* d_P, const sc_spectra_desc* d
     if (rc != SC_OK) return rc;
     FusedArgs& f = a.f;
     a.P = (const unsigned char*)d_P;
+    a.inv_scale = d_scale + ax.C;
     f.accum = d_accum;
     {
         const char* dbg = getenv("SC_FUSED_DEBUG");
         f.debug_skip = dbg ? atoi(dbg) : 0;
+        const char* t4 = getenv("SC_FUSED2_TERMS");
+        if (t4) a.terms4 = atoi(t4) == 4 ? 1 : 0;
     }
     int S = sc_internal_fused_pick_split(f.n_bins, ax.n_obs);
     const int64_t part_bytes = (int64_t)f.n_bins * f.floats_per_bin * (int64_t)sizeof(float);

@@ -34,6 +34,11 @@ struct MtArgs {
                            // 1 = no HBM stores, 2 = skip both radix-16 passes, 4 = skip the split/store loop,
                            // 8 = every wave takes the store loop with the silent / non-finite channel overrides (A/B of the fast loop),
                            // 16 = plain instead of non-temporal stores (A/B)
+    // planes-format output (sc_fused2.hip: two f16 pieces per real, x * scale[c] = h + m, rows [f][w][r][k] of row_bytes):
+    // when P is set the spectra go there INSTEAD of X
+    unsigned char* P;
+    const float* scale;    // [C] powers of two
+    int64_t row_bytes;
 };
 
 __device__ inline float2 cmul(float2 a, float2 b) {
@@ -114,10 +119,23 @@ extern "C" int sc_debug_mtfft_trace(unsigned long long* out, int reset) {
 #define MT_TICK(slot) do {} while (0)
 #endif
 
+typedef _Float16 mt_h16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned mt_pack_f16(float lo, float hi) {        // two f16 (round to nearest) in one dword
+    const mt_h16x2 v = {(_Float16)lo, (_Float16)hi};
+    return __builtin_bit_cast(unsigned, v);
+}
+// two scaled reals -> the dwords of their leading and trailing f16 pieces (x = h + m to 22 significant bits)
+__device__ __forceinline__ void mt_split2(float x0, float x1, unsigned& h, unsigned& m) {
+    h = mt_pack_f16(x0, x1);
+    const mt_h16x2 hv = __builtin_bit_cast(mt_h16x2, h);
+    m = mt_pack_f16(x0 - (float)hv[0], x1 - (float)hv[1]);
+}
+
 // THREADS: 256 by default.  Long windows (N >= 1024) take 512-thread workgroups -- twice the transforms, so twice the
 // contiguous piece of a frequency row per store group (128 bytes at N = 1024: a full line) -- at the same number of
 // waves per CU; 1024 threads would need 128 registers per lane and spill (measured slower).
-template <int LOG2N, int THREADS = 256>
+template <int LOG2N, int THREADS = 256, bool PL = false>      // PL: planes-format output (its own instantiation: registers)
 __global__ void __launch_bounds__(THREADS, THREADS == 512 ? 2 : (LOG2N <= 8 ? 4 : (LOG2N == 9 ? 3 : (LOG2N >= 11 ? 3 : 1))))
 mtfft16_kernel(MtArgs p) {
     constexpr int N = 1 << LOG2N;
@@ -159,6 +177,7 @@ mtfft16_kernel(MtArgs p) {
     // per-channel transform gives (its measures turn NaN on zero power): the conjugate-symmetry split of a packed pair
     // would leave the rounding noise of its partner there.  One flag per channel of the tile.
     __shared__ int nzf[CT], nbf[CT];       // (plain stores of a constant: many threads may set the same flag)
+    __shared__ float scs[PL ? CT : 1];     // planes format: the channel scales of this tile
 
     const int tid = threadIdx.x;
     if (tid < CT) { nzf[tid] = 0; nbf[tid] = 0; }
@@ -183,6 +202,7 @@ mtfft16_kernel(MtArgs p) {
     const int64_t RC = (int64_t)p.R * C;
     const bool resident = p.kh == p.K;
     const float* xw = p.x + ((int64_t)w * p.step * p.R + r) * C + c0;
+    if constexpr (PL) { if (tid < CT) scs[tid] = (c0 + tid < C) ? p.scale[c0 + tid] : 1.f; }     // (read after the barriers of the detrend)
     const int pf = tid / TPF, i = tid - pf * TPF;     // FFT (channel pair) and butterfly index
     float2* zf = z + pf * ZS;
     const int F = N / 2 + 1;
@@ -572,6 +592,50 @@ mtfft16_kernel(MtArgs p) {
         MT_TICK(2);
         // split the packed pair, store X[f][w][r][k][c..c+1]
         if (p.dbg & 4) continue;
+        if constexpr (PL && !LONG && NF >= 4) {
+            {
+                // Planes format: a thread takes FOUR channel pairs (8 channels) of one frequency, so that every plane leaves
+                // as one 16-byte store (16 lanes = a 256-byte tile row of the four planes): eight LDS reads, the
+                // conjugate-symmetry split, the channel scales, the two-piece f16 split (3 VALU per real).
+                constexpr int NG = NF / 4, FSTEP = THREADS / NG;
+                const int grp = tid % NG, fq = tid / NG, cg = c0 + 8 * grp;
+                const int64_t row0 = ((int64_t)w * p.R + r) * p.K + k, rows_f = (int64_t)p.W * p.R * p.K;
+                const bool in_tile = cg < ((C + 31) & ~31);
+                unsigned char* dst0 = p.P + row0 * p.row_bytes + (cg >> 5) * 256 + ((cg & 31) >> 3) * 16;
+                if (in_tile)
+                for (int f = fq; f <= N / 2; f += FSTEP) {
+                    u32x4_t rh, rm, ih, im;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float2* zp = z + (4 * grp + q) * ZS;
+                        const float2 u1 = zp[PHYS(f)], u2 = zp[PHYS((N - f) & (N - 1))];
+                        float2 A = make_float2(u1.x + u2.x, u1.y - u2.y);       // (Z[f] + conj Z[N-f]) / 2, the half already in the samples
+                        float2 B = make_float2(u1.y + u2.y, u2.x - u1.x);       // (Z[f] - conj Z[N-f]) / (2 i)
+                        if (any_flag) {
+                            const int pp = 2 * (4 * grp + q);
+                            const bool qna = nbf[pp] != 0, qnb = nbf[pp + 1] != 0;
+                            if (!qna && nzf[pp] == 0) A = make_float2(0.f, 0.f);
+                            if (!qnb && nzf[pp + 1] == 0) B = make_float2(0.f, 0.f);
+                            if (qna) A = make_float2(__int_as_float(0x7fc00000), __int_as_float(0x7fc00000));
+                            if (qnb) B = make_float2(__int_as_float(0x7fc00000), __int_as_float(0x7fc00000));
+                        }
+                        unsigned h, m;
+                        const float2 s2 = *reinterpret_cast<const float2*>(scs + 8 * grp + 2 * q);
+                        mt_split2(A.x * s2.x, B.x * s2.y, h, m);
+                        rh[q] = h; rm[q] = m;
+                        mt_split2(A.y * s2.x, B.y * s2.y, h, m);
+                        ih[q] = h; im[q] = m;
+                    }
+                    if (p.dbg & 1) continue;
+                    unsigned char* dst = dst0 + (int64_t)f * rows_f * p.row_bytes;
+                    *reinterpret_cast<u32x4_t*>(dst) = rh;
+                    *reinterpret_cast<u32x4_t*>(dst + 64) = rm;
+                    *reinterpret_cast<u32x4_t*>(dst + 128) = ih;
+                    *reinterpret_cast<u32x4_t*>(dst + 192) = im;
+                }
+                continue;
+            }
+        }
         float2* Xk = p.X + (((int64_t)w * p.R + r) * p.K + k) * C + c0;
         // F * NF = 8 * 256 + NF outputs: eight full rounds (LDS reads batched four at a time ahead of the stores) and
         // the Nyquist row on the first NF threads.
@@ -652,8 +716,8 @@ extern "C" int sc_fft_twiddles_f32(int64_t N, void* d_tw, void* stream) {
     return SC_OK;
 }
 
-template <int LOG2N, int THREADS = 256>
-static int launch_mt16(const MtArgs& a_in, hipStream_t stream) {
+template <int LOG2N, int THREADS = 256, bool PL = false>
+static int launch_mt16_(const MtArgs& a_in, hipStream_t stream) {
     constexpr int N = 1 << LOG2N;
     constexpr int TPF = N / 16, NF = THREADS / TPF, CT = 2 * NF;
     constexpr bool LONG = LOG2N >= 11;
@@ -670,7 +734,7 @@ static int launch_mt16(const MtArgs& a_in, hipStream_t stream) {
     a.kh = (all <= cu_lds && cu_lds / all == cu_lds / one) ? a.K : 1;
     { const char* d = getenv("SC_MTFFT_DEBUG"); a.dbg = d ? atoi(d) : 0; }
     const size_t shmem = a.kh == a.K ? all : one;
-    auto k = mtfft16_kernel<LOG2N, THREADS>;
+    auto k = mtfft16_kernel<LOG2N, THREADS, PL>;
     if constexpr (LOG2N < 11) SC_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     if constexpr (LOG2N >= 11) {
         // long windows: row-major spectra of a range of trials into a stream-ordered scratch (<= 2 GB), then one tiled
@@ -723,6 +787,12 @@ static int launch_mt16(const MtArgs& a_in, hipStream_t stream) {
     hipLaunchKernelGGL(k, grid, dim3(THREADS), shmem, stream, a);
     SC_CHECK_HIP(hipGetLastError());
     return SC_OK;
+}
+
+template <int LOG2N, int THREADS = 256>
+static int launch_mt16(const MtArgs& a, hipStream_t stream) {
+    if constexpr (LOG2N <= 10) { if (a.P) return launch_mt16_<LOG2N, THREADS, true>(a, stream); }
+    return launch_mt16_<LOG2N, THREADS, false>(a, stream);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -1231,6 +1301,10 @@ static int mt_wide() {
     return e ? atoi(e) : 1;
 }
 
+extern "C" int sc_multitaper_fft_planes_supported(int64_t L, int64_t N, int64_t C) {
+    return (L >= 1 && L <= N && N >= 64 && N <= 1024 && (N & (N - 1)) == 0 && C >= 2 && (C % 2) == 0) ? 1 : 0;
+}
+
 extern "C" int sc_multitaper_fft_supported(int64_t L, int64_t N) {
     if (L < 1 || L > N) return 0;
     if (N >= 64 && N <= 4096 && (N & (N - 1)) == 0) return 1;      // radix-16 kernel
@@ -1238,11 +1312,12 @@ extern "C" int sc_multitaper_fft_supported(int64_t L, int64_t N) {
     return mx_radices(N, radix) > 0 ? 1 : 0;                          // mixed-radix kernel: 2^a 3^b 5^c up to 2048
 }
 
-extern "C" int sc_multitaper_fft_f32(const float* d_x, int64_t T, int64_t R, int64_t C, int64_t L,
-                                     int64_t step, int64_t W, int64_t N, const float* d_tapers, int64_t K,
-                                     int detrend_type, const void* d_twiddles, void* d_X, void* stream) {
+// planes != nullptr: the planes-format output of sc_multitaper_fft_planes_f32
+static int mtfft_run(const float* d_x, int64_t T, int64_t R, int64_t C, int64_t L,
+                     int64_t step, int64_t W, int64_t N, const float* d_tapers, int64_t K,
+                     int detrend_type, const void* d_twiddles, void* d_X, void* d_P, const float* d_scale, void* stream) {
     ScTimed timed_("mtfft_fused", stream);
-    SC_REQUIRE(d_x && d_tapers && d_twiddles && d_X, "NULL device pointer");
+    SC_REQUIRE(d_x && d_tapers && d_twiddles && (d_X || d_P), "NULL device pointer");
     SC_REQUIRE(T >= 1 && R >= 1 && C >= 1 && L >= 1 && step >= 1 && W >= 1 && K >= 1, "dimensions must be positive");
     SC_REQUIRE((W - 1) * step + L <= T, "windows exceed the time series");
     SC_REQUIRE(detrend_type >= 0 && detrend_type <= 2, "unknown detrend_type");
@@ -1254,7 +1329,18 @@ extern "C" int sc_multitaper_fft_f32(const float* d_x, int64_t T, int64_t R, int
     }
     MtArgs a{d_x, d_tapers, (const float2*)d_twiddles, (float2*)d_X, (int)T, (int)R, (int)C, (int)L,
              (int)step, (int)W, (int)K, detrend_type};
+    a.P = (unsigned char*)d_P; a.scale = d_scale; a.row_bytes = 256 * ((C + 31) / 32);
     hipStream_t s = (hipStream_t)stream;
+    if (d_P) {
+        if (!sc_multitaper_fft_planes_supported(L, N, C)) {
+            sc_set_error("planes-format multitaper FFT needs an even number of signals and N a power of two in 64 ... 1024 (got C=%lld N=%lld)",
+                         (long long)C, (long long)N);
+            return SC_EUNSUPPORTED;
+        }
+        // workgroups of 16 channels (512 / 1024 samples) write half a 32-channel tile each: a missing half must read as zeros
+        if (N >= 512 && (C % 32) != 0 && (C % 32) <= 16)
+            SC_CHECK_HIP(hipMemsetAsync(d_P, 0, (size_t)((N / 2 + 1) * W * R * K) * (size_t)a.row_bytes, s));
+    }
     if ((N & (N - 1)) != 0) return launch_mixed(a, N, s);
     switch (N) {
     case 64: return launch_mt16<6>(a, s);
@@ -1269,4 +1355,19 @@ extern "C" int sc_multitaper_fft_f32(const float* d_x, int64_t T, int64_t R, int
     case 4096: return mt_wide() && C >= 4 ? launch_mt16<12, 512>(a, s) : launch_mt16<12>(a, s);
     }
     return SC_EUNSUPPORTED;
+}
+
+extern "C" int sc_multitaper_fft_f32(const float* d_x, int64_t T, int64_t R, int64_t C, int64_t L,
+                                     int64_t step, int64_t W, int64_t N, const float* d_tapers, int64_t K,
+                                     int detrend_type, const void* d_twiddles, void* d_X, void* stream) {
+    SC_REQUIRE(d_X, "NULL device pointer");
+    return mtfft_run(d_x, T, R, C, L, step, W, N, d_tapers, K, detrend_type, d_twiddles, d_X, nullptr, nullptr, stream);
+}
+
+extern "C" int sc_multitaper_fft_planes_f32(const float* d_x, int64_t T, int64_t R, int64_t C, int64_t L,
+                                            int64_t step, int64_t W, int64_t N, const float* d_tapers, int64_t K,
+                                            int detrend_type, const void* d_twiddles, const float* d_scale, void* d_P,
+                                            void* stream) {
+    SC_REQUIRE(d_P && d_scale, "NULL device pointer");
+    return mtfft_run(d_x, T, R, C, L, step, W, N, d_tapers, K, detrend_type, d_twiddles, nullptr, d_P, d_scale, stream);
 }

@@ -4,6 +4,7 @@ Nothing here computes on the CPU: every function launches HIP kernels / rocFFT t
 C ABI (include/sc_hip.h) on the current torch stream and returns device tensors.
 """
 import ctypes
+import os
 from ctypes import byref, c_int64, c_void_p
 
 import numpy as np
@@ -94,17 +95,36 @@ class DeviceSpectra:
     stored per row: an odd channel count gets one all-zero channel appended, so that rows stay 16-byte
     aligned and the one-pass stage-B kernels (even channel counts) apply; a record accumulated over C_alloc
     channels IS the record of the first C (same 16 x 16 tiling, the extra row / column lies in tile padding).
+
+    Planes format (float32 engine, round 4): ``P`` holds the same coefficients as two f16 pieces per real number
+    (x * scale[c] = h + m, dense rows [F][W][R][K] of sc_planes_row_bytes(C) bytes: sc_fused2.hip) and ``scale`` the
+    per-channel powers of two (then their reciprocals).  Stage A can write it instead of complex64 (same volume); the
+    CSM / |Im s| accumulation then runs on it directly, and ``X`` is decoded from it on first use by anything else.
     """
 
-    def __init__(self, X, dims, strides, n_fft, real_input, C_alloc=None):
-        self.X = X
+    def __init__(self, X, dims, strides, n_fft, real_input, C_alloc=None, P=None, scale=None):
+        self._X = X
+        self.P, self.scale = P, scale
         self.F, self.W, self.R, self.K, self.C = (int(d) for d in dims)
         self.C_alloc = self.C if C_alloc is None else int(C_alloc)
         assert self.C_alloc in (self.C, self.C + 1) and -(-self.C_alloc // 16) == -(-self.C // 16)
         self.strides = tuple(int(s) for s in strides)
         self.n_fft = int(n_fft)
         self.real_input = bool(real_input)   # negative bins are conj mirrors of positive ones
-        self.f64 = X.dtype == torch.complex128
+        self.f64 = X is not None and X.dtype == torch.complex128
+        self.device = X.device if X is not None else P.device
+
+    @property
+    def X(self):
+        """The complex64 / complex128 coefficients; decoded from the planes format (lossless up to its 22 bits) on first use."""
+        if self._X is None:
+            lib = _lib.load()
+            X = torch.empty((self.F, self.W, self.R, self.K, self.C_alloc), dtype=torch.complex64, device=self.P.device)
+            d = self.desc("trials_tapers", padded=True)
+            _lib.check(lib.sc_spectra_from_planes_f32(_ptr(self.P), byref(d), _ptr(self.scale), _ptr(X), _stream()),
+                       "sc_spectra_from_planes_f32")
+            self._X = X
+        return self._X
 
     def coefficients(self):
         """The spectra as a (F, W, R, K, C) tensor view of a contiguous X (the zero pad channel dropped)."""
@@ -112,10 +132,16 @@ class DeviceSpectra:
 
     def freq_slice(self, f0, f1):
         """The bins [f0, f1) as a view (no copy): same strides, pointer advanced by f0 * stride_freq."""
-        assert 0 <= f0 < f1 <= self.F and self.X.is_contiguous()
-        flat = self.X.view(-1)[f0 * self.strides[0]:]
+        assert 0 <= f0 < f1 <= self.F
+        P = flat = None
+        if self.P is not None:
+            per_bin = self.W * self.R * self.K * int(_lib.load().sc_planes_row_bytes(self.C_alloc))
+            P = self.P[f0 * per_bin:f1 * per_bin]
+        if self._X is not None:
+            assert self._X.is_contiguous()
+            flat = self._X.view(-1)[f0 * self.strides[0]:]
         return DeviceSpectra(flat, (f1 - f0, self.W, self.R, self.K, self.C), self.strides, self.n_fft,
-                             self.real_input, C_alloc=self.C_alloc)
+                             self.real_input, C_alloc=self.C_alloc, P=P, scale=self.scale)
 
     def desc(self, expectation_type, n_freq=None, padded=False):
         """Descriptor of the spectra; ``padded``: with the zero pad channel counted as a signal."""
@@ -126,6 +152,9 @@ class DeviceSpectra:
                            stride_window=sW, stride_trial=sR, stride_taper=sK,
                            reduce_window=int(0 in axes), reduce_trial=int(1 in axes),
                            reduce_taper=int(2 in axes), reserved=0)
+
+
+_taper_abs_sum = {}
 
 
 def twiddles(n_fft, device):
@@ -140,8 +169,18 @@ def twiddles(n_fft, device):
     return tw
 
 
+PLANES_FORMAT_FAMILIES = (_lib.PLANE_CSM, _lib.PLANE_CSM | _lib.PLANE_ABS_IM)   # what sc_fused2.hip accumulates
+
+
+def planes_format_applies(n_window, n_fft, n_alloc, planes_hint):
+    """Does stage A write the planes format for a caller that will ask for the accumulator families ``planes_hint``?"""
+    if planes_hint not in PLANES_FORMAT_FAMILIES or os.environ.get("SC_PLANES_FORMAT", "1") == "0":
+        return False
+    return n_alloc <= 128 and bool(_lib.load().sc_multitaper_fft_planes_supported(n_window, n_fft, n_alloc))
+
+
 def multitaper_spectra(x, tapers_over_fs, n_window, n_step, n_fft, n_windows, detrend_type, mark=None,
-                       use_fused=None, n_signals=None):
+                       use_fused=None, n_signals=None, planes_hint=None):
     """Stage A on device: (T,R,C) float32 tensor -> DeviceSpectra [F][W][R][K][C].
 
     ``tapers_over_fs``: (K, L) float32 device tensor = reference tapers^T / fs
@@ -149,6 +188,9 @@ def multitaper_spectra(x, tapers_over_fs, n_window, n_step, n_fft, n_windows, de
     ``n_signals``: number of real channels when ``x`` already carries the all-zero pad channel of an odd channel count
     (appended on the host before the upload, transforms.Multitaper.device_spectra); a device tensor with an odd channel
     count that arrives unpadded is copied into a padded buffer here (one strided device copy).
+    ``planes_hint``: the accumulator families the caller will ask for first.  CSM (+ |Im s|) of up to 128 signals and a
+    power-of-two window of 64 ... 1024 samples: the spectra are written in the planes format (two f16 pieces per real
+    number, sc_fused2.hip) -- a scan of the series for the channel scales, then the same fused transform.
     """
     lib = _lib.load()
     T, R, C_real = x.shape
@@ -166,6 +208,22 @@ def multitaper_spectra(x, tapers_over_fs, n_window, n_step, n_fft, n_windows, de
     strides = (n_windows * R * K * C, R * K * C, K * C, C)
     if use_fused is None:
         use_fused = bool(lib.sc_multitaper_fft_supported(L, n_fft))
+    if use_fused and planes_format_applies(L, n_fft, C, planes_hint):
+        row_bytes = int(lib.sc_planes_row_bytes(C))
+        P = torch.empty((F * n_windows * R * K * row_bytes,), dtype=torch.uint8, device=x.device)
+        scale = torch.empty((2 * C,), dtype=torch.float32, device=x.device)
+        work = torch.empty((C,), dtype=torch.int32, device=x.device)
+        key = (tapers_over_fs.data_ptr(), tuple(tapers_over_fs.shape))
+        if _taper_abs_sum.get("key") != key:            # max_k sum_n |h_k[n]|: a property of the tapers, not of the data
+            _taper_abs_sum["key"], _taper_abs_sum["value"] = key, float(tapers_over_fs.abs().sum(dim=1).max().item())
+        _lib.check(lib.sc_planes_scales_from_series_f32(_ptr(x), T, R, C, _taper_abs_sum["value"], _ptr(scale), _ptr(work),
+                                                        _stream()), "sc_planes_scales_from_series_f32")
+        _lib.check(lib.sc_multitaper_fft_planes_f32(_ptr(x), T, R, C, L, n_step, n_windows, n_fft, _ptr(tapers_over_fs), K,
+                                                    _lib.DETREND[detrend_type], _ptr(twiddles(n_fft, x.device)), _ptr(scale),
+                                                    _ptr(P), _stream()), "sc_multitaper_fft_planes_f32")
+        if mark:
+            mark("mtfft_fused")
+        return DeviceSpectra(None, (F, n_windows, R, K, C_real), strides, n_fft, real_input=True, C_alloc=C, P=P, scale=scale)
     if use_fused:
         # one kernel: window + detrend + taper + FFT + transposed store (sc_mtfft.hip)
         X = torch.empty((F, n_windows, R, K, C), dtype=torch.complex64, device=x.device)
@@ -301,7 +359,7 @@ def accumulate(spectra, expectation_type, planes, n_freq=None, mark=None, use_fu
     n_bins, fpb, _, n_obs = accum_layout(spectra, expectation_type, planes, n_freq)
     if spectra.f64:
         # float64 engine: fp64 matrix cores for the CSM planes, fp64 VALU for the others, double records
-        accum = _record_tensor(n_bins, fpb, torch.float64, spectra.X.device, row_multiple)
+        accum = _record_tensor(n_bins, fpb, torch.float64, spectra.device, row_multiple)
         which = planes
         if have is not None and have[1].dtype == torch.float64 and have[1].shape[0] == n_bins and (have[0] & planes):
             old_planes, old = have
@@ -318,7 +376,19 @@ def accumulate(spectra, expectation_type, planes, n_freq=None, mark=None, use_fu
         if mark:
             mark("accumulate_f64")
         return accum, n_obs
-    accum = _record_tensor(n_bins, fpb, torch.float32, spectra.X.device, row_multiple)
+    accum = _record_tensor(n_bins, fpb, torch.float32, spectra.device, row_multiple)
+    if spectra.P is not None and use_fused is not False:
+        dp = spectra.desc(expectation_type, n_freq, padded=True)
+        if lib.sc_fused2_supported(byref(dp), planes):
+            # planes format: CSM (+ |Im s|) straight from the f16 pieces stage A wrote (sc_fused2.hip)
+            ws_bytes = int(lib.sc_fused_workspace_bytes(byref(dp), planes))
+            ws = _workspace(ws_bytes, spectra.device)
+            _lib.check(lib.sc_fused2_csm_absim_f32(_ptr(spectra.P), byref(dp), _ptr(spectra.scale), planes, _ptr(accum),
+                                                   _ptr(ws) if ws is not None else None, ws_bytes, _stream()),
+                       "sc_fused2_csm_absim_f32")
+            if mark:
+                mark("fused2_csm_absim")
+            return accum, n_obs
     per_plane_only = use_fused is False        # explicit request (tests): every plane through its separate kernel
     if use_fused is None:
         use_fused = bool(lib.sc_fused_supported(spectra.C_alloc))
@@ -329,7 +399,7 @@ def accumulate(spectra, expectation_type, planes, n_freq=None, mark=None, use_fu
     one_pass = int(lib.sc_fused_planes_covered(byref(d), planes)) if use_fused else 0
     if one_pass:
         ws_bytes = int(lib.sc_fused_workspace_bytes(byref(d), planes))
-        ws = _workspace(ws_bytes, spectra.X.device)
+        ws = _workspace(ws_bytes, spectra.device)
         ws_ptr = _ptr(ws) if ws is not None else None
         if one_pass & _lib.PLANE_CSM:
             # CSM (+ the per-observation |Im s| products, + (Im s)^2): bf16 matrix pipe, or the f32 VALU kernel
@@ -345,7 +415,7 @@ def accumulate(spectra, expectation_type, planes, n_freq=None, mark=None, use_fu
         if one_pass & _lib.PLANE_UNIT:
             # sum s/|s| = the CSM of the unit phasors x/|x|: the same kernels on normalised rows
             sb = int(lib.sc_fused_unit_scratch_bytes(byref(d)))
-            scratch = torch.empty((sb,), dtype=torch.uint8, device=spectra.X.device) if sb else None
+            scratch = torch.empty((sb,), dtype=torch.uint8, device=spectra.device) if sb else None
             _lib.check(lib.sc_fused_unit_ws_f32(_ptr(spectra.X), byref(d), planes, _ptr(accum), ws_ptr, ws_bytes,
                                                 _ptr(scratch) if scratch is not None else None, sb, _stream()),
                        "sc_fused_unit_ws_f32")
@@ -368,7 +438,7 @@ def accumulate(spectra, expectation_type, planes, n_freq=None, mark=None, use_fu
     if nl & _lib.PLANE_UNIT and not per_plane_only:
         # sum s/|s| as the CSM of a normalised copy of the spectra (f32 MFMA) instead of a per-pair rsqrt on the VALU
         sb = int(lib.sc_unit_scratch_bytes(byref(d)))
-        scratch = torch.empty((sb,), dtype=torch.uint8, device=spectra.X.device)
+        scratch = torch.empty((sb,), dtype=torch.uint8, device=spectra.device)
         _lib.check(lib.sc_unit_accumulate_f32(_ptr(spectra.X), byref(d), planes, _ptr(accum), _ptr(scratch), sb,
                                               _stream()), "sc_unit_accumulate_f32")
         nl &= ~_lib.PLANE_UNIT

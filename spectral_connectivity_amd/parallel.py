@@ -177,7 +177,7 @@ def sharded_measures(spectra, planes, which, n_groups=4, dst=0, group=None, mark
     F, W, C = spectra.F, spectra.W, spectra.C
     n_groups = max(1, min(int(n_groups), F))
     main = torch.cuda.current_stream()
-    side = _side_stream(spectra.X.device) if xchg else main
+    side = _side_stream(spectra.device) if xchg else main
     # the measures of every frequency range land in ONE preallocated [W, F, ...] tensor per measure on `dst` (a strided
     # device copy per range), not in a list that is concatenated afterwards
     result = [None for _ in which]

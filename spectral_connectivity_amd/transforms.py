@@ -507,12 +507,22 @@ class Multitaper:
         return self.sampling_frequency / 2
 
     # ---- device path ---------------------------------------------------------------------
-    def device_spectra(self, device=None, precision=None):
+    def check_device_path(self):
+        """What device_spectra checks before it computes anything (Connectivity.from_multitaper defers the transform)."""
+        from . import _lib
+        _lib.require_gpu()
+        if self.detrend_type not in _lib.DETREND:
+            raise ValueError(f"Invalid trend type '{self.detrend_type}' is not supported.\n"
+                             "Valid options are 'linear'/'l', 'constant'/'c' or None.")
+
+    def device_spectra(self, device=None, precision=None, planes_hint=None):
         """Run stage A on the GPU; returns (and caches, per precision) the HBM-resident one-sided spectra.
 
         ``precision``: "float32" -- the fused f32 transform of the headline path (complex64 spectra) -- or "float64" --
         the reference's own arithmetic (float64 windows, tapers and FFT; complex128 spectra).  None: what
-        ``options.precision`` gives for a call without a dtype, i.e. float64 like the reference unless forced."""
+        ``options.precision`` gives for a call without a dtype, i.e. float64 like the reference unless forced.
+        ``planes_hint`` (float32 only): the accumulator families the caller is about to request; see
+        engine.multitaper_spectra (the spectra may then be held as f16 pieces and decoded to complex64 on demand)."""
         from . import options
         if precision is None:
             precision = options.engine_precision(None)
@@ -578,7 +588,8 @@ class Multitaper:
                 h = torch.from_numpy(np.ascontiguousarray(tapers.T / self.sampling_frequency, dtype=np.float32)).to(dev)
                 self._device_spectra[precision] = engine.multitaper_spectra(
                     x, h, self.n_time_samples_per_window, self.n_time_samples_per_step,
-                    self.n_fft_samples, self.n_time_windows, self.detrend_type, n_signals=n_signals)
+                    self.n_fft_samples, self.n_time_windows, self.detrend_type, n_signals=n_signals,
+                    planes_hint=planes_hint)
         return self._device_spectra[precision]
 
     def _complex_device_spectra(self, device, precision):

@@ -1,0 +1,154 @@
+"""Planes format (two f16 pieces per real number, sc_fused2.hip / sc_multitaper_fft_planes_f32): the device format the float32
+engine uses for CSM (+ |Im s|) accumulators of up to 128 signals.  Stage A into the format against the complex64 transform, the
+format's conversions, and stage B on it against the CPU oracle (reference connectivity.py:447-526, :982-1028) -- through the C
+ABI and through the public classes."""
+from ctypes import byref
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+from oracle import spectral_oracle as so                                     # noqa: E402
+from spectral_connectivity_amd import Connectivity, Multitaper, _lib, engine, transforms   # noqa: E402
+
+PLANES = _lib.PLANE_CSM | _lib.PLANE_ABS_IM
+
+
+def _dev():
+    _lib.require_gpu()
+    return torch.device("cuda:0")
+
+
+def _series(T, R, C, seed, offset=0.0):
+    rng = np.random.default_rng(seed)
+    t = np.arange(T) / 1000.0
+    x = rng.standard_normal((T, R, C))
+    x += 0.6 * np.sin(2 * np.pi * 60 * t)[:, None, None] * np.cos(np.arange(C))[None, None, :]
+    x[:, :, 0] *= 250.0                      # a loud channel
+    x[:, :, C - 1] *= 2e-3                   # a quiet one
+    return x + offset
+
+
+@pytest.mark.parametrize("L,step,C,detrend", [(256, 128, 128, "constant"), (128, 64, 20, "linear"), (64, 64, 34, None),
+                                               (512, 256, 16, "constant"), (1024, 1024, 48, "constant")])
+def test_stage_a_planes_decode_to_the_complex64_spectra(L, step, C, detrend):
+    """sc_multitaper_fft_planes_f32 + sc_spectra_from_planes_f32 = sc_multitaper_fft_f32 to the 22 bits of the format."""
+    dev, lib = _dev(), _lib.load()
+    T, R, NW = 2048, 3, 3
+    K = 2 * NW - 1
+    W = (T - L) // step + 1
+    x = torch.from_numpy(_series(T, R, C, seed=L + C).astype(np.float32)).to(dev)
+    tapers = np.asarray(transforms.dpss_windows(L, NW, K)[0])[:K]
+    h = torch.from_numpy(np.ascontiguousarray(tapers * np.sqrt(1000.0) / 1000.0, dtype=np.float32)).to(dev)
+    ref = engine.multitaper_spectra(x, h, L, step, L, W, detrend)
+    sp = engine.multitaper_spectra(x, h, L, step, L, W, detrend, planes_hint=PLANES)
+    assert sp.P is not None and sp._X is None, "the planes format was expected for this shape"
+    X, Xr = sp.X, ref.X
+    scaled_max = (Xr.abs() * sp.scale[:C]).max().item()
+    assert scaled_max < 32768.0, "a coefficient left the range the scales promise"
+    amax = Xr.abs().amax(dim=(0, 1, 2, 3))
+    # per coefficient: 2^-22 relative, or the f16 subnormal step (2^-25 scaled units) for the tiny ones
+    tol = 2.0 ** -22 * Xr.abs() + (2.0 ** -24 / sp.scale[:C])
+    assert bool(((X - Xr).abs() <= tol).all())
+    assert ((X - Xr).abs().amax(dim=(0, 1, 2, 3)) / amax).max().item() < 2.5e-7
+
+
+def test_conversions_are_inverse_and_keep_zero_and_nonfinite_channels():
+    dev, lib = _dev(), _lib.load()
+    F, W, R, K, C = 3, 2, 4, 3, 36
+    g = torch.Generator(device=dev).manual_seed(5)
+    X = torch.view_as_complex(torch.randn((F, W, R, K, C, 2), dtype=torch.float32, device=dev, generator=g))
+    X[..., 7] = 0
+    X[..., 9] *= 1e-12
+    X[..., 11] *= 1e9
+    sp = engine.DeviceSpectra(X, (F, W, R, K, C), (W * R * K * C, R * K * C, K * C, C), 4, True, C_alloc=C)
+    d = sp.desc("trials_tapers")
+    P = torch.zeros((F * W * R * K * lib.sc_planes_row_bytes(C),), dtype=torch.uint8, device=dev)
+    scale = torch.empty((2 * C,), dtype=torch.float32, device=dev)
+    work = torch.empty((C,), dtype=torch.int32, device=dev)
+    _lib.check(lib.sc_planes_scales_from_spectra_f32(X.data_ptr(), F * W * R * K, C, scale.data_ptr(), work.data_ptr(), None), "scales")
+    _lib.check(lib.sc_planes_from_spectra_f32(X.data_ptr(), byref(d), scale.data_ptr(), P.data_ptr(), None), "to planes")
+    Xb = torch.full_like(X, 7.0)
+    _lib.check(lib.sc_spectra_from_planes_f32(P.data_ptr(), byref(d), scale.data_ptr(), Xb.data_ptr(), None), "from planes")
+    torch.cuda.synchronize()
+    s = scale[:C]
+    assert bool((torch.log2(s) == torch.log2(s).round()).all()) and bool((s * scale[C:] == 1).all()), "scales are powers of two"
+    assert float(s[7]) == 1.0 and bool((Xb[..., 7] == 0).all())
+    rel = ((Xb - X).abs() / X.abs().clamp_min(1e-38))
+    assert rel[X.abs() > 0].max().item() < 2.5e-7
+
+
+@pytest.mark.parametrize("C,R,K,expectation", [(128, 12, 7, "trials_tapers"), (100, 90, 7, "trials_tapers"), (20, 3, 3, "trials_tapers"),
+                                                (64, 40, 5, "trials"), (34, 6, 7, "tapers"), (32, 30, 3, "time_trials"), (6, 1, 1, "time")])
+def test_stage_b_on_planes_against_the_oracle(C, R, K, expectation):
+    """The records of sc_fused2_csm_absim_f32 -- read back as E[s] (cross-spectral matrix) and E[Im s] / E[|Im s|] (wPLI) --
+    against float64 NumPy sums of the per-observation cross-spectra (reference connectivity.py:463-526, :982-1028), for
+    channel scales spread over six decades and every expectation type whose observations form one run of rows."""
+    from spectral_connectivity_amd.connectivity import EXPECTATION_AXES
+    dev, lib = _dev(), _lib.load()
+    W, N = 3, 16
+    F = N // 2 + 1
+    rng = np.random.default_rng(C * 7 + R)
+    coef = rng.standard_normal((W, R, K, F, C)) + 1j * rng.standard_normal((W, R, K, F, C))
+    coef = coef + 0.4 * coef[..., :1]                                  # a shared component (before the scales: no cancelling pairs)
+    coef = coef * (0.2 + rng.random(C)) * 10.0 ** rng.integers(-3, 4, C)
+    X = torch.from_numpy(np.ascontiguousarray(np.moveaxis(coef, 3, 0)).astype(np.complex64)).to(dev)     # [F][W][R][K][C]
+    strides = (W * R * K * C, R * K * C, K * C, C)
+    sp = engine.DeviceSpectra(X, (F, W, R, K, C), strides, N, True, C_alloc=C)
+    assert lib.sc_fused2_supported(byref(sp.desc(expectation)), PLANES)
+    P = torch.zeros((F * W * R * K * lib.sc_planes_row_bytes(C),), dtype=torch.uint8, device=dev)
+    scale = torch.empty((2 * C,), dtype=torch.float32, device=dev)
+    work = torch.empty((C,), dtype=torch.int32, device=dev)
+    _lib.check(lib.sc_planes_scales_from_spectra_f32(X.data_ptr(), F * W * R * K, C, scale.data_ptr(), work.data_ptr(), None), "scales")
+    _lib.check(lib.sc_planes_from_spectra_f32(X.data_ptr(), byref(sp.desc("trials_tapers")), scale.data_ptr(), P.data_ptr(), None), "to planes")
+    spp = engine.DeviceSpectra(None, (F, W, R, K, C), strides, N, True, C_alloc=C, P=P, scale=scale)
+    accum, n_obs = engine.accumulate(spp, expectation, PLANES)
+    csm = engine.to_host(engine.measure(accum, C, PLANES, n_obs, _lib.M_CSM)).reshape(-1, F, C, C)
+    wpli = engine.to_host(engine.measure(accum, C, PLANES, n_obs, _lib.M_WPLI)).reshape(-1, F, C, C)
+    c = np.moveaxis(X.cpu().numpy().astype(np.complex128), 0, 3)              # (W, R, K, F, C): the complex64-rounded input
+    axes = tuple(EXPECTATION_AXES[expectation])
+    s = c[..., :, None] * np.conj(c[..., None, :])
+    S = s.mean(axis=axes).reshape(-1, F, C, C)
+    A = np.abs(s.imag).mean(axis=axes).reshape(-1, F, C, C)
+    assert n_obs == int(np.prod([(W, R, K)[a] for a in axes]))
+    P_ = np.sqrt(np.real(np.einsum("gfii->gfi", S)))
+    scale_ij = P_[..., :, None] * P_[..., None, :]
+    assert np.max(np.abs(csm - S) / scale_ij) < 4e-6              # relative to sqrt(P_i P_j): the f32 accumulation's own level
+    ref_wpli = S.imag / np.where(A < np.finfo(float).eps, 1.0, A)
+    off = ~np.eye(C, dtype=bool)
+    assert np.allclose(wpli[..., off], ref_wpli[..., off], rtol=1e-5, atol=4e-6)
+
+
+@pytest.mark.parametrize("dtype", [np.complex64])
+def test_public_classes_take_the_planes_path_and_match_the_oracle(dtype):
+    """Multitaper -> Connectivity(dtype=complex64) on a shape the planes format applies to: coherence and wPLI equal the CPU
+    oracle's, the spectra were held as f16 pieces, and a measure outside the format's reach (PLV) decodes them transparently."""
+    _dev()
+    x = _series(1024, 9, 12, seed=3)
+    m = Multitaper(x, sampling_frequency=1000, time_halfbandwidth_product=3, n_time_samples_per_window=256, n_time_samples_per_step=128)
+    c = Connectivity.from_multitaper(m, dtype=dtype)
+    coh, wpli = c.coherence_magnitude(), c.weighted_phase_lag_index()
+    assert c._spectra.P is not None and c._spectra._X is None
+    coef, _ = so.multitaper_fft(x, fs=1000, NW=3, n_time_samples_per_window=256, n_time_samples_per_step=128)
+    np.testing.assert_allclose(coh, so.coherence_magnitude(coef), rtol=2e-4, atol=2e-5, equal_nan=True)
+    np.testing.assert_allclose(wpli, so.weighted_phase_lag_index(coef), rtol=2e-4, atol=2e-5)
+    plv = c.phase_locking_value()
+    assert c._spectra._X is not None
+    np.testing.assert_allclose(plv, so.phase_locking_value(coef), rtol=2e-4, atol=2e-5, equal_nan=True)
+
+
+def test_planes_switch_gives_the_complex64_path():
+    """SC_PLANES_FORMAT=0: the same call keeps complex64 spectra (the format is a device detail, not an interface)."""
+    import os
+    dev = _dev()
+    x = torch.from_numpy(_series(512, 2, 8, seed=1).astype(np.float32)).to(dev)
+    tapers = np.asarray(transforms.dpss_windows(128, 2, 3)[0])[:3]
+    h = torch.from_numpy(np.ascontiguousarray(tapers / np.sqrt(1000.0), dtype=np.float32)).to(dev)
+    os.environ["SC_PLANES_FORMAT"] = "0"
+    try:
+        sp = engine.multitaper_spectra(x, h, 128, 128, 128, 4, "constant", planes_hint=PLANES)
+    finally:
+        del os.environ["SC_PLANES_FORMAT"]
+    assert sp.P is None and sp._X is not None

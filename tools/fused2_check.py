@@ -24,11 +24,15 @@ def run(C, R, F=5, W=2, K=7, timing=False):
     d = sp.desc("trials_tapers")
     rb = lib.sc_planes_row_bytes(C)
     P = torch.empty((F * W * R * K * rb,), dtype=torch.uint8, device=dev)
-    _lib.check(lib.sc_planes_from_spectra_f32(X.data_ptr(), byref(d), P.data_ptr(), None), "to planes")
+    scale = torch.empty((2 * C,), dtype=torch.float32, device=dev)
+    work = torch.empty((C,), dtype=torch.int32, device=dev)
+    _lib.check(lib.sc_planes_scales_from_spectra_f32(X.data_ptr(), F * W * R * K, C, scale.data_ptr(), work.data_ptr(), None), "scales")
+    _lib.check(lib.sc_planes_from_spectra_f32(X.data_ptr(), byref(d), scale.data_ptr(), P.data_ptr(), None), "to planes")
     Xb = torch.zeros_like(X)
-    _lib.check(lib.sc_spectra_from_planes_f32(P.data_ptr(), byref(d), Xb.data_ptr(), None), "from planes")
+    _lib.check(lib.sc_spectra_from_planes_f32(P.data_ptr(), byref(d), scale.data_ptr(), Xb.data_ptr(), None), "from planes")
     torch.cuda.synchronize()
-    assert torch.equal(torch.view_as_real(X), torch.view_as_real(Xb)), "round trip is not lossless"
+    rt = ((Xb - X).abs() / X.abs().clamp_min(1e-30)).max().item()
+    print(f"    format round trip: max relative error {rt:.2e} (22 significant bits: <= 2.4e-7); scales 2^{torch.log2(scale[:C]).min().item():.0f} .. 2^{torch.log2(scale[:C]).max().item():.0f}")
     ok = lib.sc_fused2_supported(byref(d), planes)
     ref, n_obs = engine.accumulate(sp, "trials_tapers", planes)
     n_bins, fpb, _, _ = engine.accum_layout(sp, "trials_tapers", planes)
@@ -38,16 +42,16 @@ def run(C, R, F=5, W=2, K=7, timing=False):
     ws_bytes = int(lib.sc_fused_workspace_bytes(byref(d), planes))
     ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=dev)
     out = torch.full((n_bins, fpb), float("nan"), dtype=torch.float32, device=dev)
-    _lib.check(lib.sc_fused2_csm_absim_f32(P.data_ptr(), byref(d), planes, out.data_ptr(), ws.data_ptr(), ws_bytes, None), "fused2")
+    _lib.check(lib.sc_fused2_csm_absim_f32(P.data_ptr(), byref(d), scale.data_ptr(), planes, out.data_ptr(), ws.data_ptr(), ws_bytes, None), "fused2")
     torch.cuda.synchronize()
     # fp64 truth of the three planes for the scale of the errors
     Xd = X.to(torch.complex128)
     S = torch.einsum("fwrkc,fwrkd->wfcd", Xd, Xd.conj())                       # [W][F][C][C]
-    absim = torch.einsum("fwrkc,fwrkd->fwrkcd", Xd, Xd.conj()).imag.abs().sum(dim=(2, 3)).permute(1, 0, 2, 3) if C <= 64 else None
+
     nt = fpb // 3 // 256
     a, b = out.view(n_bins, 3, nt, 256), ref.view(n_bins, 3, nt, 256)
     NB = (C + 15) // 16
-    scale = S.abs().amax().item()
+    smax = S.abs().amax().item()
     errs = []
     for pl, name in ((0, "Re S"), (1, "Im S"), (2, "sum |Im s|")):
         # only entries of real channels: compare tile by tile on the valid part
@@ -63,12 +67,12 @@ def run(C, R, F=5, W=2, K=7, timing=False):
                     ta, tb = ta[:, iu[0], iu[1]], tb[:, iu[0], iu[1]]
                 worst = max(worst, (ta - tb).abs().max().item())
                 t += 1
-        errs.append(worst / scale)
+        errs.append(worst / smax)
     print(f"C={C:4d} R={R:5d} n_obs={n_obs:6d}: max |new - old| / max|S| per plane: " + "  ".join(f"{e:.2e}" for e in errs)
           + ("  NaN!" if not torch.isfinite(out).all() else ""))
     if timing:
         for name, fn in (("old (complex64)", lambda: engine.accumulate(sp, "trials_tapers", planes)),
-                         ("new (planes)", lambda: _lib.check(lib.sc_fused2_csm_absim_f32(P.data_ptr(), byref(d), planes, out.data_ptr(), ws.data_ptr(), ws_bytes, None), "fused2"))):
+                         ("new (planes)", lambda: _lib.check(lib.sc_fused2_csm_absim_f32(P.data_ptr(), byref(d), scale.data_ptr(), planes, out.data_ptr(), ws.data_ptr(), ws_bytes, None), "fused2"))):
             ts = []
             for rep in range(12):
                 torch.cuda.synchronize()
@@ -80,7 +84,7 @@ def run(C, R, F=5, W=2, K=7, timing=False):
 
 
 if __name__ == "__main__":
-    for C, R in ((128, 80), (64, 80), (96, 100), (32, 90), (100, 77), (128, 75)):
+    for C, R in ((128, 80), (64, 80), (96, 100), (32, 90), (100, 77), (128, 75), (128, 3), (64, 1), (20, 10)):
         run(C, R)
     run(128, 1000, F=129, W=7, timing=True)
     run(64, 2000, F=129, W=7, timing=True)

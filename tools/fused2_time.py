@@ -24,7 +24,10 @@ for C in (128, 64):
     d = sp.desc("trials_tapers")
     rb = lib.sc_planes_row_bytes(C)
     P = torch.empty((F * W * R * K * rb,), dtype=torch.uint8, device=dev)
-    _lib.check(lib.sc_planes_from_spectra_f32(X.data_ptr(), byref(d), P.data_ptr(), None), "to planes")
+    scale = torch.empty((2 * C,), dtype=torch.float32, device=dev)
+    work = torch.empty((C,), dtype=torch.int32, device=dev)
+    _lib.check(lib.sc_planes_scales_from_spectra_f32(X.data_ptr(), F * W * R * K, C, scale.data_ptr(), work.data_ptr(), None), "scales")
+    _lib.check(lib.sc_planes_from_spectra_f32(X.data_ptr(), byref(d), scale.data_ptr(), P.data_ptr(), None), "to planes")
     n_bins, fpb, _, _ = engine.accum_layout(sp, "trials_tapers", planes)
     ws_bytes = int(lib.sc_fused_workspace_bytes(byref(d), planes))
     ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=dev)
@@ -37,7 +40,7 @@ for C in (128, 64):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             if key[0] == "new":
-                _lib.check(lib.sc_fused2_csm_absim_f32(P.data_ptr(), byref(d), planes, out.data_ptr(), ws.data_ptr(), ws_bytes, None), "fused2")
+                _lib.check(lib.sc_fused2_csm_absim_f32(P.data_ptr(), byref(d), scale.data_ptr(), planes, out.data_ptr(), ws.data_ptr(), ws_bytes, None), "fused2")
             else:
                 engine.accumulate(sp, "trials_tapers", planes)
             torch.cuda.synchronize()
