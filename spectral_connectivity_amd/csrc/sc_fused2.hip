@@ -238,6 +238,7 @@ struct Fused2Args {
     const float* inv_scale;       // [C] 1 / scale of the record's channels
     int64_t row_bytes;            // bytes per observation row (256 per 32-channel tile)
     int64_t obs_rows;             // rows between consecutive observations of a bin (linear: checked on the host)
+    int loader_csm;               // 1: the CSM waves issue the HBM -> LDS loads (8 each), 0: the |Im s| waves (4 each)
     int terms4;                   // 1: the CSM products keep the m m term (few observations per bin: its error does not average out)
 };
 
@@ -266,13 +267,21 @@ struct F2Loader {
     unsigned voff;                // per-lane byte offset inside a chunk (the only per-lane state kept across the chunk loop)
     int lds_off;                  // LDS offset of this wave's first group (plane, o7) inside a buffer (wave-uniform)
     int o7_0, plane;              // wave-uniform; plane < 0: this wave loads nothing
+    int n_inst;                   // observation groups (instructions) per chunk: 4 (eight loader waves) or 8 (four)
 };
 __device__ __forceinline__ F2Loader f2_loader(const Fused2Args& a, int wave, const unsigned char* part_base) {
     F2Loader L;
     const int lane = fu_lane();
     const int piece = lane & 15, ct = piece >> 2;
-    L.plane = wave >= 4 ? ((wave - 4) & 3) : -1;
-    L.o7_0 = wave >= 4 ? 4 * ((wave - 4) >> 2) : 0;
+    if (a.loader_csm) {          // the four CSM waves load (they have the slack: half the matrix work of the first form)
+        L.plane = wave < 4 ? wave : -1;
+        L.o7_0 = 0;
+        L.n_inst = 8;
+    } else {
+        L.plane = wave >= 4 ? ((wave - 4) & 3) : -1;
+        L.o7_0 = wave >= 4 ? 4 * ((wave - 4) >> 2) : 0;
+        L.n_inst = 4;
+    }
     L.voff = (unsigned)(8 * (lane >> 4) * a.obs_rows * a.row_bytes + fu_byte(a.f.map.off32, ct) * F2_ROW_TILE + (piece & 3) * 16);
     L.src = part_base + (L.plane < 0 ? 0 : L.plane) * 64;
     // LDS planes: Re h m -> 0 1, Im h m -> 2 3 (-Re h m -> 4 5 are made in f2_finish)
@@ -287,7 +296,8 @@ __device__ __forceinline__ void f2_issue(const Fused2Args& a, const F2Loader& L,
     const bool lane_ok = ct < a.f.NB32 && fu_byte(a.f.map.n32, ct) > 0;      // this lane's channel tile is staged
     const int o_first = L.o7_0 + 8 * (lane >> 4);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 8; ++i) {
+        if (i >= L.n_inst) break;
         lds_u8* dst = buf + L.lds_off + i * F2_GROUP;             // wave-uniform
         const unsigned char* src = L.src + (int64_t)(o0 + L.o7_0 + i) * a.obs_rows * a.row_bytes;   // wave-uniform
         // Spelled in asm: behind the builtin the compiler's wait-count pass puts s_waitcnt vmcnt(0) in front of the next LDS
@@ -306,7 +316,8 @@ __device__ __forceinline__ void f2_finish(const F2Loader& L, lds_u8* buf, int n_
     const int lane = fu_lane();
     if (n_left < FU_OC) {                                          // wave-uniform: the last chunk of a part only
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 8; ++i) {
+            if (i >= L.n_inst) break;
             const int o = L.o7_0 + i + 8 * (lane >> 4);
             if (o >= n_left)
                 *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(buf + L.lds_off + i * F2_GROUP + 16 * lane) = (u32x4){0u, 0u, 0u, 0u};
@@ -314,7 +325,8 @@ __device__ __forceinline__ void f2_finish(const F2Loader& L, lds_u8* buf, int n_
     }
     if (L.plane < 2) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 8; ++i) {
+            if (i >= L.n_inst) break;
             lds_u8* g = buf + L.lds_off + i * F2_GROUP + 16 * lane;
             u32x4 v = *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(g);
             v[0] ^= 0x80008000u; v[1] ^= 0x80008000u; v[2] ^= 0x80008000u; v[3] ^= 0x80008000u;
@@ -328,10 +340,14 @@ __device__ __forceinline__ void f2_finish(const F2Loader& L, lds_u8* buf, int n_
 __device__ __forceinline__ int f2_issued(const F2Loader& L, int n_left) {
     if (L.plane < 0) return 0;
     const int k = n_left - L.o7_0;
-    return k < 0 ? 0 : (k > 4 ? 4 : k);
+    return k < 0 ? 0 : (k > L.n_inst ? L.n_inst : k);
 }
 __device__ __forceinline__ void f2_wait_loads(int outstanding) {
     switch (outstanding) {
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
     case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
     case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
     case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
@@ -364,6 +380,8 @@ __device__ __forceinline__ void f2_mfma_role(const Fused2Args& a, lds_u8* lds, c
     const bool t4 = a.terms4 != 0;
     for (int ch = 0; ch < n_chunks; ++ch) {
         lds_u8* cur = lds + (loads ? (ch % F2_NBUF) : 0) * F2_BUF;
+        const bool more = ch + 1 < n_chunks && loads, more2 = ch + 2 < n_chunks && loads;
+        if (more2) f2_issue(a, L, lds + ((ch + 2) % F2_NBUF) * F2_BUF, (ch + 2) * FU_OC, n_part - (ch + 2) * FU_OC);
         if (do_csm && total > 0) {
             int rA = rA_, rB = rB_, nA = nA_, cA = cA_, cB = cB_;
             asm volatile("" : "+s"(rA), "+s"(rB), "+s"(nA), "+s"(cA), "+s"(cB));
@@ -396,6 +414,13 @@ __device__ __forceinline__ void f2_mfma_role(const Fused2Args& a, lds_u8* lds, c
                     }
                 }
             }
+        }
+        if (more && L.plane >= 0) {
+            // Chunk ch + 1 has landed once only the loads of chunk ch + 2 are outstanding.  (The fold atomics of the chunk
+            // before sit between the two in this wave's queue: loads return in order, so "at most the loads of ch + 2
+            // outstanding" still means every load of ch + 1 is back; the atomics are a chunk old by now.)
+            f2_wait_loads(more2 ? f2_issued(L, n_part - (ch + 2) * FU_OC) : 0);
+            f2_finish(L, lds + ((ch + 1) % F2_NBUF) * F2_BUF, n_part - (ch + 1) * FU_OC);
         }
         // two-level summation exactly as in sc_fused.hip: a tile's accumulators are folded into the record every FU_FLUSH
         // chunks (512 observations), the tiles taking turns; the channel scales (powers of two) come out here, exactly
@@ -445,7 +470,7 @@ __device__ __forceinline__ void f2_mfma_role(const Fused2Args& a, lds_u8* lds, c
 // acc += |d|.  An operand is ONE transposing load whose four rows are planes of one observation:
 //   A (row channel i):  planes [h h m m] of Im (lanes 0-31) / -Re (lanes 32-63)
 //   B (col channel j):  planes [h m h m] of Re (lanes 0-31) /  Im (lanes 32-63)
-template <int NB32, int COL_LO, int ROW_HI, int SET, int OP>
+template <int NB32, int COL_LO, int ROW_HI, int SET, int OP, int RPW>
 __device__ __forceinline__ void f2_valu_body(const Fused2Args& a, lds_u8* lds, unsigned char* smem, const F2Loader& L, int tid,
                                              int rsub, int wps, float* rec, int n_part) {
     const FusedArgs& p = a.f;
@@ -461,7 +486,7 @@ __device__ __forceinline__ void f2_valu_body(const Fused2Args& a, lds_u8* lds, u
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const bool loads = !(p.debug_skip & 8);
     const bool compute = !(p.debug_skip & 2) && p.abs_plane >= 0;
-    const int rpw = 8 / wps;                       // observation rows of an 8-row group this wave takes (1 or 2)
+    constexpr int rpw = RPW;                       // observation rows of an 8-row group this wave takes (1 or 2)
     for (int ch = 0; ch < n_chunks; ++ch) {
         lds_u8* cur = lds + (loads ? (ch % F2_NBUF) : 0) * F2_BUF;
         lds_u8* nxt = lds + ((ch + 1) % F2_NBUF) * F2_BUF;
@@ -476,30 +501,35 @@ __device__ __forceinline__ void f2_valu_body(const Fused2Args& a, lds_u8* lds, u
             lds_u8* bA = cur + (pA * F2_PLANE + common);
             lds_u8* bB = cur + (pB * F2_PLANE + common);
             // zero rows past the end of the part contribute |0| = 0: no bound needed
-#pragma unroll 1
-            for (int j = 0; j < 4; ++j) {
-#pragma unroll 2
-                for (int k1 = 0; k1 < rpw; ++k1) {
-                    const int ro = k1 * F2_GROUP + j * 256;
-                    __builtin_amdgcn_sched_barrier(0);
-                    h16x4 FA[4], FB[4];
+            // The wave's rows t = 0 .. 4 rpw - 1 (observation 8 (t / rpw) + rsub rpw + t % rpw): the operand fragments of row
+            // t + 1 are requested before row t is multiplied, so no row starts with a wait for the LDS.
+            constexpr int NR = 4 * RPW;
+            h16x4 FA[2][4], FB[2][4];
+            auto fetch = [&](int t, int w) {
+                const int ro = (t % RPW) * F2_GROUP + (t / RPW) * 256;
 #pragma unroll
-                    for (int b = 0; b < NB32; ++b) {
-                        if (Tab::tab.use_i[b]) FA[b] = f2_tr(bA, ro + b * 64);
-                        if (Tab::tab.use_j[b]) FB[b] = f2_tr(bB, ro + b * 64);
-                    }
-                    f32x16 dprev;
-#pragma unroll
-                    for (int s = 0; s < NBLK; ++s) {
-                        const f32x16 d = __builtin_amdgcn_mfma_f32_32x32x8f16(FA[Tab::tab.bi[s]], FB[Tab::tab.bj[s]], zero, 0, 0, 0);
-                        // software pipeline: the accumulation of block s - 1 is issued AFTER the MFMA of block s
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (s > 0) fu_accumulate16<OP, (NBLK <= 4)>(acc[s - 1], dprev);
-                        dprev = d;
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    fu_accumulate16<OP, (NBLK <= 4)>(acc[NBLK - 1], dprev);
+                for (int b = 0; b < NB32; ++b) {
+                    if (Tab::tab.use_i[b]) FA[w][b] = f2_tr(bA, ro + b * 64);
+                    if (Tab::tab.use_j[b]) FB[w][b] = f2_tr(bB, ro + b * 64);
                 }
+            };
+            fetch(0, 0);
+#pragma unroll
+            for (int t = 0; t < NR; ++t) {
+                const int w = t & 1;
+                __builtin_amdgcn_sched_barrier(0);
+                if (t + 1 < NR) fetch(t + 1, w ^ 1);
+                f32x16 dprev;
+#pragma unroll
+                for (int s = 0; s < NBLK; ++s) {
+                    const f32x16 d = __builtin_amdgcn_mfma_f32_32x32x8f16(FA[w][Tab::tab.bi[s]], FB[w][Tab::tab.bj[s]], zero, 0, 0, 0);
+                    // software pipeline: the accumulation of block s - 1 is issued AFTER the MFMA of block s
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (s > 0) fu_accumulate16<OP, (NBLK <= 4)>(acc[s - 1], dprev);
+                    dprev = d;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                fu_accumulate16<OP, (NBLK <= 4)>(acc[NBLK - 1], dprev);
             }
         }
         if (more) {       // chunk ch + 1 has landed once only the loads of chunk ch + 2 are outstanding
@@ -600,10 +630,10 @@ __global__ void __launch_bounds__(FU_THREADS) fused2_kernel(Fused2Args a) {
         constexpr int wps = 8 / NSETS;
         const int vw = wave - 4, set = vw / wps, rsub = vw % wps;
         if constexpr (NSETS == 1) {
-            f2_valu_body<NB32, COL_LO, ROW_HI, 0, OP>(a, lds, smem, L, tid, rsub, wps, rec, n_part);
+            f2_valu_body<NB32, COL_LO, ROW_HI, 0, OP, 8 / wps>(a, lds, smem, L, tid, rsub, wps, rec, n_part);
         } else {
-            if (set == 0) f2_valu_body<NB32, COL_LO, ROW_HI, 0, OP>(a, lds, smem, L, tid, rsub, wps, rec, n_part);
-            else f2_valu_body<NB32, COL_LO, ROW_HI, 1, OP>(a, lds, smem, L, tid, rsub, wps, rec, n_part);
+            if (set == 0) f2_valu_body<NB32, COL_LO, ROW_HI, 0, OP, 8 / wps>(a, lds, smem, L, tid, rsub, wps, rec, n_part);
+            else f2_valu_body<NB32, COL_LO, ROW_HI, 1, OP, 8 / wps>(a, lds, smem, L, tid, rsub, wps, rec, n_part);
         }
     }
 }
@@ -654,6 +684,7 @@ static int fused2_setup(const sc_spectra_desc* desc, uint32_t planes, Fused2Args
     a.row_bytes = sc_planes_row_bytes(ax.C);
     a.obs_rows = f.st.obs_stride;
     a.terms4 = ax.n_obs < 256 ? 1 : 0;
+    a.loader_csm = f.NB32 >= 3 ? 1 : 0;      // measured (cfg3 volume): 128 channels 3.71 vs 3.82 ms with the CSM waves loading, 64 channels 3.23 vs 2.98
     *ax_out = ax;
     return SC_OK;
 }
@@ -683,6 +714,8 @@ extern "C" int sc_fused2_csm_absim_f32(const void* d_P, const sc_spectra_desc* d
         f.debug_skip = dbg ? atoi(dbg) : 0;
         const char* t4 = getenv("SC_FUSED2_TERMS");
         if (t4) a.terms4 = atoi(t4) == 4 ? 1 : 0;
+        const char* ld = getenv("SC_FUSED2_LOADER");           // A/B: "abs" = the |Im s| waves load
+        if (ld) a.loader_csm = (ld[0] == 'a') ? 0 : 1;
     }
     int S = sc_internal_fused_pick_split(f.n_bins, ax.n_obs);
     const int64_t part_bytes = (int64_t)f.n_bins * f.floats_per_bin * (int64_t)sizeof(float);
