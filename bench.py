@@ -8,7 +8,8 @@ F=129), coherence_magnitude + weighted_phase_lag_index, expectation over trials 
 
 One "step" = one full pass of the hot path over the synthetic batch, inputs resident in HBM:
   stage A  window + detrend + taper + FFT + transposed store, one fused HIP kernel (mtfft16_kernel)
-  stage B  cross-spectral accumulation AND the per-observation |Im s| plane on the bf16 matrix pipe, one pass
+  stage B  cross-spectral accumulation AND the per-observation |Im s| plane on the 16-bit matrix pipe, one pass
+           (round 4: stage A stores every coefficient as two f16 pieces, stage B multiplies three cross terms: sc_fused2.hip)
   (N>1)    reduce-scatter of the accumulator records over RCCL
   stage C  coherence + wPLI epilogue on the owned bins, (N>1) gather of the measures on rank 0
 N GPUs: the 1000 trials are sharded over the ranks (strong scaling), one process per GPU.  `python bench.py --gpus N`
@@ -24,6 +25,7 @@ kernel (durations from HIP events on the launch stream) and `cpu_baseline` (the 
 oracle's faithful per-observation path, single core, on a bounded sample).
 """
 import argparse
+from ctypes import byref, c_double
 import json
 import os
 import sys
@@ -48,14 +50,14 @@ F64_PEAK_TFLOPS = 78.6        # fp64 vector = fp64 matrix rate
 # from the committed summary of the rocprofv3 --pmc passes over THIS command (tools/profile_round.py writes it next to
 # the kernel-trace stats; it records the source hash of the kernels it measured) and is null when that file is
 # missing or was measured on other kernel sources.
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_hbm_traffic.json")
 
 
 def kernel_source_hash():
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "spectral_connectivity_amd", "csrc")
-    for name in ("sc_fused.hip", "sc_mtfft.hip", "sc_measure.hip", "sc_stage.h", "sc_common.h"):
+    for name in ("sc_fused.hip", "sc_fused2.hip", "sc_fused_common.h", "sc_mtfft.hip", "sc_measure.hip", "sc_stage.h", "sc_common.h"):
         with open(os.path.join(csrc, name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -67,7 +69,7 @@ def measured_traffic(config, stage):
     except (OSError, ValueError):
         return None, None
     if rec.get("kernel_source_hash") != kernel_source_hash():
-        return None, "profiles/r03_hbm_traffic.json was measured on other kernel sources"
+        return None, "profiles/r04_hbm_traffic.json was measured on other kernel sources"
     v = rec.get(config, {}).get(stage)
     return (float(v) if v is not None else None), rec.get("source")
 
@@ -391,11 +393,18 @@ def main():
     sync()
     _lib.timing_enable(True)                  # hipEvent pairs inside the library from here on (sc_timing.hip)
     exchange = [] if world > 1 else None
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]     # per-step times for the median (no sync inside)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         one_step(x, h, cfg, geom, planes, world, exchange)
+        marks[i + 1].record()
     sync()
     elapsed = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
+    clock = c_double(0.0)
+    _lib.load().sc_debug_fused2_clock(byref(clock))          # in-kernel cycle / real-time counters of the last stage-B launch
     timing = _lib.last_timing()
     _lib.timing_enable(False)
     if world > 1:
@@ -415,6 +424,7 @@ def main():
     # algorithmic work per launch on this rank (DESIGN.md "Roofline")
     stage_model = {
         "mtfft_fused": ("hbm", 4.0 * T * R_loc * C + 8.0 * F * W * R_loc * K * C),
+        "planes_scales": ("hbm", 4.0 * T * R_loc * C),          # the scan of the series for the f16 scales
         "taper_windows": ("hbm", 4.0 * T * R_loc * C + 4.0 * N * W * R_loc * K * C),
         "rocfft_r2c": ("hbm", 4.0 * N * W * R_loc * K * C + 8.0 * F * W * R_loc * K * C),
         "fused_stage_b": ("mfma", 8.0 * n_obs_loc * (C * (C + 1) / 2) * W * F),
@@ -440,7 +450,7 @@ def main():
                 "frac": round(wk / d / 1e9 / HBM_PEAK_GBS, 4)}
 
     traffic, traffic_src = measured_traffic(args.config, dominant) if world == 1 else (None, None)
-    KERNEL_OF = {"fused_stage_b": "fused_csm_absim_kernel (+ fused_combine_kernel)", "mtfft_fused": "mtfft16_kernel",
+    KERNEL_OF = {"fused_stage_b": "fused2_kernel (+ fused_combine_kernel)", "mtfft_fused": "mtfft16_kernel",
                  "measure_epilogue": "measure_tile_kernel"}
     roofline = {"kernel": KERNEL_OF.get(dominant, dominant), "entry_point": dominant, "bound": bound,
                 "achieved": round(achieved, 3), "peak": peak,
@@ -452,15 +462,21 @@ def main():
                 "frac_is": ("f32-equivalent flops of the Hermitian rank-n_obs update, upper triangle only "
                             "(8*n_obs*C(C+1)/2 per bin), over the f32 MFMA peak" if bound == "mfma" else
                             "algorithmic bytes over the HBM peak"),
-                "note": ("the kernel runs the update as six bf16 cross terms on the bf16 matrix pipe and also produces the "
-                         "per-observation |Im s| plane in the same launch; the other normalisations are beside `frac`"),
+                "note": ("the kernel runs the update as three f16 cross terms (two-piece split written by stage A) on the 16-bit "
+                         "matrix pipe and also produces the per-observation |Im s| plane in the same launch; the other "
+                         "normalisations are beside `frac`"),
+                # the clock the part sustained inside the dominant kernel (s_memtime / s_memrealtime in three workgroups), and
+                # `frac` against the peak AT THAT CLOCK (the 157.3 TF peak assumes 2.4 GHz)
+                **({} if not (bound == "mfma" and clock.value > 0) else {
+                    "sustained_clock_ghz": round(clock.value, 3),
+                    "frac_at_clock": round(achieved / (peak * clock.value / 2.4), 4)}),
                 **({} if bound != "mfma" else {
                     "flops_triangle": work,
                     # SURVEY 8(d) counts the full C x C matrix (the mirror is free on this design): same time, twice the flops
                     "flops_full_matrix": 8.0 * n_obs_loc * C * C * W * F,
                     "frac_full_matrix": round(8.0 * n_obs_loc * C * C * W * F / dur_s / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
-                    # the pipe the products really run on: 6 bf16 cross terms per f32-equivalent product
-                    "frac_bf16_pipe": round(6.0 * work / dur_s / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)}),
+                    # the pipe the products really run on: 3 f16 cross terms per f32-equivalent product (6 bf16 ones before round 4)
+                    "frac_f16_pipe": round(3.0 * work / dur_s / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)}),
                 # the whole step against both rooflines of SURVEY section 8(d) (the binding one is the larger time):
                 # algorithmic bytes of the two-pass design over the HBM peak, triangle-only CSM flops over the f32 MFMA peak
                 "whole_path": (lambda t_hbm, t_mfma: {
@@ -498,6 +514,25 @@ def main():
                       "sample": (f"restructured NumPy path (one-sided spectra, batched-GEMM cross-spectral matrix on all BLAS "
                                  f"threads, blocked vectorised |Im s| plane; float64) on {n_sample} of {cfg['R']} trials, linear "
                                  f"in trials; the |Im s| plane is single-threaded NumPy arithmetic, BLAS threads = {threads}")}
+
+    # end to end, NumPy in -> NumPy out (page-locked host buffers: upload of the float32 series, the step,
+    # download of both measures), a few passes after the timed region; never `value`
+    e2e_ms = None
+    if rank == 0 and world == 1:
+        x_host = torch.empty(x.shape, dtype=torch.float32, pin_memory=True)
+        x_host.copy_(x)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(4):
+            t1 = time.perf_counter()
+            xd = x_host.to(device, non_blocking=True)
+            coh_d, wpli_d = one_step(xd, h, cfg, geom, planes, world)
+            coh_h, wpli_h = engine.to_host(coh_d), engine.to_host(wpli_d)
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t1) * 1e3)
+            del xd, coh_d, wpli_d, coh_h, wpli_h
+        e2e_ms = round(sorted(ts[1:])[len(ts[1:]) // 2], 3)
+        del x_host
 
     # Beside the line (never `value`): the float64 engine -- the reference's default dtype, the path that meets 1e-5 on
     # every element at this depth -- on the same workload, a few passes after the timed region.
@@ -538,6 +573,11 @@ def main():
             "value": value, "unit": "channel-pair*freq-bins/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            # the median step (hipEvents between the steps of the same timed loop), the observation-normalised
+            # rate W F C^2 R K / t (config-independent work rate) and the end-to-end time with both PCIe legs
+            "ms_per_step_median": round(median_ms, 4), "value_at_median": units / (median_ms * 1e-3),
+            "pair_bin_obs_per_s": units * cfg["R"] * K / (elapsed / args.steps),
+            "e2e_ms": e2e_ms, "e2e_is": "NumPy (pinned) float32 series in -> coherence + wPLI as NumPy out, median of 3",
             "config": {"workload": cfg["label"], "name": args.config, "trials_total": cfg["R"],
                        "trials_per_gpu": R_loc, "n_tapers": K, "n_windows": W, "n_freq_bins": F,
                        "units_per_step": units, "parallelism": f"trials sharded over {world} GPU(s)"},
@@ -551,8 +591,10 @@ def main():
                 "exposed_exchange_ms": round(sum(e["exposed_ms"] for e in exchange) / max(len(exchange), 1), 4),
                 "bytes_reduced_per_rank": exchange[-1]["bytes_reduced"] if exchange else None,
                 "n_frequency_groups": exchange[-1]["n_groups"] if exchange else None,
-                "reduce_scatter": ("direct: all_to_all_single of the 1/N bin blocks (one xGMI link each) + local sum in rank order"
-                                   if parallel.exchange_algorithm() == "direct" else "ring: reduce_scatter_tensor")},
+                "reduce_scatter": parallel.exchange_note(),
+                # what the measured numbers should be judged against: bytes per xGMI link and their time at the assumed link rate
+                "model": parallel.exchange_model(4.0 * W * F * 3 * 256 * (((C + 15) // 16) * ((C + 15) // 16 + 1) // 2),   # 3 record planes
+                                                 2 * 4.0 * W * F * C * C, world)},
         }))
     if world > 1:
         dist.destroy_process_group()

@@ -589,12 +589,37 @@ __device__ __forceinline__ void f2_valu_body(const Fused2Args& a, lds_u8* lds, u
     }
 }
 
+// Sustained shader clock of the last launch: wave 0 of three workgroups (first, middle, last) reads the shader-cycle counter
+// (s_memtime) and the constant 100 MHz counter (s_memrealtime) when it starts and when it ends; cycles / real time over a
+// workgroup's life (~0.35 ms at cfg3) is the clock the part sustains under this kernel's load (sc_debug_fused2_clock).
+__device__ unsigned long long f2_clock_buf[3 * 4];
+__device__ __forceinline__ void f2_clock_stamp(int slot, int which) {
+    unsigned long long c, r;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c), "=s"(r));
+    f2_clock_buf[slot * 4 + 2 * which] = c;
+    f2_clock_buf[slot * 4 + 2 * which + 1] = r;
+}
+extern "C" int sc_debug_fused2_clock(double* ghz) {
+    unsigned long long h[12];
+    SC_CHECK_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(f2_clock_buf), sizeof h));
+    double sum = 0.0;
+    int n = 0;
+    for (int s = 0; s < 3; ++s) {
+        const double cyc = (double)(h[s * 4 + 2] - h[s * 4]), ticks = (double)(h[s * 4 + 3] - h[s * 4 + 1]);
+        if (ticks > 0 && cyc > 0) { sum += cyc / (ticks / 100.0e6) * 1e-9; ++n; }
+    }
+    if (ghz) *ghz = n ? sum / n : 0.0;
+    return SC_OK;
+}
+
 template <int NB32, int COL_LO, int ROW_HI, int OP>
 __global__ void __launch_bounds__(FU_THREADS) fused2_kernel(Fused2Args a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const FusedArgs& p = a.f;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int clock_slot = blockIdx.x == 0 ? 0 : (blockIdx.x == gridDim.x / 2 ? 1 : (blockIdx.x == gridDim.x - 1 ? 2 : -1));
+    if (clock_slot >= 0 && tid == 0) f2_clock_stamp(clock_slot, 0);
     const int bin = blockIdx.x / p.n_split, part = blockIdx.x - bin * p.n_split;
     const int g = bin / p.F, f = bin - g * p.F;
     const int nc = (p.st.n_obs + FU_OC - 1) / FU_OC;
@@ -624,6 +649,7 @@ __global__ void __launch_bounds__(FU_THREADS) fused2_kernel(Fused2Args a) {
     if (wave < 4) {
         if (p.debug_skip & 32) __builtin_amdgcn_s_setprio(2);
         f2_mfma_role<NB32>(a, lds, smem, L, wave, rec, n_part);
+        if (clock_slot >= 0 && tid == 0) f2_clock_stamp(clock_slot, 1);
     } else {
         if (p.debug_skip & 16) __builtin_amdgcn_s_setprio(2);
         constexpr int NSETS = fu_nsets(NB32, COL_LO, ROW_HI);

@@ -24,8 +24,26 @@ struct RecT {
     __device__ double operator[](int64_t i) const { return (double)p[i]; }
 };
 
+// A record given as n_parts partial records `stride` elements apart (the blocks a rank received in the direct exchange of the
+// trial-sharded path, parallel.py): element i = p[i] + p[i + stride] + ... summed in part (= rank) order in the records' own
+// precision -- bit for bit the record a separate summation pass would have written, without the pass and its round trip.
+template <typename AccT>
+struct RecPartsT {
+    const AccT* p;
+    int n_parts;
+    int64_t stride;
+    __device__ RecPartsT operator+(int64_t n) const { return RecPartsT{p + n, n_parts, stride}; }
+    __device__ double operator[](int64_t i) const {
+        AccT s = p[i];
+        for (int k = 1; k < n_parts; ++k) s += p[i + k * stride];
+        return (double)s;
+    }
+};
+
 struct MeasureArgs {
     ScRec accum;
+    int n_parts;                 // measure_tile_multi_kernel: > 1 = the record is the sum of this many partial records ...
+    int64_t part_stride;         // ... this many elements apart
     void* out;
     int64_t n_bins, floats_per_bin, total;
     int C, NB, n_tiles;
@@ -196,13 +214,22 @@ __global__ void __launch_bounds__(256) measure_tile_kernel(MeasureArgs a) {
                                   // workgroup run one after the other, each behind its own loads, and 32 508 small workgroups hide
                                   // that latency better than 8 127 longer ones; tools/measure_ab.py over variant libraries)
 #endif
-template <typename OutT, typename AccT>
+template <typename AccT, bool PARTS> struct RecSel { using type = RecT<AccT>; };
+template <typename AccT> struct RecSel<AccT, true> { using type = RecPartsT<AccT>; };
+template <typename AccT, bool PARTS>
+__device__ __forceinline__ typename RecSel<AccT, PARTS>::type make_rec(const MeasureArgs& a) {
+    if constexpr (PARTS) return RecPartsT<AccT>{(const AccT*)a.accum.p, a.n_parts, a.part_stride};
+    else return RecT<AccT>{(const AccT*)a.accum.p};
+}
+
+template <typename OutT, typename AccT, bool PARTS = false>
 __global__ void __launch_bounds__(256) measure_tile_multi_kernel(MeasureArgs a) {
     __shared__ MeasureIn raw[256];
     __shared__ double mir[256];
     const int tid = threadIdx.x, ii = tid >> 4, jj = tid & 15;
     const int64_t bin = blockIdx.x;
-    const RecT<AccT> rec = RecT<AccT>{(const AccT*)a.accum.p} + bin * a.floats_per_bin;
+    using Rec = typename RecSel<AccT, PARTS>::type;
+    const Rec rec = make_rec<AccT, PARTS>(a) + bin * a.floats_per_bin;
     const int64_t plane = (int64_t)a.n_tiles * SC_TILE_ELEMS;
     const int64_t obase = bin * (int64_t)a.C * a.C;
     int ti = 0, len = a.NB, t = blockIdx.y * MEASURE_MULTI_TPW;          // upper-triangular tile (ti <= tj), row-major
@@ -211,7 +238,7 @@ __global__ void __launch_bounds__(256) measure_tile_multi_kernel(MeasureArgs a) 
         const int tile_id = blockIdx.y * MEASURE_MULTI_TPW + u;
         if (tile_id >= a.n_tiles) break;
         const int tj = ti + t;
-        const RecT<AccT> tile = rec + ((int64_t)tile_id * SC_TILE_ELEMS + ii * 16 + jj);
+        const Rec tile = rec + ((int64_t)tile_id * SC_TILE_ELEMS + ii * 16 + jj);
         MeasureIn v = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         if (a.p_csm >= 0) {
             v.s_re = (double)tile[a.p_csm * plane];
@@ -269,13 +296,16 @@ static uint32_t measure_needs(int measure) {
 
 static int measure_multi_run(const void* d_accum, int64_t n_bins, int64_t n_signals, uint32_t planes,
                              int64_t n_observations, int n_measures, const int* measures, void* const* d_outs,
-                             bool wide, void* stream) {
+                             bool wide, void* stream, int n_parts = 1, int64_t part_stride = 0) {
     ScTimed timed_("measure_epilogue", stream);
     SC_REQUIRE(d_accum && measures && d_outs, "NULL argument");
     SC_REQUIRE(n_bins >= 1 && n_signals >= 1 && n_observations >= 1, "dimensions must be positive");
     SC_REQUIRE(n_measures >= 1 && n_measures <= SC_MEASURE_MULTI_MAX, "1 ... SC_MEASURE_MULTI_MAX measures per launch");
+    SC_REQUIRE(n_parts >= 1 && (n_parts == 1 || part_stride > 0), "bad partial-record layout");
     MeasureArgs a;
     a.accum = sc_rec(d_accum, planes);
+    a.n_parts = n_parts;
+    a.part_stride = part_stride;
     a.out = nullptr;
     a.n_bins = n_bins;
     a.C = (int)n_signals;
@@ -314,6 +344,17 @@ static int measure_multi_run(const void* d_accum, int64_t n_bins, int64_t n_sign
     SC_REQUIRE(n_bins < (int64_t)1 << 31 && a.n_tiles <= 65535, "output too large for one launch");
     const dim3 grid((unsigned)n_bins, (unsigned)((a.n_tiles + MEASURE_MULTI_TPW - 1) / MEASURE_MULTI_TPW));
     hipStream_t st = (hipStream_t)stream;
+    if (n_parts > 1) {
+        if (a.accum.f64) {
+            if (wide) hipLaunchKernelGGL((measure_tile_multi_kernel<double, double, true>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((measure_tile_multi_kernel<float, double, true>), grid, dim3(256), 0, st, a);
+        } else {
+            if (wide) hipLaunchKernelGGL((measure_tile_multi_kernel<double, float, true>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((measure_tile_multi_kernel<float, float, true>), grid, dim3(256), 0, st, a);
+        }
+        SC_CHECK_HIP(hipGetLastError());
+        return SC_OK;
+    }
     if (a.accum.f64) {
         if (wide) hipLaunchKernelGGL((measure_tile_multi_kernel<double, double>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((measure_tile_multi_kernel<float, double>), grid, dim3(256), 0, st, a);
@@ -329,6 +370,14 @@ extern "C" int sc_measure_multi_f32(const void* d_accum, int64_t n_bins, int64_t
                                     int64_t n_observations, int n_measures, const int* measures, void* const* d_outs,
                                     void* stream) {
     return measure_multi_run(d_accum, n_bins, n_signals, planes, n_observations, n_measures, measures, d_outs, false, stream);
+}
+// The same measures from a record that arrives as n_parts partial records (SC_RECORD_F64 in `planes`: doubles), part k at
+// d_parts + k * part_stride elements: summed in part order while they are read.
+extern "C" int sc_measure_multi_parts(const void* d_parts, int n_parts, int64_t part_stride, int64_t n_bins, int64_t n_signals,
+                                      uint32_t planes, int64_t n_observations, int n_measures, const int* measures,
+                                      void* const* d_outs, int wide, void* stream) {
+    return measure_multi_run(d_parts, n_bins, n_signals, planes, n_observations, n_measures, measures, d_outs, wide != 0, stream,
+                             n_parts, part_stride);
 }
 extern "C" int sc_measure_multi_f64(const void* d_accum, int64_t n_bins, int64_t n_signals, uint32_t planes,
                                     int64_t n_observations, int n_measures, const int* measures, void* const* d_outs,

@@ -487,10 +487,24 @@ def measure_multi(accum, n_signals, planes, n_obs, which, wide=None, stacked=Fal
     """Stage C for several real-valued C x C measures of one record: ONE launch reads the record once
     (sc_measure_multi_*); complex measures / power, or more than four, go through measure().
     ``stacked``: the results are the slices of ONE [n_measures, n_bins, C, C] tensor (returned as ``outs[0]._base``'s
-    views) when the one-launch form applies -- the trial-sharded path then gathers all measures in one collective."""
+    views) when the one-launch form applies -- the trial-sharded path then gathers all measures in one collective.
+    ``accum`` may be 3-D, [n_parts, n_bins, floats_per_bin]: partial records (the blocks received from the other ranks)
+    that the epilogue sums in part order while it reads them (sc_measure_multi_parts) -- or, where the one-launch form
+    does not apply, that are summed first."""
     which = list(which)
+    parts = None
+    if accum.dim() == 3:
+        simple_ = [w for w in which if w != _lib.M_POWER and w not in _lib.COMPLEX_MEASURES]
+        if accum.shape[0] > 1 and len(simple_) == len(which) and 1 <= len(which) <= MEASURE_MULTI_MAX and accum.is_contiguous():
+            parts = accum
+            accum = parts[0]
+        else:
+            total = accum[0].clone()
+            for k in range(1, accum.shape[0]):                 # part (= rank) order
+                total.add_(accum[k])
+            accum = total
     simple = [w for w in which if w != _lib.M_POWER and w not in _lib.COMPLEX_MEASURES]
-    if len(simple) != len(which) or not 2 <= len(which) <= MEASURE_MULTI_MAX:
+    if parts is None and (len(simple) != len(which) or not 2 <= len(which) <= MEASURE_MULTI_MAX):
         return [measure(accum, n_signals, planes, n_obs, w, wide=wide) for w in which]
     lib = _lib.load()
     n_bins, C = accum.shape[0], n_signals
@@ -503,6 +517,10 @@ def measure_multi(accum, n_signals, planes, n_obs, which, wide=None, stacked=Fal
         outs = [torch.empty((n_bins, C, C), dtype=torch.float64 if wide else torch.float32, device=accum.device) for _ in which]
     ids = (ctypes.c_int * len(which))(*which)
     ptrs = (ctypes.c_void_p * len(which))(*[o.data_ptr() for o in outs])
+    if parts is not None:
+        _lib.check(lib.sc_measure_multi_parts(_ptr(parts), parts.shape[0], parts.stride(0), n_bins, C, rec_planes(accum, planes),
+                                              n_obs, len(which), ids, ptrs, int(bool(wide)), _stream()), "sc_measure_multi_parts")
+        return outs
     fn = lib.sc_measure_multi_f64 if wide else lib.sc_measure_multi_f32
     _lib.check(fn(_ptr(accum), n_bins, C, rec_planes(accum, planes), n_obs, len(which), ids, ptrs, _stream()),
                "sc_measure_multi")

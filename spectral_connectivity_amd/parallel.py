@@ -49,14 +49,62 @@ def exchange_algorithm():
     mode = os.environ.get("SC_EXCHANGE", "direct")
     if mode not in ("direct", "ring"):
         raise ValueError(f"SC_EXCHANGE={mode!r}: expected 'direct' or 'ring'")
+    if mode == "direct" and _direct_failed:
+        return "ring"              # all_to_all_single raised on this backend once: the library reduce-scatter from then on
     return mode
 
 
-def reduce_scatter_bins(accum, group=None):
+_direct_failed = []                # [message] once the direct exchange has failed in this process (exchange_note reports it)
+
+
+def exchange_note():
+    """What the bench line / logs should say about the exchange that really ran."""
+    if _direct_failed:
+        return "ring: reduce_scatter_tensor (the direct all_to_all_single exchange raised: " + _direct_failed[0] + ")"
+    return ("direct: all_to_all_single of the 1/N bin blocks (one xGMI link each), summed in rank order inside the epilogue kernel"
+            if exchange_algorithm() == "direct" else "ring: reduce_scatter_tensor")
+
+
+XGMI_LINK_GBS = 64.0               # per direction and link, sustained (153 GB/s bidirectional peak per link: ~40 % of it one way)
+
+
+def exchange_model(record_bytes, measure_bytes, world):
+    """Bytes per xGMI link and the time they take at XGMI_LINK_GBS for one step's exchange: the direct reduce-scatter sends 1/N of
+    the record to each peer (N - 1 links at once), a ring moves (N - 1)/N of it over one link in N - 1 steps; the gather sends
+    each rank's 1/N of the measures to rank 0 (its N - 1 incoming links at once)."""
+    if world <= 1:
+        return None
+    direct = record_bytes / world
+    ring = record_bytes * (world - 1) / world
+    gather = measure_bytes / world
+    return {"record_bytes": int(record_bytes), "bytes_per_link_direct": int(direct), "bytes_per_link_ring_total": int(ring),
+            "gather_bytes_per_link": int(gather), "link_gb_per_s_assumed": XGMI_LINK_GBS,
+            "predicted_ms_direct": round((direct + gather) / (XGMI_LINK_GBS * 1e9) * 1e3, 4),
+            "predicted_ms_ring": round((ring + gather) / (XGMI_LINK_GBS * 1e9) * 1e3, 4)}
+
+
+def _direct_blocks(accum, world, per, fpb, group):
+    """all_to_all_single of the bin blocks; [world, per, fpb] on the records' device, or None when the backend refuses (RCCL
+    builds without all-to-all, ...): the caller then takes the library reduce-scatter, and says so (exchange_note)."""
+    via_host = dist.get_backend(group) == "gloo" and accum.is_cuda          # gloo moves CUDA tensors through the host
+    src = (accum.cpu() if via_host else accum).contiguous()
+    recv = torch.empty_like(src)
+    try:
+        dist.all_to_all_single(recv, src, group=group)                      # block j of every rank's record -> rank j
+    except RuntimeError as exc:
+        _direct_failed.append(str(exc).splitlines()[0][:200])
+        return None
+    blocks = recv.view(world, per, fpb)
+    return blocks.to(accum.device) if via_host else blocks
+
+
+def reduce_scatter_bins(accum, group=None, keep_parts=False):
     """Sum accumulator records over ranks; return (this rank's bin shard, bin_lo, bin_hi).
 
     ``accum``: [n_bins, floats_per_bin] float32.  Bins are padded to a multiple of the
     world size so every rank owns the same count; ``bin_hi`` is clipped to n_bins.
+    ``keep_parts`` (direct exchange only): return the N received blocks [world, per, fpb] unsummed -- the epilogue
+    kernel adds them in rank order while it reads them (engine.measure_multi), one pass and one buffer less.
     """
     if _no_exchange(group):
         return accum, 0, accum.shape[0]
@@ -74,15 +122,14 @@ def reduce_scatter_bins(accum, group=None):
     lo = rank * per
     hi = min(lo + per, n_bins)
     if exchange_algorithm() == "direct":
-        via_host = dist.get_backend(group) == "gloo" and accum.is_cuda      # gloo moves CUDA tensors through the host
-        src = (accum.cpu() if via_host else accum).contiguous()
-        recv = torch.empty_like(src)
-        dist.all_to_all_single(recv, src, group=group)                      # block j of every rank's record -> rank j
-        blocks = recv.view(world, per, fpb)
-        shard = blocks[0]
-        for k in range(1, world):                                           # rank order, in place: no further buffer
-            shard.add_(blocks[k])
-        return (shard.to(accum.device) if via_host else shard), lo, max(hi, lo)
+        blocks = _direct_blocks(accum, world, per, fpb, group)
+        if blocks is not None:
+            if keep_parts:
+                return blocks, lo, max(hi, lo)                              # [world, per, fpb]: summed by the consumer, in rank order
+            shard = blocks[0].clone()                                       # (a fresh [per, fpb]: the receive buffer can go)
+            for k in range(1, world):                                       # rank order
+                shard.add_(blocks[k])
+            return shard, lo, max(hi, lo)
     if dist.get_backend(group) == "gloo":      # CPU tests / debug runs: gloo has no reduce_scatter
         if accum.is_cuda:                      # gloo moves CUDA tensors through the host
             host = accum.cpu()
@@ -202,7 +249,7 @@ def sharded_measures(spectra, planes, which, n_groups=4, dst=0, group=None, mark
             if xchg:
                 side.wait_event(ready)
             t0 = ev(side) if timing is not None else None
-            shard, lo, hi = reduce_scatter_bins(accum, group)
+            shard, lo, hi = reduce_scatter_bins(accum, group, keep_parts=True)
             if timing is not None:
                 coll_events.append((t0, ev(side)))
                 bytes_reduced += accum.numel() * accum.element_size()
@@ -351,8 +398,14 @@ class ShardedConnectivity(_connectivity_base()):
         import numpy as np
         from . import options
         dtype = np.complex128 if dtype is None else dtype
-        obj = cls(multitaper_instance.device_spectra(precision=options.engine_precision(dtype)),
-                  expectation_type=expectation_type, time=multitaper_instance.time,
+        precision = options.engine_precision(dtype)
+        if precision == "float32" and not np.iscomplexobj(multitaper_instance.time_series):
+            from .connectivity import _PendingSpectra         # the transform runs at the first request (Connectivity.from_multitaper)
+            multitaper_instance.check_device_path()
+            first = _PendingSpectra(multitaper_instance, precision)
+        else:
+            first = multitaper_instance.device_spectra(precision=precision)
+        obj = cls(first, expectation_type=expectation_type, time=multitaper_instance.time,
                   frequencies=multitaper_instance.frequencies, blocks=blocks, dtype=dtype, process_group=process_group)
         obj._multitaper = multitaper_instance
         return obj
@@ -385,7 +438,7 @@ class ShardedConnectivity(_connectivity_base()):
                 key = have
                 break
         if key is None:
-            sp = self._device()
+            sp = self._device(planes_hint=planes)
             accum, n_obs = engine.accumulate(sp, self.expectation_type, planes, n_freq=self._n_freq)
             shard, lo, hi = reduce_scatter_bins(accum, self._group)
             key = planes

@@ -219,6 +219,23 @@ def test_trial_sharded_pipeline_ranks_share_one_gpu(world):
     assert "ShardedConnectivity OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
+def test_eight_rank_rehearsal_at_the_headline_size():
+    """What the 8-GPU run of the bench does, rehearsed on the one GPU a test box has: 8 ranks (gloo, sharing the device) with
+    125 of the 1000 trials of the cfg3 shape each -- planes-format stage A and B per rank, direct exchange of the bin blocks,
+    the epilogue kernel summing the eight received blocks in rank order, gather on rank 0 -- against the single-process result
+    over all 1000 trials."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SC_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", SC_SHARD_FULL="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+                          "--master-addr", "127.0.0.1", "--master-port", "29557",
+                          os.path.join(root, "tools", "check_sharded.py")],
+                         env=env, capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0 and "sharded_measures OK (full size, 8 ranks x 125 trials" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
 @pytest.mark.parametrize("algorithm", ["direct", "ring"])
 def test_rccl_exchange_path_world_one(algorithm):
     """The RCCL calls of the N > 1 path (all_to_all_single of the direct exchange / reduce_scatter_tensor of the ring one,

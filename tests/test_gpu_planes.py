@@ -25,7 +25,9 @@ def _series(T, R, C, seed, offset=0.0):
     rng = np.random.default_rng(seed)
     t = np.arange(T) / 1000.0
     x = rng.standard_normal((T, R, C))
-    x += 0.6 * np.sin(2 * np.pi * 60 * t)[:, None, None] * np.cos(np.arange(C))[None, None, :]
+    # a shared 60 Hz component with a different lag in every channel (a zero-lag copy would make Im s a difference of large
+    # numbers: the float32 engine's rounding, whatever the device format, would then dominate the phase-lag measures)
+    x += 0.6 * np.sin(2 * np.pi * 60 * t[:, None, None] + 2 * np.pi * np.arange(C)[None, None, :] / C)
     x[:, :, 0] *= 250.0                      # a loud channel
     x[:, :, C - 1] *= 2e-3                   # a quiet one
     return x + offset

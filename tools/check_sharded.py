@@ -22,8 +22,38 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
-    T, R, C, L, step, NW = 512, 25, 64, 128, 64, 3      # 25 trials over 2 ranks: unequal shards
+    full_size = os.environ.get("SC_SHARD_FULL") == "1"      # the headline shape (cfg3): 1000 trials x 128 channels, 125 per rank at 8
+    T, R, C, L, step, NW = (1024, 1000, 128, 256, 128, 4) if full_size else (512, 25, 64, 128, 64, 3)      # 25 trials over 2 ranks: unequal shards
     W = int(np.floor(T / step - L / step + 1))
+    if full_size:
+        from spectral_connectivity_amd.transforms import _make_tapers
+        tap7 = _make_tapers(L, 1000.0, NW, 7)
+        h = torch.from_numpy(np.ascontiguousarray(tap7.T / 1000.0, dtype=np.float32)).to(dev)
+        g = torch.Generator(device=dev).manual_seed(1234)
+        x_all = torch.randn((T, R, C), dtype=torch.float32, device=dev, generator=g)
+        x_all += 0.5 * torch.sin(2 * np.pi * 60.0 * torch.arange(T, device=dev) / 1000.0)[:, None, None]
+        lo, hi = parallel.shard_bounds(R, world, rank)
+        planes = _lib.PLANE_CSM | _lib.PLANE_ABS_IM
+        which = [_lib.M_COHERENCE_MAGNITUDE, _lib.M_WPLI]
+        sp = engine.multitaper_spectra(x_all[:, lo:hi].contiguous(), h, L, step, L, W, "constant", planes_hint=planes)
+        if rank != 0:
+            del x_all
+        got = parallel.sharded_measures(sp, planes, which, n_groups=4, equal_shards=(R % world == 0))
+        torch.cuda.synchronize()
+        if rank == 0:
+            whole = engine.multitaper_spectra(x_all, h, L, step, L, W, "constant", planes_hint=planes)
+            accum, n_obs = engine.accumulate(whole, "trials_tapers", planes)
+            assert n_obs == R * 7
+            for gm, w in zip(got, which):
+                ref = engine.measure(accum, C, planes, n_obs, w).reshape(W, L // 2 + 1, C, C)
+                a, b = gm.cpu().numpy(), ref.cpu().numpy()
+                assert a.shape == b.shape and np.array_equal(np.isnan(a), np.isnan(b))
+                err = np.nanmax(np.abs(a - b))
+                assert err < 2e-5, f"measure {w}: max err {err}"
+            print(f"sharded_measures OK (full size, {world} ranks x {hi - lo} trials, exchange: {parallel.exchange_note()})")
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     tap, _ = dpss_windows(L, NW, 5, is_low_bias=False)
     h = torch.from_numpy(np.ascontiguousarray(np.asarray(tap) * np.sqrt(200.0) / 200.0, dtype=np.float32)).to(dev)
     if h.shape[0] != 5:
@@ -32,7 +62,9 @@ def main():
     lo, hi = parallel.shard_bounds(R, world, rank)
     planes = _lib.PLANE_CSM | _lib.PLANE_ABS_IM
     which = [_lib.M_COHERENCE_MAGNITUDE, _lib.M_WPLI]
-    sp = engine.multitaper_spectra(x_all[:, lo:hi].contiguous(), h, L, step, L, W, "constant")
+    # the rank's own spectra in the planes format (f16 pieces, sc_fused2.hip) where it applies; the single-process reference
+    # below goes through the complex64 kernels
+    sp = engine.multitaper_spectra(x_all[:, lo:hi].contiguous(), h, L, step, L, W, "constant", planes_hint=planes)
     for groups in (1, 3, 4):
         got = parallel.sharded_measures(sp, planes, which, n_groups=groups)
         torch.cuda.synchronize()

@@ -6,7 +6,7 @@ import os
 import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = os.environ.get("ROUND", "r03")
+ROUND = os.environ.get("ROUND", "r04")
 F = os.path.join(ROOT, "gpurun_out", ROUND)
 P = os.path.join(ROOT, "profiles")
 
@@ -19,7 +19,7 @@ def lines(name):
 def kernel_source_hash():
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "spectral_connectivity_amd", "csrc")
-    for name in ("sc_fused.hip", "sc_mtfft.hip", "sc_measure.hip", "sc_stage.h", "sc_common.h"):
+    for name in ("sc_fused.hip", "sc_fused2.hip", "sc_fused_common.h", "sc_mtfft.hip", "sc_measure.hip", "sc_stage.h", "sc_common.h"):   # = bench.py
         with open(os.path.join(csrc, name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -55,14 +55,15 @@ if under:
     sm = st["roofline"]["stage_ms"]
     hdr.append("# stage times of the same run from the library's own hipEvent timers (sc_last_timing): " +
                ", ".join(f"{k} {v:.3f} ms" for k, v in sm.items()) + f"; step {st['ms_per_step']:.2f} ms")
-    hdr.append("# (fused_stage_b = fused_csm_absim_kernel + fused_combine_kernel; averages below include the 2 warm-up launches)")
+    hdr.append("# (fused_stage_b = fused2_kernel + fused_combine_kernel; averages below include the 2 warm-up launches)")
 open(os.path.join(P, ROUND + "_bench_kernel_stats.txt"), "w").write("\n".join(hdr + lines("kt.txt")[:12]) + "\n")
 
 fetch, write = pmc("fetch.txt", "FETCH_SIZE"), pmc("write.txt", "WRITE_SIZE")
-rows = [("fused_csm_absim_kernel", "_Z22fused_csm_absim", True), ("fused_combine_kernel", "_Z20fused_combine", True),
+rows = [("fused2_kernel", "_Z13fused2_kernel", True), ("fused_csm_absim_kernel", "_Z22fused_csm_absim", True),
+        ("fused_combine_kernel", "_Z20fused_combine", True), ("planes_absmax_kernel", "_Z20planes_absmax", True),
         ("mtfft16_kernel", "_Z14mtfft16", False), ("measure_tile_multi_kernel", "measure_tile_multi", False)]
 txt = ["# rocprofv3 --kernel-trace --pmc FETCH_SIZE  /  --pmc WRITE_SIZE (separate passes, MI355X_MICROARCH.md), python bench.py --steps 2",
-       "# --warmup 1 (cfg3, 1x MI355X), round 3 (tools/profile_round.sh).  Counter values are KB per dispatch.  gfx950 correction: FETCH_SIZE",
+       "# --warmup 1 (cfg3, 1x MI355X), round " + ROUND[1:].lstrip("0") + " (tools/profile_round.sh).  Counter values are KB per dispatch.  gfx950 correction: FETCH_SIZE",
        "# reports half of a wide (16 B / lane) coalesced read stream -> doubled for the kernels whose reads are such streams (marked x2);",
        "# WRITE_SIZE as is.",
        f"{'kernel':28s} {'FETCH_SIZE[KB]':>15s} {'WRITE_SIZE[KB]':>15s} {'HBM bytes (corrected)':>24s}"]
@@ -75,10 +76,12 @@ for name, prefix, wide in rows:
     traffic[name] = total
     txt.append(f"{name:28s} {f_kb:15.4g} {w_kb:15.4g} {total / 1e9:20.3f} GB{'  (x2)' if wide else ''}")
 open(os.path.join(P, ROUND + "_hbm_traffic.txt"), "w").write("\n".join(txt) + "\n")
-if "fused_csm_absim_kernel" in traffic:
+stage_b = "fused2_kernel" if "fused2_kernel" in traffic else "fused_csm_absim_kernel"
+if stage_b in traffic:
     rec = {"kernel_source_hash": kernel_source_hash(),
            "source": "profiles/" + ROUND + "_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 on gfx950)",
-           "cfg3": {"fused_stage_b": traffic["fused_csm_absim_kernel"] + traffic.get("fused_combine_kernel", 0.0),
+           "cfg3": {"fused_stage_b": traffic[stage_b] + traffic.get("fused_combine_kernel", 0.0),
+                    "planes_scales": traffic.get("planes_absmax_kernel"),
                     "mtfft_fused": traffic.get("mtfft16_kernel"),
                     "measure_epilogue": traffic.get("measure_tile_multi_kernel")}}
     json.dump(rec, open(os.path.join(P, ROUND + "_hbm_traffic.json"), "w"), indent=1)
@@ -88,10 +91,10 @@ if sq:
     vals = {}
     for l in sq:
         m = re.match(r"\s+(\S+)\s+(\S+)\s+n=\s*(\d+)\s+avg=(\S+)", l)
-        if m and "fused_csm_absim" in m.group(1):
+        if m and ("fused2_kernel" in m.group(1) or "fused_csm_absim" in m.group(1)):
             vals[m.group(2)] = float(m.group(4))
     busy, valu, mf = vals.get("SQ_BUSY_CYCLES", 1.0), vals.get("SQ_INSTS_VALU", 0.0), vals.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
-    h2 = ["# rocprofv3 --kernel-trace --pmc (one pass of 8 SQ counters), cfg3, 1x MI355X, round 3 (tools/profile_round.sh).",
+    h2 = ["# rocprofv3 --kernel-trace --pmc (one pass of 8 SQ counters), cfg3, 1x MI355X, round " + ROUND[1:].lstrip("0") + " (tools/profile_round.sh).",
           "# Averages per dispatch PER SHADER ENGINE (32 SEs x 8 CUs = 32 SIMDs each): SQ_INSTS_* are wave instructions, SQ_BUSY_CYCLES and",
           "# SQ_VALU_MFMA_BUSY_CYCLES cycles, SQ_WAIT_* / SQ_ACTIVE_INST_* quad-cycles.",
           "# fused kernel: VALU issue = %.3g instr x 4 cycles / 32 SIMDs = %.3g of %.3g busy cycles = %.0f %%; matrix pipe = %.4g / 32 SIMDs = %.3g cycles = %.0f %%"

@@ -8,7 +8,7 @@
 # (counters in their own runs with --kernel-trace only: MI355X_MICROARCH.md, rocprofv3 PMC slots)
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-ROUND=${ROUND:-r03}
+ROUND=${ROUND:-r04}
 OUT=$ROOT/gpurun_out/$ROUND
 mkdir -p $OUT
 cd $ROOT
