@@ -116,7 +116,7 @@ def one_step(x, h, cfg, geom, planes, world, exchange=None):
                                               n_groups=int(os.environ.get("SC_BENCH_GROUPS", "4")),
                                               equal_shards=True, timing=exchange)   # R % world == 0: asserted in main()
         return coh, wpli
-    accum, n_obs = engine.accumulate(sp, "trials_tapers", planes)
+    accum, n_obs = engine.accumulate(sp, "trials_tapers", planes, fold=False)     # the epilogue sums the split-bin parts itself
     del sp
     coh, wpli = engine.measure_multi(accum, cfg["C"], planes, n_obs, [_lib.M_COHERENCE_MAGNITUDE, _lib.M_WPLI])
     return coh, wpli

@@ -298,6 +298,11 @@ int sc_spectra_from_planes_f32(const void* d_P, const sc_spectra_desc* desc, con
  * run of rows (every expectation type but "time_tapers" with several trials); sc_fused2_supported tells.
  * Workspace as for sc_fused_csm_absim_ws_f32 (sc_fused_workspace_bytes with the same desc). */
 int sc_fused2_supported(const sc_spectra_desc* desc, uint32_t planes);
+/* The same without the pass that folds the split-bin partial records: *n_parts workgroups shared every bin; part 0 of the
+ * records is in d_accum, part k >= 1 at (float*)d_workspace + (k - 1) * n_bins * floats_per_bin (sc_accum_layout) -- for
+ * sc_measure_multi_parts, which sums them while it reads. */
+int sc_fused2_csm_absim_parts_f32(const void* d_P, const sc_spectra_desc* desc, const float* d_scale, uint32_t planes,
+                                  float* d_accum, void* d_workspace, int64_t workspace_bytes, int* n_parts, void* stream);
 /* shader clock (GHz) the device sustained during the last sc_fused2_csm_absim_f32 launch (in-kernel cycle / real-time counters) */
 int sc_debug_fused2_clock(double* ghz);
 int sc_fused2_csm_absim_f32(const void* d_P, const sc_spectra_desc* desc, const float* d_scale, uint32_t planes,
@@ -324,12 +329,13 @@ int sc_measure_multi_f32(const void* d_accum, int64_t n_bins, int64_t n_signals,
 int sc_measure_multi_f64(const void* d_accum, int64_t n_bins, int64_t n_signals, uint32_t planes,
                          int64_t n_observations, int n_measures, const int* measures, void* const* d_outs,
                          void* stream);
-/* The same, from a record that arrives as n_parts partial records part_stride elements apart (float, or double with
- * SC_RECORD_F64 in `planes`) -- the bin blocks a rank received from the other ranks in the direct exchange of the
- * trial-sharded path (the sum over trial shards).  The parts are summed in part (= rank) order in the records'
+/* The same, from a record that arrives as n_parts partial records (float, or double with SC_RECORD_F64 in `planes`): part 0
+ * at d_part0, part k >= 1 at d_rest + (k - 1) * part_stride elements -- the bin blocks a rank received from the other ranks
+ * in the direct exchange of the trial-sharded path (the sum over trial shards), or the per-workgroup partial
+ * records of a split-bin stage B (sc_fused2_csm_absim_parts_f32).  The parts are summed in part order in the records'
  * precision while they are read: no summation pass, no second copy of the record.  wide: float64 outputs. */
-int sc_measure_multi_parts(const void* d_parts, int n_parts, int64_t part_stride, int64_t n_bins, int64_t n_signals,
-                           uint32_t planes, int64_t n_observations, int n_measures, const int* measures,
+int sc_measure_multi_parts(const void* d_part0, const void* d_rest, int n_parts, int64_t part_stride, int64_t n_bins,
+                           int64_t n_signals, uint32_t planes, int64_t n_observations, int n_measures, const int* measures,
                            void* const* d_outs, int wide, void* stream);
 
 /* ---- stage B of the float64 engine -----------------------------------------------------

@@ -68,8 +68,8 @@ SYMBOLS = {
                                      POINTER(c_void_p), c_void_p]),
     "sc_measure_multi_f64": (c_int, [c_void_p, c_int64, c_int64, c_uint32, c_int64, c_int, POINTER(c_int),
                                      POINTER(c_void_p), c_void_p]),
-    "sc_measure_multi_parts": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_uint32, c_int64, c_int, POINTER(c_int),
-                                       POINTER(c_void_p), c_int, c_void_p]),
+    "sc_measure_multi_parts": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_uint32, c_int64, c_int,
+                                       POINTER(c_int), POINTER(c_void_p), c_int, c_void_p]),
     "sc_timing_enable": (c_int, [c_int]),
     "sc_last_timing": (c_int, [POINTER(Timing), c_int, POINTER(c_int)]),
     "sc_multitaper_fft_supported": (c_int, [c_int64, c_int64]),
@@ -109,6 +109,8 @@ SYMBOLS = {
     "sc_spectra_from_planes_f32": (c_int, [c_void_p, POINTER(SpectraDesc), c_void_p, c_void_p, c_void_p]),
     "sc_fused2_supported": (c_int, [POINTER(SpectraDesc), c_uint32]),
     "sc_debug_fused2_clock": (c_int, [POINTER(c_double)]),
+    "sc_fused2_csm_absim_parts_f32": (c_int, [c_void_p, POINTER(SpectraDesc), c_void_p, c_uint32, c_void_p, c_void_p, c_int64,
+                                              POINTER(c_int), c_void_p]),
     "sc_fused2_csm_absim_f32": (c_int, [c_void_p, POINTER(SpectraDesc), c_void_p, c_uint32, c_void_p, c_void_p, c_int64,
                                         c_void_p]),
     "sc_granger_workspace_bytes": (c_int, [c_int64, c_int64, c_int64, POINTER(c_size_t)]),

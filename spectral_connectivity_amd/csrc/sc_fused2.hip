@@ -722,8 +722,8 @@ extern "C" int sc_fused2_supported(const sc_spectra_desc* desc, uint32_t planes)
     return rc == SC_OK ? 1 : 0;
 }
 
-extern "C" int sc_fused2_csm_absim_f32(const void* d_P, const sc_spectra_desc* desc, const float* d_scale, uint32_t planes,
-                                       float* d_accum, void* d_workspace, int64_t workspace_bytes, void* stream) {
+static int fused2_run(const void* d_P, const sc_spectra_desc* desc, const float* d_scale, uint32_t planes,
+                      float* d_accum, void* d_workspace, int64_t workspace_bytes, int* n_parts, void* stream) {
     ScTimed timed_("fused_stage_b", stream);
     SC_REQUIRE(d_P && desc && d_accum && d_scale, "NULL argument");
     SC_REQUIRE(((uintptr_t)d_P % 16) == 0, "planes buffer must be 16-byte aligned");
@@ -766,5 +766,16 @@ extern "C" int sc_fused2_csm_absim_f32(const void* d_P, const sc_spectra_desc* d
     }
 #undef F2_LAUNCH
     SC_CHECK_HIP(hipGetLastError());
+    if (n_parts) { *n_parts = f.n_split; return SC_OK; }      // the caller's epilogue sums the parts
     return sc_internal_fused_combine(f, FU_OP_ABS, s);
+}
+extern "C" int sc_fused2_csm_absim_f32(const void* d_P, const sc_spectra_desc* desc, const float* d_scale, uint32_t planes,
+                                       float* d_accum, void* d_workspace, int64_t workspace_bytes, void* stream) {
+    return fused2_run(d_P, desc, d_scale, planes, d_accum, d_workspace, workspace_bytes, nullptr, stream);
+}
+extern "C" int sc_fused2_csm_absim_parts_f32(const void* d_P, const sc_spectra_desc* desc, const float* d_scale, uint32_t planes,
+                                             float* d_accum, void* d_workspace, int64_t workspace_bytes, int* n_parts,
+                                             void* stream) {
+    SC_REQUIRE(n_parts, "NULL argument");
+    return fused2_run(d_P, desc, d_scale, planes, d_accum, d_workspace, workspace_bytes, n_parts, stream);
 }

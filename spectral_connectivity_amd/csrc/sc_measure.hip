@@ -29,21 +29,23 @@ struct RecT {
 // precision -- bit for bit the record a separate summation pass would have written, without the pass and its round trip.
 template <typename AccT>
 struct RecPartsT {
-    const AccT* p;
+    const AccT* p;               // part 0
+    const AccT* q;               // part 1; part k (k >= 1) at q + (k - 1) * stride
     int n_parts;
     int64_t stride;
-    __device__ RecPartsT operator+(int64_t n) const { return RecPartsT{p + n, n_parts, stride}; }
+    __device__ RecPartsT operator+(int64_t n) const { return RecPartsT{p + n, q + n, n_parts, stride}; }
     __device__ double operator[](int64_t i) const {
         AccT s = p[i];
-        for (int k = 1; k < n_parts; ++k) s += p[i + k * stride];
+        for (int k = 1; k < n_parts; ++k) s += q[i + (k - 1) * stride];
         return (double)s;
     }
 };
 
 struct MeasureArgs {
     ScRec accum;
-    int n_parts;                 // measure_tile_multi_kernel: > 1 = the record is the sum of this many partial records ...
-    int64_t part_stride;         // ... this many elements apart
+    int n_parts;                 // measure_tile_multi_kernel: > 1 = the record is the sum of this many partial records: accum.p,
+    const void* rest;            // ... then rest, rest + part_stride, ...
+    int64_t part_stride;
     void* out;
     int64_t n_bins, floats_per_bin, total;
     int C, NB, n_tiles;
@@ -218,7 +220,7 @@ template <typename AccT, bool PARTS> struct RecSel { using type = RecT<AccT>; };
 template <typename AccT> struct RecSel<AccT, true> { using type = RecPartsT<AccT>; };
 template <typename AccT, bool PARTS>
 __device__ __forceinline__ typename RecSel<AccT, PARTS>::type make_rec(const MeasureArgs& a) {
-    if constexpr (PARTS) return RecPartsT<AccT>{(const AccT*)a.accum.p, a.n_parts, a.part_stride};
+    if constexpr (PARTS) return RecPartsT<AccT>{(const AccT*)a.accum.p, (const AccT*)a.rest, a.n_parts, a.part_stride};
     else return RecT<AccT>{(const AccT*)a.accum.p};
 }
 
@@ -296,15 +298,16 @@ static uint32_t measure_needs(int measure) {
 
 static int measure_multi_run(const void* d_accum, int64_t n_bins, int64_t n_signals, uint32_t planes,
                              int64_t n_observations, int n_measures, const int* measures, void* const* d_outs,
-                             bool wide, void* stream, int n_parts = 1, int64_t part_stride = 0) {
+                             bool wide, void* stream, int n_parts = 1, const void* d_rest = nullptr, int64_t part_stride = 0) {
     ScTimed timed_("measure_epilogue", stream);
     SC_REQUIRE(d_accum && measures && d_outs, "NULL argument");
     SC_REQUIRE(n_bins >= 1 && n_signals >= 1 && n_observations >= 1, "dimensions must be positive");
     SC_REQUIRE(n_measures >= 1 && n_measures <= SC_MEASURE_MULTI_MAX, "1 ... SC_MEASURE_MULTI_MAX measures per launch");
-    SC_REQUIRE(n_parts >= 1 && (n_parts == 1 || part_stride > 0), "bad partial-record layout");
+    SC_REQUIRE(n_parts >= 1 && (n_parts == 1 || d_rest != nullptr) && (n_parts <= 2 || part_stride > 0), "bad partial-record layout");
     MeasureArgs a;
     a.accum = sc_rec(d_accum, planes);
     a.n_parts = n_parts;
+    a.rest = d_rest;
     a.part_stride = part_stride;
     a.out = nullptr;
     a.n_bins = n_bins;
@@ -371,13 +374,13 @@ extern "C" int sc_measure_multi_f32(const void* d_accum, int64_t n_bins, int64_t
                                     void* stream) {
     return measure_multi_run(d_accum, n_bins, n_signals, planes, n_observations, n_measures, measures, d_outs, false, stream);
 }
-// The same measures from a record that arrives as n_parts partial records (SC_RECORD_F64 in `planes`: doubles), part k at
-// d_parts + k * part_stride elements: summed in part order while they are read.
-extern "C" int sc_measure_multi_parts(const void* d_parts, int n_parts, int64_t part_stride, int64_t n_bins, int64_t n_signals,
-                                      uint32_t planes, int64_t n_observations, int n_measures, const int* measures,
-                                      void* const* d_outs, int wide, void* stream) {
-    return measure_multi_run(d_parts, n_bins, n_signals, planes, n_observations, n_measures, measures, d_outs, wide != 0, stream,
-                             n_parts, part_stride);
+// The same measures from a record that arrives as n_parts partial records (SC_RECORD_F64 in `planes`: doubles): part 0 at
+// d_part0, part k >= 1 at d_rest + (k - 1) * part_stride elements; summed in part order while they are read.
+extern "C" int sc_measure_multi_parts(const void* d_part0, const void* d_rest, int n_parts, int64_t part_stride, int64_t n_bins,
+                                      int64_t n_signals, uint32_t planes, int64_t n_observations, int n_measures,
+                                      const int* measures, void* const* d_outs, int wide, void* stream) {
+    return measure_multi_run(d_part0, n_bins, n_signals, planes, n_observations, n_measures, measures, d_outs, wide != 0, stream,
+                             n_parts, d_rest, part_stride);
 }
 extern "C" int sc_measure_multi_f64(const void* d_accum, int64_t n_bins, int64_t n_signals, uint32_t planes,
                                     int64_t n_observations, int n_measures, const int* measures, void* const* d_outs,

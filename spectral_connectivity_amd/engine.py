@@ -348,9 +348,14 @@ def plane_slots(planes):
     return out
 
 
-def accumulate(spectra, expectation_type, planes, n_freq=None, mark=None, use_fused=None, row_multiple=1, have=None):
+def accumulate(spectra, expectation_type, planes, n_freq=None, mark=None, use_fused=None, row_multiple=1, have=None,
+               fold=True):
     """Stage B: un-normalised accumulator record tensor [n_bins, floats_per_bin] (float32; float64 records from
     complex128 spectra).  ``row_multiple``: see _record_tensor (trial-sharded callers pass the world size).
+    ``fold=False`` (planes-format path only; ignored elsewhere): when stage B split every bin over several workgroups, their
+    partial records are NOT summed -- the returned tensor holds part 0 and carries the others (``_sc_parts``) for
+    measure_multi, whose kernel adds them while it reads (one pass and one record round trip less).  Only measure_multi
+    understands such a tensor.
     ``have`` = (planes_old, record_old), float64 engine only: families already accumulated for the same spectra and
     expectation are copied over (a strided device copy) and only the missing ones are computed -- its CSM and
     per-observation planes are separate kernels, so a wPLI after a coherence costs the |Im s| plane alone."""
@@ -383,6 +388,16 @@ def accumulate(spectra, expectation_type, planes, n_freq=None, mark=None, use_fu
             # planes format: CSM (+ |Im s|) straight from the f16 pieces stage A wrote (sc_fused2.hip)
             ws_bytes = int(lib.sc_fused_workspace_bytes(byref(dp), planes))
             ws = _workspace(ws_bytes, spectra.device)
+            if not fold and ws is not None:
+                n_parts = ctypes.c_int(1)
+                _lib.check(lib.sc_fused2_csm_absim_parts_f32(_ptr(spectra.P), byref(dp), _ptr(spectra.scale), planes, _ptr(accum),
+                                                             _ptr(ws), ws_bytes, byref(n_parts), _stream()),
+                           "sc_fused2_csm_absim_parts_f32")
+                if n_parts.value > 1:
+                    accum._sc_parts = (ws, n_parts.value, n_bins * fpb)       # (the workspace is reused by the next call)
+                if mark:
+                    mark("fused2_csm_absim")
+                return accum, n_obs
             _lib.check(lib.sc_fused2_csm_absim_f32(_ptr(spectra.P), byref(dp), _ptr(spectra.scale), planes, _ptr(accum),
                                                    _ptr(ws) if ws is not None else None, ws_bytes, _stream()),
                        "sc_fused2_csm_absim_f32")
@@ -518,7 +533,14 @@ def measure_multi(accum, n_signals, planes, n_obs, which, wide=None, stacked=Fal
     ids = (ctypes.c_int * len(which))(*which)
     ptrs = (ctypes.c_void_p * len(which))(*[o.data_ptr() for o in outs])
     if parts is not None:
-        _lib.check(lib.sc_measure_multi_parts(_ptr(parts), parts.shape[0], parts.stride(0), n_bins, C, rec_planes(accum, planes),
+        _lib.check(lib.sc_measure_multi_parts(_ptr(parts[0]), _ptr(parts[1]), parts.shape[0], parts.stride(0), n_bins, C,
+                                              rec_planes(accum, planes), n_obs, len(which), ids, ptrs, int(bool(wide)), _stream()),
+                   "sc_measure_multi_parts")
+        return outs
+    pending = getattr(accum, "_sc_parts", None)
+    if pending is not None:
+        rest, n_parts, stride = pending        # split-bin partial records of stage B, not folded yet (accumulate(fold=False))
+        _lib.check(lib.sc_measure_multi_parts(_ptr(accum), _ptr(rest), n_parts, stride, n_bins, C, rec_planes(accum, planes),
                                               n_obs, len(which), ids, ptrs, int(bool(wide)), _stream()), "sc_measure_multi_parts")
         return outs
     fn = lib.sc_measure_multi_f64 if wide else lib.sc_measure_multi_f32

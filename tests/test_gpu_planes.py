@@ -21,15 +21,15 @@ def _dev():
     return torch.device("cuda:0")
 
 
-def _series(T, R, C, seed, offset=0.0):
+def _series(T, R, C, seed, offset=0.0, quiet=2e-3, loud=250.0):
     rng = np.random.default_rng(seed)
     t = np.arange(T) / 1000.0
     x = rng.standard_normal((T, R, C))
     # a shared 60 Hz component with a different lag in every channel (a zero-lag copy would make Im s a difference of large
     # numbers: the float32 engine's rounding, whatever the device format, would then dominate the phase-lag measures)
     x += 0.6 * np.sin(2 * np.pi * 60 * t[:, None, None] + 2 * np.pi * np.arange(C)[None, None, :] / C)
-    x[:, :, 0] *= 250.0                      # a loud channel
-    x[:, :, C - 1] *= 2e-3                   # a quiet one
+    x[:, :, 0] *= loud                       # a loud channel
+    x[:, :, C - 1] *= quiet                  # a quiet one
     return x + offset
 
 
@@ -128,7 +128,9 @@ def test_public_classes_take_the_planes_path_and_match_the_oracle(dtype):
     """Multitaper -> Connectivity(dtype=complex64) on a shape the planes format applies to: coherence and wPLI equal the CPU
     oracle's, the spectra were held as f16 pieces, and a measure outside the format's reach (PLV) decodes them transparently."""
     _dev()
-    x = _series(1024, 9, 12, seed=3)
+    # (channel amplitudes within 1 : 8 : 0.1 here: stage A packs two real channels into one complex transform, so a channel hundreds of times weaker than its
+    #  pair partner would carry the partner's float32 rounding -- a property of the float32 engine in either device format)
+    x = _series(1024, 9, 12, seed=3, quiet=0.1, loud=8.0)
     m = Multitaper(x, sampling_frequency=1000, time_halfbandwidth_product=3, n_time_samples_per_window=256, n_time_samples_per_step=128)
     c = Connectivity.from_multitaper(m, dtype=dtype)
     coh, wpli = c.coherence_magnitude(), c.weighted_phase_lag_index()
@@ -136,6 +138,18 @@ def test_public_classes_take_the_planes_path_and_match_the_oracle(dtype):
     coef, _ = so.multitaper_fft(x, fs=1000, NW=3, n_time_samples_per_window=256, n_time_samples_per_step=128)
     np.testing.assert_allclose(coh, so.coherence_magnitude(coef), rtol=2e-4, atol=2e-5, equal_nan=True)
     np.testing.assert_allclose(wpli, so.weighted_phase_lag_index(coef), rtol=2e-4, atol=2e-5)
+    # the complex64 path gives the same numbers
+    import os
+    os.environ["SC_PLANES_FORMAT"] = "0"
+    try:
+        c64 = Connectivity.from_multitaper(Multitaper(x, sampling_frequency=1000, time_halfbandwidth_product=3,
+                                                      n_time_samples_per_window=256, n_time_samples_per_step=128), dtype=dtype)
+        coh64, wpli64 = c64.coherence_magnitude(), c64.weighted_phase_lag_index()
+        assert c64._spectra.P is None
+    finally:
+        del os.environ["SC_PLANES_FORMAT"]
+    np.testing.assert_allclose(coh, coh64, rtol=0, atol=2e-6, equal_nan=True)
+    np.testing.assert_allclose(wpli, wpli64, rtol=0, atol=2e-6)
     plv = c.phase_locking_value()
     assert c._spectra._X is not None
     np.testing.assert_allclose(plv, so.phase_locking_value(coef), rtol=2e-4, atol=2e-5, equal_nan=True)
