@@ -294,8 +294,10 @@ int sc_spectra_from_planes_f32(const void* d_P, const sc_spectra_desc* desc, con
 /* Stage B on the planes format: the CSM planes and the |Im s| plane of every bin record in one pass, exactly what
  * sc_fused_csm_absim_ws_f32 writes (replaces _expectation_cross_spectral_matrix with fcn = identity and abs(Im),
  * connectivity.py:463-526, :982-1028).  desc: sizes and reduce flags (strides ignored: the rows are dense).  Takes
- * planes == SC_PLANE_CSM or SC_PLANE_CSM | SC_PLANE_ABS_IM, up to 128 signals, observations of a bin that form one linear
- * run of rows (every expectation type but "time_tapers" with several trials); sc_fused2_supported tells.
+ * planes == SC_PLANE_CSM, SC_PLANE_CSM | SC_PLANE_ABS_IM, the latter | SC_PLANE_IM_SQ (debiased wPLI: a second pass squares
+ * the per-observation products) or SC_PLANE_SIGN_IM alone (phase_lag_index: connectivity.py:933-980); up to 256 signals
+ * (129 ... 256 in several launches over 32-channel blocks); observations of a bin that form one linear run of rows (every
+ * expectation type but "time_tapers" with several trials); sc_fused2_supported tells.
  * Workspace as for sc_fused_csm_absim_ws_f32 (sc_fused_workspace_bytes with the same desc). */
 int sc_fused2_supported(const sc_spectra_desc* desc, uint32_t planes);
 /* The same without the pass that folds the split-bin partial records: *n_parts workgroups shared every bin; part 0 of the

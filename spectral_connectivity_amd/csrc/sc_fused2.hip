@@ -476,6 +476,8 @@ __device__ __forceinline__ void f2_valu_body(const Fused2Args& a, lds_u8* lds, u
     const FusedArgs& p = a.f;
     using Tab = FuTab<NB32, COL_LO, ROW_HI, SET>;
     constexpr int NBLK = Tab::NBLK;
+    // packed squares (v_pk_fma_f32 on aligned register pairs) only for single-set shapes: with two sets the pairs do not fit
+    constexpr bool PK = NBLK <= 4 && fu_nsets(NB32, COL_LO, ROW_HI) == 1;
     const int lane = tid & 63;
     f32x16 acc[NBLK > 0 ? NBLK : 1];
 #pragma unroll
@@ -525,11 +527,20 @@ __device__ __forceinline__ void f2_valu_body(const Fused2Args& a, lds_u8* lds, u
                     const f32x16 d = __builtin_amdgcn_mfma_f32_32x32x8f16(FA[w][Tab::tab.bi[s]], FB[w][Tab::tab.bj[s]], zero, 0, 0, 0);
                     // software pipeline: the accumulation of block s - 1 is issued AFTER the MFMA of block s
                     __builtin_amdgcn_sched_barrier(0);
-                    if (s > 0) fu_accumulate16<OP, (NBLK <= 4)>(acc[s - 1], dprev);
+                    if (s > 0) fu_accumulate16<OP, PK>(acc[s - 1], dprev);
                     dprev = d;
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                fu_accumulate16<OP, (NBLK <= 4)>(acc[NBLK - 1], dprev);
+                if constexpr (OP == FU_OP_SIGN && NBLK == 1) {
+                    // A lone block per row: the asm form of the sign accumulate (fu_accumulate16) would sit straight behind its
+                    // own MFMA, where only instructions the compiler can see get the wait states they need -- measured: wrong
+                    // sign sums from the second row of a wave on (<= 32 channels, > 8 observations).  Plain code here: one block
+                    // leaves the registers for it.
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[0][e] = fu_accumulate<OP>(acc[0][e], dprev[e]);
+                } else {
+                    fu_accumulate16<OP, PK>(acc[NBLK - 1], dprev);
+                }
             }
         }
         if (more) {       // chunk ch + 1 has landed once only the loads of chunk ch + 2 are outstanding
@@ -665,6 +676,14 @@ __global__ void __launch_bounds__(FU_THREADS) fused2_kernel(Fused2Args a) {
 }
 
 // ---- host ---------------------------------------------------------------------------------------------------------------------
+// What the planes-format kernels fill: the CSM planes, |Im s| with them, (Im s)^2 with both (a second pass of the same kernel:
+// the |Im s| waves square the per-observation products instead), and sign(Im s) on its own (a pass that sums signs as
+// integers) -- up to 256 signals (129 ... 256: the launches of sc_fused.hip's launch_fused_all, each staging four 32-channel
+// blocks), observations of a bin one linear run of rows.
+static bool fused2_families_ok(uint32_t fam) {
+    return fam == SC_PLANE_CSM || fam == (SC_PLANE_CSM | SC_PLANE_ABS_IM) ||
+           fam == (SC_PLANE_CSM | SC_PLANE_ABS_IM | SC_PLANE_IM_SQ) || fam == SC_PLANE_SIGN_IM;
+}
 static int fused2_setup(const sc_spectra_desc* desc, uint32_t planes, Fused2Args* out, ScAxes* ax_out) {
     SC_REQUIRE(desc, "NULL argument");
     sc_spectra_desc d = *desc;                 // rows of the planes buffer are dense [F][W][R][K]: strides in rows
@@ -674,45 +693,110 @@ static int fused2_setup(const sc_spectra_desc* desc, uint32_t planes, Fused2Args
     sc_make_axes(&d, &ax);
     SC_REQUIRE(ax.C >= 1 && ax.F >= 1 && ax.n_obs >= 1 && ax.n_groups >= 1, "empty dimension");
     const uint32_t fam = planes & ~(uint32_t)SC_RECORD_F64;
-    if ((fam != (SC_PLANE_CSM | SC_PLANE_ABS_IM) && fam != SC_PLANE_CSM) || (planes & SC_RECORD_F64) || ax.C > 128 ||
-        sc_stage_linear_stride(ax) <= 0) {
-        sc_set_error("planes-format stage B takes CSM (+ |Im s|) records of up to 128 signals whose observations are one linear run "
-                     "(got planes 0x%x, %d signals)", planes, ax.C);
+    if (!fused2_families_ok(fam) || (planes & SC_RECORD_F64) || ax.C > 256 || sc_stage_linear_stride(ax) <= 0) {
+        sc_set_error("planes-format stage B takes CSM (+ |Im s| (+ (Im s)^2)) or sign(Im s) records of up to 256 signals whose "
+                     "observations are one linear run (got planes 0x%x, %d signals)", planes, ax.C);
         return SC_EUNSUPPORTED;
     }
     Fused2Args& a = *out;
     FusedArgs& f = a.f;
     f.st.base = nullptr; f.st.ax = ax; f.st.obs_stride = sc_stage_linear_stride(ax); f.st.C = ax.C; f.st.n_obs = ax.n_obs;
-    f.NB32 = (ax.C + 31) / 32;
+    f.NB32 = (ax.C + 31) / 32;                  // of the whole record; a launch stages up to four (fused2_args_blocks)
     f.st.CP = f.NB32 * 32; f.st.RS = 0;
     f.NB = sc_n_blocks(ax.C);
     f.n_tiles = sc_n_tiles(f.NB);
     f.n_bins = ax.n_groups * ax.F;
     f.F = ax.F;
     f.floats_per_bin = (int64_t)sc_plane_count(planes) * f.n_tiles * SC_TILE_ELEMS;
-    f.csm_plane = sc_plane_offset(planes, SC_PLANE_CSM);
+    f.csm_plane = (planes & SC_PLANE_CSM) ? sc_plane_offset(planes, SC_PLANE_CSM) : -1;
     f.abs_plane = (planes & SC_PLANE_ABS_IM) ? sc_plane_offset(planes, SC_PLANE_ABS_IM) : -1;
-    f.sq_plane = -1; f.sign_plane = -1; f.n_fold = 0;
+    f.sq_plane = (planes & SC_PLANE_IM_SQ) ? sc_plane_offset(planes, SC_PLANE_IM_SQ) : -1;
+    f.sign_plane = (planes & SC_PLANE_SIGN_IM) ? sc_plane_offset(planes, SC_PLANE_SIGN_IM) : -1;
+    f.n_fold = 0;
     f.nl_op = FU_OP_ABS;
-    f.shape_col_lo = 0; f.shape_row_hi = f.NB32;
-    f.n_blocks32 = fu_nblocks(f.NB32, 0, f.NB32);
-    f.n_sets = fu_nsets(f.NB32, 0, f.NB32);
-    f.map.off32 = f.map.n32 = f.map.t32 = 0u;
-    for (int b = 0; b < f.NB32; ++b) {
-        const int n = ax.C - 32 * b < 32 ? ax.C - 32 * b : 32;
-        f.map.off32 |= (unsigned)b << (8 * b);
-        f.map.n32 |= (unsigned)n << (8 * b);
-        f.map.t32 |= (unsigned)(2 * b) << (8 * b);
-    }
-    f.map.NBr = f.NB; f.map.col_lo = 0; f.map.row_hi = 2 * f.NB32;
-    sc_internal_fu_assign_rows(&f);
     f.n_split = 1; f.ws = nullptr; f.debug_skip = 0;
+    f.map.NBr = f.NB;
     a.row_bytes = sc_planes_row_bytes(ax.C);
     a.obs_rows = f.st.obs_stride;
     a.terms4 = ax.n_obs < 256 ? 1 : 0;
-    a.loader_csm = f.NB32 >= 3 ? 1 : 0;      // measured (cfg3 volume): 128 channels 3.71 vs 3.82 ms with the CSM waves loading, 64 channels 3.23 vs 2.98
+    a.loader_csm = 1;
     *ax_out = ax;
     return SC_OK;
+}
+
+// One launch that stages the nb (<= 4) 32-channel blocks `blocks` (ascending block numbers of the record's channels) and owns
+// the products (bi <= bj, bj >= col_lo, bi < row_hi) of them (same scheme as fu_args_blocks of sc_fused.hip; the loader takes a
+// block's rows from tile off32 of the observation row).
+static Fused2Args fused2_args_blocks(const Fused2Args& full, const int* blocks, int nb, int col_lo, int row_hi) {
+    Fused2Args a = full;
+    FusedArgs& f = a.f;
+    const int C = full.f.st.C;
+    int n_last = 0;
+    f.map.off32 = f.map.n32 = f.map.t32 = 0u;
+    for (int b = 0; b < nb; ++b) {
+        const int c = blocks[b] * 32;
+        n_last = C - c < 32 ? C - c : 32;
+        f.map.off32 |= (unsigned)blocks[b] << (8 * b);
+        f.map.n32 |= (unsigned)n_last << (8 * b);
+        f.map.t32 |= (unsigned)(blocks[b] * 2) << (8 * b);
+    }
+    f.NB32 = nb;
+    f.NB = 2 * (nb - 1) + (n_last + 15) / 16;      // 16-channel tiles that exist among the staged blocks
+    f.shape_col_lo = col_lo;
+    f.shape_row_hi = row_hi;
+    f.n_blocks32 = fu_nblocks(nb, col_lo, row_hi);
+    f.n_sets = fu_nsets(nb, col_lo, row_hi);
+    f.st.CP = nb * 32;
+    f.map.col_lo = 2 * col_lo;
+    f.map.row_hi = 2 * row_hi;
+    sc_internal_fu_assign_rows(&f);
+    // measured at the cfg3 volume: 128 channels 3.71 vs 3.82 ms with the CSM waves loading, 64 channels 3.23 vs 2.98
+    a.loader_csm = nb >= 3 ? 1 : 0;
+    return a;
+}
+
+#define F2_SHAPES(X) X(1, 0, 1) X(2, 0, 2) X(3, 0, 3) X(4, 0, 4) X(4, 2, 2) X(3, 1, 3) X(4, 2, 4) X(4, 1, 4) X(4, 1, 1)
+template <int NB32, int COL_LO, int ROW_HI, int OP>
+static void fused2_launch_op(const Fused2Args& a, hipStream_t s) {
+    auto k = fused2_kernel<NB32, COL_LO, ROW_HI, OP>;
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F2_LDS);
+    hipLaunchKernelGGL(k, dim3((unsigned)(a.f.n_bins * a.f.n_split)), dim3(FU_THREADS), F2_LDS, s, a);
+}
+static int fused2_launch(const Fused2Args& a, int op, hipStream_t s) {
+    const int shape = a.f.NB32 * 100 + a.f.shape_col_lo * 10 + a.f.shape_row_hi;
+#define F2_CASE(NB32, COL_LO, ROW_HI)                                                              \
+    case NB32 * 100 + COL_LO * 10 + ROW_HI:                                                        \
+        if (op == FU_OP_SQ) fused2_launch_op<NB32, COL_LO, ROW_HI, FU_OP_SQ>(a, s);                \
+        else if (op == FU_OP_SIGN) fused2_launch_op<NB32, COL_LO, ROW_HI, FU_OP_SIGN>(a, s);       \
+        else fused2_launch_op<NB32, COL_LO, ROW_HI, FU_OP_ABS>(a, s);                              \
+        break;
+    switch (shape) {
+        F2_SHAPES(F2_CASE)
+    default:
+        sc_set_error("planes-format stage B: no launch shape (%d staged blocks, column %d, %d rows)", a.f.NB32, a.f.shape_col_lo, a.f.shape_row_hi);
+        return SC_EINVAL;
+    }
+#undef F2_CASE
+    SC_CHECK_HIP(hipGetLastError());
+    return SC_OK;
+}
+// every tile of the record once (the launch plans of sc_fused.hip: launch_fused_all)
+static int fused2_launch_all(const Fused2Args& full, int op, hipStream_t s) {
+    const int C = full.f.st.C, n = (C + 31) / 32;
+    struct Plan { int nb, blocks[4], col_lo, row_hi; };
+    static const Plan tri[4] = {{1, {0}, 0, 1}, {2, {0, 1}, 0, 2}, {3, {0, 1, 2}, 0, 3}, {4, {0, 1, 2, 3}, 0, 4}};
+    static const Plan p5[] = {{3, {0, 1, 2}, 0, 3}, {4, {0, 1, 3, 4}, 2, 2}, {3, {2, 3, 4}, 1, 3}};
+    static const Plan p6[] = {{4, {0, 1, 2, 3}, 0, 4}, {4, {0, 1, 4, 5}, 2, 4}, {4, {2, 3, 4, 5}, 2, 2}};
+    static const Plan p7[] = {{4, {0, 1, 2, 3}, 0, 4}, {4, {0, 4, 5, 6}, 1, 4}, {4, {1, 4, 5, 6}, 1, 1},
+                              {4, {2, 4, 5, 6}, 1, 1}, {4, {3, 4, 5, 6}, 1, 1}};
+    static const Plan p8[] = {{4, {0, 1, 2, 3}, 0, 4}, {4, {4, 5, 6, 7}, 0, 4}, {4, {0, 1, 4, 5}, 2, 2},
+                              {4, {0, 1, 6, 7}, 2, 2}, {4, {2, 3, 4, 5}, 2, 2}, {4, {2, 3, 6, 7}, 2, 2}};
+    const Plan* plan = n <= 4 ? &tri[n - 1] : n == 5 ? p5 : n == 6 ? p6 : n == 7 ? p7 : p8;
+    const int n_launch = n <= 4 ? 1 : n == 5 ? 3 : n == 6 ? 3 : n == 7 ? 5 : 6;
+    int rc = SC_OK;
+    for (int l = 0; l < n_launch && rc == SC_OK; ++l)
+        rc = fused2_launch(fused2_args_blocks(full, plan[l].blocks, plan[l].nb, plan[l].col_lo, plan[l].row_hi), op, s);
+    return rc;
 }
 
 extern "C" int sc_fused2_supported(const sc_spectra_desc* desc, uint32_t planes) {
@@ -735,14 +819,16 @@ static int fused2_run(const void* d_P, const sc_spectra_desc* desc, const float*
     a.P = (const unsigned char*)d_P;
     a.inv_scale = d_scale + ax.C;
     f.accum = d_accum;
+    int loader = -1;
     {
         const char* dbg = getenv("SC_FUSED_DEBUG");
         f.debug_skip = dbg ? atoi(dbg) : 0;
         const char* t4 = getenv("SC_FUSED2_TERMS");
         if (t4) a.terms4 = atoi(t4) == 4 ? 1 : 0;
-        const char* ld = getenv("SC_FUSED2_LOADER");           // A/B: "abs" = the |Im s| waves load
-        if (ld) a.loader_csm = (ld[0] == 'a') ? 0 : 1;
+        const char* ld = getenv("SC_FUSED2_LOADER");           // A/B: "abs" = the |Im s| waves load, "csm" = the CSM waves
+        if (ld) loader = (ld[0] == 'a') ? 0 : 1;
     }
+    (void)loader;
     int S = sc_internal_fused_pick_split(f.n_bins, ax.n_obs);
     const int64_t part_bytes = (int64_t)f.n_bins * f.floats_per_bin * (int64_t)sizeof(float);
     if (!d_workspace) S = 1;
@@ -751,23 +837,36 @@ static int fused2_run(const void* d_P, const sc_spectra_desc* desc, const float*
     f.n_split = S;
     f.ws = (float*)d_workspace;
     hipStream_t s = (hipStream_t)stream;
-#define F2_LAUNCH(NB32)                                                                                               \
-    case NB32: {                                                                                                      \
-        auto k = fused2_kernel<NB32, 0, NB32, FU_OP_ABS>;                                                            \
-        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F2_LDS);           \
-        hipLaunchKernelGGL(k, dim3((unsigned)(f.n_bins * f.n_split)), dim3(FU_THREADS), F2_LDS, s, a);                \
-        break;                                                                                                        \
+    const bool parts_ok = n_parts && ax.C <= 128 && f.sq_plane < 0 && f.sign_plane < 0;
+    if (n_parts) *n_parts = 1;
+    if (f.sign_plane >= 0) {
+        // sign(Im s) summed as integers by the |Im s| waves; the CSM waves only load
+        Fused2Args b = a;
+        b.f.csm_plane = -1;
+        b.f.abs_plane = f.sign_plane;
+        b.f.nl_op = FU_OP_SIGN;
+        b.f.fold[0] = b.f.abs_plane; b.f.n_fold = 1;
+        const int rc2 = fused2_launch_all(b, FU_OP_SIGN, s);
+        return rc2 != SC_OK ? rc2 : sc_internal_fused_combine(b.f, FU_OP_SIGN, s);
     }
-    switch (f.NB32) {
-        F2_LAUNCH(1) F2_LAUNCH(2) F2_LAUNCH(3) F2_LAUNCH(4)
-    default:
-        sc_set_error("planes-format stage B: %d staged blocks", f.NB32);
-        return SC_EINVAL;
+    {
+        Fused2Args m = a;
+        m.f.sq_plane = -1;
+        const int rc2 = fused2_launch_all(m, FU_OP_ABS, s);
+        if (rc2 != SC_OK) return rc2;
+        if (parts_ok) { *n_parts = f.n_split; return SC_OK; }      // the caller's epilogue sums the parts
+        const int rc3 = sc_internal_fused_combine(m.f, FU_OP_ABS, s);
+        if (rc3 != SC_OK || f.sq_plane < 0) return rc3;
     }
-#undef F2_LAUNCH
-    SC_CHECK_HIP(hipGetLastError());
-    if (n_parts) { *n_parts = f.n_split; return SC_OK; }      // the caller's epilogue sums the parts
-    return sc_internal_fused_combine(f, FU_OP_ABS, s);
+    // debiased wPLI: sum (Im s)^2 as a second pass (the |Im s| waves hold 80 accumulator registers per plane)
+    Fused2Args b = a;
+    b.f.csm_plane = -1;
+    b.f.abs_plane = f.sq_plane;
+    b.f.sq_plane = -1;
+    b.f.nl_op = FU_OP_SQ;
+    b.f.fold[0] = b.f.abs_plane; b.f.n_fold = 1;
+    const int rc4 = fused2_launch_all(b, FU_OP_SQ, s);
+    return rc4 != SC_OK ? rc4 : sc_internal_fused_combine(b.f, FU_OP_SQ, s);
 }
 extern "C" int sc_fused2_csm_absim_f32(const void* d_P, const sc_spectra_desc* desc, const float* d_scale, uint32_t planes,
                                        float* d_accum, void* d_workspace, int64_t workspace_bytes, void* stream) {

@@ -169,14 +169,20 @@ def twiddles(n_fft, device):
     return tw
 
 
-PLANES_FORMAT_FAMILIES = (_lib.PLANE_CSM, _lib.PLANE_CSM | _lib.PLANE_ABS_IM)   # what sc_fused2.hip accumulates
+PLANES_FORMAT_FAMILIES = (_lib.PLANE_CSM, _lib.PLANE_CSM | _lib.PLANE_ABS_IM, _lib.PLANE_CSM | _lib.PLANE_ABS_IM | _lib.PLANE_IM_SQ,
+                          _lib.PLANE_SIGN_IM)   # what sc_fused2.hip accumulates
 
 
 def planes_format_applies(n_window, n_fft, n_alloc, planes_hint):
     """Does stage A write the planes format for a caller that will ask for the accumulator families ``planes_hint``?"""
     if planes_hint not in PLANES_FORMAT_FAMILIES or os.environ.get("SC_PLANES_FORMAT", "1") == "0":
         return False
-    return n_alloc <= 128 and bool(_lib.load().sc_multitaper_fft_planes_supported(n_window, n_fft, n_alloc))
+    # Below these channel counts the float32 VALU kernel of sc_fused.hip on complex64 spectra is the faster stage B (it is
+    # HBM-bound there; crossovers measured at the cfg3 volume, profiles/r04_shape_sweep.txt)
+    lo = {_lib.PLANE_CSM: 40, _lib.PLANE_CSM | _lib.PLANE_ABS_IM: 44, _lib.PLANE_CSM | _lib.PLANE_ABS_IM | _lib.PLANE_IM_SQ: 60,
+          _lib.PLANE_SIGN_IM: 48}[planes_hint]
+    lo = int(os.environ.get("SC_PLANES_MIN_CHANNELS", lo))
+    return lo <= n_alloc <= 256 and bool(_lib.load().sc_multitaper_fft_planes_supported(n_window, n_fft, n_alloc))
 
 
 def multitaper_spectra(x, tapers_over_fs, n_window, n_step, n_fft, n_windows, detrend_type, mark=None,

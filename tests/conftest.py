@@ -34,8 +34,9 @@ def pytest_generate_tests(metafunc):
     if only is not None and metafunc.function.__name__ not in only:
         precisions = None
     if precisions and "_engine_precision" in metafunc.fixturenames:
+        names = {"float32": "f32-engine", "float32+planes": "f32-planes"}
         metafunc.parametrize("_engine_precision", list(precisions), indirect=True,
-                             ids=["f32-engine" if p == "float32" else "default-engine" for p in precisions])
+                             ids=[names.get(p, "default-engine") for p in precisions])
 
 
 @pytest.fixture(autouse=True)
@@ -45,9 +46,21 @@ def _engine_precision(request):
     see pytest_generate_tests)."""
     from spectral_connectivity_amd import options
     old = options.precision
-    options.precision = getattr(request, "param", None) or getattr(request.module, "SC_PRECISION", "float32")
+    want = getattr(request, "param", None) or getattr(request.module, "SC_PRECISION", "float32")
+    # "float32+planes": the float32 engine with the planes format (f16 pieces, sc_fused2.hip) from two channels on -- by default
+    # it starts at 40-60 channels, where the golden shapes never get
+    planes = want == "float32+planes"
+    old_env = os.environ.get("SC_PLANES_MIN_CHANNELS")
+    if planes:
+        os.environ["SC_PLANES_MIN_CHANNELS"] = "2"
+    options.precision = "float32" if planes else want
     yield options.precision
     options.precision = old
+    if planes:
+        if old_env is None:
+            os.environ.pop("SC_PLANES_MIN_CHANNELS", None)
+        else:
+            os.environ["SC_PLANES_MIN_CHANNELS"] = old_env
 
 
 def granger_close(got, ref, tol, what="granger"):

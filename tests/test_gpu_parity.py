@@ -11,7 +11,8 @@ from conftest import granger_close
 from oracle import spectral_oracle as so
 
 pytestmark = pytest.mark.gpu
-SC_PRECISIONS = ("float32", "dtype")     # under the forced float32 engine AND the package default (float64 engine for the
+SC_PRECISIONS = ("float32", "float32+planes", "dtype")     # under the forced float32 engine (complex64 spectra, and once more with the
+# planes format of round  4 from two channels on) AND the package default (float64 engine for the
 # default dtype): every test against the reference's golden vectors, the labelled wrapper, the dtype / NaN / complex-input
 # behaviour and the eigen-solver.  The kernel-selection tests below exercise float32 kernels explicitly and run once
 # (their float64 counterparts live in tests/test_gpu_fp64.py).

@@ -16,6 +16,14 @@ from spectral_connectivity_amd import Connectivity, Multitaper, _lib, engine, tr
 PLANES = _lib.PLANE_CSM | _lib.PLANE_ABS_IM
 
 
+@pytest.fixture(autouse=True)
+def _planes_from_two_channels(monkeypatch, request):
+    """The engine takes the planes format from 40-60 channels on (below, the small-channel kernel on complex64 spectra is
+    faster); the tests of the format itself lift that threshold so that small shapes exercise it too."""
+    if "default_thresholds" not in request.keywords:
+        monkeypatch.setenv("SC_PLANES_MIN_CHANNELS", "2")
+
+
 def _dev():
     _lib.require_gpu()
     return torch.device("cuda:0")
@@ -155,6 +163,18 @@ def test_public_classes_take_the_planes_path_and_match_the_oracle(dtype):
     np.testing.assert_allclose(plv, so.phase_locking_value(coef), rtol=2e-4, atol=2e-5, equal_nan=True)
 
 
+@pytest.mark.default_thresholds
+def test_few_channels_keep_complex64_by_default():
+    """Below the measured crossover (44 channels for CSM + |Im s|) the float32 engine keeps complex64 spectra."""
+    dev = _dev()
+    tapers = np.asarray(transforms.dpss_windows(128, 2, 3)[0])[:3]
+    h = torch.from_numpy(np.ascontiguousarray(tapers / np.sqrt(1000.0), dtype=np.float32)).to(dev)
+    for C, expect in ((32, False), (64, True)):
+        x = torch.from_numpy(_series(512, 2, C, seed=1).astype(np.float32)).to(dev)
+        sp = engine.multitaper_spectra(x, h, 128, 128, 128, 4, "constant", planes_hint=PLANES)
+        assert (sp.P is not None) == expect
+
+
 def test_planes_switch_gives_the_complex64_path():
     """SC_PLANES_FORMAT=0: the same call keeps complex64 spectra (the format is a device detail, not an interface)."""
     import os
@@ -168,3 +188,30 @@ def test_planes_switch_gives_the_complex64_path():
     finally:
         del os.environ["SC_PLANES_FORMAT"]
     assert sp.P is None and sp._X is not None
+
+
+@pytest.mark.parametrize("C", [64, 130, 200])
+def test_every_planes_family_through_the_public_classes(C):
+    """coherence, wPLI, debiased wPLI and PLI of 64 ... 200 channels (above 128: several launches over 32-channel blocks;
+    (Im s)^2 and sign(Im s): plane passes of the same kernel) through Multitaper -> Connectivity(dtype=complex64), every one
+    computed from spectra held as f16 pieces, against the CPU oracle."""
+    _dev()
+    R, L = 5, 64
+    x = _series(192, R, C, seed=C, quiet=0.2, loud=4.0)
+    kw = dict(sampling_frequency=1000, time_halfbandwidth_product=2, n_time_samples_per_window=L, n_time_samples_per_step=L)
+    coef, _ = so.multitaper_fft(x, fs=1000, NW=2, n_time_samples_per_window=L, n_time_samples_per_step=L)
+    checks = (("coherence_magnitude", so.coherence_magnitude), ("weighted_phase_lag_index", so.weighted_phase_lag_index),
+              ("debiased_squared_weighted_phase_lag_index", so.debiased_squared_weighted_phase_lag_index),
+              ("phase_lag_index", so.phase_lag_index))
+    for name, ref_fn in checks:
+        c = Connectivity.from_multitaper(Multitaper(x, **kw), dtype=np.complex64)       # a fresh object: the first request picks the format
+        got = getattr(c, name)()
+        assert c._spectra.P is not None and c._spectra._X is None, name
+        ref = ref_fn(coef)
+        if name == "phase_lag_index":
+            # a sign can flip where Im s is at the float32 rounding level: a few entries may differ by 2 / n_observations
+            n = c.n_observations
+            bad = np.abs(got - ref) > 1e-6
+            assert bad.mean() < 2e-4 and np.all(np.abs(got - ref)[bad] <= 2.0 / n + 1e-6), name
+        else:
+            np.testing.assert_allclose(got, ref, rtol=5e-4, atol=5e-5, equal_nan=True, err_msg=name)

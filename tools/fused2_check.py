@@ -13,10 +13,10 @@ from spectral_connectivity_amd import _lib, engine      # noqa: E402
 
 lib = _lib.load()
 dev = torch.device("cuda:0")
-planes = _lib.PLANE_CSM | _lib.PLANE_ABS_IM
+PLANES0 = _lib.PLANE_CSM | _lib.PLANE_ABS_IM
 
 
-def run(C, R, F=5, W=2, K=7, timing=False):
+def run(C, R, F=5, W=2, K=7, timing=False, planes=PLANES0):
     torch.manual_seed(C * 1000 + R)
     X = torch.view_as_complex(torch.randn((F, W, R, K, C, 2), dtype=torch.float32, device=dev))
     X = X * (0.5 + torch.rand((1, 1, 1, 1, C), device=dev)) + 0.3 * X[..., :1]          # correlated channels
@@ -35,6 +35,7 @@ def run(C, R, F=5, W=2, K=7, timing=False):
     print(f"    format round trip: max relative error {rt:.2e} (22 significant bits: <= 2.4e-7); scales 2^{torch.log2(scale[:C]).min().item():.0f} .. 2^{torch.log2(scale[:C]).max().item():.0f}")
     ok = lib.sc_fused2_supported(byref(d), planes)
     ref, n_obs = engine.accumulate(sp, "trials_tapers", planes)
+    torch.cuda.synchronize()
     n_bins, fpb, _, _ = engine.accum_layout(sp, "trials_tapers", planes)
     if not ok:
         print(f"C={C} R={R}: not supported (n_obs={n_obs})")
@@ -48,12 +49,14 @@ def run(C, R, F=5, W=2, K=7, timing=False):
     Xd = X.to(torch.complex128)
     S = torch.einsum("fwrkc,fwrkd->wfcd", Xd, Xd.conj())                       # [W][F][C][C]
 
-    nt = fpb // 3 // 256
-    a, b = out.view(n_bins, 3, nt, 256), ref.view(n_bins, 3, nt, 256)
+    npl = {_lib.PLANE_CSM: 2, PLANES0: 3, PLANES0 | _lib.PLANE_IM_SQ: 4, _lib.PLANE_SIGN_IM: 1}[planes]
+    nt = fpb // npl // 256
+    a, b = out.view(n_bins, npl, nt, 256), ref.view(n_bins, npl, nt, 256)
     NB = (C + 15) // 16
     smax = S.abs().amax().item()
     errs = []
-    for pl, name in ((0, "Re S"), (1, "Im S"), (2, "sum |Im s|")):
+    names = {1: ["sum sign Im s"], 2: ["Re S", "Im S"], 3: ["Re S", "Im S", "sum |Im s|"], 4: ["Re S", "Im S", "sum |Im s|", "sum (Im s)^2"]}[npl]
+    for pl, name in enumerate(names):
         # only entries of real channels: compare tile by tile on the valid part
         worst = 0.0
         t = 0
@@ -63,12 +66,12 @@ def run(C, R, F=5, W=2, K=7, timing=False):
                 ta = a[:, pl, t].view(n_bins, 16, 16)[:, :ni, :nj]
                 tb = b[:, pl, t].view(n_bins, 16, 16)[:, :ni, :nj]
                 if bi == bj:
-                    iu = torch.triu_indices(ni, nj, device=dev)
+                    iu = torch.triu_indices(ni, nj, offset=1, device=dev)   # (the diagonal of Im-type planes is rounding noise in either kernel; no measure reads it)
                     ta, tb = ta[:, iu[0], iu[1]], tb[:, iu[0], iu[1]]
                 worst = max(worst, (ta - tb).abs().max().item())
                 t += 1
-        errs.append(worst / smax)
-    print(f"C={C:4d} R={R:5d} n_obs={n_obs:6d}: max |new - old| / max|S| per plane: " + "  ".join(f"{e:.2e}" for e in errs)
+        errs.append(worst / (smax * smax if name == "sum (Im s)^2" else (1.0 if npl == 1 else smax)))
+    print(f"C={C:4d} R={R:5d} n_obs={n_obs:6d} planes=0x{planes:x}: max |new - old| / max|S| per plane: " + "  ".join(f"{e:.2e}" for e in errs)
           + ("  NaN!" if not torch.isfinite(out).all() else ""))
     if timing:
         for name, fn in (("old (complex64)", lambda: engine.accumulate(sp, "trials_tapers", planes)),
@@ -84,7 +87,12 @@ def run(C, R, F=5, W=2, K=7, timing=False):
 
 
 if __name__ == "__main__":
-    for C, R in ((128, 80), (64, 80), (96, 100), (32, 90), (100, 77), (128, 75), (128, 3), (64, 1), (20, 10)):
+    for C, R in ((128, 80), (64, 80), (96, 100), (32, 90), (100, 77), (128, 75), (128, 3), (64, 1), (20, 10), (130, 40), (160, 40),
+                 (192, 30), (200, 33), (224, 20), (256, 40)):
         run(C, R)
+    for C, R in ((128, 80), (60, 40), (160, 20), (256, 12)):
+        run(C, R, planes=PLANES0 | _lib.PLANE_IM_SQ)
+        run(C, R, planes=_lib.PLANE_SIGN_IM)
+        run(C, R, planes=_lib.PLANE_CSM)
     run(128, 1000, F=129, W=7, timing=True)
     run(64, 2000, F=129, W=7, timing=True)

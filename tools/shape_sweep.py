@@ -57,4 +57,21 @@ for C in CHANNELS:
     for _, planes in families:
         row.append(timed(lambda: engine.accumulate(sp, "trials_tapers", planes)) * 1e3)
     print(f"{C:8d}  " + "  ".join(f"{v:22.2f}" for v in row))
+    if Cp % 2 == 0:
+        # the same spectra in the planes format (two f16 pieces per real number, sc_fused2.hip): what the float32 engine runs from
+        # 49 channels on for these families (s/|s| has no planes-format kernel)
+        from ctypes import byref
+        lib = _lib.load()
+        d = sp.desc("trials_tapers", padded=True)
+        P = torch.zeros((F * W * R * K * lib.sc_planes_row_bytes(Cp),), dtype=torch.uint8, device=dev)
+        scale = torch.empty((2 * Cp,), dtype=torch.float32, device=dev)
+        work = torch.empty((Cp,), dtype=torch.int32, device=dev)
+        _lib.check(lib.sc_planes_scales_from_spectra_f32(X.data_ptr(), F * W * R * K, Cp, scale.data_ptr(), work.data_ptr(), None), "scales")
+        _lib.check(lib.sc_planes_from_spectra_f32(X.data_ptr(), byref(d), scale.data_ptr(), P.data_ptr(), None), "to planes")
+        spp = engine.DeviceSpectra(None, (F, W, R, K, C), sp.strides, 256, True, C_alloc=Cp, P=P, scale=scale)
+        row = []
+        for _, planes in families[:4]:
+            row.append(timed(lambda: engine.accumulate(spp, "trials_tapers", planes)) * 1e3)
+        print(f"  planes  " + "  ".join(f"{v:22.2f}" for v in row))
+        del P, spp
     del X, sp, x
