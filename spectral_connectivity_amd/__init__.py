@@ -38,7 +38,9 @@ def __getattr__(name):
         return value
     try:                                   # submodules: spectral_connectivity_amd.transforms, .engine, ...
         return importlib.import_module("." + name, __name__)
-    except ModuleNotFoundError:
+    except ModuleNotFoundError as exc:
+        if exc.name != f"{__name__}.{name}":
+            raise                          # a real submodule whose own import failed (torch missing, ...): say so
         raise AttributeError(f"module {__name__!r} has no attribute {name!r}") from None
 
 

@@ -632,6 +632,11 @@ extern "C" int sc_accumulate_f64(const void* d_X, const sc_spectra_desc* desc, u
     // of this call, allocated BEFORE the fork (both streams write disjoint planes of it) and released after the join
     const bool block_planes = a.C >= 48 && !getenv("SC_F64_NO_BLOCK") && (which & (SC_PLANE_ABS_IM | SC_PLANE_IM_SQ | SC_PLANE_SIGN_IM));
     double* ws = nullptr;
+    struct ScratchGuard {         // the scratch goes back to the pool on EVERY way out of this call, behind the work queued on `s`
+        double*& p;
+        hipStream_t s;
+        ~ScratchGuard() { if (p) (void)hipFreeAsync(p, s); }
+    } ws_guard{ws, (hipStream_t)stream};
     if ((which & (SC_PLANE_CSM | SC_PLANE_UNIT)) || block_planes) {
         int S = f64_pick_split((int64_t)a.n_bins * ((a.n_tiles + 35) / 36), a.n_obs, F64B_OC);
         const int64_t part_bytes = a.ws_part * (int64_t)sizeof(double);
@@ -646,9 +651,9 @@ extern "C" int sc_accumulate_f64(const void* d_X, const sc_spectra_desc* desc, u
     }
     hipStream_t st_nl = st;
     if (fork) {
-        SC_CHECK_HIP(hipEventRecord(ev_fork, st));
-        SC_CHECK_HIP(hipStreamWaitEvent(side, ev_fork, 0));
-        st_nl = side;
+        // (a fork that cannot be set up is not an error: the planes then run behind the CSM on the caller's stream)
+        if (hipEventRecord(ev_fork, st) == hipSuccess && hipStreamWaitEvent(side, ev_fork, 0) == hipSuccess) st_nl = side;
+        else (void)hipGetLastError();
     }
     if (which & SC_PLANE_CSM) {
         a.plane = sc_plane_offset(planes, SC_PLANE_CSM);
@@ -687,10 +692,12 @@ extern "C" int sc_accumulate_f64(const void* d_X, const sc_spectra_desc* desc, u
             if (rc) break;
         }
     } while (0);
-    if (fork) {
-        SC_CHECK_HIP(hipEventRecord(ev_join, side));
-        SC_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, ev_join, 0));
+    if (st_nl != (hipStream_t)stream) {
+        // the join must happen whatever the launches returned: the side stream may hold work that reads the scratch
+        if (hipEventRecord(ev_join, side) != hipSuccess || hipStreamWaitEvent((hipStream_t)stream, ev_join, 0) != hipSuccess) {
+            (void)hipStreamSynchronize(side);
+            if (rc == SC_OK) { sc_set_error("sc_accumulate_f64: joining the side stream failed"); rc = SC_EHIP; }
+        }
     }
-    if (ws) (void)hipFreeAsync(ws, (hipStream_t)stream);
-    return rc;
+    return rc;            // (ws_guard releases the scratch behind everything queued on the caller's stream)
 }

@@ -700,15 +700,22 @@ extern "C" int sc_global_coherence_f64(const void* d_accum, int64_t n_groups, in
     if (C > GC_CMAX && !(eig_env && strcmp(eig_env, "jacobi") == 0)) {
         // Householder tridiagonalisation + bisection + inverse iteration, matrix and work arrays in a scratch of this call
         const int64_t bins = n_groups * N;
-        const int slots = (int)(bins < 1024 ? bins : 1024);
-        const size_t a_bytes = (size_t)slots * C * C * sizeof(cd);
-        const size_t w_bytes = (size_t)slots * 8 * C * max_rank * sizeof(double);
+        // slots (workgroups that walk the bins): as many as 1 GB of scratch holds, at most 1024; halved while the allocation fails
+        const size_t per_slot = (size_t)C * C * sizeof(cd) + (size_t)8 * C * max_rank * sizeof(double);
+        int slots = (int)(bins < 1024 ? bins : 1024);
+        const size_t budget_slots = ((size_t)1 << 30) / per_slot;
+        if ((size_t)slots > budget_slots) slots = budget_slots < 1 ? 1 : (int)budget_slots;
         char* scratch = nullptr;
-        if (hipMalloc((void**)&scratch, a_bytes + w_bytes) != hipSuccess) {
+        while (hipMalloc((void**)&scratch, (size_t)slots * per_slot) != hipSuccess) {
             (void)hipGetLastError();
-            sc_set_error("global coherence: scratch alloc failed (%zu bytes)", a_bytes + w_bytes);
-            return SC_ENOMEM;
+            scratch = nullptr;
+            if (slots == 1) {
+                sc_set_error("global coherence: scratch alloc failed (%zu bytes)", per_slot);
+                return SC_ENOMEM;
+            }
+            slots = (slots + 1) / 2;
         }
+        const size_t a_bytes = (size_t)slots * C * C * sizeof(cd);
         GcEighArgs b;
         b.g = a; b.A = (cd*)scratch; b.work = (double*)(scratch + a_bytes); b.n_bins_total = (int)bins; b.KS = max_rank;
         const size_t lds = ((size_t)12 * C + GE_NT) * sizeof(double) + 64;

@@ -628,10 +628,17 @@ mtfft16_kernel(MtArgs p) {
                     }
                     if (p.dbg & 1) continue;
                     unsigned char* dst = dst0 + (int64_t)f * rows_f * p.row_bytes;
-                    *reinterpret_cast<u32x4_t*>(dst) = rh;
-                    *reinterpret_cast<u32x4_t*>(dst + 64) = rm;
-                    *reinterpret_cast<u32x4_t*>(dst + 128) = ih;
-                    *reinterpret_cast<u32x4_t*>(dst + 192) = im;
+                    if (p.dbg & 32) {          // A/B: non-temporal
+                        __builtin_nontemporal_store(rh, reinterpret_cast<u32x4_t*>(dst));
+                        __builtin_nontemporal_store(rm, reinterpret_cast<u32x4_t*>(dst + 64));
+                        __builtin_nontemporal_store(ih, reinterpret_cast<u32x4_t*>(dst + 128));
+                        __builtin_nontemporal_store(im, reinterpret_cast<u32x4_t*>(dst + 192));
+                    } else {
+                        *reinterpret_cast<u32x4_t*>(dst) = rh;
+                        *reinterpret_cast<u32x4_t*>(dst + 64) = rm;
+                        *reinterpret_cast<u32x4_t*>(dst + 128) = ih;
+                        *reinterpret_cast<u32x4_t*>(dst + 192) = im;
+                    }
                 }
                 continue;
             }

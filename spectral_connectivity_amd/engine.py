@@ -555,6 +555,17 @@ def measure_multi(accum, n_signals, planes, n_obs, which, wide=None, stacked=Fal
     return outs
 
 
+MAX_WILSON_ITERATIONS = 1024      # iterations the device kernels can log (WILSON_HIST / MV_HIST in csrc)
+
+
+def check_max_iterations(max_iterations):
+    """The reference takes any positive count (minimum_phase_decomposition.py:227-322); the device kernels log at most 1024."""
+    if not 1 <= int(max_iterations) <= MAX_WILSON_ITERATIONS:
+        raise ValueError(f"max_iterations must be between 1 and {MAX_WILSON_ITERATIONS} on the device path (got {max_iterations}); "
+                         "Wilson's iteration converges in tens of steps or not at all")
+    return int(max_iterations)
+
+
 GRANGER_WORK_BYTES = 8 << 30      # workspace bound of one sc_granger_pairwise_f64 call (160 bytes per problem and bin)
 
 
@@ -565,6 +576,7 @@ def granger_pairwise(accum, n_groups, n_freq_accum, n_fft, n_signals, planes, n_
     covariance was not positive definite).  A long pair list is walked in chunks that bound the workspace; every
     chunk writes its pairs into the same output."""
     lib = _lib.load()
+    max_iterations = check_max_iterations(max_iterations)
     dev = accum.device
     pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
     n_pairs = pairs.shape[0]
@@ -608,6 +620,7 @@ def mvar_factor(n_groups, n_fft, n_signals, accum=None, n_freq_accum=0, planes=0
                 tolerance=1e-8, max_iterations=60):
     """Full C x C Wilson factor (sc_mvar.hip) of accumulator records or of a two-sided complex128 spectrum
     tensor [n_groups, n_fft, C, C].  Returns (G [n_groups, n_fft, C, C] complex128, n_iter, status, summary)."""
+    max_iterations = check_max_iterations(max_iterations)
     lib = _lib.load()
     src = accum if accum is not None else spectra
     dev = src.device

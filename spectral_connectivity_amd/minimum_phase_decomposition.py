@@ -29,7 +29,8 @@ def minimum_phase_decomposition(cross_spectral_matrix, tolerance=1e-8, max_itera
     import torch
 
     from . import _lib
-    from .engine import _ptr, _stream
+    from .engine import _ptr, _stream, check_max_iterations
+    max_iterations = check_max_iterations(max_iterations)
     _lib.require_gpu()
     lib = _lib.load()
     csm = np.asarray(cross_spectral_matrix)

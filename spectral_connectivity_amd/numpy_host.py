@@ -145,10 +145,11 @@ class NumpyHost:
 
     def upload(self, array):
         """Contiguous NumPy array -> device buffer (asynchronous when the array is page-locked)."""
+        pinned = isinstance(array, PinnedArray) and array.flags.c_contiguous     # (ascontiguousarray returns a base-class array)
         a = np.ascontiguousarray(array)
         buf = self.alloc(a.nbytes)
         _lib.check(self.lib.sc_memcpy_h2d(buf.ptr, a.ctypes.data_as(c_void_p), a.nbytes, self.stream), "sc_memcpy_h2d")
-        if not isinstance(a, PinnedArray):
+        if not pinned:
             self.synchronize()             # a pageable source may be reused by the caller as soon as this returns
         return buf
 

@@ -295,6 +295,12 @@ class Multitaper:
 
     Parameters are those of reference transforms.py:574-589.  ``time_series`` has shape
     (n_time_samples, n_trials, n_signals).
+
+    One difference in WHEN a warning appears: the reference scans the series for NaN / infinity in the constructor
+    (transforms.py:746-753).  For real series of 4 M samples or more this class defers that scan to the device, next to
+    the upload, and the same ``UserWarning`` is raised by the first transform (``fft()``, or the first measure of a
+    ``Connectivity`` built from this object) -- not at all if no transform ever runs.  ``options.finite_check = "host"``
+    (or ``SC_HIP_FINITE_CHECK=host``) restores the constructor-time scan for every size.
     """
 
     def __init__(self, time_series, sampling_frequency=1000, time_halfbandwidth_product=3,
@@ -602,11 +608,15 @@ class Multitaper:
         from . import engine
         ts = np.asarray(self.time_series)
         C = ts.shape[2]
-        parts = Multitaper(np.concatenate([ts.real, ts.imag], axis=2), sampling_frequency=self.sampling_frequency,
-                           time_halfbandwidth_product=self.time_halfbandwidth_product, detrend_type=self.detrend_type,
-                           start_time=self.start_time, n_fft_samples=self._n_fft_samples, tapers=self._tapers,
-                           n_tapers=self._n_tapers, n_time_samples_per_window=self.n_time_samples_per_window,
-                           n_time_samples_per_step=self.n_time_samples_per_step, is_low_bias=self.is_low_bias)
+        with warnings.catch_warnings():
+            # (the checks of the 2 C real parts would repeat this object's warnings -- non-finite samples -- or raise ones that
+            #  are not true of the complex series: "may be transposed" for T < 2 C)
+            warnings.simplefilter("ignore", UserWarning)
+            parts = Multitaper(np.concatenate([ts.real, ts.imag], axis=2), sampling_frequency=self.sampling_frequency,
+                               time_halfbandwidth_product=self.time_halfbandwidth_product, detrend_type=self.detrend_type,
+                               start_time=self.start_time, n_fft_samples=self._n_fft_samples, tapers=self._tapers,
+                               n_tapers=self._n_tapers, n_time_samples_per_window=self.n_time_samples_per_window,
+                               n_time_samples_per_step=self.n_time_samples_per_step, is_low_bias=self.is_low_bias)
         parts._finite_checked = self._finite_checked
         sp2 = parts.device_spectra(device, precision)
         self._finite_checked = True
