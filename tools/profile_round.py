@@ -49,7 +49,7 @@ if os.path.exists(final) and os.path.getmtime(final) > os.path.getmtime(os.path.
 if bench:
     open(os.path.join(P, ROUND + "_bench_line.json"), "w").write(bench[-1] + "\n")
 under = [l for l in lines("bench_under_rocprof.json") if l.startswith("{")]
-hdr = ["# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline   (cfg3, 1x MI355X, round 3; tools/profile_round.sh)"]
+hdr = ["# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline   (cfg3, 1x MI355X, round %s;" % ROUND.lstrip("r0") + " tools/profile_round.sh)"]
 if under:
     st = json.loads(under[-1])
     sm = st["roofline"]["stage_ms"]
@@ -101,13 +101,17 @@ if sq:
           % (valu, valu * 4 / 32, busy, 100 * valu * 4 / 32 / busy, mf, mf / 32, 100 * mf / 32 / busy)]
     open(os.path.join(P, ROUND + "_pmc_fused.txt"), "w").write("\n".join(h2 + sq) + "\n")
 
-for src, dst, head in (("mvar_64ch.txt", ROUND + "_mvar_64ch.txt", "# tools/mvar_time.py 64 1792 256: full 64 x 64 Wilson factorisation + DTF, 7 windows x 256 bins (round 3)"),
-                       ("mvar_128ch.txt", ROUND + "_mvar_128ch.txt", "# tools/mvar_time.py 128 1792 256: full 128 x 128 Wilson factorisation + DTF, 7 windows x 256 bins (round 3)"),
-                       ("engine_time.txt", ROUND + "_engine_time.txt", "# float32 and float64 engine on the BASELINE configurations (round 3)"),
-                       ("stage_a.txt", ROUND + "_stage_a.txt", "# tools/stage_a_breakdown.py: stage A per window length, cfg3 data volume (round 3)"),
-                       ("plane_pass.txt", ROUND + "_plane_pass.txt", "# tools/plane_pass_time.py: stage B per plane family, cfg3 data volume, round 3"),
-                       ("shape_sweep.txt", ROUND + "_shape_sweep.txt", "# tools/shape_sweep.py, round 3"),
-                       ("fused_ablation.txt", ROUND + "_fused_ablation.txt", "# tools/fused_ablation.py, round 3 (SC_FUSED_DEBUG; results WRONG when set)")):
+for src, dst, head in (("mvar_64ch.txt", ROUND + "_mvar_64ch.txt", "# tools/mvar_time.py 64 1792 256: full 64 x 64 Wilson factorisation + DTF, 7 windows x 256 bins (round " + ROUND[1:].lstrip("0") + ")"),
+                       ("mvar_128ch.txt", ROUND + "_mvar_128ch.txt", "# tools/mvar_time.py 128 1792 256: full 128 x 128 Wilson factorisation + DTF, 7 windows x 256 bins (round " + ROUND[1:].lstrip("0") + ")"),
+                       ("engine_time.txt", ROUND + "_engine_time.txt", "# float32 and float64 engine on the BASELINE configurations (round " + ROUND[1:].lstrip("0") + ")"),
+                       ("stage_a.txt", ROUND + "_stage_a.txt", "# tools/stage_a_breakdown.py: stage A per window length, cfg3 data volume (round " + ROUND[1:].lstrip("0") + ")"),
+                       ("plane_pass.txt", ROUND + "_plane_pass.txt", "# tools/plane_pass_time.py: stage B per plane family, cfg3 data volume, round " + ROUND[1:].lstrip("0")),
+                       ("shape_sweep.txt", ROUND + "_shape_sweep.txt", "# tools/shape_sweep.py, round " + ROUND[1:].lstrip("0")),
+                       ("fused_ablation.txt", ROUND + "_fused_ablation.txt", "# tools/fused_ablation.py (the complex64 kernel of sc_fused.hip; SC_FUSED_DEBUG; results WRONG when set)"),
+                       ("fused2_ablation.txt", ROUND + "_fused2_ablation.txt", "# tools/fused2_time.py 0 1 2 3 8 9 10 11 64: stage B on the planes format (sc_fused2.hip) under SC_FUSED_DEBUG (1 = CSM waves skip their MFMAs, 2 = |Im s| waves skip theirs, 8 = no HBM loads after the first chunk, 64 = no intermediate folds), next to the complex64 kernel"),
+                       ("stage_a_planes_ab.txt", ROUND + "_stage_a_planes_ab.txt", "# tools/stage_a_planes_ab.py: stage A into the planes format against the complex64 output, SC_MTFFT_DEBUG switches, scale pre-pass alone"),
+                       ("stage_a_planes_check.txt", ROUND + "_stage_a_planes_check.txt", "# tools/stage_a_planes_check.py: decoded planes-format spectra against the complex64 transform"),
+                       ("sq2.txt", ROUND + "_pmc_fused_waits.txt", "# second SQ counter pass of the bench command (wait / LDS counters; rocprofv3 --kernel-trace --pmc)")):
     body = [l for l in lines(src) if "amdgpu.ids" not in l]
     if body:
         open(os.path.join(P, dst), "w").write("\n".join([head] + body) + "\n")

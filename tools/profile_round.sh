@@ -20,8 +20,9 @@ SHORT="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-f64"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -- $SHORT > /dev/null 2> $OUT/fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -- $SHORT > /dev/null 2> $OUT/write.err
 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -d $OUT/sq -- $SHORT > /dev/null 2> $OUT/sq.err
+rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_ACTIVE_INST_LDS -d $OUT/sq2 -- $SHORT > /dev/null 2> $OUT/sq2.err
 cd $ROOT
-for d in kt fetch write sq; do
+for d in kt fetch write sq sq2; do
     db=$(find $OUT/$d -name "*.db" | head -1)
     [ -n "$db" ] && python tools/rocpd_summary.py $db > $OUT/$d.txt 2>&1
 done
@@ -34,6 +35,9 @@ python tools/stage_a_breakdown.py > $OUT/stage_a.txt 2>&1
 python tools/plane_pass_time.py > $OUT/plane_pass.txt 2>&1
 python tools/shape_sweep.py > $OUT/shape_sweep.txt 2>&1
 python tools/fused_ablation.py > $OUT/fused_ablation.txt 2>&1
+python tools/fused2_time.py 0 1 2 3 8 9 10 11 64 > $OUT/fused2_ablation.txt 2>&1
+python tools/stage_a_planes_ab.py > $OUT/stage_a_planes_ab.txt 2>&1
+python tools/stage_a_planes_check.py > $OUT/stage_a_planes_check.txt 2>&1
 for c in cfg2 cfg4 cfg5; do python bench.py --config $c --steps 10 --warmup 3 > $OUT/bench_$c.json 2> $OUT/bench_$c.err; done
 python tools/api_wall.py > $OUT/api_wall.txt 2>&1
 python tools/numpy_host_time.py > $OUT/numpy_host.txt 2>&1
