@@ -562,8 +562,24 @@ def main():
         for name, ms in _lib.last_timing():
             st64[name] = st64.get(name, 0.0) + ms / n64
         _lib.timing_enable(False)
+        # stage B of this engine against the fp64 units (matrix rate = vector rate = 78.6 TFLOP/s, one set of units): the
+        # instruction slots its arithmetic occupies, an fma slot counted as 2 flop like the peak counts it
+        nb16, nb64 = (C + 15) // 16, (C + 63) // 64
+        n_bins_obs = float(W * F) * float(n_obs_loc)
+        csm_products = 4 if os.environ.get("SC_F64_FOUR_PRODUCTS") else 3
+        slots_csm = n_bins_obs * (nb16 * (nb16 + 1) // 2) * 256 * csm_products * 2
+        slots_plane = n_bins_obs * (nb64 * (nb64 + 1) // 2) * 4096 * 3 * 2
+        t_b64 = st64.get("accumulate_f64", 0.0) * 1e-3
+        roof64 = None
+        if t_b64 > 0:
+            ach = (slots_csm + slots_plane) / t_b64 / 1e12
+            roof64 = {"kernel": "csm3_f64_kernel + nonlinear_f64_block_kernel (accumulate_f64)", "bound": "mfma", "achieved": round(ach, 2),
+                      "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / F64_PEAK_TFLOPS, 4), "kernel_ms": round(t_b64 * 1e3, 4),
+                      "frac_is": "fp64 instruction slots of stage B (%d real matrix products per 16x16 tile and observation; mul + fma + "
+                                 "|.|-add per pair and observation of the 64x64 blocks), 2 flop a slot, over the fp64 peak the matrix "
+                                 "and the vector pipe share" % csm_products}
         f64 = {"ms_per_step": round(dt64 * 1e3, 3), "value": round(units / dt64, 1), "dtype": "f64", "steps": n64,
-               "stage_ms": {k: round(v, 4) for k, v in st64.items()},
+               "stage_ms": {k: round(v, 4) for k, v in st64.items()}, "roofline": roof64,
                "note": "Connectivity(dtype=complex128): float64 transform, fp64 matrix-core CSM, fp64 VALU |Im s| plane, "
                        "float64 measures; reported beside the float32 line, not as the metric"}
 

@@ -74,6 +74,12 @@ __device__ __forceinline__ void f2_split2(float x0, float x1, unsigned& h, unsig
 // x: n_rows rows of `width` floats (width = C * comps); column col belongs to channel col / comps.  A block takes a slab of
 // rows; with width % 4 == 0 a thread reads 16 bytes of 4 rows per step (1-2 KB in flight per wave-instruction), the rows
 // of a column group meet in LDS, one atomic per column and block.
+// |v| of a FINITE value, 0 otherwise: a channel with an infinite or NaN sample somewhere keeps the scale its finite samples ask
+// for (the windows that hold the bad sample come out NaN either way, the others must not overflow the f16 range)
+__device__ __forceinline__ float planes_mag(float v) {
+    const float a = fabsf(v);
+    return a <= 3.4028234e38f ? a : 0.f;
+}
 __global__ void __launch_bounds__(256) planes_absmax_kernel(const float* x, int64_t n_rows, int width, int comps, unsigned* mx) {
     __shared__ unsigned red[1024];
     const int64_t rows_per_block = (n_rows + gridDim.x - 1) / gridDim.x;
@@ -94,13 +100,13 @@ __global__ void __launch_bounds__(256) planes_absmax_kernel(const float* x, int6
                 for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(x + (r + (int64_t)u * rows_per_step) * width + 4 * cq);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    m.x = fmaxf(m.x, fabsf(v[u].x)); m.y = fmaxf(m.y, fabsf(v[u].y));
-                    m.z = fmaxf(m.z, fabsf(v[u].z)); m.w = fmaxf(m.w, fabsf(v[u].w));
+                    m.x = fmaxf(m.x, planes_mag(v[u].x)); m.y = fmaxf(m.y, planes_mag(v[u].y));
+                    m.z = fmaxf(m.z, planes_mag(v[u].z)); m.w = fmaxf(m.w, planes_mag(v[u].w));
                 }
             }
             for (; r < r1; r += rows_per_step) {
                 const float4 v = *reinterpret_cast<const float4*>(x + r * width + 4 * cq);
-                m.x = fmaxf(m.x, fabsf(v.x)); m.y = fmaxf(m.y, fabsf(v.y)); m.z = fmaxf(m.z, fabsf(v.z)); m.w = fmaxf(m.w, fabsf(v.w));
+                m.x = fmaxf(m.x, planes_mag(v.x)); m.y = fmaxf(m.y, planes_mag(v.y)); m.z = fmaxf(m.z, planes_mag(v.z)); m.w = fmaxf(m.w, planes_mag(v.w));
             }
             atomicMax(red + 4 * cq, __float_as_uint(m.x)); atomicMax(red + 4 * cq + 1, __float_as_uint(m.y));
             atomicMax(red + 4 * cq + 2, __float_as_uint(m.z)); atomicMax(red + 4 * cq + 3, __float_as_uint(m.w));
@@ -112,7 +118,7 @@ __global__ void __launch_bounds__(256) planes_absmax_kernel(const float* x, int6
     }
     for (int col = tid; col < width; col += 256) {
         float m = 0.f;
-        for (int64_t r = r0; r < r1; ++r) m = fmaxf(m, fabsf(x[r * width + col]));       // (fmaxf drops NaNs)
+        for (int64_t r = r0; r < r1; ++r) m = fmaxf(m, planes_mag(x[r * width + col]));
         if (m > 0.f) atomicMax(mx + col / comps, __float_as_uint(m));
     }
 }
@@ -819,16 +825,12 @@ static int fused2_run(const void* d_P, const sc_spectra_desc* desc, const float*
     a.P = (const unsigned char*)d_P;
     a.inv_scale = d_scale + ax.C;
     f.accum = d_accum;
-    int loader = -1;
     {
         const char* dbg = getenv("SC_FUSED_DEBUG");
         f.debug_skip = dbg ? atoi(dbg) : 0;
         const char* t4 = getenv("SC_FUSED2_TERMS");
         if (t4) a.terms4 = atoi(t4) == 4 ? 1 : 0;
-        const char* ld = getenv("SC_FUSED2_LOADER");           // A/B: "abs" = the |Im s| waves load, "csm" = the CSM waves
-        if (ld) loader = (ld[0] == 'a') ? 0 : 1;
     }
-    (void)loader;
     int S = sc_internal_fused_pick_split(f.n_bins, ax.n_obs);
     const int64_t part_bytes = (int64_t)f.n_bins * f.floats_per_bin * (int64_t)sizeof(float);
     if (!d_workspace) S = 1;

@@ -127,9 +127,11 @@ __device__ __forceinline__ unsigned mt_pack_f16(float lo, float hi) {        // 
 }
 // two scaled reals -> the dwords of their leading and trailing f16 pieces (x = h + m to 22 significant bits)
 __device__ __forceinline__ void mt_split2(float x0, float x1, unsigned& h, unsigned& m) {
-    h = mt_pack_f16(x0, x1);
-    const mt_h16x2 hv = __builtin_bit_cast(mt_h16x2, h);
-    m = mt_pack_f16(x0 - (float)hv[0], x1 - (float)hv[1]);
+    // h = f16(x), m = f16(x - h), two values per register: one packed conversion and two mixed-precision fmas that read
+    // their f16 operand straight from the halves of h (left to the compiler: four conversions and a subtraction per value)
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(x0), "v"(x1));
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(m) : "v"(x0), "v"(h));
+    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(m) : "v"(x1), "v"(h));
 }
 
 // THREADS: 256 by default.  Long windows (N >= 1024) take 512-thread workgroups -- twice the transforms, so twice the
@@ -177,7 +179,6 @@ mtfft16_kernel(MtArgs p) {
     // per-channel transform gives (its measures turn NaN on zero power): the conjugate-symmetry split of a packed pair
     // would leave the rounding noise of its partner there.  One flag per channel of the tile.
     __shared__ int nzf[CT], nbf[CT];       // (plain stores of a constant: many threads may set the same flag)
-    __shared__ float scs[PL ? CT : 1];     // planes format: the channel scales of this tile
 
     const int tid = threadIdx.x;
     if (tid < CT) { nzf[tid] = 0; nbf[tid] = 0; }
@@ -202,7 +203,6 @@ mtfft16_kernel(MtArgs p) {
     const int64_t RC = (int64_t)p.R * C;
     const bool resident = p.kh == p.K;
     const float* xw = p.x + ((int64_t)w * p.step * p.R + r) * C + c0;
-    if constexpr (PL) { if (tid < CT) scs[tid] = (c0 + tid < C) ? p.scale[c0 + tid] : 1.f; }     // (read after the barriers of the detrend)
     const int pf = tid / TPF, i = tid - pf * TPF;     // FFT (channel pair) and butterfly index
     float2* zf = z + pf * ZS;
     const int F = N / 2 + 1;
@@ -276,6 +276,17 @@ mtfft16_kernel(MtArgs p) {
             constexpr int V = CT / 4, ROUNDS = N * V / THREADS;
             const bool vec = (C % 4) == 0;
             float4 v[ROUNDS];
+            // Planes format: the channel scales (powers of two) go onto the SAMPLES -- exact, every later step is linear --
+            // so the store loop has no multiply left, and the two channels that share a complex transform enter it
+            // at the same magnitude (a weak channel no longer carries the rounding of a strong pair partner).
+            float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f);
+            if constexpr (PL) {
+                const int cs = c0 + 4 * (tid % V);          // (idx % V does not change over the rounds: THREADS % V == 0)
+                if (cs < C) sc4.x = p.scale[cs];
+                if (cs + 1 < C) sc4.y = p.scale[cs + 1];
+                if (cs + 2 < C) sc4.z = p.scale[cs + 2];
+                if (cs + 3 < C) sc4.w = p.scale[cs + 3];
+            }
     #pragma unroll
             for (int it = 0; it < ROUNDS; ++it) {
                 const int idx = tid + it * THREADS, l = idx / V, cc = 4 * (idx - l * V);
@@ -297,8 +308,13 @@ mtfft16_kernel(MtArgs p) {
                 const int idx = tid + it * THREADS, l = idx / V, cc = 4 * (idx - l * V);
                 if (l < L) {
                     float2* d = reinterpret_cast<float2*>(xt + l * XS + cc);
-                    d[0] = make_float2(v[it].x, v[it].y);
-                    d[1] = make_float2(v[it].z, v[it].w);
+                    if constexpr (PL) {
+                        d[0] = make_float2(v[it].x * sc4.x, v[it].y * sc4.y);
+                        d[1] = make_float2(v[it].z * sc4.z, v[it].w * sc4.w);
+                    } else {
+                        d[0] = make_float2(v[it].x, v[it].y);
+                        d[1] = make_float2(v[it].z, v[it].w);
+                    }
                 }
             }
         } else {
@@ -596,7 +612,7 @@ mtfft16_kernel(MtArgs p) {
             {
                 // Planes format: a thread takes FOUR channel pairs (8 channels) of one frequency, so that every plane leaves
                 // as one 16-byte store (16 lanes = a 256-byte tile row of the four planes): eight LDS reads, the
-                // conjugate-symmetry split, the channel scales, the two-piece f16 split (3 VALU per real).
+                // conjugate-symmetry split, the two-piece f16 split (the channel scales are already on the samples).
                 constexpr int NG = NF / 4, FSTEP = THREADS / NG;
                 const int grp = tid % NG, fq = tid / NG, cg = c0 + 8 * grp;
                 const int64_t row0 = ((int64_t)w * p.R + r) * p.K + k, rows_f = (int64_t)p.W * p.R * p.K;
@@ -605,10 +621,16 @@ mtfft16_kernel(MtArgs p) {
                 if (in_tile)
                 for (int f = fq; f <= N / 2; f += FSTEP) {
                     u32x4_t rh, rm, ih, im;
+                    float2 u1q[4], u2q[4];         // all eight LDS reads in flight before the first split (one wait instead of four round trips)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const float2* zp = z + (4 * grp + q) * ZS;
-                        const float2 u1 = zp[PHYS(f)], u2 = zp[PHYS((N - f) & (N - 1))];
+                        u1q[q] = zp[PHYS(f)];
+                        u2q[q] = zp[PHYS((N - f) & (N - 1))];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float2 u1 = u1q[q], u2 = u2q[q];
                         float2 A = make_float2(u1.x + u2.x, u1.y - u2.y);       // (Z[f] + conj Z[N-f]) / 2, the half already in the samples
                         float2 B = make_float2(u1.y + u2.y, u2.x - u1.x);       // (Z[f] - conj Z[N-f]) / (2 i)
                         if (any_flag) {
@@ -620,10 +642,9 @@ mtfft16_kernel(MtArgs p) {
                             if (qnb) B = make_float2(__int_as_float(0x7fc00000), __int_as_float(0x7fc00000));
                         }
                         unsigned h, m;
-                        const float2 s2 = *reinterpret_cast<const float2*>(scs + 8 * grp + 2 * q);
-                        mt_split2(A.x * s2.x, B.x * s2.y, h, m);
+                        mt_split2(A.x, B.x, h, m);
                         rh[q] = h; rm[q] = m;
-                        mt_split2(A.y * s2.x, B.y * s2.y, h, m);
+                        mt_split2(A.y, B.y, h, m);
                         ih[q] = h; im[q] = m;
                     }
                     if (p.dbg & 1) continue;

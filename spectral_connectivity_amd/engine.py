@@ -154,7 +154,14 @@ class DeviceSpectra:
                            reduce_taper=int(2 in axes), reserved=0)
 
 
-_taper_abs_sum = {}
+def _taper_abs_sum(tapers_over_fs):
+    """max_k sum_n |h_k[n]| (the bound behind the channel scales of the planes format): a property of the tapers, kept ON the
+    tensor object together with its version counter -- one device synchronisation per taper tensor, not per transform."""
+    cached = getattr(tapers_over_fs, "_sc_abs_sum", None)
+    if cached is None or cached[1] != tapers_over_fs._version:
+        cached = (float(tapers_over_fs.abs().sum(dim=1).max().item()), tapers_over_fs._version)
+        tapers_over_fs._sc_abs_sum = cached
+    return cached[0]
 
 
 def twiddles(n_fft, device):
@@ -169,20 +176,8 @@ def twiddles(n_fft, device):
     return tw
 
 
-PLANES_FORMAT_FAMILIES = (_lib.PLANE_CSM, _lib.PLANE_CSM | _lib.PLANE_ABS_IM, _lib.PLANE_CSM | _lib.PLANE_ABS_IM | _lib.PLANE_IM_SQ,
-                          _lib.PLANE_SIGN_IM)   # what sc_fused2.hip accumulates
-
-
-def planes_format_applies(n_window, n_fft, n_alloc, planes_hint):
-    """Does stage A write the planes format for a caller that will ask for the accumulator families ``planes_hint``?"""
-    if planes_hint not in PLANES_FORMAT_FAMILIES or os.environ.get("SC_PLANES_FORMAT", "1") == "0":
-        return False
-    # Below these channel counts the float32 VALU kernel of sc_fused.hip on complex64 spectra is the faster stage B (it is
-    # HBM-bound there; crossovers measured at the cfg3 volume, profiles/r04_shape_sweep.txt)
-    lo = {_lib.PLANE_CSM: 40, _lib.PLANE_CSM | _lib.PLANE_ABS_IM: 44, _lib.PLANE_CSM | _lib.PLANE_ABS_IM | _lib.PLANE_IM_SQ: 60,
-          _lib.PLANE_SIGN_IM: 48}[planes_hint]
-    lo = int(os.environ.get("SC_PLANES_MIN_CHANNELS", lo))
-    return lo <= n_alloc <= 256 and bool(_lib.load().sc_multitaper_fft_planes_supported(n_window, n_fft, n_alloc))
+PLANES_FORMAT_FAMILIES = _lib.PLANES_FORMAT_FAMILIES
+planes_format_applies = _lib.planes_format_applies
 
 
 def multitaper_spectra(x, tapers_over_fs, n_window, n_step, n_fft, n_windows, detrend_type, mark=None,
@@ -219,10 +214,7 @@ def multitaper_spectra(x, tapers_over_fs, n_window, n_step, n_fft, n_windows, de
         P = torch.empty((F * n_windows * R * K * row_bytes,), dtype=torch.uint8, device=x.device)
         scale = torch.empty((2 * C,), dtype=torch.float32, device=x.device)
         work = torch.empty((C,), dtype=torch.int32, device=x.device)
-        key = (tapers_over_fs.data_ptr(), tuple(tapers_over_fs.shape))
-        if _taper_abs_sum.get("key") != key:            # max_k sum_n |h_k[n]|: a property of the tapers, not of the data
-            _taper_abs_sum["key"], _taper_abs_sum["value"] = key, float(tapers_over_fs.abs().sum(dim=1).max().item())
-        _lib.check(lib.sc_planes_scales_from_series_f32(_ptr(x), T, R, C, _taper_abs_sum["value"], _ptr(scale), _ptr(work),
+        _lib.check(lib.sc_planes_scales_from_series_f32(_ptr(x), T, R, C, _taper_abs_sum(tapers_over_fs), _ptr(scale), _ptr(work),
                                                         _stream()), "sc_planes_scales_from_series_f32")
         _lib.check(lib.sc_multitaper_fft_planes_f32(_ptr(x), T, R, C, L, n_step, n_windows, n_fft, _ptr(tapers_over_fs), K,
                                                     _lib.DETREND[detrend_type], _ptr(twiddles(n_fft, x.device)), _ptr(scale),

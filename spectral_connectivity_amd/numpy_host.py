@@ -169,9 +169,11 @@ class NumpyHost:
         return bool(self.download(flag, (1,), np.int32)[0])
 
     # ---- stage A ------------------------------------------------------------------------------------------------
-    def spectra(self, multitaper):
+    def spectra(self, multitaper, planes_hint=None):
         """Stage A for a ``transforms.Multitaper`` (host geometry, tapers): dict with the device spectra
-        X[F][W][R][K][C_alloc] complex64 and their sizes."""
+        X[F][W][R][K][C_alloc] complex64 and their sizes -- or, when the accumulator families ``planes_hint`` the caller will
+        ask for take it (``_lib.planes_format_applies``), the same coefficients in the planes format of sc_fused2.hip:
+        P (rows of sc_planes_row_bytes) + the per-channel scales, X = None."""
         import warnings
         m, lib = multitaper, self.lib
         if np.iscomplexobj(m.time_series):
@@ -203,13 +205,27 @@ class NumpyHost:
             warnings.warn("Input time_series contains NaN or infinite values.\n"
                           "This will produce invalid spectral estimates.", UserWarning, stacklevel=3)
         F = N // 2 + 1
-        X = self.alloc(F * W * R * K * C_alloc * 8)
         detrend = _lib.DETREND[m.detrend_type]
-        if lib.sc_multitaper_fft_supported(L, N):
-            if N not in self._twiddles:
-                tw = self.alloc(N * 8)
-                _lib.check(lib.sc_fft_twiddles_f32(N, tw.ptr, self.stream), "sc_fft_twiddles_f32")
-                self._twiddles[N] = tw
+        fused = bool(lib.sc_multitaper_fft_supported(L, N))
+        if fused and N not in self._twiddles:
+            tw = self.alloc(N * 8)
+            _lib.check(lib.sc_fft_twiddles_f32(N, tw.ptr, self.stream), "sc_fft_twiddles_f32")
+            self._twiddles[N] = tw
+        if fused and _lib.planes_format_applies(L, N, C_alloc, planes_hint):
+            # planes format: one scan of the series for the channel scales, then the fused transform writes the f16 pieces
+            P = self.alloc(F * W * R * K * int(lib.sc_planes_row_bytes(C_alloc)))
+            scale, work = self.alloc(2 * C_alloc * 4), self.alloc(C_alloc * 4)
+            h_abs_sum = float(np.abs(np.asarray(tapers.T / m.sampling_frequency, dtype=np.float32)).sum(axis=1).max())
+            _lib.check(lib.sc_planes_scales_from_series_f32(x.ptr, T, R, C_alloc, h_abs_sum, scale.ptr, work.ptr, self.stream),
+                       "sc_planes_scales_from_series_f32")
+            _lib.check(lib.sc_multitaper_fft_planes_f32(x.ptr, T, R, C_alloc, L, step, W, N, h.ptr, K, detrend,
+                                                        self._twiddles[N].ptr, scale.ptr, P.ptr, self.stream),
+                       "sc_multitaper_fft_planes_f32")
+            for b in (x, h, work):
+                b.free()
+            return dict(X=None, P=P, scale=scale, F=F, W=W, R=R, K=K, C=C, C_alloc=C_alloc, N=N)
+        X = self.alloc(F * W * R * K * C_alloc * 8)
+        if fused:
             _lib.check(lib.sc_multitaper_fft_f32(x.ptr, T, R, C_alloc, L, step, W, N, h.ptr, K, detrend,
                                                  self._twiddles[N].ptr, X.ptr, self.stream), "sc_multitaper_fft_f32")
         else:
@@ -247,6 +263,18 @@ class NumpyHost:
         _lib.check(lib.sc_accum_layout(byref(d_real), planes, byref(n_bins), byref(fpb), byref(n_groups), byref(n_obs)),
                    "sc_accum_layout")
         accum = self.alloc(n_bins.value * fpb.value * 4)
+        if sp.get("P") is not None:
+            # planes format (the families planes_format_applies admits are exactly what sc_fused2.hip accumulates)
+            if not lib.sc_fused2_supported(byref(d_pad), planes):
+                raise _lib.HipEngineError("planes-format spectra: this expectation type / plane set needs complex64 spectra "
+                                          "(call spectra() without planes_hint)")
+            ws_bytes = int(lib.sc_fused_workspace_bytes(byref(d_pad), planes))
+            ws = self.alloc(ws_bytes) if ws_bytes else None
+            _lib.check(lib.sc_fused2_csm_absim_f32(sp["P"].ptr, byref(d_pad), sp["scale"].ptr, planes, accum.ptr,
+                                                   ws.ptr if ws else None, ws_bytes, self.stream), "sc_fused2_csm_absim_f32")
+            if ws:
+                ws.free()
+            return accum, n_bins.value, n_obs.value
         one_pass = int(lib.sc_fused_planes_covered(byref(d_pad), planes)) if lib.sc_fused_supported(sp["C_alloc"]) else 0
         X, st = sp["X"].ptr, self.stream
         if one_pass:
@@ -273,6 +301,14 @@ class NumpyHost:
                        "sc_nonlinear_accumulate_f32")
         return accum, n_bins.value, n_obs.value
 
+    def _planes_expectation(self, m, expectation_type, planes):
+        """Would sc_fused2.hip take this request?  (asked BEFORE stage A picks the device format of the spectra)"""
+        ts = np.asarray(m.time_series)
+        C = ts.shape[2]
+        C_alloc = C + 1 if (C % 2 and C + 1 <= 256) else C
+        geom = dict(F=m.n_fft_samples // 2 + 1, W=m.n_time_windows, R=ts.shape[1], K=np.asarray(m.tapers).shape[1], C=C, C_alloc=C_alloc)
+        return bool(self.lib.sc_fused2_supported(byref(self._desc(geom, expectation_type, True)), planes))
+
     def connectivity(self, time_series, measures=("coherence_magnitude",), expectation_type="trials_tapers", **multitaper_kwargs):
         """NumPy time series (n_time, n_trials, n_signals) -> {measure name: NumPy array} shaped like the reference's
         ``Connectivity.<measure>()`` results (non-negative frequencies)."""
@@ -284,12 +320,16 @@ class NumpyHost:
         if unknown:
             raise ValueError(f"unknown measures {unknown}; available: {sorted(MEASURES)}")
         m = Multitaper(time_series, **multitaper_kwargs)
-        sp = self.spectra(m)
         planes = 0
         for name in measures:
             planes |= _lib.MEASURE_PLANES[MEASURES[name]]
+        # (the planes format holds observations as ONE run of rows: the expectation types that reduce every stored axis but
+        #  the frequency, or a contiguous tail of them -- sc_fused2_supported decides; anything else takes complex64)
+        sp = self.spectra(m, planes_hint=planes if self._planes_expectation(m, expectation_type, planes) else None)
         accum, n_bins, n_obs = self.accumulate(sp, expectation_type, planes)
-        sp["X"].free()
+        for key in ("X", "P", "scale"):
+            if sp.get(key) is not None:
+                sp[key].free()
         C, F = sp["C"], sp["F"]
         axes = EXPECTATION_AXES[expectation_type]
         kept = tuple(n for i, n in enumerate((sp["W"], sp["R"], sp["K"])) if i not in axes)

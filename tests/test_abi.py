@@ -117,6 +117,39 @@ for xin in (x.astype(np.float32), x):             # float32 upload, and float64 
         tol = 8.0 / (R * 5) if name == "phase_lag_index" else 3e-5
         err = np.abs(a[ok] - ref[ok]).max() / np.abs(ref[ok]).max()
         assert err <= tol, (name, err)
+# the planes format of the float32 engine (two f16 pieces per real number, written by stage A: sc_fused2.hip) through this host:
+# 64 channels take it by themselves for coherence + wPLI, the small 7-channel case with the threshold lifted; a request that
+# mixes in a family the format does not carry (PLV) stays on complex64
+import os
+from spectral_connectivity_amd import _lib
+seen = []
+_orig = host.spectra
+def _spy(m, planes_hint=None):
+    sp = _orig(m, planes_hint=planes_hint)
+    seen.append(sp.get("P") is not None)
+    return sp
+host.spectra = _spy
+x64 = rng.standard_normal((T, R, 64)).astype(np.float32)
+x64 += (0.8 * np.sin(2 * np.pi * 40 * t[:, None, None] + 0.1 * np.arange(64)[None, None, :])).astype(np.float32)
+for xin, env in ((x64, None), (x.astype(np.float32), "2")):
+    if env:
+        os.environ["SC_PLANES_MIN_CHANNELS"] = env
+    for names_p, want in ((("coherence_magnitude", "weighted_phase_lag_index"), True), (("debiased_squared_weighted_phase_lag_index",), True),
+                          (("phase_lag_index",), True), (("coherence_magnitude", "phase_locking_value"), False)):
+        got = host.connectivity(xin, measures=names_p, **kw)
+        assert seen[-1] is want, (names_p, seen[-1])
+        coef, _ = so.multitaper_fft(np.asarray(xin, dtype=np.float64), fs=500.0, NW=3, n_time_samples_per_window=128,
+                                    n_time_samples_per_step=64)
+        F = coef.shape[3] // 2 + 1
+        for name in names_p:
+            ref = getattr(so, name)(coef)[..., :F, :, :]
+            a = got[name]
+            assert a.shape == ref.shape and np.array_equal(np.isnan(a), np.isnan(ref)), name
+            ok = ~np.isnan(ref)
+            tol = 8.0 / (R * 5) if name == "phase_lag_index" else 3e-5
+            assert np.abs(a[ok] - ref[ok]).max() / np.abs(ref[ok]).max() <= tol, (name, xin.shape)
+    os.environ.pop("SC_PLANES_MIN_CHANNELS", None)
+host.spectra = _orig
 # a window length the fused transform does not take (7 is a prime factor above 5): tapered windows + rocFFT
 got = host.connectivity(x[:448].astype(np.float32), measures=("coherence_magnitude",), sampling_frequency=500.0,
                         time_halfbandwidth_product=2, n_time_samples_per_window=224)

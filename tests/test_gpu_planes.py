@@ -43,8 +43,11 @@ def _series(T, R, C, seed, offset=0.0, quiet=2e-3, loud=250.0):
 
 @pytest.mark.parametrize("L,step,C,detrend", [(256, 128, 128, "constant"), (128, 64, 20, "linear"), (64, 64, 34, None),
                                                (512, 256, 16, "constant"), (1024, 1024, 48, "constant")])
-def test_stage_a_planes_decode_to_the_complex64_spectra(L, step, C, detrend):
-    """sc_multitaper_fft_planes_f32 + sc_spectra_from_planes_f32 = sc_multitaper_fft_f32 to the 22 bits of the format."""
+def test_stage_a_planes_decode_to_the_spectra(L, step, C, detrend):
+    """sc_multitaper_fft_planes_f32 + sc_spectra_from_planes_f32 against the float64 transform of the same samples and
+    tapers: the float32 transform's rounding plus the 22 bits of the format.  The scales sit on the SAMPLES, so the two
+    channels that share a complex transform enter it at the same magnitude: a channel far weaker than its pair partner (here
+    x 250 and x 1/500) comes out to its OWN rounding, where the complex64 transform leaves the partner's on it."""
     dev, lib = _dev(), _lib.load()
     T, R, NW = 2048, 3, 3
     K = 2 * NW - 1
@@ -52,17 +55,21 @@ def test_stage_a_planes_decode_to_the_complex64_spectra(L, step, C, detrend):
     x = torch.from_numpy(_series(T, R, C, seed=L + C).astype(np.float32)).to(dev)
     tapers = np.asarray(transforms.dpss_windows(L, NW, K)[0])[:K]
     h = torch.from_numpy(np.ascontiguousarray(tapers * np.sqrt(1000.0) / 1000.0, dtype=np.float32)).to(dev)
+    X64 = engine.multitaper_spectra_f64(x.double(), h.double(), L, step, L, W, detrend).X
     ref = engine.multitaper_spectra(x, h, L, step, L, W, detrend)
     sp = engine.multitaper_spectra(x, h, L, step, L, W, detrend, planes_hint=PLANES)
     assert sp.P is not None and sp._X is None, "the planes format was expected for this shape"
     X, Xr = sp.X, ref.X
-    scaled_max = (Xr.abs() * sp.scale[:C]).max().item()
+    scaled_max = (X64.abs() * sp.scale[:C]).max().item()
     assert scaled_max < 32768.0, "a coefficient left the range the scales promise"
-    amax = Xr.abs().amax(dim=(0, 1, 2, 3))
-    # per coefficient: 2^-22 relative, or the f16 subnormal step (2^-25 scaled units) for the tiny ones
-    tol = 2.0 ** -22 * Xr.abs() + (2.0 ** -24 / sp.scale[:C])
-    assert bool(((X - Xr).abs() <= tol).all())
-    assert ((X - Xr).abs().amax(dim=(0, 1, 2, 3)) / amax).max().item() < 2.5e-7
+    amax = X64.abs().amax(dim=(0, 1, 2, 3))
+    err = ((X - X64).abs().amax(dim=(0, 1, 2, 3)) / amax)
+    err_c64 = ((Xr - X64).abs().amax(dim=(0, 1, 2, 3)) / amax)
+    # every channel to (a few ulp of float32) x its own largest coefficient -- the pair partner's size does not enter
+    assert err.max().item() < 1.5e-6, (err.max().item(), err_c64.max().item())
+    assert bool((err <= 1.5 * err_c64 + 4e-7).all())
+    if C >= 4:
+        assert err_c64[1].item() > 4 * err[1].item(), "channel 1 (pair partner of the loud channel 0) was expected to gain"
 
 
 def test_conversions_are_inverse_and_keep_zero_and_nonfinite_channels():

@@ -26,7 +26,7 @@ def one_pass(x, h, cfg, f64):
     if f64:
         sp = engine.multitaper_spectra_f64(x, h, L, step, L, W, "constant")
     else:
-        sp = engine.multitaper_spectra(x, h, L, step, L, W, "constant")
+        sp = engine.multitaper_spectra(x, h, L, step, L, W, "constant", planes_hint=planes)
     accum, n_obs = engine.accumulate(sp, "trials_tapers", planes)
     del sp
     a = engine.measure(accum, cfg["C"], planes, n_obs, _lib.M_COHERENCE_MAGNITUDE, wide=f64)

@@ -22,9 +22,9 @@ for rep in range(3):
     t = [time.perf_counter()]
     m = Multitaper(x32, **kw); t.append(time.perf_counter())
     m.tapers; print(f"tapers {1e3 * (time.perf_counter() - t[-1]):.1f} ms")
-    sp = host.spectra(m); host.synchronize(); t.append(time.perf_counter())
-    print(f"inside spectra(): uploads {1e3 * spent['upload']:.1f} ms (incl. their allocations), allocations {1e3 * spent['alloc']:.1f} ms")
     planes = _lib.PLANE_CSM | _lib.PLANE_ABS_IM
+    sp = host.spectra(m, planes_hint=planes); host.synchronize(); t.append(time.perf_counter())
+    print(f"inside spectra(): uploads {1e3 * spent['upload']:.1f} ms (incl. their allocations), allocations {1e3 * spent['alloc']:.1f} ms")
     accum, n_bins, n_obs = host.accumulate(sp, "trials_tapers", planes); host.synchronize(); t.append(time.perf_counter())
     outs = []
     for name in names:
@@ -33,7 +33,10 @@ for rep in range(3):
         host.synchronize(); t.append(time.perf_counter())
         outs.append(host.download(dev, (7, 129, 128, 128), np.float64)); t.append(time.perf_counter())
         dev.free()
-    sp["X"].free(); accum.free()
+    for key in ("X", "P", "scale"):
+        if sp.get(key) is not None:
+            sp[key].free()
+    accum.free()
     t.append(time.perf_counter())
 lab = ["Multitaper()", "upload + stage A", "stage B", "epilogue 1", "download 1 (118 MB f64)", "epilogue 2", "download 2", "frees"]
 print("NumPy host, cfg3, float32 input: " + ", ".join(f"{l} {1e3*(b-a):.1f} ms" for l, a, b in zip(lab, t[:-1], t[1:]))

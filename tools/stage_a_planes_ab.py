@@ -19,11 +19,14 @@ h = torch.randn((K, L), dtype=torch.float32, device=dev) * 0.01
 planes = _lib.PLANE_CSM | _lib.PLANE_ABS_IM
 variants = [("complex64", None, "0"), ("planes", planes, "0"), ("planes, nt stores", planes, "32"), ("planes, no stores", planes, "1"), ("planes, no store loop", planes, "4"),
             ("complex64, no stores", None, "1"), ("complex64, no store loop", None, "4")]
+if len(sys.argv) > 1 and sys.argv[1] == "quick":          # (under rocprofv3 --pmc: the two plain variants, three passes)
+    variants = variants[:2]
 ts = {v[0]: [] for v in variants}
+N_REP = 5 if len(variants) == 2 else 17
 ts["scales only"] = []
 scale = torch.empty((2 * C,), dtype=torch.float32, device=dev)
 work = torch.empty((C,), dtype=torch.int32, device=dev)
-for rep in range(17):
+for rep in range(N_REP):
     for name, hint, dbg in variants:
         os.environ["SC_MTFFT_DEBUG"] = dbg
         torch.cuda.synchronize()
