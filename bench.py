@@ -566,14 +566,14 @@ def main():
         # instruction slots its arithmetic occupies, an fma slot counted as 2 flop like the peak counts it
         nb16, nb64 = (C + 15) // 16, (C + 63) // 64
         n_bins_obs = float(W * F) * float(n_obs_loc)
-        csm_products = 4 if os.environ.get("SC_F64_FOUR_PRODUCTS") else 3
+        csm_products = 4            # Re: ar ar + ai ai, Im: ai ar - ar ai  (a three-product form was tried: profiles/r04_f64_three_products.txt)
         slots_csm = n_bins_obs * (nb16 * (nb16 + 1) // 2) * 256 * csm_products * 2
         slots_plane = n_bins_obs * (nb64 * (nb64 + 1) // 2) * 4096 * 3 * 2
         t_b64 = st64.get("accumulate_f64", 0.0) * 1e-3
         roof64 = None
         if t_b64 > 0:
             ach = (slots_csm + slots_plane) / t_b64 / 1e12
-            roof64 = {"kernel": "csm3_f64_kernel + nonlinear_f64_block_kernel (accumulate_f64)", "bound": "mfma", "achieved": round(ach, 2),
+            roof64 = {"kernel": "csm_f64_kernel + nonlinear_f64_block_kernel (accumulate_f64)", "bound": "mfma", "achieved": round(ach, 2),
                       "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / F64_PEAK_TFLOPS, 4), "kernel_ms": round(t_b64 * 1e3, 4),
                       "frac_is": "fp64 instruction slots of stage B (%d real matrix products per 16x16 tile and observation; mul + fma + "
                                  "|.|-add per pair and observation of the 64x64 blocks), 2 flop a slot, over the fp64 peak the matrix "

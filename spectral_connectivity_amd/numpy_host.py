@@ -38,17 +38,37 @@ MEASURES = {
 
 
 class DeviceBuffer:
-    """``n_bytes`` of HBM from the library's stream-ordered pool; freed on the same stream when dropped."""
+    """``n_bytes`` of HBM.  Blocks come from the library's stream-ordered pool ONCE and are then recycled by this host: a
+    dropped buffer waits in ``host._released`` until the host has synchronised its stream, and only then serves the next
+    request of its size class.  (Handing blocks back to the driver's pool with hipFreeAsync and taking them out again in
+    stream order -- legal, and what this class did first -- gave intermittently corrupted measure buffers under
+    /opt/rocm 7.2's runtime as soon as a large block was carved up differently from call to call (planes-format spectra
+    where the previous call's output lay); the same sequence on the runtime PyTorch ships ran clean.  Recycling whole blocks
+    at synchronisation points does not depend on either.)"""
 
     def __init__(self, host, n_bytes):
         self._host, self.n_bytes = host, int(n_bytes)
+        self._size_class = DeviceBuffer.size_class(self.n_bytes)
+        free = host._free_blocks.get(self._size_class)
+        if free:
+            self.ptr = c_void_p(free.pop())
+            return
         p = c_void_p()
-        _lib.check(host.lib.sc_device_alloc(byref(p), self.n_bytes, host.stream), "sc_device_alloc")
+        _lib.check(host.lib.sc_device_alloc(byref(p), self._size_class, host.stream), "sc_device_alloc")
         self.ptr = p
+
+    @staticmethod
+    def size_class(n_bytes):
+        """Request rounded up to 512 bytes below 1 MB and to 1/16 of its power of two above (<= 6 % of slack)."""
+        n = max(int(n_bytes), 1)
+        if n <= (1 << 20):
+            return -(-n // 512) * 512
+        step = 1 << (n.bit_length() - 5)
+        return -(-n // step) * step
 
     def free(self):
         if self.ptr is not None and self.ptr.value:
-            self._host.lib.sc_device_free(self.ptr, self._host.stream)
+            self._host._released.append((self._size_class, self.ptr.value))     # reusable after the next synchronize()
         self.ptr = None
 
     def __del__(self):
@@ -127,17 +147,37 @@ class NumpyHost:
         _lib.check(self.lib.sc_stream_create(byref(s)), "sc_stream_create")
         self.stream = s
         self._twiddles = {}
+        self._free_blocks, self._released = {}, []      # DeviceBuffer's block cache: size class -> [address], and the not-yet-safe ones
 
     def close(self):
         if self.stream is not None:
             self._twiddles.clear()
-            self.synchronize()
+            self.trim()
             PinnedArray.trim(self.lib)
             self.lib.sc_stream_destroy(self.stream)
             self.stream = None
 
     def synchronize(self):
         _lib.check(self.lib.sc_stream_synchronize(self.stream), "sc_stream_synchronize")
+        # nothing queued can touch the buffers dropped so far any more: they may serve new requests
+        released, self._released = self._released, []
+        for size_class, address in released:
+            self._free_blocks.setdefault(size_class, []).append(address)
+        if sum(k * len(v) for k, v in self._free_blocks.items()) > self.CACHE_LIMIT:
+            self.trim()                                  # (many different shapes through one host: start over)
+
+    CACHE_LIMIT = 64 << 30
+
+    def trim(self):
+        """Hand the cached device blocks back to the library's pool."""
+        _lib.check(self.lib.sc_stream_synchronize(self.stream), "sc_stream_synchronize")
+        for size_class, address in self._released:
+            self._free_blocks.setdefault(size_class, []).append(address)
+        self._released = []
+        for blocks in self._free_blocks.values():
+            for address in blocks:
+                self.lib.sc_device_free(c_void_p(address), self.stream)
+        self._free_blocks.clear()
 
     # ---- memory -------------------------------------------------------------------------------------------------
     def alloc(self, n_bytes):

@@ -144,7 +144,8 @@ for xin, env in ((x64, None), (x.astype(np.float32), "2")):
         for name in names_p:
             ref = getattr(so, name)(coef)[..., :F, :, :]
             a = got[name]
-            assert a.shape == ref.shape and np.array_equal(np.isnan(a), np.isnan(ref)), name
+            assert a.shape == ref.shape and np.array_equal(np.isnan(a), np.isnan(ref)), (name, names_p, xin.shape, a.shape, ref.shape,
+                                                                                          int(np.isnan(a).sum()), int(np.isnan(ref).sum()))
             ok = ~np.isnan(ref)
             tol = 8.0 / (R * 5) if name == "phase_lag_index" else 3e-5
             assert np.abs(a[ok] - ref[ok]).max() / np.abs(ref[ok]).max() <= tol, (name, xin.shape)

@@ -4,7 +4,7 @@ wrong when set), next to the complex64 kernel.  Alternating inside one process, 
 import os
 import sys
 import time
-from ctypes import byref
+from ctypes import byref, c_double
 
 import numpy as np
 import torch
@@ -34,6 +34,7 @@ for C in (128, 64):
     out = torch.empty((n_bins, fpb), dtype=torch.float32, device=dev)
     times = {("new", v): [] for v in variants}
     times[("old", "0")] = []
+    clocks = {k: [] for k in times}
     for rep in range(17):
         for key in times:
             os.environ["SC_FUSED_DEBUG"] = key[1]
@@ -46,5 +47,10 @@ for C in (128, 64):
             torch.cuda.synchronize()
             if rep >= 2:
                 times[key].append(time.perf_counter() - t0)
-    print(f"C={C:4d}: " + "   ".join(f"{k[0]} dbg={k[1]}: {np.median(v) * 1e3:.3f} ms" for k, v in times.items()))
+                if key[0] == "new":
+                    ghz = c_double(0.0)
+                    lib.sc_debug_fused2_clock(byref(ghz))       # sustained shader clock of that launch (in-kernel counters)
+                    clocks[key].append(ghz.value)
+    print(f"C={C:4d}: " + "   ".join(f"{k[0]} dbg={k[1]}: {np.median(v) * 1e3:.3f} ms" + (f" @{np.median(clocks[k]):.2f} GHz" if clocks[k] else "")
+                                     for k, v in times.items()))
 os.environ.pop("SC_FUSED_DEBUG", None)
