@@ -275,10 +275,16 @@ struct F2Loader {
     int o7_0, plane;              // wave-uniform; plane < 0: this wave loads nothing
     int n_inst;                   // observation groups (instructions) per chunk: 4 (eight loader waves) or 8 (four)
 };
+// NHALF = 2 (one or two staged 32-channel blocks): a chunk is 64 observations -- observation 32 + o of the chunk sits in the channel
+// slots 64 .. 127 of observation o's row (the half of every 256-byte row slot that 64 channels leave empty), so twice the bytes are
+// in flight per buffer and every barrier covers twice the work.  Both roles then run their body twice per chunk, the second time
+// 128 bytes further into the rows.  (Measured before: at 64 channels the loads cost 0.8 of 3.1 ms -- one workgroup per CU with two
+// 16 KB chunks in flight cannot cover the HBM latency.)
+template <int NHALF>
 __device__ __forceinline__ F2Loader f2_loader(const Fused2Args& a, int wave, const unsigned char* part_base) {
     F2Loader L;
     const int lane = fu_lane();
-    const int piece = lane & 15, ct = piece >> 2;
+    const int piece = lane & 15, ct = NHALF == 2 ? ((piece >> 2) & 1) : (piece >> 2), half = NHALF == 2 ? (piece >> 3) : 0;
     if (a.loader_csm) {          // the four CSM waves load (they have the slack: half the matrix work of the first form)
         L.plane = wave < 4 ? wave : -1;
         L.o7_0 = 0;
@@ -288,19 +294,20 @@ __device__ __forceinline__ F2Loader f2_loader(const Fused2Args& a, int wave, con
         L.o7_0 = wave >= 4 ? 4 * ((wave - 4) >> 2) : 0;
         L.n_inst = 4;
     }
-    L.voff = (unsigned)(8 * (lane >> 4) * a.obs_rows * a.row_bytes + fu_byte(a.f.map.off32, ct) * F2_ROW_TILE + (piece & 3) * 16);
+    L.voff = (unsigned)((8 * (lane >> 4) + FU_OC * half) * a.obs_rows * a.row_bytes + fu_byte(a.f.map.off32, ct) * F2_ROW_TILE + (piece & 3) * 16);
     L.src = part_base + (L.plane < 0 ? 0 : L.plane) * 64;
     // LDS planes: Re h m -> 0 1, Im h m -> 2 3 (-Re h m -> 4 5 are made in f2_finish)
     L.lds_off = (L.plane < 0 ? 0 : L.plane) * F2_PLANE + L.o7_0 * F2_GROUP;
     return L;
 }
 // o0 = first observation of the chunk (relative to the part's first), n_left = observations left in the part from o0
+template <int NHALF>
 __device__ __forceinline__ void f2_issue(const Fused2Args& a, const F2Loader& L, lds_u8* buf, int o0, int n_left) {
     if (L.plane < 0) return;
     const int lane = fu_lane();                                   // (re-materialised: short live ranges, see fu_lane)
-    const int ct = (lane & 15) >> 2;
+    const int ct = NHALF == 2 ? ((lane >> 2) & 1) : ((lane & 15) >> 2);
     const bool lane_ok = ct < a.f.NB32 && fu_byte(a.f.map.n32, ct) > 0;      // this lane's channel tile is staged
-    const int o_first = L.o7_0 + 8 * (lane >> 4);
+    const int o_first = L.o7_0 + 8 * (lane >> 4) + (NHALF == 2 ? FU_OC * ((lane >> 3) & 1) : 0);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         if (i >= L.n_inst) break;
@@ -317,14 +324,15 @@ __device__ __forceinline__ void f2_issue(const Fused2Args& a, const F2Loader& L,
 }
 // After the wave's loads have landed (vmcnt): rows past the end of the part become zeros, and the waves that loaded
 // real-part planes write the negated copies (planes 4, 5) -- one xor per 8 coefficients.
+template <int NHALF>
 __device__ __forceinline__ void f2_finish(const F2Loader& L, lds_u8* buf, int n_left) {
     if (L.plane < 0) return;
     const int lane = fu_lane();
-    if (n_left < FU_OC) {                                          // wave-uniform: the last chunk of a part only
+    if (n_left < FU_OC * NHALF) {                                  // wave-uniform: the last chunk of a part only
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             if (i >= L.n_inst) break;
-            const int o = L.o7_0 + i + 8 * (lane >> 4);
+            const int o = L.o7_0 + i + 8 * (lane >> 4) + (NHALF == 2 ? FU_OC * ((lane >> 3) & 1) : 0);
             if (o >= n_left)
                 *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(buf + L.lds_off + i * F2_GROUP + 16 * lane) = (u32x4){0u, 0u, 0u, 0u};
         }
@@ -371,6 +379,7 @@ __device__ __forceinline__ void f2_mfma_role(const Fused2Args& a, lds_u8* lds, c
                                              int wave, float* rec, int n_part) {
     const FusedArgs& p = a.f;
     constexpr int MAXS = 2 * NB32 + 1;
+    constexpr int NHALF = NB32 <= 2 ? 2 : 1, CH = FU_OC * NHALF, FLUSH = FU_FLUSH / NHALF;     // (folds stay 512 observations apart)
     const unsigned sg = (unsigned)__builtin_amdgcn_readfirstlane((int)(wave == 0 ? p.seg0 : (wave == 1 ? p.seg1 : (wave == 2 ? p.seg2 : p.seg3))));
     const unsigned sg_n = (unsigned)__builtin_amdgcn_readfirstlane((int)((p.seg_n >> (8 * wave)) & 0xffu));
     const int rA_ = sg & 0xf, cA_ = (sg >> 4) & 0xf, rB_ = (sg >> 8) & 0xf, cB_ = (sg >> 12) & 0xf;
@@ -379,7 +388,7 @@ __device__ __forceinline__ void f2_mfma_role(const Fused2Args& a, lds_u8* lds, c
     f32x4 re[MAXS], im[MAXS];
 #pragma unroll
     for (int s = 0; s < MAXS; ++s) { re[s] = (f32x4){0.f, 0.f, 0.f, 0.f}; im[s] = re[s]; }
-    const int n_chunks = (n_part + FU_OC - 1) / FU_OC;
+    const int n_chunks = (n_part + CH - 1) / CH;
     float* out = rec + (int64_t)p.csm_plane * p.n_tiles * SC_TILE_ELEMS;
     const bool do_csm = p.csm_plane >= 0 && (p.debug_skip & 1) == 0;
     const bool loads = !(p.debug_skip & 8);
@@ -387,13 +396,16 @@ __device__ __forceinline__ void f2_mfma_role(const Fused2Args& a, lds_u8* lds, c
     for (int ch = 0; ch < n_chunks; ++ch) {
         lds_u8* cur = lds + (loads ? (ch % F2_NBUF) : 0) * F2_BUF;
         const bool more = ch + 1 < n_chunks && loads, more2 = ch + 2 < n_chunks && loads;
-        if (more2) f2_issue(a, L, lds + ((ch + 2) % F2_NBUF) * F2_BUF, (ch + 2) * FU_OC, n_part - (ch + 2) * FU_OC);
+        if (more2) f2_issue<NHALF>(a, L, lds + ((ch + 2) % F2_NBUF) * F2_BUF, (ch + 2) * CH, n_part - (ch + 2) * CH);
         if (do_csm && total > 0) {
             int rA = rA_, rB = rB_, nA = nA_, cA = cA_, cB = cB_;
             asm volatile("" : "+s"(rA), "+s"(rB), "+s"(nA), "+s"(cA), "+s"(cB));
             const int lane = fu_lane(), g = lane >> 4;
-            lds_u8* b0 = cur + ((4 * (g & 1) + ((lane >> 2) & 3)) * F2_GROUP + 2 * (g >> 1) * 256 + (lane & 3) * 8);
+            lds_u8* b00 = cur + ((4 * (g & 1) + ((lane >> 2) & 3)) * F2_GROUP + 2 * (g >> 1) * 256 + (lane & 3) * 8);
             h16x8 arh, arm, aih, aim, nrh, nrm;
+#pragma unroll
+            for (int hv = 0; hv < NHALF; ++hv) {          // (NHALF == 2: observations 32 .. 63 of the chunk, 128 bytes into the rows)
+            lds_u8* b0 = b00 + hv * 128;
 #pragma unroll
             for (int s = 0; s < MAXS; ++s) {
                 if (s < total) {
@@ -420,13 +432,14 @@ __device__ __forceinline__ void f2_mfma_role(const Fused2Args& a, lds_u8* lds, c
                     }
                 }
             }
+            }
         }
         if (more && L.plane >= 0) {
             // Chunk ch + 1 has landed once only the loads of chunk ch + 2 are outstanding.  (The fold atomics of the chunk
             // before sit between the two in this wave's queue: loads return in order, so "at most the loads of ch + 2
             // outstanding" still means every load of ch + 1 is back; the atomics are a chunk old by now.)
-            f2_wait_loads(more2 ? f2_issued(L, n_part - (ch + 2) * FU_OC) : 0);
-            f2_finish(L, lds + ((ch + 1) % F2_NBUF) * F2_BUF, n_part - (ch + 1) * FU_OC);
+            f2_wait_loads(more2 ? f2_issued(L, n_part - (ch + 2) * CH) : 0);
+            f2_finish<NHALF>(L, lds + ((ch + 1) % F2_NBUF) * F2_BUF, n_part - (ch + 1) * CH);
         }
         // two-level summation exactly as in sc_fused.hip: a tile's accumulators are folded into the record every FU_FLUSH
         // chunks (512 observations), the tiles taking turns; the channel scales (powers of two) come out here, exactly
@@ -434,8 +447,8 @@ __device__ __forceinline__ void f2_mfma_role(const Fused2Args& a, lds_u8* lds, c
             const bool last = ch + 1 == n_chunks;
 #pragma unroll
             for (int s = 0; s < MAXS; ++s) {
-                const int f_s = FU_FLUSH - 1 - s;
-                const bool due = ((ch + 1 + s) % FU_FLUSH) == 0 && !(p.debug_skip & 64);
+                const int f_s = FLUSH - 1 - s;
+                const bool due = ((ch + 1 + s) % FLUSH) == 0 && !(p.debug_skip & 64);
                 if (s < total && (due || last) && p.csm_plane >= 0) {
                     const bool first = ch <= f_s || (p.debug_skip & 64);
                     const bool in_a = s < nA_;
@@ -490,7 +503,8 @@ __device__ __forceinline__ void f2_valu_body(const Fused2Args& a, lds_u8* lds, u
     for (int s = 0; s < NBLK; ++s)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[s][e] = 0.f;
-    const int n_chunks = (n_part + FU_OC - 1) / FU_OC;
+    constexpr int NHALF = NB32 <= 2 ? 2 : 1, CH = FU_OC * NHALF;
+    const int n_chunks = (n_part + CH - 1) / CH;
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const bool loads = !(p.debug_skip & 8);
     const bool compute = !(p.debug_skip & 2) && p.abs_plane >= 0;
@@ -500,14 +514,16 @@ __device__ __forceinline__ void f2_valu_body(const Fused2Args& a, lds_u8* lds, u
         lds_u8* nxt = lds + ((ch + 1) % F2_NBUF) * F2_BUF;
         const bool more = ch + 1 < n_chunks && loads, more2 = ch + 2 < n_chunks && loads;
         // chunk ch + 2 into the buffer chunk ch - 1 was multiplied from (every wave is past that chunk's barrier)
-        if (more2) f2_issue(a, L, lds + ((ch + 2) % F2_NBUF) * F2_BUF, (ch + 2) * FU_OC, n_part - (ch + 2) * FU_OC);
+        if (more2) f2_issue<NHALF>(a, L, lds + ((ch + 2) % F2_NBUF) * F2_BUF, (ch + 2) * CH, n_part - (ch + 2) * CH);
         if (compute) {
             const int cl = fu_lane(), hf = cl >> 5, r = (cl >> 2) & 3;
             const int pA = hf ? (r < 2 ? 4 : 5) : (r < 2 ? 2 : 3);
             const int pB = hf ? ((r & 1) ? 3 : 2) : ((r & 1) ? 1 : 0);
             const int common = rsub * rpw * F2_GROUP + ((cl >> 4) & 1) * 32 + (cl & 3) * 8;
-            lds_u8* bA = cur + (pA * F2_PLANE + common);
-            lds_u8* bB = cur + (pB * F2_PLANE + common);
+#pragma unroll
+            for (int hv = 0; hv < NHALF; ++hv) {          // (NHALF == 2: observations 32 .. 63 of the chunk, 128 bytes into the rows)
+            lds_u8* bA = cur + (pA * F2_PLANE + common + hv * 128);
+            lds_u8* bB = cur + (pB * F2_PLANE + common + hv * 128);
             // zero rows past the end of the part contribute |0| = 0: no bound needed
             // The wave's rows t = 0 .. 4 rpw - 1 (observation 8 (t / rpw) + rsub rpw + t % rpw): the operand fragments of row
             // t + 1 are requested before row t is multiplied, so no row starts with a wait for the LDS.
@@ -548,10 +564,11 @@ __device__ __forceinline__ void f2_valu_body(const Fused2Args& a, lds_u8* lds, u
                     fu_accumulate16<OP, PK>(acc[NBLK - 1], dprev);
                 }
             }
+            }
         }
         if (more) {       // chunk ch + 1 has landed once only the loads of chunk ch + 2 are outstanding
-            f2_wait_loads(more2 ? f2_issued(L, n_part - (ch + 2) * FU_OC) : 0);
-            f2_finish(L, nxt, n_part - (ch + 1) * FU_OC);
+            f2_wait_loads(more2 ? f2_issued(L, n_part - (ch + 2) * CH) : 0);
+            f2_finish<NHALF>(L, nxt, n_part - (ch + 1) * CH);
         }
         F2_BARRIER();
     }
@@ -647,7 +664,8 @@ __global__ void __launch_bounds__(FU_THREADS) fused2_kernel(Fused2Args a) {
     float* rec = (part == 0 ? p.accum : p.ws + (int64_t)(part - 1) * p.n_bins * p.floats_per_bin) + (int64_t)bin * p.floats_per_bin;
     const unsigned char* part_base = a.P + ((int64_t)f * p.st.ax.sF + sc_group_offset(p.st.ax, g) + (int64_t)o_lo * a.obs_rows) * a.row_bytes;
     lds_u8* lds = (lds_u8*)smem;
-    const F2Loader L = f2_loader(a, wave, part_base);
+    constexpr int NHALF = NB32 <= 2 ? 2 : 1, CH = FU_OC * NHALF;
+    const F2Loader L = f2_loader<NHALF>(a, wave, part_base);
     // slots of channel tiles that are not staged stay zero for good
     for (int i = tid * 16; i < F2_SCALE_OFF; i += FU_THREADS * 16)
         *reinterpret_cast<u32x4*>(smem + i) = (u32x4){0u, 0u, 0u, 0u};
@@ -657,11 +675,11 @@ __global__ void __launch_bounds__(FU_THREADS) fused2_kernel(Fused2Args a) {
                                                                  ? a.inv_scale[gch] : 1.f;
     }
     __syncthreads();
-    f2_issue(a, L, lds, 0, n_part);
-    const bool second = n_part > FU_OC && !(p.debug_skip & 8);
-    if (second) f2_issue(a, L, lds + F2_BUF, FU_OC, n_part - FU_OC);
-    f2_wait_loads(second ? f2_issued(L, n_part - FU_OC) : 0);
-    f2_finish(L, lds, n_part);
+    f2_issue<NHALF>(a, L, lds, 0, n_part);
+    const bool second = n_part > CH && !(p.debug_skip & 8);
+    if (second) f2_issue<NHALF>(a, L, lds + F2_BUF, CH, n_part - CH);
+    f2_wait_loads(second ? f2_issued(L, n_part - CH) : 0);
+    f2_finish<NHALF>(L, lds, n_part);
     F2_BARRIER();
     if (wave < 4) {
         if (p.debug_skip & 32) __builtin_amdgcn_s_setprio(2);
