@@ -282,9 +282,10 @@ def planes_format_applies(n_window, n_fft, n_alloc, planes_hint):
     """Does stage A write the planes format for a caller that will ask for the accumulator families ``planes_hint``?"""
     if planes_hint not in PLANES_FORMAT_FAMILIES or os.environ.get("SC_PLANES_FORMAT", "1") == "0":
         return False
-    # Below these channel counts the float32 VALU kernel of sc_fused.hip on complex64 spectra is the faster stage B (it is
-    # HBM-bound there; crossovers measured at the cfg3 volume, profiles/r04_shape_sweep.txt)
-    lo = {PLANE_CSM: 40, PLANE_CSM | PLANE_ABS_IM: 44, PLANE_CSM | PLANE_ABS_IM | PLANE_IM_SQ: 60,
-          PLANE_SIGN_IM: 48}[planes_hint]
+    # Below these channel counts the float32 VALU kernel of sc_fused.hip on complex64 spectra is the faster path (it is HBM-bound
+    # there): crossovers measured at the cfg3 volume (profiles/r04_shape_sweep.txt), with the 0.5 ms the format costs stage A
+    # charged to the planes side
+    lo = {PLANE_CSM: 32, PLANE_CSM | PLANE_ABS_IM: 44, PLANE_CSM | PLANE_ABS_IM | PLANE_IM_SQ: 60,
+          PLANE_SIGN_IM: 44}[planes_hint]
     lo = int(os.environ.get("SC_PLANES_MIN_CHANNELS", lo))
     return lo <= n_alloc <= 256 and bool(_handle().sc_multitaper_fft_planes_supported(n_window, n_fft, n_alloc))

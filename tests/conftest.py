@@ -49,7 +49,7 @@ def _engine_precision(request):
     old = options.precision
     want = getattr(request, "param", None) or getattr(request.module, "SC_PRECISION", "float32")
     # "float32+planes": the float32 engine with the planes format (f16 pieces, sc_fused2.hip) from two channels on -- by default
-    # it starts at 40-60 channels, where the golden shapes never get
+    # it starts at 32-60 channels, where the golden shapes never get
     planes = want == "float32+planes"
     old_env = os.environ.get("SC_PLANES_MIN_CHANNELS")
     if planes:

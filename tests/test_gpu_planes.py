@@ -18,7 +18,7 @@ PLANES = _lib.PLANE_CSM | _lib.PLANE_ABS_IM
 
 @pytest.fixture(autouse=True)
 def _planes_from_two_channels(monkeypatch, request):
-    """The engine takes the planes format from 40-60 channels on (below, the small-channel kernel on complex64 spectra is
+    """The engine takes the planes format from 32-60 channels on (below, the small-channel kernel on complex64 spectra is
     faster); the tests of the format itself lift that threshold so that small shapes exercise it too."""
     if "default_thresholds" not in request.keywords:
         monkeypatch.setenv("SC_PLANES_MIN_CHANNELS", "2")
@@ -176,7 +176,7 @@ def test_few_channels_keep_complex64_by_default():
     dev = _dev()
     tapers = np.asarray(transforms.dpss_windows(128, 2, 3)[0])[:3]
     h = torch.from_numpy(np.ascontiguousarray(tapers / np.sqrt(1000.0), dtype=np.float32)).to(dev)
-    for C, expect in ((32, False), (64, True)):
+    for C, expect in ((30, False), (40, False), (64, True)):
         x = torch.from_numpy(_series(512, 2, C, seed=1).astype(np.float32)).to(dev)
         sp = engine.multitaper_spectra(x, h, 128, 128, 128, 4, "constant", planes_hint=PLANES)
         assert (sp.P is not None) == expect
