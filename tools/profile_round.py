@@ -110,7 +110,7 @@ for src, dst, head in (("mvar_64ch.txt", ROUND + "_mvar_64ch.txt", "# tools/mvar
                        ("fused_ablation.txt", ROUND + "_fused_ablation.txt", "# tools/fused_ablation.py (the complex64 kernel of sc_fused.hip; SC_FUSED_DEBUG; results WRONG when set)"),
                        ("fused2_ablation.txt", ROUND + "_fused2_ablation.txt", "# tools/fused2_time.py 0 1 2 3 8 9 10 11 64: stage B on the planes format (sc_fused2.hip) under SC_FUSED_DEBUG (1 = CSM waves skip their MFMAs, 2 = |Im s| waves skip theirs, 8 = no HBM loads after the first chunk, 64 = no intermediate folds), next to the complex64 kernel"),
                        ("stage_a_planes_ab.txt", ROUND + "_stage_a_planes_ab.txt", "# tools/stage_a_planes_ab.py: stage A into the planes format against the complex64 output, SC_MTFFT_DEBUG switches, scale pre-pass alone"),
-                       ("stage_a_planes_check.txt", ROUND + "_stage_a_planes_check.txt", "# tools/stage_a_planes_check.py: decoded planes-format spectra against the complex64 transform"),
+                       ("stage_a_planes_check.txt", ROUND + "_stage_a_planes_check.txt", "# tools/stage_a_planes_check.py: stage A into the planes format and into complex64, both against the float64 transform of the same samples (loud channel x300 next to channel 0, quiet channel x1e-3 at C/2)"),
                        ("sq2.txt", ROUND + "_pmc_fused_waits.txt", "# second SQ counter pass of the bench command (wait / LDS counters; rocprofv3 --kernel-trace --pmc)")):
     body = [l for l in lines(src) if "amdgpu.ids" not in l]
     if body:
