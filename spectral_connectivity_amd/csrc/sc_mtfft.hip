@@ -134,6 +134,19 @@ __device__ __forceinline__ void mt_split2(float x0, float x1, unsigned& h, unsig
     asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(m) : "v"(x1), "v"(h));
 }
 
+// One step of a 4 x 4 transpose inside a quad of lanes (planes-format store loop): lanes with `hi` clear give b and take the
+// partner's a into b, lanes with `hi` set give a and take the partner's b into a; the partner is lane ^ 1 (CTRL = quad_perm
+// [1, 0, 3, 2]) or lane ^ 2 ([2, 3, 0, 1]).
+template <int CTRL>
+__device__ __forceinline__ void mt_quad_xchg(u32x4_t& a, u32x4_t& b, bool hi) {
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const unsigned give = hi ? a[d] : b[d];
+        const unsigned take = (unsigned)__builtin_amdgcn_mov_dpp((int)give, CTRL, 0xf, 0xf, true);
+        if (hi) a[d] = take; else b[d] = take;
+    }
+}
+
 // THREADS: 256 by default.  Long windows (N >= 1024) take 512-thread workgroups -- twice the transforms, so twice the
 // contiguous piece of a frequency row per store group (128 bytes at N = 1024: a full line) -- at the same number of
 // waves per CU; 1024 threads would need 128 registers per lane and spill (measured slower).
@@ -282,10 +295,13 @@ mtfft16_kernel(MtArgs p) {
             float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f);
             if constexpr (PL) {
                 const int cs = c0 + 4 * (tid % V);          // (idx % V does not change over the rounds: THREADS % V == 0)
-                if (cs < C) sc4.x = p.scale[cs];
-                if (cs + 1 < C) sc4.y = p.scale[cs + 1];
-                if (cs + 2 < C) sc4.z = p.scale[cs + 2];
-                if (cs + 3 < C) sc4.w = p.scale[cs + 3];
+                if (cs + 3 < C) {
+                    sc4 = *reinterpret_cast<const float4*>(p.scale + cs);       // (cs is a multiple of four)
+                } else {
+                    if (cs < C) sc4.x = p.scale[cs];
+                    if (cs + 1 < C) sc4.y = p.scale[cs + 1];
+                    if (cs + 2 < C) sc4.z = p.scale[cs + 2];
+                }
             }
     #pragma unroll
             for (int it = 0; it < ROUNDS; ++it) {
@@ -613,20 +629,28 @@ mtfft16_kernel(MtArgs p) {
                 // Planes format: a thread takes FOUR channel pairs (8 channels) of one frequency, so that every plane leaves
                 // as one 16-byte store (16 lanes = a 256-byte tile row of the four planes): eight LDS reads, the
                 // conjugate-symmetry split, the two-piece f16 split (the channel scales are already on the samples).
+                // TR (four or more groups of eight channels per workgroup, i.e. N <= 256): the four lanes of a quad take four CONSECUTIVE frequencies of one
+                // channel group and transpose their 4 planes x 4 frequencies before the stores, so that store a of a lane is
+                // plane (lane & 3) of frequency a of the quad: the 16 lanes of four quads write one whole 256-byte tile row per
+                // instruction, where plane-per-instruction stores left 64-byte pieces of sixteen rows (measured with a
+                // wrong-contents variant of the same volume: 1.94 -> 1.80 ms at cfg3).
                 constexpr int NG = NF / 4, FSTEP = THREADS / NG;
-                const int grp = tid % NG, fq = tid / NG, cg = c0 + 8 * grp;
+                constexpr bool TR = NG >= 4;
+                const int j = tid & 3;
+                const int grp = TR ? (tid >> 2) % NG : tid % NG, fq = TR ? (tid / (4 * NG)) * 4 + j : tid / NG, cg = c0 + 8 * grp;
                 const int64_t row0 = ((int64_t)w * p.R + r) * p.K + k, rows_f = (int64_t)p.W * p.R * p.K;
                 const bool in_tile = cg < ((C + 31) & ~31);
-                unsigned char* dst0 = p.P + row0 * p.row_bytes + (cg >> 5) * 256 + ((cg & 31) >> 3) * 16;
+                unsigned char* dst0 = p.P + row0 * p.row_bytes + (cg >> 5) * 256 + ((cg & 31) >> 3) * 16 + (TR ? j * 64 : 0);
                 if (in_tile)
-                for (int f = fq; f <= N / 2; f += FSTEP) {
+                for (int f = fq; (TR ? f - j : f) <= N / 2; f += FSTEP) {
                     u32x4_t rh, rm, ih, im;
                     float2 u1q[4], u2q[4];         // all eight LDS reads in flight before the first split (one wait instead of four round trips)
+                    const int fr = f <= N / 2 ? f : N / 2;        // (TR: a lane past the Nyquist bin reads it again; its column is never stored)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const float2* zp = z + (4 * grp + q) * ZS;
-                        u1q[q] = zp[PHYS(f)];
-                        u2q[q] = zp[PHYS((N - f) & (N - 1))];
+                        u1q[q] = zp[PHYS(fr)];
+                        u2q[q] = zp[PHYS((N - fr) & (N - 1))];
                     }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -648,13 +672,21 @@ mtfft16_kernel(MtArgs p) {
                         ih[q] = h; im[q] = m;
                     }
                     if (p.dbg & 1) continue;
-                    unsigned char* dst = dst0 + (int64_t)f * rows_f * p.row_bytes;
-                    if (p.dbg & 32) {          // A/B: non-temporal
-                        __builtin_nontemporal_store(rh, reinterpret_cast<u32x4_t*>(dst));
-                        __builtin_nontemporal_store(rm, reinterpret_cast<u32x4_t*>(dst + 64));
-                        __builtin_nontemporal_store(ih, reinterpret_cast<u32x4_t*>(dst + 128));
-                        __builtin_nontemporal_store(im, reinterpret_cast<u32x4_t*>(dst + 192));
+                    if constexpr (TR) {
+                        // items (rh, rm, ih, im) = planes 0 .. 3 of this lane's frequency  ->  plane j of the quad's frequencies 0 .. 3
+                        mt_quad_xchg<0xB1>(rh, rm, (j & 1) != 0);
+                        mt_quad_xchg<0xB1>(ih, im, (j & 1) != 0);
+                        mt_quad_xchg<0x4E>(rh, ih, (j & 2) != 0);
+                        mt_quad_xchg<0x4E>(rm, im, (j & 2) != 0);
+                        const int f0 = f - j;
+                        unsigned char* dst = dst0 + (int64_t)f0 * rows_f * p.row_bytes;
+                        const int64_t fs = rows_f * p.row_bytes;
+                        *reinterpret_cast<u32x4_t*>(dst) = rh;
+                        if (f0 + 1 <= N / 2) *reinterpret_cast<u32x4_t*>(dst + fs) = rm;
+                        if (f0 + 2 <= N / 2) *reinterpret_cast<u32x4_t*>(dst + 2 * fs) = ih;
+                        if (f0 + 3 <= N / 2) *reinterpret_cast<u32x4_t*>(dst + 3 * fs) = im;
                     } else {
+                        unsigned char* dst = dst0 + (int64_t)f * rows_f * p.row_bytes;
                         *reinterpret_cast<u32x4_t*>(dst) = rh;
                         *reinterpret_cast<u32x4_t*>(dst + 64) = rm;
                         *reinterpret_cast<u32x4_t*>(dst + 128) = ih;
