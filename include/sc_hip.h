@@ -507,6 +507,29 @@ int sc_stream_synchronize(void* stream);
 int sc_nonfinite_f32(const float* d_x, int64_t n, int32_t* d_flag, void* stream);
 int sc_nonfinite_f64(const double* d_x, int64_t n, int32_t* d_flag, void* stream);
 
+/* ---- Exchange of trial-sharded records over RCCL / xGMI (SURVEY section 8(b) `sc_allreduce`, 8(e)) ------------------------
+ * The reference has no multi-device path (its CuPy backend is one GPU: transforms.py:405-439, connectivity.py:31-65); trials
+ * shard over one process per GPU because the expectation is a plain sum of per-observation terms (connectivity.py:67-75,
+ * :489): every rank accumulates its trials into un-normalised records, the records are summed, sc_measure_* normalises by the
+ * TOTAL observation count.  These calls are that sum for a host without torch.distributed (the PyTorch host's form of the same
+ * steps is parallel.py; SC_EXCHANGE=library routes it through here):
+ *   sc_comm_unique_id            128 bytes from ONE rank, carried to the others by the host (file, socket, MPI, torch ...)
+ *   sc_comm_create               one communicator per process on the current device (ncclCommInitRank)
+ *   sc_comm_exchange_blocks_f32  block j of d_send -> rank j, d_recv[i] <- rank i: all N - 1 links at once (the direct reduce-
+ *                                scatter; sc_measure_multi_parts sums the received blocks in rank order while it reads them)
+ *   sc_comm_allreduce_f32        in-place sum of a whole record buffer (ring form)
+ *   sc_comm_gather_f32           n floats of every rank -> d_recv[rank][n] on root
+ * RCCL is bound at run time (dlopen librccl.so.1): without it sc_comm_available() is 0 and the calls return SC_EUNSUPPORTED. */
+typedef struct sc_comm sc_comm;
+int sc_comm_available(void);
+int sc_comm_unique_id(void* id128);
+int sc_comm_create(const void* id128, int n_ranks, int rank, sc_comm** out);
+int sc_comm_destroy(sc_comm* comm);
+int sc_comm_size(const sc_comm* comm, int* n_ranks, int* rank);
+int sc_comm_allreduce_f32(sc_comm* comm, float* d_buf, int64_t n, void* stream);
+int sc_comm_exchange_blocks_f32(sc_comm* comm, const float* d_send, float* d_recv, int64_t block, void* stream);
+int sc_comm_gather_f32(sc_comm* comm, const float* d_send, float* d_recv, int64_t n, int root, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

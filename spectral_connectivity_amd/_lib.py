@@ -113,6 +113,14 @@ SYMBOLS = {
                                               POINTER(c_int), c_void_p]),
     "sc_fused2_csm_absim_f32": (c_int, [c_void_p, POINTER(SpectraDesc), c_void_p, c_uint32, c_void_p, c_void_p, c_int64,
                                         c_void_p]),
+    "sc_comm_available": (c_int, []),
+    "sc_comm_unique_id": (c_int, [c_void_p]),
+    "sc_comm_create": (c_int, [c_void_p, c_int, c_int, POINTER(c_void_p)]),
+    "sc_comm_destroy": (c_int, [c_void_p]),
+    "sc_comm_size": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
+    "sc_comm_allreduce_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "sc_comm_exchange_blocks_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "sc_comm_gather_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "sc_granger_workspace_bytes": (c_int, [c_int64, c_int64, c_int64, POINTER(c_size_t)]),
     "sc_granger_pairwise_f64": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_uint32, c_int64,
                                         c_void_p, c_int64, c_double, c_int, c_void_p, c_size_t, c_int, c_void_p,

@@ -45,11 +45,14 @@ def exchange_algorithm():
     reduce-scatter each move 1/N of the record over ONE link while the other six idle, the direct form moves the same
     bytes over all of them at once (100 MB of records at cfg3 on 8 GPUs: 12.5 MB per link once, instead of seven times
     in a row).
-    ``ring``: ``reduce_scatter_tensor``, whatever algorithm RCCL picks (gloo: all-reduce + slice)."""
+    ``ring``: ``reduce_scatter_tensor``, whatever algorithm RCCL picks (gloo: all-reduce + slice).
+    ``library``: the direct exchange through the C ABI's own RCCL communicator (``sc_comm_exchange_blocks_f32``, sc_comm.hip:
+    grouped ncclSend / ncclRecv) instead of ``torch.distributed`` -- what a host without torch would call; torch only carries
+    the 128-byte communicator id to the ranks once."""
     mode = os.environ.get("SC_EXCHANGE", "direct")
-    if mode not in ("direct", "ring"):
-        raise ValueError(f"SC_EXCHANGE={mode!r}: expected 'direct' or 'ring'")
-    if mode == "direct" and _direct_failed:
+    if mode not in ("direct", "ring", "library"):
+        raise ValueError(f"SC_EXCHANGE={mode!r}: expected 'direct', 'ring' or 'library'")
+    if mode in ("direct", "library") and _direct_failed:
         return "ring"              # all_to_all_single raised on this backend once: the library reduce-scatter from then on
     return mode
 
@@ -61,6 +64,9 @@ def exchange_note():
     """What the bench line / logs should say about the exchange that really ran."""
     if _direct_failed:
         return "ring: reduce_scatter_tensor (the direct all_to_all_single exchange raised: " + _direct_failed[0] + ")"
+    if exchange_algorithm() == "library":
+        return ("library: sc_comm_exchange_blocks_f32 (grouped ncclSend / ncclRecv of the 1/N bin blocks through the C ABI's own "
+                "communicator), summed in rank order inside the epilogue kernel")
     return ("direct: all_to_all_single of the 1/N bin blocks (one xGMI link each), summed in rank order inside the epilogue kernel"
             if exchange_algorithm() == "direct" else "ring: reduce_scatter_tensor")
 
@@ -81,6 +87,52 @@ def exchange_model(record_bytes, measure_bytes, world):
             "gather_bytes_per_link": int(gather), "link_gb_per_s_assumed": XGMI_LINK_GBS,
             "predicted_ms_direct": round((direct + gather) / (XGMI_LINK_GBS * 1e9) * 1e3, 4),
             "predicted_ms_ring": round((ring + gather) / (XGMI_LINK_GBS * 1e9) * 1e3, 4)}
+
+
+_library_comms = {}                # process group -> sc_comm handle of this process (created once, on the current device)
+
+
+def _library_comm(group, device):
+    """The C ABI's RCCL communicator over the ranks of ``group``: rank 0 draws the id (sc_comm_unique_id), torch.distributed
+    carries its 128 bytes to the others, every rank joins on its current device (sc_comm_create)."""
+    import ctypes
+    from . import _lib
+    key = id(group) if group is not None else 0
+    comm = _library_comms.get(key)
+    if comm is None:
+        lib = _lib.load()
+        if not lib.sc_comm_available():
+            raise RuntimeError("SC_EXCHANGE=library: RCCL (librccl.so.1) could not be loaded by libsc_hip.so")
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        buf = ctypes.create_string_buffer(128)
+        if rank == 0:
+            _lib.check(lib.sc_comm_unique_id(buf), "sc_comm_unique_id")
+        box = [bytes(buf.raw)]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(lib.sc_comm_create(ctypes.create_string_buffer(box[0], 128), world, rank, ctypes.byref(handle)), "sc_comm_create")
+        comm = _library_comms[key] = handle
+    return comm
+
+
+def _library_blocks(accum, world, per, fpb, group):
+    """The direct exchange through sc_comm_exchange_blocks_f32 (records on the GPU, float32); None when it cannot run."""
+    from . import _lib
+    if not accum.is_cuda or accum.dtype != torch.float32:
+        _direct_failed.append("SC_EXCHANGE=library needs float32 records on the GPU")
+        return None
+    try:
+        comm = _library_comm(group, accum.device)
+        src = accum.contiguous()
+        recv = torch.empty_like(src)
+        _lib.check(_lib.load().sc_comm_exchange_blocks_f32(comm, src.data_ptr(), recv.data_ptr(), per * fpb,
+                                                           torch.cuda.current_stream(accum.device).cuda_stream), "sc_comm_exchange_blocks_f32")
+    except (RuntimeError, _lib.HipEngineError) as exc:
+        _direct_failed.append(str(exc).splitlines()[0][:200])
+        return None
+    recv.record_stream(torch.cuda.current_stream(accum.device))
+    return recv.view(world, per, fpb)
 
 
 def _direct_blocks(accum, world, per, fpb, group):
@@ -121,8 +173,8 @@ def reduce_scatter_bins(accum, group=None, keep_parts=False):
             accum = torch.cat([accum, pad], dim=0)
     lo = rank * per
     hi = min(lo + per, n_bins)
-    if exchange_algorithm() == "direct":
-        blocks = _direct_blocks(accum, world, per, fpb, group)
+    if exchange_algorithm() in ("direct", "library"):
+        blocks = (_library_blocks if exchange_algorithm() == "library" else _direct_blocks)(accum, world, per, fpb, group)
         if blocks is not None:
             if keep_parts:
                 return blocks, lo, max(hi, lo)                              # [world, per, fpb]: summed by the consumer, in rank order

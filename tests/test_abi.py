@@ -205,3 +205,36 @@ def test_numpy_host_imports_without_torch_and_refuses_without_a_gpu():
     out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-3000:]
     assert "constructed" in out.stdout or "no CPU fallback" in out.stdout, out.stdout
+
+
+@pytest.mark.gpu
+def test_comm_entry_points_on_a_one_rank_communicator():
+    """sc_comm_* (the C ABI's own RCCL communicator: SURVEY section 8(b) `sc_allreduce`, 8(e)) on the one GPU a test box has:
+    a communicator of one rank -- the all-reduce is the identity, the block exchange and the gather copy the own block.
+    (More ranks need one GPU each; `SC_EXCHANGE=library` runs the same calls inside the N > 1 path, tests/test_gpu_configs.py.)"""
+    import ctypes
+
+    import torch
+    lib = _lib.load()
+    _lib.require_gpu()
+    assert lib.sc_comm_available() == 1
+    uid = ctypes.create_string_buffer(128)
+    _lib.check(lib.sc_comm_unique_id(uid), "sc_comm_unique_id")
+    comm = ctypes.c_void_p()
+    _lib.check(lib.sc_comm_create(uid, 1, 0, byref(comm)), "sc_comm_create")
+    n, r = ctypes.c_int(), ctypes.c_int()
+    _lib.check(lib.sc_comm_size(comm, byref(n), byref(r)), "sc_comm_size")
+    assert (n.value, r.value) == (1, 0)
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    x = torch.randn(1 << 16, device=dev)
+    y = x.clone()
+    _lib.check(lib.sc_comm_allreduce_f32(comm, y.data_ptr(), y.numel(), stream), "sc_comm_allreduce_f32")
+    recv = torch.zeros_like(x)
+    _lib.check(lib.sc_comm_exchange_blocks_f32(comm, x.data_ptr(), recv.data_ptr(), x.numel(), stream), "sc_comm_exchange_blocks_f32")
+    gathered = torch.zeros_like(x)
+    _lib.check(lib.sc_comm_gather_f32(comm, x.data_ptr(), gathered.data_ptr(), x.numel(), 0, stream), "sc_comm_gather_f32")
+    torch.cuda.synchronize()
+    assert torch.equal(y, x) and torch.equal(recv, x) and torch.equal(gathered, x)
+    assert lib.sc_comm_create(uid, 2, 5, byref(ctypes.c_void_p())) == -1          # rank outside the communicator: SC_EINVAL
+    _lib.check(lib.sc_comm_destroy(comm), "sc_comm_destroy")

@@ -236,9 +236,10 @@ def test_eight_rank_rehearsal_at_the_headline_size():
     assert out.returncode == 0 and "sharded_measures OK (full size, 8 ranks x 125 trials" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
-@pytest.mark.parametrize("algorithm", ["direct", "ring"])
+@pytest.mark.parametrize("algorithm", ["direct", "ring", "library"])
 def test_rccl_exchange_path_world_one(algorithm):
-    """The RCCL calls of the N > 1 path (all_to_all_single of the direct exchange / reduce_scatter_tensor of the ring one,
+    """The RCCL calls of the N > 1 path (all_to_all_single of the direct exchange / reduce_scatter_tensor of the ring one /
+    sc_comm_exchange_blocks_f32 of the C ABI's own communicator,
     gather, all_gather_into_tensor, all_reduce on the `nccl` backend, exchange stream, padded buffers) rehearsed with the one
     GPU a test box has: a one-rank nccl group, SC_FORCE_EXCHANGE=1 so that nothing short-cuts the collectives."""
     import os
