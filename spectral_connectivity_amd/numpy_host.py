@@ -15,8 +15,9 @@ page-locked memory, copies and the stream come from the library's own ``sc_devic
 Scope: the float32 engine's hot path -- stage A (fused transform, or tapered windows + rocFFT for the lengths the fused
 kernel does not take), stage B (every accumulator plane), the expectation-type measures of the reference
 (connectivity.py:612-1159), ``expectation_type`` as in the reference.  Results are float64 / complex128 NumPy arrays
-shaped like the reference's.  Everything else (Granger, canonical / global coherence, the float64 engine, multi-GPU)
-lives on the PyTorch host.  One process uses one host: see _lib.load().
+shaped like the reference's; plus, since round 4, stage D on float32 records: ``pairwise_spectral_granger_prediction`` (batched
+2 x 2 Wilson) and ``canonical_coherence``.  Everything else (full Wilson / MVAR measures, global coherence, the float64 engine,
+multi-GPU) lives on the PyTorch host.  One process uses one host: see _lib.load().
 """
 import ctypes
 from ctypes import byref, c_int32, c_int64, c_size_t, c_void_p
@@ -340,6 +341,106 @@ class NumpyHost:
             _lib.check(lib.sc_nonlinear_accumulate_f32(X, byref(d_real), planes, rest, accum.ptr, st),
                        "sc_nonlinear_accumulate_f32")
         return accum, n_bins.value, n_obs.value
+
+    # ---- stage D through this host: pairwise spectral Granger, canonical coherence -------------------------------------
+    def _csm_records(self, time_series, expectation_type, multitaper_kwargs):
+        from .transforms import Multitaper
+        if expectation_type not in EXPECTATION_AXES:
+            raise ValueError(f"Invalid expectation_type '{expectation_type}'. Must be one of: "
+                             + ", ".join(f"'{k}'" for k in EXPECTATION_AXES))
+        m = Multitaper(time_series, **multitaper_kwargs)
+        planes = _lib.PLANE_CSM
+        sp = self.spectra(m, planes_hint=planes if self._planes_expectation(m, expectation_type, planes) else None)
+        accum, n_bins, n_obs = self.accumulate(sp, expectation_type, planes)
+        for key in ("X", "P", "scale"):
+            if sp.get(key) is not None:
+                sp[key].free()
+        axes = EXPECTATION_AXES[expectation_type]
+        kept = tuple(n for i, n in enumerate((sp["W"], sp["R"], sp["K"])) if i not in axes)
+        return m, sp, accum, n_bins, n_obs, kept
+
+    def pairwise_spectral_granger_prediction(self, time_series, pairs=None, expectation_type="trials_tapers", tolerance=1e-8,
+                                             max_iterations=60, **multitaper_kwargs):
+        """NumPy time series -> the reference's ``Connectivity.pairwise_spectral_granger_prediction()`` (connectivity.py:
+        1161-1213; out[..., i, j] = j -> i, NaN elsewhere) for all channel pairs or the listed ``pairs``: cross-spectral records
+        on the device, batched 2 x 2 Wilson factorisations (sc_granger_pairwise_f64), one download."""
+        m, sp, accum, n_bins, n_obs, kept = self._csm_records(time_series, expectation_type, multitaper_kwargs)
+        lib, C, F, N = self.lib, sp["C"], sp["F"], sp["N"]
+        if pairs is None:
+            pairs = [(i, j) for i in range(C) for j in range(i + 1, C)]
+        pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+        if ((pairs < 0) | (pairs >= C)).any():
+            raise IndexError("pair index outside the signals")
+        pairs = pairs[pairs[:, 0] != pairs[:, 1]]
+        if not 1 <= int(max_iterations) <= 1024:
+            raise ValueError("max_iterations must be in 1 ... 1024")
+        n_groups = n_bins // F
+        out = self.alloc(n_groups * F * C * C * 8)
+        result_shape = kept + (F, C, C)
+        if len(pairs) == 0:
+            accum.free(); out.free()
+            return np.full(result_shape, np.nan)
+        per_pair = n_groups * N * 160                                   # workspace bytes per problem (sc_granger_workspace_bytes)
+        chunk = int(max(1, min(len(pairs), (8 << 30) // per_pair)))
+        nbytes = ctypes.c_size_t()
+        _lib.check(lib.sc_granger_workspace_bytes(n_groups, chunk, N, byref(nbytes)), "sc_granger_workspace_bytes")
+        work = self.alloc(nbytes.value)
+        not_converged = fallbacks = 0
+        for p0 in range(0, len(pairs), chunk):
+            n = min(chunk, len(pairs) - p0)
+            d_pairs = self.upload(pairs[p0:p0 + n])
+            it_c, st_c = self.alloc(n_groups * n * 4), self.alloc(n_groups * n * 4)
+            summary = (ctypes.c_int32 * 3)(0, 0, 0)
+            _lib.check(lib.sc_granger_pairwise_f64(accum.ptr, n_groups, F, N, C, _lib.PLANE_CSM, n_obs, d_pairs.ptr, n, tolerance,
+                                                   int(max_iterations), work.ptr, nbytes.value, _lib.GRANGER_KEEP_OUTPUT if p0 else 0,
+                                                   out.ptr, it_c.ptr, st_c.ptr, summary, self.stream), "sc_granger_pairwise_f64")
+            not_converged += summary[1]
+            fallbacks += summary[2]
+            for b in (d_pairs, it_c, st_c):
+                b.free()
+        res = np.array(self.download(out, result_shape, np.float64))
+        for b in (work, out, accum):
+            b.free()
+        self.last_wilson = dict(not_converged=int(not_converged), cholesky_fallbacks=int(fallbacks))
+        return res
+
+    def canonical_coherence(self, time_series, group_labels, **multitaper_kwargs):
+        """NumPy time series -> (array (n_time_windows, n_frequencies, n_groups, n_groups), sorted labels) like the reference's
+        ``Connectivity.canonical_coherence(group_labels)`` (connectivity.py:745-820, 1953-2032; always over trials and tapers)."""
+        m, sp, accum, n_bins, n_obs, kept = self._csm_records(time_series, "trials_tapers", multitaper_kwargs)
+        lib, C, F = self.lib, sp["C"], sp["F"]
+        group_labels = np.asarray(group_labels)
+        if group_labels.shape != (C,):
+            raise ValueError(f"group_labels needs one label per signal ({C}), got shape {group_labels.shape}")
+        labels = np.unique(group_labels)
+        groups = [np.flatnonzero(group_labels == lab) for lab in labels]
+        n_g = len(groups)
+        res = np.ones((n_bins, n_g, n_g))
+        res[:, np.arange(n_g), np.arange(n_g)] = np.nan
+        # (a group with at least as many channels as observations spans the observation space: coherence 1 with every other group)
+        small = [k for k, g in enumerate(groups) if len(g) < n_obs]
+        max_group = int(lib.sc_canonical_max_group())
+        if any(len(groups[k]) > max_group for k in small):
+            raise ValueError(f"canonical_coherence: the whitening kernel takes up to {max_group} channels per group")
+        if len(small) >= 2:
+            cmax = max(len(groups[k]) for k in small)
+            stride = 16 if cmax <= 16 else (32 if cmax <= 32 else 128)
+            members = np.full((len(small), stride), -1, dtype=np.int32)
+            for i, k in enumerate(small):
+                members[i, :len(groups[k])] = groups[k]
+            sizes = np.array([len(groups[k]) for k in small], dtype=np.int32)
+            d_members, d_sizes = self.upload(members), self.upload(sizes)
+            out, fail = self.alloc(n_bins * len(small) * len(small) * 8), self.alloc(4)
+            _lib.check(lib.sc_memset_zero(fail.ptr, 4, self.stream), "sc_memset_zero")
+            _lib.check(lib.sc_canonical_coherence_f64(accum.ptr, n_bins, C, _lib.PLANE_CSM, n_obs, d_members.ptr, d_sizes.ptr, len(small),
+                                                      int(cmax), out.ptr, fail.ptr, self.stream), "sc_canonical_coherence_f64")
+            sub = np.array(self.download(out, (n_bins, len(small), len(small)), np.float64))
+            self.last_canonical_failures = int(self.download(fail, (1,), np.int32)[0])
+            res[np.ix_(np.arange(n_bins), small, small)] = sub
+            for b in (d_members, d_sizes, out, fail):
+                b.free()
+        accum.free()
+        return res.reshape(sp["W"], F, n_g, n_g), labels
 
     def _planes_expectation(self, m, expectation_type, planes):
         """Would sc_fused2.hip take this request?  (asked BEFORE stage A picks the device format of the spectra)"""

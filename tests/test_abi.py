@@ -151,6 +151,30 @@ for xin, env in ((x64, None), (x.astype(np.float32), "2")):
             assert np.abs(a[ok] - ref[ok]).max() / np.abs(ref[ok]).max() <= tol, (name, xin.shape)
     os.environ.pop("SC_PLANES_MIN_CHANNELS", None)
 host.spectra = _orig
+# stage D through this host, against the golden vectors of the REAL reference: pairwise spectral Granger (batched 2 x 2 Wilson)
+# and canonical coherence
+import os as _os
+gdir = _os.path.join(_os.getcwd(), "tests", "golden")
+g5 = np.load(_os.path.join(gdir, "f5_granger.npz"))
+for tag, kwg in (("ding2", dict(time_halfbandwidth_product=1)), ("bacc3", dict(time_halfbandwidth_product=2, n_time_samples_per_window=250))):
+    gp = host.pairwise_spectral_granger_prediction(g5[f"{tag}__x"], sampling_frequency=200.0, **kwg)
+    ref = g5[f"{tag}__granger"]
+    assert gp.shape == ref.shape, (gp.shape, ref.shape)
+    both = ~np.isnan(gp) & ~np.isnan(ref)
+    scale_g = np.nanmax(ref)
+    assert np.abs(gp[both] - ref[both]).max() <= 2e-5 * scale_g, tag
+    one_sided = np.isnan(gp) != np.isnan(ref)                      # the reference's gp[gp <= 0] = nan cut on one side only: ~0 entries
+    assert np.nan_to_num(np.where(one_sided, np.where(np.isnan(gp), ref, gp), 0.0)).max() <= 2e-5 * scale_g, tag
+    assert host.last_wilson["not_converged"] == 0
+    sub = host.pairwise_spectral_granger_prediction(g5[f"{tag}__x"], pairs=[(0, 1)], sampling_frequency=200.0, **kwg)
+    np.testing.assert_allclose(sub[..., 0, 1], gp[..., 0, 1], rtol=1e-12, equal_nan=True)
+    assert np.isnan(sub[..., 0, 2]).all() if sub.shape[-1] > 2 else True
+g6 = np.load(_os.path.join(gdir, "f6_canonical.npz"))
+cc, labels = host.canonical_coherence(g6["x"], g6["group_labels"], sampling_frequency=float(g6["fs"]),
+                                      time_halfbandwidth_product=float(g6["NW"]), n_time_samples_per_window=int(g6["L"]))
+assert np.array_equal(labels, g6["labels"]) and cc.shape == g6["canonical_coherence"].shape
+okc = ~np.isnan(g6["canonical_coherence"])
+assert np.array_equal(np.isnan(cc), ~okc) and np.abs(cc[okc] - g6["canonical_coherence"][okc]).max() <= 2e-5
 # a window length the fused transform does not take (7 is a prime factor above 5): tapered windows + rocFFT
 got = host.connectivity(x[:448].astype(np.float32), measures=("coherence_magnitude",), sampling_frequency=500.0,
                         time_halfbandwidth_product=2, n_time_samples_per_window=224)
