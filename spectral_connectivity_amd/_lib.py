@@ -286,8 +286,9 @@ PLANES_FORMAT_FAMILIES = (PLANE_CSM, PLANE_CSM | PLANE_ABS_IM, PLANE_CSM | PLANE
                           PLANE_SIGN_IM)   # what sc_fused2.hip accumulates
 
 
-def planes_format_applies(n_window, n_fft, n_alloc, planes_hint):
-    """Does stage A write the planes format for a caller that will ask for the accumulator families ``planes_hint``?"""
+def planes_format_applies(n_window, n_fft, n_alloc, planes_hint, spectra_bytes=None):
+    """Does stage A write the planes format for a caller that will ask for the accumulator families ``planes_hint``?
+    ``spectra_bytes``: size of the complex64 spectra of the request, when the caller knows it."""
     if planes_hint not in PLANES_FORMAT_FAMILIES or os.environ.get("SC_PLANES_FORMAT", "1") == "0":
         return False
     # Below these channel counts the float32 VALU kernel of sc_fused.hip on complex64 spectra is the faster path (it is HBM-bound
@@ -295,5 +296,15 @@ def planes_format_applies(n_window, n_fft, n_alloc, planes_hint):
     # charged to the planes side
     lo = {PLANE_CSM: 32, PLANE_CSM | PLANE_ABS_IM: 44, PLANE_CSM | PLANE_ABS_IM | PLANE_IM_SQ: 60,
           PLANE_SIGN_IM: 44}[planes_hint]
-    lo = int(os.environ.get("SC_PLANES_MIN_CHANNELS", lo))
+    forced = os.environ.get("SC_PLANES_MIN_CHANNELS")               # (tests: the format from this many channels on, whatever the size)
+    if forced is not None:
+        lo = int(forced)
+    else:
+        # CSM alone gains 1 ms of stage B up to 64 channels (the 64-observation chunks) but only 0.2-0.5 ms beyond, which is what the
+        # format costs stage A; and a request of a few tens of MB is three short launches either way -- the scale pre-pass would
+        # only add two (cfg2: 0.110 -> 0.132 ms with the format, cfg5's CSM at 256 channels 7.25 -> 7.47)
+        if planes_hint == PLANE_CSM and n_alloc > 64:
+            return False
+        if spectra_bytes is not None and spectra_bytes < (256 << 20):
+            return False
     return lo <= n_alloc <= 256 and bool(_handle().sc_multitaper_fft_planes_supported(n_window, n_fft, n_alloc))

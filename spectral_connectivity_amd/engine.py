@@ -209,7 +209,7 @@ def multitaper_spectra(x, tapers_over_fs, n_window, n_step, n_fft, n_windows, de
     strides = (n_windows * R * K * C, R * K * C, K * C, C)
     if use_fused is None:
         use_fused = bool(lib.sc_multitaper_fft_supported(L, n_fft))
-    if use_fused and planes_format_applies(L, n_fft, C, planes_hint):
+    if use_fused and planes_format_applies(L, n_fft, C, planes_hint, spectra_bytes=F * n_windows * R * K * C * 8):
         row_bytes = int(lib.sc_planes_row_bytes(C))
         P = torch.empty((F * n_windows * R * K * row_bytes,), dtype=torch.uint8, device=x.device)
         scale = torch.empty((2 * C,), dtype=torch.float32, device=x.device)

@@ -252,7 +252,7 @@ class NumpyHost:
             tw = self.alloc(N * 8)
             _lib.check(lib.sc_fft_twiddles_f32(N, tw.ptr, self.stream), "sc_fft_twiddles_f32")
             self._twiddles[N] = tw
-        if fused and _lib.planes_format_applies(L, N, C_alloc, planes_hint):
+        if fused and _lib.planes_format_applies(L, N, C_alloc, planes_hint, spectra_bytes=F * W * R * K * C_alloc * 8):
             # planes format: one scan of the series for the channel scales, then the fused transform writes the f16 pieces
             P = self.alloc(F * W * R * K * int(lib.sc_planes_row_bytes(C_alloc)))
             scale, work = self.alloc(2 * C_alloc * 4), self.alloc(C_alloc * 4)

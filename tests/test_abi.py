@@ -118,8 +118,8 @@ for xin in (x.astype(np.float32), x):             # float32 upload, and float64 
         err = np.abs(a[ok] - ref[ok]).max() / np.abs(ref[ok]).max()
         assert err <= tol, (name, err)
 # the planes format of the float32 engine (two f16 pieces per real number, written by stage A: sc_fused2.hip) through this host:
-# 64 channels take it by themselves for coherence + wPLI, the small 7-channel case with the threshold lifted; a request that
-# mixes in a family the format does not carry (PLV) stays on complex64
+# (SC_PLANES_MIN_CHANNELS lifts the engine's size and channel thresholds: these requests are tiny); a request that mixes in a
+# family the format does not carry (PLV) stays on complex64
 import os
 from spectral_connectivity_amd import _lib
 seen = []
@@ -131,7 +131,7 @@ def _spy(m, planes_hint=None):
 host.spectra = _spy
 x64 = rng.standard_normal((T, R, 64)).astype(np.float32)
 x64 += (0.8 * np.sin(2 * np.pi * 40 * t[:, None, None] + 0.1 * np.arange(64)[None, None, :])).astype(np.float32)
-for xin, env in ((x64, None), (x.astype(np.float32), "2")):
+for xin, env in ((x64, "44"), (x.astype(np.float32), "2")):
     if env:
         os.environ["SC_PLANES_MIN_CHANNELS"] = env
     for names_p, want in ((("coherence_magnitude", "weighted_phase_lag_index"), True), (("debiased_squared_weighted_phase_lag_index",), True),

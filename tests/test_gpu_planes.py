@@ -171,15 +171,25 @@ def test_public_classes_take_the_planes_path_and_match_the_oracle(dtype):
 
 
 @pytest.mark.default_thresholds
-def test_few_channels_keep_complex64_by_default():
-    """Below the measured crossover (44 channels for CSM + |Im s|) the float32 engine keeps complex64 spectra."""
+def test_when_the_engine_takes_the_planes_format():
+    """The measured crossovers (engine default): CSM + |Im s| from 44 channels, CSM alone from 32 to 64 channels, nothing for a
+    request of a few tens of MB -- and the transform that follows the rule."""
+    big = 1 << 30
+    csm = _lib.PLANE_CSM
+    assert _lib.planes_format_applies(256, 256, 64, PLANES, spectra_bytes=big)
+    assert _lib.planes_format_applies(256, 256, 128, PLANES, spectra_bytes=big)
+    assert not _lib.planes_format_applies(256, 256, 40, PLANES, spectra_bytes=big)
+    assert not _lib.planes_format_applies(256, 256, 64, PLANES, spectra_bytes=32 << 20)
+    assert _lib.planes_format_applies(256, 256, 64, csm, spectra_bytes=big)
+    assert not _lib.planes_format_applies(256, 256, 30, csm, spectra_bytes=big)
+    assert not _lib.planes_format_applies(1024, 1024, 256, csm, spectra_bytes=big)
+    assert not _lib.planes_format_applies(256, 256, 64, _lib.PLANE_CSM | _lib.PLANE_UNIT, spectra_bytes=big)
     dev = _dev()
     tapers = np.asarray(transforms.dpss_windows(128, 2, 3)[0])[:3]
     h = torch.from_numpy(np.ascontiguousarray(tapers / np.sqrt(1000.0), dtype=np.float32)).to(dev)
-    for C, expect in ((30, False), (40, False), (64, True)):
-        x = torch.from_numpy(_series(512, 2, C, seed=1).astype(np.float32)).to(dev)
-        sp = engine.multitaper_spectra(x, h, 128, 128, 128, 4, "constant", planes_hint=PLANES)
-        assert (sp.P is not None) == expect
+    x = torch.from_numpy(_series(512, 2, 64, seed=1).astype(np.float32)).to(dev)
+    sp = engine.multitaper_spectra(x, h, 128, 128, 128, 4, "constant", planes_hint=PLANES)        # 0.4 MB of spectra
+    assert sp.P is None
 
 
 def test_planes_switch_gives_the_complex64_path():
