@@ -877,8 +877,11 @@ int sc_internal_fused_pick_split(int n_bins, int n_obs) {
     double best_cost = 1e30;
     for (int S = 1; S <= 24; ++S) {
         if (S > 1 && nc / S < 16) break;
-        const double rounds = (double)(((int64_t)n_bins * S + n_cu - 1) / n_cu) / S;
-        const double cost = rounds * (1.0 + 0.015 * (S - 1));      // prologue/epilogue + combine traffic per part
+        // rounds of workgroups x (chunks of a part + ~3 chunks' worth of prologue, record write and drain) x 2 % per extra
+        // partial record the epilogue / combine reads.  Fitted on 125 ... 1000 trials of cfg3 (round 4: with the flat 1.5 % per
+        // part of before, 250 trials took three parts and ran 5 % slower than one)
+        const double rounds = (double)(((int64_t)n_bins * S + n_cu - 1) / n_cu);
+        const double cost = rounds * ((double)nc / S + 3.0) * (1.0 + 0.02 * (S - 1));
         if (cost < best_cost - 1e-9) { best_cost = cost; best = S; }
     }
     if (e && atoi(e) >= 1 && atoi(e) <= 24 && (atoi(e) == 1 || nc / atoi(e) >= 1)) best = atoi(e);
