@@ -450,7 +450,7 @@ def main():
                 "frac": round(wk / d / 1e9 / HBM_PEAK_GBS, 4)}
 
     traffic, traffic_src = measured_traffic(args.config, dominant) if world == 1 else (None, None)
-    KERNEL_OF = {"fused_stage_b": "fused2_kernel (+ fused_combine_kernel)", "mtfft_fused": "mtfft16_kernel",
+    KERNEL_OF = {"fused_stage_b": "fused2_kernel (its partial records are summed by the epilogue; fused_combine_kernel only on the fold=True path)", "mtfft_fused": "mtfft16_kernel",
                  "measure_epilogue": "measure_tile_kernel"}
     roofline = {"kernel": KERNEL_OF.get(dominant, dominant), "entry_point": dominant, "bound": bound,
                 "achieved": round(achieved, 3), "peak": peak,

@@ -55,7 +55,7 @@ if under:
     sm = st["roofline"]["stage_ms"]
     hdr.append("# stage times of the same run from the library's own hipEvent timers (sc_last_timing): " +
                ", ".join(f"{k} {v:.3f} ms" for k, v in sm.items()) + f"; step {st['ms_per_step']:.2f} ms")
-    hdr.append("# (fused_stage_b = fused2_kernel + fused_combine_kernel; averages below include the 2 warm-up launches)")
+    hdr.append("# (fused_stage_b = fused2_kernel; its split-bin partial records are summed by measure_tile_multi_kernel; averages below include the 2 warm-up launches)")
 open(os.path.join(P, ROUND + "_bench_kernel_stats.txt"), "w").write("\n".join(hdr + lines("kt.txt")[:12]) + "\n")
 
 fetch, write = pmc("fetch.txt", "FETCH_SIZE"), pmc("write.txt", "WRITE_SIZE")
