@@ -192,9 +192,14 @@ mtfft16_kernel(MtArgs p) {
     // per-channel transform gives (its measures turn NaN on zero power): the conjugate-symmetry split of a packed pair
     // would leave the rounding noise of its partner there.  One flag per channel of the tile.
     __shared__ int nzf[CT], nbf[CT];       // (plain stores of a constant: many threads may set the same flag)
+    // complex64 output: largest finite |sample| of every channel of THIS window (bit pattern; non-negative floats order like
+    // unsigned).  The two channels of a pair enter their shared transform scaled to [1, 2) by powers of two and leave it scaled
+    // back -- exact -- so that a weak channel does not carry the float32 rounding of a strong pair partner (6e-5 of its own
+    // largest coefficient for a x500 pair before).  (Planes output: the global channel scales already did this at the load.)
+    __shared__ unsigned mxc[CT];
 
     const int tid = threadIdx.x;
-    if (tid < CT) { nzf[tid] = 0; nbf[tid] = 0; }
+    if (tid < CT) { nzf[tid] = 0; nbf[tid] = 0; mxc[tid] = 0u; }
     if constexpr (LONG) __syncthreads();
     MT_T0();
     int c0, r, w;
@@ -413,6 +418,10 @@ mtfft16_kernel(MtArgs p) {
         if (n1) nzf[2 * pf + 1] = 1;
         if (b0) nbf[2 * pf] = 1;
         if (b1) nbf[2 * pf + 1] = 1;
+        if constexpr (!PL) {
+            if (!b0 && n0) atomicMax(&mxc[2 * pf], mx0);
+            if (!b1 && n1) atomicMax(&mxc[2 * pf + 1], mx1);
+        }
     }
     __syncthreads();                                  // tile and detrend scratch consumed: their space is free
     if (nbf[2 * pf]) {
@@ -426,8 +435,16 @@ mtfft16_kernel(MtArgs p) {
     // The samples enter halved -- once per workgroup, they serve every taper: the 1/2 of the conjugate-symmetry split, an exact
     // scaling, leaves the store loop.  (Halving the TAPERS instead put a multiply, i.e. a wait for the taper loads, in front
     // of the barrier of the long-window kernels: 2048 samples 2.0 -> 2.6 ms, bisected with variant libraries.)
+    // 2^(127 - E) for a largest magnitude m 2^(E - 127), m in [1, 2): exponent field 254 - E; 1 for zero / denormal / huge maxima
+    auto pair_scale = [](unsigned mx, bool inverse) -> float {
+        const unsigned E = mx >> 23;
+        return (E >= 1u && E <= 253u) ? __uint_as_float((inverse ? E : 254u - E) << 23) : 1.f;
+    };
+    {
+        const float h0 = 0.5f * (PL ? 1.f : pair_scale(mxc[2 * pf], false)), h1 = 0.5f * (PL ? 1.f : pair_scale(mxc[2 * pf + 1], false));
 #pragma unroll
-    for (int t = 0; t < 16; ++t) { xs[t].x *= 0.5f; xs[t].y *= 0.5f; }
+        for (int t = 0; t < 16; ++t) { xs[t].x *= h0; xs[t].y *= h1; }
+    }
     const int spr = 2 * (tid & (NF - 1));                                   // the pair this thread stores
     const bool na = nbf[spr] != 0, nb = nbf[spr + 1] != 0, za = !na && nzf[spr] == 0, zb = !nb && nzf[spr + 1] == 0;
     const bool any_flag = __builtin_amdgcn_ballot_w64(na || nb || za || zb) != 0ull || (p.dbg & 8);      // wave-uniform
@@ -706,11 +723,12 @@ mtfft16_kernel(MtArgs p) {
             float2 zn = make_float2(0.f, 0.f);
             if (last) zn = zp[PHYS(N / 2)];
             float2* dst0 = Xk + 2 * pr;
+            const float ia = pair_scale(mxc[2 * pr], true), ib = pair_scale(mxc[2 * pr + 1], true);       // back to the samples' units
             // (the silent / non-finite channel overrides cost eight selects per row of a thread -- a tenth of the kernel's
             //  VALU instructions -- and almost never apply: a wave without a flagged channel takes the loop without them)
             auto put_any = [&](auto flagged, int f, float2 u1, float2 u2) {
-                float2 A = make_float2(u1.x + u2.x, u1.y - u2.y);       // (Z[f] + conj Z[N-f]) / 2, the half already in the taper
-                float2 B = make_float2(u1.y + u2.y, u2.x - u1.x);       // (Z[f] - conj Z[N-f]) / (2 i)
+                float2 A = make_float2((u1.x + u2.x) * ia, (u1.y - u2.y) * ia);       // (Z[f] + conj Z[N-f]) / 2, the half already in the samples
+                float2 B = make_float2((u1.y + u2.y) * ib, (u2.x - u1.x) * ib);       // (Z[f] - conj Z[N-f]) / (2 i)
                 if constexpr (decltype(flagged)::value) {
                     if (za) A = make_float2(0.f, 0.f);
                     if (zb) B = make_float2(0.f, 0.f);

@@ -47,7 +47,8 @@ def test_stage_a_planes_decode_to_the_spectra(L, step, C, detrend):
     """sc_multitaper_fft_planes_f32 + sc_spectra_from_planes_f32 against the float64 transform of the same samples and
     tapers: the float32 transform's rounding plus the 22 bits of the format.  The scales sit on the SAMPLES, so the two
     channels that share a complex transform enter it at the same magnitude: a channel far weaker than its pair partner (here
-    x 250 and x 1/500) comes out to its OWN rounding, where the complex64 transform leaves the partner's on it."""
+    x 250 and x 1/500) comes out to its OWN rounding (the complex64 kernel normalises the pair per window for the same effect;
+    before round 4 it left the partner's rounding on the weak channel: 6e-5 of its largest coefficient)."""
     dev, lib = _dev(), _lib.load()
     T, R, NW = 2048, 3, 3
     K = 2 * NW - 1
@@ -65,11 +66,10 @@ def test_stage_a_planes_decode_to_the_spectra(L, step, C, detrend):
     amax = X64.abs().amax(dim=(0, 1, 2, 3))
     err = ((X - X64).abs().amax(dim=(0, 1, 2, 3)) / amax)
     err_c64 = ((Xr - X64).abs().amax(dim=(0, 1, 2, 3)) / amax)
-    # every channel to (a few ulp of float32) x its own largest coefficient -- the pair partner's size does not enter
+    # every channel to (a few ulp of float32) x its own largest coefficient -- the pair partner's size does not enter, in either
+    # device format (complex64: the two channels of a pair are scaled to [1, 2) per window inside the kernel and scaled back)
     assert err.max().item() < 1.5e-6, (err.max().item(), err_c64.max().item())
-    assert bool((err <= 1.5 * err_c64 + 4e-7).all())
-    if C >= 4:
-        assert err_c64[1].item() > 4 * err[1].item(), "channel 1 (pair partner of the loud channel 0) was expected to gain"
+    assert err_c64.max().item() < 1.5e-6, (err.max().item(), err_c64.max().item())
 
 
 def test_conversions_are_inverse_and_keep_zero_and_nonfinite_channels():
