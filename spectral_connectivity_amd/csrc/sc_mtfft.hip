@@ -873,6 +873,14 @@ static int launch_mt16(const MtArgs& a, hipStream_t stream) {
     return launch_mt16_<LOG2N, THREADS, false>(a, stream);
 }
 
+// Powers of two that bring a channel whose largest finite magnitude has the bit pattern mx into [1, 2) (and back): the two channels
+// of a packed pair enter their shared complex transform at the same magnitude, so that the weaker one keeps its own float32
+// rounding (see mtfft16_kernel).  1 for zero / denormal / huge maxima.
+__device__ __forceinline__ float mt_pair_scale(unsigned mx, bool inverse) {
+    const unsigned E = mx >> 23;
+    return (E >= 1u && E <= 253u) ? __uint_as_float((inverse ? E : 254u - E) << 23) : 1.f;
+}
+
 // ----------------------------------------------------------------------------------------
 // Window lengths off the power-of-two list whose only prime factors are 2, 3 and 5 (250, 500, 1000, 200, 300, 1500 ...:
 // what scipy.fft.next_fast_len, transforms.py:1024-1036, hands the reference for the usual sampling rates): the same
@@ -1014,8 +1022,9 @@ __global__ void __launch_bounds__(512) mtfft_mixed_kernel(MxArgs p) {
     float* tile = reinterpret_cast<float*>(tw + N);               // [L][XS]
     double* red = reinterpret_cast<double*>(tile + ((L * XS + 1) & ~1));   // [2][512] + trend [2][CT]
     __shared__ int nzf[32], nbf[32];                              // channel not identically zero / holds a non-finite sample (see mtfft16_kernel)
+    __shared__ unsigned mxc[32];                                  // largest finite |detrended sample| of the channel in this window
     const int tid = threadIdx.x;
-    if (tid < 32) { nzf[tid] = 0; nbf[tid] = 0; }
+    if (tid < 32) { nzf[tid] = 0; nbf[tid] = 0; mxc[tid] = 0u; }
     const int c0 = blockIdx.x * CT, r = blockIdx.y, w = blockIdx.z;
     const int64_t RC = (int64_t)p.R * C;
     const float* xw = p.x + ((int64_t)w * p.step * p.R + r) * C + c0;
@@ -1074,11 +1083,16 @@ __global__ void __launch_bounds__(512) mtfft_mixed_kernel(MxArgs p) {
         const bool nz = orv != 0u, bad = mxv >= 0x7f800000u;
         if (nz) nzf[cc] = 1;
         if (bad) nbf[cc] = 1;
+        if (nz && !bad) atomicMax(&mxc[cc], mxv);
         __syncthreads();
         // a channel with a NaN / infinity leaves the packed transform (see mtfft16_kernel): zeros in, NaN bins out
         if (sl < SL && nbf[cc]) {
             for (int l = sl; l < L; l += SL) tile[l * XS + cc] = 0.f;
             nzf[cc] = 0;           // the store loop writes exact zeros for it; the fix-up after it writes the NaNs
+        } else if (sl < SL) {      // pair normalisation (mt_pair_scale): exact, undone at the store
+            const float sc = mt_pair_scale(mxc[cc], false);
+            if (sc != 1.f)
+                for (int l = sl; l < L; l += SL) tile[l * XS + cc] *= sc;
         }
         __syncthreads();
     }
@@ -1128,8 +1142,9 @@ __global__ void __launch_bounds__(512) mtfft_mixed_kernel(MxArgs p) {
             const int f = idx >> lnf, pr = idx & (NF - 1), c = c0 + 2 * pr;
             if (c >= C) continue;
             const float2 u1 = src[pr * N + f], u2 = src[pr * N + (f == 0 ? 0 : N - f)];
-            float2 A = make_float2(0.5f * (u1.x + u2.x), 0.5f * (u1.y - u2.y));
-            float2 B = make_float2(0.5f * (u1.y + u2.y), 0.5f * (u2.x - u1.x));
+            const float ha = 0.5f * mt_pair_scale(mxc[2 * pr], true), hb = 0.5f * mt_pair_scale(mxc[2 * pr + 1], true);
+            float2 A = make_float2(ha * (u1.x + u2.x), ha * (u1.y - u2.y));
+            float2 B = make_float2(hb * (u1.y + u2.y), hb * (u2.x - u1.x));
             if (nzf[2 * pr] == 0) A = make_float2(0.f, 0.f);         // identically zero channel: exact zeros
             if (nzf[2 * pr + 1] == 0) B = make_float2(0.f, 0.f);
             float2* d = Xk + (int64_t)f * sF + 2 * pr;
@@ -1169,8 +1184,9 @@ __global__ void __launch_bounds__(64 * NF) mtfft_mixed_wave_kernel(MxArgs p) {
     float2* tw = z + (NF * N > (2 * NT + 2 * CT) ? NF * N : (2 * NT + 2 * CT));   // [N]
     float* tile = reinterpret_cast<float*>(tw + N);               // [L][XS]
     __shared__ int nzf[CT], nbf[CT];                              // channel not identically zero / holds a non-finite sample (see mtfft16_kernel)
+    __shared__ unsigned mxc[CT];                                  // largest finite |detrended sample| of the channel in this window
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid < CT) { nzf[tid] = 0; nbf[tid] = 0; }
+    if (tid < CT) { nzf[tid] = 0; nbf[tid] = 0; mxc[tid] = 0u; }
     const int L = p.L, C = p.C;
     int c0, r, w;
     if constexpr (NF < 8) {
@@ -1240,11 +1256,16 @@ __global__ void __launch_bounds__(64 * NF) mtfft_mixed_wave_kernel(MxArgs p) {
         const bool nz = orv != 0u, bad = mxv >= 0x7f800000u;
         if (nz) nzf[cc] = 1;
         if (bad) nbf[cc] = 1;
+        if (nz && !bad) atomicMax(&mxc[cc], mxv);
         __syncthreads();
         // a channel with a NaN / infinity leaves the packed transform (see mtfft16_kernel): zeros in, NaN bins out
         if (nbf[cc]) {
             for (int l = sl; l < L; l += SL) tile[l * XS + cc] = 0.f;
             nzf[cc] = 0;           // the store loop writes exact zeros for it; the fix-up below overwrites them
+        } else {                   // pair normalisation (mt_pair_scale): exact, undone at the store
+            const float sc = mt_pair_scale(mxc[cc], false);
+            if (sc != 1.f)
+                for (int l = sl; l < L; l += SL) tile[l * XS + cc] *= sc;
         }
         __syncthreads();
     }
@@ -1275,8 +1296,9 @@ __global__ void __launch_bounds__(64 * NF) mtfft_mixed_wave_kernel(MxArgs p) {
             const int f = idx >> LNF, pr = idx & (NF - 1), c = c0 + 2 * pr;
             if (c >= C) continue;
             const float2 u1 = z[pr * N + f], u2 = z[pr * N + (f == 0 ? 0 : N - f)];
-            float2 A = make_float2(0.5f * (u1.x + u2.x), 0.5f * (u1.y - u2.y));
-            float2 B = make_float2(0.5f * (u1.y + u2.y), 0.5f * (u2.x - u1.x));
+            const float ha = 0.5f * mt_pair_scale(mxc[2 * pr], true), hb = 0.5f * mt_pair_scale(mxc[2 * pr + 1], true);
+            float2 A = make_float2(ha * (u1.x + u2.x), ha * (u1.y - u2.y));
+            float2 B = make_float2(hb * (u1.y + u2.y), hb * (u2.x - u1.x));
             if (nzf[2 * pr] == 0) A = make_float2(0.f, 0.f);         // identically zero channel: exact zeros
             if (nzf[2 * pr + 1] == 0) B = make_float2(0.f, 0.f);
             float2* d = Xk + (int64_t)f * sF + 2 * pr;

@@ -72,6 +72,25 @@ def test_stage_a_planes_decode_to_the_spectra(L, step, C, detrend):
     assert err_c64.max().item() < 1.5e-6, (err.max().item(), err_c64.max().item())
 
 
+@pytest.mark.parametrize("L,step,C", [(250, 125, 12), (1000, 1000, 6), (200, 100, 40), (2048, 2048, 6)])
+def test_complex64_transform_keeps_a_weak_channel_from_its_pair_partners_rounding(L, step, C):
+    """The complex64 kernels (radix-16, long windows and the mixed-radix lengths next_fast_len hands out) normalise the two
+    channels of a packed pair per window: every channel within a few float32 ulp of ITS OWN largest coefficient, next to a
+    partner 250 times louder or 500 times quieter."""
+    dev = _dev()
+    T, R, NW = 4096, 2, 2
+    K = 2 * NW - 1
+    W = (T - L) // step + 1
+    x = torch.from_numpy(_series(T, R, C, seed=L + C).astype(np.float32)).to(dev)
+    tapers = np.asarray(transforms.dpss_windows(L, NW, K)[0])[:K]
+    h = torch.from_numpy(np.ascontiguousarray(tapers * np.sqrt(1000.0) / 1000.0, dtype=np.float32)).to(dev)
+    X64 = engine.multitaper_spectra_f64(x.double(), h.double(), L, step, L, W, "constant").X
+    X = engine.multitaper_spectra(x, h, L, step, L, W, "constant").X
+    amax = X64.abs().amax(dim=(0, 1, 2, 3))
+    err = (X - X64).abs().amax(dim=(0, 1, 2, 3)) / amax
+    assert err.max().item() < 2.5e-6, err.tolist()
+
+
 def test_conversions_are_inverse_and_keep_zero_and_nonfinite_channels():
     dev, lib = _dev(), _lib.load()
     F, W, R, K, C = 3, 2, 4, 3, 36
