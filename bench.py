@@ -116,10 +116,64 @@ def one_step(x, h, cfg, geom, planes, world, exchange=None):
                                               n_groups=int(os.environ.get("SC_BENCH_GROUPS", "4")),
                                               equal_shards=True, timing=exchange)   # R % world == 0: asserted in main()
         return coh, wpli
-    accum, n_obs = engine.accumulate(sp, "trials_tapers", planes, fold=False)     # the epilogue sums the split-bin parts itself
+    # fold=False: the split-bin partial records come back as ONE [n_parts, n_bins, floats_per_bin] tensor and the epilogue sums them
+    # while it reads -- the path Connectivity takes too (connectivity.py: _accumulators), checked against the folded form and the
+    # float64 reference at this size in tests/test_gpu_full_depth.py::test_cfg3_bench_chain_full_depth
+    accum, n_obs = engine.accumulate(sp, "trials_tapers", planes, fold=False)
     del sp
     coh, wpli = engine.measure_multi(accum, cfg["C"], planes, n_obs, [_lib.M_COHERENCE_MAGNITUDE, _lib.M_WPLI])
     return coh, wpli
+
+
+def chain_check(x, h, cfg, geom, planes):
+    """Outside the timed region: the timed chain (partial records + parts-summing epilogue) against the folded form of the same
+    launch, bit for bit, and a sanity bound on the values."""
+    L, step, N, W = geom
+    sp = engine.multitaper_spectra(x, h, L, step, N, W, "constant", planes_hint=planes)
+    parts, n_obs = engine.accumulate(sp, "trials_tapers", planes, fold=False)
+    folded, _ = engine.accumulate(sp, "trials_tapers", planes)
+    which = [_lib.M_COHERENCE_MAGNITUDE, _lib.M_WPLI]
+    a = engine.measure_multi(parts, cfg["C"], planes, n_obs, which)
+    b = engine.measure_multi(folded, cfg["C"], planes, n_obs, which)
+    same = all(bool(torch.equal(u.nan_to_num(), v.nan_to_num())) for u, v in zip(a, b))
+    off = ~torch.eye(cfg["C"], dtype=torch.bool, device=x.device)
+    sane = bool(((a[0][:, off] >= 0) & (a[0][:, off] <= 1)).all()) and bool((a[1].abs() <= 1 + 1e-6).all())
+    return {"spectra_format": "planes (f16 pieces)" if sp.P is not None else "complex64",
+            "n_partial_records": int(parts.shape[0]) if parts.dim() == 3 else 1,
+            "parts_epilogue_equals_folded_record_bitwise": same, "values_in_range": sane}
+
+
+def api_pass(x, cfg, geom):
+    """The same workload through the PUBLIC classes, series resident in HBM: Multitaper(device tensor) ->
+    Connectivity.from_multitaper(dtype=complex64) -> coherence_magnitude() -> weighted_phase_lag_index() -- the BASELINE order, the
+    one that froze complex64 spectra before round 5.  Device time from the library's own timers (every kernel of the pass), wall
+    time including the two downloads (the API returns NumPy arrays)."""
+    import spectral_connectivity_amd as sc
+    L, step, N, W = geom
+    kw = dict(sampling_frequency=FS, time_halfbandwidth_product=cfg["NW"], n_time_samples_per_window=L, n_time_samples_per_step=step)
+    dev_ms, wall_ms, fmt = [], [], None
+    for _ in range(4):
+        torch.cuda.synchronize()
+        _lib.last_timing()
+        t0 = time.perf_counter()
+        c = sc.Connectivity.from_multitaper(sc.Multitaper(x, **kw), dtype=np.complex64)
+        coh = c.coherence_magnitude()
+        wpli = c.weighted_phase_lag_index()
+        wall_ms.append((time.perf_counter() - t0) * 1e3)
+        stages = {}
+        for name, ms in _lib.last_timing():
+            stages[name] = stages.get(name, 0.0) + ms
+        dev_ms.append((sum(stages.values()), stages))
+        fmt = "planes (f16 pieces)" if c._spectra.P is not None else "complex64"
+        del c, coh, wpli
+    dev_ms.sort(key=lambda t: t[0])
+    wall_ms.sort()
+    total, stages = dev_ms[1]
+    return {"device_ms": round(total, 4), "wall_ms": round(wall_ms[1], 3), "spectra_format": fmt,
+            "stage_ms": {k: round(v, 4) for k, v in stages.items()},
+            "is": "Multitaper(series in HBM) -> Connectivity.from_multitaper(dtype=complex64) -> coherence_magnitude() -> "
+                  "weighted_phase_lag_index(); device_ms = the library's hipEvent timers over every kernel of the pass, wall_ms with the "
+                  "host-side parameter logic, taper generation and the two downloads of float64 / float32 results; second fastest of 4"}
 
 
 def cpu_baseline_strong(cfg, geom, budget_trials=16):
@@ -515,7 +569,18 @@ def main():
                     "flops_full_matrix": 8.0 * n_obs_loc * C * C * W * F,
                     "frac_full_matrix": round(8.0 * n_obs_loc * C * C * W * F / dur_s / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
                     # the pipe the products really run on: 3 f16 cross terms per f32-equivalent product (6 bf16 ones before round 4)
-                    "frac_f16_pipe": round(3.0 * work / dur_s / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)}),
+                    "frac_f16_pipe": round(3.0 * work / dur_s / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                    # against the pipe the kernel really uses: every matrix instruction it issues, at that instruction's own rate
+                    "pipe": (lambda nt, nb32, obs_bins: (lambda csm_f, abs_f: {
+                        "unit": "TFLOP/s", "peak": MFMA_BF16_PEAK_TFLOPS, "achieved": round((csm_f + abs_f) / dur_s / 1e12, 2),
+                        "frac": round((csm_f + abs_f) / dur_s / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                        "pipe_busy_frac": round((csm_f / (MFMA_BF16_PEAK_TFLOPS * 1e12) + abs_f / (0.5 * MFMA_BF16_PEAK_TFLOPS * 1e12)) / dur_s, 4),
+                        "counts": "issued f16 matrix flops: cross-spectra 12 x v_mfma_f32_16x16x32_f16 per upper 16x16 tile and 32 observations "
+                                  "(three cross terms x {rr, ii, ir, (-r)i}, diagonal tiles in full) + one v_mfma_f32_32x32x8_f16 per "
+                                  "observation and upper 32x32 block for the per-observation Im s (K = 8: the four piece products of "
+                                  "Im Re and of (-Re) Im; a half-rate instruction: pipe_busy_frac prices it at 1.25 PF)"})(
+                        obs_bins * nt * 12 * 16384.0 / 32.0, obs_bins * (nb32 * (nb32 + 1) // 2) * 16384.0))(
+                        ((C + 15) // 16) * ((C + 15) // 16 + 1) // 2, (C + 31) // 32, float(n_obs_loc) * W * F)}),
                 # the whole step against both rooflines of SURVEY section 8(d) (the binding one is the larger time):
                 # algorithmic bytes of the two-pass design over the HBM peak, triangle-only CSM flops over the f32 MFMA peak
                 "whole_path": (lambda t_hbm, t_mfma: {
@@ -553,6 +618,13 @@ def main():
                       "sample": (f"restructured NumPy path (one-sided spectra, batched-GEMM cross-spectral matrix on all BLAS "
                                  f"threads, blocked vectorised |Im s| plane; float64) on {n_sample} of {cfg['R']} trials, linear "
                                  f"in trials; the |Im s| plane is single-threaded NumPy arithmetic, BLAS threads = {threads}")}
+
+    check = api = None
+    if rank == 0 and world == 1:
+        check = chain_check(x, h, cfg, geom, planes)
+        _lib.timing_enable(True)
+        api = api_pass(x, cfg, geom)
+        _lib.timing_enable(False)
 
     # end to end, NumPy in -> NumPy out (page-locked host buffers: upload of the float32 series, the step,
     # download of both measures), a few passes after the timed region; never `value`
@@ -633,6 +705,7 @@ def main():
             "ms_per_step_median": round(median_ms, 4), "value_at_median": units / (median_ms * 1e-3),
             "pair_bin_obs_per_s": units * cfg["R"] * K / (elapsed / args.steps),
             "e2e_ms": e2e_ms, "e2e_is": "NumPy (pinned) float32 series in -> coherence + wPLI as NumPy out, median of 3",
+            "api_ms": None if api is None else api["device_ms"], "api": api, "chain_check": check,
             "config": {"workload": cfg["label"], "name": args.config, "trials_total": cfg["R"],
                        "trials_per_gpu": R_loc, "n_tapers": K, "n_windows": W, "n_freq_bins": F,
                        "units_per_step": units, "parallelism": f"trials sharded over {world} GPU(s)"},

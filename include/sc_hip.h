@@ -61,7 +61,7 @@
 extern "C" {
 #endif
 
-#define SC_ABI_VERSION 4
+#define SC_ABI_VERSION 5
 
 /* error codes */
 #define SC_OK 0
@@ -277,6 +277,16 @@ int64_t sc_planes_row_bytes(int64_t n_signals);
  * max_k sum_n |tapers[k][n]| (the tapers as passed to stage A, i.e. / fs); d_work: 4 C bytes of device scratch */
 int sc_planes_scales_from_series_f32(const float* d_x, int64_t T, int64_t R, int64_t C, double taper_abs_sum,
                                      float* d_scale, void* d_work, void* stream);
+/* The same pass with the DYNAMIC RANGE of the series beside the scales: *d_range (device float) = max over the channels of
+ * max|x| / mean|x| (finite samples).  One scale per channel comes from its largest sample, so an artefact thousands of times the
+ * typical amplitude pushes the typical coefficient's trailing f16 piece into the subnormals (absolute error 2^-25 in scaled
+ * units): beyond SC_PLANES_MAX_RANGE the 22 bits of the format are not delivered for the quiet windows of that channel and the
+ * host keeps complex64 spectra (sc_multitaper_fft_f32) -- the planes format is a device detail, never a precision trade.
+ * d_work: sc_planes_scales_work_bytes(T * R, C) bytes. */
+#define SC_PLANES_MAX_RANGE 4096.0f
+int64_t sc_planes_scales_work_bytes(int64_t n_rows, int64_t width);
+int sc_planes_scales_range_f32(const float* d_x, int64_t T, int64_t R, int64_t C, double taper_abs_sum, float* d_scale,
+                               void* d_work, int64_t work_bytes, float* d_range, void* stream);
 /* scales from the largest |Re|, |Im| of dense complex64 rows [n_rows][C] */
 int sc_planes_scales_from_spectra_f32(const void* d_X /*float2*/, int64_t n_rows, int64_t C, float* d_scale, void* d_work,
                                       void* stream);
@@ -307,6 +317,10 @@ int sc_fused2_csm_absim_parts_f32(const void* d_P, const sc_spectra_desc* desc, 
                                   float* d_accum, void* d_workspace, int64_t workspace_bytes, int* n_parts, void* stream);
 /* shader clock (GHz) the device sustained during the last sc_fused2_csm_absim_f32 launch (in-kernel cycle / real-time counters) */
 int sc_debug_fused2_clock(double* ghz);
+/* The diagnostic switches of the library (SC_FUSED_DEBUG, SC_FUSED_SPLIT, SC_MTFFT_DEBUG, SC_WILSON_FFT, ...: ablation tools and
+ * the tests of alternative kernels) are environment variables read once when the library is loaded; a host that changes one
+ * afterwards calls this to have them read again.  No reference counterpart (the reference has no native code). */
+int sc_debug_reload_env(void);
 int sc_fused2_csm_absim_f32(const void* d_P, const sc_spectra_desc* desc, const float* d_scale, uint32_t planes,
                             float* d_accum, void* d_workspace, int64_t workspace_bytes, void* stream);
 

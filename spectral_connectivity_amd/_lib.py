@@ -21,7 +21,7 @@ from . import _build
 c_int64_p = POINTER(c_int64)
 
 # ---- constants mirrored from include/sc_hip.h -------------------------------------------
-SC_ABI_VERSION = 4
+SC_ABI_VERSION = 5
 GRANGER_KEEP_OUTPUT = 1
 DETREND = {None: 0, "constant": 1, "c": 1, "linear": 2, "l": 2}
 MVAR_DTF, MVAR_DC, MVAR_PDC, MVAR_GPDC, MVAR_DDTF, MVAR_TRANSFER, MVAR_COEFFICIENTS, MVAR_NOISE_COVARIANCE = range(8)
@@ -104,11 +104,14 @@ SYMBOLS = {
     "sc_multitaper_fft_planes_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64,
                                              c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sc_planes_scales_from_series_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_double, c_void_p, c_void_p, c_void_p]),
+    "sc_planes_scales_work_bytes": (c_int64, [c_int64, c_int64]),
+    "sc_planes_scales_range_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_double, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "sc_planes_scales_from_spectra_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "sc_planes_from_spectra_f32": (c_int, [c_void_p, POINTER(SpectraDesc), c_void_p, c_void_p, c_void_p]),
     "sc_spectra_from_planes_f32": (c_int, [c_void_p, POINTER(SpectraDesc), c_void_p, c_void_p, c_void_p]),
     "sc_fused2_supported": (c_int, [POINTER(SpectraDesc), c_uint32]),
     "sc_debug_fused2_clock": (c_int, [POINTER(c_double)]),
+    "sc_debug_reload_env": (c_int, []),
     "sc_fused2_csm_absim_parts_f32": (c_int, [c_void_p, POINTER(SpectraDesc), c_void_p, c_uint32, c_void_p, c_void_p, c_int64,
                                               POINTER(c_int), c_void_p]),
     "sc_fused2_csm_absim_f32": (c_int, [c_void_p, POINTER(SpectraDesc), c_void_p, c_uint32, c_void_p, c_void_p, c_int64,
@@ -220,6 +223,22 @@ def check(status, what=""):
         raise HipEngineError(f"{what} failed with status {status}: {msg.decode() if msg else ''}")
 
 
+def reload_debug_env():
+    """The library reads its diagnostic switches (SC_FUSED_DEBUG, SC_FUSED_SPLIT, SC_WILSON_FFT, ...) from the environment once,
+    when it is loaded; tools and tests that change one afterwards call this (no-op while the library is not loaded)."""
+    if _lib is not None:
+        _lib.sc_debug_reload_env()
+
+
+def set_debug_env(name, value):
+    """os.environ[name] = value (None: unset) and have the library see it."""
+    if value is None:
+        os.environ.pop(name, None)
+    else:
+        os.environ[name] = str(value)
+    reload_debug_env()
+
+
 def device_count():
     n = c_int(0)
     check(_handle().sc_device_count(byref(n)), "sc_device_count")
@@ -286,25 +305,28 @@ PLANES_FORMAT_FAMILIES = (PLANE_CSM, PLANE_CSM | PLANE_ABS_IM, PLANE_CSM | PLANE
                           PLANE_SIGN_IM)   # what sc_fused2.hip accumulates
 
 
+PLANES_FORMAT_MIN_CHANNELS = 44
+PLANES_MAX_RANGE = 4096.0       # SC_PLANES_MAX_RANGE of include/sc_hip.h: largest max|x| / mean|x| of a channel the format is used for
+
+
 def planes_format_applies(n_window, n_fft, n_alloc, planes_hint, spectra_bytes=None):
     """Does stage A write the planes format for a caller that will ask for the accumulator families ``planes_hint``?
-    ``spectra_bytes``: size of the complex64 spectra of the request, when the caller knows it."""
+    ``spectra_bytes``: size of the complex64 spectra of the request, when the caller knows it.
+
+    Round 5: for every family sc_fused2.hip accumulates the answer depends on the SHAPE of the request alone -- not on which of
+    those families is asked for first -- so that a ``Connectivity`` takes the same kernels whatever the order of the calls (the
+    reference computes every measure from the same coefficients, connectivity.py:463-526).  The format is taken from 44 signals on
+    (where CSM + |Im s|, the BASELINE pair coherence + wPLI, first wins: profiles/r04_shape_sweep.txt; at 44 ... 60 signals the
+    (Im s)^2 pass alone would be 0.7 ms faster on complex64, at 130 signals CSM alone 0.7 ms -- the price of one path) for requests
+    of at least 256 MB of spectra (a few tens of MB are three short launches either way and the scale pass would only add two).
+    Families outside the format (the unit-phasor plane of PLV / PPC) and callers without a hint (Granger, canonical and global
+    coherence: CSM of every bin, window lengths beyond the format) keep complex64."""
     if planes_hint not in PLANES_FORMAT_FAMILIES or os.environ.get("SC_PLANES_FORMAT", "1") == "0":
         return False
-    # Below these channel counts the float32 VALU kernel of sc_fused.hip on complex64 spectra is the faster path (it is HBM-bound
-    # there): crossovers measured at the cfg3 volume (profiles/r04_shape_sweep.txt), with the 0.5 ms the format costs stage A
-    # charged to the planes side
-    lo = {PLANE_CSM: 32, PLANE_CSM | PLANE_ABS_IM: 44, PLANE_CSM | PLANE_ABS_IM | PLANE_IM_SQ: 60,
-          PLANE_SIGN_IM: 44}[planes_hint]
+    lo = PLANES_FORMAT_MIN_CHANNELS
     forced = os.environ.get("SC_PLANES_MIN_CHANNELS")               # (tests: the format from this many channels on, whatever the size)
     if forced is not None:
         lo = int(forced)
-    else:
-        # CSM alone gains 1 ms of stage B up to 64 channels (the 64-observation chunks) but only 0.2-0.5 ms beyond, which is what the
-        # format costs stage A; and a request of a few tens of MB is three short launches either way -- the scale pre-pass would
-        # only add two (cfg2: 0.110 -> 0.132 ms with the format, cfg5's CSM at 256 channels 7.25 -> 7.47)
-        if planes_hint == PLANE_CSM and n_alloc > 64:
-            return False
-        if spectra_bytes is not None and spectra_bytes < (256 << 20):
-            return False
+    elif spectra_bytes is not None and spectra_bytes < (256 << 20):
+        return False
     return lo <= n_alloc <= 256 and bool(_handle().sc_multitaper_fft_planes_supported(n_window, n_fft, n_alloc))

@@ -38,9 +38,9 @@ class _PendingSpectra:
 
     def __init__(self, multitaper, precision):
         self.multitaper, self.precision = multitaper, precision
-        ts = np.asarray(multitaper.time_series)
-        self.shape5 = (int(multitaper.n_time_windows), int(ts.shape[1]), int(multitaper.n_tapers),
-                       int(multitaper.n_fft_samples), int(ts.shape[2]))
+        shape = multitaper.time_series.shape
+        self.shape5 = (int(multitaper.n_time_windows), int(shape[1]), int(multitaper.n_tapers),
+                       int(multitaper.n_fft_samples), int(shape[2]))
 
 
 class Connectivity:
@@ -172,10 +172,27 @@ class Connectivity:
         return int(np.prod([self._shape5[a] for a in EXPECTATION_AXES[self.expectation_type]]))
 
     # ---- device plumbing -----------------------------------------------------------------
+    def _planes_request_ok(self, planes):
+        """Would the planes-format stage B (sc_fused2.hip) take ``planes`` with this object's expectation type and shape?  Asked
+        BEFORE a pending transform picks the device format of the spectra: its observations must form one run of rows (every
+        expectation type but "time_tapers" with several trials)."""
+        from ctypes import byref
+        from ._lib import SpectraDesc
+        W, R, K, N, C = (int(v) for v in self._shape5)
+        C_alloc = C + 1 if (C % 2 and C + 1 <= 256) else C
+        axes = EXPECTATION_AXES[self.expectation_type]
+        d = SpectraDesc(n_freq=N // 2 + 1, n_windows=W, n_trials=R, n_tapers=K, n_signals=C_alloc, stride_freq=W * R * K * C_alloc,
+                        stride_window=R * K * C_alloc, stride_trial=K * C_alloc, stride_taper=C_alloc, reduce_window=int(0 in axes),
+                        reduce_trial=int(1 in axes), reduce_taper=int(2 in axes), reserved=0)
+        return bool(_lib.load().sc_fused2_supported(byref(d), planes))
+
     def _device(self, planes_hint=None):
-        """The device spectra; ``planes_hint``: the accumulator families about to be requested (a pending transform writes
-        the format that suits them)."""
+        """The device spectra; ``planes_hint``: the accumulator families about to be requested.  A pending transform writes the
+        planes format when the SHAPE qualifies for it and the hint is one of the families its kernels serve -- whichever
+        (_lib.planes_format_applies) -- and this object's expectation type can run on it."""
         if self._spectra is None and self._pending is not None:
+            if planes_hint is not None and not (planes_hint in _lib.PLANES_FORMAT_FAMILIES and self._planes_request_ok(planes_hint)):
+                planes_hint = None
             self._spectra = self._pending.multitaper.device_spectra(precision=self._pending.precision, planes_hint=planes_hint)
             self._pending = None
         if self._spectra is None:
@@ -196,17 +213,28 @@ class Connectivity:
                 return have, rec
         sp = self._device(planes_hint=planes)
         have = None
-        if sp.f64 and self._reduce_over_ranks.__func__ is Connectivity._reduce_over_ranks:
+        single = self._reduce_over_ranks.__func__ is Connectivity._reduce_over_ranks
+        if sp.f64 and single:
             # float64 engine, single process: families a cached record already holds are copied, not recomputed
             best = max((h for h in self._accum_cache if isinstance(h, int) and h & planes), key=lambda h: bin(h & planes).count("1"),
                        default=None)
             if best is not None:
                 planes |= best                     # the new record supersedes the old one
                 have = (best, self._accum_cache[best][0])
-        accum, n_obs = engine.accumulate(sp, self.expectation_type, planes, n_freq=self._n_freq, have=have)
+        from . import options
+        if (sp.P is not None and planes == _lib.PLANE_CSM and options.anticipate_phase_lag
+                and self._planes_request_ok(_lib.PLANE_CSM | _lib.PLANE_ABS_IM)):
+            # spectra held as f16 pieces: the launch that sums the cross-spectra also sums |Im s| (options.anticipate_phase_lag) --
+            # coherence followed by wPLI, the BASELINE pair, is then ONE pass over the spectra whichever comes first
+            planes = _lib.PLANE_CSM | _lib.PLANE_ABS_IM
+        # single process, float32 engine on the planes format: the split-bin partial records stay unfolded (a 3-D tensor) and
+        # the epilogue sums them while it reads -- the path bench.py times
+        accum, n_obs = engine.accumulate(sp, self.expectation_type, planes, n_freq=self._n_freq, have=have, fold=not single)
         accum = self._reduce_over_ranks(accum)
         if have is not None:
             del self._accum_cache[have[0]]
+        for old in [h for h in self._accum_cache if isinstance(h, int) and h & planes == h]:
+            del self._accum_cache[old]              # a record the new one covers: its memory can go
         self._accum_cache[planes] = (accum, n_obs)
         return planes, (accum, n_obs)
 

@@ -1,5 +1,6 @@
 // sc_api.hip -- library housekeeping, rocFFT plans, accumulator layout.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 #include <rocfft/rocfft.h>
 #include "sc_common.h"
@@ -12,6 +13,24 @@ void sc_set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+
+// ---- diagnostic switches: a snapshot of the environment (sc_common.h) ------------------------------------------------------
+static const char* const g_switch_names[SC_SW_COUNT] = {
+    "SC_FUSED_DEBUG", "SC_FUSED2_TERMS", "SC_FUSED_SPLIT", "SC_FUSED_NO_SMALL", "SC_MTFFT_DEBUG", "SC_MTFFT_WIDE", "SC_MTFFT_F64",
+    "SC_F64_SPLIT", "SC_F64_OC", "SC_F64_NO_FORK", "SC_F64_NO_BLOCK", "SC_WILSON_FFT", "SC_GLOBAL_EIG", "SC_GLOBAL_NT256",
+    "SC_GRANGER_KERNEL"};
+static char g_switch_val[SC_SW_COUNT][32];
+static bool g_switch_set[SC_SW_COUNT];
+extern "C" int sc_debug_reload_env(void) {
+    for (int i = 0; i < SC_SW_COUNT; ++i) {
+        const char* v = getenv(g_switch_names[i]);
+        g_switch_set[i] = v != nullptr;
+        if (v) { strncpy(g_switch_val[i], v, sizeof(g_switch_val[i]) - 1); g_switch_val[i][sizeof(g_switch_val[i]) - 1] = 0; }
+    }
+    return SC_OK;
+}
+static const int g_switches_loaded = sc_debug_reload_env();          // when the library is loaded
+const char* sc_switch(int id) { return (id >= 0 && id < SC_SW_COUNT && g_switch_set[id]) ? g_switch_val[id] : nullptr; }
 
 extern "C" int sc_abi_version(void) { return SC_ABI_VERSION; }
 extern "C" const char* sc_last_error(void) { return g_err; }

@@ -17,8 +17,29 @@
 #include <dlfcn.h>
 #include <cstring>
 #include <mutex>
-#include <rccl/rccl.h>
 #include "sc_common.h"
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#else
+// Built without RCCL's headers: the handful of declarations the run-time lookup needs (the values are RCCL's public ABI);
+// without librccl.so.1 at run time every entry point returns SC_EUNSUPPORTED either way.
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclFloat = 7 } ncclDataType_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+ncclResult_t ncclGetUniqueId(ncclUniqueId*);
+ncclResult_t ncclCommInitRank(ncclComm_t*, int, ncclUniqueId, int);
+ncclResult_t ncclCommDestroy(ncclComm_t);
+ncclResult_t ncclAllReduce(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+ncclResult_t ncclSend(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+ncclResult_t ncclRecv(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+ncclResult_t ncclGroupStart(void);
+ncclResult_t ncclGroupEnd(void);
+const char* ncclGetErrorString(ncclResult_t);
+}
+#endif
 
 namespace {
 struct RcclApi {
@@ -133,12 +154,20 @@ extern "C" int sc_comm_exchange_blocks_f32(sc_comm* c, const float* d_send, floa
     SC_NEED_RCCL();
     hipStream_t s = (hipStream_t)stream;
     SC_CHECK_RCCL(api.GroupStart());
-    for (int peer = 0; peer < c->n_ranks; ++peer) {
+    // Inside the bracket nothing returns: a failed call is remembered (the first one), the group is always closed -- an open group
+    // would swallow every later call on this communicator -- and the error is reported after ncclGroupEnd.
+    ncclResult_t first = ncclSuccess;
+    const char* what = "";
+    for (int peer = 0; peer < c->n_ranks && first == ncclSuccess; ++peer) {
         if (peer == c->rank) continue;
-        SC_CHECK_RCCL(api.Send(d_send + (int64_t)peer * block, (size_t)block, ncclFloat, peer, c->comm, s));
-        SC_CHECK_RCCL(api.Recv(d_recv + (int64_t)peer * block, (size_t)block, ncclFloat, peer, c->comm, s));
+        first = api.Send(d_send + (int64_t)peer * block, (size_t)block, ncclFloat, peer, c->comm, s);
+        if (first != ncclSuccess) { what = "ncclSend"; break; }
+        first = api.Recv(d_recv + (int64_t)peer * block, (size_t)block, ncclFloat, peer, c->comm, s);
+        if (first != ncclSuccess) what = "ncclRecv";
     }
-    SC_CHECK_RCCL(api.GroupEnd());
+    const ncclResult_t end = api.GroupEnd();
+    if (first != ncclSuccess) { sc_set_error("%s failed inside the exchange group: %s", what, api.GetErrorString(first)); return SC_EHIP; }
+    SC_CHECK_RCCL(end);
     SC_CHECK_HIP(hipMemcpyAsync(d_recv + (int64_t)c->rank * block, d_send + (int64_t)c->rank * block, (size_t)block * sizeof(float),
                                 hipMemcpyDeviceToDevice, s));
     return SC_OK;
@@ -152,9 +181,12 @@ extern "C" int sc_comm_gather_f32(sc_comm* c, const float* d_send, float* d_recv
     hipStream_t s = (hipStream_t)stream;
     if (c->rank == root) {
         SC_CHECK_RCCL(api.GroupStart());
-        for (int peer = 0; peer < c->n_ranks; ++peer)
-            if (peer != root) SC_CHECK_RCCL(api.Recv(d_recv + (int64_t)peer * n, (size_t)n, ncclFloat, peer, c->comm, s));
-        SC_CHECK_RCCL(api.GroupEnd());
+        ncclResult_t first = ncclSuccess;                       // (as in sc_comm_exchange_blocks_f32: the group is always closed)
+        for (int peer = 0; peer < c->n_ranks && first == ncclSuccess; ++peer)
+            if (peer != root) first = api.Recv(d_recv + (int64_t)peer * n, (size_t)n, ncclFloat, peer, c->comm, s);
+        const ncclResult_t end = api.GroupEnd();
+        if (first != ncclSuccess) { sc_set_error("ncclRecv failed inside the gather group: %s", api.GetErrorString(first)); return SC_EHIP; }
+        SC_CHECK_RCCL(end);
         SC_CHECK_HIP(hipMemcpyAsync(d_recv + (int64_t)root * n, d_send, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, s));
     } else {
         SC_CHECK_RCCL(api.Send(d_send, (size_t)n, ncclFloat, root, c->comm, s));

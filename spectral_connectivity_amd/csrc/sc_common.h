@@ -7,6 +7,16 @@
 
 void sc_set_error(const char* fmt, ...);
 
+// Diagnostic switches (ablation / A-B tools, tests of alternative kernels): environment variables read ONCE when the library is
+// loaded and again whenever the host calls sc_debug_reload_env() -- no getenv on a launch path.  sc_switch(id) is the value
+// string or nullptr when the variable is unset.
+enum ScSwitch {
+    SC_SW_FUSED_DEBUG, SC_SW_FUSED2_TERMS, SC_SW_FUSED_SPLIT, SC_SW_FUSED_NO_SMALL, SC_SW_MTFFT_DEBUG, SC_SW_MTFFT_WIDE,
+    SC_SW_MTFFT_F64, SC_SW_F64_SPLIT, SC_SW_F64_OC, SC_SW_F64_NO_FORK, SC_SW_F64_NO_BLOCK, SC_SW_WILSON_FFT, SC_SW_GLOBAL_EIG,
+    SC_SW_GLOBAL_NT256, SC_SW_GRANGER_KERNEL, SC_SW_COUNT
+};
+const char* sc_switch(int id);
+
 // sc_api.hip: Z[rows][F] -> X[f][b_off + row] (X has `batch` columns), imaginary part of rows 0 and nyquist_row zeroed
 int sc_internal_rows_to_bins(const void* d_Z, void* d_X, int64_t rows, int64_t F, int64_t batch, int64_t b_off,
                              int64_t nyquist_row, hipStream_t st);

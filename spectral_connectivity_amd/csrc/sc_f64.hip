@@ -510,7 +510,7 @@ static void f64_combine(const F64Args& a, int plane0, int n_planes, hipStream_t 
 // parts per bin for W workgroups per part on `slots` resident workgroups: the S with the fewest rounds / S, at least 16
 // staged chunks per part
 static int f64_pick_split(int64_t W, int n_obs, int rows_per_chunk) {
-    const char* e = getenv("SC_F64_SPLIT");
+    const char* e = sc_switch(SC_SW_F64_SPLIT);
     if (e && atoi(e) >= 1 && atoi(e) <= 16) return atoi(e);
     int dev = 0, n_cu = 256;
     if (hipGetDevice(&dev) == hipSuccess) {
@@ -546,7 +546,7 @@ template <int MAX_SLOTS, bool UNIT = false>
 static int launch_csm_f64(F64Args a, hipStream_t st) {
     // observation rows per staged chunk: 8 registers of staging, two workgroups per CU.  (SC_F64_OC=16, diagnostic: half
     // the barriers, but 256 registers with 24 spilled and one workgroup per CU -- 11.2 against 8.8 ms at cfg3.)
-    const char* e = getenv("SC_F64_OC");
+    const char* e = sc_switch(SC_SW_F64_OC);
     if (e && atoi(e) == 16) return launch_csm_f64_oc<MAX_SLOTS, UNIT, 16>(a, st);
     return launch_csm_f64_oc<MAX_SLOTS, UNIT, 8>(a, st);
 }
@@ -601,7 +601,7 @@ extern "C" int sc_accumulate_f64(const void* d_X, const sc_spectra_desc* desc, u
     // One side stream per DEVICE (created under a lock on the device that is current at the call), and a fresh event
     // pair per CALL: two host threads, or two devices, never share an event -- a shared pair would let one call's join
     // wait on the other's record.
-    const bool fork = (which & SC_PLANE_CSM) && (which & ~SC_PLANE_CSM) && a.C >= 48 && !getenv("SC_F64_NO_FORK");
+    const bool fork = (which & SC_PLANE_CSM) && (which & ~SC_PLANE_CSM) && a.C >= 48 && !sc_switch(SC_SW_F64_NO_FORK);
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     struct EventPair {            // destroyed when the call returns (hipEventDestroy defers the release past pending work)
@@ -630,7 +630,7 @@ extern "C" int sc_accumulate_f64(const void* d_X, const sc_spectra_desc* desc, u
     }
     // observations of a bin split over several workgroups (F64Args::n_split): partial records in a stream-ordered scratch
     // of this call, allocated BEFORE the fork (both streams write disjoint planes of it) and released after the join
-    const bool block_planes = a.C >= 48 && !getenv("SC_F64_NO_BLOCK") && (which & (SC_PLANE_ABS_IM | SC_PLANE_IM_SQ | SC_PLANE_SIGN_IM));
+    const bool block_planes = a.C >= 48 && !sc_switch(SC_SW_F64_NO_BLOCK) && (which & (SC_PLANE_ABS_IM | SC_PLANE_IM_SQ | SC_PLANE_SIGN_IM));
     double* ws = nullptr;
     struct ScratchGuard {         // the scratch goes back to the pool on EVERY way out of this call, behind the work queued on `s`
         double*& p;
@@ -666,7 +666,7 @@ extern "C" int sc_accumulate_f64(const void* d_X, const sc_spectra_desc* desc, u
     uint32_t w = rc ? 0u : (which & ~SC_PLANE_CSM);
     st = st_nl;
     do {        // (one exit: the side stream is joined below whether or not a launch failed)
-        if (a.C >= 48 && !getenv("SC_F64_NO_BLOCK")) {      // 64 x 64 blocks, one plane per launch (see nonlinear_f64_block_kernel)
+        if (a.C >= 48 && !sc_switch(SC_SW_F64_NO_BLOCK)) {      // 64 x 64 blocks, one plane per launch (see nonlinear_f64_block_kernel)
             if (w & SC_PLANE_ABS_IM) { if ((rc = launch_nl_f64_block<SC_PLANE_ABS_IM>(a, st))) break; w &= ~SC_PLANE_ABS_IM; }
             if (w & SC_PLANE_IM_SQ) { if ((rc = launch_nl_f64_block<SC_PLANE_IM_SQ>(a, st))) break; w &= ~SC_PLANE_IM_SQ; }
             if (w & SC_PLANE_SIGN_IM) { if ((rc = launch_nl_f64_block<SC_PLANE_SIGN_IM>(a, st))) break; w &= ~SC_PLANE_SIGN_IM; }

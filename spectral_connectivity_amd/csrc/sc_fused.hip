@@ -862,7 +862,7 @@ extern "C" int sc_fused_supported(int64_t n_signals) {
 // work).  Splitting every bin's observations over S workgroups shortens the rounds; pick the S
 // with the fewest (rounds / S), keeping >= 16 chunks per part (S <= 24: few bins with many observations).
 int sc_internal_fused_pick_split(int n_bins, int n_obs) {
-    const char* e = getenv("SC_FUSED_SPLIT");
+    const char* e = sc_switch(SC_SW_FUSED_SPLIT);
     const int nc = (n_obs + FU_OC - 1) / FU_OC;
     static int cu_of_device[64] = {0};          // compute units per device, queried once
     int dev = 0, n_cu = 256;
@@ -1044,7 +1044,7 @@ static int fused_run(const void* d_X, const sc_spectra_desc* desc, uint32_t plan
     a.st.RS = sc_row_stride(a.st.CP);
     a.st.n_obs = ax.n_obs;
     {
-        const char* dbg = getenv("SC_FUSED_DEBUG");
+        const char* dbg = sc_switch(SC_SW_FUSED_DEBUG);
         a.debug_skip = dbg ? atoi(dbg) : 0;
     }
     // as many parts per bin as the workspace allows (none: one workgroup per bin)
@@ -1056,7 +1056,7 @@ static int fused_run(const void* d_X, const sc_spectra_desc* desc, uint32_t plan
     a.n_split = S;
     a.ws = (float*)d_workspace;
     hipStream_t s = (hipStream_t)stream;
-    const char* no_small = getenv("SC_FUSED_NO_SMALL");       // diagnostic: every shape through the matrix-core kernel
+    const char* no_small = sc_switch(SC_SW_FUSED_NO_SMALL);       // diagnostic: every shape through the matrix-core kernel
     if (!(no_small && atoi(no_small)) &&
         (small_ok(ax, a.abs_plane >= 0) || (a.sq_plane >= 0 && small_ok_sq(ax)) || (mode == FU_MODE_SIGN && small_ok_sign(ax))))
         return launch_small(a, unit, s);

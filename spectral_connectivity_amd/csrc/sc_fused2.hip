@@ -51,6 +51,7 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 #define F2_LDS (F2_SCALE_OFF + 512)
 #define F2_ROW_TILE 256               // bytes of one 32-channel tile of an observation row in HBM (4 planes x 64 B)
 
+extern "C" int64_t sc_planes_scales_work_bytes(int64_t n_rows, int64_t width);
 extern "C" int64_t sc_planes_row_bytes(int64_t n_signals) { return (int64_t)F2_ROW_TILE * ((n_signals + 31) / 32); }
 
 __device__ __forceinline__ unsigned f2_pack(float lo, float hi) {        // two f16 (round to nearest) in one dword
@@ -80,8 +81,11 @@ __device__ __forceinline__ float planes_mag(float v) {
     const float a = fabsf(v);
     return a <= 3.4028234e38f ? a : 0.f;
 }
-__global__ void __launch_bounds__(256) planes_absmax_kernel(const float* x, int64_t n_rows, int width, int comps, unsigned* mx) {
+// part: per-block sums of |x| per column, [gridDim.x][width] (or nullptr): the scale kernel adds them in block order -- a
+// deterministic mean |x| per channel, against which the largest sample is judged (the dynamic-range guard, see planes_scale_kernel)
+__global__ void __launch_bounds__(256) planes_absmax_kernel(const float* x, int64_t n_rows, int width, int comps, unsigned* mx, float* part) {
     __shared__ unsigned red[1024];
+    __shared__ float sred[1024];
     const int64_t rows_per_block = (n_rows + gridDim.x - 1) / gridDim.x;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = r0 + rows_per_block < n_rows ? r0 + rows_per_block : n_rows;
     const int tid = threadIdx.x;
@@ -91,7 +95,7 @@ __global__ void __launch_bounds__(256) planes_absmax_kernel(const float* x, int6
         const int cq = tid % q, ro = tid / q;
         for (int i = tid; i < width; i += 256) red[i] = 0u;
         __syncthreads();
-        float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 m = make_float4(0.f, 0.f, 0.f, 0.f), sm = m;
         if (ro < rows_per_step) {
             int64_t r = r0 + ro;
             for (; r + 3 * rows_per_step < r1; r += 4 * rows_per_step) {
@@ -100,32 +104,49 @@ __global__ void __launch_bounds__(256) planes_absmax_kernel(const float* x, int6
                 for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(x + (r + (int64_t)u * rows_per_step) * width + 4 * cq);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    m.x = fmaxf(m.x, planes_mag(v[u].x)); m.y = fmaxf(m.y, planes_mag(v[u].y));
-                    m.z = fmaxf(m.z, planes_mag(v[u].z)); m.w = fmaxf(m.w, planes_mag(v[u].w));
+                    const float a0 = planes_mag(v[u].x), a1 = planes_mag(v[u].y), a2 = planes_mag(v[u].z), a3 = planes_mag(v[u].w);
+                    m.x = fmaxf(m.x, a0); m.y = fmaxf(m.y, a1); m.z = fmaxf(m.z, a2); m.w = fmaxf(m.w, a3);
+                    sm.x += a0; sm.y += a1; sm.z += a2; sm.w += a3;
                 }
             }
             for (; r < r1; r += rows_per_step) {
                 const float4 v = *reinterpret_cast<const float4*>(x + r * width + 4 * cq);
-                m.x = fmaxf(m.x, planes_mag(v.x)); m.y = fmaxf(m.y, planes_mag(v.y)); m.z = fmaxf(m.z, planes_mag(v.z)); m.w = fmaxf(m.w, planes_mag(v.w));
+                const float a0 = planes_mag(v.x), a1 = planes_mag(v.y), a2 = planes_mag(v.z), a3 = planes_mag(v.w);
+                m.x = fmaxf(m.x, a0); m.y = fmaxf(m.y, a1); m.z = fmaxf(m.z, a2); m.w = fmaxf(m.w, a3);
+                sm.x += a0; sm.y += a1; sm.z += a2; sm.w += a3;
             }
             atomicMax(red + 4 * cq, __float_as_uint(m.x)); atomicMax(red + 4 * cq + 1, __float_as_uint(m.y));
             atomicMax(red + 4 * cq + 2, __float_as_uint(m.z)); atomicMax(red + 4 * cq + 3, __float_as_uint(m.w));
+            *reinterpret_cast<float4*>(sred + ro * width + 4 * cq) = sm;          // rows_per_step * width <= 1024 floats
         }
         __syncthreads();
-        for (int col = tid; col < width; col += 256)
+        for (int col = tid; col < width; col += 256) {
             if (red[col]) atomicMax(mx + col / comps, red[col]);        // non-negative floats order like unsigned
+            if (part) {
+                float t = 0.f;
+                for (int k = 0; k < rows_per_step; ++k) t += sred[k * width + col];          // fixed order
+                part[(int64_t)blockIdx.x * width + col] = t;
+            }
+        }
         return;
     }
     for (int col = tid; col < width; col += 256) {
-        float m = 0.f;
-        for (int64_t r = r0; r < r1; ++r) m = fmaxf(m, planes_mag(x[r * width + col]));
+        float m = 0.f, t = 0.f;
+        for (int64_t r = r0; r < r1; ++r) { const float a = planes_mag(x[r * width + col]); m = fmaxf(m, a); t += a; }
         if (m > 0.f) atomicMax(mx + col / comps, __float_as_uint(m));
+        if (part) part[(int64_t)blockIdx.x * width + col] = t;
     }
 }
-__global__ void planes_scale_kernel(const unsigned* mx, int C, float factor, float* scale) {
+// range (optional): mx[C] is followed by one word that receives the largest max|x| / mean|x| over the channels (bit pattern of
+// a non-negative float).  A channel whose largest sample is thousands of times its typical one pushes the typical coefficient's
+// trailing f16 piece into the subnormals (sc_hip.h: sc_planes_scales_range_f32); the host reads the ratio and keeps complex64
+// spectra beyond SC_PLANES_MAX_RANGE.
+__global__ void planes_scale_kernel(unsigned* mx, int C, float factor, float* scale, const float* part, int n_blocks, int comps,
+                                    double n_samples, int want_range) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const float b = __uint_as_float(mx[c]) * factor;
+    const float top = __uint_as_float(mx[c]);
+    const float b = top * factor;
     float s = 1.f;
     if (b > 0.f && b < 3.0e38f) {
         int e;
@@ -136,28 +157,60 @@ __global__ void planes_scale_kernel(const unsigned* mx, int C, float factor, flo
     }
     scale[c] = s;
     scale[C + c] = 1.f / s;
+    if (want_range && part) {
+        double t = 0.0;
+        const int width = C * comps;
+        for (int blk = 0; blk < n_blocks; ++blk)
+            for (int k = 0; k < comps; ++k) t += (double)part[(int64_t)blk * width + c * comps + k];
+        const double mean = t / n_samples;
+        const float ratio = (mean > 0.0 && top > 0.f) ? (float)((double)top / mean) : 0.f;
+        atomicMax(mx + C, __float_as_uint(ratio));
+    }
 }
-static int planes_scales(const float* d_x, int64_t n_rows, int C, int comps, float factor, float* d_scale, void* d_work, void* stream) {
+static int planes_scales(const float* d_x, int64_t n_rows, int C, int comps, float factor, float* d_scale, void* d_work, int64_t work_bytes,
+                         float* d_range, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     unsigned* mx = (unsigned*)d_work;
-    SC_CHECK_HIP(hipMemsetAsync(mx, 0, sizeof(unsigned) * C, s));
     int64_t blocks = n_rows / 128;
     blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
-    hipLaunchKernelGGL(planes_absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, s, d_x, n_rows, C * comps, comps, mx);
-    hipLaunchKernelGGL(planes_scale_kernel, dim3((C + 63) / 64), dim3(64), 0, s, mx, C, factor, d_scale);
+    const int64_t head = ((int64_t)C + 1 + 3) / 4 * 4;                       // max bits [C], the ratio word, padded to 16 bytes
+    float* part = nullptr;
+    if (d_range) {
+        SC_REQUIRE(work_bytes >= sc_planes_scales_work_bytes(n_rows, (int64_t)C * comps), "work buffer smaller than sc_planes_scales_work_bytes");
+        part = (float*)d_work + head;
+    }
+    SC_CHECK_HIP(hipMemsetAsync(mx, 0, sizeof(unsigned) * (C + (d_range ? 1 : 0)), s));
+    hipLaunchKernelGGL(planes_absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, s, d_x, n_rows, C * comps, comps, mx, part);
+    hipLaunchKernelGGL(planes_scale_kernel, dim3((C + 63) / 64), dim3(64), 0, s, mx, C, factor, d_scale, part, (int)blocks, comps,
+                       (double)n_rows * comps, d_range ? 1 : 0);
+    if (d_range) SC_CHECK_HIP(hipMemcpyAsync(d_range, mx + C, sizeof(float), hipMemcpyDeviceToDevice, s));
     SC_CHECK_HIP(hipGetLastError());
     return SC_OK;
+}
+// bytes of device scratch the range form needs: the per-channel maxima, the ratio word and the per-block column sums
+extern "C" int64_t sc_planes_scales_work_bytes(int64_t n_rows, int64_t width) {
+    int64_t blocks = n_rows / 128;
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    return 4 * ((width + 1 + 3) / 4 * 4) + 4 * blocks * width;
 }
 // d_work: 4 * n_signals bytes of scratch
 extern "C" int sc_planes_scales_from_series_f32(const float* d_x, int64_t T, int64_t R, int64_t C, double taper_abs_sum,
                                                 float* d_scale, void* d_work, void* stream) {
     ScTimed timed_("planes_scales", stream);
     SC_REQUIRE(d_x && d_scale && d_work && T >= 1 && R >= 1 && C >= 1 && taper_abs_sum > 0.0, "bad argument");
-    return planes_scales(d_x, T * R, (int)C, 1, (float)(8.0 * taper_abs_sum), d_scale, d_work, stream);
+    return planes_scales(d_x, T * R, (int)C, 1, (float)(8.0 * taper_abs_sum), d_scale, d_work, 0, nullptr, stream);
+}
+// the same pass, and the dynamic range of the series beside the scales: *d_range (device) = max over channels of
+// max|x| / mean|x|; d_work: sc_planes_scales_work_bytes(T * R, C) bytes
+extern "C" int sc_planes_scales_range_f32(const float* d_x, int64_t T, int64_t R, int64_t C, double taper_abs_sum, float* d_scale,
+                                          void* d_work, int64_t work_bytes, float* d_range, void* stream) {
+    ScTimed timed_("planes_scales", stream);
+    SC_REQUIRE(d_x && d_scale && d_work && d_range && T >= 1 && R >= 1 && C >= 1 && taper_abs_sum > 0.0, "bad argument");
+    return planes_scales(d_x, T * R, (int)C, 1, (float)(8.0 * taper_abs_sum), d_scale, d_work, work_bytes, d_range, stream);
 }
 extern "C" int sc_planes_scales_from_spectra_f32(const void* d_X, int64_t n_rows, int64_t C, float* d_scale, void* d_work, void* stream) {
     SC_REQUIRE(d_X && d_scale && d_work && n_rows >= 1 && C >= 1, "bad argument");
-    return planes_scales((const float*)d_X, n_rows, (int)C, 2, 1.0f, d_scale, d_work, stream);          // dense rows of C complex64
+    return planes_scales((const float*)d_X, n_rows, (int)C, 2, 1.0f, d_scale, d_work, 0, nullptr, stream);          // dense rows of C complex64
 }
 
 // ---- conversions between complex64 spectra and the planes format (uploaded coefficients, consumers of complex64) -------
@@ -844,9 +897,9 @@ static int fused2_run(const void* d_P, const sc_spectra_desc* desc, const float*
     a.inv_scale = d_scale + ax.C;
     f.accum = d_accum;
     {
-        const char* dbg = getenv("SC_FUSED_DEBUG");
+        const char* dbg = sc_switch(SC_SW_FUSED_DEBUG);
         f.debug_skip = dbg ? atoi(dbg) : 0;
-        const char* t4 = getenv("SC_FUSED2_TERMS");
+        const char* t4 = sc_switch(SC_SW_FUSED2_TERMS);
         if (t4) a.terms4 = atoi(t4) == 4 ? 1 : 0;
     }
     int S = sc_internal_fused_pick_split(f.n_bins, ax.n_obs);

@@ -696,7 +696,7 @@ extern "C" int sc_global_coherence_f64(const void* d_accum, int64_t n_groups, in
     a.floats_per_bin = (int64_t)sc_plane_count(planes) * a.n_tiles * SC_TILE_ELEMS;
     a.max_rank = max_rank; a.ascending = ascending; a.n_obs = (double)n_obs;
     const int M = (int)C + ((int)C & 1);
-    const char* eig_env = getenv("SC_GLOBAL_EIG");       // "jacobi": the round-2 kernels beyond 64 signals too (cross-check)
+    const char* eig_env = sc_switch(SC_SW_GLOBAL_EIG);       // "jacobi": the round-2 kernels beyond 64 signals too (cross-check)
     if (C > GC_CMAX && !(eig_env && strcmp(eig_env, "jacobi") == 0)) {
         // Householder tridiagonalisation + bisection + inverse iteration, matrix and work arrays in a scratch of this call
         const int64_t bins = n_groups * N;
@@ -764,7 +764,7 @@ extern "C" int sc_global_coherence_f64(const void* d_accum, int64_t n_groups, in
             auto k = global_coherence_big_kernel<1024>;
             (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL(k, dim3((unsigned)slots), dim3(1024), lds, (hipStream_t)stream, b);
-        } else if (getenv("SC_GLOBAL_NT256")) {      // diagnostic: the round-2 workgroup size
+        } else if (sc_switch(SC_SW_GLOBAL_NT256)) {      // diagnostic: the round-2 workgroup size
             auto k = global_coherence_big_kernel<256>;
             (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL(k, dim3((unsigned)slots), dim3(256), lds, (hipStream_t)stream, b);

@@ -810,7 +810,7 @@ static int launch_mt16_(const MtArgs& a_in, hipStream_t stream) {
     MtArgs a = a_in;
     const size_t one = lds(TPF <= 64 ? 2 : 1, a.L), all = lds(a.K, a.L);
     a.kh = (all <= cu_lds && cu_lds / all == cu_lds / one) ? a.K : 1;
-    { const char* d = getenv("SC_MTFFT_DEBUG"); a.dbg = d ? atoi(d) : 0; }
+    { const char* d = sc_switch(SC_SW_MTFFT_DEBUG); a.dbg = d ? atoi(d) : 0; }
     const size_t shmem = a.kh == a.K ? all : one;
     auto k = mtfft16_kernel<LOG2N, THREADS, PL>;
     if constexpr (LOG2N < 11) SC_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
@@ -1397,7 +1397,7 @@ static int launch_mixed(const MtArgs& a, int64_t N, hipStream_t stream) {
 }
 
 static int mt_wide() {
-    const char* e = getenv("SC_MTFFT_WIDE");
+    const char* e = sc_switch(SC_SW_MTFFT_WIDE);
     return e ? atoi(e) : 1;
 }
 
@@ -1437,8 +1437,11 @@ static int mtfft_run(const float* d_x, int64_t T, int64_t R, int64_t C, int64_t 
                          (long long)C, (long long)N);
             return SC_EUNSUPPORTED;
         }
-        // workgroups of 16 channels (512 / 1024 samples) write half a 32-channel tile each: a missing half must read as zeros
-        if (N >= 512 && (C % 32) != 0 && (C % 32) <= 16)
+        // A workgroup writes the CT channels it transforms (CT = 2 * threads / (N / 16): 16 at 512 samples and with the 512-thread
+        // workgroups of 1024, 8 with 256 threads at 1024); where ceil(C / CT) workgroups do not cover the last 32-channel tile the
+        // uncovered part must read as zeros (stage B stages whole tiles)
+        const int64_t threads = (N == 1024 && mt_wide() && C >= 16) ? 512 : 256, ct = 2 * threads / (N / 16);
+        if ((C + ct - 1) / ct * ct < (C + 31) / 32 * 32)
             SC_CHECK_HIP(hipMemsetAsync(d_P, 0, (size_t)((N / 2 + 1) * W * R * K) * (size_t)a.row_bytes, s));
     }
     if ((N & (N - 1)) != 0) return launch_mixed(a, N, s);

@@ -598,7 +598,7 @@ extern "C" int sc_multitaper_fft_f64(const double* d_x, int64_t T, int64_t R, in
     MdArgs m{d_x, d_tapers, (zd*)d_X, (int)T, (int)R, (int)C, (int)L, (int)step, (int)W, (int)K, detrend_type};
     hipStream_t s = (hipStream_t)stream;
     // powers of two: the radix-16 kernel (SC_MTFFT_F64=wave, diagnostic: the wave-per-pair kernel for every length)
-    const char* sel = getenv("SC_MTFFT_F64");
+    const char* sel = sc_switch(SC_SW_MTFFT_F64);
     const bool wave_only = sel && strcmp(sel, "wave") == 0;
     if (!wave_only) {
         switch (N) {

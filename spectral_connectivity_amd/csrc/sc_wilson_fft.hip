@@ -192,7 +192,7 @@ static int wf_launch(void* d_A, const int32_t* d_status, int64_t n_series, int C
 // Lengths the fused kernel takes; SC_WILSON_FFT=rocfft in the environment sends every length to the library path
 // (ablation and the cross-check in tests/).
 bool sc_internal_causal_fft_supported(int64_t N) {
-    const char* e = getenv("SC_WILSON_FFT");
+    const char* e = sc_switch(SC_SW_WILSON_FFT);
     if (e && strcmp(e, "rocfft") == 0) return false;
     return N == 256 || N == 512 || N == 1024 || N == 2048 || N == 4096;
 }

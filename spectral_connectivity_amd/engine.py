@@ -112,6 +112,9 @@ class DeviceSpectra:
         self.n_fft = int(n_fft)
         self.real_input = bool(real_input)   # negative bins are conj mirrors of positive ones
         self.f64 = X is not None and X.dtype == torch.complex128
+        # planes format written by stage A: a device scalar, the largest max|x| / mean|x| over the channels of the series the scales
+        # came from -- the caller that owns the series compares it with _lib.PLANES_MAX_RANGE (Multitaper.device_spectra does)
+        self.range = None
         self.device = X.device if X is not None else P.device
 
     @property
@@ -189,9 +192,12 @@ def multitaper_spectra(x, tapers_over_fs, n_window, n_step, n_fft, n_windows, de
     ``n_signals``: number of real channels when ``x`` already carries the all-zero pad channel of an odd channel count
     (appended on the host before the upload, transforms.Multitaper.device_spectra); a device tensor with an odd channel
     count that arrives unpadded is copied into a padded buffer here (one strided device copy).
-    ``planes_hint``: the accumulator families the caller will ask for first.  CSM (+ |Im s|) of up to 128 signals and a
-    power-of-two window of 64 ... 1024 samples: the spectra are written in the planes format (two f16 pieces per real
-    number, sc_fused2.hip) -- a scan of the series for the channel scales, then the same fused transform.
+    ``planes_hint``: the accumulator families the caller will ask for.  Any family sc_fused2.hip serves, 44 ... 256 signals, a
+    power-of-two window of 64 ... 1024 samples and at least 256 MB of spectra (_lib.planes_format_applies): the spectra are
+    written in the planes format (two f16 pieces per real number) -- a scan of the series for the channel scales, then the same
+    fused transform.  The scan also reports the dynamic range of the series (``DeviceSpectra.range``): one scale per channel
+    serves every window, so the format is meant for series whose largest sample is within _lib.PLANES_MAX_RANGE of the typical
+    one; Multitaper.device_spectra checks and re-runs the transform into complex64 otherwise.
     """
     lib = _lib.load()
     T, R, C_real = x.shape
@@ -213,15 +219,19 @@ def multitaper_spectra(x, tapers_over_fs, n_window, n_step, n_fft, n_windows, de
         row_bytes = int(lib.sc_planes_row_bytes(C))
         P = torch.empty((F * n_windows * R * K * row_bytes,), dtype=torch.uint8, device=x.device)
         scale = torch.empty((2 * C,), dtype=torch.float32, device=x.device)
-        work = torch.empty((C,), dtype=torch.int32, device=x.device)
-        _lib.check(lib.sc_planes_scales_from_series_f32(_ptr(x), T, R, C, _taper_abs_sum(tapers_over_fs), _ptr(scale), _ptr(work),
-                                                        _stream()), "sc_planes_scales_from_series_f32")
+        work_bytes = int(lib.sc_planes_scales_work_bytes(T * R, C))
+        work = torch.empty((work_bytes,), dtype=torch.uint8, device=x.device)
+        rng = torch.empty((1,), dtype=torch.float32, device=x.device)     # max over channels of max|x| / mean|x| (DeviceSpectra.range)
+        _lib.check(lib.sc_planes_scales_range_f32(_ptr(x), T, R, C, _taper_abs_sum(tapers_over_fs), _ptr(scale), _ptr(work), work_bytes,
+                                                  _ptr(rng), _stream()), "sc_planes_scales_range_f32")
         _lib.check(lib.sc_multitaper_fft_planes_f32(_ptr(x), T, R, C, L, n_step, n_windows, n_fft, _ptr(tapers_over_fs), K,
                                                     _lib.DETREND[detrend_type], _ptr(twiddles(n_fft, x.device)), _ptr(scale),
                                                     _ptr(P), _stream()), "sc_multitaper_fft_planes_f32")
         if mark:
             mark("mtfft_fused")
-        return DeviceSpectra(None, (F, n_windows, R, K, C_real), strides, n_fft, real_input=True, C_alloc=C, P=P, scale=scale)
+        sp = DeviceSpectra(None, (F, n_windows, R, K, C_real), strides, n_fft, real_input=True, C_alloc=C, P=P, scale=scale)
+        sp.range = rng
+        return sp
     if use_fused:
         # one kernel: window + detrend + taper + FFT + transposed store (sc_mtfft.hip)
         X = torch.empty((F, n_windows, R, K, C), dtype=torch.complex64, device=x.device)
@@ -351,9 +361,9 @@ def accumulate(spectra, expectation_type, planes, n_freq=None, mark=None, use_fu
     """Stage B: un-normalised accumulator record tensor [n_bins, floats_per_bin] (float32; float64 records from
     complex128 spectra).  ``row_multiple``: see _record_tensor (trial-sharded callers pass the world size).
     ``fold=False`` (planes-format path only; ignored elsewhere): when stage B split every bin over several workgroups, their
-    partial records are NOT summed -- the returned tensor holds part 0 and carries the others (``_sc_parts``) for
-    measure_multi, whose kernel adds them while it reads (one pass and one record round trip less).  Only measure_multi
-    understands such a tensor.
+    partial records are NOT summed -- the result is then ONE 3-D tensor [n_parts, n_bins, floats_per_bin] of its own (the sum
+    over axis 0, in part order, is the record): measure() / measure_multi() add the parts while their kernel reads them (one pass
+    and one record round trip less), fold_parts() gives the 2-D record to any other consumer.
     ``have`` = (planes_old, record_old), float64 engine only: families already accumulated for the same spectra and
     expectation are copied over (a strided device copy) and only the missing ones are computed -- its CSM and
     per-observation planes are separate kernels, so a wPLI after a coherence costs the |Im s| plane alone."""
@@ -379,29 +389,33 @@ def accumulate(spectra, expectation_type, planes, n_freq=None, mark=None, use_fu
         if mark:
             mark("accumulate_f64")
         return accum, n_obs
-    accum = _record_tensor(n_bins, fpb, torch.float32, spectra.device, row_multiple)
+    accum = None
     if spectra.P is not None and use_fused is not False:
         dp = spectra.desc(expectation_type, n_freq, padded=True)
         if lib.sc_fused2_supported(byref(dp), planes):
             # planes format: CSM (+ |Im s|) straight from the f16 pieces stage A wrote (sc_fused2.hip)
             ws_bytes = int(lib.sc_fused_workspace_bytes(byref(dp), planes))
-            ws = _workspace(ws_bytes, spectra.device)
-            if not fold and ws is not None:
+            part_bytes = n_bins * fpb * 4
+            if not fold and ws_bytes >= part_bytes and row_multiple == 1:
+                # partial records kept: parts 1 .. behind part 0 in one allocation of the caller's own
+                max_parts = 1 + ws_bytes // part_bytes
+                parts = torch.empty((max_parts, n_bins, fpb), dtype=torch.float32, device=spectra.device)
                 n_parts = ctypes.c_int(1)
-                _lib.check(lib.sc_fused2_csm_absim_parts_f32(_ptr(spectra.P), byref(dp), _ptr(spectra.scale), planes, _ptr(accum),
-                                                             _ptr(ws), ws_bytes, byref(n_parts), _stream()),
+                _lib.check(lib.sc_fused2_csm_absim_parts_f32(_ptr(spectra.P), byref(dp), _ptr(spectra.scale), planes, _ptr(parts[0]),
+                                                             _ptr(parts[1]), (max_parts - 1) * part_bytes, byref(n_parts), _stream()),
                            "sc_fused2_csm_absim_parts_f32")
-                if n_parts.value > 1:
-                    accum._sc_parts = (ws, n_parts.value, n_bins * fpb)       # (the workspace is reused by the next call)
                 if mark:
                     mark("fused2_csm_absim")
-                return accum, n_obs
+                return (parts[:n_parts.value] if n_parts.value > 1 else parts[0]), n_obs
+            ws = _workspace(ws_bytes, spectra.device)
+            accum = _record_tensor(n_bins, fpb, torch.float32, spectra.device, row_multiple)
             _lib.check(lib.sc_fused2_csm_absim_f32(_ptr(spectra.P), byref(dp), _ptr(spectra.scale), planes, _ptr(accum),
                                                    _ptr(ws) if ws is not None else None, ws_bytes, _stream()),
                        "sc_fused2_csm_absim_f32")
             if mark:
                 mark("fused2_csm_absim")
             return accum, n_obs
+    accum = _record_tensor(n_bins, fpb, torch.float32, spectra.device, row_multiple)
     per_plane_only = use_fused is False        # explicit request (tests): every plane through its separate kernel
     if use_fused is None:
         use_fused = bool(lib.sc_fused_supported(spectra.C_alloc))
@@ -470,10 +484,31 @@ def rec_planes(accum, planes):
     return (planes | _lib.RECORD_F64) if accum.dtype == torch.float64 else (planes & ~_lib.RECORD_F64)
 
 
+def fold_parts(accum):
+    """[n_parts, n_bins, floats_per_bin] partial records -> their sum in part order (the record a folding pass of stage B
+    would have written, bit for bit: the same additions in the same order); a 2-D record is returned as it is.  The folded
+    record is kept on the tensor, so several consumers pay for one fold."""
+    if accum.dim() != 3:
+        return accum
+    cached = getattr(accum, "_sc_folded", None)
+    if cached is None:
+        cached = accum[0].clone()
+        for k in range(1, accum.shape[0]):
+            cached.add_(accum[k])
+        accum._sc_folded = cached
+    return cached
+
+
 def measure(accum, n_signals, planes, n_obs, which, out=None, wide=None):
     """Stage C: one measure from an accumulator tensor (after any cross-GPU sum).  ``wide``: write float64 /
     complex128 (what the reference returns) straight from the epilogue; default: wide for double records."""
     lib = _lib.load()
+    if accum.dim() == 3:
+        # partial records (accumulate(fold=False), or the blocks of a direct exchange): the real-valued C x C measures sum them
+        # inside the epilogue kernel, the others (power, complex measures) take the folded record
+        if which != _lib.M_POWER and which not in _lib.COMPLEX_MEASURES and accum.shape[0] > 1 and accum.is_contiguous() and out is None:
+            return measure_multi(accum, n_signals, planes, n_obs, [which], wide=wide)[0]
+        accum = fold_parts(accum)
     n_bins = accum.shape[0]
     C = n_signals
     if wide is None:
@@ -506,17 +541,13 @@ def measure_multi(accum, n_signals, planes, n_obs, which, wide=None, stacked=Fal
     does not apply, that are summed first."""
     which = list(which)
     parts = None
+    simple = [w for w in which if w != _lib.M_POWER and w not in _lib.COMPLEX_MEASURES]
     if accum.dim() == 3:
-        simple_ = [w for w in which if w != _lib.M_POWER and w not in _lib.COMPLEX_MEASURES]
-        if accum.shape[0] > 1 and len(simple_) == len(which) and 1 <= len(which) <= MEASURE_MULTI_MAX and accum.is_contiguous():
+        if accum.shape[0] > 1 and len(simple) == len(which) and 1 <= len(which) <= MEASURE_MULTI_MAX and accum.is_contiguous():
             parts = accum
             accum = parts[0]
         else:
-            total = accum[0].clone()
-            for k in range(1, accum.shape[0]):                 # part (= rank) order
-                total.add_(accum[k])
-            accum = total
-    simple = [w for w in which if w != _lib.M_POWER and w not in _lib.COMPLEX_MEASURES]
+            accum = fold_parts(accum)                                # part (= rank) order
     if parts is None and (len(simple) != len(which) or not 2 <= len(which) <= MEASURE_MULTI_MAX):
         return [measure(accum, n_signals, planes, n_obs, w, wide=wide) for w in which]
     lib = _lib.load()
@@ -534,12 +565,6 @@ def measure_multi(accum, n_signals, planes, n_obs, which, wide=None, stacked=Fal
         _lib.check(lib.sc_measure_multi_parts(_ptr(parts[0]), _ptr(parts[1]), parts.shape[0], parts.stride(0), n_bins, C,
                                               rec_planes(accum, planes), n_obs, len(which), ids, ptrs, int(bool(wide)), _stream()),
                    "sc_measure_multi_parts")
-        return outs
-    pending = getattr(accum, "_sc_parts", None)
-    if pending is not None:
-        rest, n_parts, stride = pending        # split-bin partial records of stage B, not folded yet (accumulate(fold=False))
-        _lib.check(lib.sc_measure_multi_parts(_ptr(accum), _ptr(rest), n_parts, stride, n_bins, C, rec_planes(accum, planes),
-                                              n_obs, len(which), ids, ptrs, int(bool(wide)), _stream()), "sc_measure_multi_parts")
         return outs
     fn = lib.sc_measure_multi_f64 if wide else lib.sc_measure_multi_f32
     _lib.check(fn(_ptr(accum), n_bins, C, rec_planes(accum, planes), n_obs, len(which), ids, ptrs, _stream()),

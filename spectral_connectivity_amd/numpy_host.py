@@ -255,16 +255,23 @@ class NumpyHost:
         if fused and _lib.planes_format_applies(L, N, C_alloc, planes_hint, spectra_bytes=F * W * R * K * C_alloc * 8):
             # planes format: one scan of the series for the channel scales, then the fused transform writes the f16 pieces
             P = self.alloc(F * W * R * K * int(lib.sc_planes_row_bytes(C_alloc)))
-            scale, work = self.alloc(2 * C_alloc * 4), self.alloc(C_alloc * 4)
+            work_bytes = int(lib.sc_planes_scales_work_bytes(T * R, C_alloc))
+            scale, work, rng = self.alloc(2 * C_alloc * 4), self.alloc(work_bytes), self.alloc(4)
             h_abs_sum = float(np.abs(np.asarray(tapers.T / m.sampling_frequency, dtype=np.float32)).sum(axis=1).max())
-            _lib.check(lib.sc_planes_scales_from_series_f32(x.ptr, T, R, C_alloc, h_abs_sum, scale.ptr, work.ptr, self.stream),
-                       "sc_planes_scales_from_series_f32")
+            _lib.check(lib.sc_planes_scales_range_f32(x.ptr, T, R, C_alloc, h_abs_sum, scale.ptr, work.ptr, work_bytes, rng.ptr,
+                                                      self.stream), "sc_planes_scales_range_f32")
             _lib.check(lib.sc_multitaper_fft_planes_f32(x.ptr, T, R, C_alloc, L, step, W, N, h.ptr, K, detrend,
                                                         self._twiddles[N].ptr, scale.ptr, P.ptr, self.stream),
                        "sc_multitaper_fft_planes_f32")
-            for b in (x, h, work):
-                b.free()
-            return dict(X=None, P=P, scale=scale, F=F, W=W, R=R, K=K, C=C, C_alloc=C_alloc, N=N)
+            # the dynamic-range guard of the format (Multitaper.device_spectra of the PyTorch host does the same): one scale per
+            # channel serves every window, so a channel with a sample thousands of times its typical one keeps complex64
+            ratio = float(self.download(rng, (1,), np.float32)[0])
+            work.free(); rng.free()
+            if ratio <= _lib.PLANES_MAX_RANGE:
+                for b in (x, h):
+                    b.free()
+                return dict(X=None, P=P, scale=scale, F=F, W=W, R=R, K=K, C=C, C_alloc=C_alloc, N=N)
+            P.free(); scale.free()
         X = self.alloc(F * W * R * K * C_alloc * 8)
         if fused:
             _lib.check(lib.sc_multitaper_fft_f32(x.ptr, T, R, C_alloc, L, step, W, N, h.ptr, K, detrend,

@@ -24,6 +24,16 @@ finite_check
     their upload (one read at HBM rate instead of 18 ms of one core at the cfg3 shape) and the reference's warning is
     raised by the first transform; smaller series are scanned by the constructor like the reference's.
     ``"host"``: always in the constructor.  Environment: ``SC_HIP_FINITE_CHECK``.
+
+anticipate_phase_lag
+    ``True`` (default): when the first request of a float32-engine ``Connectivity`` is a cross-spectral measure (power,
+    coherency, coherence, ...) on a shape whose spectra are held in the planes format (44 ... 256 signals, >= 256 MB of
+    spectra: _lib.planes_format_applies), the same pass over the spectra also sums the per-observation |Im s| plane that
+    ``weighted_phase_lag_index`` needs -- the matrix-core kernel produces both in one launch (sc_fused2.hip) -- so a wPLI that
+    follows costs an epilogue (0.1 ms at the BASELINE shape) instead of a second pass over 6.5 GB of spectra (3.5 ms).
+    What it costs a caller who never asks for a phase-lag measure: the |Im s| role of that launch (2.4 -> 3.5 ms of stage
+    B at 128 signals x 7000 observations x 903 bins).  ``False``: every request accumulates exactly the families it needs
+    (round-4 behaviour).  Environment: ``SC_HIP_ANTICIPATE=0``.
 """
 import os
 
@@ -31,6 +41,7 @@ precision = os.environ.get("SC_HIP_PRECISION", "dtype")
 one_sample_fisher_z = "reference"
 finite_check = os.environ.get("SC_HIP_FINITE_CHECK", "device")
 FINITE_CHECK_DEVICE_MIN = 1 << 22
+anticipate_phase_lag = os.environ.get("SC_HIP_ANTICIPATE", "1") != "0"
 
 
 def engine_precision(dtype=None):

@@ -150,6 +150,34 @@ def _direct_blocks(accum, world, per, fpb, group):
     return blocks.to(accum.device) if via_host else blocks
 
 
+_direct_agreed = set()              # process groups whose ranks have agreed that the direct exchange works
+
+
+def _agreed_direct_exchange(accum, world, per, fpb, group):
+    """The direct exchange, with the choice of algorithm AGREED over the ranks: the first exchange of a process group is followed
+    by one all-reduce of a failure flag -- if the direct form raised on ANY rank (a backend without all-to-all, RCCL missing for
+    SC_EXCHANGE=library on one of them) every rank takes the library reduce-scatter from then on, so that no two ranks ever issue
+    different collectives.  Once agreed, a failure of the direct exchange is an error (raised), not a silent switch."""
+    fn = _library_blocks if exchange_algorithm() == "library" else _direct_blocks
+    key = id(group) if group is not None else 0
+    if key in _direct_agreed:
+        blocks = fn(accum, world, per, fpb, group)
+        if blocks is None:
+            raise RuntimeError("the direct exchange failed after the ranks had agreed on it: " + (_direct_failed[-1] if _direct_failed else "?"))
+        return blocks
+    blocks = fn(accum, world, per, fpb, group)
+    flag = torch.tensor([0 if blocks is not None else 1], dtype=torch.int32)
+    if dist.get_backend(group) != "gloo":
+        flag = flag.to(accum.device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+    if int(flag.item()):
+        if not _direct_failed:
+            _direct_failed.append("the direct exchange raised on another rank")
+        return None
+    _direct_agreed.add(key)
+    return blocks
+
+
 def reduce_scatter_bins(accum, group=None, keep_parts=False):
     """Sum accumulator records over ranks; return (this rank's bin shard, bin_lo, bin_hi).
 
@@ -174,7 +202,7 @@ def reduce_scatter_bins(accum, group=None, keep_parts=False):
     lo = rank * per
     hi = min(lo + per, n_bins)
     if exchange_algorithm() in ("direct", "library"):
-        blocks = (_library_blocks if exchange_algorithm() == "library" else _direct_blocks)(accum, world, per, fpb, group)
+        blocks = _agreed_direct_exchange(accum, world, per, fpb, group)
         if blocks is not None:
             if keep_parts:
                 return blocks, lo, max(hi, lo)                              # [world, per, fpb]: summed by the consumer, in rank order

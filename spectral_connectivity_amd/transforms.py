@@ -290,6 +290,33 @@ _NONFINITE_WARNING = ("Input time_series contains NaN or infinite values.\n"
                       "This will produce invalid spectral estimates.")
 
 
+class _DeviceSeries:
+    """A time series that already lives in HBM (a ``torch`` tensor on a ROCm device handed to ``Multitaper``): the sizes and
+    the NumPy dtype the host-side parameter logic asks for, without a copy; ``numpy.asarray`` of it downloads (the reference's
+    ``time_series`` attribute is a host array -- whoever reads it as one gets one)."""
+
+    def __init__(self, tensor):
+        self.tensor = tensor
+        self.shape = tuple(int(n) for n in tensor.shape)
+        self.ndim = tensor.dim()
+        self.size = int(tensor.numel())
+        self.dtype = np.dtype(str(tensor.dtype).replace("torch.", ""))
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.tensor.detach().cpu().numpy()
+        return a if dtype is None else a.astype(dtype, copy=False)
+
+    def __len__(self):
+        return self.shape[0]
+
+
+def _as_series(time_series):
+    """``numpy.asarray`` for host input; a device tensor (torch, on the GPU) stays where it is."""
+    if type(time_series).__module__.startswith("torch") and getattr(time_series, "is_cuda", False):
+        return _DeviceSeries(time_series)
+    return np.asarray(time_series)
+
+
 class Multitaper:
     """Multitaper spectral transform on an MI355X (drop-in for the reference class).
 
@@ -301,13 +328,17 @@ class Multitaper:
     the upload, and the same ``UserWarning`` is raised by the first transform (``fft()``, or the first measure of a
     ``Connectivity`` built from this object) -- not at all if no transform ever runs.  ``options.finite_check = "host"``
     (or ``SC_HIP_FINITE_CHECK=host``) restores the constructor-time scan for every size.
+
+    Beyond the reference: ``time_series`` may be a ``torch`` tensor that already lives on the GPU (float32 / float64,
+    (n_time_samples, n_trials, n_signals)); it is used in place -- no host round trip -- and its NaN / infinity scan runs on
+    the device with the first transform.
     """
 
     def __init__(self, time_series, sampling_frequency=1000, time_halfbandwidth_product=3,
                  detrend_type="constant", time_window_duration=None, time_window_step=None,
                  n_tapers=None, tapers=None, start_time=0, n_fft_samples=None,
                  n_time_samples_per_window=None, n_time_samples_per_step=None, is_low_bias=True):
-        self.time_series = np.asarray(time_series)
+        self.time_series = _as_series(time_series)
         nd = self.time_series.ndim
         if nd != 3:
             msg = (f"Expected 3D array with shape (n_time_samples, n_trials, n_signals), "
@@ -358,7 +389,11 @@ class Multitaper:
         # the first transform; options.finite_check = "host" keeps the constructor-time scan for every size.
         from . import options as _options
         self._finite_checked = True
-        if (_options.finite_check == "device" and self.time_series.dtype.kind == "f"
+        if isinstance(self.time_series, _DeviceSeries):
+            if self.time_series.dtype.kind not in "f":
+                raise TypeError(f"a device time series must be float32 or float64, got {self.time_series.dtype}")
+            self._finite_checked = False                  # scanned on the device, with the first transform
+        elif (_options.finite_check == "device" and self.time_series.dtype.kind == "f"
                 and self.time_series.size >= _options.FINITE_CHECK_DEVICE_MIN):
             self._finite_checked = False
         elif not (self.time_series.dtype.kind == "f" and self.time_series.size and np.isfinite(self.time_series.sum())) \
@@ -560,23 +595,32 @@ class Multitaper:
                 if int(flag.item()):
                     warnings.warn(_NONFINITE_WARNING, UserWarning, stacklevel=4)
 
+            on_device = self.time_series.tensor if isinstance(self.time_series, _DeviceSeries) else None
+            if on_device is not None:
+                dev = on_device.device
             if precision == "float64":
-                x = torch.from_numpy(np.ascontiguousarray(self.time_series, dtype=np.float64)).to(dev)
+                x = (on_device.to(torch.float64).contiguous() if on_device is not None
+                     else torch.from_numpy(np.ascontiguousarray(self.time_series, dtype=np.float64)).to(dev))
                 device_scan(x)
                 h = torch.from_numpy(np.ascontiguousarray(tapers.T / self.sampling_frequency)).to(dev)
                 self._device_spectra[precision] = engine.multitaper_spectra_f64(
                     x, h, self.n_time_samples_per_window, self.n_time_samples_per_step,
                     self.n_fft_samples, self.n_time_windows, self.detrend_type)
             else:
-                ts = np.asarray(self.time_series)
+                ts = self.time_series
                 n_signals = ts.shape[2]
                 n_alloc = n_signals + 1 if (n_signals % 2 and n_signals + 1 <= 256) else n_signals
-                if ts.dtype == np.float64 and ts.size:
+                if on_device is not None and ts.dtype == np.float32:
+                    # already in HBM, float32: used in place (an odd channel count gets its zero pad channel in engine.multitaper_spectra)
+                    x = on_device.contiguous()
+                    device_scan(x)
+                    n_signals = None if n_alloc != ts.shape[2] else n_signals
+                elif ts.dtype == np.float64 and ts.size:
                     # float64 input: uploaded as it is and converted on the device (sc_timeseries_to_f32), which also takes a
                     # per-(trial, signal) constant out in float64 BEFORE the cast when a detrend is active -- every window's
                     # own detrend removes any constant, and a DC offset 1e5 times the signal (raw EEG / MEG) would otherwise
                     # cost the float32 copy all but two digits of the signal -- and appends the zero pad channel of odd counts
-                    xd = torch.from_numpy(np.ascontiguousarray(ts)).to(dev)
+                    xd = on_device.contiguous() if on_device is not None else torch.from_numpy(np.ascontiguousarray(ts)).to(dev)
                     device_scan(xd)
                     x = torch.empty(ts.shape[:2] + (n_alloc,), dtype=torch.float32, device=dev)
                     _lib.check(_lib.load().sc_timeseries_to_f32(xd.data_ptr(), ts.shape[0], ts.shape[1], n_signals,
@@ -584,7 +628,7 @@ class Multitaper:
                                                                 torch.cuda.current_stream().cuda_stream), "sc_timeseries_to_f32")
                     del xd
                 else:
-                    x_host = np.ascontiguousarray(ts, dtype=np.float32)
+                    x_host = np.ascontiguousarray(np.asarray(ts), dtype=np.float32)
                     if n_alloc != n_signals:
                         # odd channel count: ONE all-zero channel is appended on the host, before the upload, so that the
                         # rows of the spectra stay 16-byte aligned for the one-pass stage-B kernels (engine.DeviceSpectra)
@@ -592,10 +636,27 @@ class Multitaper:
                     x = torch.from_numpy(x_host).to(dev)
                     device_scan(x)
                 h = torch.from_numpy(np.ascontiguousarray(tapers.T / self.sampling_frequency, dtype=np.float32)).to(dev)
-                self._device_spectra[precision] = engine.multitaper_spectra(
+                sp = engine.multitaper_spectra(
                     x, h, self.n_time_samples_per_window, self.n_time_samples_per_step,
                     self.n_fft_samples, self.n_time_windows, self.detrend_type, n_signals=n_signals,
                     planes_hint=planes_hint)
+                self.device_format_note = None
+                if sp.P is not None and sp.range is not None:
+                    # The planes format takes ONE scale per channel from its largest sample: a channel with an artefact thousands
+                    # of times its typical amplitude would hold the quiet windows' coefficients in the f16 subnormals.  The
+                    # scale pass measured max|x| / mean|x| on the way; beyond the limit the transform runs again into complex64
+                    # (one small read-back: the first transform of an object, never a step of a loop).
+                    ratio = float(sp.range.item())
+                    if not ratio <= _lib.PLANES_MAX_RANGE:
+                        self.device_format_note = (
+                            f"a channel's largest sample is {ratio:.3g} times its mean magnitude (limit {_lib.PLANES_MAX_RANGE:g}): "
+                            "spectra kept as complex64 instead of the two-piece f16 format")
+                        logger.warning("spectral_connectivity_amd: " + self.device_format_note)
+                        del sp
+                        sp = engine.multitaper_spectra(
+                            x, h, self.n_time_samples_per_window, self.n_time_samples_per_step,
+                            self.n_fft_samples, self.n_time_windows, self.detrend_type, n_signals=n_signals, planes_hint=None)
+                self._device_spectra[precision] = sp
         return self._device_spectra[precision]
 
     def _complex_device_spectra(self, device, precision):

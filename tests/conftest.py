@@ -64,6 +64,22 @@ def _engine_precision(request):
             os.environ["SC_PLANES_MIN_CHANNELS"] = old_env
 
 
+@pytest.fixture
+def debug_env():
+    """Set / unset one of the library's diagnostic switches (environment variables it reads once at load and again on
+    sc_debug_reload_env: _lib.set_debug_env) for the rest of a test; everything is put back afterwards."""
+    from spectral_connectivity_amd import _lib
+    saved = {}
+
+    def set_(name, value):
+        saved.setdefault(name, os.environ.get(name))
+        _lib.set_debug_env(name, value)
+
+    yield set_
+    for name, old in saved.items():
+        _lib.set_debug_env(name, old)
+
+
 def granger_close(got, ref, tol, what="granger"):
     """Spectral Granger predictions against a reference: entries finite in both within ``tol`` of the array maximum;
     an entry that is NaN in exactly one of the two is a prediction the reference's `gp[gp <= 0] = nan`

@@ -222,8 +222,8 @@ def test_trial_sharded_pipeline_ranks_share_one_gpu(world):
 def test_eight_rank_rehearsal_at_the_headline_size():
     """What the 8-GPU run of the bench does, rehearsed on the one GPU a test box has: 8 ranks (gloo, sharing the device) with
     125 of the 1000 trials of the cfg3 shape each -- planes-format stage A and B per rank, direct exchange of the bin blocks,
-    the epilogue kernel summing the eight received blocks in rank order, gather on rank 0 -- against the single-process result
-    over all 1000 trials."""
+    the epilogue kernel summing the eight received blocks in rank order, gather on rank 0 -- against the FLOAT64 reference over
+    all 1000 trials (tests/fp64_device_ref.py, the bound of tests/test_gpu_full_depth.py) and against the single-process result."""
     import os
     import subprocess
     import sys

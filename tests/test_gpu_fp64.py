@@ -371,7 +371,7 @@ def test_incremental_records_equal_fresh_ones(sc):
 
 
 @pytest.mark.parametrize("L", [64, 128, 256, 512, 1024])
-def test_radix16_float64_transform_equals_the_wave_per_pair_kernel_and_the_oracle(sc, monkeypatch, L):
+def test_radix16_float64_transform_equals_the_wave_per_pair_kernel_and_the_oracle(sc, debug_env, L):
     """Powers of two 64 ... 1024 take the register-resident radix-16 kernel in doubles (round 3); SC_MTFFT_F64=wave keeps the
     radix-4 wave-per-pair kernel reachable: both against the oracle (1e-11 of the maximum) and against each other."""
     from oracle import spectral_oracle as so
@@ -384,6 +384,6 @@ def test_radix16_float64_transform_equals_the_wave_per_pair_kernel_and_the_oracl
     ref, _ = so.multitaper_fft(x, fs=500.0, NW=3, n_time_samples_per_window=L, n_time_samples_per_step=L // 2, detrend_type="linear")
     scale = np.abs(ref).max()
     assert np.abs(got - ref).max() <= 1e-11 * scale
-    monkeypatch.setenv("SC_MTFFT_F64", "wave")
+    debug_env("SC_MTFFT_F64", "wave")
     wave = sc.Multitaper(x, **kw).fft()
     assert np.abs(wave - got).max() <= 1e-12 * scale

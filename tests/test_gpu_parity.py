@@ -315,7 +315,7 @@ def test_one_pass_nonlinear_planes_equal_the_per_plane_kernel(sc, C, R):
 
 
 @pytest.mark.parametrize("C,R,split", [(128, 150, 3), (64, 130, 2), (128, 200, 5), (16, 400, 4), (40, 130, 3), (4, 900, 7)])
-def test_fused_stage_b_split_bins(sc, C, R, split, monkeypatch):
+def test_fused_stage_b_split_bins(sc, C, R, split, debug_env):
     """Several workgroups per bin (observation chunks split, partial records folded in a fixed order)
     give the sums of the one-workgroup-per-bin launch up to fp32 re-association, and repeat bit-exactly."""
     from spectral_connectivity_amd import _lib, engine
@@ -325,9 +325,9 @@ def test_fused_stage_b_split_bins(sc, C, R, split, monkeypatch):
                       n_time_samples_per_window=64, n_time_samples_per_step=64)
     sp = m.device_spectra()
     planes = _lib.PLANE_CSM | _lib.PLANE_ABS_IM
-    monkeypatch.setenv("SC_FUSED_SPLIT", "1")
+    debug_env("SC_FUSED_SPLIT", "1")
     a_1, n = engine.accumulate(sp, "trials_tapers", planes, use_fused=True)
-    monkeypatch.setenv("SC_FUSED_SPLIT", str(split))
+    debug_env("SC_FUSED_SPLIT", str(split))
     a_s, _ = engine.accumulate(sp, "trials_tapers", planes, use_fused=True)
     a_s2, _ = engine.accumulate(sp, "trials_tapers", planes, use_fused=True)
     assert bool((a_s == a_s2).all()), "split launch is not reproducible"
@@ -516,7 +516,7 @@ def test_mvar_measures_beyond_64_signals_vs_oracle(sc, C):
 
 @pytest.mark.parametrize("c,N,P", [(2, 256, 5), (2, 512, 3), (2, 1024, 3), (2, 2048, 2), (2, 4096, 2),
                                    (3, 256, 2), (4, 512, 1), (3, 2048, 1), (5, 4096, 1)])
-def test_wilson_fused_causal_fft_vs_library_path(sc, monkeypatch, c, N, P):
+def test_wilson_fused_causal_fft_vs_library_path(sc, debug_env, c, N, P):
     """Lengths 256..4096 run ifft -> causal mask -> fft as one fp64 LDS kernel (csrc/sc_wilson_fft.hip); every
     other length, and SC_WILSON_FFT=rocfft, takes rocFFT + a pointwise kernel.  Both must produce the same
     factor (fp64 rounding apart), reconstruct S, and match the oracle where it is quick."""
@@ -530,11 +530,11 @@ def test_wilson_fused_causal_fft_vs_library_path(sc, monkeypatch, c, N, P):
         L = np.linalg.cholesky(np.eye(c) + 0.3 * np.ones((c, c)) / c)
         Fz = (np.eye(c)[None] + B1[None] * z[:, None, None] + B2[None] * (z ** 2)[:, None, None]) @ L
         S[p] = Fz @ np.conj(np.swapaxes(Fz, -1, -2))
-    monkeypatch.delenv("SC_WILSON_FFT", raising=False)
+    debug_env("SC_WILSON_FFT", None)
     G = minimum_phase_decomposition(S)
-    monkeypatch.setenv("SC_WILSON_FFT", "rocfft")
+    debug_env("SC_WILSON_FFT", "rocfft")
     G_lib = minimum_phase_decomposition(S)
-    monkeypatch.delenv("SC_WILSON_FFT", raising=False)
+    debug_env("SC_WILSON_FFT", None)
     assert G.shape == S.shape and np.isfinite(G).all()
     scale = np.abs(G).max()
     np.testing.assert_allclose(G, G_lib, rtol=0, atol=1e-10 * scale)
@@ -687,14 +687,14 @@ def test_f11_band_statistics_on_the_device_coherency(sc, golden):
 
 
 @pytest.mark.parametrize("C,R", [(2, 9), (16, 7), (32, 30), (40, 5), (64, 4)])
-def test_matrix_core_kernel_below_its_crossover(sc, C, R, monkeypatch):
+def test_matrix_core_kernel_below_its_crossover(sc, C, R, debug_env):
     """SC_FUSED_NO_SMALL=1 sends every shape through the matrix-core kernel (normally <= 42-58 channels take the f32 VALU
     kernel): the one-block table of <= 32 channels -- a lone MFMA per observation row, whose results the |Im| waves read
     straight away -- and every plane pass (|Im s|, (Im s)^2, sign(Im s)) against the per-plane kernels.  (The sign pass
     once read its MFMA results from inline asm without the wait states the compiler pads for instructions it can see:
     wrong sums at <= 32 channels only.)"""
     from spectral_connectivity_amd import _lib, engine
-    monkeypatch.setenv("SC_FUSED_NO_SMALL", "1")
+    debug_env("SC_FUSED_NO_SMALL", "1")
     rng = np.random.default_rng(200 + C)
     x = rng.standard_normal((200, R, C)) + 0.5 * rng.standard_normal((200, R, 1))
     m = sc.Multitaper(x, sampling_frequency=200.0, time_halfbandwidth_product=3,
@@ -934,7 +934,7 @@ def test_global_coherence_any_rank_beyond_64_signals(sc, C, max_rank):
     assert np.abs(resid).max() <= 3e-5 * scale, f"eigen-residual {np.abs(resid).max():.2e} vs scale {scale:.2e}"
 
 
-def test_global_coherence_degenerate_eigenvalues_and_the_jacobi_cross_check(sc, monkeypatch):
+def test_global_coherence_degenerate_eigenvalues_and_the_jacobi_cross_check(sc, debug_env):
     """Beyond 64 signals the eigenpairs come from a Householder tridiagonalisation + bisection + inverse iteration.  Exactly
     repeated eigenvalues (a block-diagonal cross-spectral matrix with two identical blocks) must still give an ORTHONORMAL
     set of eigenvectors (vectors of a cluster are orthogonalised against each other like LAPACK's dstein does), and the
@@ -958,7 +958,7 @@ def test_global_coherence_degenerate_eigenvalues_and_the_jacobi_cross_check(sc, 
     V = vecs[0, 0]
     np.testing.assert_allclose(V.conj().T @ V, np.eye(K), atol=1e-6)
     assert np.abs(G @ V - V * vals[0, 0][None, :]).max() <= 1e-4 * np.abs(vals).max()
-    monkeypatch.setenv("SC_GLOBAL_EIG", "jacobi")
+    debug_env("SC_GLOBAL_EIG", "jacobi")
     vals_j, _ = sc.Connectivity(coef).global_coherence(max_rank=4)
     np.testing.assert_allclose(vals_j, vals[..., -4:], rtol=1e-6)
 

@@ -191,23 +191,29 @@ def test_public_classes_take_the_planes_path_and_match_the_oracle(dtype):
 
 @pytest.mark.default_thresholds
 def test_when_the_engine_takes_the_planes_format():
-    """The measured crossovers (engine default): CSM + |Im s| from 44 channels, CSM alone from 32 to 64 channels, nothing for a
-    request of a few tens of MB -- and the transform that follows the rule."""
+    """Round 5: the device format is a function of the SHAPE of the request for every accumulator family the planes kernels
+    serve -- 44 ... 256 signals, at least 256 MB of spectra, a window the planes transform takes -- not of which family is asked
+    for first; the unit-phasor family and hint-less callers keep complex64."""
     big = 1 << 30
     csm = _lib.PLANE_CSM
-    assert _lib.planes_format_applies(256, 256, 64, PLANES, spectra_bytes=big)
-    assert _lib.planes_format_applies(256, 256, 128, PLANES, spectra_bytes=big)
-    assert not _lib.planes_format_applies(256, 256, 40, PLANES, spectra_bytes=big)
-    assert not _lib.planes_format_applies(256, 256, 64, PLANES, spectra_bytes=32 << 20)
-    assert _lib.planes_format_applies(256, 256, 64, csm, spectra_bytes=big)
-    assert not _lib.planes_format_applies(256, 256, 30, csm, spectra_bytes=big)
-    assert not _lib.planes_format_applies(1024, 1024, 256, csm, spectra_bytes=big)
+    for fam in _lib.PLANES_FORMAT_FAMILIES:
+        assert _lib.planes_format_applies(256, 256, 64, fam, spectra_bytes=big)
+        assert _lib.planes_format_applies(256, 256, 128, fam, spectra_bytes=big)
+        assert _lib.planes_format_applies(1024, 1024, 256, fam, spectra_bytes=big)
+        assert not _lib.planes_format_applies(256, 256, 40, fam, spectra_bytes=big)
+        assert not _lib.planes_format_applies(256, 256, 64, fam, spectra_bytes=32 << 20)
+        assert not _lib.planes_format_applies(2048, 2048, 64, fam, spectra_bytes=big)
+        assert not _lib.planes_format_applies(256, 256, 258, fam, spectra_bytes=big)
     assert not _lib.planes_format_applies(256, 256, 64, _lib.PLANE_CSM | _lib.PLANE_UNIT, spectra_bytes=big)
+    assert not _lib.planes_format_applies(256, 256, 64, _lib.PLANE_UNIT, spectra_bytes=big)
+    assert not _lib.planes_format_applies(256, 256, 64, None, spectra_bytes=big)
     dev = _dev()
     tapers = np.asarray(transforms.dpss_windows(128, 2, 3)[0])[:3]
     h = torch.from_numpy(np.ascontiguousarray(tapers / np.sqrt(1000.0), dtype=np.float32)).to(dev)
     x = torch.from_numpy(_series(512, 2, 64, seed=1).astype(np.float32)).to(dev)
     sp = engine.multitaper_spectra(x, h, 128, 128, 128, 4, "constant", planes_hint=PLANES)        # 0.4 MB of spectra
+    assert sp.P is None
+    sp = engine.multitaper_spectra(x, h, 128, 128, 128, 4, "constant", planes_hint=csm)
     assert sp.P is None
 
 
@@ -251,3 +257,126 @@ def test_every_planes_family_through_the_public_classes(C):
             assert bad.mean() < 2e-4 and np.all(np.abs(got - ref)[bad] <= 2.0 / n + 1e-6), name
         else:
             np.testing.assert_allclose(got, ref, rtol=5e-4, atol=5e-5, equal_nan=True, err_msg=name)
+
+
+# ---- round 5: the three-term arithmetic, the split-bin parts and the dynamic range of the format, at depth -----------------------
+def _planes_from_complex64(X, C):
+    """Dense complex64 spectra [F][W][R][K][C] -> (planes buffer, scales) through the C ABI's conversion."""
+    lib = _lib.load()
+    F, W, R, K, _ = X.shape
+    sp = engine.DeviceSpectra(X, (F, W, R, K, C), (W * R * K * C, R * K * C, K * C, C), 2 * (F - 1), True, C_alloc=C)
+    P = torch.zeros((F * W * R * K * lib.sc_planes_row_bytes(C),), dtype=torch.uint8, device=X.device)
+    scale = torch.empty((2 * C,), dtype=torch.float32, device=X.device)
+    work = torch.empty((C,), dtype=torch.int32, device=X.device)
+    _lib.check(lib.sc_planes_scales_from_spectra_f32(X.data_ptr(), F * W * R * K, C, scale.data_ptr(), work.data_ptr(), None), "scales")
+    _lib.check(lib.sc_planes_from_spectra_f32(X.data_ptr(), byref(sp.desc("trials_tapers")), scale.data_ptr(), P.data_ptr(), None), "to planes")
+    return engine.DeviceSpectra(None, (F, W, R, K, C), sp.strides, sp.n_fft, True, C_alloc=C, P=P, scale=scale)
+
+
+@pytest.mark.parametrize("C", [44, 64, 96, 128, 130, 256])
+@pytest.mark.parametrize("n_obs", [255, 256, 511, 512, 513, 1536, 7000])
+def test_stage_b_on_planes_three_term_sweep(n_obs, C, debug_env):
+    """fused2_kernel against float64 sums of the same coefficients at the depths where its arithmetic changes: 255 / 256
+    observations per bin (four cross terms below 256, three from there on: sc_fused2.hip fused2_setup), the 512-observation fold
+    interval and its neighbours, 1536, and the 7000 of BASELINE configs[2]; 44 ... 256 signals (one launch up to 128, the staircase
+    launches above; 64-observation chunks up to 64 signals); every bin split over 1, 2, 3 and 5 workgroups (SC_FUSED_SPLIT),
+    folded by the library (fold=True) and left as partial records for the epilogue (fold=False) -- which must agree bit for bit.
+    Bound on every entry of the upper triangle, un-normalised sums: |err| <= 3e-6 |S_ij| + 2e-7 sqrt(P_i P_j) for the cross-
+    spectra (the full-depth bound of tests/test_gpu_full_depth.py with the pair's own scale sqrt(P_i P_j) in place of the array
+    maximum: channel amplitudes are spread over six decades here), 1e-5 relative for the positive sums of |Im s|."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from conftest import unpack_record_planes
+    from fp64_device_ref import sums_fp64
+    dev = _dev()
+    F, W, R, K = 3, 1, n_obs, 1
+    rng = np.random.default_rng(1000 * C + n_obs)
+    coef = rng.standard_normal((F, W, R, K, C)) + 1j * rng.standard_normal((F, W, R, K, C))
+    coef = coef + 0.4 * coef[..., :1]                                  # a shared component (before the scales: no cancelling pairs)
+    coef = coef * (0.2 + rng.random(C)) * 10.0 ** rng.integers(-3, 4, C)
+    X = torch.from_numpy(coef.astype(np.complex64)).to(dev)
+    spp = _planes_from_complex64(X, C)
+    csm, ab = sums_fp64(X.to(torch.complex128))                        # un-normalised float64 sums of the complex64-rounded input
+    S, A = csm.cpu().numpy().reshape(F, C, C), ab.cpu().numpy().reshape(F, C, C)
+    Pw = np.real(np.einsum("fii->fi", S))
+    pair = np.sqrt(Pw[:, :, None] * Pw[:, None, :])
+    upper = np.triu(np.ones((C, C), dtype=bool))
+    strict = np.triu(np.ones((C, C), dtype=bool), 1)
+    worst = {}
+    variants = [(s, None) for s in (1, 2, 3, 5)]
+    variants += [(1, 3)] if n_obs < 256 else [(1, 4)]                   # the other arithmetic at this depth, forced (SC_FUSED2_TERMS)
+    for split, terms in variants:
+        debug_env("SC_FUSED_SPLIT", split)
+        debug_env("SC_FUSED2_TERMS", terms)
+        accum, n = engine.accumulate(spp, "trials_tapers", PLANES)
+        assert n == n_obs and accum.dim() == 2
+        rec = unpack_record_planes(accum.cpu().numpy(), C)                                  # [F, 3, C, C]
+        got_S = rec[:, 0] + 1j * rec[:, 1]
+        err = np.abs(got_S - S)[:, upper] / (3e-6 * np.abs(S)[:, upper] + 2e-7 * pair[:, upper])
+        rel_a = np.abs(rec[:, 2] - A)[:, strict] / A[:, strict]
+        worst[(split, terms)] = (err.max(), rel_a.max())
+        assert err.max() <= 1.0, (split, terms, err.max())
+        assert rel_a.max() <= 1e-5, (split, terms, rel_a.max())
+        parts, _ = engine.accumulate(spp, "trials_tapers", PLANES, fold=False)
+        if parts.dim() == 3:
+            assert C <= 128 and split > 1 and parts.shape[0] == split
+            assert torch.equal(engine.fold_parts(parts), accum), "partial records summed in part order differ from the library's fold"
+            for which in (_lib.M_WPLI, _lib.M_COHERENCE_MAGNITUDE):
+                a = engine.measure(parts, C, PLANES, n, which)
+                b = engine.measure(accum, C, PLANES, n, which)
+                assert torch.equal(a.nan_to_num(), b.nan_to_num()), "the epilogue on partial records differs from the epilogue on their sum"
+            two = engine.measure_multi(parts, C, PLANES, n, [_lib.M_COHERENCE_MAGNITUDE, _lib.M_WPLI])
+            assert torch.equal(two[1], engine.measure(accum, C, PLANES, n, _lib.M_WPLI))
+            pw = engine.measure(parts, C, PLANES, n, _lib.M_POWER)                          # (power: the folded record)
+            assert torch.equal(pw, engine.measure(accum, C, PLANES, n, _lib.M_POWER))
+        else:
+            assert torch.equal(parts, accum)
+    print(f"\n  n_obs {n_obs:5d}, {C:3d} signals: err / bound and |Im s| rel err per (split, forced terms): "
+          + ", ".join(f"{k}: {v[0]:.2f} / {v[1]:.1e}" for k, v in worst.items()))
+
+
+@pytest.mark.parametrize("artefact", [1e3, 1e5, 1e7])
+def test_one_artefact_sample_in_a_channel(artefact):
+    """The format has ONE scale per channel, taken from its largest sample.  One sample 1e3 / 1e5 / 1e7 times the channel's
+    standard deviation (an electrode pop) in one trial: the quiet windows of that channel must keep their accuracy.  Up to
+    _lib.PLANES_MAX_RANGE (max|x| / mean|x| of 4096) the format is kept and the measures of EVERY window stay as close to the float64
+    oracle as the complex64 engine's; beyond, Multitaper says so (device_format_note, a logged warning) and the spectra are
+    complex64 -- the same numbers as with SC_PLANES_FORMAT=0."""
+    import os
+    _dev()
+    rng = np.random.default_rng(7)
+    T, R, C, L, step = 1024, 6, 8, 256, 128
+    t = np.arange(T) / 1000.0
+    x = rng.standard_normal((T, R, C))
+    x += 0.6 * np.sin(2 * np.pi * 60 * t[:, None, None] + 2 * np.pi * np.arange(C)[None, None, :] / C)
+    x[10, 0, 3] = artefact                          # window 0 of trial 0 only (samples 0 ... 255 with a 128-sample step: windows 0)
+    x = x.astype(np.float32)
+    kw = dict(sampling_frequency=1000, time_halfbandwidth_product=3, n_time_samples_per_window=L, n_time_samples_per_step=step)
+    m = Multitaper(x, **kw)
+    c = Connectivity.from_multitaper(m, dtype=np.complex64)
+    coh, wpli = c.coherence_magnitude(), c.weighted_phase_lag_index()
+    kept = c._spectra.P is not None
+    assert kept == (artefact < 1e4), (artefact, m.device_format_note)
+    assert (m.device_format_note is None) == kept
+    os.environ["SC_PLANES_FORMAT"] = "0"
+    try:
+        c64 = Connectivity.from_multitaper(Multitaper(x, **kw), dtype=np.complex64)
+        coh64, wpli64 = c64.coherence_magnitude(), c64.weighted_phase_lag_index()
+        assert c64._spectra.P is None
+    finally:
+        del os.environ["SC_PLANES_FORMAT"]
+    coef, _ = so.multitaper_fft(x.astype(np.float64), fs=1000, NW=3, n_time_samples_per_window=L, n_time_samples_per_step=step)
+    ref_coh, ref_wpli = so.coherence_magnitude(coef), so.weighted_phase_lag_index(coef)
+    quiet = slice(1, None)                          # the windows without the artefact
+    np.testing.assert_allclose(coh[quiet], ref_coh[quiet], rtol=2e-4, atol=2e-5, equal_nan=True)
+    np.testing.assert_allclose(wpli[quiet], ref_wpli[quiet], rtol=2e-4, atol=2e-5)
+    e_p = np.nanmax(np.abs(coh - ref_coh)[quiet]), np.abs(wpli - ref_wpli)[quiet].max()
+    e_c = np.nanmax(np.abs(coh64 - ref_coh)[quiet]), np.abs(wpli64 - ref_wpli)[quiet].max()
+    print(f"\n  artefact x{artefact:g}: planes kept {kept}; quiet windows vs float64 oracle: coherence {e_p[0]:.2e} (complex64 engine {e_c[0]:.2e}), "
+          f"wPLI {e_p[1]:.2e} ({e_c[1]:.2e})")
+    assert e_p[0] <= 2 * e_c[0] + 2e-6 and e_p[1] <= 2 * e_c[1] + 2e-6
+    if not kept:
+        np.testing.assert_array_equal(coh, coh64)
+        np.testing.assert_array_equal(wpli, wpli64)
+    # the window that holds the artefact: the float32 transform itself is limited there (in either format); the two engines agree
+    np.testing.assert_allclose(coh[0], coh64[0], rtol=0, atol=5e-5, equal_nan=True)

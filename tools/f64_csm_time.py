@@ -21,6 +21,7 @@ _lib.timing_enable(True)
 def run(label, planes, env):
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
+    _lib.reload_debug_env()
     ts = []
     for rep in range(7):
         _lib.last_timing()
@@ -35,6 +36,7 @@ def run(label, planes, env):
             os.environ.pop(k, None)
         else:
             os.environ[k] = v
+    _lib.reload_debug_env()
     print(f"C={C} {label:58s} {np.median(ts):7.3f} ms")
 
 

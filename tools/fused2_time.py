@@ -37,7 +37,7 @@ for C in (128, 64):
     clocks = {k: [] for k in times}
     for rep in range(17):
         for key in times:
-            os.environ["SC_FUSED_DEBUG"] = key[1]
+            _lib.set_debug_env("SC_FUSED_DEBUG", key[1])
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             if key[0] == "new":
@@ -53,4 +53,4 @@ for C in (128, 64):
                     clocks[key].append(ghz.value)
     print(f"C={C:4d}: " + "   ".join(f"{k[0]} dbg={k[1]}: {np.median(v) * 1e3:.3f} ms" + (f" @{np.median(clocks[k]):.2f} GHz" if clocks[k] else "")
                                      for k, v in times.items()))
-os.environ.pop("SC_FUSED_DEBUG", None)
+_lib.set_debug_env("SC_FUSED_DEBUG", None)

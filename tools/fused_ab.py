@@ -21,7 +21,7 @@ for C in (128, 64, 160, 256):
         times = {v: [] for v in variants}
         for rep in range(17):
             for v in variants:
-                os.environ["SC_FUSED_DEBUG"] = v
+                _lib.set_debug_env("SC_FUSED_DEBUG", v)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 out = engine.accumulate(sp, "trials_tapers", planes)
@@ -32,4 +32,4 @@ for C in (128, 64, 160, 256):
                     times[v].append(dt)
         print(f"C={C:4d} {name:9s}: " + "   ".join(f"dbg={v}: {np.median(times[v]) * 1e3:.3f} ms" for v in variants))
     del X, sp
-os.environ.pop("SC_FUSED_DEBUG", None)
+_lib.set_debug_env("SC_FUSED_DEBUG", None)

@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from spectral_connectivity_amd import engine      # noqa: E402
+from spectral_connectivity_amd import _lib, engine      # noqa: E402
 
 variants = sys.argv[1:] or ["0", "8"]
 dev = torch.device("cuda:0")
@@ -24,7 +24,7 @@ for (T, L, R) in SHAPES:
     times = {v: [] for v in variants}
     for rep in range(17):
         for v in variants:
-            os.environ["SC_MTFFT_DEBUG"] = v
+            _lib.set_debug_env("SC_MTFFT_DEBUG", v)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             out = engine.multitaper_spectra(x, tap, L, step, L, W, "constant")
@@ -35,4 +35,4 @@ for (T, L, R) in SHAPES:
                 times[v].append(dt)
     print(f"N={L}: " + "   ".join(f"dbg={v}: {np.median(times[v]) * 1e3:.3f} ms ({gb / np.median(times[v]) / 1e3:.2f} TB/s)" for v in variants))
     del x
-os.environ.pop("SC_MTFFT_DEBUG", None)
+_lib.set_debug_env("SC_MTFFT_DEBUG", None)

@@ -28,7 +28,7 @@ scale = torch.empty((2 * C,), dtype=torch.float32, device=dev)
 work = torch.empty((C,), dtype=torch.int32, device=dev)
 for rep in range(N_REP):
     for name, hint, dbg in variants:
-        os.environ["SC_MTFFT_DEBUG"] = dbg
+        _lib.set_debug_env("SC_MTFFT_DEBUG", dbg)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         sp = engine.multitaper_spectra(x, h, L, step, L, W, "constant", planes_hint=hint)
@@ -42,6 +42,6 @@ for rep in range(N_REP):
     torch.cuda.synchronize()
     if rep >= 2:
         ts["scales only"].append(time.perf_counter() - t0)
-os.environ.pop("SC_MTFFT_DEBUG", None)
+_lib.set_debug_env("SC_MTFFT_DEBUG", None)
 for k, v in ts.items():
     print(f"{k:28s} {np.median(v) * 1e3:.3f} ms")

@@ -5,7 +5,7 @@ import os, sys
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from spectral_connectivity_amd import engine
+from spectral_connectivity_amd import _lib, engine
 
 C, K = 128, 7
 for N, R in ((1024, 1000), (2048, 500), (4096, 250), (512, 1000)):
@@ -17,7 +17,7 @@ for N, R in ((1024, 1000), (2048, 500), (4096, 250), (512, 1000)):
     gb = (4.0 * T * R * C + 8.0 * F * W * R * K * C) / 1e9
     ref = None
     for wide in ("0", "1", "2", "3"):
-        os.environ["SC_MTFFT_WIDE"] = wide
+        _lib.set_debug_env("SC_MTFFT_WIDE", wide)
         for det in ("constant", "constant", "linear"):
             sp = engine.multitaper_spectra(x, h, N, N, N, W, det)
             if det == "linear":
