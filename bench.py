@@ -163,13 +163,18 @@ def api_pass(x, cfg, geom):
         stages = {}
         for name, ms in _lib.last_timing():
             stages[name] = stages.get(name, 0.0) + ms
-        dev_ms.append((sum(stages.values()), stages))
+        total = sum(stages.values())
+        ck = c_double(0.0)
+        _lib.load().sc_debug_fused2_clock(byref(ck))
+        stages["stage_b_clock_ghz"] = ck.value                 # (the clock the part sustained inside stage B of THIS pass)
+        dev_ms.append((total, stages))
         fmt = "planes (f16 pieces)" if c._spectra.P is not None else "complex64"
         del c, coh, wpli
+    every = [{k: round(v, 3) for k, v in st.items()} for _, st in dev_ms]
     dev_ms.sort(key=lambda t: t[0])
     wall_ms.sort()
     total, stages = dev_ms[1]
-    return {"device_ms": round(total, 4), "wall_ms": round(wall_ms[1], 3), "spectra_format": fmt,
+    return {"device_ms": round(total, 4), "wall_ms": round(wall_ms[1], 3), "spectra_format": fmt, "every_pass": every,
             "stage_ms": {k: round(v, 4) for k, v in stages.items()},
             "is": "Multitaper(series in HBM) -> Connectivity.from_multitaper(dtype=complex64) -> coherence_magnitude() -> "
                   "weighted_phase_lag_index(); device_ms = the library's hipEvent timers over every kernel of the pass, wall_ms with the "

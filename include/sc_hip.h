@@ -277,16 +277,18 @@ int64_t sc_planes_row_bytes(int64_t n_signals);
  * max_k sum_n |tapers[k][n]| (the tapers as passed to stage A, i.e. / fs); d_work: 4 C bytes of device scratch */
 int sc_planes_scales_from_series_f32(const float* d_x, int64_t T, int64_t R, int64_t C, double taper_abs_sum,
                                      float* d_scale, void* d_work, void* stream);
-/* The same pass with the DYNAMIC RANGE of the series beside the scales: *d_range (device float) = max over the channels of
- * max|x| / mean|x| (finite samples).  One scale per channel comes from its largest sample, so an artefact thousands of times the
- * typical amplitude pushes the typical coefficient's trailing f16 piece into the subnormals (absolute error 2^-25 in scaled
- * units): beyond SC_PLANES_MAX_RANGE the 22 bits of the format are not delivered for the quiet windows of that channel and the
- * host keeps complex64 spectra (sc_multitaper_fft_f32) -- the planes format is a device detail, never a precision trade.
- * d_work: sc_planes_scales_work_bytes(T * R, C) bytes. */
-#define SC_PLANES_MAX_RANGE 4096.0f
+/* The same scan with the QUALITY CHECK of the format.  One scale per channel serves every window, so the format delivers its 22
+ * bits only while a channel's typical coefficient stays well above the f16 subnormals in scaled units -- which a DC offset or an
+ * artefact thousands of times the typical amplitude would prevent.  This form (a) takes the scale from the RANGE of the channel
+ * when stage A detrends (detrend_type != 0: |x - trend| <= 4 (max x - min x), a DC offset no longer enters; without detrend
+ * |x| <= max |x|), and (b) reports *d_quality (device float) = min over the channels of (typical sample magnitude: the standard
+ * deviation -- root mean square without detrend -- of the channel's QUIETEST slab of >= 128 consecutive (time, trial) rows) * scale.  The typical coefficient in scaled units is that times
+ * min_k ||tapers_k||_2; below SC_PLANES_MIN_TYPICAL the host keeps complex64 spectra (sc_multitaper_fft_f32) -- the planes
+ * format is a device detail, never a precision trade.  d_work: sc_planes_scales_work_bytes(T * R, C) bytes. */
+#define SC_PLANES_MIN_TYPICAL 2.5f
 int64_t sc_planes_scales_work_bytes(int64_t n_rows, int64_t width);
-int sc_planes_scales_range_f32(const float* d_x, int64_t T, int64_t R, int64_t C, double taper_abs_sum, float* d_scale,
-                               void* d_work, int64_t work_bytes, float* d_range, void* stream);
+int sc_planes_scales_quality_f32(const float* d_x, int64_t T, int64_t R, int64_t C, int detrend_type, double taper_abs_sum,
+                                 float* d_scale, void* d_work, int64_t work_bytes, float* d_quality, void* stream);
 /* scales from the largest |Re|, |Im| of dense complex64 rows [n_rows][C] */
 int sc_planes_scales_from_spectra_f32(const void* d_X /*float2*/, int64_t n_rows, int64_t C, float* d_scale, void* d_work,
                                       void* stream);

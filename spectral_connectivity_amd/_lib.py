@@ -105,7 +105,8 @@ SYMBOLS = {
                                              c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sc_planes_scales_from_series_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_double, c_void_p, c_void_p, c_void_p]),
     "sc_planes_scales_work_bytes": (c_int64, [c_int64, c_int64]),
-    "sc_planes_scales_range_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_double, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "sc_planes_scales_quality_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_double, c_void_p, c_void_p, c_int64, c_void_p,
+                                             c_void_p]),
     "sc_planes_scales_from_spectra_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "sc_planes_from_spectra_f32": (c_int, [c_void_p, POINTER(SpectraDesc), c_void_p, c_void_p, c_void_p]),
     "sc_spectra_from_planes_f32": (c_int, [c_void_p, POINTER(SpectraDesc), c_void_p, c_void_p, c_void_p]),
@@ -306,7 +307,7 @@ PLANES_FORMAT_FAMILIES = (PLANE_CSM, PLANE_CSM | PLANE_ABS_IM, PLANE_CSM | PLANE
 
 
 PLANES_FORMAT_MIN_CHANNELS = 44
-PLANES_MAX_RANGE = 4096.0       # SC_PLANES_MAX_RANGE of include/sc_hip.h: largest max|x| / mean|x| of a channel the format is used for
+PLANES_MIN_TYPICAL = 2.5       # SC_PLANES_MIN_TYPICAL of include/sc_hip.h: smallest typical coefficient (scaled units) the format is used for
 
 
 def planes_format_applies(n_window, n_fft, n_alloc, planes_hint, spectra_bytes=None):

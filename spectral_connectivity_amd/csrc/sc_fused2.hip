@@ -81,72 +81,103 @@ __device__ __forceinline__ float planes_mag(float v) {
     const float a = fabsf(v);
     return a <= 3.4028234e38f ? a : 0.f;
 }
-// part: per-block sums of |x| per column, [gridDim.x][width] (or nullptr): the scale kernel adds them in block order -- a
-// deterministic mean |x| per channel, against which the largest sample is judged (the dynamic-range guard, see planes_scale_kernel)
+// Per column: the largest finite |x| (and, with `part`, the largest x and the largest -x separately: the range), plus -- for the
+// quality check of the format -- per-block sums of (x - pivot) and (x - pivot)^2 around the block's own pivot (its first row: a DC
+// offset 1e5 times the signal must not cancel the variance away in float32), [gridDim.x][width][3] = {pivot, s1, s2}; the scale
+// kernel merges the blocks in float64 in a fixed order.
+__device__ __forceinline__ float planes_fin(float v) { return fabsf(v) <= 3.4028234e38f ? v : 0.f; }
 __global__ void __launch_bounds__(256) planes_absmax_kernel(const float* x, int64_t n_rows, int width, int comps, unsigned* mx, float* part) {
-    __shared__ unsigned red[1024];
-    __shared__ float sred[1024];
+    __shared__ unsigned red[2048];                     // [width] max |x| or (with part) [width] max x, [width] max -x  (offset patterns, see below)
+    __shared__ float sred[2048];                       // [rows_per_step][width][2]
     const int64_t rows_per_block = (n_rows + gridDim.x - 1) / gridDim.x;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = r0 + rows_per_block < n_rows ? r0 + rows_per_block : n_rows;
     const int tid = threadIdx.x;
-    if ((width & 3) == 0 && width <= 1024 && (((uintptr_t)x) & 15) == 0) {
+    // ordered bit pattern of a float (monotone for every finite value): max over patterns = max over values
+    auto ord = [](float v) -> unsigned { const unsigned u = __float_as_uint(v); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); };
+    if ((width & 3) == 0 && width <= 1024 && (((uintptr_t)x) & 15) == 0 && r0 < r1) {
         const int q = width >> 2;                      // float4 columns
         const int rows_per_step = 256 / q;             // >= 1 for width <= 1024
         const int cq = tid % q, ro = tid / q;
-        for (int i = tid; i < width; i += 256) red[i] = 0u;
+        for (int i = tid; i < 2 * width; i += 256) red[i] = 0u;
         __syncthreads();
-        float4 m = make_float4(0.f, 0.f, 0.f, 0.f), sm = m;
         if (ro < rows_per_step) {
+            float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (part) {
+                pv = *reinterpret_cast<const float4*>(x + r0 * width + 4 * cq);
+                pv.x = planes_fin(pv.x); pv.y = planes_fin(pv.y); pv.z = planes_fin(pv.z); pv.w = planes_fin(pv.w);
+            }
+            float4 hi = make_float4(-3.4e38f, -3.4e38f, -3.4e38f, -3.4e38f), lo = hi;      // max x, max -x
+            float4 m = make_float4(0.f, 0.f, 0.f, 0.f), s1 = m, s2 = m;
+            auto take = [&](const float4 v) {
+                if (part) {
+                    const float a0 = planes_fin(v.x), a1 = planes_fin(v.y), a2 = planes_fin(v.z), a3 = planes_fin(v.w);
+                    const bool f0 = fabsf(v.x) <= 3.4028234e38f, f1 = fabsf(v.y) <= 3.4028234e38f, f2 = fabsf(v.z) <= 3.4028234e38f,
+                               f3 = fabsf(v.w) <= 3.4028234e38f;
+                    hi.x = fmaxf(hi.x, f0 ? a0 : hi.x); hi.y = fmaxf(hi.y, f1 ? a1 : hi.y); hi.z = fmaxf(hi.z, f2 ? a2 : hi.z); hi.w = fmaxf(hi.w, f3 ? a3 : hi.w);
+                    lo.x = fmaxf(lo.x, f0 ? -a0 : lo.x); lo.y = fmaxf(lo.y, f1 ? -a1 : lo.y); lo.z = fmaxf(lo.z, f2 ? -a2 : lo.z); lo.w = fmaxf(lo.w, f3 ? -a3 : lo.w);
+                    const float d0 = f0 ? a0 - pv.x : 0.f, d1 = f1 ? a1 - pv.y : 0.f, d2 = f2 ? a2 - pv.z : 0.f, d3 = f3 ? a3 - pv.w : 0.f;
+                    s1.x += d0; s1.y += d1; s1.z += d2; s1.w += d3;
+                    s2.x = fmaf(d0, d0, s2.x); s2.y = fmaf(d1, d1, s2.y); s2.z = fmaf(d2, d2, s2.z); s2.w = fmaf(d3, d3, s2.w);
+                } else {
+                    m.x = fmaxf(m.x, planes_mag(v.x)); m.y = fmaxf(m.y, planes_mag(v.y));
+                    m.z = fmaxf(m.z, planes_mag(v.z)); m.w = fmaxf(m.w, planes_mag(v.w));
+                }
+            };
             int64_t r = r0 + ro;
             for (; r + 3 * rows_per_step < r1; r += 4 * rows_per_step) {
                 float4 v[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(x + (r + (int64_t)u * rows_per_step) * width + 4 * cq);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float a0 = planes_mag(v[u].x), a1 = planes_mag(v[u].y), a2 = planes_mag(v[u].z), a3 = planes_mag(v[u].w);
-                    m.x = fmaxf(m.x, a0); m.y = fmaxf(m.y, a1); m.z = fmaxf(m.z, a2); m.w = fmaxf(m.w, a3);
-                    sm.x += a0; sm.y += a1; sm.z += a2; sm.w += a3;
-                }
+                for (int u = 0; u < 4; ++u) take(v[u]);
             }
-            for (; r < r1; r += rows_per_step) {
-                const float4 v = *reinterpret_cast<const float4*>(x + r * width + 4 * cq);
-                const float a0 = planes_mag(v.x), a1 = planes_mag(v.y), a2 = planes_mag(v.z), a3 = planes_mag(v.w);
-                m.x = fmaxf(m.x, a0); m.y = fmaxf(m.y, a1); m.z = fmaxf(m.z, a2); m.w = fmaxf(m.w, a3);
-                sm.x += a0; sm.y += a1; sm.z += a2; sm.w += a3;
+            for (; r < r1; r += rows_per_step) take(*reinterpret_cast<const float4*>(x + r * width + 4 * cq));
+            if (part) {
+                atomicMax(red + 4 * cq, ord(hi.x)); atomicMax(red + 4 * cq + 1, ord(hi.y)); atomicMax(red + 4 * cq + 2, ord(hi.z)); atomicMax(red + 4 * cq + 3, ord(hi.w));
+                atomicMax(red + width + 4 * cq, ord(lo.x)); atomicMax(red + width + 4 * cq + 1, ord(lo.y));
+                atomicMax(red + width + 4 * cq + 2, ord(lo.z)); atomicMax(red + width + 4 * cq + 3, ord(lo.w));
+                float* sr = sred + (ro * width + 4 * cq) * 2;          // rows_per_step * width * 2 <= 2048 floats
+                sr[0] = s1.x; sr[1] = s2.x; sr[2] = s1.y; sr[3] = s2.y; sr[4] = s1.z; sr[5] = s2.z; sr[6] = s1.w; sr[7] = s2.w;
+            } else {
+                atomicMax(red + 4 * cq, __float_as_uint(m.x)); atomicMax(red + 4 * cq + 1, __float_as_uint(m.y));
+                atomicMax(red + 4 * cq + 2, __float_as_uint(m.z)); atomicMax(red + 4 * cq + 3, __float_as_uint(m.w));
             }
-            atomicMax(red + 4 * cq, __float_as_uint(m.x)); atomicMax(red + 4 * cq + 1, __float_as_uint(m.y));
-            atomicMax(red + 4 * cq + 2, __float_as_uint(m.z)); atomicMax(red + 4 * cq + 3, __float_as_uint(m.w));
-            *reinterpret_cast<float4*>(sred + ro * width + 4 * cq) = sm;          // rows_per_step * width <= 1024 floats
         }
         __syncthreads();
         for (int col = tid; col < width; col += 256) {
-            if (red[col]) atomicMax(mx + col / comps, red[col]);        // non-negative floats order like unsigned
-            if (part) {
-                float t = 0.f;
-                for (int k = 0; k < rows_per_step; ++k) t += sred[k * width + col];          // fixed order
-                part[(int64_t)blockIdx.x * width + col] = t;
+            if (!part) {
+                if (red[col]) atomicMax(mx + col / comps, red[col]);        // non-negative floats order like unsigned
+                continue;
             }
+            if (red[col]) atomicMax(mx + col, red[col]);                    // (comps == 1 on this path) ordered patterns; 0 = no finite sample
+            if (red[width + col]) atomicMax(mx + width + col, red[width + col]);
+            float t1 = 0.f, t2 = 0.f;
+            for (int k = 0; k < rows_per_step; ++k) { t1 += sred[(k * width + col) * 2]; t2 += sred[(k * width + col) * 2 + 1]; }     // fixed order
+            float* o = part + ((int64_t)blockIdx.x * width + col) * 3;
+            o[0] = planes_fin(x[r0 * width + col]); o[1] = t1; o[2] = t2;
         }
         return;
     }
     for (int col = tid; col < width; col += 256) {
-        float m = 0.f, t = 0.f;
-        for (int64_t r = r0; r < r1; ++r) { const float a = planes_mag(x[r * width + col]); m = fmaxf(m, a); t += a; }
-        if (m > 0.f) atomicMax(mx + col / comps, __float_as_uint(m));
-        if (part) part[(int64_t)blockIdx.x * width + col] = t;
+        float m = 0.f, hi = -3.4e38f, lo = -3.4e38f, t1 = 0.f, t2 = 0.f;
+        const float pv = (part && r0 < r1) ? planes_fin(x[r0 * width + col]) : 0.f;
+        bool any = false;
+        for (int64_t r = r0; r < r1; ++r) {
+            const float v = x[r * width + col];
+            m = fmaxf(m, planes_mag(v));
+            if (fabsf(v) <= 3.4028234e38f) { any = true; hi = fmaxf(hi, v); lo = fmaxf(lo, -v); const float d = v - pv; t1 += d; t2 = fmaf(d, d, t2); }
+        }
+        if (!part) { if (m > 0.f) atomicMax(mx + col / comps, __float_as_uint(m)); continue; }
+        if (any) { atomicMax(mx + col, ord(hi)); atomicMax(mx + width + col, ord(lo)); }
+        float* o = part + ((int64_t)blockIdx.x * width + col) * 3;
+        o[0] = pv; o[1] = t1; o[2] = t2;
     }
 }
-// range (optional): mx[C] is followed by one word that receives the largest max|x| / mean|x| over the channels (bit pattern of
-// a non-negative float).  A channel whose largest sample is thousands of times its typical one pushes the typical coefficient's
-// trailing f16 piece into the subnormals (sc_hip.h: sc_planes_scales_range_f32); the host reads the ratio and keeps complex64
-// spectra beyond SC_PLANES_MAX_RANGE.
-__global__ void planes_scale_kernel(unsigned* mx, int C, float factor, float* scale, const float* part, int n_blocks, int comps,
-                                    double n_samples, int want_range) {
+// Largest-magnitude form (scales from spectra, and the series form without the quality check): one thread per channel.
+__global__ void planes_scale_kernel(const unsigned* mx, int C, float factor, float* scale) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const float top = __uint_as_float(mx[c]);
-    const float b = top * factor;
+    const float b = __uint_as_float(mx[c]) * factor;
     float s = 1.f;
     if (b > 0.f && b < 3.0e38f) {
         int e;
@@ -157,60 +188,97 @@ __global__ void planes_scale_kernel(unsigned* mx, int C, float factor, float* sc
     }
     scale[c] = s;
     scale[C + c] = 1.f / s;
-    if (want_range && part) {
-        double t = 0.0;
-        const int width = C * comps;
-        for (int blk = 0; blk < n_blocks; ++blk)
-            for (int k = 0; k < comps; ++k) t += (double)part[(int64_t)blk * width + c * comps + k];
-        const double mean = t / n_samples;
-        const float ratio = (mean > 0.0 && top > 0.f) ? (float)((double)top / mean) : 0.f;
-        atomicMax(mx + C, __float_as_uint(ratio));
-    }
 }
-static int planes_scales(const float* d_x, int64_t n_rows, int C, int comps, float factor, float* d_scale, void* d_work, int64_t work_bytes,
-                         float* d_range, void* stream) {
+// Series form with the quality check, one wave per channel.  mx: [C] ordered pattern of max x, [C] of max -x, then one word that
+// receives min over the channels of (typical sample magnitude of the channel's quietest block x scale) as the bit pattern of a
+// non-negative float.
+//   detrend on:  |x - trend| <= 4 (max x - min x): the scale ignores a DC offset; typical magnitude = a block's standard deviation
+//   detrend off: |x| <= max |x|; typical magnitude = a block's root mean square
+// rows_per_block: rows of x in every block of the statistics kernel (the last one may hold fewer)
+__global__ void __launch_bounds__(64) planes_scale_quality_kernel(unsigned* mx, int C, float taper_abs_sum, int detrend, float* scale,
+                                                                  const float* part, int n_blocks, int64_t rows_per_block, int64_t n_rows) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    auto unord = [](unsigned p) -> float { return __uint_as_float((p & 0x80000000u) ? (p & 0x7fffffffu) : ~p); };
+    const unsigned ph = mx[c], pl = mx[C + c];
+    const bool any = ph != 0u && pl != 0u;
+    const float hi = any ? unord(ph) : 0.f, lo = any ? -unord(pl) : 0.f;          // max x, min x
+    const float amp = detrend ? 4.f * (hi - lo) : fmaxf(fabsf(hi), fabsf(lo));
+    const float b = amp * taper_abs_sum;
+    float s = 1.f;
+    if (b > 0.f && b < 3.0e38f) {
+        int e;
+        (void)frexpf(b, &e);
+        int k = 15 - e;
+        k = k < -100 ? -100 : (k > 100 ? 100 : k);
+        s = ldexpf(1.f, k);
+    }
+    if (lane == 0) { scale[c] = s; scale[C + c] = 1.f / s; }
+    // The typical magnitude is taken from the QUIETEST block of rows (a slab of >= 128 consecutive (time, trial) rows), not from the
+    // whole series: an artefact inflates the overall variance with itself and would hide the very stretches it starves of precision;
+    // blocks without any variation (flat / zero-padded stretches: their coefficients are exact zeros after the detrend) do not count.
+    float quiet = 3.4e38f;
+    for (int blk = lane; blk < n_blocks; blk += 64) {
+        const int64_t rb = (int64_t)blk * rows_per_block;
+        const double nb = (double)((rb + rows_per_block < n_rows ? rb + rows_per_block : n_rows) - rb);
+        if (nb < 2.0) continue;
+        const float* o = part + ((int64_t)blk * C + c) * 3;
+        const double s1 = (double)o[1], s2 = (double)o[2];
+        const double var = (s2 - s1 * s1 / nb) / nb, mean = (double)o[0] + s1 / nb;
+        if (!(var > 1e-12 * (mean * mean + 1e-300))) continue;           // (no variation beyond the rounding of a constant)
+        const float typ = (float)sqrt(detrend ? var : var + mean * mean);
+        quiet = fminf(quiet, typ);
+    }
+    for (int off = 32; off >= 1; off >>= 1) quiet = fminf(quiet, __shfl_down(quiet, off, 64));
+    if (lane == 0 && quiet < 3.0e38f && b > 0.f && b < 3.0e38f) atomicMin(mx + 2 * C, __float_as_uint(quiet * s));
+}
+static int64_t planes_stat_blocks(int64_t n_rows) {
+    int64_t blocks = n_rows / 128;
+    return blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+}
+// bytes of device scratch the quality form needs: max x / max -x per channel, the quality word, the per-block (pivot, s1, s2)
+extern "C" int64_t sc_planes_scales_work_bytes(int64_t n_rows, int64_t width) {
+    return 4 * ((2 * width + 1 + 3) / 4 * 4) + 4 * 3 * planes_stat_blocks(n_rows) * width;
+}
+static int planes_scales(const float* d_x, int64_t n_rows, int C, int comps, float factor, float* d_scale, void* d_work, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     unsigned* mx = (unsigned*)d_work;
-    int64_t blocks = n_rows / 128;
-    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
-    const int64_t head = ((int64_t)C + 1 + 3) / 4 * 4;                       // max bits [C], the ratio word, padded to 16 bytes
-    float* part = nullptr;
-    if (d_range) {
-        SC_REQUIRE(work_bytes >= sc_planes_scales_work_bytes(n_rows, (int64_t)C * comps), "work buffer smaller than sc_planes_scales_work_bytes");
-        part = (float*)d_work + head;
-    }
-    SC_CHECK_HIP(hipMemsetAsync(mx, 0, sizeof(unsigned) * (C + (d_range ? 1 : 0)), s));
-    hipLaunchKernelGGL(planes_absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, s, d_x, n_rows, C * comps, comps, mx, part);
-    hipLaunchKernelGGL(planes_scale_kernel, dim3((C + 63) / 64), dim3(64), 0, s, mx, C, factor, d_scale, part, (int)blocks, comps,
-                       (double)n_rows * comps, d_range ? 1 : 0);
-    if (d_range) SC_CHECK_HIP(hipMemcpyAsync(d_range, mx + C, sizeof(float), hipMemcpyDeviceToDevice, s));
+    SC_CHECK_HIP(hipMemsetAsync(mx, 0, sizeof(unsigned) * C, s));
+    hipLaunchKernelGGL(planes_absmax_kernel, dim3((unsigned)planes_stat_blocks(n_rows)), dim3(256), 0, s, d_x, n_rows, C * comps, comps, mx, (float*)nullptr);
+    hipLaunchKernelGGL(planes_scale_kernel, dim3((C + 63) / 64), dim3(64), 0, s, mx, C, factor, d_scale);
     SC_CHECK_HIP(hipGetLastError());
     return SC_OK;
-}
-// bytes of device scratch the range form needs: the per-channel maxima, the ratio word and the per-block column sums
-extern "C" int64_t sc_planes_scales_work_bytes(int64_t n_rows, int64_t width) {
-    int64_t blocks = n_rows / 128;
-    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
-    return 4 * ((width + 1 + 3) / 4 * 4) + 4 * blocks * width;
 }
 // d_work: 4 * n_signals bytes of scratch
 extern "C" int sc_planes_scales_from_series_f32(const float* d_x, int64_t T, int64_t R, int64_t C, double taper_abs_sum,
                                                 float* d_scale, void* d_work, void* stream) {
     ScTimed timed_("planes_scales", stream);
     SC_REQUIRE(d_x && d_scale && d_work && T >= 1 && R >= 1 && C >= 1 && taper_abs_sum > 0.0, "bad argument");
-    return planes_scales(d_x, T * R, (int)C, 1, (float)(8.0 * taper_abs_sum), d_scale, d_work, 0, nullptr, stream);
+    return planes_scales(d_x, T * R, (int)C, 1, (float)(8.0 * taper_abs_sum), d_scale, d_work, stream);
 }
-// the same pass, and the dynamic range of the series beside the scales: *d_range (device) = max over channels of
-// max|x| / mean|x|; d_work: sc_planes_scales_work_bytes(T * R, C) bytes
-extern "C" int sc_planes_scales_range_f32(const float* d_x, int64_t T, int64_t R, int64_t C, double taper_abs_sum, float* d_scale,
-                                          void* d_work, int64_t work_bytes, float* d_range, void* stream) {
+// The same scan with the quality check of the format (sc_hip.h): scales that ignore a DC offset when stage A detrends, and
+// *d_quality (device) = min over the channels of (typical sample magnitude) * scale; d_work: sc_planes_scales_work_bytes(T * R, C)
+extern "C" int sc_planes_scales_quality_f32(const float* d_x, int64_t T, int64_t R, int64_t C, int detrend_type, double taper_abs_sum,
+                                            float* d_scale, void* d_work, int64_t work_bytes, float* d_quality, void* stream) {
     ScTimed timed_("planes_scales", stream);
-    SC_REQUIRE(d_x && d_scale && d_work && d_range && T >= 1 && R >= 1 && C >= 1 && taper_abs_sum > 0.0, "bad argument");
-    return planes_scales(d_x, T * R, (int)C, 1, (float)(8.0 * taper_abs_sum), d_scale, d_work, work_bytes, d_range, stream);
+    SC_REQUIRE(d_x && d_scale && d_work && d_quality && T >= 1 && R >= 1 && C >= 1 && taper_abs_sum > 0.0, "bad argument");
+    SC_REQUIRE(detrend_type >= 0 && detrend_type <= 2, "unknown detrend_type");
+    SC_REQUIRE(work_bytes >= sc_planes_scales_work_bytes(T * R, C), "work buffer smaller than sc_planes_scales_work_bytes");
+    hipStream_t s = (hipStream_t)stream;
+    unsigned* mx = (unsigned*)d_work;
+    const int64_t n_rows = T * R, blocks = planes_stat_blocks(n_rows), head = (2 * C + 1 + 3) / 4 * 4;
+    float* part = (float*)d_work + head;
+    SC_CHECK_HIP(hipMemsetAsync(mx, 0, sizeof(unsigned) * 2 * C, s));
+    SC_CHECK_HIP(hipMemsetAsync(mx + 2 * C, 0x7f, sizeof(unsigned), s));            // 0x7f7f7f7f = 3.4e38: "no channel yet"
+    hipLaunchKernelGGL(planes_absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, s, d_x, n_rows, (int)C, 1, mx, part);
+    hipLaunchKernelGGL(planes_scale_quality_kernel, dim3((unsigned)C), dim3(64), 0, s, mx, (int)C, (float)taper_abs_sum,
+                       detrend_type != SC_DETREND_NONE ? 1 : 0, d_scale, part, (int)blocks, (n_rows + blocks - 1) / blocks, n_rows);
+    SC_CHECK_HIP(hipMemcpyAsync(d_quality, mx + 2 * C, sizeof(float), hipMemcpyDeviceToDevice, s));
+    SC_CHECK_HIP(hipGetLastError());
+    return SC_OK;
 }
 extern "C" int sc_planes_scales_from_spectra_f32(const void* d_X, int64_t n_rows, int64_t C, float* d_scale, void* d_work, void* stream) {
     SC_REQUIRE(d_X && d_scale && d_work && n_rows >= 1 && C >= 1, "bad argument");
-    return planes_scales((const float*)d_X, n_rows, (int)C, 2, 1.0f, d_scale, d_work, 0, nullptr, stream);          // dense rows of C complex64
+    return planes_scales((const float*)d_X, n_rows, (int)C, 2, 1.0f, d_scale, d_work, stream);          // dense rows of C complex64
 }
 
 // ---- conversions between complex64 spectra and the planes format (uploaded coefficients, consumers of complex64) -------

@@ -112,10 +112,15 @@ class DeviceSpectra:
         self.n_fft = int(n_fft)
         self.real_input = bool(real_input)   # negative bins are conj mirrors of positive ones
         self.f64 = X is not None and X.dtype == torch.complex128
-        # planes format written by stage A: a device scalar, the largest max|x| / mean|x| over the channels of the series the scales
-        # came from -- the caller that owns the series compares it with _lib.PLANES_MAX_RANGE (Multitaper.device_spectra does)
-        self.range = None
+        # planes format written by stage A: ``quality`` is a device scalar, min over the channels of (typical sample magnitude x
+        # channel scale); times ``taper_l2_min`` it is the typical coefficient in scaled units, which the caller that owns the series
+        # compares with _lib.PLANES_MIN_TYPICAL (Multitaper.device_spectra does; planes_typical_coefficient() reads it back)
+        self.quality = self.taper_l2_min = None
         self.device = X.device if X is not None else P.device
+
+    def planes_typical_coefficient(self):
+        """Smallest typical coefficient over the channels, in the scaled units of the f16 pieces (one small read-back)."""
+        return float(self.quality.item()) * self.taper_l2_min
 
     @property
     def X(self):
@@ -157,13 +162,15 @@ class DeviceSpectra:
                            reduce_taper=int(2 in axes), reserved=0)
 
 
-def _taper_abs_sum(tapers_over_fs):
-    """max_k sum_n |h_k[n]| (the bound behind the channel scales of the planes format): a property of the tapers, kept ON the
-    tensor object together with its version counter -- one device synchronisation per taper tensor, not per transform."""
-    cached = getattr(tapers_over_fs, "_sc_abs_sum", None)
+def _taper_norms(tapers_over_fs):
+    """(max_k sum_n |h_k[n]|, min_k ||h_k||_2): the bound behind the channel scales of the planes format and the size of a typical
+    coefficient per unit of sample spread -- properties of the tapers, kept ON the tensor object together with its version
+    counter: one device synchronisation per taper tensor, not per transform."""
+    cached = getattr(tapers_over_fs, "_sc_norms", None)
     if cached is None or cached[1] != tapers_over_fs._version:
-        cached = (float(tapers_over_fs.abs().sum(dim=1).max().item()), tapers_over_fs._version)
-        tapers_over_fs._sc_abs_sum = cached
+        both = torch.stack([tapers_over_fs.abs().sum(dim=1).max(), tapers_over_fs.pow(2).sum(dim=1).sqrt().min()]).tolist()
+        cached = ((float(both[0]), float(both[1])), tapers_over_fs._version)
+        tapers_over_fs._sc_norms = cached
     return cached[0]
 
 
@@ -195,9 +202,10 @@ def multitaper_spectra(x, tapers_over_fs, n_window, n_step, n_fft, n_windows, de
     ``planes_hint``: the accumulator families the caller will ask for.  Any family sc_fused2.hip serves, 44 ... 256 signals, a
     power-of-two window of 64 ... 1024 samples and at least 256 MB of spectra (_lib.planes_format_applies): the spectra are
     written in the planes format (two f16 pieces per real number) -- a scan of the series for the channel scales, then the same
-    fused transform.  The scan also reports the dynamic range of the series (``DeviceSpectra.range``): one scale per channel
-    serves every window, so the format is meant for series whose largest sample is within _lib.PLANES_MAX_RANGE of the typical
-    one; Multitaper.device_spectra checks and re-runs the transform into complex64 otherwise.
+    fused transform.  The scan also reports how large a typical coefficient will be in the format's scaled units
+    (``DeviceSpectra.planes_typical_coefficient()``): one scale per channel serves every window, so the format is meant for
+    series without samples hundreds of times the typical amplitude; Multitaper.device_spectra checks against
+    _lib.PLANES_MIN_TYPICAL and re-runs the transform into complex64 otherwise.
     """
     lib = _lib.load()
     T, R, C_real = x.shape
@@ -221,16 +229,17 @@ def multitaper_spectra(x, tapers_over_fs, n_window, n_step, n_fft, n_windows, de
         scale = torch.empty((2 * C,), dtype=torch.float32, device=x.device)
         work_bytes = int(lib.sc_planes_scales_work_bytes(T * R, C))
         work = torch.empty((work_bytes,), dtype=torch.uint8, device=x.device)
-        rng = torch.empty((1,), dtype=torch.float32, device=x.device)     # max over channels of max|x| / mean|x| (DeviceSpectra.range)
-        _lib.check(lib.sc_planes_scales_range_f32(_ptr(x), T, R, C, _taper_abs_sum(tapers_over_fs), _ptr(scale), _ptr(work), work_bytes,
-                                                  _ptr(rng), _stream()), "sc_planes_scales_range_f32")
+        quality = torch.empty((1,), dtype=torch.float32, device=x.device)      # DeviceSpectra.quality, see there
+        abs_sum, l2_min = _taper_norms(tapers_over_fs)
+        _lib.check(lib.sc_planes_scales_quality_f32(_ptr(x), T, R, C, _lib.DETREND[detrend_type], abs_sum, _ptr(scale), _ptr(work),
+                                                    work_bytes, _ptr(quality), _stream()), "sc_planes_scales_quality_f32")
         _lib.check(lib.sc_multitaper_fft_planes_f32(_ptr(x), T, R, C, L, n_step, n_windows, n_fft, _ptr(tapers_over_fs), K,
                                                     _lib.DETREND[detrend_type], _ptr(twiddles(n_fft, x.device)), _ptr(scale),
                                                     _ptr(P), _stream()), "sc_multitaper_fft_planes_f32")
         if mark:
             mark("mtfft_fused")
         sp = DeviceSpectra(None, (F, n_windows, R, K, C_real), strides, n_fft, real_input=True, C_alloc=C, P=P, scale=scale)
-        sp.range = rng
+        sp.quality, sp.taper_l2_min = quality, l2_min
         return sp
     if use_fused:
         # one kernel: window + detrend + taper + FFT + transposed store (sc_mtfft.hip)

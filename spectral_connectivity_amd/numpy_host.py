@@ -257,17 +257,18 @@ class NumpyHost:
             P = self.alloc(F * W * R * K * int(lib.sc_planes_row_bytes(C_alloc)))
             work_bytes = int(lib.sc_planes_scales_work_bytes(T * R, C_alloc))
             scale, work, rng = self.alloc(2 * C_alloc * 4), self.alloc(work_bytes), self.alloc(4)
-            h_abs_sum = float(np.abs(np.asarray(tapers.T / m.sampling_frequency, dtype=np.float32)).sum(axis=1).max())
-            _lib.check(lib.sc_planes_scales_range_f32(x.ptr, T, R, C_alloc, h_abs_sum, scale.ptr, work.ptr, work_bytes, rng.ptr,
-                                                      self.stream), "sc_planes_scales_range_f32")
+            h32 = np.asarray(tapers.T / m.sampling_frequency, dtype=np.float32)
+            h_abs_sum, h_l2_min = float(np.abs(h32).sum(axis=1).max()), float(np.sqrt((h32.astype(np.float64) ** 2).sum(axis=1)).min())
+            _lib.check(lib.sc_planes_scales_quality_f32(x.ptr, T, R, C_alloc, detrend, h_abs_sum, scale.ptr, work.ptr, work_bytes, rng.ptr,
+                                                        self.stream), "sc_planes_scales_quality_f32")
             _lib.check(lib.sc_multitaper_fft_planes_f32(x.ptr, T, R, C_alloc, L, step, W, N, h.ptr, K, detrend,
                                                         self._twiddles[N].ptr, scale.ptr, P.ptr, self.stream),
                        "sc_multitaper_fft_planes_f32")
-            # the dynamic-range guard of the format (Multitaper.device_spectra of the PyTorch host does the same): one scale per
-            # channel serves every window, so a channel with a sample thousands of times its typical one keeps complex64
-            ratio = float(self.download(rng, (1,), np.float32)[0])
+            # the quality check of the format (Multitaper.device_spectra of the PyTorch host does the same): one scale per channel
+            # serves every window, so a channel with samples far outside its usual range keeps complex64
+            ratio = float(self.download(rng, (1,), np.float32)[0]) * h_l2_min
             work.free(); rng.free()
-            if ratio <= _lib.PLANES_MAX_RANGE:
+            if ratio >= _lib.PLANES_MIN_TYPICAL:
                 for b in (x, h):
                     b.free()
                 return dict(X=None, P=P, scale=scale, F=F, W=W, R=R, K=K, C=C, C_alloc=C_alloc, N=N)

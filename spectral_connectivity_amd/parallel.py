@@ -158,8 +158,11 @@ def _agreed_direct_exchange(accum, world, per, fpb, group):
     by one all-reduce of a failure flag -- if the direct form raised on ANY rank (a backend without all-to-all, RCCL missing for
     SC_EXCHANGE=library on one of them) every rank takes the library reduce-scatter from then on, so that no two ranks ever issue
     different collectives.  Once agreed, a failure of the direct exchange is an error (raised), not a silent switch."""
-    fn = _library_blocks if exchange_algorithm() == "library" else _direct_blocks
-    key = id(group) if group is not None else 0
+    # (the C ABI's exchange carries float32 records on the GPU; double records of the float64 engine, or records on the host,
+    #  take the torch form -- the same on every rank, so not a failure)
+    library = exchange_algorithm() == "library" and accum.is_cuda and accum.dtype == torch.float32
+    fn = _library_blocks if library else _direct_blocks
+    key = (id(group) if group is not None else 0, library)
     if key in _direct_agreed:
         blocks = fn(accum, world, per, fpb, group)
         if blocks is None:

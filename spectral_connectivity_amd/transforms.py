@@ -263,10 +263,22 @@ def dpss_windows(n_time_samples_per_window, time_halfbandwidth_product, n_tapers
 
 def _make_tapers(n_time_samples_per_window, sampling_frequency, time_halfbandwidth_product, n_tapers,
                  is_low_bias=True):
-    """(L, K') tapers scaled by sqrt(fs) (reference transforms.py:1408-1440)."""
-    tapers, _ = dpss_windows(n_time_samples_per_window, time_halfbandwidth_product, n_tapers,
-                             is_low_bias=is_low_bias)
-    return tapers.T * np.sqrt(sampling_frequency)
+    """(L, K') tapers scaled by sqrt(fs) (reference transforms.py:1408-1440).  The DPSS sequences depend on the window
+    geometry alone (1.8 ms of LAPACK at 256 samples, 14 ms at 4096: more than the device pipeline of a small request), so the last
+    few geometries are remembered -- like an FFT plan -- and every caller gets its own copy."""
+    key = (int(n_time_samples_per_window), float(time_halfbandwidth_product), int(n_tapers), bool(is_low_bias))
+    hit = _taper_memo.get(key)
+    if hit is None:
+        tapers, _ = dpss_windows(n_time_samples_per_window, time_halfbandwidth_product, n_tapers,
+                                 is_low_bias=is_low_bias)
+        hit = np.ascontiguousarray(tapers.T)
+        if len(_taper_memo) >= 8:
+            _taper_memo.pop(next(iter(_taper_memo)))
+        _taper_memo[key] = hit
+    return hit * np.sqrt(sampling_frequency)
+
+
+_taper_memo = {}
 
 
 def _n_windows(n_time, window, step):
@@ -641,16 +653,17 @@ class Multitaper:
                     self.n_fft_samples, self.n_time_windows, self.detrend_type, n_signals=n_signals,
                     planes_hint=planes_hint)
                 self.device_format_note = None
-                if sp.P is not None and sp.range is not None:
-                    # The planes format takes ONE scale per channel from its largest sample: a channel with an artefact thousands
-                    # of times its typical amplitude would hold the quiet windows' coefficients in the f16 subnormals.  The
-                    # scale pass measured max|x| / mean|x| on the way; beyond the limit the transform runs again into complex64
-                    # (one small read-back: the first transform of an object, never a step of a loop).
-                    ratio = float(sp.range.item())
-                    if not ratio <= _lib.PLANES_MAX_RANGE:
+                if sp.P is not None and sp.quality is not None:
+                    # The planes format takes ONE scale per channel from the range of its samples: a channel with an artefact
+                    # hundreds of times its typical amplitude would hold the quiet windows' coefficients near the f16
+                    # subnormals.  The scale pass measured the typical magnitude on the way; below the limit the transform
+                    # runs again into complex64 (one small read-back: the first transform of an object, never a step of a loop).
+                    typical = sp.planes_typical_coefficient()
+                    if not typical >= _lib.PLANES_MIN_TYPICAL:
                         self.device_format_note = (
-                            f"a channel's largest sample is {ratio:.3g} times its mean magnitude (limit {_lib.PLANES_MAX_RANGE:g}): "
-                            "spectra kept as complex64 instead of the two-piece f16 format")
+                            f"the typical coefficient of a channel would be {typical:.3g} in the scaled units of the two-piece f16 "
+                            f"format (limit {_lib.PLANES_MIN_TYPICAL:g}: a sample far outside the channel's usual range): "
+                            "spectra kept as complex64")
                         logger.warning("spectral_connectivity_amd: " + self.device_format_note)
                         del sp
                         sp = engine.multitaper_spectra(

@@ -335,13 +335,15 @@ def test_stage_b_on_planes_three_term_sweep(n_obs, C, debug_env):
           + ", ".join(f"{k}: {v[0]:.2f} / {v[1]:.1e}" for k, v in worst.items()))
 
 
-@pytest.mark.parametrize("artefact", [1e3, 1e5, 1e7])
-def test_one_artefact_sample_in_a_channel(artefact):
-    """The format has ONE scale per channel, taken from its largest sample.  One sample 1e3 / 1e5 / 1e7 times the channel's
-    standard deviation (an electrode pop) in one trial: the quiet windows of that channel must keep their accuracy.  Up to
-    _lib.PLANES_MAX_RANGE (max|x| / mean|x| of 4096) the format is kept and the measures of EVERY window stay as close to the float64
-    oracle as the complex64 engine's; beyond, Multitaper says so (device_format_note, a logged warning) and the spectra are
-    complex64 -- the same numbers as with SC_PLANES_FORMAT=0."""
+@pytest.mark.parametrize("artefact,offset", [(30.0, 0.0), (100.0, 0.0), (1e3, 0.0), (1e5, 0.0), (1e7, 0.0), (0.0, 3e3), (100.0, 3e3)])
+def test_one_artefact_sample_or_a_dc_offset_in_a_channel(artefact, offset):
+    """The format has ONE scale per channel.  (a) One sample 30 ... 1e7 times the channel's standard deviation (an electrode pop) in
+    one trial: the quiet windows of that channel must keep their accuracy.  While the typical coefficient stays above
+    _lib.PLANES_MIN_TYPICAL in scaled units (artefacts up to ~250 standard deviations at this window length) the format is kept and
+    the measures of EVERY quiet window stay as close to the float64 oracle as the complex64 engine's; beyond, Multitaper says so
+    (device_format_note, a logged warning) and the spectra are complex64 -- the same numbers as with SC_PLANES_FORMAT=0.
+    (b) A DC offset thousands of times the signal (raw EEG / MEG): with a detrend active the scales come from the channel's RANGE, so
+    the offset costs the format nothing (round 4 took the scale from max |x|: the coefficients then sat 3e3 times lower in scaled units)."""
     import os
     _dev()
     rng = np.random.default_rng(7)
@@ -349,14 +351,16 @@ def test_one_artefact_sample_in_a_channel(artefact):
     t = np.arange(T) / 1000.0
     x = rng.standard_normal((T, R, C))
     x += 0.6 * np.sin(2 * np.pi * 60 * t[:, None, None] + 2 * np.pi * np.arange(C)[None, None, :] / C)
-    x[10, 0, 3] = artefact                          # window 0 of trial 0 only (samples 0 ... 255 with a 128-sample step: windows 0)
+    if artefact:
+        x[10, 0, 3] = artefact                      # window 0 of trial 0 only (samples 0 ... 255 with a 128-sample step)
+    x[:, :, 5] += offset
     x = x.astype(np.float32)
     kw = dict(sampling_frequency=1000, time_halfbandwidth_product=3, n_time_samples_per_window=L, n_time_samples_per_step=step)
     m = Multitaper(x, **kw)
     c = Connectivity.from_multitaper(m, dtype=np.complex64)
     coh, wpli = c.coherence_magnitude(), c.weighted_phase_lag_index()
     kept = c._spectra.P is not None
-    assert kept == (artefact < 1e4), (artefact, m.device_format_note)
+    assert kept == (artefact <= 100.0), (artefact, offset, m.device_format_note)
     assert (m.device_format_note is None) == kept
     os.environ["SC_PLANES_FORMAT"] = "0"
     try:
@@ -367,16 +371,19 @@ def test_one_artefact_sample_in_a_channel(artefact):
         del os.environ["SC_PLANES_FORMAT"]
     coef, _ = so.multitaper_fft(x.astype(np.float64), fs=1000, NW=3, n_time_samples_per_window=L, n_time_samples_per_step=step)
     ref_coh, ref_wpli = so.coherence_magnitude(coef), so.weighted_phase_lag_index(coef)
-    quiet = slice(1, None)                          # the windows without the artefact
-    np.testing.assert_allclose(coh[quiet], ref_coh[quiet], rtol=2e-4, atol=2e-5, equal_nan=True)
-    np.testing.assert_allclose(wpli[quiet], ref_wpli[quiet], rtol=2e-4, atol=2e-5)
+    quiet = slice(1, None) if artefact else slice(None)          # the windows without the artefact
     e_p = np.nanmax(np.abs(coh - ref_coh)[quiet]), np.abs(wpli - ref_wpli)[quiet].max()
     e_c = np.nanmax(np.abs(coh64 - ref_coh)[quiet]), np.abs(wpli64 - ref_wpli)[quiet].max()
-    print(f"\n  artefact x{artefact:g}: planes kept {kept}; quiet windows vs float64 oracle: coherence {e_p[0]:.2e} (complex64 engine {e_c[0]:.2e}), "
-          f"wPLI {e_p[1]:.2e} ({e_c[1]:.2e})")
+    print(f"\n  artefact x{artefact:g}, offset {offset:g}: planes kept {kept}" + (f" (typical coefficient {c._spectra.planes_typical_coefficient():.1f})" if kept else "")
+          + f"; quiet windows vs float64 oracle: coherence {e_p[0]:.2e} (complex64 engine {e_c[0]:.2e}), wPLI {e_p[1]:.2e} ({e_c[1]:.2e})")
+    # 30 observations per bin: what the float32 transform leaves of a measure is the same in both device formats; the format must not add to it
     assert e_p[0] <= 2 * e_c[0] + 2e-6 and e_p[1] <= 2 * e_c[1] + 2e-6
+    if not offset:
+        np.testing.assert_allclose(coh[quiet], ref_coh[quiet], rtol=2e-4, atol=5e-5, equal_nan=True)
+        np.testing.assert_allclose(wpli[quiet], ref_wpli[quiet], rtol=2e-4, atol=5e-5)
     if not kept:
         np.testing.assert_array_equal(coh, coh64)
         np.testing.assert_array_equal(wpli, wpli64)
-    # the window that holds the artefact: the float32 transform itself is limited there (in either format); the two engines agree
-    np.testing.assert_allclose(coh[0], coh64[0], rtol=0, atol=5e-5, equal_nan=True)
+    if artefact:
+        # the window that holds the artefact: the float32 transform itself is limited there (in either format); the two engines agree
+        np.testing.assert_allclose(coh[0], coh64[0], rtol=0, atol=5e-5, equal_nan=True)
