@@ -26,6 +26,13 @@ bool sc_internal_causal_fft_supported(int64_t N);
 int sc_internal_causal_fft_pair(void* d_A, const int32_t* d_status, int64_t n_problems, int C, int64_t N,
                                 hipStream_t st);
 
+// sc_wilson_pair.hip: pairwise Granger with the 2 x 2 Wilson iteration of a pair resident on one compute unit
+bool sc_internal_granger_resident_applies(int64_t n_freq_accum, int64_t N);
+int sc_internal_granger_resident(const void* d_accum, int64_t n_groups, int64_t N, int64_t C, uint32_t planes, int64_t n_obs,
+                                 const int32_t* d_pairs, int64_t n_pairs, double tol, int max_iter, void* d_work, size_t work_bytes,
+                                 int keep_output, double* d_out, int32_t* d_n_iter, int32_t* d_status, int32_t* h_summary,
+                                 hipStream_t st);
+
 // sc_timing.hip: brackets the launches of an entry point with two hipEvents on its stream while sc_timing_enable(1)
 struct ScTimed {
     int slot;

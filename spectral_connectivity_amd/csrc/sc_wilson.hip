@@ -472,6 +472,12 @@ extern "C" int sc_granger_pairwise_f64(const void* d_accum, int64_t n_groups, in
     sc_granger_workspace_bytes(n_groups, n_pairs, N, &need);
     SC_REQUIRE(work_bytes >= need, "workspace too small");
     hipStream_t st = (hipStream_t)stream;
+    if (sc_internal_granger_resident_applies(n_freq_accum, N)) {
+        // records of real series, N = 256 ... 4096: the whole iteration of a pair on one compute unit (sc_wilson_pair.hip)
+        SC_REQUIRE(max_iter >= 1, "max_iterations must be positive");
+        return sc_internal_granger_resident(d_accum, n_groups, N, C, planes, n_obs, d_pairs, n_pairs, tol, max_iter, d_work, work_bytes,
+                                            (flags & SC_GRANGER_KEEP_OUTPUT) ? 1 : 0, d_out, d_n_iter, d_status, h_summary, st);
+    }
     WilsonDims d;
     d.P = n_groups * n_pairs; d.N = N; d.n_pairs = n_pairs; d.F = n_freq_accum; d.C = (int)C;
     d.NB = sc_n_blocks(C); d.n_tiles = sc_n_tiles(d.NB);

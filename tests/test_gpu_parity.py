@@ -394,6 +394,49 @@ def test_f12_cholesky_failure_outcome(sc, golden):
             assert np.all(np.isnan(side) | (np.abs(side) < 1e-9)), (i, j)
 
 
+@pytest.mark.parametrize("N,W", [(256, 3), (512, 2), (1024, 2), (2048, 1), (4096, 1)])
+def test_granger_resident_kernel_equals_the_batched_kernels(sc, debug_env, N, W):
+    """Pairwise spectral Granger of real series with a power-of-two window of 256 ... 4096 samples runs the whole 2 x 2 Wilson
+    iteration of a pair on one compute unit (sc_wilson_pair.hip: half spectra in registers, two packed transforms per direction,
+    convergence tested in the kernel); SC_GRANGER_KERNEL=batched keeps the three-kernels-per-iteration form of sc_wilson.hip
+    (reference minimum_phase_decomposition.py:227-322 statement by statement).  Same records in: the predictions agree to the
+    rounding of the transforms, every problem takes the same number of iterations and reaches the same status -- also when the
+    iteration limit cuts the problems short."""
+    import torch
+    from spectral_connectivity_amd import _lib, engine
+    rng = np.random.default_rng(N + W)
+    C, R = 5, 6
+    T = N * W
+    e = rng.standard_normal((T + 64, R, C))
+    x = np.zeros_like(e)
+    for t in range(2, T + 64):
+        x[t] = 0.5 * x[t - 1] - 0.3 * x[t - 2] + e[t]
+        x[t, :, 1:] += 0.35 * x[t - 1, :, :-1]
+        x[t, :, 0] += 0.2 * x[t - 2, :, 3]
+    x = x[64:]
+    m = sc.Multitaper(x, sampling_frequency=500.0, time_halfbandwidth_product=3, n_time_samples_per_window=N)
+    c = sc.Connectivity.from_multitaper(m)
+    pairs = np.array([(i, j) for i in range(C) for j in range(i + 1, C)], dtype=np.int32)
+    accum, n_obs, n_freq = c._csm_records("granger")
+    assert n_freq == N // 2 + 1 and accum.shape[0] == W * n_freq
+    out = {}
+    for kernel in ("batched", None):
+        debug_env("SC_GRANGER_KERNEL", kernel)
+        for max_it in (60, 3):
+            gp, n_iter, status, summary = engine.granger_pairwise(accum, W, n_freq, N, C, _lib.PLANE_CSM, n_obs, pairs, max_iterations=max_it)
+            out[(kernel, max_it)] = (gp.cpu().numpy(), n_iter.cpu().numpy(), status.cpu().numpy(), summary)
+    for max_it in (60, 3):
+        (gb, ib, sb, sumb), (gr, ir, sr, sumr) = out[("batched", max_it)], out[(None, max_it)]
+        assert np.array_equal(ib, ir) and np.array_equal(sb, sr) and tuple(sumb) == tuple(sumr), (max_it, sumb, sumr)
+        assert np.array_equal(np.isnan(gb), np.isnan(gr))
+        ok = ~np.isnan(gb)
+        assert np.abs(gb[ok] - gr[ok]).max() <= 1e-9 * np.abs(gb[ok]).max(), (max_it, np.abs(gb[ok] - gr[ok]).max())
+    assert out[(None, 60)][3][1] == 0 and out[(None, 3)][3][1] == len(pairs) * W          # all converged / none within three iterations
+    ref = so.pairwise_spectral_granger_prediction(so.multitaper_fft(x, fs=500.0, NW=3, n_time_samples_per_window=N)[0]) if N <= 512 else None
+    if ref is not None:
+        granger_close(out[(None, 60)][0].reshape(ref.shape), ref, 2e-5 if c._precision == "float32" else 1e-8, what="resident kernel vs the oracle")
+
+
 def test_f6_canonical_coherence(sc, golden):
     g = golden("f6_canonical")
     m = sc.Multitaper(g["x"], sampling_frequency=float(g["fs"]), time_halfbandwidth_product=float(g["NW"]),
