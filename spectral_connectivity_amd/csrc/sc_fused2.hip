@@ -367,6 +367,7 @@ struct Fused2Args {
     int64_t obs_rows;             // rows between consecutive observations of a bin (linear: checked on the host)
     int loader_csm;               // 1: the CSM waves issue the HBM -> LDS loads (8 each), 0: the |Im s| waves (4 each)
     int terms4;                   // 1: the CSM products keep the m m term (few observations per bin: its error does not average out)
+    int fold_obs;                 // observations a tile's f32 accumulators take in before they are folded into the record
 };
 
 __device__ __forceinline__ h16x4 f2_tr(lds_u8* base, int off) {
@@ -500,7 +501,8 @@ __device__ __forceinline__ void f2_mfma_role(const Fused2Args& a, lds_u8* lds, c
                                              int wave, float* rec, int n_part) {
     const FusedArgs& p = a.f;
     constexpr int MAXS = 2 * NB32 + 1;
-    constexpr int NHALF = NB32 <= 2 ? 2 : 1, CH = FU_OC * NHALF, FLUSH = FU_FLUSH / NHALF;     // (folds stay 512 observations apart)
+    constexpr int NHALF = NB32 <= 2 ? 2 : 1, CH = FU_OC * NHALF;
+    const int FLUSH = a.fold_obs / CH;           // chunks between the folds of a tile's accumulators into the record (fused2_run)
     const unsigned sg = (unsigned)__builtin_amdgcn_readfirstlane((int)(wave == 0 ? p.seg0 : (wave == 1 ? p.seg1 : (wave == 2 ? p.seg2 : p.seg3))));
     const unsigned sg_n = (unsigned)__builtin_amdgcn_readfirstlane((int)((p.seg_n >> (8 * wave)) & 0xffu));
     const int rA_ = sg & 0xf, cA_ = (sg >> 4) & 0xf, rB_ = (sg >> 8) & 0xf, cB_ = (sg >> 12) & 0xf;
@@ -562,8 +564,8 @@ __device__ __forceinline__ void f2_mfma_role(const Fused2Args& a, lds_u8* lds, c
             f2_wait_loads(more2 ? f2_issued(L, n_part - (ch + 2) * CH) : 0);
             f2_finish<NHALF>(L, lds + ((ch + 1) % F2_NBUF) * F2_BUF, n_part - (ch + 1) * CH);
         }
-        // two-level summation exactly as in sc_fused.hip: a tile's accumulators are folded into the record every FU_FLUSH
-        // chunks (512 observations), the tiles taking turns; the channel scales (powers of two) come out here, exactly
+        // two-level summation as in sc_fused.hip: a tile's accumulators are folded into the record every FLUSH chunks (512
+        // observations: fused2_run), the tiles taking turns; the channel scales (powers of two) come out here, exactly
         {
             const bool last = ch + 1 == n_chunks;
 #pragma unroll
@@ -864,6 +866,7 @@ static int fused2_setup(const sc_spectra_desc* desc, uint32_t planes, Fused2Args
     a.row_bytes = sc_planes_row_bytes(ax.C);
     a.obs_rows = f.st.obs_stride;
     a.terms4 = ax.n_obs < 256 ? 1 : 0;
+    a.fold_obs = 512;
     a.loader_csm = 1;
     *ax_out = ax;
     return SC_OK;
@@ -977,6 +980,16 @@ static int fused2_run(const void* d_P, const sc_spectra_desc* desc, const float*
     SC_REQUIRE(S == 1 || ((uintptr_t)d_workspace % 16) == 0, "workspace must be 16-byte aligned");
     f.n_split = S;
     f.ws = (float*)d_workspace;
+    {
+        // Fold interval of the two-level summation: 512 observations (16 matrix instructions per accumulator between folds).
+        // Round 5 measured what longer intervals buy and cost at cfg3 (three parts of 2333 observations; profiles/r05_fused2_fold_ab.txt):
+        // no intermediate fold at all is 0.04 ms (1 %) faster and takes the coherence of the strongly coupled bins from 0.39 to 1.67
+        // of the full-depth bound -- the accumulator's roundings do not average out over 73 instructions.  512 stays.
+        // SC_FUSED_FOLD_OBS overrides (A/B).
+        a.fold_obs = 512;
+        const char* fo = sc_switch(SC_SW_FUSED_FOLD_OBS);
+        if (fo && atoi(fo) >= 64 * 9) a.fold_obs = atoi(fo) / 64 * 64;
+    }
     hipStream_t s = (hipStream_t)stream;
     const bool parts_ok = n_parts && ax.C <= 128 && f.sq_plane < 0 && f.sign_plane < 0;
     if (n_parts) *n_parts = 1;

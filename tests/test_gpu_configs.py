@@ -343,3 +343,25 @@ def test_small_channel_kernel_at_full_observation_counts(sc, C, R):
     pli_ref = (sg / n_obs).permute(1, 0, 2, 3).cpu().numpy()
     # sign() of an f32 product vs of an fp64 product: they differ only where |Im s| is within rounding of 0
     assert np.abs(np.abs(got[:, inner][..., off]) - np.abs(pli_ref[:, inner][..., off])).max() <= 8.0 / n_obs
+
+
+def test_graphed_measures_replay_equals_the_eager_pass():
+    """engine.GraphedMeasures: the three launches of a small request (configs[1]: 32 channels x 100 trials x 1024 samples, CSM +
+    coherency) captured once in a hipGraph by the library; a replay on new data equals the eager pass bit for bit, and the
+    oracle within the float32 engine's tolerance."""
+    import torch
+    from spectral_connectivity_amd import _lib, engine
+    from spectral_connectivity_amd.transforms import _make_tapers
+    T, R, C, NW = 1024, 100, 32, 3
+    tapers = _make_tapers(T, FS, NW, 5)
+    h = torch.from_numpy(np.ascontiguousarray(tapers.T / FS, dtype=np.float32)).cuda()
+    g = engine.GraphedMeasures((T, R, C), h, T, T, T, "constant", "trials_tapers", [_lib.M_COHERENCY, _lib.M_COHERENCE_MAGNITUDE])
+    for seed in (2, 7):
+        x = synth(T, R, C, 40.0, seed)
+        coh_g, mag_g = [t.clone() for t in g(x)]
+        coh_e, mag_e = g.eager()
+        assert torch.equal(torch.view_as_real(coh_g).nan_to_num(), torch.view_as_real(coh_e).nan_to_num())
+        assert torch.equal(mag_g.nan_to_num(), mag_e.nan_to_num())
+    coef, _ = so.multitaper_fft(x.astype(np.float64), fs=FS, NW=NW)
+    ref = so.coherency(coef)
+    close(coh_g.reshape(ref.shape).cpu().numpy(), ref, 1e-5, 1e-5, "coherency from a graph replay")
