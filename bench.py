@@ -50,14 +50,15 @@ F64_PEAK_TFLOPS = 78.6        # fp64 vector = fp64 matrix rate
 # from the committed summary of the rocprofv3 --pmc passes over THIS command (tools/profile_round.py writes it next to
 # the kernel-trace stats; it records the source hash of the kernels it measured) and is null when that file is
 # missing or was measured on other kernel sources.
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_hbm_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05_hbm_traffic.json")
 
 
 def kernel_source_hash():
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "spectral_connectivity_amd", "csrc")
-    for name in ("sc_fused.hip", "sc_fused2.hip", "sc_fused_common.h", "sc_mtfft.hip", "sc_measure.hip", "sc_stage.h", "sc_common.h"):
+    for name in ("sc_fused.hip", "sc_fused2.hip", "sc_fused_common.h", "sc_mtfft.hip", "sc_measure.hip", "sc_stage.h", "sc_common.h",
+                 "sc_wilson_pair.hip", "sc_wilson_fft.h"):
         with open(os.path.join(csrc, name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -69,7 +70,7 @@ def measured_traffic(config, stage):
     except (OSError, ValueError):
         return None, None
     if rec.get("kernel_source_hash") != kernel_source_hash():
-        return None, "profiles/r04_hbm_traffic.json was measured on other kernel sources"
+        return None, "profiles/r05_hbm_traffic.json was measured on other kernel sources"
     v = rec.get(config, {}).get(stage)
     return (float(v) if v is not None else None), rec.get("source")
 
@@ -254,8 +255,8 @@ def run_side_config(args, cfg, device):
         if kind == "coherency":
             return engine.measure(accum, C, planes, n_obs, _lib.M_COHERENCY)
         if kind == "granger":
-            out, _, _, summary = engine.granger_pairwise(accum, W, F, N, C, planes, n_obs, pairs)
-            info["wilson"] = summary
+            out, n_it, _, summary = engine.granger_pairwise(accum, W, F, N, C, planes, n_obs, pairs)
+            info["wilson"], info["n_iter"] = summary, n_it
             return out
         out, n_fail = engine.canonical_coherence(accum, C, planes, n_obs, groups)
         info["canonical_failures"] = n_fail
@@ -310,6 +311,8 @@ def run_side_config(args, cfg, device):
 
     tri_flops = 8.0 * n_obs_loc * (C * (C + 1) / 2) * W * F
     iters = info.get("wilson", (0, 0, 0))[0]
+    if "n_iter" in info:
+        info["wilson_iter_sum"] = int(info["n_iter"].sum().item())
     n_gp = len(groups) * (len(groups) - 1) // 2
     # algorithmic work per launch
     stage_model = {
@@ -317,10 +320,12 @@ def run_side_config(args, cfg, device):
         "fused_stage_b": ("mfma", tri_flops),
         "csm_mfma": ("mfma", tri_flops),
         "measure_epilogue": ("hbm", (2 * 4.0 * C * (C + 1) / 2 + 8.0 * C * C) * W * F),
-        # batched Wilson: per (problem, bin, iteration) the fused causal transform pair reads A and writes A+ (2 x 64 B),
-        # the pointwise pass reads A+, G, S and writes G, A (64 + 64 + 32 + 64 + 64 B): 416 B; plus the records read and
-        # the prediction written once
-        "granger_pairwise": ("hbm", 416.0 * len(pairs) * W * N * max(iters, 1)),
+        # pairwise Granger, resident form (sc_wilson_pair.hip): everything between the records and the converged factor happens in
+        # registers / LDS, so the bound is the fp64 arithmetic -- per (problem, iteration) four 4096-point complex transforms
+        # (5 N log2 N flop each; the zero / unused halves are pruned: counted in full here) + ~255 flop per non-negative bin for
+        # A = G^-1 S G^-H + I, the conjugate-symmetry split, G <- G A+ and the convergence norm; iterations = what the problems
+        # really ran (sum over the problems of their own counts)
+        "granger_pairwise": ("f64", (4 * 5.0 * N * np.log2(N) + 255.0 * (N // 2 + 1)) * max(info.get("wilson_iter_sum", 0), 1)),
         # canonical coherence (approximate fp64 flop model, per (bin, group pair) of 16-channel groups: two 16^3 complex
         # whitening products + M M^H (3 x 32.8 kflop) + ~6 cyclic Jacobi sweeps of 120 rotations on 16 x 16 (~0.74 Mflop))
         "canonical_coherence": ("f64", 0.84e6 * W * F * n_gp),
@@ -339,9 +344,17 @@ def run_side_config(args, cfg, device):
                     stage_ms={k: round(v, 4) for k, v in stage_ms.items()},
                     stages={k: stage_roof(k) for k in stage_ms if k in stage_model})
     if dominant == "granger_pairwise":
-        roofline["note"] = (f"batched 2x2 Wilson: {len(pairs) * W} problems x {N} bins x {iters} iterations x 416 algorithmic "
-                            "bytes (fused causal transform pair + pointwise update), over the whole entry point "
-                            "(initialisation, convergence polling and the prediction included)")
+        resident = os.environ.get("SC_GRANGER_KERNEL") != "batched"
+        roofline["kernel"] = "wilson_pair_kernel (+ pair_lag0 / pair_consts / pair_granger)" if resident else "k_update + causal_fft_pair_kernel + k_flags per iteration"
+        roofline["note"] = (f"2 x 2 Wilson iteration of {len(pairs) * W} (window, pair) problems x {N // 2 + 1} non-negative bins, {info.get('wilson_iter_sum', 0)} "
+                            f"problem-iterations (most for one problem: {iters}); fp64 vector peak (the matrix and the vector pipe share the units); flop "
+                            "model in bench.py; over the whole entry point (lag-0 covariances, the factorisation, the prediction)")
+        t_bytes, t_src = measured_traffic(args.config, "granger_pairwise")
+        roofline["traffic"], roofline["traffic_source"] = t_bytes, t_src
+        # what has to move: the pairs' cross-spectra out of the records once (4 floats per pair and bin) and the prediction out once;
+        # the resident kernel adds the factor of the non-negative bins (written once, read once by the prediction kernel)
+        roofline["algorithmic_bytes"] = {"spectra_two_sided_2x2_f64": 16.0 * 4 * N * len(pairs) * W,
+                                         "records_read": 4.0 * 4 * (N // 2 + 1) * len(pairs) * W, "prediction_written": 8.0 * W * (N // 2 + 1) * C * C}
     elif dominant == "canonical_coherence":
         roofline["note"] = "approximate fp64 flop model of the Cholesky whitening + parallel Jacobi per (bin, group pair); fp64 vector peak"
 
@@ -676,7 +689,8 @@ def main():
         n_bins_obs = float(W * F) * float(n_obs_loc)
         csm_products = 4            # Re: ar ar + ai ai, Im: ai ar - ar ai  (a three-product form was tried: profiles/r04_f64_three_products.txt)
         slots_csm = n_bins_obs * (nb16 * (nb16 + 1) // 2) * 256 * csm_products * 2
-        slots_plane = n_bins_obs * (nb64 * (nb64 + 1) // 2) * 4096 * 3 * 2
+        # (a diagonal 64 x 64 block computes the 36 of its 64 sub-tiles that touch the upper triangle: sc_f64.hip)
+        slots_plane = n_bins_obs * (nb64 * (nb64 - 1) // 2 * 4096 + nb64 * 2304) * 3 * 2
         t_b64 = st64.get("accumulate_f64", 0.0) * 1e-3
         roof64 = None
         if t_b64 > 0:

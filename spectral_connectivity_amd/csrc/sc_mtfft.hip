@@ -654,6 +654,9 @@ mtfft16_kernel(MtArgs p) {
                 constexpr int NG = NF / 4, FSTEP = THREADS / NG;
                 constexpr bool TR = NG >= 4;
                 const int j = tid & 3;
+                // (Round 5, tried and dropped: starting the four 16-lane rows of a wave 16 frequencies apart instead of 4 -- a bank distance of
+                //  17 instead of 4 in the skewed exchange buffer for the eight LDS reads of a lane -- changed nothing: 1.92 / 1.93 against
+                //  1.91 / 1.94 ms per transform incl. the scale pass, A/B of two libraries on one box.  The store loop is not bank-bound.)
                 const int grp = TR ? (tid >> 2) % NG : tid % NG, fq = TR ? (tid / (4 * NG)) * 4 + j : tid / NG, cg = c0 + 8 * grp;
                 const int64_t row0 = ((int64_t)w * p.R + r) * p.K + k, rows_f = (int64_t)p.W * p.R * p.K;
                 const bool in_tile = cg < ((C + 31) & ~31);

@@ -72,23 +72,24 @@ __device__ __forceinline__ void pair_read_S(const PairArgs& a, int64_t g, int ci
     s[3] = m ? -im : im;
 }
 
-// A = G^-1 (G^-1 S)^H + I at one frequency, closed form (sc_wilson.hip's predict2x2 with ONE reciprocal of the determinant instead
-// of four complex divisions: an fp64 division is a dozen instructions, and this is the kernel's inner loop)
-__device__ __forceinline__ void pair_predict(const cd (&g)[4], const double (&sv)[4], cd (&A)[4]) {
-    const cd s00 = make_double2(sv[0], 0), s11 = make_double2(sv[1], 0);
+// A = G^-1 (G^-1 S)^H + I = G^-1 S G^-H + I at one frequency, closed form.  Against sc_wilson.hip's predict2x2: ONE reciprocal of the
+// determinant instead of four complex divisions (an fp64 division is a dozen instructions, and this is the kernel's inner loop), and
+// the Hermitian structure of A used -- a00, a11 are real (only their real parts are formed), a10 = conj(a01) is not computed at
+// all: A[0] = (a00, 0), A[1] = a01, A[2] = a11 as (a11, 0).
+__device__ __forceinline__ void pair_predict(const cd (&g)[4], const double (&sv)[4], cd (&A)[3]) {
     const cd s01 = make_double2(sv[2], sv[3]), s10 = pz_conj(s01);
     const cd det = pz_sub(pz_mul(g[0], g[3]), pz_mul(g[1], g[2]));
     const double rd = 1.0 / (det.x * det.x + det.y * det.y);
     const cd idet = make_double2(det.x * rd, -det.y * rd);
     const cd i00 = pz_mul(g[3], idet), i01 = pz_mul(make_double2(-g[1].x, -g[1].y), idet);
     const cd i10 = pz_mul(make_double2(-g[2].x, -g[2].y), idet), i11 = pz_mul(g[0], idet);
-    const cd x00 = pz_add(pz_mul(i00, s00), pz_mul(i01, s10)), x01 = pz_add(pz_mul(i00, s01), pz_mul(i01, s11));
-    const cd x10 = pz_add(pz_mul(i10, s00), pz_mul(i11, s10)), x11 = pz_add(pz_mul(i10, s01), pz_mul(i11, s11));
-    const cd h00 = pz_conj(x00), h01 = pz_conj(x10), h10 = pz_conj(x01), h11 = pz_conj(x11);
-    A[0] = pz_add(pz_mul(i00, h00), pz_mul(i01, h10)); A[0].x += 1.0;
-    A[1] = pz_add(pz_mul(i00, h01), pz_mul(i01, h11));
-    A[2] = pz_add(pz_mul(i10, h00), pz_mul(i11, h10));
-    A[3] = pz_add(pz_mul(i10, h01), pz_mul(i11, h11)); A[3].x += 1.0;
+    // X = G^-1 S (s00, s11 real)
+    const cd x00 = pz_add(make_double2(i00.x * sv[0], i00.y * sv[0]), pz_mul(i01, s10)), x01 = pz_add(pz_mul(i00, s01), make_double2(i01.x * sv[1], i01.y * sv[1]));
+    const cd x10 = pz_add(make_double2(i10.x * sv[0], i10.y * sv[0]), pz_mul(i11, s10)), x11 = pz_add(pz_mul(i10, s01), make_double2(i11.x * sv[1], i11.y * sv[1]));
+    // A = G^-1 X^H + I
+    A[0] = make_double2(i00.x * x00.x + i00.y * x00.y + i01.x * x01.x + i01.y * x01.y + 1.0, 0.0);
+    A[1] = pz_add(pz_mul(i00, pz_conj(x10)), pz_mul(i01, pz_conj(x11)));
+    A[2] = make_double2(i10.x * x10.x + i10.y * x10.y + i11.x * x11.x + i11.y * x11.y + 1.0, 0.0);
 }
 
 // Lag-0 covariance R0 = mean over the N two-sided bins of Re S = (S(0) + S(N/2) + 2 sum_{0 < f < N/2} Re S(f)) / N and its
@@ -181,24 +182,27 @@ __global__ void __launch_bounds__(WP_THREADS, 1) wilson_pair_kernel(PairArgs a) 
         gny[q * 4] = make_double2(l00, 0); gny[q * 4 + 1] = make_double2(l10, 0);
         gny[q * 4 + 2] = make_double2(0, 0); gny[q * 4 + 3] = make_double2(l11, 0);
     }
-    // A(f) -> the packed spectra z1, z2 at f and (conjugate symmetry of the entries) at N - f
-    auto stage = [&](int f, const cd (&A)[4]) {
-        b1[f] = make_double2(A[0].x - A[3].y, A[0].y + A[3].x);
-        b2[f] = make_double2(A[1].x - A[2].y, A[1].y + A[2].x);
+    // A(f) -> the packed spectra at f and (conjugate symmetry of the entries) at N - f:  z1 = a00 + i a11 with a00, a11 real is the
+    // same at both; z2 = a01 + i a10 with a10 = conj(a01) is (re + im)(1 + i) at f and (re - im)(1 + i) at N - f
+    auto stage = [&](int f, const cd (&A)[3]) {
+        const cd z1 = make_double2(A[0].x, A[2].x);
+        const double sp = A[1].x + A[1].y, sm = A[1].x - A[1].y;
+        b1[f] = z1;
+        b2[f] = make_double2(sp, sp);
         if (f != 0 && f != H) {
-            b1[N - f] = make_double2(A[0].x + A[3].y, A[3].x - A[0].y);
-            b2[N - f] = make_double2(A[1].x + A[2].y, A[2].x - A[1].y);
+            b1[N - f] = z1;
+            b2[N - f] = make_double2(sm, sm);
         }
     };
     __syncthreads();                          // (tables, errs, the Nyquist state)
 #pragma unroll
     for (int u = 0; u < WP_BINS; ++u) {
-        cd A[4];
+        cd A[3];
         pair_predict(G[u], S[u], A);
         stage(j + TPF * u, A);
     }
     if (j == 0) {
-        cd g[4], A[4];
+        cd g[4], A[3];
         double s[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) { g[e] = gny[q * 4 + e]; s[e] = sny[q * 4 + e]; }
@@ -221,11 +225,14 @@ __global__ void __launch_bounds__(WP_THREADS, 1) wilson_pair_kernel(PairArgs a) 
                 v[t] = make_double2(x.x, -x.y);
             }
             wf_fft<LOG2N>(v, zf, lo, hi, j);
+            // the mask in the time domain: lags n = j + t N/16 >= N/2 are exactly the registers t >= 8 -- written as constants, so
+            // that the compiler drops the half of the inverse's last pass that computed them and the half of the forward's first pass
+            // that would read them (zeros)
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
-                const int n = j + t * TPF;
-                double sr = (n < H) ? invN : 0.0, si = sr;
-                if (n == 0) { sr *= 0.5; si = h ? 0.0 : 0.5 * si; }       // lag 0: halved; z2's imaginary part is a10, the strict lower triangle
+                if (t >= 8) { v[t] = make_double2(0.0, 0.0); continue; }
+                double sr = invN, si = invN;
+                if (t == 0 && j == 0) { sr *= 0.5; si = h ? 0.0 : 0.5 * si; }       // lag 0: halved; z2's imaginary part is a10, the strict lower triangle
                 v[t] = make_double2(v[t].x * sr, -v[t].y * si);
             }
             wf_fft<LOG2N>(v, zf, lo, hi, j);
@@ -255,7 +262,7 @@ __global__ void __launch_bounds__(WP_THREADS, 1) wilson_pair_kernel(PairArgs a) 
                     g[k] = n[k];
                 }
             }
-            cd A[4];
+            cd A[3];
             pair_predict(g, s, A);
             stage(f, A);
         };

@@ -6,7 +6,7 @@ import os
 import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = os.environ.get("ROUND", "r04")
+ROUND = os.environ.get("ROUND", "r05")
 F = os.path.join(ROOT, "gpurun_out", ROUND)
 P = os.path.join(ROOT, "profiles")
 
@@ -19,7 +19,8 @@ def lines(name):
 def kernel_source_hash():
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "spectral_connectivity_amd", "csrc")
-    for name in ("sc_fused.hip", "sc_fused2.hip", "sc_fused_common.h", "sc_mtfft.hip", "sc_measure.hip", "sc_stage.h", "sc_common.h"):   # = bench.py
+    for name in ("sc_fused.hip", "sc_fused2.hip", "sc_fused_common.h", "sc_mtfft.hip", "sc_measure.hip", "sc_stage.h", "sc_common.h",
+                 "sc_wilson_pair.hip", "sc_wilson_fft.h"):   # = bench.py
         with open(os.path.join(csrc, name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -84,6 +85,23 @@ if stage_b in traffic:
                     "planes_scales": traffic.get("planes_absmax_kernel"),
                     "mtfft_fused": traffic.get("mtfft16_kernel"),
                     "measure_epilogue": traffic.get("measure_tile_multi_kernel")}}
+    # BASELINE configs[3]: the kernels of the resident pairwise Granger (sc_wilson_pair.hip), summed over the entry point
+    f4, w4 = pmc("fetch4.txt", "FETCH_SIZE"), pmc("write4.txt", "WRITE_SIZE")
+    g_rows = [("wilson_pair_kernel", "wilson_pair_kernel"), ("pair_lag0_kernel", "pair_lag0"), ("pair_granger_kernel", "pair_granger"),
+              ("pair_fill_nan_kernel", "pair_fill_nan"), ("pair_consts_kernel", "pair_consts")]
+    g_txt, g_total = [], 0.0
+    for name, key in g_rows:
+        fk, wk = find(f4, key), find(w4, key)
+        if fk is None or wk is None:
+            continue
+        tot = fk * 1024 + wk * 1024                  # (scattered 4- / 8-byte reads of the records: no wide-stream correction)
+        g_total += tot
+        g_txt.append(f"{name:28s} {fk:15.4g} {wk:15.4g} {tot / 1e9:20.3f} GB")
+    if g_txt:
+        open(os.path.join(P, ROUND + "_hbm_traffic.txt"), "a").write(
+            "# BASELINE configs[3] (python bench.py --config cfg4 --steps 2 --warmup 1): pairwise Granger, resident 2 x 2 Wilson kernel\n"
+            + "\n".join(g_txt) + f"\n{'entry point total':28s} {'':15s} {'':15s} {g_total / 1e9:20.3f} GB\n")
+        rec["cfg4"] = {"granger_pairwise": g_total}
     json.dump(rec, open(os.path.join(P, ROUND + "_hbm_traffic.json"), "w"), indent=1)
 
 sq = lines("sq.txt")
@@ -120,6 +138,10 @@ for src, dst, head in (("api_wall.txt", ROUND + "_api_wall.txt", "# tools/api_wa
                        ("stage_a_wide.txt", ROUND + "_stage_a_wide.txt", "# tools/stage_a_wide.py: stage A for long windows, 256-thread (wide=0) against 512-thread workgroups (wide=1, the default)"),
                        ("global_canonical.txt", ROUND + "_global_canonical.txt", "# tools/global_time.py: global coherence (1024 two-sided bins) and canonical coherence with large groups at the cfg5 shape"),
                        ("measure_table.txt", ROUND + "_measure_table.txt", "# tools/measure_table.py: every measure of the public interface at the cfg3 shape"),
+                       ("fused2_fold_ab.txt", ROUND + "_fused2_fold_ab.txt", "# (profile round's box)"),
+                       ("issue_rates_f64.txt", ROUND + "_issue_rates_f64.txt", "# fp64 issue rates (profile round's box)"),
+                       ("sharded_one_rank.txt", ROUND + "_sharded_one_rank.txt", "# tools/sharded_one_rank.sh: the N > 1 code path of bench.py on ONE rank (nccl backend, world size 1, every collective called, nothing crosses a link) at the trial counts a rank holds at 1 / 2 / 4 / 8 GPUs, for 4 / 2 / 1 pipelined frequency groups; 'plain' = the N = 1 path"),
+                       ("kt4.txt", ROUND + "_bench_kernel_stats_cfg4.txt", "# rocprofv3 --kernel-trace --stats -- python bench.py --config cfg4 --steps 5 --warmup 2 --no-cpu-baseline (pairwise Granger, 2016 pairs x 4096 bins)"),
                        ("mvar_size_time.txt", ROUND + "_mvar_size_time.txt", "# tools/mvar_size_time.py: full Wilson factorisation + DTF across system sizes, one window x 256 bins, float64 records"),
                        ("stage_a_ab.txt", ROUND + "_stage_a_ab_final.txt", "# tools/stage_a_ab.py 0 16 8 1 2 4: stage A variants inside one process (SC_MTFFT_DEBUG: 16 = plain stores, 8 = store loop with the rare-channel overrides, 1 = no stores, 2 = no passes, 4 = no split/store loop)")):
     body = [l for l in lines(src) if "amdgpu.ids" not in l]

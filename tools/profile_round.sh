@@ -8,7 +8,7 @@
 # (counters in their own runs with --kernel-trace only: MI355X_MICROARCH.md, rocprofv3 PMC slots)
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-ROUND=${ROUND:-r04}
+ROUND=${ROUND:-r05}
 OUT=$ROOT/gpurun_out/$ROUND
 mkdir -p $OUT
 cd $ROOT
@@ -21,8 +21,13 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -- $SHORT > /dev/null 2>
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -- $SHORT > /dev/null 2> $OUT/write.err
 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -d $OUT/sq -- $SHORT > /dev/null 2> $OUT/sq.err
 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_ACTIVE_INST_LDS -d $OUT/sq2 -- $SHORT > /dev/null 2> $OUT/sq2.err
+# BASELINE configs[3] (pairwise Granger): HBM traffic of the resident Wilson kernel, same two passes
+CFG4="python $ROOT/bench.py --config cfg4 --steps 2 --warmup 1 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats -d $OUT/kt4 -- python $ROOT/bench.py --config cfg4 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_cfg4_under_rocprof.json 2> $OUT/kt4.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch4 -- $CFG4 > /dev/null 2> $OUT/fetch4.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write4 -- $CFG4 > /dev/null 2> $OUT/write4.err
 cd $ROOT
-for d in kt fetch write sq sq2; do
+for d in kt fetch write sq sq2 kt4 fetch4 write4; do
     db=$(find $OUT/$d -name "*.db" | head -1)
     [ -n "$db" ] && python tools/rocpd_summary.py $db > $OUT/$d.txt 2>&1
 done
@@ -44,4 +49,7 @@ python tools/numpy_host_time.py > $OUT/numpy_host.txt 2>&1
 python tools/stage_a_wide.py > $OUT/stage_a_wide.txt 2>&1
 python tools/global_time.py > $OUT/global_canonical.txt 2>&1
 python tools/measure_table.py > $OUT/measure_table.txt 2>&1
+python tools/fused2_fold_ab.py > $OUT/fused2_fold_ab.txt 2>&1
+[ -x tools/issue_rates_f64 ] && ./tools/issue_rates_f64 > $OUT/issue_rates_f64.txt 2>&1
+bash tools/sharded_one_rank.sh > $OUT/sharded_one_rank.txt 2>&1
 ls -la $OUT
