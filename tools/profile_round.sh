@@ -30,6 +30,7 @@ cd $ROOT
 for d in kt fetch write sq sq2 kt4 fetch4 write4; do
     db=$(find $OUT/$d -name "*.db" | head -1)
     [ -n "$db" ] && python tools/rocpd_summary.py $db > $OUT/$d.txt 2>&1
+    rm -rf $OUT/$d          # (the raw databases are hundreds of MB: gpurun copies back at most 64 MB)
 done
 python tools/mvar_time.py 64 1792 256 > $OUT/mvar_64ch.txt 2>&1
 python tools/mvar_time.py 128 1792 256 > $OUT/mvar_128ch.txt 2>&1
@@ -52,4 +53,4 @@ python tools/measure_table.py > $OUT/measure_table.txt 2>&1
 python tools/fused2_fold_ab.py > $OUT/fused2_fold_ab.txt 2>&1
 [ -x tools/issue_rates_f64 ] && ./tools/issue_rates_f64 > $OUT/issue_rates_f64.txt 2>&1
 bash tools/sharded_one_rank.sh > $OUT/sharded_one_rank.txt 2>&1
-ls -la $OUT
+ls -la $OUT; du -sh $OUT
