@@ -440,7 +440,13 @@ def main():
     ap.add_argument("--trials", type=int, default=None, help="override total trial count (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f64", action="store_true", help="skip the float64-engine side measurement")
+    ap.add_argument("--timed-only", action="store_true",
+                    help="nothing but the warm-up and the timed steps (no CPU baselines, float64 engine, end-to-end / API / chain-check "
+                         "passes): the command the rocprofv3 summaries under profiles/ are taken from, so that their per-kernel "
+                         "averages are averages over the steps the line reports")
     args = ap.parse_args()
+    if args.timed_only:
+        args.no_cpu_baseline = args.no_f64 = True
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU), the same
@@ -630,7 +636,7 @@ def main():
                                  f"in trials; the |Im s| plane is single-threaded NumPy arithmetic, BLAS threads = {threads}")}
 
     check = api = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.timed_only:
         check = chain_check(x, h, cfg, geom, planes)
         _lib.timing_enable(True)
         api = api_pass(x, cfg, geom)
@@ -639,7 +645,7 @@ def main():
     # end to end, NumPy in -> NumPy out (page-locked host buffers: upload of the float32 series, the step,
     # download of both measures), a few passes after the timed region; never `value`
     e2e_ms = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.timed_only:
         x_host = torch.empty(x.shape, dtype=torch.float32, pin_memory=True)
         x_host.copy_(x)
         torch.cuda.synchronize()

@@ -358,7 +358,9 @@ class NumpyHost:
                              + ", ".join(f"'{k}'" for k in EXPECTATION_AXES))
         m = Multitaper(time_series, **multitaper_kwargs)
         planes = _lib.PLANE_CSM
-        sp = self.spectra(m, planes_hint=planes if self._planes_expectation(m, expectation_type, planes) else None)
+        # (complex64 spectra, like Connectivity._csm_records of the PyTorch host: these consumers read every bin of the CSM once, at
+        #  window lengths and channel counts where the planes format buys nothing)
+        sp = self.spectra(m, planes_hint=None)
         accum, n_bins, n_obs = self.accumulate(sp, expectation_type, planes)
         for key in ("X", "P", "scale"):
             if sp.get(key) is not None:
@@ -366,6 +368,70 @@ class NumpyHost:
         axes = EXPECTATION_AXES[expectation_type]
         kept = tuple(n for i, n in enumerate((sp["W"], sp["R"], sp["K"])) if i not in axes)
         return m, sp, accum, n_bins, n_obs, kept
+
+    # ---- SURVEY 8(f) through this host: the full Wilson factor + the directed MVAR measures, global coherence ------------------
+    MVAR_MEASURES = {"directed_transfer_function": _lib.MVAR_DTF, "directed_coherence": _lib.MVAR_DC,
+                     "partial_directed_coherence": _lib.MVAR_PDC, "generalized_partial_directed_coherence": _lib.MVAR_GPDC,
+                     "direct_directed_transfer_function": _lib.MVAR_DDTF}
+
+    def mvar_measures(self, time_series, measures=("directed_transfer_function",), expectation_type="trials_tapers", tolerance=1e-8,
+                      max_iterations=60, **multitaper_kwargs):
+        """NumPy time series -> {name: array} for the reference's directed measures of the full multivariate model
+        (``Connectivity.directed_transfer_function`` ... ``direct_directed_transfer_function``, connectivity.py:1237-1426; out[...,
+        i, j] = j -> i on the non-negative bins): cross-spectral records on the device, ONE batched C x C Wilson factorisation
+        (sc_mvar_factor_f64, connectivity.py:567-589), one small kernel and one download per measure."""
+        unknown = [name for name in measures if name not in self.MVAR_MEASURES]
+        if unknown:
+            raise ValueError(f"unknown MVAR measures {unknown}; available: {sorted(self.MVAR_MEASURES)}")
+        if not 1 <= int(max_iterations) <= 1024:
+            raise ValueError("max_iterations must be in 1 ... 1024")
+        m, sp, accum, n_bins, n_obs, kept = self._csm_records(time_series, expectation_type, multitaper_kwargs)
+        lib, C, F, N = self.lib, sp["C"], sp["F"], sp["N"]
+        if C > lib.sc_mvar_max_signals():
+            accum.free()
+            raise ValueError(f"the full Wilson factorisation supports n_signals <= {lib.sc_mvar_max_signals()} (got {C})")
+        n_groups = n_bins // F
+        nbytes = ctypes.c_size_t()
+        _lib.check(lib.sc_mvar_workspace_bytes(n_groups, C, N, byref(nbytes)), "sc_mvar_workspace_bytes")
+        work = self.alloc(nbytes.value)
+        G = self.alloc(n_groups * N * C * C * 16)
+        n_iter, status = self.alloc(n_groups * 4), self.alloc(n_groups * 4)
+        summary = (ctypes.c_int32 * 3)(0, 0, 0)
+        _lib.check(lib.sc_mvar_factor_f64(accum.ptr, None, n_groups, F, N, C, _lib.PLANE_CSM, n_obs, tolerance, int(max_iterations),
+                                          work.ptr, nbytes.value, G.ptr, n_iter.ptr, status.ptr, summary, self.stream), "sc_mvar_factor_f64")
+        self.last_wilson = dict(iterations=int(summary[0]), not_converged=int(summary[1]), cholesky_fallbacks=int(summary[2]))
+        out = {}
+        for name in measures:
+            dev = self.alloc(n_groups * F * C * C * 8)
+            _lib.check(lib.sc_mvar_measure_f64(G.ptr, n_groups, N, C, self.MVAR_MEASURES[name], dev.ptr, work.ptr, nbytes.value, self.stream),
+                       "sc_mvar_measure_f64")
+            out[name] = np.array(self.download(dev, kept + (F, C, C), np.float64))
+            dev.free()
+        for b in (work, G, n_iter, status, accum):
+            b.free()
+        return out
+
+    def global_coherence(self, time_series, max_rank=1, **multitaper_kwargs):
+        """NumPy time series -> (values (n_time_windows, n_fft_samples, max_rank), vectors (n_time_windows, n_fft_samples, n_signals,
+        max_rank)) like the reference's ``Connectivity.global_coherence`` (connectivity.py:822-895): the leading eigenpairs of the
+        cross-spectral matrix of every (window, two-sided bin) (sc_global_coherence_f64); always over trials and tapers."""
+        m, sp, accum, n_bins, n_obs, kept = self._csm_records(time_series, "trials_tapers", multitaper_kwargs)
+        lib, C, F, N, W = self.lib, sp["C"], sp["F"], sp["N"], sp["W"]
+        max_rank = int(max_rank)
+        if not 1 <= max_rank <= min(C, sp["R"] * sp["K"]):
+            accum.free()
+            raise ValueError(f"max_rank must be between 1 and min(n_signals, n_trials * n_tapers) = {min(C, sp['R'] * sp['K'])}")
+        if C > lib.sc_global_coherence_max_signals():
+            accum.free()
+            raise ValueError(f"global_coherence supports n_signals <= {lib.sc_global_coherence_max_signals()}")
+        values, vectors = self.alloc(W * N * max_rank * 8), self.alloc(W * N * C * max_rank * 16)
+        _lib.check(lib.sc_global_coherence_f64(accum.ptr, W, F, N, C, _lib.PLANE_CSM, n_obs, max_rank, int(max_rank < C - 1), values.ptr,
+                                               vectors.ptr, self.stream), "sc_global_coherence_f64")
+        res = (np.array(self.download(values, (W, N, max_rank), np.float64)),
+               np.array(self.download(vectors, (W, N, C, max_rank), np.complex128)))
+        for b in (values, vectors, accum):
+            b.free()
+        return res
 
     def pairwise_spectral_granger_prediction(self, time_series, pairs=None, expectation_type="trials_tapers", tolerance=1e-8,
                                              max_iterations=60, **multitaper_kwargs):

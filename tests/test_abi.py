@@ -175,6 +175,29 @@ cc, labels = host.canonical_coherence(g6["x"], g6["group_labels"], sampling_freq
 assert np.array_equal(labels, g6["labels"]) and cc.shape == g6["canonical_coherence"].shape
 okc = ~np.isnan(g6["canonical_coherence"])
 assert np.array_equal(np.isnan(cc), ~okc) and np.abs(cc[okc] - g6["canonical_coherence"][okc]).max() <= 2e-5
+# SURVEY 8(f) through this host: the directed MVAR measures (one full Wilson factorisation) and global coherence, golden vectors of
+# the real reference
+g9 = np.load(_os.path.join(gdir, "f9_mvar.npz"))
+mv_names = ("directed_transfer_function", "directed_coherence", "partial_directed_coherence",
+            "generalized_partial_directed_coherence", "direct_directed_transfer_function")
+for tag in ("var3", "var5"):
+    mv = host.mvar_measures(g9[f"{tag}__x"], measures=mv_names, sampling_frequency=128.0, time_halfbandwidth_product=2,
+                            n_time_samples_per_window=256)
+    assert host.last_wilson["not_converged"] == 0
+    for name in mv_names:
+        ref = g9[f"{tag}__{name}"]
+        assert mv[name].shape == ref.shape, (name, mv[name].shape, ref.shape)
+        okm = ~np.isnan(ref)
+        assert np.array_equal(np.isnan(mv[name]), ~okm), name
+        assert np.abs(mv[name][okm] - ref[okm]).max() <= 2e-4 * np.abs(ref[okm]).max(), (tag, name)
+g10 = np.load(_os.path.join(gdir, "f10_global.npz"))
+for rank in (1, 4):
+    vals, vecs = host.global_coherence(g10["x"], max_rank=rank, sampling_frequency=256.0, time_halfbandwidth_product=2,
+                                       n_time_samples_per_window=128)
+    ref = g10[f"rank{rank}__values"]
+    assert vals.shape == ref.shape and vecs.shape == g10[f"rank{rank}__vectors"].shape
+    assert np.abs(vals - ref).max() <= 2e-5 * np.abs(ref).max(), rank
+    assert np.abs(np.linalg.norm(vecs, axis=-2) - 1.0).max() <= 1e-9
 # a window length the fused transform does not take (7 is a prime factor above 5): tapered windows + rocFFT
 got = host.connectivity(x[:448].astype(np.float32), measures=("coherence_magnitude",), sampling_frequency=500.0,
                         time_halfbandwidth_product=2, n_time_samples_per_window=224)

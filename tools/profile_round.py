@@ -50,13 +50,14 @@ if os.path.exists(final) and os.path.getmtime(final) > os.path.getmtime(os.path.
 if bench:
     open(os.path.join(P, ROUND + "_bench_line.json"), "w").write(bench[-1] + "\n")
 under = [l for l in lines("bench_under_rocprof.json") if l.startswith("{")]
-hdr = ["# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline   (cfg3, 1x MI355X, round %s;" % ROUND.lstrip("r0") + " tools/profile_round.sh)"]
+hdr = ["# rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 2 --timed-only   (cfg3, 1x MI355X, round %s;" % ROUND.lstrip("r0") + " tools/profile_round.sh;",
+       "# --timed-only: nothing but the warm-up and the timed steps, so every average below is over the 12 launches of the step loop)"]
 if under:
     st = json.loads(under[-1])
     sm = st["roofline"]["stage_ms"]
     hdr.append("# stage times of the same run from the library's own hipEvent timers (sc_last_timing): " +
                ", ".join(f"{k} {v:.3f} ms" for k, v in sm.items()) + f"; step {st['ms_per_step']:.2f} ms")
-    hdr.append("# (fused_stage_b = fused2_kernel; its split-bin partial records are summed by measure_tile_multi_kernel; averages below include the 2 warm-up launches)")
+    hdr.append("# (fused_stage_b = fused2_kernel; its split-bin partial records are summed by measure_tile_multi_kernel; averages below include the 2 warm-up launches, which run before the clock has settled)")
 open(os.path.join(P, ROUND + "_bench_kernel_stats.txt"), "w").write("\n".join(hdr + lines("kt.txt")[:12]) + "\n")
 
 fetch, write = pmc("fetch.txt", "FETCH_SIZE"), pmc("write.txt", "WRITE_SIZE")
@@ -64,7 +65,7 @@ rows = [("fused2_kernel", "_Z13fused2_kernel", True), ("fused_csm_absim_kernel",
         ("fused_combine_kernel", "_Z20fused_combine", True), ("planes_absmax_kernel", "_Z20planes_absmax", True),
         ("mtfft16_kernel", "_Z14mtfft16", False), ("measure_tile_multi_kernel", "measure_tile_multi", False)]
 txt = ["# rocprofv3 --kernel-trace --pmc FETCH_SIZE  /  --pmc WRITE_SIZE (separate passes, MI355X_MICROARCH.md), python bench.py --steps 2",
-       "# --warmup 1 (cfg3, 1x MI355X), round " + ROUND[1:].lstrip("0") + " (tools/profile_round.sh).  Counter values are KB per dispatch.  gfx950 correction: FETCH_SIZE",
+       "# --warmup 1 --timed-only (cfg3, 1x MI355X), round " + ROUND[1:].lstrip("0") + " (tools/profile_round.sh).  Counter values are KB per dispatch.  gfx950 correction: FETCH_SIZE",
        "# reports half of a wide (16 B / lane) coalesced read stream -> doubled for the kernels whose reads are such streams (marked x2);",
        "# WRITE_SIZE as is.",
        f"{'kernel':28s} {'FETCH_SIZE[KB]':>15s} {'WRITE_SIZE[KB]':>15s} {'HBM bytes (corrected)':>24s}"]

@@ -14,9 +14,9 @@ mkdir -p $OUT
 cd $ROOT
 python bench.py --steps 20 --warmup 5 > $OUT/bench_line.json 2> $OUT/bench_line.err
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-f64"
+BENCH="python $ROOT/bench.py --steps 10 --warmup 2 --timed-only"
 rocprofv3 --kernel-trace --stats -d $OUT/kt -- $BENCH > $OUT/bench_under_rocprof.json 2> $OUT/kt.err
-SHORT="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-f64"
+SHORT="python $ROOT/bench.py --steps 2 --warmup 1 --timed-only"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -- $SHORT > /dev/null 2> $OUT/fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -- $SHORT > /dev/null 2> $OUT/write.err
 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -d $OUT/sq -- $SHORT > /dev/null 2> $OUT/sq.err
