@@ -305,13 +305,28 @@ class Connectivity:
     }
 
     def _prepare(self, methods):
-        """One record with every accumulator family the named measures need (one pass over the spectra per family)
-        instead of a record per measure, each re-accumulating the families it shares with the others."""
+        """The accumulator families the named measures need, each accumulated ONCE up front instead of a record per measure that
+        re-accumulates what it shares with the others.  float32 engine: one record per kernel family -- the cross-spectral one
+        (CSM, + |Im s|, + (Im s)^2: one launch, or one + a plane pass), sign(Im s), the unit phasors -- because each family is its
+        own pass over the spectra anyway and the planes-format kernels take exactly these sets (a combined CSM + sign record would
+        push the whole object back to complex64 spectra); float64 engine: one record (its kernels fill any subset, and a later
+        request copies what a record already holds)."""
         planes = 0
         for name in methods:
             planes |= self._METHOD_PLANES.get(name, 0)
-        if planes and bin(planes).count("1") > 1:
+        if not planes or bin(planes).count("1") < 2:
+            return
+        if self._precision == "float64":
             self._accumulators(planes)
+            return
+        cross = _lib.PLANE_CSM | _lib.PLANE_ABS_IM | _lib.PLANE_IM_SQ
+        for family in (planes & cross, planes & _lib.PLANE_SIGN_IM, planes & _lib.PLANE_UNIT):
+            if family & (_lib.PLANE_ABS_IM | _lib.PLANE_IM_SQ):
+                family |= _lib.PLANE_CSM                       # (the |Im s| / (Im s)^2 planes ride on the cross-spectral launch)
+            if family & _lib.PLANE_IM_SQ:
+                family |= _lib.PLANE_ABS_IM
+            if family and bin(family).count("1") > 1:
+                self._accumulators(family)
 
     # ---- measures (reference connectivity.py:612-1159) -----------------------------------
     def power(self):

@@ -387,3 +387,27 @@ def test_one_artefact_sample_or_a_dc_offset_in_a_channel(artefact, offset):
     if artefact:
         # the window that holds the artefact: the float32 transform itself is limited there (in either format); the two engines agree
         np.testing.assert_allclose(coh[0], coh64[0], rtol=0, atol=5e-5, equal_nan=True)
+
+
+def test_prepare_keeps_the_planes_route_for_mixed_families():
+    """wrapper.multitaper_connectivity([...]) prepares the accumulators of all its measures up front (Connectivity._prepare): the
+    float32 engine makes one record per kernel family -- cross-spectral (+ |Im s|), sign(Im s) -- so that a list that mixes
+    coherence, wPLI and PLI stays on the f16 pieces (a combined CSM + sign record exists in no planes kernel and would push the
+    object back to complex64 spectra), and every measure then costs an epilogue."""
+    _dev()
+    x = _series(1024, 9, 12, seed=3, quiet=0.1, loud=8.0)
+    m = Multitaper(x, sampling_frequency=1000, time_halfbandwidth_product=3, n_time_samples_per_window=256, n_time_samples_per_step=128)
+    c = Connectivity.from_multitaper(m, dtype=np.complex64)
+    names = ["coherence_magnitude", "phase_lag_index", "weighted_phase_lag_index"]
+    c._prepare(names)
+    assert c._spectra.P is not None and c._spectra._X is None
+    assert sorted(k for k in c._accum_cache if isinstance(k, int)) == [PLANES], sorted(c._accum_cache)     # CSM + |Im s|; sign follows with PLI
+    coef, _ = so.multitaper_fft(x, fs=1000, NW=3, n_time_samples_per_window=256, n_time_samples_per_step=128)
+    got = {n: getattr(c, n)() for n in names}
+    assert c._spectra._X is None, "a measure left the planes route"
+    assert sorted(k for k in c._accum_cache if isinstance(k, int)) == [PLANES, _lib.PLANE_SIGN_IM]
+    np.testing.assert_allclose(got["coherence_magnitude"], so.coherence_magnitude(coef), rtol=2e-4, atol=2e-5, equal_nan=True)
+    np.testing.assert_allclose(got["weighted_phase_lag_index"], so.weighted_phase_lag_index(coef), rtol=2e-4, atol=2e-5)
+    ref = so.phase_lag_index(coef)
+    bad = np.abs(got["phase_lag_index"] - ref) > 1e-6
+    assert bad.mean() < 2e-4 and np.all(np.abs(got["phase_lag_index"] - ref)[bad] <= 2.0 / c.n_observations + 1e-6)
