@@ -365,6 +365,77 @@ def plane_slots(planes):
     return out
 
 
+MAX_KERNEL_SIGNALS = 256          # SC_MAX_SIGNALS of csrc/sc_common.h: what one launch of the stage-B kernels stages per observation row
+BLOCK_SIGNALS = 128               # channel block of the tiling beyond that (a multiple of the 16-channel record tile)
+
+
+def _channel_subset(spectra, cols):
+    """The spectra of the channels ``cols`` (a LongTensor of channel indices) as a dense DeviceSpectra of its own: one gathering
+    copy; an odd count gets the zero pad channel of the float32 engine."""
+    X = spectra.X
+    n = int(cols.numel())
+    n_alloc = n if (spectra.f64 or n % 2 == 0) else n + 1
+    sub = torch.zeros(tuple(X.shape[:-1]) + (n_alloc,), dtype=X.dtype, device=X.device) if n_alloc != n else \
+        torch.empty(tuple(X.shape[:-1]) + (n_alloc,), dtype=X.dtype, device=X.device)
+    torch.index_select(X, X.dim() - 1, cols, out=sub[..., :n]) if n_alloc == n else sub[..., :n].copy_(X.index_select(X.dim() - 1, cols))
+    assert all(st % spectra.C_alloc == 0 for st in spectra.strides), "channel subsets need spectra whose rows are dense"
+    strides = tuple(st // spectra.C_alloc * n_alloc for st in spectra.strides)
+    return DeviceSpectra(sub, (spectra.F, spectra.W, spectra.R, spectra.K, n), strides, spectra.n_fft, spectra.real_input, C_alloc=n_alloc)
+
+
+def _accumulate_blocked(spectra, expectation_type, planes, n_freq, mark, row_multiple):
+    """Stage B for MORE signals than one launch of the kernels stages (256): the reference has no limit
+    (connectivity.py:447-526), a 306-channel MEG array is an ordinary input.  The channels are cut into blocks of 128; every pair
+    of blocks (a < b) is accumulated as a request of its own on the gathered spectra of the two blocks (<= 256 signals: the
+    ordinary kernels), and its 16 x 16 record tiles are copied to their places in the full record -- the cross tiles of (a, b)
+    from that pair, the tiles inside block a from the pair (a, a + 1) (the last block from the last pair).  Every entry of the
+    record is computed by the same kernels as for <= 256 signals; what the tiling costs is the tiles inside the blocks being
+    computed once per partner (about twice the arithmetic of an untiled triangle at three blocks) and one gathering copy of the
+    spectra per pair."""
+    C = spectra.C
+    n_blk = -(-C // BLOCK_SIGNALS)
+    n_bins, fpb, _, n_obs = accum_layout(spectra, expectation_type, planes, n_freq)
+    NB = -(-C // 16)
+    n_tiles = NB * (NB + 1) // 2
+    n_planes = fpb // (n_tiles * 256)
+    dtype = torch.float64 if spectra.f64 else torch.float32
+    full = _record_tensor(n_bins, fpb, dtype, spectra.device, row_multiple)
+    full_v = full.view(n_bins, n_planes, n_tiles, 256)
+    dev = spectra.device
+
+    def tile(bi, bj, nb):
+        return bi * nb - bi * (bi - 1) // 2 + (bj - bi)
+
+    per = BLOCK_SIGNALS // 16
+    for a in range(n_blk - 1):
+        for b in range(a + 1, n_blk):
+            ca = torch.arange(a * BLOCK_SIGNALS, (a + 1) * BLOCK_SIGNALS, device=dev)
+            cb = torch.arange(b * BLOCK_SIGNALS, min((b + 1) * BLOCK_SIGNALS, C), device=dev)
+            sub = _channel_subset(spectra, torch.cat([ca, cb]))
+            rec, _ = accumulate(sub, expectation_type, planes, n_freq=n_freq, mark=mark)
+            nb_s = -(-sub.C // 16)
+            rec_v = rec.view(n_bins, n_planes, nb_s * (nb_s + 1) // 2, 256)
+            src, dst = [], []
+            for ti in range(nb_s):
+                for tj in range(ti, nb_s):
+                    in_a_i, in_a_j = ti < per, tj < per
+                    if in_a_i and in_a_j:
+                        keep = b == a + 1                                   # inside block a: from its first partner
+                    elif not in_a_i and not in_a_j:
+                        keep = a == n_blk - 2 and b == n_blk - 1            # inside the last block: from the last pair
+                    else:
+                        keep = True                                         # cross tiles of (a, b)
+                    if keep:
+                        gi = a * per + ti if in_a_i else b * per + (ti - per)
+                        gj = a * per + tj if in_a_j else b * per + (tj - per)
+                        src.append(tile(ti, tj, nb_s))
+                        dst.append(tile(gi, gj, NB))
+            src_t, dst_t = torch.tensor(src, device=dev), torch.tensor(dst, device=dev)
+            full_v[:, :, dst_t] = rec_v[:, :, src_t]
+            del rec, sub
+    return full, n_obs
+
+
 def accumulate(spectra, expectation_type, planes, n_freq=None, mark=None, use_fused=None, row_multiple=1, have=None,
                fold=True):
     """Stage B: un-normalised accumulator record tensor [n_bins, floats_per_bin] (float32; float64 records from
@@ -377,6 +448,8 @@ def accumulate(spectra, expectation_type, planes, n_freq=None, mark=None, use_fu
     expectation are copied over (a strided device copy) and only the missing ones are computed -- its CSM and
     per-observation planes are separate kernels, so a wPLI after a coherence costs the |Im s| plane alone."""
     lib = _lib.load()
+    if spectra.C > MAX_KERNEL_SIGNALS:
+        return _accumulate_blocked(spectra, expectation_type, planes, n_freq, mark, row_multiple)
     d = spectra.desc(expectation_type, n_freq)
     n_bins, fpb, _, n_obs = accum_layout(spectra, expectation_type, planes, n_freq)
     if spectra.f64:

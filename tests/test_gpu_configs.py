@@ -365,3 +365,83 @@ def test_graphed_measures_replay_equals_the_eager_pass():
     coef, _ = so.multitaper_fft(x.astype(np.float64), fs=FS, NW=NW)
     ref = so.coherency(coef)
     close(coh_g.reshape(ref.shape).cpu().numpy(), ref, 1e-5, 1e-5, "coherency from a graph replay")
+
+
+@pytest.mark.parametrize("dtype,C", [("float32", 6), ("float32", 7), ("float64", 6), ("float64", 5)])
+def test_multitaper_takes_a_series_that_already_lives_in_hbm(sc, dtype, C):
+    """Beyond the reference: ``Multitaper(time_series=<torch tensor on the GPU>)`` uses the tensor in place (no host round trip;
+    bench.py's ``api`` pass).  Same numbers as the host-array path, bit for bit, in both engines; odd channel counts get their
+    zero pad channel on the device; the NaN scan runs on the device with the first transform."""
+    import warnings
+    import torch
+    rng = np.random.default_rng(11 + C)
+    x = rng.standard_normal((512, 5, C)).astype(dtype)
+    kw = dict(sampling_frequency=500.0, time_halfbandwidth_product=3, n_time_samples_per_window=128, n_time_samples_per_step=64)
+    xd = torch.from_numpy(x).cuda()
+    for cdtype in (np.complex64, np.complex128):
+        host = sc.Connectivity.from_multitaper(sc.Multitaper(x, **kw), dtype=cdtype)
+        dev = sc.Connectivity.from_multitaper(sc.Multitaper(xd, **kw), dtype=cdtype)
+        assert dev._shape5 == host._shape5 and dev.n_observations == host.n_observations
+        for name in ("power", "coherence_magnitude", "weighted_phase_lag_index"):
+            np.testing.assert_array_equal(getattr(dev, name)(), getattr(host, name)(), err_msg=f"{name} {np.dtype(cdtype)}")
+    m = sc.Multitaper(xd, **kw)
+    assert m.n_signals == C and m.n_trials == 5 and np.asarray(m.time_series).shape == x.shape
+    np.testing.assert_array_equal(m.fft(), sc.Multitaper(x, **kw).fft())
+    bad = xd.clone()
+    bad[7, 1, 2] = float("nan")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        sc.Multitaper(bad, **kw).fft()
+    assert any("NaN or infinite" in str(i.message) for i in w), [str(i.message) for i in w]
+
+
+@pytest.mark.parametrize("C", [258, 306, 401])
+def test_more_than_256_signals(sc, C):
+    """The reference has no channel limit (connectivity.py:447-526); one launch of the stage-B kernels stages at most 256 signals
+    per observation row.  Beyond that engine.accumulate tiles the channels in blocks of 128 and assembles the record from the
+    block pairs (engine._accumulate_blocked): a 306-channel MEG array -- or an odd 401 -- goes through every expectation measure
+    of both engines, pairwise Granger on a subset and canonical coherence, against the oracle."""
+    import spectral_connectivity_amd.options as options
+    rng = np.random.default_rng(C)
+    L, R = 64, 3
+    x = rng.standard_normal((L, R, C)) + 0.6 * rng.standard_normal((L, R, 1))
+    x[:, :, C - 3] += 0.8 * np.roll(x[:, :, 2], 3, axis=0)            # a lagged copy across the first and the last block
+    kw = dict(sampling_frequency=128.0, time_halfbandwidth_product=2)
+    coef, _ = so.multitaper_fft(x, fs=128.0, NW=2)
+    F = L // 2 + 1
+    csm = so.expectation_csm_gemm(coef)
+    refs = {"power": so.power(coef), "coherence_magnitude": so.coherence_magnitude(coef, csm=csm)}
+    if C <= 306:
+        refs.update(weighted_phase_lag_index=so.weighted_phase_lag_index(coef), phase_locking_value=so.phase_locking_value(coef),
+                    phase_lag_index=so.phase_lag_index(coef))
+    old = options.precision
+    try:
+        for precision, dtype, tol in (("float32", np.complex64, 3e-5), ("float64", np.complex128, 1e-9)):
+            options.precision = precision
+            c = sc.Connectivity.from_multitaper(sc.Multitaper(x, **kw), dtype=dtype)
+            for name, ref in refs.items():
+                got = getattr(c, name)()
+                ref = ref[:, :F]
+                assert got.shape == ref.shape, (name, got.shape, ref.shape)
+                assert np.array_equal(np.isnan(got), np.isnan(ref)), name
+                ok = ~np.isnan(ref)
+                err = np.abs(got[ok] - ref[ok]).max() / np.abs(ref[ok]).max()
+                bound = 4.0 / c.n_observations if name == "phase_lag_index" else tol
+                assert err <= bound, (precision, name, err)
+            if C == 306:
+                pairs = [(2, C - 3), (0, 130), (129, 300)]
+                gp = c.subset_pairwise_spectral_granger_prediction(pairs)
+                sub = sc.Connectivity.from_multitaper(sc.Multitaper(x[:, :, [2, C - 3]], **kw), dtype=dtype).pairwise_spectral_granger_prediction()
+                a, b = gp[..., 2, C - 3], sub[..., 0, 1]
+                both = ~np.isnan(a) & ~np.isnan(b)
+                assert both.any() and np.abs(a[both] - b[both]).max() <= (2e-4 if precision == "float32" else 1e-8) * np.nanmax(b)
+                labels = np.arange(C) // 4                                  # 77 groups of 4 channels, 9 observations per bin
+                cc, _ = c.canonical_coherence(labels)
+                ref_cc = np.asarray(so.canonical_coherence(coef, labels)[0])[:, :F]
+                okc = ~np.isnan(ref_cc)
+                assert cc.shape == ref_cc.shape and np.array_equal(np.isnan(cc), ~okc)
+                err_cc = np.abs(cc[okc] - ref_cc[okc]).max()
+                print(f"  canonical coherence, {C} signals, {precision}: max err {err_cc:.2e}")
+                assert err_cc <= (5e-3 if precision == "float32" else 1e-6)
+    finally:
+        options.precision = old
