@@ -131,11 +131,16 @@ __global__ void pair_restart_kernel(PairArgs a) {
     atomicAdd(a.summary + 2, 1);
 }
 
-#define WP_THREADS 256
-#define WP_BINS 8            // bins per thread: WP_BINS * N / 16 = N / 2
-template <int LOG2N>
-__global__ void __launch_bounds__(WP_THREADS, 1) wilson_pair_kernel(PairArgs a) {
-    constexpr int N = 1 << LOG2N, H = N / 2, TPF = N / 16, PPW = WP_THREADS / TPF, ZS = N + N / 16, NHI = N / 64;
+// HALVES = 1: 256 threads, the N/16 threads of a problem transform z1, then z2, and hold eight bins each (one wave per SIMD, the
+// whole register file); HALVES = 2: 512 threads, the two halves of a problem's N/8 threads transform z1 and z2 side by side and hold
+// four bins each (two waves per SIMD, 256 registers).
+// Which one: 512 threads need the state AND the transform in 256 registers -- they fit at N = 256 (244 registers); from N = 512 on the
+// third transform pass pushes 31 ... 209 registers to scratch, so the longer windows take the 256-thread form (456 registers at
+// N = 4096, the overflow in AGPRs, no scratch).
+template <int LOG2N, int HALVES>
+__global__ void __launch_bounds__(256 * HALVES, HALVES) wilson_pair_kernel(PairArgs a) {
+    constexpr int WP_THREADS = 256 * HALVES, WP_BINS = 8 / HALVES;
+    constexpr int N = 1 << LOG2N, H = N / 2, TPF = N / 16, TPP = TPF * HALVES, PPW = WP_THREADS / TPP, ZS = N + N / 16, NHI = N / 64;
     constexpr int64_t F = N / 2 + 1;
     extern __shared__ __align__(16) unsigned char wp_smem[];
     cd* z = reinterpret_cast<cd*>(wp_smem);                               // [PPW][2][ZS]: staging (natural order) / transform exchange
@@ -144,7 +149,8 @@ __global__ void __launch_bounds__(WP_THREADS, 1) wilson_pair_kernel(PairArgs a) 
     cd* gny = hi + NHI;                                                   // [PPW][4]: G at the Nyquist bin (thread 0 of the problem)
     double* sny = reinterpret_cast<double*>(gny + PPW * 4);              // [PPW][4]: S there
     unsigned long long* errs = reinterpret_cast<unsigned long long*>(sny + PPW * 4);   // [PPW]: max |G - G_old|^2 (bit pattern)
-    const int tid = threadIdx.x, q = tid / TPF, j = tid % TPF;
+    const int tid = threadIdx.x, q = tid / TPP, j = tid % TPP;          // j: the thread's index inside its problem
+    const int hh = j / TPF, i = j % TPF;                                 // (HALVES = 2) the series this thread transforms, its index there
     const int64_t p = (int64_t)blockIdx.x * PPW + q;
     const bool valid = p < a.P;
     if (tid < 64 + NHI) {
@@ -157,7 +163,7 @@ __global__ void __launch_bounds__(WP_THREADS, 1) wilson_pair_kernel(PairArgs a) 
     cd* b1 = z + (q * 2) * ZS;              // z1 = a00 + i a11
     cd* b2 = b1 + ZS;                        // z2 = a01 + i a10
 
-    // ---- the problem's state: this thread's bins f = j + TPF u (u < 8), the Nyquist bin with thread 0 -----------------------
+    // ---- the problem's state: this thread's bins f = j + TPP u (u < WP_BINS), the Nyquist bin with thread 0 -----------------------
     cd G[WP_BINS][4];
     double S[WP_BINS][4];
     int ci = 0, cj = 0;
@@ -170,7 +176,7 @@ __global__ void __launch_bounds__(WP_THREADS, 1) wilson_pair_kernel(PairArgs a) 
     const double l00 = valid ? a.chol[p * 4] : 1.0, l10 = valid ? a.chol[p * 4 + 1] : 0.0, l11 = valid ? a.chol[p * 4 + 2] : 1.0;
 #pragma unroll
     for (int u = 0; u < WP_BINS; ++u) {
-        if (valid) pair_read_S(a, grp, ci, cj, F, j + TPF * u, S[u]);
+        if (valid) pair_read_S(a, grp, ci, cj, F, j + TPP * u, S[u]);
         else { S[u][0] = 1.0; S[u][1] = 1.0; S[u][2] = 0.0; S[u][3] = 0.0; }
         G[u][0] = make_double2(l00, 0); G[u][1] = make_double2(l10, 0); G[u][2] = make_double2(0, 0); G[u][3] = make_double2(l11, 0);
     }
@@ -199,7 +205,7 @@ __global__ void __launch_bounds__(WP_THREADS, 1) wilson_pair_kernel(PairArgs a) 
     for (int u = 0; u < WP_BINS; ++u) {
         cd A[3];
         pair_predict(G[u], S[u], A);
-        stage(j + TPF * u, A);
+        stage(j + TPP * u, A);
     }
     if (j == 0) {
         cd g[4], A[3];
@@ -216,15 +222,16 @@ __global__ void __launch_bounds__(WP_THREADS, 1) wilson_pair_kernel(PairArgs a) 
         __syncthreads();                      // z1, z2 staged
         // ---- a = ifft(z) = conj(fft(conj z)) / N, masked; A+ = fft(a+): z1, then z2 ---------------------------------------------
 #pragma unroll 1
-        for (int h = 0; h < 2; ++h) {
+        for (int hs_ = 0; hs_ < 2 / HALVES; ++hs_) {
+            const int h = HALVES == 2 ? hh : hs_;
             cd* zf = h ? b2 : b1;
             cd v[16];
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
-                const cd x = zf[j + t * TPF];
+                const cd x = zf[i + t * TPF];
                 v[t] = make_double2(x.x, -x.y);
             }
-            wf_fft<LOG2N>(v, zf, lo, hi, j);
+            wf_fft<LOG2N>(v, zf, lo, hi, i);
             // the mask in the time domain: lags n = j + t N/16 >= N/2 are exactly the registers t >= 8 -- written as constants, so
             // that the compiler drops the half of the inverse's last pass that computed them and the half of the forward's first pass
             // that would read them (zeros)
@@ -232,13 +239,13 @@ __global__ void __launch_bounds__(WP_THREADS, 1) wilson_pair_kernel(PairArgs a) 
             for (int t = 0; t < 16; ++t) {
                 if (t >= 8) { v[t] = make_double2(0.0, 0.0); continue; }
                 double sr = invN, si = invN;
-                if (t == 0 && j == 0) { sr *= 0.5; si = h ? 0.0 : 0.5 * si; }       // lag 0: halved; z2's imaginary part is a10, the strict lower triangle
+                if (t == 0 && i == 0) { sr *= 0.5; si = h ? 0.0 : 0.5 * si; }       // lag 0: halved; z2's imaginary part is a10, the strict lower triangle
                 v[t] = make_double2(v[t].x * sr, -v[t].y * si);
             }
-            wf_fft<LOG2N>(v, zf, lo, hi, j);
+            wf_fft<LOG2N>(v, zf, lo, hi, i);
             __syncthreads();                  // the last pass has read the exchange buffer
 #pragma unroll
-            for (int t = 0; t < 16; ++t) zf[j + t * TPF] = v[t];
+            for (int t = 0; t < 16; ++t) zf[i + t * TPF] = v[t];
         }
         __syncthreads();
         // ---- split, G <- G A+, max |G - G_old|; the next A = predict(G) goes straight back into the staging buffers -------------
@@ -267,7 +274,7 @@ __global__ void __launch_bounds__(WP_THREADS, 1) wilson_pair_kernel(PairArgs a) 
             stage(f, A);
         };
 #pragma unroll
-        for (int u = 0; u < WP_BINS; ++u) update(j + TPF * u, G[u], S[u]);
+        for (int u = 0; u < WP_BINS; ++u) update(j + TPP * u, G[u], S[u]);
         if (j == 0) {
             cd g[4];
             double s[4];
@@ -295,7 +302,7 @@ __global__ void __launch_bounds__(WP_THREADS, 1) wilson_pair_kernel(PairArgs a) 
         cd* Gp = a.Ghalf + p * 4 * F;
 #pragma unroll
         for (int u = 0; u < WP_BINS; ++u) {
-            const int f = j + TPF * u;
+            const int f = j + TPP * u;
             const double w = f == 0 ? 1.0 : 2.0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) { Gp[k * F + f] = G[u][k]; hs[k] += w * G[u][k].x; }
@@ -311,7 +318,7 @@ __global__ void __launch_bounds__(WP_THREADS, 1) wilson_pair_kernel(PairArgs a) 
     __syncthreads();
     if (valid && j < 4) {
         double t = 0.0;
-        for (int m = 0; m < TPF; ++m) t += red[(q * TPF + m) * 4 + j];       // fixed order
+        for (int m = 0; m < TPP; ++m) t += red[(q * TPP + m) * 4 + j];       // fixed order
         a.h0[p * 4 + j] = t / (double)N;
     }
     if (valid && j == 0) {
@@ -385,12 +392,13 @@ __global__ void pair_granger_kernel(PairArgs a, const double* hinv, const double
 
 template <int LOG2N>
 static int pair_launch(const PairArgs& a, hipStream_t st) {
-    constexpr int N = 1 << LOG2N, TPF = N / 16, PPW = WP_THREADS / TPF, ZS = N + N / 16, NHI = N / 64;
+    constexpr int WP_HALVES = LOG2N <= 8 ? 2 : 1;
+    constexpr int N = 1 << LOG2N, TPF = N / 16, PPW = 256 / TPF, ZS = N + N / 16, NHI = N / 64;
     const size_t lds = ((size_t)PPW * 2 * ZS + 64 + NHI + PPW * 4) * sizeof(cd) + (size_t)PPW * 4 * 8 + (size_t)PPW * 8;
-    SC_CHECK_HIP(hipFuncSetAttribute((const void*)wilson_pair_kernel<LOG2N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SC_CHECK_HIP(hipFuncSetAttribute((const void*)wilson_pair_kernel<LOG2N, WP_HALVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t blocks = (a.P + PPW - 1) / PPW;
     SC_REQUIRE(blocks <= 0x7fffffffLL, "too many problems for one launch");
-    hipLaunchKernelGGL(wilson_pair_kernel<LOG2N>, dim3((unsigned)blocks), dim3(WP_THREADS), lds, st, a);
+    hipLaunchKernelGGL((wilson_pair_kernel<LOG2N, WP_HALVES>), dim3((unsigned)blocks), dim3(256 * WP_HALVES), lds, st, a);
     SC_CHECK_HIP(hipGetLastError());
     return SC_OK;
 }
