@@ -355,6 +355,10 @@ int sc_measure_multi_f64(const void* d_accum, int64_t n_bins, int64_t n_signals,
 int sc_measure_multi_parts(const void* d_part0, const void* d_rest, int n_parts, int64_t part_stride, int64_t n_bins,
                            int64_t n_signals, uint32_t planes, int64_t n_observations, int n_measures, const int* measures,
                            void* const* d_outs, int wide, void* stream);
+/* ONE measure of sc_measure_f32 / _f64 -- power and the complex-valued ones included -- from partial records (same layout);
+ * wide != 0: double / complex128 output. */
+int sc_measure_parts(const void* d_part0, const void* d_rest, int n_parts, int64_t part_stride, int64_t n_bins,
+                     int64_t n_signals, uint32_t planes, int64_t n_observations, int measure, void* d_out, int wide, void* stream);
 
 /* ---- stage B of the float64 engine -----------------------------------------------------
  * Replaces the same reference code as sc_csm_accumulate_f32 / sc_nonlinear_accumulate_f32 (connectivity.py:447-526,

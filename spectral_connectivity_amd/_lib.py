@@ -70,6 +70,7 @@ SYMBOLS = {
                                      POINTER(c_void_p), c_void_p]),
     "sc_measure_multi_parts": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_uint32, c_int64, c_int,
                                        POINTER(c_int), POINTER(c_void_p), c_int, c_void_p]),
+    "sc_measure_parts": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_uint32, c_int64, c_int, c_void_p, c_int, c_void_p]),
     "sc_timing_enable": (c_int, [c_int]),
     "sc_last_timing": (c_int, [POINTER(Timing), c_int, POINTER(c_int)]),
     "sc_multitaper_fft_supported": (c_int, [c_int64, c_int64]),

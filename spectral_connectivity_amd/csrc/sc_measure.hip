@@ -71,14 +71,22 @@ __device__ inline double tile_read(Rec bin_rec, int plane, int n_tiles, int NB, 
 }
 
 // power: one thread per (bin, channel)
-template <typename OutT, typename AccT>
+template <typename AccT, bool PARTS> struct RecSel { using type = RecT<AccT>; };
+template <typename AccT> struct RecSel<AccT, true> { using type = RecPartsT<AccT>; };
+template <typename AccT, bool PARTS>
+__device__ __forceinline__ typename RecSel<AccT, PARTS>::type make_rec(const MeasureArgs& a) {
+    if constexpr (PARTS) return RecPartsT<AccT>{(const AccT*)a.accum.p, (const AccT*)a.rest, a.n_parts, a.part_stride};
+    else return RecT<AccT>{(const AccT*)a.accum.p};
+}
+
+template <typename OutT, typename AccT, bool PARTS = false>
 __global__ void __launch_bounds__(256) power_kernel(MeasureArgs a) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= a.total) return;
     const int64_t bin = idx / a.C;
     const int i = (int)(idx - bin * a.C);
     bool m;
-    const RecT<AccT> rec = RecT<AccT>{(const AccT*)a.accum.p} + bin * a.floats_per_bin;
+    const auto rec = make_rec<AccT, PARTS>(a) + bin * a.floats_per_bin;
     ((OutT*)a.out)[idx] = (OutT)(tile_read(rec, a.p_csm, a.n_tiles, a.NB, i, i, &m) / a.n_obs);
 }
 
@@ -153,7 +161,7 @@ __device__ inline double2 measure_value(int measure, double n, MeasureIn v, bool
     }
 }
 
-template <bool COMPLEX_OUT, typename OutT, typename OutT2, typename AccT>
+template <bool COMPLEX_OUT, typename OutT, typename OutT2, typename AccT, bool PARTS = false>
 __global__ void __launch_bounds__(256) measure_tile_kernel(MeasureArgs a) {
     __shared__ MeasureIn raw[256];
     __shared__ double2 mir[256];
@@ -162,9 +170,9 @@ __global__ void __launch_bounds__(256) measure_tile_kernel(MeasureArgs a) {
     while (t >= len) { t -= len; ++ti; --len; }
     const int tj = ti + t;
     const int64_t bin = blockIdx.x;
-    const RecT<AccT> rec = RecT<AccT>{(const AccT*)a.accum.p} + bin * a.floats_per_bin;
+    const auto rec = make_rec<AccT, PARTS>(a) + bin * a.floats_per_bin;
     const int64_t plane = (int64_t)a.n_tiles * SC_TILE_ELEMS;
-    const RecT<AccT> tile = rec + ((int64_t)blockIdx.y * SC_TILE_ELEMS + ii * 16 + jj);
+    const auto tile = rec + ((int64_t)blockIdx.y * SC_TILE_ELEMS + ii * 16 + jj);
     MeasureIn v = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (a.p_csm >= 0) {
         v.s_re = (double)tile[a.p_csm * plane];
@@ -216,14 +224,6 @@ __global__ void __launch_bounds__(256) measure_tile_kernel(MeasureArgs a) {
                                   // workgroup run one after the other, each behind its own loads, and 32 508 small workgroups hide
                                   // that latency better than 8 127 longer ones; tools/measure_ab.py over variant libraries)
 #endif
-template <typename AccT, bool PARTS> struct RecSel { using type = RecT<AccT>; };
-template <typename AccT> struct RecSel<AccT, true> { using type = RecPartsT<AccT>; };
-template <typename AccT, bool PARTS>
-__device__ __forceinline__ typename RecSel<AccT, PARTS>::type make_rec(const MeasureArgs& a) {
-    if constexpr (PARTS) return RecPartsT<AccT>{(const AccT*)a.accum.p, (const AccT*)a.rest, a.n_parts, a.part_stride};
-    else return RecT<AccT>{(const AccT*)a.accum.p};
-}
-
 template <typename OutT, typename AccT, bool PARTS = false>
 __global__ void __launch_bounds__(256) measure_tile_multi_kernel(MeasureArgs a) {
     __shared__ MeasureIn raw[256];
@@ -389,13 +389,18 @@ extern "C" int sc_measure_multi_f64(const void* d_accum, int64_t n_bins, int64_t
 }
 
 static int measure_run(const void* d_accum, int64_t n_bins, int64_t n_signals, uint32_t planes,
-                       int64_t n_observations, int measure, void* d_out, bool wide, void* stream) {
+                       int64_t n_observations, int measure, void* d_out, bool wide, void* stream,
+                       int n_parts = 1, const void* d_rest = nullptr, int64_t part_stride = 0) {
     ScTimed timed_("measure_epilogue", stream);
     SC_REQUIRE(d_accum && d_out, "NULL argument");
+    SC_REQUIRE(n_parts >= 1 && (n_parts == 1 || d_rest != nullptr) && (n_parts <= 2 || part_stride > 0), "bad partial-record layout");
     SC_REQUIRE(n_bins >= 1 && n_signals >= 1 && n_observations >= 1, "dimensions must be positive");
     SC_REQUIRE(measure >= SC_M_POWER && measure <= SC_M_PLV_COMPLEX, "unknown measure");
     MeasureArgs a;
     a.accum = sc_rec(d_accum, planes);
+    a.n_parts = n_parts;
+    a.rest = d_rest;
+    a.part_stride = part_stride;
     a.out = d_out;
     a.n_bins = n_bins;
     a.C = (int)n_signals;
@@ -428,7 +433,12 @@ static int measure_run(const void* d_accum, int64_t n_bins, int64_t n_signals, u
         SC_REQUIRE(blocks < (int64_t)1 << 31, "output too large for one launch");
         hipStream_t st = (hipStream_t)stream;
         const dim3 g((unsigned)blocks);
-        if (wide && a.accum.f64) hipLaunchKernelGGL((power_kernel<double, double>), g, dim3(256), 0, st, a);
+        if (n_parts > 1) {
+            if (wide && a.accum.f64) hipLaunchKernelGGL((power_kernel<double, double, true>), g, dim3(256), 0, st, a);
+            else if (wide) hipLaunchKernelGGL((power_kernel<double, float, true>), g, dim3(256), 0, st, a);
+            else if (a.accum.f64) hipLaunchKernelGGL((power_kernel<float, double, true>), g, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((power_kernel<float, float, true>), g, dim3(256), 0, st, a);
+        } else if (wide && a.accum.f64) hipLaunchKernelGGL((power_kernel<double, double>), g, dim3(256), 0, st, a);
         else if (wide) hipLaunchKernelGGL((power_kernel<double, float>), g, dim3(256), 0, st, a);
         else if (a.accum.f64) hipLaunchKernelGGL((power_kernel<float, double>), g, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((power_kernel<float, float>), g, dim3(256), 0, st, a);
@@ -438,7 +448,11 @@ static int measure_run(const void* d_accum, int64_t n_bins, int64_t n_signals, u
         const dim3 grid((unsigned)n_bins, (unsigned)a.n_tiles);
         const bool cplx = measure == SC_M_CSM || measure == SC_M_COHERENCY || measure == SC_M_PLV_COMPLEX;
         hipStream_t st = (hipStream_t)stream;
-#define MT_LAUNCH(C, O, O2, A) hipLaunchKernelGGL((measure_tile_kernel<C, O, O2, A>), grid, dim3(256), 0, st, a)
+#define MT_LAUNCH(C, O, O2, A)                                                                                  \
+    do {                                                                                                        \
+        if (n_parts > 1) hipLaunchKernelGGL((measure_tile_kernel<C, O, O2, A, true>), grid, dim3(256), 0, st, a); \
+        else hipLaunchKernelGGL((measure_tile_kernel<C, O, O2, A>), grid, dim3(256), 0, st, a);                 \
+    } while (0)
         if (a.accum.f64) {
             if (cplx && wide) MT_LAUNCH(true, double, double2, double);
             else if (cplx) MT_LAUNCH(true, float, float2, double);
@@ -459,6 +473,14 @@ static int measure_run(const void* d_accum, int64_t n_bins, int64_t n_signals, u
 extern "C" int sc_measure_f32(const void* d_accum, int64_t n_bins, int64_t n_signals, uint32_t planes,
                               int64_t n_observations, int measure, void* d_out, void* stream) {
     return measure_run(d_accum, n_bins, n_signals, planes, n_observations, measure, d_out, false, stream);
+}
+
+// One measure -- power and the complex-valued ones included -- from a record that arrives as n_parts partial records (layout as for
+// sc_measure_multi_parts), summed in part order while they are read.  wide: double / complex128 output.
+extern "C" int sc_measure_parts(const void* d_part0, const void* d_rest, int n_parts, int64_t part_stride, int64_t n_bins,
+                                int64_t n_signals, uint32_t planes, int64_t n_observations, int measure, void* d_out, int wide,
+                                void* stream) {
+    return measure_run(d_part0, n_bins, n_signals, planes, n_observations, measure, d_out, wide != 0, stream, n_parts, d_rest, part_stride);
 }
 
 // the same measures written as double / complex128: what the reference returns, without a widening pass

@@ -585,12 +585,14 @@ def measure(accum, n_signals, planes, n_obs, which, out=None, wide=None):
     """Stage C: one measure from an accumulator tensor (after any cross-GPU sum).  ``wide``: write float64 /
     complex128 (what the reference returns) straight from the epilogue; default: wide for double records."""
     lib = _lib.load()
+    parts = None
     if accum.dim() == 3:
-        # partial records (accumulate(fold=False), or the blocks of a direct exchange): the real-valued C x C measures sum them
-        # inside the epilogue kernel, the others (power, complex measures) take the folded record
-        if which != _lib.M_POWER and which not in _lib.COMPLEX_MEASURES and accum.shape[0] > 1 and accum.is_contiguous() and out is None:
-            return measure_multi(accum, n_signals, planes, n_obs, [which], wide=wide)[0]
-        accum = fold_parts(accum)
+        # partial records (accumulate(fold=False), or the blocks of a direct exchange): the epilogue kernels sum them in part order
+        # while they read (sc_measure_parts: every measure, power and the complex-valued ones included)
+        if accum.shape[0] > 1 and accum.is_contiguous():
+            parts, accum = accum, accum[0]
+        else:
+            accum = fold_parts(accum)
     n_bins = accum.shape[0]
     C = n_signals
     if wide is None:
@@ -604,6 +606,10 @@ def measure(accum, n_signals, planes, n_obs, which, out=None, wide=None):
         shape, dtype = (n_bins, C, C), real_t
     if out is None:
         out = torch.empty(shape, dtype=dtype, device=accum.device)
+    if parts is not None:
+        _lib.check(lib.sc_measure_parts(_ptr(parts[0]), _ptr(parts[1]), parts.shape[0], parts.stride(0), n_bins, C,
+                                        rec_planes(accum, planes), n_obs, which, _ptr(out), int(bool(wide)), _stream()), "sc_measure_parts")
+        return out
     fn = lib.sc_measure_f64 if wide else lib.sc_measure_f32
     _lib.check(fn(_ptr(accum), n_bins, C, rec_planes(accum, planes), n_obs, which, _ptr(out), _stream()),
                "sc_measure")

@@ -327,8 +327,12 @@ def test_stage_b_on_planes_three_term_sweep(n_obs, C, debug_env):
                 assert torch.equal(a.nan_to_num(), b.nan_to_num()), "the epilogue on partial records differs from the epilogue on their sum"
             two = engine.measure_multi(parts, C, PLANES, n, [_lib.M_COHERENCE_MAGNITUDE, _lib.M_WPLI])
             assert torch.equal(two[1], engine.measure(accum, C, PLANES, n, _lib.M_WPLI))
-            pw = engine.measure(parts, C, PLANES, n, _lib.M_POWER)                          # (power: the folded record)
-            assert torch.equal(pw, engine.measure(accum, C, PLANES, n, _lib.M_POWER))
+            for which in (_lib.M_POWER, _lib.M_CSM, _lib.M_COHERENCY):                        # sc_measure_parts: every measure
+                for wide in (False, True):
+                    a = engine.measure(parts, C, PLANES, n, which, wide=wide)
+                    b = engine.measure(accum, C, PLANES, n, which, wide=wide)
+                    ra, rb = (torch.view_as_real(v) if v.is_complex() else v for v in (a, b))
+                    assert a.dtype == b.dtype and torch.equal(ra.nan_to_num(), rb.nan_to_num()), (which, wide)
         else:
             assert torch.equal(parts, accum)
     print(f"\n  n_obs {n_obs:5d}, {C:3d} signals: err / bound and |Im s| rel err per (split, forced terms): "
