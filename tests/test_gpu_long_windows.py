@@ -1,0 +1,137 @@
+"""Stage A for long power-of-two windows (csrc/sc_mtfft_long.hip: transposed series, two half-workgroups in anti-phase,
+several items per workgroup with the next item's prologue under the last store slot) against the float64 oracle
+(oracle/spectral_oracle.py::multitaper_fft, which follows transforms.py:1311-1405) -- every shape the kernel branches on:
+channel counts around its tiles and super-tiles, odd counts, one channel, zero padding (L < N), overlapping windows, every
+detrend, many trials (several items per workgroup), silent / constant / non-finite channels, the trial ranges of a small
+scratch; and the round-3 kernels (SC_MTFFT_LONG=0) on the same inputs.  Tolerance: the float32 engine's bar of
+tests/test_gpu_parity.py, |err| <= 1e-5 |ref| + 1e-5 max |ref|."""
+import numpy as np
+import pytest
+
+from oracle import spectral_oracle as so
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a ROCm device"
+    from spectral_connectivity_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def _close(got, ref, what, rtol=1e-5, atol_scale=1e-5):
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    nan_g, nan_r = np.isnan(got), np.isnan(ref)
+    assert np.array_equal(nan_g, nan_r), f"{what}: NaN pattern differs ({nan_g.sum()} vs {nan_r.sum()})"
+    ok = ~nan_r
+    scale = np.abs(ref[ok]).max()
+    worst = (np.abs(got[ok] - ref[ok]) / (rtol * np.abs(ref[ok]) + atol_scale * scale)).max()
+    assert worst <= 1.0, f"{what}: worst err / bound {worst:.2f}"
+    return worst
+
+
+def _oracle(x, L, step, N, det, NW=2.5, fs=200.0):
+    return so.multitaper_fft(x, fs=fs, NW=NW, detrend_type=det, n_time_samples_per_window=L, n_time_samples_per_step=step,
+                             n_fft_samples=N)[0]
+
+
+def _device(x, L, step, N, det, NW=2.5, fs=200.0):
+    """Two-sided coefficients [W, R, K, N, C] through the public class, float32 engine."""
+    import warnings
+    import spectral_connectivity_amd as sc
+    from spectral_connectivity_amd import options
+    old, options.precision = options.precision, "float32"
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m = sc.Multitaper(x, sampling_frequency=fs, time_halfbandwidth_product=NW, detrend_type=det,
+                              n_time_samples_per_window=L, n_time_samples_per_step=step, n_fft_samples=N)
+            return m.fft()
+    finally:
+        options.precision = old
+
+
+@pytest.mark.parametrize("kernel", ["anti-phase", "round-3"])
+@pytest.mark.parametrize("N,L,step,C,R,det", [
+    (2048, 2048, 2048, 1, 3, "constant"), (2048, 2048, 512, 5, 4, "linear"), (2048, 1500, 700, 16, 3, None),
+    (2048, 2048, 2048, 17, 2, "constant"), (2048, 2048, 1024, 34, 3, "linear"), (2048, 2000, 2000, 130, 2, "constant"),
+    (4096, 4096, 4096, 1, 2, "linear"), (4096, 4096, 1024, 3, 3, "constant"), (4096, 3000, 3000, 8, 3, None),
+    (4096, 4096, 4096, 16, 2, "constant"), (4096, 4096, 2048, 18, 2, "linear"), (4096, 4000, 4000, 33, 2, "constant"),
+    (4096, 4096, 4096, 66, 1, "constant"),
+])
+def test_long_windows_against_the_oracle(N, L, step, C, R, det, kernel, debug_env):
+    _dev()
+    debug_env("SC_MTFFT_LONG", None if kernel == "anti-phase" else "0")
+    rng = np.random.default_rng(N + 31 * C + L)
+    T = L + 2 * step
+    x = rng.standard_normal((T, R, C)) * (0.3 + rng.random(C)) + 4.0 * rng.standard_normal((1, R, C)) \
+        + np.linspace(0, 3, T)[:, None, None] * rng.standard_normal((1, 1, C))
+    got, ref = _device(x, L, step, N, det), _oracle(x, L, step, N, det)
+    w = _close(got, ref, f"N={N} L={L} step={step} C={C} {det} [{kernel}]")
+    print(f"\n  N={N} L={L} step={step} C={C} R={R} {det} [{kernel}]: worst err / bound {w:.2f}")
+
+
+@pytest.mark.parametrize("N,C,R", [(2048, 40, 150), (4096, 24, 90)])
+def test_many_trials_walk_several_items_per_workgroup(N, C, R, debug_env):
+    """Enough (window, trial, channel tile) items that every workgroup takes several, one after the other, with the next item's
+    samples loaded and detrended under the last store slot of the current one (every SC_MTFFT_DEBUG grid choice gives the same
+    bits); a scratch of a few trials at a time gives the same bits again."""
+    import torch
+    from spectral_connectivity_amd import engine
+    _dev()
+    rng = np.random.default_rng(N + C)
+    L, step = N, N // 2
+    T = L + step
+    x = (rng.standard_normal((T, R, C)) + 2.0).astype(np.float32)
+    from spectral_connectivity_amd.transforms import dpss_windows
+    tapers = np.asarray(dpss_windows(L, 2.0, 3)[0], dtype=np.float64)
+    xd, h = torch.from_numpy(x).cuda(), torch.from_numpy(np.ascontiguousarray(tapers, dtype=np.float32)).cuda()
+    outs = {}
+    for grid in (None, "64", "128", "256", "512"):
+        debug_env("SC_MTFFT_DEBUG", grid)
+        outs[grid] = engine.multitaper_spectra(xd, h, L, step, N, 2, "linear").X.clone()
+    for grid, X in outs.items():
+        assert torch.equal(torch.view_as_real(X), torch.view_as_real(outs[None])), f"items per workgroup ({grid}) change the result"
+    debug_env("SC_MTFFT_DEBUG", None)
+    debug_env("SC_MTFFT_LONG_SCRATCH_MB", "1")
+    few = engine.multitaper_spectra(xd, h, L, step, N, 2, "linear").X
+    assert torch.equal(torch.view_as_real(few), torch.view_as_real(outs[None])), "trial ranges of a small scratch change the result"
+    # and the values: float64 transform of the same float32 samples
+    xs = torch.from_numpy(x.astype(np.float64)).cuda()
+    t = torch.arange(1, L + 1, dtype=torch.float64, device="cuda") / L
+    A = torch.stack([t, torch.ones_like(t)], 1)
+    ref = []
+    for w in range(2):
+        seg = xs[w * step: w * step + L]                                              # [L, R, C]
+        coef = torch.linalg.lstsq(A, seg.reshape(L, -1)).solution                     # linear detrend, least squares
+        seg = (seg.reshape(L, -1) - A @ coef).reshape(L, R, C)
+        tap = torch.from_numpy(tapers).cuda()                                         # [K, L]
+        ref.append(torch.fft.rfft(seg[None] * tap[:, :, None, None], n=N, dim=1))     # [K, F, R, C]
+    ref = torch.stack(ref, 0).permute(2, 0, 3, 1, 4)                                  # [F, W, R, K, C]
+    err = (outs[None].to(torch.complex128) - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 2e-6, err
+
+
+@pytest.mark.parametrize("N", [2048, 4096])
+def test_silent_constant_and_nonfinite_channels_in_long_windows(N):
+    """A silent channel and a constant one (constant detrend) give EXACTLY zero coefficients, a NaN / infinity spoils its own
+    channel in the windows that hold it and nothing else (transforms.py:1402-1405: every channel is transformed on its own)."""
+    _dev()
+    rng = np.random.default_rng(N)
+    C, R, L, step = 10, 3, N, N // 2
+    T = L + 2 * step
+    x = rng.standard_normal((T, R, C)) * 2.0 + 1.0
+    x[:, :, 2] = 0.0
+    x[:, :, 7] = 0.75
+    x[L // 3, 1, 4] = np.nan              # windows 0 of trial 1, channel 4 (partner: channel 5)
+    x[L + step + 5, 2, 9] = np.inf        # window 2 only of trial 2, channel 9 (partner: channel 8)
+    clean = np.where(np.isfinite(x), x, 0.0)
+    got, ref = _device(x, L, step, N, "constant"), _oracle(clean, L, step, N, "constant")
+    bad = np.zeros(got.shape, dtype=bool)
+    bad[0, 1, :, :, 4] = True
+    bad[2, 2, :, :, 9] = True
+    assert np.isnan(got[bad]).all() and np.isfinite(got[~bad]).all()
+    assert np.all(got[..., 2] == 0) and np.all(got[..., 7] == 0)
+    _close(np.where(bad, 0, got), np.where(bad, 0, ref), f"N={N}: channels beside a silent / non-finite one")
