@@ -13,7 +13,7 @@ void sc_set_error(const char* fmt, ...);
 enum ScSwitch {
     SC_SW_FUSED_DEBUG, SC_SW_FUSED2_TERMS, SC_SW_FUSED_SPLIT, SC_SW_FUSED_NO_SMALL, SC_SW_MTFFT_DEBUG, SC_SW_MTFFT_WIDE,
     SC_SW_MTFFT_F64, SC_SW_F64_SPLIT, SC_SW_F64_OC, SC_SW_F64_NO_FORK, SC_SW_F64_NO_BLOCK, SC_SW_WILSON_FFT, SC_SW_GLOBAL_EIG,
-    SC_SW_GLOBAL_NT256, SC_SW_GRANGER_KERNEL, SC_SW_FUSED_FOLD_OBS, SC_SW_MTFFT_LONG, SC_SW_MTFFT_LONG_SCRATCH_MB, SC_SW_COUNT
+    SC_SW_GLOBAL_NT256, SC_SW_GRANGER_KERNEL, SC_SW_FUSED_FOLD_OBS, SC_SW_MTFFT_LONG, SC_SW_COUNT
 };
 const char* sc_switch(int id);
 
@@ -21,11 +21,8 @@ const char* sc_switch(int id);
 int sc_internal_rows_to_bins(const void* d_Z, void* d_X, int64_t rows, int64_t F, int64_t batch, int64_t b_off,
                              int64_t nyquist_row, hipStream_t st);
 
-// sc_memory.hip: hipMallocAsync from the default pool, which is told once per device to keep freed memory (release threshold)
-hipError_t sc_internal_pool_alloc(void** d_ptr, size_t bytes, hipStream_t st);
-
-// sc_mtfft_long.hip: stage A for long power-of-two windows (transposed series, two half-workgroups in anti-phase)
-bool sc_internal_mtfft_long_applies(int64_t N, int64_t C);
+// sc_mtfft_long.hip: stage A for long power-of-two windows (two half-workgroups in anti-phase)
+bool sc_internal_mtfft_long_applies(int64_t N, int64_t C, int64_t groups);
 int sc_internal_mtfft_long(const float* d_x, int64_t T, int64_t R, int64_t C, int64_t L, int64_t step, int64_t W, int64_t N,
                            const float* d_tapers, int64_t K, int detrend_type, const void* d_twiddles, void* d_X, hipStream_t st);
 

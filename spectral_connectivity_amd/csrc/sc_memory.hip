@@ -20,12 +20,6 @@ static void keep_pool_memory() {
     (void)hipGetLastError();
 }
 
-// stream-ordered scratch of the library's own entry points, from the pool that keeps what was freed
-hipError_t sc_internal_pool_alloc(void** d_ptr, size_t bytes, hipStream_t st) {
-    keep_pool_memory();
-    return hipMallocAsync(d_ptr, bytes, st);
-}
-
 extern "C" int sc_device_alloc(void** d_ptr, size_t bytes, void* stream) {
     SC_REQUIRE(d_ptr != nullptr, "NULL argument");
     *d_ptr = nullptr;

@@ -1392,10 +1392,9 @@ static int mtfft_run(const float* d_x, int64_t T, int64_t R, int64_t C, int64_t 
             SC_CHECK_HIP(hipMemsetAsync(d_P, 0, (size_t)((N / 2 + 1) * W * R * K) * (size_t)a.row_bytes, s));
     }
     if ((N & (N - 1)) != 0) return launch_mixed(a, N, s);
-    if (!d_P && sc_internal_mtfft_long_applies(N, C)) {
-        // long windows: transposed series + anti-phase half-workgroups (sc_mtfft_long.hip); without its scratch, the kernels below
-        const int rc = sc_internal_mtfft_long(d_x, T, R, C, L, step, W, N, d_tapers, K, detrend_type, d_twiddles, d_X, s);
-        if (rc != SC_ENOMEM) return rc;
+    if (!d_P && sc_internal_mtfft_long_applies(N, C, W * R)) {
+        // long windows with enough work to fill the chip: anti-phase half-workgroups (sc_mtfft_long.hip)
+        return sc_internal_mtfft_long(d_x, T, R, C, L, step, W, N, d_tapers, K, detrend_type, d_twiddles, d_X, s);
     }
     switch (N) {
     case 64: return launch_mt16<6>(a, s);

@@ -3,20 +3,23 @@
 // (reference: transforms.py:1147-1171 sliding windows, :1311-1405 _multitaper_fft, :1798-1915 detrend).
 //
 // Why a second kernel.  At these lengths one packed transform (two channels) fills 35 KB of LDS, so a workgroup holds few
-// channels, and the round-3 kernel (mtfft16_kernel<11 / 12>) ran its three phases one after the other on every compute unit
-// (SC_MTFFT_DEBUG ablation at the cfg3 volume, N = 4096: 2.38 ms = 0.87 load + detrend, 0.75 passes, 0.66 stores):
-//  * its loads took 8 bytes of 64 different rows per wave instruction (x is [time][trial][channel]: a workgroup needs 16 bytes
-//    of every 512-byte row) -- 0.6 TB/s of samples;
-//  * the two workgroups of a compute unit fell into step: both in the passes (sharing the VALU), then both in the store loop
+// channels, and the round-3 kernels (mtfft16_kernel<10 / 11 / 12>) ran their three phases one after the other on every compute
+// unit (SC_MTFFT_DEBUG ablation at the cfg3 volume, N = 4096: 2.38 ms = 0.87 load + detrend, 0.75 passes, 0.66 stores):
+//  * the long-window loads took 8 bytes of 64 different rows per wave instruction (x is [time][trial][channel]: a workgroup needs
+//    16 bytes of every 512-byte row): 0.6 TB/s of samples;
+//  * the workgroups of a compute unit fell into step: all in the passes (sharing the VALU), then all in the store loop
 //    (sharing the memory pipe), so nothing overlapped.
-// Here:
-//  1. a tiled transpose turns the series into xt[trial][channel][time] first (0.5 GB read + written once at the cfg3 volume;
-//     stream-ordered scratch, <= 1 GiB at a time), so a wave reads 256 contiguous bytes of ONE channel per instruction;
-//  2. a workgroup is TWO halves of 512 threads that run in ANTI-PHASE by construction: while half 0 runs the radix-16 passes
-//     of taper k (VALU + LDS), half 1 splits and stores its taper k - 1 (memory pipe), then they swap -- the phase boundary is
-//     a workgroup barrier both halves reach, and the passes' inner barriers are matched by barriers between the store chunks
-//     of the other half.  One workgroup (16 waves, 139 KB of LDS: one exchange buffer per half) owns the compute unit.
-// Each half transforms NF = 512 / (N / 16) channel pairs (8 / 4 / 2 at N = 1024 / 2048 / 4096), a workgroup 4 NF channels.
+// Here a workgroup is TWO halves of 512 threads that run in ANTI-PHASE by construction: while half 0 runs the radix-16 passes
+// of taper k (VALU + LDS), half 1 splits and stores its taper k - 1 (memory pipe), then they swap -- the slot boundary is a
+// workgroup barrier both halves reach, and the passes' inner barriers are matched by barriers between the store chunks of the
+// other half (N = 1024: one wave per transform, no inner barriers at all).  One workgroup (16 waves, 139 KB of exchange
+// buffers: one per half) owns the compute unit.  Each half transforms NF = 512 / (N / 16) channel pairs (8 / 4 / 2 at
+// N = 1024 / 2048 / 4096), a workgroup 4 NF channels.  The window reaches the registers through the exchange buffers, which are
+// free until the first pass: two row-major half-window tiles, loaded with 16-byte pieces of the rows and read back per thread.
+// (First form of this kernel: the series transposed to [trial][channel][time] by a pass of its own -- 0.25 ms of the 1.6 at
+//  the cfg3 volume -- and read as contiguous channel rows; and several items per workgroup with the next item's prologue under
+//  the last store slot, which gained nothing at 2048 samples and LOST 40 % at 4096: there the four workgroups whose 32-byte
+//  pieces complete a line must stay in step, and they only do when they are dispatched together.)
 // Arithmetic as in sc_mtfft.hip (two real channels per complex sequence, pair normalised per window by powers of two, halved
 // samples, fp64 trend sums, three register-resident passes through a skewed exchange buffer); pass-2 twiddles come from a
 // 16 x 16 table, pass-3 twiddles from the product of two small tables, every table access at a constant offset from a base.
@@ -26,36 +29,16 @@
 #include "sc_mtfft_bfly.h"
 
 struct LongArgs {
-    const float* xt;       // [Rc][C][Tt]: row (r - r_off, c) holds that channel's samples, time fastest
+    const float* x;        // [T][R][C]
     const float* tapers;   // [K][L], already divided by fs
     const float2* tw;      // [N] exp(-2 pi i m / N)
     float2* X;             // [F][W][R][K][C]
-    int64_t Tt;
     int R, C, L, step, W, K, detrend;
-    int r_off, Rc;         // trials [r_off, r_off + Rc) of this launch
     int n_items;           // (window, trial) groups rounded up to a multiple of 8, times channel tiles
+    int vec;               // rows can be read in 16-byte pieces (C % 4 == 0, x 16-byte aligned)
     int dbg;               // SC_MTFFT_DEBUG (results WRONG when set): 1 or 4 = no split / store loop, 2 = no passes,
                            // 16 = non-temporal stores, 32 = no super-tiles (A/B)
 };
-
-// x[t][col] (col = trial * C + channel, `ld` columns) -> xt[col - col0][t], t < T_used, 64 x 64 tiles through LDS
-__global__ void __launch_bounds__(256) series_transpose_kernel(const float* __restrict__ x, float* __restrict__ xt, int64_t T_used,
-                                                               int64_t ld, int64_t col0, int64_t ncols, int64_t Tt) {
-    __shared__ float tile[64][65];
-    const int64_t t0 = (int64_t)blockIdx.x * 64, c0 = (int64_t)blockIdx.y * 64;
-    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int64_t t = t0 + ly + 4 * j, c = c0 + lx;
-        tile[ly + 4 * j][lx] = (t < T_used && c < ncols) ? x[t * ld + col0 + c] : 0.f;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int64_t c = c0 + ly + 4 * j, t = t0 + lx;
-        if (c < ncols && t < Tt) xt[c * Tt + t] = tile[lx][ly + 4 * j];
-    }
-}
 
 template <int LOG2N>
 __global__ void __launch_bounds__(1024, 1) mtfft_long_kernel(LongArgs p) {
@@ -66,8 +49,12 @@ __global__ void __launch_bounds__(1024, 1) mtfft_long_kernel(LongArgs p) {
     constexpr int CTH = 2 * NF;          // channels per half
     constexpr int CT = 2 * CTH;          // channels per workgroup
     constexpr int ZS = N + N / 16 + 1;   // skewed exchange buffer per transform (float2), odd stride
-    constexpr int NB = LOG2N == 12 ? 5 : 4;      // workgroup barriers of one slot
     constexpr int WPF = TPF / 64;        // waves per transform
+    // One wave per transform (N = 1024): LDS executes a wave's instructions in order, so the exchanges between the passes need no
+    // workgroup barrier -- ONE barrier per slot (the hand-over between the halves), the waves of a half run free in between, and
+    // the taper is double-buffered instead of parked behind a barrier.
+    constexpr bool WAVE_LOCAL = WPF == 1;
+    constexpr int NB = WAVE_LOCAL ? 1 : (LOG2N == 12 ? 5 : 4);      // workgroup barriers of one slot
     extern __shared__ __align__(16) unsigned char smem[];
     float2* zall = reinterpret_cast<float2*>(smem);             // [2][NF][ZS]
     // Twiddle tables, every access (a per-thread base) + (a compile-time constant):
@@ -78,42 +65,40 @@ __global__ void __launch_bounds__(1024, 1) mtfft_long_kernel(LongArgs p) {
     float2* T2 = zall + 2 * NF * ZS;                             // [16][16]
     float2* TH = LOG2N == 12 ? T2 : T2 + 256;                    // [M][16]
     float2* TL = TH + (LOG2N == 12 ? 256 : M * 16);              // [M][16]
-    float* tap = reinterpret_cast<float*>(TL + M * 16);          // [N] the taper in use (zeros from L on)
+    float* tap = reinterpret_cast<float*>(TL + M * 16);          // [N] the taper in use (zeros from L on); WAVE_LOCAL: [2][N]
     __shared__ int nzf[CT], nbf[CT];
     __shared__ unsigned mxc[CT];
     __shared__ double red[16][4];                                // trend sums per wave
 
     const int tid = threadIdx.x, half = tid >> 9, ht = tid & (HT - 1), wv = tid >> 6;
     const int L = p.L, C = p.C, K = p.K;
-    // Items.  An item is (window, trial, channel tile); the workgroup walks items blockIdx.x, blockIdx.x + gridDim.x, ... (gridDim.x
-    // is a multiple of 8, so a workgroup stays on its XCD b % 8 and all tiles of a (window, trial) stay on ONE XCD).
+    // Items.  Workgroup b takes item b = (window, trial, channel tile); block b runs on XCD b % 8, and the tiles of one (window, trial)
+    // are dealt to ONE XCD (they share every row they read, and the pieces of a frequency row they write).
     // Channels of a tile: a half stores CTH channels = a 64-byte (N = 2048) or 32-byte (N = 4096) piece of every frequency row;
     // SUP = 16 / CTH tiles form a super-tile of SUP * CT channels in which the h-th halves of the SUP workgroups -- in the same
-    // phase, on one XCD -- hold 16 ADJACENT channels: their pieces complete a 128-byte line in that XCD's L2 within a store chunk,
-    // where the two halves of one workgroup are a phase apart (N = 4096: 2.8 -> 2.1 ms).  Up to 16 channels: no super-tiles.
+    // phase, on one XCD, dispatched back to back -- hold 16 ADJACENT channels: their pieces complete a 128-byte line in that XCD's
+    // L2 within a store chunk, where the two halves of one workgroup are a phase apart (N = 4096: 2.8 -> 2.1 ms).  Up to 16
+    // channels: no super-tiles.
     constexpr int SUP = CTH >= 16 ? 1 : 16 / CTH;
     const bool sup = C > 16 && SUP > 1 && !(p.dbg & 32);
     const int n_ct = sup ? (C + SUP * CT - 1) / (SUP * CT) * SUP : (C + CT - 1) / CT;
-    const int n_groups = p.W * p.Rc;
-    auto item = [&](int m, int& chalf, int& w, int& r) -> bool {
-        const int xcd = m & 7, j = m >> 3, g = (j / n_ct) * 8 + xcd;
-        if (m >= p.n_items || g >= n_groups) return false;
-        const int tile = j % n_ct;
-        chalf = sup ? (tile / SUP) * (SUP * CT) + half * (SUP * CTH) + (tile % SUP) * CTH : tile * CT + half * CTH;
-        w = g / p.Rc; r = p.r_off + (g - w * p.Rc);
-        return true;
-    };
-    int n_mine = 0;                                   // (the valid items of a workgroup are a prefix of its walk)
+    int ch0[2], w, r;                                 // first channel of either half
     {
-        int c_, w_, r_;
-        for (int m = blockIdx.x; item(m, c_, w_, r_); m += gridDim.x) ++n_mine;
+        const int m = blockIdx.x, xcd = m & 7, j = m >> 3, g = (j / n_ct) * 8 + xcd;
+        if (g >= p.W * p.R) return;
+        const int tile = j % n_ct;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            ch0[h] = sup ? (tile / SUP) * (SUP * CT) + h * (SUP * CTH) + (tile % SUP) * CTH : tile * CT + h * CTH;
+        w = g / p.R; r = g - w * p.R;
     }
-    if (n_mine == 0) return;
+    const int chalf = ch0[half];
 
     const int pf = ht / TPF, i = ht - pf * TPF;       // transform of this half and butterfly index
     const int lp = 2 * (half * NF + pf);              // this pair's slot in the flag arrays
     float2* zh = zall + half * NF * ZS;
     float2* zf = zh + pf * ZS;
+    if (tid < CT) { nzf[tid] = 0; nbf[tid] = 0; mxc[tid] = 0u; }
     if (tid < 256) T2[tid] = p.tw[((tid >> 4) * (tid & 15)) * (N / 256)];
     else if (tid < 256 + M * 16) {
         const int e = tid - 256, t = e >> 4, x = e & 15;
@@ -127,42 +112,55 @@ __global__ void __launch_bounds__(1024, 1) mtfft_long_kernel(LongArgs p) {
         return (E >= 1u && E <= 253u) ? __uint_as_float((inverse ? E : 254u - E) << 23) : 1.f;
     };
 
-    // ---- what a half holds of its current item ----
-    float2 xs[16];                                    // this thread's pass-1 inputs, all tapers
-    const int spr = ht & (NF - 1), fb = ht / NF, sl = 2 * (half * NF + spr);      // the pair this thread stores, its first bin
-    float2* Xi = nullptr;                             // X[fb][w][r][0][cs]
-    int cs = 0;                                       // first channel of the stored pair
-    unsigned fl = 0;                                  // bit 0 / 1: channel a / b non-finite, 2 / 3: identically zero
-    float ia = 1.f, ib = 1.f;                         // back to the samples' units
-    const bool vec_ok = (C % 2) == 0;
-    const int64_t sF = (int64_t)p.W * p.R * K * C;
-
-    // The prologue of an item in four steps with a workgroup barrier between consecutive ones.  For the first item both halves take
-    // them before the slot loop; from then on a half takes them in its LAST store slot of the previous item (whose passes are
-    // done: xs is free), one step per store chunk -- the samples travel while the previous spectra leave.
-    auto pro_load = [&](int chalf, int w, int r) {    // step 1: samples in flight, flags of this half cleared
-        const int cpair = chalf + 2 * pf;
-        const float* row0 = p.xt + ((int64_t)(r - p.r_off) * C + cpair) * p.Tt + (int64_t)w * p.step + i;
-        const bool h0 = cpair < C, h1 = cpair + 1 < C;
+    // ---- the window into registers: two half-window tiles [N / 2 rows][CT channels] through the exchange buffers ----
+    float2 xs[16];                                    // this thread's pass-1 inputs, all tapers: samples i + t TPF of its pair
+    {
+        constexpr int RS = CT + 2;                    // padded row (floats): the per-thread float2 reads below are conflict-free
+        constexpr int QR = CT / 4, V = CTH / 4;       // 16-byte pieces per row, per half
+        static_assert((size_t)(N / 2) * RS * 4 <= (size_t)2 * NF * ZS * 8, "tile does not fit the exchange buffers");
+        float* tile = reinterpret_cast<float*>(smem);
+        const int64_t RC = (int64_t)p.R * C;
+        const float* xw = p.x + ((int64_t)w * p.step * p.R + r) * C;
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            float2 v = make_float2(0.f, 0.f);
-            if (i + t * TPF < L) {
-                if (h0) v.x = row0[t * TPF];
-                if (h1) v.y = row0[p.Tt + t * TPF];
+        for (int hh = 0; hh < 2; ++hh) {
+            float4 v[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {          // (N / 2) QR pieces = 4096 = 4 per thread
+                const int idx = tid + it * 1024, row = idx / QR, q = idx - row * QR, c = ch0[q / V] + 4 * (q % V);
+                const int n = hh * (N / 2) + row;
+                v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (n < L && c < C) {
+                    const float* src = xw + (int64_t)n * RC + c;
+                    if (p.vec && c + 3 < C) {
+                        v[it] = *reinterpret_cast<const float4*>(src);
+                    } else {
+                        v[it].x = src[0];
+                        if (c + 1 < C) v[it].y = src[1];
+                        if (c + 2 < C) v[it].z = src[2];
+                        if (c + 3 < C) v[it].w = src[3];
+                    }
+                }
             }
-            xs[t] = v;
+            if (hh == 1) __syncthreads();             // the reads of the first half are done
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int idx = tid + it * 1024, row = idx / QR, q = idx - row * QR;
+                float2* d = reinterpret_cast<float2*>(tile + row * RS + 4 * q);
+                d[0] = make_float2(v[it].x, v[it].y);
+                d[1] = make_float2(v[it].z, v[it].w);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int t = 8 * hh; t < 8 * hh + 8; ++t)
+                xs[t] = *reinterpret_cast<const float2*>(tile + (i + (t - 8 * hh) * TPF) * RS + half * CTH + 2 * pf);
         }
-        if (ht < CTH) { nzf[half * CTH + ht] = 0; nbf[half * CTH + ht] = 0; mxc[half * CTH + ht] = 0u; }
-    };
-    auto pro_sums = [&]() {                           // step 2: trend sums in fp64 -- a thread's 16 samples, its wave by shuffles
-        if (!detr) return;
+    }
+    if (detr) {
+        // trend sums in fp64: a thread's 16 samples, its wave by shuffles, the waves of a transform in a fixed order below
         double s0 = 0.0, t0 = 0.0, s1 = 0.0, t1 = 0.0;
-        int iv = i + 1;
-        asm volatile("" : "+v"(iv));                  // (keeps the sixteen sample positions out of the slot loop's invariants: registers)
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
-            const double l1 = (double)(iv + t * TPF);
+            const double l1 = (double)(i + t * TPF + 1);
             s0 += (double)xs[t].x; t0 += (double)xs[t].x * l1;
             s1 += (double)xs[t].y; t1 += (double)xs[t].y * l1;
         }
@@ -172,40 +170,39 @@ __global__ void __launch_bounds__(1024, 1) mtfft_long_kernel(LongArgs p) {
             s1 += __shfl_xor(s1, m); t1 += __shfl_xor(t1, m);
         }
         if ((tid & 63) == 0) { red[wv][0] = s0; red[wv][1] = t0; red[wv][2] = s1; red[wv][3] = t1; }
-    };
-    auto pro_detrend = [&]() {                        // step 3: the waves of a transform in a fixed order, detrend, channel flags
-        if (detr) {
-            const int wv0 = (half * HT + pf * TPF) >> 6;
-            const double n = (double)L, invL = 1.0 / n;
-            const double St = (n + 1.0) * 0.5, Stt = (n + 1.0) * (2.0 * n + 1.0) / (6.0 * n), den = n * Stt - St * St;
-            double ab[2][2];
+    }
+    __syncthreads();                                  // the tile is consumed (the exchange buffers are free), trend sums visible
+    if (detr) {
+        const int wv0 = (half * HT + pf * TPF) >> 6;
+        const double n = (double)L, invL = 1.0 / n;
+        const double St = (n + 1.0) * 0.5, Stt = (n + 1.0) * (2.0 * n + 1.0) / (6.0 * n), den = n * Stt - St * St;
+        double ab[2][2];
 #pragma unroll
-            for (int ch = 0; ch < 2; ++ch) {
-                double sum = 0.0, sumt = 0.0;
+        for (int ch = 0; ch < 2; ++ch) {
+            double sum = 0.0, sumt = 0.0;
 #pragma unroll
-                for (int q = 0; q < WPF; ++q) { sum += red[wv0 + q][2 * ch]; sumt += red[wv0 + q][2 * ch + 1]; }
-                sumt /= n;
-                double a = 0.0, b;
-                if (p.detrend == SC_DETREND_CONSTANT) {
-                    b = sum / n;
-                } else {
-                    a = (den != 0.0) ? (n * sumt - St * sum) / den : 0.0;
-                    b = (sum - a * St) / n;
-                }
-                ab[ch][0] = a; ab[ch][1] = b;
+            for (int q = 0; q < WPF; ++q) { sum += red[wv0 + q][2 * ch]; sumt += red[wv0 + q][2 * ch + 1]; }
+            sumt /= n;
+            double a = 0.0, b;
+            if (p.detrend == SC_DETREND_CONSTANT) {
+                b = sum / n;
+            } else {
+                a = (den != 0.0) ? (n * sumt - St * sum) / den : 0.0;
+                b = (sum - a * St) / n;
             }
-            int iv = i + 1;
-            asm volatile("" : "+v"(iv));              // (as above)
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const double tt = (double)(iv + t * TPF) * invL;
-                const float dx = (float)((double)xs[t].x - (ab[0][0] * tt + ab[0][1]));
-                const float dy = (float)((double)xs[t].y - (ab[1][0] * tt + ab[1][1]));
-                const bool in = i + t * TPF < L;      // (zero padding stays zero)
-                xs[t].x = in ? dx : 0.f;
-                xs[t].y = in ? dy : 0.f;
-            }
+            ab[ch][0] = a; ab[ch][1] = b;
         }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const double tt = (double)(i + t * TPF + 1) * invL;
+            const float dx = (float)((double)xs[t].x - (ab[0][0] * tt + ab[0][1]));
+            const float dy = (float)((double)xs[t].y - (ab[1][0] * tt + ab[1][1]));
+            const bool in = i + t * TPF < L;          // (zero padding stays zero)
+            xs[t].x = in ? dx : 0.f;
+            xs[t].y = in ? dy : 0.f;
+        }
+    }
+    {
         // flag 1: the channel is not identically zero; flag 2: it holds a NaN / infinity (such a channel leaves the packed
         // transform -- zeros in its place, its partner stays clean -- and its bins are written as NaN); largest finite magnitude
         // of every channel of this window for the pair normalisation (see sc_mtfft.hip)
@@ -223,8 +220,9 @@ __global__ void __launch_bounds__(1024, 1) mtfft_long_kernel(LongArgs p) {
         if (b1) nbf[lp + 1] = 1;
         if (!b0 && n0) atomicMax(&mxc[lp], mx0);
         if (!b1 && n1) atomicMax(&mxc[lp + 1], mx1);
-    };
-    auto pro_finish = [&](int chalf, int w, int r) {  // step 4: samples ready for the passes, the store state of the item
+    }
+    __syncthreads();
+    {
         if (nbf[lp]) {
 #pragma unroll
             for (int t = 0; t < 16; ++t) xs[t].x = 0.f;
@@ -237,12 +235,18 @@ __global__ void __launch_bounds__(1024, 1) mtfft_long_kernel(LongArgs p) {
         const float h0 = 0.5f * pair_scale(mxc[lp], false), h1 = 0.5f * pair_scale(mxc[lp + 1], false);
 #pragma unroll
         for (int t = 0; t < 16; ++t) { xs[t].x *= h0; xs[t].y *= h1; }
+    }
+    // the pair this thread stores (its first bin: fb), and what it needs to know about it
+    const int spr = ht & (NF - 1), fb = ht / NF, sl = 2 * (half * NF + spr), cs = chalf + 2 * spr;
+    unsigned fl;                                      // bit 0 / 1: channel a / b non-finite, 2 / 3: identically zero
+    {
         const bool na = nbf[sl] != 0, nb = nbf[sl + 1] != 0;
         fl = (na ? 1u : 0u) | (nb ? 2u : 0u) | ((!na && nzf[sl] == 0) ? 4u : 0u) | ((!nb && nzf[sl + 1] == 0) ? 8u : 0u);
-        ia = pair_scale(mxc[sl], true); ib = pair_scale(mxc[sl + 1], true);
-        cs = chalf + 2 * spr;
-        Xi = p.X + ((int64_t)w * p.R + r) * K * C + cs + (int64_t)fb * sF;
-    };
+    }
+    const float ia = pair_scale(mxc[sl], true), ib = pair_scale(mxc[sl + 1], true);      // back to the samples' units
+    const bool vec_ok = (C % 2) == 0;
+    const int64_t sF = (int64_t)p.W * p.R * K * C;
+    float2* const Xi = p.X + ((int64_t)w * p.R + r) * K * C + cs + (int64_t)fb * sF;     // X[fb][w][r][0][cs]
 
     // Every LDS address below is (one base per role) + (compile-time constant): with phys(idx) = idx + idx / 16,
     //   pass 1 writes   phys(16 i + u)        = 17 i + u
@@ -260,15 +264,27 @@ __global__ void __launch_bounds__(1024, 1) mtfft_long_kernel(LongArgs p) {
     const float2* const zm = zh + spr * ZS + (N - fb) + ((N - fb) >> 4) - 7 * FS;      // mirrored bin of round m: zm[(7 - m) FS]
     const float2* const zm0 = fb == 0 ? zh + spr * ZS : zm + 7 * FS;                    // round 0: bin N - 0 is bin 0
 
-    // ONE taper buffer serves both halves: taper k is read by half 0 in the first interval of slot 2k and by half 1 in the first
-    // interval of slot 2k + 1; behind that interval's barrier half 0 (storing then) replaces it with the next taper.
+    // ONE taper buffer serves both halves where a transform spans several waves: taper k is read by half 0 in the first interval of
+    // slot 2k and by half 1 in the first interval of slot 2k + 1; behind that interval's barrier half 0 (storing then) replaces it
+    // with the next taper.
     constexpr int TPT = N / HT;                       // taper values per thread of a half
     const float2* const t2 = T2 + kk;                                                  // pass 2: t2[16 t]
     const float2* const th = TH + (i >> 4);                                            // pass 3, butterfly b: th[16 t + b TPF / 16]
     const float2* const tl = TL + kk;                                                  //         tl[16 t]
 
-    auto passes = [&]() {                             // NB workgroup barriers
+#define PBAR()                                                      \
+    do {                                                            \
+        if constexpr (WAVE_LOCAL) {                                 \
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  \
+            __builtin_amdgcn_wave_barrier();                        \
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  \
+        } else {                                                    \
+            __syncthreads();                                        \
+        }                                                           \
+    } while (0)
+    auto passes = [&](int k) {                        // NB workgroup barriers
         float2 a[16], o[16];
+        const float* tk = WAVE_LOCAL ? tap + (k & 1) * N + i : tap + i;
         if (p.dbg & 2) {
 #pragma unroll
             for (int b = 0; b < NB; ++b) __syncthreads();
@@ -276,13 +292,13 @@ __global__ void __launch_bounds__(1024, 1) mtfft_long_kernel(LongArgs p) {
         }
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
-            const float h = tap[i + t * TPF];
+            const float h = tk[t * TPF];
             a[t] = make_float2(xs[t].x * h, xs[t].y * h);
         }
         dft16(a, o);
 #pragma unroll
         for (int u = 0; u < 16; ++u) zw1[u] = o[u];
-        __syncthreads();                                                              // 1
+        PBAR();                                                                       // 1
         {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -294,10 +310,10 @@ __global__ void __launch_bounds__(1024, 1) mtfft_long_kernel(LongArgs p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
             dft16(a, o);
-            __syncthreads();                                                          // 2
+            PBAR();                                                                   // 2
 #pragma unroll
             for (int u = 0; u < 16; ++u) zw2[17 * u] = o[u];
-            __syncthreads();                                                          // 3
+            PBAR();                                                                   // 3
         }
         if constexpr (LOG2N == 12) {        // pass 3: radix 16, P = 256
 #pragma unroll
@@ -310,7 +326,7 @@ __global__ void __launch_bounds__(1024, 1) mtfft_long_kernel(LongArgs p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
             dft16(a, o);
-            __syncthreads();                                                          // 4
+            PBAR();                                                                   // 4
 #pragma unroll
             for (int u = 0; u < 16; ++u) zr[272 * u] = o[u];
         } else if constexpr (LOG2N == 11) { // pass 3: radix 8, P = 256, two butterflies per thread, in place
@@ -362,18 +378,15 @@ __global__ void __launch_bounds__(1024, 1) mtfft_long_kernel(LongArgs p) {
             if (cs + 1 < C) dst[1] = B;
         }
     };
-    // One store slot: taper k of the current item leaves (F * NF = 8 * 512 + NF outputs per half, in four chunks); half 0 parks taper
-    // k_next; with m_next >= 0 the half also takes the prologue of its next item.  NB workgroup barriers.
-    auto store = [&](int k, int k_next, int m_next) {
+    // One store slot: taper k leaves (F * NF = 8 * 512 + NF outputs per half, in four chunks); half 0 parks taper k + 1.  NB workgroup barriers.
+    auto store = [&](int k) {
         float2* Xk = Xi + (int64_t)k * C;
         const int64_t sR = (int64_t)FSTEP * sF;       // one round further
         const bool live = cs < C && !(p.dbg & 5);
-        const bool park = half == 0 && k_next >= 0;
-        int nc = 0, nw = 0, nr = 0;
-        const bool pro = m_next >= 0 && item(m_next, nc, nw, nr);
+        const bool park = half == 0 && k + 1 < K;
         float hn[TPT];
         if (park) {
-            const float* tp = p.tapers + ((int64_t)k_next * L + ht);       // (one address per slot, constants from there)
+            const float* tp = p.tapers + ((int64_t)(k + 1) * L + ht);      // (one address per slot, constants from there)
 #pragma unroll
             for (int j = 0; j < TPT; ++j) hn[j] = (ht + j * HT < L) ? tp[j * HT] : 0.f;
         }
@@ -394,49 +407,28 @@ __global__ void __launch_bounds__(1024, 1) mtfft_long_kernel(LongArgs p) {
                     put(Xk + 8 * sR, zn, zn);
                 }
             }
-            if (pro) {
-                if (ch == 0) pro_load(nc, nw, nr);
-                else if (ch == 1) pro_sums();
-                else if (ch == 2) pro_detrend();
-            }
-            __syncthreads();
-            if (ch == 0 && park) {                    // the other half has read the taper in use (its first interval): replace it
+            if constexpr (!WAVE_LOCAL) __syncthreads();
+            if (ch == 0 && park) {
+                // not WAVE_LOCAL: the other half has read the taper in use (its first interval), replace it; WAVE_LOCAL: the other buffer
+                float* tn = WAVE_LOCAL ? tap + ((k + 1) & 1) * N : tap;
 #pragma unroll
-                for (int j = 0; j < TPT; ++j) tap[ht + j * HT] = hn[j];
+                for (int j = 0; j < TPT; ++j) tn[ht + j * HT] = hn[j];
             }
         }
-        if constexpr (NB == 5) __syncthreads();
-        if (pro) pro_finish(nc, nw, nr);              // (behind the last store of the current item: its store state is dead)
+        if constexpr (NB == 5 || WAVE_LOCAL) __syncthreads();
     };
 
-    // ---- the first item: both halves together ----
-    {
-        int c_ = 0, w_ = 0, r_ = 0;
-        item(blockIdx.x, c_, w_, r_);
-        pro_load(c_, w_, r_);
-        __syncthreads();                              // flags cleared, tables visible
-        pro_sums();
-        __syncthreads();
-        pro_detrend();
-        __syncthreads();
-        pro_finish(c_, w_, r_);
-    }
-    // Slot q of a half: item q / 2K, taper (q % 2K) / 2, passes in the even slots and the store in the odd ones; half 1 is one slot behind half 0.
-    const int n_slots = 2 * K * n_mine;
+    // Slot q of a half: taper q / 2, the passes in the even slots and the store in the odd ones; half 1 is one slot behind half 0.
 #pragma nounroll
-    for (int gs = 0; gs <= n_slots; ++gs) {
+    for (int gs = 0; gs <= 2 * K; ++gs) {
         const int q = gs - half;
-        if (q < 0 || q >= n_slots) {
+        if (q < 0 || q >= 2 * K) {
 #pragma unroll
             for (int b = 0; b < NB; ++b) __syncthreads();
-            continue;
-        }
-        const int it = q / (2 * K), ph = q - it * 2 * K, k = ph >> 1;
-        if (!(ph & 1)) {
-            passes();
+        } else if (!(q & 1)) {
+            passes(q >> 1);
         } else {
-            const bool more = it + 1 < n_mine;
-            store(k, k + 1 < K ? k + 1 : (more ? 0 : -1), (k + 1 == K && more) ? (int)blockIdx.x + (it + 1) * (int)gridDim.x : -1);
+            store(q >> 1);
         }
     }
 }
@@ -446,55 +438,36 @@ static bool long_enabled() {
     return !e || atoi(e) != 0;
 }
 
-bool sc_internal_mtfft_long_applies(int64_t N, int64_t C) {
+// N = 1024 ... 4096 (SC_MTFFT_LONG=0: never; =2048: from 2048 samples on -- A/B of the 1024-sample kernels; =1: always), and enough
+// (window, trial, channel tile) items to give every compute unit a workgroup: a workgroup here holds 4 x the channels of the
+// round-3 kernels', so a small problem (BASELINE configs[1]: 100 trials x 32 channels = 100 items at N = 1024) fills the chip
+// better with those.
+bool sc_internal_mtfft_long_applies(int64_t N, int64_t C, int64_t groups) {
     if (!long_enabled()) return false;
     const char* e = sc_switch(SC_SW_MTFFT_LONG);
-    const int lo = e && atoi(e) >= 1024 ? atoi(e) : 2048;          // SC_MTFFT_LONG=1024: also the 1024-sample windows (A/B)
-    return N >= lo && N <= 4096 && (N & (N - 1)) == 0 && C >= 1;
+    const int lo = e && atoi(e) >= 1024 ? atoi(e) : 1024;
+    if (!(N >= lo && N <= 4096 && (N & (N - 1)) == 0 && C >= 1)) return false;
+    if (e && atoi(e) == 1) return true;                              // SC_MTFFT_LONG=1: whatever the size (tests)
+    const int64_t ct = 4 * (512 / (N / 16));
+    return groups * ((C + ct - 1) / ct) >= 256;
 }
 
 template <int LOG2N>
-static int launch_long(LongArgs a, const float* d_x, int64_t T, hipStream_t st) {
+static int launch_long(LongArgs a, hipStream_t st) {
     constexpr int N = 1 << LOG2N, TPF = N / 16, NF = 512 / TPF, CT = 4 * NF, ZS = N + N / 16 + 1;
-    constexpr size_t lds = (size_t)2 * NF * ZS * 8 + (256 + (LOG2N == 12 ? 256 : 2 * (N / 256) * 16)) * 8 + (size_t)N * 4;
+    constexpr size_t lds = (size_t)2 * NF * ZS * 8 + (256 + (LOG2N == 12 ? 256 : 2 * (N / 256) * 16)) * 8 + (size_t)N * 4 * (TPF == 64 ? 2 : 1);
     static_assert(lds + 1024 <= 160 * 1024, "LDS budget exceeded");
     auto k = mtfft_long_kernel<LOG2N>;
     SC_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    // the samples the windows cover, transposed for a range of trials at a time (scratch <= 1 GiB)
-    const int64_t T_used = (int64_t)(a.W - 1) * a.step + a.L, Tt = (T_used + 63) / 64 * 64;
-    SC_REQUIRE(T_used <= T, "windows exceed the time series");
-    const char* mb = sc_switch(SC_SW_MTFFT_LONG_SCRATCH_MB);       // (diagnostic: a small scratch exercises the trial ranges)
-    int64_t rc = (mb && atoi(mb) > 0 ? (int64_t)atoi(mb) << 20 : (int64_t)1 << 30) / (Tt * a.C * 4);
-    rc = rc < 1 ? 1 : (rc > a.R ? a.R : rc);
-    float* xt = nullptr;
-    if (sc_internal_pool_alloc((void**)&xt, (size_t)(rc * a.C * Tt) * sizeof(float), st) != hipSuccess) {
-        (void)hipGetLastError();
-        sc_set_error("multitaper FFT (N=%d): scratch allocation failed", N);
-        return SC_ENOMEM;
+    constexpr int SUP = 2 * NF >= 16 ? 1 : 16 / (2 * NF);      // = the kernel's
+    const int64_t n_ct = (a.C > 16 && SUP > 1 && !(a.dbg & 32)) ? (a.C + SUP * CT - 1) / (SUP * CT) * SUP : (a.C + CT - 1) / CT;
+    const int64_t groups8 = ((int64_t)a.W * a.R + 7) / 8 * 8;
+    if (groups8 * n_ct >= ((int64_t)1 << 31)) {
+        sc_set_error("multitaper FFT (N=%d): too many windows x trials for one launch", N);
+        return SC_EINVAL;
     }
-    a.xt = xt; a.Tt = Tt;
-    int rc_ret = SC_OK, dev = 0, n_cu = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-    n_cu = n_cu < 8 ? 8 : n_cu / 8 * 8;
-    for (int64_t r0 = 0; r0 < a.R; r0 += rc) {
-        const int64_t n = a.R - r0 < rc ? a.R - r0 : rc, ncols = n * a.C;
-        hipLaunchKernelGGL(series_transpose_kernel, dim3((unsigned)(Tt / 64), (unsigned)((ncols + 63) / 64)), dim3(256), 0, st,
-                           d_x, xt, T_used, (int64_t)a.R * a.C, r0 * a.C, ncols, Tt);
-        a.r_off = (int)r0; a.Rc = (int)n;
-        constexpr int SUP = 2 * NF >= 16 ? 1 : 16 / (2 * NF);      // = the kernel's
-        const int64_t n_ct = (a.C > 16 && SUP > 1 && !(a.dbg & 32)) ? (a.C + SUP * CT - 1) / (SUP * CT) * SUP : (a.C + CT - 1) / CT;
-        const int64_t groups8 = ((int64_t)a.W * n + 7) / 8 * 8;
-        if (groups8 * n_ct >= ((int64_t)1 << 31)) { sc_set_error("multitaper FFT (N=%d): too many windows x trials for one launch", N); rc_ret = SC_EINVAL; break; }
-        a.n_items = (int)(groups8 * n_ct);
-        // persistent workgroups, one per compute unit (a multiple of 8: a workgroup's items stay on its XCD)
-        // items per workgroup (A/B through SC_MTFFT_DEBUG: 64 -> 1, 128 -> 2, 256 -> 4, 512 -> one workgroup per compute unit)
-        const int64_t ipw = (a.dbg & 64) ? 1 : (a.dbg & 128) ? 2 : (a.dbg & 256) ? 4 : (a.dbg & 512) ? (a.n_items + n_cu - 1) / n_cu : 1;
-        int64_t grid = ((a.n_items + ipw - 1) / ipw + 7) / 8 * 8;
-        if (grid > a.n_items) grid = a.n_items;
-        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(1024), lds, st, a);
-    }
-    (void)hipFreeAsync(xt, st);
-    if (rc_ret != SC_OK) return rc_ret;
+    a.n_items = (int)(groups8 * n_ct);
+    hipLaunchKernelGGL(k, dim3((unsigned)a.n_items), dim3(1024), lds, st, a);
     SC_CHECK_HIP(hipGetLastError());
     return SC_OK;
 }
@@ -502,13 +475,15 @@ static int launch_long(LongArgs a, const float* d_x, int64_t T, hipStream_t st) 
 int sc_internal_mtfft_long(const float* d_x, int64_t T, int64_t R, int64_t C, int64_t L, int64_t step, int64_t W, int64_t N,
                            const float* d_tapers, int64_t K, int detrend_type, const void* d_twiddles, void* d_X, hipStream_t st) {
     LongArgs a{};
-    a.tapers = d_tapers; a.tw = (const float2*)d_twiddles; a.X = (float2*)d_X;
+    a.x = d_x; a.tapers = d_tapers; a.tw = (const float2*)d_twiddles; a.X = (float2*)d_X;
     a.R = (int)R; a.C = (int)C; a.L = (int)L; a.step = (int)step; a.W = (int)W; a.K = (int)K; a.detrend = detrend_type;
+    a.vec = (C % 4 == 0 && ((uintptr_t)d_x & 15) == 0) ? 1 : 0;
     { const char* d = sc_switch(SC_SW_MTFFT_DEBUG); a.dbg = d ? atoi(d) : 0; }
+    SC_REQUIRE((W - 1) * step + L <= T, "windows exceed the time series");
     switch (N) {
-    case 1024: return launch_long<10>(a, d_x, T, st);
-    case 2048: return launch_long<11>(a, d_x, T, st);
-    case 4096: return launch_long<12>(a, d_x, T, st);
+    case 1024: return launch_long<10>(a, st);
+    case 2048: return launch_long<11>(a, st);
+    case 4096: return launch_long<12>(a, st);
     }
     return SC_EUNSUPPORTED;
 }
