@@ -23,8 +23,10 @@ int sc_internal_rows_to_bins(const void* d_Z, void* d_X, int64_t rows, int64_t F
 
 // sc_mtfft_long.hip: stage A for long power-of-two windows (two half-workgroups in anti-phase)
 bool sc_internal_mtfft_long_applies(int64_t N, int64_t C, int64_t groups);
+int64_t sc_internal_mtfft_long_coverage(int64_t N, int64_t C);
 int sc_internal_mtfft_long(const float* d_x, int64_t T, int64_t R, int64_t C, int64_t L, int64_t step, int64_t W, int64_t N,
-                           const float* d_tapers, int64_t K, int detrend_type, const void* d_twiddles, void* d_X, hipStream_t st);
+                           const float* d_tapers, int64_t K, int detrend_type, const void* d_twiddles, void* d_X, void* d_P,
+                           const float* d_scale, hipStream_t st);
 
 // sc_wilson_fft.hip: A <- fft(causal(ifft(A))) in one kernel, for the lengths `supported` accepts
 bool sc_internal_causal_fft_supported(int64_t N);

@@ -1349,7 +1349,8 @@ static int mt_wide() {
 }
 
 extern "C" int sc_multitaper_fft_planes_supported(int64_t L, int64_t N, int64_t C) {
-    return (L >= 1 && L <= N && N >= 64 && N <= 1024 && (N & (N - 1)) == 0 && C >= 2 && (C % 2) == 0) ? 1 : 0;
+    // (2048 and 4096 samples: the anti-phase kernel of sc_mtfft_long.hip only)
+    return (L >= 1 && L <= N && N >= 64 && N <= 4096 && (N & (N - 1)) == 0 && C >= 2 && (C % 2) == 0) ? 1 : 0;
 }
 
 extern "C" int sc_multitaper_fft_supported(int64_t L, int64_t N) {
@@ -1378,24 +1379,26 @@ static int mtfft_run(const float* d_x, int64_t T, int64_t R, int64_t C, int64_t 
              (int)step, (int)W, (int)K, detrend_type};
     a.P = (unsigned char*)d_P; a.scale = d_scale; a.row_bytes = 256 * ((C + 31) / 32);
     hipStream_t s = (hipStream_t)stream;
+    // long windows with enough work to fill the chip -- and every planes-format request beyond 1024 samples: anti-phase
+    // half-workgroups (sc_mtfft_long.hip)
+    const bool pow2 = (N & (N - 1)) == 0;
+    const bool use_long = pow2 && (sc_internal_mtfft_long_applies(N, C, W * R) || (d_P && N >= 2048));
     if (d_P) {
         if (!sc_multitaper_fft_planes_supported(L, N, C)) {
-            sc_set_error("planes-format multitaper FFT needs an even number of signals and N a power of two in 64 ... 1024 (got C=%lld N=%lld)",
+            sc_set_error("planes-format multitaper FFT needs an even number of signals and N a power of two in 64 ... 4096 (got C=%lld N=%lld)",
                          (long long)C, (long long)N);
             return SC_EUNSUPPORTED;
         }
-        // A workgroup writes the CT channels it transforms (CT = 2 * threads / (N / 16): 16 at 512 samples and with the 512-thread
-        // workgroups of 1024, 8 with 256 threads at 1024); where ceil(C / CT) workgroups do not cover the last 32-channel tile the
-        // uncovered part must read as zeros (stage B stages whole tiles)
+        // A workgroup writes the CT channels it transforms (round-1..3 kernels: CT = 2 * threads / (N / 16), 16 at 512 samples and
+        // with the 512-thread workgroups of 1024, 8 with 256 threads at 1024); where the workgroups do not cover the last 32-channel
+        // tile the uncovered part must read as zeros (stage B stages whole tiles)
         const int64_t threads = (N == 1024 && mt_wide() && C >= 16) ? 512 : 256, ct = 2 * threads / (N / 16);
-        if ((C + ct - 1) / ct * ct < (C + 31) / 32 * 32)
+        const int64_t covered = use_long ? sc_internal_mtfft_long_coverage(N, C) : (C + ct - 1) / ct * ct;
+        if (covered < (C + 31) / 32 * 32)
             SC_CHECK_HIP(hipMemsetAsync(d_P, 0, (size_t)((N / 2 + 1) * W * R * K) * (size_t)a.row_bytes, s));
     }
-    if ((N & (N - 1)) != 0) return launch_mixed(a, N, s);
-    if (!d_P && sc_internal_mtfft_long_applies(N, C, W * R)) {
-        // long windows with enough work to fill the chip: anti-phase half-workgroups (sc_mtfft_long.hip)
-        return sc_internal_mtfft_long(d_x, T, R, C, L, step, W, N, d_tapers, K, detrend_type, d_twiddles, d_X, s);
-    }
+    if (!pow2) return launch_mixed(a, N, s);
+    if (use_long) return sc_internal_mtfft_long(d_x, T, R, C, L, step, W, N, d_tapers, K, detrend_type, d_twiddles, d_X, d_P, d_scale, s);
     switch (N) {
     case 64: return launch_mt16<6>(a, s);
     case 128: return launch_mt16<7>(a, s);

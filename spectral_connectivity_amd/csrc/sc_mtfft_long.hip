@@ -36,31 +36,61 @@ struct LongArgs {
     int R, C, L, step, W, K, detrend;
     int n_items;           // (window, trial) groups rounded up to a multiple of 8, times channel tiles
     int vec;               // rows can be read in 16-byte pieces (C % 4 == 0, x 16-byte aligned)
+    // planes-format output (sc_fused2.hip: two f16 pieces per real, x * scale[c] = h + m, rows [f][w][r][k] of row_bytes; a row is
+    // 256-byte tiles of 32 channels: planes Re h, Re m, Im h, Im m of 64 bytes each): when P is set the spectra go there INSTEAD of X
+    unsigned char* P;
+    const float* scale;    // [C] powers of two
+    int64_t row_bytes;
     int dbg;               // SC_MTFFT_DEBUG (results WRONG when set): 1 or 4 = no split / store loop, 2 = no passes,
-                           // 16 = non-temporal stores, 32 = no super-tiles (A/B)
+                           // 16 = non-temporal stores, 32 = no super-tiles, 64 = the other workgroup size at N <= 1024 (A/B)
 };
 
-template <int LOG2N>
-__global__ void __launch_bounds__(1024, 1) mtfft_long_kernel(LongArgs p) {
+// HT: threads of a half.  512 (one workgroup of 16 waves owns the compute unit) or 256 (two workgroups of 8 waves share it: half the
+// channels per workgroup, but the prologue of one runs under the slots of the other).
+typedef _Float16 ml_h16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned ml_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned ml_u32x2 __attribute__((ext_vector_type(2)));
+// two scaled reals -> the dwords of their leading and trailing f16 pieces (x = h + m to 22 significant bits): one packed conversion
+// and two mixed-precision fmas that read their f16 operand straight from the halves of h (as in sc_mtfft.hip)
+__device__ __forceinline__ void ml_split2(float x0, float x1, unsigned& h, unsigned& m) {
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(x0), "v"(x1));
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(m) : "v"(x0), "v"(h));
+    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(m) : "v"(x1), "v"(h));
+}
+// One step of a 4 x 4 transpose inside a quad of lanes: lanes with `hi` clear give b and take the partner's a into b, lanes with
+// `hi` set give a and take the partner's b into a; the partner is lane ^ 1 (CTRL = quad_perm [1, 0, 3, 2]) or lane ^ 2 ([2, 3, 0, 1]).
+template <int CTRL>
+__device__ __forceinline__ void ml_quad_xchg(ml_u32x4& a, ml_u32x4& b, bool hi) {
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const unsigned give = hi ? a[d] : b[d];
+        const unsigned take = (unsigned)__builtin_amdgcn_mov_dpp((int)give, CTRL, 0xf, 0xf, true);
+        if (hi) a[d] = take; else b[d] = take;
+    }
+}
+
+template <int LOG2N, int HT, bool PL>
+__global__ void __launch_bounds__(2 * HT, HT == 512 ? 1 : 4) mtfft_long_kernel(LongArgs p) {
     constexpr int N = 1 << LOG2N;
-    constexpr int HT = 512;              // threads of a half
+    constexpr int THREADS = 2 * HT;
     constexpr int TPF = N / 16;          // threads per transform: 16 points each
     constexpr int NF = HT / TPF;         // transforms (channel pairs) per half
     constexpr int CTH = 2 * NF;          // channels per half
     constexpr int CT = 2 * CTH;          // channels per workgroup
     constexpr int ZS = N + N / 16 + 1;   // skewed exchange buffer per transform (float2), odd stride
-    constexpr int WPF = TPF / 64;        // waves per transform
+    constexpr int WPF = TPF >= 64 ? TPF / 64 : 1;        // waves per transform (N <= 512: 64 / TPF transforms per wave)
     // One wave per transform (N = 1024): LDS executes a wave's instructions in order, so the exchanges between the passes need no
     // workgroup barrier -- ONE barrier per slot (the hand-over between the halves), the waves of a half run free in between, and
     // the taper is double-buffered instead of parked behind a barrier.
-    constexpr bool WAVE_LOCAL = WPF == 1;
+    constexpr bool WAVE_LOCAL = TPF <= 64;
     constexpr int NB = WAVE_LOCAL ? 1 : (LOG2N == 12 ? 5 : 4);      // workgroup barriers of one slot
+    static_assert(LOG2N >= 8 && LOG2N <= 12, "256 ... 4096 samples");
     extern __shared__ __align__(16) unsigned char smem[];
     float2* zall = reinterpret_cast<float2*>(smem);             // [2][NF][ZS]
     // Twiddle tables, every access (a per-thread base) + (a compile-time constant):
     //   pass 2:  W_256^(t kk)                                  = T2[t][kk]
     //   pass 3:  W_N^(t ib), ib = 16 hi + lo < 256, t < M      = TH[t][hi] * TL[t][lo],  TH[t][hi] = W_N^(16 t hi), TL[t][lo] = W_N^(t lo)
-    // (M = N / 256 is the radix of pass 3; at N = 4096 TH is T2)
+    // (M = N / 256 is the radix of pass 3 -- no pass 3 at N = 256; at N = 4096 TH is T2)
     constexpr int M = N / 256;
     float2* T2 = zall + 2 * NF * ZS;                             // [16][16]
     float2* TH = LOG2N == 12 ? T2 : T2 + 256;                    // [M][16]
@@ -68,9 +98,9 @@ __global__ void __launch_bounds__(1024, 1) mtfft_long_kernel(LongArgs p) {
     float* tap = reinterpret_cast<float*>(TL + M * 16);          // [N] the taper in use (zeros from L on); WAVE_LOCAL: [2][N]
     __shared__ int nzf[CT], nbf[CT];
     __shared__ unsigned mxc[CT];
-    __shared__ double red[16][4];                                // trend sums per wave
+    __shared__ double red[THREADS / 64][4];                      // trend sums per wave
 
-    const int tid = threadIdx.x, half = tid >> 9, ht = tid & (HT - 1), wv = tid >> 6;
+    const int tid = threadIdx.x, half = tid / HT, ht = tid & (HT - 1), wv = tid >> 6;
     const int L = p.L, C = p.C, K = p.K;
     // Items.  Workgroup b takes item b = (window, trial, channel tile); block b runs on XCD b % 8, and the tiles of one (window, trial)
     // are dealt to ONE XCD (they share every row they read, and the pieces of a frequency row they write).
@@ -99,13 +129,14 @@ __global__ void __launch_bounds__(1024, 1) mtfft_long_kernel(LongArgs p) {
     float2* zh = zall + half * NF * ZS;
     float2* zf = zh + pf * ZS;
     if (tid < CT) { nzf[tid] = 0; nbf[tid] = 0; mxc[tid] = 0u; }
+    static_assert(THREADS >= 256 + M * 16, "table fill");
     if (tid < 256) T2[tid] = p.tw[((tid >> 4) * (tid & 15)) * (N / 256)];
     else if (tid < 256 + M * 16) {
         const int e = tid - 256, t = e >> 4, x = e & 15;
         TL[e] = p.tw[t * x];
         if constexpr (LOG2N != 12) TH[e] = p.tw[16 * t * x];
     }
-    for (int n = tid; n < N; n += 1024) tap[n] = (n < L) ? p.tapers[n] : 0.f;
+    for (int n = tid; n < N; n += THREADS) tap[n] = (n < L) ? p.tapers[n] : 0.f;
     const bool detr = p.detrend != SC_DETREND_NONE;
     auto pair_scale = [](unsigned mx, bool inverse) -> float {
         const unsigned E = mx >> 23;
@@ -115,7 +146,9 @@ __global__ void __launch_bounds__(1024, 1) mtfft_long_kernel(LongArgs p) {
     // ---- the window into registers: two half-window tiles [N / 2 rows][CT channels] through the exchange buffers ----
     float2 xs[16];                                    // this thread's pass-1 inputs, all tapers: samples i + t TPF of its pair
     {
-        constexpr int RS = CT + 2;                    // padded row (floats): the per-thread float2 reads below are conflict-free
+        // padded row (floats): the per-thread float2 reads below are conflict-free -- 32 lanes = 32 rows of one pair (N >= 512: 2 RS
+        // mod 64 banks apart with RS / 2 odd) or 16 rows of two pairs (N = 256: rows 4 banks apart, the pairs 2)
+        constexpr int RS = LOG2N == 8 ? CT + 4 : CT + 2;
         constexpr int QR = CT / 4, V = CTH / 4;       // 16-byte pieces per row, per half
         static_assert((size_t)(N / 2) * RS * 4 <= (size_t)2 * NF * ZS * 8, "tile does not fit the exchange buffers");
         float* tile = reinterpret_cast<float*>(smem);
@@ -125,8 +158,8 @@ __global__ void __launch_bounds__(1024, 1) mtfft_long_kernel(LongArgs p) {
         for (int hh = 0; hh < 2; ++hh) {
             float4 v[4];
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {          // (N / 2) QR pieces = 4096 = 4 per thread
-                const int idx = tid + it * 1024, row = idx / QR, q = idx - row * QR, c = ch0[q / V] + 4 * (q % V);
+            for (int it = 0; it < 4; ++it) {          // (N / 2) QR pieces = 4 per thread
+                const int idx = tid + it * THREADS, row = idx / QR, q = idx - row * QR, c = ch0[q / V] + 4 * (q % V);
                 const int n = hh * (N / 2) + row;
                 v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (n < L && c < C) {
@@ -144,7 +177,7 @@ __global__ void __launch_bounds__(1024, 1) mtfft_long_kernel(LongArgs p) {
             if (hh == 1) __syncthreads();             // the reads of the first half are done
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
-                const int idx = tid + it * 1024, row = idx / QR, q = idx - row * QR;
+                const int idx = tid + it * THREADS, row = idx / QR, q = idx - row * QR;
                 float2* d = reinterpret_cast<float2*>(tile + row * RS + 4 * q);
                 d[0] = make_float2(v[it].x, v[it].y);
                 d[1] = make_float2(v[it].z, v[it].w);
@@ -155,33 +188,39 @@ __global__ void __launch_bounds__(1024, 1) mtfft_long_kernel(LongArgs p) {
                 xs[t] = *reinterpret_cast<const float2*>(tile + (i + (t - 8 * hh) * TPF) * RS + half * CTH + 2 * pf);
         }
     }
+    double tsum[4] = {0.0, 0.0, 0.0, 0.0};            // sum x, sum x (l + 1) of channel a; the same of channel b
     if (detr) {
-        // trend sums in fp64: a thread's 16 samples, its wave by shuffles, the waves of a transform in a fixed order below
-        double s0 = 0.0, t0 = 0.0, s1 = 0.0, t1 = 0.0;
+        // trend sums in fp64: a thread's 16 samples, then the lanes of the transform by shuffles (complete up to 1024 samples: a
+        // transform is at most one wave); beyond, the waves of a transform in a fixed order below
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             const double l1 = (double)(i + t * TPF + 1);
-            s0 += (double)xs[t].x; t0 += (double)xs[t].x * l1;
-            s1 += (double)xs[t].y; t1 += (double)xs[t].y * l1;
+            tsum[0] += (double)xs[t].x; tsum[1] += (double)xs[t].x * l1;
+            tsum[2] += (double)xs[t].y; tsum[3] += (double)xs[t].y * l1;
         }
 #pragma unroll
-        for (int m = 32; m > 0; m >>= 1) {
-            s0 += __shfl_xor(s0, m); t0 += __shfl_xor(t0, m);
-            s1 += __shfl_xor(s1, m); t1 += __shfl_xor(t1, m);
+        for (int m = (TPF < 64 ? TPF : 64) / 2; m > 0; m >>= 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tsum[e] += __shfl_xor(tsum[e], m);
         }
-        if ((tid & 63) == 0) { red[wv][0] = s0; red[wv][1] = t0; red[wv][2] = s1; red[wv][3] = t1; }
+        if constexpr (WPF > 1) {
+            if ((tid & 63) == 0) { red[wv][0] = tsum[0]; red[wv][1] = tsum[1]; red[wv][2] = tsum[2]; red[wv][3] = tsum[3]; }
+        }
     }
     __syncthreads();                                  // the tile is consumed (the exchange buffers are free), trend sums visible
     if (detr) {
-        const int wv0 = (half * HT + pf * TPF) >> 6;
         const double n = (double)L, invL = 1.0 / n;
         const double St = (n + 1.0) * 0.5, Stt = (n + 1.0) * (2.0 * n + 1.0) / (6.0 * n), den = n * Stt - St * St;
         double ab[2][2];
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch) {
-            double sum = 0.0, sumt = 0.0;
+            double sum = tsum[2 * ch], sumt = tsum[2 * ch + 1];
+            if constexpr (WPF > 1) {
+                const int wv0 = (half * HT + pf * TPF) >> 6;
+                sum = 0.0; sumt = 0.0;
 #pragma unroll
-            for (int q = 0; q < WPF; ++q) { sum += red[wv0 + q][2 * ch]; sumt += red[wv0 + q][2 * ch + 1]; }
+                for (int q = 0; q < WPF; ++q) { sum += red[wv0 + q][2 * ch]; sumt += red[wv0 + q][2 * ch + 1]; }
+            }
             sumt /= n;
             double a = 0.0, b;
             if (p.detrend == SC_DETREND_CONSTANT) {
@@ -232,7 +271,11 @@ __global__ void __launch_bounds__(1024, 1) mtfft_long_kernel(LongArgs p) {
             for (int t = 0; t < 16; ++t) xs[t].y = 0.f;
         }
         // halved (the 1/2 of the conjugate-symmetry split) and scaled into [1, 2) per channel: exact
-        const float h0 = 0.5f * pair_scale(mxc[lp], false), h1 = 0.5f * pair_scale(mxc[lp + 1], false);
+        // (planes output: the channel scales -- powers of two -- go onto the samples instead: the two channels of a pair enter their
+        //  transform at the same magnitude, and the store loop has no multiply left)
+        const int c = chalf + 2 * pf;
+        const float h0 = 0.5f * (PL ? (c < C ? p.scale[c] : 1.f) : pair_scale(mxc[lp], false));
+        const float h1 = 0.5f * (PL ? (c + 1 < C ? p.scale[c + 1] : 1.f) : pair_scale(mxc[lp + 1], false));
 #pragma unroll
         for (int t = 0; t < 16; ++t) { xs[t].x *= h0; xs[t].y *= h1; }
     }
@@ -267,7 +310,7 @@ __global__ void __launch_bounds__(1024, 1) mtfft_long_kernel(LongArgs p) {
     // ONE taper buffer serves both halves where a transform spans several waves: taper k is read by half 0 in the first interval of
     // slot 2k and by half 1 in the first interval of slot 2k + 1; behind that interval's barrier half 0 (storing then) replaces it
     // with the next taper.
-    constexpr int TPT = N / HT;                       // taper values per thread of a half
+    constexpr int TPT = N >= HT ? N / HT : 1;         // taper values per thread of a half
     const float2* const t2 = T2 + kk;                                                  // pass 2: t2[16 t]
     const float2* const th = TH + (i >> 4);                                            // pass 3, butterfly b: th[16 t + b TPF / 16]
     const float2* const tl = TL + kk;                                                  //         tl[16 t]
@@ -343,7 +386,7 @@ __global__ void __launch_bounds__(1024, 1) mtfft_long_kernel(LongArgs p) {
                 for (int u = 0; u < 8; ++u) zr[b * TS + 272 * u] = q[u];
                 __builtin_amdgcn_sched_barrier(0);
             }
-        } else {                            // pass 3: radix 4, P = 256, four butterflies per thread, in place
+        } else if constexpr (LOG2N == 10) { // pass 3: radix 4, P = 256, four butterflies per thread, in place
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 float2 q[4];
@@ -356,7 +399,14 @@ __global__ void __launch_bounds__(1024, 1) mtfft_long_kernel(LongArgs p) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) zr[b * TS + 272 * u] = q[u];
             }
-        }
+        } else if constexpr (LOG2N == 9) {  // pass 3: radix 2, P = 256, eight butterflies per thread, in place
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const float2 u0 = zr[b * TS], u1 = cmul(zr[b * TS + 272], cmul(th[16 + b * (TPF / 16)], tl[16]));
+                zr[b * TS] = make_float2(u0.x + u1.x, u0.y + u1.y);
+                zr[b * TS + 272] = make_float2(u0.x - u1.x, u0.y - u1.y);
+            }
+        }                                   // (N = 256: two passes)
         __syncthreads();                                                              // NB
     };
 
@@ -378,6 +428,77 @@ __global__ void __launch_bounds__(1024, 1) mtfft_long_kernel(LongArgs p) {
             if (cs + 1 < C) dst[1] = B;
         }
     };
+    // Planes format: a thread takes G = 4 channel pairs (8 channels; 2 pairs at N = 4096) of one frequency, so that every plane leaves
+    // as one 16-byte (8-byte) store: 2 G LDS reads, the conjugate-symmetry split, the two-piece f16 split.  TR (four or more
+    // groups per half, i.e. N = 256): the four lanes of a quad take four CONSECUTIVE frequencies of one group and transpose their
+    // 4 planes x 4 frequencies before the stores, so that store a of a lane is plane (lane & 3) of frequency a of the quad: the 16
+    // lanes of four quads write one whole 256-byte tile row per instruction (sc_mtfft.hip: 0.14 ms at cfg3 against plane-per-
+    // instruction stores).  Iteration `it` covers the FSP frequencies from it * FSP on; the last one holds the Nyquist bin alone.
+    constexpr int G = NF >= 4 ? 4 : NF, NG = NF / G, FSP = HT / NG, PIT = (N / 2) / FSP + 1;
+    constexpr bool TR = NG >= 4;
+    const int pj = ht & 3, pgrp = TR ? (ht >> 2) % NG : ht % NG, pfq = TR ? (ht / (4 * NG)) * 4 + pj : ht / NG, pcg = chalf + 2 * G * pgrp;
+    bool pflag = false;                               // some channel of this thread's group is silent or non-finite
+    if constexpr (PL) {
+#pragma unroll
+        for (int q = 0; q < 2 * G; ++q) {
+            const int e = 2 * (half * NF + G * pgrp) + q;
+            pflag = pflag || nbf[e] != 0 || nzf[e] == 0;
+        }
+        pflag = __builtin_amdgcn_ballot_w64(pflag) != 0ull;       // wave-uniform
+    }
+    auto put_planes = [&](int k, int it) {
+        using VT = std::conditional_t<G == 4, ml_u32x4, ml_u32x2>;
+        const int f = pfq + it * FSP;
+        if (!(pcg < ((C + 31) & ~31)) || (TR ? f - pj : f) > N / 2) return;      // (absent channels of a started tile are written: zeros)
+        const int64_t rows_f = (int64_t)p.W * p.R * K;
+        unsigned char* dst0 = p.P + (((int64_t)w * p.R + r) * K + k) * p.row_bytes + (pcg >> 5) * 256 + (pcg & 31) * 2 + (TR ? pj * 64 : 0);
+        const int fr = f <= N / 2 ? f : N / 2;        // (TR: a lane past the Nyquist bin reads it again; its column is never stored)
+        float2 u1q[G], u2q[G];                        // all LDS reads in flight before the first split
+        const float2* zg = zh + (G * pgrp) * ZS;
+        const int i1 = fr + (fr >> 4), n2 = (N - fr) & (N - 1), i2 = n2 + (n2 >> 4);
+#pragma unroll
+        for (int q = 0; q < G; ++q) { u1q[q] = zg[q * ZS + i1]; u2q[q] = zg[q * ZS + i2]; }
+        VT rh, rm, ih, im;
+#pragma unroll
+        for (int q = 0; q < G; ++q) {
+            const float2 u1 = u1q[q], u2 = u2q[q];
+            float2 A = make_float2(u1.x + u2.x, u1.y - u2.y);       // (Z[f] + conj Z[N-f]) / 2, the half already in the samples
+            float2 B = make_float2(u1.y + u2.y, u2.x - u1.x);       // (Z[f] - conj Z[N-f]) / (2 i)
+            if (pflag) {
+                const int e = 2 * (half * NF + G * pgrp + q);
+                const bool qna = nbf[e] != 0, qnb = nbf[e + 1] != 0;
+                if (!qna && nzf[e] == 0) A = make_float2(0.f, 0.f);
+                if (!qnb && nzf[e + 1] == 0) B = make_float2(0.f, 0.f);
+                if (qna) A = make_float2(__int_as_float(0x7fc00000), __int_as_float(0x7fc00000));
+                if (qnb) B = make_float2(__int_as_float(0x7fc00000), __int_as_float(0x7fc00000));
+            }
+            unsigned h, m;
+            ml_split2(A.x, B.x, h, m);
+            rh[q] = h; rm[q] = m;
+            ml_split2(A.y, B.y, h, m);
+            ih[q] = h; im[q] = m;
+        }
+        const int64_t fs = rows_f * p.row_bytes;
+        if constexpr (TR) {
+            // items (rh, rm, ih, im) = planes 0 .. 3 of this lane's frequency  ->  plane pj of the quad's frequencies 0 .. 3
+            ml_quad_xchg<0xB1>(rh, rm, (pj & 1) != 0);
+            ml_quad_xchg<0xB1>(ih, im, (pj & 1) != 0);
+            ml_quad_xchg<0x4E>(rh, ih, (pj & 2) != 0);
+            ml_quad_xchg<0x4E>(rm, im, (pj & 2) != 0);
+            const int f0 = f - pj;
+            unsigned char* dst = dst0 + (int64_t)f0 * fs;
+            *reinterpret_cast<VT*>(dst) = rh;
+            if (f0 + 1 <= N / 2) *reinterpret_cast<VT*>(dst + fs) = rm;
+            if (f0 + 2 <= N / 2) *reinterpret_cast<VT*>(dst + 2 * fs) = ih;
+            if (f0 + 3 <= N / 2) *reinterpret_cast<VT*>(dst + 3 * fs) = im;
+        } else {
+            unsigned char* dst = dst0 + (int64_t)f * fs;
+            *reinterpret_cast<VT*>(dst) = rh;
+            *reinterpret_cast<VT*>(dst + 64) = rm;
+            *reinterpret_cast<VT*>(dst + 128) = ih;
+            *reinterpret_cast<VT*>(dst + 192) = im;
+        }
+    };
     // One store slot: taper k leaves (F * NF = 8 * 512 + NF outputs per half, in four chunks); half 0 parks taper k + 1.  NB workgroup barriers.
     auto store = [&](int k) {
         float2* Xk = Xi + (int64_t)k * C;
@@ -392,7 +513,12 @@ __global__ void __launch_bounds__(1024, 1) mtfft_long_kernel(LongArgs p) {
         }
 #pragma unroll
         for (int ch = 0; ch < 4; ++ch) {
-            if (live) {
+            if constexpr (PL) {
+                if (!(p.dbg & 5)) {
+#pragma unroll
+                    for (int it = ch; it < (ch == 3 ? PIT : ch + 1); ++it) put_planes(k, it);
+                }
+            } else if (live) {
                 float2 z1[2], z2[2];
 #pragma unroll
                 for (int it = 0; it < 2; ++it) {
@@ -412,7 +538,8 @@ __global__ void __launch_bounds__(1024, 1) mtfft_long_kernel(LongArgs p) {
                 // not WAVE_LOCAL: the other half has read the taper in use (its first interval), replace it; WAVE_LOCAL: the other buffer
                 float* tn = WAVE_LOCAL ? tap + ((k + 1) & 1) * N : tap;
 #pragma unroll
-                for (int j = 0; j < TPT; ++j) tn[ht + j * HT] = hn[j];
+                for (int j = 0; j < TPT; ++j)
+                    if (ht + j * HT < N) tn[ht + j * HT] = hn[j];
             }
         }
         if constexpr (NB == 5 || WAVE_LOCAL) __syncthreads();
@@ -438,26 +565,37 @@ static bool long_enabled() {
     return !e || atoi(e) != 0;
 }
 
-// N = 1024 ... 4096 (SC_MTFFT_LONG=0: never; =2048: from 2048 samples on -- A/B of the 1024-sample kernels; =1: always), and enough
+// N = 256 ... 4096 (SC_MTFFT_LONG=0: never; =512 / 1024 / 2048: from that many samples on -- A/B; =1: whatever the size), and enough
 // (window, trial, channel tile) items to give every compute unit a workgroup: a workgroup here holds 4 x the channels of the
 // round-3 kernels', so a small problem (BASELINE configs[1]: 100 trials x 32 channels = 100 items at N = 1024) fills the chip
 // better with those.
 bool sc_internal_mtfft_long_applies(int64_t N, int64_t C, int64_t groups) {
     if (!long_enabled()) return false;
     const char* e = sc_switch(SC_SW_MTFFT_LONG);
-    const int lo = e && atoi(e) >= 1024 ? atoi(e) : 1024;
+    const bool force = e && atoi(e) == 1;                            // SC_MTFFT_LONG=1: every length it has, whatever the size (tests)
+    const int lo = (e && atoi(e) >= 256) ? atoi(e) : 256;
     if (!(N >= lo && N <= 4096 && (N & (N - 1)) == 0 && C >= 1)) return false;
-    if (e && atoi(e) == 1) return true;                              // SC_MTFFT_LONG=1: whatever the size (tests)
-    const int64_t ct = 4 * (512 / (N / 16));
+    if (force) return true;
+    const int64_t ct = 4 * ((N <= 512 ? 256 : 512) / (N / 16));
     return groups * ((C + ct - 1) / ct) >= 256;
 }
 
-template <int LOG2N>
-static int launch_long(LongArgs a, hipStream_t st) {
-    constexpr int N = 1 << LOG2N, TPF = N / 16, NF = 512 / TPF, CT = 4 * NF, ZS = N + N / 16 + 1;
-    constexpr size_t lds = (size_t)2 * NF * ZS * 8 + (256 + (LOG2N == 12 ? 256 : 2 * (N / 256) * 16)) * 8 + (size_t)N * 4 * (TPF == 64 ? 2 : 1);
-    static_assert(lds + 1024 <= 160 * 1024, "LDS budget exceeded");
-    auto k = mtfft_long_kernel<LOG2N>;
+// the channels the workgroups of a launch write (planes output: where this leaves part of the last 32-channel tile unwritten, the
+// caller clears the buffer first)
+int64_t sc_internal_mtfft_long_coverage(int64_t N, int64_t C) {
+    const int64_t ht = N <= 512 ? 256 : 512, nf = ht / (N / 16), ct = 4 * nf, sup = 2 * nf >= 16 ? 1 : 16 / (2 * nf);
+    const char* d = sc_switch(SC_SW_MTFFT_DEBUG);
+    const int dbg = d ? atoi(d) : 0;
+    if (dbg & 64) return 0;                                           // (A/B of the other workgroup size: always clear)
+    return (C > 16 && sup > 1 && !(dbg & 32)) ? (C + sup * ct - 1) / (sup * ct) * sup * ct : (C + ct - 1) / ct * ct;
+}
+
+template <int LOG2N, int HT, bool PL>
+static int launch_long_(LongArgs a, hipStream_t st) {
+    constexpr int N = 1 << LOG2N, TPF = N / 16, NF = HT / TPF, CT = 4 * NF, ZS = N + N / 16 + 1;
+    constexpr size_t lds = (size_t)2 * NF * ZS * 8 + (256 + (LOG2N == 12 ? 256 : 2 * (N / 256) * 16)) * 8 + (size_t)N * 4 * (TPF <= 64 ? 2 : 1);
+    static_assert((lds + 512) * (HT == 512 ? 1 : 2) <= 160 * 1024, "LDS budget exceeded");      // (+ the static flags and trend sums)
+    auto k = mtfft_long_kernel<LOG2N, HT, PL>;
     SC_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     constexpr int SUP = 2 * NF >= 16 ? 1 : 16 / (2 * NF);      // = the kernel's
     const int64_t n_ct = (a.C > 16 && SUP > 1 && !(a.dbg & 32)) ? (a.C + SUP * CT - 1) / (SUP * CT) * SUP : (a.C + CT - 1) / CT;
@@ -467,23 +605,33 @@ static int launch_long(LongArgs a, hipStream_t st) {
         return SC_EINVAL;
     }
     a.n_items = (int)(groups8 * n_ct);
-    hipLaunchKernelGGL(k, dim3((unsigned)a.n_items), dim3(1024), lds, st, a);
+    hipLaunchKernelGGL(k, dim3((unsigned)a.n_items), dim3(2 * HT), lds, st, a);
     SC_CHECK_HIP(hipGetLastError());
     return SC_OK;
 }
 
+template <int LOG2N, int HT>
+static int launch_long(const LongArgs& a, hipStream_t st) {
+    return a.P ? launch_long_<LOG2N, HT, true>(a, st) : launch_long_<LOG2N, HT, false>(a, st);
+}
+
 int sc_internal_mtfft_long(const float* d_x, int64_t T, int64_t R, int64_t C, int64_t L, int64_t step, int64_t W, int64_t N,
-                           const float* d_tapers, int64_t K, int detrend_type, const void* d_twiddles, void* d_X, hipStream_t st) {
+                           const float* d_tapers, int64_t K, int detrend_type, const void* d_twiddles, void* d_X, void* d_P,
+                           const float* d_scale, hipStream_t st) {
     LongArgs a{};
     a.x = d_x; a.tapers = d_tapers; a.tw = (const float2*)d_twiddles; a.X = (float2*)d_X;
+    a.P = (unsigned char*)d_P; a.scale = d_scale; a.row_bytes = 256 * ((C + 31) / 32);
+    SC_REQUIRE(!d_P || (d_scale && C % 2 == 0), "planes output needs channel scales and an even number of signals");
     a.R = (int)R; a.C = (int)C; a.L = (int)L; a.step = (int)step; a.W = (int)W; a.K = (int)K; a.detrend = detrend_type;
     a.vec = (C % 4 == 0 && ((uintptr_t)d_x & 15) == 0) ? 1 : 0;
     { const char* d = sc_switch(SC_SW_MTFFT_DEBUG); a.dbg = d ? atoi(d) : 0; }
     SC_REQUIRE((W - 1) * step + L <= T, "windows exceed the time series");
     switch (N) {
-    case 1024: return launch_long<10>(a, st);
-    case 2048: return launch_long<11>(a, st);
-    case 4096: return launch_long<12>(a, st);
+    case 256: return (a.dbg & 64) ? launch_long<8, 512>(a, st) : launch_long<8, 256>(a, st);
+    case 512: return (a.dbg & 64) ? launch_long<9, 512>(a, st) : launch_long<9, 256>(a, st);
+    case 1024: return (a.dbg & 64) ? launch_long<10, 256>(a, st) : launch_long<10, 512>(a, st);
+    case 2048: return launch_long<11, 512>(a, st);
+    case 4096: return launch_long<12, 512>(a, st);
     }
     return SC_EUNSUPPORTED;
 }

@@ -41,16 +41,22 @@ def _series(T, R, C, seed, offset=0.0, quiet=2e-3, loud=250.0):
     return x + offset
 
 
+@pytest.mark.parametrize("kernel", ["engine's choice", "anti-phase"])
 @pytest.mark.parametrize("L,step,C,detrend", [(256, 128, 128, "constant"), (128, 64, 20, "linear"), (64, 64, 34, None),
-                                               (512, 256, 16, "constant"), (1024, 1024, 48, "constant")])
-def test_stage_a_planes_decode_to_the_spectra(L, step, C, detrend):
+                                               (512, 256, 16, "constant"), (1024, 1024, 48, "constant"), (256, 256, 70, "linear"),
+                                               (512, 512, 100, None), (1024, 512, 34, "linear"), (2048, 2048, 48, "constant"),
+                                               (2048, 1024, 22, "linear"), (4096, 4096, 20, "constant"), (4096, 2048, 36, None)])
+def test_stage_a_planes_decode_to_the_spectra(L, step, C, detrend, kernel, debug_env):
     """sc_multitaper_fft_planes_f32 + sc_spectra_from_planes_f32 against the float64 transform of the same samples and
     tapers: the float32 transform's rounding plus the 22 bits of the format.  The scales sit on the SAMPLES, so the two
     channels that share a complex transform enter it at the same magnitude: a channel far weaker than its pair partner (here
     x 250 and x 1/500) comes out to its OWN rounding (the complex64 kernel normalises the pair per window for the same effect;
     before round 4 it left the partner's rounding on the weak channel: 6e-5 of its largest coefficient)."""
     dev, lib = _dev(), _lib.load()
-    T, R, NW = 2048, 3, 3
+    # ("anti-phase": sc_mtfft_long.hip from 256 samples on, whatever the size; the engine's choice at these sizes: the round-1..3
+    #  kernels up to 1024 samples, the anti-phase kernel -- the only one with this output there -- beyond)
+    debug_env("SC_MTFFT_LONG", "1" if kernel == "anti-phase" else None)
+    T, R, NW = max(2048, 2 * L), 3, 3
     K = 2 * NW - 1
     W = (T - L) // step + 1
     x = torch.from_numpy(_series(T, R, C, seed=L + C).astype(np.float32)).to(dev)
@@ -202,7 +208,9 @@ def test_when_the_engine_takes_the_planes_format():
         assert _lib.planes_format_applies(1024, 1024, 256, fam, spectra_bytes=big)
         assert not _lib.planes_format_applies(256, 256, 40, fam, spectra_bytes=big)
         assert not _lib.planes_format_applies(256, 256, 64, fam, spectra_bytes=32 << 20)
-        assert not _lib.planes_format_applies(2048, 2048, 64, fam, spectra_bytes=big)
+        assert _lib.planes_format_applies(2048, 2048, 64, fam, spectra_bytes=big)          # (round 5: 2048 and 4096 samples too)
+        assert _lib.planes_format_applies(4096, 4096, 64, fam, spectra_bytes=big)
+        assert not _lib.planes_format_applies(8192, 8192, 64, fam, spectra_bytes=big)
         assert not _lib.planes_format_applies(256, 256, 258, fam, spectra_bytes=big)
     assert not _lib.planes_format_applies(256, 256, 64, _lib.PLANE_CSM | _lib.PLANE_UNIT, spectra_bytes=big)
     assert not _lib.planes_format_applies(256, 256, 64, _lib.PLANE_UNIT, spectra_bytes=big)
