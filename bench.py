@@ -7,7 +7,7 @@ x 1024 samples, NW=4 (7 tapers), sliding 256-sample windows with 128-sample step
 F=129), coherence_magnitude + weighted_phase_lag_index, expectation over trials x tapers.
 
 One "step" = one full pass of the hot path over the synthetic batch, inputs resident in HBM:
-  stage A  window + detrend + taper + FFT + transposed store, one fused HIP kernel (mtfft16_kernel)
+  stage A  window + detrend + taper + FFT + transposed store, one fused HIP kernel (mtfft_long_kernel: two half-workgroups in anti-phase; small problems: mtfft16_kernel)
   stage B  cross-spectral accumulation AND the per-observation |Im s| plane on the 16-bit matrix pipe, one pass
            (round 4: stage A stores every coefficient as two f16 pieces, stage B multiplies three cross terms: sc_fused2.hip)
   (N>1)    reduce-scatter of the accumulator records over RCCL
@@ -57,7 +57,7 @@ def kernel_source_hash():
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "spectral_connectivity_amd", "csrc")
-    for name in ("sc_fused.hip", "sc_fused2.hip", "sc_fused_common.h", "sc_mtfft.hip", "sc_measure.hip", "sc_stage.h", "sc_common.h",
+    for name in ("sc_fused.hip", "sc_fused2.hip", "sc_fused_common.h", "sc_mtfft.hip", "sc_mtfft_long.hip", "sc_mtfft_bfly.h", "sc_measure.hip", "sc_stage.h", "sc_common.h",
                  "sc_wilson_pair.hip", "sc_wilson_fft.h"):
         with open(os.path.join(csrc, name), "rb") as f:
             h.update(f.read())
@@ -559,7 +559,7 @@ def main():
                 "frac": round(wk / d / 1e9 / HBM_PEAK_GBS, 4)}
 
     traffic, traffic_src = measured_traffic(args.config, dominant) if world == 1 else (None, None)
-    KERNEL_OF = {"fused_stage_b": "fused2_kernel (its partial records are summed by the epilogue; fused_combine_kernel only on the fold=True path)", "mtfft_fused": "mtfft16_kernel",
+    KERNEL_OF = {"fused_stage_b": "fused2_kernel (its partial records are summed by the epilogue; fused_combine_kernel only on the fold=True path)", "mtfft_fused": "mtfft_long_kernel (anti-phase half-workgroups; mtfft16_kernel below 256 items)",
                  "measure_epilogue": "measure_tile_kernel"}
     roofline = {"kernel": KERNEL_OF.get(dominant, dominant), "entry_point": dominant, "bound": bound,
                 "achieved": round(achieved, 3), "peak": peak,

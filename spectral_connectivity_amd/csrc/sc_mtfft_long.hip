@@ -154,33 +154,37 @@ __global__ void __launch_bounds__(2 * HT, HT == 512 ? 1 : 4) mtfft_long_kernel(L
         float* tile = reinterpret_cast<float*>(smem);
         const int64_t RC = (int64_t)p.R * C;
         const float* xw = p.x + ((int64_t)w * p.step * p.R + r) * C;
+        // (all sixteen-byte pieces of BOTH halves in flight before the first one is parked: one memory latency per workgroup)
+        float4 v[2][4];
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
-            float4 v[4];
 #pragma unroll
             for (int it = 0; it < 4; ++it) {          // (N / 2) QR pieces = 4 per thread
                 const int idx = tid + it * THREADS, row = idx / QR, q = idx - row * QR, c = ch0[q / V] + 4 * (q % V);
                 const int n = hh * (N / 2) + row;
-                v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                v[hh][it] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (n < L && c < C) {
                     const float* src = xw + (int64_t)n * RC + c;
                     if (p.vec && c + 3 < C) {
-                        v[it] = *reinterpret_cast<const float4*>(src);
+                        v[hh][it] = *reinterpret_cast<const float4*>(src);
                     } else {
-                        v[it].x = src[0];
-                        if (c + 1 < C) v[it].y = src[1];
-                        if (c + 2 < C) v[it].z = src[2];
-                        if (c + 3 < C) v[it].w = src[3];
+                        v[hh][it].x = src[0];
+                        if (c + 1 < C) v[hh][it].y = src[1];
+                        if (c + 2 < C) v[hh][it].z = src[2];
+                        if (c + 3 < C) v[hh][it].w = src[3];
                     }
                 }
             }
+        }
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
             if (hh == 1) __syncthreads();             // the reads of the first half are done
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int idx = tid + it * THREADS, row = idx / QR, q = idx - row * QR;
                 float2* d = reinterpret_cast<float2*>(tile + row * RS + 4 * q);
-                d[0] = make_float2(v[it].x, v[it].y);
-                d[1] = make_float2(v[it].z, v[it].w);
+                d[0] = make_float2(v[hh][it].x, v[hh][it].y);
+                d[1] = make_float2(v[hh][it].z, v[hh][it].w);
             }
             __syncthreads();
 #pragma unroll

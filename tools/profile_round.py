@@ -19,7 +19,7 @@ def lines(name):
 def kernel_source_hash():
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "spectral_connectivity_amd", "csrc")
-    for name in ("sc_fused.hip", "sc_fused2.hip", "sc_fused_common.h", "sc_mtfft.hip", "sc_measure.hip", "sc_stage.h", "sc_common.h",
+    for name in ("sc_fused.hip", "sc_fused2.hip", "sc_fused_common.h", "sc_mtfft.hip", "sc_mtfft_long.hip", "sc_mtfft_bfly.h", "sc_measure.hip", "sc_stage.h", "sc_common.h",
                  "sc_wilson_pair.hip", "sc_wilson_fft.h"):   # = bench.py
         with open(os.path.join(csrc, name), "rb") as f:
             h.update(f.read())
@@ -63,7 +63,7 @@ open(os.path.join(P, ROUND + "_bench_kernel_stats.txt"), "w").write("\n".join(hd
 fetch, write = pmc("fetch.txt", "FETCH_SIZE"), pmc("write.txt", "WRITE_SIZE")
 rows = [("fused2_kernel", "_Z13fused2_kernel", True), ("fused_csm_absim_kernel", "_Z22fused_csm_absim", True),
         ("fused_combine_kernel", "_Z20fused_combine", True), ("planes_absmax_kernel", "_Z20planes_absmax", True),
-        ("mtfft16_kernel", "_Z14mtfft16", False), ("measure_tile_multi_kernel", "measure_tile_multi", False)]
+        ("mtfft_long_kernel", "_Z17mtfft_long", False), ("mtfft16_kernel", "_Z14mtfft16", False), ("measure_tile_multi_kernel", "measure_tile_multi", False)]
 txt = ["# rocprofv3 --kernel-trace --pmc FETCH_SIZE  /  --pmc WRITE_SIZE (separate passes, MI355X_MICROARCH.md), python bench.py --steps 2",
        "# --warmup 1 --timed-only (cfg3, 1x MI355X), round " + ROUND[1:].lstrip("0") + " (tools/profile_round.sh).  Counter values are KB per dispatch.  gfx950 correction: FETCH_SIZE",
        "# reports half of a wide (16 B / lane) coalesced read stream -> doubled for the kernels whose reads are such streams (marked x2);",
@@ -84,7 +84,7 @@ if stage_b in traffic:
            "source": "profiles/" + ROUND + "_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 on gfx950)",
            "cfg3": {"fused_stage_b": traffic[stage_b] + traffic.get("fused_combine_kernel", 0.0),
                     "planes_scales": traffic.get("planes_absmax_kernel"),
-                    "mtfft_fused": traffic.get("mtfft16_kernel"),
+                    "mtfft_fused": traffic.get("mtfft_long_kernel", traffic.get("mtfft16_kernel")),
                     "measure_epilogue": traffic.get("measure_tile_multi_kernel")}}
     # BASELINE configs[3]: the kernels of the resident pairwise Granger (sc_wilson_pair.hip), summed over the entry point
     f4, w4 = pmc("fetch4.txt", "FETCH_SIZE"), pmc("write4.txt", "WRITE_SIZE")
@@ -136,7 +136,8 @@ for src, dst, head in (("mvar_64ch.txt", ROUND + "_mvar_64ch.txt", "# tools/mvar
         open(os.path.join(P, dst), "w").write("\n".join([head] + body) + "\n")
 for src, dst, head in (("api_wall.txt", ROUND + "_api_wall.txt", "# tools/api_wall.py: NumPy time series -> NumPy results through the public API at the cfg3 shape (third call), and the torch-free NumPy host"),
                        ("numpy_host.txt", ROUND + "_numpy_host.txt", "# tools/numpy_host_time.py: the torch-free host (ctypes + NumPy over sc_device_alloc / sc_memcpy_* / sc_stream_*), cfg3 shape"),
-                       ("stage_a_wide.txt", ROUND + "_stage_a_wide.txt", "# tools/stage_a_wide.py: stage A for long windows, 256-thread (wide=0) against 512-thread workgroups (wide=1, the default)"),
+                       ("stage_a_wide.txt", ROUND + "_stage_a_wide.txt", "# tools/stage_a_long.py: stage A for long windows at the cfg3 data volume (128 channels, 7 tapers, one window per trial, linear detrend): the round-3 kernels (SC_MTFFT_LONG=0) against the anti-phase kernel of sc_mtfft_long.hip (the default)"),
+                       ("stage_a_antiphase_ab.txt", ROUND + "_stage_a_antiphase_ab.txt", "# tools/stage_a_antiphase_ab.py: complex64 stage A at the cfg3 volume, round-3 kernels against the anti-phase kernel with either workgroup size"),
                        ("global_canonical.txt", ROUND + "_global_canonical.txt", "# tools/global_time.py: global coherence (1024 two-sided bins) and canonical coherence with large groups at the cfg5 shape"),
                        ("measure_table.txt", ROUND + "_measure_table.txt", "# tools/measure_table.py: every measure of the public interface at the cfg3 shape"),
                        ("fused2_fold_ab.txt", ROUND + "_fused2_fold_ab.txt", "# (profile round's box)"),
@@ -144,7 +145,7 @@ for src, dst, head in (("api_wall.txt", ROUND + "_api_wall.txt", "# tools/api_wa
                        ("sharded_one_rank.txt", ROUND + "_sharded_one_rank.txt", "# tools/sharded_one_rank.sh: the N > 1 code path of bench.py on ONE rank (nccl backend, world size 1, every collective called, nothing crosses a link) at the trial counts a rank holds at 1 / 2 / 4 / 8 GPUs, for 4 / 2 / 1 pipelined frequency groups; 'plain' = the N = 1 path"),
                        ("kt4.txt", ROUND + "_bench_kernel_stats_cfg4.txt", "# rocprofv3 --kernel-trace --stats -- python bench.py --config cfg4 --steps 5 --warmup 2 --no-cpu-baseline (pairwise Granger, 2016 pairs x 4096 bins)"),
                        ("mvar_size_time.txt", ROUND + "_mvar_size_time.txt", "# tools/mvar_size_time.py: full Wilson factorisation + DTF across system sizes, one window x 256 bins, float64 records"),
-                       ("stage_a_ab.txt", ROUND + "_stage_a_ab_final.txt", "# tools/stage_a_ab.py 0 16 8 1 2 4: stage A variants inside one process (SC_MTFFT_DEBUG: 16 = plain stores, 8 = store loop with the rare-channel overrides, 1 = no stores, 2 = no passes, 4 = no split/store loop)")):
+                       ("stage_a_ab.txt", ROUND + "_stage_a_ab_final.txt", "# tools/stage_a_ab.py 0 16 2 4 6 (and again with SC_AB_LONG=1): the anti-phase stage A under SC_MTFFT_DEBUG inside one process, wall time per call incl. launch (16 = non-temporal stores, 2 = no passes, 4 = no split / store loop, 6 = neither: tile load + detrend + the empty slots' barriers)")):
     body = [l for l in lines(src) if "amdgpu.ids" not in l]
     if body:
         open(os.path.join(P, dst), "w").write("\n".join([head] + body) + "\n")

@@ -35,7 +35,8 @@ done
 python tools/mvar_time.py 64 1792 256 > $OUT/mvar_64ch.txt 2>&1
 python tools/mvar_time.py 128 1792 256 > $OUT/mvar_128ch.txt 2>&1
 python tools/mvar_size_time.py > $OUT/mvar_size_time.txt 2>&1
-python tools/stage_a_ab.py 0 16 8 1 2 4 > $OUT/stage_a_ab.txt 2>&1
+python tools/stage_a_ab.py 0 16 2 4 6 > $OUT/stage_a_ab.txt 2>&1
+SC_AB_LONG=1 python tools/stage_a_ab.py 0 16 2 4 6 >> $OUT/stage_a_ab.txt 2>&1
 python tools/engine_time.py > $OUT/engine_time.txt 2>&1
 python tools/stage_a_breakdown.py > $OUT/stage_a.txt 2>&1
 python tools/plane_pass_time.py > $OUT/plane_pass.txt 2>&1
@@ -47,7 +48,8 @@ python tools/stage_a_planes_check.py > $OUT/stage_a_planes_check.txt 2>&1
 for c in cfg2 cfg4 cfg5; do python bench.py --config $c --steps 10 --warmup 3 > $OUT/bench_$c.json 2> $OUT/bench_$c.err; done
 python tools/api_wall.py > $OUT/api_wall.txt 2>&1
 python tools/numpy_host_time.py > $OUT/numpy_host.txt 2>&1
-python tools/stage_a_wide.py > $OUT/stage_a_wide.txt 2>&1
+python tools/stage_a_long.py > $OUT/stage_a_wide.txt 2>&1
+python tools/stage_a_antiphase_ab.py > $OUT/stage_a_antiphase_ab.txt 2>&1
 python tools/global_time.py > $OUT/global_canonical.txt 2>&1
 python tools/measure_table.py > $OUT/measure_table.txt 2>&1
 python tools/fused2_fold_ab.py > $OUT/fused2_fold_ab.txt 2>&1
