@@ -426,6 +426,194 @@ __global__ void __launch_bounds__(64 * CB_WAVES) canonical_pair_kernel(CanonArgs
     }
 }
 
+// ---- the same pair problem without the Jacobi sweeps (round 5) ----------------------------------------------------------
+// The parallel Jacobi above spends ~7 sweeps x 15 rounds x ~100 wave instructions per problem on ALL sixteen eigenvalues of
+// B = M M^H (2.9 ms for the 61 560 problems of BASELINE configs[4]: fp64 issue-bound); only the largest one is asked for.
+// Here B lives in REGISTERS (lane (i, jq) = row i, columns 4 jq .. 4 jq + 3: four complex entries), is reduced to a real symmetric
+// tridiagonal matrix by fourteen Householder reflections (LAPACK zhetd2, lower form: p = tau B v, w = p - (tau / 2)(p^H v) v,
+// B <- B - v w^H - w v^H; v and w travel through 512 bytes of LDS, sums over rows / column groups by lane shuffles), and the
+// largest eigenvalue of T is bracketed by multisection on the Sturm sequence: 64 shifts per round, one per lane (x > lambda_max
+// iff every leading principal minor of T - x changes sign), nine rounds from the Gershgorin bracket to the last bits.  Only |e_k|^2
+// of the subdiagonal is needed, so a column that is already reduced needs no reflection.  LDS: M alone (4 KB a wave).
+__device__ inline double cb_sum16(double v) {            // over the sixteen lanes of a row group, result in all of them
+    for (int off = 1; off < 16; off <<= 1) v += __shfl_xor(v, off);
+    return v;
+}
+__device__ inline double cb_sum4(double v) {             // over the four row groups
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+__device__ inline double cb_lane(double v, int lane) {    // (lane: compile-time constant after unrolling)
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// largest eigenvalue of the Hermitian positive semi-definite 16 x 16 matrix held as a[c] = B[i][4 jq + c], i = lane & 15, jq = lane >> 4
+// (rows / columns from the matrix order on: zero); vb: 32 complex numbers of this wave's LDS
+__device__ double cb_top_eigenvalue(cd (&a)[4], cd* vb, int lane) {
+    const int i = lane & 15, jq = lane >> 4;
+    double d[16], e2[15];
+#pragma unroll
+    for (int k = 0; k < 14; ++k) {
+        const int kq = k >> 2, src = 16 * kq;             // column k lives in row group kq, register k & 3
+        const bool owner = jq == kq;
+        const cd x = a[k & 3];
+        d[k] = cb_lane(x.x, src + k);
+        const double alr = cb_lane(x.x, src + k + 1), ali = cb_lane(x.y, src + k + 1);
+        double s2 = (owner && i > k + 1) ? x.x * x.x + x.y * x.y : 0.0;
+        s2 = cb_sum16(s2);
+        const double xn2 = cb_lane(s2, src);
+        e2[k] = alr * alr + ali * ali + xn2;
+        if (xn2 == 0.0) continue;                         // (wave-uniform) nothing below the subdiagonal: no reflection
+        const double beta = alr > 0.0 ? -sqrt(e2[k]) : sqrt(e2[k]), rb = 1.0 / beta;
+        const cd tau = make_double2((beta - alr) * rb, -ali * rb);
+        const double dr = alr - beta, den = 1.0 / (dr * dr + ali * ali);
+        const cd sc = make_double2(dr * den, -ali * den);                       // 1 / (alpha - beta)
+        if (owner) vb[i] = i > k + 1 ? zmul(x, sc) : (i == k + 1 ? make_double2(1.0, 0.0) : make_double2(0.0, 0.0));
+        CB_WSYNC();
+        const cd vi = vb[i];
+        cd vc[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) vc[c] = vb[4 * jq + c];
+        cd acc = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const cd t = zmul(a[c], vc[c]); acc.x += t.x; acc.y += t.y; }
+        acc.x = cb_sum4(acc.x); acc.y = cb_sum4(acc.y);
+        cd pv = zmul(tau, acc);
+        if (i <= k) pv = make_double2(0.0, 0.0);
+        const double kx = cb_sum16(pv.x * vi.x + pv.y * vi.y), ky = cb_sum16(pv.x * vi.y - pv.y * vi.x);      // p^H v
+        const cd hk = zmul(make_double2(0.5 * tau.x, 0.5 * tau.y), make_double2(kx, ky));
+        const cd t0 = zmul(hk, vi);
+        const cd w = make_double2(pv.x - t0.x, pv.y - t0.y);
+        if (jq == 0) vb[16 + i] = w;
+        CB_WSYNC();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const cd wc = vb[16 + 4 * jq + c];
+            const cd u0 = zmulc(vi, wc), u1 = zmulc(w, vc[c]);
+            a[c].x -= u0.x + u1.x;
+            a[c].y -= u0.y + u1.y;
+        }
+        CB_WSYNC();                                       // (v and w are read: the next step may write them)
+    }
+    d[14] = cb_lane(a[2].x, 48 + 14);
+    d[15] = cb_lane(a[3].x, 48 + 15);
+    {
+        const double er = cb_lane(a[2].x, 48 + 15), ei = cb_lane(a[2].y, 48 + 15);
+        e2[14] = er * er + ei * ei;
+    }
+    double dmax = d[0], emax = e2[0];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) dmax = fmax(dmax, d[q]);
+#pragma unroll
+    for (int q = 1; q < 15; ++q) emax = fmax(emax, e2[q]);
+    const double top = dmax + 2.0 * sqrt(emax);           // Gershgorin; lambda_max >= the largest diagonal entry
+    if (!(top > 0.0)) return dmax > 0.0 ? dmax : 0.0;
+    const double sc1 = 1.0 / top, sc2 = sc1 * sc1;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) d[q] *= sc1;
+#pragma unroll
+    for (int q = 0; q < 15; ++q) e2[q] *= sc2;
+    double lo = dmax * sc1, hi = 1.0;
+    for (int round = 0; round < 9 && hi > lo; ++round) {
+        const double x = lane == 63 ? hi : lo + (hi - lo) * ((double)(lane + 1) * (1.0 / 64.0));
+        double p0 = 1.0, p1 = d[0] - x;
+        bool above = p1 < 0.0;
+#pragma unroll
+        for (int q = 1; q < 16; ++q) {
+            const double p2 = (d[q] - x) * p1 - e2[q - 1] * p0;
+            above = above && (p2 * p1 < 0.0);
+            p0 = p1; p1 = p2;
+        }
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(above);
+        if (mask == 0ull) break;                          // (cannot happen for x = hi; rounding at the last bits)
+        const int b = __builtin_ctzll(mask);
+        const double xh = __shfl(x, b), xl = __shfl(x, b > 0 ? b - 1 : 0);
+        hi = xh;
+        if (b > 0) lo = xl;
+    }
+    return 0.5 * (lo + hi) * top;
+}
+
+__global__ void __launch_bounds__(64 * CB_WAVES) canonical_pair_hh_kernel(CanonArgs a, const cd* Lg, const int* okb) {
+    extern __shared__ __align__(16) unsigned char cb_smem[];
+    const int G = a.G;
+    cd* scratch = reinterpret_cast<cd*>(cb_smem);                              // per wave: M, T [16][16]; v, w [32]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int n_chunks = (a.n_gpairs + CB_WAVES - 1) / CB_WAVES;
+    const int64_t bin = blockIdx.x / n_chunks;
+    const int chunk = blockIdx.x % n_chunks;
+    const ScRec rec = a.accum + bin * a.floats_per_bin;
+    const cd* Ls = Lg + (size_t)bin * G * CB_C * CB_C;
+    const int* okg = okb + bin * G;
+    cd* M = scratch + (size_t)wave * (2 * CB_C * CB_C + 32);
+    cd* T = M + CB_C * CB_C;
+    cd* vb = T + CB_C * CB_C;
+    const int pr = chunk * CB_WAVES + wave;
+    if (pr >= a.n_gpairs) return;                                  // no workgroup barriers below
+    int gp = pr, ga = 0, len = G - 1;
+    while (gp >= len) { gp -= len; ++ga; --len; }
+    const int gb = ga + 1 + gp;
+    const int na = a.sizes[ga], nb = a.sizes[gb];
+    const int32_t* ma = a.members + ga * CB_C;
+    const int32_t* mb = a.members + gb * CB_C;
+    const cd* La = Ls + (size_t)ga * CB_C * CB_C;
+    const cd* Lb = Ls + (size_t)gb * CB_C * CB_C;
+    const bool ok = okg[ga] && okg[gb];
+    for (int e = lane; e < CB_C * CB_C; e += 64) {
+        const int i = e / CB_C, j = e % CB_C;
+        M[e] = (i < na && j < nb) ? csm_read(rec, a, ma[i], mb[j]) : make_double2(0.0, 0.0);
+    }
+    CB_WSYNC();
+    // M <- Linv_a M Linv_b^H as two dense products through T (the inverse factors come from the workspace: L2)
+    for (int e = lane; e < CB_C * CB_C; e += 64) {
+        const int i = e / CB_C, j = e % CB_C;
+        cd la[CB_C];
+#pragma unroll
+        for (int k = 0; k < CB_C; ++k) la[k] = La[i * CB_C + k];
+        cd sv = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int k = 0; k < CB_C; ++k) { const cd t = zmul(la[k], M[k * CB_C + j]); sv.x += t.x; sv.y += t.y; }
+        T[e] = sv;
+    }
+    CB_WSYNC();
+    for (int e = lane; e < CB_C * CB_C; e += 64) {
+        const int i = e / CB_C, j = e % CB_C;
+        cd lb[CB_C];
+#pragma unroll
+        for (int k = 0; k < CB_C; ++k) lb[k] = Lb[j * CB_C + k];
+        cd sv = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int k = 0; k < CB_C; ++k) { const cd t = zmulc(T[i * CB_C + k], lb[k]); sv.x += t.x; sv.y += t.y; }
+        M[e] = sv;
+    }
+    CB_WSYNC();
+    // B = M M^H straight into the registers of the reduction: lane (i, jq) holds B[i][4 jq .. 4 jq + 3] (zero outside na x na)
+    cd breg[4];
+    {
+        const int i = lane & 15, jq = lane >> 4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int j = 4 * jq + c;
+            cd sv = make_double2(0.0, 0.0);
+            if (i < na && j < na) {
+#pragma unroll
+                for (int k = 0; k < CB_C; ++k) { const cd t = zmulc(M[i * CB_C + k], M[j * CB_C + k]); sv.x += t.x; sv.y += t.y; }
+                if (i == j) sv.y = 0.0;
+            }
+            breg[c] = sv;
+        }
+    }
+    double lmax = cb_top_eigenvalue(breg, vb, lane);
+    if (lane == 0) {
+        if (!ok) { lmax = nan(""); atomicAdd(a.fail, 1); }
+        double* o = a.out + bin * G * G;
+        o[ga * G + gb] = lmax;
+        o[gb * G + ga] = lmax;
+    }
+}
+
 __global__ void canon_fill_nan(double* out, int64_t total) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < total) out[i] = nan("");
@@ -611,8 +799,17 @@ extern "C" int sc_canonical_coherence_f64(const void* d_accum, int64_t n_bins, i
             const int64_t n_gp = a.n_gpairs;
             const int64_t n_wg = ((n_gp + CB_WAVES - 1) / CB_WAVES) * n_bins;
             if (n_wg > 0x7fffffffLL) { (void)hipFreeAsync(Lg, st); sc_set_error("canonical coherence: too many (bin, pair) tasks"); return SC_EINVAL; }
-            hipLaunchKernelGGL(canonical_pair_kernel, dim3((unsigned)n_wg), dim3(64 * CB_WAVES), lds_p, st, a, (const cd*)Lg,
-                               (const int*)okb);
+            // (SC_CANON_EIG=jacobi: the parallel Jacobi of rounds 1-4, all sixteen eigenvalues -- A/B and cross-check)
+            const char* eig = sc_switch(SC_SW_CANON_EIG);
+            if (eig && eig[0] == 'j') {
+                hipLaunchKernelGGL(canonical_pair_kernel, dim3((unsigned)n_wg), dim3(64 * CB_WAVES), lds_p, st, a, (const cd*)Lg,
+                                   (const int*)okb);
+            } else {
+                const size_t lds_h = (size_t)CB_WAVES * (2 * CB_C * CB_C + 32) * sizeof(cd);
+                (void)hipFuncSetAttribute((const void*)canonical_pair_hh_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h);
+                hipLaunchKernelGGL(canonical_pair_hh_kernel, dim3((unsigned)n_wg), dim3(64 * CB_WAVES), lds_h, st, a, (const cd*)Lg,
+                                   (const int*)okb);
+            }
             (void)hipFreeAsync(Lg, st);
         } else if (max_group_size <= 32) {
             hipLaunchKernelGGL(canonical_kernel<32>, dim3(blocks), dim3(64), 0, st, a);

@@ -348,6 +348,47 @@ def test_canonical_coherence_large_groups_float64(sc, sizes):
     close64(got, ref, rtol=1e-7, floor=1e-9, what=f"canonical coherence, groups {sizes}")
 
 
+@pytest.mark.parametrize("case", ["ragged", "sixteen", "degenerate", "tiny"])
+def test_canonical_coherence_top_eigenvalue_kernel_equals_the_jacobi_kernel(sc, debug_env, case):
+    """Groups of at most 16 channels: the (bin, pair) kernel reduces B = M M^H to a tridiagonal matrix by Householder reflections in
+    registers and brackets its LARGEST eigenvalue by multisection on the Sturm sequence (csrc/sc_canonical.hip, round 5);
+    SC_CANON_EIG=jacobi keeps the parallel Jacobi of rounds 1-4, which finds all sixteen.  Both from the same double records:
+    the new kernel equals the oracle's SVD form (connectivity.py:745-820) to 1e-12, the Jacobi kernel to 1e-7 -- ragged group sizes incl.
+    single channels, full groups, groups with duplicated channels (rank-deficient blocks fail the Cholesky in both: NaN pattern
+    equal), and a group pair with a coupling at the rounding level."""
+    from oracle import spectral_oracle as so
+    rng = np.random.default_rng({"ragged": 3, "sixteen": 4, "degenerate": 5, "tiny": 6}[case])
+    sizes = {"ragged": (1, 16, 7, 2, 11, 16, 3), "sixteen": (16,) * 6, "degenerate": (8, 8, 5), "tiny": (6, 9)}[case]
+    C = sum(sizes)
+    labels = np.repeat(np.arange(len(sizes)), sizes)
+    T, R = 128, 40
+    x = rng.standard_normal((T, R, C))
+    if case != "tiny":
+        x += 0.8 * rng.standard_normal((T, R, 1)) + 0.5 * x[:, :, ::-1]
+    if case == "degenerate":
+        x[:, :, 9] = x[:, :, 8]                       # group 1 holds one channel twice
+    kw = dict(sampling_frequency=128.0, time_halfbandwidth_product=2, n_time_samples_per_window=64)
+    out = {}
+    for eig in (None, "jacobi"):
+        debug_env("SC_CANON_EIG", eig)
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            out[eig], _ = sc.Connectivity.from_multitaper(sc.Multitaper(x, **kw)).canonical_coherence(labels)
+    a, b = out[None], out["jacobi"]
+    assert np.array_equal(np.isnan(a), np.isnan(b))
+    ok = ~np.isnan(b)
+    assert ok.any()
+    # (the Jacobi kernel takes its rotation angles in float32 and stops at off^2 <= 1e-24 dia^2: 1e-9 ... 1e-8 of the value; the
+    #  new one sits at the rounding of the doubles)
+    assert np.abs(a[ok] - b[ok]).max() <= 1e-7 * np.abs(b[ok]).max(), np.abs(a[ok] - b[ok]).max()
+    if case != "degenerate":
+        coef, _ = so.multitaper_fft(x, fs=128.0, NW=2, n_time_samples_per_window=64)
+        ref, _ = so.canonical_coherence(coef, labels)
+        close64(a, ref, rtol=1e-12, floor=1e-13, what=f"canonical coherence, groups {sizes}")
+        close64(b, ref, rtol=1e-7, floor=1e-9, what=f"canonical coherence (Jacobi kernel), groups {sizes}")
+
+
 def test_incremental_records_equal_fresh_ones(sc):
     """float64 engine: a measure asked for after others re-uses the record families already accumulated (copied into the
     wider record) and computes only the missing ones -- bit for bit what a fresh Connectivity returns."""
