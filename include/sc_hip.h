@@ -176,7 +176,8 @@ int sc_fft_execute_f64(sc_fft_plan* plan, const double* d_y, void* d_X /*double2
  *   X[f][w][r][k][c],  f = 0..N/2   (one-sided; the negative bins of a real input are
  *                                    conjugate mirrors and are never materialised).
  * Supported when sc_multitaper_fft_supported(L, N) != 0: L <= N and N either a power of two in
- * 64 ... 4096 (register-resident radix-16 passes) or 2^a 3^b 5^c in 8 ... 2048 (mixed-radix Stockham
+ * 64 ... 4096 (register-resident radix-16 passes; from 256 samples on, when the request fills the chip, two half-workgroups
+ * in anti-phase -- one runs the passes while the other stores: sc_mtfft_long.hip) or 2^a 3^b 5^c in 8 ... 2048 (mixed-radix Stockham
  * passes in LDS: the lengths next_fast_len, transforms.py:1024-1036, returns for the usual window
  * durations -- 200, 250, 500, 1000 ...); otherwise use sc_taper_windows_f32 + sc_fft_execute
  * (rocFFT, any length).
@@ -293,7 +294,7 @@ int sc_planes_scales_quality_f32(const float* d_x, int64_t T, int64_t R, int64_t
 int sc_planes_scales_from_spectra_f32(const void* d_X /*float2*/, int64_t n_rows, int64_t C, float* d_scale, void* d_work,
                                       void* stream);
 /* Stage A straight into the planes format: sc_multitaper_fft_f32 with the spectra leaving as f16 pieces (same transform,
- * same coefficients up to the 22-bit representation; window lengths N = 64 ... 1024, powers of two, even n_signals). */
+ * same coefficients up to the 22-bit representation; window lengths N = 64 ... 4096, powers of two, even n_signals). */
 int sc_multitaper_fft_planes_supported(int64_t L, int64_t N, int64_t n_signals);
 int sc_multitaper_fft_planes_f32(const float* d_x, int64_t T, int64_t R, int64_t C, int64_t L, int64_t step, int64_t W,
                                  int64_t N, const float* d_tapers, int64_t K, int detrend_type, const void* d_twiddles,
