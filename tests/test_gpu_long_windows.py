@@ -1,5 +1,5 @@
-"""Stage A for long power-of-two windows (csrc/sc_mtfft_long.hip: two half-workgroups in anti-phase, the window through
-half-window tiles in the exchange buffers) against the float64 oracle
+"""Stage A on the anti-phase kernel (csrc/sc_mtfft_long.hip, power-of-two windows of 256 ... 4096 samples: two half-workgroups in
+anti-phase, the window through half-window tiles in the exchange buffers) against the float64 oracle
 (oracle/spectral_oracle.py::multitaper_fft, which follows transforms.py:1311-1405) -- every shape the kernel branches on:
 channel counts around its tiles and super-tiles, odd counts, one channel, zero padding (L < N), overlapping windows, every
 detrend, many trials (the engine's own choice of kernel), silent / constant / non-finite channels; and the round-3 kernels
@@ -61,6 +61,8 @@ def _device(x, L, step, N, det, NW=2.5, fs=200.0):
     (4096, 4096, 4096, 16, 2, "constant"), (4096, 4096, 2048, 18, 2, "linear"), (4096, 4000, 4000, 33, 2, "constant"),
     (4096, 4096, 4096, 66, 1, "constant"),
     (1024, 1024, 1024, 1, 3, "linear"), (1024, 700, 300, 31, 3, "constant"), (1024, 1024, 512, 32, 2, None), (1024, 1000, 1000, 70, 2, "linear"),
+    (512, 512, 256, 1, 3, "constant"), (512, 300, 300, 33, 3, "linear"), (512, 512, 128, 64, 2, None), (512, 500, 250, 130, 2, "constant"),
+    (256, 256, 128, 3, 4, "linear"), (256, 200, 100, 64, 3, "constant"), (256, 256, 64, 65, 3, None), (256, 256, 256, 130, 2, "linear"),
 ])
 def test_long_windows_against_the_oracle(N, L, step, C, R, det, kernel, debug_env):
     _dev()
@@ -74,7 +76,7 @@ def test_long_windows_against_the_oracle(N, L, step, C, R, det, kernel, debug_en
     print(f"\n  N={N} L={L} step={step} C={C} R={R} {det} [{kernel}]: worst err / bound {w:.2f}")
 
 
-@pytest.mark.parametrize("N,C,R", [(1024, 70, 120), (2048, 40, 150), (4096, 24, 90)])
+@pytest.mark.parametrize("N,C,R", [(256, 130, 200), (512, 70, 180), (1024, 70, 120), (2048, 40, 150), (4096, 24, 90)])
 def test_many_trials_default_policy(N, C, R, debug_env):
     """Enough (window, trial, channel tile) items that the engine takes the anti-phase kernel by itself (no switch), overlapping
     windows, against a float64 transform of the same float32 samples; the round-3 kernels agree to float32 rounding; two runs give
@@ -95,7 +97,8 @@ def test_many_trials_default_policy(N, C, R, debug_env):
     assert torch.equal(torch.view_as_real(got), torch.view_as_real(again))
     debug_env("SC_MTFFT_LONG", "0")
     old = engine.multitaper_spectra(xd, h, L, step, N, 2, "linear").X
-    assert not torch.equal(torch.view_as_real(got), torch.view_as_real(old)), "SC_MTFFT_LONG=0 still ran the same kernel"
+    if N >= 512:        # (at 256 samples the two kernels use the same twiddles in the same order: the same bits; beyond, pass 3 differs)
+        assert not torch.equal(torch.view_as_real(got), torch.view_as_real(old)), "SC_MTFFT_LONG=0 still ran the same kernel"
     xs = torch.from_numpy(x.astype(np.float64)).cuda()
     t = torch.arange(1, L + 1, dtype=torch.float64, device="cuda") / L
     A = torch.stack([t, torch.ones_like(t)], 1)
@@ -113,7 +116,7 @@ def test_many_trials_default_policy(N, C, R, debug_env):
         assert err < 2e-6, (name, err)
 
 
-@pytest.mark.parametrize("N", [1024, 2048, 4096])
+@pytest.mark.parametrize("N", [256, 512, 1024, 2048, 4096])
 def test_silent_constant_and_nonfinite_channels_in_long_windows(N, debug_env):
     """A silent channel and a constant one (constant detrend) give EXACTLY zero coefficients, a NaN / infinity spoils its own
     channel in the windows that hold it and nothing else (transforms.py:1402-1405: every channel is transformed on its own)."""
