@@ -329,7 +329,11 @@ struct GcEighArgs {
     int n_bins_total, KS;
 };
 
-#define GE_NT 256
+// GE_NT threads: one per row of the matrix / per eigenvalue -- 256 up to 256 signals, 512 beyond (round 5: a 306-channel MEG array
+// is an ordinary input, the reference has no limit; 1024 threads would hold 16 elements of every vector per lane in the back-
+// transformation: 265 registers spilled)
+#define GC_EIGH_CMAX 512
+template <int GE_NT>
 __device__ __forceinline__ double ge_block_sum(double v, double* red, int tid) {
     red[tid] = v;
     __syncthreads();
@@ -342,6 +346,7 @@ __device__ __forceinline__ double ge_block_sum(double v, double* red, int tid) {
     return r;
 }
 
+template <int GE_NT>
 __global__ void __launch_bounds__(GE_NT) global_coherence_eigh_kernel(GcEighArgs b) {
     extern __shared__ __align__(16) unsigned char gc_smem[];
     const GcArgs& a = b.g;
@@ -384,11 +389,11 @@ __global__ void __launch_bounds__(GE_NT) global_coherence_eigh_kernel(GcEighArgs
         __syncthreads();
         // ---- tridiagonalisation (zhetd2, lower) ----
         for (int k = 0; k + 1 < C; ++k) {
-            const int m = C - k - 1;                       // order of the trailing block; m <= 255 < GE_NT
+            const int m = C - k - 1;                       // order of the trailing block; m < C <= GE_NT
             cd* col = A + (size_t)k * C + (k + 1);
             cd xi = make_double2(0.0, 0.0);
             if (tid < m) xi = col[tid];
-            const double xn2 = ge_block_sum((tid >= 1 && tid < m) ? xi.x * xi.x + xi.y * xi.y : 0.0, red, tid);
+            const double xn2 = ge_block_sum<GE_NT>((tid >= 1 && tid < m) ? xi.x * xi.x + xi.y * xi.y : 0.0, red, tid);
             if (tid == 0) { sh_scalar[0] = xi.x; sh_scalar[1] = xi.y; d[k] = A[(size_t)k * C + k].x; }
             __syncthreads();
             const double alr = sh_scalar[0], ali = sh_scalar[1];
@@ -422,8 +427,8 @@ __global__ void __launch_bounds__(GE_NT) global_coherence_eigh_kernel(GcEighArgs
                 pi = g_mul(tk, acc);
             }
             const cd vi = tid < m ? vs[tid] : make_double2(0.0, 0.0);
-            const double dre = ge_block_sum(pi.x * vi.x + pi.y * vi.y, red, tid);       // p^H v
-            const double dim = ge_block_sum(pi.x * vi.y - pi.y * vi.x, red, tid);
+            const double dre = ge_block_sum<GE_NT>(pi.x * vi.x + pi.y * vi.y, red, tid);       // p^H v
+            const double dim = ge_block_sum<GE_NT>(pi.x * vi.y - pi.y * vi.x, red, tid);
             const cd al2 = g_mul(make_double2(-0.5 * tk.x, -0.5 * tk.y), make_double2(dre, dim));
             cd wi = make_double2(0.0, 0.0);
             if (tid < m) {
@@ -585,7 +590,7 @@ __global__ void __launch_bounds__(GE_NT) global_coherence_eigh_kernel(GcEighArgs
                     }
                     __syncthreads();
                 }
-                const double nn = ge_block_sum(tid < C ? WK(5, tid, j) * WK(5, tid, j) : 0.0, red, tid);
+                const double nn = ge_block_sum<GE_NT>(tid < C ? WK(5, tid, j) * WK(5, tid, j) : 0.0, red, tid);
                 if (tid < C && nn > 0.0) WK(5, tid, j) *= 1.0 / sqrt(nn);
                 __syncthreads();
             }
@@ -613,9 +618,10 @@ __global__ void __launch_bounds__(GE_NT) global_coherence_eigh_kernel(GcEighArgs
         {
             const int lane = tid & 63, wv = tid >> 6;
             for (int tv = wv; tv < K; tv += GE_NT / 64) {
-                double xr[4], xim[4];
+                constexpr int XQ = GE_NT / 64;                      // elements of the vector per lane
+                double xr[XQ], xim[XQ];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < XQ; ++q) {
                     const int i = lane + 64 * q;
                     xr[q] = i < C ? WK(5, i, tv) : 0.0;
                     xim[q] = 0.0;
@@ -624,10 +630,10 @@ __global__ void __launch_bounds__(GE_NT) global_coherence_eigh_kernel(GcEighArgs
                     const cd tk = tau[k];
                     if (tk.x == 0.0 && tk.y == 0.0) continue;
                     const cd* col = A + (size_t)k * C;             // v_i sits at col[i], i = k + 1 .. C - 1 (v_{k+1} = 1)
-                    cd vq[4];
+                    cd vq[XQ];
                     double sr = 0.0, si = 0.0;                      // v^H x
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
+                    for (int q = 0; q < XQ; ++q) {
                         const int i = lane + 64 * q;
                         vq[q] = (i > k && i < C) ? col[i] : make_double2(0.0, 0.0);
                         sr += vq[q].x * xr[q] + vq[q].y * xim[q];
@@ -637,7 +643,7 @@ __global__ void __launch_bounds__(GE_NT) global_coherence_eigh_kernel(GcEighArgs
                     for (int off = 32; off > 0; off >>= 1) { sr += __shfl_xor(sr, off); si += __shfl_xor(si, off); }
                     const cd f = g_mul(tk, make_double2(sr, si));
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
+                    for (int q = 0; q < XQ; ++q) {
                         xr[q] -= vq[q].x * f.x - vq[q].y * f.y;
                         xim[q] -= vq[q].x * f.y + vq[q].y * f.x;
                     }
@@ -646,7 +652,7 @@ __global__ void __launch_bounds__(GE_NT) global_coherence_eigh_kernel(GcEighArgs
                 double ss = 0.0, best = -1.0, br = 1.0, bi = 0.0;
                 int bidx = 0;                                       // ties go to the smaller element index: every lane agrees
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < XQ; ++q) {
                     const double m2 = xr[q] * xr[q] + xim[q] * xim[q];
                     ss += m2;
                     if (m2 > best) { best = m2; br = xr[q]; bi = xim[q]; bidx = lane + 64 * q; }
@@ -663,7 +669,7 @@ __global__ void __launch_bounds__(GE_NT) global_coherence_eigh_kernel(GcEighArgs
                 const int r = K - 1 - tv;                          // rank from the top of eigenvalue index C - K + tv
                 const int kout = a.ascending ? K - 1 - r : r;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < XQ; ++q) {
                     const int i = lane + 64 * q;
                     if (i < C) vec[(int64_t)i * K + kout] = g_mul(make_double2(xr[q], xim[q]), ph);
                 }
@@ -672,7 +678,7 @@ __global__ void __launch_bounds__(GE_NT) global_coherence_eigh_kernel(GcEighArgs
     }
 }
 
-extern "C" int sc_global_coherence_max_signals(void) { return GC_HUGE_CMAX; }
+extern "C" int sc_global_coherence_max_signals(void) { return GC_EIGH_CMAX; }
 
 extern "C" int sc_global_coherence_f64(const void* d_accum, int64_t n_groups, int64_t n_freq_accum, int64_t N,
                                        int64_t C, uint32_t planes, int64_t n_obs, int max_rank, int ascending,
@@ -682,8 +688,8 @@ extern "C" int sc_global_coherence_f64(const void* d_accum, int64_t n_groups, in
     SC_REQUIRE(planes & SC_PLANE_CSM, "accumulator record must contain SC_PLANE_CSM");
     SC_REQUIRE(n_freq_accum == N || n_freq_accum == N / 2 + 1, "accumulators must hold N or N/2+1 bins");
     SC_REQUIRE(n_groups >= 1 && n_groups <= 65535 && N >= 1 && n_obs >= 1, "bad problem size");
-    if (C < 1 || C > GC_HUGE_CMAX) {
-        sc_set_error("global coherence: n_signals <= %d (got %lld)", GC_HUGE_CMAX, (long long)C);
+    if (C < 1 || C > GC_EIGH_CMAX) {
+        sc_set_error("global coherence: n_signals <= %d (got %lld)", GC_EIGH_CMAX, (long long)C);
         return SC_EUNSUPPORTED;
     }
     SC_REQUIRE(max_rank >= 1 && max_rank <= C, "max_rank must be in 1..n_signals");
@@ -697,6 +703,10 @@ extern "C" int sc_global_coherence_f64(const void* d_accum, int64_t n_groups, in
     a.max_rank = max_rank; a.ascending = ascending; a.n_obs = (double)n_obs;
     const int M = (int)C + ((int)C & 1);
     const char* eig_env = sc_switch(SC_SW_GLOBAL_EIG);       // "jacobi": the round-2 kernels beyond 64 signals too (cross-check)
+    if (C > GC_HUGE_CMAX && eig_env && strcmp(eig_env, "jacobi") == 0) {
+        sc_set_error("global coherence: the Jacobi kernels (SC_GLOBAL_EIG=jacobi) take n_signals <= %d (got %lld)", GC_HUGE_CMAX, (long long)C);
+        return SC_EUNSUPPORTED;
+    }
     if (C > GC_CMAX && !(eig_env && strcmp(eig_env, "jacobi") == 0)) {
         // Householder tridiagonalisation + bisection + inverse iteration, matrix and work arrays in a scratch of this call
         const int64_t bins = n_groups * N;
@@ -718,8 +728,14 @@ extern "C" int sc_global_coherence_f64(const void* d_accum, int64_t n_groups, in
         const size_t a_bytes = (size_t)slots * C * C * sizeof(cd);
         GcEighArgs b;
         b.g = a; b.A = (cd*)scratch; b.work = (double*)(scratch + a_bytes); b.n_bins_total = (int)bins; b.KS = max_rank;
-        const size_t lds = ((size_t)12 * C + GE_NT) * sizeof(double) + 64;
-        hipLaunchKernelGGL(global_coherence_eigh_kernel, dim3((unsigned)slots), dim3(GE_NT), lds, (hipStream_t)stream, b);
+        const int nt = C <= 256 ? 256 : 512;
+        const size_t lds = ((size_t)12 * C + nt) * sizeof(double) + 64;
+        if (nt == 256) {
+            hipLaunchKernelGGL(global_coherence_eigh_kernel<256>, dim3((unsigned)slots), dim3(256), lds, (hipStream_t)stream, b);
+        } else {
+            (void)hipFuncSetAttribute((const void*)global_coherence_eigh_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(global_coherence_eigh_kernel<512>, dim3((unsigned)slots), dim3(512), lds, (hipStream_t)stream, b);
+        }
         const hipError_t e1 = hipGetLastError();
         const hipError_t e2 = hipStreamSynchronize((hipStream_t)stream);       // the scratch is freed below
         (void)hipFree(scratch);

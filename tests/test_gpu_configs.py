@@ -400,7 +400,7 @@ def test_more_than_256_signals(sc, C):
     """The reference has no channel limit (connectivity.py:447-526); one launch of the stage-B kernels stages at most 256 signals
     per observation row.  Beyond that engine.accumulate tiles the channels in blocks of 128 and assembles the record from the
     block pairs (engine._accumulate_blocked): a 306-channel MEG array -- or an odd 401 -- goes through every expectation measure
-    of both engines, pairwise Granger on a subset and canonical coherence, against the oracle."""
+    of both engines, pairwise Granger on a subset, canonical coherence and (up to 512 signals) global coherence, against the oracle."""
     import spectral_connectivity_amd.options as options
     rng = np.random.default_rng(C)
     L, R = 64, 3
@@ -428,6 +428,15 @@ def test_more_than_256_signals(sc, C):
                 err = np.abs(got[ok] - ref[ok]).max() / np.abs(ref[ok]).max()
                 bound = 4.0 / c.n_observations if name == "phase_lag_index" else tol
                 assert err <= bound, (precision, name, err)
+            if C in (306, 401):
+                # global coherence beyond 256 signals (round 5: the Householder / bisection kernel with a thread per row up to 512):
+                # the leading squared singular values of the oracle's thin SVD, all two-sided bins
+                vals, vecs = c.global_coherence(max_rank=2)
+                ref_vals, _ = so.global_coherence(coef, max_rank=2)
+                assert vals.shape == ref_vals.shape and vecs.shape[-2:] == (C, 2)
+                gerr = np.abs(vals - ref_vals).max() / np.abs(ref_vals).max()
+                print(f"  global coherence, {C} signals, {precision}: max err {gerr:.2e}")
+                assert gerr <= (5e-5 if precision == "float32" else 1e-9), (precision, gerr)
             if C == 306:
                 pairs = [(2, C - 3), (0, 130), (129, 300)]
                 gp = c.subset_pairwise_spectral_granger_prediction(pairs)
