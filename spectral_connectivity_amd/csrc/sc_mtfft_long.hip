@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(2 * HT, HT == 512 ? 1 : 4) mtfft_long_kernel(L
     // workgroup barrier -- ONE barrier per slot (the hand-over between the halves), the waves of a half run free in between, and
     // the taper is double-buffered instead of parked behind a barrier.
     constexpr bool WAVE_LOCAL = TPF <= 64;
-    constexpr int NB = WAVE_LOCAL ? 1 : (LOG2N == 12 ? 5 : 4);      // workgroup barriers of one slot
+    constexpr int NB = WAVE_LOCAL ? 1 : 4;                           // workgroup barriers of one slot
     static_assert(LOG2N >= 8 && LOG2N <= 12, "256 ... 4096 samples");
     extern __shared__ __align__(16) unsigned char smem[];
     float2* zall = reinterpret_cast<float2*>(smem);             // [2][NF][ZS]
@@ -372,8 +372,7 @@ __global__ void __launch_bounds__(2 * HT, HT == 512 ? 1 : 4) mtfft_long_kernel(L
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            dft16(a, o);
-            PBAR();                                                                   // 4
+            dft16(a, o);                    // (in place: every thread writes back exactly the slots it read -- no barrier between)
 #pragma unroll
             for (int u = 0; u < 16; ++u) zr[272 * u] = o[u];
         } else if constexpr (LOG2N == 11) { // pass 3: radix 8, P = 256, two butterflies per thread, in place
@@ -546,7 +545,7 @@ __global__ void __launch_bounds__(2 * HT, HT == 512 ? 1 : 4) mtfft_long_kernel(L
                     if (ht + j * HT < N) tn[ht + j * HT] = hn[j];
             }
         }
-        if constexpr (NB == 5 || WAVE_LOCAL) __syncthreads();
+        if constexpr (WAVE_LOCAL) __syncthreads();
     };
 
     // Slot q of a half: taper q / 2, the passes in the even slots and the store in the odd ones; half 1 is one slot behind half 0.
