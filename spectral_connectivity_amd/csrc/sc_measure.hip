@@ -50,7 +50,7 @@ struct MeasureArgs {
     int64_t n_bins, floats_per_bin, total;
     int C, NB, n_tiles;
     int p_csm, p_abs, p_sq, p_sign, p_unit;  // plane offsets or -1
-    double n_obs;
+    double n_obs, rn_obs;        // observations per bin and 1 / that (one fp64 division on the host instead of one per entry and measure)
     int measure;
     int n_multi;                 // measure_tile_multi_kernel: the real-valued measures of one launch ...
     int multi[SC_MEASURE_MULTI_MAX];
@@ -105,12 +105,20 @@ __device__ inline MeasureIn measure_mirror(MeasureIn v) {
     return w;
 }
 
+// 1 / x for a normal positive double: v_rcp_f64 and two Newton steps (<= 1 ulp; the IEEE division sequence is three times as long)
+__device__ inline double measure_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
 // one measure of one entry; complex measures return (re, im), real ones (value, 0)
-__device__ inline double2 measure_value(int measure, double n, MeasureIn v, bool diag) {
+__device__ inline double2 measure_value(int measure, double n, double rn, MeasureIn v, bool diag) {
     const double NaN = nan("");
-    // (the expectation = sum * (1 / n): ONE fp64 division for the five quantities of an entry instead of five -- an fp64
-    //  division is ~12 instructions at half rate, and they were most of this kernel's arithmetic; 1 ulp of fp64 apart from x / n)
-    const double rn = 1.0 / n;
+    // (the expectation = sum * rn, rn = 1 / n from the host: no fp64 division per entry for it -- an fp64 division or square root is
+    //  ~12-20 instructions at half rate, and they were HALF of this kernel's time: 0.131 ms for coherence + wPLI at cfg3 against 0.065 with
+    //  the algebra switched off (-DMEASURE_AB_NOMATH); 1 ulp of fp64 apart from x / n)
     double s_re = v.s_re * rn, s_im = diag ? 0.0 : v.s_im * rn;
     const double p_i = v.p_i * rn, p_j = v.p_j * rn;
     switch (measure) {
@@ -119,7 +127,9 @@ __device__ inline double2 measure_value(int measure, double n, MeasureIn v, bool
     case SC_M_COHERENCY:
     case SC_M_COHERENCE_MAGNITUDE:
     case SC_M_COHERENCE_PHASE: {
-        const double rden = 1.0 / fmax(sqrt(p_i * p_j), SC_EPS64);       // (one division for both parts)
+        // 1 / max(sqrt(p_i p_j), eps) as ONE reciprocal square root (v_rsq_f64 + refinement) instead of a square root and a division
+        const double pp = p_i * p_j;
+        const double rden = pp > SC_EPS64 * SC_EPS64 ? rsqrt(pp) : 1.0 / SC_EPS64;
         double c_re = s_re * rden, c_im = s_im * rden;
         if (diag) { c_re = NaN; c_im = NaN; }
         if (measure == SC_M_COHERENCY) return make_double2(c_re, c_im);
@@ -147,7 +157,7 @@ __device__ inline double2 measure_value(int measure, double n, MeasureIn v, bool
     case SC_M_WPLI: {
         double w = diag ? 0.0 : v.sa * rn;
         if (w < SC_EPS64) w = 1.0;
-        return make_double2((s_im / w), 0.0);
+        return make_double2((s_im * measure_rcp(w)), 0.0);
     }
     case SC_M_DEBIASED_WPLI2: {
         const double si = s_im * n;
@@ -200,13 +210,13 @@ __global__ void __launch_bounds__(256) measure_tile_kernel(MeasureArgs a) {
     OutT* outf = (OutT*)a.out;
     OutT2* outc = (OutT2*)a.out;
     const int64_t obase = bin * (int64_t)a.C * a.C;
-    const double2 direct = measure_value(a.measure, a.n_obs, v, i == j);
+    const double2 direct = measure_value(a.measure, a.n_obs, a.rn_obs, v, i == j);
     if (i < a.C && j < a.C) {
         if (COMPLEX_OUT) outc[obase + (int64_t)i * a.C + j] = OutT2{(OutT)direct.x, (OutT)direct.y};
         else outf[obase + (int64_t)i * a.C + j] = (OutT)direct.x;
     }
     if (!dtile) {
-        mir[jj * 16 + ii] = measure_value(a.measure, a.n_obs, measure_mirror(v), false);
+        mir[jj * 16 + ii] = measure_value(a.measure, a.n_obs, a.rn_obs, measure_mirror(v), false);
         __syncthreads();
         const int r = tj * 16 + ii, c = ti * 16 + jj;       // thread (ii, jj) now owns row ii of the mirrored block
         if (r < a.C && c < a.C) {
@@ -266,7 +276,11 @@ __global__ void __launch_bounds__(256) measure_tile_multi_kernel(MeasureArgs a) 
         for (int m = 0; m < a.n_multi; ++m) {
             OutT* outf = (OutT*)a.multi_out[m];
             const int w = a.multi[m];
-            const double direct = measure_value(w, a.n_obs, v, i == j).x;
+#ifdef MEASURE_AB_NOMATH      // (A/B: what the loads, the LDS mirror and the stores cost without the fp64 algebra; results wrong)
+            const double direct = v.s_re + v.sa + w;
+#else
+            const double direct = measure_value(w, a.n_obs, a.rn_obs, v, i == j).x;
+#endif
             if (i < a.C && j < a.C) outf[obase + (int64_t)i * a.C + j] = (OutT)direct;
             if (!dtile) {
                 // entry (j, i): every real-valued measure is even or odd under (i, j) -> (j, i) (conjugated s, swapped
@@ -342,6 +356,7 @@ static int measure_multi_run(const void* d_accum, int64_t n_bins, int64_t n_sign
     a.p_sign = (need & SC_PLANE_SIGN_IM) ? sc_plane_offset(planes, SC_PLANE_SIGN_IM) : -1;
     a.p_unit = (need & SC_PLANE_UNIT) ? sc_plane_offset(planes, SC_PLANE_UNIT) : -1;
     a.n_obs = (double)n_observations;
+    a.rn_obs = 1.0 / a.n_obs;
     a.measure = measures[0];
     a.total = n_bins * n_signals * n_signals;
     SC_REQUIRE(n_bins < (int64_t)1 << 31 && a.n_tiles <= 65535, "output too large for one launch");
@@ -413,6 +428,7 @@ static int measure_run(const void* d_accum, int64_t n_bins, int64_t n_signals, u
     a.p_sign = (planes & SC_PLANE_SIGN_IM) ? sc_plane_offset(planes, SC_PLANE_SIGN_IM) : -1;
     a.p_unit = (planes & SC_PLANE_UNIT) ? sc_plane_offset(planes, SC_PLANE_UNIT) : -1;
     a.n_obs = (double)n_observations;
+    a.rn_obs = 1.0 / a.n_obs;
     a.measure = measure;
     uint32_t need = 0;
     switch (measure) {
