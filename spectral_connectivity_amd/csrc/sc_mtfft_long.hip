@@ -432,13 +432,19 @@ __global__ void __launch_bounds__(2 * HT, HT == 512 ? 1 : 4) mtfft_long_kernel(L
         }
     };
     // Planes format: a thread takes G = 4 channel pairs (8 channels; 2 pairs at N = 4096) of one frequency, so that every plane leaves
-    // as one 16-byte (8-byte) store: 2 G LDS reads, the conjugate-symmetry split, the two-piece f16 split.  TR (four or more
-    // groups per half, i.e. N = 256): the four lanes of a quad take four CONSECUTIVE frequencies of one group and transpose their
-    // 4 planes x 4 frequencies before the stores, so that store a of a lane is plane (lane & 3) of frequency a of the quad: the 16
-    // lanes of four quads write one whole 256-byte tile row per instruction (sc_mtfft.hip: 0.14 ms at cfg3 against plane-per-
-    // instruction stores).  Iteration `it` covers the FSP frequencies from it * FSP on; the last one holds the Nyquist bin alone.
+    // as one 16-byte (8-byte) store: 2 G LDS reads, the conjugate-symmetry split, the two-piece f16 split; the four stores of a
+    // thread go to the four 64-byte planes of one 256-byte tile row, back to back.  (sc_mtfft.hip transposes 4 planes x 4 frequencies
+    // inside a quad of lanes first, so that 16 lanes write one whole tile row per instruction: 0.14 ms at cfg3 THERE, where the
+    // store loop waits on the memory side; HERE the storing half shares the VALU with the half that runs the passes, and the 64
+    // extra instructions per iteration cost more than the wider pieces return: 1.75 -> 1.66 ms at cfg3 without it, A/B of two
+    // libraries on one box, -DML_QUAD_TR.)  Iteration `it` covers the FSP frequencies from it * FSP on; the last one holds the
+    // Nyquist bin alone.
     constexpr int G = NF >= 4 ? 4 : NF, NG = NF / G, FSP = HT / NG, PIT = (N / 2) / FSP + 1;
+#ifdef ML_QUAD_TR             // (A/B: the quad transposition of sc_mtfft.hip's planes store loop)
     constexpr bool TR = NG >= 4;
+#else
+    constexpr bool TR = false;
+#endif
     const int pj = ht & 3, pgrp = TR ? (ht >> 2) % NG : ht % NG, pfq = TR ? (ht / (4 * NG)) * 4 + pj : ht / NG, pcg = chalf + 2 * G * pgrp;
     bool pflag = false;                               // some channel of this thread's group is silent or non-finite
     if constexpr (PL) {
