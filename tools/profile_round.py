@@ -50,8 +50,8 @@ if os.path.exists(final) and os.path.getmtime(final) > os.path.getmtime(os.path.
 if bench:
     open(os.path.join(P, ROUND + "_bench_line.json"), "w").write(bench[-1] + "\n")
 under = [l for l in lines("bench_under_rocprof.json") if l.startswith("{")]
-hdr = ["# rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 2 --timed-only   (cfg3, 1x MI355X, round %s;" % ROUND.lstrip("r0") + " tools/profile_round.sh;",
-       "# --timed-only: nothing but the warm-up and the timed steps, so every average below is over the 12 launches of the step loop)"]
+hdr = ["# rocprofv3 --kernel-trace --stats -- python bench.py --steps 40 --warmup 2 --timed-only   (cfg3, 1x MI355X, round %s;" % ROUND.lstrip("r0") + " tools/profile_round.sh;",
+       "# --timed-only: nothing but the warm-up and the timed steps, so every average below is over the 42 launches of the step loop)"]
 if under:
     st = json.loads(under[-1])
     sm = st["roofline"]["stage_ms"]

@@ -14,7 +14,7 @@ mkdir -p $OUT
 cd $ROOT
 python bench.py --steps 20 --warmup 5 > $OUT/bench_line.json 2> $OUT/bench_line.err
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 10 --warmup 2 --timed-only"
+BENCH="python $ROOT/bench.py --steps 40 --warmup 2 --timed-only"
 rocprofv3 --kernel-trace --stats -d $OUT/kt -- $BENCH > $OUT/bench_under_rocprof.json 2> $OUT/kt.err
 SHORT="python $ROOT/bench.py --steps 2 --warmup 1 --timed-only"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -- $SHORT > /dev/null 2> $OUT/fetch.err
