@@ -1,28 +1,31 @@
-// sc_mtfft_long.hip -- stage A for long power-of-two windows (N = 1024, 2048, 4096): window extraction + detrend + DPSS taper
-// multiply + real FFT + transposed store of the one-sided spectra X[f][w][r][k][c], like sc_mtfft.hip
+// sc_mtfft_long.hip -- stage A for power-of-two windows of 256 ... 4096 samples (written for the long ones, hence the name): window
+// extraction + detrend + DPSS taper multiply + real FFT + transposed store of the one-sided spectra X[f][w][r][k][c] -- or of the
+// planes format of sc_fused2.hip -- like sc_mtfft.hip
 // (reference: transforms.py:1147-1171 sliding windows, :1311-1405 _multitaper_fft, :1798-1915 detrend).
 //
-// Why a second kernel.  At these lengths one packed transform (two channels) fills 35 KB of LDS, so a workgroup holds few
+// Why a second kernel.  At the long lengths one packed transform (two channels) fills 35 KB of LDS, so a workgroup holds few
 // channels, and the round-3 kernels (mtfft16_kernel<10 / 11 / 12>) ran their three phases one after the other on every compute
 // unit (SC_MTFFT_DEBUG ablation at the cfg3 volume, N = 4096: 2.38 ms = 0.87 load + detrend, 0.75 passes, 0.66 stores):
 //  * the long-window loads took 8 bytes of 64 different rows per wave instruction (x is [time][trial][channel]: a workgroup needs
 //    16 bytes of every 512-byte row): 0.6 TB/s of samples;
 //  * the workgroups of a compute unit fell into step: all in the passes (sharing the VALU), then all in the store loop
 //    (sharing the memory pipe), so nothing overlapped.
-// Here a workgroup is TWO halves of 512 threads that run in ANTI-PHASE by construction: while half 0 runs the radix-16 passes
+// Here a workgroup is TWO halves of HT threads that run in ANTI-PHASE by construction: while half 0 runs the radix-16 passes
 // of taper k (VALU + LDS), half 1 splits and stores its taper k - 1 (memory pipe), then they swap -- the slot boundary is a
 // workgroup barrier both halves reach, and the passes' inner barriers are matched by barriers between the store chunks of the
-// other half (N = 1024: one wave per transform, no inner barriers at all).  One workgroup (16 waves, 139 KB of exchange
-// buffers: one per half) owns the compute unit.  Each half transforms NF = 512 / (N / 16) channel pairs (8 / 4 / 2 at
-// N = 1024 / 2048 / 4096), a workgroup 4 NF channels.  The window reaches the registers through the exchange buffers, which are
-// free until the first pass: two row-major half-window tiles, loaded with 16-byte pieces of the rows and read back per thread.
+// other half (up to 1024 samples: one wave per transform, no inner barriers at all).  HT = 512 from 1024 samples on: one workgroup
+// (16 waves, 139 KB of exchange buffers: one per half) owns the compute unit; HT = 256 at 256 / 512 samples: two workgroups share
+// it.  Each half transforms NF = HT / (N / 16) channel pairs, a workgroup 4 NF channels.  The window reaches the registers through
+// the exchange buffers, which are free until the first pass: two row-major half-window tiles, loaded with 16-byte pieces of the
+// rows and read back per thread.
 // (First form of this kernel: the series transposed to [trial][channel][time] by a pass of its own -- 0.25 ms of the 1.6 at
 //  the cfg3 volume -- and read as contiguous channel rows; and several items per workgroup with the next item's prologue under
 //  the last store slot, which gained nothing at 2048 samples and LOST 40 % at 4096: there the four workgroups whose 32-byte
 //  pieces complete a line must stay in step, and they only do when they are dispatched together.)
-// Arithmetic as in sc_mtfft.hip (two real channels per complex sequence, pair normalised per window by powers of two, halved
-// samples, fp64 trend sums, three register-resident passes through a skewed exchange buffer); pass-2 twiddles come from a
-// 16 x 16 table, pass-3 twiddles from the product of two small tables, every table access at a constant offset from a base.
+// Arithmetic as in sc_mtfft.hip (two real channels per complex sequence, pair normalised per window by powers of two -- planes
+// output: the channel scales on the samples --, halved samples, fp64 trend sums, register-resident passes through a skewed exchange
+// buffer); pass-2 twiddles come from a 16 x 16 table, pass-3 twiddles from the product of two small tables, every table access at a
+// constant offset from a base.  Measured: DESIGN.md section 4.1, profiles/r05_stage_a_*.txt.
 #include <cstdlib>
 #include <type_traits>
 #include "sc_common.h"
