@@ -32,6 +32,35 @@ extern "C" int sc_debug_reload_env(void) {
 static const int g_switches_loaded = sc_debug_reload_env();          // when the library is loaded
 const char* sc_switch(int id) { return (id >= 0 && id < SC_SW_COUNT && g_switch_set[id]) ? g_switch_val[id] : nullptr; }
 
+// Batched in-place complex128 transforms of the Wilson kernels (sc_wilson.hip, sc_mvar.hip), one plan per (direction, length, batch)
+// for the life of the process.  rocFFT compiles the kernels of a length outside its prebuilt set at run time and unloads their code
+// object when the plan is destroyed; a plan destroyed right before the FIRST launch of one of this library's own kernels (whose code
+// object the runtime loads lazily) was followed, one run in five on MI355X / ROCm 7.0, by "illegal shader instruction" + a write to
+// address 0 in that kernel -- stale instructions where the unloaded code had been (pairwise Granger at 250 samples, then canonical
+// coherence: tests/test_gpu_fp64.py run first in a process).  Plans that are never destroyed never free code memory, and the second
+// call with a geometry pays no plan creation (tens of ms with run-time compilation).
+#include <mutex>
+struct ScZ2zEntry { int type; size_t N, batch; rocfft_plan plan; };
+static ScZ2zEntry g_z2z[64];
+static int g_z2z_n = 0;
+static std::mutex g_z2z_mutex;
+int sc_internal_z2z_plan(rocfft_plan* plan, int forward, size_t N, size_t batch, bool* cached) {
+    std::lock_guard<std::mutex> lock(g_z2z_mutex);
+    for (int i = 0; i < g_z2z_n; ++i)
+        if (g_z2z[i].type == forward && g_z2z[i].N == N && g_z2z[i].batch == batch) { *plan = g_z2z[i].plan; *cached = true; return SC_OK; }
+    size_t lengths[1] = {N};
+    const rocfft_status s = rocfft_plan_create(plan, rocfft_placement_inplace,
+                                               forward ? rocfft_transform_type_complex_forward : rocfft_transform_type_complex_inverse,
+                                               rocfft_precision_double, 1, lengths, batch, nullptr);
+    if (s != rocfft_status_success) {
+        sc_set_error("rocfft_plan_create(Z2Z N=%zu batch=%zu) failed: %d", N, batch, (int)s);
+        return SC_EFFT;
+    }
+    *cached = g_z2z_n < 64;
+    if (*cached) g_z2z[g_z2z_n++] = ScZ2zEntry{forward, N, batch, *plan};
+    return SC_OK;                                    // (table full: the caller owns the plan and destroys it)
+}
+
 extern "C" int sc_abi_version(void) { return SC_ABI_VERSION; }
 extern "C" const char* sc_last_error(void) { return g_err; }
 

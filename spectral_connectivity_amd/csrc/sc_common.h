@@ -28,6 +28,11 @@ int sc_internal_mtfft_long(const float* d_x, int64_t T, int64_t R, int64_t C, in
                            const float* d_tapers, int64_t K, int detrend_type, const void* d_twiddles, void* d_X, void* d_P,
                            const float* d_scale, hipStream_t st);
 
+// sc_api.hip: process-wide cache of the batched in-place complex128 rocFFT plans of the Wilson kernels (never destroyed: see there);
+// *cached == false: the table is full and the caller destroys the plan
+struct rocfft_plan_t;
+int sc_internal_z2z_plan(struct rocfft_plan_t** plan, int forward, size_t N, size_t batch, bool* cached);
+
 // sc_wilson_fft.hip: A <- fft(causal(ifft(A))) in one kernel, for the lengths `supported` accepts
 bool sc_internal_causal_fft_supported(int64_t N);
 int sc_internal_causal_fft_pair(void* d_A, const int32_t* d_status, int64_t n_problems, int C, int64_t N,

@@ -1132,17 +1132,6 @@ __global__ void m_measure(const cd* H, const cd* Amv, const double* sigma, const
 }
 
 // ---- host side ------------------------------------------------------------------------------------
-static int mv_make_z2z(rocfft_plan* plan, rocfft_transform_type type, size_t N, size_t batch) {
-    size_t lengths[1] = {N};
-    rocfft_status s = rocfft_plan_create(plan, rocfft_placement_inplace, type, rocfft_precision_double, 1,
-                                         lengths, batch, nullptr);
-    if (s != rocfft_status_success) {
-        sc_set_error("rocfft_plan_create(Z2Z N=%zu batch=%zu) failed: %d", N, batch, (int)s);
-        return SC_EFFT;
-    }
-    return SC_OK;
-}
-
 #define MV_CHECK_FFT(expr)                                                                       \
     do {                                                                                         \
         rocfft_status s_ = (expr);                                                               \
@@ -1315,6 +1304,7 @@ extern "C" int sc_mvar_factor_f64(const void* d_accum, const void* d_S, int64_t 
     }
     int rc = SC_OK;
     rocfft_plan fwd = nullptr, inv = nullptr;
+    bool fwd_cached = false, inv_cached = false;
     rocfft_execution_info info = nullptr;
     void* fft_work = nullptr;
     size_t ws_f = 0, ws_i = 0;
@@ -1330,8 +1320,8 @@ extern "C" int sc_mvar_factor_f64(const void* d_accum, const void* d_S, int64_t 
         return SC_EINVAL;
     }
     if (!fused) {
-        if ((rc = mv_make_z2z(&fwd, rocfft_transform_type_complex_forward, (size_t)N, (size_t)E * P)) != SC_OK) goto done;
-        if ((rc = mv_make_z2z(&inv, rocfft_transform_type_complex_inverse, (size_t)N, (size_t)E * P)) != SC_OK) goto done;
+        if ((rc = sc_internal_z2z_plan(&fwd, 1, (size_t)N, (size_t)E * P, &fwd_cached)) != SC_OK) goto done;
+        if ((rc = sc_internal_z2z_plan(&inv, 0, (size_t)N, (size_t)E * P, &inv_cached)) != SC_OK) goto done;
         MV_CHECK_FFT(rocfft_plan_get_work_buffer_size(fwd, &ws_f));
         MV_CHECK_FFT(rocfft_plan_get_work_buffer_size(inv, &ws_i));
         MV_CHECK_FFT(rocfft_execution_info_create(&info));
@@ -1413,8 +1403,8 @@ extern "C" int sc_mvar_factor_f64(const void* d_accum, const void* d_S, int64_t 
     }
 done:
     if (info) rocfft_execution_info_destroy(info);
-    if (fwd) rocfft_plan_destroy(fwd);
-    if (inv) rocfft_plan_destroy(inv);
+    if (fwd && !fwd_cached) rocfft_plan_destroy(fwd);       // (cached plans live as long as the process: sc_internal_z2z_plan)
+    if (inv && !inv_cached) rocfft_plan_destroy(inv);
     if (fft_work) (void)hipFreeAsync(fft_work, st);
     return rc;
 }

@@ -322,17 +322,6 @@ struct WilsonPlan {
     size_t work_bytes;
 };
 
-static int make_z2z(rocfft_plan* plan, rocfft_transform_type type, size_t N, size_t batch) {
-    size_t lengths[1] = {N};
-    rocfft_status s = rocfft_plan_create(plan, rocfft_placement_inplace, type, rocfft_precision_double, 1,
-                                         lengths, batch, nullptr);
-    if (s != rocfft_status_success) {
-        sc_set_error("rocfft_plan_create(Z2Z N=%zu batch=%zu) failed: %d", N, batch, (int)s);
-        return SC_EFFT;
-    }
-    return SC_OK;
-}
-
 #define WILSON_HIST 1024     // iterations whose "still running" counts the workspace can log (max_iterations <= this)
 #define WILSON_POLL 4        // iterations queued between two looks at the counts
 extern "C" int sc_granger_workspace_bytes(int64_t n_groups, int64_t n_pairs, int64_t N, size_t* bytes) {
@@ -381,6 +370,7 @@ static int wilson_iterate(const WilsonWork& k, int64_t P, int64_t n_batch, int64
                           hipStream_t st) {
     int rc = SC_OK;
     rocfft_plan fwd = nullptr, inv = nullptr;
+    bool fwd_cached = false, inv_cached = false;
     rocfft_execution_info info = nullptr;
     void* fft_work = nullptr;
     size_t ws_f = 0, ws_i = 0;
@@ -396,8 +386,8 @@ static int wilson_iterate(const WilsonWork& k, int64_t P, int64_t n_batch, int64
     }
 
     if (!fused) {
-        if ((rc = make_z2z(&fwd, rocfft_transform_type_complex_forward, N, 4 * P)) != SC_OK) goto done;
-        if ((rc = make_z2z(&inv, rocfft_transform_type_complex_inverse, N, 4 * P)) != SC_OK) goto done;
+        if ((rc = sc_internal_z2z_plan(&fwd, 1, N, 4 * P, &fwd_cached)) != SC_OK) goto done;
+        if ((rc = sc_internal_z2z_plan(&inv, 0, N, 4 * P, &inv_cached)) != SC_OK) goto done;
         SC_CHECK_FFT2(rocfft_plan_get_work_buffer_size(fwd, &ws_f));
         SC_CHECK_FFT2(rocfft_plan_get_work_buffer_size(inv, &ws_i));
         SC_CHECK_FFT2(rocfft_execution_info_create(&info));
@@ -452,8 +442,8 @@ static int wilson_iterate(const WilsonWork& k, int64_t P, int64_t n_batch, int64
     *running_out = running;
 done:
     if (info) rocfft_execution_info_destroy(info);
-    if (fwd) rocfft_plan_destroy(fwd);
-    if (inv) rocfft_plan_destroy(inv);
+    if (fwd && !fwd_cached) rocfft_plan_destroy(fwd);       // (cached plans live as long as the process: sc_internal_z2z_plan)
+    if (inv && !inv_cached) rocfft_plan_destroy(inv);
     if (fft_work) (void)hipFreeAsync(fft_work, st);
     return rc;
 }
