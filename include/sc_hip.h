@@ -14,7 +14,10 @@
  *    retains caller buffers past the call.  Device memory the library allocates ITSELF, all of it
  *    released before the owning call returns or with the owning handle:
  *      - `sc_fft_plan` handles (sc_fft_plan_create*): the rocFFT plan, its work buffer and a <= 64 MB
- *        transform scratch (hipMalloc; freed by sc_fft_plan_destroy; sc_fft_plan_work_bytes reports it);
+ *        transform scratch (hipMalloc; freed by sc_fft_plan_destroy; sc_fft_plan_work_bytes reports it) -- the rocFFT plan
+ *        object itself (twiddle tables, run-time compiled code: KBs to a few MB) is retired, not destroyed, and the
+ *        Wilson kernels keep theirs for the life of the process: unloading rocFFT's code right before the first
+ *        launch of another kernel has run stale instructions on MI355X / ROCm 7.0;
  *      - stream-ordered scratch (hipMallocAsync / hipFreeAsync on the call's stream) inside
  *        sc_multitaper_fft_f32 for N = 4096 (row-major spectra before the transpose, <= 2 GB),
  *        sc_canonical_coherence_f64 (inverted group factors, n_bins * n_groups * 4 KB; groups beyond 32 channels:

@@ -245,11 +245,13 @@ extern "C" int sc_fft_execute_f64(sc_fft_plan* plan, const double* d_y, void* d_
     return fft_execute(plan, d_y, d_X, true, stream);
 }
 
+// Releases what a plan owns in device memory (work buffer, transform scratch: up to tens of MB).  The rocFFT plan objects themselves
+// are RETIRED, not destroyed: destroying a plan whose kernels rocFFT compiled at run time unloads their code object, and a kernel of
+// this library launched for the first time right after that has run stale instructions there (see sc_internal_z2z_plan above:
+// "illegal shader instruction", one fresh process in five).  A retired plan keeps its twiddle tables and code (KBs to a few MB).
 extern "C" int sc_fft_plan_destroy(sc_fft_plan* plan) {
     if (!plan) return SC_OK;
     if (plan->info) rocfft_execution_info_destroy(plan->info);
-    if (plan->plan) rocfft_plan_destroy(plan->plan);
-    if (plan->tail_plan) rocfft_plan_destroy(plan->tail_plan);
     if (plan->work) (void)hipFree(plan->work);
     if (plan->Z) (void)hipFree(plan->Z);
     delete plan;
