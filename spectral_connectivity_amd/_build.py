@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsc_hip.so")
 OBJ_DIR = os.path.join(os.path.dirname(HERE), "build", "obj")
-SOURCES = ["sc_api.hip", "sc_taper.hip", "sc_mtfft.hip", "sc_mtfft_long.hip", "sc_mtfft_f64.hip", "sc_csm.hip", "sc_nonlinear.hip", "sc_fused.hip", "sc_fused2.hip", "sc_measure.hip",
+SOURCES = ["sc_api.hip", "sc_taper.hip", "sc_mtfft.hip", "sc_mtfft_long.hip", "sc_mtfft_mixed.hip", "sc_mtfft_f64.hip", "sc_csm.hip", "sc_nonlinear.hip", "sc_fused.hip", "sc_fused2.hip", "sc_measure.hip",
            "sc_wilson.hip", "sc_wilson_fft.hip", "sc_wilson_pair.hip", "sc_mvar.hip", "sc_global.hip", "sc_canonical.hip", "sc_f64.hip",
            "sc_timing.hip", "sc_memory.hip", "sc_comm.hip"]
 HEADERS = ["sc_common.h", "sc_stage.h", "sc_fused_common.h", "sc_jacobi.h", "sc_wilson_fft.h", "sc_mtfft_bfly.h", os.path.join("..", "..", "include", "sc_hip.h")]

@@ -13,7 +13,7 @@ void sc_set_error(const char* fmt, ...);
 enum ScSwitch {
     SC_SW_FUSED_DEBUG, SC_SW_FUSED2_TERMS, SC_SW_FUSED_SPLIT, SC_SW_FUSED_NO_SMALL, SC_SW_MTFFT_DEBUG, SC_SW_MTFFT_WIDE,
     SC_SW_MTFFT_F64, SC_SW_F64_SPLIT, SC_SW_F64_OC, SC_SW_F64_NO_FORK, SC_SW_F64_NO_BLOCK, SC_SW_WILSON_FFT, SC_SW_GLOBAL_EIG,
-    SC_SW_GLOBAL_NT256, SC_SW_GRANGER_KERNEL, SC_SW_FUSED_FOLD_OBS, SC_SW_MTFFT_LONG, SC_SW_CANON_EIG, SC_SW_COUNT
+    SC_SW_GLOBAL_NT256, SC_SW_GRANGER_KERNEL, SC_SW_FUSED_FOLD_OBS, SC_SW_MTFFT_LONG, SC_SW_CANON_EIG, SC_SW_MTFFT_MIXED, SC_SW_MTFFT_MIXED_GEO, SC_SW_COUNT
 };
 const char* sc_switch(int id);
 
@@ -27,6 +27,15 @@ int64_t sc_internal_mtfft_long_coverage(int64_t N, int64_t C);
 int sc_internal_mtfft_long(const float* d_x, int64_t T, int64_t R, int64_t C, int64_t L, int64_t step, int64_t W, int64_t N,
                            const float* d_tapers, int64_t K, int detrend_type, const void* d_twiddles, void* d_X, void* d_P,
                            const float* d_scale, hipStream_t st);
+
+// sc_mtfft_mixed.hip: stage A for the window lengths N = 10 RM RF that are not powers of two (register-resident radix-10 passes,
+// anti-phase half-workgroups, planes-format output)
+bool sc_internal_mtfft_mix_has(int64_t N);
+bool sc_internal_mtfft_mix_applies(int64_t N, int64_t C, int64_t groups);
+int64_t sc_internal_mtfft_mix_coverage(int64_t N, int64_t C, bool planes);
+int sc_internal_mtfft_mix(const float* d_x, int64_t T, int64_t R, int64_t C, int64_t L, int64_t step, int64_t W, int64_t N,
+                          const float* d_tapers, int64_t K, int detrend_type, const void* d_twiddles, void* d_X, void* d_P,
+                          const float* d_scale, hipStream_t st);
 
 // sc_api.hip: process-wide cache of the batched in-place complex128 rocFFT plans of the Wilson kernels (never destroyed: see there);
 // *cached == false: the table is full and the caller destroys the plan

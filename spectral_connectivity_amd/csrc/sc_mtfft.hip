@@ -1349,8 +1349,10 @@ static int mt_wide() {
 }
 
 extern "C" int sc_multitaper_fft_planes_supported(int64_t L, int64_t N, int64_t C) {
-    // (2048 and 4096 samples: the anti-phase kernel of sc_mtfft_long.hip only)
-    return (L >= 1 && L <= N && N >= 64 && N <= 4096 && (N & (N - 1)) == 0 && C >= 2 && (C % 2) == 0) ? 1 : 0;
+    // (2048 and 4096 samples: the anti-phase kernel of sc_mtfft_long.hip only; N = 10 RM RF: sc_mtfft_mixed.hip only)
+    if (!(L >= 1 && L <= N && C >= 2 && (C % 2) == 0)) return 0;
+    if (N >= 64 && N <= 4096 && (N & (N - 1)) == 0) return 1;
+    return sc_internal_mtfft_mix_has(N) ? 1 : 0;
 }
 
 extern "C" int sc_multitaper_fft_supported(int64_t L, int64_t N) {
@@ -1385,18 +1387,23 @@ static int mtfft_run(const float* d_x, int64_t T, int64_t R, int64_t C, int64_t 
     const bool use_long = pow2 && (sc_internal_mtfft_long_applies(N, C, W * R) || (d_P && N >= 2048));
     if (d_P) {
         if (!sc_multitaper_fft_planes_supported(L, N, C)) {
-            sc_set_error("planes-format multitaper FFT needs an even number of signals and N a power of two in 64 ... 4096 (got C=%lld N=%lld)",
+            sc_set_error("planes-format multitaper FFT needs an even number of signals and N a power of two in 64 ... 4096 or one of "
+                         "200 ... 2000 = 10 RM RF (got C=%lld N=%lld)",
                          (long long)C, (long long)N);
             return SC_EUNSUPPORTED;
         }
         // A workgroup writes the CT channels it transforms (round-1..3 kernels: CT = 2 * threads / (N / 16), 16 at 512 samples and
         // with the 512-thread workgroups of 1024, 8 with 256 threads at 1024); where the workgroups do not cover the last 32-channel
         // tile the uncovered part must read as zeros (stage B stages whole tiles)
-        const int64_t threads = (N == 1024 && mt_wide() && C >= 16) ? 512 : 256, ct = 2 * threads / (N / 16);
-        const int64_t covered = use_long ? sc_internal_mtfft_long_coverage(N, C) : (C + ct - 1) / ct * ct;
+        const int64_t threads = (N == 1024 && mt_wide() && C >= 16) ? 512 : 256, ct = pow2 ? 2 * threads / (N / 16) : 1;
+        const int64_t covered = !pow2 ? sc_internal_mtfft_mix_coverage(N, C, true)
+                                      : (use_long ? sc_internal_mtfft_long_coverage(N, C) : (C + ct - 1) / ct * ct);
         if (covered < (C + 31) / 32 * 32)
             SC_CHECK_HIP(hipMemsetAsync(d_P, 0, (size_t)((N / 2 + 1) * W * R * K) * (size_t)a.row_bytes, s));
     }
+    // the lengths N = 10 RM RF with enough work to fill the chip -- and every planes-format request: sc_mtfft_mixed.hip
+    if (!pow2 && (d_P || sc_internal_mtfft_mix_applies(N, C, W * R)))
+        return sc_internal_mtfft_mix(d_x, T, R, C, L, step, W, N, d_tapers, K, detrend_type, d_twiddles, d_X, d_P, d_scale, s);
     if (!pow2) return launch_mixed(a, N, s);
     if (use_long) return sc_internal_mtfft_long(d_x, T, R, C, L, step, W, N, d_tapers, K, detrend_type, d_twiddles, d_X, d_P, d_scale, s);
     switch (N) {

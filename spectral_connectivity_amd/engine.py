@@ -328,15 +328,18 @@ def accum_layout(spectra, expectation_type, planes, n_freq=None):
 _ws_cache = {}
 
 
-def _workspace(n_bytes, device):
-    """Scratch the fused stage-B kernel uses to split bins over workgroups (kept and reused per device)."""
+def _workspace(n_bytes, device, owner=None):
+    """Scratch the fused stage-B kernel uses to split bins over workgroups (kept and reused per device).  ``owner``: a dict of
+    the caller's in which the buffer lives instead of the per-device cache -- a captured pass (GraphedMeasures) replays the
+    buffer's ADDRESS, so it must not be the shared one, which a later, larger request replaces and frees."""
     if n_bytes <= 0:
         return None
+    cache = _ws_cache if owner is None else owner
     key = (device.type, device.index)
-    buf = _ws_cache.get(key)
+    buf = cache.get(key)
     if buf is None or buf.numel() < n_bytes:
         buf = torch.empty(n_bytes, dtype=torch.uint8, device=device)
-        _ws_cache[key] = buf
+        cache[key] = buf
     return buf
 
 
@@ -437,7 +440,7 @@ def _accumulate_blocked(spectra, expectation_type, planes, n_freq, mark, row_mul
 
 
 def accumulate(spectra, expectation_type, planes, n_freq=None, mark=None, use_fused=None, row_multiple=1, have=None,
-               fold=True):
+               fold=True, ws_owner=None):
     """Stage B: un-normalised accumulator record tensor [n_bins, floats_per_bin] (float32; float64 records from
     complex128 spectra).  ``row_multiple``: see _record_tensor (trial-sharded callers pass the world size).
     ``fold=False`` (planes-format path only; ignored elsewhere): when stage B split every bin over several workgroups, their
@@ -446,7 +449,8 @@ def accumulate(spectra, expectation_type, planes, n_freq=None, mark=None, use_fu
     and one record round trip less), fold_parts() gives the 2-D record to any other consumer.
     ``have`` = (planes_old, record_old), float64 engine only: families already accumulated for the same spectra and
     expectation are copied over (a strided device copy) and only the missing ones are computed -- its CSM and
-    per-observation planes are separate kernels, so a wPLI after a coherence costs the |Im s| plane alone."""
+    per-observation planes are separate kernels, so a wPLI after a coherence costs the |Im s| plane alone.
+    ``ws_owner``: see _workspace (a dict that owns the split-bin scratch of this call instead of the per-device cache)."""
     lib = _lib.load()
     if spectra.C > MAX_KERNEL_SIGNALS:
         return _accumulate_blocked(spectra, expectation_type, planes, n_freq, mark, row_multiple)
@@ -489,7 +493,7 @@ def accumulate(spectra, expectation_type, planes, n_freq=None, mark=None, use_fu
                 if mark:
                     mark("fused2_csm_absim")
                 return (parts[:n_parts.value] if n_parts.value > 1 else parts[0]), n_obs
-            ws = _workspace(ws_bytes, spectra.device)
+            ws = _workspace(ws_bytes, spectra.device, ws_owner)
             accum = _record_tensor(n_bins, fpb, torch.float32, spectra.device, row_multiple)
             _lib.check(lib.sc_fused2_csm_absim_f32(_ptr(spectra.P), byref(dp), _ptr(spectra.scale), planes, _ptr(accum),
                                                    _ptr(ws) if ws is not None else None, ws_bytes, _stream()),
@@ -508,7 +512,7 @@ def accumulate(spectra, expectation_type, planes, n_freq=None, mark=None, use_fu
     one_pass = int(lib.sc_fused_planes_covered(byref(d), planes)) if use_fused else 0
     if one_pass:
         ws_bytes = int(lib.sc_fused_workspace_bytes(byref(d), planes))
-        ws = _workspace(ws_bytes, spectra.device)
+        ws = _workspace(ws_bytes, spectra.device, ws_owner)
         ws_ptr = _ptr(ws) if ws is not None else None
         if one_pass & _lib.PLANE_CSM:
             # CSM (+ the per-observation |Im s| products, + (Im s)^2): bf16 matrix pipe, or the f32 VALU kernel
@@ -821,10 +825,11 @@ class GraphedMeasures:
             self.planes |= _lib.MEASURE_PLANES[w]
         n_windows = int(np.floor(T / n_step - n_window / n_step + 1))
         h = tapers_over_fs.to(dev)
+        self._ws = {}                                 # the split-bin scratch of the captured stage B: this object's own
 
         def run():
             sp = multitaper_spectra(self.x, h, n_window, n_step, n_fft, n_windows, detrend_type)
-            accum, n_obs = accumulate(sp, expectation_type, self.planes)
+            accum, n_obs = accumulate(sp, expectation_type, self.planes, ws_owner=self._ws)
             return measure_multi(accum, C, self.planes, n_obs, self.measures)
 
         self._eager = run

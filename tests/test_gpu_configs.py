@@ -367,6 +367,34 @@ def test_graphed_measures_replay_equals_the_eager_pass():
     close(coh_g.reshape(ref.shape).cpu().numpy(), ref, 1e-5, 1e-5, "coherency from a graph replay")
 
 
+def test_graphed_measures_owns_its_split_bin_workspace():
+    """A captured pass replays the ADDRESS of stage B's split-bin scratch; the shared per-device scratch is replaced (and freed)
+    by the next larger eager request.  GraphedMeasures keeps a scratch of its own: a replay after such a request still equals
+    the eager pass bit for bit (few bins x many observations: every bin split over several workgroups)."""
+    import torch
+    from spectral_connectivity_amd import _lib, engine
+    from spectral_connectivity_amd.transforms import _make_tapers
+    T, R, C, NW = 64, 3000, 32, 2
+    tapers = _make_tapers(T, FS, NW, 3)
+    h = torch.from_numpy(np.ascontiguousarray(tapers.T / FS, dtype=np.float32)).cuda()
+    g = engine.GraphedMeasures((T, R, C), h, T, T, T, "constant", "trials_tapers", [_lib.M_COHERENCE_MAGNITUDE])
+    assert g._ws, "this shape was chosen so that stage B splits its bins (a scratch buffer)"
+    own = next(iter(g._ws.values()))
+    shared = engine._ws_cache.get((own.device.type, own.device.index))
+    assert shared is None or shared.data_ptr() != own.data_ptr()
+    x = synth(T, R, C, 40.0, 3)
+    first = g(x)[0].clone()
+    # a larger eager request on the same device: the shared scratch grows (the old block goes back to the allocator) ...
+    big = torch.randn((T, 4 * R, C), dtype=torch.float32, device="cuda")
+    sp = engine.multitaper_spectra(big, h, T, T, T, 1, "constant")
+    engine.accumulate(sp, "trials_tapers", _lib.PLANE_CSM)
+    junk = [torch.full((1 << 20,), float("nan"), device="cuda") for _ in range(8)]       # ... and whatever was freed is overwritten
+    again = g()[0]
+    assert torch.equal(first.nan_to_num(), again.nan_to_num())
+    assert torch.equal(again.nan_to_num(), g.eager()[0].nan_to_num())
+    del junk
+
+
 @pytest.mark.parametrize("dtype,C", [("float32", 6), ("float32", 7), ("float64", 6), ("float64", 5)])
 def test_multitaper_takes_a_series_that_already_lives_in_hbm(sc, dtype, C):
     """Beyond the reference: ``Multitaper(time_series=<torch tensor on the GPU>)`` uses the tensor in place (no host round trip;

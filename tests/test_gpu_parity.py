@@ -149,7 +149,11 @@ def test_f3_every_measure_every_expectation(sc, golden, et):
     ("L256_N255", dict(n_time_samples_per_window=256, n_fft_samples=255)),
     ("dur_step", dict(time_window_duration=0.8, time_window_step=0.29)),
 ])
-def test_f4_lengths(sc, golden, tag, kw):
+@pytest.mark.parametrize("kernel", ["engine's choice", "register passes"])
+def test_f4_lengths(sc, golden, tag, kw, kernel, debug_env):
+    # ("register passes": csrc/sc_mtfft_mixed.hip whatever the size -- 250 and 300 samples here; the engine by itself takes it from
+    #  256 (window, trial, channel tile) items on and for every planes-format request)
+    debug_env("SC_MTFFT_MIXED", "1" if kernel == "register passes" else None)
     g = golden("f4_lengths")
     m = sc.Multitaper(g["x"], sampling_frequency=float(g["fs"]), time_halfbandwidth_product=float(g["NW"]), **kw)
     close32(m.fft(), g[f"{tag}__fft"], what=f"{tag} fft")

@@ -45,7 +45,14 @@ def _series(T, R, C, seed, offset=0.0, quiet=2e-3, loud=250.0):
 @pytest.mark.parametrize("L,step,C,detrend", [(256, 128, 128, "constant"), (128, 64, 20, "linear"), (64, 64, 34, None),
                                                (512, 256, 16, "constant"), (1024, 1024, 48, "constant"), (256, 256, 70, "linear"),
                                                (512, 512, 100, None), (1024, 512, 34, "linear"), (2048, 2048, 48, "constant"),
-                                               (2048, 1024, 22, "linear"), (4096, 4096, 20, "constant"), (4096, 2048, 36, None)])
+                                               (2048, 1024, 22, "linear"), (4096, 4096, 20, "constant"), (4096, 2048, 36, None),
+                                               # the lengths that are not powers of two (sc_mtfft_mixed.hip: the only kernel with this
+                                               # output there, both values of `kernel` run it)
+                                               (250, 125, 128, "constant"), (200, 100, 20, "linear"), (500, 250, 34, None),
+                                               (1000, 1000, 48, "constant"), (1000, 500, 22, "linear"), (300, 300, 70, "constant"),
+                                               (400, 200, 36, None), (600, 300, 24, "linear"), (750, 750, 18, "constant"),
+                                               (800, 400, 40, None), (1200, 1200, 16, "linear"), (1500, 750, 12, "constant"),
+                                               (2000, 2000, 10, "linear")])
 def test_stage_a_planes_decode_to_the_spectra(L, step, C, detrend, kernel, debug_env):
     """sc_multitaper_fft_planes_f32 + sc_spectra_from_planes_f32 against the float64 transform of the same samples and
     tapers: the float32 transform's rounding plus the 22 bits of the format.  The scales sit on the SAMPLES, so the two
