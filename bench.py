@@ -400,7 +400,7 @@ def run_side_config(args, cfg, device):
         cpu = {"value": round(cpu_value, 3), "unit": unit, "cores": 1, "kind": "port",
                "measured_seconds_on_sample": round(dt, 3), "sample": sample + f"; os.cpu_count()={os.cpu_count()}"}
 
-    print(json.dumps({
+    return ({
         "metric": metric, "value": value, "unit": unit, "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32" if kind == "coherency" else "f32 spectra + records, f64 " + ("Wilson iteration" if kind == "granger" else "whitening + Jacobi"),
@@ -408,7 +408,30 @@ def run_side_config(args, cfg, device):
         "config": {"workload": cfg["label"], "name": args.config, "trials_total": R, "n_tapers": K, "n_windows": W,
                    "n_freq_bins": F, "units_per_step": units,
                    **({"wilson_iterations": iters, "wilson_not_converged": info["wilson"][1]} if kind == "granger" else {})},
-        "roofline": roofline, "launch": launch, "cpu_baseline": cpu}))
+        "roofline": roofline, "launch": launch, "cpu_baseline": cpu})
+
+
+def side_configs(args, device):
+    """The other GPU configurations of BASELINE.json (configs[1], [3], [4]) behind the headline's timed region, each with its own
+    metric, stage times, roofline and CPU baseline -- `side_configs` of the default line, so that the driver's one run carries
+    every configuration (python bench.py --config cfgN prints any of them as a line of its own)."""
+    import copy
+    out = {}
+    for name in ("cfg2", "cfg4", "cfg5"):
+        a = copy.copy(args)
+        a.config, a.steps, a.warmup = name, 10, 3
+        try:
+            t0 = time.perf_counter()
+            line = run_side_config(a, dict(CONFIGS[name]), device)
+            line["wall_seconds_in_bench"] = round(time.perf_counter() - t0, 2)
+            for k in ("n_gpus", "higher_is_better", "vs_baseline", "data", "scaling"):
+                line.pop(k, None)
+            out[name] = line
+        except Exception as exc:                      # a side configuration never costs the headline its line
+            out[name] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+    return out
 
 
 def self_launch(n_ranks):
@@ -476,7 +499,8 @@ def main():
         cfg["R"] = args.trials
     if cfg["kind"] != "measures":
         assert world == 1, f"--config {args.config} is a single-GPU line; the scaling bench is cfg3"
-        return run_side_config(args, cfg, device)
+        print(json.dumps(run_side_config(args, cfg, device)))
+        return
     assert cfg["R"] % world == 0, "trials must divide evenly over ranks"
     r_lo, r_hi = parallel.shard_bounds(cfg["R"], world, rank)
     T, C, L, step = cfg["T"], cfg["C"], cfg["L"], cfg["step"]
@@ -711,6 +735,14 @@ def main():
                "note": "Connectivity(dtype=complex128): float64 transform, fp64 matrix-core CSM, fp64 VALU |Im s| plane, "
                        "float64 measures; reported beside the float32 line, not as the metric"}
 
+    side = None
+    if rank == 0 and world == 1 and not args.timed_only and os.environ.get("SC_BENCH_SIDE_CONFIGS", "1") == "1":
+        try:
+            del xd, hd
+        except NameError:
+            pass
+        torch.cuda.empty_cache()
+        side = side_configs(args, device)
     if rank == 0:
         print(json.dumps({
             "metric": "channel-pair*freq-bins/s for CSM+coherence(+wPLI)",
@@ -728,6 +760,8 @@ def main():
                        "units_per_step": units, "parallelism": f"trials sharded over {world} GPU(s)"},
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_restructured": cpu_strong,
             "float64_engine": f64,
+            # BASELINE.json configs[1], [3], [4] on this GPU, behind the timed region of the headline (side_configs())
+            "side_configs": side,
             "backend": None if world == 1 else ("rccl" if backend == "nccl" else backend + " (ranks share GPUs: rehearsal only)"),
             # N > 1: time inside the RCCL collectives of one step on the exchange stream (reduce-scatter of the records,
             # gather of the measures) and the part of the exchange + epilogue the launch stream had to wait for

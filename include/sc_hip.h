@@ -64,7 +64,7 @@
 extern "C" {
 #endif
 
-#define SC_ABI_VERSION 5
+#define SC_ABI_VERSION 6
 
 /* error codes */
 #define SC_OK 0
@@ -327,6 +327,12 @@ int sc_debug_fused2_clock(double* ghz);
  * the tests of alternative kernels) are environment variables read once when the library is loaded; a host that changes one
  * afterwards calls this to have them read again.  No reference counterpart (the reference has no native code). */
 int sc_debug_reload_env(void);
+/* rocFFT plans are never destroyed (a destroyed plan unloads run-time compiled code that a lazily loaded kernel of this library
+ * has then executed stale: see sc_fft_plan_destroy); they live in pools keyed by geometry and are re-used.  *n_created:
+ * rocfft_plan_create calls of the process; *n_pooled: plans the pools hold; *n_idle: of those, real-to-complex row plans that
+ * belong to no live sc_fft_plan.  n_created == n_pooled always: what a process holds is bounded by the DISTINCT (length, batch,
+ * precision) geometries it has asked for, not by how many sc_fft_plan objects it created and destroyed.  Any pointer may be NULL. */
+int sc_debug_fft_plans(int64_t* n_created, int64_t* n_pooled, int64_t* n_idle);
 int sc_fused2_csm_absim_f32(const void* d_P, const sc_spectra_desc* desc, const float* d_scale, uint32_t planes,
                             float* d_accum, void* d_workspace, int64_t workspace_bytes, void* stream);
 

@@ -21,7 +21,7 @@ from . import _build
 c_int64_p = POINTER(c_int64)
 
 # ---- constants mirrored from include/sc_hip.h -------------------------------------------
-SC_ABI_VERSION = 5
+SC_ABI_VERSION = 6
 GRANGER_KEEP_OUTPUT = 1
 DETREND = {None: 0, "constant": 1, "c": 1, "linear": 2, "l": 2}
 MVAR_DTF, MVAR_DC, MVAR_PDC, MVAR_GPDC, MVAR_DDTF, MVAR_TRANSFER, MVAR_COEFFICIENTS, MVAR_NOISE_COVARIANCE = range(8)
@@ -114,6 +114,7 @@ SYMBOLS = {
     "sc_fused2_supported": (c_int, [POINTER(SpectraDesc), c_uint32]),
     "sc_debug_fused2_clock": (c_int, [POINTER(c_double)]),
     "sc_debug_reload_env": (c_int, []),
+    "sc_debug_fft_plans": (c_int, [POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)]),
     "sc_fused2_csm_absim_parts_f32": (c_int, [c_void_p, POINTER(SpectraDesc), c_void_p, c_uint32, c_void_p, c_void_p, c_int64,
                                               POINTER(c_int), c_void_p]),
     "sc_fused2_csm_absim_f32": (c_int, [c_void_p, POINTER(SpectraDesc), c_void_p, c_uint32, c_void_p, c_void_p, c_int64,
@@ -230,6 +231,15 @@ def reload_debug_env():
     when it is loaded; tools and tests that change one afterwards call this (no-op while the library is not loaded)."""
     if _lib is not None:
         _lib.sc_debug_reload_env()
+
+
+def fft_plan_counts():
+    """(rocfft_plan_create calls of the process, plans the library's pools hold, idle real-to-complex row plans among them): rocFFT
+    plans are pooled by geometry and never destroyed (sc_fft_plan_destroy), so the first two are always equal and grow with the
+    DISTINCT geometries only."""
+    a, b, c = c_int64(0), c_int64(0), c_int64(0)
+    check(_handle().sc_debug_fft_plans(byref(a), byref(b), byref(c)), "sc_debug_fft_plans")
+    return a.value, b.value, c.value
 
 
 def set_debug_env(name, value):

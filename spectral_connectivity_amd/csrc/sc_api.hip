@@ -40,14 +40,15 @@ const char* sc_switch(int id) { return (id >= 0 && id < SC_SW_COUNT && g_switch_
 // coherence: tests/test_gpu_fp64.py run first in a process).  Plans that are never destroyed never free code memory, and the second
 // call with a geometry pays no plan creation (tens of ms with run-time compilation).
 #include <mutex>
+#include <vector>
 struct ScZ2zEntry { int type; size_t N, batch; rocfft_plan plan; };
-static ScZ2zEntry g_z2z[64];
-static int g_z2z_n = 0;
+static std::vector<ScZ2zEntry> g_z2z;              // grows with the distinct geometries of the process: never a destroyed plan
 static std::mutex g_z2z_mutex;
+static int64_t g_plans_created = 0;                // rocfft_plan_create calls of the process (both pools), for sc_debug_fft_plans
 int sc_internal_z2z_plan(rocfft_plan* plan, int forward, size_t N, size_t batch, bool* cached) {
     std::lock_guard<std::mutex> lock(g_z2z_mutex);
-    for (int i = 0; i < g_z2z_n; ++i)
-        if (g_z2z[i].type == forward && g_z2z[i].N == N && g_z2z[i].batch == batch) { *plan = g_z2z[i].plan; *cached = true; return SC_OK; }
+    for (const ScZ2zEntry& e : g_z2z)
+        if (e.type == forward && e.N == N && e.batch == batch) { *plan = e.plan; *cached = true; return SC_OK; }
     size_t lengths[1] = {N};
     const rocfft_status s = rocfft_plan_create(plan, rocfft_placement_inplace,
                                                forward ? rocfft_transform_type_complex_forward : rocfft_transform_type_complex_inverse,
@@ -56,9 +57,44 @@ int sc_internal_z2z_plan(rocfft_plan* plan, int forward, size_t N, size_t batch,
         sc_set_error("rocfft_plan_create(Z2Z N=%zu batch=%zu) failed: %d", N, batch, (int)s);
         return SC_EFFT;
     }
-    *cached = g_z2z_n < 64;
-    if (*cached) g_z2z[g_z2z_n++] = ScZ2zEntry{forward, N, batch, *plan};
-    return SC_OK;                                    // (table full: the caller owns the plan and destroys it)
+    ++g_plans_created;
+    *cached = true;                                  // (always: the callers' "not cached -> destroy" branch is never taken)
+    g_z2z.push_back(ScZ2zEntry{forward, N, batch, *plan});
+    return SC_OK;
+}
+
+// The real-to-complex row plans of sc_fft_plan (the transform of window lengths no fused kernel has): a pool keyed by (length, rows,
+// precision).  A plan whose sc_fft_plan is destroyed goes back to the pool -- same hazard as above: never rocfft_plan_destroy -- and
+// the next sc_fft_plan of that geometry takes it instead of creating (and compiling) another: what the pool holds is bounded by the
+// DISTINCT geometries a process ever asks for, not by how often the host's plan cache evicts one (round 5 dropped the handle on
+// every eviction: an unbounded leak of twiddle tables and code).
+struct ScR2cEntry { int64_t N, rows; int f64; rocfft_plan plan; bool busy; };
+static std::vector<ScR2cEntry> g_r2c;
+static rocfft_plan r2c_pool_take(int64_t N, int64_t rows, bool f64) {
+    std::lock_guard<std::mutex> lock(g_z2z_mutex);
+    for (ScR2cEntry& e : g_r2c)
+        if (!e.busy && e.N == N && e.rows == rows && e.f64 == (f64 ? 1 : 0)) { e.busy = true; return e.plan; }
+    return nullptr;
+}
+static void r2c_pool_add(int64_t N, int64_t rows, bool f64, rocfft_plan plan) {
+    std::lock_guard<std::mutex> lock(g_z2z_mutex);
+    ++g_plans_created;
+    g_r2c.push_back(ScR2cEntry{N, rows, f64 ? 1 : 0, plan, true});
+}
+static void r2c_pool_release(rocfft_plan plan) {
+    if (!plan) return;
+    std::lock_guard<std::mutex> lock(g_z2z_mutex);
+    for (ScR2cEntry& e : g_r2c)
+        if (e.plan == plan) { e.busy = false; return; }
+}
+extern "C" int sc_debug_fft_plans(int64_t* n_created, int64_t* n_pooled, int64_t* n_idle) {
+    std::lock_guard<std::mutex> lock(g_z2z_mutex);
+    int64_t idle = 0;
+    for (const ScR2cEntry& e : g_r2c) idle += e.busy ? 0 : 1;
+    if (n_created) *n_created = g_plans_created;
+    if (n_pooled) *n_pooled = (int64_t)(g_r2c.size() + g_z2z.size());
+    if (n_idle) *n_idle = idle;
+    return SC_OK;
 }
 
 extern "C" int sc_abi_version(void) { return SC_ABI_VERSION; }
@@ -100,6 +136,7 @@ static int g_rocfft_ready = 0;
     } while (0)
 
 static int make_r2c_rows(rocfft_plan* plan, int64_t N, int64_t rows, bool f64) {
+    if ((*plan = r2c_pool_take(N, rows, f64)) != nullptr) return SC_OK;
     rocfft_plan_description desc = nullptr;
     SC_CHECK_FFT(rocfft_plan_description_create(&desc));
     size_t one[1] = {1};
@@ -114,8 +151,10 @@ static int make_r2c_rows(rocfft_plan* plan, int64_t N, int64_t rows, bool f64) {
     rocfft_plan_description_destroy(desc);
     if (s != rocfft_status_success) {
         sc_set_error("rocfft_plan_create(N=%lld, rows=%lld) failed: status %d", (long long)N, (long long)rows, (int)s);
+        *plan = nullptr;
         return SC_EFFT;
     }
+    r2c_pool_add(N, rows, f64, *plan);
     return SC_OK;
 }
 
@@ -246,11 +285,14 @@ extern "C" int sc_fft_execute_f64(sc_fft_plan* plan, const double* d_y, void* d_
 }
 
 // Releases what a plan owns in device memory (work buffer, transform scratch: up to tens of MB).  The rocFFT plan objects themselves
-// are RETIRED, not destroyed: destroying a plan whose kernels rocFFT compiled at run time unloads their code object, and a kernel of
-// this library launched for the first time right after that has run stale instructions there (see sc_internal_z2z_plan above:
-// "illegal shader instruction", one fresh process in five).  A retired plan keeps its twiddle tables and code (KBs to a few MB).
+// go back to the pool above, not to rocfft_plan_destroy: destroying a plan whose kernels rocFFT compiled at run time unloads their
+// code object, and a kernel of this library launched for the first time right after that has run stale instructions there (see
+// sc_internal_z2z_plan above: "illegal shader instruction", one fresh process in five).  A pooled plan keeps its twiddle tables and
+// code (KBs to a few MB) and serves the next sc_fft_plan of its geometry.
 extern "C" int sc_fft_plan_destroy(sc_fft_plan* plan) {
     if (!plan) return SC_OK;
+    r2c_pool_release(plan->plan);
+    r2c_pool_release(plan->tail_plan);
     if (plan->info) rocfft_execution_info_destroy(plan->info);
     if (plan->work) (void)hipFree(plan->work);
     if (plan->Z) (void)hipFree(plan->Z);

@@ -41,3 +41,38 @@ def test_granger_through_rocfft_then_a_first_launch_in_fresh_processes():
     for run in range(6):
         res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
         assert res.returncode == 0 and "fresh process ok" in res.stdout, (run, res.returncode, res.stderr[-800:])
+
+
+def test_evicting_a_hundred_fft_plans_creates_no_more_rocfft_plans_than_distinct_geometries():
+    """rocFFT plans are pooled by (length, rows, precision) and re-used, never destroyed (csrc/sc_api.hip: the stale-code hazard above):
+    a host whose plan cache evicts the same few geometries over and over -- 100 sc_fft_plan objects created and destroyed here, five
+    distinct lengths -- makes five rocFFT plans, not 100 (round 5 dropped the handle on every destroy: an unbounded leak), and the
+    transforms of a re-used plan are the same numbers."""
+    import numpy as np
+    import torch
+    from ctypes import byref, c_void_p
+    from spectral_connectivity_amd import _lib
+    _lib.require_gpu()
+    lib = _lib.load()
+    created0, pooled0, _ = _lib.fft_plan_counts()
+    lengths, rows = (77, 91, 119, 133, 143), 24         # (no fused kernel has these lengths: 7, 11, 13, 17, 19 among their factors)
+    rng = np.random.default_rng(0)
+    first = {}
+    for it in range(100):
+        N = lengths[it % len(lengths)]
+        h = c_void_p()
+        _lib.check(lib.sc_fft_plan_create(byref(h), N, rows), "sc_fft_plan_create")
+        y = torch.from_numpy(rng.standard_normal((rows, N)).astype(np.float32)).cuda() if it < len(lengths) else first[N][0]
+        X = torch.empty((N // 2 + 1, rows), dtype=torch.complex64, device="cuda")
+        _lib.check(lib.sc_fft_execute(h, y.data_ptr(), X.data_ptr(), None), "sc_fft_execute")
+        torch.cuda.synchronize()
+        if it < len(lengths):
+            ref = np.fft.rfft(y.cpu().numpy().astype(np.float64), axis=1).T
+            assert np.abs(X.cpu().numpy() - ref).max() < 2e-5 * np.abs(ref).max()
+            first[N] = (y, X.clone())
+        else:
+            assert torch.equal(torch.view_as_real(X), torch.view_as_real(first[N][1])), "a pooled plan gave other numbers"
+        lib.sc_fft_plan_destroy(h)
+    created, pooled, idle = _lib.fft_plan_counts()
+    assert created - created0 == len(lengths) and pooled - pooled0 == len(lengths), (created0, created, pooled0, pooled)
+    assert idle >= len(lengths)
