@@ -33,7 +33,12 @@ _binding.honour_gpu_switch()
 
 def __getattr__(name):
     if name in _EXPORTS:
-        value = getattr(importlib.import_module(_EXPORTS[name], __name__), name)
+        module = _EXPORTS[name]
+        if name == "Connectivity":
+            # two hosts of the same C ABI (SC_HIP_HOST=torch|numpy, _hosts.py): the torch-free one needs NumPy + SciPy only
+            from . import _hosts
+            module = ".numpy_api" if _hosts.kind() == "numpy" else module
+        value = getattr(importlib.import_module(module, __name__), name)
         globals()[name] = value
         return value
     try:                                   # submodules: spectral_connectivity_amd.transforms, .engine, ...

@@ -26,6 +26,16 @@ GRANGER_KEEP_OUTPUT = 1
 DETREND = {None: 0, "constant": 1, "c": 1, "linear": 2, "l": 2}
 MVAR_DTF, MVAR_DC, MVAR_PDC, MVAR_GPDC, MVAR_DDTF, MVAR_TRANSFER, MVAR_COEFFICIENTS, MVAR_NOISE_COVARIANCE = range(8)
 PLANE_CSM, PLANE_ABS_IM, PLANE_IM_SQ, PLANE_SIGN_IM, PLANE_UNIT = 0x01, 0x02, 0x04, 0x08, 0x10
+# axes of (window, trial, taper) an expectation type averages over (reference connectivity.py:67-75)
+EXPECTATION_AXES = {
+    "time": (0,),
+    "trials": (1,),
+    "tapers": (2,),
+    "time_trials": (0, 1),
+    "time_tapers": (0, 2),
+    "trials_tapers": (1, 2),
+    "time_trials_tapers": (0, 1, 2),
+}
 RECORD_F64 = 0x100          # OR-ed into `planes` when the records handed to a consumer hold doubles (float64 engine)
 (M_POWER, M_CSM, M_COHERENCY, M_COHERENCE_MAGNITUDE, M_COHERENCE_PHASE, M_IMAGINARY_COHERENCE,
  M_PLV, M_PLI, M_WPLI, M_DEBIASED_PLI2, M_DEBIASED_WPLI2, M_PPC, M_PLV_COMPLEX) = range(13)
@@ -176,11 +186,15 @@ def library_path():
     return os.environ.get("SC_HIP_LIB", _build.LIB)
 
 
-def load(torch_host=True):
+def load(torch_host=None):
     """Load (building in-tree if the sources are newer) and type libsc_hip.so.  Raises if impossible.
     ``torch_host``: the caller hands torch tensors' device pointers to the library, so torch's HIP runtime must be the
-    one the library binds to (torch imported first); numpy_host passes False and never imports torch."""
+    one the library binds to (torch imported first); numpy_host passes False and never imports torch.  None: whatever the host of
+    this process is (SC_HIP_HOST, _hosts.py)."""
     global _lib, _bound_with_torch
+    if torch_host is None:
+        from . import _hosts
+        torch_host = _hosts.kind() != "numpy"
     if _lib is not None:
         if torch_host and not _bound_with_torch:
             raise RuntimeError(
@@ -291,6 +305,15 @@ def require_gpu():
             f"{ENABLE_GPU_ENV}={os.environ.get(ENABLE_GPU_ENV)!r} selects the reference's NumPy backend, which "
             "spectral_connectivity_amd does not have: every computation here runs on the HIP engine. Unset the "
             "variable or set it to 'true' (or use the reference package for a CPU run).")
+    from . import _hosts
+    if _hosts.kind() == "numpy":
+        # the torch-free host: the library's own device count (the check numpy_host.NumpyHost makes)
+        n = c_int(0)
+        load(torch_host=False).sc_device_count(byref(n))
+        if n.value < 1:
+            raise RuntimeError("spectral_connectivity_amd: no ROCm GPU is visible (sc_device_count() = 0). "
+                               "This engine has no CPU fallback; run on an MI355X host.")
+        return
     import torch
     if not torch.cuda.is_available():
         raise RuntimeError(

@@ -21,7 +21,7 @@ from logging import getLogger
 import numpy as np
 
 from . import _lib
-from .engine import EXPECTATION_AXES
+from ._lib import EXPECTATION_AXES
 
 # scale of the Tikhonov terms in the MVAR quantities (reference connectivity.py: same name and value; applied on the
 # device in sc_mvar.hip / sc_wilson.hip)
@@ -65,13 +65,13 @@ class Connectivity:
     def __init__(self, fourier_coefficients, expectation_type="trials_tapers", frequencies=None,
                  time=None, blocks=None, dtype=np.complex128):
         from . import options
-        from .engine import DeviceSpectra
         self._precision = options.engine_precision(dtype)
         self._spectra = None
         self._pending = None
+        self._deferred_source = None      # (Multitaper, precision) whose transform left checks pending: _settle
         self._host_coefficients = None
         self._multitaper = None
-        if isinstance(fourier_coefficients, DeviceSpectra):
+        if getattr(fourier_coefficients, "is_device_spectra", False):
             self._spectra = fourier_coefficients
         elif isinstance(fourier_coefficients, _PendingSpectra):
             self._pending = fourier_coefficients
@@ -186,15 +186,35 @@ class Connectivity:
                         reduce_trial=int(1 in axes), reduce_taper=int(2 in axes), reserved=0)
         return bool(_lib.load().sc_fused2_supported(byref(d), planes))
 
-    def _device(self, planes_hint=None):
+    def _settle(self):
+        """Settle what the transform left pending (Multitaper.settle_device_checks: the deferred NaN / infinity warning, the planes
+        format's quality check) -- called where a result is downloaded anyway.  False: the spectra were replaced (complex64 instead
+        of the planes format) and everything computed from the old ones is dropped; the caller computes again."""
+        src = self._deferred_source
+        if src is None:
+            return True
+        self._deferred_source = None
+        m, precision = src
+        if m.settle_device_checks(precision):
+            return True
+        self._spectra = m.device_spectra(precision=precision)
+        self._accum_cache.clear()
+        return False
+
+    def _device(self, planes_hint=None, defer_checks=False):
         """The device spectra; ``planes_hint``: the accumulator families about to be requested.  A pending transform writes the
         planes format when the SHAPE qualifies for it and the hint is one of the families its kernels serve -- whichever
-        (_lib.planes_format_applies) -- and this object's expectation type can run on it."""
+        (_lib.planes_format_applies) -- and this object's expectation type can run on it.  ``defer_checks``: the caller downloads a
+        result next and calls _settle() there (and computes again if that says so); every other caller gets settled spectra."""
         if self._spectra is None and self._pending is not None:
             if planes_hint is not None and not (planes_hint in _lib.PLANES_FORMAT_FAMILIES and self._planes_request_ok(planes_hint)):
                 planes_hint = None
-            self._spectra = self._pending.multitaper.device_spectra(precision=self._pending.precision, planes_hint=planes_hint)
+            m, precision = self._pending.multitaper, self._pending.precision
+            self._spectra = m.device_spectra(precision=precision, planes_hint=planes_hint, defer_checks=True)
+            self._deferred_source = (m, precision)
             self._pending = None
+        if not defer_checks and self._deferred_source is not None:
+            self._settle()
         if self._spectra is None:
             from . import engine
             _lib.require_gpu()
@@ -205,13 +225,13 @@ class Connectivity:
     def _n_freq(self):
         return self._shape5[3] // 2 + 1
 
-    def _accumulators(self, planes):
+    def _accumulators(self, planes, defer_checks=False):
         """Accumulator record containing at least ``planes`` (cached)."""
         from . import engine
         for have, rec in self._accum_cache.items():
             if isinstance(have, int) and have & planes == planes:
                 return have, rec
-        sp = self._device(planes_hint=planes)
+        sp = self._device(planes_hint=planes, defer_checks=defer_checks)
         have = None
         single = self._reduce_over_ranks.__func__ is Connectivity._reduce_over_ranks
         if sp.f64 and single:
@@ -265,11 +285,16 @@ class Connectivity:
 
     def _measure(self, which):
         from . import engine
-        have, (accum, n_obs) = self._accumulators(_lib.MEASURE_PLANES[which])
         C = self._shape5[4]
-        # the epilogue writes the dtype the reference returns (_wide_output) itself: no widening pass on the way out
-        host = engine.to_host(engine.measure(accum, C, have, self._n_observations_total(n_obs), which,
-                                             wide=self._wide_output(which)))
+        for _ in range(2):
+            # (a fresh transform's two small read-backs are settled with this download, not before stage B: _settle; in the rare
+            #  case the planes format is withdrawn there, the measure is computed once more from the complex64 spectra)
+            have, (accum, n_obs) = self._accumulators(_lib.MEASURE_PLANES[which], defer_checks=True)
+            # the epilogue writes the dtype the reference returns (_wide_output) itself: no widening pass on the way out
+            host = engine.to_host(engine.measure(accum, C, have, self._n_observations_total(n_obs), which,
+                                                 wide=self._wide_output(which)))
+            if self._settle():
+                break
         tail = (C,) if which == _lib.M_POWER else (C, C)
         return host.reshape(self._kept_shape() + (self._n_freq,) + tail)
 

@@ -38,6 +38,7 @@ struct LongArgs {
     float2* X;             // [F][W][R][K][C]
     int R, C, L, step, W, K, detrend;
     int n_items;           // (window, trial) groups rounded up to a multiple of 8, times channel tiles
+    int g_off, g_end;      // this launch takes the (window, trial) groups g_off ... g_end - 1 (long windows are launched in slices)
     int vec;               // rows can be read in 16-byte pieces (C % 4 == 0, x 16-byte aligned)
     // planes-format output (sc_fused2.hip: two f16 pieces per real, x * scale[c] = h + m, rows [f][w][r][k] of row_bytes; a row is
     // 256-byte tiles of 32 channels: planes Re h, Re m, Im h, Im m of 64 bytes each): when P is set the spectra go there INSTEAD of X
@@ -117,8 +118,8 @@ __global__ void __launch_bounds__(2 * HT, HT == 512 ? 1 : 4) mtfft_long_kernel(L
     const int n_ct = sup ? (C + SUP * CT - 1) / (SUP * CT) * SUP : (C + CT - 1) / CT;
     int ch0[2], w, r;                                 // first channel of either half
     {
-        const int m = blockIdx.x, xcd = m & 7, j = m >> 3, g = (j / n_ct) * 8 + xcd;
-        if (g >= p.W * p.R) return;
+        const int m = blockIdx.x, xcd = m & 7, j = m >> 3, g = p.g_off + (j / n_ct) * 8 + xcd;
+        if (g >= p.g_end) return;
         const int tile = j % n_ct;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
@@ -611,13 +612,30 @@ static int launch_long_(LongArgs a, hipStream_t st) {
     SC_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     constexpr int SUP = 2 * NF >= 16 ? 1 : 16 / (2 * NF);      // = the kernel's
     const int64_t n_ct = (a.C > 16 && SUP > 1 && !(a.dbg & 32)) ? (a.C + SUP * CT - 1) / (SUP * CT) * SUP : (a.C + CT - 1) / CT;
-    const int64_t groups8 = ((int64_t)a.W * a.R + 7) / 8 * 8;
-    if (groups8 * n_ct >= ((int64_t)1 << 31)) {
-        sc_set_error("multitaper FFT (N=%d): too many windows x trials for one launch", N);
-        return SC_EINVAL;
+    // Slices.  Where a half stores 32- / 64-byte pieces (N >= 2048) a 128-byte line is completed in the L2 by SUP workgroups that were
+    // dispatched back to back; over the dispatch rounds of a long launch they drift apart (compute units free up one by one), the
+    // pieces leave the L2 unmerged and the store stream falls from 2.8 to 2.0 TB/s (N = 4096: 3.7 GB of spectra in 16 rounds 2.73-2.81
+    // TB/s, 11 GB in 47 rounds 1.96 whatever the number of windows: profiles/r06_stage_a_volume.txt).  A launch boundary puts the
+    // partners back in step: launches of at most SLICE_ROUNDS dispatch rounds each (SC_MTFFT_SLICE overrides; 0 = one launch).
+    const int64_t groups = (int64_t)a.W * a.R;
+    int64_t slice_groups = groups;
+    {
+        const char* e = sc_switch(SC_SW_MTFFT_SLICE);
+        const int64_t rounds = e ? atoll(e) : (SUP > 1 ? 12 : 0);
+        if (rounds > 0) slice_groups = (rounds * 256 / n_ct + 7) / 8 * 8;
+        if (slice_groups < 8) slice_groups = 8;
     }
-    a.n_items = (int)(groups8 * n_ct);
-    hipLaunchKernelGGL(k, dim3((unsigned)a.n_items), dim3(2 * HT), lds, st, a);
+    for (int64_t g0 = 0; g0 < groups; g0 += slice_groups) {
+        const int64_t g1 = g0 + slice_groups < groups ? g0 + slice_groups : groups;
+        const int64_t groups8 = (g1 - g0 + 7) / 8 * 8;
+        if (groups8 * n_ct >= ((int64_t)1 << 31)) {
+            sc_set_error("multitaper FFT (N=%d): too many windows x trials for one launch", N);
+            return SC_EINVAL;
+        }
+        a.n_items = (int)(groups8 * n_ct);
+        a.g_off = (int)g0; a.g_end = (int)g1;
+        hipLaunchKernelGGL(k, dim3((unsigned)a.n_items), dim3(2 * HT), lds, st, a);
+    }
     SC_CHECK_HIP(hipGetLastError());
     return SC_OK;
 }

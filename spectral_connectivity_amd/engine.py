@@ -14,15 +14,7 @@ from . import _lib
 from ._lib import SpectraDesc
 
 # connectivity.py:67-75 of the reference: which of (window, trial, taper) are averaged
-EXPECTATION_AXES = {
-    "time": (0,),
-    "trials": (1,),
-    "tapers": (2,),
-    "time_trials": (0, 1),
-    "time_tapers": (0, 2),
-    "trials_tapers": (1, 2),
-    "time_trials_tapers": (0, 1, 2),
-}
+EXPECTATION_AXES = _lib.EXPECTATION_AXES
 
 import collections
 
@@ -101,6 +93,8 @@ class DeviceSpectra:
     per-channel powers of two (then their reciprocals).  Stage A can write it instead of complex64 (same volume); the
     CSM / |Im s| accumulation then runs on it directly, and ``X`` is decoded from it on first use by anything else.
     """
+
+    is_device_spectra = True        # (what Connectivity tests for: the torch-free host has a class of its own with the same mark)
 
     def __init__(self, X, dims, strides, n_fft, real_input, C_alloc=None, P=None, scale=None):
         self._X = X

@@ -27,8 +27,7 @@ import numpy as np
 from . import _lib
 from ._lib import SpectraDesc
 
-EXPECTATION_AXES = {"time": (0,), "trials": (1,), "tapers": (2,), "time_trials": (0, 1), "time_tapers": (0, 2),
-                    "trials_tapers": (1, 2), "time_trials_tapers": (0, 1, 2)}
+EXPECTATION_AXES = _lib.EXPECTATION_AXES
 MEASURES = {
     "power": _lib.M_POWER, "coherency": _lib.M_COHERENCY, "coherence_magnitude": _lib.M_COHERENCE_MAGNITUDE,
     "coherence_phase": _lib.M_COHERENCE_PHASE, "imaginary_coherence": _lib.M_IMAGINARY_COHERENCE,
@@ -131,6 +130,29 @@ class _PinnedOwner:
                 self.lib.sc_host_free(c_void_p(self.address))
         except Exception:
             pass
+
+
+class NpSpectra(dict):
+    """Device spectra of this host: a dict (X / P / scale: DeviceBuffer or None; F, W, R, K, C, C_alloc, N; f64; real_input;
+    strides = (frequency, window, trial, taper) in elements or None for the dense [F][W][R][K][C_alloc] layout) with attribute
+    access and the mark Connectivity looks for."""
+    is_device_spectra = True
+
+    def __getattr__(self, name):
+        try:
+            return self[name]
+        except KeyError:
+            raise AttributeError(name) from None
+
+    @property
+    def n_fft(self):
+        return self["N"]
+
+    def free(self):
+        for key in ("X", "P", "scale"):
+            if self.get(key) is not None:
+                self[key].free()
+                self[key] = None
 
 
 class NumpyHost:
@@ -271,7 +293,8 @@ class NumpyHost:
             if ratio >= _lib.PLANES_MIN_TYPICAL:
                 for b in (x, h):
                     b.free()
-                return dict(X=None, P=P, scale=scale, F=F, W=W, R=R, K=K, C=C, C_alloc=C_alloc, N=N)
+                return NpSpectra(X=None, P=P, scale=scale, F=F, W=W, R=R, K=K, C=C, C_alloc=C_alloc, N=N, f64=False, real_input=True,
+                                 strides=None)
             P.free(); scale.free()
         X = self.alloc(F * W * R * K * C_alloc * 8)
         if fused:
@@ -292,25 +315,97 @@ class NumpyHost:
             y.free()
         x.free()
         h.free()
-        return dict(X=X, F=F, W=W, R=R, K=K, C=C, C_alloc=C_alloc, N=N)
+        return NpSpectra(X=X, P=None, scale=None, F=F, W=W, R=R, K=K, C=C, C_alloc=C_alloc, N=N, f64=False, real_input=True, strides=None)
+
+    def spectra_f64(self, multitaper):
+        """Stage A of the float64 engine (the reference's default dtype): float64 windows, tapers and transform, complex128
+        spectra X[F][W][R][K][C] -- one fused kernel (sc_multitaper_fft_f64) for the lengths it has, sc_taper_windows_f64 +
+        double-precision rocFFT otherwise (engine.multitaper_spectra_f64 of the PyTorch host)."""
+        import warnings
+        m, lib = multitaper, self.lib
+        if np.iscomplexobj(m.time_series):
+            raise TypeError("complex-valued time series: use the PyTorch host (SC_HIP_HOST=torch)")
+        if m.detrend_type not in _lib.DETREND:
+            raise ValueError(f"Invalid trend type '{m.detrend_type}' is not supported.\n"
+                             "Valid options are 'linear'/'l', 'constant'/'c' or None.")
+        ts = np.ascontiguousarray(np.asarray(m.time_series), dtype=np.float64)
+        T, R, C = ts.shape
+        L, step, N, W = m.n_time_samples_per_window, m.n_time_samples_per_step, m.n_fft_samples, m.n_time_windows
+        tapers = np.asarray(m.tapers, dtype=np.float64)
+        K = tapers.shape[1]
+        x = self.upload(ts)
+        h = self.upload(np.ascontiguousarray(tapers.T / m.sampling_frequency, dtype=np.float64))
+        if getattr(m, "_finite_checked", True) is False:
+            m._finite_checked = True
+            if self.has_nonfinite(x, T * R * C, f64=True):
+                warnings.warn("Input time_series contains NaN or infinite values.\n"
+                              "This will produce invalid spectral estimates.", UserWarning, stacklevel=3)
+        F = N // 2 + 1
+        detrend = _lib.DETREND[m.detrend_type]
+        X = self.alloc(F * W * R * K * C * 16)
+        if bool(lib.sc_multitaper_fft_f64_supported(L, N)) and R <= 65535 and W <= 65535:
+            _lib.check(lib.sc_multitaper_fft_f64(x.ptr, T, R, C, L, step, W, N, h.ptr, K, detrend, X.ptr, self.stream),
+                       "sc_multitaper_fft_f64")
+        else:
+            batch = W * R * K * C
+            y = self.alloc(batch * N * 8)
+            _lib.check(lib.sc_taper_windows_f64(x.ptr, T, R, C, L, step, W, N, h.ptr, K, detrend, y.ptr, self.stream),
+                       "sc_taper_windows_f64")
+            plan = c_void_p()
+            _lib.check(lib.sc_fft_plan_create_f64(byref(plan), N, batch), "sc_fft_plan_create_f64")
+            try:
+                _lib.check(lib.sc_fft_execute_f64(plan, y.ptr, X.ptr, self.stream), "sc_fft_execute_f64")
+                self.synchronize()
+            finally:
+                lib.sc_fft_plan_destroy(plan)
+            y.free()
+        x.free()
+        h.free()
+        return NpSpectra(X=X, P=None, scale=None, F=F, W=W, R=R, K=K, C=C, C_alloc=C, N=N, f64=True, real_input=True, strides=None)
+
+    def upload_coefficients(self, coef, f64=False):
+        """Reference-layout (W, R, K, N, C) complex coefficients -> device spectra that hold all N bins as given
+        (engine.upload_coefficients of the PyTorch host: same strides, the zero pad channel of an odd count in the float32 engine)."""
+        coef = np.asarray(coef)
+        W, R, K, N, C = coef.shape
+        if f64:
+            X = self.upload(np.ascontiguousarray(coef, dtype=np.complex128))
+            return NpSpectra(X=X, P=None, scale=None, F=N, W=W, R=R, K=K, C=C, C_alloc=C, N=N, f64=True, real_input=False,
+                             strides=(C, R * K * N * C, K * N * C, N * C))
+        coef = np.ascontiguousarray(coef, dtype=np.complex64)
+        if C % 2 and C + 1 <= 256:
+            coef = np.concatenate([coef, np.zeros(coef.shape[:-1] + (1,), dtype=np.complex64)], axis=-1)
+        Ca = coef.shape[-1]
+        X = self.upload(coef)
+        return NpSpectra(X=X, P=None, scale=None, F=N, W=W, R=R, K=K, C=C, C_alloc=Ca, N=N, f64=False, real_input=False,
+                         strides=(Ca, R * K * N * Ca, K * N * Ca, N * Ca))
 
     # ---- stages B and C -----------------------------------------------------------------------------------------
     @staticmethod
-    def _desc(sp, expectation_type, padded):
+    def _desc(sp, expectation_type, padded, n_freq=None):
         axes = EXPECTATION_AXES[expectation_type]
         W, R, K, Ca = sp["W"], sp["R"], sp["K"], sp["C_alloc"]
-        return SpectraDesc(n_freq=sp["F"], n_windows=W, n_trials=R, n_tapers=K, n_signals=Ca if padded else sp["C"],
-                           stride_freq=W * R * K * Ca, stride_window=R * K * Ca, stride_trial=K * Ca, stride_taper=Ca,
+        sF, sW, sR, sK = sp.get("strides") or (W * R * K * Ca, R * K * Ca, K * Ca, Ca)
+        return SpectraDesc(n_freq=sp["F"] if n_freq is None else n_freq, n_windows=W, n_trials=R, n_tapers=K,
+                           n_signals=Ca if padded else sp["C"], stride_freq=sF, stride_window=sW, stride_trial=sR, stride_taper=sK,
                            reduce_window=int(0 in axes), reduce_trial=int(1 in axes), reduce_taper=int(2 in axes),
                            reserved=0)
 
-    def accumulate(self, sp, expectation_type, planes):
-        """Stage B: un-normalised records [n_bins][floats_per_bin] float32 on the device."""
+    def accumulate(self, sp, expectation_type, planes, n_freq=None):
+        """Stage B: un-normalised records [n_bins][floats_per_bin] on the device -- float32, or float64 from complex128 spectra
+        (the float64 engine: sc_accumulate_f64).  ``n_freq``: accumulate the first n_freq bins only."""
         lib = self.lib
-        d_real, d_pad = self._desc(sp, expectation_type, False), self._desc(sp, expectation_type, True)
+        if sp["C"] > 256:
+            raise ValueError(f"one launch of the stage-B kernels takes n_signals <= 256 (got {sp['C']}): Connectivity of this host "
+                             "tiles more signals into channel blocks (numpy_api.Connectivity); NumpyHost.accumulate does not")
+        d_real, d_pad = self._desc(sp, expectation_type, False, n_freq), self._desc(sp, expectation_type, True, n_freq)
         n_bins, fpb, n_groups, n_obs = c_int64(), c_int64(), c_int64(), c_int64()
         _lib.check(lib.sc_accum_layout(byref(d_real), planes, byref(n_bins), byref(fpb), byref(n_groups), byref(n_obs)),
                    "sc_accum_layout")
+        if sp.get("f64"):
+            accum = self.alloc(n_bins.value * fpb.value * 8)
+            _lib.check(lib.sc_accumulate_f64(sp["X"].ptr, byref(d_real), planes, planes, accum.ptr, self.stream), "sc_accumulate_f64")
+            return accum, n_bins.value, n_obs.value
         accum = self.alloc(n_bins.value * fpb.value * 4)
         if sp.get("P") is not None:
             # planes format (the families planes_format_applies admits are exactly what sc_fused2.hip accumulates)

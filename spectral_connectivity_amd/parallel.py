@@ -52,18 +52,17 @@ def exchange_algorithm():
     mode = os.environ.get("SC_EXCHANGE", "direct")
     if mode not in ("direct", "ring", "library"):
         raise ValueError(f"SC_EXCHANGE={mode!r}: expected 'direct', 'ring' or 'library'")
-    if mode in ("direct", "library") and _direct_failed:
-        return "ring"              # all_to_all_single raised on this backend once: the library reduce-scatter from then on
-    return mode
+    return mode                    # (a group whose ranks AGREED that the direct form fails takes the ring: _ring_agreed, per group)
 
 
-_direct_failed = []                # [message] once the direct exchange has failed in this process (exchange_note reports it)
+_direct_failed = []                # [message] of every failure of the direct exchange in this process (exchange_note reports the first)
+_ring_agreed = set()               # (process group, algorithm) keys whose ranks have agreed to take the library reduce-scatter instead
 
 
 def exchange_note():
     """What the bench line / logs should say about the exchange that really ran."""
-    if _direct_failed:
-        return "ring: reduce_scatter_tensor (the direct all_to_all_single exchange raised: " + _direct_failed[0] + ")"
+    if _ring_agreed:
+        return "ring: reduce_scatter_tensor (the direct all_to_all_single exchange raised: " + (_direct_failed[0] if _direct_failed else "?") + ")"
     if exchange_algorithm() == "library":
         return ("library: sc_comm_exchange_blocks_f32 (grouped ncclSend / ncclRecv of the 1/N bin blocks through the C ABI's own "
                 "communicator), summed in rank order inside the epilogue kernel")
@@ -163,6 +162,8 @@ def _agreed_direct_exchange(accum, world, per, fpb, group):
     library = exchange_algorithm() == "library" and accum.is_cuda and accum.dtype == torch.float32
     fn = _library_blocks if library else _direct_blocks
     key = (id(group) if group is not None else 0, library)
+    if key in _ring_agreed:            # decided for this group, on every rank at the same exchange: no collective here
+        return None
     if key in _direct_agreed:
         blocks = fn(accum, world, per, fpb, group)
         if blocks is None:
@@ -174,8 +175,9 @@ def _agreed_direct_exchange(accum, world, per, fpb, group):
         flag = flag.to(accum.device)
     dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
     if int(flag.item()):
-        if not _direct_failed:
+        if blocks is not None or not _direct_failed:
             _direct_failed.append("the direct exchange raised on another rank")
+        _ring_agreed.add(key)          # every rank of the group passes through here at this exchange: the same decision everywhere
         return None
     _direct_agreed.add(key)
     return blocks

@@ -425,6 +425,7 @@ class Multitaper:
         self._n_time_samples_per_window = n_time_samples_per_window
         self._n_samples_per_time_step = n_time_samples_per_step
         self._device_spectra = None
+        self._deferred_checks = None      # {precision: (flag, quality, taper norm, redo)}: settle_device_checks
 
     def __repr__(self):
         return ("Multitaper("
@@ -568,8 +569,40 @@ class Multitaper:
             raise ValueError(f"Invalid trend type '{self.detrend_type}' is not supported.\n"
                              "Valid options are 'linear'/'l', 'constant'/'c' or None.")
 
-    def device_spectra(self, device=None, precision=None, planes_hint=None):
+    def settle_device_checks(self, precision):
+        """The read-backs a transform with ``defer_checks=True`` left pending -- the NaN / infinity flag of the constructor's scan
+        (raised here as the constructor's warning) and the quality statistic of the planes format -- in ONE small device-to-host copy,
+        at a moment the caller synchronises anyway (the first download of a result).  Returns True when the spectra of ``precision``
+        stand; False when the planes format failed its check: the transform has then run again into complex64 (the cached spectra
+        are the new ones) and whatever the caller computed from the old ones must be computed again."""
+        pend = (self._deferred_checks or {}).pop(precision, None)
+        if pend is None:
+            return True
+        import torch
+        from . import _lib
+        flag, quality, l2_min, redo = pend
+        vals = torch.stack([t.reshape(()).to(torch.float32) for t in (flag, quality) if t is not None]).cpu().tolist()
+        if flag is not None and vals[0] != 0.0:
+            warnings.warn(_NONFINITE_WARNING, UserWarning, stacklevel=4)
+        if quality is not None:
+            typical = vals[-1] * l2_min
+            if not typical >= _lib.PLANES_MIN_TYPICAL:
+                self.device_format_note = (
+                    f"the typical coefficient of a channel would be {typical:.3g} in the scaled units of the two-piece f16 "
+                    f"format (limit {_lib.PLANES_MIN_TYPICAL:g}: a sample far outside the channel's usual range): "
+                    "spectra kept as complex64")
+                logger.warning("spectral_connectivity_amd: " + self.device_format_note)
+                self._device_spectra[precision] = redo()
+                return False
+        return True
+
+    def device_spectra(self, device=None, precision=None, planes_hint=None, defer_checks=False):
         """Run stage A on the GPU; returns (and caches, per precision) the HBM-resident one-sided spectra.
+
+        ``defer_checks`` (float32 engine): the two 4-byte read-backs of a fresh object -- the NaN / infinity flag of the deferred
+        constructor scan and the planes format's quality statistic -- are not waited for here (each idled the GPU long enough for
+        the clock to fall back before stage B); the caller settles them with settle_device_checks() at its first download and
+        computes again in the rare case the format is withdrawn (Connectivity._measure does).
 
         ``precision``: "float32" -- the fused f32 transform of the headline path (complex64 spectra) -- or "float64" --
         the reference's own arithmetic (float64 windows, tapers and FFT; complex128 spectra).  None: what
@@ -581,6 +614,11 @@ class Multitaper:
             precision = options.engine_precision(None)
         if self._device_spectra is None:
             self._device_spectra = {}
+        from . import _hosts
+        if precision not in self._device_spectra and _hosts.kind() == "numpy":
+            from . import numpy_api                      # the torch-free host (SC_HIP_HOST=numpy): same library, NumPy buffers
+            self.check_device_path()
+            self._device_spectra[precision] = numpy_api.multitaper_spectra(self, precision, planes_hint)
         if precision not in self._device_spectra:
             import torch
             from . import _lib, engine
@@ -595,6 +633,8 @@ class Multitaper:
             dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
             tapers = np.asarray(self.tapers, dtype=np.float64)             # (L, K), * sqrt(fs)
             logger.info(self)
+            pending_flag = [None]
+
             def device_scan(t):
                 # the constructor's NaN / infinity scan, deferred to the uploaded copy (see __init__)
                 if self._finite_checked:
@@ -604,7 +644,9 @@ class Multitaper:
                 fn = _lib.load().sc_nonfinite_f64 if t.dtype == torch.float64 else _lib.load().sc_nonfinite_f32
                 _lib.check(fn(t.data_ptr(), t.numel(), flag.data_ptr(), torch.cuda.current_stream().cuda_stream),
                            "sc_nonfinite")
-                if int(flag.item()):
+                if defer_checks and precision != "float64":
+                    pending_flag[0] = flag                 # read with the first download (settle_device_checks)
+                elif int(flag.item()):
                     warnings.warn(_NONFINITE_WARNING, UserWarning, stacklevel=4)
 
             on_device = self.time_series.tensor if isinstance(self.time_series, _DeviceSeries) else None
@@ -653,7 +695,18 @@ class Multitaper:
                     self.n_fft_samples, self.n_time_windows, self.detrend_type, n_signals=n_signals,
                     planes_hint=planes_hint)
                 self.device_format_note = None
-                if sp.P is not None and sp.quality is not None:
+
+                def redo_complex64():
+                    return engine.multitaper_spectra(
+                        x, h, self.n_time_samples_per_window, self.n_time_samples_per_step,
+                        self.n_fft_samples, self.n_time_windows, self.detrend_type, n_signals=n_signals, planes_hint=None)
+                if defer_checks and (pending_flag[0] is not None or (sp.P is not None and sp.quality is not None)):
+                    if self._deferred_checks is None:
+                        self._deferred_checks = {}
+                    checked = sp.P is not None and sp.quality is not None
+                    self._deferred_checks[precision] = (pending_flag[0], sp.quality if checked else None,
+                                                        sp.taper_l2_min if checked else None, redo_complex64)
+                elif sp.P is not None and sp.quality is not None:
                     # The planes format takes ONE scale per channel from the range of its samples: a channel with an artefact
                     # hundreds of times its typical amplitude would hold the quiet windows' coefficients near the f16
                     # subnormals.  The scale pass measured the typical magnitude on the way; below the limit the transform
@@ -666,10 +719,10 @@ class Multitaper:
                             "spectra kept as complex64")
                         logger.warning("spectral_connectivity_amd: " + self.device_format_note)
                         del sp
-                        sp = engine.multitaper_spectra(
-                            x, h, self.n_time_samples_per_window, self.n_time_samples_per_step,
-                            self.n_fft_samples, self.n_time_windows, self.detrend_type, n_signals=n_signals, planes_hint=None)
+                        sp = redo_complex64()
                 self._device_spectra[precision] = sp
+        if not defer_checks and self._deferred_checks:
+            self.settle_device_checks(precision)          # (a caller that cannot compute again: settled before it sees the spectra)
         return self._device_spectra[precision]
 
     def _complex_device_spectra(self, device, precision):
@@ -714,6 +767,10 @@ class Multitaper:
         (float32 if ``options.precision == "float32"``) as a one-sided real transform; the negative-frequency half is
         the conjugate mirror (real input) and is filled on the host only for this export.
         """
+        from . import _hosts
+        if _hosts.kind() == "numpy":
+            from . import numpy_api
+            return numpy_api.fft(self)
         sp = self.device_spectra()
         one = sp.coefficients().cpu().numpy().astype(np.complex128, copy=False)          # (F, W, R, K, C)
         one = np.moveaxis(one, 0, 3)                            # (W, R, K, F, C)

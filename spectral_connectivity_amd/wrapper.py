@@ -13,8 +13,23 @@ from logging import getLogger
 
 import numpy as np
 
-from .connectivity import Connectivity
+from . import _hosts
+from .connectivity import Connectivity as _BaseConnectivity
 from .transforms import Multitaper
+
+
+class _ConnectivityOfTheHost:
+    """``Connectivity`` of the host this process uses (SC_HIP_HOST, _hosts.py): the torch-free class needs no torch import."""
+
+    def __getattr__(self, name):
+        if _hosts.kind() == "numpy":
+            from .numpy_api import Connectivity as cls
+        else:
+            cls = _BaseConnectivity
+        return getattr(cls, name)
+
+
+Connectivity = _ConnectivityOfTheHost()
 
 logger = getLogger(__name__)
 
@@ -91,7 +106,7 @@ def multitaper_connectivity(time_series, sampling_frequency, time_window_duratio
     connectivity_kwargs = connectivity_kwargs or {}
     single = isinstance(method, str)
     if method is None:
-        methods = [name for name, _ in inspect.getmembers(Connectivity, predicate=inspect.isfunction)
+        methods = [name for name, _ in inspect.getmembers(_BaseConnectivity, predicate=inspect.isfunction)
                    if not name.startswith("_") and name not in _NOT_IN_DATASET]
     else:
         methods = [method] if single else list(method)

@@ -98,6 +98,29 @@ def granger_close(got, ref, tol, what="granger"):
 
 
 
+def device_record(c, expectation_type, planes):
+    """The accumulator record of ``planes`` a Connectivity object's device spectra give, as a NumPy array -- on whichever host the
+    process runs (PyTorch: engine.accumulate; torch-free: the object's own record, downloaded)."""
+    from spectral_connectivity_amd import _hosts
+    if _hosts.kind() == "numpy":
+        from spectral_connectivity_amd import numpy_api
+        assert c.expectation_type == expectation_type
+        _, (rec, _) = c._accumulators(planes)
+        return np.array(numpy_api.host().download(rec.buf, rec.shape, np.float64 if rec.f64 else np.float32))
+    import torch
+    from spectral_connectivity_amd import engine
+    accum, _ = engine.accumulate(c._device(), expectation_type, planes, n_freq=c._n_freq)
+    torch.cuda.synchronize()
+    return accum.cpu().numpy()
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """SC_HIP_HOST=numpy: the whole session must have run without torch (the reference depends on NumPy + SciPy only)."""
+    if os.environ.get("SC_HIP_HOST") == "numpy" and "torch" in sys.modules:
+        print("\nERROR: SC_HIP_HOST=numpy but torch was imported during the session", file=sys.stderr)
+        session.exitstatus = 1
+
+
 def unpack_record_planes(accum, C):
     """Accumulator records [n_bins, n_planes * n_tiles * 256] (include/sc_hip.h: upper-triangular 16 x 16 channel tiles,
     tile index = bi NB - bi (bi - 1) / 2 + (bj - bi)) -> [n_bins, n_planes, C, C] float64, NaN where no tile holds the

@@ -49,10 +49,15 @@ def close32(a, b, rtol=RTOL, atol_scale=ATOL_SCALE, what=""):
 
 @pytest.fixture(scope="module")
 def sc():
+    import spectral_connectivity_amd as pkg
+    from spectral_connectivity_amd import _hosts, _lib
+    if _hosts.kind() == "numpy":
+        # the torch-free host (SC_HIP_HOST=numpy; tests/test_gpu_numpy_host_suite.py runs this module that way in a process of its
+        # own): torch is never imported, conftest.pytest_sessionfinish checks that it was not
+        _lib.require_gpu()
+        return pkg
     import torch
     assert torch.cuda.is_available(), "gpu tests need a ROCm device"
-    import spectral_connectivity_amd as pkg
-    from spectral_connectivity_amd import _lib
     _lib.load()
     return pkg
 
@@ -108,15 +113,11 @@ def test_f3_every_measure_every_expectation(sc, golden, et):
             # differences whose conditioning is unbounded.  Compared without any conditioning allowance: the three SUMS
             # the device accumulated, straight from its records, against the oracle's (each at the plain tolerance), and
             # the measure against the reference's formula evaluated on those same device sums (the fp64 epilogue: 1e-9).
-            import torch
-            from conftest import unpack_record_planes
-            from spectral_connectivity_amd import _lib, engine
-            sp = c._device()
+            from conftest import device_record, unpack_record_planes
+            from spectral_connectivity_amd import _lib
             planes = _lib.PLANE_CSM | _lib.PLANE_ABS_IM | _lib.PLANE_IM_SQ
-            accum, n_obs = engine.accumulate(sp, et, planes, n_freq=c._n_freq)
-            torch.cuda.synchronize()
             C = g["x"].shape[2]
-            dev = unpack_record_planes(accum.cpu().numpy(), C).reshape(ref.shape[:-3] + (ref.shape[-3], 4, C, C))
+            dev = unpack_record_planes(device_record(c, et, planes), C).reshape(ref.shape[:-3] + (ref.shape[-3], 4, C, C))
             d_im, d_abs, d_sq = (np.moveaxis(dev, -3, 0)[k] for k in (1, 2, 3))
             coef, _ = so.multitaper_fft(np.asarray(g["x"], dtype=np.float64), fs=float(g["fs"]), NW=float(g["NW"]),
                                         n_time_samples_per_window=int(g["L"]), n_time_samples_per_step=int(g["step"]))
