@@ -612,16 +612,18 @@ static int launch_long_(LongArgs a, hipStream_t st) {
     SC_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     constexpr int SUP = 2 * NF >= 16 ? 1 : 16 / (2 * NF);      // = the kernel's
     const int64_t n_ct = (a.C > 16 && SUP > 1 && !(a.dbg & 32)) ? (a.C + SUP * CT - 1) / (SUP * CT) * SUP : (a.C + CT - 1) / CT;
-    // Slices.  Where a half stores 32- / 64-byte pieces (N >= 2048) a 128-byte line is completed in the L2 by SUP workgroups that were
-    // dispatched back to back; over the dispatch rounds of a long launch they drift apart (compute units free up one by one), the
-    // pieces leave the L2 unmerged and the store stream falls from 2.8 to 2.0 TB/s (N = 4096: 3.7 GB of spectra in 16 rounds 2.73-2.81
-    // TB/s, 11 GB in 47 rounds 1.96 whatever the number of windows: profiles/r06_stage_a_volume.txt).  A launch boundary puts the
-    // partners back in step: launches of at most SLICE_ROUNDS dispatch rounds each (SC_MTFFT_SLICE overrides; 0 = one launch).
+    // Slices (SC_MTFFT_SLICE=<dispatch rounds per launch>, default 0 = one launch; an A/B switch).  Round 5 saw N = 4096 fall from 2.7-2.8
+    // TB/s at 3.7 GB of spectra to 1.96 at 11 GB, whatever the number of windows.  Round 6 (profiles/r06_stage_a_volume.txt): it is the
+    // STORE stream and the FOOTPRINT -- with the passes off the stores of 3.7 GB take 0.72 ms (5.1 TB/s), those of 11 GB 4.05 ms (2.7
+    // TB/s), while the passes and the prologue scale linearly (x 2.9 for x 3 the volume) -- and not the drift of the super-tile partners
+    // over a long launch, which was the suspicion this switch was written to test: launches of 6, 12 or 24 dispatch rounds change
+    // nothing (1.96-1.98 TB/s).  Every wave instruction of a store slot writes 32-byte pieces of 64 different frequency rows, megabytes
+    // apart: 2049 pages per slot and half, which stops fitting the address-translation reach somewhere between 4 and 11 GB of output.
     const int64_t groups = (int64_t)a.W * a.R;
     int64_t slice_groups = groups;
     {
         const char* e = sc_switch(SC_SW_MTFFT_SLICE);
-        const int64_t rounds = e ? atoll(e) : (SUP > 1 ? 12 : 0);
+        const int64_t rounds = e ? atoll(e) : 0;
         if (rounds > 0) slice_groups = (rounds * 256 / n_ct + 7) / 8 * 8;
         if (slice_groups < 8) slice_groups = 8;
     }

@@ -176,12 +176,16 @@ __device__ __forceinline__ void mx_split2(float x0, float x1, unsigned& h, unsig
 }
 
 // Geometry of one instantiation, shared by the kernel and its launcher.
-template <int N_, int RM_, int RF_, int HT_, bool ALIGNED_, int BP_, int ZPAD_>
+template <int N_, int RM_, int RF_, int HT_, bool ALIGNED_, int BP_, int ZPAD_, int RP_ = 10>
 struct MixGeo {
-    static constexpr int N = N_, RM = RM_, RF = RF_, HT = HT_, RP = 10;
+    // RP: points per thread = radix of pass 1.  10 everywhere but where 20 puts a transform into ONE wave (1000 / 1200 samples: 50 / 60
+    // threads per transform -- the exchanges then need no workgroup barrier, a half holds eight channel pairs instead of four, and a
+    // half's store pieces are whole 128-byte lines)
+    static constexpr int N = N_, RM = RM_, RF = RF_, HT = HT_, RP = RP_;
     static constexpr bool ALIGNED = ALIGNED_;
-    static_assert(N == RP * (RM ? RM : 1) * RF, "N = 10 RM RF");
-    static_assert(RM == 0 || RP % RM == 0, "the middle radix divides 10");
+    static_assert(N == RP * (RM ? RM : 1) * RF, "N = RP RM RF");
+    static_assert(RM == 0 || RP % RM == 0, "the middle radix divides the first");
+    static_assert(RP % 2 == 0, "16-byte pieces of pass 1");
     static_assert(HT % 64 == 0, "a half is whole waves");
     static constexpr int TPF = N / RP;                               // threads per transform
     static constexpr int GL = ALIGNED ? (TPF <= 64 ? 64 : (TPF + 63) / 64 * 64) : TPF;       // lanes of a group of transforms
@@ -412,10 +416,17 @@ __global__ void __launch_bounds__(2 * GEO::HT, 2 * GEO::HT <= 512 ? 4 : 1) mtfft
     // ---- addresses of the passes: (one base per role) + constants wherever the geometry allows ----
     constexpr int BP = GEO::BP;
     auto phys = [](int idx) -> int { return BP ? idx + (idx / LS) * BP : idx; };                    // (LS is a constant: multiply + shift)
-    float2* const zw1 = zf + phys(RP * i);            // pass 1 writes phys(10 i + u) = phys(10 i) + u: five 16-byte pieces
-    int zr_off[RP];                                   // passes 2, 3 read phys(i + s TPF)
+    float2* const zw1 = zf + phys(RP * i);            // pass 1 writes phys(RP i + u) = phys(RP i) + u: RP / 2 16-byte pieces
+    // passes 2, 3 read phys(i + s TPF).  Where a block of LS elements is whole runs of TPF (LS % TPF == 0) the block of i + s TPF is
+    // s / (LS / TPF) whatever i: a constant offset from zf + i, no register; otherwise one offset per s, computed once
+    constexpr bool ZCONST = LS % TPF == 0;
+    constexpr int NZ = ZCONST ? 1 : RP;
+    int zr_tab[NZ];
+    if constexpr (!ZCONST) {
 #pragma unroll
-    for (int s = 0; s < RP; ++s) zr_off[s] = phys(i + s * TPF);
+        for (int s = 0; s < RP; ++s) zr_tab[s] = phys(i + s * TPF);
+    }
+    auto zr_off = [&](int s) -> int { return ZCONST ? i + s * TPF + (s / (ZCONST ? LS / TPF : 1)) * BP : zr_tab[ZCONST ? 0 : s]; };
 
 #define XBAR()                                                      \
     do {                                                            \
@@ -454,7 +465,7 @@ __global__ void __launch_bounds__(2 * GEO::HT, 2 * GEO::HT <= 512 ? 4 : 1) mtfft
             constexpr int J2 = RP / RM;               // butterflies of this thread: b = i + j TPF, inputs s = j + t J2
             float2 a[RP];
 #pragma unroll
-            for (int s = 0; s < RP; ++s) a[s] = zf[zr_off[s]];
+            for (int s = 0; s < RP; ++s) a[s] = zf[zr_off(s)];
             float2 o[J2][RM];
             int wbase[J2];
 #pragma unroll
@@ -482,7 +493,7 @@ __global__ void __launch_bounds__(2 * GEO::HT, 2 * GEO::HT <= 512 ? 4 : 1) mtfft
             for (int j = 0; j < JF; ++j) {
                 const int b = i + j * TPF;
                 if (JF * TPF == LS || b < LS) {
-                    float2* zb = zf + zr_off[j];      // phys(i + j TPF): j < JF <= RP
+                    float2* zb = zf + zr_off(j);      // phys(i + j TPF): j < JF <= RP
                     const float2* tf = TF + b;
                     float2 q[RF];
 #pragma unroll
@@ -673,39 +684,38 @@ static int64_t coverage_of(int64_t C, int dbg) {
 }
 
 // The instantiated lengths and their geometries (threads of a half, lanes aligned to waves or packed, block pad, transform pad);
-// geometry 0 is the one the library takes, SC_MTFFT_MIXED_GEO=g takes geometry g of a length where it has one (A/B on MI355X:
-// profiles/r06_stage_a_mixed_ab.txt).  X(N, RM, RF, g, HT, ALIGNED, BP, ZPAD)
+// SC_MTFFT_MIXED_GEO=g takes geometry g of a length where it has one (A/B on MI355X: profiles/r06_stage_a_mixed_ab.txt, which also
+// holds the geometries that were tried and taken out again: 128- and 256-thread halves -- two to four workgroups per compute unit --
+// 2.4-2.5 TB/s where geometry 0 has 2.9-3.0 at 200 / 250 samples; six waves per SIMD with the registers capped at 80: 2.4-2.7; RP = 20
+// at 500 ... 1200 samples -- one wave per transform, eight pairs per half -- 1.6-2.5 TB/s against 2.0-2.9: its radix-20 pass needs
+// more than the 128 registers a 1024-thread workgroup has).  X(N, RM, RF, g, HT, ALIGNED, BP, ZPAD, RP)
 #define MIX_GEOS(X)                                     \
-    X(200, 10, 2, 0, 256, true, 6, 6)                   \
-    X(200, 10, 2, 1, 320, false, 6, 6)                  \
-    X(200, 10, 2, 2, 128, true, 6, 6)                   \
-    X(250, 5, 5, 0, 256, true, 0, 2)                    \
-    X(250, 5, 5, 1, 448, false, 0, 0)                   \
-    X(250, 5, 5, 2, 128, true, 0, 14)                   \
-    X(300, 10, 3, 0, 256, true, 6, 6)                   \
-    X(300, 10, 3, 1, 256, false, 6, 6)                  \
-    X(400, 10, 4, 0, 256, true, 6, 6)                   \
-    X(400, 10, 4, 1, 320, false, 6, 6)                  \
-    X(500, 10, 5, 0, 256, true, 6, 12)                  \
-    X(500, 10, 5, 1, 448, false, 6, 6)                  \
-    X(500, 10, 5, 2, 128, true, 6, 4)                   \
-    X(500, 10, 5, 3, 256, false, 6, 6)                  \
-    X(600, 10, 6, 0, 256, true, 6, 2)                   \
-    X(600, 10, 6, 1, 512, false, 6, 6)                  \
-    X(750, 5, 15, 0, 320, false, 0, 10)                 \
-    X(750, 5, 15, 1, 512, true, 0, 10)                  \
-    X(800, 10, 8, 0, 320, false, 6, 14)                 \
-    X(800, 10, 8, 1, 512, true, 6, 14)                  \
-    X(1000, 10, 10, 0, 512, true, 6, 10)                \
-    X(1000, 10, 10, 1, 448, false, 6, 10)               \
-    X(1000, 10, 10, 2, 256, true, 6, 18)                \
-    X(1000, 10, 10, 3, 256, false, 6, 18)               \
-    X(1200, 10, 12, 0, 512, true, 6, 6)                 \
-    X(1200, 10, 12, 1, 512, false, 6, 6)                \
-    X(1500, 10, 15, 0, 320, false, 6, 0)                \
-    X(1500, 10, 15, 1, 512, false, 6, 0)                \
-    X(2000, 10, 20, 0, 448, false, 6, 14)               \
-    X(2000, 10, 20, 1, 512, true, 6, 14)
+    X(200, 10, 2, 0, 256, true, 6, 6, 10)                   \
+    X(200, 10, 2, 1, 320, false, 6, 6, 10)                  \
+    X(250, 5, 5, 0, 256, true, 0, 2, 10)                    \
+    X(250, 5, 5, 1, 448, false, 0, 0, 10)                   \
+    X(300, 10, 3, 0, 256, true, 6, 6, 10)                   \
+    X(300, 10, 3, 1, 256, false, 6, 6, 10)                  \
+    X(400, 10, 4, 0, 256, true, 6, 6, 10)                   \
+    X(400, 10, 4, 1, 320, false, 6, 6, 10)                  \
+    X(500, 10, 5, 0, 256, true, 6, 12, 10)                  \
+    X(500, 10, 5, 1, 448, false, 6, 6, 10)                  \
+    X(600, 10, 6, 0, 256, true, 6, 2, 10)                   \
+    X(600, 10, 6, 1, 512, false, 6, 6, 10)                  \
+    X(750, 5, 15, 0, 320, false, 0, 10, 10)                 \
+    X(750, 5, 15, 1, 512, true, 0, 10, 10)                  \
+    X(800, 10, 8, 0, 320, false, 6, 14, 10)                 \
+    X(800, 10, 8, 1, 512, true, 6, 14, 10)                  \
+    X(1000, 10, 10, 0, 512, true, 6, 10, 10)                \
+    X(1000, 10, 10, 1, 448, false, 6, 10, 10)               \
+    X(1200, 10, 12, 0, 512, true, 6, 6, 10)                 \
+    X(1200, 10, 12, 1, 512, false, 6, 6, 10)                \
+    X(1500, 10, 15, 0, 320, false, 6, 0, 10)                \
+    X(1500, 10, 15, 1, 512, false, 6, 0, 10)                \
+    X(2000, 10, 20, 0, 448, false, 6, 14, 10)               \
+    X(2000, 10, 20, 1, 512, true, 6, 14, 10)             \
+    X(1000, 10, 5, 2, 384, true, 12, 4, 20)             \
+    X(2000, 10, 10, 2, 512, true, 2, 6, 20)
 
 static int mix_dbg() {
     const char* d = sc_switch(SC_SW_MTFFT_DEBUG);
@@ -713,7 +723,7 @@ static int mix_dbg() {
 }
 static bool mix_has_geo(int64_t N, int g) {
     switch (N * 8 + g) {
-#define X(NN, RM, RF, GI, HT, AL, BP, ZP) case NN * 8 + GI: return true;
+#define X(NN, RM, RF, GI, HT, AL, BP, ZP, RP) case NN * 8 + GI: return true;
         MIX_GEOS(X)
 #undef X
     }
@@ -728,8 +738,9 @@ static int mix_geo(int64_t N, bool planes) {
         const int g = atoi(e);
         return (g > 0 && g < 8 && mix_has_geo(N, g)) ? g : 0;
     }
-    if (planes) return (N == 400 || N == 500 || N == 600 || N == 800 || N == 1500 || N == 2000) ? 1 : 0;
-    return (N == 1200 || N == 2000) ? 1 : 0;
+    if (N == 2000) return 2;          // RP = 20: 2.6 / 3.0 ms against 3.1 / 3.9 (radix 20 as the FINAL pass of RP = 10 spills)
+    if (planes) return (N == 400 || N == 500 || N == 600 || N == 800 || N == 1500) ? 1 : 0;
+    return N == 1200 ? 1 : 0;
 }
 
 bool sc_internal_mtfft_mix_has(int64_t N) { return mix_has_geo(N, 0); }
@@ -746,7 +757,7 @@ bool sc_internal_mtfft_mix_applies(int64_t N, int64_t C, int64_t groups) {
     if (e && atoi(e) == 1) return true;
     int64_t n_ct = 1;
     switch (N * 8 + mix_geo(N, false)) {
-#define X(NN, RM, RF, GI, HT, AL, BP, ZP) case NN * 8 + GI: n_ct = tiles_of<MixGeo<NN, RM, RF, HT, AL, BP, ZP>>(C, mix_dbg()); break;
+#define X(NN, RM, RF, GI, HT, AL, BP, ZP, RP) case NN * 8 + GI: n_ct = tiles_of<MixGeo<NN, RM, RF, HT, AL, BP, ZP, RP>>(C, mix_dbg()); break;
         MIX_GEOS(X)
 #undef X
     }
@@ -756,7 +767,7 @@ bool sc_internal_mtfft_mix_applies(int64_t N, int64_t C, int64_t groups) {
 int64_t sc_internal_mtfft_mix_coverage(int64_t N, int64_t C, bool planes) {
     const int dbg = mix_dbg();
     switch (N * 8 + mix_geo(N, planes)) {
-#define X(NN, RM, RF, GI, HT, AL, BP, ZP) case NN * 8 + GI: return coverage_of<MixGeo<NN, RM, RF, HT, AL, BP, ZP>>(C, dbg);
+#define X(NN, RM, RF, GI, HT, AL, BP, ZP, RP) case NN * 8 + GI: return coverage_of<MixGeo<NN, RM, RF, HT, AL, BP, ZP, RP>>(C, dbg);
         MIX_GEOS(X)
 #undef X
     }
@@ -775,7 +786,7 @@ int sc_internal_mtfft_mix(const float* d_x, int64_t T, int64_t R, int64_t C, int
     a.dbg = mix_dbg();
     SC_REQUIRE((W - 1) * step + L <= T, "windows exceed the time series");
     switch (N * 8 + mix_geo(N, d_P != nullptr)) {
-#define X(NN, RM, RF, GI, HT, AL, BP, ZP) case NN * 8 + GI: return launch_mix<MixGeo<NN, RM, RF, HT, AL, BP, ZP>>(a, st);
+#define X(NN, RM, RF, GI, HT, AL, BP, ZP, RP) case NN * 8 + GI: return launch_mix<MixGeo<NN, RM, RF, HT, AL, BP, ZP, RP>>(a, st);
         MIX_GEOS(X)
 #undef X
     }
