@@ -50,7 +50,7 @@ F64_PEAK_TFLOPS = 78.6        # fp64 vector = fp64 matrix rate
 # from the committed summary of the rocprofv3 --pmc passes over THIS command (tools/profile_round.py writes it next to
 # the kernel-trace stats; it records the source hash of the kernels it measured) and is null when that file is
 # missing or was measured on other kernel sources.
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05_hbm_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r06_hbm_traffic.json")
 
 
 def kernel_source_hash():
@@ -70,7 +70,7 @@ def measured_traffic(config, stage):
     except (OSError, ValueError):
         return None, None
     if rec.get("kernel_source_hash") != kernel_source_hash():
-        return None, "profiles/r05_hbm_traffic.json was measured on other kernel sources"
+        return None, "profiles/r06_hbm_traffic.json was measured on other kernel sources"
     v = rec.get(config, {}).get(stage)
     return (float(v) if v is not None else None), rec.get("source")
 

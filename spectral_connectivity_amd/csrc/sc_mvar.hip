@@ -870,7 +870,11 @@ __global__ void __launch_bounds__(512) m_gemm_mfma(MvMat X, MvMat Y, MvMat O, co
     for (int tj = 0; tj < Q; ++tj) { re[tj] = (mv_f64x4){0.0, 0.0, 0.0, 0.0}; im[tj] = re[tj]; }
     const int li = lane & 15, lk = lane >> 4;
     const int Cr = (C + 15) & ~15;
-    const bool mine = wave < Q;
+    // Tiles that hold signals only: a block of the cut output (and any system that is not a multiple of 128 wide) multiplies the
+    // tile rows / columns below C and nothing else -- at 130 signals the four 128 x 128 blocks were 4 x the arithmetic of 128 signals
+    // for 3 % more entries (round 5: 2.0-2.3 ms per product against 0.5-0.7; profiles/r06_mvar_kernels.txt).  Wave-uniform tests.
+    const int ntj = (C - j0 + 15) / 16 < Q ? (C - j0 + 15) / 16 : Q;
+    const bool mine = wave < Q && i0 + 16 * wave < C;
     fetch(0);
     park();
     __syncthreads();
@@ -883,6 +887,7 @@ __global__ void __launch_bounds__(512) m_gemm_mfma(MvMat X, MvMat Y, MvMat O, co
                 const cd av = Xs[(16 * wave + li) * LSX + 4 * kk + lk];
 #pragma unroll
                 for (int tj = 0; tj < Q; ++tj) {
+                    if (tj >= ntj) continue;
                     const cd b = Ys[(4 * kk + lk) * LSY + 16 * tj + li];
                     re[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, b.x, re[tj], 0, 0, 0);
                     re[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(-av.y, b.y, re[tj], 0, 0, 0);

@@ -188,3 +188,28 @@ def test_silent_constant_and_nonfinite_channels_in_mixed_windows(N, debug_env):
     assert np.isnan(got[bad]).all() and np.isfinite(got[~bad]).all()
     assert np.all(got[..., 2] == 0) and np.all(got[..., 7] == 0)
     _close(np.where(bad, 0, got), np.where(bad, 0, ref), f"N={N}: channels beside a silent / non-finite one")
+
+
+@pytest.mark.parametrize("L,C", [(250, 64), (1000, 48), (200, 130), (500, 70)])
+def test_public_classes_on_the_planes_format_at_these_lengths(L, C, monkeypatch):
+    """Multitaper -> Connectivity.from_multitaper(dtype=complex64) at window lengths that are not powers of two: stage A writes the
+    planes format (sc_mtfft_mixed.hip: the only kernel with that output there), stage B is sc_fused2.hip on the f16 pieces --
+    asserted: the spectra are never decoded --, coherence / imaginary coherence / wPLI / power against the float64 oracle at the
+    float32 engine's bar, and the same numbers as with SC_PLANES_FORMAT=0 (complex64 spectra, the round-3 kernels) to that bar."""
+    import spectral_connectivity_amd as sc
+    _dev()
+    monkeypatch.setenv("SC_PLANES_MIN_CHANNELS", "2")
+    rng = np.random.default_rng(L + C)
+    R, step = 6, L // 2
+    T = L + 3 * step
+    t = np.arange(T) / 1000.0
+    x = rng.standard_normal((T, R, C))
+    x += 0.6 * np.sin(2 * np.pi * 60 * t[:, None, None] + 2 * np.pi * np.arange(C)[None, None, :] / C)
+    kw = dict(sampling_frequency=1000.0, time_halfbandwidth_product=3, n_time_samples_per_window=L, n_time_samples_per_step=step)
+    coef, _ = so.multitaper_fft(x, fs=1000.0, NW=3, n_time_samples_per_window=L, n_time_samples_per_step=step)
+    c = sc.Connectivity.from_multitaper(sc.Multitaper(x.astype(np.float32), **kw), dtype=np.complex64)
+    got = {name: getattr(c, name)() for name in ("coherence_magnitude", "weighted_phase_lag_index", "imaginary_coherence", "power")}
+    assert c._spectra.P is not None and c._spectra._X is None, "the planes format (never decoded) was expected"
+    for name, g in got.items():
+        w = _close(g, getattr(so, name)(coef), f"L={L} C={C} {name}")
+        print(f"\n  L={L} C={C} {name}: worst err / bound {w:.2f}")

@@ -6,7 +6,7 @@ import os
 import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = os.environ.get("ROUND", "r05")
+ROUND = os.environ.get("ROUND", "r06")
 F = os.path.join(ROOT, "gpurun_out", ROUND)
 P = os.path.join(ROOT, "profiles")
 
@@ -146,6 +146,12 @@ for src, dst, head in (("api_wall.txt", ROUND + "_api_wall.txt", "# tools/api_wa
                        ("kt4.txt", ROUND + "_bench_kernel_stats_cfg4.txt", "# rocprofv3 --kernel-trace --stats -- python bench.py --config cfg4 --steps 5 --warmup 2 --no-cpu-baseline (pairwise Granger, 2016 pairs x 4096 bins)"),
                        ("mvar_size_time.txt", ROUND + "_mvar_size_time.txt", "# tools/mvar_size_time.py: full Wilson factorisation + DTF across system sizes, one window x 256 bins, float64 records"),
                        ("stage_a_ab.txt", ROUND + "_stage_a_ab_final.txt", "# tools/stage_a_ab.py 0 16 2 4 6 (and again with SC_AB_LONG=1): the anti-phase stage A under SC_MTFFT_DEBUG inside one process, wall time per call incl. launch (16 = non-temporal stores, 2 = no passes, 4 = no split / store loop, 6 = neither: tile load + detrend + the empty slots' barriers)")):
+    body = [l for l in lines(src) if "amdgpu.ids" not in l]
+    if body:
+        open(os.path.join(P, dst), "w").write("\n".join([head] + body) + "\n")
+for src, dst, head in (("stage_a_mixed.txt", ROUND + "_stage_a_mixed.txt", "# tools/stage_a_mixed.py time: stage A for the window lengths that are not powers of two, the round-2 kernels (SC_MTFFT_MIXED=0) against sc_mtfft_mixed.hip (geometry 0 / 1 of every length), both outputs (profile round's box)"),
+                       ("e2e_lengths.txt", ROUND + "_e2e_lengths.txt", "# tools/e2e_lengths.py: stage A -> stage B -> epilogue (coherence + wPLI) at the cfg3 data volume per window length, the engine's own choice of kernels and device format"),
+                       ("api_timeline.txt", ROUND + "_api_timeline.txt", "# tools/api_timeline.py: the public-API pass (series in HBM, cfg3) phase by phase, and the engine chain after n ms of idle GPU (profile round's box)")):
     body = [l for l in lines(src) if "amdgpu.ids" not in l]
     if body:
         open(os.path.join(P, dst), "w").write("\n".join([head] + body) + "\n")

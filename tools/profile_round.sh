@@ -8,7 +8,7 @@
 # (counters in their own runs with --kernel-trace only: MI355X_MICROARCH.md, rocprofv3 PMC slots)
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-ROUND=${ROUND:-r05}
+ROUND=${ROUND:-r06}
 OUT=$ROOT/gpurun_out/$ROUND
 mkdir -p $OUT
 cd $ROOT
@@ -32,27 +32,34 @@ for d in kt fetch write sq sq2 kt4 fetch4 write4; do
     [ -n "$db" ] && python tools/rocpd_summary.py $db > $OUT/$d.txt 2>&1
     rm -rf $OUT/$d          # (the raw databases are hundreds of MB: gpurun copies back at most 64 MB)
 done
-python tools/mvar_time.py 64 1792 256 > $OUT/mvar_64ch.txt 2>&1
-python tools/mvar_time.py 128 1792 256 > $OUT/mvar_128ch.txt 2>&1
-python tools/mvar_size_time.py > $OUT/mvar_size_time.txt 2>&1
-python tools/stage_a_ab.py 0 16 2 4 6 > $OUT/stage_a_ab.txt 2>&1
-SC_AB_LONG=1 python tools/stage_a_ab.py 0 16 2 4 6 >> $OUT/stage_a_ab.txt 2>&1
-python tools/engine_time.py > $OUT/engine_time.txt 2>&1
-python tools/stage_a_breakdown.py > $OUT/stage_a.txt 2>&1
-python tools/plane_pass_time.py > $OUT/plane_pass.txt 2>&1
+# Round 6: only what changed or what the bench line needs is measured again (the review of round 5: GPU minutes belong to kernels, not to
+# re-measuring unchanged ones); FULL=1 adds the whole round-5 set (MVAR sizes, stage-B ablations, issue rates, ...), whose r05 files stand.
 python tools/shape_sweep.py > $OUT/shape_sweep.txt 2>&1
-python tools/fused_ablation.py > $OUT/fused_ablation.txt 2>&1
-python tools/fused2_time.py 0 1 2 3 8 9 10 11 64 > $OUT/fused2_ablation.txt 2>&1
-python tools/stage_a_planes_ab.py > $OUT/stage_a_planes_ab.txt 2>&1
-python tools/stage_a_planes_check.py > $OUT/stage_a_planes_check.txt 2>&1
+MIX_GEOS=0,1 python tools/stage_a_mixed.py time > $OUT/stage_a_mixed.txt 2>&1
+python tools/e2e_lengths.py 256 250 200 500 1000 1024 > $OUT/e2e_lengths.txt 2>&1
 for c in cfg2 cfg4 cfg5; do python bench.py --config $c --steps 10 --warmup 3 > $OUT/bench_$c.json 2> $OUT/bench_$c.err; done
-python tools/api_wall.py > $OUT/api_wall.txt 2>&1
-python tools/numpy_host_time.py > $OUT/numpy_host.txt 2>&1
-python tools/stage_a_long.py > $OUT/stage_a_wide.txt 2>&1
-python tools/stage_a_antiphase_ab.py > $OUT/stage_a_antiphase_ab.txt 2>&1
-python tools/global_time.py > $OUT/global_canonical.txt 2>&1
-python tools/measure_table.py > $OUT/measure_table.txt 2>&1
-python tools/fused2_fold_ab.py > $OUT/fused2_fold_ab.txt 2>&1
-[ -x tools/issue_rates_f64 ] && ./tools/issue_rates_f64 > $OUT/issue_rates_f64.txt 2>&1
+python tools/api_timeline.py > $OUT/api_timeline.txt 2>&1
 bash tools/sharded_one_rank.sh > $OUT/sharded_one_rank.txt 2>&1
+if [ "${FULL:-0}" = "1" ]; then
+  python tools/mvar_time.py 64 1792 256 > $OUT/mvar_64ch.txt 2>&1
+  python tools/mvar_time.py 128 1792 256 > $OUT/mvar_128ch.txt 2>&1
+  python tools/mvar_size_time.py > $OUT/mvar_size_time.txt 2>&1
+  python tools/stage_a_ab.py 0 16 2 4 6 > $OUT/stage_a_ab.txt 2>&1
+  SC_AB_LONG=1 python tools/stage_a_ab.py 0 16 2 4 6 >> $OUT/stage_a_ab.txt 2>&1
+  python tools/engine_time.py > $OUT/engine_time.txt 2>&1
+  python tools/stage_a_breakdown.py > $OUT/stage_a.txt 2>&1
+  python tools/plane_pass_time.py > $OUT/plane_pass.txt 2>&1
+  python tools/fused_ablation.py > $OUT/fused_ablation.txt 2>&1
+  python tools/fused2_time.py 0 1 2 3 8 9 10 11 64 > $OUT/fused2_ablation.txt 2>&1
+  python tools/stage_a_planes_ab.py > $OUT/stage_a_planes_ab.txt 2>&1
+  python tools/stage_a_planes_check.py > $OUT/stage_a_planes_check.txt 2>&1
+  python tools/api_wall.py > $OUT/api_wall.txt 2>&1
+  python tools/numpy_host_time.py > $OUT/numpy_host.txt 2>&1
+  python tools/stage_a_long.py > $OUT/stage_a_wide.txt 2>&1
+  python tools/stage_a_antiphase_ab.py > $OUT/stage_a_antiphase_ab.txt 2>&1
+  python tools/global_time.py > $OUT/global_canonical.txt 2>&1
+  python tools/measure_table.py > $OUT/measure_table.txt 2>&1
+  python tools/fused2_fold_ab.py > $OUT/fused2_fold_ab.txt 2>&1
+  [ -x tools/issue_rates_f64 ] && ./tools/issue_rates_f64 > $OUT/issue_rates_f64.txt 2>&1
+fi
 ls -la $OUT; du -sh $OUT
