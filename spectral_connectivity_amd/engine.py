@@ -194,7 +194,8 @@ def multitaper_spectra(x, tapers_over_fs, n_window, n_step, n_fft, n_windows, de
     (appended on the host before the upload, transforms.Multitaper.device_spectra); a device tensor with an odd channel
     count that arrives unpadded is copied into a padded buffer here (one strided device copy).
     ``planes_hint``: the accumulator families the caller will ask for.  Any family sc_fused2.hip serves, 44 ... 256 signals, a
-    power-of-two window of 64 ... 1024 samples and at least 256 MB of spectra (_lib.planes_format_applies): the spectra are
+    window length stage A has the output for (the powers of two 64 ... 4096, the lengths 200 ... 2000 of sc_mtfft_mixed.hip:
+    sc_multitaper_fft_planes_supported) and at least 256 MB of spectra (_lib.planes_format_applies): the spectra are
     written in the planes format (two f16 pieces per real number) -- a scan of the series for the channel scales, then the same
     fused transform.  The scan also reports how large a typical coefficient will be in the format's scaled units
     (``DeviceSpectra.planes_typical_coefficient()``): one scale per channel serves every window, so the format is meant for

@@ -452,6 +452,9 @@ class NumpyHost:
             raise ValueError(f"Invalid expectation_type '{expectation_type}'. Must be one of: "
                              + ", ".join(f"'{k}'" for k in EXPECTATION_AXES))
         m = Multitaper(time_series, **multitaper_kwargs)
+        if np.asarray(m.time_series).shape[2] > 256:      # (before anything is allocated on the device)
+            raise ValueError(f"n_signals <= 256 through NumpyHost's functional interface (got {np.asarray(m.time_series).shape[2]}): "
+                             "numpy_api.Connectivity (SC_HIP_HOST=numpy) tiles more signals into channel blocks")
         planes = _lib.PLANE_CSM
         # (complex64 spectra, like Connectivity._csm_records of the PyTorch host: these consumers read every bin of the CSM once, at
         #  window lengths and channel counts where the planes format buys nothing)
@@ -630,6 +633,9 @@ class NumpyHost:
         if unknown:
             raise ValueError(f"unknown measures {unknown}; available: {sorted(MEASURES)}")
         m = Multitaper(time_series, **multitaper_kwargs)
+        if np.asarray(m.time_series).shape[2] > 256:      # (before anything is allocated on the device)
+            raise ValueError(f"n_signals <= 256 through NumpyHost's functional interface (got {np.asarray(m.time_series).shape[2]}): "
+                             "numpy_api.Connectivity (SC_HIP_HOST=numpy) tiles more signals into channel blocks")
         planes = 0
         for name in measures:
             planes |= _lib.MEASURE_PLANES[MEASURES[name]]

@@ -6,7 +6,7 @@ from spectral_connectivity_amd import engine, _lib
 F, W, R, K, C = 129, 7, 1000, 7, 128
 X = torch.randn(F, W, R, K, C, dtype=torch.complex128, device="cuda")
 sp = engine.DeviceSpectra(X, (F, W, R, K, C), (W * R * K * C, R * K * C, K * C, C), 256, real_input=True)
-os.environ["SC_F64_NO_FORK"] = "1"
+_lib.set_debug_env("SC_F64_NO_FORK", "1")         # (read by the library at load: set and re-read)
 for _ in range(3):
     engine.accumulate(sp, "trials_tapers", _lib.PLANE_CSM | _lib.PLANE_ABS_IM)
 torch.cuda.synchronize()

@@ -18,7 +18,8 @@ if __name__ == "__main__":
         build()
         sys.exit(0)
     os.environ["SC_HIP_LIB"] = LIB
-    os.environ["SC_FUSED_SPLIT"] = "1"          # one workgroup per bin: workgroup 0 sees every chunk
+    os.environ["SC_FUSED_SPLIT"] = "1"          # one workgroup per bin: workgroup 0 sees every chunk (set BEFORE the library is
+                                                # loaded below: its switches are a snapshot taken at load)
     sys.path.insert(0, ROOT)
     import torch
     from spectral_connectivity_amd import engine, _lib

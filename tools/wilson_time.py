@@ -43,10 +43,8 @@ def run():
 
 res = {}
 for mode in ("fused", "rocfft", "fused", "rocfft"):
-    if mode == "rocfft":
-        os.environ["SC_WILSON_FFT"] = "rocfft"
-    else:
-        os.environ.pop("SC_WILSON_FFT", None)
+    # (the library reads its switches once, at load: set_debug_env changes the variable AND has it read again)
+    _lib.set_debug_env("SC_WILSON_FFT", "rocfft" if mode == "rocfft" else None)
     run()
     t0 = time.perf_counter()
     for _ in range(3):
