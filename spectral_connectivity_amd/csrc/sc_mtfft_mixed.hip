@@ -692,16 +692,22 @@ static int64_t coverage_of(int64_t C, int dbg) {
 #define MIX_GEOS(X)                                     \
     X(200, 10, 2, 0, 256, true, 6, 6, 10)                   \
     X(200, 10, 2, 1, 320, false, 6, 6, 10)                  \
+    X(200, 10, 2, 2, 512, true, 6, 6, 10)                   \
     X(250, 5, 5, 0, 256, true, 0, 2, 10)                    \
     X(250, 5, 5, 1, 448, false, 0, 0, 10)                   \
+    X(250, 5, 5, 2, 512, true, 0, 0, 10)                    \
     X(300, 10, 3, 0, 256, true, 6, 6, 10)                   \
     X(300, 10, 3, 1, 256, false, 6, 6, 10)                  \
+    X(300, 10, 3, 2, 512, true, 6, 6, 10)                   \
     X(400, 10, 4, 0, 256, true, 6, 6, 10)                   \
     X(400, 10, 4, 1, 320, false, 6, 6, 10)                  \
+    X(400, 10, 4, 2, 512, true, 6, 2, 10)                   \
     X(500, 10, 5, 0, 256, true, 6, 12, 10)                  \
     X(500, 10, 5, 1, 448, false, 6, 6, 10)                  \
+    X(500, 10, 5, 2, 512, true, 6, 0, 10)                   \
     X(600, 10, 6, 0, 256, true, 6, 2, 10)                   \
     X(600, 10, 6, 1, 512, false, 6, 6, 10)                  \
+    X(600, 10, 6, 2, 512, true, 6, 6, 10)                   \
     X(750, 5, 15, 0, 320, false, 0, 10, 10)                 \
     X(750, 5, 15, 1, 512, true, 0, 10, 10)                  \
     X(800, 10, 8, 0, 320, false, 6, 14, 10)                 \
@@ -739,7 +745,10 @@ static int mix_geo(int64_t N, bool planes) {
         return (g > 0 && g < 8 && mix_has_geo(N, g)) ? g : 0;
     }
     if (N == 2000) return 2;          // RP = 20: 2.6 / 3.0 ms against 3.1 / 3.9 (radix 20 as the FINAL pass of RP = 10 spills)
-    if (planes) return (N == 400 || N == 500 || N == 600 || N == 800 || N == 1500) ? 1 : 0;
+    // 400 ... 600 samples: one transform per wave, eight pairs per half, one workgroup of sixteen waves per compute unit (geometry 2):
+    // 2.09 / 1.86 ms against 2.22 / 2.21 at 500 / 600 samples, and the planes output 2.18-2.48 against 2.5-3.1 ms
+    if (N == 400 || N == 500 || N == 600) return 2;
+    if (planes) return N == 300 ? 2 : ((N == 800 || N == 1500) ? 1 : 0);
     return N == 1200 ? 1 : 0;
 }
 
