@@ -254,6 +254,29 @@ def test_numpy_host_imports_without_torch_and_refuses_without_a_gpu():
     assert "constructed" in out.stdout or "no CPU fallback" in out.stdout, out.stdout
 
 
+def test_public_classes_select_the_torch_free_host_and_refuse_without_a_gpu():
+    """SC_HIP_HOST=numpy: the package's Connectivity is numpy_api.Connectivity (the same class with the device methods replaced),
+    constructing objects and asking for host-side properties never imports torch, and the first computation refuses without a GPU
+    through the library's own device count (no CPU fallback on this host either).  A bad value of the switch is an error."""
+    import subprocess
+    import sys
+    code = ("import sys\nimport numpy as np\nimport spectral_connectivity_amd as sc\n"
+            "from spectral_connectivity_amd import connectivity\n"
+            "assert sc.Connectivity.__module__.endswith('numpy_api') and issubclass(sc.Connectivity, connectivity.Connectivity)\n"
+            "m = sc.Multitaper(np.random.default_rng(0).standard_normal((64, 3, 4)), sampling_frequency=100.0)\n"
+            "assert m.n_tapers == 5 and m.frequencies.shape == (64,)\n"
+            "try:\n    c = sc.Connectivity.from_multitaper(m)\n    c.power()\n    print('computed')\n"
+            "except RuntimeError as exc:\n    print('refused:', exc)\n"
+            "assert 'torch' not in sys.modules\n")
+    env = dict(os.environ, SC_HIP_HOST="numpy")
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "computed" in out.stdout or "no CPU fallback" in out.stdout, out.stdout
+    bad = subprocess.run([sys.executable, "-c", "import spectral_connectivity_amd as sc\nsc.Connectivity"], cwd=ROOT, capture_output=True,
+                         text=True, timeout=300, env=dict(os.environ, SC_HIP_HOST="cupy"))
+    assert bad.returncode != 0 and "SC_HIP_HOST" in bad.stderr
+
+
 @pytest.mark.gpu
 def test_comm_entry_points_on_a_one_rank_communicator():
     """sc_comm_* (the C ABI's own RCCL communicator: SURVEY section 8(b) `sc_allreduce`, 8(e)) on the one GPU a test box has:
