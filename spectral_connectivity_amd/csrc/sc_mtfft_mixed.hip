@@ -1,6 +1,6 @@
 // sc_mtfft_mixed.hip -- stage A for the window lengths next_fast_len hands out in an ordinary lab setting that are NOT powers of
-// two: N = 10 * RM * RF (200, 250, 300, 400, 500, 600, 750, 800, 1000, 1200, 1500, 2000 samples: 0.2 ... 2 s windows at 1 kHz,
-// 0.4 ... 4 s at 500 Hz): window extraction + detrend + DPSS taper multiply + real FFT + transposed store of the one-sided spectra
+// two: N = 10 * RM * RF (100, 150, 160, 200, 240, 250, 300, 320, 360, 400, 450, 480, 500, 600, 750, 800, 900, 1000, 1200, 1250, 1500,
+// 1600, 1800, 2000 samples: 0.1 ... 2 s windows at 1 kHz, round durations at 100 Hz ... 2 kHz): window extraction + detrend + DPSS taper multiply + real FFT + transposed store of the one-sided spectra
 // X[f][w][r][k][c] -- or of the planes format of sc_fused2.hip, so that the matrix-pipe stage B serves these lengths too
 // (reference: transforms.py:1147-1171 sliding windows, :1311-1405 _multitaper_fft with n_fft = next_fast_len(L) :1024-1036,
 //  :1798-1915 detrend).
@@ -721,7 +721,20 @@ static int64_t coverage_of(int64_t C, int dbg) {
     X(2000, 10, 20, 0, 448, false, 6, 14, 10)               \
     X(2000, 10, 20, 1, 512, true, 6, 14, 10)             \
     X(1000, 10, 5, 2, 384, true, 12, 4, 20)             \
-    X(2000, 10, 10, 2, 512, true, 2, 6, 20)
+    X(2000, 10, 10, 2, 512, true, 2, 6, 20)             \
+    X(100, 0, 10, 0, 256, true, 0, 6, 10)               \
+    X(150, 5, 3, 0, 256, true, 0, 0, 10)                \
+    X(160, 2, 8, 0, 256, true, 6, 0, 10)                \
+    X(240, 2, 12, 0, 256, true, 8, 12, 10)              \
+    X(320, 2, 16, 0, 256, true, 0, 4, 10)               \
+    X(360, 2, 18, 0, 256, true, 0, 0, 10)               \
+    X(360, 2, 18, 1, 512, true, 0, 0, 10)               \
+    X(450, 5, 9, 0, 512, true, 0, 2, 10)                \
+    X(480, 2, 24, 0, 384, true, 8, 4, 10)               \
+    X(900, 10, 9, 0, 512, true, 6, 4, 10)               \
+    X(1250, 5, 25, 0, 384, true, 0, 6, 10)              \
+    X(1600, 10, 16, 0, 320, false, 6, 22, 10)           \
+    X(1800, 10, 18, 0, 384, false, 6, 2, 10)
 
 static int mix_dbg() {
     const char* d = sc_switch(SC_SW_MTFFT_DEBUG);
@@ -748,7 +761,7 @@ static int mix_geo(int64_t N, bool planes) {
     // 400 ... 600 samples: one transform per wave, eight pairs per half, one workgroup of sixteen waves per compute unit (geometry 2):
     // 2.09 / 1.86 ms against 2.22 / 2.21 at 500 / 600 samples, and the planes output 2.18-2.48 against 2.5-3.1 ms
     if (N == 400 || N == 500 || N == 600) return 2;
-    if (planes) return N == 300 ? 2 : ((N == 800 || N == 1500) ? 1 : 0);
+    if (planes) return N == 300 ? 2 : ((N == 800 || N == 1500 || N == 360) ? 1 : 0);
     return N == 1200 ? 1 : 0;
 }
 

@@ -1,5 +1,5 @@
 """Stage A for the window lengths that are not powers of two on the register-resident kernel (csrc/sc_mtfft_mixed.hip: N = 10 RM RF =
-200 ... 2000 samples, radix-10 first pass in registers, two exchanges, anti-phase half-workgroups, planes output) against the float64
+100 ... 2000 samples, radix-10 first pass in registers, two exchanges, anti-phase half-workgroups, planes output) against the float64
 oracle (oracle/spectral_oracle.py::multitaper_fft, which follows transforms.py:1311-1405; n_fft = next_fast_len(L), transforms.py:
 1024-1036) -- every shape the kernel branches on: one channel, odd counts, counts around its channel tiles and super-tiles, zero
 padding (L < N), overlapping windows, every detrend, silent / constant / non-finite channels, every geometry it is built with --
@@ -11,7 +11,7 @@ import pytest
 from oracle import spectral_oracle as so
 
 pytestmark = pytest.mark.gpu
-LENGTHS = (200, 250, 300, 400, 500, 600, 750, 800, 1000, 1200, 1500, 2000)
+LENGTHS = (100, 150, 160, 200, 240, 250, 300, 320, 360, 400, 450, 480, 500, 600, 750, 800, 900, 1000, 1200, 1250, 1500, 1600, 1800, 2000)
 
 
 def _dev():
@@ -69,6 +69,10 @@ def _device(x, L, step, N, det, NW=2.5, fs=200.0):
     (1200, 1200, 600, 14, 2, "constant"), (1200, 1100, 1100, 20, 2, "linear"),
     (1500, 1500, 750, 9, 2, None), (1500, 1400, 700, 18, 2, "constant"),
     (2000, 2000, 1000, 7, 2, "linear"), (2000, 1900, 1900, 10, 2, "constant"), (2000, 2000, 2000, 34, 1, None),
+    (100, 100, 50, 97, 2, "constant"), (100, 80, 80, 5, 3, "linear"), (150, 150, 75, 33, 2, None), (160, 160, 160, 64, 2, "linear"),
+    (240, 240, 120, 17, 2, "constant"), (320, 300, 150, 34, 2, "linear"), (360, 360, 360, 9, 2, None), (450, 450, 225, 18, 2, "constant"),
+    (480, 480, 240, 25, 2, "linear"), (900, 900, 450, 10, 2, "constant"), (1250, 1250, 625, 6, 2, "linear"),
+    (1600, 1500, 1500, 7, 2, None), (1800, 1800, 900, 5, 2, "constant"),
 ])
 def test_mixed_windows_against_the_oracle(N, L, step, C, R, det, kernel, debug_env):
     _dev()

@@ -16,7 +16,7 @@ from spectral_connectivity_amd import _lib, engine      # noqa: E402
 dev = torch.device("cuda:0")
 GEOS = tuple(os.environ.get("MIX_GEOS", "0,1").split(","))
 PL = _lib.PLANE_CSM | _lib.PLANE_ABS_IM
-LENGTHS = (200, 250, 300, 400, 500, 600, 750, 800, 1000, 1200, 1500, 2000)
+LENGTHS = (100, 150, 160, 200, 240, 250, 300, 320, 360, 400, 450, 480, 500, 600, 750, 800, 900, 1000, 1200, 1250, 1500, 1600, 1800, 2000)
 
 
 def env(**kw):
