@@ -176,7 +176,7 @@ __device__ __forceinline__ void mx_split2(float x0, float x1, unsigned& h, unsig
 }
 
 // Geometry of one instantiation, shared by the kernel and its launcher.
-template <int N_, int RM_, int RF_, int HT_, bool ALIGNED_, int BP_, int ZPAD_, int RP_ = 10>
+template <int N_, int RM_, int RF_, int HT_, bool ALIGNED_, int BP_, int ZPAD_, int RP_ = 10, bool GRP_ = false>
 struct MixGeo {
     // RP: points per thread = radix of pass 1.  10 everywhere but where 20 puts a transform into ONE wave (1000 / 1200 samples: 50 / 60
     // threads per transform -- the exchanges then need no workgroup barrier, a half holds eight channel pairs instead of four, and a
@@ -196,7 +196,12 @@ struct MixGeo {
     static constexpr int CTH = 2 * NF, CT = 2 * CTH;                 // channels per half / per workgroup
     static constexpr int LS = RP * (RM ? RM : 1);                    // butterflies of the last pass = its input stride
     static constexpr bool WAVE_LOCAL = ALIGNED && TPF <= 64;
-    static constexpr int NB = WAVE_LOCAL ? 1 : (RM ? 4 : 2);         // workgroup barriers of one slot
+    // GROUP_LOCAL: a transform is GL / 64 WHOLE waves (lanes aligned, more than 64 threads per transform) that meet at a counter in
+    // LDS instead of the workgroup barrier -- the exchanges of a transform then concern its own two to four waves only, a slot has ONE
+    // workgroup barrier like the wave-local geometries, and the storing half is not chopped into chunks to match the passes' barriers
+    static constexpr bool GROUP_LOCAL = GRP_ && ALIGNED && TPF > 64;
+    static constexpr bool SLOT1 = WAVE_LOCAL || GROUP_LOCAL;         // one workgroup barrier per slot, the taper double-buffered
+    static constexpr int NB = SLOT1 ? 1 : (RM ? 4 : 2);              // workgroup barriers of one slot
     // Exchange buffer of a transform (float2): phys(idx) = idx + (idx / LS) BP -- BP pad elements behind every block of LS = 10 RM.
     // What the pad is for: pass 2 writes runs of ten consecutive elements LS apart; with LS + BP = 10 (mod 16) the runs of a
     // 16-lane store group tile the 32 banks (BP = 6 at RM = 10 or 2; RM = 5 keeps 0: its runs start mid-decade), every other access
@@ -216,14 +221,14 @@ struct MixGeo {
     static constexpr size_t red_bytes = (size_t)2 * NF * (TPF + G1) * 4 * 8;
     static constexpr size_t un_bytes0 = z_bytes > tile_bytes ? z_bytes : tile_bytes;
     static constexpr size_t un_bytes = ((un_bytes0 > red_bytes ? un_bytes0 : red_bytes) + 15) / 16 * 16;
-    static constexpr size_t lds = un_bytes + (size_t)((RM ? RM * RP : 0) + N) * 8 + (size_t)N * 4 * (WAVE_LOCAL ? 2 : 1);
+    static constexpr size_t lds = un_bytes + (size_t)((RM ? RM * RP : 0) + N) * 8 + (size_t)N * 4 * (SLOT1 ? 2 : 1);
 };
 
 template <class GEO, bool PL>
 __global__ void __launch_bounds__(2 * GEO::HT, 2 * GEO::HT <= 512 ? 4 : 1) mtfft_mix_kernel(MixArgs p) {
     constexpr int N = GEO::N, RM = GEO::RM, RF = GEO::RF, HT = GEO::HT, RP = GEO::RP;
     constexpr int THREADS = 2 * HT, TPF = GEO::TPF, GL = GEO::GL, TPG = GEO::TPG, NF = GEO::NF, CTH = GEO::CTH, CT = GEO::CT;
-    constexpr bool WAVE_LOCAL = GEO::WAVE_LOCAL;
+    constexpr bool WAVE_LOCAL = GEO::WAVE_LOCAL, GROUP_LOCAL = GEO::GROUP_LOCAL, SLOT1 = GEO::SLOT1;
     constexpr int NB = GEO::NB, ZS = GEO::ZS, LS = GEO::LS, SUP = GEO::SUP, RS = GEO::RS;
     constexpr int F = N / 2 + 1;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -233,6 +238,7 @@ __global__ void __launch_bounds__(2 * GEO::HT, 2 * GEO::HT <= 512 ? 4 : 1) mtfft
     float* tap = reinterpret_cast<float*>(TF + N);                                // [N] the taper in use (zeros from L on); WAVE_LOCAL: [2][N]
     __shared__ int nzf[CT], nbf[CT];
     __shared__ unsigned mxc[CT];
+    __shared__ unsigned gcnt[16];                     // GROUP_LOCAL: arrivals at the group barriers, one counter per group of waves
 
     const int tid = threadIdx.x, half = tid / HT, ht = tid - half * HT;
     const int L = p.L, C = p.C, K = p.K;
@@ -259,6 +265,7 @@ __global__ void __launch_bounds__(2 * GEO::HT, 2 * GEO::HT <= 512 ? 4 : 1) mtfft
     float2* zh = zall + half * NF * ZS;
     float2* zf = zh + pfc * ZS;
     if (tid < CT) { nzf[tid] = 0; nbf[tid] = 0; mxc[tid] = 0u; }
+    if (tid < 16) gcnt[tid] = 0u;
     const bool detr = p.detrend != SC_DETREND_NONE;
     auto pair_scale = [](unsigned mx, bool inverse) -> float {
         const unsigned E = mx >> 23;
@@ -428,18 +435,31 @@ __global__ void __launch_bounds__(2 * GEO::HT, 2 * GEO::HT <= 512 ? 4 : 1) mtfft
     }
     auto zr_off = [&](int s) -> int { return ZCONST ? i + s * TPF + (s / (ZCONST ? LS / TPF : 1)) * BP : zr_tab[ZCONST ? 0 : s]; };
 
+    // The waves of one transform meet at a counter in LDS (GROUP_LOCAL): a wave's LDS instructions execute in order, so when the
+    // partners see the arrival their exchange writes are there too; the counter only grows (no reset, compared modulo 2^32).
+    unsigned epoch = 0u;
+    unsigned* const gc = gcnt + half * 8 + grp;
+    auto group_barrier = [&]() {
+        epoch += (unsigned)(GL / 64);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if ((tid & 63) == 0) __hip_atomic_fetch_add(gc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while ((int)(__hip_atomic_load(gc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - epoch) < 0) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
 #define XBAR()                                                      \
     do {                                                            \
         if constexpr (WAVE_LOCAL) {                                 \
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  \
             __builtin_amdgcn_wave_barrier();                        \
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  \
+        } else if constexpr (GROUP_LOCAL) {                         \
+            group_barrier();                                        \
         } else {                                                    \
             __syncthreads();                                        \
         }                                                           \
     } while (0)
     auto passes = [&](int k) {                        // NB workgroup barriers
-        const float* tk = WAVE_LOCAL ? tap + (k & 1) * N + i : tap + i;
+        const float* tk = SLOT1 ? tap + (k & 1) * N + i : tap + i;
         if (p.dbg & 2) {
 #pragma unroll
             for (int b = 0; b < NB; ++b) __syncthreads();
@@ -608,7 +628,7 @@ __global__ void __launch_bounds__(2 * GEO::HT, 2 * GEO::HT <= 512 ? 4 : 1) mtfft
         for (int ch = 0; ch < NB; ++ch) {
             if constexpr (PL) {
                 // (every chunk stores the frequencies of one NB-th of the lanes: the stream is spread over the slot)
-                if (!(p.dbg & 5) && (WAVE_LOCAL || pchunk == ch)) {
+                if (!(p.dbg & 5) && (SLOT1 || pchunk == ch)) {
 #pragma unroll
                     for (int it = 0; it < PIT; ++it) put_planes(k, it);
                 }
@@ -628,16 +648,16 @@ __global__ void __launch_bounds__(2 * GEO::HT, 2 * GEO::HT <= 512 ? 4 : 1) mtfft
                     if (ch * MC + e < MR && f <= N / 2) put(Xk + (int64_t)f * sF, z1[e], z2[e]);
                 }
             }
-            if constexpr (!WAVE_LOCAL) __syncthreads();
+            if constexpr (!SLOT1) __syncthreads();
             if (ch == 0 && park) {
                 // not WAVE_LOCAL: the other half has read the taper in use (its first interval), replace it; WAVE_LOCAL: the other buffer
-                float* tn = WAVE_LOCAL ? tap + ((k + 1) & 1) * N : tap;
+                float* tn = SLOT1 ? tap + ((k + 1) & 1) * N : tap;
 #pragma unroll
                 for (int j = 0; j < TPT; ++j)
                     if (ht + j * HT < N) tn[ht + j * HT] = hn[j];
             }
         }
-        if constexpr (WAVE_LOCAL) __syncthreads();
+        if constexpr (SLOT1) __syncthreads();
     };
 
     // Slot q of a half: taper q / 2, the passes in the even slots and the store in the odd ones; half 1 is one slot behind half 0.
@@ -688,53 +708,58 @@ static int64_t coverage_of(int64_t C, int dbg) {
 // holds the geometries that were tried and taken out again: 128- and 256-thread halves -- two to four workgroups per compute unit --
 // 2.4-2.5 TB/s where geometry 0 has 2.9-3.0 at 200 / 250 samples; six waves per SIMD with the registers capped at 80: 2.4-2.7; RP = 20
 // at 500 ... 1200 samples -- one wave per transform, eight pairs per half -- 1.6-2.5 TB/s against 2.0-2.9: its radix-20 pass needs
-// more than the 128 registers a 1024-thread workgroup has).  X(N, RM, RF, g, HT, ALIGNED, BP, ZPAD, RP)
+// more than the 128 registers a 1024-thread workgroup has).  X(N, RM, RF, g, HT, ALIGNED, BP, ZPAD, RP, GRP)
 #define MIX_GEOS(X)                                     \
-    X(200, 10, 2, 0, 256, true, 6, 6, 10)                   \
-    X(200, 10, 2, 1, 320, false, 6, 6, 10)                  \
-    X(200, 10, 2, 2, 512, true, 6, 6, 10)                   \
-    X(250, 5, 5, 0, 256, true, 0, 2, 10)                    \
-    X(250, 5, 5, 1, 448, false, 0, 0, 10)                   \
-    X(250, 5, 5, 2, 512, true, 0, 0, 10)                    \
-    X(300, 10, 3, 0, 256, true, 6, 6, 10)                   \
-    X(300, 10, 3, 1, 256, false, 6, 6, 10)                  \
-    X(300, 10, 3, 2, 512, true, 6, 6, 10)                   \
-    X(400, 10, 4, 0, 256, true, 6, 6, 10)                   \
-    X(400, 10, 4, 1, 320, false, 6, 6, 10)                  \
-    X(400, 10, 4, 2, 512, true, 6, 2, 10)                   \
-    X(500, 10, 5, 0, 256, true, 6, 12, 10)                  \
-    X(500, 10, 5, 1, 448, false, 6, 6, 10)                  \
-    X(500, 10, 5, 2, 512, true, 6, 0, 10)                   \
-    X(600, 10, 6, 0, 256, true, 6, 2, 10)                   \
-    X(600, 10, 6, 1, 512, false, 6, 6, 10)                  \
-    X(600, 10, 6, 2, 512, true, 6, 6, 10)                   \
-    X(750, 5, 15, 0, 320, false, 0, 10, 10)                 \
-    X(750, 5, 15, 1, 512, true, 0, 10, 10)                  \
-    X(800, 10, 8, 0, 320, false, 6, 14, 10)                 \
-    X(800, 10, 8, 1, 512, true, 6, 14, 10)                  \
-    X(1000, 10, 10, 0, 512, true, 6, 10, 10)                \
-    X(1000, 10, 10, 1, 448, false, 6, 10, 10)               \
-    X(1200, 10, 12, 0, 512, true, 6, 6, 10)                 \
-    X(1200, 10, 12, 1, 512, false, 6, 6, 10)                \
-    X(1500, 10, 15, 0, 320, false, 6, 0, 10)                \
-    X(1500, 10, 15, 1, 512, false, 6, 0, 10)                \
-    X(2000, 10, 20, 0, 448, false, 6, 14, 10)               \
-    X(2000, 10, 20, 1, 512, true, 6, 14, 10)             \
-    X(1000, 10, 5, 2, 384, true, 12, 4, 20)             \
-    X(2000, 10, 10, 2, 512, true, 2, 6, 20)             \
-    X(100, 0, 10, 0, 256, true, 0, 6, 10)               \
-    X(150, 5, 3, 0, 256, true, 0, 0, 10)                \
-    X(160, 2, 8, 0, 256, true, 6, 0, 10)                \
-    X(240, 2, 12, 0, 256, true, 8, 12, 10)              \
-    X(320, 2, 16, 0, 256, true, 0, 4, 10)               \
-    X(360, 2, 18, 0, 256, true, 0, 0, 10)               \
-    X(360, 2, 18, 1, 512, true, 0, 0, 10)               \
-    X(450, 5, 9, 0, 512, true, 0, 2, 10)                \
-    X(480, 2, 24, 0, 384, true, 8, 4, 10)               \
-    X(900, 10, 9, 0, 512, true, 6, 4, 10)               \
-    X(1250, 5, 25, 0, 384, true, 0, 6, 10)              \
-    X(1600, 10, 16, 0, 320, false, 6, 22, 10)           \
-    X(1800, 10, 18, 0, 384, false, 6, 2, 10)
+    X(200, 10, 2, 0, 256, true, 6, 6, 10, false)                   \
+    X(200, 10, 2, 1, 320, false, 6, 6, 10, false)                  \
+    X(200, 10, 2, 2, 512, true, 6, 6, 10, false)                   \
+    X(250, 5, 5, 0, 256, true, 0, 2, 10, false)                    \
+    X(250, 5, 5, 1, 448, false, 0, 0, 10, false)                   \
+    X(250, 5, 5, 2, 512, true, 0, 0, 10, false)                    \
+    X(300, 10, 3, 0, 256, true, 6, 6, 10, false)                   \
+    X(300, 10, 3, 1, 256, false, 6, 6, 10, false)                  \
+    X(300, 10, 3, 2, 512, true, 6, 6, 10, false)                   \
+    X(400, 10, 4, 0, 256, true, 6, 6, 10, false)                   \
+    X(400, 10, 4, 1, 320, false, 6, 6, 10, false)                  \
+    X(400, 10, 4, 2, 512, true, 6, 2, 10, false)                   \
+    X(500, 10, 5, 0, 256, true, 6, 12, 10, false)                  \
+    X(500, 10, 5, 1, 448, false, 6, 6, 10, false)                  \
+    X(500, 10, 5, 2, 512, true, 6, 0, 10, false)                   \
+    X(600, 10, 6, 0, 256, true, 6, 2, 10, false)                   \
+    X(600, 10, 6, 1, 512, false, 6, 6, 10, false)                  \
+    X(600, 10, 6, 2, 512, true, 6, 6, 10, false)                   \
+    X(750, 5, 15, 0, 320, false, 0, 10, 10, false)                 \
+    X(750, 5, 15, 1, 512, true, 0, 10, 10, false)                  \
+    X(750, 5, 15, 2, 512, true, 0, 10, 10, true)                  \
+    X(800, 10, 8, 0, 320, false, 6, 14, 10, false)                 \
+    X(800, 10, 8, 1, 512, true, 6, 14, 10, false)                  \
+    X(800, 10, 8, 2, 512, true, 6, 14, 10, true)                  \
+    X(1000, 10, 10, 0, 512, true, 6, 10, 10, false)                \
+    X(1000, 10, 10, 1, 448, false, 6, 10, 10, false)               \
+    X(1000, 10, 10, 3, 512, true, 6, 10, 10, true)               \
+    X(1200, 10, 12, 0, 512, true, 6, 6, 10, false)                 \
+    X(1200, 10, 12, 1, 512, false, 6, 6, 10, false)                \
+    X(1200, 10, 12, 2, 512, true, 6, 6, 10, true)                \
+    X(1500, 10, 15, 0, 320, false, 6, 0, 10, false)                \
+    X(1500, 10, 15, 1, 512, false, 6, 0, 10, false)                \
+    X(2000, 10, 20, 0, 448, false, 6, 14, 10, false)               \
+    X(2000, 10, 20, 1, 512, true, 6, 14, 10, false)             \
+    X(1000, 10, 5, 2, 384, true, 12, 4, 20, false)             \
+    X(2000, 10, 10, 2, 512, true, 2, 6, 20, false)             \
+    X(100, 0, 10, 0, 256, true, 0, 6, 10, false)               \
+    X(150, 5, 3, 0, 256, true, 0, 0, 10, false)                \
+    X(160, 2, 8, 0, 256, true, 6, 0, 10, false)                \
+    X(240, 2, 12, 0, 256, true, 8, 12, 10, false)              \
+    X(320, 2, 16, 0, 256, true, 0, 4, 10, false)               \
+    X(360, 2, 18, 0, 256, true, 0, 0, 10, false)               \
+    X(360, 2, 18, 1, 512, true, 0, 0, 10, false)               \
+    X(450, 5, 9, 0, 512, true, 0, 2, 10, false)                \
+    X(480, 2, 24, 0, 384, true, 8, 4, 10, false)               \
+    X(900, 10, 9, 0, 512, true, 6, 4, 10, false)               \
+    X(900, 10, 9, 1, 512, true, 6, 4, 10, true)               \
+    X(1250, 5, 25, 0, 384, true, 0, 6, 10, false)              \
+    X(1600, 10, 16, 0, 320, false, 6, 22, 10, false)           \
+    X(1800, 10, 18, 0, 384, false, 6, 2, 10, false)
 
 static int mix_dbg() {
     const char* d = sc_switch(SC_SW_MTFFT_DEBUG);
@@ -742,7 +767,7 @@ static int mix_dbg() {
 }
 static bool mix_has_geo(int64_t N, int g) {
     switch (N * 8 + g) {
-#define X(NN, RM, RF, GI, HT, AL, BP, ZP, RP) case NN * 8 + GI: return true;
+#define X(NN, RM, RF, GI, HT, AL, BP, ZP, RP, GRP) case NN * 8 + GI: return true;
         MIX_GEOS(X)
 #undef X
     }
@@ -761,8 +786,13 @@ static int mix_geo(int64_t N, bool planes) {
     // 400 ... 600 samples: one transform per wave, eight pairs per half, one workgroup of sixteen waves per compute unit (geometry 2):
     // 2.09 / 1.86 ms against 2.22 / 2.21 at 500 / 600 samples, and the planes output 2.18-2.48 against 2.5-3.1 ms
     if (N == 400 || N == 500 || N == 600) return 2;
-    if (planes) return N == 300 ? 2 : ((N == 800 || N == 1500 || N == 360) ? 1 : 0);
-    return N == 1200 ? 1 : 0;
+    // two waves per transform meeting at a counter in LDS instead of the workgroup barrier (GROUP_LOCAL): the planes output gains
+    // 0.2-0.7 ms at 750 ... 1200 samples (its store slot is no longer cut into chunks), the complex64 output only at 900 ... 1200
+    if (N == 1000) return 3;
+    if (N == 1200) return 2;
+    if (N == 900) return 1;
+    if (planes) return N == 300 ? 2 : ((N == 750 || N == 800) ? 2 : ((N == 1500 || N == 360) ? 1 : 0));
+    return 0;
 }
 
 bool sc_internal_mtfft_mix_has(int64_t N) { return mix_has_geo(N, 0); }
@@ -779,7 +809,7 @@ bool sc_internal_mtfft_mix_applies(int64_t N, int64_t C, int64_t groups) {
     if (e && atoi(e) == 1) return true;
     int64_t n_ct = 1;
     switch (N * 8 + mix_geo(N, false)) {
-#define X(NN, RM, RF, GI, HT, AL, BP, ZP, RP) case NN * 8 + GI: n_ct = tiles_of<MixGeo<NN, RM, RF, HT, AL, BP, ZP, RP>>(C, mix_dbg()); break;
+#define X(NN, RM, RF, GI, HT, AL, BP, ZP, RP, GRP) case NN * 8 + GI: n_ct = tiles_of<MixGeo<NN, RM, RF, HT, AL, BP, ZP, RP, GRP>>(C, mix_dbg()); break;
         MIX_GEOS(X)
 #undef X
     }
@@ -789,7 +819,7 @@ bool sc_internal_mtfft_mix_applies(int64_t N, int64_t C, int64_t groups) {
 int64_t sc_internal_mtfft_mix_coverage(int64_t N, int64_t C, bool planes) {
     const int dbg = mix_dbg();
     switch (N * 8 + mix_geo(N, planes)) {
-#define X(NN, RM, RF, GI, HT, AL, BP, ZP, RP) case NN * 8 + GI: return coverage_of<MixGeo<NN, RM, RF, HT, AL, BP, ZP, RP>>(C, dbg);
+#define X(NN, RM, RF, GI, HT, AL, BP, ZP, RP, GRP) case NN * 8 + GI: return coverage_of<MixGeo<NN, RM, RF, HT, AL, BP, ZP, RP, GRP>>(C, dbg);
         MIX_GEOS(X)
 #undef X
     }
@@ -808,7 +838,7 @@ int sc_internal_mtfft_mix(const float* d_x, int64_t T, int64_t R, int64_t C, int
     a.dbg = mix_dbg();
     SC_REQUIRE((W - 1) * step + L <= T, "windows exceed the time series");
     switch (N * 8 + mix_geo(N, d_P != nullptr)) {
-#define X(NN, RM, RF, GI, HT, AL, BP, ZP, RP) case NN * 8 + GI: return launch_mix<MixGeo<NN, RM, RF, HT, AL, BP, ZP, RP>>(a, st);
+#define X(NN, RM, RF, GI, HT, AL, BP, ZP, RP, GRP) case NN * 8 + GI: return launch_mix<MixGeo<NN, RM, RF, HT, AL, BP, ZP, RP, GRP>>(a, st);
         MIX_GEOS(X)
 #undef X
     }
