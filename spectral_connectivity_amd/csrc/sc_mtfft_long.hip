@@ -73,7 +73,7 @@ __device__ __forceinline__ void ml_quad_xchg(ml_u32x4& a, ml_u32x4& b, bool hi) 
     }
 }
 
-template <int LOG2N, int HT, bool PL>
+template <int LOG2N, int HT, bool PL, bool GRP = false>
 __global__ void __launch_bounds__(2 * HT, HT == 512 ? 1 : 4) mtfft_long_kernel(LongArgs p) {
     constexpr int N = 1 << LOG2N;
     constexpr int THREADS = 2 * HT;
@@ -87,7 +87,13 @@ __global__ void __launch_bounds__(2 * HT, HT == 512 ? 1 : 4) mtfft_long_kernel(L
     // workgroup barrier -- ONE barrier per slot (the hand-over between the halves), the waves of a half run free in between, and
     // the taper is double-buffered instead of parked behind a barrier.
     constexpr bool WAVE_LOCAL = TPF <= 64;
-    constexpr int NB = WAVE_LOCAL ? 1 : 4;                           // workgroup barriers of one slot
+    // GROUP_LOCAL (round 6, 2048 samples): the WPF waves of a transform meet at a counter in LDS instead of the workgroup barrier (as in
+    // sc_mtfft_mixed.hip): a slot has one workgroup barrier like the wave-local lengths, the taper is double-buffered, and the store
+    // slot is not cut into chunks -- the planes output gains most (its four stores per thread leave in one go).  4096 samples keep the
+    // barriers: a second taper buffer does not fit beside its exchange buffers.
+    constexpr bool GROUP_LOCAL = GRP && !WAVE_LOCAL;
+    constexpr bool SLOT1 = WAVE_LOCAL || GROUP_LOCAL;
+    constexpr int NB = SLOT1 ? 1 : 4;                                // workgroup barriers of one slot
     static_assert(LOG2N >= 8 && LOG2N <= 12, "256 ... 4096 samples");
     extern __shared__ __align__(16) unsigned char smem[];
     float2* zall = reinterpret_cast<float2*>(smem);             // [2][NF][ZS]
@@ -99,7 +105,8 @@ __global__ void __launch_bounds__(2 * HT, HT == 512 ? 1 : 4) mtfft_long_kernel(L
     float2* T2 = zall + 2 * NF * ZS;                             // [16][16]
     float2* TH = LOG2N == 12 ? T2 : T2 + 256;                    // [M][16]
     float2* TL = TH + (LOG2N == 12 ? 256 : M * 16);              // [M][16]
-    float* tap = reinterpret_cast<float*>(TL + M * 16);          // [N] the taper in use (zeros from L on); WAVE_LOCAL: [2][N]
+    float* tap = reinterpret_cast<float*>(TL + M * 16);          // [N] the taper in use (zeros from L on); SLOT1: [2][N]
+    __shared__ unsigned gcnt[16];                                // GROUP_LOCAL: arrivals at the group barriers, one counter per transform
     __shared__ int nzf[CT], nbf[CT];
     __shared__ unsigned mxc[CT];
     __shared__ double red[THREADS / 64][4];                      // trend sums per wave
@@ -133,6 +140,7 @@ __global__ void __launch_bounds__(2 * HT, HT == 512 ? 1 : 4) mtfft_long_kernel(L
     float2* zh = zall + half * NF * ZS;
     float2* zf = zh + pf * ZS;
     if (tid < CT) { nzf[tid] = 0; nbf[tid] = 0; mxc[tid] = 0u; }
+    if (tid < 16) gcnt[tid] = 0u;
     static_assert(THREADS >= 256 + M * 16, "table fill");
     if (tid < 256) T2[tid] = p.tw[((tid >> 4) * (tid & 15)) * (N / 256)];
     else if (tid < 256 + M * 16) {
@@ -323,19 +331,30 @@ __global__ void __launch_bounds__(2 * HT, HT == 512 ? 1 : 4) mtfft_long_kernel(L
     const float2* const th = TH + (i >> 4);                                            // pass 3, butterfly b: th[16 t + b TPF / 16]
     const float2* const tl = TL + kk;                                                  //         tl[16 t]
 
+    unsigned epoch = 0u;
+    unsigned* const gc = gcnt + half * NF + pf;
+    auto group_barrier = [&]() {                      // (a wave's LDS instructions execute in order: the arrival is behind its exchange writes)
+        epoch += (unsigned)WPF;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if ((tid & 63) == 0) __hip_atomic_fetch_add(gc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while ((int)(__hip_atomic_load(gc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - epoch) < 0) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
 #define PBAR()                                                      \
     do {                                                            \
         if constexpr (WAVE_LOCAL) {                                 \
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  \
             __builtin_amdgcn_wave_barrier();                        \
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  \
+        } else if constexpr (GROUP_LOCAL) {                         \
+            group_barrier();                                        \
         } else {                                                    \
             __syncthreads();                                        \
         }                                                           \
     } while (0)
     auto passes = [&](int k) {                        // NB workgroup barriers
         float2 a[16], o[16];
-        const float* tk = WAVE_LOCAL ? tap + (k & 1) * N + i : tap + i;
+        const float* tk = SLOT1 ? tap + (k & 1) * N + i : tap + i;
         if (p.dbg & 2) {
 #pragma unroll
             for (int b = 0; b < NB; ++b) __syncthreads();
@@ -546,16 +565,16 @@ __global__ void __launch_bounds__(2 * HT, HT == 512 ? 1 : 4) mtfft_long_kernel(L
                     put(Xk + 8 * sR, zn, zn);
                 }
             }
-            if constexpr (!WAVE_LOCAL) __syncthreads();
+            if constexpr (!SLOT1) __syncthreads();
             if (ch == 0 && park) {
                 // not WAVE_LOCAL: the other half has read the taper in use (its first interval), replace it; WAVE_LOCAL: the other buffer
-                float* tn = WAVE_LOCAL ? tap + ((k + 1) & 1) * N : tap;
+                float* tn = SLOT1 ? tap + ((k + 1) & 1) * N : tap;
 #pragma unroll
                 for (int j = 0; j < TPT; ++j)
                     if (ht + j * HT < N) tn[ht + j * HT] = hn[j];
             }
         }
-        if constexpr (WAVE_LOCAL) __syncthreads();
+        if constexpr (SLOT1) __syncthreads();
     };
 
     // Slot q of a half: taper q / 2, the passes in the even slots and the store in the odd ones; half 1 is one slot behind half 0.
@@ -603,12 +622,12 @@ int64_t sc_internal_mtfft_long_coverage(int64_t N, int64_t C) {
     return (C > 16 && sup > 1 && !(dbg & 32)) ? (C + sup * ct - 1) / (sup * ct) * sup * ct : (C + ct - 1) / ct * ct;
 }
 
-template <int LOG2N, int HT, bool PL>
+template <int LOG2N, int HT, bool PL, bool GRP = false>
 static int launch_long_(LongArgs a, hipStream_t st) {
     constexpr int N = 1 << LOG2N, TPF = N / 16, NF = HT / TPF, CT = 4 * NF, ZS = N + N / 16 + 1;
-    constexpr size_t lds = (size_t)2 * NF * ZS * 8 + (256 + (LOG2N == 12 ? 256 : 2 * (N / 256) * 16)) * 8 + (size_t)N * 4 * (TPF <= 64 ? 2 : 1);
+    constexpr size_t lds = (size_t)2 * NF * ZS * 8 + (256 + (LOG2N == 12 ? 256 : 2 * (N / 256) * 16)) * 8 + (size_t)N * 4 * ((TPF <= 64 || GRP) ? 2 : 1);
     static_assert((lds + 512) * (HT == 512 ? 1 : 2) <= 160 * 1024, "LDS budget exceeded");      // (+ the static flags and trend sums)
-    auto k = mtfft_long_kernel<LOG2N, HT, PL>;
+    auto k = mtfft_long_kernel<LOG2N, HT, PL, GRP>;
     SC_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     constexpr int SUP = 2 * NF >= 16 ? 1 : 16 / (2 * NF);      // = the kernel's
     const int64_t n_ct = (a.C > 16 && SUP > 1 && !(a.dbg & 32)) ? (a.C + SUP * CT - 1) / (SUP * CT) * SUP : (a.C + CT - 1) / CT;
@@ -642,9 +661,9 @@ static int launch_long_(LongArgs a, hipStream_t st) {
     return SC_OK;
 }
 
-template <int LOG2N, int HT>
+template <int LOG2N, int HT, bool GRP = false>
 static int launch_long(const LongArgs& a, hipStream_t st) {
-    return a.P ? launch_long_<LOG2N, HT, true>(a, st) : launch_long_<LOG2N, HT, false>(a, st);
+    return a.P ? launch_long_<LOG2N, HT, true, GRP>(a, st) : launch_long_<LOG2N, HT, false, GRP>(a, st);
 }
 
 int sc_internal_mtfft_long(const float* d_x, int64_t T, int64_t R, int64_t C, int64_t L, int64_t step, int64_t W, int64_t N,
@@ -662,7 +681,7 @@ int sc_internal_mtfft_long(const float* d_x, int64_t T, int64_t R, int64_t C, in
     case 256: return (a.dbg & 64) ? launch_long<8, 512>(a, st) : launch_long<8, 256>(a, st);
     case 512: return (a.dbg & 64) ? launch_long<9, 512>(a, st) : launch_long<9, 256>(a, st);
     case 1024: return (a.dbg & 64) ? launch_long<10, 256>(a, st) : launch_long<10, 512>(a, st);
-    case 2048: return launch_long<11, 512>(a, st);
+    case 2048: return (a.dbg & 256) ? launch_long<11, 512>(a, st) : launch_long<11, 512, true>(a, st);      // (256: the barrier form, A/B)
     case 4096: return launch_long<12, 512>(a, st);
     }
     return SC_EUNSUPPORTED;
