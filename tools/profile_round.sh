@@ -32,6 +32,9 @@ for d in kt fetch write sq sq2 kt4 fetch4 write4; do
     [ -n "$db" ] && python tools/rocpd_summary.py $db > $OUT/$d.txt 2>&1
     rm -rf $OUT/$d          # (the raw databases are hundreds of MB: gpurun copies back at most 64 MB)
 done
+if [ "${PARTIAL:-0}" = "1" ]; then      # only the bench line, its kernel stats and the PMC passes (after a change to a kernel in bench.py's source hash)
+  ls -la $OUT; exit 0
+fi
 # Round 6: only what changed or what the bench line needs is measured again (the review of round 5: GPU minutes belong to kernels, not to
 # re-measuring unchanged ones); FULL=1 adds the whole round-5 set (MVAR sizes, stage-B ablations, issue rates, ...), whose r05 files stand.
 python tools/shape_sweep.py > $OUT/shape_sweep.txt 2>&1
