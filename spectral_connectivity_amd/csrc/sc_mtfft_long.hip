@@ -120,8 +120,14 @@ __global__ void __launch_bounds__(2 * HT, HT == 512 ? 1 : 4) mtfft_long_kernel(L
     // phase, on one XCD, dispatched back to back -- hold 16 ADJACENT channels: their pieces complete a 128-byte line in that XCD's
     // L2 within a store chunk, where the two halves of one workgroup are a phase apart (N = 4096: 2.8 -> 2.1 ms).  Up to 16
     // channels: no super-tiles.
-    constexpr int SUP = CTH >= 16 ? 1 : 16 / CTH;
-    const bool sup = C > 16 && SUP > 1 && !(p.dbg & 32);
+    // Planes output (round 6): a 128-byte line of a tile row is two planes of THIRTY-TWO channels, so the pieces of 32 adjacent channels
+    // must meet in the L2 -- super-tiles of 32 / CTH workgroups there (two at 512 / 1024 samples, where the complex64 output needs
+    // none: before, a line waited for the other half of its own workgroup, a phase later).
+    // (512 / 1024 / 2048 samples: 2.6 / 2.5 / 2.1 -> 1.8 / 1.4 / 1.5 ms at the cfg3 volume, the complex64 output's 1.6 / 1.4 / 1.3; 4096 samples
+    //  keep four workgroups per super-tile: eight were slower, 2.58 against 2.40 ms; profiles/r06_stage_a_planes_sup.txt)
+    constexpr int LINE_CH = (PL && LOG2N <= 11) ? 32 : 16;
+    constexpr int SUP = CTH >= LINE_CH ? 1 : LINE_CH / CTH;
+    const bool sup = C > LINE_CH && SUP > 1 && !(p.dbg & 32);
     const int n_ct = sup ? (C + SUP * CT - 1) / (SUP * CT) * SUP : (C + CT - 1) / CT;
     int ch0[2], w, r;                                 // first channel of either half
     {
@@ -615,11 +621,12 @@ bool sc_internal_mtfft_long_applies(int64_t N, int64_t C, int64_t groups) {
 // the channels the workgroups of a launch write (planes output: where this leaves part of the last 32-channel tile unwritten, the
 // caller clears the buffer first)
 int64_t sc_internal_mtfft_long_coverage(int64_t N, int64_t C) {
-    const int64_t ht = N <= 512 ? 256 : 512, nf = ht / (N / 16), ct = 4 * nf, sup = 2 * nf >= 16 ? 1 : 16 / (2 * nf);
+    // (called for the planes output only: its super-tiles span 32 channels)
+    const int64_t ht = N <= 512 ? 256 : 512, nf = ht / (N / 16), ct = 4 * nf, line = N <= 2048 ? 32 : 16, sup = 2 * nf >= line ? 1 : line / (2 * nf);
     const char* d = sc_switch(SC_SW_MTFFT_DEBUG);
     const int dbg = d ? atoi(d) : 0;
     if (dbg & 64) return 0;                                           // (A/B of the other workgroup size: always clear)
-    return (C > 16 && sup > 1 && !(dbg & 32)) ? (C + sup * ct - 1) / (sup * ct) * sup * ct : (C + ct - 1) / ct * ct;
+    return (C > line && sup > 1 && !(dbg & 32)) ? (C + sup * ct - 1) / (sup * ct) * sup * ct : (C + ct - 1) / ct * ct;
 }
 
 template <int LOG2N, int HT, bool PL, bool GRP = false>
@@ -629,8 +636,8 @@ static int launch_long_(LongArgs a, hipStream_t st) {
     static_assert((lds + 512) * (HT == 512 ? 1 : 2) <= 160 * 1024, "LDS budget exceeded");      // (+ the static flags and trend sums)
     auto k = mtfft_long_kernel<LOG2N, HT, PL, GRP>;
     SC_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    constexpr int SUP = 2 * NF >= 16 ? 1 : 16 / (2 * NF);      // = the kernel's
-    const int64_t n_ct = (a.C > 16 && SUP > 1 && !(a.dbg & 32)) ? (a.C + SUP * CT - 1) / (SUP * CT) * SUP : (a.C + CT - 1) / CT;
+    constexpr int LINE_CH = (PL && LOG2N <= 11) ? 32 : 16, SUP = 2 * NF >= LINE_CH ? 1 : LINE_CH / (2 * NF);      // = the kernel's
+    const int64_t n_ct = (a.C > LINE_CH && SUP > 1 && !(a.dbg & 32)) ? (a.C + SUP * CT - 1) / (SUP * CT) * SUP : (a.C + CT - 1) / CT;
     // Slices (SC_MTFFT_SLICE=<dispatch rounds per launch>, default 0 = one launch; an A/B switch).  Round 5 saw N = 4096 fall from 2.7-2.8
     // TB/s at 3.7 GB of spectra to 1.96 at 11 GB, whatever the number of windows.  Round 6 (profiles/r06_stage_a_volume.txt): it is the
     // STORE stream and the FOOTPRINT -- with the passes off the stores of 3.7 GB take 0.72 ms (5.1 TB/s), those of 11 GB 4.05 ms (2.7

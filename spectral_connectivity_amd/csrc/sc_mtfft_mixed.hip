@@ -212,7 +212,11 @@ struct MixGeo {
     static constexpr int BP = BP_;
     static_assert(BP % 2 == 0 && ZPAD_ % 2 == 0, "16-byte pieces");
     static constexpr int ZS = N + ((N - 1) / LS) * BP + ZPAD_;
+    // super-tiles: the workgroups whose pieces complete a 128-byte line run back to back on one XCD -- 16 channels of the complex64
+    // rows, 32 of the planes rows (a line there is two planes of a 32-channel tile)
     static constexpr int SUP = (CTH >= 16 || 16 % CTH != 0) ? 1 : 16 / CTH;
+    static constexpr int SUP_PL = SUP;      // (32-channel super-tiles for the planes rows -- what the power-of-two kernel gained 0.6-1.1 ms from --
+                                            //  changed nothing here at 250 ... 1200 samples and cost 0.15 ms at 800: r06_stage_a_planes_sup.txt)
     static constexpr int RS = CT + 2;                                // padded row of the window tile (floats)
     static constexpr size_t z_bytes = (size_t)2 * NF * ZS * 8;
     static constexpr size_t tile_bytes = (size_t)(N / 2) * RS * 4;
@@ -229,7 +233,7 @@ __global__ void __launch_bounds__(2 * GEO::HT, 2 * GEO::HT <= 512 ? 4 : 1) mtfft
     constexpr int N = GEO::N, RM = GEO::RM, RF = GEO::RF, HT = GEO::HT, RP = GEO::RP;
     constexpr int THREADS = 2 * HT, TPF = GEO::TPF, GL = GEO::GL, TPG = GEO::TPG, NF = GEO::NF, CTH = GEO::CTH, CT = GEO::CT;
     constexpr bool WAVE_LOCAL = GEO::WAVE_LOCAL, GROUP_LOCAL = GEO::GROUP_LOCAL, SLOT1 = GEO::SLOT1;
-    constexpr int NB = GEO::NB, ZS = GEO::ZS, LS = GEO::LS, SUP = GEO::SUP, RS = GEO::RS;
+    constexpr int NB = GEO::NB, ZS = GEO::ZS, LS = GEO::LS, SUP = PL ? GEO::SUP_PL : GEO::SUP, RS = GEO::RS, LINE_CH = 16;
     constexpr int F = N / 2 + 1;
     extern __shared__ __align__(16) unsigned char smem[];
     float2* zall = reinterpret_cast<float2*>(smem);                               // [2][NF][ZS]
@@ -243,7 +247,7 @@ __global__ void __launch_bounds__(2 * GEO::HT, 2 * GEO::HT <= 512 ? 4 : 1) mtfft
     const int tid = threadIdx.x, half = tid / HT, ht = tid - half * HT;
     const int L = p.L, C = p.C, K = p.K;
     // items: as in sc_mtfft_long.hip -- workgroup b takes (window, trial, channel tile), the tiles of one (window, trial) on ONE XCD
-    const bool sup = C > 16 && SUP > 1 && !(p.dbg & 32);
+    const bool sup = C > LINE_CH && SUP > 1 && !(p.dbg & 32);
     const int n_ct = sup ? (C + SUP * CT - 1) / (SUP * CT) * SUP : (C + CT - 1) / CT;
     int ch0[2], w, r;
     {
@@ -682,8 +686,8 @@ static int launch_mix_(MixArgs a, hipStream_t st) {
     static_assert(GEO::lds + 1024 <= 160 * 1024, "LDS budget exceeded");
     auto k = mtfft_mix_kernel<GEO, PL>;
     SC_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEO::lds));
-    constexpr int SUP = GEO::SUP, CT = GEO::CT;
-    const int64_t n_ct = (a.C > 16 && SUP > 1 && !(a.dbg & 32)) ? (a.C + SUP * CT - 1) / (SUP * CT) * SUP : (a.C + CT - 1) / CT;
+    constexpr int SUP = PL ? GEO::SUP_PL : GEO::SUP, CT = GEO::CT, LINE_CH = 16;
+    const int64_t n_ct = (a.C > LINE_CH && SUP > 1 && !(a.dbg & 32)) ? (a.C + SUP * CT - 1) / (SUP * CT) * SUP : (a.C + CT - 1) / CT;
     const int64_t groups8 = ((int64_t)a.W * a.R + 7) / 8 * 8;
     if (groups8 * n_ct >= ((int64_t)1 << 31)) {
         sc_set_error("multitaper FFT (N=%d): too many windows x trials for one launch", GEO::N);
@@ -697,10 +701,10 @@ template <class GEO>
 static int launch_mix(const MixArgs& a, hipStream_t st) {
     return a.P ? launch_mix_<GEO, true>(a, st) : launch_mix_<GEO, false>(a, st);
 }
-template <class GEO>
+template <class GEO, bool PL = true>
 static int64_t coverage_of(int64_t C, int dbg) {
-    constexpr int SUP = GEO::SUP, CT = GEO::CT;
-    return (C > 16 && SUP > 1 && !(dbg & 32)) ? (C + SUP * CT - 1) / (SUP * CT) * SUP * CT : (C + CT - 1) / CT * CT;
+    constexpr int SUP = PL ? GEO::SUP_PL : GEO::SUP, CT = GEO::CT, LINE_CH = 16;
+    return (C > LINE_CH && SUP > 1 && !(dbg & 32)) ? (C + SUP * CT - 1) / (SUP * CT) * SUP * CT : (C + CT - 1) / CT * CT;
 }
 
 // The instantiated lengths and their geometries (threads of a half, lanes aligned to waves or packed, block pad, transform pad);
@@ -798,7 +802,7 @@ static int mix_geo(int64_t N, bool planes) {
 bool sc_internal_mtfft_mix_has(int64_t N) { return mix_has_geo(N, 0); }
 
 template <class GEO>
-static int64_t tiles_of(int64_t C, int dbg) { return coverage_of<GEO>(C, dbg) / GEO::CT; }
+static int64_t tiles_of(int64_t C, int dbg) { return coverage_of<GEO, false>(C, dbg) / GEO::CT; }
 
 // SC_MTFFT_MIXED=0: never (the round-2 kernels); =1: whatever the size (tests); unset: when the launch gives every compute unit a
 // workgroup (a workgroup here holds 16 ... 48 channels; a small problem fills the chip better with the one-wave-per-pair kernels)
