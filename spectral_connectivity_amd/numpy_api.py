@@ -281,7 +281,7 @@ class Connectivity(_TorchHostConnectivity):
         fn = h.lib.sc_measure_f64 if wide else h.lib.sc_measure_f32
         _lib.check(fn(rec.buf.ptr, rec.n_bins, C, rec.planes(have), self._n_observations_total(n_obs), which, out.ptr, h.stream),
                    "sc_measure")
-        res = np.array(h.download(out, shape, dt))
+        res = h.download(out, shape, dt)        # (the page-locked array itself: its owner recycles the block with the last view)
         out.free()
         tail = (C,) if which == _lib.M_POWER else (C, C)
         return res.reshape(self._kept_shape() + (self._n_freq,) + tail)
@@ -319,7 +319,7 @@ class Connectivity(_TorchHostConnectivity):
             status_all.append(np.array(h.download(st_c, (n_groups * n,), np.int32)))
             for b in (d_pairs, it_c, st_c):
                 b.free()
-        res = np.array(h.download(out, (n_groups, F, C, C), np.float64))
+        res = h.download(out, (n_groups, F, C, C), np.float64)
         work.free(); out.free()
         status = np.concatenate(status_all)
         if fallback:
@@ -374,7 +374,7 @@ class Connectivity(_TorchHostConnectivity):
         dt = np.complex128 if cplx else np.float64
         dev = h.alloc(int(np.prod(shape)) * np.dtype(dt).itemsize)
         _lib.check(h.lib.sc_mvar_measure_f64(G.ptr, n_groups, N, C, which, dev.ptr, work.ptr, nbytes, h.stream), "sc_mvar_measure_f64")
-        out = np.array(h.download(dev, shape, dt))
+        out = h.download(dev, shape, dt)
         dev.free()
         return out.reshape(self._kept_shape() + shape[1:])
 
