@@ -223,6 +223,10 @@ class Connectivity(_TorchHostConnectivity):
         if (getattr(sp, "P", None) is not None and planes == _lib.PLANE_CSM and options.anticipate_phase_lag
                 and self._planes_request_ok(_lib.PLANE_CSM | _lib.PLANE_ABS_IM)):
             planes = _lib.PLANE_CSM | _lib.PLANE_ABS_IM            # (Connectivity._accumulators: coherence then wPLI is one pass)
+        elif getattr(sp, "f64", False) and planes == _lib.PLANE_CSM and options.anticipate_phase_lag and not isinstance(sp, _WideSeries):
+            # float64 engine on this host: a later phase-lag request cannot copy the families a record already holds (the PyTorch
+            # host does, with a strided device copy) and would accumulate everything again -- the |Im s| plane rides along instead
+            planes = _lib.PLANE_CSM | _lib.PLANE_ABS_IM
         if getattr(sp, "P", None) is not None and not host().lib.sc_fused2_supported(
                 byref(host()._desc(sp, self.expectation_type, True, self._n_freq)), planes):
             # spectra held as f16 pieces, and a family their kernels do not take (PLV after coherence, ...): decoded once
