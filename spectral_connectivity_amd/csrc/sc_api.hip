@@ -18,7 +18,7 @@ void sc_set_error(const char* fmt, ...) {
 static const char* const g_switch_names[SC_SW_COUNT] = {
     "SC_FUSED_DEBUG", "SC_FUSED2_TERMS", "SC_FUSED_SPLIT", "SC_FUSED_NO_SMALL", "SC_MTFFT_DEBUG", "SC_MTFFT_WIDE", "SC_MTFFT_F64",
     "SC_F64_SPLIT", "SC_F64_OC", "SC_F64_NO_FORK", "SC_F64_NO_BLOCK", "SC_WILSON_FFT", "SC_GLOBAL_EIG", "SC_GLOBAL_NT256",
-    "SC_GRANGER_KERNEL", "SC_FUSED_FOLD_OBS", "SC_MTFFT_LONG", "SC_CANON_EIG", "SC_MTFFT_MIXED", "SC_MTFFT_MIXED_GEO", "SC_MTFFT_SLICE"};
+    "SC_GRANGER_KERNEL", "SC_FUSED_FOLD_OBS", "SC_MTFFT_LONG", "SC_CANON_EIG", "SC_MTFFT_MIXED", "SC_MTFFT_MIXED_GEO", "SC_MTFFT_SLICE", "SC_MVAR_INVERSE"};
 static char g_switch_val[SC_SW_COUNT][32];
 static bool g_switch_set[SC_SW_COUNT];
 extern "C" int sc_debug_reload_env(void) {

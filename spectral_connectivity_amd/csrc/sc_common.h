@@ -13,7 +13,7 @@ void sc_set_error(const char* fmt, ...);
 enum ScSwitch {
     SC_SW_FUSED_DEBUG, SC_SW_FUSED2_TERMS, SC_SW_FUSED_SPLIT, SC_SW_FUSED_NO_SMALL, SC_SW_MTFFT_DEBUG, SC_SW_MTFFT_WIDE,
     SC_SW_MTFFT_F64, SC_SW_F64_SPLIT, SC_SW_F64_OC, SC_SW_F64_NO_FORK, SC_SW_F64_NO_BLOCK, SC_SW_WILSON_FFT, SC_SW_GLOBAL_EIG,
-    SC_SW_GLOBAL_NT256, SC_SW_GRANGER_KERNEL, SC_SW_FUSED_FOLD_OBS, SC_SW_MTFFT_LONG, SC_SW_CANON_EIG, SC_SW_MTFFT_MIXED, SC_SW_MTFFT_MIXED_GEO, SC_SW_MTFFT_SLICE, SC_SW_COUNT
+    SC_SW_GLOBAL_NT256, SC_SW_GRANGER_KERNEL, SC_SW_FUSED_FOLD_OBS, SC_SW_MTFFT_LONG, SC_SW_CANON_EIG, SC_SW_MTFFT_MIXED, SC_SW_MTFFT_MIXED_GEO, SC_SW_MTFFT_SLICE, SC_SW_MVAR_INVERSE, SC_SW_COUNT
 };
 const char* sc_switch(int id);
 

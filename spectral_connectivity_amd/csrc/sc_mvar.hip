@@ -679,6 +679,177 @@ __global__ void __launch_bounds__(512) m_inverse_inplace(MvMat M, const double* 
         }
 }
 
+// Out = (M + lam I)^-1 for 65 ... 128 signals, third generation (round 6): the same pivoted Gauss-Jordan, sixteen pivots at a
+// time.  m_inverse_inplace pays two workgroup barriers, a pivot search and a division for every rank-1 update of the whole
+// matrix: 128 dependent steps of ~3 800 cycles where the arithmetic of a step is 1 000 (0.27 of the fp64 rate).  Here the
+// matrix sits in the registers of the workgroup as matrix-core accumulator tiles (wave w: tile row w, every tile column,
+// (re, im) x 4 doubles per tile and lane -- the layout m_gemm_mfma produces), and one PANEL of sixteen columns at a time
+// goes through the dependent steps:
+//   1. tile column kb of every wave -> LDS; thread (row r, column quad g) keeps four panel entries of its row in registers;
+//   2. sixteen pivot steps on the 16 Q x 16 panel alone, ONE barrier each: after its update every thread publishes its
+//      four entries (and the search key of the next column), so that after the barrier any thread finds the pivot row
+//      (search over the rows not used yet, no row ever moves), reads the pivot, its own multiplier and the four pivot-row
+//      entries it needs, and takes the reciprocal itself (v_rcp_f64 + two Newton steps: a division would be a third of
+//      the dependent chain) -- the in-place trick of m_inverse_inplace: the pivot's slot takes 1 / pivot, the slot of
+//      row r takes -m_r / pivot; afterwards column j of the panel is column pr_j of the product E of the sixteen row operations;
+//   3. the sixteen pivot rows (old values, all columns) leave the accumulators for LDS and are cleared there;
+//   4. W <- W + E[:, pivots] R on the matrix cores: 4 x (Q - 1) x 4 v_mfma_f64_16x16x4 per wave, A operand = the panel,
+//      B operand = the pivot rows, both from LDS; tile column kb takes the panel itself.
+// 19 barriers per panel instead of 32 per sixteen whole-matrix updates, and the O(C^3) work without a dependent step.
+// M^-1[k][pr_j] = W[pr_k][j] at the end, as before.  64 Q threads, ~105 KB of LDS, one workgroup per CU.
+__device__ __forceinline__ double mv_rcp(double d) {
+    double x = __builtin_amdgcn_rcp(d);
+    x = fma(fma(-d, x, 1.0), x, x);
+    return fma(fma(-d, x, 1.0), x, x);
+}
+template <int Q>
+__global__ void __launch_bounds__(64 * Q) m_inverse_mfma(MvMat M, const double* __restrict__ lam, MvMat Out,
+                                                         const int32_t* __restrict__ status, int C) {
+    constexpr int CP = 16 * Q, NT = 64 * Q, LSA = 17, LSR = CP + 1;
+    extern __shared__ __align__(16) unsigned char mv_smem[];
+    cd* Pn = reinterpret_cast<cd*>(mv_smem);          // [2][CP][LSA]  the panel before an even / odd pivot step (the last one: the A operand)
+    cd* Rr = Pn + 2 * CP * LSA;                       // [16][LSR]     the pivot rows of the panel (values before the update)
+    __shared__ unsigned key[2][128];
+    __shared__ int prow[CP], pos[CP], ppos[CP];
+    const int64_t n = mv_bin_of_block(), p = blockIdx.y;
+    if (status && status[p] != 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pr_row = tid % CP, pg = tid / CP;       // panel role: row, column quad
+    const cd* src = M.p + mv_at(M, p, n);
+    const double l0 = lam ? lam[0] : 0.0;
+    mv_f64x4 re[Q], im[Q];
+#pragma unroll
+    for (int tj = 0; tj < Q; ++tj)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const int r = 16 * wave + lk + 4 * r4, c = 16 * tj + li;
+            cd v = make_double2(r == c ? 1.0 : 0.0, 0.0);
+            if (r < C && c < C) {
+                v = src[(int64_t)(r * C + c) * M.se];
+                if (r == c) v.x += l0;
+            }
+            re[tj][r4] = v.x; im[tj][r4] = v.y;
+        }
+    if (tid < CP) { pos[tid] = tid < C ? tid : 0; prow[tid] = tid < C ? tid : 0; }
+    if (tid < 128) { key[0][tid] = 0u; key[1][tid] = 0u; }
+    for (int idx = tid; idx < 16 * LSR; idx += NT) Rr[idx] = make_double2(0.0, 0.0);
+    bool used = false;                                 // row pr_row has been a pivot (the four threads of a row agree)
+    const int Cr = (C + 15) & ~15;
+    auto keyof = [&](cd v) -> unsigned {
+        const unsigned hi = (unsigned)(__double_as_longlong(v.x * v.x + v.y * v.y) >> 32);
+        return (used || pr_row >= C) ? 0u : ((hi & ~255u) | 128u | (unsigned)(127 - pr_row));
+    };
+#pragma unroll 1
+    for (int kb = 0; 16 * kb < C; ++kb) {
+        const int nb = C - 16 * kb < 16 ? C - 16 * kb : 16;
+        __syncthreads();                               // (the panel and the pivot rows of the last block are consumed)
+#pragma unroll
+        for (int tj = 0; tj < Q; ++tj)
+            if (tj == kb) {
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4)
+                    Pn[(16 * wave + lk + 4 * r4) * LSA + li] = make_double2(re[tj][r4], im[tj][r4]);
+            }
+        if (tid < CP) ppos[tid] = -1;
+        __syncthreads();
+        cd pe[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) pe[c] = Pn[pr_row * LSA + 4 * pg + c];
+        if (pg == 0) key[0][pr_row] = keyof(pe[0]);
+        // (step 0 reads the panel from buffer 0 as the extraction left it; the keys need one more barrier)
+#pragma unroll 1
+        for (int jg = 0; jg < 4; ++jg) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int j = 4 * jg + jj;
+                if (j < nb) {
+                    const cd* cur = Pn + (j & 1) * CP * LSA;
+                    cd* nxt = Pn + ((j + 1) & 1) * CP * LSA;
+                    __syncthreads();
+                    const unsigned* kc = key[j & 1];
+                    const int pr = 127 - (int)(mv_wave_max_u32(max(kc[lane], kc[lane + 64])) & 127u);
+                    const cd piv = cur[pr * LSA + j];
+                    const cd m = cur[pr_row * LSA + j];
+                    cd w[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) w[c] = cur[pr * LSA + 4 * pg + c];
+                    const double d = mv_rcp(piv.x * piv.x + piv.y * piv.y);
+                    const cd inv = make_double2(piv.x * d, -piv.y * d);
+                    if (pr_row == pr) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) pe[c] = (pg == jg && c == jj) ? inv : m_mul(w[c], inv);
+                        used = true;
+                        if (pg == 0) { prow[16 * kb + j] = pr; pos[pr] = 16 * kb + j; ppos[pr] = j; }
+                    } else {
+                        const cd l = m_mul(m, inv);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            if (pg == jg && c == jj) { pe[c] = make_double2(-l.x, -l.y); continue; }
+                            pe[c].x = fma(-l.x, w[c].x, fma(l.y, w[c].y, pe[c].x));
+                            pe[c].y = fma(-l.x, w[c].y, fma(-l.y, w[c].x, pe[c].y));
+                        }
+                    }
+                    // publish: the panel before step j + 1 (after the last step: the A operand, columns past a short panel zero)
+                    const bool last = j + 1 == nb;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        nxt[pr_row * LSA + 4 * pg + c] = (last && 4 * pg + c >= nb) ? make_double2(0.0, 0.0) : pe[c];
+                    if (jj < 3) { if (pg == jg) key[(j + 1) & 1][pr_row] = keyof(pe[(jj + 1) & 3]); }
+                    else if (pg == jg + 1) key[(j + 1) & 1][pr_row] = keyof(pe[0]);
+                }
+            }
+        }
+        __syncthreads();                               // the panel is final (buffer nb & 1), the pivots are known
+        const cd* Pa = Pn + (nb & 1) * CP * LSA;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const int jp = ppos[16 * wave + lk + 4 * r4];
+            if (jp >= 0) {
+#pragma unroll
+                for (int tj = 0; tj < Q; ++tj) {
+                    Rr[jp * LSR + 16 * tj + li] = make_double2(re[tj][r4], im[tj][r4]);
+                    re[tj][r4] = 0.0; im[tj][r4] = 0.0;
+                }
+            }
+        }
+        __syncthreads();
+        if (16 * wave < Cr) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const cd av = Pa[(16 * wave + li) * LSA + 4 * kk + lk];
+#pragma unroll
+                for (int tj = 0; tj < Q; ++tj) {
+                    if (tj == kb || 16 * tj >= Cr) continue;
+                    const cd b = Rr[(4 * kk + lk) * LSR + 16 * tj + li];
+                    re[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, b.x, re[tj], 0, 0, 0);
+                    re[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(-av.y, b.y, re[tj], 0, 0, 0);
+                    im[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, b.y, im[tj], 0, 0, 0);
+                    im[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, b.x, im[tj], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int tj = 0; tj < Q; ++tj)
+            if (tj == kb) {
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const cd v = Pa[(16 * wave + lk + 4 * r4) * LSA + li];
+                    re[tj][r4] = v.x; im[tj][r4] = v.y;
+                }
+            }
+    }
+    __syncthreads();
+    cd* dst = Out.p + mv_at(Out, p, n);
+#pragma unroll
+    for (int tj = 0; tj < Q; ++tj)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const int r = 16 * wave + lk + 4 * r4, c = 16 * tj + li;
+            if (r < C && c < C) dst[(int64_t)(pos[r] * C + prow[c]) * Out.se] = make_double2(re[tj][r4], im[tj][r4]);
+        }
+}
+
 // Out = (M + lam I)^-1 for 129 ... 256 signals: the matrix (1 MB at 256) lives in a global scratch W (one C x C row-major
 // matrix per (window, bin)) and is inverted in place by Gauss-Jordan with partial pivoting, sixteen pivots at a time so that
 // the matrix crosses the memory system once per PANEL instead of once per pivot:
@@ -828,6 +999,13 @@ __global__ void __launch_bounds__(512) m_gemm_mfma(MvMat X, MvMat Y, MvMat O, co
     const cd* xb = X.p + mv_at(X, p, n);
     const cd* yb = Y.p + mv_at(Y, p, n);
     const int i0 = (int)(blockIdx.z >> 1) * CP, j0 = (int)(blockIdx.z & 1) * CP;      // output block (0, 0 up to 128 signals)
+    // X Y^H + I is the prediction step's G^-1 S G^-H + I: Hermitian.  Tiles below the diagonal are not computed but written as
+    // the mirror images of the tiles above (the lower-left block of a cut output: by the workgroup of the upper-right one), and
+    // the tile rows are dealt so that the two waves of a SIMD (w, w + 4) share 9 of the 36 tiles: rows w and Q + 3 - w.
+    constexpr bool HERM = BH && ADD_I;
+    if (HERM && i0 > j0) return;
+    const bool diag = i0 == j0;
+    const int wrow = (HERM && wave >= 4) ? Q + 3 - wave : wave;
     if (status && status[p] != 0) {
         if (ERR && gridDim.z > 1) {              // frozen window, blocked launch: O <- X for this block
             cd* ob = O.p + mv_at(O, p, n);
@@ -874,7 +1052,7 @@ __global__ void __launch_bounds__(512) m_gemm_mfma(MvMat X, MvMat Y, MvMat O, co
     // tile rows / columns below C and nothing else -- at 130 signals the four 128 x 128 blocks were 4 x the arithmetic of 128 signals
     // for 3 % more entries (round 5: 2.0-2.3 ms per product against 0.5-0.7; profiles/r06_mvar_kernels.txt).  Wave-uniform tests.
     const int ntj = (C - j0 + 15) / 16 < Q ? (C - j0 + 15) / 16 : Q;
-    const bool mine = wave < Q && i0 + 16 * wave < C;
+    const bool mine = wave < Q && i0 + 16 * wrow < C;
     fetch(0);
     park();
     __syncthreads();
@@ -884,10 +1062,10 @@ __global__ void __launch_bounds__(512) m_gemm_mfma(MvMat X, MvMat Y, MvMat O, co
         if (mine) {
 #pragma unroll
             for (int kk = 0; kk < KS / 4; ++kk) {
-                const cd av = Xs[(16 * wave + li) * LSX + 4 * kk + lk];
+                const cd av = Xs[(16 * wrow + li) * LSX + 4 * kk + lk];
 #pragma unroll
                 for (int tj = 0; tj < Q; ++tj) {
-                    if (tj >= ntj) continue;
+                    if (tj >= ntj || (HERM && diag && tj < wrow)) continue;
                     const cd b = Ys[(4 * kk + lk) * LSY + 16 * tj + li];
                     re[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, b.x, re[tj], 0, 0, 0);
                     re[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(-av.y, b.y, re[tj], 0, 0, 0);
@@ -903,10 +1081,11 @@ __global__ void __launch_bounds__(512) m_gemm_mfma(MvMat X, MvMat Y, MvMat O, co
     double emax = 0.0;
     if (mine) {
 #pragma unroll
-        for (int tj = 0; tj < Q; ++tj)
+        for (int tj = 0; tj < Q; ++tj) {
+            if (HERM && diag && tj < wrow) continue;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int i = i0 + 16 * wave + lk + 4 * r, j = j0 + 16 * tj + li;
+                const int i = i0 + 16 * wrow + lk + 4 * r, j = j0 + 16 * tj + li;
                 if (i < C && j < C) {
                     cd v = make_double2(re[tj][r], im[tj][r]);
                     if (ADD_I && i == j) v.x += 1.0;
@@ -915,8 +1094,10 @@ __global__ void __launch_bounds__(512) m_gemm_mfma(MvMat X, MvMat Y, MvMat O, co
                         emax = fmax(emax, hypot(v.x - old.x, v.y - old.y));
                     }
                     ob[(int64_t)(i * C + j) * O.se] = v;
+                    if (HERM && (!diag || tj > wrow)) ob[(int64_t)(j * C + i) * O.se] = m_conj(v);
                 }
             }
+        }
     }
     if constexpr (ERR) {
 #pragma unroll
@@ -1196,8 +1377,19 @@ static int mv_launch_inverse_big(int64_t C, dim3 grid, hipStream_t st, MvMat M, 
         SC_CHECK_HIP(hipGetLastError());
         return SC_OK;
     }
-    if (mv_big_q(C) == 6) hipLaunchKernelGGL(m_inverse_inplace<6>, grid, dim3(512), 0, st, M, lam, Out, status, (int)C);
-    else hipLaunchKernelGGL(m_inverse_inplace<8>, grid, dim3(512), 0, st, M, lam, Out, status, (int)C);
+    const char* sel = sc_switch(SC_SW_MVAR_INVERSE);      // "registers": the round-3 kernel (one whole-matrix update per pivot)
+    if (sel && sel[0] == 'r') {
+        if (mv_big_q(C) == 6) hipLaunchKernelGGL(m_inverse_inplace<6>, grid, dim3(512), 0, st, M, lam, Out, status, (int)C);
+        else hipLaunchKernelGGL(m_inverse_inplace<8>, grid, dim3(512), 0, st, M, lam, Out, status, (int)C);
+    } else if (mv_big_q(C) == 6) {
+        const size_t lds = (size_t)(2 * 96 * 17 + 16 * 97) * sizeof(cd);
+        SC_CHECK_HIP(hipFuncSetAttribute((const void*)m_inverse_mfma<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(m_inverse_mfma<6>, grid, dim3(384), lds, st, M, lam, Out, status, (int)C);
+    } else {
+        const size_t lds = (size_t)(2 * 128 * 17 + 16 * 129) * sizeof(cd);
+        SC_CHECK_HIP(hipFuncSetAttribute((const void*)m_inverse_mfma<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(m_inverse_mfma<8>, grid, dim3(512), lds, st, M, lam, Out, status, (int)C);
+    }
     SC_CHECK_HIP(hipGetLastError());
     return SC_OK;
 }

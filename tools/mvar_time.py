@@ -30,3 +30,22 @@ for rep in range(2):
     torch.cuda.synchronize()
     print(f"C={C} T={T} window={L or T}: directed_transfer_function() {1e3 * (time.perf_counter() - t0):.1f} ms, "
           f"Wilson iterations {c._last_wilson['iterations']}, not converged {c._last_wilson['not_converged']}, out {dtf.shape}")
+
+# where the call's time goes: the library's stage timers (hipEvents around every entry point) against the wall clock
+from spectral_connectivity_amd import _lib      # noqa: E402
+_lib.timing_enable(True)
+c = sc.Connectivity.from_multitaper(m)
+torch.cuda.synchronize()
+_lib.last_timing()
+t0 = time.perf_counter()
+G = c._mvar_factor_device()
+torch.cuda.synchronize()
+t1 = time.perf_counter()
+from spectral_connectivity_amd import engine      # noqa: E402
+d = engine.mvar_measure(G, _lib.MVAR_DTF)
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+h = engine.to_host(d)
+t3 = time.perf_counter()
+print(f"  factor {1e3 * (t1 - t0):.1f} ms (records + Wilson), measure {1e3 * (t2 - t1):.1f} ms, download of {h.nbytes / 1e6:.0f} MB {1e3 * (t3 - t2):.1f} ms")
+print("  library timers:", ", ".join(f"{k} {v:.2f}" for k, v in _lib.last_timing()))
