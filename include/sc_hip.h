@@ -441,8 +441,9 @@ int sc_wilson_factor_f64(const double* d_S, int64_t n_problems, int64_t N, doubl
  * partial_directed_coherence, generalized_partial_directed_coherence,
  * direct_directed_transfer_function (connectivity.py:1237-1426).  All windows iterate together,
  * converged windows are frozen; up to 128 signals the C x C factor of one (window, bin) lives in the registers of one
- * workgroup, 129 ... 256 run a panel-blocked inverse in global memory and blocked products:
- * n_signals <= sc_mvar_max_signals() (256, the most an accumulator record holds), larger systems return SC_EUNSUPPORTED.
+ * workgroup, 129 ... 512 run a panel-blocked inverse in global memory and products cut into 128 x 128 blocks:
+ * n_signals <= sc_mvar_max_signals() (512 since round 6; records of more than 256 signals are assembled from channel-block
+ * pairs by the host), larger systems return SC_EUNSUPPORTED.
  * sc_mvar_factor_f64: exactly one of d_accum (accumulator records holding SC_PLANE_CSM, N or N/2+1
  * bins per window, real-input symmetry completes the rest) and d_S (complex128 [P][N][C][C], two-sided
  * Hermitian spectra) is non-NULL.  d_G: complex128 [P][N][C][C].  d_status[p]: 1 converged, 0 not

@@ -44,6 +44,9 @@ int sc_internal_z2z_plan(struct rocfft_plan_t** plan, int forward, size_t N, siz
 
 // sc_wilson_fft.hip: A <- fft(causal(ifft(A))) in one kernel, for the lengths `supported` accepts
 bool sc_internal_causal_fft_supported(int64_t N);
+bool sc_internal_causal_fft_natural_supported(int64_t N);
+int sc_internal_causal_fft_pair_natural(void* d_A, const int32_t* d_status, int64_t n_problems, int C, int64_t N,
+                                        hipStream_t st);
 int sc_internal_causal_fft_pair(void* d_A, const int32_t* d_status, int64_t n_problems, int C, int64_t N,
                                 hipStream_t st);
 

@@ -19,9 +19,10 @@
 //   measures                H0 = Re mean_n G; H = G (H0 + lam I)^-1 on the non-negative bins;
 //                           A_mvar = (H + lam' I)^-1; Sigma = H0 H0^T; DTF / DC / PDC / gPDC / dDTF.
 // Everything is fp64 (the reference's convergence test max |dG| < 1e-8 is out of fp32's reach).  Up to 128 signals the
-// C x C factor of one (window, bin) lives in the registers of one workgroup; 129 ... 256 signals (the most an accumulator
+// C x C factor of one (window, bin) lives in the registers of one workgroup; 129 ... 512 signals (round 6; 256 before: the most an accumulator
 // record holds) run the same iteration with the inverse as a panel-blocked Gauss-Jordan on the matrix in global memory
 // (m_inverse_global) and the products as 128 x 128 output blocks of m_gemm_mfma.
+#include <stdlib.h>
 #include <rocfft/rocfft.h>
 #include "sc_common.h"
 
@@ -34,8 +35,8 @@ __device__ inline cd m_div(cd a, cd b) {
     return make_double2((a.x * b.x + a.y * b.y) / d, (a.y * b.x - a.x * b.y) / d);
 }
 
-#define MV_CMAX 256          // <= 64: register-resident [G | S] elimination; 65 ... 128: explicit in-register inverse + matrix-
-#define MV_CSMALL 64         // core products; 129 ... 256: panel-blocked inverse in global memory + blocked products
+#define MV_CMAX 512          // <= 64: register-resident [G | S] elimination; 65 ... 128: explicit in-register inverse + matrix-
+#define MV_CSMALL 64         // core products; 129 ... 512: panel-blocked inverse in global memory + blocked products
 #define MV_CMID 128
 #define MV_GRID_Y 32768      // grid.y of the per-element kernels (C^2 = 65536 elements at 256 signals exceed the limit of 65535)
 
@@ -704,7 +705,7 @@ __device__ __forceinline__ double mv_rcp(double d) {
 }
 template <int Q>
 __global__ void __launch_bounds__(64 * Q) m_inverse_mfma(MvMat M, const double* __restrict__ lam, MvMat Out,
-                                                         const int32_t* __restrict__ status, int C) {
+                                                         const int32_t* __restrict__ status, int C, int dbg) {
     constexpr int CP = 16 * Q, NT = 64 * Q, LSA = 17, LSR = CP + 1;
     extern __shared__ __align__(16) unsigned char mv_smem[];
     cd* Pn = reinterpret_cast<cd*>(mv_smem);          // [2][CP][LSA]  the panel before an even / odd pivot step (the last one: the A operand)
@@ -763,7 +764,7 @@ __global__ void __launch_bounds__(64 * Q) m_inverse_mfma(MvMat M, const double* 
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
                 const int j = 4 * jg + jj;
-                if (j < nb) {
+                if (j < nb && !(dbg & 2)) {
                     const cd* cur = Pn + (j & 1) * CP * LSA;
                     cd* nxt = Pn + ((j + 1) & 1) * CP * LSA;
                     __syncthreads();
@@ -814,7 +815,7 @@ __global__ void __launch_bounds__(64 * Q) m_inverse_mfma(MvMat M, const double* 
             }
         }
         __syncthreads();
-        if (16 * wave < Cr) {
+        if (16 * wave < Cr && !(dbg & 1)) {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const cd av = Pa[(16 * wave + li) * LSA + 4 * kk + lk];
@@ -841,6 +842,10 @@ __global__ void __launch_bounds__(64 * Q) m_inverse_mfma(MvMat M, const double* 
     }
     __syncthreads();
     cd* dst = Out.p + mv_at(Out, p, n);
+    // (tried: rows through an LDS patch so that they leave as whole lines -- 1.098 against 1.087 ms, the store is not what the kernel
+    //  waits for; the pivot steps on one wave per SIMD with eight entries a thread -- 0.76 against 0.57 ms for the steps, the same
+    //  1.10 in total: the steps are bound by the LDS traffic of republishing the panel, not by instruction issue;
+    //  profiles/r06_mvar_inverse_ab.txt)
 #pragma unroll
     for (int tj = 0; tj < Q; ++tj)
 #pragma unroll
@@ -862,17 +867,19 @@ __global__ void __launch_bounds__(64 * Q) m_inverse_mfma(MvMat M, const double* 
 //      (E M = M + (E - I)[:, pivot rows] M[pivot rows, :]): 2 x 4 elements per thread and pass, 0.75 LDS reads per complex FMA;
 //   4. the panel is written back.
 // M^-1[k][pr_j] = W[pr_k][j] at the end.  1024 threads, 133 KB of LDS: one workgroup per CU.
-#define MV_PB 16
+// RMAX = 256 with panels of PB = 16 columns (135 KB of LDS), RMAX = 512 with panels of 8 (139 KB): the limit of the full
+// factorisation (sc_mvar_max_signals).
+template <int PB, int RMAX>
 __global__ void __launch_bounds__(1024) m_inverse_global(MvMat M, const double* __restrict__ lam, MvMat Out, cd* Work,
                                                          const int32_t* __restrict__ status, int C) {
     extern __shared__ __align__(16) unsigned char mv_smem[];
-    cd* Pn = reinterpret_cast<cd*>(mv_smem);          // [256][MV_PB]   the panel
-    cd* Rr = Pn + 256 * MV_PB;                        // [MV_PB][256]   the pivot rows
-    cd* colbuf = Rr + MV_PB * 256;                    // [256]          column j of the panel before step j
-    cd* rowbuf = colbuf + 256;                        // [MV_PB]        the scaled pivot row of step j
-    __shared__ unsigned key[256];
-    __shared__ int prow[256], pos[256];
-    __shared__ unsigned char used[256];
+    cd* Pn = reinterpret_cast<cd*>(mv_smem);          // [RMAX][PB]     the panel
+    cd* Rr = Pn + RMAX * PB;                          // [PB][RMAX]     the pivot rows
+    cd* colbuf = Rr + PB * RMAX;                      // [RMAX]         column j of the panel before step j
+    cd* rowbuf = colbuf + RMAX;                       // [PB]           the scaled pivot row of step j
+    __shared__ unsigned key[RMAX];
+    __shared__ int prow[RMAX], pos[RMAX];
+    __shared__ unsigned char used[RMAX];
     const int64_t n = mv_bin_of_block(), p = blockIdx.y;
     if (status && status[p] != 0) return;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -885,33 +892,35 @@ __global__ void __launch_bounds__(1024) m_inverse_global(MvMat M, const double* 
         if (e / C == e % C) v.x += l0;
         W[e] = v;
     }
-    if (tid < 256) { used[tid] = 0; prow[tid] = 0; pos[tid] = 0; key[tid] = 0u; }
+    if (tid < RMAX) { used[tid] = 0; prow[tid] = 0; pos[tid] = 0; key[tid] = 0u; }
     __syncthreads();
-    for (int k0 = 0; k0 < C; k0 += MV_PB) {
-        const int nb = C - k0 < MV_PB ? C - k0 : MV_PB;
-        for (int idx = tid; idx < C * MV_PB; idx += 1024) {
-            const int r = idx / MV_PB, j = idx % MV_PB;
+    for (int k0 = 0; k0 < C; k0 += PB) {
+        const int nb = C - k0 < PB ? C - k0 : PB;
+        for (int idx = tid; idx < C * PB; idx += 1024) {
+            const int r = idx / PB, j = idx % PB;
             Pn[idx] = j < nb ? W[r * C + k0 + j] : make_double2(0.0, 0.0);
         }
         __syncthreads();
         for (int j = 0; j < nb; ++j) {
-            if (tid < 256) {
-                const cd v = tid < C ? Pn[tid * MV_PB + j] : make_double2(0.0, 0.0);
+            if (tid < RMAX) {
+                const cd v = tid < C ? Pn[tid * PB + j] : make_double2(0.0, 0.0);
                 colbuf[tid] = v;
                 const unsigned hi = (unsigned)(__double_as_longlong(v.x * v.x + v.y * v.y) >> 32);
-                key[tid] = (tid >= C || used[tid]) ? 0u : ((hi & ~511u) | 256u | (unsigned)(255 - tid));
+                key[tid] = (tid >= C || used[tid]) ? 0u : ((hi & ~(unsigned)(2 * RMAX - 1)) | (unsigned)RMAX | (unsigned)(RMAX - 1 - tid));
             }
             __syncthreads();
-            const unsigned kv = max(max(key[lane], key[lane + 64]), max(key[lane + 128], key[lane + 192]));
-            const int pr = 255 - (int)(mv_wave_max_u32(kv) & 255u);
+            unsigned kv = 0u;
+#pragma unroll
+            for (int q = 0; q < RMAX / 64; ++q) kv = max(kv, key[lane + 64 * q]);
+            const int pr = RMAX - 1 - (int)(mv_wave_max_u32(kv) & (unsigned)(RMAX - 1));
             const cd piv = colbuf[pr];
             const double pden = piv.x * piv.x + piv.y * piv.y;
             const cd inv = make_double2(piv.x / pden, -piv.y / pden);
-            if (tid < MV_PB) rowbuf[tid] = tid == j ? inv : m_mul(Pn[pr * MV_PB + tid], inv);
+            if (tid < PB) rowbuf[tid] = tid == j ? inv : m_mul(Pn[pr * PB + tid], inv);
             if (tid == 0) { prow[k0 + j] = pr; pos[pr] = k0 + j; used[pr] = 1; }
             __syncthreads();
-            for (int idx = tid; idx < C * MV_PB; idx += 1024) {
-                const int r = idx / MV_PB, jj = idx % MV_PB;
+            for (int idx = tid; idx < C * PB; idx += 1024) {
+                const int r = idx / PB, jj = idx % PB;
                 if (r == pr) { Pn[idx] = rowbuf[jj]; continue; }
                 const cd m = colbuf[r], w = rowbuf[jj];
                 cd g = jj == j ? make_double2(0.0, 0.0) : Pn[idx];
@@ -921,19 +930,20 @@ __global__ void __launch_bounds__(1024) m_inverse_global(MvMat M, const double* 
             }
             __syncthreads();
         }
-        for (int idx = tid; idx < MV_PB * C; idx += 1024) {
+        for (int idx = tid; idx < PB * C; idx += 1024) {
             const int j = idx / C, c = idx - j * C;
-            Rr[j * 256 + c] = j < nb ? W[prow[k0 + j] * C + c] : make_double2(0.0, 0.0);
+            Rr[j * RMAX + c] = j < nb ? W[prow[k0 + j] * C + c] : make_double2(0.0, 0.0);
         }
         __syncthreads();
         {
             const int ty = tid >> 6, tx = lane;          // rows ty + 16 a, columns tx + 64 b
-            for (int a = 0; a < 16; a += 2) {
+            constexpr int NB = RMAX / 64;
+            for (int a = 0; a < RMAX / 16; a += 2) {
                 const int r0 = ty + 16 * a, r1 = r0 + 16;
                 if (r0 >= C) break;
-                cd acc[2][4];
+                cd acc[2][NB];
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
+                for (int b = 0; b < NB; ++b) {
                     const int c = tx + 64 * b;
                     const bool live = c < C && !(c >= k0 && c < k0 + nb);
                     const bool p0 = used[r0] && pos[r0] >= k0;
@@ -942,10 +952,10 @@ __global__ void __launch_bounds__(1024) m_inverse_global(MvMat M, const double* 
                     acc[1][b] = (live && r1 < C && !p1) ? W[r1 * C + c] : make_double2(0.0, 0.0);
                 }
                 for (int j = 0; j < nb; ++j) {
-                    const cd e0 = Pn[r0 * MV_PB + j], e1 = r1 < C ? Pn[r1 * MV_PB + j] : make_double2(0.0, 0.0);
+                    const cd e0 = Pn[r0 * PB + j], e1 = r1 < C ? Pn[r1 * PB + j] : make_double2(0.0, 0.0);
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        const cd w = Rr[j * 256 + tx + 64 * b];
+                    for (int b = 0; b < NB; ++b) {
+                        const cd w = Rr[j * RMAX + tx + 64 * b];
                         acc[0][b].x = fma(e0.x, w.x, fma(-e0.y, w.y, acc[0][b].x));
                         acc[0][b].y = fma(e0.x, w.y, fma(e0.y, w.x, acc[0][b].y));
                         acc[1][b].x = fma(e1.x, w.x, fma(-e1.y, w.y, acc[1][b].x));
@@ -953,7 +963,7 @@ __global__ void __launch_bounds__(1024) m_inverse_global(MvMat M, const double* 
                     }
                 }
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
+                for (int b = 0; b < NB; ++b) {
                     const int c = tx + 64 * b;
                     if (c < C && !(c >= k0 && c < k0 + nb)) {
                         W[r0 * C + c] = acc[0][b];
@@ -963,8 +973,8 @@ __global__ void __launch_bounds__(1024) m_inverse_global(MvMat M, const double* 
             }
         }
         __syncthreads();
-        for (int idx = tid; idx < C * MV_PB; idx += 1024) {
-            const int r = idx / MV_PB, j = idx % MV_PB;
+        for (int idx = tid; idx < C * PB; idx += 1024) {
+            const int r = idx / PB, j = idx % PB;
             if (j < nb) W[r * C + k0 + j] = Pn[idx];
         }
         __syncthreads();
@@ -998,7 +1008,8 @@ __global__ void __launch_bounds__(512) m_gemm_mfma(MvMat X, MvMat Y, MvMat O, co
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const cd* xb = X.p + mv_at(X, p, n);
     const cd* yb = Y.p + mv_at(Y, p, n);
-    const int i0 = (int)(blockIdx.z >> 1) * CP, j0 = (int)(blockIdx.z & 1) * CP;      // output block (0, 0 up to 128 signals)
+    const int nbk = gridDim.z == 1 ? 1 : (C + CP - 1) / CP;                          // the output cut into nbk x nbk blocks
+    const int i0 = (int)(blockIdx.z / nbk) * CP, j0 = (int)(blockIdx.z % nbk) * CP;   // output block (0, 0 up to 128 signals)
     // X Y^H + I is the prediction step's G^-1 S G^-H + I: Hermitian.  Tiles below the diagonal are not computed but written as
     // the mirror images of the tiles above (the lower-left block of a cut output: by the workgroup of the upper-right one), and
     // the tile rows are dealt so that the two waves of a SIMD (w, w + 4) share 9 of the 36 tiles: rows w and Q + 3 - w.
@@ -1371,9 +1382,15 @@ static int mv_launch_inverse_big(int64_t C, dim3 grid, hipStream_t st, MvMat M, 
                                  const int32_t* status, cd* scratch) {
     if (C > MV_CMID) {
         SC_REQUIRE(scratch, "inverse beyond 128 signals needs a scratch");
-        const size_t lds = (size_t)(2 * 256 * MV_PB + 256 + MV_PB) * sizeof(cd);
-        SC_CHECK_HIP(hipFuncSetAttribute((const void*)m_inverse_global, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(m_inverse_global, grid, dim3(1024), lds, st, M, lam, Out, scratch, status, (int)C);
+        if (C <= 256) {
+            const size_t lds = (size_t)(2 * 256 * 16 + 256 + 16) * sizeof(cd);
+            SC_CHECK_HIP(hipFuncSetAttribute((const void*)m_inverse_global<16, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((m_inverse_global<16, 256>), grid, dim3(1024), lds, st, M, lam, Out, scratch, status, (int)C);
+        } else {
+            const size_t lds = (size_t)(2 * 512 * 8 + 512 + 8) * sizeof(cd);
+            SC_CHECK_HIP(hipFuncSetAttribute((const void*)m_inverse_global<8, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((m_inverse_global<8, 512>), grid, dim3(1024), lds, st, M, lam, Out, scratch, status, (int)C);
+        }
         SC_CHECK_HIP(hipGetLastError());
         return SC_OK;
     }
@@ -1382,13 +1399,15 @@ static int mv_launch_inverse_big(int64_t C, dim3 grid, hipStream_t st, MvMat M, 
         if (mv_big_q(C) == 6) hipLaunchKernelGGL(m_inverse_inplace<6>, grid, dim3(512), 0, st, M, lam, Out, status, (int)C);
         else hipLaunchKernelGGL(m_inverse_inplace<8>, grid, dim3(512), 0, st, M, lam, Out, status, (int)C);
     } else if (mv_big_q(C) == 6) {
+        const int dbg = sel ? atoi(sel) : 0;             // (timing ablations: 1 no matrix-core updates, 2 no pivot steps)
         const size_t lds = (size_t)(2 * 96 * 17 + 16 * 97) * sizeof(cd);
         SC_CHECK_HIP(hipFuncSetAttribute((const void*)m_inverse_mfma<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(m_inverse_mfma<6>, grid, dim3(384), lds, st, M, lam, Out, status, (int)C);
+        hipLaunchKernelGGL(m_inverse_mfma<6>, grid, dim3(384), lds, st, M, lam, Out, status, (int)C, dbg);
     } else {
+        const int dbg = sel ? atoi(sel) : 0;
         const size_t lds = (size_t)(2 * 128 * 17 + 16 * 129) * sizeof(cd);
         SC_CHECK_HIP(hipFuncSetAttribute((const void*)m_inverse_mfma<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(m_inverse_mfma<8>, grid, dim3(512), lds, st, M, lam, Out, status, (int)C);
+        hipLaunchKernelGGL(m_inverse_mfma<8>, grid, dim3(512), lds, st, M, lam, Out, status, (int)C, dbg);
     }
     SC_CHECK_HIP(hipGetLastError());
     return SC_OK;
@@ -1415,9 +1434,10 @@ static int mv_launch_gemm_q(int mode, dim3 grid, hipStream_t st, MvMat X, MvMat 
 }
 static int mv_launch_gemm(int64_t C, int mode, dim3 grid, hipStream_t st, MvMat X, MvMat Y, MvMat O,
                           const int32_t* status, double* err) {
-    if (C > MV_CMID) {          // four 128 x 128 output blocks per problem; O must not alias X or Y
+    if (C > MV_CMID) {          // 128 x 128 output blocks, one workgroup each; O must not alias X or Y
         SC_REQUIRE(O.p != X.p && O.p != Y.p, "blocked product in place");
-        grid.z = 4;
+        const unsigned nbk = (unsigned)((C + 127) / 128);
+        grid.z = nbk * nbk;
     }
     return mv_big_q(C) == 6 ? mv_launch_gemm_q<6>(mode, grid, st, X, Y, O, status, err, (int)C)
                             : mv_launch_gemm_q<8>(mode, grid, st, X, Y, O, status, err, (int)C);
@@ -1439,7 +1459,9 @@ extern "C" int sc_mvar_workspace_bytes(int64_t n_groups, int64_t C, int64_t N, s
     const size_t n_big = C > MV_CSMALL ? 5 : 3;
     const size_t factor = n_big * P * E * (size_t)N * sizeof(cd) + P * 16 + P * E * 8 + 128 + (size_t)MV_HIST * 4;
     // (beyond 128 signals: + the scratch of the blocked inverse, which also parks |H|^2 / |A|^2 for m_measure)
-    const size_t meas = (C > MV_CMID ? 3 : 2) * P * F * E * sizeof(cd) + P * E * 8 * 3 + P * (F > 16 ? F : 16) * 8 +
+    // (sq: one partial sum per (window, bin) and, before that, per (window, 256-element chunk of the matrix))
+    const size_t n_sq = (F > 16 ? F : 16) > (E + 255) / 256 ? (F > 16 ? F : 16) : (E + 255) / 256;
+    const size_t meas = (C > MV_CMID ? 3 : 2) * P * F * E * sizeof(cd) + P * E * 8 * 3 + P * n_sq * 8 +
                         P * (size_t)C * 8 + P * 8 + 256;
     *bytes = (factor > meas ? factor : meas) + 256;
     return SC_OK;
@@ -1455,7 +1477,7 @@ extern "C" int sc_mvar_factor_f64(const void* d_accum, const void* d_S, int64_t 
     SC_REQUIRE(d_work && d_G && d_n_iter && d_status, "NULL argument");
     SC_REQUIRE(n_groups >= 1 && n_groups <= 65535 && N >= 2 && N <= 1 << 24, "bad problem size");
     if (C < 1 || C > MV_CMAX) {
-        sc_set_error("full Wilson factorisation: n_signals <= %d, the most an accumulator record holds (got %lld)",
+        sc_set_error("full Wilson factorisation: n_signals <= %d (got %lld)",
                      MV_CMAX, (long long)C);
         return SC_EUNSUPPORTED;
     }
@@ -1511,6 +1533,9 @@ extern "C" int sc_mvar_factor_f64(const void* d_accum, const void* d_S, int64_t 
     int iters = 0, running = (int)P, queued = 0;
     int32_t hist[MV_POLL];
     const bool fused = sc_internal_causal_fft_supported(N);
+    // Beyond 64 signals A crosses the transform in the layout of the products around it where the transform has the loads for it
+    const bool natA = big && fused && sc_internal_causal_fft_natural_supported(N);
+    const MvMat Adesc = natA ? mv_natural(A, N, E) : mv_series(A, N, E);
     const int Q = (int)((C + 15) / 16);
     if (max_iter > MV_HIST) {
         sc_set_error("max_iterations = %d exceeds the %d iterations the workspace can log", max_iter, MV_HIST);
@@ -1556,21 +1581,22 @@ extern "C" int sc_mvar_factor_f64(const void* d_accum, const void* d_S, int64_t 
                 if ((rc = mv_launch_gemm(C, MV_GEMM_PLAIN, gridB, st, mv_natural(Ginv, N, E), mv_natural(S, N, E),
                                          mv_natural(T, N, E), d_status, nullptr)) != SC_OK) goto done;
                 if ((rc = mv_launch_gemm(C, MV_GEMM_BH_I, gridB, st, mv_natural(T, N, E), mv_natural(Ginv, N, E),
-                                         mv_series(A, N, E), d_status, nullptr)) != SC_OK) goto done;
+                                         Adesc, d_status, nullptr)) != SC_OK) goto done;
             } else if ((rc = mv_launch_predict(Q, gridB, st, S, G, d_status, A, N, (int)C)) != SC_OK) goto done;
             if (fused) {        // ifft -> causal mask -> fft in one kernel (sc_wilson_fft.hip)
-                if ((rc = sc_internal_causal_fft_pair(A, d_status, P, (int)C, N, st)) != SC_OK) goto done;
+                if ((rc = natA ? sc_internal_causal_fft_pair_natural(A, d_status, P, (int)C, N, st)
+                               : sc_internal_causal_fft_pair(A, d_status, P, (int)C, N, st)) != SC_OK) goto done;
             } else {
                 MV_CHECK_FFT(rocfft_execute(inv, bufs, nullptr, info));
                 hipLaunchKernelGGL(m_causal, gridE, dim3(256), 0, st, A, N, (int)C);
                 MV_CHECK_FFT(rocfft_execute(fwd, bufs, nullptr, info));
             }
             if (huge) {         // the blocked product cannot run in place: G A+ into T (frozen windows copied), then swap
-                if ((rc = mv_launch_gemm(C, MV_GEMM_ERR, gridB, st, mv_natural(G, N, E), mv_series(A, N, E), mv_natural(T, N, E),
+                if ((rc = mv_launch_gemm(C, MV_GEMM_ERR, gridB, st, mv_natural(G, N, E), Adesc, mv_natural(T, N, E),
                                          d_status, err)) != SC_OK) goto done;
                 cd* t = G; G = T; T = t;
             } else if (big) {
-                if ((rc = mv_launch_gemm(C, MV_GEMM_ERR, gridB, st, mv_natural(G, N, E), mv_series(A, N, E), mv_natural(G, N, E),
+                if ((rc = mv_launch_gemm(C, MV_GEMM_ERR, gridB, st, mv_natural(G, N, E), Adesc, mv_natural(G, N, E),
                                          d_status, err)) != SC_OK) goto done;
             } else if ((rc = mv_launch_update(Q, gridB, st, G, A, d_status, err, N, (int)C)) != SC_OK) goto done;
             hipLaunchKernelGGL(m_flags, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, d_status, d_n_iter, err, tol, P,
@@ -1616,7 +1642,7 @@ extern "C" int sc_mvar_measure_f64(const void* d_G, int64_t n_groups, int64_t N,
     SC_REQUIRE(d_G && d_out && d_work, "NULL argument");
     SC_REQUIRE(which >= SC_MVAR_DTF && which <= SC_MVAR_NOISE_COVARIANCE, "unknown MVAR quantity");
     if (C < 1 || C > MV_CMAX) {
-        sc_set_error("MVAR measures: n_signals <= %d, the most an accumulator record holds (got %lld)", MV_CMAX, (long long)C);
+        sc_set_error("MVAR measures: n_signals <= %d (got %lld)", MV_CMAX, (long long)C);
         return SC_EUNSUPPORTED;
     }
     size_t need = 0;
@@ -1631,7 +1657,8 @@ extern "C" int sc_mvar_measure_f64(const void* d_G, int64_t n_groups, int64_t N,
     double* h0 = (double*)w; w += (size_t)P * E * 8;
     double* hinv = (double*)w; w += (size_t)P * E * 8;
     double* sigma = (double*)w; w += (size_t)P * E * 8;
-    double* sq = (double*)w; w += (size_t)P * (F > 16 ? F : 16) * 8;      // per (window, bin) or per (window, 256-element chunk)
+    const size_t n_sq = (size_t)(F > 16 ? F : 16) > ((size_t)E + 255) / 256 ? (size_t)(F > 16 ? F : 16) : ((size_t)E + 255) / 256;
+    double* sq = (double*)w; w += (size_t)P * n_sq * 8;      // per (window, bin) or per (window, 256-element chunk)
     double* tot = (double*)w; w += (size_t)P * C * 8;
     double* lam = (double*)w; w += 64;                // [0] lam of H0, [1] lam' of H
     const bool huge = C > MV_CMID;

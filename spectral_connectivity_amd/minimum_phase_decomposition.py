@@ -4,7 +4,7 @@ Drop-in for ``spectral_connectivity.minimum_phase_decomposition.minimum_phase_de
 (reference minimum_phase_decomposition.py:227-322).  1x1 and 2x2 cross-spectral matrices -- the
 sizes the hot path (pairwise spectral Granger prediction) uses -- advance together in fp64 through
 ``sc_wilson_factor_f64`` (batched closed-form 2x2 solves, fused causal transform pair along the frequency axis);
-larger systems (up to ``sc_mvar_max_signals()`` = 256 signals) go through ``sc_mvar_factor_f64``
+larger systems (up to ``sc_mvar_max_signals()`` = 512 signals) go through ``sc_mvar_factor_f64``
 (register-resident Gauss-Jordan solves, one workgroup per window and frequency bin).  There is no CPU fallback.
 """
 import ctypes

@@ -473,8 +473,10 @@ def test_minimum_phase_decomposition_vs_reference_and_known_filters(sc, golden):
     np.testing.assert_allclose(G, np.tile(np.eye(3, dtype=complex), (1, 8, 1, 1)), atol=1e-12)
     G = minimum_phase_decomposition(np.tile(np.eye(129, dtype=complex), (1, 4, 1, 1)))   # (round 3: up to 256 signals)
     np.testing.assert_allclose(G, np.tile(np.eye(129, dtype=complex), (1, 4, 1, 1)), atol=1e-12)
+    G = minimum_phase_decomposition(np.tile(np.eye(257, dtype=complex), (1, 4, 1, 1)))   # (round 6: up to 512)
+    np.testing.assert_allclose(G, np.tile(np.eye(257, dtype=complex), (1, 4, 1, 1)), atol=1e-12)
     with pytest.raises(NotImplementedError):
-        minimum_phase_decomposition(np.tile(np.eye(257, dtype=complex), (1, 4, 1, 1)))
+        minimum_phase_decomposition(np.tile(np.eye(513, dtype=complex), (1, 4, 1, 1)))
 
 
 @pytest.mark.parametrize("tag", ["var3", "var5"])
@@ -503,7 +505,8 @@ def test_f9_mvar_measures_vs_reference(sc, golden, tag):
 
 @pytest.mark.parametrize("c,N,P", [(3, 64, 2), (8, 128, 3), (17, 64, 1), (40, 32, 2), (64, 32, 1),
                                    (65, 32, 2), (80, 48, 1), (96, 64, 1), (97, 32, 1), (128, 32, 2), (100, 256, 1),
-                                   (129, 32, 1), (160, 32, 1), (200, 256, 1), (250, 48, 1), (256, 32, 1)])
+                                   (129, 32, 1), (160, 32, 1), (200, 256, 1), (250, 48, 1), (256, 32, 1),
+                                   (257, 32, 1), (306, 64, 2), (400, 32, 1), (512, 32, 1)])
 def test_full_wilson_factor_standalone_fp64(sc, c, N, P):
     """minimum_phase_decomposition() for c > 2 on exactly representable fp64 spectra of known
     minimum-phase filters: S = F F^H with F(z) = I + B z^-1 (||B|| < 1) factors back to F Q with the
@@ -521,17 +524,19 @@ def test_full_wilson_factor_standalone_fp64(sc, c, N, P):
     G = minimum_phase_decomposition(S)
     assert G.shape == S.shape and np.isfinite(G).all()
     np.testing.assert_allclose(G @ np.conj(np.swapaxes(G, -1, -2)), S, rtol=0, atol=1e-7 * np.abs(S).max())
-    # (beyond 64 signals: explicit inverse + matrix-core products; beyond 128: panel-blocked inverse in global memory)
+    # (beyond 64 signals: explicit inverse + matrix-core products; beyond 128: panel-blocked inverse in global memory and products
+    #  cut into 128 x 128 blocks -- up to 512 signals since round 6, panels of eight columns beyond 256)
     # (the oracle's numpy iteration takes a minute at 256 signals: the largest sizes are held to G G^H = S only)
     if c <= 17 or (c, N) in ((65, 32), (128, 32), (129, 32), (160, 32)):
         np.testing.assert_allclose(G, so.minimum_phase_decomposition(S), rtol=0, atol=1e-6 * np.abs(G).max())
 
 
-@pytest.mark.parametrize("C", [72, 128, 130, 160])
+@pytest.mark.parametrize("C", [72, 128, 130, 160, 306])
 def test_mvar_measures_beyond_64_signals_vs_oracle(sc, C):
     """65 ... 128 signals: Wilson factor, transfer function, noise covariance, MVAR coefficients and the directed
     measures through the explicit-inverse / matrix-core kernels (sc_mvar.hip), float64 engine, against the oracle;
-    129 ... 256 signals: the same iteration on the panel-blocked inverse and the blocked products."""
+    129 ... 512 signals: the same iteration on the panel-blocked inverse and the blocked products (306: a whole-head MEG array,
+    its record assembled from channel-block pairs by engine._accumulate_blocked)."""
     rng = np.random.default_rng(C)
     T, R = (64 if C <= 128 else 32), (90 if C <= 128 else C)         # (beyond 128 signals: 32 bins, the oracle's time)
     e = rng.standard_normal((T + 8, R, C))
