@@ -864,19 +864,20 @@ __global__ void __launch_bounds__(64 * Q) m_inverse_mfma(MvMat M, const double* 
 //      row operations;
 //   2. the sixteen pivot rows R = W[pr_j][:] (old values) go to LDS;
 //   3. every other column c:  W[r][c] <- (r is one of the pivot rows ? 0 : W[r][c]) + sum_j E[r][j] R[j][c]
-//      (E M = M + (E - I)[:, pivot rows] M[pivot rows, :]): 2 x 4 elements per thread and pass, 0.75 LDS reads per complex FMA;
+//      (E M = M + (E - I)[:, pivot rows] M[pivot rows, :]): round 6: 16 x 16 tiles on the fp64 matrix cores;
 //   4. the panel is written back.
 // M^-1[k][pr_j] = W[pr_k][j] at the end.  1024 threads, 133 KB of LDS: one workgroup per CU.
-// RMAX = 256 with panels of PB = 16 columns (135 KB of LDS), RMAX = 512 with panels of 8 (139 KB): the limit of the full
+// RMAX = 256 with panels of PB = 16 columns (144 KB of LDS), RMAX = 512 with panels of 8 (156 KB + 7 KB static): the limit of the full
 // factorisation (sc_mvar_max_signals).
 template <int PB, int RMAX>
 __global__ void __launch_bounds__(1024) m_inverse_global(MvMat M, const double* __restrict__ lam, MvMat Out, cd* Work,
                                                          const int32_t* __restrict__ status, int C) {
     extern __shared__ __align__(16) unsigned char mv_smem[];
-    cd* Pn = reinterpret_cast<cd*>(mv_smem);          // [RMAX][PB]     the panel
-    cd* Rr = Pn + RMAX * PB;                          // [PB][RMAX]     the pivot rows
-    cd* colbuf = Rr + PB * RMAX;                      // [RMAX]         column j of the panel before step j
-    cd* rowbuf = colbuf + RMAX;                       // [PB]           the scaled pivot row of step j
+    constexpr int PBS = PB + 1, RS = RMAX + 1;        // (odd strides: the matrix-core operand reads walk rows of Pn and columns of Rr)
+    cd* Pn = reinterpret_cast<cd*>(mv_smem);          // [RMAX][PBS]    the panel
+    cd* Rr = Pn + RMAX * PBS;                         // [PB][RS]       the pivot rows
+    cd* colbuf = Rr + PB * RS;                        // [2][RMAX]      column j of the panel before step j (even / odd j)
+    cd* rowbuf = colbuf + 2 * RMAX;                   // [PB]           the scaled pivot row of step j
     __shared__ unsigned key[RMAX];
     __shared__ int prow[RMAX], pos[RMAX];
     __shared__ unsigned char used[RMAX];
@@ -896,86 +897,121 @@ __global__ void __launch_bounds__(1024) m_inverse_global(MvMat M, const double* 
     __syncthreads();
     for (int k0 = 0; k0 < C; k0 += PB) {
         const int nb = C - k0 < PB ? C - k0 : PB;
-        for (int idx = tid; idx < C * PB; idx += 1024) {
-            const int r = idx / PB, j = idx % PB;
-            Pn[idx] = j < nb ? W[r * C + k0 + j] : make_double2(0.0, 0.0);
-        }
-        __syncthreads();
-        for (int j = 0; j < nb; ++j) {
-            if (tid < RMAX) {
-                const cd v = tid < C ? Pn[tid * PB + j] : make_double2(0.0, 0.0);
-                colbuf[tid] = v;
-                const unsigned hi = (unsigned)(__double_as_longlong(v.x * v.x + v.y * v.y) >> 32);
-                key[tid] = (tid >= C || used[tid]) ? 0u : ((hi & ~(unsigned)(2 * RMAX - 1)) | (unsigned)RMAX | (unsigned)(RMAX - 1 - tid));
-            }
-            __syncthreads();
-            unsigned kv = 0u;
+        const int Cr = (C + 15) & ~15;
+        // The panel in registers: thread (row, column quad) keeps four entries (RMAX rows x PB / 4 quads = the 1024 threads); a pivot
+        // step publishes column j, finds the pivot row, has its four owners publish the scaled row, and updates from registers: two
+        // barriers and ~0.7 KB of LDS traffic per wave where the LDS-resident form had three and 16 accesses per thread (round 6).
+        constexpr int NQ = PB / 4;
+        static_assert(RMAX * NQ == 1024, "one thread per (row, column quad)");
+        const int prw = tid % RMAX, pq = tid / RMAX;
+        cd pe[4];
 #pragma unroll
-            for (int q = 0; q < RMAX / 64; ++q) kv = max(kv, key[lane + 64 * q]);
-            const int pr = RMAX - 1 - (int)(mv_wave_max_u32(kv) & (unsigned)(RMAX - 1));
-            const cd piv = colbuf[pr];
-            const double pden = piv.x * piv.x + piv.y * piv.y;
-            const cd inv = make_double2(piv.x / pden, -piv.y / pden);
-            if (tid < PB) rowbuf[tid] = tid == j ? inv : m_mul(Pn[pr * PB + tid], inv);
-            if (tid == 0) { prow[k0 + j] = pr; pos[pr] = k0 + j; used[pr] = 1; }
-            __syncthreads();
-            for (int idx = tid; idx < C * PB; idx += 1024) {
-                const int r = idx / PB, jj = idx % PB;
-                if (r == pr) { Pn[idx] = rowbuf[jj]; continue; }
-                const cd m = colbuf[r], w = rowbuf[jj];
-                cd g = jj == j ? make_double2(0.0, 0.0) : Pn[idx];
-                g.x = fma(-m.x, w.x, fma(m.y, w.y, g.x));
-                g.y = fma(-m.x, w.y, fma(-m.y, w.x, g.y));
-                Pn[idx] = g;
-            }
-            __syncthreads();
-        }
-        for (int idx = tid; idx < PB * C; idx += 1024) {
-            const int j = idx / C, c = idx - j * C;
-            Rr[j * RMAX + c] = j < nb ? W[prow[k0 + j] * C + c] : make_double2(0.0, 0.0);
-        }
-        __syncthreads();
-        {
-            const int ty = tid >> 6, tx = lane;          // rows ty + 16 a, columns tx + 64 b
-            constexpr int NB = RMAX / 64;
-            for (int a = 0; a < RMAX / 16; a += 2) {
-                const int r0 = ty + 16 * a, r1 = r0 + 16;
-                if (r0 >= C) break;
-                cd acc[2][NB];
+        for (int c = 0; c < 4; ++c)
+            pe[c] = (prw < C && 4 * pq + c < nb) ? W[prw * C + k0 + 4 * pq + c] : make_double2(0.0, 0.0);
+        bool row_used = prw < C && used[prw];
+#pragma unroll 1
+        for (int jq = 0; jq < NQ; ++jq) {
 #pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    const int c = tx + 64 * b;
-                    const bool live = c < C && !(c >= k0 && c < k0 + nb);
-                    const bool p0 = used[r0] && pos[r0] >= k0;
-                    const bool p1 = r1 < C && used[r1] && pos[r1] >= k0;
-                    acc[0][b] = (live && !p0) ? W[r0 * C + c] : make_double2(0.0, 0.0);
-                    acc[1][b] = (live && r1 < C && !p1) ? W[r1 * C + c] : make_double2(0.0, 0.0);
-                }
-                for (int j = 0; j < nb; ++j) {
-                    const cd e0 = Pn[r0 * PB + j], e1 = r1 < C ? Pn[r1 * PB + j] : make_double2(0.0, 0.0);
-#pragma unroll
-                    for (int b = 0; b < NB; ++b) {
-                        const cd w = Rr[j * RMAX + tx + 64 * b];
-                        acc[0][b].x = fma(e0.x, w.x, fma(-e0.y, w.y, acc[0][b].x));
-                        acc[0][b].y = fma(e0.x, w.y, fma(e0.y, w.x, acc[0][b].y));
-                        acc[1][b].x = fma(e1.x, w.x, fma(-e1.y, w.y, acc[1][b].x));
-                        acc[1][b].y = fma(e1.x, w.y, fma(e1.y, w.x, acc[1][b].y));
+            for (int jj = 0; jj < 4; ++jj) {
+                const int j = 4 * jq + jj;
+                if (j < nb) {
+                    cd* cb = colbuf + (j & 1) * RMAX;
+                    if (pq == jq) {
+                        const cd v = pe[jj];
+                        cb[prw] = v;
+                        const unsigned hi = (unsigned)(__double_as_longlong(v.x * v.x + v.y * v.y) >> 32);
+                        key[prw] = (prw >= C || row_used) ? 0u : ((hi & ~(unsigned)(2 * RMAX - 1)) | (unsigned)RMAX | (unsigned)(RMAX - 1 - prw));
                     }
-                }
+                    __syncthreads();
+                    unsigned kv = 0u;
 #pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    const int c = tx + 64 * b;
-                    if (c < C && !(c >= k0 && c < k0 + nb)) {
-                        W[r0 * C + c] = acc[0][b];
-                        if (r1 < C) W[r1 * C + c] = acc[1][b];
+                    for (int q = 0; q < RMAX / 64; ++q) kv = max(kv, key[lane + 64 * q]);
+                    const int pr = RMAX - 1 - (int)(mv_wave_max_u32(kv) & (unsigned)(RMAX - 1));
+                    if (prw == pr) {
+                        const cd piv = cb[pr];
+                        const double pden = piv.x * piv.x + piv.y * piv.y;
+                        const cd inv = make_double2(piv.x / pden, -piv.y / pden);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            pe[c] = (pq == jq && c == jj) ? inv : m_mul(pe[c], inv);
+                            rowbuf[4 * pq + c] = pe[c];
+                        }
+                        row_used = true;
+                        if (pq == 0) { prow[k0 + j] = pr; pos[pr] = k0 + j; used[pr] = 1; }
+                    }
+                    __syncthreads();
+                    if (prw != pr) {
+                        const cd m = cb[prw];
+                        if (pq == jq) pe[jj] = make_double2(0.0, 0.0);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const cd w = rowbuf[4 * pq + c];
+                            pe[c].x = fma(-m.x, w.x, fma(m.y, w.y, pe[c].x));
+                            pe[c].y = fma(-m.x, w.y, fma(-m.y, w.x, pe[c].y));
+                        }
                     }
                 }
             }
         }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) Pn[prw * PBS + 4 * pq + c] = pe[c];          // (rows >= C and columns >= nb: zeros)
+        __syncthreads();
+        for (int idx = tid; idx < PB * Cr; idx += 1024) {
+            const int j = idx / Cr, c = idx - j * Cr;
+            Rr[j * RS + c] = (j < nb && c < C) ? W[prow[k0 + j] * C + c] : make_double2(0.0, 0.0);
+        }
+        __syncthreads();
+        {   // W <- (pivot row of this panel ? 0 : W) + E R on the matrix cores (round 6; the VALU form read LDS six times for eight complex
+            // FMAs and ran at a quarter of the fp64 rate): 16 x 16 tiles dealt over the 16 waves, two in flight per wave, A operand = the
+            // panel, B operand = the pivot rows; a panel of 16 columns is a whole tile column and is skipped, one of 8 is masked on the store
+            const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lk = lane >> 4;
+            const int nt = Cr >> 4, ntt = nt * nt;
+            const int tskip = PB == 16 ? (k0 >> 4) : -1;
+            for (int t0 = wave; t0 < ntt; t0 += 32) {
+                mv_f64x4 re[2], im[2];
+                int ti[2], tj[2];
+                bool on[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int t = t0 + 16 * u;
+                    ti[u] = t / nt; tj[u] = t - ti[u] * nt;
+                    on[u] = t < ntt && tj[u] != tskip;
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const int r = 16 * ti[u] + lk + 4 * r4, c = 16 * tj[u] + li;
+                        cd v = make_double2(0.0, 0.0);
+                        if (on[u] && r < C && c < C && !(used[r] && pos[r] >= k0)) v = W[r * C + c];
+                        re[u][r4] = v.x; im[u][r4] = v.y;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (!on[u]) continue;
+#pragma unroll
+                    for (int kk = 0; kk < PB / 4; ++kk) {
+                        const cd av = Pn[(16 * ti[u] + li) * PBS + 4 * kk + lk];
+                        const cd bv = Rr[(4 * kk + lk) * RS + 16 * tj[u] + li];
+                        re[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, bv.x, re[u], 0, 0, 0);
+                        re[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-av.y, bv.y, re[u], 0, 0, 0);
+                        im[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, bv.y, im[u], 0, 0, 0);
+                        im[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, bv.x, im[u], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (!on[u]) continue;
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const int r = 16 * ti[u] + lk + 4 * r4, c = 16 * tj[u] + li;
+                        if (r < C && c < C && !(c >= k0 && c < k0 + nb)) W[r * C + c] = make_double2(re[u][r4], im[u][r4]);
+                    }
+                }
+            }
+        }
         __syncthreads();
         for (int idx = tid; idx < C * PB; idx += 1024) {
             const int r = idx / PB, j = idx % PB;
-            if (j < nb) W[r * C + k0 + j] = Pn[idx];
+            if (j < nb) W[r * C + k0 + j] = Pn[r * PBS + j];
         }
         __syncthreads();
     }
@@ -1383,11 +1419,11 @@ static int mv_launch_inverse_big(int64_t C, dim3 grid, hipStream_t st, MvMat M, 
     if (C > MV_CMID) {
         SC_REQUIRE(scratch, "inverse beyond 128 signals needs a scratch");
         if (C <= 256) {
-            const size_t lds = (size_t)(2 * 256 * 16 + 256 + 16) * sizeof(cd);
+            const size_t lds = (size_t)(256 * 17 + 16 * 257 + 2 * 256 + 16) * sizeof(cd);
             SC_CHECK_HIP(hipFuncSetAttribute((const void*)m_inverse_global<16, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL((m_inverse_global<16, 256>), grid, dim3(1024), lds, st, M, lam, Out, scratch, status, (int)C);
         } else {
-            const size_t lds = (size_t)(2 * 512 * 8 + 512 + 8) * sizeof(cd);
+            const size_t lds = (size_t)(512 * 9 + 8 * 513 + 2 * 512 + 8) * sizeof(cd);
             SC_CHECK_HIP(hipFuncSetAttribute((const void*)m_inverse_global<8, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL((m_inverse_global<8, 512>), grid, dim3(1024), lds, st, M, lam, Out, scratch, status, (int)C);
         }
