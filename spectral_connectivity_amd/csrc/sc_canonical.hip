@@ -752,6 +752,186 @@ __global__ void __launch_bounds__(256) canonical_big_kernel(CanonArgs a, cd* scr
     }
 }
 
+// ---- the same problem with the largest eigenvalue alone (round 6) -------------------------------------------------------------
+// canonical_big_kernel spends most of a problem in the parallel Jacobi (14 sweeps x (n - 1) rounds over the packed triangle:
+// 2 ms of 3.6 at 64 channels, 21 ms a problem at 128) for ONE number, the largest eigenvalue of B = M M^H.  Here B is reduced
+// to a real symmetric tridiagonal matrix by n - 2 Householder reflections (LAPACK zhetd2, lower form, one thread per row of the
+// trailing block: p = tau B22 v, w = p - (tau / 2)(p^H v) v, B22 <- B22 - v w^H - w v^H; only the diagonal and the SQUARES of the
+// subdiagonal are kept, no reflector is stored), and lambda_max is bracketed by multisection on the Sturm count: 256 shifts a
+// round, one per thread, seven rounds from the Gershgorin bracket to the last bits.  B (full storage, column-major) lives in
+// LDS up to 96 channels, beyond in the workgroup's global scratch (the block La is free once M is whitened).
+__device__ __forceinline__ double cbh_sum(double v, double* red4, int tid) {      // block sum over 256 threads, two barriers
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if ((tid & 63) == 0) red4[tid >> 6] = v;
+    __syncthreads();
+    const double r = red4[0] + red4[1] + red4[2] + red4[3];
+    __syncthreads();
+    return r;
+}
+#define CBH_LDS_N 96
+__global__ void __launch_bounds__(256) canonical_big_hh_kernel(CanonArgs a, cd* scratch, int64_t n_items) {
+    extern __shared__ __align__(16) unsigned char cb_smem[];
+    cd* Bl = reinterpret_cast<cd*>(cb_smem);                 // [CBH_LDS_N][CBH_LDS_N] column-major (groups of at most CBH_LDS_N)
+    __shared__ double dg[CBIG_C], e2[CBIG_C];
+    __shared__ cd vs[CBIG_C], ws[CBIG_C];
+    __shared__ double red4[4], sh[4];
+    __shared__ int bad, first_above;
+    const int tid = threadIdx.x;
+    cd* La = scratch + (size_t)blockIdx.x * 3 * CBIG_C * CBIG_C;
+    cd* Lb = La + CBIG_C * CBIG_C;
+    cd* M = Lb + CBIG_C * CBIG_C;
+    for (int64_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int64_t bin = item / a.n_gpairs;
+        int gp = (int)(item - bin * a.n_gpairs);
+        int ga = 0, len = a.G - 1;
+        while (gp >= len) { gp -= len; ++ga; --len; }
+        int gb = ga + 1 + gp;
+        if (a.sizes[gb] < a.sizes[ga]) { const int t = ga; ga = gb; gb = t; }      // B on the smaller group's side
+        const int na = a.sizes[ga], nb = a.sizes[gb];
+        const int32_t* ma = a.members + ga * CBIG_C;
+        const int32_t* mb = a.members + gb * CBIG_C;
+        const ScRec rec = a.accum + bin * a.floats_per_bin;
+        if (tid == 0) bad = 0;
+        for (int e = tid; e < na * na; e += 256) { const int i = e / na, j = e % na; if (j <= i) La[i * CBIG_C + j] = csm_read(rec, a, ma[i], ma[j]); }
+        for (int e = tid; e < nb * nb; e += 256) { const int i = e / nb, j = e % nb; if (j <= i) Lb[i * CBIG_C + j] = csm_read(rec, a, mb[i], mb[j]); }
+        for (int e = tid; e < na * nb; e += 256) { const int i = e / nb, j = e % nb; M[i * CBIG_C + j] = csm_read(rec, a, ma[i], mb[j]); }
+        __syncthreads();
+        cbig_cholesky(La, na, &bad);
+        cbig_cholesky(Lb, nb, &bad);
+        for (int j = tid; j < nb; j += 256)                  // M <- La^-1 M: thread j owns column j
+            for (int i = 0; i < na; ++i) {
+                cd sacc = M[i * CBIG_C + j];
+                for (int k = 0; k < i; ++k) { const cd t = zmul(La[i * CBIG_C + k], M[k * CBIG_C + j]); sacc.x -= t.x; sacc.y -= t.y; }
+                const double d = La[i * CBIG_C + i].x;
+                M[i * CBIG_C + j] = make_double2(sacc.x / d, sacc.y / d);
+            }
+        __syncthreads();
+        for (int i = tid; i < na; i += 256)                  // M <- M Lb^-H: thread i owns row i
+            for (int j = 0; j < nb; ++j) {
+                cd sacc = M[i * CBIG_C + j];
+                for (int k = 0; k < j; ++k) { const cd t = zmulc(M[i * CBIG_C + k], Lb[j * CBIG_C + k]); sacc.x -= t.x; sacc.y -= t.y; }
+                const double d = Lb[j * CBIG_C + j].x;
+                M[i * CBIG_C + j] = make_double2(sacc.x / d, sacc.y / d);
+            }
+        __syncthreads();
+        // B = M M^H, full storage, column-major with leading dimension na
+        cd* B = na <= CBH_LDS_N ? Bl : La;
+        for (int e = tid; e < na * na; e += 256) {
+            const int i = e % na, j = e / na;
+            cd sacc = make_double2(0.0, 0.0);
+            for (int k = 0; k < nb; ++k) { const cd t = zmulc(M[i * CBIG_C + k], M[j * CBIG_C + k]); sacc.x += t.x; sacc.y += t.y; }
+            if (i == j) sacc.y = 0.0;
+            B[(size_t)j * na + i] = sacc;
+        }
+        __syncthreads();
+        // ---- tridiagonalisation (zhetd2, lower): d, e^2 ----
+        for (int k = 0; k + 1 < na; ++k) {
+            const int m = na - k - 1;                        // order of the trailing block
+            const cd* col = B + (size_t)k * na + (k + 1);
+            cd xi = make_double2(0.0, 0.0);
+            if (tid < m) xi = col[tid];
+            if (tid == 0) { sh[0] = xi.x; sh[1] = xi.y; dg[k] = B[(size_t)k * na + k].x; }
+            const double xn2 = cbh_sum((tid >= 1 && tid < m) ? xi.x * xi.x + xi.y * xi.y : 0.0, red4, tid);
+            const double alr = sh[0], ali = sh[1];
+            if (xn2 == 0.0 && ali == 0.0) {                  // H = I (uniform over the workgroup)
+                if (tid == 0) e2[k] = alr * alr;
+                __syncthreads();
+                continue;
+            }
+            const double nrm = sqrt(alr * alr + ali * ali + xn2);
+            const double beta = alr >= 0.0 ? -nrm : nrm;
+            const cd tk = make_double2((beta - alr) / beta, -ali / beta);
+            cd vi = make_double2(0.0, 0.0);
+            {
+                const double dr = alr - beta, di = ali, dd = dr * dr + di * di;
+                const cd scale = make_double2(dr / dd, -di / dd);          // 1 / (alpha - beta)
+                if (tid < m) { vi = tid == 0 ? make_double2(1.0, 0.0) : zmul(xi, scale); vs[tid] = vi; }
+                if (tid == 0) e2[k] = beta * beta;
+            }
+            __syncthreads();
+            const cd* B22 = B + (size_t)(k + 1) * na + (k + 1);
+            cd pi = make_double2(0.0, 0.0);
+            if (tid < m) {
+                cd acc = make_double2(0.0, 0.0);
+                for (int j = 0; j < m; ++j) {
+                    const cd aij = B22[(size_t)j * na + tid], vj = vs[j];
+                    acc.x += aij.x * vj.x - aij.y * vj.y;
+                    acc.y += aij.x * vj.y + aij.y * vj.x;
+                }
+                pi = zmul(tk, acc);
+            }
+            const double dre = cbh_sum(pi.x * vi.x + pi.y * vi.y, red4, tid);       // p^H v
+            const double dim = cbh_sum(pi.x * vi.y - pi.y * vi.x, red4, tid);
+            const cd al2 = zmul(make_double2(-0.5 * tk.x, -0.5 * tk.y), make_double2(dre, dim));
+            cd wi = make_double2(0.0, 0.0);
+            if (tid < m) {
+                const cd t = zmul(al2, vi);
+                wi = make_double2(pi.x + t.x, pi.y + t.y);
+                ws[tid] = wi;
+            }
+            __syncthreads();
+            if (tid < m) {
+                cd* row = B + (size_t)(k + 1) * na + (k + 1) + tid;
+                for (int j = 0; j < m; ++j) {
+                    const cd wj = ws[j], vj = vs[j];
+                    cd aij = row[(size_t)j * na];
+                    aij.x -= vi.x * wj.x + vi.y * wj.y + wi.x * vj.x + wi.y * vj.y;       // a_ij -= v_i conj(w_j) + w_i conj(v_j)
+                    aij.y -= vi.y * wj.x - vi.x * wj.y + wi.y * vj.x - wi.x * vj.y;
+                    row[(size_t)j * na] = aij;
+                }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) { dg[na - 1] = B[(size_t)(na - 1) * na + (na - 1)].x; e2[na - 1] = 0.0; }
+        __syncthreads();
+        // ---- lambda_max by multisection on the Sturm count (x > lambda_max iff all n leading minors of T - x are negative) ----
+        double lo, hi;
+        {
+            double g_hi = -1e300, g_lo = 1e300, emax = 0.0;
+            for (int i = 0; i < na; ++i) {                   // (every thread: n <= 128 LDS reads)
+                const double el = i > 0 ? sqrt(e2[i - 1]) : 0.0, er = i + 1 < na ? sqrt(e2[i]) : 0.0;
+                g_hi = fmax(g_hi, dg[i] + el + er); g_lo = fmin(g_lo, dg[i] - el - er);
+                emax = fmax(emax, e2[i]);
+            }
+            const double tn = fmax(fabs(g_hi), fabs(g_lo));
+            const double pivmin = 2.2250738585072014e-308 * fmax(1.0, emax);
+            const double pad = 2.0 * tn * 2.220446049250313e-16 * na + 2.0 * pivmin;
+            lo = g_lo - pad; hi = g_hi + pad;
+            for (int round = 0; round < 8; ++round) {
+                const double x = lo + (hi - lo) * ((double)(tid + 1) / 257.0);
+                int cnt = 0;
+                double q = dg[0] - x;
+                if (fabs(q) < pivmin) q = -pivmin;
+                cnt += q < 0.0;
+                for (int i = 1; i < na; ++i) {
+                    q = dg[i] - x - e2[i - 1] / q;
+                    if (fabs(q) < pivmin) q = -pivmin;
+                    cnt += q < 0.0;
+                }
+                if (tid == 0) first_above = 256;
+                __syncthreads();
+                if (cnt == na) atomicMin(&first_above, tid);     // every eigenvalue lies below x
+                __syncthreads();
+                const int f = first_above;
+                const double nlo = f == 0 ? lo : lo + (hi - lo) * ((double)f / 257.0);
+                const double nhi = f == 256 ? hi : lo + (hi - lo) * ((double)(f + 1) / 257.0);
+                __syncthreads();
+                if (!(nhi - nlo < hi - lo)) break;           // (uniform: the bracket is down to neighbouring doubles)
+                lo = nlo; hi = nhi;
+            }
+        }
+        if (tid == 0) {
+            double v = 0.5 * (lo + hi);
+            if (bad) { v = nan(""); atomicAdd(a.fail, 1); }
+            double* o = a.out + bin * a.G * a.G;
+            o[ga * a.G + gb] = v;
+            o[gb * a.G + ga] = v;
+        }
+        __syncthreads();
+    }
+}
+
 extern "C" int sc_canonical_max_group(void) { return CBIG_C; }
 
 extern "C" int sc_canonical_coherence_f64(const void* d_accum, int64_t n_bins, int64_t n_signals, uint32_t planes,
@@ -822,11 +1002,18 @@ extern "C" int sc_canonical_coherence_f64(const void* d_accum, int64_t n_bins, i
                 sc_set_error("canonical coherence: scratch allocation of %zu bytes failed", sbytes);
                 return SC_ENOMEM;
             }
-            constexpr size_t HM = CBIG_C / 2;
-            const size_t lds = (size_t)CBIG_C * (CBIG_C + 1) / 2 * sizeof(cd) + HM * 8 + HM * 16 + 2 * HM * 4 +
-                               HM * (HM + 1) * 2 + 64;
-            SC_CHECK_HIP(hipFuncSetAttribute((const void*)canonical_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(canonical_big_kernel, dim3((unsigned)slots), dim3(256), lds, st, a, scratch, threads);
+            const char* eig = sc_switch(SC_SW_CANON_EIG);       // (=jacobi: the round-2 kernel, every eigenvalue of B -- A/B and cross-check)
+            if (eig && eig[0] == 'j') {
+                constexpr size_t HM = CBIG_C / 2;
+                const size_t lds = (size_t)CBIG_C * (CBIG_C + 1) / 2 * sizeof(cd) + HM * 8 + HM * 16 + 2 * HM * 4 +
+                                   HM * (HM + 1) * 2 + 64;
+                SC_CHECK_HIP(hipFuncSetAttribute((const void*)canonical_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(canonical_big_kernel, dim3((unsigned)slots), dim3(256), lds, st, a, scratch, threads);
+            } else {
+                const size_t lds = (size_t)CBH_LDS_N * CBH_LDS_N * sizeof(cd);
+                SC_CHECK_HIP(hipFuncSetAttribute((const void*)canonical_big_hh_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(canonical_big_hh_kernel, dim3((unsigned)slots), dim3(256), lds, st, a, scratch, threads);
+            }
             (void)hipFreeAsync(scratch, st);
         }
     }

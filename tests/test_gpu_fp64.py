@@ -348,17 +348,19 @@ def test_canonical_coherence_large_groups_float64(sc, sizes):
     close64(got, ref, rtol=1e-7, floor=1e-9, what=f"canonical coherence, groups {sizes}")
 
 
-@pytest.mark.parametrize("case", ["ragged", "sixteen", "degenerate", "tiny"])
+@pytest.mark.parametrize("case", ["ragged", "sixteen", "degenerate", "tiny", "big"])
 def test_canonical_coherence_top_eigenvalue_kernel_equals_the_jacobi_kernel(sc, debug_env, case):
     """Groups of at most 16 channels: the (bin, pair) kernel reduces B = M M^H to a tridiagonal matrix by Householder reflections in
     registers and brackets its LARGEST eigenvalue by multisection on the Sturm sequence (csrc/sc_canonical.hip, round 5);
     SC_CANON_EIG=jacobi keeps the parallel Jacobi of rounds 1-4, which finds all sixteen.  Both from the same double records:
     the new kernel equals the oracle's SVD form (connectivity.py:745-820) to 1e-12, the Jacobi kernel to 1e-7 -- ragged group sizes incl.
     single channels, full groups, groups with duplicated channels (rank-deficient blocks fail the Cholesky in both: NaN pattern
-    equal), and a group pair with a coupling at the rounding level."""
+    equal), and a group pair with a coupling at the rounding level.  "big" (round 6): groups beyond 32 channels, a workgroup per (bin,
+    pair) -- canonical_big_hh_kernel (Householder reflections over B in LDS, lambda_max by 256-way multisection on the Sturm count)
+    against canonical_big_kernel (the parallel Jacobi over the packed triangle)."""
     from oracle import spectral_oracle as so
-    rng = np.random.default_rng({"ragged": 3, "sixteen": 4, "degenerate": 5, "tiny": 6}[case])
-    sizes = {"ragged": (1, 16, 7, 2, 11, 16, 3), "sixteen": (16,) * 6, "degenerate": (8, 8, 5), "tiny": (6, 9)}[case]
+    rng = np.random.default_rng({"ragged": 3, "sixteen": 4, "degenerate": 5, "tiny": 6, "big": 7}[case])
+    sizes = {"ragged": (1, 16, 7, 2, 11, 16, 3), "sixteen": (16,) * 6, "degenerate": (8, 8, 5), "tiny": (6, 9), "big": (40, 64, 33, 100)}[case]
     C = sum(sizes)
     labels = np.repeat(np.arange(len(sizes)), sizes)
     T, R = 128, 40

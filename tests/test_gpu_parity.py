@@ -506,7 +506,7 @@ def test_f9_mvar_measures_vs_reference(sc, golden, tag):
 @pytest.mark.parametrize("c,N,P", [(3, 64, 2), (8, 128, 3), (17, 64, 1), (40, 32, 2), (64, 32, 1),
                                    (65, 32, 2), (80, 48, 1), (96, 64, 1), (97, 32, 1), (128, 32, 2), (100, 256, 1),
                                    (129, 32, 1), (160, 32, 1), (200, 256, 1), (250, 48, 1), (256, 32, 1),
-                                   (257, 32, 1), (306, 64, 2), (400, 32, 1), (512, 32, 1)])
+                                   (257, 32, 1), (306, 32, 2), (512, 32, 1)])
 def test_full_wilson_factor_standalone_fp64(sc, c, N, P):
     """minimum_phase_decomposition() for c > 2 on exactly representable fp64 spectra of known
     minimum-phase filters: S = F F^H with F(z) = I + B z^-1 (||B|| < 1) factors back to F Q with the
@@ -538,7 +538,8 @@ def test_mvar_measures_beyond_64_signals_vs_oracle(sc, C):
     129 ... 512 signals: the same iteration on the panel-blocked inverse and the blocked products (306: a whole-head MEG array,
     its record assembled from channel-block pairs by engine._accumulate_blocked)."""
     rng = np.random.default_rng(C)
-    T, R = (64 if C <= 128 else 32), (90 if C <= 128 else C)         # (beyond 128 signals: 32 bins, the oracle's time)
+    # (beyond 128 signals: 32 bins, the oracle's time; 306 signals: 204 trials x 3 tapers = 612 observations)
+    T, R = (64 if C <= 128 else 32), (90 if C <= 128 else (C if C <= 256 else 204))
     e = rng.standard_normal((T + 8, R, C))
     x = e.copy()
     for t in range(2, T + 8):                                 # a sparse stable VAR(2): neighbours drive each other
@@ -562,8 +563,9 @@ def test_mvar_measures_beyond_64_signals_vs_oracle(sc, C):
     close(c._transfer_function, q["H"], "transfer function", tol=loose)
     close(c._MVAR_Fourier_coefficients, q["A"], "MVAR coefficients", tol=1e-5)
     close(c.directed_transfer_function(), so.directed_transfer_function(coef, q=q), "DTF", tol=loose)
-    close(c.partial_directed_coherence(), so.partial_directed_coherence(coef, q=q), "PDC", tol=1e-5)
-    close(c.direct_directed_transfer_function(), so.direct_directed_transfer_function(coef, q=q), "dDTF", tol=1e-5)
+    if C <= 256:                # (306 signals: the oracle's partial coherence alone takes half a minute; the kernels are those of 160)
+        close(c.partial_directed_coherence(), so.partial_directed_coherence(coef, q=q), "PDC", tol=1e-5)
+        close(c.direct_directed_transfer_function(), so.direct_directed_transfer_function(coef, q=q), "dDTF", tol=1e-5)
     assert c._last_wilson["not_converged"] == 0 and c._last_wilson["iterations"] < 60
 
 
