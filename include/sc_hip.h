@@ -502,8 +502,9 @@ int sc_global_coherence_f64(const void* d_accum, int64_t n_groups, int64_t n_fre
  *   d_out       double [n_bins][n_groups][n_groups], symmetric, NaN diagonal
  *   d_fail      int32 [1]: number of group blocks that were not positive definite
  * Groups of <= 16 channels take a stream-ordered workspace of n_bins * n_groups * 4 KB for the
- * inverted group factors, groups beyond 32 channels one of 768 KB per persistent workgroup (<= 256) for the blocks of
- * the pair in flight (hipMallocAsync / hipFreeAsync on `stream`); SC_ENOMEM if that fails. */
+ * inverted group factors, groups beyond 64 channels one of 768 KB per persistent workgroup (<= 256) for the blocks of
+ * the pair in flight (hipMallocAsync / hipFreeAsync on `stream`); SC_ENOMEM if that fails.  17 ... 64 channels: a
+ * workgroup per (bin, group pair) with the whole problem in LDS (round 6), no workspace. */
 int sc_canonical_max_group(void);
 int sc_canonical_coherence_f64(const void* d_accum, int64_t n_bins, int64_t n_signals, uint32_t planes,
                                int64_t n_observations, const int32_t* d_members, const int32_t* d_sizes,

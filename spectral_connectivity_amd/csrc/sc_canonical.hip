@@ -28,6 +28,7 @@ struct CanonArgs {
     int32_t* fail;            // [1] count of non positive-definite group blocks
     int64_t n_bins, floats_per_bin;
     int G, n_gpairs, NB, n_tiles, p_csm;
+    int mstride;              // row length of `members` for the workgroup-per-problem kernels (32 or CBIG_C)
     double jtol;
     double n_obs;
 };
@@ -687,8 +688,8 @@ __global__ void __launch_bounds__(256) canonical_big_kernel(CanonArgs a, cd* scr
         // the Jacobi runs on the SMALLER group's side: B = M M^H is n_a x n_a with the same non-zero spectrum either way
         if (a.sizes[gb] < a.sizes[ga]) { const int t = ga; ga = gb; gb = t; }
         const int na = a.sizes[ga], nb = a.sizes[gb];
-        const int32_t* ma = a.members + ga * CBIG_C;
-        const int32_t* mb = a.members + gb * CBIG_C;
+        const int32_t* ma = a.members + ga * a.mstride;
+        const int32_t* mb = a.members + gb * a.mstride;
         const ScRec rec = a.accum + bin * a.floats_per_bin;
         if (tid == 0) bad = 0;
         for (int e = tid; e < na * na; e += 256) { const int i = e / na, j = e % na; if (j <= i) La[i * CBIG_C + j] = csm_read(rec, a, ma[i], ma[j]); }
@@ -760,6 +761,38 @@ __global__ void __launch_bounds__(256) canonical_big_kernel(CanonArgs a, cd* scr
 // subdiagonal are kept, no reflector is stored), and lambda_max is bracketed by multisection on the Sturm count: 256 shifts a
 // round, one per thread, seven rounds from the Gershgorin bracket to the last bits.  B (full storage, column-major) lives in
 // LDS up to 96 channels, beyond in the workgroup's global scratch (the block La is free once M is whitened).
+#define CBH_LDS_N 96
+#define CBH_SMALL 64           // pairs of groups of at most this many channels are processed in LDS entirely
+#define CBH_LD 65              // their row length (odd: a column walk touches every bank)
+// in-place lower Cholesky of the n x n Hermitian matrix L (row-major, row length ld, lower triangle valid), all 256 threads
+__device__ inline void cbh_cholesky(cd* L, int ld, int n, int* bad) {
+    const int tid = threadIdx.x;
+    for (int k = 0; k < n; ++k) {
+        if (tid == 0) {
+            const double d = L[k * ld + k].x;
+            if (!(d > 0.0)) *bad = 1;
+            L[k * ld + k] = make_double2(sqrt(d > 0.0 ? d : 1.0), 0.0);
+        }
+        __syncthreads();
+        const double dk = L[k * ld + k].x;
+        for (int i = k + 1 + tid; i < n; i += 256) {
+            const cd v = L[i * ld + k];
+            L[i * ld + k] = make_double2(v.x / dk, v.y / dk);
+        }
+        __syncthreads();
+        const int m = n - k - 1;
+        for (int e = tid; e < m * m; e += 256) {           // trailing lower triangle: L[i][j] -= L[i][k] conj(L[j][k]), k < j <= i
+            const int i = k + 1 + e / m, j = k + 1 + e % m;
+            if (j <= i) {
+                const cd t = zmulc(L[i * ld + k], L[j * ld + k]);
+                cd v = L[i * ld + j];
+                v.x -= t.x; v.y -= t.y;
+                L[i * ld + j] = v;
+            }
+        }
+        __syncthreads();
+    }
+}
 __device__ __forceinline__ double cbh_sum(double v, double* red4, int tid) {      // block sum over 256 threads, two barriers
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
@@ -769,18 +802,17 @@ __device__ __forceinline__ double cbh_sum(double v, double* red4, int tid) {    
     __syncthreads();
     return r;
 }
-#define CBH_LDS_N 96
-__global__ void __launch_bounds__(256) canonical_big_hh_kernel(CanonArgs a, cd* scratch, int64_t n_items) {
+__global__ void __launch_bounds__(256) canonical_big_hh_kernel(CanonArgs a, cd* scratch, int64_t n_items, int small_n, int small_ld) {
     extern __shared__ __align__(16) unsigned char cb_smem[];
-    cd* Bl = reinterpret_cast<cd*>(cb_smem);                 // [CBH_LDS_N][CBH_LDS_N] column-major (groups of at most CBH_LDS_N)
-    __shared__ double dg[CBIG_C], e2[CBIG_C];
+    cd* Bl = reinterpret_cast<cd*>(cb_smem);                 // CBH_LDS_N^2 elements: B (column-major) or, for pairs of groups of at
+    __shared__ double dg[CBIG_C], e2[CBIG_C];                // most CBH_SMALL channels, the whole problem (one factor block + M)
     __shared__ cd vs[CBIG_C], ws[CBIG_C];
     __shared__ double red4[4], sh[4];
     __shared__ int bad, first_above;
     const int tid = threadIdx.x;
-    cd* La = scratch + (size_t)blockIdx.x * 3 * CBIG_C * CBIG_C;
-    cd* Lb = La + CBIG_C * CBIG_C;
-    cd* M = Lb + CBIG_C * CBIG_C;
+    cd* Lag = scratch + (size_t)blockIdx.x * 3 * CBIG_C * CBIG_C;
+    cd* Lbg = Lag + CBIG_C * CBIG_C;
+    cd* Mg = Lbg + CBIG_C * CBIG_C;
     for (int64_t item = blockIdx.x; item < n_items; item += gridDim.x) {
         const int64_t bin = item / a.n_gpairs;
         int gp = (int)(item - bin * a.n_gpairs);
@@ -789,38 +821,62 @@ __global__ void __launch_bounds__(256) canonical_big_hh_kernel(CanonArgs a, cd* 
         int gb = ga + 1 + gp;
         if (a.sizes[gb] < a.sizes[ga]) { const int t = ga; ga = gb; gb = t; }      // B on the smaller group's side
         const int na = a.sizes[ga], nb = a.sizes[gb];
-        const int32_t* ma = a.members + ga * CBIG_C;
-        const int32_t* mb = a.members + gb * CBIG_C;
+        const int32_t* ma = a.members + ga * a.mstride;
+        const int32_t* mb = a.members + gb * a.mstride;
         const ScRec rec = a.accum + bin * a.floats_per_bin;
+        // Pairs of groups of at most CBH_SMALL channels stay in LDS from the records to lambda_max: one factor block at a time (L_b takes
+        // L_a's place once M is multiplied by L_a^-1, B takes L_b's) beside M; larger pairs keep the three blocks in the global scratch.
+        // (small_n: CBH_SMALL, or the largest group when no group is larger -- the launch then asks for 2 small_n small_ld elements of LDS
+        //  only and several workgroups share a compute unit: 34 KB at 32 channels)
+        const bool small = nb <= small_n;                    // (na <= nb)
+        cd* PA = small ? Bl : Lag;
+        cd* PB = small ? Bl : Lbg;
+        cd* PM = small ? Bl + small_n * small_ld : Mg;
+        const int ld = small ? small_ld : CBIG_C;
         if (tid == 0) bad = 0;
-        for (int e = tid; e < na * na; e += 256) { const int i = e / na, j = e % na; if (j <= i) La[i * CBIG_C + j] = csm_read(rec, a, ma[i], ma[j]); }
-        for (int e = tid; e < nb * nb; e += 256) { const int i = e / nb, j = e % nb; if (j <= i) Lb[i * CBIG_C + j] = csm_read(rec, a, mb[i], mb[j]); }
-        for (int e = tid; e < na * nb; e += 256) { const int i = e / nb, j = e % nb; M[i * CBIG_C + j] = csm_read(rec, a, ma[i], mb[j]); }
+        for (int e = tid; e < na * na; e += 256) { const int i = e / na, j = e % na; if (j <= i) PA[i * ld + j] = csm_read(rec, a, ma[i], ma[j]); }
+        for (int e = tid; e < na * nb; e += 256) { const int i = e / nb, j = e % nb; PM[i * ld + j] = csm_read(rec, a, ma[i], mb[j]); }
         __syncthreads();
-        cbig_cholesky(La, na, &bad);
-        cbig_cholesky(Lb, nb, &bad);
-        for (int j = tid; j < nb; j += 256)                  // M <- La^-1 M: thread j owns column j
-            for (int i = 0; i < na; ++i) {
-                cd sacc = M[i * CBIG_C + j];
-                for (int k = 0; k < i; ++k) { const cd t = zmul(La[i * CBIG_C + k], M[k * CBIG_C + j]); sacc.x -= t.x; sacc.y -= t.y; }
-                const double d = La[i * CBIG_C + i].x;
-                M[i * CBIG_C + j] = make_double2(sacc.x / d, sacc.y / d);
+        cbh_cholesky(PA, ld, na, &bad);
+        // M <- L_a^-1 M, right-looking: row k is final once it is divided by L_a[k][k]; every row below loses its multiple of it
+        for (int k = 0; k < na; ++k) {
+            const double dk = PA[k * ld + k].x;
+            if (tid < nb) { const cd v = PM[k * ld + tid]; PM[k * ld + tid] = make_double2(v.x / dk, v.y / dk); }
+            __syncthreads();
+            const int rows = na - k - 1;
+            for (int e = tid; e < rows * nb; e += 256) {
+                const int i = k + 1 + e / nb, j = e % nb;
+                const cd t = zmul(PA[i * ld + k], PM[k * ld + j]);
+                cd v = PM[i * ld + j];
+                v.x -= t.x; v.y -= t.y;
+                PM[i * ld + j] = v;
             }
+            __syncthreads();
+        }
+        for (int e = tid; e < nb * nb; e += 256) { const int i = e / nb, j = e % nb; if (j <= i) PB[i * ld + j] = csm_read(rec, a, mb[i], mb[j]); }
         __syncthreads();
-        for (int i = tid; i < na; i += 256)                  // M <- M Lb^-H: thread i owns row i
-            for (int j = 0; j < nb; ++j) {
-                cd sacc = M[i * CBIG_C + j];
-                for (int k = 0; k < j; ++k) { const cd t = zmulc(M[i * CBIG_C + k], Lb[j * CBIG_C + k]); sacc.x -= t.x; sacc.y -= t.y; }
-                const double d = Lb[j * CBIG_C + j].x;
-                M[i * CBIG_C + j] = make_double2(sacc.x / d, sacc.y / d);
+        cbh_cholesky(PB, ld, nb, &bad);
+        // M <- M L_b^-H: column k is final once it is divided by L_b[k][k]; every column to its right loses conj(L_b[j][k]) times it
+        for (int k = 0; k < nb; ++k) {
+            const double dk = PB[k * ld + k].x;
+            if (tid < na) { const cd v = PM[tid * ld + k]; PM[tid * ld + k] = make_double2(v.x / dk, v.y / dk); }
+            __syncthreads();
+            const int cols = nb - k - 1;
+            for (int e = tid; e < na * cols; e += 256) {
+                const int i = e / cols, j = k + 1 + e % cols;
+                const cd t = zmulc(PM[i * ld + k], PB[j * ld + k]);
+                cd v = PM[i * ld + j];
+                v.x -= t.x; v.y -= t.y;
+                PM[i * ld + j] = v;
             }
-        __syncthreads();
-        // B = M M^H, full storage, column-major with leading dimension na
-        cd* B = na <= CBH_LDS_N ? Bl : La;
+            __syncthreads();
+        }
+        // B = M M^H, full storage, column-major with leading dimension na (small pairs: where the factor blocks were)
+        cd* B = (small || na <= CBH_LDS_N) ? Bl : Lag;
         for (int e = tid; e < na * na; e += 256) {
             const int i = e % na, j = e / na;
             cd sacc = make_double2(0.0, 0.0);
-            for (int k = 0; k < nb; ++k) { const cd t = zmulc(M[i * CBIG_C + k], M[j * CBIG_C + k]); sacc.x += t.x; sacc.y += t.y; }
+            for (int k = 0; k < nb; ++k) { const cd t = zmulc(PM[i * ld + k], PM[j * ld + k]); sacc.x += t.x; sacc.y += t.y; }
             if (i == j) sacc.y = 0.0;
             B[(size_t)j * na + i] = sacc;
         }
@@ -954,6 +1010,7 @@ extern "C" int sc_canonical_coherence_f64(const void* d_accum, int64_t n_bins, i
     a.floats_per_bin = (int64_t)sc_plane_count(planes) * a.n_tiles * SC_TILE_ELEMS;
     a.p_csm = sc_plane_offset(planes, SC_PLANE_CSM);
     a.n_obs = (double)n_observations;
+    a.mstride = max_group_size <= 32 ? 32 : CBIG_C;      // (the member table's row length is the caller's: sc_hip.h)
     a.jtol = 1e-24;          // off^2 <= jtol dia^2: eigenvalues to ~1e-12 relative (quadratic convergence)
     const int64_t total_out = n_bins * n_groups * n_groups;
     hipLaunchKernelGGL(canon_fill_nan, dim3((unsigned)((total_out + 255) / 256)), dim3(256), 0, st, d_out, total_out);
@@ -991,8 +1048,20 @@ extern "C" int sc_canonical_coherence_f64(const void* d_accum, int64_t n_bins, i
                                    (const int*)okb);
             }
             (void)hipFreeAsync(Lg, st);
-        } else if (max_group_size <= 32) {
+        } else if (max_group_size <= 32 && sc_switch(SC_SW_CANON_EIG) && sc_switch(SC_SW_CANON_EIG)[0] == 'j') {
+            // (rounds 1-5: a wave per problem, its three blocks in the lanes' scratch, Jacobi -- 134 ms for 8 groups of 32 x 513 bins
+            //  where the workgroup-per-problem kernel below takes 22: kept for A/B and cross-check only)
             hipLaunchKernelGGL(canonical_kernel<32>, dim3(blocks), dim3(64), 0, st, a);
+        } else if (max_group_size <= CBH_SMALL && !(sc_switch(SC_SW_CANON_EIG) && sc_switch(SC_SW_CANON_EIG)[0] == 'j')) {
+            // every pair fits LDS: no scratch, and as many persistent workgroups per compute unit as their LDS allows
+            const int sn = max_group_size, sld = max_group_size | 1;
+            const size_t lds = (size_t)2 * sn * sld * sizeof(cd);
+            int per_cu = (int)((160 * 1024 - 8 * 1024) / (lds + 7 * 1024));          // (static arrays: ~7 KB a workgroup)
+            per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+            const int64_t want = (int64_t)256 * per_cu;
+            const int slots = (int)(threads < want ? threads : want);
+            SC_CHECK_HIP(hipFuncSetAttribute((const void*)canonical_big_hh_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(canonical_big_hh_kernel, dim3((unsigned)slots), dim3(256), lds, st, a, (cd*)nullptr, threads, sn, sld);
         } else {
             // (members stride CBIG_C) persistent workgroups, three C x C matrices each in a stream-ordered scratch
             const int slots = (int)(threads < 256 ? threads : 256);
@@ -1012,7 +1081,7 @@ extern "C" int sc_canonical_coherence_f64(const void* d_accum, int64_t n_bins, i
             } else {
                 const size_t lds = (size_t)CBH_LDS_N * CBH_LDS_N * sizeof(cd);
                 SC_CHECK_HIP(hipFuncSetAttribute((const void*)canonical_big_hh_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(canonical_big_hh_kernel, dim3((unsigned)slots), dim3(256), lds, st, a, scratch, threads);
+                hipLaunchKernelGGL(canonical_big_hh_kernel, dim3((unsigned)slots), dim3(256), lds, st, a, scratch, threads, CBH_SMALL, CBH_LD);
             }
             (void)hipFreeAsync(scratch, st);
         }

@@ -28,11 +28,12 @@ x += (0.6 * np.repeat(np.random.default_rng(8).standard_normal((1024, 500, 4)), 
 m = sc.Multitaper(x, sampling_frequency=1000.0, time_halfbandwidth_product=3)
 c = sc.Connectivity.from_multitaper(m, dtype=np.complex64)
 c.coherence_magnitude()
-for sizes in ((16,) * 16, (64,) * 4, (128,) * 2):
+# ((32,) * 8: the wave-per-problem kernel of groups up to 32; (33,) + (32,) * 6 + (31,): the same work on the workgroup-per-problem kernel)
+for sizes in ((16,) * 16, (32,) * 8, (33,) + (32,) * 6 + (31,), (24,) * 10 + (16,), (64,) * 4, (128,) * 2):
     labels = np.repeat(np.arange(len(sizes)), sizes)
     for rep in range(2):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         cc, _ = c.canonical_coherence(labels)
         torch.cuda.synchronize()
-    print(f"canonical coherence, {len(sizes)} groups of {sizes[0]}: {1e3 * (time.perf_counter() - t0):.1f} ms, out {cc.shape}")
+    print(f"canonical coherence, {len(sizes)} groups of {sizes[0]} ({sizes[-1]}): {1e3 * (time.perf_counter() - t0):.1f} ms, out {cc.shape}")
