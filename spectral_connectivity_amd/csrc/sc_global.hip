@@ -16,6 +16,7 @@
 typedef double2 cd;
 
 #define GC_CMAX 64
+#define GC_EIGH_MIN 32       // beyond: Householder + bisection + inverse iteration (global_coherence_eigh_kernel)
 
 struct GcArgs {
     ScRec accum;
@@ -707,7 +708,9 @@ extern "C" int sc_global_coherence_f64(const void* d_accum, int64_t n_groups, in
         sc_set_error("global coherence: the Jacobi kernels (SC_GLOBAL_EIG=jacobi) take n_signals <= %d (got %lld)", GC_HUGE_CMAX, (long long)C);
         return SC_EUNSUPPORTED;
     }
-    if (C > GC_CMAX && !(eig_env && strcmp(eig_env, "jacobi") == 0)) {
+    // (round 6: from 33 signals on -- the LDS Jacobi kernel below took 22.5 ms for 1024 bins of 64 signals where this one takes 3.3 at 65;
+    //  tools/cliff_sweep.py)
+    if (C > GC_EIGH_MIN && !(eig_env && strcmp(eig_env, "jacobi") == 0)) {
         // Householder tridiagonalisation + bisection + inverse iteration, matrix and work arrays in a scratch of this call
         const int64_t bins = n_groups * N;
         // slots (workgroups that walk the bins): as many as 1 GB of scratch holds, at most 1024; halved while the allocation fails

@@ -965,7 +965,7 @@ def test_f13_canonical_coherence_with_fewer_observations_than_channels(sc, golde
         close32(cc, g[f"cc_{tag}"], rtol=2e-5, atol_scale=2e-5, what=f"canonical coherence, few observations ({tag})")
 
 
-@pytest.mark.parametrize("C,max_rank", [(72, 9), (96, 96), (128, 40), (130, 7), (160, 160)])
+@pytest.mark.parametrize("C,max_rank", [(33, 5), (48, 48), (64, 3), (72, 9), (96, 96), (128, 40), (130, 7), (160, 160)])
 def test_global_coherence_any_rank_beyond_64_signals(sc, C, max_rank):
     """max_rank up to n_signals beyond 64 signals (the reference's full SVD, connectivity.py:2245-2279): every value
     against the oracle, and G V = V diag(values) for the returned vectors (each column an eigenvector of the cross-

@@ -1,0 +1,70 @@
+"""Timing sweep over NEIGHBOURING parameters of the stage-D / section 8(f) measures (round 6): a kernel family usually changes at a
+size boundary (16 / 17 channels a group, 64 / 65 signals, a power-of-two window or not) -- a cliff there is a path nobody measured.
+ms per call (second call of two), public classes, float64 records where the measure is fp64.  Usage: python tools/cliff_sweep.py [what...]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import spectral_connectivity_amd as sc      # noqa: E402
+
+what = set(sys.argv[1:]) or {"global", "granger", "mvar", "expectation"}
+
+
+def timed(fn, reps=2):
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = fn()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    return 1e3 * dt, out
+
+
+def series(T, R, C, seed=0):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((T, R, C)).astype(np.float32)
+    x[1:] += 0.5 * x[:-1]
+    x[:, :, 1:] += 0.3 * x[:, :, :-1]
+    return x
+
+
+if "global" in what:
+    for C in (32, 48, 64, 65, 96, 128):
+        m = sc.Multitaper(series(1024, 200, C), sampling_frequency=1000.0, time_halfbandwidth_product=3)
+        c = sc.Connectivity.from_multitaper(m, dtype=np.complex64)
+        c.coherence_magnitude()
+        ms, (vals, _) = timed(lambda: c.global_coherence(max_rank=2))
+        print(f"global coherence    C={C:4d}, {vals.shape[1]} bins: {ms:8.1f} ms")
+
+if "granger" in what:
+    for L in (4096, 4000, 2048, 2000, 1024, 1000, 500):
+        m = sc.Multitaper(series(4096, 50, 32, 1), sampling_frequency=1000.0, time_halfbandwidth_product=3,
+                          n_time_samples_per_window=L, n_time_samples_per_step=L)
+        c = sc.Connectivity.from_multitaper(m)
+        c.coherence_magnitude()
+        ms, g = timed(lambda: c.pairwise_spectral_granger_prediction())
+        it = c._last_wilson["iterations"] if getattr(c, "_last_wilson", None) else -1
+        print(f"pairwise Granger    32 ch (496 pairs), window {L:5d} ({g.shape[0]} windows): {ms:8.1f} ms, {it} iterations")
+
+if "mvar" in what:
+    for C in (8, 16, 32, 48, 64, 65, 80):
+        m = sc.Multitaper(series(1792, 40, C, 2), sampling_frequency=500.0, time_halfbandwidth_product=3, n_time_samples_per_window=256)
+        def run():
+            c = sc.Connectivity.from_multitaper(m)
+            return c.directed_transfer_function(), c
+        ms, (d, c) = timed(run)
+        print(f"full Wilson + DTF   C={C:4d}, 7 windows x 256 bins: {ms:8.1f} ms, {c._last_wilson['iterations']} iterations")
+
+if "expectation" in what:
+    x = series(1024, 200, 64, 3)
+    for et in ("trials_tapers", "trials", "tapers", "time_trials_tapers", "time_trials", "time_tapers", "time"):
+        m = sc.Multitaper(x, sampling_frequency=1000.0, time_halfbandwidth_product=4, n_time_samples_per_window=256, n_time_samples_per_step=128)
+        def run():
+            c = sc.Connectivity.from_multitaper(m, expectation_type=et, dtype=np.complex64)
+            return c.coherence_magnitude(), c.weighted_phase_lag_index()
+        ms, (coh, w) = timed(run)
+        print(f"coherence + wPLI    64 ch x 200 trials, expectation over {et:20s}: {ms:8.1f} ms, out {coh.shape}")
