@@ -68,3 +68,44 @@ if "expectation" in what:
             return c.coherence_magnitude(), c.weighted_phase_lag_index()
         ms, (coh, w) = timed(run)
         print(f"coherence + wPLI    64 ch x 200 trials, expectation over {et:20s}: {ms:8.1f} ms, out {coh.shape}")
+
+if "hot" in what:
+    # the hot path itself (float32 engine, coherence + wPLI through the public classes, series resident in HBM, the library's own timers):
+    # one parameter of BASELINE configs[2] varied at a time; ms of device time per pass and per GB of one-sided complex64 spectra
+    from spectral_connectivity_amd import _lib
+    base = dict(T=1024, R=250, C=128, L=256, step=128, NW=4, detrend="constant")
+    variants = [("base (cfg3 / 4 trials)", {})]
+    variants += [(f"C={c}", dict(C=c)) for c in (40, 44, 64, 100, 127, 129, 130, 192, 256, 258)]
+    variants += [(f"window={l} step={s}", dict(L=l, step=s)) for l, s in ((256, 256), (256, 64), (128, 64), (64, 32), (32, 16), (100, 50), (300, 150),
+                                                                          (384, 192), (768, 384), (1024, 1024))]
+    variants += [(f"T={t} window={t}", dict(T=t, L=t, step=t, R=64)) for t in (4096, 8192, 5000, 6000)]
+    variants += [(f"R={r}", dict(R=r)) for r in (249, 10, 1)]
+    variants += [(f"NW={nw}", dict(NW=nw)) for nw in (1.5, 2, 8)]
+    variants += [(f"detrend={d}", dict(detrend=d)) for d in (None, "linear")]
+    _lib.timing_enable(True)
+    for name, kv in variants:
+        p = dict(base, **kv)
+        x = torch.from_numpy(series(p["T"], p["R"], p["C"], 5)).cuda()
+        try:
+            def run():
+                m = sc.Multitaper(x, sampling_frequency=1000.0, time_halfbandwidth_product=p["NW"], n_time_samples_per_window=p["L"],
+                                  n_time_samples_per_step=p["step"], detrend_type=p["detrend"])
+                c = sc.Connectivity.from_multitaper(m, dtype=np.complex64)
+                return c.coherence_magnitude(), c.weighted_phase_lag_index(), m
+            run()
+            torch.cuda.synchronize(); _lib.last_timing()
+            coh, w, m = run()
+            torch.cuda.synchronize()
+            tm = _lib.last_timing()
+            dev = sum(v for _, v in tm)
+            W = coh.shape[0] if coh.ndim == 4 else 1
+            F = coh.shape[-3]
+            K = m.tapers.shape[1]
+            gb = 8.0 * W * p["R"] * K * F * p["C"] / 1e9
+            stages = {}
+            for k, v in tm:
+                stages[k] = stages.get(k, 0.0) + v
+            top = ", ".join(f"{k} {v:.2f}" for k, v in sorted(stages.items(), key=lambda kv: -kv[1])[:4])
+            print(f"hot path  {name:28s}: device {dev:7.2f} ms for {gb:6.2f} GB of spectra = {dev / gb:6.2f} ms/GB   [{top}]")
+        except Exception as e:      # noqa: BLE001
+            print(f"hot path  {name:28s}: {type(e).__name__}: {str(e)[:120]}")
