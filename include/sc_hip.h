@@ -311,8 +311,8 @@ int sc_spectra_from_planes_f32(const void* d_P, const sc_spectra_desc* desc, con
  * sc_fused_csm_absim_ws_f32 writes (replaces _expectation_cross_spectral_matrix with fcn = identity and abs(Im),
  * connectivity.py:463-526, :982-1028).  desc: sizes and reduce flags (strides ignored: the rows are dense).  Takes
  * planes == SC_PLANE_CSM, SC_PLANE_CSM | SC_PLANE_ABS_IM, the latter | SC_PLANE_IM_SQ (debiased wPLI: a second pass squares
- * the per-observation products) or SC_PLANE_SIGN_IM alone (phase_lag_index: connectivity.py:933-980); up to 256 signals
- * (129 ... 256 in several launches over 32-channel blocks); observations of a bin that form one linear run of rows (every
+ * the per-observation products) or SC_PLANE_SIGN_IM alone (phase_lag_index: connectivity.py:933-980); up to 1024 signals
+ * (129 and more in several launches over 32-channel blocks; more than 256: round 6); observations of a bin that form one linear run of rows (every
  * expectation type but "time_tapers" with several trials); sc_fused2_supported tells.
  * Workspace as for sc_fused_csm_absim_ws_f32 (sc_fused_workspace_bytes with the same desc). */
 int sc_fused2_supported(const sc_spectra_desc* desc, uint32_t planes);
@@ -442,8 +442,8 @@ int sc_wilson_factor_f64(const double* d_S, int64_t n_problems, int64_t N, doubl
  * direct_directed_transfer_function (connectivity.py:1237-1426).  All windows iterate together,
  * converged windows are frozen; up to 128 signals the C x C factor of one (window, bin) lives in the registers of one
  * workgroup, 129 ... 512 run a panel-blocked inverse in global memory and products cut into 128 x 128 blocks:
- * n_signals <= sc_mvar_max_signals() (512 since round 6; records of more than 256 signals are assembled from channel-block
- * pairs by the host), larger systems return SC_EUNSUPPORTED.
+ * n_signals <= sc_mvar_max_signals() (512 since round 6; records of more than 256 signals come from the planes-format
+ * stage B or are assembled from channel-block pairs by the host), larger systems return SC_EUNSUPPORTED.
  * sc_mvar_factor_f64: exactly one of d_accum (accumulator records holding SC_PLANE_CSM, N or N/2+1
  * bins per window, real-input symmetry completes the rest) and d_S (complex128 [P][N][C][C], two-sided
  * Hermitian spectra) is non-NULL.  d_G: complex128 [P][N][C][C].  d_status[p]: 1 converged, 0 not

@@ -341,6 +341,7 @@ PLANES_FORMAT_FAMILIES = (PLANE_CSM, PLANE_CSM | PLANE_ABS_IM, PLANE_CSM | PLANE
 
 
 PLANES_FORMAT_MIN_CHANNELS = 44
+PLANES_FORMAT_MAX_CHANNELS = 1024      # F2_MAX_SIGNALS of csrc/sc_fused2.hip
 PLANES_MIN_TYPICAL = 2.5       # SC_PLANES_MIN_TYPICAL of include/sc_hip.h: smallest typical coefficient (scaled units) the format is used for
 
 
@@ -364,4 +365,5 @@ def planes_format_applies(n_window, n_fft, n_alloc, planes_hint, spectra_bytes=N
         lo = int(forced)
     elif spectra_bytes is not None and spectra_bytes < (256 << 20):
         return False
-    return lo <= n_alloc <= 256 and bool(_handle().sc_multitaper_fft_planes_supported(n_window, n_fft, n_alloc))
+    # (up to 1024 signals since round 6: sc_fused2.hip plans its launches over any number of 32-channel blocks; 256 before)
+    return lo <= n_alloc <= PLANES_FORMAT_MAX_CHANNELS and bool(_handle().sc_multitaper_fft_planes_supported(n_window, n_fft, n_alloc))

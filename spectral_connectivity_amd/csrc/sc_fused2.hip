@@ -825,8 +825,9 @@ __global__ void __launch_bounds__(FU_THREADS) fused2_kernel(Fused2Args a) {
 // ---- host ---------------------------------------------------------------------------------------------------------------------
 // What the planes-format kernels fill: the CSM planes, |Im s| with them, (Im s)^2 with both (a second pass of the same kernel:
 // the |Im s| waves square the per-observation products instead), and sign(Im s) on its own (a pass that sums signs as
-// integers) -- up to 256 signals (129 ... 256: the launches of sc_fused.hip's launch_fused_all, each staging four 32-channel
-// blocks), observations of a bin one linear run of rows.
+// integers) -- up to 1024 signals (129 ... 256: the launches of sc_fused.hip's launch_fused_all, each staging four 32-channel
+// blocks; beyond: the general plan of fused2_launch_all), observations of a bin one linear run of rows.
+#define F2_MAX_SIGNALS 1024      // 32 blocks of 32 channels (the block map packs a block's 16-tile row into 8 bits: 127 blocks at most)
 static bool fused2_families_ok(uint32_t fam) {
     return fam == SC_PLANE_CSM || fam == (SC_PLANE_CSM | SC_PLANE_ABS_IM) ||
            fam == (SC_PLANE_CSM | SC_PLANE_ABS_IM | SC_PLANE_IM_SQ) || fam == SC_PLANE_SIGN_IM;
@@ -840,8 +841,8 @@ static int fused2_setup(const sc_spectra_desc* desc, uint32_t planes, Fused2Args
     sc_make_axes(&d, &ax);
     SC_REQUIRE(ax.C >= 1 && ax.F >= 1 && ax.n_obs >= 1 && ax.n_groups >= 1, "empty dimension");
     const uint32_t fam = planes & ~(uint32_t)SC_RECORD_F64;
-    if (!fused2_families_ok(fam) || (planes & SC_RECORD_F64) || ax.C > 256 || sc_stage_linear_stride(ax) <= 0) {
-        sc_set_error("planes-format stage B takes CSM (+ |Im s| (+ (Im s)^2)) or sign(Im s) records of up to 256 signals whose "
+    if (!fused2_families_ok(fam) || (planes & SC_RECORD_F64) || ax.C > F2_MAX_SIGNALS || sc_stage_linear_stride(ax) <= 0) {
+        sc_set_error("planes-format stage B takes CSM (+ |Im s| (+ (Im s)^2)) or sign(Im s) records of up to 1024 signals whose "
                      "observations are one linear run (got planes 0x%x, %d signals)", planes, ax.C);
         return SC_EUNSUPPORTED;
     }
@@ -903,7 +904,7 @@ static Fused2Args fused2_args_blocks(const Fused2Args& full, const int* blocks, 
     return a;
 }
 
-#define F2_SHAPES(X) X(1, 0, 1) X(2, 0, 2) X(3, 0, 3) X(4, 0, 4) X(4, 2, 2) X(3, 1, 3) X(4, 2, 4) X(4, 1, 4) X(4, 1, 1)
+#define F2_SHAPES(X) X(1, 0, 1) X(2, 0, 2) X(3, 0, 3) X(4, 0, 4) X(4, 2, 2) X(3, 1, 3) X(4, 2, 4) X(4, 1, 4) X(4, 1, 1) X(3, 2, 2)
 template <int NB32, int COL_LO, int ROW_HI, int OP>
 static void fused2_launch_op(const Fused2Args& a, hipStream_t s) {
     auto k = fused2_kernel<NB32, COL_LO, ROW_HI, OP>;
@@ -939,9 +940,33 @@ static int fused2_launch_all(const Fused2Args& full, int op, hipStream_t s) {
                               {4, {2, 4, 5, 6}, 1, 1}, {4, {3, 4, 5, 6}, 1, 1}};
     static const Plan p8[] = {{4, {0, 1, 2, 3}, 0, 4}, {4, {4, 5, 6, 7}, 0, 4}, {4, {0, 1, 4, 5}, 2, 2},
                               {4, {0, 1, 6, 7}, 2, 2}, {4, {2, 3, 4, 5}, 2, 2}, {4, {2, 3, 6, 7}, 2, 2}};
+    int rc = SC_OK;
+    if (n > 8) {
+        // More than 256 signals (round 6; before: the host tiled the channels in blocks of 128 and paid a gathered 256-channel triangle per
+        // block pair, on the complex64 kernels).  Groups of four consecutive blocks take their triangle; two halves (pairs of blocks) of
+        // DIFFERENT groups take their 64 x 64 rectangle; with an odd block count the last block is a group (or the third block of one)
+        // of its own and meets every pair outside its group as a 64 x 32 rectangle.  Every 32 x 32 block product exactly once.
+        const int n_pairs = n / 2, lone = (n & 1) ? n - 1 : -1;
+        for (int g0 = 0; g0 < n && rc == SC_OK; g0 += 4) {
+            const int nbg = n - g0 < 4 ? n - g0 : 4;
+            Plan t = {nbg, {g0, g0 + 1, g0 + 2, g0 + 3}, 0, nbg};
+            rc = fused2_launch(fused2_args_blocks(full, t.blocks, t.nb, t.col_lo, t.row_hi), op, s);
+        }
+        for (int hi = 0; hi < n_pairs && rc == SC_OK; ++hi) {
+            for (int hj = hi + 1; hj < n_pairs && rc == SC_OK; ++hj) {
+                if (hi / 2 == hj / 2) continue;                    // the two halves of one group: inside its triangle
+                const int b[4] = {2 * hi, 2 * hi + 1, 2 * hj, 2 * hj + 1};
+                rc = fused2_launch(fused2_args_blocks(full, b, 4, 2, 2), op, s);
+            }
+            if (lone >= 0 && hi / 2 != lone / 4 && rc == SC_OK) {
+                const int b[3] = {2 * hi, 2 * hi + 1, lone};
+                rc = fused2_launch(fused2_args_blocks(full, b, 3, 2, 2), op, s);
+            }
+        }
+        return rc;
+    }
     const Plan* plan = n <= 4 ? &tri[n - 1] : n == 5 ? p5 : n == 6 ? p6 : n == 7 ? p7 : p8;
     const int n_launch = n <= 4 ? 1 : n == 5 ? 3 : n == 6 ? 3 : n == 7 ? 5 : 6;
-    int rc = SC_OK;
     for (int l = 0; l < n_launch && rc == SC_OK; ++l)
         rc = fused2_launch(fused2_args_blocks(full, plan[l].blocks, plan[l].nb, plan[l].col_lo, plan[l].row_hi), op, s);
     return rc;

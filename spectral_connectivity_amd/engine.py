@@ -448,7 +448,12 @@ def accumulate(spectra, expectation_type, planes, n_freq=None, mark=None, use_fu
     ``ws_owner``: see _workspace (a dict that owns the split-bin scratch of this call instead of the per-device cache)."""
     lib = _lib.load()
     if spectra.C > MAX_KERNEL_SIGNALS:
-        return _accumulate_blocked(spectra, expectation_type, planes, n_freq, mark, row_multiple)
+        # planes-format spectra go straight to sc_fused2.hip, which plans its launches over any number of 32-channel blocks (round 6);
+        # every other request beyond 256 signals is tiled over channel-block pairs
+        direct = (not spectra.f64 and spectra.P is not None and use_fused is not False
+                  and bool(lib.sc_fused2_supported(byref(spectra.desc(expectation_type, n_freq, padded=True)), planes)))
+        if not direct:
+            return _accumulate_blocked(spectra, expectation_type, planes, n_freq, mark, row_multiple)
     d = spectra.desc(expectation_type, n_freq)
     n_bins, fpb, _, n_obs = accum_layout(spectra, expectation_type, planes, n_freq)
     if spectra.f64:

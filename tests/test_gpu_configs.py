@@ -482,3 +482,48 @@ def test_more_than_256_signals(sc, C):
                 assert err_cc <= (5e-3 if precision == "float32" else 1e-6)
     finally:
         options.precision = old
+
+
+@pytest.mark.parametrize("C", [258, 306, 320, 418])
+def test_more_than_256_signals_on_the_planes_format(sc, C, monkeypatch):
+    """Round 6: planes-format spectra of MORE than 256 signals go straight to sc_fused2.hip, which plans its launches over any number of
+    32-channel blocks (groups of four: triangles; pairs of blocks of different groups: 64 x 64 rectangles; an odd block count: the last
+    block against every pair outside its group, the new launch shape (3, 2, 2)) -- no channel tiling on the host, no gathered copies.
+    258 = 9 blocks (odd, the last one of 2 channels), 306 = 10, 320 = 10 whole blocks, 418 = 14 (the last group holds two blocks).
+    Every accumulator family of the format against the oracle; the path is asserted (P is not None, no call of _accumulate_blocked)."""
+    import spectral_connectivity_amd.engine as engine
+    import spectral_connectivity_amd.options as options
+    monkeypatch.setenv("SC_PLANES_MIN_CHANNELS", "44")                     # the format whatever the size of the request
+    calls = []
+    real = engine._accumulate_blocked
+    monkeypatch.setattr(engine, "_accumulate_blocked", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    rng = np.random.default_rng(C)
+    L, R = 64, 3
+    x = rng.standard_normal((L, R, C)) + 0.6 * rng.standard_normal((L, R, 1))
+    x[:, :, C - 3] += 0.8 * np.roll(x[:, :, 2], 3, axis=0)                  # a lagged copy across the first and the last block
+    x[:, :, 140] += 0.7 * np.roll(x[:, :, 70], 2, axis=0)                   # ... and across two groups of four blocks
+    kw = dict(sampling_frequency=128.0, time_halfbandwidth_product=2)
+    coef, _ = so.multitaper_fft(x, fs=128.0, NW=2)
+    F = L // 2 + 1
+    refs = {"coherence_magnitude": so.coherence_magnitude(coef), "weighted_phase_lag_index": so.weighted_phase_lag_index(coef),
+            "debiased_squared_weighted_phase_lag_index": so.debiased_squared_weighted_phase_lag_index(coef),
+            "phase_lag_index": so.phase_lag_index(coef), "power": so.power(coef)}
+    old = options.precision
+    try:
+        options.precision = "float32"
+        for first in ("coherence_magnitude", "phase_lag_index", "debiased_squared_weighted_phase_lag_index"):
+            c = sc.Connectivity.from_multitaper(sc.Multitaper(x, **kw), dtype=np.complex64)
+            order = [first] + [n for n in refs if n != first]
+            for name in order:
+                got, ref = getattr(c, name)(), refs[name][:, :F]
+                assert got.shape == ref.shape, (name, got.shape, ref.shape)
+                assert np.array_equal(np.isnan(got), np.isnan(ref)), name
+                ok = ~np.isnan(ref)
+                err = np.abs(got[ok] - ref[ok]).max() / np.abs(ref[ok]).max()
+                bound = 4.0 / c.n_observations if name == "phase_lag_index" else 3e-5
+                assert err <= bound, (first, name, err)
+            sp = c._device()
+            assert sp.P is not None, "the spectra of this request should be in the planes format"
+        assert not calls, "planes-format spectra beyond 256 signals must not be tiled on the host"
+    finally:
+        options.precision = old

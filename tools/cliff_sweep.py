@@ -75,7 +75,7 @@ if "hot" in what:
     from spectral_connectivity_amd import _lib
     base = dict(T=1024, R=250, C=128, L=256, step=128, NW=4, detrend="constant")
     variants = [("base (cfg3 / 4 trials)", {})]
-    variants += [(f"C={c}", dict(C=c)) for c in (40, 44, 64, 100, 127, 129, 130, 192, 256, 258)]
+    variants += [(f"C={c}", dict(C=c)) for c in (40, 44, 64, 100, 127, 129, 130, 192, 256, 258, 306, 307, 512)]
     variants += [(f"window={l} step={s}", dict(L=l, step=s)) for l, s in ((256, 256), (256, 64), (128, 64), (64, 32), (32, 16), (100, 50), (300, 150),
                                                                           (384, 192), (768, 384), (1024, 1024))]
     variants += [(f"T={t} window={t}", dict(T=t, L=t, step=t, R=64)) for t in (4096, 8192, 5000, 6000)]
