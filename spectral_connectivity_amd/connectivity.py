@@ -179,7 +179,7 @@ class Connectivity:
         from ctypes import byref
         from ._lib import SpectraDesc
         W, R, K, N, C = (int(v) for v in self._shape5)
-        C_alloc = C + 1 if (C % 2 and C + 1 <= 256) else C
+        C_alloc = C + 1 if (C % 2 and C + 1 <= _lib.PLANES_FORMAT_MAX_CHANNELS) else C
         axes = EXPECTATION_AXES[self.expectation_type]
         d = SpectraDesc(n_freq=N // 2 + 1, n_windows=W, n_trials=R, n_tapers=K, n_signals=C_alloc, stride_freq=W * R * K * C_alloc,
                         stride_window=R * K * C_alloc, stride_trial=K * C_alloc, stride_taper=C_alloc, reduce_window=int(0 in axes),

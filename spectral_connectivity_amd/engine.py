@@ -193,7 +193,7 @@ def multitaper_spectra(x, tapers_over_fs, n_window, n_step, n_fft, n_windows, de
     ``n_signals``: number of real channels when ``x`` already carries the all-zero pad channel of an odd channel count
     (appended on the host before the upload, transforms.Multitaper.device_spectra); a device tensor with an odd channel
     count that arrives unpadded is copied into a padded buffer here (one strided device copy).
-    ``planes_hint``: the accumulator families the caller will ask for.  Any family sc_fused2.hip serves, 44 ... 256 signals, a
+    ``planes_hint``: the accumulator families the caller will ask for.  Any family sc_fused2.hip serves, 44 ... 1024 signals, a
     window length stage A has the output for (the powers of two 64 ... 4096, the lengths 200 ... 2000 of sc_mtfft_mixed.hip:
     sc_multitaper_fft_planes_supported) and at least 256 MB of spectra (_lib.planes_format_applies): the spectra are
     written in the planes format (two f16 pieces per real number) -- a scan of the series for the channel scales, then the same
@@ -207,7 +207,7 @@ def multitaper_spectra(x, tapers_over_fs, n_window, n_step, n_fft, n_windows, de
     if n_signals is not None:
         assert n_signals in (C_real, C_real - 1)
         C_real = int(n_signals)
-    elif C_real % 2 and C_real + 1 <= 256:
+    elif C_real % 2 and C_real + 1 <= _lib.PLANES_FORMAT_MAX_CHANNELS:
         padded = torch.zeros((T, R, C_real + 1), dtype=x.dtype, device=x.device)
         padded[..., :C_real].copy_(x)                # odd channel count: one zero channel (see DeviceSpectra)
         x = padded

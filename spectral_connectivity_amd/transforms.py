@@ -663,7 +663,8 @@ class Multitaper:
             else:
                 ts = self.time_series
                 n_signals = ts.shape[2]
-                n_alloc = n_signals + 1 if (n_signals % 2 and n_signals + 1 <= 256) else n_signals
+                # (an odd channel count rides on one zero pad channel -- up to the planes format's 1024 signals since round 6, 256 before)
+                n_alloc = n_signals + 1 if (n_signals % 2 and n_signals + 1 <= _lib.PLANES_FORMAT_MAX_CHANNELS) else n_signals
                 if on_device is not None and ts.dtype == np.float32:
                     # already in HBM, float32: used in place (an odd channel count gets its zero pad channel in engine.multitaper_spectra)
                     x = on_device.contiguous()

@@ -484,12 +484,12 @@ def test_more_than_256_signals(sc, C):
         options.precision = old
 
 
-@pytest.mark.parametrize("C", [258, 306, 320, 418])
+@pytest.mark.parametrize("C", [258, 306, 307, 320, 418])
 def test_more_than_256_signals_on_the_planes_format(sc, C, monkeypatch):
     """Round 6: planes-format spectra of MORE than 256 signals go straight to sc_fused2.hip, which plans its launches over any number of
     32-channel blocks (groups of four: triangles; pairs of blocks of different groups: 64 x 64 rectangles; an odd block count: the last
     block against every pair outside its group, the new launch shape (3, 2, 2)) -- no channel tiling on the host, no gathered copies.
-    258 = 9 blocks (odd, the last one of 2 channels), 306 = 10, 320 = 10 whole blocks, 418 = 14 (the last group holds two blocks).
+    258 = 9 blocks (odd, the last one of 2 channels), 306 = 10, 307 = 10 with a zero pad channel, 320 = 10 whole blocks, 418 = 14 (the last group holds two blocks).
     Every accumulator family of the format against the oracle; the path is asserted (P is not None, no call of _accumulate_blocked)."""
     import spectral_connectivity_amd.engine as engine
     import spectral_connectivity_amd.options as options
