@@ -847,7 +847,19 @@ struct MxArgs {
     int T, R, C, L, step, W, K, detrend;
     int N, NF, n_pass;
     int radix[16];
+    // planes-format output (mtfft_mixed_kernel only; see MtArgs): when P is set the spectra go there INSTEAD of X
+    unsigned char* P;
+    const float* scale;    // [C] powers of two
+    int64_t row_bytes;
 };
+// two scaled reals (channels c, c + 1 of one component) -> their f16 pieces h and m = x - h, one dword each (sc_fused2.hip: f2_split2)
+__device__ __forceinline__ void mx_split2(float x0, float x1, unsigned& h, unsigned& m) {
+    typedef _Float16 mx_h2 __attribute__((ext_vector_type(2)));
+    const mx_h2 hv = {(_Float16)x0, (_Float16)x1};
+    const mx_h2 mv = {(_Float16)(x0 - (float)hv[0]), (_Float16)(x1 - (float)hv[1])};
+    h = __builtin_bit_cast(unsigned, hv);
+    m = __builtin_bit_cast(unsigned, mv);
+}
 
 __device__ __forceinline__ float2 mx_add(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 mx_sub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
@@ -1085,6 +1097,11 @@ __global__ void __launch_bounds__(512) mtfft_mixed_kernel(MxArgs p) {
         }
         // split the packed pair: A[f] = (Z[f] + conj Z[N-f]) / 2, B[f] = (Z[f] - conj Z[N-f]) / (2 i); store X[f][w][r][k][c..c+1]
         float2* Xk = p.X + (((int64_t)w * p.R + r) * p.K + k) * C + c0;
+        // planes-format output (round 6: every 2^a 3^b 5^c length this kernel takes -- 384, 768, 96 ... -- so that the matrix-pipe stage B
+        // serves them): row [f][w][r][k], tile of 32 channels, planes Re h, Re m, Im h, Im m of 64 bytes; a channel pair is one dword per
+        // plane.  The workgroup that holds the last channel also zeroes the rest of its 32-channel tile (stage B stages whole tiles).
+        const int64_t prow0 = ((int64_t)w * p.R + r) * p.K + k, prowF = (int64_t)p.W * p.R * p.K;
+        const int c_pad = (c0 + CT >= C) ? ((C + 31) & ~31) : 0;     // zero channels [C, c_pad) (C is even on this path)
         for (int idx = tid; idx < F * NF; idx += 512) {
             const int f = idx >> lnf, pr = idx & (NF - 1), c = c0 + 2 * pr;
             if (c >= C) continue;
@@ -1094,6 +1111,19 @@ __global__ void __launch_bounds__(512) mtfft_mixed_kernel(MxArgs p) {
             float2 B = make_float2(hb * (u1.y + u2.y), hb * (u2.x - u1.x));
             if (nzf[2 * pr] == 0) A = make_float2(0.f, 0.f);         // identically zero channel: exact zeros
             if (nzf[2 * pr + 1] == 0) B = make_float2(0.f, 0.f);
+            if (p.P) {
+                const float qn = __int_as_float(0x7fc00000);
+                if (nbf[2 * pr]) A = make_float2(qn, qn);             // a NaN / infinity in the channel: its bins are NaN
+                if (nbf[2 * pr + 1]) B = make_float2(qn, qn);
+                const float sa = p.scale[c], sb = p.scale[c + 1];
+                unsigned h, m;
+                unsigned* d = reinterpret_cast<unsigned*>(p.P + (prow0 + (int64_t)f * prowF) * p.row_bytes + (c >> 5) * 256 + (c & 31) * 2);
+                mx_split2(A.x * sa, B.x * sb, h, m);
+                d[0] = h; d[16] = m;
+                mx_split2(A.y * sa, B.y * sb, h, m);
+                d[32] = h; d[48] = m;
+                continue;
+            }
             float2* d = Xk + (int64_t)f * sF + 2 * pr;
             if (vec_ok) {
                 *reinterpret_cast<float4*>(d) = make_float4(A.x, A.y, B.x, B.y);
@@ -1102,7 +1132,15 @@ __global__ void __launch_bounds__(512) mtfft_mixed_kernel(MxArgs p) {
                 if (c + 1 < C) d[1] = B;
             }
         }
-        if (any_bad) {       // rare: a channel of this tile held a NaN / infinity -- its bins become NaN (same thread, same
+        if (p.P && c_pad > C) {
+            const int npad = (c_pad - C) >> 1;                       // channel pairs to zero per row
+            for (int idx = tid; idx < F * npad; idx += 512) {
+                const int f = idx / npad, c = C + 2 * (idx - f * npad);
+                unsigned* d = reinterpret_cast<unsigned*>(p.P + (prow0 + (int64_t)f * prowF) * p.row_bytes + (c >> 5) * 256 + (c & 31) * 2);
+                d[0] = 0u; d[16] = 0u; d[32] = 0u; d[48] = 0u;
+            }
+        }
+        if (any_bad && !p.P) {       // rare: a channel of this tile held a NaN / infinity -- its bins become NaN (same thread, same
                              // addresses as the store loop above, so the order is the program's)
             const float qn = __int_as_float(0x7fc00000);
             for (int idx = tid; idx < F * NF; idx += 512) {
@@ -1239,6 +1277,9 @@ __global__ void __launch_bounds__(64 * NF) mtfft_mixed_wave_kernel(MxArgs p) {
         mx_passes_wave<N, 1>(zw, tw, lane);
         __syncthreads();                                          // every pair transformed
         float2* Xk = p.X + (((int64_t)w * p.R + r) * p.K + k) * C + c0;
+        // (planes-format output: see mtfft_mixed_kernel)
+        const int64_t prow0 = ((int64_t)w * p.R + r) * p.K + k, prowF = (int64_t)p.W * p.R * p.K;
+        const int c_pad = (c0 + CT >= C) ? ((C + 31) & ~31) : 0;
         for (int idx = tid; idx < F * NF; idx += NT) {
             const int f = idx >> LNF, pr = idx & (NF - 1), c = c0 + 2 * pr;
             if (c >= C) continue;
@@ -1248,6 +1289,19 @@ __global__ void __launch_bounds__(64 * NF) mtfft_mixed_wave_kernel(MxArgs p) {
             float2 B = make_float2(hb * (u1.y + u2.y), hb * (u2.x - u1.x));
             if (nzf[2 * pr] == 0) A = make_float2(0.f, 0.f);         // identically zero channel: exact zeros
             if (nzf[2 * pr + 1] == 0) B = make_float2(0.f, 0.f);
+            if (p.P) {
+                const float qn = __int_as_float(0x7fc00000);
+                if (nbf[2 * pr]) A = make_float2(qn, qn);
+                if (nbf[2 * pr + 1]) B = make_float2(qn, qn);
+                const float sa = p.scale[c], sb = p.scale[c + 1];
+                unsigned h, m;
+                unsigned* d = reinterpret_cast<unsigned*>(p.P + (prow0 + (int64_t)f * prowF) * p.row_bytes + (c >> 5) * 256 + (c & 31) * 2);
+                mx_split2(A.x * sa, B.x * sb, h, m);
+                d[0] = h; d[16] = m;
+                mx_split2(A.y * sa, B.y * sb, h, m);
+                d[32] = h; d[48] = m;
+                continue;
+            }
             float2* d = Xk + (int64_t)f * sF + 2 * pr;
             if (vec_ok) {
                 if constexpr (NF >= 8) sc_stream_store(d, A, B);        // whole 128-byte lines per frequency row
@@ -1257,7 +1311,15 @@ __global__ void __launch_bounds__(64 * NF) mtfft_mixed_wave_kernel(MxArgs p) {
                 if (c + 1 < C) d[1] = B;
             }
         }
-        if (any_bad) {       // rare: a channel of this tile held a NaN / infinity -- its bins become NaN (same thread, same
+        if (p.P && c_pad > C) {
+            const int npad = (c_pad - C) >> 1;
+            for (int idx = tid; idx < F * npad; idx += NT) {
+                const int f = idx / npad, c = C + 2 * (idx - f * npad);
+                unsigned* d = reinterpret_cast<unsigned*>(p.P + (prow0 + (int64_t)f * prowF) * p.row_bytes + (c >> 5) * 256 + (c & 31) * 2);
+                d[0] = 0u; d[16] = 0u; d[32] = 0u; d[48] = 0u;
+            }
+        }
+        if (any_bad && !p.P) {       // rare: a channel of this tile held a NaN / infinity -- its bins become NaN (same thread, same
                              // addresses as the store loop above, so the order is the program's)
             const float qn = __int_as_float(0x7fc00000);
             for (int idx = tid; idx < F * NF; idx += NT) {
@@ -1305,6 +1367,7 @@ static int launch_mixed(const MtArgs& a, int64_t N, hipStream_t stream) {
     m.x = a.x; m.tapers = a.tapers; m.tw = a.tw; m.X = a.X;
     m.T = a.T; m.R = a.R; m.C = a.C; m.L = a.L; m.step = a.step; m.W = a.W; m.K = a.K; m.detrend = a.detrend;
     m.N = (int)N;
+    m.P = a.P; m.scale = a.scale; m.row_bytes = a.row_bytes;
     m.n_pass = mx_radices(N, m.radix);
     int nf = 16;
     while (nf > 2 && (int64_t)nf * N > 4096) nf >>= 1;
@@ -1316,6 +1379,12 @@ static int launch_mixed(const MtArgs& a, int64_t N, hipStream_t stream) {
                        (size_t)(1024 + 2 * CT) * 8;
     if (lds > 160 * 1024 - 128) { sc_set_error("multitaper FFT (N=%lld): window tile does not fit LDS", (long long)N); return SC_EUNSUPPORTED; }
     switch (N) {        // one wave per channel pair, in place (mtfft_mixed_wave_kernel): the common lengths up to 1000 samples
+    // (round 6: the 2^a 3 lengths -- 0.75 / 1.5 s at 128 ... 512 Hz -- with them; planes-format requests of 200 ... 1000 never come here)
+    case 96: return launch_mixed_wave<96, 8>(m, stream);
+    case 192: return launch_mixed_wave<192, 8>(m, stream);
+    case 384: return launch_mixed_wave<384, 8>(m, stream);
+    case 768: return launch_mixed_wave<768, 4>(m, stream);
+    case 960: return launch_mixed_wave<960, 4>(m, stream);
     case 200: return launch_mixed_wave<200, 8>(m, stream);
     case 250: return launch_mixed_wave<250, 8>(m, stream);
     case 300: return launch_mixed_wave<300, 8>(m, stream);
@@ -1352,7 +1421,9 @@ extern "C" int sc_multitaper_fft_planes_supported(int64_t L, int64_t N, int64_t 
     // (2048 and 4096 samples: the anti-phase kernel of sc_mtfft_long.hip only; N = 10 RM RF: sc_mtfft_mixed.hip only)
     if (!(L >= 1 && L <= N && C >= 2 && (C % 2) == 0)) return 0;
     if (N >= 64 && N <= 4096 && (N & (N - 1)) == 0) return 1;
-    return sc_internal_mtfft_mix_has(N) ? 1 : 0;
+    if (sc_internal_mtfft_mix_has(N)) return 1;
+    int radix[16];
+    return mx_radices(N, radix) > 0 ? 1 : 0;          // (round 6) every other 2^a 3^b 5^c <= 2048: the Stockham kernel's planes store
 }
 
 extern "C" int sc_multitaper_fft_supported(int64_t L, int64_t N) {
@@ -1387,8 +1458,8 @@ static int mtfft_run(const float* d_x, int64_t T, int64_t R, int64_t C, int64_t 
     const bool use_long = pow2 && (sc_internal_mtfft_long_applies(N, C, W * R) || (d_P && N >= 2048));
     if (d_P) {
         if (!sc_multitaper_fft_planes_supported(L, N, C)) {
-            sc_set_error("planes-format multitaper FFT needs an even number of signals and N a power of two in 64 ... 4096 or one of "
-                         "200 ... 2000 = 10 RM RF (got C=%lld N=%lld)",
+            sc_set_error("planes-format multitaper FFT needs an even number of signals and N a power of two in 64 ... 4096 or "
+                         "2^a 3^b 5^c in 8 ... 2048 (got C=%lld N=%lld)",
                          (long long)C, (long long)N);
             return SC_EUNSUPPORTED;
         }
@@ -1396,13 +1467,14 @@ static int mtfft_run(const float* d_x, int64_t T, int64_t R, int64_t C, int64_t 
         // with the 512-thread workgroups of 1024, 8 with 256 threads at 1024); where the workgroups do not cover the last 32-channel
         // tile the uncovered part must read as zeros (stage B stages whole tiles)
         const int64_t threads = (N == 1024 && mt_wide() && C >= 16) ? 512 : 256, ct = pow2 ? 2 * threads / (N / 16) : 1;
-        const int64_t covered = !pow2 ? sc_internal_mtfft_mix_coverage(N, C, true)
+        // (the Stockham kernel of the other 2^a 3^b 5^c lengths zeroes the rest of its last tile itself)
+        const int64_t covered = !pow2 ? (sc_internal_mtfft_mix_has(N) ? sc_internal_mtfft_mix_coverage(N, C, true) : (C + 31) / 32 * 32)
                                       : (use_long ? sc_internal_mtfft_long_coverage(N, C) : (C + ct - 1) / ct * ct);
         if (covered < (C + 31) / 32 * 32)
             SC_CHECK_HIP(hipMemsetAsync(d_P, 0, (size_t)((N / 2 + 1) * W * R * K) * (size_t)a.row_bytes, s));
     }
     // the lengths N = 10 RM RF with enough work to fill the chip -- and every planes-format request: sc_mtfft_mixed.hip
-    if (!pow2 && (d_P || sc_internal_mtfft_mix_applies(N, C, W * R)))
+    if (!pow2 && sc_internal_mtfft_mix_has(N) && (d_P || sc_internal_mtfft_mix_applies(N, C, W * R)))
         return sc_internal_mtfft_mix(d_x, T, R, C, L, step, W, N, d_tapers, K, detrend_type, d_twiddles, d_X, d_P, d_scale, s);
     if (!pow2) return launch_mixed(a, N, s);
     if (use_long) return sc_internal_mtfft_long(d_x, T, R, C, L, step, W, N, d_tapers, K, detrend_type, d_twiddles, d_X, d_P, d_scale, s);

@@ -52,7 +52,11 @@ def _series(T, R, C, seed, offset=0.0, quiet=2e-3, loud=250.0):
                                                (1000, 1000, 48, "constant"), (1000, 500, 22, "linear"), (300, 300, 70, "constant"),
                                                (400, 200, 36, None), (600, 300, 24, "linear"), (750, 750, 18, "constant"),
                                                (800, 400, 40, None), (1200, 1200, 16, "linear"), (1500, 750, 12, "constant"),
-                                               (2000, 2000, 10, "linear")])
+                                               (2000, 2000, 10, "linear"),
+                                               # every other 2^a 3^b 5^c length (round 6: the planes store of the Stockham kernel in
+                                               # sc_mtfft.hip; last tiles of 2 ... 22 channels zeroed by the kernel itself)
+                                               (384, 192, 34, "constant"), (768, 768, 20, "linear"), (96, 48, 70, None),
+                                               (1536, 1536, 12, "constant"), (960, 480, 22, "linear"), (108, 54, 36, "constant")])
 def test_stage_a_planes_decode_to_the_spectra(L, step, C, detrend, kernel, debug_env):
     """sc_multitaper_fft_planes_f32 + sc_spectra_from_planes_f32 against the float64 transform of the same samples and
     tapers: the float32 transform's rounding plus the 22 bits of the format.  The scales sit on the SAMPLES, so the two
@@ -218,7 +222,10 @@ def test_when_the_engine_takes_the_planes_format():
         assert _lib.planes_format_applies(2048, 2048, 64, fam, spectra_bytes=big)          # (round 5: 2048 and 4096 samples too)
         assert _lib.planes_format_applies(4096, 4096, 64, fam, spectra_bytes=big)
         assert not _lib.planes_format_applies(8192, 8192, 64, fam, spectra_bytes=big)
-        assert not _lib.planes_format_applies(256, 256, 258, fam, spectra_bytes=big)
+        assert _lib.planes_format_applies(256, 256, 258, fam, spectra_bytes=big)           # (round 6: up to 1024 signals)
+        assert not _lib.planes_format_applies(256, 256, 1026, fam, spectra_bytes=big)
+        assert _lib.planes_format_applies(384, 384, 64, fam, spectra_bytes=big)             # (round 6: every 2^a 3^b 5^c <= 2048)
+        assert not _lib.planes_format_applies(448, 448, 64, fam, spectra_bytes=big)         # (7 among the factors)
     assert not _lib.planes_format_applies(256, 256, 64, _lib.PLANE_CSM | _lib.PLANE_UNIT, spectra_bytes=big)
     assert not _lib.planes_format_applies(256, 256, 64, _lib.PLANE_UNIT, spectra_bytes=big)
     assert not _lib.planes_format_applies(256, 256, 64, None, spectra_bytes=big)
