@@ -538,8 +538,8 @@ def test_mvar_measures_beyond_64_signals_vs_oracle(sc, C):
     129 ... 512 signals: the same iteration on the panel-blocked inverse and the blocked products (306: a whole-head MEG array,
     its record assembled from channel-block pairs by engine._accumulate_blocked)."""
     rng = np.random.default_rng(C)
-    # (beyond 128 signals: 32 bins, the oracle's time; 306 signals: 204 trials x 3 tapers = 612 observations)
-    T, R = (64 if C <= 128 else 32), (90 if C <= 128 else (C if C <= 256 else 204))
+    # (beyond 128 signals: 32 bins, the oracle's time; 306 signals: 16 bins, 204 trials x 3 tapers = 612 observations)
+    T, R = (64 if C <= 128 else (32 if C <= 256 else 16)), (90 if C <= 128 else (C if C <= 256 else 204))
     e = rng.standard_normal((T + 8, R, C))
     x = e.copy()
     for t in range(2, T + 8):                                 # a sparse stable VAR(2): neighbours drive each other
