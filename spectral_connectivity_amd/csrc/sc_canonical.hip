@@ -810,9 +810,10 @@ __global__ void __launch_bounds__(256) canonical_big_hh_kernel(CanonArgs a, cd* 
     __shared__ double red4[4], sh[4];
     __shared__ int bad, first_above;
     const int tid = threadIdx.x;
-    cd* Lag = scratch + (size_t)blockIdx.x * 3 * CBIG_C * CBIG_C;
-    cd* Lbg = Lag + CBIG_C * CBIG_C;
-    cd* Mg = Lbg + CBIG_C * CBIG_C;
+    // (scratch == nullptr: every pair of this launch fits LDS -- small_n is the largest group -- and the three pointers are never used)
+    cd* Lag = scratch ? scratch + (size_t)blockIdx.x * 3 * CBIG_C * CBIG_C : nullptr;
+    cd* Lbg = scratch ? Lag + CBIG_C * CBIG_C : nullptr;
+    cd* Mg = scratch ? Lbg + CBIG_C * CBIG_C : nullptr;
     for (int64_t item = blockIdx.x; item < n_items; item += gridDim.x) {
         const int64_t bin = item / a.n_gpairs;
         int gp = (int)(item - bin * a.n_gpairs);
