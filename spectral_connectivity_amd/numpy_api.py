@@ -66,7 +66,21 @@ def multitaper_spectra(m, precision, planes_hint=None):
     if np.iscomplexobj(m.time_series):
         raise TypeError("complex-valued time series need the PyTorch host (SC_HIP_HOST=torch): it transforms the real and imaginary "
                         "parts with the real-input kernels and assembles the two-sided spectrum on the device")
-    if np.asarray(m.time_series).shape[2] > 256:
+    ts = np.asarray(m.time_series)
+    if ts.shape[2] > 256:
+        # more than 256 signals: planes-format spectra of the whole array where the format applies (round 6: sc_fused2.hip plans its
+        # launches over any number of 32-channel blocks) -- otherwise no device spectra of the whole array, the record is tiled
+        C = ts.shape[2]
+        C_alloc = C + (C & 1)
+        F, W, R, K = m.n_fft_samples // 2 + 1, int(m.n_time_windows), ts.shape[1], int(m.n_tapers)
+        if (precision != "float64" and C_alloc <= _lib.PLANES_FORMAT_MAX_CHANNELS
+                and _lib.planes_format_applies(m.n_time_samples_per_window, m.n_fft_samples, C_alloc, planes_hint,
+                                               spectra_bytes=F * W * R * K * C_alloc * 8)):
+            sp = h.spectra(m, planes_hint=planes_hint)
+            if sp.get("P") is not None:
+                sp["wide_source"] = (m, precision)       # (a family outside the format later: back to the tiling, see _accumulators)
+                return sp
+            sp.free()                                    # (the format's quality check sent the transform to complex64)
         return _WideSeries(m, precision)
     return h.spectra_f64(m) if precision == "float64" else h.spectra(m, planes_hint=planes_hint)
 
@@ -238,8 +252,13 @@ class Connectivity(_TorchHostConnectivity):
         return planes, (rec, n_obs)
 
     def _decode_planes(self, sp):
-        """complex64 spectra from the planes format (sc_spectra_from_planes_f32: lossless up to its 22 bits)."""
+        """complex64 spectra from the planes format (sc_spectra_from_planes_f32: lossless up to its 22 bits).  More than 256 signals:
+        the complex64 kernels do not take them in one piece -- back to the series and the channel-block tiling."""
         h = host()
+        if sp["C"] > 256:
+            m, precision = sp["wide_source"]
+            sp.free()
+            return _WideSeries(m, precision)
         X = h.alloc(sp["F"] * sp["W"] * sp["R"] * sp["K"] * sp["C_alloc"] * 8)
         d = h._desc(sp, "trials_tapers", True)
         _lib.check(h.lib.sc_spectra_from_planes_f32(sp["P"].ptr, byref(d), sp["scale"].ptr, X.ptr, h.stream), "sc_spectra_from_planes_f32")

@@ -247,7 +247,7 @@ class NumpyHost:
                              "Valid options are 'linear'/'l', 'constant'/'c' or None.")
         ts = np.asarray(m.time_series)
         T, R, C = ts.shape
-        C_alloc = C + 1 if (C % 2 and C + 1 <= 256) else C
+        C_alloc = C + 1 if (C % 2 and C + 1 <= _lib.PLANES_FORMAT_MAX_CHANNELS) else C       # (beyond 256 signals: planes-format requests only)
         L, step, N, W = m.n_time_samples_per_window, m.n_time_samples_per_step, m.n_fft_samples, m.n_time_windows
         tapers = np.asarray(m.tapers, dtype=np.float64)                                   # (L, K), * sqrt(fs)
         K = tapers.shape[1]
@@ -395,8 +395,8 @@ class NumpyHost:
         """Stage B: un-normalised records [n_bins][floats_per_bin] on the device -- float32, or float64 from complex128 spectra
         (the float64 engine: sc_accumulate_f64).  ``n_freq``: accumulate the first n_freq bins only."""
         lib = self.lib
-        if sp["C"] > 256:
-            raise ValueError(f"one launch of the stage-B kernels takes n_signals <= 256 (got {sp['C']}): Connectivity of this host "
+        if sp["C"] > 256 and sp.get("P") is None:
+            raise ValueError(f"one launch of the complex64 / float64 stage-B kernels takes n_signals <= 256 (got {sp['C']}): Connectivity of this host "
                              "tiles more signals into channel blocks (numpy_api.Connectivity); NumpyHost.accumulate does not")
         d_real, d_pad = self._desc(sp, expectation_type, False, n_freq), self._desc(sp, expectation_type, True, n_freq)
         n_bins, fpb, n_groups, n_obs = c_int64(), c_int64(), c_int64(), c_int64()

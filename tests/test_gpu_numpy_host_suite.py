@@ -54,3 +54,44 @@ print("numpy host OK")
     env = dict(os.environ, SC_HIP_HOST="numpy")
     out = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=1200)
     assert out.returncode == 0 and "numpy host OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+def test_more_than_256_signals_on_the_planes_format_on_the_torch_free_host():
+    """Round 6: the planes-format stage B takes more than 256 signals in one request (sc_fused2.hip plans its launches over any
+    number of 32-channel blocks); on this host the whole-array planes spectra replace the channel-block tiling wherever the format
+    applies (forced here by SC_PLANES_MIN_CHANNELS: the request is small), an odd count rides on its zero pad channel, and a family
+    outside the format afterwards (PLV) goes back to the tiling from the series."""
+    code = r"""
+import sys
+import numpy as np
+import spectral_connectivity_amd as sc
+import spectral_connectivity_amd.numpy_api as api
+from oracle import spectral_oracle as so
+calls = []
+real = api.Connectivity._accumulate_wide
+api.Connectivity._accumulate_wide = lambda self, *a, **k: (calls.append(1), real(self, *a, **k))[1]
+for C in (306, 307):
+    rng = np.random.default_rng(C)
+    T, R = 64, 6
+    x = rng.standard_normal((T, R, C))
+    x[:, :, 1:] += 0.4 * x[:, :, :-1]
+    x[:, :, C - 2] += 0.8 * np.roll(x[:, :, 3], 2, axis=0)
+    kw = dict(sampling_frequency=100.0, time_halfbandwidth_product=2)
+    coef, _ = so.multitaper_fft(x, fs=100.0, NW=2)
+    c = sc.Connectivity.from_multitaper(sc.Multitaper(x, **kw), dtype=np.complex64)
+    for name in ("coherence_magnitude", "weighted_phase_lag_index", "debiased_squared_weighted_phase_lag_index", "power"):
+        got, ref = getattr(c, name)(), getattr(so, name)(coef)
+        ok = ~np.isnan(ref)
+        assert np.array_equal(np.isnan(got), ~ok), name
+        assert np.abs(got[ok] - ref[ok]).max() <= 3e-5 * max(1.0, np.abs(ref[ok]).max()), (C, name, np.abs(got[ok] - ref[ok]).max())
+    assert c._spectra.get("P") is not None and not calls, "the planes format was expected, without the tiling"
+    got, ref = c.phase_locking_value(), so.phase_locking_value(coef)          # a family outside the format: tiled from the series
+    ok = ~np.isnan(ref)
+    assert np.abs(np.abs(got[ok]) - np.abs(ref[ok])).max() <= 3e-5 and calls, "PLV beyond 256 signals goes through the tiling"
+    del calls[:]
+assert "torch" not in sys.modules, "torch was imported"
+print("numpy host OK")
+"""
+    env = dict(os.environ, SC_HIP_HOST="numpy", SC_PLANES_MIN_CHANNELS="44")
+    out = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0 and "numpy host OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
