@@ -22,7 +22,8 @@
 //
 // Arithmetic is the reference's (A = G^-1 (G^-1 S)^H + I in closed form, the same mask, the same update and test) in float64; what
 // differs from the batched kernels is the rounding of the packed transforms (1e-13 of the factor, tests/test_gpu_parity.py).
-// Applies to records of real series (N/2 + 1 accumulated bins) and N = 256 ... 4096; everything else -- uploaded two-sided
+// Applies to records of real series (N/2 + 1 accumulated bins) and N = 256 ... 4096 (round 6: also fourteen lengths 200 ... 4000 that are
+// not powers of two, wilson_pair_mixed_kernel); everything else -- uploaded two-sided
 // coefficients, other lengths, sc_wilson_factor_f64 -- stays on sc_wilson.hip.  SC_GRANGER_KERNEL=batched forces that path.
 #include <string.h>
 #include "sc_wilson_fft.h"
@@ -329,6 +330,343 @@ __global__ void __launch_bounds__(256 * HALVES, HALVES) wilson_pair_kernel(PairA
     }
 }
 
+// ---- windows that are NOT powers of two (round 6) -----------------------------------------------------------------------------------
+// next_fast_len hands the reference 1000, 2000, 4000 ... samples in the ordinary lab setting (1 / 2 / 4 s at 1 kHz); those windows ran the
+// batched kernels of sc_wilson.hip -- state in HBM, three kernels + two library transforms per iteration: 18.6 ms at the shape of BASELINE
+// configs[3] with 4000 samples where the kernel above takes 3.1 at 4096.  Same kernel, other transform: N = P M with P = 16, 8, 4 or 2
+// points per thread and M = N / P <= 256 threads per problem, M = 2^a 3^b 5^c.  A transform is Cooley-Tukey with the P-point DFT in
+// registers first (over t: the thread's own points x[i + t M]), the twiddles W_N^(i k1), then P transforms of length M across the
+// threads: Stockham passes of radix 5 / 4 / 3 / 2 IN LDS -- every thread takes its share of the pass's P M / R butterflies into
+// registers, the workgroup meets, and the outputs go back to the same rows -- and a gather X[i + t M] = row (k mod P), entry k / P.
+// The thread's points and bins are those of the kernel above (lags >= N / 2 are the registers t >= P / 2, bins f = j + M u), so the
+// staging, the mask, the update and the convergence test are unchanged.
+constexpr int wpm_radix(int M, int pass) {
+    int m = M;
+    for (int p = 0;; ++p) {
+        const int r = (m % 5 == 0) ? 5 : (m % 4 == 0) ? 4 : (m % 3 == 0) ? 3 : (m % 2 == 0) ? 2 : 1;
+        if (p == pass || r == 1) return r;
+        m /= r;
+    }
+}
+constexpr bool wpm_len_ok(int M) {
+    int m = M;
+    while (m % 5 == 0) m /= 5;
+    while (m % 3 == 0) m /= 3;
+    while (m % 2 == 0) m /= 2;
+    return m == 1 && M >= 1 && M <= 512;
+}
+constexpr int wpm_row(int M) { return M | 1; }             // row length of the P rows in LDS (odd)
+
+template <int R>
+__device__ __forceinline__ void wpm_dft(cd (&v)[R]) {
+    if constexpr (R == 2) {
+        zdft2(v[0], v[1]);
+    } else if constexpr (R == 3) {
+        constexpr double S3 = 0.86602540378443864676;
+        const cd s = make_double2(v[1].x + v[2].x, v[1].y + v[2].y), d = make_double2(v[1].x - v[2].x, v[1].y - v[2].y);
+        const cd t = make_double2(v[0].x - 0.5 * s.x, v[0].y - 0.5 * s.y);
+        v[0] = make_double2(v[0].x + s.x, v[0].y + s.y);
+        v[1] = make_double2(t.x + S3 * d.y, t.y - S3 * d.x);      // t - i S3 d
+        v[2] = make_double2(t.x - S3 * d.y, t.y + S3 * d.x);      // t + i S3 d
+    } else if constexpr (R == 4) {
+        zdft4(v[0], v[1], v[2], v[3]);
+    } else {
+        static_assert(R == 5, "radix 2, 3, 4 or 5");
+        constexpr double C1 = 0.30901699437494742410, C2 = -0.80901699437494742410;
+        constexpr double S1 = 0.95105651629515357212, S2 = 0.58778525229247312917;
+        const cd a1 = make_double2(v[1].x + v[4].x, v[1].y + v[4].y), a2 = make_double2(v[2].x + v[3].x, v[2].y + v[3].y);
+        const cd b1 = make_double2(v[1].x - v[4].x, v[1].y - v[4].y), b2 = make_double2(v[2].x - v[3].x, v[2].y - v[3].y);
+        const cd p1 = make_double2(v[0].x + C1 * a1.x + C2 * a2.x, v[0].y + C1 * a1.y + C2 * a2.y);
+        const cd p2 = make_double2(v[0].x + C2 * a1.x + C1 * a2.x, v[0].y + C2 * a1.y + C1 * a2.y);
+        const cd q1 = make_double2(S1 * b1.x + S2 * b2.x, S1 * b1.y + S2 * b2.y);
+        const cd q2 = make_double2(S2 * b1.x - S1 * b2.x, S2 * b1.y - S1 * b2.y);
+        v[0] = make_double2(v[0].x + a1.x + a2.x, v[0].y + a1.y + a2.y);
+        v[1] = make_double2(p1.x + q1.y, p1.y - q1.x);            // p1 - i q1
+        v[4] = make_double2(p1.x - q1.y, p1.y + q1.x);
+        v[2] = make_double2(p2.x + q2.y, p2.y - q2.x);            // p2 - i q2
+        v[3] = make_double2(p2.x - q2.y, p2.y + q2.x);
+    }
+}
+// One Stockham pass of radix R over the P rows of length M: butterfly b of a row reads row[b + t M / R] (twiddled by W_(Ls R)^(t k),
+// k = b mod Ls) and writes row[(b - k) R + k + t Ls] -- natural order after the last pass.  All threads of the problem must call.
+template <int P, int M, int R>
+__device__ __forceinline__ void wpm_pass(cd* z, const cd* lo, const cd* hi, int i, int Ls) {
+    constexpr int N = P * M, MS = wpm_row(M), m = M / R, NBF = (P * m + M - 1) / M;
+    cd v[NBF][R];
+    const int twm = N / (Ls * R);
+#pragma unroll
+    for (int u = 0; u < NBF; ++u) {
+        const int q = i + u * M;
+        if (q < P * m) {
+            const int row = q / m, b = q - row * m, k = b % Ls;
+            const cd* src = z + row * MS;
+#pragma unroll
+            for (int t = 0; t < R; ++t) {
+                v[u][t] = src[b + t * m];
+                if (t > 0 && Ls > 1) {
+                    const int e = t * k * twm;
+                    v[u][t] = zmul(v[u][t], zmul(lo[e & 63], hi[e >> 6]));
+                }
+            }
+            wpm_dft<R>(v[u]);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NBF; ++u) {
+        const int q = i + u * M;
+        if (q < P * m) {
+            const int row = q / m, b = q - row * m, k = b % Ls;
+            cd* dst = z + row * MS + (b - k) * R + k;
+#pragma unroll
+            for (int t = 0; t < R; ++t) dst[t * Ls] = v[u][t];
+        }
+    }
+    __syncthreads();
+}
+template <int P, int M, int PASS, int LS>
+__device__ __forceinline__ void wpm_passes(cd* z, const cd* lo, const cd* hi, int i) {
+    constexpr int R = wpm_radix(M, PASS);
+    if constexpr (R > 1 && LS < M) {
+        wpm_pass<P, M, R>(z, lo, hi, i, LS);
+        wpm_passes<P, M, PASS + 1, LS * R>(z, lo, hi, i);
+    }
+}
+// One forward transform of a problem's series: a[t] = x[i + t M] in, a[t] = X[i + t M] out; zf: P rows of wpm_row(M) elements.
+template <int P, int M>
+__device__ __forceinline__ void wpm_fft(cd (&a)[P], cd* zf, const cd* lo, const cd* hi, int i) {
+    constexpr int MS = wpm_row(M);
+    __syncthreads();                    // the previous reads of zf are done
+    if constexpr (P == 16) {
+        cd o[16];
+        zdft16(a, o);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) a[t] = o[t];
+    } else if constexpr (P == 8) {
+        zdft8(a);
+    } else if constexpr (P == 4) {
+        zdft4(a[0], a[1], a[2], a[3]);
+    } else {
+        zdft2(a[0], a[1]);
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < P; ++k1) {
+        const int e = i * k1;                                   // < N
+        zf[k1 * MS + i] = k1 == 0 ? a[0] : zmul(a[k1], zmul(lo[e & 63], hi[e >> 6]));
+    }
+    __syncthreads();
+    wpm_passes<P, M, 0, 1>(zf, lo, hi, i);
+#pragma unroll
+    for (int t = 0; t < P; ++t) {
+        const int k = i + t * M;
+        a[t] = zf[(k % P) * MS + k / P];
+    }
+}
+
+// TB: thread budget of a workgroup (256: one wave per SIMD with the whole register file, the form of the kernel above; 512: two waves per
+// SIMD on 256 registers -- eight points and four bins per thread fit them, sixteen and eight do not)
+template <int P, int M, int TB>
+__global__ void __launch_bounds__(TB) wilson_pair_mixed_kernel(PairArgs a) {
+    static_assert(wpm_len_ok(M) && M <= TB && (P == 16 || P == 8 || P == 4 || P == 2), "N = P M, M = 2^a 3^b 5^c <= TB");
+    constexpr int N = P * M, H = N / 2, WP_BINS = P / 2, PPW = TB / M, WP_THREADS = PPW * M;
+    constexpr int ZS = (P * wpm_row(M) > N ? P * wpm_row(M) : N), NHI = (N + 63) / 64;
+    constexpr int64_t F = N / 2 + 1;
+    extern __shared__ __align__(16) unsigned char wp_smem[];
+    cd* z = reinterpret_cast<cd*>(wp_smem);                               // [PPW][2][ZS]: staging (natural order) / transform rows
+    cd* lo = z + PPW * 2 * ZS;
+    cd* hi = lo + 64;
+    cd* gny = hi + NHI;
+    double* sny = reinterpret_cast<double*>(gny + PPW * 4);
+    unsigned long long* errs = reinterpret_cast<unsigned long long*>(sny + PPW * 4);
+    const int tid = threadIdx.x, q = tid / M, j = tid % M, i = j;        // (launched with PPW M threads)
+    const int64_t p = (int64_t)blockIdx.x * PPW + q;
+    const bool valid = p < a.P;
+    for (int t = tid; t < 64 + NHI; t += WP_THREADS) {
+        const int m = t < 64 ? t : (t - 64) * 64;
+        double s, c;
+        sincospi(-2.0 * (double)m / (double)N, &s, &c);
+        (t < 64 ? lo[t] : hi[t - 64]) = make_double2(c, s);
+    }
+    if (tid < PPW) errs[tid] = 0ull;
+    cd* b1 = z + (q * 2) * ZS;              // z1 = a00 + i a11
+    cd* b2 = b1 + ZS;                        // z2 = a01 + i a10
+    cd G[WP_BINS][4];
+    double S[WP_BINS][4];
+    int ci = 0, cj = 0;
+    int64_t grp = 0;
+    if (valid) {
+        grp = p / a.n_pairs;
+        const int64_t pr = p % a.n_pairs;
+        ci = a.pairs[2 * pr]; cj = a.pairs[2 * pr + 1];
+    }
+    const double l00 = valid ? a.chol[p * 4] : 1.0, l10 = valid ? a.chol[p * 4 + 1] : 0.0, l11 = valid ? a.chol[p * 4 + 2] : 1.0;
+#pragma unroll
+    for (int u = 0; u < WP_BINS; ++u) {
+        if (valid) pair_read_S(a, grp, ci, cj, F, j + M * u, S[u]);
+        else { S[u][0] = 1.0; S[u][1] = 1.0; S[u][2] = 0.0; S[u][3] = 0.0; }
+        G[u][0] = make_double2(l00, 0); G[u][1] = make_double2(l10, 0); G[u][2] = make_double2(0, 0); G[u][3] = make_double2(l11, 0);
+    }
+    if (j == 0) {
+        double s[4] = {1.0, 1.0, 0.0, 0.0};
+        if (valid) pair_read_S(a, grp, ci, cj, F, H, s);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sny[q * 4 + e] = s[e];
+        gny[q * 4] = make_double2(l00, 0); gny[q * 4 + 1] = make_double2(l10, 0);
+        gny[q * 4 + 2] = make_double2(0, 0); gny[q * 4 + 3] = make_double2(l11, 0);
+    }
+    auto stage = [&](int f, const cd (&A)[3]) {
+        const cd z1 = make_double2(A[0].x, A[2].x);
+        const double sp = A[1].x + A[1].y, sm = A[1].x - A[1].y;
+        b1[f] = z1;
+        b2[f] = make_double2(sp, sp);
+        if (f != 0 && f != H) {
+            b1[N - f] = z1;
+            b2[N - f] = make_double2(sm, sm);
+        }
+    };
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < WP_BINS; ++u) {
+        cd A[3];
+        pair_predict(G[u], S[u], A);
+        stage(j + M * u, A);
+    }
+    if (j == 0) {
+        cd g[4], A[3];
+        double s[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { g[e] = gny[q * 4 + e]; s[e] = sny[q * 4 + e]; }
+        pair_predict(g, s, A);
+        stage(H, A);
+    }
+    bool done = !valid;
+    int n_it = 0;
+    const double invN = 1.0 / (double)N, tol2 = a.tol * a.tol;
+    for (int it = 0; it < a.max_iter; ++it) {
+        __syncthreads();                      // z1, z2 staged
+#pragma unroll 1
+        for (int h = 0; h < 2; ++h) {
+            cd* zf = h ? b2 : b1;
+            cd v[P];
+#pragma unroll
+            for (int t = 0; t < P; ++t) {
+                const cd x = zf[i + t * M];
+                v[t] = make_double2(x.x, -x.y);
+            }
+            wpm_fft<P, M>(v, zf, lo, hi, i);
+#pragma unroll
+            for (int t = 0; t < P; ++t) {
+                if (t >= P / 2) { v[t] = make_double2(0.0, 0.0); continue; }
+                double sr = invN, si = invN;
+                if (t == 0 && i == 0) { sr *= 0.5; si = h ? 0.0 : 0.5 * si; }
+                v[t] = make_double2(v[t].x * sr, -v[t].y * si);
+            }
+            wpm_fft<P, M>(v, zf, lo, hi, i);
+            __syncthreads();                  // the gather has read the rows
+#pragma unroll
+            for (int t = 0; t < P; ++t) zf[i + t * M] = v[t];
+        }
+        __syncthreads();
+        double e2 = 0.0;
+        auto update = [&](int f, cd (&g)[4], const double (&s)[4]) {
+            const int fm = f == 0 ? 0 : N - f;
+            const cd p1 = b1[f], m1 = b1[fm], p2 = b2[f], m2 = b2[fm];
+            cd Ap[4];
+            Ap[0] = make_double2(0.5 * (p1.x + m1.x), 0.5 * (p1.y - m1.y));
+            Ap[3] = make_double2(0.5 * (p1.y + m1.y), 0.5 * (m1.x - p1.x));
+            Ap[1] = make_double2(0.5 * (p2.x + m2.x), 0.5 * (p2.y - m2.y));
+            Ap[2] = make_double2(0.5 * (p2.y + m2.y), 0.5 * (m2.x - p2.x));
+            if (!done) {
+                cd n[4];
+                n[0] = pz_add(pz_mul(g[0], Ap[0]), pz_mul(g[1], Ap[2])); n[1] = pz_add(pz_mul(g[0], Ap[1]), pz_mul(g[1], Ap[3]));
+                n[2] = pz_add(pz_mul(g[2], Ap[0]), pz_mul(g[3], Ap[2])); n[3] = pz_add(pz_mul(g[2], Ap[1]), pz_mul(g[3], Ap[3]));
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const cd d = pz_sub(n[k], g[k]);
+                    e2 = fmax(e2, d.x * d.x + d.y * d.y);
+                    g[k] = n[k];
+                }
+            }
+            cd A[3];
+            pair_predict(g, s, A);
+            stage(f, A);
+        };
+        // (update reads b[f] and b[N - f] and re-stages both: the bins of a thread are its own, the staging of bin f touches f and N - f only)
+#pragma unroll
+        for (int u = 0; u < WP_BINS; ++u) update(j + M * u, G[u], S[u]);
+        if (j == 0) {
+            cd g[4];
+            double s[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { g[k] = gny[q * 4 + k]; s[k] = sny[q * 4 + k]; }
+            update(H, g, s);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) gny[q * 4 + k] = g[k];
+        }
+        if (!done && e2 > 0.0) atomicMax(errs + q, (unsigned long long)__double_as_longlong(e2));
+        __syncthreads();
+        if (!done) {
+            ++n_it;
+            if (__longlong_as_double((long long)errs[q]) < tol2) done = true;
+        }
+        const int running = __syncthreads_or(done ? 0 : 1);
+        if (j == 0) errs[q] = 0ull;
+        if (!running) break;
+    }
+    __syncthreads();
+    double hs[4] = {0, 0, 0, 0};
+    if (valid) {
+        cd* Gp = a.Ghalf + p * 4 * F;
+#pragma unroll
+        for (int u = 0; u < WP_BINS; ++u) {
+            const int f = j + M * u;
+            const double w = f == 0 ? 1.0 : 2.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { Gp[k * F + f] = G[u][k]; hs[k] += w * G[u][k].x; }
+        }
+        if (j == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const cd g = gny[q * 4 + k]; Gp[k * F + H] = g; hs[k] += g.x; }
+        }
+    }
+    double* red = reinterpret_cast<double*>(z);                           // [WP_THREADS][4]
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[tid * 4 + k] = hs[k];
+    __syncthreads();
+    if (valid && j < 4) {
+        double t = 0.0;
+        for (int m = 0; m < M; ++m) t += red[(q * M + m) * 4 + j];            // fixed order
+        a.h0[p * 4 + j] = t / (double)N;
+    }
+    if (valid && j == 0) {
+        a.n_iter[p] = n_it;
+        a.status[p] = done ? 1 : 0;
+        atomicMax(a.summary, n_it);
+        if (!done) atomicAdd(a.summary + 1, 1);
+    }
+}
+template <int P, int M, int TB>
+static int pair_launch_mixed(const PairArgs& a, hipStream_t st) {
+    constexpr int N = P * M, PPW = TB / M, ZS = (P * wpm_row(M) > N ? P * wpm_row(M) : N), NHI = (N + 63) / 64;
+    const size_t lds = ((size_t)PPW * 2 * ZS + 64 + NHI + PPW * 4) * sizeof(cd) + (size_t)PPW * 4 * 8 + (size_t)PPW * 8;
+    static_assert(((size_t)PPW * 2 * ZS + 64 + NHI + PPW * 4) * sizeof(cd) + (size_t)PPW * 48 <= 160 * 1024, "the problems of a workgroup must fit LDS");
+    SC_CHECK_HIP(hipFuncSetAttribute((const void*)wilson_pair_mixed_kernel<P, M, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int64_t blocks = (a.P + PPW - 1) / PPW;
+    SC_REQUIRE(blocks <= 0x7fffffffLL, "too many problems for one launch");
+    hipLaunchKernelGGL((wilson_pair_mixed_kernel<P, M, TB>), dim3((unsigned)blocks), dim3(PPW * M), lds, st, a);
+    SC_CHECK_HIP(hipGetLastError());
+    return SC_OK;
+}
+// the window lengths of the mixed form: X(N, P) with M = N / P
+#define WPM_LENGTHS(X) X(4000, 8, 512) X(3200, 8, 512) X(2400, 8, 512) X(2000, 8, 512) X(1600, 8, 512) X(1200, 8, 512) X(800, 8, 512) \
+                       X(1000, 8, 256) X(600, 8, 256) X(400, 8, 256) X(200, 8, 256) X(500, 4, 256) X(300, 4, 256) X(250, 2, 256)
+static bool pair_mixed_has(int64_t N) {
+#define WPM_HAS(NN, PP, TT) if (N == NN) return true;
+    WPM_LENGTHS(WPM_HAS)
+#undef WPM_HAS
+    return false;
+}
+
 // lam = 1e-12 * mean over (windows, entries) of H0^2 per pair, Hinv = (H0 + lam I)^-1, rot from Sigma = H0 H0^T
 // (connectivity.py:1739-1742, :1847-1848; the arithmetic of sc_wilson.hip's k_pair_consts)
 __global__ void pair_consts_kernel(const double* h0, double* hinv, double* rot, int64_t n_groups, int64_t n_pairs) {
@@ -411,7 +749,7 @@ static size_t pair_workspace_bytes(int64_t P, int64_t n_pairs, int64_t N) {
 bool sc_internal_granger_resident_applies(int64_t n_freq_accum, int64_t N) {
     const char* e = sc_switch(SC_SW_GRANGER_KERNEL);
     if (e && strcmp(e, "batched") == 0) return false;
-    return n_freq_accum == N / 2 + 1 && (N == 256 || N == 512 || N == 1024 || N == 2048 || N == 4096);
+    return n_freq_accum == N / 2 + 1 && (N == 256 || N == 512 || N == 1024 || N == 2048 || N == 4096 || pair_mixed_has(N));
 }
 
 // The resident form of sc_granger_pairwise_f64 (same arguments; called from there when it applies).
@@ -446,7 +784,14 @@ int sc_internal_granger_resident(const void* d_accum, int64_t n_groups, int64_t 
     hipLaunchKernelGGL(pair_lag0_kernel, dim3((unsigned)P), dim3(256), 0, st, a, N);
     hipLaunchKernelGGL(pair_restart_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, a);
     int rc;
+    const char* gk = sc_switch(SC_SW_GRANGER_KERNEL);
+    if (gk && strcmp(gk, "p16") == 0 && (N == 4000 || N == 2000)) {        // (A/B: sixteen points per thread, one wave per SIMD)
+        rc = N == 4000 ? pair_launch_mixed<16, 250, 256>(a, st) : pair_launch_mixed<16, 125, 256>(a, st);
+    } else
     switch (N) {
+#define WPM_CASE(NN, PP, TT) case NN: rc = pair_launch_mixed<PP, NN / PP, TT>(a, st); break;
+    WPM_LENGTHS(WPM_CASE)
+#undef WPM_CASE
     case 256: rc = pair_launch<8>(a, st); break;
     case 512: rc = pair_launch<9>(a, st); break;
     case 1024: rc = pair_launch<10>(a, st); break;

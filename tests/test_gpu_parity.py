@@ -399,9 +399,13 @@ def test_f12_cholesky_failure_outcome(sc, golden):
             assert np.all(np.isnan(side) | (np.abs(side) < 1e-9)), (i, j)
 
 
-@pytest.mark.parametrize("N,W", [(256, 3), (512, 2), (1024, 2), (2048, 1), (4096, 1)])
+@pytest.mark.parametrize("N,W", [(256, 3), (512, 2), (1024, 2), (2048, 1), (4096, 1),
+                                 # (round 6) windows that are not powers of two: wilson_pair_mixed_kernel, N = P M -- every P, every radix
+                                 (250, 3), (500, 2), (300, 2), (200, 3), (400, 2), (600, 2), (1000, 2), (800, 1), (1200, 1), (1600, 1),
+                                 (2000, 1), (2400, 1), (3200, 1), (4000, 1)])
 def test_granger_resident_kernel_equals_the_batched_kernels(sc, debug_env, N, W):
-    """Pairwise spectral Granger of real series with a power-of-two window of 256 ... 4096 samples runs the whole 2 x 2 Wilson
+    """Pairwise spectral Granger of real series with a power-of-two window of 256 ... 4096 samples (round 6: and fourteen other lengths
+    200 ... 4000, a mixed-radix transform in the same kernel) runs the whole 2 x 2 Wilson
     iteration of a pair on one compute unit (sc_wilson_pair.hip: half spectra in registers, two packed transforms per direction,
     convergence tested in the kernel); SC_GRANGER_KERNEL=batched keeps the three-kernels-per-iteration form of sc_wilson.hip
     (reference minimum_phase_decomposition.py:227-322 statement by statement).  Same records in: the predictions agree to the
