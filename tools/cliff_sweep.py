@@ -109,3 +109,13 @@ if "hot" in what:
             print(f"hot path  {name:28s}: device {dev:7.2f} ms for {gb:6.2f} GB of spectra = {dev / gb:6.2f} ms/GB   [{top}]")
         except Exception as e:      # noqa: BLE001
             print(f"hot path  {name:28s}: {type(e).__name__}: {str(e)[:120]}")
+
+if "mvar_windows" in what:
+    for C in (16, 64, 128):
+        for L in (256, 250, 1024, 1000):
+            m = sc.Multitaper(series(7 * L, 40, C, 2), sampling_frequency=500.0, time_halfbandwidth_product=3, n_time_samples_per_window=L)
+            def run():
+                c = sc.Connectivity.from_multitaper(m)
+                return c.directed_transfer_function(), c
+            ms, (d, c) = timed(run)
+            print(f"full Wilson + DTF   C={C:4d}, 7 windows x {L:5d} bins: {ms:8.1f} ms, {c._last_wilson['iterations']} iterations")
