@@ -69,7 +69,7 @@ if "expectation" in what:
         ms, (coh, w) = timed(run)
         print(f"coherence + wPLI    64 ch x 200 trials, expectation over {et:20s}: {ms:8.1f} ms, out {coh.shape}")
 
-if "hot" in what:
+if "hot" in what or "hot64" in what:
     # the hot path itself (float32 engine, coherence + wPLI through the public classes, series resident in HBM, the library's own timers):
     # one parameter of BASELINE configs[2] varied at a time; ms of device time per pass and per GB of one-sided complex64 spectra
     from spectral_connectivity_amd import _lib
@@ -90,7 +90,7 @@ if "hot" in what:
             def run():
                 m = sc.Multitaper(x, sampling_frequency=1000.0, time_halfbandwidth_product=p["NW"], n_time_samples_per_window=p["L"],
                                   n_time_samples_per_step=p["step"], detrend_type=p["detrend"])
-                c = sc.Connectivity.from_multitaper(m, dtype=np.complex64)
+                c = sc.Connectivity.from_multitaper(m, dtype=np.complex128 if "hot64" in what else np.complex64)
                 return c.coherence_magnitude(), c.weighted_phase_lag_index(), m
             run()
             torch.cuda.synchronize(); _lib.last_timing()
