@@ -1103,6 +1103,7 @@ __global__ void __launch_bounds__(512) m_gemm_mfma(MvMat X, MvMat Y, MvMat O, co
     fetch(0);
     park();
     __syncthreads();
+#pragma unroll 1
     for (int k0 = 0; k0 < Cr; k0 += KS) {
         const bool more = k0 + KS < Cr;
         if (more) fetch(k0 + KS);
@@ -1411,7 +1412,14 @@ static int mv_launch_update(int Q, dim3 grid, hipStream_t st, cd* G, const cd* A
 
 static MvMat mv_series(cd* b, int64_t N, int E) { return MvMat{b, (int64_t)E * N, 1, N}; }
 static MvMat mv_natural(cd* b, int64_t N, int E) { return MvMat{b, N * (int64_t)E, (int64_t)E, 1}; }
-static int mv_big_q(int64_t C) { return C <= 96 ? 6 : 8; }
+static int mv_big_q(int64_t C) { return C <= 64 ? 4 : (C <= 96 ? 6 : 8); }
+// Largest system of the register-resident [G | S] elimination (m_predict_gj / m_update_mfma).  Round 6: 48 -- at 49 ... 64 signals the
+// explicit inverse + matrix-core products are faster (7 windows x 256 bins of 64 signals: DTF 24.7 -> 20.3 ms; at 48 signals the two
+// paths tie, 13.3 ms, tools/cliff_sweep.py mvar); SC_MVAR_INVERSE=small64 keeps the round-3 boundary (A/B, tests).
+static int mv_small_max(void) {
+    const char* sel = sc_switch(SC_SW_MVAR_INVERSE);
+    return (sel && sel[0] == 's') ? MV_CSMALL : 48;
+}
 
 // (scratch: one C x C matrix per problem of the grid, beyond 128 signals only)
 static int mv_launch_inverse_big(int64_t C, dim3 grid, hipStream_t st, MvMat M, const double* lam, MvMat Out,
@@ -1431,9 +1439,13 @@ static int mv_launch_inverse_big(int64_t C, dim3 grid, hipStream_t st, MvMat M, 
         return SC_OK;
     }
     const char* sel = sc_switch(SC_SW_MVAR_INVERSE);      // "registers": the round-3 kernel (one whole-matrix update per pivot)
-    if (sel && sel[0] == 'r') {
+    if (sel && sel[0] == 'r' && mv_big_q(C) >= 6) {
         if (mv_big_q(C) == 6) hipLaunchKernelGGL(m_inverse_inplace<6>, grid, dim3(512), 0, st, M, lam, Out, status, (int)C);
         else hipLaunchKernelGGL(m_inverse_inplace<8>, grid, dim3(512), 0, st, M, lam, Out, status, (int)C);
+    } else if (mv_big_q(C) == 4) {
+        const size_t lds = (size_t)(2 * 64 * 17 + 16 * 65) * sizeof(cd);          // 51 KB: three workgroups of 256 threads per compute unit
+        SC_CHECK_HIP(hipFuncSetAttribute((const void*)m_inverse_mfma<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(m_inverse_mfma<4>, grid, dim3(256), lds, st, M, lam, Out, status, (int)C, 0);
     } else if (mv_big_q(C) == 6) {
         const int dbg = sel ? atoi(sel) : 0;             // (timing ablations: 1 no matrix-core updates, 2 no pivot steps)
         const size_t lds = (size_t)(2 * 96 * 17 + 16 * 97) * sizeof(cd);
@@ -1475,7 +1487,9 @@ static int mv_launch_gemm(int64_t C, int mode, dim3 grid, hipStream_t st, MvMat 
         const unsigned nbk = (unsigned)((C + 127) / 128);
         grid.z = nbk * nbk;
     }
-    return mv_big_q(C) == 6 ? mv_launch_gemm_q<6>(mode, grid, st, X, Y, O, status, err, (int)C)
+    // (<= 64 signals: the 96-wide instantiation with its tile rows / columns beyond the signals skipped -- a 64-wide one compiles to
+    //  an accumulator shuffle of 800 moves and 420 bytes of scratch a lane)
+    return mv_big_q(C) <= 6 ? mv_launch_gemm_q<6>(mode, grid, st, X, Y, O, status, err, (int)C)
                             : mv_launch_gemm_q<8>(mode, grid, st, X, Y, O, status, err, (int)C);
 }
 
@@ -1492,7 +1506,7 @@ extern "C" int sc_mvar_workspace_bytes(int64_t n_groups, int64_t C, int64_t N, s
     SC_REQUIRE(bytes && n_groups >= 1 && C >= 1 && N >= 2, "bad workspace query");
     const size_t E = (size_t)C * C, P = (size_t)n_groups, F = (size_t)N / 2 + 1;
     // factor: S, G, A series (beyond 64 signals also G^-1 and G^-1 S); measures: H, A_mvar natural + small per-window arrays
-    const size_t n_big = C > MV_CSMALL ? 5 : 3;
+    const size_t n_big = C > mv_small_max() ? 5 : 3;
     const size_t factor = n_big * P * E * (size_t)N * sizeof(cd) + P * 16 + P * E * 8 + 128 + (size_t)MV_HIST * 4;
     // (beyond 128 signals: + the scratch of the blocked inverse, which also parks |H|^2 / |A|^2 for m_measure)
     // (sq: one partial sum per (window, bin) and, before that, per (window, 256-element chunk of the matrix))
@@ -1527,7 +1541,7 @@ extern "C" int sc_mvar_factor_f64(const void* d_accum, const void* d_S, int64_t 
     cd* S = (cd*)w; w += (size_t)P * E * N * sizeof(cd);
     cd* G = (cd*)w; w += (size_t)P * E * N * sizeof(cd);
     cd* A = (cd*)w; w += (size_t)P * E * N * sizeof(cd);
-    const bool big = C > MV_CSMALL;
+    const bool big = C > mv_small_max();
     cd* Ginv = nullptr;
     cd* T = nullptr;
     if (big) {
@@ -1701,7 +1715,7 @@ extern "C" int sc_mvar_measure_f64(const void* d_G, int64_t n_groups, int64_t N,
     w += (16 - ((uintptr_t)w & 15)) & 15;
     cd* scratch = huge ? (cd*)w : nullptr;            // [P][F][E]: the blocked inverse's matrices, then m_measure's squared moduli
     const int nt = mv_threads((int)C);
-    const bool big = C > MV_CSMALL;
+    const bool big = C > mv_small_max();
     const size_t lds = big ? 0 : mv_pair_lds((int)C);
     if (!big) {
         (void)hipFuncSetAttribute((const void*)m_h0_inverse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
