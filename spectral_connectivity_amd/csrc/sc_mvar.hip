@@ -23,6 +23,7 @@
 // record holds) run the same iteration with the inverse as a panel-blocked Gauss-Jordan on the matrix in global memory
 // (m_inverse_global) and the products as 128 x 128 output blocks of m_gemm_mfma.
 #include <stdlib.h>
+#include <string.h>
 #include <rocfft/rocfft.h>
 #include "sc_common.h"
 
@@ -1418,7 +1419,11 @@ static int mv_big_q(int64_t C) { return C <= 64 ? 4 : (C <= 96 ? 6 : 8); }
 // paths tie, 13.3 ms, tools/cliff_sweep.py mvar); SC_MVAR_INVERSE=small64 keeps the round-3 boundary (A/B, tests).
 static int mv_small_max(void) {
     const char* sel = sc_switch(SC_SW_MVAR_INVERSE);
-    return (sel && sel[0] == 's') ? MV_CSMALL : 48;
+    if (sel && strncmp(sel, "small", 5) == 0) {               // small64 (rounds 3-5), small32, ...: the boundary itself
+        const int v = atoi(sel + 5);
+        return v >= 16 && v <= MV_CSMALL ? v : MV_CSMALL;
+    }
+    return 48;
 }
 
 // (scratch: one C x C matrix per problem of the grid, beyond 128 signals only)
@@ -1487,8 +1492,9 @@ static int mv_launch_gemm(int64_t C, int mode, dim3 grid, hipStream_t st, MvMat 
         const unsigned nbk = (unsigned)((C + 127) / 128);
         grid.z = nbk * nbk;
     }
-    // (<= 64 signals: the 96-wide instantiation with its tile rows / columns beyond the signals skipped -- a 64-wide one compiles to
-    //  an accumulator shuffle of 800 moves and 420 bytes of scratch a lane)
+    // (<= 64 signals: the 96-wide instantiation with its tile rows / columns beyond the signals skipped -- a 64-wide one on 512 threads
+    //  compiles to an accumulator shuffle of 800 moves and 420 bytes of scratch a lane, on 256 threads it is slower: DTF at 64 signals x 7
+    //  windows 29.3 ms against 20.3)
     return mv_big_q(C) <= 6 ? mv_launch_gemm_q<6>(mode, grid, st, X, Y, O, status, err, (int)C)
                             : mv_launch_gemm_q<8>(mode, grid, st, X, Y, O, status, err, (int)C);
 }
