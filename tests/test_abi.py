@@ -50,6 +50,25 @@ def test_accum_layout_and_validation():
         _lib.check(rc, "sc_measure_f32")
 
 
+def test_limits_and_supported_shapes_of_round_6():
+    """Host-callable queries of the ABI (no device needed): the limits the Python side relies on and which window lengths stage A
+    has the planes-format output for (round 6: every 2^a 3^b 5^c up to 2048 samples beside the powers of two 64 ... 4096;
+    more than 256 signals)."""
+    lib = _lib.load()
+    assert lib.sc_mvar_max_signals() == 512 and lib.sc_global_coherence_max_signals() == 512 and lib.sc_canonical_max_group() == 128
+    for n in (64, 256, 4096, 200, 1000, 2000, 96, 108, 384, 768, 960, 1536):
+        assert lib.sc_multitaper_fft_planes_supported(n, n, 128) == 1, n
+    for n in (32, 8192, 448, 1100, 2304, 4000):            # too short / too long / a factor 7 or 11 / 2^a 3^b 5^c beyond 2048
+        assert lib.sc_multitaper_fft_planes_supported(n, n, 128) == 0, n
+    assert lib.sc_multitaper_fft_planes_supported(256, 256, 127) == 0          # an even number of signals (the caller pads)
+    assert lib.sc_multitaper_fft_planes_supported(256, 256, 306) == 1 and lib.sc_multitaper_fft_planes_supported(256, 256, 1024) == 1
+    assert _lib.PLANES_FORMAT_MAX_CHANNELS == 1024
+    big = 1 << 30
+    assert _lib.planes_format_applies(256, 256, 306, _lib.PLANE_CSM | _lib.PLANE_ABS_IM, spectra_bytes=big)
+    assert not _lib.planes_format_applies(256, 256, 1026, _lib.PLANE_CSM, spectra_bytes=big)
+    assert not _lib.planes_format_applies(256, 256, 306, _lib.PLANE_CSM | _lib.PLANE_UNIT, spectra_bytes=big)
+
+
 def test_no_cpu_fallback_without_gpu():
     import numpy as np
     import torch
