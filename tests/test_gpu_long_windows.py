@@ -138,3 +138,36 @@ def test_silent_constant_and_nonfinite_channels_in_long_windows(N, debug_env):
     assert np.isnan(got[bad]).all() and np.isfinite(got[~bad]).all()
     assert np.all(got[..., 2] == 0) and np.all(got[..., 7] == 0)
     _close(np.where(bad, 0, got), np.where(bad, 0, ref), f"N={N}: channels beside a silent / non-finite one")
+
+
+@pytest.mark.parametrize("engine_precision", ["float32", "float64"])
+@pytest.mark.parametrize("N,L,step,C,R,det", [
+    (8192, 8192, 4096, 5, 2, "constant"), (6000, 6000, 6000, 18, 2, "linear"), (5000, 4500, 2000, 3, 3, None),
+    (448, 448, 224, 33, 3, "constant"), (2048, 2048, 1024, 6, 2, "linear"), (4096, 4000, 4000, 9, 2, "constant"),
+    (308, 300, 150, 7, 3, "linear"), (130, 130, 65, 4, 3, "constant"), (50, 50, 25, 11, 4, None)])
+def test_windows_through_the_taper_kernel_and_rocfft(N, L, step, C, R, det, engine_precision):
+    """The lengths no fused transform takes -- beyond 4096 samples, a 7 / 11 / 13 among the factors, below 64; in the float64 engine also
+    2048 / 4096 and every length outside its list -- run sc_taper_windows + rocFFT + a transposition.  Round 6: the taper kernel
+    stores 16 bytes a lane (1 KB a wave and row) from 1024 samples on in float32, 512 in float64 (N % 4 == 0 / N % 2 == 0); the shorter
+    windows keep the one-sample-a-lane form.  Both engines against the float64 oracle."""
+    import warnings
+    import spectral_connectivity_amd as sc
+    from spectral_connectivity_amd import options
+    _dev()
+    rng = np.random.default_rng(N + 31 * C + L)
+    T = L + 2 * step
+    x = rng.standard_normal((T, R, C)) * (0.3 + rng.random(C)) + 4.0 * rng.standard_normal((1, R, C)) \
+        + np.linspace(0, 3, T)[:, None, None] * rng.standard_normal((1, 1, C))
+    ref = _oracle(x, L, step, N, det)
+    old, options.precision = options.precision, engine_precision
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            got = sc.Multitaper(x, sampling_frequency=200.0, time_halfbandwidth_product=2.5, detrend_type=det,
+                                n_time_samples_per_window=L, n_time_samples_per_step=step, n_fft_samples=N).fft()
+    finally:
+        options.precision = old
+    if engine_precision == "float64":
+        _close(got, ref, f"float64 N={N} L={L}", rtol=1e-9, atol_scale=1e-10)
+    else:
+        _close(got, ref, f"float32 N={N} L={L}")
